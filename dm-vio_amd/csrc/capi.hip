@@ -1,0 +1,451 @@
+// libdmvio_hip.so — C ABI implementation (include/dmvio_hip.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/dmvio_hip.h"
+#include "common.h"
+#include "lie_dev.h"
+#include "image_kernels.hpp"
+#include "ref_kernels.hpp"
+#include "tracker_kernels.hpp"
+
+using namespace dmv;
+
+static thread_local std::string g_err;
+static int fail(const char* what, const char* file, int line, hipError_t e) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
+  g_err = buf;
+  return -1;
+}
+static int failmsg(const std::string& m) { g_err = m; return -2; }
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, __FILE__, __LINE__, _e); } while (0)
+#define HIPCHKP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fail(#x, __FILE__, __LINE__, _e); return nullptr; } } while (0)
+
+struct dmvio_hip_ctx {
+  int device = 0, w = 0, h = 0, levels = 0, n_slots = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  FrameStore fs{};
+  float* d_planar[DMV_MAX_LEVELS] = {};
+  float* d_f3 = nullptr;  // download scratch (w*h*3)
+  int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
+  std::mutex mu;
+};
+
+struct dmvio_hip_tracker {
+  dmvio_hip_ctx* ctx = nullptr;
+  TrackerDev dev{};
+  bool haveK = false, haveRef = false;
+  RefLevels R{};
+  int n_tiles = 0;
+  float *d_idp = nullptr, *d_wsp = nullptr, *d_idp2 = nullptr, *d_wsp2 = nullptr, *d_dense = nullptr;
+  int *d_tile_count = nullptr, *d_tile_base = nullptr, *d_pc_n = nullptr;
+  float4* d_pc[DMV_MAX_LEVELS] = {};
+  float4** d_pc_ptrs = nullptr;
+  float* d_pts = nullptr;
+  int pts_cap = 0;
+  float *d_partials = nullptr, *d_tot = nullptr, *h_tot = nullptr;
+  int max_eval_blocks = 1024;
+  LMProblemIn *d_in = nullptr, *h_in = nullptr;
+  LMProblemOut *d_out = nullptr, *h_out = nullptr;
+  int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
+  long long last_evals = 0, last_point_evals = 0;
+  int lm_threads_override = 0;
+};
+
+extern "C" {
+
+const char* dmvio_hip_last_error(void) { return g_err.c_str(); }
+
+int dmvio_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int pyrLevels(int w, int h) {
+  // setGlobalCalib (src/dso/util/globalCalib.cpp:47-55)
+  int wl = w, hl = h, used = 1;
+  while (wl % 2 == 0 && hl % 2 == 0 && wl * hl > 5000 && used < DMV_MAX_LEVELS) { wl /= 2; hl /= 2; used++; }
+  return used;
+}
+
+dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
+  if (w <= 0 || h <= 0 || n_frame_slots <= 0) { failmsg("dmvio_hip_create: bad arguments"); return nullptr; }
+  int ndev = 0;
+  HIPCHKP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { failmsg("dmvio_hip_create: no such device"); return nullptr; }
+  HIPCHKP(hipSetDevice(device));
+  dmvio_hip_ctx* c = new dmvio_hip_ctx();
+  c->device = device; c->w = w; c->h = h; c->n_slots = n_frame_slots;
+  c->levels = pyrLevels(w, h);
+  size_t off = 0;
+  for (int l = 0; l < c->levels; l++) {
+    c->wl[l] = w >> l; c->hl[l] = h >> l;
+    c->fs.level_off[l] = off;
+    off += (size_t)c->wl[l] * c->hl[l];
+  }
+  c->fs.levels = c->levels;
+  c->fs.slot_stride = (off + 63) & ~(size_t)63;
+  HIPCHKP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHKP(hipMalloc((void**)&c->fs.base, sizeof(float4) * c->fs.slot_stride * n_frame_slots));
+  HIPCHKP(hipMemsetAsync(c->fs.base, 0, sizeof(float4) * c->fs.slot_stride * n_frame_slots, c->stream));
+  for (int l = 0; l < c->levels; l++) HIPCHKP(hipMalloc((void**)&c->d_planar[l], sizeof(float) * c->wl[l] * c->hl[l]));
+  HIPCHKP(hipMalloc((void**)&c->d_f3, sizeof(float) * 3 * w * h));
+  HIPCHKP(hipStreamSynchronize(c->stream));
+  return c;
+}
+
+void dmvio_hip_destroy(dmvio_hip_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipFree(c->fs.base);
+  for (int l = 0; l < c->levels; l++) hipFree(c->d_planar[l]);
+  hipFree(c->d_f3);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dmvio_hip_pyr_levels(const dmvio_hip_ctx* c) { return c ? c->levels : 0; }
+
+int dmvio_hip_set_stream(dmvio_hip_ctx* c, void* s) {
+  if (!c) return failmsg("null ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (s) {
+    if (c->own_stream) { HIPCHK(hipStreamDestroy(c->stream)); }
+    c->stream = (hipStream_t)s; c->own_stream = false;
+  } else if (!c->own_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true;
+  }
+  return 0;
+}
+
+int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
+  if (!c) return failmsg("null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------ frames
+static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
+  const float* Il = d_color;
+  for (int l = 0; l < c->levels; l++) {
+    const int n = c->wl[l] * c->hl[l];
+    float* next = (l + 1 < c->levels) ? c->d_planar[l + 1] : nullptr;
+    const int blocks = std::min((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_make_level, dim3(blocks), dim3(256), 0, c->stream, Il, c->wl[l], c->hl[l], c->fs.level_mut(slot, l), next);
+    Il = next;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dmvio_hip_frame_upload(dmvio_hip_ctx* c, int slot, const float* host) {
+  if (!c || !host) return failmsg("frame_upload: null argument");
+  if (slot < 0 || slot >= c->n_slots) return failmsg("frame_upload: slot out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->d_planar[0], host, sizeof(float) * c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  if (int r = buildPyramid(c, slot, c->d_planar[0])) return r;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
+  if (!c || !dev) return failmsg("frame_from_device: null argument");
+  if (slot < 0 || slot >= c->n_slots) return failmsg("frame_from_device: slot out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  return buildPyramid(c, slot, dev);  // asynchronous on the ctx stream
+}
+
+int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
+  if (!c || !out) return failmsg("frame_download: null argument");
+  if (slot < 0 || slot >= c->n_slots || lvl < 0 || lvl >= c->levels) return failmsg("frame_download: out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const int n = c->wl[lvl] * c->hl[lvl];
+  hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(slot, lvl), n, c->d_f3);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, c->d_f3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------ tracker
+dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
+  if (!c) { failmsg("tracker_create: null ctx"); return nullptr; }
+  HIPCHKP(hipSetDevice(c->device));
+  dmvio_hip_tracker* t = new dmvio_hip_tracker();
+  t->ctx = c;
+  t->dev.levels = c->levels;
+  t->dev.huberTH = 9.0f; t->dev.coarseCutoffTH = 20.0f; t->dev.modeA = 1e12f; t->dev.modeB = 1e8f;
+  t->dev.ref_exposure = 1.0f; t->dev.ref_aff_a = 0; t->dev.ref_aff_b = 0;
+  RefLevels& R = t->R;
+  R.levels = c->levels;
+  size_t off = 0; int tiles = 0;
+  for (int l = 0; l < c->levels; l++) {
+    R.w[l] = c->wl[l]; R.h[l] = c->hl[l]; R.off[l] = off; R.tile_off[l] = tiles;
+    off += (size_t)R.w[l] * R.h[l];
+    tiles += (R.w[l] * R.h[l] + 255) / 256;
+    t->dev.g[l].w = R.w[l]; t->dev.g[l].h = R.h[l];
+  }
+  R.tile_off[c->levels] = tiles; R.total = off; t->n_tiles = tiles;
+  HIPCHKP(hipMalloc((void**)&t->d_idp, sizeof(float) * off));
+  HIPCHKP(hipMalloc((void**)&t->d_wsp, sizeof(float) * off));
+  HIPCHKP(hipMalloc((void**)&t->d_idp2, sizeof(float) * off));
+  HIPCHKP(hipMalloc((void**)&t->d_wsp2, sizeof(float) * off));
+  HIPCHKP(hipMalloc((void**)&t->d_dense, sizeof(float) * off));
+  HIPCHKP(hipMalloc((void**)&t->d_tile_count, sizeof(int) * tiles));
+  HIPCHKP(hipMalloc((void**)&t->d_tile_base, sizeof(int) * tiles));
+  HIPCHKP(hipMalloc((void**)&t->d_pc_n, sizeof(int) * DMV_MAX_LEVELS));
+  for (int l = 0; l < c->levels; l++) HIPCHKP(hipMalloc((void**)&t->d_pc[l], sizeof(float4) * R.w[l] * R.h[l]));
+  HIPCHKP(hipMalloc((void**)&t->d_pc_ptrs, sizeof(float4*) * DMV_MAX_LEVELS));
+  HIPCHKP(hipMemcpy(t->d_pc_ptrs, t->d_pc, sizeof(float4*) * DMV_MAX_LEVELS, hipMemcpyHostToDevice));
+  HIPCHKP(hipMalloc((void**)&t->d_partials, sizeof(float) * ACC_PAD * t->max_eval_blocks));
+  HIPCHKP(hipMalloc((void**)&t->d_tot, sizeof(float) * ACC_PAD));
+  HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * ACC_PAD, hipHostMallocDefault));
+  if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
+  return t;
+}
+
+void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
+  if (!t) return;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
+  hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n);
+  for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
+  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
+  hipHostFree(t->h_tot);
+  hipFree(t->d_in); hipFree(t->d_out);
+  if (t->h_in) hipHostFree(t->h_in);
+  if (t->h_out) hipHostFree(t->h_out);
+  delete t;
+}
+
+int dmvio_hip_tracker_set_settings(dmvio_hip_tracker* t, const dmvio_hip_tracker_settings* s) {
+  if (!t || !s) return failmsg("tracker_set_settings: null argument");
+  t->dev.huberTH = s->huberTH; t->dev.coarseCutoffTH = s->coarseCutoffTH; t->dev.modeA = s->affineOptModeA; t->dev.modeB = s->affineOptModeB;
+  return 0;
+}
+
+int dmvio_hip_tracker_make_k(dmvio_hip_tracker* t, const float k[4]) {
+  if (!t || !k) return failmsg("tracker_make_k: null argument");
+  const int L = t->ctx->levels;
+  LevelGeom* g = t->dev.g;
+  g[0].fx = k[0]; g[0].fy = k[1]; g[0].cx = k[2]; g[0].cy = k[3];
+  for (int l = 1; l < L; l++) {
+    g[l].fx = g[l - 1].fx * 0.5;
+    g[l].fy = g[l - 1].fy * 0.5;
+    g[l].cx = (g[0].cx + 0.5) / ((int)1 << l) - 0.5;
+    g[l].cy = (g[0].cy + 0.5) / ((int)1 << l) - 0.5;
+  }
+  for (int l = 0; l < L; l++) {
+    // K^-1 by cofactors / determinant in float (what Eigen's Matrix3f::inverse() evaluates for
+    // K = [fx 0 cx; 0 fy cy; 0 0 1]; CoarseTracker.cpp:127-128)
+    const float a = g[l].fx, e = g[l].fy, c = g[l].cx, f = g[l].cy;
+    const float det = a * (e * 1.0f - f * 0.0f);
+    const float invdet = 1.0f / det;
+    float* Ki = g[l].Ki;
+    Ki[0] = (e * 1.0f - f * 0.0f) * invdet; Ki[1] = (c * 0.0f - 0.0f * 1.0f) * invdet; Ki[2] = (0.0f * f - c * e) * invdet;
+    Ki[3] = (f * 0.0f - 0.0f * 1.0f) * invdet; Ki[4] = (a * 1.0f - c * 0.0f) * invdet; Ki[5] = (c * 0.0f - a * f) * invdet;
+    Ki[6] = (0.0f * 0.0f - e * 0.0f) * invdet; Ki[7] = (0.0f * 0.0f - a * 0.0f) * invdet; Ki[8] = (a * e - 0.0f * 0.0f) * invdet;
+  }
+  t->haveK = true;
+  return 0;
+}
+
+int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_exposure, double aff_a, double aff_b,
+                              int n, const float* u, const float* v, const float* idepth, const float* hdiF) {
+  if (!t) return failmsg("tracker_set_ref: null tracker");
+  dmvio_hip_ctx* c = t->ctx;
+  if (ref_slot < 0 || ref_slot >= c->n_slots) return failmsg("tracker_set_ref: slot out of range");
+  if (n < 0 || (n > 0 && (!u || !v || !idepth || !hdiF))) return failmsg("tracker_set_ref: bad point arrays");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  if (n > t->pts_cap) {
+    if (t->d_pts) HIPCHK(hipFree(t->d_pts));
+    t->pts_cap = std::max(n, 4096);
+    HIPCHK(hipMalloc((void**)&t->d_pts, sizeof(float) * 4 * t->pts_cap));
+  }
+  const RefLevels& R = t->R;
+  HIPCHK(hipMemsetAsync(t->d_idp, 0, sizeof(float) * R.w[0] * R.h[0], s));
+  HIPCHK(hipMemsetAsync(t->d_wsp, 0, sizeof(float) * R.w[0] * R.h[0], s));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(t->d_pts + 0 * (size_t)t->pts_cap, u, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(t->d_pts + 1 * (size_t)t->pts_cap, v, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(t->d_pts + 2 * (size_t)t->pts_cap, idepth, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(t->d_pts + 3 * (size_t)t->pts_cap, hdiF, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ref_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, t->d_pts, t->d_pts + t->pts_cap, t->d_pts + 2 * (size_t)t->pts_cap,
+                       t->d_pts + 3 * (size_t)t->pts_cap, t->d_idp, t->d_wsp, R.w[0], R.h[0]);
+  }
+  if (R.levels > 1) {
+    const size_t npool = R.total - R.off[1];
+    hipLaunchKernelGGL(k_ref_pool, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, s, R, t->d_idp, t->d_wsp);
+  }
+  hipLaunchKernelGGL(k_ref_dilate, dim3((unsigned)((R.total + 255) / 256)), dim3(256), 0, s, R, t->d_idp, t->d_wsp, t->d_idp2, t->d_wsp2);
+  hipLaunchKernelGGL(k_ref_count, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_count);
+  hipLaunchKernelGGL(k_ref_scan, dim3(R.levels), dim3(1024), 0, s, R, t->d_tile_count, t->d_tile_base, t->d_pc_n);
+  hipLaunchKernelGGL(k_ref_write, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_base, t->d_pc_ptrs, t->d_dense);
+  HIPCHK(hipGetLastError());
+  int pcn[DMV_MAX_LEVELS] = {};
+  HIPCHK(hipMemcpyAsync(pcn, t->d_pc_n, sizeof(int) * R.levels, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int l = 0; l < R.levels; l++) { t->dev.pc_n[l] = pcn[l]; t->dev.pc[l] = t->d_pc[l]; }
+  t->dev.ref_exposure = ref_exposure; t->dev.ref_aff_a = aff_a; t->dev.ref_aff_b = aff_b;
+  t->haveRef = true;
+  return 0;
+}
+
+int dmvio_hip_tracker_pc_n(dmvio_hip_tracker* t, int lvl) {
+  if (!t || lvl < 0 || lvl >= t->ctx->levels) return failmsg("tracker_pc_n: bad argument");
+  return t->dev.pc_n[lvl];
+}
+
+int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* t, int lvl, float* u, float* v, float* idepth, float* color) {
+  if (!t || lvl < 0 || lvl >= t->ctx->levels) return failmsg("tracker_get_pc: bad argument");
+  dmvio_hip_ctx* c = t->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const int n = t->dev.pc_n[lvl];
+  std::vector<float4> tmp(n);
+  HIPCHK(hipMemcpyAsync(tmp.data(), t->d_pc[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) { u[i] = tmp[i].x; v[i] = tmp[i].y; idepth[i] = tmp[i].z; color[i] = tmp[i].w; }
+  return 0;
+}
+
+int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float new_exposure, const double pose7[7], const double aff[2],
+                           float cutoffTH, double res6[6], double H[64], double b[8]) {
+  if (!t || !pose7 || !aff) return failmsg("tracker_eval: null argument");
+  dmvio_hip_ctx* c = t->ctx;
+  if (!t->haveK || !t->haveRef) return failmsg("tracker_eval: makeK / setCoarseTrackingRef not called");
+  if (lvl < 0 || lvl >= c->levels || new_slot < 0 || new_slot >= c->n_slots) return failmsg("tracker_eval: out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  EvalP e;
+  makeEvalP(t->dev, lvl, poseFrom7(pose7), aff[0], aff[1], new_exposure, cutoffTH, e);
+  const int n = t->dev.pc_n[lvl];
+  constexpr int T = 256;
+  const int G = std::max(1, std::min((n + T - 1) / T, t->max_eval_blocks));
+  hipLaunchKernelGGL(k_eval_partial<T>, dim3(G), dim3(T), 0, c->stream, t->dev, e, c->fs.level(new_slot, lvl), t->d_partials);
+  hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(64), 0, c->stream, t->d_partials, G, t->d_tot);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->h_tot, t->d_tot, sizeof(float) * ACC_PAD, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (res6) res6FromSums(t->h_tot, res6);
+  if (H && b) systemFromSums(t->h_tot, H, b);
+  return 0;
+}
+
+static int ensureBatch(dmvio_hip_tracker* t, int B) {
+  if (B <= t->batch_cap) return 0;
+  if (t->d_in) { HIPCHK(hipFree(t->d_in)); HIPCHK(hipFree(t->d_out)); HIPCHK(hipHostFree(t->h_in)); HIPCHK(hipHostFree(t->h_out)); }
+  t->batch_cap = std::max(B, 64);
+  HIPCHK(hipMalloc((void**)&t->d_in, sizeof(LMProblemIn) * t->batch_cap));
+  HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut) * t->batch_cap));
+  HIPCHK(hipHostMalloc((void**)&t->h_in, sizeof(LMProblemIn) * t->batch_cap, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_out, sizeof(LMProblemOut) * t->batch_cap, hipHostMallocDefault));
+  return 0;
+}
+
+int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* t, int B, const int* new_slots, const float* new_exposures,
+                                        const double* pose7_in, const double* aff_in, int coarsestLvl, const double* minRes) {
+  if (!t || !new_slots || !pose7_in || !aff_in) return failmsg("track_batch_stage: null argument");
+  dmvio_hip_ctx* c = t->ctx;
+  if (!t->haveK || !t->haveRef) return failmsg("track: makeK / setCoarseTrackingRef not called");
+  if (B <= 0) return failmsg("track: B must be positive");
+  if (coarsestLvl < 0 || coarsestLvl >= c->levels || coarsestLvl >= 5) return failmsg("track: coarsestLvl out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  if (int r = ensureBatch(t, B)) return r;
+  for (int i = 0; i < B; i++) {
+    if (new_slots[i] < 0 || new_slots[i] >= c->n_slots) return failmsg("track: frame slot out of range");
+    LMProblemIn& p = t->h_in[i];
+    memcpy(p.pose7, pose7_in + 7 * i, sizeof(double) * 7);
+    p.aff[0] = aff_in[2 * i]; p.aff[1] = aff_in[2 * i + 1];
+    for (int k = 0; k < 5; k++) p.minRes[k] = minRes ? minRes[5 * i + k] : NAN;
+    p.new_slot = new_slots[i];
+    p.new_exposure = new_exposures ? new_exposures[i] : 1.0f;
+  }
+  HIPCHK(hipMemcpyAsync(t->d_in, t->h_in, sizeof(LMProblemIn) * B, hipMemcpyHostToDevice, c->stream));
+  t->staged_B = B; t->staged_coarsest = coarsestLvl;
+  return 0;
+}
+
+int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
+  if (!t || t->staged_B <= 0) return failmsg("track_batch_launch: nothing staged");
+  dmvio_hip_ctx* c = t->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int B = t->staged_B;
+  int T = t->lm_threads_override ? t->lm_threads_override : (B <= 256 ? 1024 : (B <= 1024 ? 512 : 256));
+  if (T == 1024) hipLaunchKernelGGL(k_track_lm<1024>, dim3(B), dim3(1024), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
+  else if (T == 512) hipLaunchKernelGGL(k_track_lm<512>, dim3(B), dim3(512), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
+  else if (T == 256) hipLaunchKernelGGL(k_track_lm<256>, dim3(B), dim3(256), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
+  else if (T == 128) hipLaunchKernelGGL(k_track_lm<128>, dim3(B), dim3(128), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
+  else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out, double* aff_out, double* lastResiduals, double* lastFlow,
+                                        double* H, double* b, int* good, int* iterations) {
+  if (!t || t->staged_B <= 0) return failmsg("track_batch_fetch: nothing staged");
+  dmvio_hip_ctx* c = t->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const int B = t->staged_B;
+  HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  long long ev = 0, pe = 0;
+  for (int i = 0; i < B; i++) {
+    const LMProblemOut& o = t->h_out[i];
+    if (pose7_out) memcpy(pose7_out + 7 * i, o.pose7, sizeof(double) * 7);
+    if (aff_out) { aff_out[2 * i] = o.aff[0]; aff_out[2 * i + 1] = o.aff[1]; }
+    if (lastResiduals) memcpy(lastResiduals + 5 * i, o.lastRes, sizeof(double) * 5);
+    if (lastFlow) memcpy(lastFlow + 3 * i, o.flow, sizeof(double) * 3);
+    if (H) memcpy(H + 64 * i, o.H, sizeof(double) * 64);
+    if (b) memcpy(b + 8 * i, o.b, sizeof(double) * 8);
+    if (good) good[i] = o.good;
+    if (iterations) iterations[i] = o.iterations;
+    ev += o.n_evals; pe += o.n_point_evals;
+  }
+  t->last_evals = ev; t->last_point_evals = pe;
+  return 0;
+}
+
+int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_slots, const float* new_exposures, double* pose7_io, double* aff_io,
+                                  int coarsestLvl, const double* minRes, double* lastResiduals, double* lastFlow, double* H, double* b,
+                                  int* good, int* iterations) {
+  if (int r = dmvio_hip_tracker_track_batch_stage(t, B, new_slots, new_exposures, pose7_io, aff_io, coarsestLvl, minRes)) return r;
+  if (int r = dmvio_hip_tracker_track_batch_launch(t)) return r;
+  return dmvio_hip_tracker_track_batch_fetch(t, pose7_io, aff_io, lastResiduals, lastFlow, H, b, good, iterations);
+}
+
+int dmvio_hip_tracker_track(dmvio_hip_tracker* t, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
+                            const double minRes[5], double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good) {
+  return dmvio_hip_tracker_track_batch(t, 1, &new_slot, &new_exposure, pose7_io, aff_io, coarsestLvl, minRes, lastResiduals, lastFlow, H, b, good, nullptr);
+}
+
+int dmvio_hip_tracker_last_work(dmvio_hip_tracker* t, long long* n_evals, long long* n_point_evals) {
+  if (!t) return failmsg("null tracker");
+  if (n_evals) *n_evals = t->last_evals;
+  if (n_point_evals) *n_point_evals = t->last_point_evals;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Shared POD types of libdmvio_hip (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DMV_MAX_LEVELS 6
+
+namespace dmv {
+
+// Per pyramid level geometry + intrinsics (CoarseTracker::makeK, CoarseTracker.cpp:105-134).
+struct LevelGeom {
+  int w, h;
+  float fx, fy, cx, cy;
+  float Ki[9];
+};
+
+// Resident image pyramids: every frame slot holds all levels back to back as float4 (I, dx, dy, 0):
+// one 16-byte aligned load per bilinear tap (the reference's Eigen::Vector3f AoS is 12 B / pixel).
+struct FrameStore {
+  float4* base;          // n_slots * slot_stride float4
+  size_t slot_stride;    // float4 elements per slot
+  size_t level_off[DMV_MAX_LEVELS];
+  int levels;
+  __host__ __device__ const float4* level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
+  __host__ __device__ float4* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
+};
+
+// Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one
+// float4 {u, v, idepth, color} record per template point: one coalesced 16-byte load per point).
+struct TrackerDev {
+  int levels;
+  LevelGeom g[DMV_MAX_LEVELS];
+  const float4* pc[DMV_MAX_LEVELS];
+  int pc_n[DMV_MAX_LEVELS];
+  float ref_exposure;
+  double ref_aff_a, ref_aff_b;
+  float huberTH, coarseCutoffTH, modeA, modeB;
+};
+
+// Uniform inputs of one calcRes+calcGS evaluation.
+struct EvalP {
+  float RKi[9];
+  float t[3];
+  float aff0, aff1;   // affLL (CoarseTracker.cpp:379)
+  float b0;           // lastRef_aff_g2l.b (CoarseTracker.cpp:305)
+  float cutoff, maxEnergy;
+  int lvl;
+};
+
+// accumulator slots of one evaluation
+enum {
+  ACC_H = 0,        // 45 upper-triangular sums of w * [J0..J7, r] [J0..J7, r]^T  (Accumulator9 order)
+  ACC_E = 45,
+  ACC_NE = 46,      // numTermsInE
+  ACC_NSAT = 47,    // numSaturated
+  ACC_NW = 48,      // numTermsInWarped (before padding to x4)
+  ACC_FT = 49,      // sumSquaredShiftT
+  ACC_FRT = 50,     // sumSquaredShiftRT
+  ACC_FN = 51,      // sumSquaredShiftNum
+  ACC_N = 52,
+  ACC_PAD = 64
+};
+
+struct LMProblemIn {
+  double pose7[7];
+  double aff[2];
+  double minRes[5];
+  int new_slot;
+  float new_exposure;
+};
+struct LMProblemOut {
+  double pose7[7];
+  double aff[2];
+  double lastRes[5];
+  double flow[3];
+  double H[64];
+  double b[8];
+  int good;
+  int iterations;
+  int n_evals;
+  int pad_;
+  long long n_point_evals;
+};
+
+}  // namespace dmv

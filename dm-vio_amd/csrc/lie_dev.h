@@ -1,0 +1,168 @@
+// SE3 / small dense algebra used by the device-resident Levenberg–Marquardt loop and by the host
+// side of the C ABI.  double precision, __host__ __device__.
+//
+// Follows the conventions of the reference's Sophus v0.9a (thirdparty/Sophus/sophus/se3.hpp:407-428
+// exp with [translation; rotation] tangent order, so3.hpp:343-369 quaternion exp, group product =
+// quaternion product + renormalisation so3.hpp:266-269) and of Eigen's pivoted LDLT that
+// CoarseTracker.cpp:639-658 calls, so results track the reference CPU path to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DMV_HD __host__ __device__ __forceinline__
+
+namespace dmv {
+
+struct Quatd { double w, x, y, z; };
+struct Pose { Quatd q; double t[3]; };
+
+DMV_HD Quatd qmul(const Quatd& a, const Quatd& b) {
+  Quatd r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+DMV_HD Quatd qnormalize(const Quatd& a) {
+  const double n = sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+  Quatd r = {a.w / n, a.x / n, a.y / n, a.z / n};
+  return r;
+}
+DMV_HD void quatToR(const Quatd& q, double R[9]) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+DMV_HD void quatRotate(const Quatd& q, const double v[3], double out[3]) {
+  double ux = q.y * v[2] - q.z * v[1];
+  double uy = q.z * v[0] - q.x * v[2];
+  double uz = q.x * v[1] - q.y * v[0];
+  ux += ux; uy += uy; uz += uz;
+  out[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+  out[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+  out[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
+
+// exp of a = [upsilon; omega]
+DMV_HD Pose poseExp(const double a[6]) {
+  Pose r;
+  const double ox = a[3], oy = a[4], oz = a[5];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  const double theta = sqrt(theta_sq);
+  double imag, real;
+  if (theta < 1e-10) {
+    const double p4 = theta_sq * theta_sq;
+    imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * p4;
+    real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * p4;
+  } else {
+    imag = sin(0.5 * theta) / theta;
+    real = cos(0.5 * theta);
+  }
+  Quatd q = {real, imag * ox, imag * oy, imag * oz};
+  r.q = qnormalize(q);
+  // V = I + c1*Om + c2*Om^2   (Om = hat(omega));  theta ~ 0: V = R
+  double V[9];
+  if (theta < 1e-10) {
+    quatToR(r.q, V);
+  } else {
+    const double c1 = (1.0 - cos(theta)) / theta_sq;
+    const double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    double O2[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3 + 0] * O[0 * 3 + j] + O[i * 3 + 1] * O[1 * 3 + j] + O[i * 3 + 2] * O[2 * 3 + j];
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+  }
+  for (int i = 0; i < 3; i++) r.t[i] = V[i * 3 + 0] * a[0] + V[i * 3 + 1] * a[1] + V[i * 3 + 2] * a[2];
+  return r;
+}
+
+DMV_HD Pose poseMul(const Pose& a, const Pose& b) {
+  Pose r;
+  double rt[3];
+  quatRotate(a.q, b.t, rt);
+  r.t[0] = a.t[0] + rt[0]; r.t[1] = a.t[1] + rt[1]; r.t[2] = a.t[2] + rt[2];
+  r.q = qnormalize(qmul(a.q, b.q));
+  return r;
+}
+
+DMV_HD Pose poseFrom7(const double p[7]) {
+  Pose T;
+  T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+  Quatd q = {p[6], p[3], p[4], p[5]};
+  T.q = qnormalize(q);
+  return T;
+}
+DMV_HD void poseTo7(const Pose& T, double p[7]) {
+  p[0] = T.t[0]; p[1] = T.t[1]; p[2] = T.t[2];
+  p[3] = T.q.x; p[4] = T.q.y; p[5] = T.q.z; p[6] = T.q.w;
+}
+
+// AffLight::fromToVecExposure (src/dso/util/NumType.h:174-186)
+DMV_HD void affFromTo(float exposureF, float exposureT, double aF, double bF, double aT, double bT, double out[2]) {
+  if (exposureF == 0 || exposureT == 0) { exposureT = exposureF = 1; }
+  const double a = exp(aT - aF) * exposureT / exposureF;
+  out[0] = a;
+  out[1] = bT - a * bF;
+}
+
+// Symmetric n x n (n <= NMAX) solve by LDL^T with diagonal pivoting (largest |d_kk| first), the
+// decomposition CoarseTracker.cpp:639 uses through Eigen.  m: row-major, leading dimension ld, destroyed.
+template <int NMAX>
+DMV_HD void ldltSolveInPlace(double* m, int ld, double* d /*rhs in, x out*/, int n) {
+  int tr[NMAX];
+  double temp[NMAX];
+  bool zero = false;
+  for (int k = 0; k < n; k++) {
+    int big = k;
+    double bigv = fabs(m[k * ld + k]);
+    for (int i = k + 1; i < n; i++) {
+      const double v = fabs(m[i * ld + i]);
+      if (v > bigv) { bigv = v; big = i; }
+    }
+    tr[k] = big;
+    if (k != big) {
+      for (int c = 0; c < k; c++) { double s = m[k * ld + c]; m[k * ld + c] = m[big * ld + c]; m[big * ld + c] = s; }
+      for (int r = big + 1; r < n; r++) { double s = m[r * ld + k]; m[r * ld + k] = m[r * ld + big]; m[r * ld + big] = s; }
+      { double s = m[k * ld + k]; m[k * ld + k] = m[big * ld + big]; m[big * ld + big] = s; }
+      for (int i = k + 1; i < big; i++) { double s = m[i * ld + k]; m[i * ld + k] = m[big * ld + i]; m[big * ld + i] = s; }
+    }
+    if (k > 0) {
+      for (int j = 0; j < k; j++) temp[j] = m[j * ld + j] * m[k * ld + j];
+      double s = 0;
+      for (int j = 0; j < k; j++) s += m[k * ld + j] * temp[j];
+      m[k * ld + k] -= s;
+      for (int r = k + 1; r < n; r++) {
+        double s2 = 0;
+        for (int j = 0; j < k; j++) s2 += m[r * ld + j] * temp[j];
+        m[r * ld + k] -= s2;
+      }
+    }
+    const double akk = m[k * ld + k];
+    const bool ok = fabs(akk) > 0;
+    if (k == 0 && !ok) { zero = true; break; }
+    if (ok) for (int r = k + 1; r < n; r++) m[r * ld + k] /= akk;
+  }
+  if (zero) { for (int i = 0; i < n; i++) d[i] = 0; return; }
+  for (int k = 0; k < n; k++) if (tr[k] != k) { double s = d[k]; d[k] = d[tr[k]]; d[tr[k]] = s; }
+  for (int i = 0; i < n; i++) {
+    double s = d[i];
+    for (int j = 0; j < i; j++) s -= m[i * ld + j] * d[j];
+    d[i] = s;
+  }
+  for (int i = 0; i < n; i++) {
+    if (fabs(m[i * ld + i]) > 2.2250738585072014e-308) d[i] /= m[i * ld + i]; else d[i] = 0;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = d[i];
+    for (int j = i + 1; j < n; j++) s -= m[j * ld + i] * d[j];
+    d[i] = s;
+  }
+  for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { double s = d[k]; d[k] = d[tr[k]]; d[tr[k]] = s; }
+}
+
+}  // namespace dmv

@@ -1,0 +1,111 @@
+/*
+ * dmvio_hip.h — C ABI of libdmvio_hip.so: the MI355X (gfx950) implementation of DM-VIO's photometric
+ * direct-alignment hot path (coarse tracking + sliding-window photometric bundle adjustment).
+ *
+ * The reference (lukasvst/dm-vio) has no FFI on this path; its boundary is the C++ member surface that
+ * FullSystem uses.  Each entry point below names the reference interface it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the C++ adapter a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - opaque handles, POD in / POD out, caller owns every host array, no pointers retained after return
+ *   - poses are pose7 = [tx ty tz qx qy qz qw] (double), the reference's result.txt order
+ *     (FullSystem.cpp:256-298); an SE3 "refToNew" maps reference-frame points into the new frame
+ *   - return value: 0 = ok, <0 = error (dmvio_hip_last_error() describes it).  The reference's own
+ *     convention on this path is bool / NaN / isLost; the adapter maps <0 to "tracking failed"/isLost
+ *   - a dmvio_hip_tracker / dmvio_hip_ba is used by one thread at a time (tracking thread resp. mapping
+ *     thread under mapMutex — FullSystem.h:273-332); the ctx is shared and internally locked
+ *   - calls are synchronous on return unless named *_async
+ */
+#ifndef DMVIO_HIP_H
+#define DMVIO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMVIO_HIP_MAX_LEVELS 6 /* PYR_LEVELS, src/dso/util/settings.h:52 */
+
+typedef struct dmvio_hip_ctx dmvio_hip_ctx;
+typedef struct dmvio_hip_tracker dmvio_hip_tracker;
+typedef struct dmvio_hip_ba dmvio_hip_ba;
+
+/* ------------------------------------------------------------------ context ------------------ */
+const char* dmvio_hip_last_error(void);
+int dmvio_hip_device_count(void);
+
+/* Replaces the allocations of FullSystem::FullSystem (FullSystem.cpp:73-187) + setGlobalCalib's level rule
+ * (src/dso/util/globalCalib.cpp:45-105).  n_frame_slots image pyramids are kept resident in HBM. */
+dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots);
+void dmvio_hip_destroy(dmvio_hip_ctx* ctx);
+int dmvio_hip_pyr_levels(const dmvio_hip_ctx* ctx);
+/* Run all work of this ctx on a caller-provided hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int dmvio_hip_set_stream(dmvio_hip_ctx* ctx, void* hip_stream);
+int dmvio_hip_synchronize(dmvio_hip_ctx* ctx);
+
+/* ------------------------------------------------------------------ frames ------------------- */
+/* FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:128-191): irradiance w*h floats (0..255)
+ * -> dIp[lvl] = (I, dx, dy) pyramids resident in slot.  *_upload copies from host first; *_from_device
+ * consumes a device pointer already in HBM (no PCIe traffic). */
+int dmvio_hip_frame_upload(dmvio_hip_ctx* ctx, int slot, const float* irradiance_host);
+int dmvio_hip_frame_from_device(dmvio_hip_ctx* ctx, int slot, const float* irradiance_dev);
+/* dIp[lvl] back on host as w_l*h_l*3 floats (AoS, the reference's Eigen::Vector3f layout). */
+int dmvio_hip_frame_download(dmvio_hip_ctx* ctx, int slot, int lvl, float* dIp_host);
+
+/* ------------------------------------------------------------------ coarse tracker ----------- */
+typedef struct dmvio_hip_tracker_settings {
+  float huberTH;          /* setting_huberTH          = 9    settings.cpp:148 */
+  float coarseCutoffTH;   /* setting_coarseCutoffTH   = 20   settings.cpp:160 */
+  float affineOptModeA;   /* setting_affineOptModeA   = 1e12 settings.cpp:139 */
+  float affineOptModeB;   /* setting_affineOptModeB   = 1e8  settings.cpp:140 */
+} dmvio_hip_tracker_settings;
+
+/* CoarseTracker::CoarseTracker (CoarseTracker.cpp:62-97) */
+dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* ctx);
+void dmvio_hip_tracker_destroy(dmvio_hip_tracker* trk);
+int dmvio_hip_tracker_set_settings(dmvio_hip_tracker* trk, const dmvio_hip_tracker_settings* s);
+/* CoarseTracker::makeK (CoarseTracker.cpp:105-134): fx, fy, cx, cy of level 0 */
+int dmvio_hip_tracker_make_k(dmvio_hip_tracker* trk, const float fxfycxcy[4]);
+/* CoarseTracker::setCoarseTrackingRef + makeCoarseDepthL0 (CoarseTracker.cpp:524-538, 138-295).
+ * ref_slot: frame slot of lastRef.  The n points are the active points whose newest residual
+ * (target == lastRef) is IN: (u,v,idepth) = centerProjectedTo, hdiF = efPoint->HdiF (:144-161). */
+int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* trk, int ref_slot, float ref_exposure, double ref_aff_a, double ref_aff_b,
+                              int n, const float* u, const float* v, const float* idepth, const float* hdiF);
+/* pc_n[lvl] / pc_u,pc_v,pc_idepth,pc_color[lvl] (CoarseTracker.h:113-118) — parity / debugPlotIDepthMap */
+int dmvio_hip_tracker_pc_n(dmvio_hip_tracker* trk, int lvl);
+int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* trk, int lvl, float* u, float* v, float* idepth, float* color);
+/* One fused CoarseTracker::calcRes + calcGSSSE evaluation (CoarseTracker.cpp:361-517, 299-356) at refToNew.
+ * res6 = {E, numTermsInE, flowT, 0, flowRT, saturatedRatio}; H (8x8 row-major) and b are the SCALE_*-scaled
+ * system handed to IMUIntegration::computeCoarseUpdate in VIO mode (CoarseTracker.cpp:612-637). */
+int dmvio_hip_tracker_eval(dmvio_hip_tracker* trk, int lvl, int new_slot, float new_exposure,
+                           const double pose7_ref_to_new[7], const double aff_g2l_new[2], float cutoffTH,
+                           double res6[6], double H[64], double b[8]);
+/* CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:539-770), visual-only (useimu=0) branch, whole LM loop
+ * resident on the device.  pose7/aff are in/out (written only when every level finished, like the reference);
+ * returns trackingGood in *good; lastResiduals(5)/lastFlow(3) = CoarseTracker::lastResiduals/lastFlowIndicators;
+ * H,b = system at the accepted state of the last level. */
+int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_exposure,
+                            double pose7_io[7], double aff_io[2], int coarsestLvl, const double minResForAbort[5],
+                            double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good);
+/* Same for B independent alignment problems against the current reference in one launch: the pose-hypothesis
+ * list of FullSystem::trackNewCoarse (FullSystem.cpp:364-402) and/or a batch of new frames.  All arrays are
+ * B-major (pose7_io[B*7], aff_io[B*2], minResForAbort[B*5], lastResiduals[B*5], lastFlow[B*3], H[B*64], b[B*8],
+ * good[B], iterations[B] (may be NULL)). */
+int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* trk, int B, const int* new_slots, const float* new_exposures,
+                                  double* pose7_io, double* aff_io, int coarsestLvl, const double* minResForAbort,
+                                  double* lastResiduals, double* lastFlow, double* H, double* b, int* good, int* iterations);
+/* Enqueue-only variant: inputs must have been staged with a previous _track_batch call of the same B or
+ * _track_batch_stage; results stay on the device until _track_batch_fetch.  Used for kernel timing. */
+int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* trk, int B, const int* new_slots, const float* new_exposures,
+                                        const double* pose7_in, const double* aff_in, int coarsestLvl, const double* minResForAbort);
+int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* trk);
+int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* trk, double* pose7_out, double* aff_out, double* lastResiduals,
+                                        double* lastFlow, double* H, double* b, int* good, int* iterations);
+/* Work counters of the last batch launch: evals (calcRes+calcGS passes) and point-evaluations
+ * (sum over evals of pc_n[lvl]) — the unit count behind the roofline's algorithmic bytes. */
+int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long long* n_point_evals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVIO_HIP_H */

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return graft.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def synth(pkg):
+    import dmvio_amd.synth as s
+    return s
+
+
+def _have_gpu():
+    try:
+        p = graft.load_package()
+        return p.load_library().dmvio_hip_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_required(pkg):
+    # -m gpu tests must FAIL (not skip) when the HIP library or the device is missing: no silent fallback.
+    lib = pkg.load_library()
+    assert lib.dmvio_hip_device_count() > 0, "no HIP device visible"
+    return True

@@ -1,0 +1,176 @@
+"""GPU parity tests of the coarse tracker: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Tolerances (north_star): final photometric energy within 1e-4 relative, translation within 1e-3 m.
+Single evaluations are compared much tighter: per-point arithmetic is bit-identical to the oracle
+(integer counts must match EXACTLY); only the fp32 summation order differs (tree vs the reference's
+sequential 4-lane SSE order), which bounds sums at ~1e-6 relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+@pytest.fixture(scope="module")
+def setup(pkg, oracle, synth, gpu_required):
+    w = h = 512
+    case = synth.tracking_case(w, h, n_ref=2000, n_frames=3, xi_jitter=0.3)
+    ctx = pkg.Context(w, h, n_slots=8)
+    trk = pkg.CoarseTrackerHip(ctx)
+    trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"])
+    for k, f in enumerate(case["frames"]):
+        ctx.frame_upload(1 + k, f["img"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    dIr, _ = oracle.make_images(case["ref_img"], w, h)
+    dIn = [oracle.make_images(f["img"], w, h)[0] for f in case["frames"]]
+    T = oracle.Tracker(w, h)
+    T.make_k(case["K4"])
+    T.set_ref(dIr, case["u"], case["v"], case["idepth"], case["hdiF"])
+    return dict(case=case, ctx=ctx, trk=trk, T=T, dIr=dIr, dIn=dIn, w=w, h=h)
+
+
+def test_pyramid_bit_exact(setup):
+    """FrameHessian::makeImages: every level of (I,dx,dy) identical to the oracle, bit for bit."""
+    ctx = setup["ctx"]
+    assert ctx.levels == 4
+    for lvl in range(ctx.levels):
+        g = ctx.frame_download(0, lvl)
+        o = setup["dIr"][lvl]
+        assert g.shape == o.shape
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), "level %d differs" % lvl
+
+
+def test_set_ref_bit_exact(setup):
+    """makeCoarseDepthL0: same number of template points per level, same order, same bits."""
+    trk, T = setup["trk"], setup["T"]
+    for lvl in range(setup["ctx"].levels):
+        assert trk.pc_n(lvl) == T.pc_n(lvl)
+        g = trk.get_pc(lvl)
+        o = T.get_pc(lvl)
+        for a, b, name in zip(g, o, "u v idepth color".split()):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "pc_%s level %d" % (name, lvl)
+
+
+def _cmp_eval(rs_g, H_g, b_g, rs_o, H_o, b_o, tol=2e-5):
+    assert rs_g[1] == rs_o[1], "numTermsInE must match exactly"
+    assert abs(rs_g[5] - rs_o[5]) < 1e-7, "saturated ratio"
+    assert abs(rs_g[0] - rs_o[0]) <= tol * abs(rs_o[0]) + 1e-6
+    for k in (2, 4):
+        assert abs(rs_g[k] - rs_o[k]) <= 1e-4 * abs(rs_o[k]) + 1e-9
+    scale = np.sqrt(np.outer(np.diag(H_o), np.diag(H_o))) + 1e-30
+    assert np.max(np.abs(H_g - H_o) / scale) < tol
+    assert np.max(np.abs(b_g - b_o) / (np.sqrt(np.diag(H_o)) * np.sqrt(rs_o[0] / max(rs_o[1], 1)) + 1e-30)) < 10 * tol
+
+
+@pytest.mark.parametrize("lvl", [3, 2, 1, 0])
+def test_eval_parity(setup, lvl):
+    """One calcRes+calcGSSSE evaluation at identity, at the true pose and at a perturbed pose / affine."""
+    trk, T, case = setup["trk"], setup["T"], setup["case"]
+    T.set_new(setup["dIn"][0])
+    poses = [IDENT, case["frames"][0]["pose7"], case["frames"][1]["pose7"]]
+    affs = [(0.0, 0.0), (0.0, 0.0), (0.02, -3.0)]
+    for pose, aff in zip(poses, affs):
+        for cutoff in (20.0, 40.0):
+            rs_o = T.calc_res(lvl, pose, aff, cutoff)
+            H_o, b_o = T.calc_gs(lvl, aff)
+            rs_g, H_g, b_g = trk.eval(lvl, 1, pose, aff, cutoff)
+            _cmp_eval(rs_g, H_g, b_g, rs_o, H_o, b_o)
+
+
+def test_eval_deterministic(setup):
+    """Fixed summation order: two evaluations give the same bits."""
+    trk, case = setup["trk"], setup["case"]
+    a = trk.eval(0, 1, case["frames"][0]["pose7"], (0.0, 0.0))
+    b = trk.eval(0, 1, case["frames"][0]["pose7"], (0.0, 0.0))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_eval_identity_frame_zero_residual(setup):
+    """Identical frame, identity pose: r = 0, b = 0, E = 0 (known-answer)."""
+    trk = setup["trk"]
+    rs, H, b = trk.eval(0, 0, IDENT, (0.0, 0.0))
+    assert rs[0] == 0.0 and rs[5] == 0.0 and rs[1] > 9000
+    assert np.all(b == 0.0)
+    assert np.all(np.linalg.eigvalsh(H) > -1e-9 * np.max(np.abs(H)))
+
+
+def _cmp_track(g, o):
+    assert g["good"] == o["good"]
+    if not o["good"] and not np.all(np.isfinite(o["lastResiduals"][:1])):
+        return
+    dt = np.linalg.norm(g["pose7"][:3] - o["pose7"][:3])
+    dq = min(np.linalg.norm(g["pose7"][3:] - o["pose7"][3:]), np.linalg.norm(g["pose7"][3:] + o["pose7"][3:]))
+    assert dt < 1e-3, "translation differs by %g m" % dt
+    assert dq < 1e-3
+    for lvl in range(4):
+        eo, eg = o["lastResiduals"][lvl] ** 2, g["lastResiduals"][lvl] ** 2
+        if np.isfinite(eo):
+            assert abs(eg - eo) <= 1e-4 * eo, "level %d energy rel diff %g" % (lvl, abs(eg - eo) / eo)
+    assert np.allclose(g["aff"], o["aff"], rtol=1e-3, atol=1e-3)
+
+
+def test_track_parity(setup):
+    """Full 4-level trackNewestCoarse (device-resident LM) vs the oracle, from the identity guess."""
+    trk, T, case = setup["trk"], setup["T"], setup["case"]
+    for k in range(len(case["frames"])):
+        T.set_new(setup["dIn"][k])
+        o = T.track(IDENT, (0.0, 0.0))
+        g = trk.trackNewestCoarse(1 + k, IDENT, (0.0, 0.0))
+        _cmp_track(g, o)
+        # and it actually converged to the ground truth
+        assert np.linalg.norm(g["pose7"][:3] - case["frames"][k]["pose7"][:3]) < 2e-3
+        assert g["iterations"] == o["iterations"]
+
+
+def test_track_batch_hypotheses(setup, synth):
+    """B pose hypotheses in one launch (FullSystem::trackNewCoarse's try list) == B sequential oracle runs."""
+    trk, T, case = setup["trk"], setup["T"], setup["case"]
+    rng = np.random.RandomState(7)
+    B = 12
+    poses = []
+    for i in range(B):
+        xi = case["frames"][0]["xi"] * rng.uniform(0.0, 1.6) + rng.normal(0, 0.004, 6)
+        R, t = synth.se3_exp(xi)
+        poses.append(synth.pose7(R, t))
+    slots = [1 + (i % 3) for i in range(B)]
+    affs = [(0.0, 0.0)] * B
+    g = trk.track_batch(slots, poses, affs)
+    for i in range(B):
+        T.set_new(setup["dIn"][slots[i] - 1])
+        o = T.track(poses[i], affs[i])
+        gi = dict(good=bool(g["good"][i]), pose7=g["pose7"][i], aff=g["aff"][i], lastResiduals=g["lastResiduals"][i])
+        _cmp_track(gi, o)
+
+
+def test_track_abort_and_failure_semantics(setup):
+    """minResForAbort: a level RMSE above 1.5x the threshold aborts, returns false and leaves pose/aff untouched."""
+    trk, T = setup["trk"], setup["T"]
+    T.set_new(setup["dIn"][0])
+    mr = np.array([0.1, 0.1, 0.1, 0.1, np.nan])
+    o = T.track(IDENT, (0.0, 0.0), min_res=mr)
+    g = trk.trackNewestCoarse(1, IDENT, (0.0, 0.0), minResForAbort=mr)
+    assert o["good"] is False and g["good"] is False
+    assert np.array_equal(g["pose7"], IDENT)
+    assert np.isnan(g["lastResiduals"][0]) and np.isfinite(g["lastResiduals"][3])
+    assert abs(g["lastResiduals"][3] - o["lastResiduals"][3]) < 1e-4 * o["lastResiduals"][3]
+
+
+def test_affine_brightness_recovered(pkg, oracle, synth, gpu_required):
+    """New frame rendered with an affine brightness change: a,b are estimated like the oracle does."""
+    w = h = 512
+    case = synth.tracking_case(w, h, n_ref=1500, aff_new=(0.04, 4.0))
+    ctx = pkg.Context(w, h, n_slots=2)
+    trk = pkg.CoarseTrackerHip(ctx)
+    trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, case["frames"][0]["img"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    T = oracle.Tracker(w, h); T.make_k(case["K4"])
+    T.set_ref(oracle.make_images(case["ref_img"], w, h)[0], case["u"], case["v"], case["idepth"], case["hdiF"])
+    T.set_new(oracle.make_images(case["frames"][0]["img"], w, h)[0])
+    o = T.track(IDENT, (0.0, 0.0)); g = trk.trackNewestCoarse(1, IDENT, (0.0, 0.0))
+    _cmp_track(g, o)
+    assert abs(g["aff"][0] - 0.04) < 0.02 and abs(g["aff"][1] - 4.0) < 3.0
