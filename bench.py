@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — tracked frames/s of the photometric direct-alignment hot path on N MI355X.
+
+One "step" = one batch of B independent new frames aligned against the current reference keyframe:
+per frame the image pyramid + gradients are built on the device from the resident irradiance image
+(FrameHessian::makeImages) and the full 4-level CoarseTracker::trackNewestCoarse LM loop runs
+device-resident (calcRes + calcGSSSE fused).  Inputs are resident in HBM before the timed region.
+
+Workload (BASELINE.json configs[1]): synthetic 512x512 4-level pyramid, ~2000 reference points
+(TUM-VI rectified intrinsics), plane-world renderer, seed 20250204.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank aligns its own batch against its
+own replica of the reference (weak scaling, no data-path collective — coarse tracking of independent frames
+does not shard); timing is barrier + synchronize bracketed and MAX-reduced.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_POINT_EVAL = 64      # 16 B template record + 4 taps x 12 B
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVIO_BENCH_BATCH", "1024")), help="frames per step per GPU")
+    ap.add_argument("--points", type=int, default=2000, help="reference points (active points of the window)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct rendered frames (replicated into the batch slots)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pyramid", action="store_true", help="exclude makeImages from the step (track only)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = graft.load_package()
+    import dmvio_amd.synth as synth
+
+    w = h = args.size
+    B = args.batch
+    # ---------------- synthetic inputs (deterministic; rank-dependent jitter so ranks do not share data)
+    case = synth.tracking_case(w, h, n_ref=args.points, seed=synth.SEED + 1000 * rank, n_frames=args.distinct, xi_jitter=0.35)
+    ctx = pkg.Context(w, h, n_slots=B + 1, device=local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+    trk = pkg.CoarseTrackerHip(ctx)
+    trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    pc_n = [trk.pc_n(l) for l in range(ctx.levels)]
+    # resident raw irradiance images of the batch (device memory via torch: plumbing only)
+    raw = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    host_frames = np.stack([f["img"] for f in case["frames"]])
+    raw_distinct = torch.from_numpy(host_frames).to(dev)
+    idx = torch.arange(B, device=dev) % args.distinct
+    raw.copy_(raw_distinct[idx])
+    torch.cuda.synchronize(dev)
+    slots = np.arange(1, B + 1, dtype=np.int32)
+    rng = np.random.RandomState(99 + rank)
+    # initial guesses: identity + small perturbation (the constant-motion guess of trackNewCoarse is near the truth)
+    poses0 = np.zeros((B, 7)); poses0[:, 6] = 1.0
+    for i in range(B):
+        R, t = synth.se3_exp(rng.normal(0, 0.002, 6))
+        poses0[i] = synth.pose7(R, t)
+    affs0 = np.zeros((B, 2))
+    raw_ptr = raw.data_ptr()
+    frame_bytes = w * h * 4
+
+    def step(fetch=True):
+        if not args.no_pyramid:
+            ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes)
+        trk.stage(slots, poses0, affs0)
+        trk.launch()
+        return trk.fetch() if fetch else None
+
+    # ---------------- warmup + correctness guard (poses must reach the ground truth)
+    res = None
+    for _ in range(max(args.warmup, 1)):
+        res = step()
+    truth = np.stack([case["frames"][i % args.distinct]["pose7"] for i in range(B)])
+    terr = np.linalg.norm(res["pose7"][:, :3] - truth[:, :3], axis=1)
+    n_evals, n_point_evals = trk.last_work()
+    if not (res["good"].all() and terr.max() < 5e-3):
+        raise SystemExit("bench: tracking did not converge (good=%d/%d, max err %.3g m)" % (res["good"].sum(), B, terr.max()))
+
+    # ---------------- timed region: EXACTLY K steps, barrier + synchronize on both sides
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames_per_s = world * B * args.steps / elapsed
+
+    # ---------------- kernel-level roofline of the dominant kernel (k_track_lm), HIP events on ITS stream
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    reps = max(3, min(args.steps, 10))
+    trk.stage(slots, poses0, affs0)
+    torch.cuda.synchronize(dev)
+    kms = []
+    for _ in range(reps):
+        ev0.record(stream); trk.launch(); ev1.record(stream)
+        ev1.synchronize()
+        kms.append(ev0.elapsed_time(ev1))
+    trk.fetch()
+    n_evals, n_point_evals = trk.last_work()
+    k_ms = float(np.mean(kms))
+    alg_bytes = BYTES_PER_POINT_EVAL * n_point_evals
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="k_track_lm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    kernel_ms=round(k_ms, 4), algorithmic_bytes_per_launch=int(alg_bytes),
+                    point_evals_per_launch=int(n_point_evals), evals_per_launch=int(n_evals))
+    pm = None
+    if not args.no_pyramid:
+        pms = []
+        for _ in range(reps):
+            ev0.record(stream); ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes); ev1.record(stream)
+            ev1.synchronize(); pms.append(ev0.elapsed_time(ev1))
+        pm = float(np.mean(pms))
+        pyr_bytes = B * (4 * w * h + sum(16 * (w >> l) * (h >> l) for l in range(ctx.levels)))
+        roofline["pyramid_kernel_ms"] = round(pm, 4)
+        roofline["pyramid_GBps"] = round(pyr_bytes / (pm * 1e-3) / 1e9, 1)
+
+    # ---------------- CPU baseline: the oracle (port of the reference's SSE path), 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        O = graft.load_oracle()
+        T = O.Tracker(w, h)
+        T.make_k(case["K4"])
+        T.set_ref(O.make_images(case["ref_img"], w, h)[0], case["u"], case["v"], case["idepth"], case["hdiF"])
+        n_done = 0
+        t_cpu0 = time.perf_counter()
+        while True:
+            i = n_done % B
+            tA = time.perf_counter()
+            dIn = O.make_images(host_frames[i % args.distinct], w, h)[0]
+            T.set_new(dIn)
+            o = T.track(poses0[i], affs0[i])
+            n_done += 1
+            if time.perf_counter() - t_cpu0 > args.cpu_seconds:
+                break
+        t_cpu = time.perf_counter() - t_cpu0
+        cpu = dict(value=round(n_done / t_cpu, 2), unit="frames/s", cores=1, kind="port",
+                   sample="%d frames of the same batch (makeImages + trackNewestCoarse), oracle -O3 -msse2, 1 thread "
+                          "(the reference tracks single-threaded), %.1f s on %s" % (n_done, t_cpu, _cpu_name()))
+
+    if rank == 0:
+        out = {
+            "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
+            "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
+                                   "per step (%d distinct renders), makeImages%s + trackNewestCoarse (useimu=0 LM) per frame"
+                                   % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else ""),
+                       "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "lm_iterations_mean": float(np.mean(res["iterations"])),
+            "max_pose_err_m": float(terr.max()),
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip() + " (%d hw threads)" % os.cpu_count()
+    except Exception:
+        pass
+    return "unknown cpu"
+
+
+if __name__ == "__main__":
+    main()

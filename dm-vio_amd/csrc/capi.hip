@@ -37,6 +37,12 @@ struct dmvio_hip_ctx {
   float* d_planar[DMV_MAX_LEVELS] = {};
   float* d_f3 = nullptr;  // download scratch (w*h*3)
   int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
+  // batched pyramid scratch: per frame the planar intensities of levels >= 1
+  float* d_planar_batch = nullptr;
+  size_t planar_batch_stride = 0, planar_lvl_off[DMV_MAX_LEVELS] = {};
+  int planar_batch_cap = 0;
+  int *d_slots = nullptr, *h_slots = nullptr;
+  int slots_cap = 0, slots_valid = 0;
   std::mutex mu;
 };
 
@@ -111,6 +117,8 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipFree(c->fs.base);
   for (int l = 0; l < c->levels; l++) hipFree(c->d_planar[l]);
   hipFree(c->d_f3);
+  hipFree(c->d_planar_batch); hipFree(c->d_slots);
+  if (c->h_slots) hipHostFree(c->h_slots);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -169,6 +177,50 @@ int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   return buildPyramid(c, slot, dev);  // asynchronous on the ctx stream
+}
+
+int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes) {
+  if (!c || !slots || !dev_base) return failmsg("frames_from_device_batch: null argument");
+  if (B <= 0 || stride_bytes % sizeof(float)) return failmsg("frames_from_device_batch: bad B / stride");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  if (B > c->slots_cap) {
+    if (c->d_slots) { HIPCHK(hipFree(c->d_slots)); HIPCHK(hipHostFree(c->h_slots)); }
+    c->slots_cap = std::max(B, 64); c->slots_valid = 0;
+    HIPCHK(hipMalloc((void**)&c->d_slots, sizeof(int) * c->slots_cap));
+    HIPCHK(hipHostMalloc((void**)&c->h_slots, sizeof(int) * c->slots_cap, hipHostMallocDefault));
+  }
+  if (B > c->planar_batch_cap && c->levels > 1) {
+    if (c->d_planar_batch) HIPCHK(hipFree(c->d_planar_batch));
+    size_t off = 0;
+    for (int l = 1; l < c->levels; l++) { c->planar_lvl_off[l] = off; off += (size_t)c->wl[l] * c->hl[l]; }
+    c->planar_batch_stride = off;
+    c->planar_batch_cap = std::max(B, 64);
+    HIPCHK(hipMalloc((void**)&c->d_planar_batch, sizeof(float) * off * c->planar_batch_cap));
+  }
+  bool same = (B == c->slots_valid);
+  for (int i = 0; i < B; i++) {
+    if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frames_from_device_batch: slot out of range");
+    if (same && c->h_slots[i] != slots[i]) same = false;
+  }
+  if (!same) {
+    // the pinned staging buffer may still be the source of an in-flight copy: drain before rewriting it
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < B; i++) c->h_slots[i] = slots[i];
+    HIPCHK(hipMemcpyAsync(c->d_slots, c->h_slots, sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
+    c->slots_valid = B;
+  }
+  for (int l = 0; l < c->levels; l++) {
+    const int n = c->wl[l] * c->hl[l];
+    const float* in = (l == 0) ? dev_base : c->d_planar_batch + c->planar_lvl_off[l];
+    const size_t in_stride = (l == 0) ? stride_bytes / sizeof(float) : c->planar_batch_stride;
+    float* next = (l + 1 < c->levels) ? c->d_planar_batch + c->planar_lvl_off[l + 1] : nullptr;
+    const int bx = std::max(1, std::min((n + 255) / 256, 64));
+    hipLaunchKernelGGL(k_make_level_batch, dim3(bx, B), dim3(256), 0, c->stream, in, in_stride, c->wl[l], c->hl[l], c->fs, c->d_slots, l,
+                       next, c->planar_batch_stride);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {

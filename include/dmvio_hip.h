@@ -18,6 +18,7 @@
  */
 #ifndef DMVIO_HIP_H
 #define DMVIO_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -49,6 +50,9 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* ctx);
  * consumes a device pointer already in HBM (no PCIe traffic). */
 int dmvio_hip_frame_upload(dmvio_hip_ctx* ctx, int slot, const float* irradiance_host);
 int dmvio_hip_frame_from_device(dmvio_hip_ctx* ctx, int slot, const float* irradiance_dev);
+/* makeImages for B frames in 4 launches: frame i is read from dev_base + i*stride_bytes and written to slots[i].
+ * Asynchronous on the ctx stream (ordering with later tracker calls is by stream order). */
+int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);
 /* dIp[lvl] back on host as w_l*h_l*3 floats (AoS, the reference's Eigen::Vector3f layout). */
 int dmvio_hip_frame_download(dmvio_hip_ctx* ctx, int slot, int lvl, float* dIp_host);
 
