@@ -142,13 +142,15 @@ def main():
         kms.append(ev0.elapsed_time(ev1))
     trk.fetch()
     n_evals, n_point_evals = trk.last_work()
+    tk_step, tk_eval = trk.last_ticks()
     k_ms = float(np.mean(kms))
     alg_bytes = BYTES_PER_POINT_EVAL * n_point_evals
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel="k_track_lm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
                     kernel_ms=round(k_ms, 4), algorithmic_bytes_per_launch=int(alg_bytes),
-                    point_evals_per_launch=int(n_point_evals), evals_per_launch=int(n_evals))
+                    point_evals_per_launch=int(n_point_evals), evals_per_launch=int(n_evals),
+                    in_kernel_us_per_problem=dict(lm_control=round(tk_step / 100.0 / B, 2), evaluation=round(tk_eval / 100.0 / B, 2)))
     pm = None
     if not args.no_pyramid:
         pms = []

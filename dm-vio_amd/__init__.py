@@ -54,6 +54,7 @@ def _sig(L):
     L.dmvio_hip_tracker_track_batch_stage.argtypes = [vp, C.c_int, c_i, c_f, c_d, c_d, C.c_int, c_d]
     L.dmvio_hip_tracker_track_batch_launch.argtypes = [vp]
     L.dmvio_hip_tracker_track_batch_fetch.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
+    L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
 
 
@@ -63,6 +64,13 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HipLibraryError("libdmvio_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        # torch wheels bundle their own libamdhip64; when torch shares the process (bench.py uses it for device
+        # memory, streams and RCCL) it must be loaded FIRST so that both sides run on one HIP runtime — two
+        # runtimes in one process leave the second one without devices ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _sig(_lib)
     return _lib
@@ -237,6 +245,11 @@ class CoarseTrackerHip:
         good = np.zeros(B, dtype=np.int32); its = np.zeros(B, dtype=np.int32)
         _chk(self.L, self.L.dmvio_hip_tracker_track_batch_fetch(self.p, _d(poses), _d(affs), _d(lr), _d(fl), _d(H), _d(b), _i(good), _i(its)), "fetch")
         return dict(good=good, pose7=poses, aff=affs, lastResiduals=lr, flow=fl, H=H.reshape(B, 8, 8), b=b, iterations=its)
+
+    def last_ticks(self):
+        a = C.c_longlong(0); b = C.c_longlong(0)
+        _chk(self.L, self.L.dmvio_hip_tracker_last_ticks(self.p, C.byref(a), C.byref(b)), "last_ticks")
+        return a.value, b.value
 
     def last_work(self):
         a = C.c_longlong(0); b = C.c_longlong(0)

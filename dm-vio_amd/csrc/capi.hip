@@ -63,7 +63,7 @@ struct dmvio_hip_tracker {
   LMProblemIn *d_in = nullptr, *h_in = nullptr;
   LMProblemOut *d_out = nullptr, *h_out = nullptr;
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
-  long long last_evals = 0, last_point_evals = 0;
+  long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
   int lm_threads_override = 0;
 };
 
@@ -464,6 +464,7 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
   HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   long long ev = 0, pe = 0;
+  t->last_ticks_step = t->last_ticks_eval = 0;
   for (int i = 0; i < B; i++) {
     const LMProblemOut& o = t->h_out[i];
     if (pose7_out) memcpy(pose7_out + 7 * i, o.pose7, sizeof(double) * 7);
@@ -474,7 +475,7 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
     if (b) memcpy(b + 8 * i, o.b, sizeof(double) * 8);
     if (good) good[i] = o.good;
     if (iterations) iterations[i] = o.iterations;
-    ev += o.n_evals; pe += o.n_point_evals;
+    ev += o.n_evals; pe += o.n_point_evals; t->last_ticks_step += o.ticks_step; t->last_ticks_eval += o.ticks_eval;
   }
   t->last_evals = ev; t->last_point_evals = pe;
   return 0;
@@ -491,6 +492,13 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_sl
 int dmvio_hip_tracker_track(dmvio_hip_tracker* t, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
                             const double minRes[5], double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good) {
   return dmvio_hip_tracker_track_batch(t, 1, &new_slot, &new_exposure, pose7_io, aff_io, coarsestLvl, minRes, lastResiduals, lastFlow, H, b, good, nullptr);
+}
+
+int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* t, long long* ticks_step, long long* ticks_eval) {
+  if (!t) return failmsg("null tracker");
+  if (ticks_step) *ticks_step = t->last_ticks_step;
+  if (ticks_eval) *ticks_eval = t->last_ticks_eval;
+  return 0;
 }
 
 int dmvio_hip_tracker_last_work(dmvio_hip_tracker* t, long long* n_evals, long long* n_point_evals) {

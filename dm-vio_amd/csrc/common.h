@@ -80,6 +80,7 @@ struct LMProblemOut {
   int n_evals;
   int pad_;
   long long n_point_evals;
+  long long ticks_step, ticks_eval;  // wall_clock64 (100 MHz) spent in LM control steps / evaluations
 };
 
 }  // namespace dmv

@@ -233,7 +233,13 @@ DMV_HD void makeEvalP(const TrackerDev& trk, int lvl, const Pose& T, double affA
 // ---------------------------------------------------------------------------------------------
 // device-resident trackNewestCoarse: one workgroup per alignment problem
 // ---------------------------------------------------------------------------------------------
+// The LM control step between two evaluations is executed by wave 0 of the workgroup:
+//   * scalar decisions (accept/reject, lambda schedule, level logic) by lane 0,
+//   * the 8x8 system: lane (r*8+c) owns H(r,c); H,b from the 45 sums, damping and the pivoted LDL^T solve
+//     are wave-wide register + cross-lane operations (no scratch memory, no serial fp64 loops),
+//   * SE3 exp / pose composition by lane 0 (static indices only -> registers).
 enum { LM_LEVEL_BEGIN = 0, LM_INIT_EVAL, LM_ITER_BEGIN, LM_ITER_EVAL, LM_LEVEL_END };
+enum { ACT_DONE = 0, ACT_EVAL_CUR = 1, ACT_SOLVE = 2 };
 
 struct LMState {
   Pose cur, nxt;
@@ -245,17 +251,149 @@ struct LMState {
   float lambda, cutoffRepeat;
   int lvl, iteration, st, totalIts, nEvals;
   long long nPointEvals;
-  bool haveRepeated;
+  int haveRepeated;
 };
 
-// Thread-0 state machine.  Returns true when an evaluation (described by *e) is requested, false when done.
-__device__ bool lmAdvance(LMState& S, const TrackerDev& trk, const LMProblemIn& in, LMProblemOut& out,
-                          const float* tot, double* H, double* b, double* Hl, EvalP* e) {
+// H(r,c) (SCALE_*-scaled, double) of lane = r*8+c from the 45 sums — calcGSSSE's tail (CoarseTracker.cpp:340-355).
+__device__ __forceinline__ double systemEntryFromSums(const float* tot, const int r, const int c) {
+  const int nW = (int)tot[ACC_NW];
+  const int n = (nW + 3) & ~3;
+  const float invn = 1.0f / n;
+  const int rr = r < c ? r : c, cc = r < c ? c : r;
+  const float scr = r == 6 ? 10.0f : (r == 7 ? 1000.0f : 1.0f);
+  const float scc = c == 6 ? 10.0f : (c == 7 ? 1000.0f : 1.0f);
+  return (((double)tot[accIdx(rr, cc)] * invn) * scc) * scr;
+}
+__device__ __forceinline__ double rhsEntryFromSums(const float* tot, const int r) {
+  const int nW = (int)tot[ACC_NW];
+  const int n = (nW + 3) & ~3;
+  const float invn = 1.0f / n;
+  const float scr = r == 6 ? 10.0f : (r == 7 ? 1000.0f : 1.0f);
+  return ((double)tot[accIdx(r, 8)] * invn) * scr;
+}
+
+// Wave-cooperative LDL^T with symmetric diagonal pivoting (largest |d| first — the pivot rule of the
+// decomposition CoarseTracker.cpp:639 calls).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).
+// Returns x(r) in every lane of row r.
+__device__ __forceinline__ double waveLdltSolve8(double m, double dv, const int lane) {
+  const int r = lane >> 3, c = lane & 7;
+  int trk[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int p = k;
+    double best = fabs(__shfl(m, k * 9, 64));
+#pragma unroll
+    for (int i = k + 1; i < 8; i++) {
+      const double v = fabs(__shfl(m, i * 9, 64));
+      if (v > best) { best = v; p = i; }
+    }
+    trk[k] = p;
+    {
+      const int pr = (r == k) ? p : ((r == p) ? k : r);
+      const int pc = (c == k) ? p : ((c == p) ? k : c);
+      m = __shfl(m, pr * 8 + pc, 64);
+      dv = __shfl(dv, pr * 8 + c, 64);
+    }
+    const double dk = __shfl(m, k * 9, 64);
+    const bool ok = fabs(dk) > 0;
+    const double mrk = __shfl(m, r * 8 + k, 64);
+    const double mck = __shfl(m, c * 8 + k, 64);
+    const double Lrk = ok ? mrk / dk : mrk;
+    const double Lck = ok ? mck / dk : mck;
+    if (r > k && c > k) m = m - Lrk * (dk * Lck);
+    if (c == k && r > k) m = Lrk;
+  }
+  // forward substitution  (L y = P b)
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const double dkv = __shfl(dv, k * 8, 64);
+    const double Lrk = __shfl(m, r * 8 + k, 64);
+    if (r > k) dv = dv - Lrk * dkv;
+  }
+  {
+    const double D = __shfl(m, r * 9, 64);
+    dv = (fabs(D) > 2.2250738585072014e-308) ? dv / D : 0.0;
+  }
+  // backward substitution  (L^T x = z)
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    const double dkv = __shfl(dv, k * 8, 64);
+    const double Lkr = __shfl(m, k * 8 + r, 64);
+    if (r < k) dv = dv - Lkr * dkv;
+  }
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    const int p = trk[k];
+    const int pr = (r == k) ? p : ((r == p) ? k : r);
+    dv = __shfl(dv, pr * 8 + c, 64);
+  }
+  return dv;
+}
+
+// One LM control step, executed by all 64 lanes of wave 0.  Consumes the finished evaluation in s_tot, decides,
+// and either prepares the next evaluation (s_e, returns true) or finishes the problem (returns false).
+__device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, const LMProblemIn& in, LMProblemOut& out,
+                                           const float* s_tot, double* s_H, double* s_b, double* s_x, EvalP& s_e, const int lane) {
   const int maxIterations[5] = {10, 20, 50, 50, 50};
   const float lambdaExtrapolationLimit = 0.001f;
-  for (;;) {
-    switch (S.st) {
-      case LM_LEVEL_BEGIN: {
+  int takeH = 0, action = ACT_DONE;
+  if (lane == 0) {
+    // (1) consume the evaluation that just finished
+    if (S.st == LM_INIT_EVAL) {
+      res6FromSums(s_tot, S.resOld);
+      if (S.resOld[5] > 0.6 && (S.cutoffRepeat < 50 || S.resOld[5] > 0.99)) {
+        S.cutoffRepeat *= 2;
+        action = ACT_EVAL_CUR;  // same pose, doubled cutoff; stay in LM_INIT_EVAL
+      } else {
+        takeH = 1;
+        S.lambda = 0.01f;
+        S.iteration = 0;
+        S.st = LM_ITER_BEGIN;
+      }
+    } else if (S.st == LM_ITER_EVAL) {
+      double resNew[6];
+      res6FromSums(s_tot, resNew);
+      const bool accept = (resNew[0] / resNew[1]) < (S.resOld[0] / S.resOld[1]);
+      if (accept) {
+        takeH = 1;
+        for (int i = 0; i < 6; i++) S.resOld[i] = resNew[i];
+        S.affA = S.affA_n; S.affB = S.affB_n;
+        S.cur = S.nxt;
+        S.lambda *= 0.5f;
+      } else {
+        S.lambda *= 4;
+        if (S.lambda < lambdaExtrapolationLimit) S.lambda = lambdaExtrapolationLimit;
+      }
+      S.totalIts++;
+      S.iteration++;
+      S.st = (!(S.incNorm > 1e-3)) ? LM_LEVEL_END : LM_ITER_BEGIN;
+    }
+    // (2) bookkeeping until the next evaluation (or the end) is determined
+    if (action != ACT_EVAL_CUR) {
+      for (;;) {
+        if (S.st == LM_ITER_BEGIN) {
+          if (S.iteration >= maxIterations[S.lvl]) { S.st = LM_LEVEL_END; continue; }
+          action = ACT_SOLVE;
+          break;
+        }
+        if (S.st == LM_LEVEL_END) {
+          S.lastRes[S.lvl] = sqrtf((float)(S.resOld[0] / S.resOld[1]));
+          S.flow[0] = S.resOld[2]; S.flow[1] = S.resOld[3]; S.flow[2] = S.resOld[4];
+          const bool failed = isnan(S.lastRes[S.lvl]) || (S.lastRes[S.lvl] > 1.5 * in.minRes[S.lvl]);
+          if (failed) {
+            // reference returns false without touching lastToNew_out / aff_g2l_out (CoarseTracker.cpp:731-732)
+            for (int i = 0; i < 7; i++) out.pose7[i] = in.pose7[i];
+            out.aff[0] = in.aff[0]; out.aff[1] = in.aff[1];
+            out.good = 0;
+            action = ACT_DONE;
+            break;
+          }
+          if (S.cutoffRepeat > 1 && !S.haveRepeated) { S.lvl++; S.haveRepeated = 1; }
+          S.lvl--;
+          S.st = LM_LEVEL_BEGIN;
+          continue;
+        }
+        // LM_LEVEL_BEGIN
         if (S.lvl < 0) {
           // success: write back (CoarseTracker.cpp:743-760)
           double aff[2] = {S.affA, S.affB};
@@ -269,106 +407,91 @@ __device__ bool lmAdvance(LMState& S, const TrackerDev& trk, const LMProblemIn& 
           poseTo7(S.cur, out.pose7);
           out.aff[0] = aff[0]; out.aff[1] = aff[1];
           out.good = good ? 1 : 0;
-          return false;
+          action = ACT_DONE;
+          break;
         }
         S.cutoffRepeat = 1;
-        makeEvalP(trk, S.lvl, S.cur, S.affA, S.affB, in.new_exposure, trk.coarseCutoffTH * S.cutoffRepeat, *e);
         S.st = LM_INIT_EVAL;
-        return true;
-      }
-      case LM_INIT_EVAL: {
-        res6FromSums(tot, S.resOld);
-        if (S.resOld[5] > 0.6 && (S.cutoffRepeat < 50 || S.resOld[5] > 0.99)) {
-          S.cutoffRepeat *= 2;
-          makeEvalP(trk, S.lvl, S.cur, S.affA, S.affB, in.new_exposure, trk.coarseCutoffTH * S.cutoffRepeat, *e);
-          return true;
-        }
-        systemFromSums(tot, H, b);
-        S.lambda = 0.01f;
-        S.iteration = 0;
-        S.st = LM_ITER_BEGIN;
-        break;
-      }
-      case LM_ITER_BEGIN: {
-        if (S.iteration >= maxIterations[S.lvl]) { S.st = LM_LEVEL_END; break; }
-        for (int i = 0; i < 64; i++) Hl[i] = H[i];
-        for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + S.lambda);
-        float extrapFac = 1;
-        if (S.lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / S.lambda));
-        double inc[8];
-        for (int i = 0; i < 8; i++) inc[i] = -b[i];
-        const bool fixA = trk.modeA < 0, fixB = trk.modeB < 0;
-        if (!fixA && !fixB) {
-          ldltSolveInPlace<8>(Hl, 8, inc, 8);
-        } else if (fixA && fixB) {
-          ldltSolveInPlace<8>(Hl, 8, inc, 6);
-          inc[6] = inc[7] = 0;
-        } else if (!fixA && fixB) {
-          ldltSolveInPlace<8>(Hl, 8, inc, 7);
-          inc[7] = 0;
-        } else {  // fix a: stitch b's row/col into slot 6 (CoarseTracker.cpp:653-664)
-          for (int r = 0; r < 8; r++) Hl[r * 8 + 6] = Hl[r * 8 + 7];
-          for (int c = 0; c < 8; c++) Hl[6 * 8 + c] = Hl[7 * 8 + c];
-          inc[6] = inc[7];
-          ldltSolveInPlace<8>(Hl, 8, inc, 7);
-          inc[7] = inc[6];
-          inc[6] = 0;
-        }
-        for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
-        double incScaled[8];
-        for (int i = 0; i < 6; i++) incScaled[i] = inc[i] * 1.0f;  // SCALE_XI_ROT / SCALE_XI_TRANS
-        incScaled[6] = inc[6] * 10.0f;                               // SCALE_A
-        incScaled[7] = inc[7] * 1000.0f;                             // SCALE_B
-        double ssum = 0;
-        for (int i = 0; i < 8; i++) ssum += incScaled[i];
-        if (!isfinite(ssum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
-        S.nxt = poseMul(poseExp(incScaled), S.cur);
-        S.affA_n = S.affA + incScaled[6];
-        S.affB_n = S.affB + incScaled[7];
-        double nn = 0;
-        for (int i = 0; i < 8; i++) nn += inc[i] * inc[i];
-        S.incNorm = sqrt(nn);
-        makeEvalP(trk, S.lvl, S.nxt, S.affA_n, S.affB_n, in.new_exposure, trk.coarseCutoffTH * S.cutoffRepeat, *e);
-        S.st = LM_ITER_EVAL;
-        return true;
-      }
-      case LM_ITER_EVAL: {
-        double resNew[6];
-        res6FromSums(tot, resNew);
-        const bool accept = (resNew[0] / resNew[1]) < (S.resOld[0] / S.resOld[1]);
-        if (accept) {
-          systemFromSums(tot, H, b);
-          for (int i = 0; i < 6; i++) S.resOld[i] = resNew[i];
-          S.affA = S.affA_n; S.affB = S.affB_n;
-          S.cur = S.nxt;
-          S.lambda *= 0.5f;
-        } else {
-          S.lambda *= 4;
-          if (S.lambda < lambdaExtrapolationLimit) S.lambda = lambdaExtrapolationLimit;
-        }
-        S.totalIts++;
-        S.iteration++;
-        S.st = (!(S.incNorm > 1e-3)) ? LM_LEVEL_END : LM_ITER_BEGIN;
-        break;
-      }
-      case LM_LEVEL_END: {
-        S.lastRes[S.lvl] = sqrtf((float)(S.resOld[0] / S.resOld[1]));
-        S.flow[0] = S.resOld[2]; S.flow[1] = S.resOld[3]; S.flow[2] = S.resOld[4];
-        const bool failed = isnan(S.lastRes[S.lvl]) || (S.lastRes[S.lvl] > 1.5 * in.minRes[S.lvl]);
-        if (failed) {
-          // reference returns false without touching lastToNew_out / aff_g2l_out (CoarseTracker.cpp:731-732)
-          for (int i = 0; i < 7; i++) out.pose7[i] = in.pose7[i];
-          out.aff[0] = in.aff[0]; out.aff[1] = in.aff[1];
-          out.good = 0;
-          return false;
-        }
-        if (S.cutoffRepeat > 1 && !S.haveRepeated) { S.lvl++; S.haveRepeated = true; }
-        S.lvl--;
-        S.st = LM_LEVEL_BEGIN;
+        action = ACT_EVAL_CUR;
         break;
       }
     }
   }
+  takeH = __builtin_amdgcn_readfirstlane(takeH);
+  action = __builtin_amdgcn_readfirstlane(action);
+
+  const int r = lane >> 3, c = lane & 7;
+  double hv, bv;
+  if (takeH) {
+    hv = systemEntryFromSums(s_tot, r, c);
+    bv = rhsEntryFromSums(s_tot, r);
+    s_H[lane] = hv;
+    if (c == 0) s_b[r] = bv;
+  } else {
+    hv = s_H[lane];
+    bv = s_b[r];
+  }
+
+  if (action == ACT_SOLVE) {
+    const float lambda = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lane == 0 ? S.lambda : 0.0f)));
+    const bool fixA = trk.modeA < 0, fixB = trk.modeB < 0;
+    // damped system Hl = H, diag *= (1+lambda); rhs = -b          (CoarseTracker.cpp:601-602, 639)
+    double m = (r == c) ? hv * (1 + lambda) : hv;
+    double dv = -bv;
+    if (fixA && !fixB) {
+      // stitch b's row/col into slot 6 and drop slot 7 (CoarseTracker.cpp:653-664)
+      const int sr = (r == 6) ? 7 : r, sc = (c == 6) ? 7 : c;
+      m = __shfl(m, sr * 8 + sc, 64);
+      dv = __shfl(dv, sr * 8 + c, 64);
+    }
+    const int nact = (fixA && fixB) ? 6 : ((fixA || fixB) ? 7 : 8);
+    if (r >= nact || c >= nact) { m = (r == c) ? 1.0 : 0.0; }
+    if (r >= nact) dv = 0.0;
+    double x = waveLdltSolve8(m, dv, lane);
+    if (fixA && !fixB) {
+      // inc[7] = incStitch[6]; inc[6] = 0
+      const double x6 = __shfl(x, 6 * 8, 64);
+      x = (r == 7) ? x6 : ((r == 6) ? 0.0 : x);
+    }
+    if (c == 0) s_x[r] = x;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  if (lane == 0) {
+    if (action == ACT_SOLVE) {
+      float extrapFac = 1;
+      if (S.lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / S.lambda));
+      double inc[8], incScaled[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) inc[i] = s_x[i] * extrapFac;
+#pragma unroll
+      for (int i = 0; i < 6; i++) incScaled[i] = inc[i] * 1.0f;  // SCALE_XI_ROT / SCALE_XI_TRANS
+      incScaled[6] = inc[6] * 10.0f;                               // SCALE_A
+      incScaled[7] = inc[7] * 1000.0f;                             // SCALE_B
+      double ssum = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) ssum += incScaled[i];
+      if (!isfinite(ssum)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) incScaled[i] = 0;
+      }
+      S.nxt = poseMul(poseExp(incScaled), S.cur);
+      S.affA_n = S.affA + incScaled[6];
+      S.affB_n = S.affB + incScaled[7];
+      double nn = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) nn += inc[i] * inc[i];
+      S.incNorm = sqrt(nn);
+      makeEvalP(trk, S.lvl, S.nxt, S.affA_n, S.affB_n, in.new_exposure, trk.coarseCutoffTH * S.cutoffRepeat, s_e);
+      S.st = LM_ITER_EVAL;
+    } else if (action == ACT_EVAL_CUR) {
+      makeEvalP(trk, S.lvl, S.cur, S.affA, S.affB, in.new_exposure, trk.coarseCutoffTH * S.cutoffRepeat, s_e);
+    }
+    if (action != ACT_DONE) { S.nEvals++; S.nPointEvals += trk.pc_n[S.lvl]; }
+  }
+  return action != ACT_DONE;
 }
 
 template <int T>
@@ -377,9 +500,9 @@ __global__ void __launch_bounds__(T) k_track_lm(const TrackerDev trk, const Fram
   __shared__ float s_part[T / 64][ACC_PAD];
   __shared__ float s_tot[ACC_PAD];
   __shared__ EvalP s_e;
-  __shared__ double s_H[64], s_b[8], s_Hl[64];
+  __shared__ double s_H[64], s_b[8], s_x[8];
   __shared__ int s_go;
-  __shared__ LMState S;  // touched by thread 0 only; kept in LDS so it costs no VGPRs during evaluations
+  __shared__ LMState S;  // written by lane 0 of wave 0 only
   const LMProblemIn& pin = in[blockIdx.x];
   LMProblemOut& pout = out[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -387,32 +510,38 @@ __global__ void __launch_bounds__(T) k_track_lm(const TrackerDev trk, const Fram
     S.affA = pin.aff[0]; S.affB = pin.aff[1];
     for (int i = 0; i < 5; i++) S.lastRes[i] = __builtin_nan("");
     for (int i = 0; i < 3; i++) S.flow[i] = 1000;
-    S.lvl = coarsestLvl; S.st = LM_LEVEL_BEGIN; S.totalIts = 0; S.nEvals = 0; S.nPointEvals = 0; S.haveRepeated = false;
+    S.lvl = coarsestLvl; S.st = LM_LEVEL_BEGIN; S.totalIts = 0; S.nEvals = 0; S.nPointEvals = 0; S.haveRepeated = 0;
     S.iteration = 0; S.lambda = 0.01f; S.cutoffRepeat = 1; S.incNorm = 0;
-    for (int i = 0; i < 64; i++) s_H[i] = 0;
-    for (int i = 0; i < 8; i++) s_b[i] = 0;
   }
+  if (threadIdx.x < 64) { s_H[threadIdx.x] = 0; if (threadIdx.x < 8) { s_b[threadIdx.x] = 0; s_x[threadIdx.x] = 0; } }
+  __syncthreads();
   const int slot = pin.new_slot;
+  long long tStep = 0, tEval = 0;
   for (;;) {
-    if (threadIdx.x == 0) {
-      const bool go = lmAdvance(S, trk, pin, pout, s_tot, s_H, s_b, s_Hl, &s_e);
-      if (go) { S.nEvals++; S.nPointEvals += trk.pc_n[s_e.lvl]; }
-      s_go = go ? 1 : 0;
+    const long long t0 = wall_clock64();
+    if (threadIdx.x < 64) {
+      const bool go = lmWaveStep(S, trk, pin, pout, s_tot, s_H, s_b, s_x, s_e, threadIdx.x);
+      if (threadIdx.x == 0) s_go = go ? 1 : 0;
     }
     __syncthreads();
+    const long long t1 = wall_clock64();
+    tStep += t1 - t0;
     if (!s_go) break;
     const int lvl = s_e.lvl;
     blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], threadIdx.x, T, fs.level(slot, lvl), trk.huberTH, s_part, s_tot);
+    tEval += wall_clock64() - t1;
   }
   if (threadIdx.x == 0) {
     for (int i = 0; i < 5; i++) pout.lastRes[i] = S.lastRes[i];
     for (int i = 0; i < 3; i++) pout.flow[i] = S.flow[i];
-    for (int i = 0; i < 64; i++) pout.H[i] = s_H[i];
-    for (int i = 0; i < 8; i++) pout.b[i] = s_b[i];
     pout.iterations = S.totalIts;
     pout.n_evals = S.nEvals;
     pout.n_point_evals = S.nPointEvals;
+    pout.ticks_step = tStep;
+    pout.ticks_eval = tEval;
   }
+  if (threadIdx.x < 64) pout.H[threadIdx.x] = s_H[threadIdx.x];
+  if (threadIdx.x < 8) pout.b[threadIdx.x] = s_b[threadIdx.x];
 }
 
 }  // namespace dmv

@@ -108,6 +108,9 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* trk, double* pose7_ou
 /* Work counters of the last batch launch: evals (calcRes+calcGS passes) and point-evaluations
  * (sum over evals of pc_n[lvl]) — the unit count behind the roofline's algorithmic bytes. */
 int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long long* n_point_evals);
+/* In-kernel time split of the last batch launch, summed over problems, in 100 MHz wall_clock64 ticks:
+ * LM control steps (solve, pose update, bookkeeping) vs evaluations (calcRes+calcGS). Diagnostics only. */
+int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* trk, long long* ticks_step, long long* ticks_eval);
 
 #ifdef __cplusplus
 }
