@@ -62,7 +62,7 @@ def pose7_to_Rt(p):
 class PlaneWorld:
     """Two textured planes: a slanted wall  n1.X = d1  and a floor  n2.X = d2  (camera y points down)."""
 
-    def __init__(self, seed=SEED, n_waves=24, depth=4.0):
+    def __init__(self, seed=SEED, n_waves=24, depth=4.0, fmax=22.0):
         rng = np.random.RandomState(seed)
         n1 = np.array([-0.25, 0.05, 1.0]); n1 /= np.linalg.norm(n1)
         n2 = np.array([0.0, 1.0, 0.08]); n2 /= np.linalg.norm(n2)
@@ -75,7 +75,7 @@ class PlaneWorld:
             self.bases.append((a, b))
         self.waves = []
         for _ in self.planes:
-            f = np.exp(rng.uniform(np.log(0.8), np.log(22.0), n_waves))      # rad / m
+            f = np.exp(rng.uniform(np.log(min(0.8, fmax / 4)), np.log(fmax), n_waves))      # rad / m
             ang = rng.uniform(0, np.pi, n_waves)
             amp = rng.uniform(4.0, 20.0, n_waves) / np.sqrt(np.maximum(f, 1.0)) * 2.2
             ph = rng.uniform(0, 2 * np.pi, n_waves)
@@ -125,13 +125,13 @@ def select_points(img, n, rng, border=4, min_grad=8.0):
 
 
 def tracking_case(w=512, h=512, n_ref=2000, seed=SEED, xi_true=(0.03, -0.02, 0.04, 0.01, -0.015, 0.008),
-                  aff_new=(0.0, 0.0), n_frames=1, xi_jitter=0.0):
+                  aff_new=(0.0, 0.0), n_frames=1, xi_jitter=0.0, fmax=22.0, min_grad=8.0):
     """Config-2 style case: reference KF at identity with n_ref points of exact idepth; new frame(s) at xi_true."""
-    world = PlaneWorld(seed)
+    world = PlaneWorld(seed, fmax=fmax)
     K4 = default_intrinsics(w, h)
     rng = np.random.RandomState(seed + 1)
     ref_img, ref_id = world.render(K4, np.eye(3), np.zeros(3), w, h)
-    u, v = select_points(ref_img, n_ref, rng)
+    u, v = select_points(ref_img, n_ref, rng, min_grad=min_grad)
     idepth = ref_id[v.astype(int), u.astype(int)].astype(np.float32)
     frames = []
     for k in range(n_frames):

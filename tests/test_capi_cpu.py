@@ -1,0 +1,48 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU, exports every symbol
+include/dmvio_hip.h declares, and the product path refuses to run without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    syms = pkg.declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_header_cites_reference_lines(pkg):
+    txt = open(pkg.INCLUDE_PATH).read()
+    assert len(re.findall(r"\.(?:cpp|h):\d+", txt)) >= 15, "every entry point names the reference interface it replaces"
+
+
+def test_code_object_is_gfx950_only(pkg):
+    blob = open(pkg.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"sm_90"):
+        assert other not in blob
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    lib = pkg.load_library()
+    if lib.dmvio_hip_device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device refusal is exercised on the CPU box")
+    with pytest.raises(pkg.HipLibraryError):
+        pkg.Context(64, 64, 2)
+    lib.dmvio_hip_create.restype = ctypes.c_void_p
+    assert not lib.dmvio_hip_create(0, 64, 64, 2)
+    assert lib.dmvio_hip_last_error()
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under dm-vio_amd/ may reference it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, files in os.walk(os.path.join(root, "dm-vio_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("see oracle/", ""), os.path.join(dp, f)
