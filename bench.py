@@ -158,7 +158,7 @@ def main():
             ev0.record(stream); ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes); ev1.record(stream)
             ev1.synchronize(); pms.append(ev0.elapsed_time(ev1))
         pm = float(np.mean(pms))
-        pyr_bytes = B * (4 * w * h + sum(16 * (w >> l) * (h >> l) for l in range(ctx.levels)))
+        pyr_bytes = B * (4 * w * h + sum(4 * (w >> l) * (h >> l) for l in range(ctx.levels)))  # read raw + write every level plane
         roofline["pyramid_kernel_ms"] = round(pm, 4)
         roofline["pyramid_GBps"] = round(pyr_bytes / (pm * 1e-3) / 1e9, 1)
 

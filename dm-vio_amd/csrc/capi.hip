@@ -34,13 +34,10 @@ struct dmvio_hip_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   FrameStore fs{};
-  float* d_planar[DMV_MAX_LEVELS] = {};
-  float* d_f3 = nullptr;  // download scratch (w*h*3)
+  float* d_upload = nullptr;  // staging for host uploads (w*h)
+  float* d_f3 = nullptr;      // download scratch (w*h*3)
+  PyrGeom pg{};
   int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
-  // batched pyramid scratch: per frame the planar intensities of levels >= 1
-  float* d_planar_batch = nullptr;
-  size_t planar_batch_stride = 0, planar_lvl_off[DMV_MAX_LEVELS] = {};
-  int planar_batch_cap = 0;
   int *d_slots = nullptr, *h_slots = nullptr;
   int slots_cap = 0, slots_valid = 0;
   std::mutex mu;
@@ -53,7 +50,9 @@ struct dmvio_hip_tracker {
   RefLevels R{};
   int n_tiles = 0;
   float *d_idp = nullptr, *d_wsp = nullptr, *d_idp2 = nullptr, *d_wsp2 = nullptr, *d_dense = nullptr;
-  int *d_tile_count = nullptr, *d_tile_base = nullptr, *d_pc_n = nullptr;
+  int *d_tile_count = nullptr, *d_tile_base = nullptr, *d_pc_n = nullptr, *d_seg = nullptr;
+  unsigned long long* d_flow_mask = nullptr;
+  size_t flow_words = 0;
   float4* d_pc[DMV_MAX_LEVELS] = {};
   float4** d_pc_ptrs = nullptr;
   float* d_pts = nullptr;
@@ -64,7 +63,7 @@ struct dmvio_hip_tracker {
   LMProblemOut *d_out = nullptr, *h_out = nullptr;
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
-  int lm_threads_override = 0;
+  int lm_threads_override = 0, lm_waves_override = 0;
 };
 
 extern "C" {
@@ -102,9 +101,12 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   c->fs.levels = c->levels;
   c->fs.slot_stride = (off + 63) & ~(size_t)63;
   HIPCHKP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHKP(hipMalloc((void**)&c->fs.base, sizeof(float4) * c->fs.slot_stride * n_frame_slots));
-  HIPCHKP(hipMemsetAsync(c->fs.base, 0, sizeof(float4) * c->fs.slot_stride * n_frame_slots, c->stream));
-  for (int l = 0; l < c->levels; l++) HIPCHKP(hipMalloc((void**)&c->d_planar[l], sizeof(float) * c->wl[l] * c->hl[l]));
+  HIPCHKP(hipMalloc((void**)&c->fs.base, sizeof(float) * c->fs.slot_stride * n_frame_slots));
+  HIPCHKP(hipMemsetAsync(c->fs.base, 0, sizeof(float) * c->fs.slot_stride * n_frame_slots, c->stream));
+  HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
+  c->pg.levels = c->levels;
+  for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
+  c->pg.tiles_x = (w + 31) / 32; c->pg.tiles_y = (h + 31) / 32;
   HIPCHKP(hipMalloc((void**)&c->d_f3, sizeof(float) * 3 * w * h));
   HIPCHKP(hipStreamSynchronize(c->stream));
   return c;
@@ -115,9 +117,9 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipFree(c->fs.base);
-  for (int l = 0; l < c->levels; l++) hipFree(c->d_planar[l]);
+  hipFree(c->d_upload);
   hipFree(c->d_f3);
-  hipFree(c->d_planar_batch); hipFree(c->d_slots);
+  hipFree(c->d_slots);
   if (c->h_slots) hipHostFree(c->h_slots);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -148,14 +150,8 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
 
 // ------------------------------------------------------------------ frames
 static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
-  const float* Il = d_color;
-  for (int l = 0; l < c->levels; l++) {
-    const int n = c->wl[l] * c->hl[l];
-    float* next = (l + 1 < c->levels) ? c->d_planar[l + 1] : nullptr;
-    const int blocks = std::min((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_make_level, dim3(blocks), dim3(256), 0, c->stream, Il, c->wl[l], c->hl[l], c->fs.level_mut(slot, l), next);
-    Il = next;
-  }
+  hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, 1), dim3(256), 0, c->stream, d_color, (size_t)0, c->pg, c->fs,
+                     (const int*)nullptr, slot);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -165,8 +161,8 @@ int dmvio_hip_frame_upload(dmvio_hip_ctx* c, int slot, const float* host) {
   if (slot < 0 || slot >= c->n_slots) return failmsg("frame_upload: slot out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpyAsync(c->d_planar[0], host, sizeof(float) * c->w * c->h, hipMemcpyHostToDevice, c->stream));
-  if (int r = buildPyramid(c, slot, c->d_planar[0])) return r;
+  HIPCHK(hipMemcpyAsync(c->d_upload, host, sizeof(float) * c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  if (int r = buildPyramid(c, slot, c->d_upload)) return r;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -190,14 +186,6 @@ int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots
     HIPCHK(hipMalloc((void**)&c->d_slots, sizeof(int) * c->slots_cap));
     HIPCHK(hipHostMalloc((void**)&c->h_slots, sizeof(int) * c->slots_cap, hipHostMallocDefault));
   }
-  if (B > c->planar_batch_cap && c->levels > 1) {
-    if (c->d_planar_batch) HIPCHK(hipFree(c->d_planar_batch));
-    size_t off = 0;
-    for (int l = 1; l < c->levels; l++) { c->planar_lvl_off[l] = off; off += (size_t)c->wl[l] * c->hl[l]; }
-    c->planar_batch_stride = off;
-    c->planar_batch_cap = std::max(B, 64);
-    HIPCHK(hipMalloc((void**)&c->d_planar_batch, sizeof(float) * off * c->planar_batch_cap));
-  }
   bool same = (B == c->slots_valid);
   for (int i = 0; i < B; i++) {
     if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frames_from_device_batch: slot out of range");
@@ -210,15 +198,8 @@ int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots
     HIPCHK(hipMemcpyAsync(c->d_slots, c->h_slots, sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
     c->slots_valid = B;
   }
-  for (int l = 0; l < c->levels; l++) {
-    const int n = c->wl[l] * c->hl[l];
-    const float* in = (l == 0) ? dev_base : c->d_planar_batch + c->planar_lvl_off[l];
-    const size_t in_stride = (l == 0) ? stride_bytes / sizeof(float) : c->planar_batch_stride;
-    float* next = (l + 1 < c->levels) ? c->d_planar_batch + c->planar_lvl_off[l + 1] : nullptr;
-    const int bx = std::max(1, std::min((n + 255) / 256, 64));
-    hipLaunchKernelGGL(k_make_level_batch, dim3(bx, B), dim3(256), 0, c->stream, in, in_stride, c->wl[l], c->hl[l], c->fs, c->d_slots, l,
-                       next, c->planar_batch_stride);
-  }
+  hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
+                     c->pg, c->fs, (const int*)c->d_slots, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -229,7 +210,7 @@ int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   const int n = c->wl[lvl] * c->hl[lvl];
-  hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(slot, lvl), n, c->d_f3);
+  hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, c->d_f3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -251,10 +232,17 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   for (int l = 0; l < c->levels; l++) {
     R.w[l] = c->wl[l]; R.h[l] = c->hl[l]; R.off[l] = off; R.tile_off[l] = tiles;
     off += (size_t)R.w[l] * R.h[l];
-    tiles += (R.w[l] * R.h[l] + 255) / 256;
+    R.blocks_x[l] = (R.w[l] + 15) / 16;
+    tiles += R.blocks_x[l] * ((R.h[l] + 15) / 16);
     t->dev.g[l].w = R.w[l]; t->dev.g[l].h = R.h[l];
   }
   R.tile_off[c->levels] = tiles; R.total = off; t->n_tiles = tiles;
+  R.seg_x0 = (R.w[0] + 7) / 8;
+  t->flow_words = ((size_t)R.w[0] * R.h[0] + 63) / 64;
+  HIPCHKP(hipMalloc((void**)&t->d_seg, sizeof(int) * R.seg_x0 * R.h[0]));
+  HIPCHKP(hipMalloc((void**)&t->d_flow_mask, sizeof(unsigned long long) * t->flow_words));
+  HIPCHKP(hipMemset(t->d_flow_mask, 0, sizeof(unsigned long long) * t->flow_words));
+  t->dev.flow_mask = t->d_flow_mask;
   HIPCHKP(hipMalloc((void**)&t->d_idp, sizeof(float) * off));
   HIPCHKP(hipMalloc((void**)&t->d_wsp, sizeof(float) * off));
   HIPCHKP(hipMalloc((void**)&t->d_idp2, sizeof(float) * off));
@@ -270,6 +258,7 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   HIPCHKP(hipMalloc((void**)&t->d_tot, sizeof(float) * ACC_PAD));
   HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * ACC_PAD, hipHostMallocDefault));
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
+  if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);
   return t;
 }
 
@@ -278,7 +267,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
-  hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n);
+  hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
   hipHostFree(t->h_tot);
@@ -350,9 +339,11 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
     hipLaunchKernelGGL(k_ref_pool, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, s, R, t->d_idp, t->d_wsp);
   }
   hipLaunchKernelGGL(k_ref_dilate, dim3((unsigned)((R.total + 255) / 256)), dim3(256), 0, s, R, t->d_idp, t->d_wsp, t->d_idp2, t->d_wsp2);
-  hipLaunchKernelGGL(k_ref_count, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_count);
-  hipLaunchKernelGGL(k_ref_scan, dim3(R.levels), dim3(1024), 0, s, R, t->d_tile_count, t->d_tile_base, t->d_pc_n);
-  hipLaunchKernelGGL(k_ref_write, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_base, t->d_pc_ptrs, t->d_dense);
+  HIPCHK(hipMemsetAsync(t->d_flow_mask, 0, sizeof(unsigned long long) * t->flow_words, s));
+  hipLaunchKernelGGL(k_ref_count, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_count, t->d_seg);
+  hipLaunchKernelGGL(k_ref_scan, dim3(R.levels + 1), dim3(1024), 0, s, R, t->d_tile_count, t->d_tile_base, t->d_pc_n, t->d_seg);
+  hipLaunchKernelGGL(k_ref_write, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_base, t->d_seg, t->d_pc_ptrs,
+                     t->d_dense, t->d_flow_mask);
   HIPCHK(hipGetLastError());
   int pcn[DMV_MAX_LEVELS] = {};
   HIPCHK(hipMemcpyAsync(pcn, t->d_pc_n, sizeof(int) * R.levels, hipMemcpyDeviceToHost, s));
@@ -377,6 +368,8 @@ int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* t, int lvl, float* u, float* v, 
   std::vector<float4> tmp(n);
   HIPCHK(hipMemcpyAsync(tmp.data(), t->d_pc[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  // the device keeps the template in tile order; hand it out in the reference's row-major order (y, then x)
+  std::sort(tmp.begin(), tmp.end(), [](const float4& a, const float4& b) { return a.y < b.y || (a.y == b.y && a.x < b.x); });
   for (int i = 0; i < n; i++) { u[i] = tmp[i].x; v[i] = tmp[i].y; idepth[i] = tmp[i].z; color[i] = tmp[i].w; }
   return 0;
 }
@@ -444,12 +437,19 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
   const int B = t->staged_B;
-  int T = t->lm_threads_override ? t->lm_threads_override : (B <= 256 ? 1024 : (B <= 1024 ? 512 : 256));
-  if (T == 1024) hipLaunchKernelGGL(k_track_lm<1024>, dim3(B), dim3(1024), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
-  else if (T == 512) hipLaunchKernelGGL(k_track_lm<512>, dim3(B), dim3(512), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
-  else if (T == 256) hipLaunchKernelGGL(k_track_lm<256>, dim3(B), dim3(256), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
-  else if (T == 128) hipLaunchKernelGGL(k_track_lm<128>, dim3(B), dim3(128), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest);
+  // workgroup size: one problem per workgroup.  Few problems -> wide workgroups (latency); many -> narrow ones (more
+  // problems resident per CU).  Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES.
+  const int T = t->lm_threads_override ? t->lm_threads_override : (B <= 128 ? 1024 : 256);
+  const int W = t->lm_waves_override ? t->lm_waves_override : 4;
+#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest)
+  if (T == 1024) DMV_LAUNCH_LM(1024, 4);
+  else if (T == 512 && W >= 6) DMV_LAUNCH_LM(512, 6);
+  else if (T == 512) DMV_LAUNCH_LM(512, 4);
+  else if (T == 256 && W >= 6) DMV_LAUNCH_LM(256, 6);
+  else if (T == 256) DMV_LAUNCH_LM(256, 4);
+  else if (T == 128) DMV_LAUNCH_LM(128, 4);
   else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024");
+#undef DMV_LAUNCH_LM
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -14,15 +14,17 @@ struct LevelGeom {
   float Ki[9];
 };
 
-// Resident image pyramids: every frame slot holds all levels back to back as float4 (I, dx, dy, 0):
-// one 16-byte aligned load per bilinear tap (the reference's Eigen::Vector3f AoS is 12 B / pixel).
+// Resident image pyramids: every frame slot holds the INTENSITY plane of all levels back to back (float, 4 B/px).
+// The reference materialises (I, dx, dy) as Eigen::Vector3f per pixel (HessianBlocks.cpp:128-191); here the
+// central-difference gradients are recomputed from the 4x4 intensity neighbourhood at every tap — bit-identical
+// values (same fp32 operations), 4x less pyramid traffic and footprint, whole pyramids stay L2-resident.
 struct FrameStore {
-  float4* base;          // n_slots * slot_stride float4
-  size_t slot_stride;    // float4 elements per slot
+  float* base;           // n_slots * slot_stride floats
+  size_t slot_stride;    // floats per slot
   size_t level_off[DMV_MAX_LEVELS];
   int levels;
-  __host__ __device__ const float4* level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
-  __host__ __device__ float4* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
+  __host__ __device__ const float* level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
+  __host__ __device__ float* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };
 
 // Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one
@@ -32,6 +34,9 @@ struct TrackerDev {
   LevelGeom g[DMV_MAX_LEVELS];
   const float4* pc[DMV_MAX_LEVELS];
   int pc_n[DMV_MAX_LEVELS];
+  // level 0 only: bit j of word k set <=> template entry 64k+j is one of the reference's "every 32nd point in
+  // row-major order" flow-indicator samples (CoarseTracker.cpp:416); entries are stored in tile order.
+  const unsigned long long* flow_mask;
   float ref_exposure;
   double ref_aff_a, ref_aff_b;
   float huberTH, coarseCutoffTH, modeA, modeB;

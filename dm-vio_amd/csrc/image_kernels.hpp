@@ -1,79 +1,94 @@
-// Image pyramid + gradients on the device.
-// Replaces FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:128-191): 2x2 box pyramid
-// (0.25f * ((a+b)+c)+d, the reference's operand order) and central-difference gradients over the flat
-// index range [w, w*(h-1)) — including the reference's row wrap-around at x=0 / x=w-1.
-// Output layout: float4 (I, dx, dy, 0) per pixel per level (common.h FrameStore).  Rows 0 and h-1
-// (never written by the reference) carry dx=dy=0.  absSquaredGrad (pixel selector only) is not produced.
+// Image pyramid on the device.
+// Replaces FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:128-191).  Only the intensity plane of
+// every level is stored (common.h FrameStore); level l+1 = 0.25f * (((a+b)+c)+d) of the 2x2 block of level l, in the
+// reference's operand order, so every level is bit-identical to the reference's dIp[l][.][0].  The gradient channels
+// dIp[l][.][1..2] are central differences of that plane over the flat index range [w, w*(h-1)) and are recomputed
+// where they are consumed (gradAt below = the reference's formula incl. its isfinite guard); absSquaredGrad (pixel
+// selector only) is not produced.
+//
+// One launch builds ALL levels of B frames: a workgroup owns a 32x32 level-0 tile, keeps the successive 2x2
+// reductions in LDS (32x32 -> 16x16 -> ... -> 1x1) and streams each level out.  HBM traffic per frame:
+// read 4 B/px + write 4 B/px * (1 + 1/4 + 1/16 + ...).
 #pragma once
 #include "common.h"
 
 namespace dmv {
 
-// One launch per level: reads planar intensity of level l (Il), writes the float4 level image and the
-// planar intensity of level l+1 (Inext, may be null on the coarsest level).  Pure streaming kernel.
-__global__ void __launch_bounds__(256) k_make_level(const float* __restrict__ Il, const int w, const int h,
-                                                     float4* __restrict__ out, float* __restrict__ Inext) {
-  const int n = w * h;
-  const int stride = gridDim.x * blockDim.x;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-    const float I = Il[idx];
-    float dx = 0.0f, dy = 0.0f;
-    if (idx >= w && idx < w * (h - 1)) {
-      dx = 0.5f * (Il[idx + 1] - Il[idx - 1]);
-      dy = 0.5f * (Il[idx + w] - Il[idx - w]);
-      if (!isfinite(dx)) dx = 0.0f;
-      if (!isfinite(dy)) dy = 0.0f;
-    }
-    out[idx] = make_float4(I, dx, dy, 0.0f);
-  }
-  if (Inext) {
-    const int w2 = w >> 1, h2 = h >> 1, n2 = w2 * h2;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n2; idx += stride) {
-      const int x = idx % w2, y = idx / w2;
-      const int b = 2 * x + 2 * y * w;
-      Inext[idx] = 0.25f * (Il[b] + Il[b + 1] + Il[b + w] + Il[b + w + 1]);
-    }
-  }
-}
+struct PyrGeom {
+  int levels;
+  int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
+  int tiles_x, tiles_y;  // 32x32 level-0 tiles
+};
 
-// Batched variant: blockIdx.y = frame of the batch.  in_base/in_stride address the planar intensity of level l of
-// frame f (raw images for l = 0, per-frame scratch above); slots[f] selects the destination pyramid.
-__global__ void __launch_bounds__(256) k_make_level_batch(const float* __restrict__ in_base, const size_t in_stride, const int w, const int h,
-                                                           const FrameStore fs, const int* __restrict__ slots, const int lvl,
-                                                           float* __restrict__ next_base, const size_t next_stride) {
+__global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
+                                                         const FrameStore fs, const int* __restrict__ slots, const int single_slot) {
+  __shared__ float s_a[32 * 32];
+  __shared__ float s_b[16 * 16];
   const int f = blockIdx.y;
-  const float* __restrict__ Il = in_base + (size_t)f * in_stride;
-  float4* __restrict__ out = fs.level_mut(slots[f], lvl);
-  const int n = w * h;
-  const int stride = gridDim.x * blockDim.x;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
-    const float I = Il[idx];
-    float dx = 0.0f, dy = 0.0f;
-    if (idx >= w && idx < w * (h - 1)) {
-      dx = 0.5f * (Il[idx + 1] - Il[idx - 1]);
-      dy = 0.5f * (Il[idx + w] - Il[idx - w]);
-      if (!isfinite(dx)) dx = 0.0f;
-      if (!isfinite(dy)) dy = 0.0f;
+  const int slot = slots ? slots[f] : single_slot;
+  const float* __restrict__ src = in_base + (size_t)f * in_stride;
+  const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
+  const int w0 = G.w[0], h0 = G.h[0];
+  const int x0 = tx * 32, y0 = ty * 32;
+  // level 0: 256 threads x 4 consecutive pixels
+  {
+    const int lx = (threadIdx.x & 7) * 4, ly = threadIdx.x >> 3;
+    const int x = x0 + lx, y = y0 + ly;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* __restrict__ dst = fs.level_mut(slot, 0);
+    if (y < h0) {
+      if (x + 3 < w0) {
+        __builtin_memcpy(&v, src + (size_t)y * w0 + x, 16);
+        __builtin_memcpy(dst + (size_t)y * w0 + x, &v, 16);
+      } else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; k++)
+          if (x + k < w0) { t[k] = src[(size_t)y * w0 + x + k]; dst[(size_t)y * w0 + x + k] = t[k]; }
+        v = make_float4(t[0], t[1], t[2], t[3]);
+      }
     }
-    out[idx] = make_float4(I, dx, dy, 0.0f);
+    s_a[ly * 32 + lx + 0] = v.x; s_a[ly * 32 + lx + 1] = v.y; s_a[ly * 32 + lx + 2] = v.z; s_a[ly * 32 + lx + 3] = v.w;
   }
-  if (next_base) {
-    float* __restrict__ Inext = next_base + (size_t)f * next_stride;
-    const int w2 = w >> 1, h2 = h >> 1, n2 = w2 * h2;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n2; idx += stride) {
-      const int x = idx % w2, y = idx / w2;
-      const int b = 2 * x + 2 * y * w;
-      Inext[idx] = 0.25f * (Il[b] + Il[b + 1] + Il[b + w] + Il[b + w + 1]);
+  __syncthreads();
+  float* cur = s_a;
+  float* nxt = s_b;
+  int side = 32;
+  for (int l = 1; l < G.levels; l++) {
+    const int ns = side >> 1;
+    if ((int)threadIdx.x < ns * ns) {
+      const int lx = threadIdx.x % ns, ly = threadIdx.x / ns;
+      const int b = 2 * lx + 2 * ly * side;
+      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + side] + cur[b + side + 1]);
+      nxt[ly * ns + lx] = val;
+      const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
+      if (x < G.w[l] && y < G.h[l]) fs.level_mut(slot, l)[(size_t)y * G.w[l] + x] = val;
     }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+    side = ns;
   }
 }
 
-// float4 level image -> the reference's float3 AoS (parity tests / debug download)
-__global__ void __launch_bounds__(256) k_level_to_f3(const float4* __restrict__ in, const int n, float* __restrict__ out) {
+// dIp[lvl][idx][1], [2] of the reference at pixel (x, y) of a level plane: central differences with the reference's
+// flat-index range (rows 1..h-2) and isfinite guard (HessianBlocks.cpp:172-181).
+__device__ __forceinline__ float2 gradAt(const float* __restrict__ I, const int w, const int h, const int x, const int y) {
+  const int idx = x + y * w;
+  float dx = 0.f, dy = 0.f;
+  if (idx >= w && idx < w * (h - 1)) {
+    dx = 0.5f * (I[idx + 1] - I[idx - 1]);
+    dy = 0.5f * (I[idx + w] - I[idx - w]);
+    if (!isfinite(dx)) dx = 0.f;
+    if (!isfinite(dy)) dy = 0.f;
+  }
+  return make_float2(dx, dy);
+}
+
+// level plane -> the reference's Eigen::Vector3f AoS (I, dx, dy)   (parity tests / debug download)
+__global__ void __launch_bounds__(256) k_level_to_f3(const float* __restrict__ I, const int w, const int h, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n) {
-    const float4 p = in[idx];
-    out[3 * idx + 0] = p.x; out[3 * idx + 1] = p.y; out[3 * idx + 2] = p.z;
+  if (idx < w * h) {
+    const float2 g = gradAt(I, w, h, idx % w, idx / w);
+    out[3 * idx + 0] = I[idx]; out[3 * idx + 1] = g.x; out[3 * idx + 2] = g.y;
   }
 }
 

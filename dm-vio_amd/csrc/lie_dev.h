@@ -12,6 +12,44 @@
 
 namespace dmv {
 
+// ---- small-footprint fp64 elementary functions -------------------------------------------------------------
+// The device libm's double sin/cos/exp carry a Payne-Hanek / double-double path that costs >150 VGPRs; since the LM
+// control step shares its kernel with the evaluation loop, that footprint would halve the occupancy of every wave.
+// These are the classic fdlibm kernels (Sun Microsystems' freely distributable libm: k_sin.c, k_cos.c, e_exp.c) with a
+// Cody-Waite reduction — ~1 ulp for the |x| < 1e5 arguments that occur here (rotation increments, affine exponents).
+// The same code runs on the host side of the C ABI, so host-driven and device-resident paths agree bit for bit.
+DMV_HD void dsincos(const double x, double* sn, double* cs) {
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+  const double n = rint(x * invpio2);
+  double r = x - n * pio2_1;
+  r = r - n * pio2_1t;
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double ks = r + (r * z) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+  const double kc = 1.0 - 0.5 * z + (z * z) * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const int q = ((int)(long long)n) & 3;
+  const double s0 = (q & 1) ? kc : ks, c0 = (q & 1) ? ks : kc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+DMV_HD double dexp(const double x) {
+  if (!(x < 709.0)) return x != x ? x : __builtin_huge_val();
+  if (x < -745.0) return 0.0;
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  const double k = rint(invln2 * x);
+  const double hi = x - k * ln2HI, lo = k * ln2LO;
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return ldexp(y, (int)k);
+}
+
 struct Quatd { double w, x, y, z; };
 struct Pose { Quatd q; double t[3]; };
 
@@ -59,8 +97,10 @@ DMV_HD Pose poseExp(const double a[6]) {
     imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * p4;
     real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * p4;
   } else {
-    imag = sin(0.5 * theta) / theta;
-    real = cos(0.5 * theta);
+    double sh, ch;
+    dsincos(0.5 * theta, &sh, &ch);
+    imag = sh / theta;
+    real = ch;
   }
   Quatd q = {real, imag * ox, imag * oy, imag * oz};
   r.q = qnormalize(q);
@@ -69,8 +109,10 @@ DMV_HD Pose poseExp(const double a[6]) {
   if (theta < 1e-10) {
     quatToR(r.q, V);
   } else {
-    const double c1 = (1.0 - cos(theta)) / theta_sq;
-    const double c2 = (theta - sin(theta)) / (theta_sq * theta);
+    double sth, cth;
+    dsincos(theta, &sth, &cth);
+    const double c1 = (1.0 - cth) / theta_sq;
+    const double c2 = (theta - sth) / (theta_sq * theta);
     const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
     double O2[9];
     for (int i = 0; i < 3; i++)
@@ -105,7 +147,7 @@ DMV_HD void poseTo7(const Pose& T, double p[7]) {
 // AffLight::fromToVecExposure (src/dso/util/NumType.h:174-186)
 DMV_HD void affFromTo(float exposureF, float exposureT, double aF, double bF, double aT, double bT, double out[2]) {
   if (exposureF == 0 || exposureT == 0) { exposureT = exposureF = 1; }
-  const double a = exp(aT - aF) * exposureT / exposureF;
+  const double a = dexp(aT - aF) * exposureT / exposureF;
   out[0] = a;
   out[1] = bT - a * bF;
 }

@@ -3,9 +3,12 @@
 //   scatter of weighted inverse depths (:144-161), 2x2 sum-pool down the pyramid (:164-189),
 //   1-pixel dilation — diagonal neighbours on levels 0/1 (:193-220), 4-neighbourhood above (:224-245) —
 //   normalisation and row-major compaction into pc_u/pc_v/pc_idepth/pc_color (:249-293).
-// The compaction is an ORDERED stream compaction (tile counts -> exclusive scan -> ranked write), so the
-// template point order — which decides the every-32nd-point flow-indicator sample of calcRes — is the
-// reference's row-major order.
+// The compaction is an ORDERED (deterministic) stream compaction: counts -> exclusive scan -> ranked write.
+// Template points are emitted in TILE order (8x8-pixel tiles, Z-ordered inside 16x16 blocks, blocks row-major) rather
+// than the reference's row-major order: neighbouring lanes then tap neighbouring pixels, so the dilated 3x3 clusters
+// around each active point share cache lines.  Sums do not depend on the order; the one order-dependent rule of the
+// reference — flow indicators are sampled at every 32nd point of the ROW-MAJOR list (CoarseTracker.cpp:416) — is kept
+// exactly: each point's row-major rank is reconstructed from per-(row, tile) counts and stored as a bit mask.
 #pragma once
 #include "common.h"
 
@@ -15,7 +18,9 @@ struct RefLevels {
   int levels;
   int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
   size_t off[DMV_MAX_LEVELS];      // offset of the level inside the concatenated per-pixel float planes
-  int tile_off[DMV_MAX_LEVELS + 1];  // first tile of each level (tiles of 256 consecutive pixels)
+  int tile_off[DMV_MAX_LEVELS + 1];  // first 16x16 block of each level
+  int blocks_x[DMV_MAX_LEVELS];      // 16x16 blocks per row of the level
+  int seg_x0;                        // level 0: 8-pixel segments per row (row-major rank reconstruction)
   size_t total;                    // total pixels over all levels
 };
 
@@ -92,18 +97,18 @@ __global__ void __launch_bounds__(256) k_ref_dilate(const RefLevels R, const flo
   wsp2[idx] = ows;
 }
 
-// normalise; returns whether pixel li of level lvl becomes a template point, and its record
-__device__ __forceinline__ bool refPixel(const RefLevels& R, const int lvl, const int li, const float* __restrict__ idp2,
-                                         const float* __restrict__ wsp2, const float4* __restrict__ refImg, float4& rec, float& idOut) {
+// normalise; returns whether pixel (x,y) of level lvl becomes a template point, and its record
+__device__ __forceinline__ bool refPixel(const RefLevels& R, const int lvl, const int x, const int y, const float* __restrict__ idp2,
+                                         const float* __restrict__ wsp2, const float* __restrict__ refI, float4& rec, float& idOut) {
   const int wl = R.w[lvl], hl = R.h[lvl];
-  const int x = li % wl, y = li / wl;
+  const int li = x + y * wl;
   const float idv = idp2[R.off[lvl] + li];
   idOut = idv;
   if (!(x >= 2 && x < wl - 2 && y >= 2 && y < hl - 2)) return false;
   const float wsv = wsp2[R.off[lvl] + li];
   if (wsv > 0) {
     const float idn = idv / wsv;
-    const float color = refImg[li].x;
+    const float color = refI[li];
     if (!isfinite(color) || !(idn > 0)) { idOut = -1; return false; }
     idOut = idn;
     rec = make_float4((float)x, (float)y, idn, color);
@@ -113,73 +118,98 @@ __device__ __forceinline__ bool refPixel(const RefLevels& R, const int lvl, cons
   return false;
 }
 
-__device__ __forceinline__ void tileToLevel(const RefLevels& R, const int tile, int& lvl, int& li0) {
+// workgroup = one 16x16 pixel block; wave k = 8x8 tile (k&1, k>>1) of the block; lane = (lx = l&7, ly = l>>3)
+__device__ __forceinline__ void blockToPixel(const RefLevels& R, const int blk, int& lvl, int& x, int& y) {
   lvl = 0;
-  while (lvl + 1 < R.levels && tile >= R.tile_off[lvl + 1]) lvl++;
-  li0 = (tile - R.tile_off[lvl]) * 256;
+  while (lvl + 1 < R.levels && blk >= R.tile_off[lvl + 1]) lvl++;
+  const int b = blk - R.tile_off[lvl];
+  const int bx = b % R.blocks_x[lvl], by = b / R.blocks_x[lvl];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  x = bx * 16 + (wave & 1) * 8 + (lane & 7);
+  y = by * 16 + (wave >> 1) * 8 + (lane >> 3);
 }
 
-// pass 1: per-tile counts.  One workgroup (256 threads) per tile of 256 consecutive pixels.
+// pass 1: per-block counts (+ per (row, 8-px segment) counts on level 0)
 __global__ void __launch_bounds__(256) k_ref_count(const RefLevels R, const float* __restrict__ idp2, const float* __restrict__ wsp2,
-                                                    const FrameStore fs, const int ref_slot, int* __restrict__ tile_count) {
-  int lvl, li0;
-  tileToLevel(R, blockIdx.x, lvl, li0);
-  const int li = li0 + threadIdx.x;
+                                                    const FrameStore fs, const int ref_slot, int* __restrict__ blk_count, int* __restrict__ seg_count) {
+  int lvl, x, y;
+  blockToPixel(R, blockIdx.x, lvl, x, y);
   bool flag = false;
-  if (li < R.w[lvl] * R.h[lvl]) {
+  const bool inside = x < R.w[lvl] && y < R.h[lvl];
+  if (inside) {
     float4 rec; float idn;
-    flag = refPixel(R, lvl, li, idp2, wsp2, fs.level(ref_slot, lvl), rec, idn);
+    flag = refPixel(R, lvl, x, y, idp2, wsp2, fs.level(ref_slot, lvl), rec, idn);
   }
   __shared__ int s_cnt[4];
   const unsigned long long m = __ballot(flag);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  if (lvl == 0 && inside && (lane & 7) == 0) seg_count[y * R.seg_x0 + (x >> 3)] = __popcll((m >> (lane & 56)) & 0xffull);
   __syncthreads();
-  if (threadIdx.x == 0) tile_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// pass 2: exclusive scan of the tile counts of each level (one workgroup per level), pc_n[lvl]
-__global__ void __launch_bounds__(1024) k_ref_scan(const RefLevels R, const int* __restrict__ tile_count, int* __restrict__ tile_base, int* __restrict__ pc_n) {
-  const int lvl = blockIdx.x;
-  const int t0 = R.tile_off[lvl], t1 = R.tile_off[lvl + 1];
-  __shared__ int s_wave[16];
-  __shared__ int s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = t0; base < t1; base += 1024) {
-    const int t = base + threadIdx.x;
-    const int c = (t < t1) ? tile_count[t] : 0;
-    // inclusive scan inside the wave
-    int v = c;
+// block-wide exclusive scan helper over 1024 threads (value per thread) ; returns exclusive prefix, total via s_total
+__device__ __forceinline__ int scan1024(const int c, int* s_wave, int& total) {
+  int v = c;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(v, d, 64);
-      if ((threadIdx.x & 63) >= d) v += o;
-    }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); k++) woff += s_wave[k];
-    const int carry = s_carry;
-    if (t < t1) tile_base[t] = carry + woff + v - c;
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + woff + v;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) v += o;
   }
-  if (threadIdx.x == 0) pc_n[lvl] = s_carry;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int woff = 0, tot = 0;
+  for (int k = 0; k < 16; k++) { const int sv = s_wave[k]; if (k < (int)(threadIdx.x >> 6)) woff += sv; tot += sv; }
+  total = tot;
+  return woff + v - c;
 }
 
-// pass 3: ranked write of the template records + the dense normalised idepth map (debugPlotIDepthMap)
+// pass 2: blockIdx.x < levels: exclusive scan of the block counts of that level -> blk_base, pc_n[lvl].
+//         blockIdx.x == levels: level-0 row-major rank tables: seg_count -> exclusive prefix in row-major order (in place).
+__global__ void __launch_bounds__(1024) k_ref_scan(const RefLevels R, const int* __restrict__ blk_count, int* __restrict__ blk_base,
+                                                    int* __restrict__ pc_n, int* __restrict__ seg_count) {
+  __shared__ int s_wave[16];
+  int carry = 0;
+  if ((int)blockIdx.x < R.levels) {
+    const int lvl = blockIdx.x;
+    const int t0 = R.tile_off[lvl], t1 = R.tile_off[lvl + 1];
+    for (int base = t0; base < t1; base += 1024) {
+      const int t = base + threadIdx.x;
+      const int c = (t < t1) ? blk_count[t] : 0;
+      int total;
+      const int ex = scan1024(c, s_wave, total);
+      if (t < t1) blk_base[t] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0) pc_n[lvl] = carry;
+  } else {
+    const int n = R.h[0] * R.seg_x0;  // row-major (y, segment) order == raster order of the segments
+    for (int base = 0; base < n; base += 1024) {
+      const int t = base + threadIdx.x;
+      const int c = (t < n) ? seg_count[t] : 0;
+      int total;
+      const int ex = scan1024(c, s_wave, total);
+      if (t < n) seg_count[t] = carry + ex;
+      carry += total;
+    }
+  }
+}
+
+// pass 3: ranked write of the template records in tile order, the dense normalised idepth map (debugPlotIDepthMap)
+// and, on level 0, the flow-sample bit of every entry whose ROW-MAJOR rank is a multiple of 32.
 __global__ void __launch_bounds__(256) k_ref_write(const RefLevels R, const float* __restrict__ idp2, const float* __restrict__ wsp2,
-                                                    const FrameStore fs, const int ref_slot, const int* __restrict__ tile_base,
-                                                    float4* const* __restrict__ pc, float* __restrict__ idepth_dense) {
-  int lvl, li0;
-  tileToLevel(R, blockIdx.x, lvl, li0);
-  const int li = li0 + threadIdx.x;
+                                                    const FrameStore fs, const int ref_slot, const int* __restrict__ blk_base,
+                                                    const int* __restrict__ seg_prefix, float4* const* __restrict__ pc,
+                                                    float* __restrict__ idepth_dense, unsigned long long* __restrict__ flow_mask) {
+  int lvl, x, y;
+  blockToPixel(R, blockIdx.x, lvl, x, y);
   bool flag = false;
   float4 rec = make_float4(0, 0, 0, 0);
   float idn = -1;
-  const bool inside = li < R.w[lvl] * R.h[lvl];
-  if (inside) flag = refPixel(R, lvl, li, idp2, wsp2, fs.level(ref_slot, lvl), rec, idn);
+  const bool inside = x < R.w[lvl] && y < R.h[lvl];
+  if (inside) flag = refPixel(R, lvl, x, y, idp2, wsp2, fs.level(ref_slot, lvl), rec, idn);
   __shared__ int s_cnt[4];
   const unsigned long long m = __ballot(flag);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,9 +217,16 @@ __global__ void __launch_bounds__(256) k_ref_write(const RefLevels R, const floa
   __syncthreads();
   int woff = 0;
   for (int k = 0; k < wave; k++) woff += s_cnt[k];
-  const int rank = __popcll(m & ((1ull << lane) - 1ull));
-  if (flag) pc[lvl][tile_base[blockIdx.x] + woff + rank] = rec;
-  if (inside) idepth_dense[R.off[lvl] + li] = idn;
+  if (flag) {
+    const int pos = blk_base[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull));
+    pc[lvl][pos] = rec;
+    if (lvl == 0) {
+      const unsigned long long rowbits = (m >> (lane & 56)) & 0xffull;
+      const int raster = seg_prefix[y * R.seg_x0 + (x >> 3)] + __popcll(rowbits & ((1ull << (lane & 7)) - 1ull));
+      if ((raster & 31) == 0) atomicOr(&flow_mask[pos >> 6], 1ull << (pos & 63));
+    }
+  }
+  if (inside) idepth_dense[R.off[lvl] + x + y * R.w[lvl]] = idn;
 }
 
 }  // namespace dmv

@@ -10,10 +10,14 @@
 // Design (MI355X-first, not a translation):
 //   * calcRes and calcGS are ONE pass: the reference writes 8 "warped" SoA buffers and re-reads them
 //     in calcGSSSE; here the Jacobian row never leaves registers.  Algorithmic traffic per template
-//     point: 16 B point record + 4 taps x 12 B = 64 B.
-//   * per-thread register accumulators (52 sums), then a transposing wave64 butterfly (63 cross-lane
-//     exchanges for 64 values instead of 64 x 6), one LDS hop across waves — fixed summation order,
-//     bitwise reproducible run to run.
+//     point: 16 B point record + 4 taps x 12 B = 64 B (the kernel actually reads 16 B + a 48 B intensity
+//     neighbourhood and rebuilds the gradients, see interp33).
+//   * the 9x9 weighted outer-product reduction runs on the matrix cores (v_mfma_f32_16x16x4_f32, fp32 in /
+//     fp32 accumulate): per wave the 64 Jacobian rows are staged in LDS and consumed as a (9 x 64)(64 x 9)
+//     product, 4 accumulator registers per lane instead of 45.  The first version of this kernel kept 52
+//     register accumulators per lane (230 VGPRs, 2 waves/SIMD, latency bound — profiles/r01_*); the MFMA
+//     form is what buys the occupancy.  The 7 scalar statistics use a transposing wave64 butterfly.
+//     Fixed summation order, bitwise reproducible run to run.
 //   * the LM loop (8x8 pivoted LDLT in fp64, SE3 exp, accept/reject, lambda schedule, level logic)
 //     runs inside the same launch: one workgroup per alignment problem, thread 0 is a small state
 //     machine that asks the workgroup for evaluations.  B problems (pose hypotheses / frames) = B
@@ -27,39 +31,50 @@
 
 namespace dmv {
 
-__device__ __forceinline__ float3 interp33(const float4* __restrict__ img, float x, float y, int width) {
-  // getInterpolatedElement33 (src/dso/util/globalFuncs.h:103-118)
+// getInterpolatedElement33 (src/dso/util/globalFuncs.h:103-118) on an intensity-only plane: the four taps' gradient
+// channels are the central differences the reference stored in dIp[.][1..2] (HessianBlocks.cpp:172-181), rebuilt from the
+// 4x4 intensity neighbourhood: rows iy-1 (2 px), iy (4 px), iy+1 (4 px), iy+2 (2 px) = 48 B in four unaligned vector loads.
+// Callers guarantee 1 <= ix, ix+2 <= w-1, 1 <= iy, iy+2 <= h-1 (true for every in-bounds tap of tracker and BA).
+__device__ __forceinline__ float fin0(const float v) { return isfinite(v) ? v : 0.0f; }
+__device__ __forceinline__ float3 interp33(const float* __restrict__ img, const float x, const float y, const int width) {
   const int ix = (int)x, iy = (int)y;
   const float dx = x - ix, dy = y - iy;
   const float dxdy = dx * dy;
-  const float4* bp = img + ix + iy * width;
-  const float4 p00 = bp[0], p10 = bp[1], p01 = bp[width], p11 = bp[1 + width];
+  const float* bp = img + ix + iy * width;
+  float2 A, D;
+  float4 B, C;
+  __builtin_memcpy(&A, bp - width, 8);
+  __builtin_memcpy(&B, bp - 1, 16);
+  __builtin_memcpy(&C, bp + width - 1, 16);
+  __builtin_memcpy(&D, bp + 2 * width, 8);
   const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+  // taps: p00 = (ix,iy) = B.y, p10 = B.z, p01 = C.y, p11 = C.z
+  const float gx00 = fin0(0.5f * (B.z - B.x)), gx10 = fin0(0.5f * (B.w - B.y));
+  const float gx01 = fin0(0.5f * (C.z - C.x)), gx11 = fin0(0.5f * (C.w - C.y));
+  const float gy00 = fin0(0.5f * (C.y - A.x)), gy10 = fin0(0.5f * (C.z - A.y));
+  const float gy01 = fin0(0.5f * (D.x - B.y)), gy11 = fin0(0.5f * (D.y - B.z));
   float3 r;
-  r.x = w11 * p11.x + w01 * p01.x + w10 * p10.x + w00 * p00.x;
-  r.y = w11 * p11.y + w01 * p01.y + w10 * p10.y + w00 * p00.y;
-  r.z = w11 * p11.z + w01 * p01.z + w10 * p10.z + w00 * p00.z;
+  r.x = w11 * C.z + w01 * C.y + w10 * B.z + w00 * B.y;
+  r.y = w11 * gx11 + w01 * gx01 + w10 * gx10 + w00 * gx00;
+  r.z = w11 * gy11 + w01 * gy01 + w10 * gy10 + w00 * gy00;
   return r;
 }
 
 // Accumulator9 slot of H(r,c), r <= c: rows of the upper triangle back to back (MatrixAccumulators.h:1091-1166).
 __host__ __device__ constexpr int accIdx(int r, int c) { return ACC_H + r * 9 - (r * (r - 1)) / 2 + (c - r); }
 
-// acc[H(R,C..8)] += (J[R]*w) * J[C]; all indices are compile-time constants so the 64 accumulators stay in VGPRs.
-template <int R, int C>
-__device__ __forceinline__ void accumulateCols(float (&acc)[ACC_PAD], const float (&J)[9], const float Jw) {
-  acc[accIdx(R, C)] = __builtin_fmaf(Jw, J[C], acc[accIdx(R, C)]);
-  if constexpr (C < 8) accumulateCols<R, C + 1>(acc, J, Jw);
-}
-template <int R>
-__device__ __forceinline__ void accumulateRows(float (&acc)[ACC_PAD], const float (&J)[9], const float w) {
-  accumulateCols<R, R>(acc, J, J[R] * w);
-  if constexpr (R < 8) accumulateRows<R + 1>(acc, J, w);
-}
+// per-lane running statistics of calcRes (everything except the 9x9 outer products)
+struct EvalStats {
+  float E, nE, nSat, nW, fT, fRT, fN;
+};
 
-// One template point: everything calcRes does for it plus its calcGS row, accumulated in registers.
-__device__ __forceinline__ void evalPoint(const float4 P, const int i, const EvalP& e, const LevelGeom& g,
-                                          const float4* __restrict__ img, const float huberTH, float (&acc)[ACC_PAD]) {
+// One template point: everything calcRes does for it plus its calcGS row.  Returns the row J[0..8] = (J0..J7, r) and
+// its Huber weight w (w = 0 and J = 0 when the point does not enter the system).
+__device__ __forceinline__ void evalPoint(const float4 P, const bool flowSample, const EvalP& e, const LevelGeom& g,
+                                          const float* __restrict__ img, const float huberTH, EvalStats& st, float (&J)[9], float& wOut) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) J[k] = 0.0f;
+  wOut = 0.0f;
   const float x = P.x, y = P.y, id = P.z, refColor = P.w;
   const float pt0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f + e.t[0] * id;
   const float pt1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f + e.t[1] * id;
@@ -68,8 +83,8 @@ __device__ __forceinline__ void evalPoint(const float4 P, const int i, const Eva
   const float Ku = g.fx * u + g.cx, Kv = g.fy * v + g.cy;
   const float new_idepth = id / pt2;
 
-  if (e.lvl == 0 && (i & 31) == 0) {
-    // flow indicators (CoarseTracker.cpp:416-447)
+  if (flowSample) {
+    // flow indicators (CoarseTracker.cpp:416-447): every 32nd point of the reference's row-major list, level 0 only
     const float k0 = g.Ki[0] * x + g.Ki[1] * y + g.Ki[2] * 1.0f;
     const float k1 = g.Ki[3] * x + g.Ki[4] * y + g.Ki[5] * 1.0f;
     const float k2 = g.Ki[6] * x + g.Ki[7] * y + g.Ki[8] * 1.0f;
@@ -86,9 +101,9 @@ __device__ __forceinline__ void evalPoint(const float4 P, const int i, const Eva
     sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
     float sRT = (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
     sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-    acc[ACC_FT] += sT;
-    acc[ACC_FRT] += sRT;
-    acc[ACC_FN] += 2.0f;
+    st.fT += sT;
+    st.fRT += sRT;
+    st.fN += 2.0f;
   }
 
   if (!(Ku > 2 && Kv > 2 && Ku < g.w - 3 && Kv < g.h - 3 && new_idepth > 0)) return;
@@ -99,18 +114,17 @@ __device__ __forceinline__ void evalPoint(const float4 P, const int i, const Eva
   const float ar = fabsf(residual);
   const float hw = ar < huberTH ? 1.0f : huberTH / ar;
 
-  acc[ACC_NE] += 1.0f;
+  st.nE += 1.0f;
   if (ar > e.cutoff) {
-    acc[ACC_E] += e.maxEnergy;
-    acc[ACC_NSAT] += 1.0f;
+    st.E += e.maxEnergy;
+    st.nSat += 1.0f;
     return;
   }
-  acc[ACC_E] += hw * residual * residual * (2 - hw);
-  acc[ACC_NW] += 1.0f;
+  st.E += hw * residual * residual * (2 - hw);
+  st.nW += 1.0f;
 
   // calcGSSSE row (CoarseTracker.cpp:314-338)
   const float dx = hit.y * g.fx, dy = hit.z * g.fy;
-  float J[9];
   J[0] = new_idepth * dx;
   J[1] = new_idepth * dy;
   J[2] = 0.0f - new_idepth * (u * dx + v * dy);
@@ -120,53 +134,142 @@ __device__ __forceinline__ void evalPoint(const float4 P, const int i, const Eva
   J[6] = e.aff0 * (e.b0 - refColor);
   J[7] = -1.0f;
   J[8] = residual;
-  accumulateRows<0>(acc, J, hw);
+  wOut = hw;
 }
 
-// Transposing butterfly: on entry every lane holds 64 partial sums v[0..63]; on exit lane L holds the
-// wave-wide total of slot L in v[0].  63 cross-lane exchanges.  Template recursion keeps every register
-// index a compile-time constant (a runtime-indexed array would be demoted to scratch memory).
-template <int HALF, int I>
-__device__ __forceinline__ void butterflyStep(float (&v)[ACC_PAD], const bool hi) {
-  const float lo_v = v[I], hi_v = v[I + HALF];
-  const float keep = hi ? hi_v : lo_v;
-  const float send = hi ? lo_v : hi_v;
-  v[I] = keep + __shfl_xor(send, HALF, 64);
-  if constexpr (I + 1 < HALF) butterflyStep<HALF, I + 1>(v, hi);
-}
-template <int HALF>
-__device__ __forceinline__ void butterflyLevel(float (&v)[ACC_PAD], const int lane) {
-  butterflyStep<HALF, 0>(v, (lane & HALF) != 0);
-  if constexpr (HALF > 1) butterflyLevel<HALF / 2>(v, lane);
-}
-__device__ __forceinline__ float waveReduceTranspose(float (&v)[ACC_PAD]) {
-  butterflyLevel<32>(v, __lane_id());
-  return v[0];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS staging of one wave: the 64 rows J (transposed: component-major, padded stride) + the 64 weights.
+// Stride 66 makes both the component-major writes (lane -> consecutive banks) and the MFMA operand reads
+// (lane (i = l&15, k = l>>4) reads component i of point 4m+k: bank (2i + k + 4m) mod 32) conflict free.
+enum { SJ_STRIDE = 66, SJ_ROWS = 16, SJ_WAVE_FLOATS = SJ_ROWS * SJ_STRIDE + 64 };
+
+// 7 per-lane statistics -> wave totals: transposing butterfly over 8 slots (lane l ends with the total of slot l&7).
+__device__ __forceinline__ float waveReduceStats(const EvalStats& st, const int lane) {
+  float v[8] = {st.E, st.nE, st.nSat, st.nW, st.fT, st.fRT, st.fN, 0.0f};
+  {
+    const bool hi = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+      v[i] = keep + __shfl_xor(send, 4, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float keep = hi ? v[i + 2] : v[i], send = hi ? v[i] : v[i + 2];
+      v[i] = keep + __shfl_xor(send, 2, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 1) != 0;
+    const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+    v[0] = keep + __shfl_xor(send, 1, 64);
+  }
+  float t = v[0];
+  t += __shfl_xor(t, 8, 64);
+  t += __shfl_xor(t, 16, 64);
+  t += __shfl_xor(t, 32, 64);
+  return t;  // total of slot (lane & 7)
 }
 
-// Workgroup-wide evaluation over points [first, n) with the given stride.  Result: s_tot[0..63] (LDS)
-// valid for all threads after return.  T = threads per workgroup (multiple of 64).
+// Workgroup-wide evaluation over the template points first, first+stride, ... < n (first = this THREAD's first index;
+// stride = threads taking part).  The weighted 9x9 outer products  sum_p w_p J_p J_p^T  are accumulated on the matrix
+// cores: per wave, 64 rows are staged component-major in LDS and consumed by 16 v_mfma_f32_16x16x4_f32 (A = J,
+// B = w*J, K = 4 points per instruction, 9 of the 16 rows/columns used).  fp32 in, fp32 accumulate — same numerics
+// class as the reference's fp32 sums; the accumulator costs 4 registers per lane instead of 45, which is what lets
+// 4-8 waves per SIMD stay resident to hide the gather latency.  Fixed summation order (bitwise reproducible).
+// Result: s_tot[0..63] (ACC_* slots) valid for all threads after return.
 template <int T>
 __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, const float4* __restrict__ pc, const int n,
-                                          const int first, const int stride, const float4* __restrict__ img,
-                                          const float huberTH, float (*s_part)[ACC_PAD], float* s_tot) {
-  float acc[ACC_PAD];
-#pragma unroll
-  for (int k = 0; k < ACC_PAD; k++) acc[k] = 0.0f;
-  for (int i = first; i < n; i += stride) {
-    const float4 P = pc[i];
-    evalPoint(P, i, e, g, img, huberTH, acc);
-  }
-  const float tot = waveReduceTranspose(acc);
+                                          const unsigned long long* __restrict__ flow_mask, const int first, const int stride,
+                                          const float* __restrict__ img, const float huberTH, float* s_stage, float* s_partH,
+                                          float (*s_partS)[8], float* s_tot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  s_part[wave][lane] = tot;
+  float* __restrict__ wJ = s_stage + wave * SJ_WAVE_FLOATS;
+  float* __restrict__ wW = wJ + SJ_ROWS * SJ_STRIDE;
+  // four independent accumulator chains: a 16x16x4 f32 MFMA has a 40-cycle dependent latency but a 32-cycle issue slot
+  f32x4 accH0 = {0.0f, 0.0f, 0.0f, 0.0f}, accH1 = accH0, accH2 = accH0, accH3 = accH0;
+  EvalStats st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool lvl0 = (e.lvl == 0);
+  const int mi = lane & 15, mk = lane >> 4;
+  // wave-uniform trip count: lane 0 of the wave owns index first - lane.  The template record (and flow-sample word)
+  // of the NEXT iteration is requested before this iteration's taps, so the two dependent memory round trips of a
+  // point (record -> projection -> taps) overlap across iterations.
+  const int base0 = first - lane;
+  float4 Pn = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned long long Fn = 0ull;
+  if (base0 + lane < n) {
+    Pn = pc[base0 + lane];
+    if (lvl0) Fn = flow_mask[(base0 + lane) >> 6];
+  }
+  for (int base = base0; base < n; base += stride) {
+    const int i = base + lane;
+    const float4 P = Pn;
+    const unsigned long long F = Fn;
+    const int inext = i + stride;
+    if (inext < n) {
+      Pn = pc[inext];
+      if (lvl0) Fn = flow_mask[inext >> 6];
+    }
+    float J[9], w;
+    if (i < n) {
+      const bool flowSample = lvl0 && ((F >> (i & 63)) & 1ull);
+      evalPoint(P, flowSample, e, g, img, huberTH, st, J, w);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) J[k] = 0.0f;
+      w = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
+    wW[lane] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int m = 0; m < 16; m += 4) {
+      const float a0 = wJ[mi * SJ_STRIDE + 4 * m + mk], a1 = wJ[mi * SJ_STRIDE + 4 * m + 4 + mk];
+      const float a2 = wJ[mi * SJ_STRIDE + 4 * m + 8 + mk], a3 = wJ[mi * SJ_STRIDE + 4 * m + 12 + mk];
+      const float b0 = a0 * wW[4 * m + mk], b1 = a1 * wW[4 * m + 4 + mk], b2 = a2 * wW[4 * m + 8 + mk], b3 = a3 * wW[4 * m + 12 + mk];
+      accH0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accH0, 0, 0, 0);
+      accH1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accH1, 0, 0, 0);
+      accH2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, accH2, 0, 0, 0);
+      accH3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, accH3, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // per-wave partials -> LDS.  accH[r] = D[row = mk*4 + r][col = mi]
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_partH[wave * 256 + (mk * 4 + r) * 16 + mi] = (accH0[r] + accH1[r]) + (accH2[r] + accH3[r]);
+  const float stot = waveReduceStats(st, lane);
+  if (lane < 8) s_partS[wave][lane] = stot;
   __syncthreads();
   if (threadIdx.x < ACC_PAD) {
+    // slot -> (r, c) of the upper triangle, or a statistic
     float s = 0.0f;
+    const int k = threadIdx.x;
+    if (k < 45) {
+      int r = 0, off = 0;
+      while (k >= off + (9 - r)) { off += 9 - r; r++; }
+      const int c = r + (k - off);
 #pragma unroll
-    for (int wv = 0; wv < T / 64; wv++) s += s_part[wv][threadIdx.x];
-    s_tot[threadIdx.x] = s;
+      for (int wv = 0; wv < T / 64; wv++) s += s_partH[wv * 256 + r * 16 + c];
+    } else if (k < ACC_N) {
+#pragma unroll
+      for (int wv = 0; wv < T / 64; wv++) s += s_partS[wv][k - 45];
+    }
+    s_tot[k] = s;
   }
+  __syncthreads();
+}
+
+// zero the rows 9..15 of every wave's staging area once (they are never written afterwards)
+template <int T>
+__device__ __forceinline__ void initStage(float* s_stage) {
+  for (int k = threadIdx.x; k < (T / 64) * SJ_WAVE_FLOATS; k += T) s_stage[k] = 0.0f;
   __syncthreads();
 }
 
@@ -174,11 +277,15 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
 // single evaluation (host-driven LM / VIO mode hand-off / parity unit): G workgroups -> partials
 // ---------------------------------------------------------------------------------------------
 template <int T>
-__global__ void __launch_bounds__(T) k_eval_partial(const TrackerDev trk, const EvalP e, const float4* __restrict__ img, float* __restrict__ partials) {
-  __shared__ float s_part[T / 64][ACC_PAD];
+__global__ void __launch_bounds__(T) k_eval_partial(const TrackerDev trk, const EvalP e, const float* __restrict__ img, float* __restrict__ partials) {
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
   __shared__ float s_tot[ACC_PAD];
+  initStage<T>(s_stage);
   const int lvl = e.lvl;
-  blockEval<T>(e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH, s_part, s_tot);
+  blockEval<T>(e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH,
+               s_stage, s_partH, s_partS, s_tot);
   if (threadIdx.x < ACC_PAD) partials[blockIdx.x * ACC_PAD + threadIdx.x] = s_tot[threadIdx.x];
 }
 __global__ void __launch_bounds__(64) k_eval_final(const float* __restrict__ partials, const int G, float* __restrict__ out) {
@@ -275,19 +382,20 @@ __device__ __forceinline__ double rhsEntryFromSums(const float* tot, const int r
 // Wave-cooperative LDL^T with symmetric diagonal pivoting (largest |d| first — the pivot rule of the
 // decomposition CoarseTracker.cpp:639 calls).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).
 // Returns x(r) in every lane of row r.
-__device__ __forceinline__ double waveLdltSolve8(double m, double dv, const int lane) {
+__device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lane, int* s_trk) {
+  // loops are deliberately NOT unrolled: this runs once per LM iteration on one wave, while its register footprint is
+  // charged to every wave of the kernel (the evaluation loop wants the occupancy).
   const int r = lane >> 3, c = lane & 7;
-  int trk[8];
-#pragma unroll
+#pragma unroll 1
   for (int k = 0; k < 8; k++) {
     int p = k;
     double best = fabs(__shfl(m, k * 9, 64));
-#pragma unroll
+#pragma unroll 1
     for (int i = k + 1; i < 8; i++) {
       const double v = fabs(__shfl(m, i * 9, 64));
       if (v > best) { best = v; p = i; }
     }
-    trk[k] = p;
+    if (lane == 0) s_trk[k] = p;
     {
       const int pr = (r == k) ? p : ((r == p) ? k : r);
       const int pc = (c == k) ? p : ((c == p) ? k : c);
@@ -304,7 +412,7 @@ __device__ __forceinline__ double waveLdltSolve8(double m, double dv, const int 
     if (c == k && r > k) m = Lrk;
   }
   // forward substitution  (L y = P b)
-#pragma unroll
+#pragma unroll 1
   for (int k = 0; k < 8; k++) {
     const double dkv = __shfl(dv, k * 8, 64);
     const double Lrk = __shfl(m, r * 8 + k, 64);
@@ -315,15 +423,18 @@ __device__ __forceinline__ double waveLdltSolve8(double m, double dv, const int 
     dv = (fabs(D) > 2.2250738585072014e-308) ? dv / D : 0.0;
   }
   // backward substitution  (L^T x = z)
-#pragma unroll
+#pragma unroll 1
   for (int k = 7; k >= 0; k--) {
     const double dkv = __shfl(dv, k * 8, 64);
     const double Lkr = __shfl(m, k * 8 + r, 64);
     if (r < k) dv = dv - Lkr * dkv;
   }
-#pragma unroll
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
   for (int k = 7; k >= 0; k--) {
-    const int p = trk[k];
+    const int p = s_trk[k];
     const int pr = (r == k) ? p : ((r == p) ? k : r);
     dv = __shfl(dv, pr * 8 + c, 64);
   }
@@ -333,7 +444,7 @@ __device__ __forceinline__ double waveLdltSolve8(double m, double dv, const int 
 // One LM control step, executed by all 64 lanes of wave 0.  Consumes the finished evaluation in s_tot, decides,
 // and either prepares the next evaluation (s_e, returns true) or finishes the problem (returns false).
 __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, const LMProblemIn& in, LMProblemOut& out,
-                                           const float* s_tot, double* s_H, double* s_b, double* s_x, EvalP& s_e, const int lane) {
+                                           const float* s_tot, double* s_H, double* s_b, double* s_x, int* s_trk, EvalP& s_e, const int lane) {
   const int maxIterations[5] = {10, 20, 50, 50, 50};
   const float lambdaExtrapolationLimit = 0.001f;
   int takeH = 0, action = ACT_DONE;
@@ -447,7 +558,7 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
     const int nact = (fixA && fixB) ? 6 : ((fixA || fixB) ? 7 : 8);
     if (r >= nact || c >= nact) { m = (r == c) ? 1.0 : 0.0; }
     if (r >= nact) dv = 0.0;
-    double x = waveLdltSolve8(m, dv, lane);
+    double x = waveLdltSolve8(m, dv, lane, s_trk);
     if (fixA && !fixB) {
       // inc[7] = incStitch[6]; inc[6] = 0
       const double x6 = __shfl(x, 6 * 8, 64);
@@ -494,14 +605,18 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
   return action != ACT_DONE;
 }
 
-template <int T>
-__global__ void __launch_bounds__(T) k_track_lm(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in,
+// W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): the LM control step
+// (fp64) wants more registers than the evaluation loop; W trades its spills against the occupancy of the gathers.
+template <int T, int W>
+__global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in,
                                                  LMProblemOut* __restrict__ out, const int coarsestLvl) {
-  __shared__ float s_part[T / 64][ACC_PAD];
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
   __shared__ float s_tot[ACC_PAD];
   __shared__ EvalP s_e;
   __shared__ double s_H[64], s_b[8], s_x[8];
-  __shared__ int s_go;
+  __shared__ int s_go, s_trk[8];
   __shared__ LMState S;  // written by lane 0 of wave 0 only
   const LMProblemIn& pin = in[blockIdx.x];
   LMProblemOut& pout = out[blockIdx.x];
@@ -514,13 +629,13 @@ __global__ void __launch_bounds__(T) k_track_lm(const TrackerDev trk, const Fram
     S.iteration = 0; S.lambda = 0.01f; S.cutoffRepeat = 1; S.incNorm = 0;
   }
   if (threadIdx.x < 64) { s_H[threadIdx.x] = 0; if (threadIdx.x < 8) { s_b[threadIdx.x] = 0; s_x[threadIdx.x] = 0; } }
-  __syncthreads();
+  initStage<T>(s_stage);
   const int slot = pin.new_slot;
   long long tStep = 0, tEval = 0;
   for (;;) {
     const long long t0 = wall_clock64();
     if (threadIdx.x < 64) {
-      const bool go = lmWaveStep(S, trk, pin, pout, s_tot, s_H, s_b, s_x, s_e, threadIdx.x);
+      const bool go = lmWaveStep(S, trk, pin, pout, s_tot, s_H, s_b, s_x, s_trk, s_e, threadIdx.x);
       if (threadIdx.x == 0) s_go = go ? 1 : 0;
     }
     __syncthreads();
@@ -528,7 +643,7 @@ __global__ void __launch_bounds__(T) k_track_lm(const TrackerDev trk, const Fram
     tStep += t1 - t0;
     if (!s_go) break;
     const int lvl = s_e.lvl;
-    blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], threadIdx.x, T, fs.level(slot, lvl), trk.huberTH, s_part, s_tot);
+    blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, fs.level(slot, lvl), trk.huberTH, s_stage, s_partH, s_partS, s_tot);
     tEval += wall_clock64() - t1;
   }
   if (threadIdx.x == 0) {
