@@ -143,3 +143,83 @@ def tracking_case(w=512, h=512, n_ref=2000, seed=SEED, xi_true=(0.03, -0.02, 0.0
         frames.append(dict(img=img, R=R, t=t, pose7=pose7(R, t), xi=xi))
     return dict(K4=K4, w=w, h=h, ref_img=ref_img, u=u, v=v, idepth=idepth,
                 hdiF=np.full(n_ref, 1e-4, dtype=np.float32), frames=frames, world=world)
+
+
+PATTERN8 = np.array([[0, -2], [-1, -1], [1, -1], [-2, 0], [0, 0], [2, 0], [-1, 1], [0, 2]], dtype=np.int32)  # settings.cpp:296, pattern 8
+
+
+def ba_case(w=512, h=512, n_frames=8, n_points=2000, seed=SEED, idepth_noise=0.05, trans_noise=0.005, rot_noise=0.0035,
+            step_t=0.1, step_r=np.deg2rad(2.0), hosts_share=(400, 350, 300, 300, 250, 250, 150, 0)):
+    """Sliding-window BA case: F keyframes on a smooth trajectory, N points hosted in the older
+    keyframes, each observed in every other frame where its centre projects in bounds.  Returns ground truth, the
+    perturbed initial state (poses as evalPT, idepths) and the residual graph."""
+    world = PlaneWorld(seed)
+    K4 = default_intrinsics(w, h)
+    rng = np.random.RandomState(seed + 7)
+    fx, fy, cx, cy = K4
+    # smooth trajectory: sideways + forward drift, gentle yaw
+    Rs, ts, imgs, ids = [], [], [], []
+    for k in range(n_frames):
+        xi = np.array([step_t * k, 0.02 * k * step_t / 0.1, 0.3 * step_t * k, 0.2 * step_r * k, -step_r * k, 0.1 * step_r * k])
+        R, t = se3_exp(xi)
+        Rs.append(R); ts.append(t)
+        img, idm = world.render(K4, R, t, w, h)
+        imgs.append(img); ids.append(idm)
+    share = np.array(hosts_share[:n_frames], dtype=np.float64)
+    if share.sum() <= 0:
+        share = np.ones(n_frames); share[-1] = 0
+    counts = np.floor(share / share.sum() * n_points).astype(int)
+    counts[0] += n_points - counts.sum()
+    pts = []  # (host, u, v, idepth_true)
+    for hf in range(n_frames):
+        if counts[hf] == 0:
+            continue
+        u, v = select_points(imgs[hf], counts[hf], rng, border=8)
+        for a, b in zip(u, v):
+            pts.append((hf, float(a), float(b), float(ids[hf][int(b), int(a)])))
+    # colors / weights exactly as ImmaturePoint's constructor samples them (ImmaturePoint.cpp:40-56): pattern pixels of the
+    # host image at integer positions; weights = sqrt(c / (c + |grad|^2)), c = setting_outlierTHSumComponent = 50^2
+    grads = []
+    for img in imgs:
+        gx = np.zeros_like(img); gy = np.zeros_like(img)
+        flat = img.reshape(-1); idx = np.arange(w, w * (h - 1))
+        gx.reshape(-1)[idx] = np.float32(0.5) * (flat[idx + 1] - flat[idx - 1])
+        gy.reshape(-1)[idx] = np.float32(0.5) * (flat[idx + w] - flat[idx - w])
+        grads.append((gx, gy))
+    N = len(pts)
+    host = np.array([p[0] for p in pts], dtype=np.int32)
+    u = np.array([p[1] for p in pts], dtype=np.float32); v = np.array([p[2] for p in pts], dtype=np.float32)
+    idepth_true = np.array([p[3] for p in pts], dtype=np.float32)
+    color = np.zeros((N, 8), dtype=np.float32); weights = np.zeros((N, 8), dtype=np.float32)
+    for i in range(N):
+        hf = host[i]
+        px = u[i].astype(int) + PATTERN8[:, 0]; py = v[i].astype(int) + PATTERN8[:, 1]
+        color[i] = imgs[hf][py, px]
+        g2 = grads[hf][0][py, px] ** 2 + grads[hf][1][py, px] ** 2
+        weights[i] = np.sqrt(np.float32(2500.0) / (np.float32(2500.0) + g2))
+    # residual graph: point i observed in frame t != host when its centre projects well inside the image
+    res_point, res_target = [], []
+    for i in range(N):
+        hf = host[i]
+        X_h = np.array([(u[i] - cx) / fx, (v[i] - cy) / fy, 1.0]) / idepth_true[i]
+        X_w = Rs[hf].T @ (X_h - ts[hf])
+        for t in range(n_frames):
+            if t == hf:
+                continue
+            X_t = Rs[t] @ X_w + ts[t]
+            if X_t[2] <= 0.1:
+                continue
+            pu = fx * X_t[0] / X_t[2] + cx; pv = fy * X_t[1] / X_t[2] + cy
+            if 6 < pu < w - 7 and 6 < pv < h - 7:
+                res_point.append(i); res_target.append(t)
+    # perturbed initial state
+    idepth0 = (idepth_true * (1.0 + idepth_noise * rng.standard_normal(N))).astype(np.float32)
+    poses0 = []
+    for k in range(n_frames):
+        d = np.concatenate([rng.normal(0, trans_noise, 3), rng.normal(0, rot_noise, 3)]) if k > 0 else np.zeros(6)
+        dR, dt = se3_exp(d)
+        R0 = dR @ Rs[k]; t0 = dR @ ts[k] + dt
+        poses0.append(pose7(R0, t0))
+    return dict(K4=K4, w=w, h=h, imgs=imgs, poses_true=[pose7(R, t) for R, t in zip(Rs, ts)], poses0=poses0, host=host, u=u, v=v,
+                idepth_true=idepth_true, idepth0=idepth0, color=color, weights=weights,
+                res_point=np.array(res_point, dtype=np.int32), res_target=np.array(res_target, dtype=np.int32), n_frames=n_frames)

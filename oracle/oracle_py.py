@@ -186,3 +186,169 @@ class Tracker:
 
     def stats(self):
         o = (C.c_long * 3)(); self.L.orc_tracker_stats(self.p, o); return list(o)
+
+
+# ---------------------------------------------------------------------------------------------- bundle adjustment oracle
+_BA_SIG = False
+
+
+def _ba_sig(L):
+    global _BA_SIG
+    if _BA_SIG:
+        return
+    vp = C.c_void_p
+    L.orc_ba_create.restype = vp; L.orc_ba_create.argtypes = [C.c_int, C.c_int, c_d]
+    L.orc_ba_destroy.argtypes = [vp]
+    L.orc_ba_set_threads.argtypes = [vp, C.c_int]
+    L.orc_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
+    L.orc_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
+    L.orc_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int]
+    L.orc_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
+    L.orc_ba_finalize.argtypes = [vp]
+    L.orc_ba_set_marg_prior.argtypes = [vp, c_d, c_d]
+    for n in ("orc_ba_nframes", "orc_ba_npoints", "orc_ba_nres"):
+        getattr(L, n).argtypes = [vp]
+    L.orc_ba_activate_all.argtypes = [vp]
+    L.orc_ba_linearize_all.restype = C.c_double; L.orc_ba_linearize_all.argtypes = [vp, C.c_int]
+    L.orc_ba_apply_res.argtypes = [vp]
+    ci = C.POINTER(C.c_int)
+    L.orc_ba_get_res_state.argtypes = [vp, ci, c_d, c_d, ci, c_f]
+    L.orc_ba_get_J.argtypes = [vp, C.c_int, C.c_int, c_f, c_f]
+    L.orc_ba_get_frame_energy_th.argtypes = [vp, c_f]
+    L.orc_ba_get_precalc.argtypes = [vp, C.c_int, C.c_int, c_f]
+    L.orc_ba_get_adjoints.argtypes = [vp, c_d, c_d, c_f]
+    L.orc_ba_accumulate.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, ci]
+    L.orc_ba_get_point_acc.argtypes = [vp, c_f, c_f, c_f, c_f, c_f]
+    L.orc_ba_solve.argtypes = [vp, C.c_int, C.c_double, c_d]
+    L.orc_ba_get_last_system.argtypes = [vp, c_d, c_d]
+    L.orc_ba_resubstitute.argtypes = [vp, c_d]
+    L.orc_ba_get_point_state.argtypes = [vp, c_f, c_f]
+    L.orc_ba_get_frame_pose.argtypes = [vp, C.c_int, c_d, c_d, c_d]
+    L.orc_ba_get_calib.argtypes = [vp, c_d]
+    L.orc_ba_get_nullspaces.argtypes = [vp, c_d]
+    L.orc_ba_orthogonalize.argtypes = [vp, c_d]
+    L.orc_ba_calc_lenergy.restype = C.c_double; L.orc_ba_calc_lenergy.argtypes = [vp]
+    L.orc_ba_calc_menergy.restype = C.c_double; L.orc_ba_calc_menergy.argtypes = [vp]
+    L.orc_ba_optimize.restype = C.c_float; L.orc_ba_optimize.argtypes = [vp, C.c_int, c_d, ci, c_d]
+    L.orc_ba_gn_iteration.argtypes = [vp, C.c_int, c_d, c_d]
+    _BA_SIG = True
+
+
+class BAWindow:
+    """Oracle mirror of the sliding window the reference optimises in FullSystem::optimize (FullSystemOptimize.cpp:417-647)."""
+
+    def __init__(self, case, poses=None, idepth=None, threads=1):
+        self.L = lib(); _ba_sig(self.L)
+        self.case = case
+        K4 = np.ascontiguousarray(case["K4"], dtype=np.float64)
+        self.p = C.c_void_p(self.L.orc_ba_create(case["w"], case["h"], _d(K4)))
+        self.L.orc_ba_set_threads(self.p, threads)
+        self._dI = [make_images(img, case["w"], case["h"])[0][0] for img in case["imgs"]]
+        poses = case["poses0"] if poses is None else poses
+        idepth = case["idepth0"] if idepth is None else idepth
+        for k in range(case["n_frames"]):
+            self.L.orc_ba_add_frame(self.p, _d(np.ascontiguousarray(poses[k], dtype=np.float64)), 0.0, 0.0, 1.0, k, _f(self._dI[k]))
+        col = np.ascontiguousarray(case["color"], dtype=np.float32); wts = np.ascontiguousarray(case["weights"], dtype=np.float32)
+        for i in range(len(case["u"])):
+            self.L.orc_ba_add_point(self.p, int(case["host"][i]), float(case["u"][i]), float(case["v"][i]), float(idepth[i]), _f(col[i]), _f(wts[i]), 0)
+        for pi, ti in zip(case["res_point"], case["res_target"]):
+            self.L.orc_ba_add_residual(self.p, int(pi), int(ti))
+        self.L.orc_ba_finalize(self.p)
+        self.F = case["n_frames"]; self.N = len(case["u"]); self.R = len(case["res_point"]); self.n = 4 + 8 * self.F
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.orc_ba_destroy(self.p); self.p = None
+
+    def perturb_frame(self, k, d8):
+        self.L.orc_ba_perturb_frame(self.p, k, _d(np.ascontiguousarray(d8, dtype=np.float64)))
+
+    def activate_all(self):
+        self.L.orc_ba_activate_all(self.p)
+
+    def linearize_all(self, fix=False):
+        return self.L.orc_ba_linearize_all(self.p, 1 if fix else 0)
+
+    def apply_res(self):
+        self.L.orc_ba_apply_res(self.p)
+
+    def res_state(self):
+        ns = np.zeros(self.R, dtype=np.int32); ne = np.zeros(self.R); nw = np.zeros(self.R); ia = np.zeros(self.R, dtype=np.int32)
+        cp = np.zeros((self.R, 3), dtype=np.float32)
+        ci = C.POINTER(C.c_int)
+        self.L.orc_ba_get_res_state(self.p, ns.ctypes.data_as(ci), _d(ne), _d(nw), ia.ctypes.data_as(ci), _f(cp))
+        return dict(newState=ns, newEnergy=ne, newEnergyWO=nw, isActive=ia, center=cp)
+
+    def get_J(self, i, which=0):
+        j = np.zeros(74, dtype=np.float32); jp = np.zeros(8, dtype=np.float32)
+        self.L.orc_ba_get_J(self.p, i, which, _f(j), _f(jp))
+        o = 0; out = {}
+        for name, shape in (("resF", (8,)), ("Jpdxi", (2, 6)), ("Jpdc", (2, 4)), ("Jpdd", (2,)), ("JIdx", (2, 8)), ("JabF", (2, 8)),
+                            ("JIdx2", (2, 2)), ("JabJIdx", (2, 2)), ("Jab2", (2, 2))):
+            n = int(np.prod(shape)); out[name] = j[o:o + n].reshape(shape); o += n
+        out["JpJdF"] = jp
+        return out
+
+    def frame_energy_th(self):
+        o = np.zeros(self.F, dtype=np.float32); self.L.orc_ba_get_frame_energy_th(self.p, _f(o)); return o
+
+    def precalc(self, h, t):
+        o = np.zeros(37, dtype=np.float32); self.L.orc_ba_get_precalc(self.p, h, t, _f(o))
+        return dict(KRKi=o[0:9].reshape(3, 3), Kt=o[9:12], R0=o[12:21].reshape(3, 3), t0=o[21:24], aff=o[24:26], b0=o[26], R=o[27:36].reshape(3, 3))
+
+    def adjoints(self):
+        n = self.F * self.F
+        ah = np.zeros((n, 8, 8)); at = np.zeros((n, 8, 8)); d = np.zeros((n, 8), dtype=np.float32)
+        self.L.orc_ba_get_adjoints(self.p, _d(ah), _d(at), _f(d)); return ah, at, d
+
+    def accumulate(self):
+        n = self.n
+        m = [np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n)]
+        r = C.c_int(0)
+        self.L.orc_ba_accumulate(self.p, *[_d(a) for a in m], C.byref(r))
+        return dict(HA=m[0], bA=m[1], HL=m[2], bL=m[3], Hsc=m[4], bsc=m[5], resInA=r.value)
+
+    def point_acc(self):
+        N = self.N
+        o = [np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32), np.zeros((N, 4), dtype=np.float32), np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32)]
+        self.L.orc_ba_get_point_acc(self.p, *[_f(a) for a in o])
+        return dict(Hdd=o[0], bd=o[1], Hcd=o[2], HdiF=o[3], bdSumF=o[4])
+
+    def solve(self, iteration, lam):
+        x = np.zeros(self.n); self.L.orc_ba_solve(self.p, iteration, lam, _d(x)); return x
+
+    def last_system(self):
+        H = np.zeros((self.n, self.n)); b = np.zeros(self.n); self.L.orc_ba_get_last_system(self.p, _d(H), _d(b)); return H, b
+
+    def resubstitute(self, x):
+        self.L.orc_ba_resubstitute(self.p, _d(np.ascontiguousarray(x, dtype=np.float64)))
+
+    def point_state(self):
+        a = np.zeros(self.N, dtype=np.float32); b = np.zeros(self.N, dtype=np.float32)
+        self.L.orc_ba_get_point_state(self.p, _f(a), _f(b)); return a, b
+
+    def frame_pose(self, k):
+        p = np.zeros(7); a = np.zeros(2); s = np.zeros(10)
+        self.L.orc_ba_get_frame_pose(self.p, k, _d(p), _d(a), _d(s)); return p, a, s
+
+    def nullspaces(self):
+        o = np.zeros((7, self.n)); self.L.orc_ba_get_nullspaces(self.p, _d(o)); return o
+
+    def orthogonalize(self, x):
+        x = np.array(x, dtype=np.float64); self.L.orc_ba_orthogonalize(self.p, _d(x)); return x
+
+    def lenergy(self):
+        return self.L.orc_ba_calc_lenergy(self.p)
+
+    def menergy(self):
+        return self.L.orc_ba_calc_menergy(self.p)
+
+    def optimize(self, its=6):
+        fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))
+        rmse = self.L.orc_ba_optimize(self.p, its, C.byref(fe), C.byref(it), _d(tr))
+        return dict(rmse=rmse, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])
+
+    def gn_iteration(self, iteration, lam, lastE):
+        l = C.c_double(lam); e = np.array(lastE, dtype=np.float64)
+        acc = self.L.orc_ba_gn_iteration(self.p, iteration, C.byref(l), _d(e))
+        return bool(acc), l.value, e
