@@ -56,6 +56,28 @@ def _sig(L):
     L.dmvio_hip_tracker_track_batch_fetch.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    c_u8 = C.POINTER(C.c_ubyte)
+    L.dmvio_hip_ba_create.restype = vp
+    L.dmvio_hip_ba_create.argtypes = [vp]
+    L.dmvio_hip_ba_destroy.argtypes = [vp]
+    L.dmvio_hip_ba_set_window.argtypes = [vp, C.c_int, c_i, c_d, c_d, c_f, c_i, c_d]
+    L.dmvio_hip_ba_set_marg_prior.argtypes = [vp, c_d, c_d]
+    L.dmvio_hip_ba_set_graph.argtypes = [vp, C.c_int, c_i, c_f, c_f, c_f, c_f, c_f, c_u8, C.c_int, c_i, c_i]
+    L.dmvio_hip_ba_activate_all.argtypes = [vp]
+    L.dmvio_hip_ba_linearize.argtypes = [vp, C.c_int, c_d]
+    L.dmvio_hip_ba_apply.argtypes = [vp]
+    L.dmvio_hip_ba_get_res_state.argtypes = [vp, c_u8, c_f, c_f, c_u8, c_f]
+    L.dmvio_hip_ba_get_jacobians.argtypes = [vp, c_f]
+    L.dmvio_hip_ba_get_frame_energy_th.argtypes = [vp, c_f]
+    L.dmvio_hip_ba_accumulate.argtypes = [vp, c_d, c_d, c_d, c_d, c_i]
+    L.dmvio_hip_ba_get_point_acc.argtypes = [vp, c_f, c_f, c_f, c_f, c_f]
+    L.dmvio_hip_ba_solve.argtypes = [vp, C.c_int, C.c_double, c_d]
+    L.dmvio_hip_ba_resubstitute.argtypes = [vp, c_d]
+    L.dmvio_hip_ba_get_points.argtypes = [vp, c_f, c_f]
+    L.dmvio_hip_ba_get_frame.argtypes = [vp, C.c_int, c_d, c_d, c_d]
+    L.dmvio_hip_ba_get_calib.argtypes = [vp, c_d]
+    L.dmvio_hip_ba_gn_iteration.argtypes = [vp, C.c_int, c_d, c_d, c_i]
+    L.dmvio_hip_ba_optimize.argtypes = [vp, C.c_int, c_f, c_d, c_i, c_d]
 
 
 def load_library():
@@ -255,3 +277,120 @@ class CoarseTrackerHip:
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_work(self.p, C.byref(a), C.byref(b)), "last_work")
         return a.value, b.value
+
+
+class BundleAdjusterHip:
+    """The sliding window FullSystem::optimize works on, over the C ABI (include/dmvio_hip.h, "sliding-window BA")."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = ctx.L
+        p = self.L.dmvio_hip_ba_create(ctx.p)
+        if not p:
+            raise HipLibraryError("ba_create: " + (self.L.dmvio_hip_last_error() or b"").decode())
+        self.p = C.c_void_p(p)
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_ba_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_case(self, case, slots, poses=None, idepth=None):
+        """Window + graph from a dm-vio_amd.synth.ba_case dictionary (frames must already be uploaded into `slots`)."""
+        F = case["n_frames"]
+        poses = np.ascontiguousarray(case["poses0"] if poses is None else poses, dtype=np.float64).reshape(F, 7)
+        idepth = np.ascontiguousarray(case["idepth0"] if idepth is None else idepth, dtype=np.float32)
+        self.set_window(slots, poses, np.zeros((F, 2)), np.ones(F, dtype=np.float32), np.arange(F, dtype=np.int32), case["K4"])
+        self.set_graph(case["host"], case["u"], case["v"], idepth, case["color"], case["weights"], None, case["res_point"], case["res_target"])
+
+    def set_window(self, slots, poses7_w2c, aff_ab, exposures, frameIDs, K4):
+        self.F = len(slots); self.n = 4 + 8 * self.F
+        slots = np.ascontiguousarray(slots, dtype=np.int32); poses = np.ascontiguousarray(poses7_w2c, dtype=np.float64)
+        aff = np.ascontiguousarray(aff_ab, dtype=np.float64); ex = np.ascontiguousarray(exposures, dtype=np.float32)
+        ids = np.ascontiguousarray(frameIDs, dtype=np.int32); K = np.ascontiguousarray(K4, dtype=np.float64)
+        _chk(self.L, self.L.dmvio_hip_ba_set_window(self.p, self.F, _i(slots), _d(poses), _d(aff), _f(ex), _i(ids), _d(K)), "ba_set_window")
+
+    def set_marg_prior(self, HM, bM):
+        HM = np.ascontiguousarray(HM, dtype=np.float64); bM = np.ascontiguousarray(bM, dtype=np.float64)
+        _chk(self.L, self.L.dmvio_hip_ba_set_marg_prior(self.p, _d(HM), _d(bM)), "ba_set_marg_prior")
+
+    def set_graph(self, host, u, v, idepth, color, weights, hasDepthPrior, res_point, res_target):
+        self.N = len(u); self.R = len(res_point)
+        a = [np.ascontiguousarray(host, dtype=np.int32), np.ascontiguousarray(u, dtype=np.float32), np.ascontiguousarray(v, dtype=np.float32),
+             np.ascontiguousarray(idepth, dtype=np.float32), np.ascontiguousarray(color, dtype=np.float32), np.ascontiguousarray(weights, dtype=np.float32)]
+        hp = None if hasDepthPrior is None else np.ascontiguousarray(hasDepthPrior, dtype=np.uint8)
+        rp = np.ascontiguousarray(res_point, dtype=np.int32); rt = np.ascontiguousarray(res_target, dtype=np.int32)
+        u8 = C.POINTER(C.c_ubyte)
+        _chk(self.L, self.L.dmvio_hip_ba_set_graph(self.p, self.N, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), _f(a[4]), _f(a[5]),
+                                                   None if hp is None else hp.ctypes.data_as(u8), self.R, _i(rp), _i(rt)), "ba_set_graph")
+
+    def activate_all(self):
+        _chk(self.L, self.L.dmvio_hip_ba_activate_all(self.p), "ba_activate_all")
+
+    def linearize_all(self, fix=False):
+        e = C.c_double(0)
+        _chk(self.L, self.L.dmvio_hip_ba_linearize(self.p, 1 if fix else 0, C.byref(e)), "ba_linearize")
+        return e.value
+
+    def apply_res(self):
+        _chk(self.L, self.L.dmvio_hip_ba_apply(self.p), "ba_apply")
+
+    def res_state(self):
+        R = self.R; u8 = C.POINTER(C.c_ubyte)
+        ns = np.zeros(R, dtype=np.uint8); ne = np.zeros(R, dtype=np.float32); nw = np.zeros(R, dtype=np.float32)
+        ia = np.zeros(R, dtype=np.uint8); cp = np.zeros((R, 3), dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_get_res_state(self.p, ns.ctypes.data_as(u8), _f(ne), _f(nw), ia.ctypes.data_as(u8), _f(cp)), "ba_get_res_state")
+        return dict(newState=ns, newEnergy=ne, newEnergyWO=nw, isActive=ia, center=cp)
+
+    def jacobians(self):
+        J = np.zeros((self.R, 74), dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_get_jacobians(self.p, _f(J)), "ba_get_jacobians")
+        return J
+
+    def frame_energy_th(self):
+        o = np.zeros(self.F, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_get_frame_energy_th(self.p, _f(o)), "ba_get_frame_energy_th"); return o
+
+    def accumulate(self):
+        n = self.n
+        HA = np.zeros((n, n)); bA = np.zeros(n); Hsc = np.zeros((n, n)); bsc = np.zeros(n); r = C.c_int(0)
+        _chk(self.L, self.L.dmvio_hip_ba_accumulate(self.p, _d(HA), _d(bA), _d(Hsc), _d(bsc), C.byref(r)), "ba_accumulate")
+        return dict(HA=HA, bA=bA, Hsc=Hsc, bsc=bsc, resInA=r.value)
+
+    def point_acc(self):
+        N = self.N
+        o = [np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32), np.zeros((N, 4), dtype=np.float32), np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32)]
+        _chk(self.L, self.L.dmvio_hip_ba_get_point_acc(self.p, *[_f(a) for a in o]), "ba_get_point_acc")
+        return dict(Hdd=o[0], bd=o[1], Hcd=o[2], HdiF=o[3], bdSumF=o[4])
+
+    def solve(self, iteration, lam):
+        x = np.zeros(self.n)
+        _chk(self.L, self.L.dmvio_hip_ba_solve(self.p, iteration, lam, _d(x)), "ba_solve"); return x
+
+    def resubstitute(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        _chk(self.L, self.L.dmvio_hip_ba_resubstitute(self.p, _d(x)), "ba_resubstitute")
+
+    def point_state(self):
+        a = np.zeros(self.N, dtype=np.float32); b = np.zeros(self.N, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_get_points(self.p, _f(a), _f(b)), "ba_get_points"); return a, b
+
+    def frame_pose(self, k):
+        p = np.zeros(7); a = np.zeros(2); s = np.zeros(10)
+        _chk(self.L, self.L.dmvio_hip_ba_get_frame(self.p, k, _d(p), _d(a), _d(s)), "ba_get_frame"); return p, a, s
+
+    def gn_iteration(self, iteration, lam, lastE):
+        l = C.c_double(lam); e = np.array(lastE, dtype=np.float64); acc = C.c_int(0)
+        _chk(self.L, self.L.dmvio_hip_ba_gn_iteration(self.p, iteration, C.byref(l), _d(e), C.byref(acc)), "ba_gn_iteration")
+        return bool(acc.value), l.value, e
+
+    def optimize(self, its=6):
+        rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))
+        _chk(self.L, self.L.dmvio_hip_ba_optimize(self.p, its, C.byref(rm), C.byref(fe), C.byref(it), _d(tr)), "ba_optimize")
+        return dict(rmse=rm.value, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])

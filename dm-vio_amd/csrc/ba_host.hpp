@@ -1,0 +1,344 @@
+// Host side of the BA path of libdmvio_hip: window state the reference keeps in FrameHessian / CalibHessian / EFFrame, the
+// tiny dense algebra around the kernels (precalc tables, adjoints, nullspaces, damped Jacobi-scaled LDLT, orthogonalisation,
+// step application, accept / reject) and the FullSystem::optimize loop driving the kernels of ba_kernels.hpp.
+//
+// Reference interfaces mirrored here (all under src/dso/):
+//   FrameHessian::setState / setStateZero / setEvalPT / getPrior   FullSystem/HessianBlocks.h:179-299, HessianBlocks.cpp:74-107
+//   CalibHessian::setValue                                         FullSystem/HessianBlocks.h:356-372
+//   FrameFramePrecalc::set, FullSystem::setPrecalcValues           FullSystem/HessianBlocks.cpp:193-223, FullSystem.cpp:1670-1680
+//   EnergyFunctional::setAdjointsF / solveSystemF / orthogonalize / resubstituteF_MT / calcLEnergyF_MT / calcMEnergyF
+//                                                                  OptimizationBackend/EnergyFunctional.cpp:48-108,784-996,267-431
+//   FullSystem::getNullspaces / linearizeAll / setNewFrameEnergyTH / doStepFromBackup / backupState / loadSateBackup / optimize
+//                                                                  FullSystem/FullSystemOptimize.cpp:96-218,224-388,417-647,704-758
+// In a drop-in integration the reference's own host code keeps doing this part and calls the kernel-level entry points
+// (dmvio_hip_ba_linearize / _accumulate / _resubstitute); dmvio_hip_ba_optimize exists so the whole loop can be verified
+// against the oracle and timed end to end.
+#pragma once
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include "common.h"
+#include "lie_dev.h"
+#include "ba_kernels.hpp"
+
+namespace dmv {
+
+struct BASettingsHost {
+  float huberTH = 9, outlierTHSumComponent = 50 * 50, idepthFixPrior = 50 * 50;
+  float initialRotPrior = 1e11f, initialTransPrior = 1e10f, initialAffBPrior = 1e14f, initialAffAPrior = 1e14f, initialCalibHessian = 5e9f;
+  float affineOptModeA = 1e12f, affineOptModeB = 1e8f;
+  float frameEnergyTHConstWeight = 0.5f, frameEnergyTHN = 0.7f, frameEnergyTHFacMedian = 1.5f, overallEnergyTHWeight = 1;
+  float thOptIterations = 1.2f;
+  int minOptIterations = 1;
+  double solverModeDelta = 0.00001;
+};
+
+struct BAFrameHost {
+  Pose evalPT, w2c, c2w;
+  double state[10], state_zero[10], state_scaled[10], step[10], state_backup[10];
+  float ab_exposure = 1, frameEnergyTH = 8 * 8 * 8;
+  int frameID = 0, slot = 0;
+  double ns_pose[6][6], ns_scale[6];
+  double prior[8], delta[8], delta_prior[8];
+};
+
+// log of an SE3 element (se3.hpp:560-586, so3.hpp:497-540) — host only (nullspace construction)
+inline void poseLogHost(const Pose& T, double out[6]) {
+  const double n2 = T.q.x * T.q.x + T.q.y * T.q.y + T.q.z * T.q.z, n = std::sqrt(n2), w = T.q.w;
+  double f;
+  if (n < 1e-10) f = 2.0 / w - 2.0 * n2 / (w * w * w);
+  else if (std::fabs(w) < 1e-10) f = (w > 0 ? M_PI : -M_PI) / n;
+  else f = 2.0 * std::atan(n / w) / n;
+  const double theta = f * n;
+  out[3] = f * T.q.x; out[4] = f * T.q.y; out[5] = f * T.q.z;
+  const double O[9] = {0, -out[5], out[4], out[5], 0, -out[3], -out[4], out[3], 0};
+  double O2[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+  const double c = std::fabs(theta) < 1e-10 ? 1.0 / 12.0 : (1.0 - theta / (2.0 * std::tan(theta / 2.0))) / (theta * theta);
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int j = 0; j < 3; j++) s += (((i == j) ? 1.0 : 0.0) - 0.5 * O[i * 3 + j] + c * O2[i * 3 + j]) * T.t[j];
+    out[i] = s;
+  }
+}
+
+struct BAHost {
+  BASettingsHost S;
+  int w = 0, h = 0, F = 0, N = 0, R = 0;
+  double c_value[4], c_value_zero[4], c_value_scaled[4], c_step[4], c_value_backup[4], c_vmz[4];
+  float c_f[4], c_i[4];
+  BAFrameHost fr[BA_MAXF];
+  std::vector<double> adHost, adTarget;      // F*F x 64, index h + t*F
+  std::vector<float> adHostF, adTargetF;
+  std::vector<BAPrecalc> pre;                // F*F, index h + F*t
+  float cDeltaF[4], cPriorF[4];
+  double cPrior[4];
+  std::vector<double> HM, bM, lastX;
+  std::vector<std::vector<double>> nsp;      // 7 nullspace vectors
+  int resInA = 0;
+
+  void calibSetValue(const double v[4]) {
+    for (int i = 0; i < 4; i++) c_value[i] = v[i];
+    c_value_scaled[0] = 50.0f * v[0]; c_value_scaled[1] = 50.0f * v[1]; c_value_scaled[2] = 50.0f * v[2]; c_value_scaled[3] = 50.0f * v[3];
+    for (int i = 0; i < 4; i++) c_f[i] = (float)c_value_scaled[i];
+    c_i[0] = 1.0f / c_f[0]; c_i[1] = 1.0f / c_f[1]; c_i[2] = -c_f[2] / c_f[0]; c_i[3] = -c_f[3] / c_f[1];
+    for (int i = 0; i < 4; i++) c_vmz[i] = c_value[i] - c_value_zero[i];
+  }
+  void calibInitScaled(const double vs[4]) {
+    const float inv = 1.0f / 50.0f;
+    for (int i = 0; i < 4; i++) { c_value_scaled[i] = vs[i]; c_f[i] = (float)vs[i]; c_value[i] = inv * vs[i]; }
+    c_i[0] = 1.0f / c_f[0]; c_i[1] = 1.0f / c_f[1]; c_i[2] = -c_f[2] / c_f[0]; c_i[3] = -c_f[3] / c_f[1];
+    for (int i = 0; i < 4; i++) { c_value_zero[i] = c_value[i]; c_vmz[i] = 0; c_step[i] = 0; c_value_backup[i] = c_value[i]; }
+  }
+  static void frameSetState(BAFrameHost& f, const double st[10]) {
+    for (int i = 0; i < 10; i++) f.state[i] = st[i];
+    for (int i = 0; i < 6; i++) f.state_scaled[i] = 1.0f * st[i];
+    f.state_scaled[6] = 10.0f * st[6]; f.state_scaled[7] = 1000.0f * st[7]; f.state_scaled[8] = 10.0f * st[8]; f.state_scaled[9] = 1000.0f * st[9];
+    f.w2c = poseMul(poseExp(f.state_scaled), f.evalPT);
+    f.c2w = poseInv(f.w2c);
+  }
+  static void frameSetStateZero(BAFrameHost& f, const double st0[10]) {
+    for (int i = 0; i < 10; i++) f.state_zero[i] = st0[i];
+    const Pose Tinv = poseInv(f.evalPT);
+    for (int i = 0; i < 6; i++) {
+      double ep[6] = {0, 0, 0, 0, 0, 0}, em[6] = {0, 0, 0, 0, 0, 0};
+      ep[i] = 1e-3; em[i] = -1e-3;
+      double lp[6], lm[6];
+      poseLogHost(poseMul(poseMul(f.evalPT, poseExp(ep)), Tinv), lp);
+      poseLogHost(poseMul(poseMul(f.evalPT, poseExp(em)), Tinv), lm);
+      for (int r = 0; r < 6; r++) f.ns_pose[r][i] = (lp[r] - lm[r]) / (2e-3);
+    }
+    Pose P = f.evalPT, M = f.evalPT;
+    for (int i = 0; i < 3; i++) { P.t[i] *= 1.00001; M.t[i] /= 1.00001; }
+    double lp[6], lm[6];
+    poseLogHost(poseMul(P, Tinv), lp); poseLogHost(poseMul(M, Tinv), lm);
+    for (int r = 0; r < 6; r++) f.ns_scale[r] = (lp[r] - lm[r]) / (2e-3);
+  }
+  void frameTakeData(BAFrameHost& f) const {
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (f.frameID == 0) {
+      for (int i = 0; i < 3; i++) p[i] = S.initialTransPrior;
+      for (int i = 3; i < 6; i++) p[i] = S.initialRotPrior;
+      p[6] = S.initialAffAPrior; p[7] = S.initialAffBPrior;
+    } else {
+      p[6] = S.affineOptModeA < 0 ? S.initialAffAPrior : S.affineOptModeA;
+      p[7] = S.affineOptModeB < 0 ? S.initialAffBPrior : S.affineOptModeB;
+    }
+    for (int i = 0; i < 8; i++) { f.prior[i] = p[i]; f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+  }
+
+  static void m33f(const float* A, const float* B, float* C) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3 + 0] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+  }
+  void setPrecalcValues() {
+    pre.resize((size_t)F * F);
+    const float K[9] = {c_f[0], 0, c_f[2], 0, c_f[1], c_f[3], 0, 0, 1};
+    const float a = K[0], e = K[4], c = K[2], ff = K[5];
+    const float det = a * (e * 1.0f - ff * 0.0f), invdet = 1.0f / det;
+    const float Ki[9] = {(e * 1.0f - ff * 0.0f) * invdet, (c * 0.0f - 0.0f * 1.0f) * invdet, (0.0f * ff - c * e) * invdet,
+                         (ff * 0.0f - 0.0f * 1.0f) * invdet, (a * 1.0f - c * 0.0f) * invdet, (c * 0.0f - a * ff) * invdet,
+                         (0.0f * 0.0f - e * 0.0f) * invdet, (0.0f * 0.0f - a * 0.0f) * invdet, (a * e - 0.0f * 0.0f) * invdet};
+    for (int hh = 0; hh < F; hh++)
+      for (int t = 0; t < F; t++) {
+        BAPrecalc& pc = pre[(size_t)hh + (size_t)F * t];
+        const Pose l0 = poseMul(fr[t].evalPT, poseInv(fr[hh].evalPT));
+        double Rd[9];
+        quatToR(l0.q, Rd);
+        for (int i = 0; i < 9; i++) pc.R0[i] = (float)Rd[i];
+        for (int i = 0; i < 3; i++) pc.t0[i] = (float)l0.t[i];
+        const Pose l = poseMul(fr[t].w2c, fr[hh].c2w);
+        quatToR(l.q, Rd);
+        float Rf[9], tf[3], KR[9];
+        for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+        for (int i = 0; i < 3; i++) tf[i] = (float)l.t[i];
+        m33f(K, Rf, KR);
+        m33f(KR, Ki, pc.KRKi);
+        for (int r = 0; r < 3; r++) pc.Kt[r] = K[r * 3 + 0] * tf[0] + K[r * 3 + 1] * tf[1] + K[r * 3 + 2] * tf[2];
+        double aff[2];
+        affFromToHost(fr[hh].ab_exposure, fr[t].ab_exposure, fr[hh].state_scaled[6], fr[hh].state_scaled[7], fr[t].state_scaled[6], fr[t].state_scaled[7], aff);
+        pc.aff0 = (float)aff[0]; pc.aff1 = (float)aff[1];
+        pc.b0 = (float)(fr[hh].state_zero[7] * 1000.0f);
+        pc.pad = 0;
+      }
+    // setDeltaF: frame deltas (the kernels recompute the per-point deltaF = idepth - idepth_zero themselves)
+    for (int i = 0; i < 4; i++) cDeltaF[i] = (float)c_vmz[i];
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { fr[f].delta[i] = fr[f].state[i] - fr[f].state_zero[i]; fr[f].delta_prior[i] = fr[f].state[i]; }
+  }
+  // AffLight::fromToVecExposure with the C library's exp: the brightness transfer enters every residual, and the reference
+  // evaluates it with std::exp (NumType.h:183).
+  static void affFromToHost(float eF, float eT, double aF, double bF, double aT, double bT, double out[2]) {
+    if (eF == 0 || eT == 0) { eT = eF = 1; }
+    const double a = std::exp(aT - aF) * eT / eF;
+    out[0] = a; out[1] = bT - a * bF;
+  }
+  void setAdjointsF() {
+    adHost.assign((size_t)F * F * 64, 0); adTarget.assign((size_t)F * F * 64, 0);
+    adHostF.assign((size_t)F * F * 64, 0); adTargetF.assign((size_t)F * F * 64, 0);
+    for (int hh = 0; hh < F; hh++)
+      for (int t = 0; t < F; t++) {
+        const Pose hostToTarget = poseMul(fr[t].evalPT, poseInv(fr[hh].evalPT));
+        double Adj[36];
+        poseAdj(hostToTarget, Adj);
+        double AH[64], AT[64];
+        for (int i = 0; i < 64; i++) { AH[i] = 0; AT[i] = 0; }
+        for (int i = 0; i < 8; i++) { AH[i * 8 + i] = 1; AT[i * 8 + i] = 1; }
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) AH[r * 8 + c] = -Adj[c * 6 + r];
+        double aff[2];
+        affFromToHost(fr[hh].ab_exposure, fr[t].ab_exposure, fr[hh].state_zero[6] * 10.0f, fr[hh].state_zero[7] * 1000.0f,
+                      fr[t].state_zero[6] * 10.0f, fr[t].state_zero[7] * 1000.0f, aff);
+        const float a0 = (float)aff[0];
+        AT[6 * 8 + 6] = -a0; AH[6 * 8 + 6] = a0; AT[7 * 8 + 7] = -1; AH[7 * 8 + 7] = a0;
+        const float rs[8] = {1, 1, 1, 1, 1, 1, 10.0f, 1000.0f};
+        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { AH[r * 8 + c] *= rs[r]; AT[r * 8 + c] *= rs[r]; }
+        const size_t o = ((size_t)hh + (size_t)t * F) * 64;
+        for (int i = 0; i < 64; i++) { adHost[o + i] = AH[i]; adTarget[o + i] = AT[i]; adHostF[o + i] = (float)AH[i]; adTargetF[o + i] = (float)AT[i]; }
+      }
+    for (int i = 0; i < 4; i++) { cPrior[i] = S.initialCalibHessian; cPriorF[i] = (float)cPrior[i]; }
+  }
+
+  int n() const { return 4 + 8 * F; }
+  void getNullspaces() {
+    nsp.assign(7, std::vector<double>(n(), 0.0));
+    for (int i = 0; i < 6; i++) for (int f = 0; f < F; f++) for (int r = 0; r < 6; r++) nsp[i][4 + f * 8 + r] = fr[f].ns_pose[r][i];
+    for (int f = 0; f < F; f++) for (int r = 0; r < 6; r++) nsp[6][4 + f * 8 + r] = fr[f].ns_scale[r];
+  }
+  // x -= N N^+ x : orthonormal basis of span(N) by modified Gram-Schmidt with re-orthogonalisation and the reference's
+  // relative singular-value cut (EnergyFunctional.cpp:812-824), evaluated through the Gram matrix's Jacobi eigen-decomposition
+  void orthogonalize(std::vector<double>& x) const {
+    const int nn = n(), m = 7;
+    std::vector<std::vector<double>> U(m);
+    for (int i = 0; i < m; i++) { double s = 0; for (double v : nsp[i]) s += v * v; s = std::sqrt(s); U[i] = nsp[i]; for (auto& v : U[i]) v /= s; }
+    // G = U^T U (7x7), Jacobi eigenvalue iteration: G = V diag(s^2) V^T
+    double G[7][7], V[7][7];
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) { double s = 0; for (int k = 0; k < nn; k++) s += U[i][k] * U[j][k]; G[i][j] = s; V[i][j] = i == j ? 1 : 0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+      double off = 0;
+      for (int p = 0; p < m; p++) for (int q = p + 1; q < m; q++) off += G[p][q] * G[p][q];
+      if (off < 1e-30) break;
+      for (int p = 0; p < m; p++)
+        for (int q = p + 1; q < m; q++) {
+          if (std::fabs(G[p][q]) < 1e-300) continue;
+          const double theta = (G[q][q] - G[p][p]) / (2 * G[p][q]);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+          const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+          for (int k = 0; k < m; k++) { const double gkp = G[k][p], gkq = G[k][q]; G[k][p] = c * gkp - s * gkq; G[k][q] = s * gkp + c * gkq; }
+          for (int k = 0; k < m; k++) { const double gpk = G[p][k], gqk = G[q][k]; G[p][k] = c * gpk - s * gqk; G[q][k] = s * gpk + c * gqk; }
+          for (int k = 0; k < m; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+        }
+    }
+    double maxSv = 0;
+    double sv[7];
+    for (int i = 0; i < m; i++) { sv[i] = std::sqrt(std::max(G[i][i], 0.0)); maxSv = std::max(maxSv, sv[i]); }
+    std::vector<double> proj(nn, 0.0);
+    for (int i = 0; i < m; i++) {
+      if (!(sv[i] > S.solverModeDelta * maxSv)) continue;
+      // left singular vector u_i = U V_i / s_i
+      std::vector<double> u(nn, 0.0);
+      for (int j = 0; j < m; j++) for (int k = 0; k < nn; k++) u[k] += U[j][k] * V[j][i];
+      double dot = 0;
+      for (int k = 0; k < nn; k++) { u[k] /= sv[i]; dot += u[k] * x[k]; }
+      for (int k = 0; k < nn; k++) proj[k] += u[k] * dot;
+    }
+    for (int k = 0; k < nn; k++) x[k] -= proj[k];
+  }
+
+  // EnergyFunctional::solveSystemF after the accumulations: HA,bA / Hsc,bsc come from the device; priors (accumulateLF with no
+  // linearised residuals) and the marginalisation prior are added here.
+  void solveSystem(int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, std::vector<double>& x) {
+    const int nn = n();
+    std::vector<double> HF((size_t)nn * nn), bF(nn);
+    std::vector<double> d(nn);
+    for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
+    for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = HM[i] + HA[i];
+    for (int i = 0; i < nn; i++) { double s = bM[i]; for (int j = 0; j < nn; j++) s += HM[(size_t)i * nn + j] * d[j]; bF[i] = s + bA[i] - bsc[i]; }
+    // HL_top / bL_top = priors (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302)
+    for (int i = 0; i < 4; i++) { HF[(size_t)i * nn + i] += cPrior[i]; bF[i] += cPrior[i] * (double)cDeltaF[i]; }
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HF[(size_t)q * nn + q] += fr[f].prior[i]; bF[q] += fr[f].prior[i] * fr[f].delta_prior[i]; }
+    for (int i = 0; i < nn; i++) HF[(size_t)i * nn + i] *= (1 + lambda);
+    const double fac = 1.0f / (1 + lambda);
+    for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] -= Hsc[i] * fac;
+    std::vector<double> sv(nn), Hs((size_t)nn * nn), bs(nn);
+    for (int i = 0; i < nn; i++) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * nn + i] + 10);
+    for (int i = 0; i < nn; i++) { for (int j = 0; j < nn; j++) Hs[(size_t)i * nn + j] = sv[i] * HF[(size_t)i * nn + j] * sv[j]; bs[i] = sv[i] * bF[i]; }
+    ldltSolveInPlace<4 + 8 * BA_MAXF>(Hs.data(), nn, bs.data(), nn);
+    x.resize(nn);
+    for (int i = 0; i < nn; i++) x[i] = sv[i] * bs[i];
+    if (iteration >= 2) orthogonalize(x);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:81)
+    lastX = x;
+  }
+  // xc (4) and xAd (F*F x 8, index h*F + t) of resubstituteF_MT; frame / calib steps
+  void prepareResubstitute(const std::vector<double>& x, float xc[4], std::vector<float>& xAd) {
+    const int nn = n();
+    std::vector<float> xF(nn);
+    for (int i = 0; i < nn; i++) xF[i] = (float)x[i];
+    for (int i = 0; i < 4; i++) { c_step[i] = -x[i]; xc[i] = xF[i]; }
+    xAd.assign((size_t)F * F * 8, 0.f);
+    for (int hh = 0; hh < F; hh++) {
+      for (int i = 0; i < 8; i++) fr[hh].step[i] = -x[4 + 8 * hh + i];
+      fr[hh].step[8] = fr[hh].step[9] = 0;
+      for (int t = 0; t < F; t++) {
+        const size_t o = ((size_t)hh + (size_t)F * t) * 64;
+        for (int c = 0; c < 8; c++) {
+          float s1 = 0, s2 = 0;
+          for (int r = 0; r < 8; r++) { s1 += xF[4 + 8 * hh + r] * adHostF[o + r * 8 + c]; s2 += xF[4 + 8 * t + r] * adTargetF[o + r * 8 + c]; }
+          xAd[((size_t)F * hh + t) * 8 + c] = s1 + s2;
+        }
+      }
+    }
+  }
+  double calcLEnergyFrames() const {
+    double E = 0;
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) E += fr[f].delta_prior[i] * fr[f].prior[i] * fr[f].delta_prior[i];
+    float ec = 0;
+    for (int i = 0; i < 4; i++) ec += cDeltaF[i] * cPriorF[i] * cDeltaF[i];
+    return E + ec;  // + sum_p deltaF^2 priorF, which is zero while idepth_zero follows idepth (doStepFromBackup) — added by the caller when not
+  }
+  double calcMEnergy() const {
+    const int nn = n();
+    std::vector<double> d(nn);
+    for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
+    double s = 0;
+    for (int i = 0; i < nn; i++) { double t = 2 * bM[i]; for (int j = 0; j < nn; j++) t += HM[(size_t)i * nn + j] * d[j]; s += d[i] * t; }
+    return s;
+  }
+  void backupFrames() {
+    for (int i = 0; i < 4; i++) c_value_backup[i] = c_value[i];
+    for (int f = 0; f < F; f++) for (int i = 0; i < 10; i++) fr[f].state_backup[i] = fr[f].state[i];
+  }
+  // frame / calib part of doStepFromBackup; returns the four frame sums (A, B, T, R) already divided by F
+  void stepFrames(float stepfac, float sums[4]) {
+    double nv[4];
+    for (int i = 0; i < 4; i++) nv[i] = c_value_backup[i] + stepfac * c_step[i];
+    calibSetValue(nv);
+    float sA = 0, sB = 0, sT = 0, sR = 0;
+    for (int f = 0; f < F; f++) {
+      double st[10];
+      for (int i = 0; i < 10; i++) st[i] = fr[f].state_backup[i] + (double)stepfac * fr[f].step[i];
+      frameSetState(fr[f], st);
+      sA += fr[f].step[6] * fr[f].step[6]; sB += fr[f].step[7] * fr[f].step[7];
+      sT += fr[f].step[0] * fr[f].step[0] + fr[f].step[1] * fr[f].step[1] + fr[f].step[2] * fr[f].step[2];
+      sR += fr[f].step[3] * fr[f].step[3] + fr[f].step[4] * fr[f].step[4] + fr[f].step[5] * fr[f].step[5];
+    }
+    sums[0] = sA / F; sums[1] = sB / F; sums[2] = sT / F; sums[3] = sR / F;
+  }
+  void restoreFrames() {
+    calibSetValue(c_value_backup);
+    for (int f = 0; f < F; f++) frameSetState(fr[f], fr[f].state_backup);
+  }
+  float newFrameEnergyTH(std::vector<float>& allResVec) const {
+    if (allResVec.empty()) return 12 * 12 * 8;
+    const int nthIdx = (int)(S.frameEnergyTHN * allResVec.size());
+    std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+    const float nthElement = sqrtf(allResVec[nthIdx]);
+    float th = nthElement * S.frameEnergyTHFacMedian;
+    th = 26.0f * S.frameEnergyTHConstWeight + th * (1 - S.frameEnergyTHConstWeight);
+    th = th * th;
+    th *= S.overallEnergyTHWeight * S.overallEnergyTHWeight;
+    return th;
+  }
+};
+
+}  // namespace dmv

@@ -18,30 +18,7 @@
 
 using namespace dmv;
 
-static thread_local std::string g_err;
-static int fail(const char* what, const char* file, int line, hipError_t e) {
-  char buf[512];
-  snprintf(buf, sizeof(buf), "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
-  g_err = buf;
-  return -1;
-}
-static int failmsg(const std::string& m) { g_err = m; return -2; }
-#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, __FILE__, __LINE__, _e); } while (0)
-#define HIPCHKP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fail(#x, __FILE__, __LINE__, _e); return nullptr; } } while (0)
-
-struct dmvio_hip_ctx {
-  int device = 0, w = 0, h = 0, levels = 0, n_slots = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  FrameStore fs{};
-  float* d_upload = nullptr;  // staging for host uploads (w*h)
-  float* d_f3 = nullptr;      // download scratch (w*h*3)
-  PyrGeom pg{};
-  int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
-  int *d_slots = nullptr, *h_slots = nullptr;
-  int slots_cap = 0, slots_valid = 0;
-  std::mutex mu;
-};
+#include "internal.h"
 
 struct dmvio_hip_tracker {
   dmvio_hip_ctx* ctx = nullptr;
@@ -66,9 +43,11 @@ struct dmvio_hip_tracker {
   int lm_threads_override = 0, lm_waves_override = 0;
 };
 
+std::string& dmv_err() { static thread_local std::string e; return e; }
+
 extern "C" {
 
-const char* dmvio_hip_last_error(void) { return g_err.c_str(); }
+const char* dmvio_hip_last_error(void) { return dmv_err().c_str(); }
 
 int dmvio_hip_device_count(void) {
   int n = 0;

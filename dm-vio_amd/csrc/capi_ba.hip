@@ -1,0 +1,523 @@
+// libdmvio_hip.so — C ABI of the bundle-adjustment path (include/dmvio_hip.h, "sliding-window BA" section).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/dmvio_hip.h"
+#include "internal.h"
+#include "ba_kernels.hpp"
+#include "ba_host.hpp"
+
+using namespace dmv;
+
+struct dmvio_hip_ba {
+  dmvio_hip_ctx* ctx = nullptr;
+  BAHost H;
+  BAWindow W{};
+  BAPoints P{};
+  BARes Rs{};
+  // host copies of the graph
+  std::vector<int> h_host, h_point, h_target, h_res_begin;
+  std::vector<unsigned char> h_prior_flag;
+  // device storage
+  std::vector<void*> allocs;
+  BAPrecalc* d_pre = nullptr;
+  double *d_adHost = nullptr, *d_adTarget = nullptr;
+  int *d_top_begin = nullptr, *d_top_members = nullptr, *d_scd_begin = nullptr, *d_scd_members = nullptr;
+  float *d_accTop = nullptr, *d_accD = nullptr, *d_accE = nullptr, *d_accC = nullptr;
+  int *d_numTop = nullptr, *d_numD = nullptr;
+  StitchBufs SB{};
+  double *d_sys = nullptr, *h_sys = nullptr;     // [H_A | b_A | H_sc | b_sc]
+  double *d_epart = nullptr, *h_epart = nullptr;  // linearize energy partials
+  float *d_spart = nullptr, *h_spart = nullptr;  // point-step partial sums
+  float *d_xc = nullptr, *d_xAd = nullptr;
+  float *h_newEnergyWO = nullptr;
+  float* d_fullJ = nullptr;
+  int n_lin_blocks = 0, n_pt_blocks = 0;
+  bool graph_ready = false;
+  // energies of the last optimize
+  double trace[64][4];
+  int iterations_done = 0;
+  double final_energy = 0;
+};
+
+template <class T>
+static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
+  HIPCHK(hipMemset(*p, 0, sizeof(T) * std::max<size_t>(n, 1)));
+  b->allocs.push_back((void*)*p);
+  return 0;
+}
+static void freeDevice(dmvio_hip_ba* b) {
+  for (void* p : b->allocs) hipFree(p);
+  b->allocs.clear();
+  if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
+  if (b->h_epart) { hipHostFree(b->h_epart); b->h_epart = nullptr; }
+  if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
+  if (b->h_newEnergyWO) { hipHostFree(b->h_newEnergyWO); b->h_newEnergyWO = nullptr; }
+  b->graph_ready = false;
+}
+
+static int uploadWindowTables(dmvio_hip_ba* b) {
+  dmvio_hip_ctx* c = b->ctx;
+  BAHost& H = b->H;
+  BAWindow& W = b->W;
+  W.F = H.F; W.w = H.w; W.h = H.h; W.N = H.N; W.R = H.R;
+  W.fx = H.c_f[0]; W.fy = H.c_f[1]; W.cx = H.c_f[2]; W.cy = H.c_f[3];
+  W.fxi = H.c_i[0]; W.fyi = H.c_i[1]; W.cxi = H.c_i[2]; W.cyi = H.c_i[3];
+  W.wM3 = H.w - 3; W.hM3 = H.h - 3;
+  W.huberTH = H.S.huberTH; W.outlierTHSum = H.S.outlierTHSumComponent; W.modeA = H.S.affineOptModeA; W.modeB = H.S.affineOptModeB;
+  for (int f = 0; f < H.F; f++) { W.slot[f] = H.fr[f].slot; W.frameEnergyTH[f] = H.fr[f].frameEnergyTH; }
+  HIPCHK(hipMemcpyAsync(b->d_pre, H.pre.data(), sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+static int uploadAdjoints(dmvio_hip_ba* b) {
+  dmvio_hip_ctx* c = b->ctx;
+  HIPCHK(hipMemcpyAsync(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+// FullSystem::linearizeAll (FullSystemOptimize.cpp:150-218) — returns the energy sum; updates the newest frame's energy threshold
+static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
+  dmvio_hip_ctx* c = b->ctx;
+  BAHost& H = b->H;
+  if (int r = uploadWindowTables(b)) return r;  // precalc + frameEnergyTH of the current state
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, c->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ);
+  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, c->stream, H.R, b->Rs);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(b->h_newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * H.R, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double e = 0;
+  for (int i = 0; i < b->n_lin_blocks; i++) e += b->h_epart[i];
+  *energy = e;
+  // setNewFrameEnergyTH (FullSystemOptimize.cpp:96-149)
+  std::vector<float> all;
+  all.reserve(H.R);
+  for (int ri = 0; ri < H.R; ri++) if (b->h_newEnergyWO[ri] >= 0 && b->h_target[ri] == H.F - 1) all.push_back(b->h_newEnergyWO[ri]);
+  H.fr[H.F - 1].frameEnergyTH = H.newFrameEnergyTH(all);
+  return 0;
+}
+static int applyRes(dmvio_hip_ba* b) {
+  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->ctx->stream, b->H.R, b->Rs);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
+static int accumulate(dmvio_hip_ba* b) {
+  dmvio_hip_ctx* c = b->ctx;
+  BAHost& H = b->H;
+  const int F = H.F, F2 = F * F, n = H.n();
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, s, b->W, b->P, b->Rs);
+  hipLaunchKernelGGL(k_ba_accum_top, dim3(F2), dim3(128), 0, s, b->W, b->Rs, b->d_top_begin, b->d_top_members, b->d_accTop, b->d_numTop);
+  hipLaunchKernelGGL(k_ba_accum_scD, dim3(F2 * F), dim3(64), 0, s, b->Rs, b->P, b->d_scd_begin, b->d_scd_members, b->d_accD, b->d_numD);
+  hipLaunchKernelGGL(k_ba_accum_scE, dim3(F2), dim3(64), 0, s, b->Rs, b->P, b->d_top_begin, b->d_top_members, b->d_accE);
+  hipLaunchKernelGGL(k_ba_accum_scC, dim3(1), dim3(64), 0, s, H.N, b->P, b->d_accC);
+  hipLaunchKernelGGL(k_ba_stitch_top, dim3(F2), dim3(64), 0, s, F, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
+  hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2 * F), dim3(64), 0, s, F, b->d_accD, b->d_numD, b->d_adHost, b->d_adTarget, b->SB);
+  hipLaunchKernelGGL(k_ba_stitch_scE, dim3(F2), dim3(64), 0, s, F, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
+  const int tot = 2 * (n * n + n);
+  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 255) / 256), dim3(256), 0, s, F, b->d_accTop, b->d_numTop, b->d_accC, b->SB, b->d_sys);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(b->h_sys, b->d_sys, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_numTop, sizeof(int) * F2, hipMemcpyDeviceToHost, s));  // reuse pinned scratch for the counts
+  HIPCHK(hipStreamSynchronize(s));
+  int res = 0;
+  const int* cnt = (const int*)b->h_epart;
+  for (int k = 0; k < F2; k++) res += cnt[k];
+  H.resInA = res;
+  return 0;
+}
+static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
+  dmvio_hip_ctx* c = b->ctx;
+  float xc[4];
+  std::vector<float> xAd;
+  b->H.prepareResubstitute(x, xc, xAd);
+  HIPCHK(hipMemcpyAsync(b->d_xc, xc, sizeof(xc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b->d_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // xc / xAd are stack / vector storage
+  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int pointStep(dmvio_hip_ba* b, int mode, float fac, float* sumID, float* sumNID) {
+  dmvio_hip_ctx* c = b->ctx;
+  hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->H.N, b->P, mode, fac, b->d_spart);
+  HIPCHK(hipGetLastError());
+  if (mode == 1) {
+    HIPCHK(hipMemcpyAsync(b->h_spart, b->d_spart, sizeof(float) * 2 * b->n_pt_blocks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float a = 0, d = 0;
+    for (int i = 0; i < b->n_pt_blocks; i++) { a += b->h_spart[2 * i]; d += b->h_spart[2 * i + 1]; }
+    *sumID = a / b->H.N; *sumNID = d / b->H.N;
+  }
+  return 0;
+}
+
+extern "C" {
+
+dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
+  if (!ctx) { failmsg("ba_create: null ctx"); return nullptr; }
+  dmvio_hip_ba* b = new dmvio_hip_ba();
+  b->ctx = ctx;
+  b->H.w = ctx->w; b->H.h = ctx->h;
+  return b;
+}
+void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  freeDevice(b);
+  delete b;
+}
+
+int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
+                            const int* frameIDs, const double fxfycxcy[4]) {
+  if (!b || !slots || !pose7_w2c || !fxfycxcy) return failmsg("ba_set_window: null argument");
+  if (F < 1 || F > BA_MAXF) return failmsg("ba_set_window: 1 <= F <= 8");
+  BAHost& H = b->H;
+  H.F = F;
+  H.calibInitScaled(fxfycxcy);
+  for (int f = 0; f < F; f++) {
+    if (slots[f] < 0 || slots[f] >= b->ctx->n_slots) return failmsg("ba_set_window: frame slot out of range");
+    BAFrameHost& fr = H.fr[f];
+    fr = BAFrameHost();
+    fr.slot = slots[f];
+    fr.ab_exposure = exposures ? exposures[f] : 1.0f;
+    fr.frameID = frameIDs ? frameIDs[f] : f;
+    fr.evalPT = poseFrom7(pose7_w2c + 7 * f);
+    const double a = aff_ab ? aff_ab[2 * f] : 0.0, bb = aff_ab ? aff_ab[2 * f + 1] : 0.0;
+    double st[10] = {0, 0, 0, 0, 0, 0, (1.0f / 10.0f) * a, (1.0f / 1000.0f) * bb, 0, 0};   // setEvalPT_scaled (HessianBlocks.h:220-227)
+    for (int i = 0; i < 10; i++) { fr.step[i] = 0; fr.state_backup[i] = 0; }
+    BAHost::frameSetState(fr, st);
+    BAHost::frameSetStateZero(fr, fr.state);
+  }
+  const int n = H.n();
+  H.HM.assign((size_t)n * n, 0.0); H.bM.assign(n, 0.0);
+  for (int f = 0; f < F; f++) H.frameTakeData(H.fr[f]);
+  H.setAdjointsF();
+  H.setPrecalcValues();
+  b->graph_ready = false;
+  return 0;
+}
+
+int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double* bM) {
+  if (!b || !HM || !bM) return failmsg("ba_set_marg_prior: null argument");
+  const int n = b->H.n();
+  b->H.HM.assign(HM, HM + (size_t)n * n); b->H.bM.assign(bM, bM + n);
+  return 0;
+}
+
+int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
+                           const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
+  if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
+  BAHost& H = b->H;
+  if (H.F < 1) return failmsg("ba_set_graph: set_window first");
+  if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
+  dmvio_hip_ctx* c = b->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  freeDevice(b);
+  const int F = H.F, F2 = F * F;
+  H.N = N; H.R = R;
+  b->h_host.assign(host, host + N); b->h_point.assign(res_point, res_point + R); b->h_target.assign(res_target, res_target + R);
+  // residuals must be grouped by point, points in window order
+  b->h_res_begin.assign(N + 1, 0);
+  for (int ri = 0; ri < R; ri++) {
+    const int p = res_point[ri];
+    if (p < 0 || p >= N || res_target[ri] < 0 || res_target[ri] >= F) return failmsg("ba_set_graph: residual index out of range");
+    if (ri > 0 && p < res_point[ri - 1]) return failmsg("ba_set_graph: residuals must be sorted by point");
+    if (host[p] < 0 || host[p] >= F || host[p] == res_target[ri]) return failmsg("ba_set_graph: bad host / target");
+    b->h_res_begin[p + 1]++;
+  }
+  for (int p = 0; p < N; p++) b->h_res_begin[p + 1] += b->h_res_begin[p];
+  // bucket member lists in the reference's traversal order (points, then residuals of the point)
+  std::vector<int> top_begin(F2 + 1, 0), top_members(R), scd_begin(F2 * F + 1, 0);
+  for (int ri = 0; ri < R; ri++) top_begin[host[res_point[ri]] + F * res_target[ri] + 1]++;
+  for (int k = 0; k < F2; k++) top_begin[k + 1] += top_begin[k];
+  { std::vector<int> cur(top_begin.begin(), top_begin.end() - 1); for (int ri = 0; ri < R; ri++) top_members[cur[host[res_point[ri]] + F * res_target[ri]]++] = ri; }
+  size_t npairs = 0;
+  for (int p = 0; p < N; p++) { const size_t k = b->h_res_begin[p + 1] - b->h_res_begin[p]; npairs += k * k; }
+  std::vector<int> scd_members(3 * npairs);
+  for (int p = 0; p < N; p++)
+    for (int r1 = b->h_res_begin[p]; r1 < b->h_res_begin[p + 1]; r1++)
+      for (int r2 = b->h_res_begin[p]; r2 < b->h_res_begin[p + 1]; r2++) scd_begin[(host[p] + F * res_target[r1]) + res_target[r2] * F2 + 1]++;
+  for (int k = 0; k < F2 * F; k++) scd_begin[k + 1] += scd_begin[k];
+  {
+    std::vector<int> cur(scd_begin.begin(), scd_begin.end() - 1);
+    for (int p = 0; p < N; p++)
+      for (int r1 = b->h_res_begin[p]; r1 < b->h_res_begin[p + 1]; r1++)
+        for (int r2 = b->h_res_begin[p]; r2 < b->h_res_begin[p + 1]; r2++) {
+          const int k = (host[p] + F * res_target[r1]) + res_target[r2] * F2;
+          const int o = cur[k]++;
+          scd_members[3 * o] = r1; scd_members[3 * o + 1] = r2; scd_members[3 * o + 2] = p;
+        }
+  }
+  // ---- device arrays
+  int *d_host, *d_res_begin, *d_point, *d_target;
+  float *d_u, *d_v, *d_color, *d_weights, *d_prior;
+  if (dalloc(b, &d_host, N) || dalloc(b, &d_res_begin, N + 1) || dalloc(b, &d_point, R) || dalloc(b, &d_target, R) || dalloc(b, &d_u, N) || dalloc(b, &d_v, N) ||
+      dalloc(b, &d_color, (size_t)N * 8) || dalloc(b, &d_weights, (size_t)N * 8) || dalloc(b, &d_prior, N)) return -1;
+  BAPoints& P = b->P; BARes& Rs = b->Rs;
+  if (dalloc(b, &P.idepth, N) || dalloc(b, &P.idepth_zero, N) || dalloc(b, &P.idepth_backup, N) || dalloc(b, &P.step, N) || dalloc(b, &P.Hdd, N) || dalloc(b, &P.bd, N) ||
+      dalloc(b, &P.Hcd, (size_t)N * 4) || dalloc(b, &P.HdiF, N) || dalloc(b, &P.bdSumF, N)) return -1;
+  if (dalloc(b, &Rs.state, R) || dalloc(b, &Rs.newState, R) || dalloc(b, &Rs.active, R) || dalloc(b, &Rs.which, R) || dalloc(b, &Rs.energy, R) || dalloc(b, &Rs.newEnergy, R) ||
+      dalloc(b, &Rs.newEnergyWO, R) || dalloc(b, &Rs.center, (size_t)R * 3) || dalloc(b, &Rs.rec[0], (size_t)R * REC_FLOATS) || dalloc(b, &Rs.rec[1], (size_t)R * REC_FLOATS)) return -1;
+  P.host = d_host; P.u = d_u; P.v = d_v; P.color = d_color; P.weights = d_weights; P.priorF = d_prior; P.res_begin = d_res_begin;
+  Rs.point = d_point; Rs.target = d_target;
+  std::vector<float> prior(N, 0.0f);
+  if (hasDepthPrior) for (int p = 0; p < N; p++) prior[p] = hasDepthPrior[p] ? H.S.idepthFixPrior : 0.0f;   // EFPoint::takeData
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(d_host, host, sizeof(int) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_point, res_point, sizeof(int) * R, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_target, res_target, sizeof(int) * R, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_u, u, sizeof(float) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_v, v, sizeof(float) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_color, color8, sizeof(float) * N * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_weights, weights8, sizeof(float) * N * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_prior, prior.data(), sizeof(float) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(P.idepth, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(P.idepth_zero, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
+  if (dalloc(b, &b->d_pre, F2) || dalloc(b, &b->d_adHost, (size_t)F2 * 64) || dalloc(b, &b->d_adTarget, (size_t)F2 * 64) || dalloc(b, &b->d_top_begin, F2 + 1) ||
+      dalloc(b, &b->d_top_members, R) || dalloc(b, &b->d_scd_begin, F2 * F + 1) || dalloc(b, &b->d_scd_members, 3 * npairs) || dalloc(b, &b->d_accTop, (size_t)F2 * 96) ||
+      dalloc(b, &b->d_accD, (size_t)F2 * F * 64) || dalloc(b, &b->d_accE, (size_t)F2 * 40) || dalloc(b, &b->d_accC, 32) || dalloc(b, &b->d_numTop, F2) || dalloc(b, &b->d_numD, F2 * F)) return -1;
+  HIPCHK(hipMemcpyAsync(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(b->d_top_members, top_members.data(), sizeof(int) * R, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, hipMemcpyHostToDevice, s));
+  StitchBufs& SB = b->SB;
+  if (dalloc(b, &SB.topHH, (size_t)F2 * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F2 * 32) ||
+      dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F2 * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.scHH, (size_t)F2 * F * 64) ||
+      dalloc(b, &SB.scTT, (size_t)F2 * F * 64) || dalloc(b, &SB.scTH, (size_t)F2 * F * 64) || dalloc(b, &SB.scHT, (size_t)F2 * F * 64) || dalloc(b, &SB.scHC, (size_t)F2 * 32) ||
+      dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
+  const int n = H.n(), tot = 2 * (n * n + n);
+  b->n_lin_blocks = (R + 127) / 128; b->n_pt_blocks = (N + 255) / 256;
+  if (dalloc(b, &b->d_sys, tot) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4) ||
+      dalloc(b, &b->d_xAd, (size_t)F2 * 8) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
+  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * tot, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * std::max(b->n_lin_blocks, F2), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_newEnergyWO, sizeof(float) * R, hipHostMallocDefault));
+  if (int r = uploadAdjoints(b)) return r;
+  HIPCHK(hipStreamSynchronize(s));
+  b->graph_ready = true;
+  return 0;
+}
+
+#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
+
+// activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
+int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
+  BA_READY(b);
+  hipStream_t s = b->ctx->stream;
+  HIPCHK(hipMemsetAsync(b->Rs.state, BA_IN, b->H.R, s));
+  HIPCHK(hipMemsetAsync(b->Rs.newState, BA_OUTLIER, b->H.R, s));
+  HIPCHK(hipMemsetAsync(b->Rs.energy, 0, sizeof(float) * b->H.R, s));
+  HIPCHK(hipMemsetAsync(b->Rs.newEnergy, 0, sizeof(float) * b->H.R, s));
+  return 0;
+}
+int dmvio_hip_ba_linearize(dmvio_hip_ba* b, int fix, double* energy) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  double e = 0;
+  if (int r = linearizeAll(b, fix != 0, &e)) return r;
+  if (energy) *energy = e;
+  return 0;
+}
+int dmvio_hip_ba_apply(dmvio_hip_ba* b) {
+  BA_READY(b);
+  return applyRes(b);
+}
+int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* newEnergy, float* newEnergyWO, unsigned char* active, float* center3) {
+  BA_READY(b);
+  hipStream_t s = b->ctx->stream;
+  const int R = b->H.R;
+  if (newState) HIPCHK(hipMemcpyAsync(newState, b->Rs.newState, R, hipMemcpyDeviceToHost, s));
+  if (newEnergy) HIPCHK(hipMemcpyAsync(newEnergy, b->Rs.newEnergy, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  if (newEnergyWO) HIPCHK(hipMemcpyAsync(newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  if (active) HIPCHK(hipMemcpyAsync(active, b->Rs.active, R, hipMemcpyDeviceToHost, s));
+  if (center3) HIPCHK(hipMemcpyAsync(center3, b->Rs.center, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+// RawResidualJacobian of the LAST linearisation (74 floats per residual, RawResidualJacobian.h:32-61 order) — parity/debug
+int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
+  BA_READY(b);
+  HIPCHK(hipMemcpyAsync(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, hipMemcpyDeviceToHost, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return 0;
+}
+int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
+  if (!b || !th) return failmsg("null argument");
+  for (int f = 0; f < b->H.F; f++) th[f] = b->H.fr[f].frameEnergyTH;
+  return 0;
+}
+int dmvio_hip_ba_accumulate(dmvio_hip_ba* b, double* HA, double* bA, double* Hsc, double* bsc, int* resInA) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  if (int r = accumulate(b)) return r;
+  const int n = b->H.n();
+  const double* p = b->h_sys;
+  if (HA) memcpy(HA, p, sizeof(double) * n * n);
+  if (bA) memcpy(bA, p + n * n, sizeof(double) * n);
+  if (Hsc) memcpy(Hsc, p + n * n + n, sizeof(double) * n * n);
+  if (bsc) memcpy(bsc, p + 2 * n * n + n, sizeof(double) * n);
+  if (resInA) *resInA = b->H.resInA;
+  return 0;
+}
+int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hcd4, float* HdiF, float* bdSumF) {
+  BA_READY(b);
+  hipStream_t s = b->ctx->stream;
+  const int N = b->H.N;
+  if (Hdd) HIPCHK(hipMemcpyAsync(Hdd, b->P.Hdd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+  if (bd) HIPCHK(hipMemcpyAsync(bd, b->P.bd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+  if (Hcd4) HIPCHK(hipMemcpyAsync(Hcd4, b->P.Hcd, sizeof(float) * 4 * N, hipMemcpyDeviceToHost, s));
+  if (HdiF) HIPCHK(hipMemcpyAsync(HdiF, b->P.HdiF, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+  if (bdSumF) HIPCHK(hipMemcpyAsync(bdSumF, b->P.bdSumF, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+// EnergyFunctional::solveSystemF: accumulate on the device, solve on the host (the hand-off point of
+// BAGTSAMIntegration::computeBAUpdate in VIO mode, EnergyFunctional.cpp:958-969), back-substitute on the device.
+int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_out) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  if (int r = accumulate(b)) return r;
+  const int n = b->H.n();
+  const double* p = b->h_sys;
+  b->H.getNullspaces();
+  std::vector<double> x;
+  b->H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
+  if (x_out) memcpy(x_out, x.data(), sizeof(double) * n);
+  return resubstitute(b, x);
+}
+int dmvio_hip_ba_resubstitute(dmvio_hip_ba* b, const double* x) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::vector<double> xv(x, x + b->H.n());
+  return resubstitute(b, xv);
+}
+int dmvio_hip_ba_get_points(dmvio_hip_ba* b, float* idepth, float* step) {
+  BA_READY(b);
+  hipStream_t s = b->ctx->stream;
+  if (idepth) HIPCHK(hipMemcpyAsync(idepth, b->P.idepth, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
+  if (step) HIPCHK(hipMemcpyAsync(step, b->P.step, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double aff[2], double state10[10]) {
+  if (!b || f < 0 || f >= b->H.F) return failmsg("ba_get_frame: bad argument");
+  const BAFrameHost& fr = b->H.fr[f];
+  if (pose7_w2c) poseTo7(fr.w2c, pose7_w2c);
+  if (aff) { aff[0] = fr.state_scaled[6]; aff[1] = fr.state_scaled[7]; }
+  if (state10) memcpy(state10, fr.state, sizeof(double) * 10);
+  return 0;
+}
+int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
+  if (!b) return failmsg("null ba");
+  memcpy(fxfycxcy, b->H.c_value_scaled, sizeof(double) * 4);
+  return 0;
+}
+
+// One Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586).
+static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted) {
+  BAHost& H = b->H;
+  const int n = H.n();
+  // backupState
+  H.backupFrames();
+  float dummy0, dummy1;
+  if (int r = pointStep(b, 0, 0.f, &dummy0, &dummy1)) return r;
+  // solveSystem
+  H.getNullspaces();
+  if (int r = accumulate(b)) return r;
+  const double* p = b->h_sys;
+  std::vector<double> x;
+  H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
+  if (int r = resubstitute(b, x)) return r;
+  // doStepFromBackup
+  float fs[4], sumID = 0, sumNID = 0;
+  H.stepFrames(1.0f, fs);
+  if (int r = pointStep(b, 1, 1.0f, &sumID, &sumNID)) return r;
+  H.setPrecalcValues();
+  // eval new energy
+  double newE = 0;
+  if (int r = linearizeAll(b, false, &newE)) return r;
+  const double newL = H.calcLEnergyFrames(), newM = H.calcMEnergy();
+  accepted = (newE + newL + newM < lastE[0] + lastE[1] + lastE[2]);
+  if (accepted) {
+    if (int r = applyRes(b)) return r;
+    lastE[0] = newE; lastE[1] = newL; lastE[2] = newM;
+    lambda = std::max(lambda * 0.25, 1e-5);
+  } else {
+    H.restoreFrames();
+    if (int r = pointStep(b, 2, 0.f, &dummy0, &dummy1)) return r;
+    H.setPrecalcValues();
+    if (int r = linearizeAll(b, false, &lastE[0])) return r;
+    lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
+    lambda *= 1e2;
+  }
+  return 0;
+}
+
+int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io, double lastE[3], int* accepted) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  bool acc = false;
+  double lam = *lambda_io;
+  if (int r = gnIteration(b, iteration, lam, lastE, acc)) return r;
+  *lambda_io = lam;
+  if (accepted) *accepted = acc ? 1 : 0;
+  return 0;
+}
+
+// FullSystem::optimize (FullSystemOptimize.cpp:417-647), visual-only branch.
+int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  BAHost& H = b->H;
+  if (H.F < 2) { if (rmse) *rmse = 0; return 0; }
+  if (H.F < 3) mnumOptIts = 20;
+  if (H.F < 4) mnumOptIts = 15;
+  if (int r = dmvio_hip_ba_activate_all(b)) return r;
+  double lastE[3];
+  if (int r = linearizeAll(b, false, &lastE[0])) return r;
+  lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
+  if (int r = applyRes(b)) return r;
+  double lambda = 1e-5;
+  int done = 0;
+  b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;
+  for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+    bool acc = false;
+    if (int r = gnIteration(b, iteration, lambda, lastE, acc)) return r;
+    done++;
+    if (done < 64) { b->trace[done][0] = lastE[0]; b->trace[done][1] = lastE[1]; b->trace[done][2] = lastE[2]; b->trace[done][3] = acc ? 1 : 0; }
+    // canbreak && iteration >= setting_minOptIterations: baIntegration->canBreak() stays false without the GTSAM path
+  }
+  // fix the newest frame's linearisation point, re-linearise with applyRes (FullSystemOptimize.cpp:596-609)
+  BAFrameHost& last = H.fr[H.F - 1];
+  double newStateZero[10] = {0, 0, 0, 0, 0, 0, last.state[6], last.state[7], 0, 0};
+  last.evalPT = last.w2c;
+  BAHost::frameSetState(last, newStateZero);
+  BAHost::frameSetStateZero(last, newStateZero);
+  H.setAdjointsF();
+  if (int r = uploadAdjoints(b)) return r;
+  H.setPrecalcValues();
+  double fe = 0;
+  if (int r = linearizeAll(b, true, &fe)) return r;
+  b->final_energy = fe; b->iterations_done = done;
+  if (rmse) *rmse = sqrtf((float)(fe / (8 * H.resInA)));
+  if (finalEnergy) *finalEnergy = fe;
+  if (iterations) *iterations = done;
+  if (trace) memcpy(trace, b->trace, sizeof(b->trace));
+  return 0;
+}
+
+}  // extern "C"

@@ -27,6 +27,12 @@ struct FrameStore {
   __host__ __device__ float* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };
 
+struct PyrGeom {
+  int levels;
+  int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
+  int tiles_x, tiles_y;  // 32x32 level-0 tiles
+};
+
 // Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one
 // float4 {u, v, idepth, color} record per template point: one coalesced 16-byte load per point).
 struct TrackerDev {

@@ -14,12 +14,6 @@
 
 namespace dmv {
 
-struct PyrGeom {
-  int levels;
-  int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
-  int tiles_x, tiles_y;  // 32x32 level-0 tiles
-};
-
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot) {
   __shared__ float s_a[32 * 32];

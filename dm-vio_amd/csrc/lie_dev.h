@@ -132,6 +132,28 @@ DMV_HD Pose poseMul(const Pose& a, const Pose& b) {
   return r;
 }
 
+DMV_HD Pose poseInv(const Pose& a) {
+  Pose r;
+  r.q.w = a.q.w; r.q.x = -a.q.x; r.q.y = -a.q.y; r.q.z = -a.q.z;
+  const double nt[3] = {-a.t[0], -a.t[1], -a.t[2]};
+  quatRotate(r.q, nt, r.t);
+  return r;
+}
+
+// 6x6 adjoint [R, hat(t) R; 0, R], row-major (se3.hpp:131-140)
+DMV_HD void poseAdj(const Pose& T, double A[36]) {
+  double R[9];
+  quatToR(T.q, R);
+  const double H[9] = {0, -T.t[2], T.t[1], T.t[2], 0, -T.t[0], -T.t[1], T.t[0], 0};
+  for (int i = 0; i < 36; i++) A[i] = 0;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      A[r * 6 + c] = R[r * 3 + c];
+      A[(r + 3) * 6 + c + 3] = R[r * 3 + c];
+      A[r * 6 + c + 3] = H[r * 3 + 0] * R[0 * 3 + c] + H[r * 3 + 1] * R[1 * 3 + c] + H[r * 3 + 2] * R[2 * 3 + c];
+    }
+}
+
 DMV_HD Pose poseFrom7(const double p[7]) {
   Pose T;
   T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];

@@ -28,37 +28,9 @@
 #pragma once
 #include "common.h"
 #include "lie_dev.h"
+#include "interp.hpp"
 
 namespace dmv {
-
-// getInterpolatedElement33 (src/dso/util/globalFuncs.h:103-118) on an intensity-only plane: the four taps' gradient
-// channels are the central differences the reference stored in dIp[.][1..2] (HessianBlocks.cpp:172-181), rebuilt from the
-// 4x4 intensity neighbourhood: rows iy-1 (2 px), iy (4 px), iy+1 (4 px), iy+2 (2 px) = 48 B in four unaligned vector loads.
-// Callers guarantee 1 <= ix, ix+2 <= w-1, 1 <= iy, iy+2 <= h-1 (true for every in-bounds tap of tracker and BA).
-__device__ __forceinline__ float fin0(const float v) { return isfinite(v) ? v : 0.0f; }
-__device__ __forceinline__ float3 interp33(const float* __restrict__ img, const float x, const float y, const int width) {
-  const int ix = (int)x, iy = (int)y;
-  const float dx = x - ix, dy = y - iy;
-  const float dxdy = dx * dy;
-  const float* bp = img + ix + iy * width;
-  float2 A, D;
-  float4 B, C;
-  __builtin_memcpy(&A, bp - width, 8);
-  __builtin_memcpy(&B, bp - 1, 16);
-  __builtin_memcpy(&C, bp + width - 1, 16);
-  __builtin_memcpy(&D, bp + 2 * width, 8);
-  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-  // taps: p00 = (ix,iy) = B.y, p10 = B.z, p01 = C.y, p11 = C.z
-  const float gx00 = fin0(0.5f * (B.z - B.x)), gx10 = fin0(0.5f * (B.w - B.y));
-  const float gx01 = fin0(0.5f * (C.z - C.x)), gx11 = fin0(0.5f * (C.w - C.y));
-  const float gy00 = fin0(0.5f * (C.y - A.x)), gy10 = fin0(0.5f * (C.z - A.y));
-  const float gy01 = fin0(0.5f * (D.x - B.y)), gy11 = fin0(0.5f * (D.y - B.z));
-  float3 r;
-  r.x = w11 * C.z + w01 * C.y + w10 * B.z + w00 * B.y;
-  r.y = w11 * gx11 + w01 * gx01 + w10 * gx10 + w00 * gx00;
-  r.z = w11 * gy11 + w01 * gy01 + w10 * gy10 + w00 * gy00;
-  return r;
-}
 
 // Accumulator9 slot of H(r,c), r <= c: rows of the upper triangle back to back (MatrixAccumulators.h:1091-1166).
 __host__ __device__ constexpr int accIdx(int r, int c) { return ACC_H + r * 9 - (r * (r - 1)) / 2 + (c - r); }

@@ -112,6 +112,54 @@ int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long
  * LM control steps (solve, pose update, bookkeeping) vs evaluations (calcRes+calcGS). Diagnostics only. */
 int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* trk, long long* ticks_step, long long* ticks_eval);
 
+/* ------------------------------------------------------------------ sliding-window BA -------- */
+/* The window FullSystem::optimize works on (FullSystemOptimize.cpp:417-647): F <= 8 keyframes, N active points, R residuals.
+ * Frame order = frameHessians order (newest last); frame f's image pyramid must be resident in slots[f].
+ *   pose7_w2c[F*7]  worldToCam_evalPT of every frame (HessianBlocks.h:160), aff_ab[F*2] = aff_g2l (a, b), exposures[F] = ab_exposure,
+ *   frameIDs[F]     FrameHessian::frameID (0 = very first keyframe -> strong pose prior, HessianBlocks.h:264-299),
+ *   fxfycxcy        CalibHessian::value_scaled (HessianBlocks.h:318).
+ * Corresponds to EnergyFunctional::insertFrame + setAdjointsF + FullSystem::setPrecalcValues. */
+dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx);
+void dmvio_hip_ba_destroy(dmvio_hip_ba* ba);
+int dmvio_hip_ba_set_window(dmvio_hip_ba* ba, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
+                            const int* frameIDs, const double fxfycxcy[4]);
+/* Marginalisation prior HM (n x n row-major), bM (n), n = 4 + 8F (EnergyFunctional.h:129-131); zero when never called. */
+int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* ba, const double* HM, const double* bM);
+/* Flattened point / residual graph (EnergyFunctional::makeIDX, EnergyFunctional.cpp:997-1017): point p is hosted in frame host[p],
+ * has PointHessian::u, v, idepth, color[8], weights[8] (HessianBlocks.h:419-436) and hasDepthPrior; residual r observes point
+ * res_point[r] in frame res_target[r].  Residuals must be sorted by point (points in allPoints order). */
+int dmvio_hip_ba_set_graph(dmvio_hip_ba* ba, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
+                           const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target);
+/* resetOOB of every residual (FullSystemOptimize.cpp:431-448) */
+int dmvio_hip_ba_activate_all(dmvio_hip_ba* ba);
+/* FullSystem::linearizeAll(fixLinearization) (FullSystemOptimize.cpp:150-218): PointFrameResidual::linearize over all residuals,
+ * energy sum, setNewFrameEnergyTH; fix != 0 also applies the results (applyRes(true)). */
+int dmvio_hip_ba_linearize(dmvio_hip_ba* ba, int fix, double* energy);
+/* FullSystem::applyRes_Reductor(true) (FullSystemOptimize.cpp:91-95) */
+int dmvio_hip_ba_apply(dmvio_hip_ba* ba);
+/* per-residual state_NewState (0 IN, 1 OOB, 2 OUTLIER), state_NewEnergy, state_NewEnergyWithOutlier, efResidual->isActive(), centerProjectedTo */
+int dmvio_hip_ba_get_res_state(dmvio_hip_ba* ba, unsigned char* newState, float* newEnergy, float* newEnergyWO, unsigned char* active, float* center3);
+/* RawResidualJacobian of the last linearisation, 74 floats per residual in the member order of RawResidualJacobian.h:32-61 (parity / debug) */
+int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* ba, float* J74);
+int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* ba, float* th);
+/* accumulateAF_MT + accumulateSCF_MT with adjoint stitching (EnergyFunctional.cpp:201-265): H_A, b_A, H_sc, b_sc ((4+8F)^2 / (4+8F), double)
+ * — the matrices handed to BAGTSAMIntegration::computeBAUpdate in VIO mode; resInA = number of active residuals. */
+int dmvio_hip_ba_accumulate(dmvio_hip_ba* ba, double* HA, double* bA, double* Hsc, double* bsc, int* resInA);
+/* EFPoint::Hdd_accAF, bd_accAF, Hcd_accAF, HdiF, bdSumF (EnergyFunctionalStructs.h:118-128) */
+int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* ba, float* Hdd, float* bd, float* Hcd4, float* HdiF, float* bdSumF);
+/* EnergyFunctional::solveSystemF (EnergyFunctional.cpp:841-996), no-GTSAM branch: accumulate, damped Jacobi-scaled LDLT,
+ * orthogonalisation from iteration 2, resubstituteF_MT.  x_out = lastX (minus the step). */
+int dmvio_hip_ba_solve(dmvio_hip_ba* ba, int iteration, double lambda, double* x_out);
+/* EnergyFunctional::resubstituteF_MT with a caller-provided x (e.g. from GTSAM) */
+int dmvio_hip_ba_resubstitute(dmvio_hip_ba* ba, const double* x);
+int dmvio_hip_ba_get_points(dmvio_hip_ba* ba, float* idepth, float* step);
+int dmvio_hip_ba_get_frame(dmvio_hip_ba* ba, int f, double pose7_w2c[7], double aff[2], double state10[10]);
+int dmvio_hip_ba_get_calib(dmvio_hip_ba* ba, double fxfycxcy[4]);
+/* one Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586); lastE = {E_A, E_L, E_M} in/out */
+int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io, double lastE[3], int* accepted);
+/* FullSystem::optimize(mnumOptIts) (FullSystemOptimize.cpp:417-647): returns statistics_lastFineTrackRMSE in *rmse */
+int dmvio_hip_ba_optimize(dmvio_hip_ba* ba, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
+
 #ifdef __cplusplus
 }
 #endif

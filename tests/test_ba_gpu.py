@@ -1,0 +1,107 @@
+"""GPU parity tests of the sliding-window bundle adjustment: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Per-residual linearisation is compared bit for bit (states, energies, the full RawResidualJacobian); the block accumulators
+replay the reference's sequential fp32 order, so the stitched systems agree to double rounding; the full optimize()
+must meet the north-star tolerances: final energy within 1e-4 relative, poses within 1e-3 m.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _window(pkg, oracle, case, n_extra_slots=0):
+    F = case["n_frames"]
+    ctx = pkg.Context(case["w"], case["h"], n_slots=F + n_extra_slots)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx)
+    ba.set_case(case, list(range(F)))
+    W = oracle.BAWindow(case)
+    return ctx, ba, W
+
+
+@pytest.fixture(scope="module")
+def big(pkg, oracle, synth, gpu_required):
+    case = synth.ba_case(512, 512, n_frames=8, n_points=2000)
+    ctx, ba, W = _window(pkg, oracle, case)
+    return dict(case=case, ctx=ctx, ba=ba, W=W)
+
+
+def test_linearize_bit_exact(big):
+    """PointFrameResidual::linearize: same state, same energies, same Jacobians for every residual."""
+    ba, W = big["ba"], big["W"]
+    ba.activate_all(); W.activate_all()
+    e_g = ba.linearize_all(False); e_o = W.linearize_all(False)
+    sg, so = ba.res_state(), W.res_state()
+    assert np.array_equal(sg["newState"], so["newState"].astype(np.uint8))
+    assert (so["newState"] == 0).sum() > 0.5 * W.R
+    assert np.array_equal(sg["newEnergy"], so["newEnergy"].astype(np.float32))
+    assert np.array_equal(sg["newEnergyWO"], so["newEnergyWO"].astype(np.float32))
+    ok = so["newState"] != 1
+    assert np.array_equal(sg["center"][ok], so["center"][ok])
+    assert abs(e_g - e_o) <= 1e-9 * e_o
+    assert np.array_equal(ba.frame_energy_th(), W.frame_energy_th())
+    J = ba.jacobians()
+    rng = np.random.RandomState(0)
+    for ri in rng.choice(np.nonzero(so["newState"] == 0)[0], 300, replace=False):
+        Jo = W.get_J(int(ri), 0)
+        flat = np.concatenate([Jo[k].reshape(-1) for k in ("resF", "Jpdxi", "Jpdc", "Jpdd", "JIdx", "JabF", "JIdx2", "JabJIdx", "Jab2")])
+        assert np.array_equal(J[ri].view(np.uint32), flat.view(np.uint32)), "residual %d" % ri
+
+
+def test_accumulate_and_solve_parity(big):
+    """accumulateAF / accumulateSCF + adjoint stitching, solveSystemF, resubstitute."""
+    ba, W = big["ba"], big["W"]
+    ba.activate_all(); W.activate_all()
+    ba.linearize_all(False); W.linearize_all(False)
+    ba.apply_res(); W.apply_res()
+    ag, ao = ba.accumulate(), W.accumulate()
+    assert ag["resInA"] == ao["resInA"] and ag["resInA"] > 6000
+    pg, po = ba.point_acc(), W.point_acc()
+    for k in ("Hdd", "bd", "Hcd", "HdiF", "bdSumF"):
+        assert np.array_equal(pg[k], po[k]), k
+    sc = np.sqrt(np.outer(np.diag(ao["HA"]) + 1e-12, np.diag(ao["HA"]) + 1e-12))
+    assert np.max(np.abs(ag["HA"] - ao["HA"]) / sc) < 1e-11
+    assert np.max(np.abs(ag["Hsc"] - ao["Hsc"]) / sc) < 1e-11
+    assert np.allclose(ag["bA"], ao["bA"], rtol=1e-10, atol=1e-10 * np.abs(ao["bA"]).max())
+    assert np.allclose(ag["bsc"], ao["bsc"], rtol=1e-10, atol=1e-10 * np.abs(ao["bsc"]).max())
+    for it, lam in ((0, 1e-5), (2, 1e-3)):
+        xg = ba.solve(it, lam); xo = W.solve(it, lam)
+        assert np.allclose(xg, xo, rtol=1e-6, atol=1e-8 * np.abs(xo).max())
+        _, sg = ba.point_state(); _, so = W.point_state()
+        assert np.allclose(sg, so, rtol=1e-4, atol=1e-6 * np.abs(so).max())
+
+
+def test_optimize_parity(pkg, oracle, synth, gpu_required):
+    """FullSystem::optimize, 8-keyframe window, 2000 points: energy trace, final energy (1e-4 rel) and poses (1e-3 m) vs the oracle."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=2000, seed=4321)
+    ctx, ba, W = _window(pkg, oracle, case)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"] == 6
+    assert np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3]), "same accept / reject decisions"
+    assert np.allclose(rg["trace"][:, 0], ro["trace"][:, 0], rtol=1e-4)
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    assert abs(rg["rmse"] - ro["rmse"]) <= 1e-4 * ro["rmse"]
+    for k in range(8):
+        pg, ag, _ = ba.frame_pose(k); po, ao, _ = W.frame_pose(k)
+        assert np.linalg.norm(pg[:3] - po[:3]) < 1e-3
+        assert min(np.linalg.norm(pg[3:] - po[3:]), np.linalg.norm(pg[3:] + po[3:])) < 1e-4
+        assert np.allclose(ag, ao, atol=1e-3)
+    ig, _ = ba.point_state(); io, _ = W.point_state()
+    assert np.median(np.abs(ig - io) / io) < 1e-4
+    # and the optimisation did its job: poses closer to the ground truth than the initial guess
+    e0 = np.mean([np.linalg.norm(np.asarray(case["poses0"][k][:3]) - case["poses_true"][k][:3]) for k in range(1, 8)])
+    e1 = np.mean([np.linalg.norm(ba.frame_pose(k)[0][:3] - case["poses_true"][k][:3]) for k in range(1, 8)])
+    assert e1 < 0.5 * e0
+
+
+def test_small_window_and_ragged_graph(pkg, oracle, synth, gpu_required):
+    """3-keyframe window (forces 15 iterations), hosts without points, points with a single residual."""
+    case = synth.ba_case(320, 256, n_frames=3, n_points=150, hosts_share=(90, 60, 0), seed=99)
+    ctx, ba, W = _window(pkg, oracle, case)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"] == 15
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    for k in range(3):
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
