@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true", help="exclude makeImages from the step (track only)")
+    ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
+    ap.add_argument("--ba-points", type=int, default=2000)
+    ap.add_argument("--ba-iters", type=int, default=300, help="timed GN iterations of the BA leg")
     return ap.parse_args()
 
 
@@ -185,6 +188,11 @@ def main():
                    sample="%d frames of the same batch (makeImages + trackNewestCoarse), oracle -O3 -msse2, 1 thread "
                           "(the reference tracks single-threaded), %.1f s on %s" % (n_done, t_cpu, _cpu_name()))
 
+    # ---------------- BA leg: Gauss-Newton iterations / s of the 8-keyframe sliding-window photometric BA (rank 0 window per rank)
+    ba_out = None
+    if not args.no_ba:
+        ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, torch=torch, cpu=(rank == 0 and world == 1 and not args.no_cpu))
+
     if rank == 0:
         out = {
             "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
@@ -197,12 +205,75 @@ def main():
                        "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "ba": ba_out,
             "lm_iterations_mean": float(np.mean(res["iterations"])),
             "max_pose_err_m": float(terr.max()),
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, torch, cpu):
+    """GN iterations / s of FullSystem::optimize's loop body (solveSystemF + doStepFromBackup + linearizeAll + energies + applyRes)
+    on an 8-keyframe, ~2000-point, ~12k-residual window.  Every rank optimises its own window replica."""
+    w = h = args.size
+    case = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED + 17 * rank)
+    F = case["n_frames"]
+    ctx = pkg.Context(w, h, n_slots=F, device=ctx_device)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx)
+
+    def fresh():
+        ba.set_case(case, list(range(F)))
+        ba.activate_all()
+        e = ba.linearize_all(False)
+        ba.apply_res()
+        return [e, 0.0, 0.0]
+
+    # correctness guard: the full optimize must decrease the energy
+    ba.set_case(case, list(range(F)))
+    r = ba.optimize(6)
+    if not (r["trace"][-1, 0] < 0.7 * r["trace"][0, 0]):
+        raise SystemExit("bench: BA did not converge")
+    lastE = fresh()
+    lam = 1e-5
+    for it in range(12):  # warmup (first touches of the freshly allocated window buffers)
+        acc, lam, lastE = ba.gn_iteration(it, lam, lastE)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    n_it = args.ba_iters
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_it:   # keep iterating on the same window (accepted or rejected, an iteration does the same work) — like the CPU leg below
+        acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
+        done += 1
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    out = dict(metric="BA GN-iterations/sec (8-KF window)", value=round(world * done / elapsed, 1), unit="GN-iters/s", ms_per_iter=round(1e3 * elapsed / done, 4),
+               window=dict(frames=F, points=int(len(case["u"])), residuals=int(len(case["res_point"]))),
+               algorithmic_bytes_per_iter=int(len(case["res_point"]) * 464), note="one window per GPU")
+    if cpu:
+        O = graft.load_oracle()
+        res = {}
+        for threads in (1, 6):
+            W = O.BAWindow(case, threads=threads)
+            W.activate_all(); e = W.linearize_all(False); W.apply_res()
+            lastE = [e, W.lenergy(), W.menergy()]; lam = 1e-5
+            n = 0; t0 = time.perf_counter()
+            while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
+                acc, lam, lastE = W.gn_iteration(n % 6, lam, lastE); n += 1
+            res[threads] = n / (time.perf_counter() - t0)
+        out["cpu_baseline"] = dict(value=round(res[6], 2), unit="GN-iters/s", cores=6, kind="port", value_1thread=round(res[1], 2),
+                                   sample="oracle gn_iteration on the same window, 6 accumulation workers (NUM_THREADS 6) and 1 thread, on %s" % _cpu_name())
+    ba.close(); ctx.close()
+    return out
 
 
 def _cpu_name():

@@ -275,85 +275,121 @@ struct Acc3 {
     if (n1k > 1000) { d1m = d1k + d1m; n1k = 0; d1k = 0.f; }
   }
   __device__ __forceinline__ float finish() { d1k = d + d1k; d1m = d1k + d1m; return d1m; }
+  // true when nAct more bump()s cannot trigger a shift-up: the tile can then be added without per-member counter checks
+  __device__ __forceinline__ bool tileFits(const int nAct) const { return n1 + nAct <= 1000; }
 };
 
 // ------------------------------------------------------------------------------------------------ top accumulation
+// Two-phase tiles keep the reference's SEQUENTIAL fp32 summation order without serialising the arithmetic:
+//   phase A (parallel): the workgroup computes the contribution of every (member, element) pair of a tile into LDS,
+//   phase B (sequential, cheap): the thread that owns element e adds the tile's contributions in member order — one LDS read
+//   and one dependent add per member — replaying AccumulatorApprox / AccumulatorXX incl. the 1k / 1M shift-up.
 // One workgroup per (host,target) bucket; thread e < 91 owns element e of the 13x13 block:
 //   e in [0,55): upper triangle of the 10x10 [calib4 | pose6] block, row-major (AccumulatorApprox::update order)
-//   e in [55,85): TopRight 10x3, e in [85,91): BotRight (a00,a01,a02,a11,a12,a22).  Thread 91 counts members (num).
-// out: F*F blocks of 96 floats (91 used) + counts.
-__global__ void __launch_bounds__(128) k_ba_accum_top(const BAWindow W, const BARes Rs, const int* __restrict__ bucket_begin,
-                                                       const int* __restrict__ bucket_members, float* __restrict__ out, int* __restrict__ out_num) {
-  __shared__ float s_rec[32][36];
-  const int b = blockIdx.x;
+//   e in [55,85): TopRight 10x3, e in [85,91): BotRight (a00,a01,a02,a11,a12,a22).
+// gridDim.y = number of PARTIAL accumulators per bucket: partial sp owns a contiguous slice of the member list — the device
+// analogue of the reference's per-worker accumulators acc[tid] (AccumulatedTopHessian.h:146), which stitchDoubleInternal
+// sums in double (AccumulatedTopHessian.cpp:263-268).  gridDim.y == 1 (default) replays the single-threaded reference bit for bit.
+// out: (F*F x nsplit) blocks of 96 floats (91 used) + counts of active members.
+struct TopElem { int kind, r, c; };   // decoded once per thread
+__device__ __forceinline__ TopElem decodeTop(const int e) {
+  TopElem t; t.kind = 3; t.r = 0; t.c = 0;
+  if (e < 55) { t.kind = 0; int off = 0, r = 0; while (e >= off + (10 - r)) { off += 10 - r; r++; } t.r = r; t.c = r + (e - off); }
+  else if (e < 85) { t.kind = 1; t.r = (e - 55) / 3; t.c = (e - 55) % 3; }
+  else if (e < 91) { t.kind = 2; t.r = e - 85; }
+  return t;
+}
+__device__ __forceinline__ float topContribution(const float* q, const TopElem t) {
+  // x[i] = (i < 4) ? Jpdc0[i] : Jpdxi0[i-4]  -> q[i < 4 ? i : 4 + i];   y[i] -> q[i < 4 ? 4 + i : 10 + i]
+  const int r = t.r, c = t.c;
+  if (t.kind == 0) {
+    const float xr = q[r < 4 ? r : 4 + r], xc = q[c < 4 ? c : 4 + c];
+    const float yr = q[r < 4 ? 4 + r : 10 + r], yc = q[c < 4 ? 4 + c : 10 + c];
+    const float a = q[REC_JIDX2], bb = q[REC_JIDX2 + 1], cc = q[REC_JIDX2 + 2];
+    return a * xc * xr + cc * yc * yr + bb * (xc * yr + yc * xr);
+  } else if (t.kind == 1) {
+    const float xr = q[r < 4 ? r : 4 + r], yr = q[r < 4 ? 4 + r : 10 + r];
+    // TR col 0: (JabJIdx00, JabJIdx01), col 1: (JabJIdx10, JabJIdx11), col 2: (JI_r0, JI_r1)
+    const float t0 = c == 0 ? q[REC_JABJIDX + 0] : (c == 1 ? q[REC_JABJIDX + 2] : q[REC_JI_R + 0]);
+    const float t1 = c == 0 ? q[REC_JABJIDX + 1] : (c == 1 ? q[REC_JABJIDX + 3] : q[REC_JI_R + 1]);
+    return xr * t0 + yr * t1;
+  } else {
+    // a00 = Jab2_00, a01 = Jab2_01, a02 = Jab_r0, a11 = Jab2_11, a12 = Jab_r1, a22 = rr
+    return r == 0 ? q[REC_JAB2 + 0] : r == 1 ? q[REC_JAB2 + 1] : r == 2 ? q[REC_JAB_R + 0] : r == 3 ? q[REC_JAB2 + 2] : r == 4 ? q[REC_JAB_R + 1] : q[REC_RR];
+  }
+}
+
+#define TOP_TILE 64
+__device__ __forceinline__ void accumTopBlock(const int b, const int sp, const int nsp, const BARes& Rs, const int* __restrict__ bucket_begin,
+                                              const int* __restrict__ bucket_members, float* __restrict__ out, int* __restrict__ out_num) {
+  __shared__ float s_rec[TOP_TILE][37];
+  __shared__ int s_nact;
   const int e = threadIdx.x;
-  const int m0 = bucket_begin[b], m1 = bucket_begin[b + 1];
-  // decode the element once
-  int kind = 3, r = 0, c = 0;
-  if (e < 55) { kind = 0; int off = 0; r = 0; while (e >= off + (10 - r)) { off += 10 - r; r++; } c = r + (e - off); }
-  else if (e < 85) { kind = 1; r = (e - 55) / 3; c = (e - 55) % 3; }
-  else if (e < 91) { kind = 2; r = e - 85; }
+  const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
+  const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
+  const TopElem te = decodeTop(e);
   Acc3 acc; acc.init();
   int num = 0;
-  for (int base = m0; base < m1; base += 32) {
-    const int cnt = min(32, m1 - base);
+  for (int base = m0; base < m1; base += TOP_TILE) {
+    const int cnt = min(TOP_TILE, m1 - base);
     __syncthreads();
-    // stage up to 32 member records (first 35 floats) — 128 threads, 4 per record
-    {
-      const int j = threadIdx.x >> 2, part = threadIdx.x & 3;
+    if (e == 0) s_nact = 0;
+    __syncthreads();
+    {  // stage up to 64 member records (first 35 floats): 4 threads per record; inactive members become all-zero rows
+      const int j = e >> 2, part = e & 3;
       if (j < cnt) {
         const int ri = bucket_members[base + j];
         const bool act = Rs.active[ri] != 0;
         const float* __restrict__ rec = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
         for (int k = part; k < 35; k += 4) s_rec[j][k] = act ? rec[k] : 0.0f;
-        if (part == 0) s_rec[j][35] = act ? 1.0f : 0.0f;
+        if (part == 0) { s_rec[j][35] = act ? 1.0f : 0.0f; if (act) atomicAdd(&s_nact, 1); }
       }
     }
     __syncthreads();
-    if (e < 92)
-      for (int j = 0; j < cnt; j++) {
-        const float* q = s_rec[j];
-        if (q[35] == 0.0f) continue;
-        // x[i] = (i < 4) ? Jpdc0[i] : Jpdxi0[i-4]  -> q[i < 4 ? i : 4 + i]   (REC_JPDXI0 = 8)
-        // y[i] = (i < 4) ? Jpdc1[i] : Jpdxi1[i-4]  -> q[i < 4 ? 4 + i : 10 + i]   (REC_JPDC1 = 4, REC_JPDXI1 = 14)
-        if (kind == 0) {
-          const float xr = q[r < 4 ? r : 4 + r], xc = q[c < 4 ? c : 4 + c];
-          const float yr = q[r < 4 ? 4 + r : 10 + r], yc = q[c < 4 ? 4 + c : 10 + c];
-          const float a = q[REC_JIDX2], bb = q[REC_JIDX2 + 1], cc = q[REC_JIDX2 + 2];
-          acc.add(a * xc * xr + cc * yc * yr + bb * (xc * yr + yc * xr));
-          acc.bump();
-        } else if (kind == 1) {
-          const float xr = q[r < 4 ? r : 4 + r], yr = q[r < 4 ? 4 + r : 10 + r];
-          // TR col 0: (JabJIdx00, JabJIdx01), col 1: (JabJIdx10, JabJIdx11), col 2: (JI_r0, JI_r1)
-          const float t0 = c == 0 ? q[REC_JABJIDX + 0] : (c == 1 ? q[REC_JABJIDX + 2] : q[REC_JI_R + 0]);
-          const float t1 = c == 0 ? q[REC_JABJIDX + 1] : (c == 1 ? q[REC_JABJIDX + 3] : q[REC_JI_R + 1]);
-          acc.bump();   // the shared counters are advanced by update() BEFORE updateTopRight/BotRight of the same residual
-          acc.add(xr * t0 + yr * t1);
-        } else if (kind == 2) {
-          // a00 = Jab2_00, a01 = Jab2_01, a02 = Jab_r0, a11 = Jab2_11, a12 = Jab_r1, a22 = rr
-          const float v = r == 0 ? q[REC_JAB2 + 0] : r == 1 ? q[REC_JAB2 + 1] : r == 2 ? q[REC_JAB_R + 0] : r == 3 ? q[REC_JAB2 + 2] : r == 4 ? q[REC_JAB_R + 1] : q[REC_RR];
-          acc.bump();
-          acc.add(v);
-        } else num++;
+    const int nact = s_nact;
+    if (e < 91) {
+      if (acc.tileFits(nact)) {
+        // no shift-up can happen inside this tile: contributions of inactive members are exact zeros (x + 0 == x), so the
+        // adds run back to back in member order; the shared counters advance by the number of active members
+        for (int j0 = 0; j0 < cnt; j0 += 16) {
+          float c[16];
+#pragma unroll
+          for (int j = 0; j < 16; j++) c[j] = (j0 + j < cnt) ? topContribution(s_rec[j0 + j], te) : 0.0f;   // independent: pipelined LDS reads
+#pragma unroll
+          for (int j = 0; j < 16; j++) acc.d += c[j];                                                       // the sequential part
+        }
+        acc.n1 += nact;
+      } else {
+        for (int j = 0; j < cnt; j++) {
+          if (s_rec[j][35] == 0.0f) continue;
+          const float v = topContribution(s_rec[j], te);
+          if (te.kind == 0) { acc.add(v); acc.bump(); }
+          else { acc.bump(); acc.add(v); }   // update() advances the shared counters BEFORE updateTopRight/BotRight
+        }
       }
+    }
+    num += nact;
   }
-  if (e < 91) out[b * 96 + e] = acc.finish();
-  if (e == 91) out_num[b] = num;
+  if (e < 91) out[(b * nsp + sp) * 96 + e] = acc.finish();
+  if (e == 91) out_num[b * nsp + sp] = num;
 }
 
 // ------------------------------------------------------------------------------------------------ Schur accumulation
 // accD[h,t1,t2] (8x8) += (HdiF * JpJd(r1)) JpJd(r2)^T : one workgroup (64 threads) per bucket, member = (r1, r2, point).
-__global__ void __launch_bounds__(64) k_ba_accum_scD(const BARes Rs, const BAPoints P, const int* __restrict__ bucket_begin,
-                                                      const int* __restrict__ members /* 3 ints each */, float* __restrict__ outD, int* __restrict__ outNum) {
-  __shared__ float s_l[64][8], s_r[64][8], s_w[64];
-  const int b = blockIdx.x, e = threadIdx.x, i = e >> 3, j = e & 7;
-  const int m0 = bucket_begin[b], m1 = bucket_begin[b + 1];
+__device__ __forceinline__ void accumScDBlock(const int b, const int sp, const int nsp, const BARes& Rs, const BAPoints& P, const int* __restrict__ bucket_begin,
+                                              const int* __restrict__ members /* 3 ints each */, float* __restrict__ outD, int* __restrict__ outNum) {
+  __shared__ float s_l[64][9], s_r[64][9], s_w[64];
+  __shared__ float s_c[64][65];
+  const int e = threadIdx.x & 63, i = e >> 3, j = e & 7;
+  const bool live = threadIdx.x < 64;   // the block is launched with 256 threads; the first wave does the work
+  const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
+  const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
   Acc3 acc; acc.init();
   int num = 0;
   for (int base = m0; base < m1; base += 64) {
     const int cnt = min(64, m1 - base);
     __syncthreads();
-    if (e < cnt) {
+    if (live && e < cnt) {
       const int r1 = members[3 * (base + e)], r2 = members[3 * (base + e) + 1], pi = members[3 * (base + e) + 2];
       const bool act = Rs.active[r1] && Rs.active[r2];
       const float* __restrict__ q1 = Rs.rec[Rs.which[r1]] + (size_t)r1 * REC_FLOATS + REC_JPJD;
@@ -363,24 +399,30 @@ __global__ void __launch_bounds__(64) k_ba_accum_scD(const BARes Rs, const BAPoi
       s_w[e] = act ? P.HdiF[pi] : -1.0f;
     }
     __syncthreads();
-    for (int m = 0; m < cnt; m++) {
-      const float wv = s_w[m];
-      if (wv < 0) continue;
-      acc.add((wv * s_l[m][i]) * s_r[m][j]);   // A += w*L*R^T
-      acc.bump();
-      num++;
-    }
+    if (live) for (int m = 0; m < cnt; m++) s_c[m][e] = (s_w[m] * s_l[m][i]) * s_r[m][j];   // A += w*L*R^T (phase A, independent)
+    __syncthreads();
+    if (live)
+      for (int m = 0; m < cnt; m++) {
+        if (s_w[m] < 0) continue;
+        acc.add(s_c[m][e]);
+        acc.bump();
+        num++;
+      }
   }
-  outD[b * 64 + e] = acc.finish();
-  if (e == 0) outNum[b] = num;
+  if (live) {
+    outD[(b * nsp + sp) * 64 + e] = acc.finish();
+    if (e == 0) outNum[b * nsp + sp] = num;
+  }
 }
 
 // accE[h,t] (8x4) += (HdiF JpJd) Hcd^T ; accEB[h,t] (8) += (HdiF*bdSumF) JpJd : workgroup per (h,t) bucket, 40 owners
-__global__ void __launch_bounds__(64) k_ba_accum_scE(const BARes Rs, const BAPoints P, const int* __restrict__ bucket_begin,
-                                                      const int* __restrict__ bucket_members, float* __restrict__ outE /* 40 per bucket */) {
-  __shared__ float s_l[64][8], s_h[64][4], s_w[64], s_wb[64];
-  const int b = blockIdx.x, e = threadIdx.x;
-  const int m0 = bucket_begin[b], m1 = bucket_begin[b + 1];
+__device__ __forceinline__ void accumScEBlock(const int b, const int sp, const int nsp, const BARes& Rs, const BAPoints& P, const int* __restrict__ bucket_begin,
+                                              const int* __restrict__ bucket_members, float* __restrict__ outE /* 40 per bucket */) {
+  __shared__ float s_l[64][9], s_h[64][5], s_w[64], s_wb[64];
+  __shared__ float s_c[64][41];
+  const int e = threadIdx.x;
+  const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
+  const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
   Acc3 acc; acc.init();
   for (int base = m0; base < m1; base += 64) {
     const int cnt = min(64, m1 - base);
@@ -400,144 +442,220 @@ __global__ void __launch_bounds__(64) k_ba_accum_scE(const BARes Rs, const BAPoi
     }
     __syncthreads();
     if (e < 40)
+      for (int m = 0; m < cnt; m++) s_c[m][e] = (e < 32) ? (s_w[m] * s_l[m][e >> 2]) * s_h[m][e & 3] : s_wb[m] * s_l[m][e - 32];
+    __syncthreads();
+    if (e < 40)
       for (int m = 0; m < cnt; m++) {
         if (s_w[m] < 0) continue;
-        if (e < 32) acc.add((s_w[m] * s_l[m][e >> 2]) * s_h[m][e & 3]);
-        else acc.add(s_wb[m] * s_l[m][e - 32]);
+        acc.add(s_c[m][e]);
         acc.bump();
       }
   }
-  if (e < 40) outE[b * 40 + e] = acc.finish();
+  if (e < 40) outE[(b * nsp + sp) * 40 + e] = acc.finish();
 }
 
-// accHcc (4x4) += HdiF Hcd Hcd^T ; accbc (4) += (bdSumF*HdiF) Hcd over all points with an active residual: 20 owners, one workgroup
-__global__ void __launch_bounds__(64) k_ba_accum_scC(const int N, const BAPoints P, float* __restrict__ outC /* 20 */) {
-  __shared__ float s_h[64][4], s_w[64], s_wb[64];
+// accHcc (4x4) += HdiF Hcd Hcd^T ; accbc (4) += (bdSumF*HdiF) Hcd over all points with an active residual: 20 owners per workgroup,
+// gridDim.x partial accumulators over contiguous point ranges (1 = the reference's single-threaded order)
+__device__ __forceinline__ void accumScCBlock(const int sp, const int nsp, const int N, const BAPoints& P, float* __restrict__ outC /* 20 */) {
+  __shared__ float s_c[256][21];
+  __shared__ float s_w[256];
   const int e = threadIdx.x;
+  const int p0 = (int)(((long long)N * sp) / nsp), p1 = (int)(((long long)N * (sp + 1)) / nsp);
   Acc3 acc; acc.init();
-  for (int base = 0; base < N; base += 64) {
-    const int cnt = min(64, N - base);
+  for (int base = p0; base < p1; base += 256) {
+    const int cnt = min(256, p1 - base);
     __syncthreads();
     if (e < cnt) {
       const int pi = base + e;
       const float hdi = P.HdiF[pi];
+      float hc[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) s_h[e][k] = P.Hcd[4 * pi + k] + 0.0f;
+      for (int k = 0; k < 4; k++) hc[k] = P.Hcd[4 * pi + k] + 0.0f;
       s_w[e] = hdi > 0 ? hdi : -1.0f;   // HdiF == 0 <=> no active residual (point skipped by addPoint)
-      s_wb[e] = P.bdSumF[pi] * hdi;
+      const float wb = P.bdSumF[pi] * hdi;
+#pragma unroll
+      for (int q = 0; q < 16; q++) s_c[e][q] = (hdi * hc[q >> 2]) * hc[q & 3];
+#pragma unroll
+      for (int q = 0; q < 4; q++) s_c[e][16 + q] = wb * hc[q];
     }
-    __syncthreads();
-    if (e < 20)
-      for (int m = 0; m < cnt; m++) {
-        if (s_w[m] < 0) continue;
-        if (e < 16) acc.add((s_w[m] * s_h[m][e >> 2]) * s_h[m][e & 3]);
-        else acc.add(s_wb[m] * s_h[m][e - 16]);
-        acc.bump();
+    const int nact = __syncthreads_count(e < cnt && s_w[e] >= 0);
+    if (e < 20) {
+      if (acc.tileFits(nact)) {
+        for (int m0 = 0; m0 < cnt; m0 += 16) {
+          float c[16];
+#pragma unroll
+          for (int m = 0; m < 16; m++) c[m] = (m0 + m < cnt && s_w[m0 + m] >= 0) ? s_c[m0 + m][e] : 0.0f;
+#pragma unroll
+          for (int m = 0; m < 16; m++) acc.d += c[m];
+        }
+        acc.n1 += nact;
+      } else {
+        for (int m = 0; m < cnt; m++) {
+          if (s_w[m] < 0) continue;
+          acc.add(s_c[m][e]);
+          acc.bump();
+        }
       }
+    }
   }
-  if (e < 20) outC[e] = acc.finish();
+  if (e < 20) outC[sp * 20 + e] = acc.finish();
+}
+
+// All four accumulations of solveSystemF in ONE launch (they only depend on the applied records and the per-point sums):
+// blocks [0, nTop) top buckets, [nTop, nTop+nD) accD buckets, then accE buckets, then the calibration partials.
+struct AccumArgs {
+  int F, N, nsTop, nsD, nsC;
+  const int *top_begin, *top_members, *scd_begin, *scd_members;
+  float *accTop, *accD, *accE, *accC;
+  int *numTop, *numD;
+};
+__global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const BARes Rs, const BAPoints P) {
+  const int F2 = A.F * A.F;
+  const int nTop = F2 * A.nsTop, nD = F2 * A.F * A.nsD, nE = F2 * A.nsTop;
+  int blk = blockIdx.x;
+  if (blk < nTop) { accumTopBlock(blk / A.nsTop, blk % A.nsTop, A.nsTop, Rs, A.top_begin, A.top_members, A.accTop, A.numTop); return; }
+  blk -= nTop;
+  if (blk < nD) { accumScDBlock(blk / A.nsD, blk % A.nsD, A.nsD, Rs, P, A.scd_begin, A.scd_members, A.accD, A.numD); return; }
+  blk -= nD;
+  if (blk < nE) { accumScEBlock(blk / A.nsTop, blk % A.nsTop, A.nsTop, Rs, P, A.top_begin, A.top_members, A.accE); return; }
+  blk -= nE;
+  accumScCBlock(blk, A.nsC, A.N, P, A.accC);
 }
 
 // ------------------------------------------------------------------------------------------------ fp64 stitching
-// step 1: per bucket adjoint sandwiches into contribution slabs.  step 2 (k_ba_stitch_gather) sums them in a fixed order.
+// step 1: adjoint sandwiches per bucket (summed over the inner frame index where the destination block is fixed),
+// step 2 (k_ba_stitch_gather): every element of H_A, b_A, H_sc, b_sc sums <= 2F+1 slab entries in a fixed order.
 struct StitchBufs {
-  double* topHH; double* topTT; double* topHT;   // F*F x 64
-  double* topHC; double* topTC;                  // F*F x 32   (8x4)
-  double* topBH; double* topBT;                  // F*F x 8
-  double* scHH; double* scTT; double* scTH; double* scHT;  // F^3 x 64
+  double* topHH;  // F x 64     sum_t AH B AH^T            -> block (h,h)
+  double* topTT;  // F*F x 64   AT B AT^T   per (h,t)      -> block (t,t)
+  double* topHT;  // F*F x 64   AH B AT^T   per (h,t)      -> block (h,t)
+  double* topHC;  // F x 32     sum_t AH B8C               -> rows of frame h, calib columns
+  double* topTC;  // F*F x 32   AT B8C      per (h,t)      -> rows of frame t
+  double* topBH;  // F x 8      sum_t AH b8
+  double* topBT;  // F*F x 8    AT b8       per (h,t)
+  double* topCC;  // F x 20     sum_t [Bcc (16) | bc (4)]
+  double* scHH;   // F*F x 64   sum_k AH_ij D AH_ik^T      -> block (i,i)
+  double* scTH;   // F*F x 64   sum_k AT_ij D AH_ik^T      -> block (j,i)
+  double* scTT;   // F^3 x 64   AT_ij D AT_ik^T            -> block (j,k)
+  double* scHT;   // F^3 x 64   AH_ij D AT_ik^T            -> block (i,k)
   double* scHC; double* scTC; double* scBH; double* scBT;  // F*F x 32 / 8
 };
 
-__device__ __forceinline__ double sandwich(const double* A, const double* T /*8x8 LDS: A*B*/, const double* C, int r, int c) {
-  (void)A;
+__device__ __forceinline__ double rowDotT(const double* T /*8x8: A*B*/, const double* C, int r, int c) {
   double s = 0;
 #pragma unroll
   for (int q = 0; q < 8; q++) s += T[r * 8 + q] * C[c * 8 + q];
   return s;
 }
 
-// top: bucket k = h + F*t : B = acc.H (13x13) ; 64 threads
-__global__ void __launch_bounds__(64) k_ba_stitch_top(const int F, const float* __restrict__ acc /* F*F x 96 */, const int* __restrict__ num,
-                                                       const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
+// top: one workgroup per host h, loop over targets t; bucket k = h + F*t : B = acc.H (13x13)
+__global__ void __launch_bounds__(64) k_ba_stitch_top(const int F, const int nsplit, const float* __restrict__ acc /* F*F x nsplit x 96 */,
+                                                       const int* __restrict__ num, const double* __restrict__ adHost, const double* __restrict__ adTarget,
+                                                       const StitchBufs S) {
   __shared__ double sB[13][13], sAH[64], sAT[64], sT1[64], sT2[64];
-  const int k = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
-  const bool has = num[k] > 0;
-  // unpack the 91 sums into the symmetric 13x13 (finish(), MatrixAccumulators.h:621-653)
-  for (int q = e; q < 169; q += 64) {
-    int i = q / 13, j = q % 13;
-    if (i > j) { int t = i; i = j; j = t; }
-    float v;
-    if (j < 10) { int off = i * 10 - (i * (i - 1)) / 2; v = acc[k * 96 + off + (j - i)]; }
-    else if (i < 10) v = acc[k * 96 + 55 + i * 3 + (j - 10)];
-    else { const int br = (i == 10) ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5); v = acc[k * 96 + 85 + br]; }
-    sB[q / 13][q % 13] = has ? (double)v : 0.0;
-  }
-  sAH[e] = adHost[k * 64 + e]; sAT[e] = adTarget[k * 64 + e];
-  __syncthreads();
-  double t1 = 0, t2 = 0;
+  const int hI = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
+  double hh = 0, hc = 0, bh = 0, cc = 0;
+  for (int t = 0; t < F; t++) {
+    const int k = hI + F * t;
+    __syncthreads();
+    // unpack the 91 sums into the symmetric 13x13 (finish(), MatrixAccumulators.h:621-653)
+    for (int q = e; q < 169; q += 64) {
+      int i = q / 13, j = q % 13;
+      if (i > j) { int tt = i; i = j; j = tt; }
+      int slot;
+      if (j < 10) slot = i * 10 - (i * (i - 1)) / 2 + (j - i);
+      else if (i < 10) slot = 55 + i * 3 + (j - 10);
+      else slot = 85 + ((i == 10) ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5));
+      double v = 0.0;
+      for (int sp = 0; sp < nsplit; sp++) if (num[k * nsplit + sp] > 0) v += (double)acc[(k * nsplit + sp) * 96 + slot];
+      sB[q / 13][q % 13] = v;
+    }
+    sAH[e] = adHost[k * 64 + e]; sAT[e] = adTarget[k * 64 + e];
+    __syncthreads();
+    double t1 = 0, t2 = 0;
 #pragma unroll
-  for (int q = 0; q < 8; q++) { t1 += sAH[r * 8 + q] * sB[4 + q][4 + c]; t2 += sAT[r * 8 + q] * sB[4 + q][4 + c]; }
-  sT1[e] = t1; sT2[e] = t2;
-  __syncthreads();
-  S.topHH[k * 64 + e] = sandwich(nullptr, sT1, sAH, r, c);
-  S.topTT[k * 64 + e] = sandwich(nullptr, sT2, sAT, r, c);
-  S.topHT[k * 64 + e] = sandwich(nullptr, sT1, sAT, r, c);
+    for (int q = 0; q < 8; q++) { t1 += sAH[r * 8 + q] * sB[4 + q][4 + c]; t2 += sAT[r * 8 + q] * sB[4 + q][4 + c]; }
+    sT1[e] = t1; sT2[e] = t2;
+    __syncthreads();
+    hh += rowDotT(sT1, sAH, r, c);
+    S.topTT[k * 64 + e] = rowDotT(sT2, sAT, r, c);
+    S.topHT[k * 64 + e] = rowDotT(sT1, sAT, r, c);
+    if (c < 4) {
+      double h1 = 0, h2 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { h1 += sAH[r * 8 + q] * sB[4 + q][c]; h2 += sAT[r * 8 + q] * sB[4 + q][c]; }
+      hc += h1; S.topTC[k * 32 + r * 4 + c] = h2;
+    }
+    if (c == 4) {
+      double b1 = 0, b2 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { b1 += sAH[r * 8 + q] * sB[4 + q][12]; b2 += sAT[r * 8 + q] * sB[4 + q][12]; }
+      bh += b1; S.topBT[k * 8 + r] = b2;
+    }
+    if (e < 16) cc += sB[e >> 2][e & 3];
+    else if (e < 20) cc += sB[e - 16][12];
+  }
+  S.topHH[hI * 64 + e] = hh;
+  if (c < 4) S.topHC[hI * 32 + r * 4 + c] = hc;
+  if (c == 4) S.topBH[hI * 8 + r] = bh;
+  if (e < 20) S.topCC[hI * 20 + e] = cc;
+}
+
+// SC: one workgroup per (i,j), loop over k; accD index = ((i + F*j) + k*F*F)
+__global__ void __launch_bounds__(64) k_ba_stitch_sc(const int F, const int nsplit, const int nsplitE, const float* __restrict__ accD, const int* __restrict__ numD,
+                                                      const float* __restrict__ accE /* F*F x nsplitE x 40 */,
+                                                      const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
+  __shared__ double sD[64], sAHij[64], sATij[64], sAHik[64], sATik[64], sT1[64], sT2[64], sE[40];
+  const int ij = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
+  const int F2 = F * F, i = ij % F;
+  sAHij[e] = adHost[ij * 64 + e]; sATij[e] = adTarget[ij * 64 + e];
+  if (e < 40) {
+    double v = 0.0;
+    for (int sp = 0; sp < nsplitE; sp++) v += (double)accE[(ij * nsplitE + sp) * 40 + e];
+    sE[e] = v;
+  }
+  double hh = 0, th = 0;
+  for (int kk = 0; kk < F; kk++) {
+    const int ijk = ij + kk * F2, ik = i + F * kk;
+    __syncthreads();
+    {
+      double v = 0.0;
+      for (int sp = 0; sp < nsplit; sp++) if (numD[ijk * nsplit + sp] > 0) v += (double)accD[(ijk * nsplit + sp) * 64 + e];
+      sD[e] = v;
+    }
+    sAHik[e] = adHost[ik * 64 + e]; sATik[e] = adTarget[ik * 64 + e];
+    __syncthreads();
+    double t1 = 0, t2 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { t1 += sAHij[r * 8 + q] * sD[q * 8 + c]; t2 += sATij[r * 8 + q] * sD[q * 8 + c]; }
+    sT1[e] = t1; sT2[e] = t2;
+    __syncthreads();
+    hh += rowDotT(sT1, sAHik, r, c);
+    th += rowDotT(sT2, sAHik, r, c);
+    S.scTT[ijk * 64 + e] = rowDotT(sT2, sATik, r, c);
+    S.scHT[ijk * 64 + e] = rowDotT(sT1, sATik, r, c);
+  }
+  S.scHH[ij * 64 + e] = hh;
+  S.scTH[ij * 64 + e] = th;
+  // accE (8x4) and accEB (8)
   if (c < 4) {
     double h1 = 0, h2 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { h1 += sAH[r * 8 + q] * sB[4 + q][c]; h2 += sAT[r * 8 + q] * sB[4 + q][c]; }
-    S.topHC[k * 32 + r * 4 + c] = h1; S.topTC[k * 32 + r * 4 + c] = h2;
+    for (int q = 0; q < 8; q++) { h1 += sAHij[r * 8 + q] * sE[q * 4 + c]; h2 += sATij[r * 8 + q] * sE[q * 4 + c]; }
+    S.scHC[ij * 32 + r * 4 + c] = h1; S.scTC[ij * 32 + r * 4 + c] = h2;
   }
-  if (c == 0) {
+  if (c == 4) {
     double b1 = 0, b2 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { b1 += sAH[r * 8 + q] * sB[4 + q][12]; b2 += sAT[r * 8 + q] * sB[4 + q][12]; }
-    S.topBH[k * 8 + r] = b1; S.topBT[k * 8 + r] = b2;
-  }
-}
-
-// SC: block idx = ijk = (i + F*j) + k*F*F
-__global__ void __launch_bounds__(64) k_ba_stitch_sc(const int F, const float* __restrict__ accD, const int* __restrict__ numD,
-                                                      const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
-  __shared__ double sD[64], sAHij[64], sATij[64], sAHik[64], sATik[64], sT1[64], sT2[64];
-  const int ijk = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
-  const int F2 = F * F;
-  const int ij = ijk % F2, kk = ijk / F2, i = ij % F;
-  const int ik = i + F * kk;
-  sD[e] = numD[ijk] > 0 ? (double)accD[ijk * 64 + e] : 0.0;
-  sAHij[e] = adHost[ij * 64 + e]; sATij[e] = adTarget[ij * 64 + e];
-  sAHik[e] = adHost[ik * 64 + e]; sATik[e] = adTarget[ik * 64 + e];
-  __syncthreads();
-  double t1 = 0, t2 = 0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) { t1 += sAHij[r * 8 + q] * sD[q * 8 + c]; t2 += sATij[r * 8 + q] * sD[q * 8 + c]; }
-  sT1[e] = t1; sT2[e] = t2;
-  __syncthreads();
-  S.scHH[ijk * 64 + e] = sandwich(nullptr, sT1, sAHik, r, c);
-  S.scTT[ijk * 64 + e] = sandwich(nullptr, sT2, sATik, r, c);
-  S.scTH[ijk * 64 + e] = sandwich(nullptr, sT2, sAHik, r, c);
-  S.scHT[ijk * 64 + e] = sandwich(nullptr, sT1, sATik, r, c);
-}
-__global__ void __launch_bounds__(64) k_ba_stitch_scE(const int F, const float* __restrict__ accE /* F*F x 40 */,
-                                                       const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
-  const int ij = blockIdx.x, e = threadIdx.x;
-  if (e < 32) {
-    const int r = e >> 2, c = e & 3;
-    double h1 = 0, h2 = 0;
-    for (int q = 0; q < 8; q++) { const double v = (double)accE[ij * 40 + q * 4 + c]; h1 += adHost[ij * 64 + r * 8 + q] * v; h2 += adTarget[ij * 64 + r * 8 + q] * v; }
-    S.scHC[ij * 32 + e] = h1; S.scTC[ij * 32 + e] = h2;
-  } else if (e < 40) {
-    const int r = e - 32;
-    double b1 = 0, b2 = 0;
-    for (int q = 0; q < 8; q++) { const double v = (double)accE[ij * 40 + 32 + q]; b1 += adHost[ij * 64 + r * 8 + q] * v; b2 += adTarget[ij * 64 + r * 8 + q] * v; }
+    for (int q = 0; q < 8; q++) { b1 += sAHij[r * 8 + q] * sE[32 + q]; b2 += sATij[r * 8 + q] * sE[32 + q]; }
     S.scBH[ij * 8 + r] = b1; S.scBT[ij * 8 + r] = b2;
   }
 }
 
 // step 2: one thread per element of H_A, H_sc (n x n, n = 4+8F) and b_A, b_sc; fixed summation order.
 // Output layout: out[0 .. n*n) = H_A, then b_A (n), then H_sc (n*n), then b_sc (n).
-__global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const float* __restrict__ accTop, const int* __restrict__ numTop,
-                                                           const float* __restrict__ accC, const StitchBufs S, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs S,
+                                                           double* __restrict__ out) {
   const int n = 4 + 8 * F, F2 = F * F;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int per = n * n + n;
@@ -548,26 +666,25 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const flo
   if (t < n * n) {
     const int row = t / n, col = t % n;
     if (row < 4 && col < 4) {
-      if (!sc) { for (int k = 0; k < F2; k++) if (numTop[k] > 0) { int i = row < col ? row : col, j = row < col ? col : row; val += (double)accTop[k * 96 + (i * 10 - (i * (i - 1)) / 2) + (j - i)]; } }
-      else val = (double)accC[row * 4 + col];
+      if (!sc) { for (int q = 0; q < F; q++) val += S.topCC[q * 20 + row * 4 + col]; }
+      else for (int sp = 0; sp < nsC; sp++) val += (double)accC[sp * 20 + row * 4 + col];
     } else if (row < 4 || col < 4) {
-      // calib cross terms: H[fIdx.., 0..4) accumulated, then mirrored into H[0..4), fIdx..)
+      // calib cross terms: H[fIdx.., 0..4) accumulated, mirrored into H[0..4), fIdx..)
       const int cc = row < 4 ? row : col, fr = (row < 4 ? col : row) - 4;
       const int f = fr >> 3, r = fr & 7;
-      if (!sc) { for (int q = 0; q < F; q++) val += S.topHC[(f + F * q) * 32 + r * 4 + cc]; for (int q = 0; q < F; q++) val += S.topTC[(q + F * f) * 32 + r * 4 + cc]; }
+      if (!sc) { val = S.topHC[f * 32 + r * 4 + cc]; for (int q = 0; q < F; q++) val += S.topTC[(q + F * f) * 32 + r * 4 + cc]; }
       else { for (int q = 0; q < F; q++) val += S.scHC[(f + F * q) * 32 + r * 4 + cc]; for (int q = 0; q < F; q++) val += S.scTC[(q + F * f) * 32 + r * 4 + cc]; }
     } else {
       const int bi = (row - 4) >> 3, bj = (col - 4) >> 3, r = (row - 4) & 7, c = (col - 4) & 7;
       if (!sc) {
         // H[h,h] += HH[h,t], H[t,t] += TT[h,t], H[h,t] += HT[h,t]; then (h<t): H[h,t] += H[t,h]^T, H[t,h] = H[h,t]^T
-        if (bi == bj) { for (int q = 0; q < F; q++) val += S.topHH[(bi + F * q) * 64 + r * 8 + c]; for (int q = 0; q < F; q++) val += S.topTT[(q + F * bi) * 64 + r * 8 + c]; val += S.topHT[(bi + F * bi) * 64 + r * 8 + c]; }
-        else if (bi < bj) val = S.topHT[(bi + F * bj) * 64 + r * 8 + c] + S.topHT[(bj + F * bi) * 64 + c * 8 + r];
-        else val = S.topHT[(bj + F * bi) * 64 + c * 8 + r] + S.topHT[(bi + F * bj) * 64 + r * 8 + c];
+        if (bi == bj) { val = S.topHH[bi * 64 + r * 8 + c]; for (int q = 0; q < F; q++) val += S.topTT[(q + F * bi) * 64 + r * 8 + c]; val += S.topHT[(bi + F * bi) * 64 + r * 8 + c]; }
+        else val = S.topHT[(bi + F * bj) * 64 + r * 8 + c] + S.topHT[(bj + F * bi) * 64 + c * 8 + r];
       } else {
-        // H[i,i] += HH[ijk] (all j,k); H[j,k] += TT[ijk] (all i); H[j,i] += TH[ijk] (all k); H[i,k] += HT[ijk] (all j)
-        if (bi == bj) for (int j = 0; j < F; j++) for (int k = 0; k < F; k++) val += S.scHH[((bi + F * j) + k * F2) * 64 + r * 8 + c];
+        // H[i,i] += HH[ij] (all j); H[j,k] += TT[ijk] (all i); H[j,i] += TH[ij]; H[i,k] += HT[ijk] (all j)
+        if (bi == bj) for (int j = 0; j < F; j++) val += S.scHH[(bi + F * j) * 64 + r * 8 + c];
         for (int i = 0; i < F; i++) val += S.scTT[((i + F * bi) + bj * F2) * 64 + r * 8 + c];
-        for (int k = 0; k < F; k++) val += S.scTH[((bj + F * bi) + k * F2) * 64 + r * 8 + c];
+        val += S.scTH[(bj + F * bi) * 64 + r * 8 + c];
         for (int j = 0; j < F; j++) val += S.scHT[((bi + F * j) + bj * F2) * 64 + r * 8 + c];
       }
     }
@@ -575,11 +692,11 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const flo
   } else {
     const int row = t - n * n;
     if (row < 4) {
-      if (!sc) { for (int k = 0; k < F2; k++) if (numTop[k] > 0) val += (double)accTop[k * 96 + 55 + row * 3 + 2]; }
-      else val = (double)accC[16 + row];
+      if (!sc) { for (int q = 0; q < F; q++) val += S.topCC[q * 20 + 16 + row]; }
+      else for (int sp = 0; sp < nsC; sp++) val += (double)accC[sp * 20 + 16 + row];
     } else {
       const int f = (row - 4) >> 3, r = (row - 4) & 7;
-      if (!sc) { for (int q = 0; q < F; q++) val += S.topBH[(f + F * q) * 8 + r]; for (int q = 0; q < F; q++) val += S.topBT[(q + F * f) * 8 + r]; }
+      if (!sc) { val = S.topBH[f * 8 + r]; for (int q = 0; q < F; q++) val += S.topBT[(q + F * f) * 8 + r]; }
       else { for (int q = 0; q < F; q++) val += S.scBH[(f + F * q) * 8 + r]; for (int q = 0; q < F; q++) val += S.scBT[(q + F * f) * 8 + r]; }
     }
     out[(sc ? per : 0) + n * n + row] = val;

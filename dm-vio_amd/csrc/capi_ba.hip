@@ -14,6 +14,11 @@
 
 using namespace dmv;
 
+#include <chrono>
+// optional host-side time split of the GN iteration (DMVIO_HIP_BA_TIMING=1 prints it when the handle is destroyed)
+struct BATimes { double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n = 0; };
+static inline double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct dmvio_hip_ba {
   dmvio_hip_ctx* ctx = nullptr;
   BAHost H;
@@ -38,11 +43,15 @@ struct dmvio_hip_ba {
   float *h_newEnergyWO = nullptr;
   float* d_fullJ = nullptr;
   int n_lin_blocks = 0, n_pt_blocks = 0;
+  // partial accumulators per bucket (1 = replay the single-threaded reference bit for bit; DMVIO_HIP_BA_EXACT=1)
+  int nsTop = 1, nsD = 1, nsC = 1;
   bool graph_ready = false;
   // energies of the last optimize
   double trace[64][4];
   int iterations_done = 0;
   double final_energy = 0;
+  BATimes tm;
+  bool timing = false;
 };
 
 template <class T>
@@ -115,22 +124,25 @@ static int accumulate(dmvio_hip_ba* b) {
   const int F = H.F, F2 = F * F, n = H.n();
   hipStream_t s = c->stream;
   hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, s, b->W, b->P, b->Rs);
-  hipLaunchKernelGGL(k_ba_accum_top, dim3(F2), dim3(128), 0, s, b->W, b->Rs, b->d_top_begin, b->d_top_members, b->d_accTop, b->d_numTop);
-  hipLaunchKernelGGL(k_ba_accum_scD, dim3(F2 * F), dim3(64), 0, s, b->Rs, b->P, b->d_scd_begin, b->d_scd_members, b->d_accD, b->d_numD);
-  hipLaunchKernelGGL(k_ba_accum_scE, dim3(F2), dim3(64), 0, s, b->Rs, b->P, b->d_top_begin, b->d_top_members, b->d_accE);
-  hipLaunchKernelGGL(k_ba_accum_scC, dim3(1), dim3(64), 0, s, H.N, b->P, b->d_accC);
-  hipLaunchKernelGGL(k_ba_stitch_top, dim3(F2), dim3(64), 0, s, F, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
-  hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2 * F), dim3(64), 0, s, F, b->d_accD, b->d_numD, b->d_adHost, b->d_adTarget, b->SB);
-  hipLaunchKernelGGL(k_ba_stitch_scE, dim3(F2), dim3(64), 0, s, F, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
+  {
+    AccumArgs A;
+    A.F = F; A.N = H.N; A.nsTop = b->nsTop; A.nsD = b->nsD; A.nsC = b->nsC;
+    A.top_begin = b->d_top_begin; A.top_members = b->d_top_members; A.scd_begin = b->d_scd_begin; A.scd_members = b->d_scd_members;
+    A.accTop = b->d_accTop; A.accD = b->d_accD; A.accE = b->d_accE; A.accC = b->d_accC; A.numTop = b->d_numTop; A.numD = b->d_numD;
+    const int nblk = F2 * b->nsTop + F2 * F * b->nsD + F2 * b->nsTop + b->nsC;
+    hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, b->Rs, b->P);
+  }
+  hipLaunchKernelGGL(k_ba_stitch_top, dim3(F), dim3(64), 0, s, F, b->nsTop, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
+  hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2), dim3(64), 0, s, F, b->nsD, b->nsTop, b->d_accD, b->d_numD, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
   const int tot = 2 * (n * n + n);
-  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 255) / 256), dim3(256), 0, s, F, b->d_accTop, b->d_numTop, b->d_accC, b->SB, b->d_sys);
+  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 255) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_sys);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(b->h_sys, b->d_sys, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_numTop, sizeof(int) * F2, hipMemcpyDeviceToHost, s));  // reuse pinned scratch for the counts
+  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_numTop, sizeof(int) * F2 * b->nsTop, hipMemcpyDeviceToHost, s));  // reuse pinned scratch for the counts
   HIPCHK(hipStreamSynchronize(s));
   int res = 0;
   const int* cnt = (const int*)b->h_epart;
-  for (int k = 0; k < F2; k++) res += cnt[k];
+  for (int k = 0; k < F2 * b->nsTop; k++) res += cnt[k];
   H.resInA = res;
   return 0;
 }
@@ -167,12 +179,21 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   dmvio_hip_ba* b = new dmvio_hip_ba();
   b->ctx = ctx;
   b->H.w = ctx->w; b->H.h = ctx->h;
+  // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
+  if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
+  if (const char* e = getenv("DMVIO_HIP_BA_SPLIT")) { const int k = atoi(e); if (k >= 1 && k <= 8) { b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = 4 * k; } }
   return b;
 }
 void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
+  if (b->timing && b->tm.n > 0) {
+    const char* names[8] = {"backup", "accumulate+D2H", "host solve", "resubstitute", "step frames+points", "precalc", "linearize+TH", "apply/restore"};
+    fprintf(stderr, "[dmvio_hip_ba] GN iteration host-side split over %ld iterations (us/iter):", b->tm.n);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f", names[i], b->tm.t[i] / b->tm.n);
+    fprintf(stderr, "\n");
+  }
   freeDevice(b);
   delete b;
 }
@@ -287,23 +308,24 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipMemcpyAsync(P.idepth, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(P.idepth_zero, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
   if (dalloc(b, &b->d_pre, F2) || dalloc(b, &b->d_adHost, (size_t)F2 * 64) || dalloc(b, &b->d_adTarget, (size_t)F2 * 64) || dalloc(b, &b->d_top_begin, F2 + 1) ||
-      dalloc(b, &b->d_top_members, R) || dalloc(b, &b->d_scd_begin, F2 * F + 1) || dalloc(b, &b->d_scd_members, 3 * npairs) || dalloc(b, &b->d_accTop, (size_t)F2 * 96) ||
-      dalloc(b, &b->d_accD, (size_t)F2 * F * 64) || dalloc(b, &b->d_accE, (size_t)F2 * 40) || dalloc(b, &b->d_accC, 32) || dalloc(b, &b->d_numTop, F2) || dalloc(b, &b->d_numD, F2 * F)) return -1;
+      dalloc(b, &b->d_top_members, R) || dalloc(b, &b->d_scd_begin, F2 * F + 1) || dalloc(b, &b->d_scd_members, 3 * npairs) || dalloc(b, &b->d_accTop, (size_t)F2 * 96 * b->nsTop) ||
+      dalloc(b, &b->d_accD, (size_t)F2 * F * 64 * b->nsD) || dalloc(b, &b->d_accE, (size_t)F2 * 40 * b->nsTop) || dalloc(b, &b->d_accC, 20 * b->nsC) || dalloc(b, &b->d_numTop, F2 * b->nsTop) || dalloc(b, &b->d_numD, F2 * F * b->nsD)) return -1;
   HIPCHK(hipMemcpyAsync(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(b->d_top_members, top_members.data(), sizeof(int) * R, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, hipMemcpyHostToDevice, s));
   StitchBufs& SB = b->SB;
-  if (dalloc(b, &SB.topHH, (size_t)F2 * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F2 * 32) ||
-      dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F2 * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.scHH, (size_t)F2 * F * 64) ||
-      dalloc(b, &SB.scTT, (size_t)F2 * F * 64) || dalloc(b, &SB.scTH, (size_t)F2 * F * 64) || dalloc(b, &SB.scHT, (size_t)F2 * F * 64) || dalloc(b, &SB.scHC, (size_t)F2 * 32) ||
+  if (dalloc(b, &SB.topHH, (size_t)F * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F * 32) ||
+      dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.topCC, (size_t)F * 20) ||
+      dalloc(b, &SB.scHH, (size_t)F2 * 64) || dalloc(b, &SB.scTT, (size_t)F2 * F * 64) || dalloc(b, &SB.scTH, (size_t)F2 * 64) || dalloc(b, &SB.scHT, (size_t)F2 * F * 64) ||
+      dalloc(b, &SB.scHC, (size_t)F2 * 32) ||
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
   b->n_lin_blocks = (R + 127) / 128; b->n_pt_blocks = (N + 255) / 256;
-  if (dalloc(b, &b->d_sys, tot) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4) ||
+  if (dalloc(b, &b->d_sys, tot) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2 * 8)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4) ||
       dalloc(b, &b->d_xAd, (size_t)F2 * 8) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * tot, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * std::max(b->n_lin_blocks, F2), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * std::max(b->n_lin_blocks, F2 * 8), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_newEnergyWO, sizeof(float) * R, hipHostMallocDefault));
   if (int r = uploadAdjoints(b)) return r;
@@ -431,25 +453,34 @@ int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
 static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted) {
   BAHost& H = b->H;
   const int n = H.n();
+  double t0 = nowUs(), t1;
+#define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->ctx->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
   // backupState
   H.backupFrames();
   float dummy0, dummy1;
   if (int r = pointStep(b, 0, 0.f, &dummy0, &dummy1)) return r;
+  BA_LAP(0);
   // solveSystem
   H.getNullspaces();
   if (int r = accumulate(b)) return r;
+  BA_LAP(1);
   const double* p = b->h_sys;
   std::vector<double> x;
   H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
+  BA_LAP(2);
   if (int r = resubstitute(b, x)) return r;
+  BA_LAP(3);
   // doStepFromBackup
   float fs[4], sumID = 0, sumNID = 0;
   H.stepFrames(1.0f, fs);
   if (int r = pointStep(b, 1, 1.0f, &sumID, &sumNID)) return r;
+  BA_LAP(4);
   H.setPrecalcValues();
+  BA_LAP(5);
   // eval new energy
   double newE = 0;
   if (int r = linearizeAll(b, false, &newE)) return r;
+  BA_LAP(6);
   const double newL = H.calcLEnergyFrames(), newM = H.calcMEnergy();
   accepted = (newE + newL + newM < lastE[0] + lastE[1] + lastE[2]);
   if (accepted) {
@@ -464,6 +495,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
     lambda *= 1e2;
   }
+  BA_LAP(7);
+  b->tm.n++;
+#undef BA_LAP
   return 0;
 }
 

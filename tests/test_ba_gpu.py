@@ -50,9 +50,21 @@ def test_linearize_bit_exact(big):
         assert np.array_equal(J[ri].view(np.uint32), flat.view(np.uint32)), "residual %d" % ri
 
 
-def test_accumulate_and_solve_parity(big):
-    """accumulateAF / accumulateSCF + adjoint stitching, solveSystemF, resubstitute."""
-    ba, W = big["ba"], big["W"]
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_accumulate_and_solve_parity(big, pkg, oracle, mode, monkeypatch):
+    """accumulateAF / accumulateSCF + adjoint stitching, solveSystemF, resubstitute.
+    exact (default): one accumulator per bucket replays the single-threaded reference order (incl. 1k/1M shift-up) -> systems agree
+    to double rounding.  fast (DMVIO_HIP_BA_SPLIT=6): several partial accumulators per bucket, summed in double like the reference's
+    six per-worker accumulators -> agreement at fp32 summation level."""
+    if mode == "exact":
+        monkeypatch.delenv("DMVIO_HIP_BA_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("DMVIO_HIP_BA_SPLIT", "6")
+    case = big["case"]
+    ba = pkg.BundleAdjusterHip(big["ctx"])
+    ba.set_case(case, list(range(case["n_frames"])))
+    W = oracle.BAWindow(case)
+    tolH, tolx = (1e-11, 1e-6) if mode == "exact" else (2e-6, 2e-3)
     ba.activate_all(); W.activate_all()
     ba.linearize_all(False); W.linearize_all(False)
     ba.apply_res(); W.apply_res()
@@ -62,15 +74,17 @@ def test_accumulate_and_solve_parity(big):
     for k in ("Hdd", "bd", "Hcd", "HdiF", "bdSumF"):
         assert np.array_equal(pg[k], po[k]), k
     sc = np.sqrt(np.outer(np.diag(ao["HA"]) + 1e-12, np.diag(ao["HA"]) + 1e-12))
-    assert np.max(np.abs(ag["HA"] - ao["HA"]) / sc) < 1e-11
-    assert np.max(np.abs(ag["Hsc"] - ao["Hsc"]) / sc) < 1e-11
-    assert np.allclose(ag["bA"], ao["bA"], rtol=1e-10, atol=1e-10 * np.abs(ao["bA"]).max())
-    assert np.allclose(ag["bsc"], ao["bsc"], rtol=1e-10, atol=1e-10 * np.abs(ao["bsc"]).max())
+    assert np.max(np.abs(ag["HA"] - ao["HA"]) / sc) < tolH
+    assert np.max(np.abs(ag["Hsc"] - ao["Hsc"]) / sc) < tolH
+    bs = np.sqrt(np.diag(ao["HA"]) + 1e-12) * np.sqrt(ao["HA"].shape[0])
+    assert np.max(np.abs(ag["bA"] - ao["bA"]) / (np.abs(ao["bA"]) + bs)) < max(tolH, 1e-10) * 1e3
+    assert np.max(np.abs(ag["bsc"] - ao["bsc"]) / (np.abs(ao["bsc"]) + bs)) < max(tolH, 1e-10) * 1e3
     for it, lam in ((0, 1e-5), (2, 1e-3)):
         xg = ba.solve(it, lam); xo = W.solve(it, lam)
-        assert np.allclose(xg, xo, rtol=1e-6, atol=1e-8 * np.abs(xo).max())
+        assert np.allclose(xg, xo, rtol=tolx, atol=tolx * 1e-2 * np.abs(xo).max())
         _, sg = ba.point_state(); _, so = W.point_state()
-        assert np.allclose(sg, so, rtol=1e-4, atol=1e-6 * np.abs(so).max())
+        assert np.allclose(sg, so, rtol=100 * tolx, atol=tolx * np.abs(so).max())
+    ba.close()
 
 
 def test_optimize_parity(pkg, oracle, synth, gpu_required):
