@@ -56,15 +56,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # test hooks for single-GPU boxes: DMVIO_BENCH_BACKEND=gloo + DMVIO_BENCH_SHARE_DEVICE=1 run the N>1 code path with all ranks on GPU 0
+    backend = os.environ.get("DMVIO_BENCH_BACKEND", "nccl")
+    if os.environ.get("DMVIO_BENCH_SHARE_DEVICE"):
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     pkg = graft.load_package()
     import dmvio_amd.synth as synth
@@ -127,7 +135,7 @@ def main():
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -191,7 +199,8 @@ def main():
     # ---------------- BA leg: Gauss-Newton iterations / s of the 8-keyframe sliding-window photometric BA (rank 0 window per rank)
     ba_out = None
     if not args.no_ba:
-        ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, torch=torch, cpu=(rank == 0 and world == 1 and not args.no_cpu))
+        ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, coll_dev=coll_dev, torch=torch,
+                          cpu=(rank == 0 and world == 1 and not args.no_cpu))
 
     if rank == 0:
         out = {
@@ -214,33 +223,36 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, torch, cpu):
+def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):
     """GN iterations / s of FullSystem::optimize's loop body (solveSystemF + doStepFromBackup + linearizeAll + energies + applyRes)
-    on an 8-keyframe, ~2000-point, ~12k-residual window.  Every rank optimises its own window replica."""
+    on an 8-keyframe, ~2000-point, ~12k-residual window."""
+    import dmvio_amd.sharding as sh
     w = h = args.size
-    case = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED + 17 * rank)
+    # N == 1: the rank optimises the whole window.  N > 1: ONE window, its points sharded by host keyframe over the ranks
+    # (north_star: "one keyframe per GPU"), the packed dense system all-reduced over RCCL every iteration (strong scaling).
+    case_full = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED)
+    parts = sh.partition_points_by_host(case_full["host"], world)
+    case = sh.shard_case(case_full, parts[rank]) if world > 1 else case_full
     F = case["n_frames"]
     ctx = pkg.Context(w, h, n_slots=F, device=ctx_device)
     for k in range(F):
         ctx.frame_upload(k, case["imgs"][k])
     ba = pkg.BundleAdjusterHip(ctx)
-
-    def fresh():
-        ba.set_case(case, list(range(F)))
-        ba.activate_all()
-        e = ba.linearize_all(False)
-        ba.apply_res()
-        return [e, 0.0, 0.0]
-
-    # correctness guard: the full optimize must decrease the energy
+    coll = sh.Collective(dist, coll_dev if coll_dev.type != "cpu" else None)
     ba.set_case(case, list(range(F)))
-    r = ba.optimize(6)
-    if not (r["trace"][-1, 0] < 0.7 * r["trace"][0, 0]):
-        raise SystemExit("bench: BA did not converge")
-    lastE = fresh()
-    lam = 1e-5
+    if world == 1:
+        # correctness guard: the full optimize must decrease the energy
+        r = ba.optimize(6)
+        if not (r["trace"][-1, 0] < 0.7 * r["trace"][0, 0]):
+            raise SystemExit("bench: BA did not converge")
+        ba.set_case(case, list(range(F)))
+    sba = sh.ShardedBA(ba, coll)
+    e0 = sba.begin()[0]
     for it in range(12):  # warmup (first touches of the freshly allocated window buffers)
-        acc, lam, lastE = ba.gn_iteration(it, lam, lastE)
+        sba.iteration(it % 6)
+    if not (sba.lastE[0] < 0.8 * e0):
+        raise SystemExit("bench: sharded BA did not reduce the energy (%g -> %g)" % (e0, sba.lastE[0]))
+    lam, lastE = sba.lam, list(sba.lastE)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -248,17 +260,22 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, torch, cpu):
     t0 = time.perf_counter()
     done = 0
     while done < n_it:   # keep iterating on the same window (accepted or rejected, an iteration does the same work) — like the CPU leg below
-        acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
+        if world == 1:
+            acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
+        else:
+            sba.iteration(done % 6)
         done += 1
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    case = case_full
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    out = dict(metric="BA GN-iterations/sec (8-KF window)", value=round(world * done / elapsed, 1), unit="GN-iters/s", ms_per_iter=round(1e3 * elapsed / done, 4),
+    out = dict(metric="BA GN-iterations/sec (8-KF window)", value=round(done / elapsed, 1), unit="GN-iters/s", ms_per_iter=round(1e3 * elapsed / done, 4),
+               scaling="strong" if world > 1 else None, shard_points=[int(len(p)) for p in parts],
                window=dict(frames=F, points=int(len(case["u"])), residuals=int(len(case["res_point"]))),
-               algorithmic_bytes_per_iter=int(len(case["res_point"]) * 464), note="one window per GPU")
+               algorithmic_bytes_per_iter=int(len(case["res_point"]) * 464), note="N=1: whole window on the GPU; N>1: one window, points sharded by host keyframe, one RCCL all-reduce of the packed 68x68 systems per iteration")
     if cpu:
         O = graft.load_oracle()
         res = {}

@@ -78,6 +78,13 @@ def _sig(L):
     L.dmvio_hip_ba_get_calib.argtypes = [vp, c_d]
     L.dmvio_hip_ba_gn_iteration.argtypes = [vp, C.c_int, c_d, c_d, c_i]
     L.dmvio_hip_ba_optimize.argtypes = [vp, C.c_int, c_f, c_d, c_i, c_d]
+    L.dmvio_hip_ba_backup.argtypes = [vp]
+    L.dmvio_hip_ba_solve_system.argtypes = [vp, C.c_int, C.c_double, c_d, c_d, c_d, c_d, c_d]
+    L.dmvio_hip_ba_step.argtypes = [vp, C.c_float, c_f]
+    L.dmvio_hip_ba_restore.argtypes = [vp]
+    L.dmvio_hip_ba_linearize_local.argtypes = [vp, C.c_int, c_d, c_f, c_i]
+    L.dmvio_hip_ba_set_new_frame_energy_th.argtypes = [vp, C.c_float]
+    L.dmvio_hip_ba_energy_terms.argtypes = [vp, c_d, c_d]
 
 
 def load_library():
@@ -384,6 +391,35 @@ class BundleAdjusterHip:
     def frame_pose(self, k):
         p = np.zeros(7); a = np.zeros(2); s = np.zeros(10)
         _chk(self.L, self.L.dmvio_hip_ba_get_frame(self.p, k, _d(p), _d(a), _d(s)), "ba_get_frame"); return p, a, s
+
+    # ---- sharded-iteration building blocks
+    def backup(self):
+        _chk(self.L, self.L.dmvio_hip_ba_backup(self.p), "ba_backup")
+
+    def solve_system(self, iteration, lam, HA, bA, Hsc, bsc):
+        x = np.zeros(self.n)
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (HA, bA, Hsc, bsc)]
+        _chk(self.L, self.L.dmvio_hip_ba_solve_system(self.p, iteration, lam, _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(x)), "ba_solve_system")
+        return x
+
+    def step(self, stepfac=1.0):
+        s6 = np.zeros(6, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_step(self.p, stepfac, _f(s6)), "ba_step"); return s6
+
+    def restore(self):
+        _chk(self.L, self.L.dmvio_hip_ba_restore(self.p), "ba_restore")
+
+    def linearize_local(self, fix=False):
+        e = C.c_double(0); n = C.c_int(0); buf = np.zeros(self.R, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_linearize_local(self.p, 1 if fix else 0, C.byref(e), _f(buf), C.byref(n)), "ba_linearize_local")
+        return e.value, buf[:n.value].copy()
+
+    def set_new_frame_energy_th(self, th):
+        _chk(self.L, self.L.dmvio_hip_ba_set_new_frame_energy_th(self.p, float(th)), "ba_set_new_frame_energy_th")
+
+    def energy_terms(self):
+        a = C.c_double(0); b = C.c_double(0)
+        _chk(self.L, self.L.dmvio_hip_ba_energy_terms(self.p, C.byref(a), C.byref(b)), "ba_energy_terms"); return a.value, b.value
 
     def gn_iteration(self, iteration, lam, lastE):
         l = C.c_double(lam); e = np.array(lastE, dtype=np.float64); acc = C.c_int(0)

@@ -512,6 +512,73 @@ int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io,
   return 0;
 }
 
+// ---- building blocks of a SHARDED Gauss-Newton iteration (one keyframe's points per GPU): the caller sums the packed
+// local systems / energies of all ranks (RCCL all-reduce) between these calls; every rank then solves the identical reduced system.
+int dmvio_hip_ba_backup(dmvio_hip_ba* b) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  b->H.backupFrames();
+  float d0, d1;
+  return pointStep(b, 0, 0.f, &d0, &d1);
+}
+int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* x_out) {
+  BA_READY(b);
+  if (!HA || !bA || !Hsc || !bsc) return failmsg("ba_solve_system: null argument");
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  b->H.getNullspaces();
+  std::vector<double> x;
+  b->H.solveSystem(iteration, lambda, HA, bA, Hsc, bsc, x);
+  if (x_out) memcpy(x_out, x.data(), sizeof(double) * b->H.n());
+  return resubstitute(b, x);
+}
+int dmvio_hip_ba_step(dmvio_hip_ba* b, float stepfac, float sums6[6]) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  float fs[4], sumID = 0, sumNID = 0;
+  b->H.stepFrames(stepfac, fs);
+  if (int r = pointStep(b, 1, stepfac, &sumID, &sumNID)) return r;
+  b->H.setPrecalcValues();
+  if (sums6) { for (int i = 0; i < 4; i++) sums6[i] = fs[i]; sums6[4] = sumID * b->H.N; sums6[5] = sumNID * b->H.N; }  // point sums un-normalised (local shard)
+  return 0;
+}
+int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  b->H.restoreFrames();
+  float d0, d1;
+  if (int r = pointStep(b, 2, 0.f, &d0, &d1)) return r;
+  b->H.setPrecalcValues();
+  return 0;
+}
+// linearizeAll WITHOUT the setNewFrameEnergyTH tail: returns the local energy and the state_NewEnergyWithOutlier values of the local
+// residuals that target the newest keyframe (the inputs of setNewFrameEnergyTH, FullSystemOptimize.cpp:96-149) so the caller can
+// gather them over all shards.
+int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  const float keep = b->H.fr[b->H.F - 1].frameEnergyTH;
+  double e = 0;
+  if (int r = linearizeAll(b, fix != 0, &e)) return r;
+  b->H.fr[b->H.F - 1].frameEnergyTH = keep;   // the threshold is set by the caller from the gathered energies
+  if (energy) *energy = e;
+  int n = 0;
+  for (int ri = 0; ri < b->H.R; ri++)
+    if (b->h_newEnergyWO[ri] >= 0 && b->h_target[ri] == b->H.F - 1) { if (new_frame_energies) new_frame_energies[n] = b->h_newEnergyWO[ri]; n++; }
+  if (n_new_frame_energies) *n_new_frame_energies = n;
+  return 0;
+}
+int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
+  if (!b) return failmsg("null ba");
+  b->H.fr[b->H.F - 1].frameEnergyTH = th;
+  return 0;
+}
+int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
+  if (!b) return failmsg("null ba");
+  if (EL) *EL = b->H.calcLEnergyFrames();
+  if (EM) *EM = b->H.calcMEnergy();
+  return 0;
+}
+
 // FullSystem::optimize (FullSystemOptimize.cpp:417-647), visual-only branch.
 int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
   BA_READY(b);

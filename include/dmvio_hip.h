@@ -157,6 +157,17 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* ba, int f, double pose7_w2c[7], double 
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* ba, double fxfycxcy[4]);
 /* one Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586); lastE = {E_A, E_L, E_M} in/out */
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io, double lastE[3], int* accepted);
+/* Building blocks of a SHARDED GN iteration (points of one keyframe per GPU; the packed systems / energies are summed by the caller
+ * with one RCCL all-reduce): backupState, solve of an externally reduced system + resubstitute, doStepFromBackup (sums6 = frame sums
+ * A,B,T,R and the local point sums step^2, |idepth_backup|), loadSateBackup, linearizeAll without the setNewFrameEnergyTH tail
+ * (returns the newest-frame energies it would use), the threshold setter and the prior / marginalisation energy terms. */
+int dmvio_hip_ba_backup(dmvio_hip_ba* ba);
+int dmvio_hip_ba_solve_system(dmvio_hip_ba* ba, int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* x_out);
+int dmvio_hip_ba_step(dmvio_hip_ba* ba, float stepfac, float sums6[6]);
+int dmvio_hip_ba_restore(dmvio_hip_ba* ba);
+int dmvio_hip_ba_linearize_local(dmvio_hip_ba* ba, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies);
+int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* ba, float th);
+int dmvio_hip_ba_energy_terms(dmvio_hip_ba* ba, double* EL, double* EM);
 /* FullSystem::optimize(mnumOptIts) (FullSystemOptimize.cpp:417-647): returns statistics_lastFineTrackRMSE in *rmse */
 int dmvio_hip_ba_optimize(dmvio_hip_ba* ba, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
 

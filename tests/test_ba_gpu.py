@@ -119,3 +119,44 @@ def test_small_window_and_ragged_graph(pkg, oracle, synth, gpu_required):
     assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
     for k in range(3):
         assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+
+
+def test_sharded_driver_world1_equals_gn_iteration(pkg, oracle, synth, gpu_required):
+    """dm-vio_amd/sharding.ShardedBA with a single rank == the library's own GN iteration (same accept sequence, same energies)."""
+    import dmvio_amd.sharding as sh
+    case = synth.ba_case(512, 512, n_frames=8, n_points=1000, seed=11)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba2 = pkg.BundleAdjusterHip(ctx); ba2.set_case(case, list(range(8)))
+    s = sh.ShardedBA(ba, sh.Collective(None, None))
+    lastE = list(s.begin())
+    ba2.activate_all(); e = ba2.linearize_all(False); ba2.apply_res()
+    assert e == lastE[0]
+    lam, lE = 1e-5, [e, 0.0, 0.0]
+    for it in range(6):
+        acc_s = s.iteration(it)
+        acc_l, lam, lE = ba2.gn_iteration(it, lam, lE)
+        assert acc_s == acc_l and abs(s.lastE[0] - lE[0]) <= 1e-9 * abs(lE[0]) and abs(s.lam - lam) < 1e-15
+    for k in range(8):
+        assert np.allclose(ba.frame_pose(k)[0], ba2.frame_pose(k)[0], atol=1e-12)
+
+
+def test_shard_systems_sum_to_full_system(pkg, oracle, synth, gpu_required):
+    """Rank emulation on one GPU: the packed systems of two keyframe shards add up to the full window's system."""
+    import dmvio_amd.sharding as sh
+    case = synth.ba_case(512, 512, n_frames=8, n_points=1000, seed=12)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba.activate_all(); e_full = ba.linearize_all(False); ba.apply_res(); full = ba.accumulate()
+    parts = sh.partition_points_by_host(case["host"], 2)
+    tot, e_sum = None, 0.0
+    for idx in parts:
+        sub = sh.shard_case(case, idx)
+        b = pkg.BundleAdjusterHip(ctx); b.set_case(sub, list(range(8)))
+        b.activate_all(); e_loc, _ = b.linearize_local(False); b.apply_res(); a = b.accumulate()
+        buf = sh.pack_system(a["HA"], a["bA"], a["Hsc"], a["bsc"], e_loc, a["resInA"])
+        tot = buf if tot is None else tot + buf
+        b.close()
+    HA, bA, Hsc, bsc, e_sum, res = sh.unpack_system(tot, ba.n)
+    sc = np.sqrt(np.outer(np.diag(full["HA"]) + 1e-9, np.diag(full["HA"]) + 1e-9))
+    assert np.max(np.abs(HA - full["HA"]) / sc) < 1e-11 and np.max(np.abs(Hsc - full["Hsc"])[4:, 4:] / sc[4:, 4:]) < 1e-11
+    assert np.max(np.abs(Hsc - full["Hsc"]) / sc) < 2e-6
+    assert res == full["resInA"] and abs(e_sum - e_full) <= 1e-9 * e_full
