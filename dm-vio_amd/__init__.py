@@ -54,6 +54,8 @@ def _sig(L):
     L.dmvio_hip_tracker_track_batch_stage.argtypes = [vp, C.c_int, c_i, c_f, c_d, c_d, C.c_int, c_d]
     L.dmvio_hip_tracker_track_batch_launch.argtypes = [vp]
     L.dmvio_hip_tracker_track_batch_fetch.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
+    L.dmvio_hip_make_track_hypotheses.argtypes = [c_d, c_d, c_d, c_d, C.c_int]
+    L.dmvio_hip_tracker_track_new_coarse.argtypes = [vp, C.c_int, C.c_float, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, c_i, c_i, c_i]
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     c_u8 = C.POINTER(C.c_ubyte)
@@ -128,6 +130,15 @@ def _d(a):
 
 def _i(a):
     return a.ctypes.data_as(c_i)
+
+
+def make_track_hypotheses(slast_c2w, sprelast_c2w, lastF_c2w):
+    """lastF_2_fh_tries of FullSystem::trackNewCoarse (host-side pose algebra of the library)."""
+    L = load_library()
+    out = np.zeros((31, 7))
+    n = L.dmvio_hip_make_track_hypotheses(_d(np.ascontiguousarray(slast_c2w, dtype=np.float64)), _d(np.ascontiguousarray(sprelast_c2w, dtype=np.float64)),
+                                          _d(np.ascontiguousarray(lastF_c2w, dtype=np.float64)), _d(out), 31)
+    return out[:n]
 
 
 class Context:
@@ -274,6 +285,16 @@ class CoarseTrackerHip:
         good = np.zeros(B, dtype=np.int32); its = np.zeros(B, dtype=np.int32)
         _chk(self.L, self.L.dmvio_hip_tracker_track_batch_fetch(self.p, _d(poses), _d(affs), _d(lr), _d(fl), _d(H), _d(b), _i(good), _i(its)), "fetch")
         return dict(good=good, pose7=poses, aff=affs, lastResiduals=lr, flow=fl, H=H.reshape(B, 8, 8), b=b, iterations=its)
+
+    def trackNewCoarse(self, new_slot, tries7, aff_last=(0.0, 0.0), lastCoarseRMSE=None, reTrackThreshold=1.5, new_exposure=1.0):
+        """The try loop of FullSystem::trackNewCoarse over the hypothesis list tries7 [n,7]."""
+        tries = np.ascontiguousarray(tries7, dtype=np.float64).reshape(-1, 7)
+        rm = np.full(5, 100.0) if lastCoarseRMSE is None else np.array(lastCoarseRMSE, dtype=np.float64)
+        pose = np.zeros(7); aff = np.zeros(2); flow = np.zeros(3); w = C.c_int(0); used = C.c_int(0); good = C.c_int(0)
+        al = np.array(aff_last, dtype=np.float64)
+        _chk(self.L, self.L.dmvio_hip_tracker_track_new_coarse(self.p, new_slot, new_exposure, len(tries), _d(tries), _d(al), _d(rm), reTrackThreshold,
+                                                               _d(pose), _d(aff), _d(flow), C.byref(w), C.byref(used), C.byref(good)), "trackNewCoarse")
+        return dict(winner=w.value, pose7=pose, aff=aff, achievedRes=rm, flow=flow, tries_used=used.value, good=bool(good.value))
 
     def last_ticks(self):
         a = C.c_longlong(0); b = C.c_longlong(0)

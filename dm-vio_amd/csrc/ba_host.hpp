@@ -43,26 +43,6 @@ struct BAFrameHost {
   double prior[8], delta[8], delta_prior[8];
 };
 
-// log of an SE3 element (se3.hpp:560-586, so3.hpp:497-540) — host only (nullspace construction)
-inline void poseLogHost(const Pose& T, double out[6]) {
-  const double n2 = T.q.x * T.q.x + T.q.y * T.q.y + T.q.z * T.q.z, n = std::sqrt(n2), w = T.q.w;
-  double f;
-  if (n < 1e-10) f = 2.0 / w - 2.0 * n2 / (w * w * w);
-  else if (std::fabs(w) < 1e-10) f = (w > 0 ? M_PI : -M_PI) / n;
-  else f = 2.0 * std::atan(n / w) / n;
-  const double theta = f * n;
-  out[3] = f * T.q.x; out[4] = f * T.q.y; out[5] = f * T.q.z;
-  const double O[9] = {0, -out[5], out[4], out[5], 0, -out[3], -out[4], out[3], 0};
-  double O2[9];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
-  const double c = std::fabs(theta) < 1e-10 ? 1.0 / 12.0 : (1.0 - theta / (2.0 * std::tan(theta / 2.0))) / (theta * theta);
-  for (int i = 0; i < 3; i++) {
-    double s = 0;
-    for (int j = 0; j < 3; j++) s += (((i == j) ? 1.0 : 0.0) - 0.5 * O[i * 3 + j] + c * O2[i * 3 + j]) * T.t[j];
-    out[i] = s;
-  }
-}
-
 struct BAHost {
   BASettingsHost S;
   int w = 0, h = 0, F = 0, N = 0, R = 0;

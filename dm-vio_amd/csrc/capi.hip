@@ -473,6 +473,98 @@ int dmvio_hip_tracker_track(dmvio_hip_tracker* t, int new_slot, float new_exposu
   return dmvio_hip_tracker_track_batch(t, 1, &new_slot, &new_exposure, pose7_io, aff_io, coarsestLvl, minRes, lastResiduals, lastFlow, H, b, good, nullptr);
 }
 
+// lastF_2_fh_tries of FullSystem::trackNewCoarse (FullSystem.cpp:364-402) from three camToWorld poses
+int dmvio_hip_make_track_hypotheses(const double slast_c2w[7], const double sprelast_c2w[7], const double lastF_c2w[7], double* out, int max_out) {
+  if (!slast_c2w || !sprelast_c2w || !lastF_c2w || !out) return failmsg("make_track_hypotheses: null argument");
+  const Pose slast = poseFrom7(slast_c2w), sprelast = poseFrom7(sprelast_c2w), lastF = poseFrom7(lastF_c2w);
+  const Pose fh_2_slast = poseMul(poseInv(sprelast), slast);          // slast_2_sprelast, assumed equal to fh_2_slast
+  const Pose lastF_2_slast = poseMul(poseInv(slast), lastF);
+  const Pose fhInv = poseInv(fh_2_slast);
+  std::vector<Pose> tries;
+  tries.push_back(poseMul(fhInv, lastF_2_slast));                       // constant motion
+  tries.push_back(poseMul(poseMul(fhInv, fhInv), lastF_2_slast));       // double motion (frame skipped)
+  { double lg[6]; poseLogHost(fh_2_slast, lg); for (int i = 0; i < 6; i++) lg[i] *= 0.5; tries.push_back(poseMul(poseInv(poseExp(lg)), lastF_2_slast)); }  // half motion
+  tries.push_back(lastF_2_slast);                                       // zero motion
+  Pose ident; ident.q.w = 1; ident.q.x = ident.q.y = ident.q.z = 0; ident.t[0] = ident.t[1] = ident.t[2] = 0;
+  tries.push_back(ident);                                               // zero motion from the keyframe
+  const double d = 0.02;                                                // the reference's rotDelta loop runs exactly once (:376)
+  static const int sg[26][3] = {{1,0,0},{0,1,0},{0,0,1},{-1,0,0},{0,-1,0},{0,0,-1},{1,1,0},{0,1,1},{1,0,1},{-1,1,0},{0,-1,1},{-1,0,1},{1,-1,0},{0,1,-1},{1,0,-1},
+                                {-1,-1,0},{0,-1,-1},{-1,0,-1},{-1,-1,-1},{-1,-1,1},{-1,1,-1},{-1,1,1},{1,-1,-1},{1,-1,1},{1,1,-1},{1,1,1}};
+  const Pose base = poseMul(fhInv, lastF_2_slast);
+  for (int k = 0; k < 26; k++) {
+    Pose R = ident;
+    Quatd q = {1, sg[k][0] * d, sg[k][1] * d, sg[k][2] * d};
+    R.q = qnormalize(q);
+    tries.push_back(poseMul(base, R));
+  }
+  const int n = std::min((int)tries.size(), max_out);
+  for (int i = 0; i < n; i++) poseTo7(tries[i], out + 7 * i);
+  return n;
+}
+
+// The try loop of FullSystem::trackNewCoarse (FullSystem.cpp:419-489).  The reference runs the hypotheses one after the other, feeding
+// the best residuals so far (achievedRes) to the next try as abort thresholds.  Here try 0 runs alone (the usual winner); only if it
+// misses the re-track threshold the remaining tries run as ONE batch without thresholds, and the sequential rule is replayed on
+// their per-level residuals: a level residual above 1.5x the running threshold marks the try as aborted at that level, exactly as
+// CoarseTracker.cpp:731-732 would have — per-level results do not depend on the thresholds, so the outcome is identical.
+int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float new_exposure, int n_tries, const double* tries7, const double aff_last[2],
+                                       double lastCoarseRMSE_io[5], double reTrackThreshold, double pose7_out[7], double aff_out[2], double flow_out[3],
+                                       int* winner, int* tries_used, int* tracking_good) {
+  if (!t || !tries7 || !aff_last || !lastCoarseRMSE_io || !pose7_out || !aff_out) return failmsg("track_new_coarse: null argument");
+  if (n_tries < 1) return failmsg("track_new_coarse: no hypotheses");
+  const int L = t->ctx->levels;
+  std::vector<double> poses(tries7, tries7 + 7 * (size_t)n_tries), affs(2 * (size_t)n_tries), lr(5 * (size_t)n_tries), fl(3 * (size_t)n_tries);
+  std::vector<int> good(n_tries), slots(n_tries, new_slot);
+  std::vector<float> exps(n_tries, new_exposure);
+  for (int i = 0; i < n_tries; i++) { affs[2 * i] = aff_last[0]; affs[2 * i + 1] = aff_last[1]; }
+  double achieved[5];
+  for (int k = 0; k < 5; k++) achieved[k] = NAN;
+  bool haveOneGood = false, trackingGoodRet = false;
+  int win = -1, used = 0;
+  double flow[3] = {100, 100, 100}, bestPose[7], bestAff[2] = {0, 0};
+  memcpy(bestPose, tries7, sizeof(bestPose));
+  int computed = 0;
+  for (int i = 0; i < n_tries; i++) {
+    if (i >= computed) {
+      const int first = computed, cnt = (first == 0) ? 1 : n_tries - first;
+      if (int r = dmvio_hip_tracker_track_batch(t, cnt, slots.data() + first, exps.data() + first, poses.data() + 7 * first, affs.data() + 2 * first, L - 1, nullptr,
+                                                lr.data() + 5 * first, fl.data() + 3 * first, nullptr, nullptr, good.data() + first, nullptr)) return r;
+      computed = first + cnt;
+    }
+    used++;
+    // replay the abort thresholds of the sequential loop on this try's per-level residuals
+    double res[5];
+    for (int k = 0; k < 5; k++) res[k] = NAN;
+    bool ok = good[i] != 0, aborted = false;
+    for (int lvl = L - 1; lvl >= 0; lvl--) {
+      const double rv = lr[5 * i + lvl];
+      res[lvl] = rv;
+      if (std::isnan(rv) || rv > 1.5 * achieved[lvl]) { aborted = true; break; }
+    }
+    if (aborted) ok = false;
+    if (ok) trackingGoodRet = true;
+    if (ok && std::isfinite((float)res[0]) && !(res[0] >= achieved[0])) {
+      for (int k = 0; k < 3; k++) flow[k] = fl[3 * i + k];
+      bestAff[0] = affs[2 * i]; bestAff[1] = affs[2 * i + 1];
+      memcpy(bestPose, poses.data() + 7 * i, sizeof(bestPose));
+      haveOneGood = true; win = i;
+    }
+    if (haveOneGood)
+      for (int k = 0; k < 5; k++)
+        if (!std::isfinite((float)achieved[k]) || achieved[k] > res[k]) achieved[k] = res[k];
+    if (haveOneGood && achieved[0] < lastCoarseRMSE_io[0] * reTrackThreshold) break;
+  }
+  if (!haveOneGood) { flow[0] = flow[1] = flow[2] = 0; bestAff[0] = aff_last[0]; bestAff[1] = aff_last[1]; memcpy(bestPose, tries7, sizeof(bestPose)); }
+  for (int k = 0; k < 5; k++) lastCoarseRMSE_io[k] = achieved[k];
+  memcpy(pose7_out, bestPose, sizeof(bestPose));
+  aff_out[0] = bestAff[0]; aff_out[1] = bestAff[1];
+  if (flow_out) for (int k = 0; k < 3; k++) flow_out[k] = flow[k];
+  if (winner) *winner = win;
+  if (tries_used) *tries_used = used;
+  if (tracking_good) *tracking_good = trackingGoodRet ? 1 : 0;
+  return 0;
+}
+
 int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* t, long long* ticks_step, long long* ticks_eval) {
   if (!t) return failmsg("null tracker");
   if (ticks_step) *ticks_step = t->last_ticks_step;

@@ -166,6 +166,26 @@ DMV_HD void poseTo7(const Pose& T, double p[7]) {
   p[3] = T.q.x; p[4] = T.q.y; p[5] = T.q.z; p[6] = T.q.w;
 }
 
+// log of an SE3 element (se3.hpp:560-586, so3.hpp:497-540) — host only (nullspace construction)
+inline void poseLogHost(const Pose& T, double out[6]) {
+  const double n2 = T.q.x * T.q.x + T.q.y * T.q.y + T.q.z * T.q.z, n = sqrt(n2), w = T.q.w;
+  double f;
+  if (n < 1e-10) f = 2.0 / w - 2.0 * n2 / (w * w * w);
+  else if (fabs(w) < 1e-10) f = (w > 0 ? 3.14159265358979323846 : -3.14159265358979323846) / n;
+  else f = 2.0 * atan(n / w) / n;
+  const double theta = f * n;
+  out[3] = f * T.q.x; out[4] = f * T.q.y; out[5] = f * T.q.z;
+  const double O[9] = {0, -out[5], out[4], out[5], 0, -out[3], -out[4], out[3], 0};
+  double O2[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+  const double c = fabs(theta) < 1e-10 ? 1.0 / 12.0 : (1.0 - theta / (2.0 * tan(theta / 2.0))) / (theta * theta);
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int j = 0; j < 3; j++) s += (((i == j) ? 1.0 : 0.0) - 0.5 * O[i * 3 + j] + c * O2[i * 3 + j]) * T.t[j];
+    out[i] = s;
+  }
+}
+
 // AffLight::fromToVecExposure (src/dso/util/NumType.h:174-186)
 DMV_HD void affFromTo(float exposureF, float exposureT, double aF, double bF, double aT, double bT, double out[2]) {
   if (exposureF == 0 || exposureT == 0) { exposureT = exposureF = 1; }

@@ -105,6 +105,15 @@ int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* trk, int B, const int
 int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* trk);
 int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* trk, double* pose7_out, double* aff_out, double* lastResiduals,
                                         double* lastFlow, double* H, double* b, int* good, int* iterations);
+/* FullSystem::trackNewCoarse (FullSystem.cpp:300-539), visual-only path without IMU hint:
+ *  - dmvio_hip_make_track_hypotheses builds lastF_2_fh_tries (:364-402: constant / double / half / zero motion, zero motion from the
+ *    keyframe, 26 small rotations) from the camToWorld poses of the last two frames and of the reference keyframe; returns the count (31);
+ *  - dmvio_hip_tracker_track_new_coarse runs the try loop (:419-489) and returns what the reference writes into fh->shell:
+ *    the winning refToNew pose, aff_g2l, flow indicators; lastCoarseRMSE is in/out (achievedRes); *winner = index of the winning try or -1. */
+int dmvio_hip_make_track_hypotheses(const double slast_c2w[7], const double sprelast_c2w[7], const double lastF_c2w[7], double* out7, int max_out);
+int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* trk, int new_slot, float new_exposure, int n_tries, const double* tries7, const double aff_last[2],
+                                       double lastCoarseRMSE_io[5], double reTrackThreshold, double pose7_out[7], double aff_out[2], double flow_out[3],
+                                       int* winner, int* tries_used, int* tracking_good);
 /* Work counters of the last batch launch: evals (calcRes+calcGS passes) and point-evaluations
  * (sum over evals of pc_n[lvl]) — the unit count behind the roofline's algorithmic bytes. */
 int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long long* n_point_evals);

@@ -53,6 +53,8 @@ def lib():
         L.orc_se3_mul.argtypes = [c_d, c_d, c_d]
         L.orc_se3_matrix.argtypes = [c_d, c_d, c_d]
         L.orc_ldlt_solve.argtypes = [c_d, c_d, c_d, C.c_int]
+        L.orc_make_track_hypotheses.argtypes = [c_d, c_d, c_d, c_d]
+        L.orc_tracker_track_new_coarse.argtypes = [C.c_void_p, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _LIB
 
 
@@ -111,6 +113,14 @@ def se3_adj(a):
 def ldlt_solve(A, rhs):
     A = np.ascontiguousarray(A, dtype=np.float64); rhs = np.ascontiguousarray(rhs, dtype=np.float64)
     x = np.zeros_like(rhs); lib().orc_ldlt_solve(_d(A), _d(rhs), _d(x), len(rhs)); return x
+
+
+def make_track_hypotheses(slast_c2w, sprelast_c2w, lastF_c2w):
+    """lastF_2_fh_tries of FullSystem::trackNewCoarse (FullSystem.cpp:364-402) from three camToWorld poses -> [31, 7]."""
+    out = np.zeros((31, 7))
+    n = lib().orc_make_track_hypotheses(_d(np.ascontiguousarray(slast_c2w, dtype=np.float64)), _d(np.ascontiguousarray(sprelast_c2w, dtype=np.float64)),
+                                        _d(np.ascontiguousarray(lastF_c2w, dtype=np.float64)), _d(out))
+    return out[:n]
 
 
 class Tracker:
@@ -186,6 +196,14 @@ class Tracker:
 
     def stats(self):
         o = (C.c_long * 3)(); self.L.orc_tracker_stats(self.p, o); return list(o)
+
+    def track_new_coarse(self, tries7, aff_last=(0.0, 0.0), lastCoarseRMSE=None, reTrackThreshold=1.5):
+        tries = np.ascontiguousarray(tries7, dtype=np.float64).reshape(-1, 7)
+        rm = np.full(5, 100.0) if lastCoarseRMSE is None else np.array(lastCoarseRMSE, dtype=np.float64)
+        pose = np.zeros(7); aff = np.zeros(2); flow = np.zeros(3); used = C.c_int(0); good = C.c_int(0)
+        w = self.L.orc_tracker_track_new_coarse(self.p, len(tries), _d(tries), _d(np.array(aff_last, dtype=np.float64)), _d(rm), reTrackThreshold,
+                                                _d(pose), _d(aff), _d(flow), C.byref(used), C.byref(good))
+        return dict(winner=w, pose7=pose, aff=aff, achievedRes=rm, flow=flow, tries_used=used.value, good=bool(good.value))
 
 
 # ---------------------------------------------------------------------------------------------- bundle adjustment oracle

@@ -612,6 +612,66 @@ void orc_tracker_stats(void* p, long out[3]) {
   OrcTracker* t = (OrcTracker*)p; out[0] = t->n_calcRes; out[1] = t->n_calcGS; out[2] = t->n_points_evaluated;
 }
 
+// FullSystem::trackNewCoarse (src/dso/FullSystem/FullSystem.cpp:300-539), visual-only path without IMU hint.
+// Hypothesis list (:364-402): constant / double / half / zero motion, zero motion from the keyframe, 26 small rotations
+// (note the reference's `for(rotDelta=0.02; rotDelta<0.05; rotDelta++)` runs once).  Inputs are camToWorld poses.
+int orc_make_track_hypotheses(const double slast_c2w[7], const double sprelast_c2w[7], const double lastF_c2w[7], double* out /* 31 x 7 */) {
+  SE3 slast = poseFrom7(slast_c2w), sprelast = poseFrom7(sprelast_c2w), lastF = poseFrom7(lastF_c2w);
+  SE3 slast_2_sprelast = se3Mul(se3Inv(sprelast), slast);
+  SE3 lastF_2_slast = se3Mul(se3Inv(slast), lastF);
+  SE3 fh_2_slast = slast_2_sprelast;
+  std::vector<SE3> tries;
+  SE3 fhInv = se3Inv(fh_2_slast);
+  tries.push_back(se3Mul(fhInv, lastF_2_slast));
+  tries.push_back(se3Mul(se3Mul(fhInv, fhInv), lastF_2_slast));
+  { double lg[6]; se3Log(fh_2_slast, lg); for (int i = 0; i < 6; i++) lg[i] *= 0.5; tries.push_back(se3Mul(se3Inv(se3Exp(lg)), lastF_2_slast)); }
+  tries.push_back(lastF_2_slast);
+  tries.push_back(SE3());
+  const double d = 0.02;
+  const double rot[26][3] = {{d,0,0},{0,d,0},{0,0,d},{-d,0,0},{0,-d,0},{0,0,-d},{d,d,0},{0,d,d},{d,0,d},{-d,d,0},{0,-d,d},{-d,0,d},{d,-d,0},{0,d,-d},{d,0,-d},
+                             {-d,-d,0},{0,-d,-d},{-d,0,-d},{-d,-d,-d},{-d,-d,d},{-d,d,-d},{-d,d,d},{d,-d,-d},{d,-d,d},{d,d,-d},{d,d,d}};
+  SE3 base = se3Mul(fhInv, lastF_2_slast);
+  for (int k = 0; k < 26; k++) {
+    SE3 R; R.q = qnormalize(Quat{1, rot[k][0], rot[k][1], rot[k][2]});  // SE3(Quaterniond(1,x,y,z), 0): Sophus normalises the quaternion
+    tries.push_back(se3Mul(base, R));
+  }
+  for (size_t i = 0; i < tries.size(); i++) poseTo7(tries[i], out + 7 * i);
+  return (int)tries.size();
+}
+// the try loop (:419-489): returns the index of the winning hypothesis (or -1), outputs as the reference leaves them
+int orc_tracker_track_new_coarse(void* p, int n_tries, const double* tries7, const double aff_last[2], double lastCoarseRMSE_io[5], double reTrackThreshold,
+                                 double pose7_out[7], double aff_out[2], double flow_out[3], int* tries_used, int* tracking_good) {
+  OrcTracker* t = (OrcTracker*)p;
+  double achievedRes[5]; for (int i = 0; i < 5; i++) achievedRes[i] = NAN;
+  bool haveOneGood = false, trackingGoodRet = false;
+  int winner = -1, used = 0;
+  double flow[3] = {100, 100, 100};
+  SE3 best; double bestAff[2] = {0, 0};
+  for (int i = 0; i < n_tries; i++) {
+    double aff[2] = {aff_last[0], aff_last[1]};
+    SE3 T = poseFrom7(tries7 + 7 * i);
+    double H[64], b[8]; int its;
+    bool good = t->track(T, aff, t->levels - 1, achievedRes, 1e12f, 1e8f, H, b, &its);
+    used++;
+    if (good) trackingGoodRet = true;
+    if (good && std::isfinite((float)t->lastResiduals[0]) && !(t->lastResiduals[0] >= achievedRes[0])) {
+      for (int k = 0; k < 3; k++) flow[k] = t->lastFlowIndicators[k];
+      bestAff[0] = aff[0]; bestAff[1] = aff[1]; best = T; haveOneGood = true; winner = i;
+    }
+    if (haveOneGood)
+      for (int k = 0; k < 5; k++)
+        if (!std::isfinite((float)achievedRes[k]) || achievedRes[k] > t->lastResiduals[k]) achievedRes[k] = t->lastResiduals[k];
+    if (haveOneGood && achievedRes[0] < lastCoarseRMSE_io[0] * reTrackThreshold) break;
+  }
+  if (!haveOneGood) { for (int k = 0; k < 3; k++) flow[k] = 0; bestAff[0] = aff_last[0]; bestAff[1] = aff_last[1]; best = poseFrom7(tries7); }
+  for (int k = 0; k < 5; k++) lastCoarseRMSE_io[k] = achievedRes[k];
+  poseTo7(best, pose7_out); aff_out[0] = bestAff[0]; aff_out[1] = bestAff[1];
+  for (int k = 0; k < 3; k++) flow_out[k] = flow[k];
+  if (tries_used) *tries_used = used;
+  if (tracking_good) *tracking_good = trackingGoodRet ? 1 : 0;
+  return winner;
+}
+
 // --- Lie helpers exposed for tests ---
 void orc_se3_exp(const double a[6], double pose7[7]) { poseTo7(se3Exp(a), pose7); }
 void orc_se3_log(const double pose7[7], double a[6]) { se3Log(poseFrom7(pose7), a); }

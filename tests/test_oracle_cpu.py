@@ -290,3 +290,45 @@ def test_golden_fixture(oracle):
         assert np.max(np.abs(H - Hg) / np.sqrt(np.outer(np.diag(Hg), np.diag(Hg)))) < 5e-5
     r = T.track(IDENT, (0.0, 0.0))
     assert np.linalg.norm(r["pose7"][:3] - g["pose7"][:3]) < 2e-3
+
+
+def _T(p7):
+    import numpy as np
+    x, y, z, w = p7[3:7]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    M = np.eye(4); M[:3, :3] = R; M[:3, 3] = p7[:3]
+    return M
+
+
+def test_track_hypotheses_match_matrix_algebra(oracle, pkg):
+    """lastF_2_fh_tries (FullSystem.cpp:364-402): oracle list vs independent 4x4 matrix algebra; the library's host-side
+    generator (no device work) must give the same list."""
+    import numpy as np
+    from scipy.linalg import expm, logm
+    rng = np.random.RandomState(5)
+    sprelast = oracle.se3_exp(0.1 * rng.standard_normal(6))
+    slast = oracle.se3_mul(sprelast, oracle.se3_exp(0.05 * rng.standard_normal(6)))
+    lastF = oracle.se3_exp(0.1 * rng.standard_normal(6))
+    tries = oracle.make_track_hypotheses(slast, sprelast, lastF)
+    assert tries.shape == (31, 7)
+    A = np.linalg.inv(_T(sprelast)) @ _T(slast)            # fh_2_slast
+    Bm = np.linalg.inv(_T(slast)) @ _T(lastF)              # lastF_2_slast
+    Ai = np.linalg.inv(A)
+    expect = [Ai @ Bm, Ai @ Ai @ Bm, np.linalg.inv(expm(0.5 * np.real(logm(A)))) @ Bm, Bm, np.eye(4)]
+    for k, E in enumerate(expect):
+        assert np.allclose(_T(tries[k]), E, atol=1e-9), k
+    # 26 rotation tries: base * small rotation with unit quaternion ~ (1, +-d, +-d, +-d), all distinct, no translation change
+    base = Ai @ Bm
+    seen = set()
+    for k in range(5, 31):
+        D = np.linalg.inv(base) @ _T(tries[k])
+        assert np.allclose(D[:3, 3], 0, atol=1e-12)
+        ang = np.arccos(np.clip((np.trace(D[:3, :3]) - 1) / 2, -1, 1))
+        assert 0.03 < ang < 0.08
+        seen.add(tuple(np.round(D[:3, :3].ravel(), 6)))
+    assert len(seen) == 26
+    g = pkg.make_track_hypotheses(slast, sprelast, lastF)
+    assert g.shape == (31, 7)
+    assert np.max(np.abs(g - tries)) < 1e-14

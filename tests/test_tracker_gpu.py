@@ -192,3 +192,43 @@ def test_affine_brightness_recovered(pkg, oracle, synth, gpu_required):
     o = T.track(IDENT, (0.0, 0.0)); g = trk.trackNewestCoarse(1, IDENT, (0.0, 0.0))
     _cmp_track(g, o)
     assert abs(g["aff"][0] - 0.04) < 0.02 and abs(g["aff"][1] - 4.0) < 3.0
+
+
+def test_track_new_coarse_try_loop(setup, oracle, pkg):
+    """FullSystem::trackNewCoarse (FullSystem.cpp:419-489): hypothesis list + sequential try loop with achievedRes thresholds.
+    The library runs try 0 alone and the rest as one batch, replaying the abort rule; winner, number of tries, achieved
+    residuals and the winning pose must match the sequential oracle."""
+    case, trk, T = setup["case"], setup["trk"], setup["T"]
+    f = case["frames"][0]
+    T.set_new(setup["dIn"][0])
+    true = f["pose7"]
+    # (1) good constant-motion prediction: first try wins and ends the loop
+    lastF = IDENT.copy()
+    slast = oracle.se3_exp(-0.5 * f["xi"])      # camToWorld of a frame half-way: try 0 = exp(xi/2)^2
+    sprelast = IDENT.copy()
+    tries_o = oracle.make_track_hypotheses(slast, sprelast, lastF)
+    tries_g = pkg.make_track_hypotheses(slast, sprelast, lastF)
+    assert np.max(np.abs(tries_o - tries_g)) < 1e-14
+    o = T.track_new_coarse(tries_o, lastCoarseRMSE=np.full(5, 100.0))
+    g = trk.trackNewCoarse(1, tries_g, lastCoarseRMSE=np.full(5, 100.0))
+    assert o["winner"] == g["winner"] == 0 and o["tries_used"] == g["tries_used"] == 1 and g["good"] and o["good"]
+    assert np.max(np.abs(g["pose7"] - o["pose7"])) < 1e-5
+    assert np.allclose(g["achievedRes"], o["achievedRes"], rtol=1e-4, equal_nan=True)
+    assert np.max(np.abs(g["pose7"][:3] - true[:3])) < 1e-3
+    # (2) tight re-track threshold forces the loop through every hypothesis: winner selection + threshold replay
+    rm = np.full(5, 1e-3)
+    o = T.track_new_coarse(tries_o, lastCoarseRMSE=rm.copy())
+    g = trk.trackNewCoarse(1, tries_g, lastCoarseRMSE=rm.copy())
+    assert o["tries_used"] == g["tries_used"] == 31
+    assert o["winner"] == g["winner"]
+    assert np.max(np.abs(g["pose7"] - o["pose7"])) < 1e-5
+    assert np.allclose(g["achievedRes"], o["achievedRes"], rtol=1e-4, equal_nan=True)
+    assert np.allclose(g["flow"], o["flow"], rtol=1e-4, atol=1e-5)
+    # (3) bad motion model (large wrong rotation as "constant motion"): first tries fail or are worse, a later one wins
+    bad = oracle.se3_exp(np.array([0.0, 0, 0, 0.0, 0.35, 0.0]))
+    tries_bad = np.concatenate([bad[None], oracle.se3_mul(bad, bad)[None], tries_o])
+    o = T.track_new_coarse(tries_bad, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    g = trk.trackNewCoarse(1, tries_bad, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    assert o["winner"] == g["winner"] and o["tries_used"] == g["tries_used"] and o["good"] == g["good"]
+    assert np.max(np.abs(g["pose7"] - o["pose7"])) < 1e-5
+    assert np.allclose(g["achievedRes"], o["achievedRes"], rtol=1e-4, equal_nan=True)
