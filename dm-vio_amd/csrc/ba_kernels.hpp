@@ -279,6 +279,52 @@ struct Acc3 {
   __device__ __forceinline__ bool tileFits(const int nAct) const { return n1 + nAct <= 1000; }
 };
 
+// Tile addition in member order.  Rows of inactive members (and rows past the end of the tile) hold exact zeros and x + 0 == x,
+// so the owner adds every row of a range back to back: 16 independent LDS reads, then 16 dependent adds (a taken branch costs a
+// lone wavefront ~15 ns, a dependent add ~2 ns — measured, tools/chaintest.hip).
+template <class F>
+__device__ __forceinline__ void addRange(float& d, int lo, const int hi, F contrib) {
+  for (; lo + 16 <= hi; lo += 16) {
+    float c[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) c[q] = contrib(lo + q);
+#pragma unroll
+    for (int q = 0; q < 16; q++) d += c[q];
+  }
+  for (; lo < hi; lo++) d += contrib(lo);
+}
+// n1u: the accumulator's numIn1 counter (identical for every element, so every thread mirrors it).  A tile either fits below the
+// 1000-entry shift-up threshold, or the (1001 - n1u)-th ACTIVE member of the tile triggers shiftUp: `cross` is its row.
+// ADD_FIRST: the element is added before the counters advance (AccumulatorApprox::update's 10x10 part, AccumulatorXX/X::update);
+// otherwise after (updateTopRight / updateBotRight run after update() has advanced them).  rows = cnt rounded up to 16 (<= tile).
+template <bool ADD_FIRST, class F>
+__device__ __forceinline__ void addTile(Acc3& acc, const int cnt, const int nact, const int cross, F contrib) {
+  if (acc.tileFits(nact)) {
+    addRange(acc.d, 0, (cnt + 15) & ~15, contrib);
+    acc.n1 += nact;
+  } else {
+    const int split = ADD_FIRST ? cross + 1 : cross, used = 1001 - acc.n1;
+    addRange(acc.d, 0, split, contrib);
+    acc.n1 = 1000; acc.bump();   // numIn1 reaches 1001 -> shiftUp
+    addRange(acc.d, split, cnt, contrib);
+    acc.n1 = nact - used;
+  }
+}
+// row of the target-th (1-based) active member of a workgroup-wide tile with one flag per thread (stride = threads per member);
+// s_w: 5 ints of LDS.  Called by all threads (contains barriers).
+__device__ __forceinline__ int blockFindActive(const bool flag, const int row, const int target, int* s_w) {
+  const unsigned long long mask = __ballot(flag);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_w[wave] = __popcll(mask);
+  if (threadIdx.x == 0) s_w[4] = 0;
+  __syncthreads();
+  int before = __popcll(mask & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; w++) before += s_w[w];
+  if (flag && before + 1 == target) s_w[4] = row;
+  __syncthreads();
+  return s_w[4];
+}
+
 // ------------------------------------------------------------------------------------------------ top accumulation
 // Two-phase tiles keep the reference's SEQUENTIAL fp32 summation order without serialising the arithmetic:
 //   phase A (parallel): the workgroup computes the contribution of every (member, element) pair of a tile into LDS,
@@ -291,235 +337,292 @@ struct Acc3 {
 // analogue of the reference's per-worker accumulators acc[tid] (AccumulatedTopHessian.h:146), which stitchDoubleInternal
 // sums in double (AccumulatedTopHessian.cpp:263-268).  gridDim.y == 1 (default) replays the single-threaded reference bit for bit.
 // out: (F*F x nsplit) blocks of 96 floats (91 used) + counts of active members.
-struct TopElem { int kind, r, c; };   // decoded once per thread
-__device__ __forceinline__ TopElem decodeTop(const int e) {
-  TopElem t; t.kind = 3; t.r = 0; t.c = 0;
-  if (e < 55) { t.kind = 0; int off = 0, r = 0; while (e >= off + (10 - r)) { off += 10 - r; r++; } t.r = r; t.c = r + (e - off); }
-  else if (e < 85) { t.kind = 1; t.r = (e - 55) / 3; t.c = (e - 55) % 3; }
-  else if (e < 91) { t.kind = 2; t.r = e - 85; }
-  return t;
+// Roles of the owner threads of a (host,target) workgroup — one role per wavefront, so the tile loops do not diverge:
+//   role 0 (wave 0, lanes 0..54): element of the upper triangle of the 10x10 [calib4 | pose6] block,
+//   role 1 (wave 1, lanes 0..29): TopRight 10x3,   role 2 (wave 3, lanes 0..5): BotRight,   role 3 (wave 2, lanes 0..39): accE / accEB.
+// Every contribution is a fixed expression of <= 4 thread-specific columns of the staged member row (offsets o0..o3).
+struct HTRole { int role, o0, o1, o2, o3, out; };
+__device__ __forceinline__ int topX(const int i) { return i < 4 ? REC_JPDC0 + i : REC_JPDXI0 + (i - 4); }   // x[i] = (i < 4) ? Jpdc0[i] : Jpdxi0[i-4]
+__device__ __forceinline__ int topY(const int i) { return i < 4 ? REC_JPDC1 + i : REC_JPDXI1 + (i - 4); }
+__device__ __forceinline__ HTRole htRole(const int tid) {
+  HTRole R; R.role = -1; R.o0 = R.o1 = R.o2 = R.o3 = 0; R.out = 0;
+  const int wave = tid >> 6, lane = tid & 63;
+  if (wave == 0 && lane < 55) {
+    int off = 0, r = 0;
+    while (lane >= off + (10 - r)) { off += 10 - r; r++; }
+    const int c = r + (lane - off);
+    R.role = 0; R.o0 = topX(r); R.o1 = topX(c); R.o2 = topY(r); R.o3 = topY(c); R.out = lane;
+  } else if (wave == 1 && lane < 30) {
+    const int r = lane / 3, c = lane % 3;
+    // TR col 0: (JabJIdx00, JabJIdx01), col 1: (JabJIdx10, JabJIdx11), col 2: (JI_r0, JI_r1)
+    R.role = 1; R.o0 = topX(r); R.o1 = topY(r);
+    R.o2 = c == 0 ? REC_JABJIDX + 0 : (c == 1 ? REC_JABJIDX + 2 : REC_JI_R + 0);
+    R.o3 = c == 0 ? REC_JABJIDX + 1 : (c == 1 ? REC_JABJIDX + 3 : REC_JI_R + 1);
+    R.out = 55 + lane;
+  } else if (wave == 3 && lane < 6) {
+    // a00 = Jab2_00, a01 = Jab2_01, a02 = Jab_r0, a11 = Jab2_11, a12 = Jab_r1, a22 = rr
+    const int col[6] = {REC_JAB2 + 0, REC_JAB2 + 1, REC_JAB_R + 0, REC_JAB2 + 2, REC_JAB_R + 1, REC_RR};
+    R.role = 2; R.o0 = col[lane]; R.out = 85 + lane;
+  } else if (wave == 2 && lane < 40) {
+    // accE (8x4): (HdiF * JpJd[i]) * Hcd[k];  accEB (8): (HdiF*bdSumF) * JpJd[i] — written as (..)*1 with the active flag (exact)
+    R.role = 3; R.out = lane;
+    if (lane < 32) { R.o0 = 49; R.o1 = REC_JPJD + (lane >> 2); R.o2 = 45 + (lane & 3); }
+    else { R.o0 = 50; R.o1 = REC_JPJD + (lane - 32); R.o2 = 51; }
+  }
+  return R;
 }
-__device__ __forceinline__ float topContribution(const float* q, const TopElem t) {
-  // x[i] = (i < 4) ? Jpdc0[i] : Jpdxi0[i-4]  -> q[i < 4 ? i : 4 + i];   y[i] -> q[i < 4 ? 4 + i : 10 + i]
-  const int r = t.r, c = t.c;
-  if (t.kind == 0) {
-    const float xr = q[r < 4 ? r : 4 + r], xc = q[c < 4 ? c : 4 + c];
-    const float yr = q[r < 4 ? 4 + r : 10 + r], yc = q[c < 4 ? 4 + c : 10 + c];
+template <int ROLE>
+__device__ __forceinline__ float htContribution(const float* q, const HTRole& R) {
+  if (ROLE == 0) {
+    const float xr = q[R.o0], xc = q[R.o1], yr = q[R.o2], yc = q[R.o3];
     const float a = q[REC_JIDX2], bb = q[REC_JIDX2 + 1], cc = q[REC_JIDX2 + 2];
     return a * xc * xr + cc * yc * yr + bb * (xc * yr + yc * xr);
-  } else if (t.kind == 1) {
-    const float xr = q[r < 4 ? r : 4 + r], yr = q[r < 4 ? 4 + r : 10 + r];
-    // TR col 0: (JabJIdx00, JabJIdx01), col 1: (JabJIdx10, JabJIdx11), col 2: (JI_r0, JI_r1)
-    const float t0 = c == 0 ? q[REC_JABJIDX + 0] : (c == 1 ? q[REC_JABJIDX + 2] : q[REC_JI_R + 0]);
-    const float t1 = c == 0 ? q[REC_JABJIDX + 1] : (c == 1 ? q[REC_JABJIDX + 3] : q[REC_JI_R + 1]);
-    return xr * t0 + yr * t1;
+  } else if (ROLE == 1) {
+    return q[R.o0] * q[R.o2] + q[R.o1] * q[R.o3];
+  } else if (ROLE == 2) {
+    return q[R.o0];
   } else {
-    // a00 = Jab2_00, a01 = Jab2_01, a02 = Jab_r0, a11 = Jab2_11, a12 = Jab_r1, a22 = rr
-    return r == 0 ? q[REC_JAB2 + 0] : r == 1 ? q[REC_JAB2 + 1] : r == 2 ? q[REC_JAB_R + 0] : r == 3 ? q[REC_JAB2 + 2] : r == 4 ? q[REC_JAB_R + 1] : q[REC_RR];
+    return (q[R.o0] * q[R.o1]) * q[R.o2];
   }
 }
 
-#define TOP_TILE 64
-__device__ __forceinline__ void accumTopBlock(const int b, const int sp, const int nsp, const BARes& Rs, const int* __restrict__ bucket_begin,
-                                              const int* __restrict__ bucket_members, float* __restrict__ out, int* __restrict__ out_num) {
-  __shared__ float s_rec[TOP_TILE][37];
-  __shared__ int s_nact;
-  const int e = threadIdx.x;
+// wave-level LDS hand-off: the 64 lanes of a wavefront run in lockstep, a fence orders the LDS traffic (no workgroup barrier)
+__device__ __forceinline__ void waveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One workgroup per (host,target) bucket accumulates BOTH the 13x13 top block (owners: threads 0..90) and the Schur terms
+// accE (8x4) / accEB (8) (owners: threads 128..167) — the two walk the same member list in the same order
+// (AccumulatedTopHessian.cpp:34-146, AccumulatedSCHessian.cpp:56-78), so the records are staged once.
+// Staging is software-pipelined three tiles deep (member index -> activity / buffer / point -> record) so that no global
+// load is waited for in the iteration that issued it; the owners add a tile while the next one is in flight.
+#define HT_TILE 64
+#define HT_STRIDE 53   // [0,45) record, [45,49) Hcd, 49 HdiF, 50 HdiF*bdSumF, 51 active flag
+struct HTMeta { int act, which, pi; };
+struct HTFetch { float r[12]; float hc, hdi, bds; };
+
+// all staging loads are UNCONDITIONAL (indices clamped into the bucket, validity applied when the tile is written to LDS): no
+// branch, hence no s_waitcnt, sits between issuing a load and the iteration that consumes it
+__device__ __forceinline__ HTMeta htLoadMeta(const BARes& Rs, const int ri) {
+  HTMeta m; m.act = Rs.active[ri] != 0; m.which = Rs.which[ri]; m.pi = Rs.point[ri];
+  return m;
+}
+__device__ __forceinline__ void htLoadRec(const BARes& Rs, const BAPoints& P, const int ri, const HTMeta m, const int part, HTFetch& f) {
+  const float* __restrict__ rec = Rs.rec[m.which] + (size_t)ri * REC_FLOATS;
+#pragma unroll
+  for (int k = 0; k < 12; k++) f.r[k] = rec[part + 4 * k];   // part + 44 <= 47 < REC_FLOATS: in bounds, columns >= 45 are not staged
+  f.hc = P.Hcd[4 * m.pi + part] + 0.0f;
+  f.hdi = P.HdiF[m.pi];
+  f.bds = P.bdSumF[m.pi];
+}
+
+__device__ __forceinline__ void accumHTBlock(float* __restrict__ s_buf, const int b, const int sp, const int nsp, const BARes& Rs, const BAPoints& P,
+                                             const int* __restrict__ bucket_begin, const int* __restrict__ bucket_members, float* __restrict__ outTop,
+                                             int* __restrict__ outNum, float* __restrict__ outE) {
+  float (*s_rec)[HT_STRIDE] = reinterpret_cast<float (*)[HT_STRIDE]>(s_buf);
+  int* s_w = reinterpret_cast<int*>(s_buf + HT_TILE * HT_STRIDE);
+  const int tid = threadIdx.x, j = tid >> 2, part = tid & 3;
   const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
   const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
-  const TopElem te = decodeTop(e);
+  const HTRole R = htRole(tid);
   Acc3 acc; acc.init();
-  int num = 0;
-  for (int base = m0; base < m1; base += TOP_TILE) {
-    const int cnt = min(TOP_TILE, m1 - base);
-    __syncthreads();
-    if (e == 0) s_nact = 0;
-    __syncthreads();
-    {  // stage up to 64 member records (first 35 floats): 4 threads per record; inactive members become all-zero rows
-      const int j = e >> 2, part = e & 3;
-      if (j < cnt) {
-        const int ri = bucket_members[base + j];
-        const bool act = Rs.active[ri] != 0;
-        const float* __restrict__ rec = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
-        for (int k = part; k < 35; k += 4) s_rec[j][k] = act ? rec[k] : 0.0f;
-        if (part == 0) { s_rec[j][35] = act ? 1.0f : 0.0f; if (act) atomicAdd(&s_nact, 1); }
-      }
+  int num = 0, n1u = 0;
+  if (m1 <= m0) {   // empty bucket (host == target)
+    if (R.role >= 0 && R.role < 3) outTop[(b * nsp + sp) * 96 + R.out] = 0.0f;
+    if (R.role == 3) outE[(b * nsp + sp) * 40 + R.out] = 0.0f;
+    if (tid == 255) outNum[b * nsp + sp] = 0;
+    return;
+  }
+  // pipeline prologue
+  int ri1 = bucket_members[min(m0 + j, m1 - 1)];
+  int ri2 = bucket_members[min(m0 + HT_TILE + j, m1 - 1)];
+  int ri3 = bucket_members[min(m0 + 2 * HT_TILE + j, m1 - 1)];
+  HTMeta me1 = htLoadMeta(Rs, ri1), me2 = htLoadMeta(Rs, ri2);
+  HTFetch pf;
+  htLoadRec(Rs, P, ri1, me1, part, pf);
+  for (int base = m0; base < m1; base += HT_TILE) {
+    const int cnt = min(HT_TILE, m1 - base);
+    __syncthreads();   // the owners are done with the previous tile
+    {
+      const bool act = base + j < m1 && me1.act;
+#pragma unroll
+      for (int k = 0; k < 12; k++) { const int idx = part + 4 * k; if (idx < 45) s_rec[j][idx] = act ? pf.r[k] : 0.0f; }
+      s_rec[j][45 + part] = act ? pf.hc : 0.0f;
+      if (part == 0) { s_rec[j][49] = act ? pf.hdi : 0.0f; s_rec[j][50] = act ? pf.hdi * pf.bds : 0.0f; s_rec[j][51] = act ? 1.0f : 0.0f; }
     }
-    __syncthreads();
-    const int nact = s_nact;
-    if (e < 91) {
-      if (acc.tileFits(nact)) {
-        // no shift-up can happen inside this tile: contributions of inactive members are exact zeros (x + 0 == x), so the
-        // adds run back to back in member order; the shared counters advance by the number of active members
-        for (int j0 = 0; j0 < cnt; j0 += 16) {
-          float c[16];
-#pragma unroll
-          for (int j = 0; j < 16; j++) c[j] = (j0 + j < cnt) ? topContribution(s_rec[j0 + j], te) : 0.0f;   // independent: pipelined LDS reads
-#pragma unroll
-          for (int j = 0; j < 16; j++) acc.d += c[j];                                                       // the sequential part
-        }
-        acc.n1 += nact;
-      } else {
-        for (int j = 0; j < cnt; j++) {
-          if (s_rec[j][35] == 0.0f) continue;
-          const float v = topContribution(s_rec[j], te);
-          if (te.kind == 0) { acc.add(v); acc.bump(); }
-          else { acc.bump(); acc.add(v); }   // update() advances the shared counters BEFORE updateTopRight/BotRight
-        }
-      }
+    const bool flag = part == 0 && base + j < m1 && me1.act;
+    const int nact = __syncthreads_count(flag);
+    int cross = 0;
+    if (n1u + nact > 1000) cross = blockFindActive(flag, j, 1001 - n1u, s_w);   // block-uniform condition
+    n1u = n1u + nact > 1000 ? nact - (1001 - n1u) : n1u + nact;
+    // issue the loads of the following tiles (consumed one / two / three iterations from now)
+    ri1 = ri2; me1 = me2;
+    htLoadRec(Rs, P, ri1, me1, part, pf);
+    ri2 = ri3; me2 = htLoadMeta(Rs, ri2);
+    ri3 = bucket_members[min(base + 3 * HT_TILE + j, m1 - 1)];
+    switch (R.role) {   // wave-uniform
+      case 0: addTile<true>(acc, cnt, nact, cross, [&](const int m) { return htContribution<0>(s_rec[m], R); }); break;
+      case 1: addTile<false>(acc, cnt, nact, cross, [&](const int m) { return htContribution<1>(s_rec[m], R); }); break;
+      case 2: addTile<false>(acc, cnt, nact, cross, [&](const int m) { return htContribution<2>(s_rec[m], R); }); break;
+      case 3: addTile<true>(acc, cnt, nact, cross, [&](const int m) { return htContribution<3>(s_rec[m], R); }); break;
+      default: break;
     }
     num += nact;
   }
-  if (e < 91) out[(b * nsp + sp) * 96 + e] = acc.finish();
-  if (e == 91) out_num[b * nsp + sp] = num;
+  if (R.role >= 0 && R.role < 3) outTop[(b * nsp + sp) * 96 + R.out] = acc.finish();
+  if (R.role == 3) outE[(b * nsp + sp) * 40 + R.out] = acc.finish();
+  if (tid == 255) outNum[b * nsp + sp] = num;
 }
 
 // ------------------------------------------------------------------------------------------------ Schur accumulation
-// accD[h,t1,t2] (8x8) += (HdiF * JpJd(r1)) JpJd(r2)^T : one workgroup (64 threads) per bucket, member = (r1, r2, point).
-__device__ __forceinline__ void accumScDBlock(const int b, const int sp, const int nsp, const BARes& Rs, const BAPoints& P, const int* __restrict__ bucket_begin,
-                                              const int* __restrict__ members /* 3 ints each */, float* __restrict__ outD, int* __restrict__ outNum) {
-  __shared__ float s_l[64][9], s_r[64][9], s_w[64];
-  __shared__ float s_c[64][65];
-  const int e = threadIdx.x & 63, i = e >> 3, j = e & 7;
-  const bool live = threadIdx.x < 64;   // the block is launched with 256 threads; the first wave does the work
+// accD[h,t1,t2] (8x8) += (HdiF * JpJd(r1)) JpJd(r2)^T : one WAVEFRONT per bucket (four buckets per workgroup), lane (i,j) owns
+// element (i,j); member = (r1, r2, point).  Same three-deep staging pipeline, wave-level synchronisation only.
+#define SCD_STRIDE 19   // [0,8) HdiF-side JpJd(r1), [8,16) JpJd(r2), 16 HdiF, 17 active flag
+struct SCDMeta { int act, w1, w2; float hdi; };
+__device__ __forceinline__ SCDMeta scdLoadMeta(const BARes& Rs, const BAPoints& P, const int r1, const int r2, const int pi) {
+  SCDMeta m;
+  const int ac1 = Rs.active[r1], ac2 = Rs.active[r2];
+  m.act = (ac1 != 0) & (ac2 != 0); m.w1 = Rs.which[r1]; m.w2 = Rs.which[r2]; m.hdi = P.HdiF[pi];
+  return m;
+}
+__device__ __forceinline__ void accumScDWave(float* __restrict__ s_buf, const int bucket, const int nsp, const BARes& Rs, const BAPoints& P,
+                                             const int* __restrict__ bucket_begin, const int* __restrict__ members /* 3 ints each */,
+                                             float* __restrict__ outD, int* __restrict__ outNum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane >> 3, jj = lane & 7;
+  float (*s_m)[SCD_STRIDE] = reinterpret_cast<float (*)[SCD_STRIDE]>(s_buf + wave * 64 * SCD_STRIDE);
+  const int b = bucket / nsp, sp = bucket % nsp;
   const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
   const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
   Acc3 acc; acc.init();
   int num = 0;
+  int a1[3], a2[3], a3[3];
+  if (m1 <= m0) { outD[bucket * 64 + lane] = 0.0f; if (lane == 0) outNum[bucket] = 0; return; }
+  auto ldIdx = [&](const int m, int* a) {   // unconditional, clamped (see htLoadMeta)
+    const int mc = min(m, m1 - 1);
+    a[0] = members[3 * mc]; a[1] = members[3 * mc + 1]; a[2] = members[3 * mc + 2];
+  };
+  ldIdx(m0 + lane, a1); ldIdx(m0 + 64 + lane, a2); ldIdx(m0 + 128 + lane, a3);
+  SCDMeta me1 = scdLoadMeta(Rs, P, a1[0], a1[1], a1[2]), me2 = scdLoadMeta(Rs, P, a2[0], a2[1], a2[2]);
+  float q1[8], q2[8];
+  auto ldRec = [&](const int* a, const SCDMeta& m) {
+    const float* __restrict__ p1 = Rs.rec[m.w1] + (size_t)a[0] * REC_FLOATS + REC_JPJD;
+    const float* __restrict__ p2 = Rs.rec[m.w2] + (size_t)a[1] * REC_FLOATS + REC_JPJD;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { q1[k] = p1[k]; q2[k] = p2[k]; }
+  };
+  ldRec(a1, me1);
   for (int base = m0; base < m1; base += 64) {
     const int cnt = min(64, m1 - base);
-    __syncthreads();
-    if (live && e < cnt) {
-      const int r1 = members[3 * (base + e)], r2 = members[3 * (base + e) + 1], pi = members[3 * (base + e) + 2];
-      const bool act = Rs.active[r1] && Rs.active[r2];
-      const float* __restrict__ q1 = Rs.rec[Rs.which[r1]] + (size_t)r1 * REC_FLOATS + REC_JPJD;
-      const float* __restrict__ q2 = Rs.rec[Rs.which[r2]] + (size_t)r2 * REC_FLOATS + REC_JPJD;
+    waveSync();
+    const bool act = base + lane < m1 && me1.act;
 #pragma unroll
-      for (int k = 0; k < 8; k++) { s_l[e][k] = q1[k]; s_r[e][k] = q2[k]; }
-      s_w[e] = act ? P.HdiF[pi] : -1.0f;
+    for (int k = 0; k < 8; k++) { s_m[lane][k] = act ? q1[k] : 0.0f; s_m[lane][8 + k] = act ? q2[k] : 0.0f; }
+    s_m[lane][16] = act ? me1.hdi : 0.0f;
+    s_m[lane][17] = act ? 1.0f : 0.0f;
+    const unsigned long long amask = __ballot(act);
+    const int nact = __popcll(amask);
+    waveSync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a1[k] = a2[k]; a2[k] = a3[k]; }
+    me1 = me2;
+    ldRec(a1, me1);
+    me2 = scdLoadMeta(Rs, P, a2[0], a2[1], a2[2]);
+    ldIdx(base + 192 + lane, a3);
+    int cross = 0;
+    if (!acc.tileFits(nact)) {   // wave-uniform: row of the (1001 - n1)-th active member
+      const bool isCross = act && __popcll(amask & ((1ull << lane) - 1ull)) + 1 == 1001 - acc.n1;
+      cross = __ffsll((long long)__ballot(isCross)) - 1;
     }
-    __syncthreads();
-    if (live) for (int m = 0; m < cnt; m++) s_c[m][e] = (s_w[m] * s_l[m][i]) * s_r[m][j];   // A += w*L*R^T (phase A, independent)
-    __syncthreads();
-    if (live)
-      for (int m = 0; m < cnt; m++) {
-        if (s_w[m] < 0) continue;
-        acc.add(s_c[m][e]);
-        acc.bump();
-        num++;
-      }
+    addTile<true>(acc, cnt, nact, cross, [&](const int m) { return (s_m[m][16] * s_m[m][i]) * s_m[m][8 + jj]; });
+    num += nact;
   }
-  if (live) {
-    outD[(b * nsp + sp) * 64 + e] = acc.finish();
-    if (e == 0) outNum[b * nsp + sp] = num;
-  }
-}
-
-// accE[h,t] (8x4) += (HdiF JpJd) Hcd^T ; accEB[h,t] (8) += (HdiF*bdSumF) JpJd : workgroup per (h,t) bucket, 40 owners
-__device__ __forceinline__ void accumScEBlock(const int b, const int sp, const int nsp, const BARes& Rs, const BAPoints& P, const int* __restrict__ bucket_begin,
-                                              const int* __restrict__ bucket_members, float* __restrict__ outE /* 40 per bucket */) {
-  __shared__ float s_l[64][9], s_h[64][5], s_w[64], s_wb[64];
-  __shared__ float s_c[64][41];
-  const int e = threadIdx.x;
-  const int mb = bucket_begin[b], mcnt = bucket_begin[b + 1] - mb;
-  const int m0 = mb + (int)(((long long)mcnt * sp) / nsp), m1 = mb + (int)(((long long)mcnt * (sp + 1)) / nsp);
-  Acc3 acc; acc.init();
-  for (int base = m0; base < m1; base += 64) {
-    const int cnt = min(64, m1 - base);
-    __syncthreads();
-    if (e < cnt) {
-      const int ri = bucket_members[base + e];
-      const int pi = Rs.point[ri];
-      const bool act = Rs.active[ri] != 0;
-      const float* __restrict__ q = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS + REC_JPJD;
-#pragma unroll
-      for (int k = 0; k < 8; k++) s_l[e][k] = q[k];
-#pragma unroll
-      for (int k = 0; k < 4; k++) s_h[e][k] = P.Hcd[4 * pi + k] + 0.0f;
-      const float hdi = P.HdiF[pi];
-      s_w[e] = act ? hdi : -1.0f;
-      s_wb[e] = hdi * P.bdSumF[pi];
-    }
-    __syncthreads();
-    if (e < 40)
-      for (int m = 0; m < cnt; m++) s_c[m][e] = (e < 32) ? (s_w[m] * s_l[m][e >> 2]) * s_h[m][e & 3] : s_wb[m] * s_l[m][e - 32];
-    __syncthreads();
-    if (e < 40)
-      for (int m = 0; m < cnt; m++) {
-        if (s_w[m] < 0) continue;
-        acc.add(s_c[m][e]);
-        acc.bump();
-      }
-  }
-  if (e < 40) outE[(b * nsp + sp) * 40 + e] = acc.finish();
+  outD[bucket * 64 + lane] = acc.finish();
+  if (lane == 0) outNum[bucket] = num;
 }
 
 // accHcc (4x4) += HdiF Hcd Hcd^T ; accbc (4) += (bdSumF*HdiF) Hcd over all points with an active residual: 20 owners per workgroup,
-// gridDim.x partial accumulators over contiguous point ranges (1 = the reference's single-threaded order)
-__device__ __forceinline__ void accumScCBlock(const int sp, const int nsp, const int N, const BAPoints& P, float* __restrict__ outC /* 20 */) {
-  __shared__ float s_c[256][21];
-  __shared__ float s_w[256];
+// nsp partial accumulators over contiguous point ranges (1 = the reference's single-threaded order)
+#define SCC_STRIDE 260   // element-major tile [20][256 (+4)]: the owner of element e reads four consecutive members per ds_read_b128
+__device__ __forceinline__ void accumScCBlock(float* __restrict__ s_buf, const int sp, const int nsp, const int N, const BAPoints& P, float* __restrict__ outC /* 20 */) {
+  float (*s_c)[SCC_STRIDE] = reinterpret_cast<float (*)[SCC_STRIDE]>(s_buf);
+  int* s_w = reinterpret_cast<int*>(s_buf + 20 * SCC_STRIDE);
   const int e = threadIdx.x;
   const int p0 = (int)(((long long)N * sp) / nsp), p1 = (int)(((long long)N * (sp + 1)) / nsp);
+  if (p1 <= p0) { if (e < 20) outC[sp * 20 + e] = 0.0f; return; }
   Acc3 acc; acc.init();
+  int n1u = 0;
+  float hdi, bds, hc[4];
+  auto ld = [&](const int pi_) {   // unconditional, clamped (see htLoadMeta)
+    const int pi = min(pi_, p1 - 1);
+    hdi = P.HdiF[pi]; bds = P.bdSumF[pi];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hc[k] = P.Hcd[4 * pi + k] + 0.0f;
+  };
+  ld(p0 + e);
   for (int base = p0; base < p1; base += 256) {
     const int cnt = min(256, p1 - base);
     __syncthreads();
-    if (e < cnt) {
-      const int pi = base + e;
-      const float hdi = P.HdiF[pi];
-      float hc[4];
+    const bool act = base + e < p1 && hdi > 0;   // HdiF == 0 <=> no active residual (point skipped by addPoint)
+    {
+      const float wb = bds * hdi;
 #pragma unroll
-      for (int k = 0; k < 4; k++) hc[k] = P.Hcd[4 * pi + k] + 0.0f;
-      s_w[e] = hdi > 0 ? hdi : -1.0f;   // HdiF == 0 <=> no active residual (point skipped by addPoint)
-      const float wb = P.bdSumF[pi] * hdi;
+      for (int q = 0; q < 16; q++) s_c[q][e] = act ? (hdi * hc[q >> 2]) * hc[q & 3] : 0.0f;
 #pragma unroll
-      for (int q = 0; q < 16; q++) s_c[e][q] = (hdi * hc[q >> 2]) * hc[q & 3];
-#pragma unroll
-      for (int q = 0; q < 4; q++) s_c[e][16 + q] = wb * hc[q];
+      for (int q = 0; q < 4; q++) s_c[16 + q][e] = act ? wb * hc[q] : 0.0f;
     }
-    const int nact = __syncthreads_count(e < cnt && s_w[e] >= 0);
+    const int nact = __syncthreads_count(act);
+    int cross = 0;
+    if (n1u + nact > 1000) cross = blockFindActive(act, e, 1001 - n1u, s_w);   // block-uniform condition
+    const bool fits = n1u + nact <= 1000;
+    n1u = fits ? n1u + nact : nact - (1001 - n1u);
+    ld(base + 256 + e);
     if (e < 20) {
-      if (acc.tileFits(nact)) {
+      if (fits) {
         for (int m0 = 0; m0 < cnt; m0 += 16) {
-          float c[16];
+          float4 c[4];
 #pragma unroll
-          for (int m = 0; m < 16; m++) c[m] = (m0 + m < cnt && s_w[m0 + m] >= 0) ? s_c[m0 + m][e] : 0.0f;
+          for (int m = 0; m < 4; m++) c[m] = *reinterpret_cast<const float4*>(&s_c[e][m0 + 4 * m]);
 #pragma unroll
-          for (int m = 0; m < 16; m++) acc.d += c[m];
+          for (int m = 0; m < 4; m++) { acc.d += c[m].x; acc.d += c[m].y; acc.d += c[m].z; acc.d += c[m].w; }
         }
         acc.n1 += nact;
       } else {
-        for (int m = 0; m < cnt; m++) {
-          if (s_w[m] < 0) continue;
-          acc.add(s_c[m][e]);
-          acc.bump();
-        }
+        addTile<true>(acc, cnt, nact, cross, [&](const int m) { return s_c[e][m]; });
       }
     }
   }
   if (e < 20) outC[sp * 20 + e] = acc.finish();
 }
 
-// All four accumulations of solveSystemF in ONE launch (they only depend on the applied records and the per-point sums):
-// blocks [0, nTop) top buckets, [nTop, nTop+nD) accD buckets, then accE buckets, then the calibration partials.
+// All accumulations of solveSystemF in ONE launch (they only depend on the applied records and the per-point sums).  Longest
+// sequential chains first: blocks [0, nsC) calibration partials, then the (host,target) buckets (top + accE), then accD (4 per block).
 struct AccumArgs {
   int F, N, nsTop, nsD, nsC;
   const int *top_begin, *top_members, *scd_begin, *scd_members;
   float *accTop, *accD, *accE, *accC;
   int *numTop, *numD;
+  long long* ticks;   // optional [gridDim.x][2] start / end wall-clock stamps per block (DMVIO_HIP_BA_TIMING), else null
 };
+#define ACC_LDS_FLOATS (20 * SCC_STRIDE + 8)
 __global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const BARes Rs, const BAPoints P) {
+  __shared__ float s_buf[ACC_LDS_FLOATS];
+  static_assert(ACC_LDS_FLOATS >= HT_TILE * HT_STRIDE + 8 && ACC_LDS_FLOATS >= 4 * 64 * SCD_STRIDE, "LDS carve-up");
   const int F2 = A.F * A.F;
-  const int nTop = F2 * A.nsTop, nD = F2 * A.F * A.nsD, nE = F2 * A.nsTop;
+  const int nHT = F2 * A.nsTop, nD = F2 * A.F * A.nsD;
   int blk = blockIdx.x;
-  if (blk < nTop) { accumTopBlock(blk / A.nsTop, blk % A.nsTop, A.nsTop, Rs, A.top_begin, A.top_members, A.accTop, A.numTop); return; }
-  blk -= nTop;
-  if (blk < nD) { accumScDBlock(blk / A.nsD, blk % A.nsD, A.nsD, Rs, P, A.scd_begin, A.scd_members, A.accD, A.numD); return; }
-  blk -= nD;
-  if (blk < nE) { accumScEBlock(blk / A.nsTop, blk % A.nsTop, A.nsTop, Rs, P, A.top_begin, A.top_members, A.accE); return; }
-  blk -= nE;
-  accumScCBlock(blk, A.nsC, A.N, P, A.accC);
+  if (A.ticks && threadIdx.x == 0) A.ticks[2 * blockIdx.x] = wall_clock64();
+  if (blk < A.nsC) accumScCBlock(s_buf, blk, A.nsC, A.N, P, A.accC);
+  else if (blk < A.nsC + nHT) {
+    blk -= A.nsC;
+    accumHTBlock(s_buf, blk / A.nsTop, blk % A.nsTop, A.nsTop, Rs, P, A.top_begin, A.top_members, A.accTop, A.numTop, A.accE);
+  } else {
+    blk -= A.nsC + nHT;
+    const int bucket = blk * 4 + (threadIdx.x >> 6);
+    if (bucket < nD) accumScDWave(s_buf, bucket, A.nsD, Rs, P, A.scd_begin, A.scd_members, A.accD, A.numD);
+  }
+  if (A.ticks) { __syncthreads(); if (threadIdx.x == 0) A.ticks[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
 // ------------------------------------------------------------------------------------------------ fp64 stitching

@@ -52,6 +52,8 @@ struct dmvio_hip_ba {
   double final_energy = 0;
   BATimes tm;
   bool timing = false;
+  long long* d_accTicks = nullptr;   // per-block stamps of k_ba_accumulate (timing mode only)
+  int accTicksBlocks = 0;
 };
 
 template <class T>
@@ -129,7 +131,12 @@ static int accumulate(dmvio_hip_ba* b) {
     A.F = F; A.N = H.N; A.nsTop = b->nsTop; A.nsD = b->nsD; A.nsC = b->nsC;
     A.top_begin = b->d_top_begin; A.top_members = b->d_top_members; A.scd_begin = b->d_scd_begin; A.scd_members = b->d_scd_members;
     A.accTop = b->d_accTop; A.accD = b->d_accD; A.accE = b->d_accE; A.accC = b->d_accC; A.numTop = b->d_numTop; A.numD = b->d_numD;
-    const int nblk = F2 * b->nsTop + F2 * F * b->nsD + F2 * b->nsTop + b->nsC;
+    const int nblk = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
+    A.ticks = nullptr;
+    if (b->timing) {
+      if (b->accTicksBlocks != nblk) { if (b->d_accTicks) hipFree(b->d_accTicks); HIPCHK(hipMalloc((void**)&b->d_accTicks, sizeof(long long) * 2 * nblk)); b->accTicksBlocks = nblk; }
+      A.ticks = b->d_accTicks;
+    }
     hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, b->Rs, b->P);
   }
   hipLaunchKernelGGL(k_ba_stitch_top, dim3(F), dim3(64), 0, s, F, b->nsTop, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
@@ -193,7 +200,27 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
     fprintf(stderr, "[dmvio_hip_ba] GN iteration host-side split over %ld iterations (us/iter):", b->tm.n);
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f", names[i], b->tm.t[i] / b->tm.n);
     fprintf(stderr, "\n");
+    if (b->d_accTicks) {   // block timeline of the LAST k_ba_accumulate launch (wall_clock64 = 100 MHz)
+      std::vector<long long> tk(2 * (size_t)b->accTicksBlocks);
+      hipMemcpy(tk.data(), b->d_accTicks, sizeof(long long) * tk.size(), hipMemcpyDeviceToHost);
+      long long t0 = tk[0];
+      for (int i = 0; i < b->accTicksBlocks; i++) t0 = std::min(t0, tk[2 * i]);
+      const int F2 = b->H.F * b->H.F, lim[3] = {b->nsC, b->nsC + F2 * b->nsTop, b->accTicksBlocks};
+      const char* cls[3] = {"calib", "top+E", "accD x4"};
+      int i0 = 0;
+      for (int c = 0; c < 3; c++) {
+        double dmax = 0, dsum = 0, smax = 0, emax = 0; int argmax = -1;
+        for (int i = i0; i < lim[c]; i++) {
+          const double d = (tk[2 * i + 1] - tk[2 * i]) * 0.01, st = (tk[2 * i] - t0) * 0.01, en = (tk[2 * i + 1] - t0) * 0.01;
+          dsum += d; if (d > dmax) { dmax = d; argmax = i - i0; } smax = std::max(smax, st); emax = std::max(emax, en);
+        }
+        fprintf(stderr, "[dmvio_hip_ba]   k_ba_accumulate %s blocks=%d: duration mean %.1f max %.1f us (block %d), latest start %.1f, latest end %.1f us\n", cls[c],
+                lim[c] - i0, dsum / std::max(1, lim[c] - i0), dmax, argmax, smax, emax);
+        i0 = lim[c];
+      }
+    }
   }
+  if (b->d_accTicks) hipFree(b->d_accTicks);
   freeDevice(b);
   delete b;
 }

@@ -64,7 +64,7 @@ def test_accumulate_and_solve_parity(big, pkg, oracle, mode, monkeypatch):
     ba = pkg.BundleAdjusterHip(big["ctx"])
     ba.set_case(case, list(range(case["n_frames"])))
     W = oracle.BAWindow(case)
-    tolH, tolx = (1e-11, 1e-6) if mode == "exact" else (2e-6, 2e-3)
+    tolH, tolx = (1e-11, 1e-6) if mode == "exact" else (2e-6, 1e-2)
     ba.activate_all(); W.activate_all()
     ba.linearize_all(False); W.linearize_all(False)
     ba.apply_res(); W.apply_res()
@@ -120,6 +120,20 @@ def test_small_window_and_ragged_graph(pkg, oracle, synth, gpu_required):
     assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
     for k in range(3):
         assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+
+
+def test_shift_up_boundaries_inside_buckets(pkg, oracle, synth, gpu_required):
+    """> 1000 members per (host,target) and per (host,t1,t2) bucket: the accumulators' 1000-entry shiftUp (MatrixAccumulators.h
+    numIn1 / Data1k / Data1m) happens INSIDE buckets, twice; exact mode must still reproduce the oracle's sums."""
+    case = synth.ba_case(512, 512, n_frames=3, n_points=4200, hosts_share=(4000, 200, 0), seed=5)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba.activate_all(); eg = ba.linearize_all(False); ba.apply_res()
+    W.activate_all(); eo = W.linearize_all(False); W.apply_res()
+    assert abs(eg - eo) <= 1e-6 * eo
+    a = ba.accumulate(); o = W.accumulate()
+    assert a["resInA"] == o["resInA"] and a["resInA"] > 2200   # > 1000 active members in both buckets of host 0
+    for k in ("HA", "bA", "Hsc", "bsc"):
+        assert np.linalg.norm(a[k] - o[k]) <= 1e-11 * np.linalg.norm(o[k]), k
 
 
 def test_sharded_driver_world1_equals_gn_iteration(pkg, oracle, synth, gpu_required):
