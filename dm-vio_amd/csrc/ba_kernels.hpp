@@ -758,10 +758,16 @@ __global__ void __launch_bounds__(64) k_ba_stitch_sc(const int F, const int nspl
 // step 2: one thread per element of H_A, H_sc (n x n, n = 4+8F) and b_A, b_sc; fixed summation order.
 // Output layout: out[0 .. n*n) = H_A, then b_A (n), then H_sc (n*n), then b_sc (n).
 __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs S,
-                                                           double* __restrict__ out) {
+                                                           const int* __restrict__ numTop, const int nNum, double* __restrict__ out) {
   const int n = 4 + 8 * F, F2 = F * F;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int per = n * n + n;
+  if (tid == 2 * per) {   // resInA: number of active residuals that entered the top accumulation, appended to the system
+    int cnt = 0;
+    for (int k = 0; k < nNum; k++) cnt += numTop[k];
+    out[2 * per] = (double)cnt;
+    return;
+  }
   if (tid >= 2 * per) return;
   const bool sc = tid >= per;
   const int t = sc ? tid - per : tid;

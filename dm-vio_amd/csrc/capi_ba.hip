@@ -41,6 +41,10 @@ struct dmvio_hip_ba {
   float *d_spart = nullptr, *h_spart = nullptr;  // point-step partial sums
   float *d_xc = nullptr, *d_xAd = nullptr;
   float *h_newEnergyWO = nullptr;
+  // pinned staging for the small per-iteration uploads (no pageable copies, no sync before the kernel that consumes them)
+  float* h_xstage = nullptr;        // [xc (4) | xAd (F*F*8)]
+  BAPrecalc* h_pre[2] = {nullptr, nullptr};
+  int pre_toggle = 0;
   float* d_fullJ = nullptr;
   int n_lin_blocks = 0, n_pt_blocks = 0;
   // partial accumulators per bucket (1 = replay the single-threaded reference bit for bit; DMVIO_HIP_BA_EXACT=1)
@@ -70,6 +74,8 @@ static void freeDevice(dmvio_hip_ba* b) {
   if (b->h_epart) { hipHostFree(b->h_epart); b->h_epart = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
   if (b->h_newEnergyWO) { hipHostFree(b->h_newEnergyWO); b->h_newEnergyWO = nullptr; }
+  if (b->h_xstage) { hipHostFree(b->h_xstage); b->h_xstage = nullptr; }
+  for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
   b->graph_ready = false;
 }
 
@@ -83,7 +89,10 @@ static int uploadWindowTables(dmvio_hip_ba* b) {
   W.wM3 = H.w - 3; W.hM3 = H.h - 3;
   W.huberTH = H.S.huberTH; W.outlierTHSum = H.S.outlierTHSumComponent; W.modeA = H.S.affineOptModeA; W.modeB = H.S.affineOptModeB;
   for (int f = 0; f < H.F; f++) { W.slot[f] = H.fr[f].slot; W.frameEnergyTH[f] = H.fr[f].frameEnergyTH; }
-  HIPCHK(hipMemcpyAsync(b->d_pre, H.pre.data(), sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, c->stream));
+  // two pinned staging copies: at most one earlier upload can still be in flight (every linearize ends with a stream sync)
+  BAPrecalc* stage = b->h_pre[b->pre_toggle ^= 1];
+  memcpy(stage, H.pre.data(), sizeof(BAPrecalc) * H.F * H.F);
+  HIPCHK(hipMemcpyAsync(b->d_pre, stage, sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
 static int uploadAdjoints(dmvio_hip_ba* b) {
@@ -142,15 +151,11 @@ static int accumulate(dmvio_hip_ba* b) {
   hipLaunchKernelGGL(k_ba_stitch_top, dim3(F), dim3(64), 0, s, F, b->nsTop, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
   hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2), dim3(64), 0, s, F, b->nsD, b->nsTop, b->d_accD, b->d_numD, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
   const int tot = 2 * (n * n + n);
-  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 255) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_sys);
+  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(b->h_sys, b->d_sys, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_numTop, sizeof(int) * F2 * b->nsTop, hipMemcpyDeviceToHost, s));  // reuse pinned scratch for the counts
+  HIPCHK(hipMemcpyAsync(b->h_sys, b->d_sys, sizeof(double) * (tot + 1), hipMemcpyDeviceToHost, s));   // [H_A | b_A | H_sc | b_sc | resInA]
   HIPCHK(hipStreamSynchronize(s));
-  int res = 0;
-  const int* cnt = (const int*)b->h_epart;
-  for (int k = 0; k < F2 * b->nsTop; k++) res += cnt[k];
-  H.resInA = res;
+  H.resInA = (int)b->h_sys[tot];
   return 0;
 }
 static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
@@ -158,18 +163,20 @@ static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
   float xc[4];
   std::vector<float> xAd;
   b->H.prepareResubstitute(x, xc, xAd);
-  HIPCHK(hipMemcpyAsync(b->d_xc, xc, sizeof(xc), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(b->d_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));  // xc / xAd are stack / vector storage
+  // pinned staging; the previous upload was consumed before the accumulate sync that produced x
+  memcpy(b->h_xstage, xc, sizeof(xc));
+  memcpy(b->h_xstage + 4, xAd.data(), sizeof(float) * xAd.size());
+  HIPCHK(hipMemcpyAsync(b->d_xc, b->h_xstage, sizeof(float) * (4 + xAd.size()), hipMemcpyHostToDevice, c->stream));   // d_xAd = d_xc + 4
   hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd);
   HIPCHK(hipGetLastError());
   return 0;
 }
+// mode 0 backup, 1 step from backup, 2 restore; the step-norm sums (mode 1) are only fetched when the caller asks for them
 static int pointStep(dmvio_hip_ba* b, int mode, float fac, float* sumID, float* sumNID) {
   dmvio_hip_ctx* c = b->ctx;
   hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->H.N, b->P, mode, fac, b->d_spart);
   HIPCHK(hipGetLastError());
-  if (mode == 1) {
+  if (mode == 1 && sumID && sumNID) {
     HIPCHK(hipMemcpyAsync(b->h_spart, b->d_spart, sizeof(float) * 2 * b->n_pt_blocks, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float a = 0, d = 0;
@@ -349,9 +356,12 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
   b->n_lin_blocks = (R + 127) / 128; b->n_pt_blocks = (N + 255) / 256;
-  if (dalloc(b, &b->d_sys, tot) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2 * 8)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4) ||
-      dalloc(b, &b->d_xAd, (size_t)F2 * 8) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
-  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * tot, hipHostMallocDefault));
+  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2 * 8)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4 + (size_t)F2 * 8) ||
+      dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
+  b->d_xAd = b->d_xc + 4;   // one staging upload fills both
+  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_xstage, sizeof(float) * (4 + (size_t)F2 * 8), hipHostMallocDefault));
+  for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * std::max(b->n_lin_blocks, F2 * 8), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_newEnergyWO, sizeof(float) * R, hipHostMallocDefault));
@@ -484,8 +494,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
 #define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->ctx->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
   // backupState
   H.backupFrames();
-  float dummy0, dummy1;
-  if (int r = pointStep(b, 0, 0.f, &dummy0, &dummy1)) return r;
+  if (int r = pointStep(b, 0, 0.f, nullptr, nullptr)) return r;
   BA_LAP(0);
   // solveSystem
   H.getNullspaces();
@@ -498,9 +507,10 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   if (int r = resubstitute(b, x)) return r;
   BA_LAP(3);
   // doStepFromBackup
-  float fs[4], sumID = 0, sumNID = 0;
+  // the step norms only feed canbreak, which stays false without the GTSAM path (FullSystemOptimize.cpp:387,583): not fetched
+  float fs[4];
   H.stepFrames(1.0f, fs);
-  if (int r = pointStep(b, 1, 1.0f, &sumID, &sumNID)) return r;
+  if (int r = pointStep(b, 1, 1.0f, nullptr, nullptr)) return r;
   BA_LAP(4);
   H.setPrecalcValues();
   BA_LAP(5);
@@ -516,7 +526,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     lambda = std::max(lambda * 0.25, 1e-5);
   } else {
     H.restoreFrames();
-    if (int r = pointStep(b, 2, 0.f, &dummy0, &dummy1)) return r;
+    if (int r = pointStep(b, 2, 0.f, nullptr, nullptr)) return r;
     H.setPrecalcValues();
     if (int r = linearizeAll(b, false, &lastE[0])) return r;
     lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
