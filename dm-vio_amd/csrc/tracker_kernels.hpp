@@ -40,73 +40,91 @@ struct EvalStats {
   float E, nE, nSat, nW, fT, fRT, fN;
 };
 
-// One template point: everything calcRes does for it plus its calcGS row.  Returns the row J[0..8] = (J0..J7, r) and
-// its Huber weight w (w = 0 and J = 0 when the point does not enter the system).
-__device__ __forceinline__ void evalPoint(const float4 P, const bool flowSample, const EvalP& e, const LevelGeom& g,
-                                          const float* __restrict__ img, const float huberTH, EvalStats& st, float (&J)[9], float& wOut) {
+// Wave-uniform copy of the evaluation parameters in scalar registers (the LDS / kernel-argument originals would be re-read every
+// iteration: the compiler cannot prove they do not alias the staging writes).
+__device__ __forceinline__ float uni(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+struct EvalU {
+  float RKi[9], t[3], aff0, aff1, b0, cutoff, maxEnergy;
+  float fx, fy, cx, cy, wM3, hM3, huberTH;
+  int w;
+};
+__device__ __forceinline__ EvalU makeEvalU(const EvalP& e, const LevelGeom& g, const float huberTH) {
+  EvalU u;
 #pragma unroll
-  for (int k = 0; k < 9; k++) J[k] = 0.0f;
-  wOut = 0.0f;
+  for (int k = 0; k < 9; k++) u.RKi[k] = uni(e.RKi[k]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) u.t[k] = uni(e.t[k]);
+  u.aff0 = uni(e.aff0); u.aff1 = uni(e.aff1); u.b0 = uni(e.b0); u.cutoff = uni(e.cutoff); u.maxEnergy = uni(e.maxEnergy);
+  u.fx = uni(g.fx); u.fy = uni(g.fy); u.cx = uni(g.cx); u.cy = uni(g.cy);
+  u.w = __builtin_amdgcn_readfirstlane(g.w);
+  u.wM3 = (float)(u.w - 3); u.hM3 = (float)(__builtin_amdgcn_readfirstlane(g.h) - 3);
+  u.huberTH = uni(huberTH);
+  return u;
+}
+
+// One template point: everything calcRes does for it (flow indicators excepted, see flowSamplePoint) plus its calcGS row.
+// Returns the row J[0..8] = (J0..J7, r) and its Huber weight w (w = 0 and J = 0 when the point does not enter the system).
+// Written without branches: lanes that fail a test keep computing on a safe in-bounds tap and are masked out at the end —
+// the arithmetic of the surviving lanes is the reference's, operation for operation.
+__device__ __forceinline__ void evalPoint(const float4 P, const bool live, const EvalU& e, const float* __restrict__ img, EvalStats& st,
+                                          float (&J)[9], float& wOut) {
   const float x = P.x, y = P.y, id = P.z, refColor = P.w;
   const float pt0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f + e.t[0] * id;
   const float pt1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f + e.t[1] * id;
   const float pt2 = e.RKi[6] * x + e.RKi[7] * y + e.RKi[8] * 1.0f + e.t[2] * id;
   const float u = pt0 / pt2, v = pt1 / pt2;
-  const float Ku = g.fx * u + g.cx, Kv = g.fy * v + g.cy;
+  const float Ku = e.fx * u + e.cx, Kv = e.fy * v + e.cy;
   const float new_idepth = id / pt2;
-
-  if (flowSample) {
-    // flow indicators (CoarseTracker.cpp:416-447): every 32nd point of the reference's row-major list, level 0 only
-    const float k0 = g.Ki[0] * x + g.Ki[1] * y + g.Ki[2] * 1.0f;
-    const float k1 = g.Ki[3] * x + g.Ki[4] * y + g.Ki[5] * 1.0f;
-    const float k2 = g.Ki[6] * x + g.Ki[7] * y + g.Ki[8] * 1.0f;
-    const float r0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f;
-    const float r1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f;
-    const float r2 = e.RKi[6] * x + e.RKi[7] * y + e.RKi[8] * 1.0f;
-    const float a0 = k0 + e.t[0] * id, a1 = k1 + e.t[1] * id, a2 = k2 + e.t[2] * id;
-    const float KuT = g.fx * (a0 / a2) + g.cx, KvT = g.fy * (a1 / a2) + g.cy;
-    const float b0 = k0 - e.t[0] * id, b1 = k1 - e.t[1] * id, b2 = k2 - e.t[2] * id;
-    const float KuT2 = g.fx * (b0 / b2) + g.cx, KvT2 = g.fy * (b1 / b2) + g.cy;
-    const float c0 = r0 - e.t[0] * id, c1 = r1 - e.t[1] * id, c2 = r2 - e.t[2] * id;
-    const float Ku3 = g.fx * (c0 / c2) + g.cx, Kv3 = g.fy * (c1 / c2) + g.cy;
-    float sT = (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-    sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-    float sRT = (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-    sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-    st.fT += sT;
-    st.fRT += sRT;
-    st.fN += 2.0f;
-  }
-
-  if (!(Ku > 2 && Kv > 2 && Ku < g.w - 3 && Kv < g.h - 3 && new_idepth > 0)) return;
-
-  const float3 hit = interp33(img, Ku, Kv, g.w);
-  if (!isfinite(hit.x)) return;
+  const bool inb = live && (Ku > 2 && Kv > 2 && Ku < e.wM3 && Kv < e.hM3 && new_idepth > 0);
+  const float3 hit = interp33(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, e.w);
+  const bool fin = inb && isfinite(hit.x);
   const float residual = hit.x - (e.aff0 * refColor + e.aff1);
   const float ar = fabsf(residual);
-  const float hw = ar < huberTH ? 1.0f : huberTH / ar;
-
-  st.nE += 1.0f;
-  if (ar > e.cutoff) {
-    st.E += e.maxEnergy;
-    st.nSat += 1.0f;
-    return;
-  }
-  st.E += hw * residual * residual * (2 - hw);
-  st.nW += 1.0f;
-
+  const float hw = ar < e.huberTH ? 1.0f : e.huberTH / ar;
+  const bool sat = ar > e.cutoff, ok = fin && !sat;
+  st.nE += fin ? 1.0f : 0.0f;
+  st.nSat += (fin && sat) ? 1.0f : 0.0f;
+  st.nW += ok ? 1.0f : 0.0f;
+  st.E += fin ? (sat ? e.maxEnergy : hw * residual * residual * (2 - hw)) : 0.0f;   // x + 0 == x: masked lanes leave E untouched
   // calcGSSSE row (CoarseTracker.cpp:314-338)
-  const float dx = hit.y * g.fx, dy = hit.z * g.fy;
-  J[0] = new_idepth * dx;
-  J[1] = new_idepth * dy;
-  J[2] = 0.0f - new_idepth * (u * dx + v * dy);
-  J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
-  J[4] = (u * v) * dy + dx * (1.0f + u * u);
-  J[5] = u * dy - v * dx;
-  J[6] = e.aff0 * (e.b0 - refColor);
-  J[7] = -1.0f;
-  J[8] = residual;
-  wOut = hw;
+  const float dx = hit.y * e.fx, dy = hit.z * e.fy;
+  J[0] = ok ? new_idepth * dx : 0.0f;
+  J[1] = ok ? new_idepth * dy : 0.0f;
+  J[2] = ok ? 0.0f - new_idepth * (u * dx + v * dy) : 0.0f;
+  J[3] = ok ? 0.0f - ((u * v) * dx + dy * (1.0f + v * v)) : 0.0f;
+  J[4] = ok ? (u * v) * dy + dx * (1.0f + u * u) : 0.0f;
+  J[5] = ok ? u * dy - v * dx : 0.0f;
+  J[6] = ok ? e.aff0 * (e.b0 - refColor) : 0.0f;
+  J[7] = ok ? -1.0f : 0.0f;
+  J[8] = ok ? residual : 0.0f;
+  wOut = ok ? hw : 0.0f;
+}
+
+// Flow indicators of one sample point (CoarseTracker.cpp:416-447): every 32nd point of the reference's row-major list, level 0
+// only.  Run as a separate dense pass over the flagged template entries (1/32 of level 0), not inside the evaluation loop.
+__device__ __forceinline__ void flowSamplePoint(const float4 P, const EvalU& e, const float* __restrict__ Ki, EvalStats& st) {
+  const float x = P.x, y = P.y, id = P.z;
+  const float r0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f;
+  const float r1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f;
+  const float r2 = e.RKi[6] * x + e.RKi[7] * y + e.RKi[8] * 1.0f;
+  const float pt0 = r0 + e.t[0] * id, pt1 = r1 + e.t[1] * id, pt2 = r2 + e.t[2] * id;
+  const float Ku = e.fx * (pt0 / pt2) + e.cx, Kv = e.fy * (pt1 / pt2) + e.cy;
+  const float k0 = Ki[0] * x + Ki[1] * y + Ki[2] * 1.0f;
+  const float k1 = Ki[3] * x + Ki[4] * y + Ki[5] * 1.0f;
+  const float k2 = Ki[6] * x + Ki[7] * y + Ki[8] * 1.0f;
+  const float a0 = k0 + e.t[0] * id, a1 = k1 + e.t[1] * id, a2 = k2 + e.t[2] * id;
+  const float KuT = e.fx * (a0 / a2) + e.cx, KvT = e.fy * (a1 / a2) + e.cy;
+  const float b0 = k0 - e.t[0] * id, b1 = k1 - e.t[1] * id, b2 = k2 - e.t[2] * id;
+  const float KuT2 = e.fx * (b0 / b2) + e.cx, KvT2 = e.fy * (b1 / b2) + e.cy;
+  const float c0 = r0 - e.t[0] * id, c1 = r1 - e.t[1] * id, c2 = r2 - e.t[2] * id;
+  const float Ku3 = e.fx * (c0 / c2) + e.cx, Kv3 = e.fy * (c1 / c2) + e.cy;
+  float sT = (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+  sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+  float sRT = (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+  sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+  st.fT += sT;
+  st.fRT += sRT;
+  st.fN += 2.0f;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -166,35 +184,19 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
   f32x4 accH0 = {0.0f, 0.0f, 0.0f, 0.0f}, accH1 = accH0, accH2 = accH0, accH3 = accH0;
   EvalStats st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool lvl0 = (e.lvl == 0);
+  const EvalU eu = makeEvalU(e, g, huberTH);
   const int mi = lane & 15, mk = lane >> 4;
-  // wave-uniform trip count: lane 0 of the wave owns index first - lane.  The template record (and flow-sample word)
-  // of the NEXT iteration is requested before this iteration's taps, so the two dependent memory round trips of a
-  // point (record -> projection -> taps) overlap across iterations.
+  // wave-uniform trip count: lane 0 of the wave owns index first - lane.  The template record of the NEXT iteration is
+  // requested before this iteration's taps, so the two dependent memory round trips of a point (record -> projection ->
+  // taps) overlap across iterations.
   const int base0 = first - lane;
-  float4 Pn = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned long long Fn = 0ull;
-  if (base0 + lane < n) {
-    Pn = pc[base0 + lane];
-    if (lvl0) Fn = flow_mask[(base0 + lane) >> 6];
-  }
+  float4 Pn = n > 0 ? pc[min(base0 + lane, n - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = base0; base < n; base += stride) {
     const int i = base + lane;
     const float4 P = Pn;
-    const unsigned long long F = Fn;
-    const int inext = i + stride;
-    if (inext < n) {
-      Pn = pc[inext];
-      if (lvl0) Fn = flow_mask[inext >> 6];
-    }
+    Pn = pc[min(i + stride, n - 1)];   // unconditional (clamped): no branch between the request and its use
     float J[9], w;
-    if (i < n) {
-      const bool flowSample = lvl0 && ((F >> (i & 63)) & 1ull);
-      evalPoint(P, flowSample, e, g, img, huberTH, st, J, w);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; k++) J[k] = 0.0f;
-      w = 0.0f;
-    }
+    evalPoint(P, i < n, eu, img, st, J, w);
 #pragma unroll
     for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
     wW[lane] = w;
@@ -212,6 +214,18 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
       accH3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, accH3, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (lvl0) {
+    // flow-indicator samples: dense pass over the flagged entries (bit j of word k <=> template entry 64k + j)
+    const int nwords = (n + 63) >> 6;
+    for (int wI = first; wI < nwords; wI += stride) {
+      unsigned long long m = flow_mask[wI];
+      while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        flowSamplePoint(pc[64 * wI + bit], eu, g.Ki, st);
+      }
+    }
   }
   // per-wave partials -> LDS.  accH[r] = D[row = mk*4 + r][col = mi]
 #pragma unroll

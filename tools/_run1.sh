@@ -1,9 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out; rm -rf gpurun_out/p_stats gpurun_out/p_fetch gpurun_out/p_write
-timeout 600 python bench.py > gpurun_out/bench_full.log 2>&1; tail -1 gpurun_out/bench_full.log | cut -c1-3000
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/p_stats -o stats -- python bench.py --no-cpu > gpurun_out/p_stats.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/p_fetch -o fetch -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > gpurun_out/p_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/p_write -o write -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > gpurun_out/p_write.log 2>&1
-ls -la gpurun_out/p_stats gpurun_out/p_fetch gpurun_out/p_write
-python tools/rocprof_summary.py gpurun_out/p_stats/*.db | head -12 | cut -c1-180
-python tools/rocprof_summary.py gpurun_out/p_fetch/*.db --counters | head -8 | cut -c1-180
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -q -m gpu > gpurun_out/t1.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t1.log
+grep -E "^E |passed|failed|rc=" gpurun_out/t1.log | cut -c1-300 | head -30
+timeout 300 python bench.py --no-cpu --no-ba 2>&1 | tail -1 | cut -c1-1800
+MB_BATCH=1 timeout 120 python tools/microbench.py 2>&1 | grep track_lm | tail -1
