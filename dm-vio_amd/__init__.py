@@ -59,6 +59,17 @@ def _sig(L):
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     c_u8 = C.POINTER(C.c_ubyte)
+    L.dmvio_hip_immature_create.restype = vp
+    L.dmvio_hip_immature_create.argtypes = [vp, C.c_int]
+    L.dmvio_hip_immature_destroy.argtypes = [vp]
+    L.dmvio_hip_immature_clear.argtypes = [vp]
+    L.dmvio_hip_immature_count.argtypes = [vp]
+    L.dmvio_hip_immature_add_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_i, c_i]
+    L.dmvio_hip_immature_get_static.argtypes = [vp, c_f, c_f, c_i, c_f, c_f, c_f, c_f]
+    L.dmvio_hip_immature_get_state.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, c_i]
+    L.dmvio_hip_immature_set_state.argtypes = [vp, c_f, c_f, c_f, c_i]
+    L.dmvio_hip_immature_trace.argtypes = [vp, C.c_int, C.c_int, c_f, c_f, c_f]
+    L.dmvio_hip_trace_new_coarse.argtypes = [vp, C.c_int, c_d, c_d, C.c_float, C.c_int, c_d, c_d, c_f, c_d, c_i]
     L.dmvio_hip_ba_create.restype = vp
     L.dmvio_hip_ba_create.argtypes = [vp]
     L.dmvio_hip_ba_destroy.argtypes = [vp]
@@ -118,6 +129,10 @@ def _chk(L, r, what):
     if r is None or (isinstance(r, int) and r < 0):
         raise HipLibraryError("%s: %s" % (what, (L.dmvio_hip_last_error() or b"").decode()))
     return r
+
+
+def _err(L):
+    return (L.dmvio_hip_last_error() or b"").decode()
 
 
 def _f(a):
@@ -305,6 +320,78 @@ class CoarseTrackerHip:
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_work(self.p, C.byref(a), C.byref(b)), "last_work")
         return a.value, b.value
+
+
+class ImmaturePointsHip:
+    """Mirror of the immature-point path: ImmaturePoint construction, ImmaturePoint::traceOn, FullSystem::traceNewCoarse."""
+
+    def __init__(self, ctx, capacity=16384):
+        self.ctx, self.L = ctx, ctx.L
+        p = self.L.dmvio_hip_immature_create(ctx.p, capacity)
+        if not p:
+            raise HipLibraryError("dmvio_hip_immature_create: %s" % _err(self.L))
+        self.p = C.c_void_p(p)
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_immature_destroy(self.p); self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return self.L.dmvio_hip_immature_count(self.p)
+
+    def clear(self):
+        _chk(self.L, self.L.dmvio_hip_immature_clear(self.p), "immature_clear")
+
+    def add_points(self, host_tag, host_slot, u, v):
+        u = np.ascontiguousarray(u, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)
+        r = self.L.dmvio_hip_immature_add_points(self.p, host_tag, host_slot, len(u), _i(u), _i(v))
+        if r < 0:
+            raise HipLibraryError("immature_add_points: %s" % _err(self.L))
+        return r
+
+    def get_static(self):
+        n = self.n
+        o = dict(u=np.zeros(n, np.float32), v=np.zeros(n, np.float32), host=np.zeros(n, np.int32), color=np.zeros((n, 8), np.float32),
+                 weights=np.zeros((n, 8), np.float32), gradH=np.zeros((n, 4), np.float32), energyTH=np.zeros(n, np.float32))
+        _chk(self.L, self.L.dmvio_hip_immature_get_static(self.p, _f(o["u"]), _f(o["v"]), _i(o["host"]), _f(o["color"]), _f(o["weights"]), _f(o["gradH"]),
+                                                           _f(o["energyTH"])), "immature_get_static")
+        return o
+
+    def get_state(self):
+        n = self.n
+        o = dict(idepth_min=np.zeros(n, np.float32), idepth_max=np.zeros(n, np.float32), quality=np.zeros(n, np.float32), lastTraceUV=np.zeros((n, 2), np.float32),
+                 lastTracePixelInterval=np.zeros(n, np.float32), lastTraceStatus=np.zeros(n, np.int32))
+        _chk(self.L, self.L.dmvio_hip_immature_get_state(self.p, _f(o["idepth_min"]), _f(o["idepth_max"]), _f(o["quality"]), _f(o["lastTraceUV"]),
+                                                          _f(o["lastTracePixelInterval"]), _i(o["lastTraceStatus"])), "immature_get_state")
+        return o
+
+    def set_state(self, idepth_min, idepth_max, quality, status):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (idepth_min, idepth_max, quality)]
+        st = np.ascontiguousarray(status, dtype=np.int32)
+        _chk(self.L, self.L.dmvio_hip_immature_set_state(self.p, _f(a[0]), _f(a[1]), _f(a[2]), _i(st)), "immature_set_state")
+
+    def trace(self, new_slot, KRKi, Kt, aff):
+        KRKi = np.ascontiguousarray(KRKi, dtype=np.float32).reshape(-1, 9); Kt = np.ascontiguousarray(Kt, dtype=np.float32).reshape(-1, 3)
+        aff = np.ascontiguousarray(aff, dtype=np.float32).reshape(-1, 2)
+        _chk(self.L, self.L.dmvio_hip_immature_trace(self.p, new_slot, len(KRKi), _f(KRKi), _f(Kt), _f(aff)), "immature_trace")
+
+    def traceNewCoarse(self, new_slot, new_w2c7, host_c2w7, fxfycxcy, new_aff=(0.0, 0.0), new_exposure=1.0, host_aff=None, host_exposure=None):
+        host_c2w7 = np.ascontiguousarray(host_c2w7, dtype=np.float64).reshape(-1, 7)
+        H = len(host_c2w7)
+        ha = np.zeros((H, 2)) if host_aff is None else np.ascontiguousarray(host_aff, dtype=np.float64)
+        he = np.ones(H, np.float32) if host_exposure is None else np.ascontiguousarray(host_exposure, dtype=np.float32)
+        counts = np.zeros(6, np.int32)
+        _chk(self.L, self.L.dmvio_hip_trace_new_coarse(self.p, new_slot, _d(np.ascontiguousarray(new_w2c7, dtype=np.float64)), _d(np.array(new_aff, dtype=np.float64)),
+                                                        new_exposure, H, _d(host_c2w7), _d(ha), _f(he), _d(np.ascontiguousarray(fxfycxcy, dtype=np.float64)), _i(counts)),
+             "trace_new_coarse")
+        return dict(zip(("good", "oob", "outlier", "skipped", "badcondition", "uninitialized"), counts.tolist()))
 
 
 class BundleAdjusterHip:

@@ -1,0 +1,190 @@
+// C ABI of the immature-point path (include/dmvio_hip.h): ImmaturePoint construction and FullSystem::traceNewCoarse.
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include "../../include/dmvio_hip.h"
+#include "internal.h"
+#include "lie_dev.h"
+#include "immature_kernels.hpp"
+
+using namespace dmv;
+
+struct dmvio_hip_immature {
+  dmvio_hip_ctx* ctx = nullptr;
+  int capacity = 0, n = 0;
+  ImmaturePts P{};
+  ImmatureSettings S;
+  float* d_tables = nullptr;   // [KRKi 9H | Kt 3H | aff 2H], H <= 64
+  float* h_tables = nullptr;   // pinned
+  int* d_uv_stage = nullptr;   // 2 x capacity ints
+  std::vector<void*> allocs;
+};
+
+#define IMM_READY(m) do { if (!(m)) return failmsg("null immature handle"); HIPCHK(hipSetDevice((m)->ctx->device)); } while (0)
+enum { IMM_MAX_HOSTS = 64 };
+
+template <class T>
+static int ialloc(dmvio_hip_immature* m, T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
+  HIPCHK(hipMemset(*p, 0, sizeof(T) * std::max<size_t>(n, 1)));
+  m->allocs.push_back(*p);
+  return 0;
+}
+
+extern "C" {
+
+dmvio_hip_immature* dmvio_hip_immature_create(dmvio_hip_ctx* ctx, int capacity) {
+  if (!ctx || capacity < 1) { failmsg("immature_create: bad argument"); return nullptr; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { failmsg("immature_create: hipSetDevice failed"); return nullptr; }
+  dmvio_hip_immature* m = new dmvio_hip_immature();
+  m->ctx = ctx; m->capacity = capacity;
+  ImmaturePts& P = m->P;
+  const size_t c = capacity;
+  if (ialloc(m, &P.u, c) || ialloc(m, &P.v, c) || ialloc(m, &P.host, c) || ialloc(m, &P.color, 8 * c) || ialloc(m, &P.weights, 8 * c) || ialloc(m, &P.gradH, 4 * c) ||
+      ialloc(m, &P.energyTH, c) || ialloc(m, &P.idepth_min, c) || ialloc(m, &P.idepth_max, c) || ialloc(m, &P.quality, c) || ialloc(m, &P.lastTraceUV, 2 * c) ||
+      ialloc(m, &P.lastTracePixelInterval, c) || ialloc(m, &P.lastTraceStatus, c) || ialloc(m, &m->d_tables, 14 * IMM_MAX_HOSTS) || ialloc(m, &m->d_uv_stage, 2 * c) ||
+      hipHostMalloc((void**)&m->h_tables, sizeof(float) * 14 * IMM_MAX_HOSTS, hipHostMallocDefault) != hipSuccess) {
+    for (void* p : m->allocs) hipFree(p);
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+void dmvio_hip_immature_destroy(dmvio_hip_immature* m) {
+  if (!m) return;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) hipFree(p);
+  if (m->h_tables) hipHostFree(m->h_tables);
+  delete m;
+}
+int dmvio_hip_immature_clear(dmvio_hip_immature* m) { IMM_READY(m); m->n = 0; return 0; }
+int dmvio_hip_immature_count(dmvio_hip_immature* m) { return m ? m->n : -1; }
+
+int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_slot, int n, const int* u, const int* v) {
+  IMM_READY(m);
+  dmvio_hip_ctx* c = m->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n < 0 || !u || !v) return failmsg("immature_add_points: bad argument");
+  if (m->n + n > m->capacity) return failmsg("immature_add_points: capacity exceeded");
+  if (host_slot < 0 || host_slot >= c->n_slots || host_tag < 0 || host_tag >= IMM_MAX_HOSTS) return failmsg("immature_add_points: slot / tag out of range");
+  // the constructor reads the 2x2 cell of every pattern pixel: u +- 2 .. +1 must be inside the image (pixel selector margin, PixelSelector2.cpp)
+  for (int i = 0; i < n; i++)
+    if (u[i] < 2 || v[i] < 2 || u[i] + 3 >= c->w || v[i] + 3 >= c->h) return failmsg("immature_add_points: point closer than 3 px to the border");
+  if (n == 0) return m->n;
+  const int first = m->n;
+  std::vector<float> uf(n), vf(n);
+  for (int i = 0; i < n; i++) { uf[i] = (float)u[i]; vf[i] = (float)v[i]; }
+  HIPCHK(hipMemcpyAsync(m->P.u + first, uf.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(m->P.v + first, vf.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // uf / vf are local
+  m->P.n = first + n;
+  hipLaunchKernelGGL(k_immature_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(host_slot, 0), c->w, first, n, m->P, host_tag, m->S);
+  HIPCHK(hipGetLastError());
+  m->n = first + n;
+  return first;
+}
+
+int dmvio_hip_immature_get_static(dmvio_hip_immature* m, float* u, float* v, int* host_tag, float* color8, float* weights8, float* gradH4, float* energyTH) {
+  IMM_READY(m);
+  hipStream_t s = m->ctx->stream;
+  const size_t n = m->n;
+  if (u) HIPCHK(hipMemcpyAsync(u, m->P.u, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (v) HIPCHK(hipMemcpyAsync(v, m->P.v, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (host_tag) HIPCHK(hipMemcpyAsync(host_tag, m->P.host, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  if (color8) HIPCHK(hipMemcpyAsync(color8, m->P.color, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, s));
+  if (weights8) HIPCHK(hipMemcpyAsync(weights8, m->P.weights, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, s));
+  if (gradH4) HIPCHK(hipMemcpyAsync(gradH4, m->P.gradH, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, s));
+  if (energyTH) HIPCHK(hipMemcpyAsync(energyTH, m->P.energyTH, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+int dmvio_hip_immature_get_state(dmvio_hip_immature* m, float* idepth_min, float* idepth_max, float* quality, float* lastTraceUV2, float* lastTracePixelInterval,
+                                 int* lastTraceStatus) {
+  IMM_READY(m);
+  hipStream_t s = m->ctx->stream;
+  const size_t n = m->n;
+  if (idepth_min) HIPCHK(hipMemcpyAsync(idepth_min, m->P.idepth_min, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (idepth_max) HIPCHK(hipMemcpyAsync(idepth_max, m->P.idepth_max, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (quality) HIPCHK(hipMemcpyAsync(quality, m->P.quality, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (lastTraceUV2) HIPCHK(hipMemcpyAsync(lastTraceUV2, m->P.lastTraceUV, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+  if (lastTracePixelInterval) HIPCHK(hipMemcpyAsync(lastTracePixelInterval, m->P.lastTracePixelInterval, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (lastTraceStatus) HIPCHK(hipMemcpyAsync(lastTraceStatus, m->P.lastTraceStatus, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+int dmvio_hip_immature_set_state(dmvio_hip_immature* m, const float* idepth_min, const float* idepth_max, const float* quality, const int* lastTraceStatus) {
+  IMM_READY(m);
+  hipStream_t s = m->ctx->stream;
+  const size_t n = m->n;
+  if (idepth_min) HIPCHK(hipMemcpyAsync(m->P.idepth_min, idepth_min, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (idepth_max) HIPCHK(hipMemcpyAsync(m->P.idepth_max, idepth_max, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (quality) HIPCHK(hipMemcpyAsync(m->P.quality, quality, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (lastTraceStatus) HIPCHK(hipMemcpyAsync(m->P.lastTraceStatus, lastTraceStatus, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// traceOn of every point against the frame in new_slot; per-host tables indexed by the points' host_tag
+int dmvio_hip_immature_trace(dmvio_hip_immature* m, int new_slot, int n_hosts, const float* KRKi9, const float* Kt3, const float* aff2) {
+  IMM_READY(m);
+  dmvio_hip_ctx* c = m->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!KRKi9 || !Kt3 || !aff2 || n_hosts < 1 || n_hosts > IMM_MAX_HOSTS) return failmsg("immature_trace: bad argument");
+  if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("immature_trace: frame slot out of range");
+  if (m->n == 0) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));   // the pinned tables of a previous call may still be in flight
+  float* t = m->h_tables;
+  memcpy(t, KRKi9, sizeof(float) * 9 * n_hosts);
+  memcpy(t + 9 * IMM_MAX_HOSTS, Kt3, sizeof(float) * 3 * n_hosts);
+  memcpy(t + 12 * IMM_MAX_HOSTS, aff2, sizeof(float) * 2 * n_hosts);
+  HIPCHK(hipMemcpyAsync(m->d_tables, t, sizeof(float) * 14 * IMM_MAX_HOSTS, hipMemcpyHostToDevice, c->stream));
+  TraceTables T;
+  T.KRKi = m->d_tables; T.Kt = m->d_tables + 9 * IMM_MAX_HOSTS; T.aff = m->d_tables + 12 * IMM_MAX_HOSTS;
+  m->P.n = m->n;
+  hipLaunchKernelGGL(k_immature_trace, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->fs.level(new_slot, 0), c->w, c->h, m->P, T, m->S);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// FullSystem::traceNewCoarse (FullSystem.cpp:541-584): per-host KRKi / Kt / affine tables from the poses, traceOn of every immature point,
+// status histogram counts6 = {good, oob, outlier, skipped, badcondition, uninitialized}
+int dmvio_hip_trace_new_coarse(dmvio_hip_immature* m, int new_slot, const double new_w2c7[7], const double new_aff[2], float new_exposure, int n_hosts,
+                               const double* host_c2w7, const double* host_aff2, const float* host_exposure, const double fxfycxcy[4], int counts6[6]) {
+  IMM_READY(m);
+  if (!new_w2c7 || !new_aff || !host_c2w7 || !host_aff2 || !host_exposure || !fxfycxcy || n_hosts < 1 || n_hosts > IMM_MAX_HOSTS) return failmsg("trace_new_coarse: bad argument");
+  std::vector<float> KRKi(9 * (size_t)n_hosts), Kt(3 * (size_t)n_hosts), aff(2 * (size_t)n_hosts);
+  const float fx = (float)fxfycxcy[0], fy = (float)fxfycxcy[1], cx = (float)fxfycxcy[2], cy = (float)fxfycxcy[3];
+  const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+  // K.inverse(): Eigen's 3x3 cofactor inverse
+  const float a = K[0], e = K[4], cc = K[2], ff = K[5];
+  const float det = a * (e * 1.0f - ff * 0.0f), invdet = 1.0f / det;
+  const float Ki[9] = {(e * 1.0f - ff * 0.0f) * invdet, (cc * 0.0f - 0.0f * 1.0f) * invdet, (0.0f * ff - cc * e) * invdet,
+                       (ff * 0.0f - 0.0f * 1.0f) * invdet, (a * 1.0f - cc * 0.0f) * invdet, (cc * 0.0f - a * ff) * invdet,
+                       (0.0f * 0.0f - e * 0.0f) * invdet, (0.0f * 0.0f - a * 0.0f) * invdet, (a * e - 0.0f * 0.0f) * invdet};
+  const Pose Tn = poseFrom7(new_w2c7);
+  for (int hI = 0; hI < n_hosts; hI++) {
+    const Pose T = poseMul(Tn, poseFrom7(host_c2w7 + 7 * hI));
+    double Rd[9];
+    quatToR(T.q, Rd);
+    float R[9], t[3], KR[9];
+    for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
+    for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
+    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) KR[r * 3 + q] = K[r * 3 + 0] * R[q] + K[r * 3 + 1] * R[3 + q] + K[r * 3 + 2] * R[6 + q];
+    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) KRKi[9 * hI + r * 3 + q] = KR[r * 3 + 0] * Ki[q] + KR[r * 3 + 1] * Ki[3 + q] + KR[r * 3 + 2] * Ki[6 + q];
+    for (int r = 0; r < 3; r++) Kt[3 * hI + r] = K[r * 3 + 0] * t[0] + K[r * 3 + 1] * t[1] + K[r * 3 + 2] * t[2];
+    double ab[2];
+    affFromTo(host_exposure[hI], new_exposure, host_aff2[2 * hI], host_aff2[2 * hI + 1], new_aff[0], new_aff[1], ab);
+    aff[2 * hI] = (float)ab[0]; aff[2 * hI + 1] = (float)ab[1];
+  }
+  if (int r = dmvio_hip_immature_trace(m, new_slot, n_hosts, KRKi.data(), Kt.data(), aff.data())) return r;
+  if (counts6) {
+    std::vector<int> st(m->n);
+    if (int r = dmvio_hip_immature_get_state(m, nullptr, nullptr, nullptr, nullptr, nullptr, st.data())) return r;
+    for (int k = 0; k < 6; k++) counts6[k] = 0;
+    for (int v : st) if (v >= 0 && v < 6) counts6[v]++;
+  }
+  return 0;
+}
+
+}  // extern "C"

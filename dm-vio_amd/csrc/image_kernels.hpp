@@ -11,6 +11,7 @@
 // read 4 B/px + write 4 B/px * (1 + 1/4 + 1/16 + ...).
 #pragma once
 #include "common.h"
+#include "interp.hpp"
 
 namespace dmv {
 
@@ -61,20 +62,6 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
     float* t = cur; cur = nxt; nxt = t;
     side = ns;
   }
-}
-
-// dIp[lvl][idx][1], [2] of the reference at pixel (x, y) of a level plane: central differences with the reference's
-// flat-index range (rows 1..h-2) and isfinite guard (HessianBlocks.cpp:172-181).
-__device__ __forceinline__ float2 gradAt(const float* __restrict__ I, const int w, const int h, const int x, const int y) {
-  const int idx = x + y * w;
-  float dx = 0.f, dy = 0.f;
-  if (idx >= w && idx < w * (h - 1)) {
-    dx = 0.5f * (I[idx + 1] - I[idx - 1]);
-    dy = 0.5f * (I[idx + w] - I[idx - w]);
-    if (!isfinite(dx)) dx = 0.f;
-    if (!isfinite(dy)) dy = 0.f;
-  }
-  return make_float2(dx, dy);
 }
 
 // level plane -> the reference's Eigen::Vector3f AoS (I, dx, dy)   (parity tests / debug download)

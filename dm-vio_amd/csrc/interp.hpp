@@ -33,4 +33,18 @@ __device__ __forceinline__ float3 interp33(const float* __restrict__ img, const 
   return r;
 }
 
+// dIp[lvl][idx][1], [2] of the reference at pixel (x, y) of a level plane: central differences with the reference's
+// flat-index range (rows 1..h-2) and isfinite guard (HessianBlocks.cpp:172-181).
+__device__ __forceinline__ float2 gradAt(const float* __restrict__ I, const int w, const int h, const int x, const int y) {
+  const int idx = x + y * w;
+  float dx = 0.f, dy = 0.f;
+  if (idx >= w && idx < w * (h - 1)) {
+    dx = 0.5f * (I[idx + 1] - I[idx - 1]);
+    dy = 0.5f * (I[idx + w] - I[idx - w]);
+    if (!isfinite(dx)) dx = 0.f;
+    if (!isfinite(dy)) dy = 0.f;
+  }
+  return make_float2(dx, dy);
+}
+
 }  // namespace dmv

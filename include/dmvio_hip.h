@@ -180,6 +180,33 @@ int dmvio_hip_ba_energy_terms(dmvio_hip_ba* ba, double* EL, double* EM);
 /* FullSystem::optimize(mnumOptIts) (FullSystemOptimize.cpp:417-647): returns statistics_lastFineTrackRMSE in *rmse */
 int dmvio_hip_ba_optimize(dmvio_hip_ba* ba, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Immature points: candidate points traced along their epipolar line in every new frame.
+ *   ImmaturePoint::ImmaturePoint   src/dso/FullSystem/ImmaturePoint.cpp:34-62   -> dmvio_hip_immature_add_points
+ *   ImmaturePoint::traceOn         src/dso/FullSystem/ImmaturePoint.cpp:76-437  -> dmvio_hip_immature_trace
+ *   FullSystem::traceNewCoarse     src/dso/FullSystem/FullSystem.cpp:541-584    -> dmvio_hip_trace_new_coarse
+ * Every point is independent; results are bit-identical to the CPU path.  The handle keeps the points of all keyframes of the window
+ * in one structure-of-arrays; host_tag (0..63) selects the per-host table row (KRKi, Kt, affine) of a trace call.
+ * status codes = enum ImmaturePointStatus (ImmaturePoint.h:46-52): 0 GOOD, 1 OOB, 2 OUTLIER, 3 SKIPPED, 4 BADCONDITION, 5 UNINITIALIZED. */
+typedef struct dmvio_hip_immature dmvio_hip_immature;
+dmvio_hip_immature* dmvio_hip_immature_create(dmvio_hip_ctx* ctx, int capacity);
+void dmvio_hip_immature_destroy(dmvio_hip_immature* imm);
+int dmvio_hip_immature_clear(dmvio_hip_immature* imm);
+int dmvio_hip_immature_count(dmvio_hip_immature* imm);
+/* constructs n points at integer pixels (u, v) of the keyframe in host_slot (FullSystem::makeNewTraces, FullSystem.cpp:1465-1490);
+ * returns the index of the first new point or <0 */
+int dmvio_hip_immature_add_points(dmvio_hip_immature* imm, int host_tag, int host_slot, int n, const int* u, const int* v);
+int dmvio_hip_immature_get_static(dmvio_hip_immature* imm, float* u, float* v, int* host_tag, float* color8, float* weights8, float* gradH4, float* energyTH);
+int dmvio_hip_immature_get_state(dmvio_hip_immature* imm, float* idepth_min, float* idepth_max, float* quality, float* lastTraceUV2,
+                                 float* lastTracePixelInterval, int* lastTraceStatus);
+int dmvio_hip_immature_set_state(dmvio_hip_immature* imm, const float* idepth_min, const float* idepth_max, const float* quality, const int* lastTraceStatus);
+/* traceOn of every point against the frame in new_slot; tables: hostToFrame_KRKi (row-major 3x3), hostToFrame_Kt, hostToFrame_affine per host_tag */
+int dmvio_hip_immature_trace(dmvio_hip_immature* imm, int new_slot, int n_hosts, const float* KRKi9, const float* Kt3, const float* aff2);
+/* FullSystem::traceNewCoarse: builds the per-host tables from the poses (new frame worldToCam, hosts camToWorld, pose7 = tx ty tz qx qy qz qw),
+ * traces, and returns the status histogram counts6 = {good, oob, outlier, skipped, badcondition, uninitialized} */
+int dmvio_hip_trace_new_coarse(dmvio_hip_immature* imm, int new_slot, const double new_w2c7[7], const double new_aff[2], float new_exposure, int n_hosts,
+                               const double* host_c2w7, const double* host_aff2, const float* host_exposure, const double fxfycxcy[4], int counts6[6]);
+
 #ifdef __cplusplus
 }
 #endif

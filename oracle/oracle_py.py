@@ -54,6 +54,10 @@ def lib():
         L.orc_se3_matrix.argtypes = [c_d, c_d, c_d]
         L.orc_ldlt_solve.argtypes = [c_d, c_d, c_d, C.c_int]
         L.orc_make_track_hypotheses.argtypes = [c_d, c_d, c_d, c_d]
+        c_i = C.POINTER(C.c_int)
+        L.orc_immature_init.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_i, c_i, c_f, c_f, c_f, c_f]
+        L.orc_immature_trace.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i]
+        L.orc_trace_precalc.argtypes = [c_d, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
         L.orc_tracker_track_new_coarse.argtypes = [C.c_void_p, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _LIB
 
@@ -121,6 +125,41 @@ def make_track_hypotheses(slast_c2w, sprelast_c2w, lastF_c2w):
     n = lib().orc_make_track_hypotheses(_d(np.ascontiguousarray(slast_c2w, dtype=np.float64)), _d(np.ascontiguousarray(sprelast_c2w, dtype=np.float64)),
                                         _d(np.ascontiguousarray(lastF_c2w, dtype=np.float64)), _d(out))
     return out[:n]
+
+
+class ImmaturePoints:
+    """Oracle mirror of the immature points of ONE host keyframe (ImmaturePoint.h:57-114): constructor + traceOn."""
+
+    def __init__(self, dI_host, w, h, u, v):
+        self.w, self.h = w, h
+        self.u_int = np.ascontiguousarray(u, dtype=np.int32); self.v_int = np.ascontiguousarray(v, dtype=np.int32)
+        n = self.n = len(self.u_int)
+        self.u = self.u_int.astype(np.float32); self.v = self.v_int.astype(np.float32)
+        self.color = np.zeros((n, 8), np.float32); self.weights = np.zeros((n, 8), np.float32)
+        self.gradH = np.zeros((n, 4), np.float32); self.energyTH = np.zeros(n, np.float32)
+        c_i = C.POINTER(C.c_int)
+        lib().orc_immature_init(_f(np.ascontiguousarray(dI_host, dtype=np.float32)), w, h, n, self.u_int.ctypes.data_as(c_i), self.v_int.ctypes.data_as(c_i),
+                                _f(self.color), _f(self.weights), _f(self.gradH), _f(self.energyTH))
+        self.idepth_min = np.zeros(n, np.float32); self.idepth_max = np.full(n, np.nan, np.float32); self.quality = np.full(n, 10000.0, np.float32)
+        self.lastTraceUV = np.zeros((n, 2), np.float32); self.lastTracePixelInterval = np.zeros(n, np.float32)
+        self.lastTraceStatus = np.full(n, 5, np.int32)
+
+    def trace_on(self, dI_new, KRKi9, Kt3, aff2):
+        c_i = C.POINTER(C.c_int)
+        lib().orc_immature_trace(_f(np.ascontiguousarray(dI_new, dtype=np.float32)), self.w, self.h, self.n, _f(self.u), _f(self.v), _f(self.color), _f(self.weights),
+                                 _f(self.gradH), _f(self.energyTH), _f(np.ascontiguousarray(KRKi9, dtype=np.float32)), _f(np.ascontiguousarray(Kt3, dtype=np.float32)),
+                                 _f(np.ascontiguousarray(aff2, dtype=np.float32)), _f(self.idepth_min), _f(self.idepth_max), _f(self.quality), _f(self.lastTraceUV),
+                                 _f(self.lastTracePixelInterval), self.lastTraceStatus.ctypes.data_as(c_i))
+        return self.lastTraceStatus
+
+
+def trace_precalc(new_w2c7, host_c2w7, fxfycxcy, new_exposure=1.0, host_exposure=1.0, new_aff=(0.0, 0.0), host_aff=(0.0, 0.0)):
+    """Per-host tables of FullSystem::traceNewCoarse (FullSystem.cpp:554-560): KRKi (9), Kt (3), aff (2) as float32."""
+    KRKi = np.zeros(9, np.float32); Kt = np.zeros(3, np.float32); aff = np.zeros(2, np.float32)
+    lib().orc_trace_precalc(_d(np.ascontiguousarray(new_w2c7, dtype=np.float64)), _d(np.ascontiguousarray(host_c2w7, dtype=np.float64)),
+                            _d(np.ascontiguousarray(fxfycxcy, dtype=np.float64)), new_exposure, host_exposure, _d(np.array(new_aff, dtype=np.float64)),
+                            _d(np.array(host_aff, dtype=np.float64)), _f(KRKi), _f(Kt), _f(aff))
+    return KRKi, Kt, aff
 
 
 class Tracker:

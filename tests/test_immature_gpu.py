@@ -1,0 +1,99 @@
+"""GPU parity of the immature-point path (ImmaturePoint constructor, traceOn, traceNewCoarse): every point is independent and
+sequential, so the HIP path must reproduce the oracle BIT FOR BIT (statuses, intervals, qualities, trace positions)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _same(a, b):
+    a = np.asarray(a, dtype=np.float32); b = np.asarray(b, dtype=np.float32)
+    return np.array_equal(_bits(a), _bits(b)) or (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]))
+
+
+def test_constructor_and_trace_bit_exact(pkg, oracle, synth, gpu_required):
+    from test_immature_cpu import _case
+    c = _case(synth, oracle, w=512, h=512, n=1500, seed=4)
+    w, h = c["w"], c["h"]
+    ctx = pkg.Context(w, h, n_slots=8)
+    ctx.frame_upload(0, c["host_img"])
+    for k, f in enumerate(c["frames"]):
+        ctx.frame_upload(1 + k, f["img"])
+    imm = pkg.ImmaturePointsHip(ctx, capacity=4096)
+    assert imm.add_points(0, 0, c["u"], c["v"]) == 0
+    assert imm.n == len(c["u"])
+    dI = oracle.make_images(c["host_img"], w, h)[0][0]
+    P = oracle.ImmaturePoints(dI, w, h, c["u"], c["v"])
+    s = imm.get_static()
+    for k in ("color", "weights", "gradH", "energyTH"):
+        assert _same(s[k], getattr(P, k)), k
+    statuses = set()
+    for k, f in enumerate(c["frames"]):
+        dIn = oracle.make_images(f["img"], w, h)[0][0]
+        KRKi, Kt, aff = oracle.trace_precalc(f["pose7"], IDENT, c["K4"])
+        P.trace_on(dIn, KRKi, Kt, aff)
+        counts = imm.traceNewCoarse(1 + k, f["pose7"], IDENT[None], c["K4"])
+        g = imm.get_state()
+        assert np.array_equal(g["lastTraceStatus"], P.lastTraceStatus), "frame %d: %d status mismatches" % (k, (g["lastTraceStatus"] != P.lastTraceStatus).sum())
+        for name in ("idepth_min", "idepth_max", "quality", "lastTraceUV", "lastTracePixelInterval"):
+            assert _same(g[name], getattr(P, name)), "frame %d %s" % (k, name)
+        assert sum(counts.values()) == imm.n
+        assert counts["good"] == int((P.lastTraceStatus == 0).sum())
+        statuses |= set(np.unique(P.lastTraceStatus).tolist())
+    assert 0 in statuses and len(statuses) >= 3, statuses      # GOOD plus at least two other outcomes were exercised
+
+
+def test_trace_affine_exposure_multi_host_and_edge_states(pkg, oracle, synth, gpu_required):
+    """Two hosts with different exposures / affine parameters, points near the border (OOB paths), pre-set OUTLIER / OOB states."""
+    from test_immature_cpu import _case
+    w = h = 256
+    world = synth.PlaneWorld(synth.SEED + 9, fmax=22.0)
+    K4 = synth.default_intrinsics(w, h)
+    rng = np.random.RandomState(11)
+    poses = [np.zeros(6), np.array([0.06, 0.01, -0.02, 0.004, -0.006, 0.002]), np.array([0.11, -0.03, 0.01, -0.003, 0.008, 0.004])]
+    imgs, c2w, w2c = [], [], []
+    for k, xi in enumerate(poses):
+        R, t = synth.se3_exp(xi)
+        img, _ = world.render(K4, R, t, w, h, aff=(0.03 * k, 2.0 * k))
+        imgs.append(img); w2c.append(synth.pose7(R, t)); c2w.append(oracle.se3_inv(synth.pose7(R, t)))
+    ctx = pkg.Context(w, h, n_slots=4)
+    for k, im in enumerate(imgs):
+        ctx.frame_upload(k, im)
+    imm = pkg.ImmaturePointsHip(ctx, capacity=4096)
+    hosts = []
+    for tag in (0, 1):
+        u = rng.randint(3, w - 4, 600).astype(np.int32); v = rng.randint(3, h - 4, 600).astype(np.int32)   # includes border-hugging points
+        imm.add_points(tag, tag, u, v)
+        dI = oracle.make_images(imgs[tag], w, h)[0][0]
+        hosts.append(oracle.ImmaturePoints(dI, w, h, u, v))
+    # pre-set states: some OUTLIER (second outlier -> OOB), some OOB (untouched), some with a finite interval
+    n = imm.n
+    st = np.full(n, 5, np.int32); st[::7] = 2; st[3::11] = 1
+    imin = np.zeros(n, np.float32); imax = np.full(n, np.nan, np.float32)
+    imin[::3] = 0.1; imax[::3] = 0.6
+    q = np.full(n, 10000.0, np.float32)
+    imm.set_state(imin, imax, q, st)
+    o = 0
+    for P in hosts:
+        P.lastTraceStatus[:] = st[o:o + P.n]; P.idepth_min[:] = imin[o:o + P.n]; P.idepth_max[:] = imax[o:o + P.n]; o += P.n
+    host_aff = np.array([[0.0, 0.0], [0.03, 2.0]]); host_exp = np.array([1.0, 0.7], np.float32)
+    new_aff, new_exp = (0.06, 4.0), 1.3
+    dIn = oracle.make_images(imgs[2], w, h)[0][0]
+    for tag, P in enumerate(hosts):
+        KRKi, Kt, aff = oracle.trace_precalc(w2c[2], c2w[tag], K4, new_exp, float(host_exp[tag]), new_aff, tuple(host_aff[tag]))
+        P.trace_on(dIn, KRKi, Kt, aff)
+    counts = imm.traceNewCoarse(2, w2c[2], np.stack(c2w[:2]), K4, new_aff=new_aff, new_exposure=new_exp, host_aff=host_aff, host_exposure=host_exp)
+    g = imm.get_state()
+    ref = {k: np.concatenate([getattr(P, k) for P in hosts]) for k in ("lastTraceStatus", "idepth_min", "idepth_max", "quality", "lastTraceUV", "lastTracePixelInterval")}
+    assert np.array_equal(g["lastTraceStatus"], ref["lastTraceStatus"])
+    for name in ("idepth_min", "idepth_max", "quality", "lastTraceUV", "lastTracePixelInterval"):
+        assert _same(g[name], ref[name]), name
+    assert counts["oob"] >= int((st == 1).sum()) and sum(counts.values()) == n
+    with pytest.raises(pkg.HipLibraryError):
+        imm.add_points(0, 0, np.array([1]), np.array([50]))        # closer than 3 px to the border: the constructor would read outside the image
