@@ -208,6 +208,11 @@ def main():
         ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, coll_dev=coll_dev, torch=torch,
                           cpu=(rank == 0 and world == 1 and not args.no_cpu))
 
+    # ---------------- trace leg (rank 0, N = 1): FullSystem::traceNewCoarse over 7 hosts x 1500 immature points
+    trace_out = None
+    if rank == 0 and world == 1 and not args.no_ba:
+        trace_out = bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu=not args.no_cpu)
+
     if rank == 0:
         out = {
             "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
@@ -221,12 +226,54 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "ba": ba_out,
+            "trace": trace_out,
             "lm_iterations_mean": float(np.mean(res["iterations"])),
             "max_pose_err_m": float(terr.max()),
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
+    """ImmaturePoint::traceOn over the immature points of a 7-host window against one new frame (FullSystem::traceNewCoarse):
+    points / s on the GPU (kernel, HIP events) and for the oracle on one host core."""
+    w, h = case["w"], case["h"]
+    rng = np.random.RandomState(5)
+    n_per_host, hosts = 1500, 7
+    u, v = synth.select_points(case["ref_img"], n_per_host, rng, min_grad=8.0)
+    u = np.clip(u.astype(np.int32), 8, w - 9); v = np.clip(v.astype(np.int32), 8, h - 9)
+    imm = pkg.ImmaturePointsHip(ctx, capacity=n_per_host * hosts)
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, case["frames"][0]["img"])
+    for tag in range(hosts):
+        imm.add_points(tag, 0, u, v)
+    n = imm.n
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    st0 = (np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 10000.0, np.float32), np.full(n, 5, np.int32))
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(12):
+        imm.set_state(*st0)
+        ev0.record(stream); imm.traceNewCoarse(1, case["frames"][0]["pose7"], np.tile(ident, (hosts, 1)), case["K4"]); ev1.record(stream)
+        ev1.synchronize(); ts.append(ev0.elapsed_time(ev1))
+    k_ms = float(np.median(ts[2:]))
+    st = imm.get_state()["lastTraceStatus"]
+    out = dict(metric="immature points traced / s (ImmaturePoint::traceOn, first trace with unbounded depth interval)", value=round(n / (k_ms * 1e-3), 1),
+               unit="points/s", points=n, hosts=hosts, ms_per_call=round(k_ms, 4), good_fraction=round(float((st == 0).mean()), 3))
+    if cpu:
+        O = graft.load_oracle()
+        KRKi, Kt, aff = O.trace_precalc(case["frames"][0]["pose7"], ident, case["K4"])
+        dIh = O.make_images(case["ref_img"], w, h)[0][0]; dIn = O.make_images(case["frames"][0]["img"], w, h)[0][0]
+        P = O.ImmaturePoints(dIh, w, h, u, v)
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            P.idepth_min[:] = 0; P.idepth_max[:] = np.nan; P.quality[:] = 10000; P.lastTraceStatus[:] = 5
+            P.trace_on(dIn, KRKi, Kt, aff); reps += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(reps * n_per_host / dt, 1), unit="points/s", cores=1, kind="port",
+                                   sample="%d x %d points, oracle traceOn, 1 thread (the reference traces single-threaded)" % (reps, n_per_host))
+    imm.close()
+    return out
 
 
 def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):
