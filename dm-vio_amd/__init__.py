@@ -69,6 +69,7 @@ def _sig(L):
     L.dmvio_hip_immature_get_state.argtypes = [vp, c_f, c_f, c_f, c_f, c_f, c_i]
     L.dmvio_hip_immature_set_state.argtypes = [vp, c_f, c_f, c_f, c_i]
     L.dmvio_hip_immature_trace.argtypes = [vp, C.c_int, C.c_int, c_f, c_f, c_f]
+    L.dmvio_hip_immature_optimize.argtypes = [vp, C.c_int, c_i, c_d, c_d, c_f, c_d, C.c_char_p, C.c_int, c_i, c_f, c_i]
     L.dmvio_hip_trace_new_coarse.argtypes = [vp, C.c_int, c_d, c_d, C.c_float, C.c_int, c_d, c_d, c_f, c_d, c_i]
     L.dmvio_hip_ba_create.restype = vp
     L.dmvio_hip_ba_create.argtypes = [vp]
@@ -381,6 +382,19 @@ class ImmaturePointsHip:
         KRKi = np.ascontiguousarray(KRKi, dtype=np.float32).reshape(-1, 9); Kt = np.ascontiguousarray(Kt, dtype=np.float32).reshape(-1, 3)
         aff = np.ascontiguousarray(aff, dtype=np.float32).reshape(-1, 2)
         _chk(self.L, self.L.dmvio_hip_immature_trace(self.p, new_slot, len(KRKi), _f(KRKi), _f(Kt), _f(aff)), "immature_trace")
+
+    def optimize(self, frame_slots, w2c7, fxfycxcy, aff=None, exposure=None, select=None, min_obs=1):
+        """FullSystem::optimizeImmaturePoint for the selected points; returns (result, idepth, res_state[n, F])."""
+        slots = np.ascontiguousarray(frame_slots, dtype=np.int32); F = len(slots)
+        w2c7 = np.ascontiguousarray(w2c7, dtype=np.float64).reshape(F, 7)
+        a = np.zeros((F, 2)) if aff is None else np.ascontiguousarray(aff, dtype=np.float64)
+        e = np.ones(F, np.float32) if exposure is None else np.ascontiguousarray(exposure, dtype=np.float32)
+        n = self.n
+        result = np.zeros(n, np.int32); idepth = np.zeros(n, np.float32); res_state = np.zeros((n, F), np.int32)
+        sel = None if select is None else np.ascontiguousarray(select, dtype=np.uint8).tobytes()
+        _chk(self.L, self.L.dmvio_hip_immature_optimize(self.p, F, _i(slots), _d(w2c7), _d(a), _f(e), _d(np.ascontiguousarray(fxfycxcy, dtype=np.float64)), sel, min_obs,
+                                                         _i(result), _f(idepth), _i(res_state)), "immature_optimize")
+        return result, idepth, res_state
 
     def traceNewCoarse(self, new_slot, new_w2c7, host_c2w7, fxfycxcy, new_aff=(0.0, 0.0), new_exposure=1.0, host_aff=None, host_exposure=None):
         host_c2w7 = np.ascontiguousarray(host_c2w7, dtype=np.float64).reshape(-1, 7)

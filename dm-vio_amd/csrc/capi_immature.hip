@@ -17,6 +17,11 @@ struct dmvio_hip_immature {
   float* d_tables = nullptr;   // [KRKi 9H | Kt 3H | aff 2H], H <= 64
   float* h_tables = nullptr;   // pinned
   int* d_uv_stage = nullptr;   // 2 x capacity ints
+  float* d_opt_tables = nullptr;   // [R 9 F*F | t 3 F*F | aff 2 F*F], F <= 8
+  float* h_opt_tables = nullptr;
+  int *d_result = nullptr, *d_res_state = nullptr;
+  float* d_idepth = nullptr;
+  unsigned char* d_select = nullptr;
   std::vector<void*> allocs;
 };
 
@@ -42,7 +47,8 @@ dmvio_hip_immature* dmvio_hip_immature_create(dmvio_hip_ctx* ctx, int capacity) 
   const size_t c = capacity;
   if (ialloc(m, &P.u, c) || ialloc(m, &P.v, c) || ialloc(m, &P.host, c) || ialloc(m, &P.color, 8 * c) || ialloc(m, &P.weights, 8 * c) || ialloc(m, &P.gradH, 4 * c) ||
       ialloc(m, &P.energyTH, c) || ialloc(m, &P.idepth_min, c) || ialloc(m, &P.idepth_max, c) || ialloc(m, &P.quality, c) || ialloc(m, &P.lastTraceUV, 2 * c) ||
-      ialloc(m, &P.lastTracePixelInterval, c) || ialloc(m, &P.lastTraceStatus, c) || ialloc(m, &m->d_tables, 14 * IMM_MAX_HOSTS) || ialloc(m, &m->d_uv_stage, 2 * c) ||
+      ialloc(m, &P.lastTracePixelInterval, c) || ialloc(m, &P.lastTraceStatus, c) || ialloc(m, &m->d_tables, 14 * IMM_MAX_HOSTS) || ialloc(m, &m->d_uv_stage, 2 * c) || ialloc(m, &m->d_opt_tables, 14 * 64) || ialloc(m, &m->d_result, c) || ialloc(m, &m->d_res_state, 8 * c) ||
+      ialloc(m, &m->d_idepth, c) || ialloc(m, &m->d_select, c) || hipHostMalloc((void**)&m->h_opt_tables, sizeof(float) * 14 * 64, hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&m->h_tables, sizeof(float) * 14 * IMM_MAX_HOSTS, hipHostMallocDefault) != hipSuccess) {
     for (void* p : m->allocs) hipFree(p);
     delete m;
@@ -56,6 +62,7 @@ void dmvio_hip_immature_destroy(dmvio_hip_immature* m) {
   hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_tables) hipHostFree(m->h_tables);
+  if (m->h_opt_tables) hipHostFree(m->h_opt_tables);
   delete m;
 }
 int dmvio_hip_immature_clear(dmvio_hip_immature* m) { IMM_READY(m); m->n = 0; return 0; }
@@ -184,6 +191,55 @@ int dmvio_hip_trace_new_coarse(dmvio_hip_immature* m, int new_slot, const double
     for (int k = 0; k < 6; k++) counts6[k] = 0;
     for (int v : st) if (v >= 0 && v < 6) counts6[v]++;
   }
+  return 0;
+}
+
+// FullSystem::optimizeImmaturePoint for the selected points (FullSystemOptPoint.cpp:51-205; caller: activatePointsMT_Reductor,
+// FullSystem.cpp:587-602).  The pair tables PRE_RTll / PRE_tTll / PRE_aff_mode are FrameFramePrecalc::set (HessianBlocks.cpp:193-223).
+int dmvio_hip_immature_optimize(dmvio_hip_immature* m, int F, const int* frame_slots, const double* w2c7, const double* aff2, const float* exposure,
+                                const double fxfycxcy[4], const unsigned char* select, int minObs, int* result, float* idepth, int* res_state) {
+  IMM_READY(m);
+  dmvio_hip_ctx* c = m->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (F < 2 || F > 8 || !frame_slots || !w2c7 || !aff2 || !exposure || !fxfycxcy || !result || !idepth) return failmsg("immature_optimize: bad argument");
+  if (m->n == 0) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float* tb = m->h_opt_tables;
+  float *R = tb, *t = tb + 9 * 64, *aff = tb + 12 * 64;
+  OptTables T;
+  T.F = F;
+  for (int f = 0; f < 8; f++) T.slot[f] = 0;
+  for (int f = 0; f < F; f++) {
+    if (frame_slots[f] < 0 || frame_slots[f] >= c->n_slots) return failmsg("immature_optimize: frame slot out of range");
+    T.slot[f] = frame_slots[f];
+  }
+  for (int hI = 0; hI < F; hI++) {
+    const Pose c2w = poseInv(poseFrom7(w2c7 + 7 * hI));
+    for (int tI = 0; tI < F; tI++) {
+      const Pose l = poseMul(poseFrom7(w2c7 + 7 * tI), c2w);
+      double Rd[9];
+      quatToR(l.q, Rd);
+      const int o = hI * F + tI;
+      for (int i = 0; i < 9; i++) R[9 * o + i] = (float)Rd[i];
+      for (int i = 0; i < 3; i++) t[3 * o + i] = (float)l.t[i];
+      double ab[2];
+      affFromTo(exposure[hI], exposure[tI], aff2[2 * hI], aff2[2 * hI + 1], aff2[2 * tI], aff2[2 * tI + 1], ab);
+      aff[2 * o] = (float)ab[0]; aff[2 * o + 1] = (float)ab[1];
+    }
+  }
+  HIPCHK(hipMemcpyAsync(m->d_opt_tables, tb, sizeof(float) * 14 * 64, hipMemcpyHostToDevice, c->stream));
+  T.R = m->d_opt_tables; T.t = m->d_opt_tables + 9 * 64; T.aff = m->d_opt_tables + 12 * 64;
+  T.fxl = (float)fxfycxcy[0]; T.fyl = (float)fxfycxcy[1]; T.cxl = (float)fxfycxcy[2]; T.cyl = (float)fxfycxcy[3];
+  T.fxli = 1.0f / T.fxl; T.fyli = 1.0f / T.fyl;   // CalibHessian::setValueScaled (HessianBlocks.h:373-387)
+  if (select) HIPCHK(hipMemcpyAsync(m->d_select, select, m->n, hipMemcpyHostToDevice, c->stream));
+  m->P.n = m->n;
+  hipLaunchKernelGGL(k_immature_optimize, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->fs, c->w, c->h, m->P, T, select ? m->d_select : nullptr, minObs,
+                     100.0f /* setting_minIdepthH_act */, 3 /* setting_GNItsOnPointActivation */, m->S.huberTH, m->d_result, m->d_idepth, m->d_res_state);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(result, m->d_result, sizeof(int) * m->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(idepth, m->d_idepth, sizeof(float) * m->n, hipMemcpyDeviceToHost, c->stream));
+  if (res_state) HIPCHK(hipMemcpyAsync(res_state, m->d_res_state, sizeof(int) * (size_t)m->n * F, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

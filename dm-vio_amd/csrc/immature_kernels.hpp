@@ -317,4 +317,150 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:51-205) + ImmaturePoint::linearizeResidual (ImmaturePoint.cpp:498-565):
+// Gauss-Newton on the inverse depth of one candidate over its residuals to all other keyframes.  One wavefront per point: lane
+// (r, idx) = (lane >> 3, lane & 7) evaluates pattern pixel idx of the residual to the r-th other keyframe; the sums Hdd, bd, the
+// residual energies and the accept / reject logic are replayed by every lane in the reference's order (bit-identical results).
+struct OptTables {
+  int F;
+  int slot[8];                 // level-0 image of every keyframe
+  const float* R;              // F*F x 9, index host*F + target: PRE_RTll
+  const float* t;              // F*F x 3: PRE_tTll
+  const float* aff;            // F*F x 2: PRE_aff_mode
+  float fxl, fyl, cxl, cyl, fxli, fyli;
+};
+enum { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+
+struct OptPass { float energy, Hdd, bd; };
+
+__global__ void __launch_bounds__(256) k_immature_optimize(const FrameStore fs, const int w, const int h, const ImmaturePts P, const OptTables T,
+                                                            const unsigned char* __restrict__ select, const int minObs, const float minIdepthH_act,
+                                                            const int GNIts, const float huberTH, int* __restrict__ result, float* __restrict__ idepth_out,
+                                                            int* __restrict__ res_state /* n x F, host entry -1 */) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= P.n) return;
+  if (select && !select[k]) { if (lane == 0) { result[k] = 0; idepth_out[k] = 0.f; } return; }
+  const int F = T.F, hI = P.host[k], nres = F - 1;
+  const int r = lane >> 3, idx = lane & 7;
+  const bool active = r < nres;
+  const int tI = active ? (r < hI ? r : r + 1) : 0;          // r-th keyframe that is not the host
+  const float* __restrict__ R = T.R + 9 * (hI * F + tI);
+  const float* __restrict__ tt = T.t + 3 * (hI * F + tI);
+  const float aff0 = T.aff[2 * (hI * F + tI)], aff1 = T.aff[2 * (hI * F + tI) + 1];
+  const float* __restrict__ I = fs.level(T.slot[tI], 0);
+  const float pu = P.u[k], pv = P.v[k];
+  const float color = P.color[8 * k + idx], wgt = P.weights[8 * k + idx], energyTH = P.energyTH[k];
+  const int pdx = c_pattern8[idx][0], pdy = c_pattern8[idx][1];
+  const float wM3G = (float)(w - 3), hM3G = (float)(h - 3);
+  int state[7], newState[7];
+  float energy[7], newEnergy[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) { state[i] = RS_IN; newState[i] = RS_OUTLIER; energy[i] = 0.f; newEnergy[i] = 0.f; }
+
+  auto pass = [&](const float idepth, const float slack, float Hdd, float bd) -> OptPass {
+    // this lane's pattern pixel (projectPoint, ResidualProjections.h:61-87)
+    bool ok = false;
+    float eTerm = 0.f, hTerm = 0.f, bTerm = 0.f;
+    if (active) {
+      const float Kl0 = (pu + pdx - T.cxl) * T.fxli, Kl1 = (pv + pdy - T.cyl) * T.fyli, Kl2 = 1;
+      const float p0 = R[0] * Kl0 + R[1] * Kl1 + R[2] * Kl2 + tt[0] * idepth;
+      const float p1 = R[3] * Kl0 + R[4] * Kl1 + R[5] * Kl2 + tt[1] * idepth;
+      const float p2 = R[6] * Kl0 + R[7] * Kl1 + R[8] * Kl2 + tt[2] * idepth;
+      const float drescale = 1.0f / p2;
+      if (drescale > 0) {
+        const float u = p0 * drescale, v = p1 * drescale;
+        const float Ku = u * T.fxl + T.cxl, Kv = v * T.fyl + T.cyl;
+        if (Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G) {
+          const float3 hit = interp33Any(I, Ku, Kv, w, h);
+          if (isfinite(hit.x)) {
+            ok = true;
+            const float residual = hit.x - (aff0 * color + aff1);
+            float hw = fabsf(residual) < huberTH ? 1 : huberTH / fabsf(residual);
+            eTerm = wgt * wgt * hw * residual * residual * (2 - hw);
+            const float dxInterp = hit.y * T.fxl, dyInterp = hit.z * T.fyl;
+            const float d_idepth = (dxInterp * drescale * (tt[0] - tt[2] * u) + dyInterp * drescale * (tt[1] - tt[2] * v)) * 1.0f;   // SCALE_IDEPTH
+            hw *= wgt * wgt;
+            hTerm = (hw * d_idepth) * d_idepth;
+            bTerm = (hw * residual) * d_idepth;
+          }
+        }
+      }
+    }
+    // sequential replay, identical on every lane
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      if (i < nres) {
+        float ret;
+        if (state[i] == RS_OOB) { newState[i] = RS_OOB; ret = energy[i]; }
+        else {
+          float energyLeft = 0.f;
+          bool broke = false;
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            if (!broke) {
+              const int src = i * 8 + q;
+              if (!__shfl((int)ok, src, 64)) broke = true;
+              else { energyLeft += __shfl(eTerm, src, 64); Hdd += __shfl(hTerm, src, 64); bd += __shfl(bTerm, src, 64); }
+            }
+          }
+          if (broke) { newState[i] = RS_OOB; ret = energy[i]; }
+          else {
+            if (energyLeft > energyTH * slack) { energyLeft = energyTH * slack; newState[i] = RS_OUTLIER; }
+            else newState[i] = RS_IN;
+            newEnergy[i] = energyLeft;
+            ret = energyLeft;
+          }
+        }
+        total = (float)((double)total + (double)ret);
+      }
+    }
+    OptPass o; o.energy = total; o.Hdd = Hdd; o.bd = bd;
+    return o;
+  };
+
+  float currentIdepth = (P.idepth_max[k] + P.idepth_min[k]) * 0.5f;
+  OptPass last = pass(currentIdepth, 1000.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 7; i++) { state[i] = newState[i]; energy[i] = newEnergy[i]; }
+  int res = 1;
+  bool finished = false;
+  if (!isfinite(last.energy) || last.Hdd < minIdepthH_act) { res = 0; finished = true; }
+  float lambda = 0.1f;
+  for (int iteration = 0; iteration < GNIts && !finished; iteration++) {
+    float H = last.Hdd;
+    H *= 1 + lambda;
+    const float step = (float)((1.0 / (double)H) * (double)last.bd);
+    const float newIdepth = currentIdepth - step;
+    const OptPass nw = pass(newIdepth, 1.f, 0.f, 0.f);
+    if (!isfinite(last.energy) || nw.Hdd < minIdepthH_act) { res = 0; finished = true; break; }
+    if (nw.energy < last.energy) {
+      currentIdepth = newIdepth;
+      last = nw;
+#pragma unroll
+      for (int i = 0; i < 7; i++) { state[i] = newState[i]; energy[i] = newEnergy[i]; }
+      lambda *= 0.5f;
+    } else lambda *= 5.f;
+    if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break;
+  }
+  if (res == 1) {
+    if (!isfinite(currentIdepth)) res = -1;
+    else {
+      int numGoodRes = 0;
+#pragma unroll
+      for (int i = 0; i < 7; i++) if (i < nres && state[i] == RS_IN) numGoodRes++;
+      if (numGoodRes < minObs || !isfinite(energyTH)) res = -1;
+    }
+  }
+  if (lane == 0) {
+    result[k] = res;
+    idepth_out[k] = currentIdepth;
+    for (int t = 0; t < F; t++) res_state[(size_t)k * F + t] = -1;
+#pragma unroll
+    for (int i = 0; i < 7; i++) if (i < nres) res_state[(size_t)k * F + (i < hI ? i : i + 1)] = state[i];
+  }
+}
+
 }  // namespace dmv

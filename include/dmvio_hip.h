@@ -202,6 +202,14 @@ int dmvio_hip_immature_get_state(dmvio_hip_immature* imm, float* idepth_min, flo
 int dmvio_hip_immature_set_state(dmvio_hip_immature* imm, const float* idepth_min, const float* idepth_max, const float* quality, const int* lastTraceStatus);
 /* traceOn of every point against the frame in new_slot; tables: hostToFrame_KRKi (row-major 3x3), hostToFrame_Kt, hostToFrame_affine per host_tag */
 int dmvio_hip_immature_trace(dmvio_hip_immature* imm, int new_slot, int n_hosts, const float* KRKi9, const float* Kt3, const float* aff2);
+/* FullSystem::optimizeImmaturePoint (src/dso/FullSystem/FullSystemOptPoint.cpp:51-205) with ImmaturePoint::linearizeResidual
+ * (ImmaturePoint.cpp:498-565) for the points with select[i] != 0 (NULL = all): Gauss-Newton on the inverse depth over the residuals
+ * to the other F-1 keyframes of the window (host_tag of a point = its keyframe's index; w2c7 = PRE_worldToCam, aff2 = aff_g2l per frame).
+ * result[i]: 1 = activate (idepth[i], res_state valid), 0 = not well constrained (stays immature), -1 = delete;
+ * res_state[i*F + t] = ResState of the residual to keyframe t (0 IN, 1 OOB, 2 OUTLIER; -1 for the host itself): the IN entries are
+ * the PointFrameResiduals the reference creates (FullSystemOptPoint.cpp:178-197). */
+int dmvio_hip_immature_optimize(dmvio_hip_immature* imm, int F, const int* frame_slots, const double* w2c7, const double* aff2, const float* exposure,
+                                const double fxfycxcy[4], const unsigned char* select, int minObs, int* result, float* idepth, int* res_state);
 /* FullSystem::traceNewCoarse: builds the per-host tables from the poses (new frame worldToCam, hosts camToWorld, pose7 = tx ty tz qx qy qz qw),
  * traces, and returns the status histogram counts6 = {good, oob, outlier, skipped, badcondition, uninitialized} */
 int dmvio_hip_trace_new_coarse(dmvio_hip_immature* imm, int new_slot, const double new_w2c7[7], const double new_aff[2], float new_exposure, int n_hosts,

@@ -3,6 +3,10 @@
 //   orc_immature_init   <- ImmaturePoint::ImmaturePoint        src/dso/FullSystem/ImmaturePoint.cpp:34-62
 //   orc_immature_trace  <- ImmaturePoint::traceOn              src/dso/FullSystem/ImmaturePoint.cpp:76-437
 //   orc_trace_precalc   <- FullSystem::traceNewCoarse          src/dso/FullSystem/FullSystem.cpp:541-584 (per-host KRKi, Kt, aff)
+//   orc_immature_optimize <- FullSystem::optimizeImmaturePoint src/dso/FullSystem/FullSystemOptPoint.cpp:51-205
+//                            ImmaturePoint::linearizeResidual   src/dso/FullSystem/ImmaturePoint.cpp:498-565
+//                            projectPoint / derive_idepth       src/dso/FullSystem/ResidualProjections.h:36-87
+//   orc_pair_precalc    <- FrameFramePrecalc::set              src/dso/FullSystem/HessianBlocks.cpp:193-223 (PRE_RTll, PRE_tTll, PRE_aff_mode)
 // Interpolators: getInterpolatedElement31 / 33 / 33BiLin       src/dso/util/globalFuncs.h:160-176,103-118,203-227
 // Settings: src/dso/util/settings.cpp:111-112,159,178-187,296 (pattern 8), src/dso/util/settings.h:227-228.
 // Images are the reference's Eigen::Vector3f (I, dx, dy) level-0 arrays as produced by orc_make_images.
@@ -191,6 +195,95 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
   return s.lastTraceStatus = IPS_GOOD;
 }
 
+
+enum { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };   // ResState (Residuals.h:44)
+const float setting_minIdepthH_act = 100;
+const int setting_GNItsOnPointActivation = 3;
+const float SCALE_IDEPTH = 1.0f;
+
+struct TmpRes { int state_state, state_NewState; double state_energy, state_NewEnergy; };
+struct PairPre { const float* R; const float* t; const float* aff; const float* dI; };
+struct CalibF { float fxl, fyl, cxl, cyl, fxli, fyli; int w, h; };
+
+double linearizeResidual(const CalibF& C, const PairPre& pre, float pu, float pv, const float* color, const float* weights, float energyTH, float outlierTHSlack,
+                         TmpRes& tmp, float& Hdd, float& bd, float idepth) {
+  if (tmp.state_state == RS_OOB) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+  float energyLeft = 0;
+  const float wM3G = C.w - 3, hM3G = C.h - 3;
+  for (int idx = 0; idx < patternNum; idx++) {
+    const int dx = patternP[idx][0], dy = patternP[idx][1];
+    // projectPoint (ResidualProjections.h:61-87)
+    const float Kl0 = (pu + dx - C.cxl) * C.fxli, Kl1 = (pv + dy - C.cyl) * C.fyli, Kl2 = 1;
+    float ptp[3];
+    for (int r = 0; r < 3; r++) ptp[r] = pre.R[r * 3 + 0] * Kl0 + pre.R[r * 3 + 1] * Kl1 + pre.R[r * 3 + 2] * Kl2 + pre.t[r] * idepth;
+    const float drescale = 1.0f / ptp[2];
+    bool ok = drescale > 0;
+    float u = 0, v = 0, Ku = 0, Kv = 0;
+    if (ok) {
+      u = ptp[0] * drescale; v = ptp[1] * drescale;
+      Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
+      ok = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+    }
+    if (!ok) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+    float hit[3];
+    interp33(pre.dI, Ku, Kv, C.w, hit);
+    if (!std::isfinite(hit[0])) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+    const float residual = hit[0] - (pre.aff[0] * color[idx] + pre.aff[1]);
+    float hw = fabsf(residual) < setting_huberTH ? 1 : setting_huberTH / fabsf(residual);
+    energyLeft += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+    // depth derivatives.
+    const float dxInterp = hit[1] * C.fxl, dyInterp = hit[2] * C.fyl;
+    const float d_idepth = (dxInterp * drescale * (pre.t[0] - pre.t[2] * u) + dyInterp * drescale * (pre.t[1] - pre.t[2] * v)) * SCALE_IDEPTH;
+    hw *= weights[idx] * weights[idx];
+    Hdd += (hw * d_idepth) * d_idepth;
+    bd += (hw * residual) * d_idepth;
+  }
+  if (energyLeft > energyTH * outlierTHSlack) { energyLeft = energyTH * outlierTHSlack; tmp.state_NewState = RS_OUTLIER; }
+  else tmp.state_NewState = RS_IN;
+  tmp.state_NewEnergy = energyLeft;
+  return energyLeft;
+}
+
+// returns 1 = activated (idepth_out, res_state valid), 0 = not well-constrained (keep immature), -1 = delete the point
+int optimizeImmaturePoint(const CalibF& C, int nres, const PairPre* pre, float pu, float pv, const float* color, const float* weights, float energyTH,
+                          float idepth_min, float idepth_max, int minObs, float& idepth_out, int* res_state) {
+  TmpRes residuals[16];
+  for (int i = 0; i < nres; i++) { residuals[i].state_NewEnergy = residuals[i].state_energy = 0; residuals[i].state_NewState = RS_OUTLIER; residuals[i].state_state = RS_IN; }
+  float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+  float currentIdepth = (idepth_max + idepth_min) * 0.5f;
+  for (int i = 0; i < nres; i++) {
+    lastEnergy += linearizeResidual(C, pre[i], pu, pv, color, weights, energyTH, 1000, residuals[i], lastHdd, lastbd, currentIdepth);
+    residuals[i].state_state = residuals[i].state_NewState;
+    residuals[i].state_energy = residuals[i].state_NewEnergy;
+  }
+  idepth_out = currentIdepth;
+  if (!std::isfinite(lastEnergy) || lastHdd < setting_minIdepthH_act) return 0;
+  float lambda = 0.1;
+  for (int iteration = 0; iteration < setting_GNItsOnPointActivation; iteration++) {
+    float H = lastHdd;
+    H *= 1 + lambda;
+    const float step = (1.0 / H) * lastbd;
+    const float newIdepth = currentIdepth - step;
+    float newHdd = 0, newbd = 0, newEnergy = 0;
+    for (int i = 0; i < nres; i++) newEnergy += linearizeResidual(C, pre[i], pu, pv, color, weights, energyTH, 1, residuals[i], newHdd, newbd, newIdepth);
+    if (!std::isfinite(lastEnergy) || newHdd < setting_minIdepthH_act) return 0;
+    if (newEnergy < lastEnergy) {
+      currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
+      for (int i = 0; i < nres; i++) { residuals[i].state_state = residuals[i].state_NewState; residuals[i].state_energy = residuals[i].state_NewEnergy; }
+      lambda *= 0.5;
+    } else lambda *= 5;
+    if (fabsf(step) < 0.0001 * currentIdepth) break;
+  }
+  idepth_out = currentIdepth;
+  for (int i = 0; i < nres; i++) res_state[i] = residuals[i].state_state;
+  if (!std::isfinite(currentIdepth)) return -1;
+  int numGoodRes = 0;
+  for (int i = 0; i < nres; i++) if (residuals[i].state_state == RS_IN) numGoodRes++;
+  if (numGoodRes < minObs) return -1;
+  if (!std::isfinite(energyTH)) return -1;   // PointHessian::energyTH copied from the immature point (HessianBlocks.cpp:39-57)
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -256,6 +349,39 @@ void orc_trace_precalc(const double* new_w2c7, const double* host_c2w7, const do
   const double ea = exp(new_aff[0] - host_aff[0]) * new_exposure / host_exposure;
   const double eb = new_aff[1] - ea * host_aff[1];
   aff2[0] = (float)ea; aff2[1] = (float)eb;
+}
+
+// FrameFramePrecalc::set (HessianBlocks.cpp:193-223): PRE_RTll, PRE_tTll (current state), PRE_aff_mode of the pair (host -> target)
+void orc_pair_precalc(const double* target_w2c7, const double* host_c2w7, float host_exposure, float target_exposure, const double* host_aff, const double* target_aff,
+                      float* R9, float* t3, float* aff2) {
+  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qnormalize(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
+  const orc::SE3 T = orc::se3Mul(from7(target_w2c7), from7(host_c2w7));
+  double Rd[9];
+  orc::qToR(T.q, Rd);
+  for (int i = 0; i < 9; i++) R9[i] = (float)Rd[i];
+  for (int i = 0; i < 3; i++) t3[i] = (float)T.t[i];
+  float eF = host_exposure, eT = target_exposure;
+  if (eF == 0 || eT == 0) { eT = eF = 1; }
+  const double a = exp(target_aff[0] - host_aff[0]) * eT / eF;
+  aff2[0] = (float)a; aff2[1] = (float)(target_aff[1] - a * host_aff[1]);
+}
+
+// optimizeImmaturePoint for the n points of ONE host against nres targets (the other keyframes in window order).
+// result[n]: 1 activated / 0 skip / -1 delete; idepth[n]; res_state[n x nres] (ResState of the residual to every target, valid when result != 0)
+void orc_immature_optimize(int w, int h, const float* fxfycxcy, int nres, const float* const* dI_targets, const float* R9, const float* t3, const float* aff2, int n,
+                           const float* u, const float* v, const float* color, const float* weights, const float* energyTH, const float* idepth_min,
+                           const float* idepth_max, int minObs, int* result, float* idepth, int* res_state) {
+  CalibF C;
+  C.fxl = fxfycxcy[0]; C.fyl = fxfycxcy[1]; C.cxl = fxfycxcy[2]; C.cyl = fxfycxcy[3];
+  C.fxli = 1.0f / C.fxl; C.fyli = 1.0f / C.fyl;   // CalibHessian::setValueScaled (HessianBlocks.h:374-387)
+  C.w = w; C.h = h;
+  PairPre pre[16];
+  for (int i = 0; i < nres; i++) { pre[i].R = R9 + 9 * i; pre[i].t = t3 + 3 * i; pre[i].aff = aff2 + 2 * i; pre[i].dI = dI_targets[i]; }
+  for (int k = 0; k < n; k++) {
+    for (int i = 0; i < nres; i++) res_state[(size_t)k * nres + i] = RS_OOB;
+    result[k] = optimizeImmaturePoint(C, nres, pre, u[k], v[k], color + 8 * k, weights + 8 * k, energyTH[k], idepth_min[k], idepth_max[k], minObs, idepth[k],
+                                      res_state + (size_t)k * nres);
+  }
 }
 
 }  // extern "C"

@@ -58,6 +58,9 @@ def lib():
         L.orc_immature_init.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_i, c_i, c_f, c_f, c_f, c_f]
         L.orc_immature_trace.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i]
         L.orc_trace_precalc.argtypes = [c_d, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
+        L.orc_pair_precalc.argtypes = [c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
+        L.orc_immature_optimize.argtypes = [C.c_int, C.c_int, c_f, C.c_int, C.POINTER(c_f), c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int,
+                                            c_i, c_f, c_i]
         L.orc_tracker_track_new_coarse.argtypes = [C.c_void_p, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _LIB
 
@@ -151,6 +154,28 @@ class ImmaturePoints:
                                  _f(np.ascontiguousarray(aff2, dtype=np.float32)), _f(self.idepth_min), _f(self.idepth_max), _f(self.quality), _f(self.lastTraceUV),
                                  _f(self.lastTracePixelInterval), self.lastTraceStatus.ctypes.data_as(c_i))
         return self.lastTraceStatus
+
+
+def pair_precalc(target_w2c7, host_c2w7, host_exposure=1.0, target_exposure=1.0, host_aff=(0.0, 0.0), target_aff=(0.0, 0.0)):
+    """FrameFramePrecalc::set: PRE_RTll (9), PRE_tTll (3), PRE_aff_mode (2) of the pair host -> target."""
+    R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); aff = np.zeros(2, np.float32)
+    lib().orc_pair_precalc(_d(np.ascontiguousarray(target_w2c7, dtype=np.float64)), _d(np.ascontiguousarray(host_c2w7, dtype=np.float64)), host_exposure, target_exposure,
+                           _d(np.array(host_aff, dtype=np.float64)), _d(np.array(target_aff, dtype=np.float64)), _f(R), _f(t), _f(aff))
+    return R, t, aff
+
+
+def immature_optimize(P, K4, dI_targets, R, t, aff, min_obs=1):
+    """FullSystem::optimizeImmaturePoint for all points of the ImmaturePoints set P (one host) against the targets (window order)."""
+    nres = len(dI_targets)
+    dIs = [np.ascontiguousarray(d, dtype=np.float32) for d in dI_targets]
+    arr = (c_f * nres)(*[_f(d) for d in dIs])
+    R = np.ascontiguousarray(R, dtype=np.float32); t = np.ascontiguousarray(t, dtype=np.float32); aff = np.ascontiguousarray(aff, dtype=np.float32)
+    result = np.zeros(P.n, np.int32); idepth = np.zeros(P.n, np.float32); res_state = np.zeros((P.n, nres), np.int32)
+    c_i = C.POINTER(C.c_int)
+    K = np.ascontiguousarray(K4, dtype=np.float32)
+    lib().orc_immature_optimize(P.w, P.h, _f(K), nres, arr, _f(R), _f(t), _f(aff), P.n, _f(P.u), _f(P.v), _f(P.color), _f(P.weights), _f(P.energyTH),
+                                _f(P.idepth_min), _f(P.idepth_max), min_obs, result.ctypes.data_as(c_i), _f(idepth), res_state.ctypes.data_as(c_i))
+    return result, idepth, res_state
 
 
 def trace_precalc(new_w2c7, host_c2w7, fxfycxcy, new_exposure=1.0, host_exposure=1.0, new_aff=(0.0, 0.0), host_aff=(0.0, 0.0)):

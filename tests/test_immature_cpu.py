@@ -72,3 +72,54 @@ def test_trace_precalc_matches_matrix_algebra(oracle, synth):
     assert np.allclose(Kt, K @ t, rtol=1e-5, atol=1e-5)
     a = np.exp(0.05 + 0.02) * 0.8 / 1.2
     assert np.allclose(aff, [a, 3.0 - a * 1.0], rtol=1e-6)
+
+
+def _window(synth, oracle, w=320, h=256, n=300, seed=6, F=5):
+    """Host keyframe 0 + F-1 other keyframes on a smooth trajectory; immature points traced through all of them."""
+    world = synth.PlaneWorld(synth.SEED + seed, fmax=22.0)
+    K4 = synth.default_intrinsics(w, h)
+    rng = np.random.RandomState(seed)
+    imgs, w2c = [], []
+    for k in range(F):
+        xi = np.array([0.05 * k, -0.02 * k, 0.012 * k, 0.003 * k, -0.004 * k, 0.0015 * k])
+        R, t = synth.se3_exp(xi)
+        img, idm = world.render(K4, R, t, w, h, aff=(0.01 * k, 0.5 * k))
+        imgs.append(img); w2c.append(synth.pose7(R, t))
+        if k == 0:
+            host_id = idm
+    u, v = synth.select_points(imgs[0], n, rng, min_grad=8.0)
+    u = u.astype(np.int32); v = v.astype(np.int32)
+    keep = (u >= 8) & (v >= 8) & (u < w - 8) & (v < h - 8)
+    return dict(w=w, h=h, K4=K4, imgs=imgs, w2c=w2c, u=u[keep], v=v[keep], host_id=host_id, F=F,
+                aff=np.array([[0.01 * k, 0.5 * k] for k in range(F)]), exposure=np.ones(F, np.float32))
+
+
+def _oracle_traced(oracle, c):
+    w, h = c["w"], c["h"]
+    dIs = [oracle.make_images(im, w, h)[0][0] for im in c["imgs"]]
+    P = oracle.ImmaturePoints(dIs[0], w, h, c["u"], c["v"])
+    c2w0 = oracle.se3_inv(c["w2c"][0])
+    for k in range(1, c["F"]):
+        KRKi, Kt, aff = oracle.trace_precalc(c["w2c"][k], c2w0, c["K4"], 1.0, 1.0, tuple(c["aff"][k]), tuple(c["aff"][0]))
+        P.trace_on(dIs[k], KRKi, Kt, aff)
+    return P, dIs, c2w0
+
+
+def test_optimize_immature_point_recovers_idepth(oracle, synth):
+    c = _window(synth, oracle)
+    P, dIs, c2w0 = _oracle_traced(oracle, c)
+    pre = [oracle.pair_precalc(c["w2c"][k], c2w0, 1.0, 1.0, tuple(c["aff"][0]), tuple(c["aff"][k])) for k in range(1, c["F"])]
+    R = np.stack([p[0] for p in pre]); t = np.stack([p[1] for p in pre]); aff = np.stack([p[2] for p in pre])
+    usable = np.isfinite(P.idepth_max) & (P.lastTraceStatus != 1)
+    P.idepth_max[~usable] = 0.5; P.idepth_min[~usable] = 0.1
+    result, idepth, res_state = oracle.immature_optimize(P, c["K4"], dIs[1:], R, t, aff, min_obs=1)
+    act = (result == 1) & usable
+    assert act.sum() > 0.6 * usable.sum()
+    true_id = c["host_id"][c["v"], c["u"]]
+    rel = np.abs(idepth[act] - true_id[act]) / true_id[act]
+    # the window's baseline is short (<= 3 px of parallax): 0.06 px of photometric precision is ~2 % of inverse depth
+    assert np.median(rel) < 0.04 and np.mean(rel < 0.15) > 0.9
+    mid = 0.5 * (P.idepth_min + P.idepth_max)
+    assert np.median(rel) <= np.median(np.abs(mid[act] - true_id[act]) / true_id[act]) * 1.05
+    assert np.all((res_state[act] == 0).sum(axis=1) >= 1)
+    assert set(np.unique(result)) <= {-1, 0, 1}

@@ -97,3 +97,36 @@ def test_trace_affine_exposure_multi_host_and_edge_states(pkg, oracle, synth, gp
     assert counts["oob"] >= int((st == 1).sum()) and sum(counts.values()) == n
     with pytest.raises(pkg.HipLibraryError):
         imm.add_points(0, 0, np.array([1]), np.array([50]))        # closer than 3 px to the border: the constructor would read outside the image
+
+
+def test_optimize_immature_point_bit_exact(pkg, oracle, synth, gpu_required):
+    """FullSystem::optimizeImmaturePoint: result code, inverse depth (bits) and per-target residual states vs the oracle, 5-keyframe
+    window with affine brightness; includes points with degenerate intervals (skip / delete outcomes)."""
+    from test_immature_cpu import _window, _oracle_traced
+    c = _window(synth, oracle, w=512, h=512, n=1200, seed=8, F=5)
+    P, dIs, c2w0 = _oracle_traced(oracle, c)
+    F = c["F"]
+    ctx = pkg.Context(c["w"], c["h"], n_slots=F)
+    for k in range(F):
+        ctx.frame_upload(k, c["imgs"][k])
+    imm = pkg.ImmaturePointsHip(ctx, capacity=4096)
+    imm.add_points(0, 0, c["u"], c["v"])
+    # same traced state on both sides (trace parity itself is covered above); a few hand-made intervals exercise the skip / delete paths
+    P.idepth_min[::17] = 0.0; P.idepth_max[::17] = 5.0
+    P.idepth_min[5::23] = 0.3; P.idepth_max[5::23] = np.nan
+    imm.set_state(P.idepth_min, P.idepth_max, P.quality, P.lastTraceStatus)
+    pre = [oracle.pair_precalc(c["w2c"][k], c2w0, 1.0, 1.0, tuple(c["aff"][0]), tuple(c["aff"][k])) for k in range(1, F)]
+    R = np.stack([p[0] for p in pre]); t = np.stack([p[1] for p in pre]); aff = np.stack([p[2] for p in pre])
+    ro, io, so = oracle.immature_optimize(P, c["K4"], dIs[1:], R, t, aff, min_obs=1)
+    rg, ig, sg = imm.optimize(list(range(F)), np.stack(c["w2c"]), c["K4"], aff=c["aff"], exposure=c["exposure"], min_obs=1)
+    assert np.array_equal(rg, ro), "%d result mismatches" % (rg != ro).sum()
+    act = ro == 1
+    assert act.sum() > 300 and (ro == 0).sum() > 0
+    assert np.array_equal(_bits(ig[act]), _bits(io[act]))
+    nz = ro != 0
+    assert np.array_equal(sg[nz][:, 1:], so[nz])
+    assert np.all(sg[:, 0] == -1)
+    # selection mask: unselected points are left alone
+    sel = np.zeros(imm.n, np.uint8); sel[::2] = 1
+    rg2, ig2, _ = imm.optimize(list(range(F)), np.stack(c["w2c"]), c["K4"], aff=c["aff"], exposure=c["exposure"], select=sel, min_obs=1)
+    assert np.array_equal(rg2[::2], ro[::2]) and np.all(rg2[1::2] == 0)
