@@ -59,6 +59,13 @@ def _sig(L):
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     c_u8 = C.POINTER(C.c_ubyte)
+    c_u8 = C.POINTER(C.c_ubyte)
+    L.dmvio_hip_initializer_create.restype = vp
+    L.dmvio_hip_initializer_create.argtypes = [vp, C.c_int]
+    L.dmvio_hip_initializer_destroy.argtypes = [vp]
+    L.dmvio_hip_initializer_set_points.argtypes = [vp, C.c_int, c_f, c_f, c_f, c_u8, c_f, c_f]
+    L.dmvio_hip_initializer_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_d, c_f, c_d, c_d, c_f, C.c_float, C.c_float, C.c_float, C.c_double, C.c_double,
+                                                        c_f, c_f, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f]
     L.dmvio_hip_immature_create.restype = vp
     L.dmvio_hip_immature_create.argtypes = [vp, C.c_int]
     L.dmvio_hip_immature_destroy.argtypes = [vp]
@@ -321,6 +328,52 @@ class CoarseTrackerHip:
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_work(self.p, C.byref(a), C.byref(b)), "last_work")
         return a.value, b.value
+
+
+class CoarseInitializerHip:
+    """Mirror of CoarseInitializer's hot function calcResAndGS (CoarseInitializer.cpp:331-624) for one pyramid level's point set."""
+
+    def __init__(self, ctx, capacity=32768):
+        self.ctx, self.L = ctx, ctx.L
+        p = self.L.dmvio_hip_initializer_create(ctx.p, capacity)
+        if not p:
+            raise HipLibraryError("dmvio_hip_initializer_create: %s" % _err(self.L))
+        self.p = C.c_void_p(p)
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_initializer_destroy(self.p); self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_points(self, pts):
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u, v, iR, en, oth = f32(pts["u"]), f32(pts["v"]), f32(pts["iR"]), f32(pts["energy"]), f32(pts["outlierTH"])
+        good = np.ascontiguousarray(pts["isGood"], dtype=np.uint8)
+        _chk(self.L, self.L.dmvio_hip_initializer_set_points(self.p, len(u), _f(u), _f(v), _f(iR), good.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(en), _f(oth)),
+             "initializer_set_points")
+        self.n = len(u)
+
+    def calcResAndGS(self, lvl, first_slot, new_slot, Ki9, fxfycxcy_lvl, refToNew7, aff_ab, idepth_new, alphaW=150 * 150, alphaK=2.5 * 2.5, couplingWeight=1.0,
+                     priorY=0.0, priorX=0.0):
+        n = self.n
+        o = dict(H=np.zeros((8, 8), np.float32), b=np.zeros(8, np.float32), Hsc=np.zeros((8, 8), np.float32), bsc=np.zeros(8, np.float32), res3=np.zeros(3, np.float32),
+                 energy_new=np.zeros((n, 2), np.float32), isGood_new=np.zeros(n, np.uint8), maxstep=np.zeros(n, np.float32), lastHessian_new=np.zeros(n, np.float32),
+                 JbBuffer_new=np.zeros((n, 10), np.float32))
+        c_u8 = C.POINTER(C.c_ubyte)
+        idn = np.ascontiguousarray(idepth_new, dtype=np.float32)
+        K = np.ascontiguousarray(fxfycxcy_lvl, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_initializer_calc_res_and_gs(self.p, lvl, first_slot, new_slot, _d(np.ascontiguousarray(Ki9, dtype=np.float64)), _f(K),
+                                                                  _d(np.ascontiguousarray(refToNew7, dtype=np.float64)), _d(np.array(aff_ab, dtype=np.float64)), _f(idn),
+                                                                  alphaW, alphaK, couplingWeight, priorY, priorX, _f(o["H"]), _f(o["b"]), _f(o["Hsc"]), _f(o["bsc"]),
+                                                                  _f(o["res3"]), _f(o["energy_new"]), o["isGood_new"].ctypes.data_as(c_u8), _f(o["maxstep"]),
+                                                                  _f(o["lastHessian_new"]), _f(o["JbBuffer_new"])), "initializer_calc_res_and_gs")
+        return o
 
 
 class ImmaturePointsHip:

@@ -215,6 +215,23 @@ int dmvio_hip_immature_optimize(dmvio_hip_immature* imm, int F, const int* frame
 int dmvio_hip_trace_new_coarse(dmvio_hip_immature* imm, int new_slot, const double new_w2c7[7], const double new_aff[2], float new_exposure, int n_hosts,
                                const double* host_c2w7, const double* host_aff2, const float* host_exposure, const double fxfycxcy[4], int counts6[6]);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Initializer: CoarseInitializer::calcResAndGS  src/dso/FullSystem/CoarseInitializer.cpp:331-624.
+ * The handle holds the point set of one pyramid level (struct Pnt, CoarseInitializer.h:44-83); every call evaluates the 8-pixel
+ * pattern of all points at (refToNew, aff) for the current idepth_new and returns the 8x8 system H_out, b_out, its Schur part
+ * H_out_sc, b_out_sc (row-major floats, Mat88f / Vec8f), res3 = (energy, alphaEnergy, num) and — for non-NULL pointers — the
+ * per-point fields calcResAndGS writes (energy_new[2n], isGood_new, maxstep, lastHessian_new, JbBuffer_new[10n]).
+ * Ki9: the level's inverse intrinsics (Mat33 Ki[lvl], row-major double); fxfycxcy_lvl: fx[lvl] .. cy[lvl]; aff_ab = (a, b) of refToNew_aff. */
+typedef struct dmvio_hip_initializer dmvio_hip_initializer;
+dmvio_hip_initializer* dmvio_hip_initializer_create(dmvio_hip_ctx* ctx, int capacity);
+void dmvio_hip_initializer_destroy(dmvio_hip_initializer* ini);
+int dmvio_hip_initializer_set_points(dmvio_hip_initializer* ini, int n, const float* u, const float* v, const float* iR, const unsigned char* isGood,
+                                     const float* energy2, const float* outlierTH);
+int dmvio_hip_initializer_calc_res_and_gs(dmvio_hip_initializer* ini, int lvl, int first_slot, int new_slot, const double Ki9[9], const float fxfycxcy_lvl[4],
+                                          const double refToNew7[7], const double aff_ab[2], const float* idepth_new, float alphaW, float alphaK,
+                                          float couplingWeight, double priorY, double priorX, float* H_out64, float* b_out8, float* H_sc64, float* b_sc8,
+                                          float res3[3], float* energy_new2, unsigned char* isGood_new, float* maxstep, float* lastHessian_new, float* JbBuffer_new10);
+
 #ifdef __cplusplus
 }
 #endif

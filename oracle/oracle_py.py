@@ -58,6 +58,10 @@ def lib():
         L.orc_immature_init.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_i, c_i, c_f, c_f, c_f, c_f]
         L.orc_immature_trace.argtypes = [c_f, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i]
         L.orc_trace_precalc.argtypes = [c_d, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
+        c_u8 = C.POINTER(C.c_ubyte)
+        L.orc_init_calc_res_and_gs.argtypes = [c_f, c_f, C.c_int, C.c_int, c_d, C.c_float, C.c_float, C.c_float, C.c_float, c_d, C.c_double, C.c_double, C.c_int,
+                                               c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_float, C.c_float, C.c_float, C.c_double, C.c_double,
+                                               c_f, c_f, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f]
         L.orc_pair_precalc.argtypes = [c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
         L.orc_immature_optimize.argtypes = [C.c_int, C.c_int, c_f, C.c_int, C.POINTER(c_f), c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int,
                                             c_i, c_f, c_i]
@@ -154,6 +158,26 @@ class ImmaturePoints:
                                  _f(np.ascontiguousarray(aff2, dtype=np.float32)), _f(self.idepth_min), _f(self.idepth_max), _f(self.quality), _f(self.lastTraceUV),
                                  _f(self.lastTracePixelInterval), self.lastTraceStatus.ctypes.data_as(c_i))
         return self.lastTraceStatus
+
+
+def init_calc_res_and_gs(dI_ref, dI_new, wl, hl, Ki9, fxfycxcy_lvl, refToNew7, aff_ab, pts, idepth_new, alphaW=150 * 150, alphaK=2.5 * 2.5,
+                         couplingWeight=1.0, priorY=0.0, priorX=0.0):
+    """CoarseInitializer::calcResAndGS; pts = dict(u, v, iR, isGood, energy[n,2], outlierTH).  Returns a dict of all outputs."""
+    n = len(pts["u"])
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    u, v, iR, en, oth, idn = f32(pts["u"]), f32(pts["v"]), f32(pts["iR"]), f32(pts["energy"]), f32(pts["outlierTH"]), f32(idepth_new)
+    good = np.ascontiguousarray(pts["isGood"], dtype=np.uint8)
+    o = dict(H=np.zeros((8, 8), np.float32), b=np.zeros(8, np.float32), Hsc=np.zeros((8, 8), np.float32), bsc=np.zeros(8, np.float32), res3=np.zeros(3, np.float32),
+             energy_new=np.zeros((n, 2), np.float32), isGood_new=np.zeros(n, np.uint8), maxstep=np.zeros(n, np.float32), lastHessian_new=np.zeros(n, np.float32),
+             JbBuffer_new=np.zeros((n, 10), np.float32))
+    c_u8 = C.POINTER(C.c_ubyte)
+    K = f32(fxfycxcy_lvl)
+    lib().orc_init_calc_res_and_gs(_f(f32(dI_ref)), _f(f32(dI_new)), wl, hl, _d(np.ascontiguousarray(Ki9, dtype=np.float64)), float(K[0]), float(K[1]), float(K[2]), float(K[3]),
+                                   _d(np.ascontiguousarray(refToNew7, dtype=np.float64)), float(aff_ab[0]), float(aff_ab[1]), n, _f(u), _f(v), _f(idn), _f(iR),
+                                   good.ctypes.data_as(c_u8), _f(en), _f(oth), alphaW, alphaK, couplingWeight, priorY, priorX, _f(o["H"]), _f(o["b"]), _f(o["Hsc"]),
+                                   _f(o["bsc"]), _f(o["res3"]), _f(o["energy_new"]), o["isGood_new"].ctypes.data_as(c_u8), _f(o["maxstep"]), _f(o["lastHessian_new"]),
+                                   _f(o["JbBuffer_new"]))
+    return o
 
 
 def pair_precalc(target_w2c7, host_c2w7, host_exposure=1.0, target_exposure=1.0, host_aff=(0.0, 0.0), target_aff=(0.0, 0.0)):

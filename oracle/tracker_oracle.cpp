@@ -24,6 +24,7 @@
 #include <vector>
 #include <emmintrin.h>
 #include "lie.h"
+#include "acc9.h"
 #include "dense.h"
 
 namespace orc {
@@ -56,54 +57,6 @@ static inline V3f interp33(const V3f* mat, float x, float y, int width) {
 }
 
 // Accumulator9: 45 upper-triangular sums x 4 SSE lanes, hierarchical 1k/1M shift-up.
-struct Acc9 {
-  alignas(16) float SSEData[4 * 45];
-  alignas(16) float SSEData1k[4 * 45];
-  alignas(16) float SSEData1m[4 * 45];
-  float numIn1, numIn1k, numIn1m;
-  size_t num;
-  float H[9][9];
-  void initialize() {
-    memset(SSEData, 0, sizeof(SSEData)); memset(SSEData1k, 0, sizeof(SSEData1k)); memset(SSEData1m, 0, sizeof(SSEData1m));
-    num = 0; numIn1 = numIn1k = numIn1m = 0; memset(H, 0, sizeof(H));
-  }
-  void shiftUp(bool force) {
-    if (numIn1 > 1000 || force) {
-      for (int i = 0; i < 45; i++)
-        _mm_store_ps(SSEData1k + 4 * i, _mm_add_ps(_mm_load_ps(SSEData + 4 * i), _mm_load_ps(SSEData1k + 4 * i)));
-      numIn1k += numIn1; numIn1 = 0; memset(SSEData, 0, sizeof(SSEData));
-    }
-    if (numIn1k > 1000 || force) {
-      for (int i = 0; i < 45; i++)
-        _mm_store_ps(SSEData1m + 4 * i, _mm_add_ps(_mm_load_ps(SSEData1k + 4 * i), _mm_load_ps(SSEData1m + 4 * i)));
-      numIn1m += numIn1k; numIn1k = 0; memset(SSEData1k, 0, sizeof(SSEData1k));
-    }
-  }
-  inline void updateSSE_eighted(const __m128 J[9], const __m128 w) {
-    float* pt = SSEData;
-    for (int r = 0; r < 9; r++) {
-      __m128 Jrw = _mm_mul_ps(J[r], w);
-      for (int c = r; c < 9; c++) {
-        _mm_store_ps(pt, _mm_add_ps(_mm_load_ps(pt), _mm_mul_ps(Jrw, J[c])));
-        pt += 4;
-      }
-    }
-    num += 4; numIn1++;
-    shiftUp(false);
-  }
-  void finish() {
-    memset(H, 0, sizeof(H));
-    shiftUp(true);
-    int idx = 0;
-    for (int r = 0; r < 9; r++)
-      for (int c = r; c < 9; c++) {
-        float d = SSEData1m[idx + 0] + SSEData1m[idx + 1] + SSEData1m[idx + 2] + SSEData1m[idx + 3];
-        H[r][c] = H[c][r] = d;
-        idx += 4;
-      }
-  }
-};
-
 struct OrcTracker {
   int w[PYR_LEVELS], h[PYR_LEVELS], levels;
   float fx[PYR_LEVELS], fy[PYR_LEVELS], cx[PYR_LEVELS], cy[PYR_LEVELS];
