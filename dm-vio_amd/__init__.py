@@ -78,6 +78,8 @@ def _sig(L):
     L.dmvio_hip_immature_trace.argtypes = [vp, C.c_int, C.c_int, c_f, c_f, c_f]
     L.dmvio_hip_immature_optimize.argtypes = [vp, C.c_int, c_i, c_d, c_d, c_f, c_d, C.c_char_p, C.c_int, c_i, c_f, c_i]
     L.dmvio_hip_trace_new_coarse.argtypes = [vp, C.c_int, c_d, c_d, C.c_float, C.c_int, c_d, c_d, c_f, c_d, c_i]
+    L.dmvio_hip_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.dmvio_hip_ba_marginalize_points.argtypes = [vp, C.c_char_p, C.POINTER(C.c_ubyte), c_d, c_d, c_i, C.c_int]
     L.dmvio_hip_ba_create.restype = vp
     L.dmvio_hip_ba_create.argtypes = [vp]
     L.dmvio_hip_ba_destroy.argtypes = [vp]
@@ -501,6 +503,18 @@ class BundleAdjusterHip:
     def set_marg_prior(self, HM, bM):
         HM = np.ascontiguousarray(HM, dtype=np.float64); bM = np.ascontiguousarray(bM, dtype=np.float64)
         _chk(self.L, self.L.dmvio_hip_ba_set_marg_prior(self.p, _d(HM), _d(bM)), "ba_set_marg_prior")
+
+    def set_frame_state(self, k, state10):
+        _chk(self.L, self.L.dmvio_hip_ba_set_frame_state(self.p, k, _d(np.ascontiguousarray(state10, dtype=np.float64))), "ba_set_frame_state")
+
+    def marginalize_points(self, candidates, update_prior=False):
+        """flagPointsForRemoval's relinearisation + EnergyFunctional::marginalizePointsF: (decision[N], Hadd, badd, resInM)."""
+        n = self.n
+        cand = np.ascontiguousarray(candidates, dtype=np.uint8)
+        dec = np.zeros(self.N, np.uint8); H = np.zeros((n, n)); b = np.zeros(n); r = C.c_int(0)
+        _chk(self.L, self.L.dmvio_hip_ba_marginalize_points(self.p, cand.tobytes(), dec.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(H), _d(b), C.byref(r),
+                                                             1 if update_prior else 0), "ba_marginalize_points")
+        return dec, H, b, r.value
 
     def set_graph(self, host, u, v, idepth, color, weights, hasDepthPrior, res_point, res_target):
         self.N = len(u); self.R = len(res_point)

@@ -248,6 +248,21 @@ struct BAHost {
     if (iteration >= 2) orthogonalize(x);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:81)
     lastX = x;
   }
+  // adHTdeltaF of EnergyFunctional::setDeltaF (EnergyFunctional.cpp:175-198): F*F x 8, index h + F*t
+  void adHTdeltaF(std::vector<float>& out) const {
+    out.assign((size_t)F * F * 8, 0.f);
+    for (int hh = 0; hh < F; hh++)
+      for (int t = 0; t < F; t++) {
+        const size_t idx = (size_t)hh + (size_t)t * F;
+        float dh[8], dt[8];
+        for (int i = 0; i < 8; i++) { dh[i] = (float)(fr[hh].state[i] - fr[hh].state_zero[i]); dt[i] = (float)(fr[t].state[i] - fr[t].state_zero[i]); }
+        for (int c = 0; c < 8; c++) {
+          float s1 = 0, s2 = 0;
+          for (int r = 0; r < 8; r++) { s1 += dh[r] * adHostF[idx * 64 + r * 8 + c]; s2 += dt[r] * adTargetF[idx * 64 + r * 8 + c]; }
+          out[idx * 8 + c] = s1 + s2;
+        }
+      }
+  }
   // xc (4) and xAd (F*F x 8, index h*F + t) of resubstituteF_MT; frame / calib steps
   void prepareResubstitute(const std::vector<double>& x, float xc[4], std::vector<float>& xAd) {
     const int nn = n();

@@ -71,6 +71,7 @@ struct BAPoints {   // SoA, N entries
   const float* priorF;
   const int* res_begin;  // N+1: residuals of point p are [res_begin[p], res_begin[p+1])
   float *Hdd, *bd, *Hcd, *HdiF, *bdSumF;  // accumulated per point (Hcd: N x 4)
+  float* idepth_hessian;                  // PointHessian::idepth_hessian (AccumulatedSCHessian.cpp:42,50)
 };
 
 struct BARes {      // SoA, R entries
@@ -85,12 +86,16 @@ __constant__ int c_patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}
 
 // ------------------------------------------------------------------------------------------------ linearize
 __global__ void __launch_bounds__(128) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
-                                                       const FrameStore fs, double* __restrict__ energy_partials, float* __restrict__ fullJ) {
+                                                       const FrameStore fs, double* __restrict__ energy_partials, float* __restrict__ fullJ,
+                                                       const unsigned char* __restrict__ pt_mask) {
+  // pt_mask != NULL: only the residuals of the flagged points, after PointFrameResidual::resetOOB (Residuals.h:82-89) — the
+  // relinearisation FullSystem::flagPointsForRemoval performs before a point is marginalised (FullSystem.cpp:836-849)
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   double myE = 0.0;
-  if (ri < W.R) {
+  if (ri < W.R && (!pt_mask || pt_mask[Rs.point[ri]])) {
     float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
     Rs.newEnergyWO[ri] = -1.0f;
+    if (pt_mask) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
     const int state = Rs.state[ri];
     bool done = false;
     if (state == BA_OOB) { Rs.newState[ri] = BA_OOB; myE = Rs.energy[ri]; done = true; }
@@ -224,9 +229,10 @@ __global__ void __launch_bounds__(128) k_ba_linearize(const BAWindow W, const BA
 }
 
 // applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector
-__global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs) {
+__global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, const unsigned char* __restrict__ pt_mask) {
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= R) return;
+  if (pt_mask && !pt_mask[Rs.point[ri]]) return;
   if (Rs.state[ri] == BA_OOB) return;  // can never go back from OOB
   const int ns = Rs.newState[ri];
   if (ns == BA_IN) { Rs.active[ri] = 1; Rs.which[ri] ^= 1; }
@@ -255,12 +261,87 @@ __global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const B
   P.Hdd[pi] = Hdd; P.bd[pi] = bd;
 #pragma unroll
   for (int k = 0; k < 4; k++) P.Hcd[4 * pi + k] = Hcd[k];
-  if (ngood == 0) { P.HdiF[pi] = 0; P.bdSumF[pi] = 0; return; }
+  if (ngood == 0) { P.HdiF[pi] = 0; P.bdSumF[pi] = 0; P.idepth_hessian[pi] = 0; return; }
   float H = Hdd + 0.0f + P.priorF[pi];
   if (H < 1e-10) H = 1e-10;
+  P.idepth_hessian[pi] = H;
   P.HdiF[pi] = 1.0 / H;
   const float deltaF = P.idepth[pi] - P.idepth_zero[pi];
   P.bdSumF[pi] = (bd + 0.0f) + P.priorF[pi] * deltaF;  // shiftPriorToZero = true
+}
+
+// ------------------------------------------------------------------------------------------------ point marginalisation
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:76-106) for the active residuals of the points to marginalise, and the
+// record AccumulatedTopHessianSSE::addPoint<2> consumes: identical to the applied record except that the inner products with the
+// residual use res_toZeroF (AccumulatedTopHessian.cpp:70-71,103-113,131).  fullJ: the 74-float RawResidualJacobian of the applied
+// linearisation ([0,8) resF, [8,20) Jpdxi, [20,28) Jpdc, 28-29 Jpdd, [30,46) JIdx, [46,62) JabF).
+__global__ void __launch_bounds__(256) k_ba_fix_linearization(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ fullJ,
+                                                               const unsigned char* __restrict__ decision, const float* __restrict__ adHTdeltaF /* F*F x 8, h + F*t */,
+                                                               const float4 cDeltaF, float* __restrict__ margRec, unsigned char* __restrict__ margActive,
+                                                               float* __restrict__ res_toZeroF /* R x 8 or NULL */) {
+  const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= W.R) return;
+  const int pi = Rs.point[ri];
+  const bool on = decision[pi] == 1 && Rs.active[ri] != 0;
+  margActive[ri] = on ? 1 : 0;
+  if (!on) return;
+  const float* __restrict__ J = fullJ + (size_t)ri * 74;
+  const float* __restrict__ dp = adHTdeltaF + (size_t)(P.host[pi] + W.F * Rs.target[ri]) * 8;
+  const float dd = P.idepth[pi] - P.idepth_zero[pi];
+  const float cd[4] = {cDeltaF.x, cDeltaF.y, cDeltaF.z, cDeltaF.w};
+  float sx = 0, sy = 0, cx = 0, cy = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { sx += J[8 + i] * dp[i]; sy += J[14 + i] * dp[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { cx += J[20 + i] * cd[i]; cy += J[24 + i] * cd[i]; }
+  const float Jp_delta_x = sx + cx + J[28] * dd, Jp_delta_y = sy + cy + J[29] * dd;
+  float JIr0 = 0, JIr1 = 0, Jar0 = 0, Jar1 = 0, rr = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float rtz = J[i];
+    rtz = rtz - J[30 + i] * Jp_delta_x; rtz = rtz - J[38 + i] * Jp_delta_y;
+    rtz = rtz - J[46 + i] * dp[6]; rtz = rtz - J[54 + i] * dp[7];
+    if (res_toZeroF) res_toZeroF[(size_t)ri * 8 + i] = rtz;
+    JIr0 += rtz * J[30 + i]; JIr1 += rtz * J[38 + i]; Jar0 += rtz * J[46 + i]; Jar1 += rtz * J[54 + i]; rr += rtz * rtz;
+  }
+  const float* __restrict__ src = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
+  float* __restrict__ dst = margRec + (size_t)ri * REC_FLOATS;
+  for (int k = 0; k < REC_FLOATS; k++) dst[k] = src[k];
+  dst[REC_JI_R + 0] = JIr0; dst[REC_JI_R + 1] = JIr1; dst[REC_JAB_R + 0] = Jar0; dst[REC_JAB_R + 1] = Jar1; dst[REC_RR] = rr;
+  dst[REC_BD] = JIr0 * J[28] + JIr1 * J[29];
+}
+// decision of flagPointsForRemoval for the candidates: marginalise (1) if idepth_hessian > setting_minIdepthH_marg, else drop (2)
+__global__ void __launch_bounds__(256) k_ba_marg_decide(const int N, const unsigned char* __restrict__ cand, const float* __restrict__ idepth_hessian,
+                                                         const float minIdepthH_marg, unsigned char* __restrict__ decision) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi < N) decision[pi] = cand[pi] ? (idepth_hessian[pi] > minIdepthH_marg ? 1 : 2) : 0;
+}
+// addPoint<2>'s per-point sums (Hdd_accLF, bd_accLF, Hcd_accLF; accAF = 0) and the head of AccumulatedSCHessianSSE::addPoint(p, false)
+// with priorF * setting_idepthFixPriorMargFac; points that are not marginalised get HdiF = 0 (skipped by every accumulator)
+__global__ void __launch_bounds__(256) k_ba_marg_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ margRec,
+                                                             const unsigned char* __restrict__ margActive, const unsigned char* __restrict__ decision,
+                                                             const float priorMargFac, float* __restrict__ HdiF, float* __restrict__ bdSumF, float* __restrict__ Hcd4) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= W.N) return;
+  float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
+  int ngood = 0;
+  if (decision[pi] == 1)
+    for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) {
+      if (!margActive[ri]) continue;
+      const float* __restrict__ rec = margRec + (size_t)ri * REC_FLOATS;
+      bd += rec[REC_BD];
+      Hdd += rec[REC_HDD];
+#pragma unroll
+      for (int k = 0; k < 4; k++) Hcd[k] += rec[REC_HCD + k];
+      ngood++;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; k++) Hcd4[4 * pi + k] = 0.0f + Hcd[k];
+  if (ngood == 0) { HdiF[pi] = 0; bdSumF[pi] = 0; return; }
+  float H = Hdd + 0.0f + P.priorF[pi] * priorMargFac;
+  if (H < 1e-10) H = 1e-10;
+  HdiF[pi] = 1.0 / H;
+  bdSumF[pi] = 0.0f + bd;   // shiftPriorToZero = false
 }
 
 // hierarchical fp32 accumulator of the reference (Data / Data1k / Data1m + numIn1 counters), one value per thread

@@ -56,6 +56,9 @@ struct dmvio_hip_ba {
   double final_energy = 0;
   BATimes tm;
   bool timing = false;
+  // point marginalisation scratch (dmvio_hip_ba_marginalize_points)
+  unsigned char *d_cand = nullptr, *d_decision = nullptr, *d_margActive = nullptr;
+  float *d_mHdiF = nullptr, *d_mbdSumF = nullptr, *d_mHcd = nullptr, *d_margRec = nullptr, *d_adHTdelta = nullptr;
   long long* d_accTicks = nullptr;   // per-block stamps of k_ba_accumulate (timing mode only)
   int accTicksBlocks = 0;
 };
@@ -107,8 +110,8 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b)) return r;  // precalc + frameEnergyTH of the current state
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, c->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ);
-  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, c->stream, H.R, b->Rs);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, c->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
+  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, c->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(b->h_newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * H.R, hipMemcpyDeviceToHost, c->stream));
@@ -124,17 +127,22 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   return 0;
 }
 static int applyRes(dmvio_hip_ba* b) {
-  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->ctx->stream, b->H.R, b->Rs);
+  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->ctx->stream, b->H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
+static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P);
 static int accumulate(dmvio_hip_ba* b) {
+  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->ctx->stream, b->W, b->P, b->Rs);
+  return accumulateViews(b, b->Rs, b->P);
+}
+// the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
+static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   const int F = H.F, F2 = F * F, n = H.n();
   hipStream_t s = c->stream;
-  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, s, b->W, b->P, b->Rs);
   {
     AccumArgs A;
     A.F = F; A.N = H.N; A.nsTop = b->nsTop; A.nsD = b->nsD; A.nsC = b->nsC;
@@ -146,7 +154,7 @@ static int accumulate(dmvio_hip_ba* b) {
       if (b->accTicksBlocks != nblk) { if (b->d_accTicks) hipFree(b->d_accTicks); HIPCHK(hipMalloc((void**)&b->d_accTicks, sizeof(long long) * 2 * nblk)); b->accTicksBlocks = nblk; }
       A.ticks = b->d_accTicks;
     }
-    hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, b->Rs, b->P);
+    hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV);
   }
   hipLaunchKernelGGL(k_ba_stitch_top, dim3(F), dim3(64), 0, s, F, b->nsTop, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
   hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2), dim3(64), 0, s, F, b->nsD, b->nsTop, b->d_accD, b->d_numD, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
@@ -269,6 +277,50 @@ int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double*
   return 0;
 }
 
+// FullSystem::flagPointsForRemoval's relinearisation (FullSystem.cpp:829-859) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742)
+int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM, int update_prior) {
+  if (!b || !b->graph_ready) return failmsg("ba_marginalize_points: window / graph not set");
+  if (!candidates || !decision) return failmsg("ba_marginalize_points: null argument");
+  dmvio_hip_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  std::lock_guard<std::mutex> lk(c->mu);
+  BAHost& H = b->H;
+  const int N = H.N, R = H.R, n = H.n();
+  hipStream_t s = c->stream;
+  const float setting_minIdepthH_marg = 50, setting_idepthFixPriorMargFac = 600 * 600;
+  const double setting_margWeightFac = 0.5 * 0.5;
+  // deltas at the current state (EnergyFunctional::setDeltaF, EnergyFunctional.cpp:175-198)
+  std::vector<float> adHT;
+  H.adHTdeltaF(adHT);
+  HIPCHK(hipMemcpyAsync(b->d_cand, candidates, N, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));   // adHT is local
+  if (int r = uploadWindowTables(b)) return r;
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
+  hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand);
+  hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
+  const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
+  hipLaunchKernelGGL(k_ba_fix_linearization, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, b->d_fullJ, b->d_decision, b->d_adHTdelta, cd, b->d_margRec,
+                     b->d_margActive, (float*)nullptr);
+  hipLaunchKernelGGL(k_ba_marg_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, s, b->W, b->P, b->Rs, b->d_margRec, b->d_margActive, b->d_decision,
+                     setting_idepthFixPriorMargFac, b->d_mHdiF, b->d_mbdSumF, b->d_mHcd);
+  HIPCHK(hipGetLastError());
+  BARes RsV = b->Rs; RsV.rec[0] = RsV.rec[1] = b->d_margRec; RsV.active = b->d_margActive;
+  BAPoints PV = b->P; PV.HdiF = b->d_mHdiF; PV.bdSumF = b->d_mbdSumF; PV.Hcd = b->d_mHcd;
+  const int resInA_keep = H.resInA;
+  if (int r = accumulateViews(b, RsV, PV)) return r;
+  const int nres = H.resInA;
+  H.resInA = resInA_keep;
+  HIPCHK(hipMemcpyAsync(decision, b->d_decision, N, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const double* M = b->h_sys; const double* Mb = M + (size_t)n * n; const double* Msc = Mb + n; const double* Mbsc = Msc + (size_t)n * n;
+  if (H.HM.size() != (size_t)n * n) { H.HM.assign((size_t)n * n, 0.0); H.bM.assign(n, 0.0); }
+  for (size_t k = 0; k < (size_t)n * n; k++) { const double v = setting_margWeightFac * (M[k] - Msc[k]); if (Hadd) Hadd[k] = v; if (update_prior) H.HM[k] += v; }
+  for (int k = 0; k < n; k++) { const double v = setting_margWeightFac * (Mb[k] - Mbsc[k]); if (badd) badd[k] = v; if (update_prior) H.bM[k] += v; }
+  if (resInM) *resInM = nres;
+  return 0;
+}
+
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
   if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
@@ -322,7 +374,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &d_color, (size_t)N * 8) || dalloc(b, &d_weights, (size_t)N * 8) || dalloc(b, &d_prior, N)) return -1;
   BAPoints& P = b->P; BARes& Rs = b->Rs;
   if (dalloc(b, &P.idepth, N) || dalloc(b, &P.idepth_zero, N) || dalloc(b, &P.idepth_backup, N) || dalloc(b, &P.step, N) || dalloc(b, &P.Hdd, N) || dalloc(b, &P.bd, N) ||
-      dalloc(b, &P.Hcd, (size_t)N * 4) || dalloc(b, &P.HdiF, N) || dalloc(b, &P.bdSumF, N)) return -1;
+      dalloc(b, &P.Hcd, (size_t)N * 4) || dalloc(b, &P.HdiF, N) || dalloc(b, &P.bdSumF, N) || dalloc(b, &P.idepth_hessian, N) ||
+      dalloc(b, &b->d_cand, N) || dalloc(b, &b->d_decision, N) || dalloc(b, &b->d_mHdiF, N) || dalloc(b, &b->d_mbdSumF, N) || dalloc(b, &b->d_mHcd, (size_t)N * 4) ||
+      dalloc(b, &b->d_margRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_margActive, R) || dalloc(b, &b->d_adHTdelta, (size_t)F2 * 8)) return -1;
   if (dalloc(b, &Rs.state, R) || dalloc(b, &Rs.newState, R) || dalloc(b, &Rs.active, R) || dalloc(b, &Rs.which, R) || dalloc(b, &Rs.energy, R) || dalloc(b, &Rs.newEnergy, R) ||
       dalloc(b, &Rs.newEnergyWO, R) || dalloc(b, &Rs.center, (size_t)R * 3) || dalloc(b, &Rs.rec[0], (size_t)R * REC_FLOATS) || dalloc(b, &Rs.rec[1], (size_t)R * REC_FLOATS)) return -1;
   P.host = d_host; P.u = d_u; P.v = d_v; P.color = d_color; P.weights = d_weights; P.priorF = d_prior; P.res_begin = d_res_begin;
@@ -478,6 +532,14 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double a
   if (pose7_w2c) poseTo7(fr.w2c, pose7_w2c);
   if (aff) { aff[0] = fr.state_scaled[6]; aff[1] = fr.state_scaled[7]; }
   if (state10) memcpy(state10, fr.state, sizeof(double) * 10);
+  return 0;
+}
+// FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
+int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
+  if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  BAHost::frameSetState(b->H.fr[f], state10);
+  b->H.setPrecalcValues();
   return 0;
 }
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {

@@ -134,6 +134,18 @@ int dmvio_hip_ba_set_window(dmvio_hip_ba* ba, int F, const int* slots, const dou
                             const int* frameIDs, const double fxfycxcy[4]);
 /* Marginalisation prior HM (n x n row-major), bM (n), n = 4 + 8F (EnergyFunctional.h:129-131); zero when never called. */
 int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* ba, const double* HM, const double* bM);
+/* FrameHessian::setState (HessianBlocks.h:179-199): state10 = [xi (6, left increment on the evaluation point) | a, b | 0, 0] in the
+ * reference's unscaled units, followed by FullSystem::setPrecalcValues (FullSystem.cpp:1670-1680). */
+int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* ba, int frame, const double state10[10]);
+/* Point marginalisation: the relinearisation branch of FullSystem::flagPointsForRemoval (FullSystem.cpp:829-859: resetOOB, linearize,
+ * applyRes, EFResidual::fixLinearizationF EnergyFunctionalStructs.cpp:76-106) for the points with candidates[i] != 0, the
+ * marginalise-or-drop decision (idepth_hessian > setting_minIdepthH_marg), then EnergyFunctional::marginalizePointsF
+ * (EnergyFunctional.cpp:678-742): AccumulatedTopHessianSSE::addPoint<2> + AccumulatedSCHessianSSE::addPoint(p, false) over the
+ * marginalised points, stitched.  decision[i]: 0 untouched, 1 marginalised, 2 dropped.  Hadd / badd (may be NULL) = the increment
+ * setting_margWeightFac * (M - Msc) of HM / bM; with update_prior != 0 it is also added to the handle's marginalisation prior.
+ * The caller then rebuilds the graph without the decided points (dmvio_hip_ba_set_graph), as the reference's removePoint does. */
+int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* ba, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM,
+                                    int update_prior);
 /* Flattened point / residual graph (EnergyFunctional::makeIDX, EnergyFunctional.cpp:997-1017): point p is hosted in frame host[p],
  * has PointHessian::u, v, idepth, color[8], weights[8] (HessianBlocks.h:419-436) and hasDepthPrior; residual r observes point
  * res_point[r] in frame res_target[r].  Residuals must be sorted by point (points in allPoints order). */

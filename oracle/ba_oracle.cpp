@@ -575,11 +575,13 @@ struct OWindow {
       if (r.dropped) continue;
       if (mode == 0) { if (r.isLinearized || !r.isActive) continue; }
       if (mode == 1) { if (!r.isLinearized || !r.isActive) continue; }
+      if (mode == 2) { if (!r.isActive) continue; }   // marginalisation: every active residual, all linearised (asserted in the reference)
       const RawJ& rJ = r.Jef;
       const int htIDX = r.host + r.target * nF;
       const float* dp = &adHTdeltaF[(size_t)htIDX * 8];
       float resApprox[8];
       if (mode == 0) for (int i = 0; i < 8; i++) resApprox[i] = rJ.resF[i];
+      if (mode == 2) for (int i = 0; i < 8; i++) resApprox[i] = r.res_toZeroF[i];
       if (mode == 1) {
         float jx = rJ.Jpdd[0] * dd, jy = rJ.Jpdd[1] * dd;
         float sx = 0, sy = 0;
@@ -612,7 +614,68 @@ struct OWindow {
       nres++;
     }
     if (mode == 0) { p.Hdd_accAF = Hdd_acc; p.bd_accAF = bd_acc; for (int i = 0; i < 4; i++) p.Hcd_accAF[i] = Hcd_acc[i]; }
-    if (mode == 1) { p.Hdd_accLF = Hdd_acc; p.bd_accLF = bd_acc; for (int i = 0; i < 4; i++) p.Hcd_accLF[i] = Hcd_acc[i]; }
+    if (mode == 1 || mode == 2) { p.Hdd_accLF = Hdd_acc; p.bd_accLF = bd_acc; for (int i = 0; i < 4; i++) p.Hcd_accLF[i] = Hcd_acc[i]; }
+    if (mode == 2) { p.Hdd_accAF = 0; p.bd_accAF = 0; for (int i = 0; i < 4; i++) p.Hcd_accAF[i] = 0; }
+  }
+
+  // EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:76-106): res_toZeroF = resF - [JI*Jp Ja] * delta
+  void fixLinearizationF(ORes& r) {
+    const RawJ& J = r.Jef;
+    const float* dp = &adHTdeltaF[(size_t)(r.host + nF * r.target) * 8];
+    const float dd = points[r.point].deltaF;
+    float sx = 0, sy = 0, cx = 0, cy = 0;
+    for (int i = 0; i < 6; i++) { sx += J.Jpdxi[0][i] * dp[i]; sy += J.Jpdxi[1][i] * dp[i]; }
+    for (int i = 0; i < 4; i++) { cx += J.Jpdc[0][i] * cDeltaF[i]; cy += J.Jpdc[1][i] * cDeltaF[i]; }
+    const float Jp_delta_x = sx + cx + J.Jpdd[0] * dd, Jp_delta_y = sy + cy + J.Jpdd[1] * dd;
+    for (int i = 0; i < 8; i++) {
+      float rtz = J.resF[i];
+      rtz = rtz - J.JIdx[0][i] * Jp_delta_x; rtz = rtz - J.JIdx[1][i] * Jp_delta_y;
+      rtz = rtz - J.JabF[0][i] * dp[6]; rtz = rtz - J.JabF[1][i] * dp[7];
+      r.res_toZeroF[i] = rtz;
+    }
+    r.isLinearized = true;
+  }
+
+  // FullSystem::flagPointsForRemoval's relinearisation branch (FullSystem.cpp:829-859) for the candidate points, then
+  // EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742).  decision[i]: 0 untouched, 1 marginalised, 2 dropped.
+  // Hadd / badd = setting_margWeightFac * (M - Msc), the increment of HM / bM.
+  int marginalizePoints(const unsigned char* cand, unsigned char* decision, Mat& Hadd, Mat& badd) {
+    const float setting_minIdepthH_marg = 50, setting_idepthFixPriorMargFac = 600 * 600, setting_margWeightFac = 0.5 * 0.5;
+    for (size_t i = 0; i < points.size(); i++) {
+      decision[i] = 0;
+      if (!cand[i]) continue;
+      OPoint& p = points[i];
+      for (int ri : p.residuals) {
+        ORes& r = res[ri];
+        if (r.dropped) continue;
+        r.state_NewEnergy = r.state_energy = 0; r.state_NewState = RS_OUTLIER; r.state_state = RS_IN;   // resetOOB
+        linearizeRes(r);
+        r.isLinearized = false;
+        applyRes(r);
+        if (r.isActive) fixLinearizationF(r);
+      }
+      decision[i] = (p.idepth_hessian > setting_minIdepthH_marg) ? 1 : 2;
+    }
+    std::vector<std::vector<AccApprox>> accs(1, std::vector<AccApprox>((size_t)nF * nF));
+    for (auto& x : accs[0]) x.initialize();
+    std::vector<SCAcc> As(1);
+    As[0].init(nF);
+    int nres = 0;
+    for (size_t i = 0; i < points.size(); i++) {
+      if (decision[i] != 1) continue;
+      OPoint& p = points[i];
+      p.priorF *= setting_idepthFixPriorMargFac;
+      topAddPoint(2, p, accs[0], nres);
+      scAddPoint(p, false, As[0]);
+    }
+    Mat M, Mb, Msc, Mbsc;
+    topStitch(accs, M, Mb, false);
+    scStitch(As, Msc, Mbsc);
+    const int n = nF * 8 + CPARS;
+    Hadd.assign((size_t)n * n, 0); badd.assign(n, 0);
+    for (size_t k = 0; k < Hadd.size(); k++) Hadd[k] = setting_margWeightFac * (M[k] - Msc[k]);
+    for (int k = 0; k < n; k++) badd[k] = setting_margWeightFac * (Mb[k] - Mbsc[k]);
+    return nres;
   }
   static inline void blkMulAdd(Mat& H, int n, int r0, int c0, const double* A, const double* B, const double* Ct, int inner = 8) {
     // H[r0.., c0..] (8x8) += A(8x8) * B(8x8) * Ct^T, all row-major 8x8
@@ -1075,6 +1138,11 @@ void orc_ba_perturb_frame(void* p, int fidx, const double dstate8[8]) {
   st[6] += dstate8[6] * SCALE_A_INVERSE; st[7] += dstate8[7] * SCALE_B_INVERSE;
   OWindow::frameSetState(f, st);
 }
+void orc_ba_set_frame_state(void* p, int fidx, const double state10[10]) {
+  OWindow* W = (OWindow*)p;
+  OWindow::frameSetState(W->frames[fidx], state10);
+  W->setPrecalcValues();
+}
 int orc_ba_add_point(void* p, int host, float u, float v, float idepth, const float color[8], const float weights[8], int hasDepthPrior) {
   OWindow* W = (OWindow*)p;
   OPoint q; q.host = host; q.u = u; q.v = v;
@@ -1103,6 +1171,13 @@ void orc_ba_finalize(void* p) {
   W->setAdjointsF();
   W->setPrecalcValues();
   for (auto& f : W->frames) W->frameTakeData(f);
+}
+int orc_ba_marginalize_points(void* p, const unsigned char* cand, unsigned char* decision, double* Hadd, double* badd) {
+  OWindow* W = (OWindow*)p;
+  Mat H, b;
+  const int nres = W->marginalizePoints(cand, decision, H, b);
+  memcpy(Hadd, H.data(), sizeof(double) * H.size()); memcpy(badd, b.data(), sizeof(double) * b.size());
+  return nres;
 }
 void orc_ba_set_marg_prior(void* p, const double* HM, const double* bM) {
   OWindow* W = (OWindow*)p; const int n = CPARS + W->nF * 8;

@@ -308,10 +308,12 @@ def _ba_sig(L):
     L.orc_ba_set_threads.argtypes = [vp, C.c_int]
     L.orc_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
     L.orc_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
+    L.orc_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
     L.orc_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int]
     L.orc_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
     L.orc_ba_finalize.argtypes = [vp]
     L.orc_ba_set_marg_prior.argtypes = [vp, c_d, c_d]
+    L.orc_ba_marginalize_points.argtypes = [vp, C.c_char_p, C.POINTER(C.c_ubyte), c_d, c_d]
     for n in ("orc_ba_nframes", "orc_ba_npoints", "orc_ba_nres"):
         getattr(L, n).argtypes = [vp]
     L.orc_ba_activate_all.argtypes = [vp]
@@ -366,6 +368,9 @@ class BAWindow:
         if getattr(self, "p", None):
             self.L.orc_ba_destroy(self.p); self.p = None
 
+    def set_frame_state(self, k, state10):
+        self.L.orc_ba_set_frame_state(self.p, k, _d(np.ascontiguousarray(state10, dtype=np.float64)))
+
     def perturb_frame(self, k, d8):
         self.L.orc_ba_perturb_frame(self.p, k, _d(np.ascontiguousarray(d8, dtype=np.float64)))
 
@@ -413,6 +418,14 @@ class BAWindow:
         r = C.c_int(0)
         self.L.orc_ba_accumulate(self.p, *[_d(a) for a in m], C.byref(r))
         return dict(HA=m[0], bA=m[1], HL=m[2], bL=m[3], Hsc=m[4], bsc=m[5], resInA=r.value)
+
+    def marginalize_points(self, candidates):
+        """flagPointsForRemoval's relinearisation + marginalizePointsF: (decision[N], Hadd, badd, resInM)."""
+        n = self.n
+        cand = np.ascontiguousarray(candidates, dtype=np.uint8)
+        dec = np.zeros(self.N, np.uint8); H = np.zeros((n, n)); b = np.zeros(n)
+        nres = self.L.orc_ba_marginalize_points(self.p, cand.tobytes(), dec.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(H), _d(b))
+        return dec, H, b, nres
 
     def point_acc(self):
         N = self.N

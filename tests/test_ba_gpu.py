@@ -175,3 +175,33 @@ def test_shard_systems_sum_to_full_system(pkg, oracle, synth, gpu_required):
     assert np.max(np.abs(HA - full["HA"]) / sc) < 1e-11 and np.max(np.abs(Hsc - full["Hsc"])[4:, 4:] / sc[4:, 4:]) < 1e-11
     assert np.max(np.abs(Hsc - full["Hsc"]) / sc) < 2e-6
     assert res == full["resInA"] and abs(e_sum - e_full) <= 1e-9 * e_full
+
+
+def test_marginalize_points_parity(pkg, oracle, synth, gpu_required):
+    """Relinearisation + fixLinearizationF + addPoint<2> / SC accumulation of the points hosted in keyframe 0, with non-zero frame
+    deltas (state != state_zero) set identically on both sides: decisions and residual counts identical, HM / bM increments as tight
+    as the BA accumulation itself."""
+    case = synth.ba_case(512, 512, n_frames=6, n_points=1200, hosts_share=(350, 300, 250, 200, 100, 0), seed=31)
+    ctx, ba, W = _window(pkg, oracle, case)
+    rng = np.random.RandomState(3)
+    for k in range(1, case["n_frames"]):
+        st = np.zeros(10); st[:3] = 2e-3 * rng.standard_normal(3); st[3:6] = 1e-3 * rng.standard_normal(3); st[6] = 1e-3 * rng.standard_normal(); st[7] = 1e-4 * rng.standard_normal()
+        ba.set_frame_state(k, st); W.set_frame_state(k, st)
+    ba.activate_all(); W.activate_all()
+    eg = ba.linearize_all(False); eo = W.linearize_all(False)
+    assert abs(eg - eo) <= 1e-6 * eo
+    ba.apply_res(); W.apply_res()
+    ba.accumulate(); W.accumulate()                 # idepth_hessian of every point (AccumulatedSCHessian.cpp:50)
+    cand = (np.asarray(case["host"]) == 0).astype(np.uint8)
+    cand[1::9] = 1                                   # a few points of other hosts too (isOOB candidates)
+    dg, Hg, bg, ng = ba.marginalize_points(cand)
+    do, Ho, bo, no = W.marginalize_points(cand)
+    assert np.array_equal(dg, do) and ng == no and (do == 1).sum() > 100
+    assert np.linalg.norm(Hg - Ho) <= 1e-9 * np.linalg.norm(Ho)
+    assert np.linalg.norm(bg - bo) <= 1e-8 * np.linalg.norm(bo) + 1e-12
+    # with update_prior the handle's HM / bM take the increment and the next solve uses it
+    x0 = ba.solve(0, 1e-5)
+    ba.marginalize_points(cand, update_prior=True)
+    ba.accumulate()
+    x1 = ba.solve(0, 1e-5)
+    assert np.all(np.isfinite(x1)) and np.linalg.norm(x1 - x0) > 0

@@ -228,3 +228,22 @@ def test_multithreaded_accumulation_matches(oracle, small_case):
         sc = np.sqrt(np.outer(np.diag(a1["HA"]) + 1e-9, np.diag(a1["HA"]) + 1e-9))
         assert np.max(np.abs(a1[k] - a6[k]) / sc) < 1e-5
     assert a1["resInA"] == a6["resInA"]
+
+
+def test_marginalize_points_prior_is_consistent(oracle, synth):
+    """marginalizePointsF: the increment of (HM, bM) is symmetric positive semi-definite, only touches frames the marginalised
+    points connect, and equals the Schur complement of the marginalised points' normal equations built from res_toZeroF."""
+    import numpy as np
+    case = synth.ba_case(320, 256, n_frames=4, n_points=300, hosts_share=(120, 100, 80, 0), seed=21)
+    W = oracle.BAWindow(case)
+    W.optimize(3)
+    cand = (np.asarray(case["host"]) == 0).astype(np.uint8)
+    dec, H, b, nres = W.marginalize_points(cand)
+    assert set(np.unique(dec[cand == 1])) <= {1, 2} and np.all(dec[cand == 0] == 0)
+    assert (dec == 1).sum() > 20 and nres > 0
+    assert np.abs(H - H.T).max() <= 1e-6 * np.abs(H).max()      # the Schur part is accumulated in fp32 per (t1, t2) ordering: symmetric to ~1e-8 only
+    ev = np.linalg.eigvalsh(0.5 * (H + H.T))
+    assert ev.min() > -1e-6 * ev.max()
+    # a window without candidates leaves the prior untouched
+    dec0, H0, b0, n0 = W.marginalize_points(np.zeros(len(cand), np.uint8))
+    assert n0 == 0 and not H0.any() and not b0.any() and not dec0.any()
