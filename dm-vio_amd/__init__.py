@@ -79,6 +79,8 @@ def _sig(L):
     L.dmvio_hip_immature_optimize.argtypes = [vp, C.c_int, c_i, c_d, c_d, c_f, c_d, C.c_char_p, C.c_int, c_i, c_f, c_i]
     L.dmvio_hip_trace_new_coarse.argtypes = [vp, C.c_int, c_d, c_d, C.c_float, C.c_int, c_d, c_d, c_f, c_d, c_i]
     L.dmvio_hip_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.dmvio_hip_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
+    L.dmvio_hip_ba_get_marg_prior.argtypes = [vp, c_d, c_d]
     L.dmvio_hip_ba_marginalize_points.argtypes = [vp, C.c_char_p, C.POINTER(C.c_ubyte), c_d, c_d, c_i, C.c_int]
     L.dmvio_hip_ba_create.restype = vp
     L.dmvio_hip_ba_create.argtypes = [vp]
@@ -503,6 +505,18 @@ class BundleAdjusterHip:
     def set_marg_prior(self, HM, bM):
         HM = np.ascontiguousarray(HM, dtype=np.float64); bM = np.ascontiguousarray(bM, dtype=np.float64)
         _chk(self.L, self.L.dmvio_hip_ba_set_marg_prior(self.p, _d(HM), _d(bM)), "ba_set_marg_prior")
+
+    def marginalize_frame(self, k):
+        n = self.n - 8
+        H = np.zeros((n, n)); b = np.zeros(n)
+        _chk(self.L, self.L.dmvio_hip_ba_marginalize_frame(self.p, k, _d(H), _d(b)), "ba_marginalize_frame")
+        return H, b
+
+    def get_marg_prior(self):
+        n = self.n
+        H = np.zeros((n, n)); b = np.zeros(n)
+        _chk(self.L, self.L.dmvio_hip_ba_get_marg_prior(self.p, _d(H), _d(b)), "ba_get_marg_prior")
+        return H, b
 
     def set_frame_state(self, k, state10):
         _chk(self.L, self.L.dmvio_hip_ba_set_frame_state(self.p, k, _d(np.ascontiguousarray(state10, dtype=np.float64))), "ba_set_frame_state")

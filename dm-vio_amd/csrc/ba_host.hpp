@@ -248,6 +248,45 @@ struct BAHost {
     if (iteration >= 2) orthogonalize(x);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:81)
     lastX = x;
   }
+  // EnergyFunctional::marginalizeFrame, visual-only branch (EnergyFunctional.cpp:570-640): returns the prior of the window without
+  // keyframe idx.  8x8 block inverse: Gauss-Jordan with partial pivoting (the reference: Eigen's PartialPivLU behind Mat88::inverse()).
+  void marginalizeFrame(int idx, std::vector<double>& HMn, std::vector<double>& bMn) const {
+    const int odim = n(), ndim = odim - 8, io = idx * 8 + 4;
+    std::vector<double> Hm = HM, bm = bM;
+    if (Hm.size() != (size_t)odim * odim) { Hm.assign((size_t)odim * odim, 0.0); bm.assign(odim, 0.0); }
+    std::vector<int> perm;
+    for (int i = 0; i < io; i++) perm.push_back(i);
+    for (int i = io + 8; i < odim; i++) perm.push_back(i);
+    for (int i = io; i < io + 8; i++) perm.push_back(i);
+    std::vector<double> Hp((size_t)odim * odim), bp(odim);
+    for (int i = 0; i < odim; i++) { bp[i] = bm[perm[i]]; for (int j = 0; j < odim; j++) Hp[(size_t)i * odim + j] = Hm[(size_t)perm[i] * odim + perm[j]]; }
+    for (int i = 0; i < 8; i++) { Hp[(size_t)(ndim + i) * odim + ndim + i] += fr[idx].prior[i]; bp[ndim + i] += fr[idx].prior[i] * fr[idx].delta_prior[i]; }
+    std::vector<double> sv(odim), svi(odim);
+    for (int i = 0; i < odim; i++) { sv[i] = std::sqrt(std::fabs(Hp[(size_t)i * odim + i]) + 10); svi[i] = 1.0 / sv[i]; }
+    for (int i = 0; i < odim; i++) { bp[i] *= svi[i]; for (int j = 0; j < odim; j++) Hp[(size_t)i * odim + j] = svi[i] * Hp[(size_t)i * odim + j] * svi[j]; }
+    double A[8][16];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { A[i][j] = Hp[(size_t)(ndim + i) * odim + ndim + j]; A[i][8 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 8; c++) {
+      int piv = c;
+      for (int r = c + 1; r < 8; r++) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+      if (piv != c) for (int k = 0; k < 16; k++) std::swap(A[c][k], A[piv][k]);
+      const double d = A[c][c];
+      for (int k = 0; k < 16; k++) A[c][k] /= d;
+      for (int r = 0; r < 8; r++) if (r != c) { const double m = A[r][c]; if (m != 0) for (int k = 0; k < 16; k++) A[r][k] -= m * A[c][k]; }
+    }
+    std::vector<double> bli((size_t)ndim * 8);
+    for (int i = 0; i < ndim; i++) for (int j = 0; j < 8; j++) { double s = 0; for (int k = 0; k < 8; k++) s += Hp[(size_t)(ndim + k) * odim + i] * A[k][8 + j]; bli[(size_t)i * 8 + j] = s; }
+    for (int i = 0; i < ndim; i++) {
+      for (int j = 0; j < ndim; j++) { double s = 0; for (int k = 0; k < 8; k++) s += bli[(size_t)i * 8 + k] * Hp[(size_t)(ndim + k) * odim + j]; Hp[(size_t)i * odim + j] -= s; }
+      double sb = 0; for (int k = 0; k < 8; k++) sb += bli[(size_t)i * 8 + k] * bp[ndim + k];
+      bp[i] -= sb;
+    }
+    HMn.assign((size_t)ndim * ndim, 0.0); bMn.assign(ndim, 0.0);
+    for (int i = 0; i < ndim; i++) {
+      bMn[i] = sv[i] * bp[i];
+      for (int j = 0; j < ndim; j++) HMn[(size_t)i * ndim + j] = 0.5 * (sv[i] * Hp[(size_t)i * odim + j] * sv[j] + sv[j] * Hp[(size_t)j * odim + i] * sv[i]);
+    }
+  }
   // adHTdeltaF of EnergyFunctional::setDeltaF (EnergyFunctional.cpp:175-198): F*F x 8, index h + F*t
   void adHTdeltaF(std::vector<float>& out) const {
     out.assign((size_t)F * F * 8, 0.f);

@@ -534,6 +534,24 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double a
   if (state10) memcpy(state10, fr.state, sizeof(double) * 10);
   return 0;
 }
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:520-660), visual-only branch: the marginalisation prior of the window
+// without keyframe `frame` ((n-8) x (n-8), n-8); also returns the current prior when HM_cur / bM_cur are given.
+int dmvio_hip_ba_marginalize_frame(dmvio_hip_ba* b, int frame, double* HM_new, double* bM_new) {
+  if (!b || !HM_new || !bM_new || frame < 0 || frame >= b->H.F) return failmsg("ba_marginalize_frame: bad argument");
+  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::vector<double> Hn, bn;
+  b->H.marginalizeFrame(frame, Hn, bn);
+  memcpy(HM_new, Hn.data(), sizeof(double) * Hn.size());
+  memcpy(bM_new, bn.data(), sizeof(double) * bn.size());
+  return 0;
+}
+int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
+  if (!b || !HM || !bM) return failmsg("ba_get_marg_prior: null argument");
+  const int n = b->H.n();
+  if (b->H.HM.size() != (size_t)n * n) { memset(HM, 0, sizeof(double) * n * n); memset(bM, 0, sizeof(double) * n); return 0; }
+  memcpy(HM, b->H.HM.data(), sizeof(double) * n * n); memcpy(bM, b->H.bM.data(), sizeof(double) * n);
+  return 0;
+}
 // FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
   if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");

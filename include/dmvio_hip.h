@@ -146,6 +146,12 @@ int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* ba, int frame, const double state
  * The caller then rebuilds the graph without the decided points (dmvio_hip_ba_set_graph), as the reference's removePoint does. */
 int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* ba, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM,
                                     int update_prior);
+/* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:520-660, visual-only branch :570-640): Schur complement of keyframe `frame`
+ * (its block moved last, its prior added, diagonal pre-scaling) on the handle's marginalisation prior; returns the prior of the
+ * remaining window, (n-8) x (n-8) row-major and n-8.  The caller re-creates the window without the frame (dmvio_hip_ba_set_window)
+ * and installs the result with dmvio_hip_ba_set_marg_prior.  dmvio_hip_ba_get_marg_prior reads the current HM, bM. */
+int dmvio_hip_ba_marginalize_frame(dmvio_hip_ba* ba, int frame, double* HM_new, double* bM_new);
+int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* ba, double* HM, double* bM);
 /* Flattened point / residual graph (EnergyFunctional::makeIDX, EnergyFunctional.cpp:997-1017): point p is hosted in frame host[p],
  * has PointHessian::u, v, idepth, color[8], weights[8] (HessianBlocks.h:419-436) and hasDepthPrior; residual r observes point
  * res_point[r] in frame res_target[r].  Residuals must be sorted by point (points in allPoints order). */

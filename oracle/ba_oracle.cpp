@@ -618,6 +618,51 @@ struct OWindow {
     if (mode == 2) { p.Hdd_accAF = 0; p.bd_accAF = 0; for (int i = 0; i < 4; i++) p.Hcd_accAF[i] = 0; }
   }
 
+  // EnergyFunctional::marginalizeFrame, visual part (EnergyFunctional.cpp:570-640): move the frame's block to the end, add its
+  // prior, diagonal pre-scaling, Schur complement of the 8x8 block, unscale, symmetrise.  Returns the (n-8)-dimensional prior.
+  void marginalizeFrame(int idx, Mat& HMn, Mat& bMn) const {
+    const int odim = nF * 8 + CPARS, ndim = odim - 8;
+    Mat Hm = HM, bm = bM;
+    if (Hm.size() != (size_t)odim * odim) { Hm.assign((size_t)odim * odim, 0.0); bm.assign(odim, 0.0); }
+    // permutation: everything before the frame stays, the tail moves up, the frame goes last
+    std::vector<int> perm;
+    const int io = idx * 8 + CPARS;
+    for (int i = 0; i < io; i++) perm.push_back(i);
+    for (int i = io + 8; i < odim; i++) perm.push_back(i);
+    for (int i = io; i < io + 8; i++) perm.push_back(i);
+    Mat H((size_t)odim * odim), b(odim);
+    for (int i = 0; i < odim; i++) { b[i] = bm[perm[i]]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = Hm[(size_t)perm[i] * odim + perm[j]]; }
+    const OFrame& f = frames[idx];
+    for (int i = 0; i < 8; i++) { H[(size_t)(ndim + i) * odim + ndim + i] += f.prior[i]; b[ndim + i] += f.prior[i] * f.delta_prior[i]; }
+    Mat SVec(odim), SVecI(odim);
+    for (int i = 0; i < odim; i++) { SVec[i] = std::sqrt(std::fabs(H[(size_t)i * odim + i]) + 10); SVecI[i] = 1.0 / SVec[i]; }
+    for (int i = 0; i < odim; i++) { b[i] *= SVecI[i]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = SVecI[i] * H[(size_t)i * odim + j] * SVecI[j]; }
+    // invert the bottom-right 8x8 (Eigen: partial-pivot LU), symmetrised as the reference does (0.5f*(hpi+hpi) is the identity map)
+    double A[8][16];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { A[i][j] = H[(size_t)(ndim + i) * odim + ndim + j]; A[i][8 + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 8; c++) {
+      int piv = c;
+      for (int r = c + 1; r < 8; r++) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+      if (piv != c) for (int k = 0; k < 16; k++) std::swap(A[c][k], A[piv][k]);
+      const double d = A[c][c];
+      for (int k = 0; k < 16; k++) A[c][k] /= d;
+      for (int r = 0; r < 8; r++) if (r != c) { const double m = A[r][c]; if (m != 0) for (int k = 0; k < 16; k++) A[r][k] -= m * A[c][k]; }
+    }
+    // bli = BL^T * hpi (ndim x 8); top-left -= bli * BL; b_head -= bli * b_tail
+    std::vector<double> bli((size_t)ndim * 8);
+    for (int i = 0; i < ndim; i++) for (int j = 0; j < 8; j++) { double sum = 0; for (int k = 0; k < 8; k++) sum += H[(size_t)(ndim + k) * odim + i] * A[k][8 + j]; bli[(size_t)i * 8 + j] = sum; }
+    for (int i = 0; i < ndim; i++) {
+      for (int j = 0; j < ndim; j++) { double sum = 0; for (int k = 0; k < 8; k++) sum += bli[(size_t)i * 8 + k] * H[(size_t)(ndim + k) * odim + j]; H[(size_t)i * odim + j] -= sum; }
+      double sb = 0; for (int k = 0; k < 8; k++) sb += bli[(size_t)i * 8 + k] * b[ndim + k];
+      b[i] -= sb;
+    }
+    HMn.assign((size_t)ndim * ndim, 0.0); bMn.assign(ndim, 0.0);
+    for (int i = 0; i < ndim; i++) {
+      bMn[i] = SVec[i] * b[i];
+      for (int j = 0; j < ndim; j++) HMn[(size_t)i * ndim + j] = 0.5 * (SVec[i] * H[(size_t)i * odim + j] * SVec[j] + SVec[j] * H[(size_t)j * odim + i] * SVec[i]);
+    }
+  }
+
   // EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:76-106): res_toZeroF = resF - [JI*Jp Ja] * delta
   void fixLinearizationF(ORes& r) {
     const RawJ& J = r.Jef;
@@ -1178,6 +1223,12 @@ int orc_ba_marginalize_points(void* p, const unsigned char* cand, unsigned char*
   const int nres = W->marginalizePoints(cand, decision, H, b);
   memcpy(Hadd, H.data(), sizeof(double) * H.size()); memcpy(badd, b.data(), sizeof(double) * b.size());
   return nres;
+}
+void orc_ba_marginalize_frame(void* p, int idx, double* HMn, double* bMn) {
+  OWindow* W = (OWindow*)p;
+  Mat H, b;
+  W->marginalizeFrame(idx, H, b);
+  memcpy(HMn, H.data(), sizeof(double) * H.size()); memcpy(bMn, b.data(), sizeof(double) * b.size());
 }
 void orc_ba_set_marg_prior(void* p, const double* HM, const double* bM) {
   OWindow* W = (OWindow*)p; const int n = CPARS + W->nF * 8;

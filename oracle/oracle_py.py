@@ -309,6 +309,7 @@ def _ba_sig(L):
     L.orc_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
     L.orc_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
     L.orc_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.orc_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
     L.orc_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int]
     L.orc_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
     L.orc_ba_finalize.argtypes = [vp]
@@ -418,6 +419,15 @@ class BAWindow:
         r = C.c_int(0)
         self.L.orc_ba_accumulate(self.p, *[_d(a) for a in m], C.byref(r))
         return dict(HA=m[0], bA=m[1], HL=m[2], bL=m[3], Hsc=m[4], bsc=m[5], resInA=r.value)
+
+    def set_marg_prior(self, HM, bM):
+        self.L.orc_ba_set_marg_prior(self.p, _d(np.ascontiguousarray(HM, dtype=np.float64)), _d(np.ascontiguousarray(bM, dtype=np.float64)))
+
+    def marginalize_frame(self, k):
+        n = self.n - 8
+        H = np.zeros((n, n)); b = np.zeros(n)
+        self.L.orc_ba_marginalize_frame(self.p, k, _d(H), _d(b))
+        return H, b
 
     def marginalize_points(self, candidates):
         """flagPointsForRemoval's relinearisation + marginalizePointsF: (decision[N], Hadd, badd, resInM)."""

@@ -205,3 +205,22 @@ def test_marginalize_points_parity(pkg, oracle, synth, gpu_required):
     ba.accumulate()
     x1 = ba.solve(0, 1e-5)
     assert np.all(np.isfinite(x1)) and np.linalg.norm(x1 - x0) > 0
+
+
+def test_marginalize_frame_parity(pkg, oracle, synth, gpu_required):
+    """marginalizePointsF into the prior, then marginalizeFrame of a middle and of the last keyframe: reduced prior vs the oracle."""
+    case = synth.ba_case(512, 512, n_frames=5, n_points=600, hosts_share=(200, 180, 120, 100, 0), seed=33)
+    ctx, ba, W = _window(pkg, oracle, case)
+    for X in (ba, W):
+        X.activate_all(); X.linearize_all(False); X.apply_res(); X.accumulate()
+    cand = (np.asarray(case["host"]) == 1).astype(np.uint8)
+    dg, Hg, bg, _ = ba.marginalize_points(cand, update_prior=True)
+    do, Ho, bo, _ = W.marginalize_points(cand)
+    W.set_marg_prior(Ho, bo)
+    Hp, bp = ba.get_marg_prior()
+    assert np.linalg.norm(Hp - Ho) <= 1e-9 * np.linalg.norm(Ho)
+    for k in (1, 4, 0):
+        Hn_g, bn_g = ba.marginalize_frame(k)
+        Hn_o, bn_o = W.marginalize_frame(k)
+        assert np.linalg.norm(Hn_g - Hn_o) <= 1e-7 * np.linalg.norm(Hn_o) + 1e-9
+        assert np.linalg.norm(bn_g - bn_o) <= 1e-7 * np.linalg.norm(bn_o) + 1e-9
