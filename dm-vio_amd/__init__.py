@@ -66,6 +66,10 @@ def _sig(L):
     L.dmvio_hip_initializer_set_points.argtypes = [vp, C.c_int, c_f, c_f, c_f, c_u8, c_f, c_f]
     L.dmvio_hip_initializer_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_d, c_f, c_d, c_d, c_f, C.c_float, C.c_float, C.c_float, C.c_double, C.c_double,
                                                         c_f, c_f, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f]
+    L.dmvio_hip_undistorter_create.restype = vp
+    L.dmvio_hip_undistorter_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f]
+    L.dmvio_hip_undistorter_destroy.argtypes = [vp]
+    L.dmvio_hip_frame_upload_raw.argtypes = [vp, vp, C.c_int, C.c_void_p, C.c_float, c_f]
     L.dmvio_hip_immature_create.restype = vp
     L.dmvio_hip_immature_create.argtypes = [vp, C.c_int]
     L.dmvio_hip_immature_destroy.argtypes = [vp]
@@ -332,6 +336,37 @@ class CoarseTrackerHip:
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_work(self.p, C.byref(a), C.byref(b)), "last_work")
         return a.value, b.value
+
+
+class UndistorterHip:
+    """Raw camera image -> PhotometricUndistorter::processFrame + Undistort::undistort on the device (upload path)."""
+
+    def __init__(self, ctx, wOrg, hOrg, bits=8, G=None, vignetteMapInv=None, remapX=None, remapY=None):
+        self.ctx, self.L = ctx, ctx.L
+        self._keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (G, vignetteMapInv, remapX, remapY)]
+        ptr = [None if a is None else _f(a) for a in self._keep]
+        p = self.L.dmvio_hip_undistorter_create(ctx.p, wOrg, hOrg, bits, ptr[0], ptr[1], ptr[2], ptr[3])
+        if not p:
+            raise HipLibraryError("dmvio_hip_undistorter_create: %s" % _err(self.L))
+        self.p = C.c_void_p(p)
+        self.dtype = np.uint8 if bits == 8 else np.uint16
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_undistorter_destroy(self.p); self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, slot, raw, factor=1.0, want_image=True):
+        raw = np.ascontiguousarray(raw, dtype=self.dtype)
+        out = np.zeros((self.ctx.h, self.ctx.w), np.float32) if want_image else None
+        _chk(self.L, self.L.dmvio_hip_frame_upload_raw(self.ctx.p, self.p, slot, raw.ctypes.data_as(C.c_void_p), factor, None if out is None else _f(out)),
+             "frame_upload_raw")
+        return out
 
 
 class CoarseInitializerHip:

@@ -146,6 +146,66 @@ int dmvio_hip_frame_upload(dmvio_hip_ctx* c, int slot, const float* host) {
   return 0;
 }
 
+// ---- raw camera image -> photometric + geometric undistortion -> pyramids (Undistort::undistort + FrameHessian::makeImages)
+struct dmvio_hip_undistorter {
+  dmvio_hip_ctx* ctx = nullptr;
+  UndistortDev U{};
+  int bytes_per_px = 1;
+  float *d_G = nullptr, *d_vig = nullptr, *d_rx = nullptr, *d_ry = nullptr;
+  void *d_raw = nullptr, *h_raw = nullptr;
+};
+dmvio_hip_undistorter* dmvio_hip_undistorter_create(dmvio_hip_ctx* c, int wOrg, int hOrg, int bits, const float* G, const float* vignetteMapInv, const float* remapX,
+                                                    const float* remapY) {
+  if (!c || wOrg < 1 || hOrg < 1 || (bits != 8 && bits != 16)) { failmsg("undistorter_create: bad argument"); return nullptr; }
+  if ((remapX == nullptr) != (remapY == nullptr)) { failmsg("undistorter_create: remapX / remapY must both be given or both be NULL"); return nullptr; }
+  if (!remapX && (wOrg != c->w || hOrg != c->h)) { failmsg("undistorter_create: passthrough needs wOrg x hOrg == w x h"); return nullptr; }
+  if (hipSetDevice(c->device) != hipSuccess) { failmsg("undistorter_create: hipSetDevice failed"); return nullptr; }
+  dmvio_hip_undistorter* u = new dmvio_hip_undistorter();
+  u->ctx = c; u->bytes_per_px = bits / 8;
+  const size_t nOrg = (size_t)wOrg * hOrg, nOut = (size_t)c->w * c->h, nG = bits == 8 ? 256 : 65536;
+  bool ok = hipMalloc(&u->d_raw, nOrg * u->bytes_per_px) == hipSuccess && hipHostMalloc(&u->h_raw, nOrg * u->bytes_per_px, hipHostMallocDefault) == hipSuccess;
+  auto up = [&](float** d, const float* h, size_t n) {
+    if (!h) return true;
+    return hipMalloc((void**)d, sizeof(float) * n) == hipSuccess && hipMemcpy(*d, h, sizeof(float) * n, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  ok = ok && up(&u->d_G, G, nG) && up(&u->d_vig, G ? vignetteMapInv : nullptr, nOrg) && up(&u->d_rx, remapX, nOut) && up(&u->d_ry, remapY, nOut);
+  if (!ok) { failmsg("undistorter_create: device allocation failed"); dmvio_hip_undistorter_destroy(u); return nullptr; }
+  u->U.wOrg = wOrg; u->U.hOrg = hOrg; u->U.w = c->w; u->U.h = c->h;
+  u->U.G = u->d_G; u->U.vignetteMapInv = u->d_vig; u->U.remapX = u->d_rx; u->U.remapY = u->d_ry; u->U.factor = 1.0f;
+  return u;
+}
+void dmvio_hip_undistorter_destroy(dmvio_hip_undistorter* u) {
+  if (!u) return;
+  hipSetDevice(u->ctx->device);
+  hipStreamSynchronize(u->ctx->stream);
+  if (u->d_raw) hipFree(u->d_raw);
+  if (u->h_raw) hipHostFree(u->h_raw);
+  if (u->d_G) hipFree(u->d_G);
+  if (u->d_vig) hipFree(u->d_vig);
+  if (u->d_rx) hipFree(u->d_rx);
+  if (u->d_ry) hipFree(u->d_ry);
+  delete u;
+}
+int dmvio_hip_frame_upload_raw(dmvio_hip_ctx* c, dmvio_hip_undistorter* u, int slot, const void* raw, float factor, float* undistorted_out) {
+  if (!c || !u || !raw || u->ctx != c) return failmsg("frame_upload_raw: bad argument");
+  if (slot < 0 || slot >= c->n_slots) return failmsg("frame_upload_raw: slot out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const size_t nOrg = (size_t)u->U.wOrg * u->U.hOrg, nOut = (size_t)c->w * c->h;
+  HIPCHK(hipStreamSynchronize(c->stream));   // the pinned staging buffer of a previous upload
+  memcpy(u->h_raw, raw, nOrg * u->bytes_per_px);
+  HIPCHK(hipMemcpyAsync(u->d_raw, u->h_raw, nOrg * u->bytes_per_px, hipMemcpyHostToDevice, c->stream));
+  UndistortDev U = u->U;
+  U.factor = factor;
+  if (u->bytes_per_px == 1) hipLaunchKernelGGL((k_undistort<unsigned char>), dim3((nOut + 255) / 256), dim3(256), 0, c->stream, (const unsigned char*)u->d_raw, U, c->d_upload);
+  else hipLaunchKernelGGL((k_undistort<unsigned short>), dim3((nOut + 255) / 256), dim3(256), 0, c->stream, (const unsigned short*)u->d_raw, U, c->d_upload);
+  HIPCHK(hipGetLastError());
+  if (int r = buildPyramid(c, slot, c->d_upload)) return r;
+  if (undistorted_out) HIPCHK(hipMemcpyAsync(undistorted_out, c->d_upload, sizeof(float) * nOut, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
   if (!c || !dev) return failmsg("frame_from_device: null argument");
   if (slot < 0 || slot >= c->n_slots) return failmsg("frame_from_device: slot out of range");

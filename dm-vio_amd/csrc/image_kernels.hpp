@@ -64,6 +64,40 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   }
 }
 
+// Photometric + geometric undistortion of a raw camera image on the upload path:
+//   PhotometricUndistorter::processFrame (src/dso/util/Undistort.cpp:214-250): data = G[raw] (* vignetteMapInv), or factor * raw without calibration,
+//   Undistort::undistort            (src/dso/util/Undistort.cpp:386-481): bilinear remap of that image through remapX / remapY (xx < 0 -> 0).
+// Fused: each output pixel evaluates the photometric value of its four source taps — the same per-pixel arithmetic, bit-identical output.
+// T = unsigned char / unsigned short.  remapX == NULL: passthrough (no geometric step, wOrg x hOrg == w x h).
+struct UndistortDev {
+  int wOrg, hOrg, w, h;
+  const float* G;               // 256 (u8) or 65536 (u16) entries, NULL = no photometric calibration
+  const float* vignetteMapInv;  // wOrg*hOrg or NULL
+  const float *remapX, *remapY; // w*h or NULL
+  float factor;
+};
+template <typename T>
+__device__ __forceinline__ float photoAt(const T* __restrict__ raw, const UndistortDev& U, const int i) {
+  if (!U.G) return U.factor * raw[i];
+  float v = U.G[raw[i]];
+  if (U.vignetteMapInv) v *= U.vignetteMapInv[i];
+  return v;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_undistort(const T* __restrict__ raw, const UndistortDev U, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= U.w * U.h) return;
+  if (!U.remapX) { out[idx] = photoAt(raw, U, idx); return; }
+  float xx = U.remapX[idx], yy = U.remapY[idx];
+  if (xx < 0) { out[idx] = 0; return; }
+  const int xxi = (int)xx, yyi = (int)yy;
+  xx -= xxi; yy -= yyi;
+  const float xxyy = xx * yy;
+  const int base = xxi + yyi * U.wOrg;
+  out[idx] = xxyy * photoAt(raw, U, base + 1 + U.wOrg) + (yy - xxyy) * photoAt(raw, U, base + U.wOrg) + (xx - xxyy) * photoAt(raw, U, base + 1) +
+             (1 - xx - yy + xxyy) * photoAt(raw, U, base);
+}
+
 // level plane -> the reference's Eigen::Vector3f AoS (I, dx, dy)   (parity tests / debug download)
 __global__ void __launch_bounds__(256) k_level_to_f3(const float* __restrict__ I, const int w, const int h, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,6 +50,16 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* ctx);
  * consumes a device pointer already in HBM (no PCIe traffic). */
 int dmvio_hip_frame_upload(dmvio_hip_ctx* ctx, int slot, const float* irradiance_host);
 int dmvio_hip_frame_from_device(dmvio_hip_ctx* ctx, int slot, const float* irradiance_dev);
+/* Raw camera image on the upload path (data-format edge): PhotometricUndistorter::processFrame
+ * (src/dso/util/Undistort.cpp:214-250: G[raw] * vignetteMapInv, or factor * raw when G == NULL) and Undistort::undistort
+ * (Undistort.cpp:386-481: bilinear remap through remapX / remapY, xx < 0 -> 0; NULL maps = passthrough) run on the device, then
+ * makeImages.  bits = 8 / 16 (unsigned char / unsigned short raw pixels, G with 256 / 65536 entries).  1 B/px crosses PCIe instead of
+ * 4 B/px.  undistorted_out (may be NULL) receives the w*h irradiance image the reference would hand to makeImages. */
+typedef struct dmvio_hip_undistorter dmvio_hip_undistorter;
+dmvio_hip_undistorter* dmvio_hip_undistorter_create(dmvio_hip_ctx* ctx, int wOrg, int hOrg, int bits, const float* G, const float* vignetteMapInv,
+                                                    const float* remapX, const float* remapY);
+void dmvio_hip_undistorter_destroy(dmvio_hip_undistorter* und);
+int dmvio_hip_frame_upload_raw(dmvio_hip_ctx* ctx, dmvio_hip_undistorter* und, int slot, const void* raw, float factor, float* undistorted_out);
 /* makeImages for B frames in 4 launches: frame i is read from dev_base + i*stride_bytes and written to slots[i].
  * Asynchronous on the ctx stream (ordering with later tracker calls is by stream order). */
 int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);

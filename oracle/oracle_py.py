@@ -62,6 +62,7 @@ def lib():
         L.orc_init_calc_res_and_gs.argtypes = [c_f, c_f, C.c_int, C.c_int, c_d, C.c_float, C.c_float, C.c_float, C.c_float, c_d, C.c_double, C.c_double, C.c_int,
                                                c_f, c_f, c_f, c_f, c_u8, c_f, c_f, C.c_float, C.c_float, C.c_float, C.c_double, C.c_double,
                                                c_f, c_f, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f]
+        L.orc_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, c_f]
         L.orc_pair_precalc.argtypes = [c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_f, c_f, c_f]
         L.orc_immature_optimize.argtypes = [C.c_int, C.c_int, c_f, C.c_int, C.POINTER(c_f), c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int,
                                             c_i, c_f, c_i]
@@ -178,6 +179,19 @@ def init_calc_res_and_gs(dI_ref, dI_new, wl, hl, Ki9, fxfycxcy_lvl, refToNew7, a
                                    _f(o["bsc"]), _f(o["res3"]), _f(o["energy_new"]), o["isGood_new"].ctypes.data_as(c_u8), _f(o["maxstep"]), _f(o["lastHessian_new"]),
                                    _f(o["JbBuffer_new"]))
     return o
+
+
+def undistort(raw, G, vig, remapX, remapY, w, h, factor=1.0):
+    """PhotometricUndistorter::processFrame + Undistort::undistort; raw: uint8 / uint16 [hOrg, wOrg]."""
+    raw = np.ascontiguousarray(raw)
+    bits = 8 if raw.dtype == np.uint8 else 16
+    hOrg, wOrg = raw.shape
+    out = np.zeros((h, w), np.float32)
+    f = lambda a: None if a is None else _f(np.ascontiguousarray(a, dtype=np.float32))
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (G, vig, remapX, remapY)]
+    ptr = [None if a is None else _f(a) for a in keep]
+    lib().orc_undistort(raw.ctypes.data_as(C.c_void_p), bits, wOrg, hOrg, ptr[0], ptr[1], ptr[2], ptr[3], w, h, factor, _f(out))
+    return out
 
 
 def pair_precalc(target_w2c7, host_c2w7, host_exposure=1.0, target_exposure=1.0, host_aff=(0.0, 0.0), target_aff=(0.0, 0.0)):
