@@ -33,6 +33,34 @@ __device__ __forceinline__ float3 interp33(const float* __restrict__ img, const 
   return r;
 }
 
+// The same tap split in two: the four unaligned vector loads (issued early, software pipelining) and the arithmetic on them.
+struct Taps33 { float2 A, D; float4 B, C; };
+__device__ __forceinline__ void interp33Load(const float* __restrict__ img, const float x, const float y, const int width, Taps33& t) {
+  const int ix = (int)x, iy = (int)y;
+  const float* bp = img + ix + iy * width;
+  __builtin_memcpy(&t.A, bp - width, 8);
+  __builtin_memcpy(&t.B, bp - 1, 16);
+  __builtin_memcpy(&t.C, bp + width - 1, 16);
+  __builtin_memcpy(&t.D, bp + 2 * width, 8);
+}
+__device__ __forceinline__ float3 interp33Finish(const Taps33& t, const float x, const float y) {
+  const int ix = (int)x, iy = (int)y;
+  const float dx = x - ix, dy = y - iy;
+  const float dxdy = dx * dy;
+  const float2 A = t.A, D = t.D;
+  const float4 B = t.B, C = t.C;
+  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+  const float gx00 = fin0(0.5f * (B.z - B.x)), gx10 = fin0(0.5f * (B.w - B.y));
+  const float gx01 = fin0(0.5f * (C.z - C.x)), gx11 = fin0(0.5f * (C.w - C.y));
+  const float gy00 = fin0(0.5f * (C.y - A.x)), gy10 = fin0(0.5f * (C.z - A.y));
+  const float gy01 = fin0(0.5f * (D.x - B.y)), gy11 = fin0(0.5f * (D.y - B.z));
+  float3 r;
+  r.x = w11 * C.z + w01 * C.y + w10 * B.z + w00 * B.y;
+  r.y = w11 * gx11 + w01 * gx01 + w10 * gx10 + w00 * gx00;
+  r.z = w11 * gy11 + w01 * gy01 + w10 * gy10 + w00 * gy00;
+  return r;
+}
+
 // dIp[lvl][idx][1], [2] of the reference at pixel (x, y) of a level plane: central differences with the reference's
 // flat-index range (rows 1..h-2) and isfinite guard (HessianBlocks.cpp:172-181).
 __device__ __forceinline__ float2 gradAt(const float* __restrict__ I, const int w, const int h, const int x, const int y) {

@@ -66,18 +66,26 @@ __device__ __forceinline__ EvalU makeEvalU(const EvalP& e, const LevelGeom& g, c
 // Returns the row J[0..8] = (J0..J7, r) and its Huber weight w (w = 0 and J = 0 when the point does not enter the system).
 // Written without branches: lanes that fail a test keep computing on a safe in-bounds tap and are masked out at the end —
 // the arithmetic of the surviving lanes is the reference's, operation for operation.
-__device__ __forceinline__ void evalPoint(const float4 P, const bool live, const EvalU& e, const float* __restrict__ img, EvalStats& st,
-                                          float (&J)[9], float& wOut) {
-  const float x = P.x, y = P.y, id = P.z, refColor = P.w;
+// Split in two so that the taps of the NEXT point are in flight while the current one is finished (software pipelining):
+// projectPoint = warp + bounds test + the four tap loads; finishPoint = everything that consumes the taps.
+struct PointProj { float u, v, Ku, Kv, new_idepth, refColor; bool inb; };
+__device__ __forceinline__ void projectPoint(const float4 P, const bool live, const EvalU& e, const float* __restrict__ img, PointProj& q, Taps33& taps) {
+  const float x = P.x, y = P.y, id = P.z;
   const float pt0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f + e.t[0] * id;
   const float pt1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f + e.t[1] * id;
   const float pt2 = e.RKi[6] * x + e.RKi[7] * y + e.RKi[8] * 1.0f + e.t[2] * id;
-  const float u = pt0 / pt2, v = pt1 / pt2;
-  const float Ku = e.fx * u + e.cx, Kv = e.fy * v + e.cy;
-  const float new_idepth = id / pt2;
-  const bool inb = live && (Ku > 2 && Kv > 2 && Ku < e.wM3 && Kv < e.hM3 && new_idepth > 0);
-  const float3 hit = interp33(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, e.w);
-  const bool fin = inb && isfinite(hit.x);
+  q.u = pt0 / pt2; q.v = pt1 / pt2;
+  const float Ku = e.fx * q.u + e.cx, Kv = e.fy * q.v + e.cy;
+  q.new_idepth = id / pt2;
+  q.refColor = P.w;
+  q.inb = live && (Ku > 2 && Kv > 2 && Ku < e.wM3 && Kv < e.hM3 && q.new_idepth > 0);
+  q.Ku = q.inb ? Ku : 2.5f; q.Kv = q.inb ? Kv : 2.5f;   // masked lanes tap a safe pixel
+  interp33Load(img, q.Ku, q.Kv, e.w, taps);
+}
+__device__ __forceinline__ void finishPoint(const PointProj& q, const Taps33& taps, const EvalU& e, EvalStats& st, float (&J)[9], float& wOut) {
+  const float u = q.u, v = q.v, new_idepth = q.new_idepth, refColor = q.refColor;
+  const float3 hit = interp33Finish(taps, q.Ku, q.Kv);
+  const bool fin = q.inb && isfinite(hit.x);
   const float residual = hit.x - (e.aff0 * refColor + e.aff1);
   const float ar = fabsf(residual);
   const float hw = ar < e.huberTH ? 1.0f : e.huberTH / ar;
@@ -190,13 +198,27 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
   // requested before this iteration's taps, so the two dependent memory round trips of a point (record -> projection ->
   // taps) overlap across iterations.
   const int base0 = first - lane;
-  float4 Pn = n > 0 ? pc[min(base0 + lane, n - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // three-stage software pipeline per lane: template record two points ahead, warp + tap loads one point ahead, residual /
+  // Jacobian row / MFMA of the current point — the gathers of point i+1 are in flight during the arithmetic of point i
+  const int nm1 = max(n - 1, 0);
+  float4 P1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  PointProj q0;
+  Taps33 t0;
+  q0.u = q0.v = q0.new_idepth = q0.refColor = 0.f; q0.Ku = q0.Kv = 2.5f; q0.inb = false;
+  if (n > 0) {
+    const float4 P0 = pc[min(base0 + lane, nm1)];
+    P1 = pc[min(base0 + lane + stride, nm1)];
+    projectPoint(P0, base0 + lane < n, eu, img, q0, t0);
+  }
   for (int base = base0; base < n; base += stride) {
     const int i = base + lane;
-    const float4 P = Pn;
-    Pn = pc[min(i + stride, n - 1)];   // unconditional (clamped): no branch between the request and its use
+    PointProj q1;
+    Taps33 t1;
+    projectPoint(P1, i + stride < n, eu, img, q1, t1);     // next point: its taps are requested now, consumed next iteration
+    P1 = pc[min(i + 2 * stride, nm1)];                     // unconditional (clamped) prefetch
     float J[9], w;
-    evalPoint(P, i < n, eu, img, st, J, w);
+    finishPoint(q0, t0, eu, st, J, w);
+    q0 = q1; t0 = t1;
 #pragma unroll
     for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
     wW[lane] = w;
