@@ -30,7 +30,7 @@ struct FrameStore {
 struct PyrGeom {
   int levels;
   int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
-  int tiles_x, tiles_y;  // 32x32 level-0 tiles
+  int tiles_x, tiles_y;  // 64x64 level-0 tiles
 };
 
 // Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one

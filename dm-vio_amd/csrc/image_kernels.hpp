@@ -6,8 +6,8 @@
 // where they are consumed (gradAt below = the reference's formula incl. its isfinite guard); absSquaredGrad (pixel
 // selector only) is not produced.
 //
-// One launch builds ALL levels of B frames: a workgroup owns a 32x32 level-0 tile, keeps the successive 2x2
-// reductions in LDS (32x32 -> 16x16 -> ... -> 1x1) and streams each level out.  HBM traffic per frame:
+// One launch builds ALL levels of B frames: a workgroup owns a 64x64 level-0 tile (level-1 rows of a tile are full 128-byte
+// lines), keeps the successive 2x2 reductions in LDS (64x64 -> 32x32 -> ... ) and streams each level out.  HBM traffic per frame:
 // read 4 B/px + write 4 B/px * (1 + 1/4 + 1/16 + ...).
 #pragma once
 #include "common.h"
@@ -15,43 +15,56 @@
 
 namespace dmv {
 
+#define PYR_TILE 64
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot) {
-  __shared__ float s_a[32 * 32];
-  __shared__ float s_b[16 * 16];
+  __shared__ float s_a[PYR_TILE * PYR_TILE];
+  __shared__ float s_b[(PYR_TILE / 2) * (PYR_TILE / 2)];
   const int f = blockIdx.y;
   const int slot = slots ? slots[f] : single_slot;
   const float* __restrict__ src = in_base + (size_t)f * in_stride;
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
-  const int x0 = tx * 32, y0 = ty * 32;
-  // level 0: 256 threads x 4 consecutive pixels
+  const int x0 = tx * PYR_TILE, y0 = ty * PYR_TILE;
+  // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store
   {
-    const int lx = (threadIdx.x & 7) * 4, ly = threadIdx.x >> 3;
-    const int x = x0 + lx, y = y0 + ly;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int lx = (threadIdx.x & 15) * 4, lyb = threadIdx.x >> 4;
     float* __restrict__ dst = fs.level_mut(slot, 0);
-    if (y < h0) {
-      if (x + 3 < w0) {
-        __builtin_memcpy(&v, src + (size_t)y * w0 + x, 16);
-        __builtin_memcpy(dst + (size_t)y * w0 + x, &v, 16);
-      } else {
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 4; k++)
-          if (x + k < w0) { t[k] = src[(size_t)y * w0 + x + k]; dst[(size_t)y * w0 + x + k] = t[k]; }
-        v = make_float4(t[0], t[1], t[2], t[3]);
+    float4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int x = x0 + lx, y = y0 + lyb + 16 * p;
+      v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < h0) {
+        if (x + 3 < w0) __builtin_memcpy(&v[p], src + (size_t)y * w0 + x, 16);
+        else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < 4; k++) if (x + k < w0) t[k] = src[(size_t)y * w0 + x + k];
+          v[p] = make_float4(t[0], t[1], t[2], t[3]);
+        }
       }
     }
-    s_a[ly * 32 + lx + 0] = v.x; s_a[ly * 32 + lx + 1] = v.y; s_a[ly * 32 + lx + 2] = v.z; s_a[ly * 32 + lx + 3] = v.w;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int x = x0 + lx, y = y0 + lyb + 16 * p, ly = lyb + 16 * p;
+      if (y < h0) {
+        if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
+        else {
+          const float t[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+          for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
+        }
+      }
+      *reinterpret_cast<float4*>(&s_a[ly * PYR_TILE + lx]) = v[p];
+    }
   }
   __syncthreads();
   float* cur = s_a;
   float* nxt = s_b;
-  int side = 32;
+  int side = PYR_TILE;
   for (int l = 1; l < G.levels; l++) {
     const int ns = side >> 1;
-    if ((int)threadIdx.x < ns * ns) {
-      const int lx = threadIdx.x % ns, ly = threadIdx.x / ns;
+    for (int o = threadIdx.x; o < ns * ns; o += 256) {
+      const int lx = o % ns, ly = o / ns;
       const int b = 2 * lx + 2 * ly * side;
       const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + side] + cur[b + side + 1]);
       nxt[ly * ns + lx] = val;
