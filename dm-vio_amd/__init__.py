@@ -527,8 +527,11 @@ class BundleAdjusterHip:
         F = case["n_frames"]
         poses = np.ascontiguousarray(case["poses0"] if poses is None else poses, dtype=np.float64).reshape(F, 7)
         idepth = np.ascontiguousarray(case["idepth0"] if idepth is None else idepth, dtype=np.float32)
-        self.set_window(slots, poses, np.zeros((F, 2)), np.ones(F, dtype=np.float32), np.arange(F, dtype=np.int32), case["K4"])
-        self.set_graph(case["host"], case["u"], case["v"], idepth, case["color"], case["weights"], None, case["res_point"], case["res_target"])
+        aff = np.zeros((F, 2)) if case.get("aff") is None else case["aff"]
+        expo = np.ones(F, dtype=np.float32) if case.get("exposure") is None else case["exposure"]
+        fids = np.arange(F, dtype=np.int32) if case.get("frameIDs") is None else case["frameIDs"]
+        self.set_window(slots, poses, aff, expo, fids, case["K4"])
+        self.set_graph(case["host"], case["u"], case["v"], idepth, case["color"], case["weights"], case.get("hasDepthPrior"), case["res_point"], case["res_target"])
 
     def set_window(self, slots, poses7_w2c, aff_ab, exposures, frameIDs, K4):
         self.F = len(slots); self.n = 4 + 8 * self.F

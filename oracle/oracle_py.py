@@ -366,14 +366,20 @@ class BAWindow:
         K4 = np.ascontiguousarray(case["K4"], dtype=np.float64)
         self.p = C.c_void_p(self.L.orc_ba_create(case["w"], case["h"], _d(K4)))
         self.L.orc_ba_set_threads(self.p, threads)
-        self._dI = [make_images(img, case["w"], case["h"])[0][0] for img in case["imgs"]]
+        self._dI = case["dI0"] if case.get("dI0") is not None else [make_images(img, case["w"], case["h"])[0][0] for img in case["imgs"]]
         poses = case["poses0"] if poses is None else poses
         idepth = case["idepth0"] if idepth is None else idepth
-        for k in range(case["n_frames"]):
-            self.L.orc_ba_add_frame(self.p, _d(np.ascontiguousarray(poses[k], dtype=np.float64)), 0.0, 0.0, 1.0, k, _f(self._dI[k]))
+        F = case["n_frames"]
+        aff = np.zeros((F, 2)) if case.get("aff") is None else np.asarray(case["aff"], dtype=np.float64)
+        expo = np.ones(F) if case.get("exposure") is None else np.asarray(case["exposure"], dtype=np.float64)
+        fids = np.arange(F) if case.get("frameIDs") is None else np.asarray(case["frameIDs"])
+        for k in range(F):
+            self.L.orc_ba_add_frame(self.p, _d(np.ascontiguousarray(poses[k], dtype=np.float64)), float(aff[k, 0]), float(aff[k, 1]), float(expo[k]), int(fids[k]),
+                                    _f(self._dI[k]))
         col = np.ascontiguousarray(case["color"], dtype=np.float32); wts = np.ascontiguousarray(case["weights"], dtype=np.float32)
+        hdp = np.zeros(len(case["u"]), np.uint8) if case.get("hasDepthPrior") is None else np.asarray(case["hasDepthPrior"], dtype=np.uint8)
         for i in range(len(case["u"])):
-            self.L.orc_ba_add_point(self.p, int(case["host"][i]), float(case["u"][i]), float(case["v"][i]), float(idepth[i]), _f(col[i]), _f(wts[i]), 0)
+            self.L.orc_ba_add_point(self.p, int(case["host"][i]), float(case["u"][i]), float(case["v"][i]), float(idepth[i]), _f(col[i]), _f(wts[i]), int(hdp[i]))
         for pi, ti in zip(case["res_point"], case["res_target"]):
             self.L.orc_ba_add_residual(self.p, int(pi), int(ti))
         self.L.orc_ba_finalize(self.p)
