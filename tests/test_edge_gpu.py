@@ -1,0 +1,75 @@
+"""Edge cases through the C ABI: empty inputs, degenerate windows, out-of-range arguments — the library must answer with the
+reference's conventions (tracking failed / nothing to do) or a clean error, never crash."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+def test_tracker_empty_reference_and_bad_slots(pkg, oracle, synth, gpu_required):
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=300)
+    ctx = pkg.Context(w, h, n_slots=3)
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, case["frames"][0]["img"])
+    # no reference points at all: every level is empty -> NaN residuals, tracking reported as failed, outputs finite or untouched
+    e = np.zeros(0, np.float32)
+    trk.setCoarseTrackingRef(0, e, e, e, e)
+    assert all(trk.pc_n(l) == 0 for l in range(ctx.levels))
+    r = trk.trackNewestCoarse(1, IDENT, [0.0, 0.0])
+    T = oracle.Tracker(w, h); T.make_k(case["K4"])
+    dIr, _ = oracle.make_images(case["ref_img"], w, h); dIn, _ = oracle.make_images(case["frames"][0]["img"], w, h)
+    T.set_ref(dIr, e, e, e, e); T.set_new(dIn)
+    o = T.track(IDENT, [0.0, 0.0])
+    assert bool(r["good"]) == bool(o["good"]) == False
+    # a single reference point, far outside after the warp
+    one = lambda x: np.array([x], np.float32)
+    trk.setCoarseTrackingRef(0, one(5), one(5), one(0.5), one(1e-3))
+    far = oracle.se3_exp(np.array([5.0, 0, 0, 0, 0, 0]))
+    r = trk.trackNewestCoarse(1, far, [0.0, 0.0])
+    assert not r["good"]
+    with pytest.raises(pkg.HipLibraryError):
+        ctx.frame_upload(7, case["ref_img"])
+    with pytest.raises(pkg.HipLibraryError):
+        trk.trackNewestCoarse(9, IDENT, [0.0, 0.0])
+
+
+def test_ba_degenerate_windows(pkg, oracle, synth, gpu_required):
+    # two keyframes (the reference forces 20 iterations), a host without points, a point with a single residual
+    case = synth.ba_case(256, 192, n_frames=2, n_points=60, hosts_share=(60, 0), seed=41)
+    ctx = pkg.Context(256, 192, n_slots=2)
+    for k in range(2):
+        ctx.frame_upload(k, case["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx); ba.set_case(case, [0, 1])
+    W = oracle.BAWindow(case)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"]
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * max(ro["finalEnergy"], 1e-9)
+    # marginalising with no candidates is a no-op
+    dec, H, b, n = ba.marginalize_points(np.zeros(ba.N, np.uint8))
+    assert n == 0 and not dec.any() and not H.any() and not b.any()
+    with pytest.raises(pkg.HipLibraryError):
+        ba.set_frame_state(5, np.zeros(10))
+
+
+def test_immature_empty_and_initializer_empty(pkg, oracle, synth, gpu_required):
+    w = h = 128
+    ctx = pkg.Context(w, h, n_slots=2)
+    img = synth.PlaneWorld(3).render(synth.default_intrinsics(w, h), np.eye(3), np.zeros(3), w, h)[0]
+    ctx.frame_upload(0, img); ctx.frame_upload(1, img)
+    imm = pkg.ImmaturePointsHip(ctx, capacity=16)
+    assert imm.n == 0
+    counts = imm.traceNewCoarse(1, IDENT, IDENT[None], synth.default_intrinsics(w, h))      # nothing to trace
+    assert sum(counts.values()) == 0
+    res, idp, rs = imm.optimize([0, 1], np.stack([IDENT, IDENT]), synth.default_intrinsics(w, h))
+    assert len(res) == 0
+    with pytest.raises(pkg.HipLibraryError):
+        imm.add_points(0, 0, np.arange(40) % 100 + 10, np.arange(40) % 100 + 10)                # capacity exceeded
+    ini = pkg.CoarseInitializerHip(ctx, capacity=8)
+    ini.set_points(dict(u=np.zeros(0), v=np.zeros(0), iR=np.zeros(0), isGood=np.zeros(0, np.uint8), energy=np.zeros((0, 2)), outlierTH=np.zeros(0)))
+    K4 = synth.default_intrinsics(w, h)
+    Ki = np.linalg.inv(np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]]))
+    g = ini.calcResAndGS(0, 0, 1, Ki, K4, IDENT, (0.0, 0.0), np.zeros(0, np.float32))
+    assert not g["H"][3:, 3:].any() and g["res3"][0] == 0 and g["res3"][2] == 0
