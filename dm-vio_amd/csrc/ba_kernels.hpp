@@ -732,107 +732,141 @@ __device__ __forceinline__ double rowDotT(const double* T /*8x8: A*B*/, const do
   return s;
 }
 
-// top: one workgroup per host h, loop over targets t; bucket k = h + F*t : B = acc.H (13x13)
-__global__ void __launch_bounds__(64) k_ba_stitch_top(const int F, const int nsplit, const float* __restrict__ acc /* F*F x nsplit x 96 */,
-                                                       const int* __restrict__ num, const double* __restrict__ adHost, const double* __restrict__ adTarget,
-                                                       const StitchBufs S) {
-  __shared__ double sB[13][13], sAH[64], sAT[64], sT1[64], sT2[64];
-  const int hI = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
-  double hh = 0, hc = 0, bh = 0, cc = 0;
-  for (int t = 0; t < F; t++) {
-    const int k = hI + F * t;
-    __syncthreads();
-    // unpack the 91 sums into the symmetric 13x13 (finish(), MatrixAccumulators.h:621-653)
-    for (int q = e; q < 169; q += 64) {
-      int i = q / 13, j = q % 13;
-      if (i > j) { int tt = i; i = j; j = tt; }
-      int slot;
-      if (j < 10) slot = i * 10 - (i * (i - 1)) / 2 + (j - i);
-      else if (i < 10) slot = 55 + i * 3 + (j - 10);
-      else slot = 85 + ((i == 10) ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5));
-      double v = 0.0;
-      for (int sp = 0; sp < nsplit; sp++) if (num[k * nsplit + sp] > 0) v += (double)acc[(k * nsplit + sp) * 96 + slot];
-      sB[q / 13][q % 13] = v;
-    }
-    sAH[e] = adHost[k * 64 + e]; sAT[e] = adTarget[k * 64 + e];
-    __syncthreads();
-    double t1 = 0, t2 = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) { t1 += sAH[r * 8 + q] * sB[4 + q][4 + c]; t2 += sAT[r * 8 + q] * sB[4 + q][4 + c]; }
-    sT1[e] = t1; sT2[e] = t2;
-    __syncthreads();
-    hh += rowDotT(sT1, sAH, r, c);
-    S.topTT[k * 64 + e] = rowDotT(sT2, sAT, r, c);
-    S.topHT[k * 64 + e] = rowDotT(sT1, sAT, r, c);
-    if (c < 4) {
-      double h1 = 0, h2 = 0;
-#pragma unroll
-      for (int q = 0; q < 8; q++) { h1 += sAH[r * 8 + q] * sB[4 + q][c]; h2 += sAT[r * 8 + q] * sB[4 + q][c]; }
-      hc += h1; S.topTC[k * 32 + r * 4 + c] = h2;
-    }
-    if (c == 4) {
-      double b1 = 0, b2 = 0;
-#pragma unroll
-      for (int q = 0; q < 8; q++) { b1 += sAH[r * 8 + q] * sB[4 + q][12]; b2 += sAT[r * 8 + q] * sB[4 + q][12]; }
-      bh += b1; S.topBT[k * 8 + r] = b2;
-    }
-    if (e < 16) cc += sB[e >> 2][e & 3];
-    else if (e < 20) cc += sB[e - 16][12];
-  }
-  S.topHH[hI * 64 + e] = hh;
-  if (c < 4) S.topHC[hI * 32 + r * 4 + c] = hc;
-  if (c == 4) S.topBH[hI * 8 + r] = bh;
-  if (e < 20) S.topCC[hI * 20 + e] = cc;
-}
+// Step 1 in ONE launch of F + F*F workgroups, F wavefronts each (one wavefront per inner index, results summed over the inner
+// index in index order by wavefront 0 — the same fp64 sums as a sequential loop, computed F-way in parallel):
+//   blocks [0, F):      host h, wavefront t: bucket k = h + F*t, B = acc.H (13x13)
+//   blocks [F, F+F*F):  pair (i,j), wavefront k: accD index (i + F*j) + k*F*F; wavefront 0 also stitches accE / accEB
+struct StitchWave { double B[13][13]; double AH[64], AT[64], T1[64], T2[64]; double pHH[64], pHC[32], pBH[8], pCC[20]; };
 
-// SC: one workgroup per (i,j), loop over k; accD index = ((i + F*j) + k*F*F)
-__global__ void __launch_bounds__(64) k_ba_stitch_sc(const int F, const int nsplit, const int nsplitE, const float* __restrict__ accD, const int* __restrict__ numD,
-                                                      const float* __restrict__ accE /* F*F x nsplitE x 40 */,
-                                                      const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
-  __shared__ double sD[64], sAHij[64], sATij[64], sAHik[64], sATik[64], sT1[64], sT2[64], sE[40];
-  const int ij = blockIdx.x, e = threadIdx.x, r = e >> 3, c = e & 7;
-  const int F2 = F * F, i = ij % F;
-  sAHij[e] = adHost[ij * 64 + e]; sATij[e] = adTarget[ij * 64 + e];
-  if (e < 40) {
+__device__ __forceinline__ void stitchTopWave(StitchWave& W, const int F, const int hI, const int t, const int nsplit, const float* __restrict__ acc,
+                                              const int* __restrict__ num, const double* __restrict__ adHost, const double* __restrict__ adTarget,
+                                              const StitchBufs& S, const int e) {
+  const int r = e >> 3, c = e & 7;
+  const int k = hI + F * t;
+  // unpack the 91 sums into the symmetric 13x13 (finish(), MatrixAccumulators.h:621-653)
+  for (int q = e; q < 169; q += 64) {
+    int i = q / 13, j = q % 13;
+    if (i > j) { int tt = i; i = j; j = tt; }
+    int slot;
+    if (j < 10) slot = i * 10 - (i * (i - 1)) / 2 + (j - i);
+    else if (i < 10) slot = 55 + i * 3 + (j - 10);
+    else slot = 85 + ((i == 10) ? (j - 10) : (i == 11 ? 3 + (j - 11) : 5));
     double v = 0.0;
-    for (int sp = 0; sp < nsplitE; sp++) v += (double)accE[(ij * nsplitE + sp) * 40 + e];
-    sE[e] = v;
+    for (int sp = 0; sp < nsplit; sp++) if (num[k * nsplit + sp] > 0) v += (double)acc[(k * nsplit + sp) * 96 + slot];
+    W.B[q / 13][q % 13] = v;
   }
-  double hh = 0, th = 0;
-  for (int kk = 0; kk < F; kk++) {
-    const int ijk = ij + kk * F2, ik = i + F * kk;
-    __syncthreads();
-    {
-      double v = 0.0;
-      for (int sp = 0; sp < nsplit; sp++) if (numD[ijk * nsplit + sp] > 0) v += (double)accD[(ijk * nsplit + sp) * 64 + e];
-      sD[e] = v;
-    }
-    sAHik[e] = adHost[ik * 64 + e]; sATik[e] = adTarget[ik * 64 + e];
-    __syncthreads();
-    double t1 = 0, t2 = 0;
+  W.AH[e] = adHost[k * 64 + e]; W.AT[e] = adTarget[k * 64 + e];
+  waveSync();
+  double t1 = 0, t2 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { t1 += sAHij[r * 8 + q] * sD[q * 8 + c]; t2 += sATij[r * 8 + q] * sD[q * 8 + c]; }
-    sT1[e] = t1; sT2[e] = t2;
-    __syncthreads();
-    hh += rowDotT(sT1, sAHik, r, c);
-    th += rowDotT(sT2, sAHik, r, c);
-    S.scTT[ijk * 64 + e] = rowDotT(sT2, sATik, r, c);
-    S.scHT[ijk * 64 + e] = rowDotT(sT1, sATik, r, c);
-  }
-  S.scHH[ij * 64 + e] = hh;
-  S.scTH[ij * 64 + e] = th;
-  // accE (8x4) and accEB (8)
+  for (int q = 0; q < 8; q++) { t1 += W.AH[r * 8 + q] * W.B[4 + q][4 + c]; t2 += W.AT[r * 8 + q] * W.B[4 + q][4 + c]; }
+  W.T1[e] = t1; W.T2[e] = t2;
+  waveSync();
+  W.pHH[e] = rowDotT(W.T1, W.AH, r, c);
+  S.topTT[k * 64 + e] = rowDotT(W.T2, W.AT, r, c);
+  S.topHT[k * 64 + e] = rowDotT(W.T1, W.AT, r, c);
   if (c < 4) {
     double h1 = 0, h2 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { h1 += sAHij[r * 8 + q] * sE[q * 4 + c]; h2 += sATij[r * 8 + q] * sE[q * 4 + c]; }
-    S.scHC[ij * 32 + r * 4 + c] = h1; S.scTC[ij * 32 + r * 4 + c] = h2;
+    for (int q = 0; q < 8; q++) { h1 += W.AH[r * 8 + q] * W.B[4 + q][c]; h2 += W.AT[r * 8 + q] * W.B[4 + q][c]; }
+    W.pHC[r * 4 + c] = h1; S.topTC[k * 32 + r * 4 + c] = h2;
   }
   if (c == 4) {
     double b1 = 0, b2 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { b1 += sAHij[r * 8 + q] * sE[32 + q]; b2 += sATij[r * 8 + q] * sE[32 + q]; }
-    S.scBH[ij * 8 + r] = b1; S.scBT[ij * 8 + r] = b2;
+    for (int q = 0; q < 8; q++) { b1 += W.AH[r * 8 + q] * W.B[4 + q][12]; b2 += W.AT[r * 8 + q] * W.B[4 + q][12]; }
+    W.pBH[r] = b1; S.topBT[k * 8 + r] = b2;
+  }
+  if (e < 16) W.pCC[e] = W.B[e >> 2][e & 3];
+  else if (e < 20) W.pCC[e] = W.B[e - 16][12];
+}
+
+__device__ __forceinline__ void stitchScWave(StitchWave& W, const int F, const int ij, const int kk, const int nsplit, const float* __restrict__ accD,
+                                             const int* __restrict__ numD, const double* __restrict__ adHost, const double* __restrict__ adTarget,
+                                             const StitchBufs& S, const int e) {
+  const int r = e >> 3, c = e & 7;
+  const int F2 = F * F, i = ij % F;
+  const int ijk = ij + kk * F2, ik = i + F * kk;
+  // LDS reuse inside the wavefront's slot: B (169 doubles) holds D in [0,64) and AH_ik in [64,128); AT_ik lives in pHH
+  double* sD = &W.B[0][0];
+  double* AHik = &W.B[0][0] + 64;
+  double* ATik = W.pHH;
+  {
+    double v = 0.0;
+    for (int sp = 0; sp < nsplit; sp++) if (numD[ijk * nsplit + sp] > 0) v += (double)accD[(ijk * nsplit + sp) * 64 + e];
+    sD[e] = v;
+  }
+  W.AH[e] = adHost[ij * 64 + e]; W.AT[e] = adTarget[ij * 64 + e];
+  AHik[e] = adHost[ik * 64 + e]; ATik[e] = adTarget[ik * 64 + e];
+  waveSync();
+  double t1 = 0, t2 = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) { t1 += W.AH[r * 8 + q] * sD[q * 8 + c]; t2 += W.AT[r * 8 + q] * sD[q * 8 + c]; }
+  W.T1[e] = t1; W.T2[e] = t2;
+  waveSync();
+  const double hh = rowDotT(W.T1, AHik, r, c), th = rowDotT(W.T2, AHik, r, c);
+  S.scTT[ijk * 64 + e] = rowDotT(W.T2, ATik, r, c);
+  S.scHT[ijk * 64 + e] = rowDotT(W.T1, ATik, r, c);
+  waveSync();
+  // partials for the ordered sum over k: reuse T1 / T2
+  W.T1[e] = hh; W.T2[e] = th;
+}
+
+__global__ void __launch_bounds__(512) k_ba_stitch(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
+                                                    const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE /* F*F x nsTop x 40 */,
+                                                    const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
+  extern __shared__ double s_dyn[];
+  StitchWave* Ws = reinterpret_cast<StitchWave*>(s_dyn);
+  const int wave = threadIdx.x >> 6, e = threadIdx.x & 63, r = e >> 3, c = e & 7;
+  if ((int)blockIdx.x < F) {
+    const int hI = blockIdx.x;
+    stitchTopWave(Ws[wave], F, hI, wave, nsTop, accTop, numTop, adHost, adTarget, S, e);
+    __syncthreads();
+    if (wave == 0) {
+      double hh = 0, hc = 0, bh = 0, cc = 0;
+      for (int t = 0; t < F; t++) {
+        hh += Ws[t].pHH[e];
+        if (c < 4) hc += Ws[t].pHC[r * 4 + c];
+        if (c == 4) bh += Ws[t].pBH[r];
+        if (e < 20) cc += Ws[t].pCC[e];
+      }
+      S.topHH[hI * 64 + e] = hh;
+      if (c < 4) S.topHC[hI * 32 + r * 4 + c] = hc;
+      if (c == 4) S.topBH[hI * 8 + r] = bh;
+      if (e < 20) S.topCC[hI * 20 + e] = cc;
+    }
+  } else {
+    const int ij = blockIdx.x - F;
+    stitchScWave(Ws[wave], F, ij, wave, nsD, accD, numD, adHost, adTarget, S, e);
+    __syncthreads();
+    if (wave == 0) {
+      double hh = 0, th = 0;
+      for (int kk = 0; kk < F; kk++) { hh += Ws[kk].T1[e]; th += Ws[kk].T2[e]; }
+      S.scHH[ij * 64 + e] = hh;
+      S.scTH[ij * 64 + e] = th;
+      // accE (8x4) and accEB (8): AH_ij / AT_ij are still in this wavefront's AH / AT
+      StitchWave& W = Ws[0];
+      double* sE = &W.B[0][0];
+      waveSync();
+      if (e < 40) {
+        double v = 0.0;
+        for (int sp = 0; sp < nsTop; sp++) v += (double)accE[(ij * nsTop + sp) * 40 + e];
+        sE[e] = v;
+      }
+      waveSync();
+      if (c < 4) {
+        double h1 = 0, h2 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { h1 += W.AH[r * 8 + q] * sE[q * 4 + c]; h2 += W.AT[r * 8 + q] * sE[q * 4 + c]; }
+        S.scHC[ij * 32 + r * 4 + c] = h1; S.scTC[ij * 32 + r * 4 + c] = h2;
+      }
+      if (c == 4) {
+        double b1 = 0, b2 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { b1 += W.AH[r * 8 + q] * sE[32 + q]; b2 += W.AT[r * 8 + q] * sE[32 + q]; }
+        S.scBH[ij * 8 + r] = b1; S.scBT[ij * 8 + r] = b2;
+      }
+    }
   }
 }
 

@@ -156,8 +156,8 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
     }
     hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV);
   }
-  hipLaunchKernelGGL(k_ba_stitch_top, dim3(F), dim3(64), 0, s, F, b->nsTop, b->d_accTop, b->d_numTop, b->d_adHost, b->d_adTarget, b->SB);
-  hipLaunchKernelGGL(k_ba_stitch_sc, dim3(F2), dim3(64), 0, s, F, b->nsD, b->nsTop, b->d_accD, b->d_numD, b->d_accE, b->d_adHost, b->d_adTarget, b->SB);
+  hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
+                     b->d_adHost, b->d_adTarget, b->SB);
   const int tot = 2 * (n * n + n);
   hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys);
   HIPCHK(hipGetLastError());

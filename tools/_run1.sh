@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_tracker_gpu.py tests/test_io_gpu.py -q -m gpu > gpurun_out/t1.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t1.log
+timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_sequence_gpu.py -q -m gpu > gpurun_out/t1.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t1.log
 grep -E "^E |passed|failed|rc=|Error" gpurun_out/t1.log | cut -c1-300 | head -20
-for b in 1024; do timeout 300 python bench.py --no-cpu --no-ba --batch $b --steps 10 --warmup 3 2>&1 | tail -1 | python -c "
+DMVIO_HIP_BA_TIMING=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --batch 64 2>&1 | grep -E "dmvio_hip_ba|GN-iters" | sed 's/.*"ba": /ba: /' | cut -c1-300
+timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --batch 64 2>&1 | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); r = d['roofline']
-print('B=%d kernel %.4f ms  frac %.3f  pyramid %.4f ms %.0f GB/s step %.3f ms value %.0f' % (d['config']['frames_per_step_per_gpu'], r['kernel_ms'], r['frac'], r['pyramid_kernel_ms'], r['pyramid_GBps'], d['ms_per_step'], d['value']))"; done
+d = json.loads(sys.stdin.read()); print('BA its/s', d['ba']['value'], d['ba']['ms_per_iter'])"
