@@ -249,14 +249,29 @@ __global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const B
   if (pi >= W.N) return;
   float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
   int ngood = 0;
-  for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) {
-    if (!Rs.active[ri]) continue;
-    const float* __restrict__ rec = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
-    bd += rec[REC_BD];
-    Hdd += rec[REC_HDD];
+  const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
+  // the 6 floats of up to 8 residuals are requested together (independent loads), then added in residual order
+  for (int rb = r0; rb < r1; rb += 8) {
+    float v[8][6];
+    bool act[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) Hcd[k] += rec[REC_HCD + k];
-    ngood++;
+    for (int q = 0; q < 8; q++) {
+      const int ri = min(rb + q, r1 - 1);
+      act[q] = rb + q < r1 && Rs.active[ri] != 0;
+      const float* __restrict__ rec = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
+      v[q][0] = rec[REC_BD]; v[q][1] = rec[REC_HDD];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[q][2 + k] = rec[REC_HCD + k];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (!act[q]) continue;
+      bd += v[q][0];
+      Hdd += v[q][1];
+#pragma unroll
+      for (int k = 0; k < 4; k++) Hcd[k] += v[q][2 + k];
+      ngood++;
+    }
   }
   P.Hdd[pi] = Hdd; P.bd[pi] = bd;
 #pragma unroll

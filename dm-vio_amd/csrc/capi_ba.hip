@@ -27,6 +27,7 @@ struct dmvio_hip_ba {
   BARes Rs{};
   // host copies of the graph
   std::vector<int> h_host, h_point, h_target, h_res_begin;
+  std::vector<int> h_newest;   // residuals that target the newest keyframe (inputs of setNewFrameEnergyTH), ascending
   std::vector<unsigned char> h_prior_flag;
   // device storage
   std::vector<void*> allocs;
@@ -121,8 +122,8 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   *energy = e;
   // setNewFrameEnergyTH (FullSystemOptimize.cpp:96-149)
   std::vector<float> all;
-  all.reserve(H.R);
-  for (int ri = 0; ri < H.R; ri++) if (b->h_newEnergyWO[ri] >= 0 && b->h_target[ri] == H.F - 1) all.push_back(b->h_newEnergyWO[ri]);
+  all.reserve(b->h_newest.size());
+  for (int ri : b->h_newest) if (b->h_newEnergyWO[ri] >= 0) all.push_back(b->h_newEnergyWO[ri]);
   H.fr[H.F - 1].frameEnergyTH = H.newFrameEnergyTH(all);
   return 0;
 }
@@ -335,6 +336,8 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   const int F = H.F, F2 = F * F;
   H.N = N; H.R = R;
   b->h_host.assign(host, host + N); b->h_point.assign(res_point, res_point + R); b->h_target.assign(res_target, res_target + R);
+  b->h_newest.clear();
+  for (int ri = 0; ri < R; ri++) if (res_target[ri] == H.F - 1) b->h_newest.push_back(ri);
   // residuals must be grouped by point, points in window order
   b->h_res_begin.assign(N + 1, 0);
   for (int ri = 0; ri < R; ri++) {
