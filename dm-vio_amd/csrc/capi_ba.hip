@@ -48,7 +48,7 @@ struct dmvio_hip_ba {
   int pre_toggle = 0;
   float* d_fullJ = nullptr;
   int n_lin_blocks = 0, n_pt_blocks = 0;
-  // partial accumulators per bucket (1 = replay the single-threaded reference bit for bit; DMVIO_HIP_BA_EXACT=1)
+  // partial accumulators per bucket: 1 (default) replays the single-threaded reference order bit for bit; DMVIO_HIP_BA_SPLIT=k uses k
   int nsTop = 1, nsD = 1, nsC = 1;
   bool graph_ready = false;
   // energies of the last optimize
