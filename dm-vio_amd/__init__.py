@@ -574,6 +574,7 @@ class BundleAdjusterHip:
              np.ascontiguousarray(idepth, dtype=np.float32), np.ascontiguousarray(color, dtype=np.float32), np.ascontiguousarray(weights, dtype=np.float32)]
         hp = None if hasDepthPrior is None else np.ascontiguousarray(hasDepthPrior, dtype=np.uint8)
         rp = np.ascontiguousarray(res_point, dtype=np.int32); rt = np.ascontiguousarray(res_target, dtype=np.int32)
+        self._n_newest = int((rt == self.F - 1).sum())
         u8 = C.POINTER(C.c_ubyte)
         _chk(self.L, self.L.dmvio_hip_ba_set_graph(self.p, self.N, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), _f(a[4]), _f(a[5]),
                                                    None if hp is None else hp.ctypes.data_as(u8), self.R, _i(rp), _i(rt)), "ba_set_graph")
@@ -649,6 +650,10 @@ class BundleAdjusterHip:
 
     def restore(self):
         _chk(self.L, self.L.dmvio_hip_ba_restore(self.p), "ba_restore")
+
+    def count_newest_residuals(self):
+        """Residuals of this graph that target the newest keyframe (the inputs of setNewFrameEnergyTH)."""
+        return self._n_newest
 
     def linearize_local(self, fix=False):
         e = C.c_double(0); n = C.c_int(0); buf = np.zeros(self.R, dtype=np.float32)

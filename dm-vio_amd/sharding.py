@@ -6,8 +6,9 @@ a GPU; the ONLY exchange of a Gauss-Newton iteration is the sum of the packed de
 
     [ H_A (n*n) | b_A (n) | H_sc (n*n) | b_sc (n) | energy | resInA ]      n = 4 + 8F  (75 KB for F = 8)
 
-— one small all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests) — plus an all-gather of the newest-frame residual
-energies for setNewFrameEnergyTH (FullSystemOptimize.cpp:96-149).  Every rank then solves the identical reduced system.
+— one small all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests) — plus ONE fixed-width all-gather per linearisation carrying
+[local energy | count | newest-frame residual energies] for the accept test and setNewFrameEnergyTH (FullSystemOptimize.cpp:96-149).
+Every rank then solves the identical reduced system.
 
 This module is harness-level plumbing (numpy + torch.distributed); the arithmetic lives behind the C ABI.
 """
@@ -76,54 +77,98 @@ def new_frame_energy_th(energies, th_n=0.7, fac_median=1.5, const_weight=0.5, ov
 
 
 class Collective:
-    """Thin wrapper over torch.distributed (nccl = RCCL on ROCm, or gloo on CPU); world == 1 degenerates to identity."""
+    """Thin wrapper over torch.distributed (nccl = RCCL on ROCm, or gloo on CPU); world == 1 degenerates to identity.
+    Buffers are persistent (no per-call allocation); with a device the exchange goes HBM -> RCCL -> HBM."""
 
     def __init__(self, dist=None, device=None):
         self.dist = dist
         self.device = device
         self.world = dist.get_world_size() if dist is not None else 1
+        self._bufs = {}
+
+    def _buf(self, key, n, dtype):
+        import torch
+        b = self._bufs.get(key)
+        if b is None or b[0].numel() != n:
+            host = torch.zeros(n, dtype=dtype)
+            if self.device is not None:
+                host = host.pin_memory()
+            dev = torch.zeros(n, dtype=dtype, device=self.device) if self.device is not None else host
+            b = (host, dev)
+            self._bufs[key] = b
+        return b
 
     def allreduce_sum(self, arr):
+        arr = np.asarray(arr, dtype=np.float64)
         if self.world == 1:
-            return np.asarray(arr, dtype=np.float64)
+            return arr
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
-        if self.device is not None:
-            t = t.to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        host, dev = self._buf("ar", arr.size, torch.float64)
+        host.numpy()[:] = arr.ravel()
+        if dev is not host:
+            dev.copy_(host, non_blocking=True)
+        self.dist.all_reduce(dev, op=self.dist.ReduceOp.SUM)
+        if dev is not host:
+            host.copy_(dev)
+        return host.numpy().copy()
+
+    def allgather_fixed(self, arr, width):
+        """All ranks contribute exactly `width` float64 values; returns [world, width]."""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world == 1:
+            return arr.reshape(1, width)
+        import torch
+        host, dev = self._buf("ag_in", width, torch.float64)
+        ohost, odev = self._buf("ag_out", width * self.world, torch.float64)
+        host.numpy()[:] = arr
+        if dev is not host:
+            dev.copy_(host, non_blocking=True)
+        self.dist.all_gather_into_tensor(odev, dev)
+        if odev is not ohost:
+            ohost.copy_(odev)
+        return ohost.numpy().reshape(self.world, width).copy()
 
     def allgather_var(self, arr):
         """Concatenate variable-length float32 arrays of all ranks (rank order)."""
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         if self.world == 1:
             return arr
+        n = int(self.allreduce_max(arr.size))
+        pad = np.zeros(n + 1, np.float64); pad[0] = arr.size; pad[1:1 + arr.size] = arr
+        g = self.allgather_fixed(pad, n + 1)
+        return np.concatenate([row[1:1 + int(row[0])] for row in g]).astype(np.float32)
+
+    def allreduce_max(self, v):
+        if self.world == 1:
+            return v
         import torch
-        n = torch.tensor([arr.size], dtype=torch.int64, device=self.device)
-        sizes = [torch.zeros_like(n) for _ in range(self.world)]
-        self.dist.all_gather(sizes, n)
-        sizes = [int(s.item()) for s in sizes]
-        m = max(max(sizes), 1)
-        pad = torch.zeros(m, dtype=torch.float32, device=self.device)
-        pad[:arr.size] = torch.from_numpy(arr).to(pad.device)
-        outs = [torch.zeros_like(pad) for _ in range(self.world)]
-        self.dist.all_gather(outs, pad)
-        return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)])
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
 
 class ShardedBA:
     """FullSystem::optimize's GN loop over a window whose points are sharded across ranks.  `ba` is this rank's
-    BundleAdjusterHip holding its shard (all frames, its points); `coll` a Collective."""
+    BundleAdjusterHip holding its shard (all frames, its points); `coll` a Collective.
+    Exchanges per Gauss-Newton iteration: ONE all-reduce of the packed system and ONE fixed-width all-gather per linearisation
+    ([local energy | count | newest-frame residual energies], width fixed at begin())."""
 
     def __init__(self, ba, coll):
         self.ba, self.coll = ba, coll
         self.lam = 1e-5
         self.lastE = None
+        self.width = None
 
     def _linearize(self, fix=False):
         e_local, nf = self.ba.linearize_local(fix)
-        e = float(self.coll.allreduce_sum(np.array([e_local]))[0])
-        self.ba.set_new_frame_energy_th(new_frame_energy_th(self.coll.allgather_var(nf)))
+        if self.width is None:      # residuals that target the newest keyframe: a property of the graph, agreed on once
+            self.width = 2 + int(self.coll.allreduce_max(self.ba.count_newest_residuals()))
+        buf = np.zeros(self.width, np.float64)          # float64 carries the local energy exactly; the float32 energies fit losslessly
+        buf[0] = e_local; buf[1] = len(nf); buf[2:2 + len(nf)] = nf
+        g = self.coll.allgather_fixed(buf, self.width)
+        e = float(np.sum(g[:, 0]))                       # rank order: deterministic
+        allnf = np.concatenate([row[2:2 + int(row[1])] for row in g]).astype(np.float32)
+        self.ba.set_new_frame_energy_th(new_frame_energy_th(allnf))
         return e
 
     def begin(self):

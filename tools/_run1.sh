@@ -1,8 +1,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_sequence_gpu.py -q -m gpu > gpurun_out/t1.log 2>&1; echo "pytest rc=$?" >> gpurun_out/t1.log
-grep -E "^E |passed|failed|rc=|Error" gpurun_out/t1.log | cut -c1-300 | head -20
-DMVIO_HIP_BA_TIMING=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --batch 64 2>&1 | grep -E "dmvio_hip_ba|GN-iters" | sed 's/.*"ba": /ba: /' | cut -c1-300
-timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --batch 64 2>&1 | tail -1 | python -c "
+export DMVIO_BENCH_SHARE_DEVICE=1 DMVIO_BENCH_BACKEND=gloo
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --batch 256 > gpurun_out/n2.log 2>&1
+grep -E "Error|error|Traceback" -A8 gpurun_out/n2.log | head -40
+tail -1 gpurun_out/n2.log | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('BA its/s', d['ba']['value'], d['ba']['ms_per_iter'])"
+d = json.loads(sys.stdin.read()); print(d['n_gpus'], d['value'], json.dumps(d['ba'])[:600])"
