@@ -205,8 +205,13 @@ def main():
     # ---------------- BA leg: Gauss-Newton iterations / s of the 8-keyframe sliding-window photometric BA (rank 0 window per rank)
     ba_out = None
     if not args.no_ba:
-        ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, coll_dev=coll_dev, torch=torch,
-                          cpu=(rank == 0 and world == 1 and not args.no_cpu))
+        try:
+            ba_out = bench_ba(args, pkg, synth, ctx_device=local_rank, rank=rank, world=world, dist=dist, dev=dev, coll_dev=coll_dev, torch=torch,
+                              cpu=(rank == 0 and world == 1 and not args.no_cpu))
+        except Exception as ex:      # the secondary leg must not take the headline line down with it
+            if world == 1:
+                raise
+            ba_out = dict(error="%s: %s" % (type(ex).__name__, ex))
 
     # ---------------- trace leg (rank 0, N = 1): FullSystem::traceNewCoarse over 7 hosts x 1500 immature points
     trace_out = None
