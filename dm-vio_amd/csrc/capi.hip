@@ -40,7 +40,10 @@ struct dmvio_hip_tracker {
   LMProblemOut *d_out = nullptr, *h_out = nullptr;
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
-  int lm_threads_override = 0, lm_waves_override = 0;
+  int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0;
+  float* d_cl_part = nullptr;          // cluster mode: B x 2 x C x ACC_PAD partial sums
+  unsigned int* d_cl_cnt = nullptr;    // cluster mode: arrive counters
+  size_t cl_part_cap = 0; int cl_cnt_cap = 0;
 };
 
 std::string& dmv_err() { static thread_local std::string e; return e; }
@@ -298,6 +301,7 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * ACC_PAD, hipHostMallocDefault));
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);
+  if (const char* e = getenv("DMVIO_HIP_LM_CLUSTER")) t->lm_cluster_override = atoi(e);
   return t;
 }
 
@@ -311,6 +315,8 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
   hipHostFree(t->h_tot);
   hipFree(t->d_in); hipFree(t->d_out);
+  if (t->d_cl_part) hipFree(t->d_cl_part);
+  if (t->d_cl_cnt) hipFree(t->d_cl_cnt);
   if (t->h_in) hipHostFree(t->h_in);
   if (t->h_out) hipHostFree(t->h_out);
   delete t;
@@ -441,7 +447,7 @@ static int ensureBatch(dmvio_hip_tracker* t, int B) {
   if (t->d_in) { HIPCHK(hipFree(t->d_in)); HIPCHK(hipFree(t->d_out)); HIPCHK(hipHostFree(t->h_in)); HIPCHK(hipHostFree(t->h_out)); }
   t->batch_cap = std::max(B, 64);
   HIPCHK(hipMalloc((void**)&t->d_in, sizeof(LMProblemIn) * t->batch_cap));
-  HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut) * t->batch_cap));
+  HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut) * (t->batch_cap + 1)));   // + the discard entry of cluster mode
   HIPCHK(hipHostMalloc((void**)&t->h_in, sizeof(LMProblemIn) * t->batch_cap, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&t->h_out, sizeof(LMProblemOut) * t->batch_cap, hipHostMallocDefault));
   return 0;
@@ -476,18 +482,31 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
   const int B = t->staged_B;
-  // workgroup size: one problem per workgroup.  Few problems -> wide workgroups (latency); many -> narrow ones (more
-  // problems resident per CU).  Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES.
-  const int T = t->lm_threads_override ? t->lm_threads_override : (B <= 128 ? 1024 : 256);
+  // Few problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs 367 us
+  // for one 1024-thread workgroup); up to 128 problems -> one 1024-thread workgroup each; more -> 256-thread workgroups, four resident
+  // per CU (throughput).  Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES / DMVIO_HIP_LM_CLUSTER.
+  int C = 1;
+  if (t->lm_cluster_override > 0) C = t->lm_cluster_override;
+  else if (!t->lm_threads_override) C = B <= 8 ? 8 : (B <= 16 ? 4 : (B <= 32 ? 2 : 1));
+  if ((long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
+  const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : 256));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
-#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest)
-  if (T == 1024) DMV_LAUNCH_LM(1024, 4);
-  else if (T == 512 && W >= 6) DMV_LAUNCH_LM(512, 6);
-  else if (T == 512) DMV_LAUNCH_LM(512, 4);
+  ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr;
+  if (C > 1) {
+    const size_t need = (size_t)B * 2 * C * ACC_PAD;
+    if (need > t->cl_part_cap) { if (t->d_cl_part) HIPCHK(hipFree(t->d_cl_part)); HIPCHK(hipMalloc((void**)&t->d_cl_part, sizeof(float) * need)); t->cl_part_cap = need; }
+    if (B > t->cl_cnt_cap) { if (t->d_cl_cnt) HIPCHK(hipFree(t->d_cl_cnt)); HIPCHK(hipMalloc((void**)&t->d_cl_cnt, sizeof(unsigned int) * B)); t->cl_cnt_cap = B; }
+    HIPCHK(hipMemsetAsync(t->d_cl_cnt, 0, sizeof(unsigned int) * B, c->stream));
+    cl.part = t->d_cl_part; cl.cnt = t->d_cl_cnt;
+  }
+#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest, cl)
+  if (T == 1024 && C == 1) DMV_LAUNCH_LM(1024, 4);
+  else if (T == 512 && W >= 6 && C == 1) DMV_LAUNCH_LM(512, 6);
+  else if (T == 512 && C == 1) DMV_LAUNCH_LM(512, 4);
   else if (T == 256 && W >= 6) DMV_LAUNCH_LM(256, 6);
   else if (T == 256) DMV_LAUNCH_LM(256, 4);
-  else if (T == 128) DMV_LAUNCH_LM(128, 4);
-  else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024");
+  else if (T == 128 && C == 1) DMV_LAUNCH_LM(128, 4);
+  else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024 (cluster mode: 256)");
 #undef DMV_LAUNCH_LM
   HIPCHK(hipGetLastError());
   return 0;

@@ -615,9 +615,35 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
 
 // W = minimum waves per SIMD the register allocator must leave room for (launch-bounds hint): the LM control step
 // (fp64) wants more registers than the evaluation loop; W trades its spills against the occupancy of the gathers.
+// Cluster mode (few problems in flight): C workgroups share one alignment problem.  Every evaluation is split over the C
+// workgroups (point index first = rank*T + thread, stride C*T); the per-workgroup sums are exchanged through global memory behind
+// one device-scope arrive counter, every workgroup adds the C partials in rank order and runs the (deterministic) LM control
+// step redundantly — one inter-workgroup barrier per evaluation, no second one.  Partials are double-buffered by evaluation
+// parity; the launch guarantees B*C <= resident workgroups, so the spin cannot deadlock.
+struct ClusterArgs { int C; float* part; /* B x 2 x C x ACC_PAD */ unsigned int* cnt; /* B, zeroed before the launch */ };
+
+__device__ __forceinline__ void clusterExchange(float* s_tot, const ClusterArgs& cl, const int prob, const int rank, const unsigned int phase) {
+  float* __restrict__ mine = cl.part + (((size_t)prob * 2 + (phase & 1u)) * cl.C + rank) * ACC_PAD;
+  if (threadIdx.x < ACC_PAD) __hip_atomic_store(mine + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(cl.cnt + prob, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int target = (unsigned int)cl.C * (phase + 1u);
+    while (__hip_atomic_load(cl.cnt + prob, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  if (threadIdx.x < ACC_PAD) {
+    const float* __restrict__ all = cl.part + ((size_t)prob * 2 + (phase & 1u)) * cl.C * ACC_PAD;
+    float s = 0.0f;
+    for (int r = 0; r < cl.C; r++) s += __hip_atomic_load(all + r * ACC_PAD + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
 template <int T, int W>
 __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in,
-                                                 LMProblemOut* __restrict__ out, const int coarsestLvl) {
+                                                 LMProblemOut* __restrict__ out, const int coarsestLvl, const ClusterArgs cl) {
   __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
   __shared__ float s_partH[(T / 64) * 256];
   __shared__ float s_partS[T / 64][8];
@@ -626,8 +652,10 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   __shared__ double s_H[64], s_b[8], s_x[8];
   __shared__ int s_go, s_trk[8];
   __shared__ LMState S;  // written by lane 0 of wave 0 only
-  const LMProblemIn& pin = in[blockIdx.x];
-  LMProblemOut& pout = out[blockIdx.x];
+  const int prob = blockIdx.x / cl.C, rank = blockIdx.x % cl.C;
+  const LMProblemIn& pin = in[prob];
+  LMProblemOut& pout = out[rank == 0 ? prob : (int)(gridDim.x / cl.C)];   // non-leading workgroups write into the spare entry after the batch
+  unsigned int phase = 0;
   if (threadIdx.x == 0) {
     S.cur = poseFrom7(pin.pose7);
     S.affA = pin.aff[0]; S.affB = pin.aff[1];
@@ -651,7 +679,9 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     tStep += t1 - t0;
     if (!s_go) break;
     const int lvl = s_e.lvl;
-    blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, fs.level(slot, lvl), trk.huberTH, s_stage, s_partH, s_partS, s_tot);
+    blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage, s_partH,
+                 s_partS, s_tot);
+    if (cl.C > 1) { clusterExchange(s_tot, cl, prob, rank, phase); phase++; }
     tEval += wall_clock64() - t1;
   }
   if (threadIdx.x == 0) {
@@ -663,8 +693,10 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     pout.ticks_step = tStep;
     pout.ticks_eval = tEval;
   }
-  if (threadIdx.x < 64) pout.H[threadIdx.x] = s_H[threadIdx.x];
-  if (threadIdx.x < 8) pout.b[threadIdx.x] = s_b[threadIdx.x];
+  if (rank == 0) {
+    if (threadIdx.x < 64) pout.H[threadIdx.x] = s_H[threadIdx.x];
+    if (threadIdx.x < 8) pout.b[threadIdx.x] = s_b[threadIdx.x];
+  }
 }
 
 }  // namespace dmv
