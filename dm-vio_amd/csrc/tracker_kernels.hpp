@@ -387,6 +387,12 @@ __device__ __forceinline__ double rhsEntryFromSums(const float* tot, const int r
   return ((double)tot[accIdx(r, 8)] * invn) * scr;
 }
 
+// value of `v` in lane `src` when `src` is wave-uniform: two v_readlane_b32 (a few cycles) instead of the LDS-crossbar shuffle (~100+)
+__device__ __forceinline__ double readLaneD(const double v, const int src) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)b, src), hi = __builtin_amdgcn_readlane((unsigned int)(b >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 // Wave-cooperative LDL^T with symmetric diagonal pivoting (largest |d| first — the pivot rule of the
 // decomposition CoarseTracker.cpp:639 calls).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).
 // Returns x(r) in every lane of row r.
@@ -397,20 +403,20 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
 #pragma unroll 1
   for (int k = 0; k < 8; k++) {
     int p = k;
-    double best = fabs(__shfl(m, k * 9, 64));
+    double best = fabs(readLaneD(m, k * 9));
 #pragma unroll 1
     for (int i = k + 1; i < 8; i++) {
-      const double v = fabs(__shfl(m, i * 9, 64));
+      const double v = fabs(readLaneD(m, i * 9));
       if (v > best) { best = v; p = i; }
     }
     if (lane == 0) s_trk[k] = p;
-    {
+    if (p != k) {   // wave-uniform: the symmetric row / column swap is only needed when the pivot is not already in place
       const int pr = (r == k) ? p : ((r == p) ? k : r);
       const int pc = (c == k) ? p : ((c == p) ? k : c);
       m = __shfl(m, pr * 8 + pc, 64);
       dv = __shfl(dv, pr * 8 + c, 64);
     }
-    const double dk = __shfl(m, k * 9, 64);
+    const double dk = readLaneD(m, k * 9);
     const bool ok = fabs(dk) > 0;
     const double mrk = __shfl(m, r * 8 + k, 64);
     const double mck = __shfl(m, c * 8 + k, 64);
@@ -422,7 +428,7 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
   // forward substitution  (L y = P b)
 #pragma unroll 1
   for (int k = 0; k < 8; k++) {
-    const double dkv = __shfl(dv, k * 8, 64);
+    const double dkv = readLaneD(dv, k * 8);
     const double Lrk = __shfl(m, r * 8 + k, 64);
     if (r > k) dv = dv - Lrk * dkv;
   }
@@ -433,7 +439,7 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
   // backward substitution  (L^T x = z)
 #pragma unroll 1
   for (int k = 7; k >= 0; k--) {
-    const double dkv = __shfl(dv, k * 8, 64);
+    const double dkv = readLaneD(dv, k * 8);
     const double Lkr = __shfl(m, k * 8 + r, 64);
     if (r < k) dv = dv - Lkr * dkv;
   }
@@ -442,7 +448,8 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 1
   for (int k = 7; k >= 0; k--) {
-    const int p = s_trk[k];
+    const int p = __builtin_amdgcn_readfirstlane(s_trk[k]);
+    if (p == k) continue;   // wave-uniform
     const int pr = (r == k) ? p : ((r == p) ? k : r);
     dv = __shfl(dv, pr * 8 + c, 64);
   }
