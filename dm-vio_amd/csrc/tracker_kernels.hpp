@@ -425,23 +425,26 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
     if (r > k && c > k) m = m - Lrk * (dk * Lck);
     if (c == k && r > k) m = Lrk;
   }
+  // row r and column r of L are gathered ONCE (16 independent cross-lane reads, pipelined); the substitutions then only need
+  // wave-uniform reads of the running solution — no dependent shuffle per step
+  double Lrow[8], Lcol[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { Lrow[k] = __shfl(m, r * 8 + k, 64); Lcol[k] = __shfl(m, k * 8 + r, 64); }
   // forward substitution  (L y = P b)
-#pragma unroll 1
+#pragma unroll
   for (int k = 0; k < 8; k++) {
     const double dkv = readLaneD(dv, k * 8);
-    const double Lrk = __shfl(m, r * 8 + k, 64);
-    if (r > k) dv = dv - Lrk * dkv;
+    if (r > k) dv = dv - Lrow[k] * dkv;
   }
   {
     const double D = __shfl(m, r * 9, 64);
     dv = (fabs(D) > 2.2250738585072014e-308) ? dv / D : 0.0;
   }
   // backward substitution  (L^T x = z)
-#pragma unroll 1
+#pragma unroll
   for (int k = 7; k >= 0; k--) {
     const double dkv = readLaneD(dv, k * 8);
-    const double Lkr = __shfl(m, k * 8 + r, 64);
-    if (r < k) dv = dv - Lkr * dkv;
+    if (r < k) dv = dv - Lcol[k] * dkv;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
