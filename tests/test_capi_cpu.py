@@ -46,3 +46,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("see oracle/", ""), os.path.join(dp, f)
+
+
+def test_header_is_plain_c_and_cxx(pkg, tmp_path):
+    """include/dmvio_hip.h is the drop-in boundary: it must compile as C99 and as C++11 on its own (no torch / HIP / Eigen types), and a
+    C++ translation unit that takes the address of every declared entry point must link against the shared library."""
+    import subprocess
+    hdr = pkg.INCLUDE_PATH
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr])
+    subprocess.check_call(["g++", "-fsyntax-only", "-x", "c++", "-std=c++11", "-Wall", "-Werror", hdr])
+    src = tmp_path / "link_all.cpp"
+    syms = pkg.declared_symbols()
+    src.write_text('#include "%s"\n#include <cstdio>\nint main() {\n  const void* p[] = {%s};\n  std::printf("%%d\\n", (int)(sizeof(p) / sizeof(p[0])));\n  return p[0] ? 0 : 1;\n}\n'
+                   % (hdr, ", ".join("(const void*)&%s" % s for s in syms)))
+    exe = tmp_path / "link_all"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", str(src), "-o", str(exe), "-L" + libdir, "-ldmvio_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
