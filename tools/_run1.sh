@@ -1,7 +1,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_tracker_gpu.py -q -m gpu 2>&1 | tail -2
-for b in 1 31; do MB_BATCH=$b timeout 120 python tools/microbench.py 2>&1 | grep track_lm | tail -1; done
-timeout 300 python bench.py --no-cpu --no-ba --steps 10 --warmup 3 2>&1 | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); r = d['roofline']
-print('B=1024 kernel %.4f ms  frac %.3f  step %.3f ms value %.0f' % (r['kernel_ms'], r['frac'], d['ms_per_step'], d['value']))"
+mkdir -p gpurun_out; rm -rf gpurun_out/p_stats gpurun_out/p_fetch gpurun_out/p_write
+timeout 600 python bench.py > gpurun_out/bench_full.log 2>&1; tail -1 gpurun_out/bench_full.log | cut -c1-300
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/p_stats -o stats -- python bench.py --no-cpu > gpurun_out/p_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/p_fetch -o fetch -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > gpurun_out/p_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/p_write -o write -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > gpurun_out/p_write.log 2>&1
+DMVIO_HIP_BA_TIMING=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --batch 64 2>&1 | grep -E "dmvio_hip_ba" > gpurun_out/ba_timing.log
+python tools/rocprof_summary.py gpurun_out/p_stats/*.db | head -6 | cut -c1-160
