@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
   float outU = -1.f, outV = -1.f, outInterval = 0.f;
   bool writeInterval = false;   // idepth_min / idepth_max updated
   const float maxPixSearch = (w + h) * S.maxPixSearch;
-  // ============== project min and max. return if one of them is OOB ===================
+  // 1. both ends of the depth interval must project inside the image
   const float pr0 = KRKi[0] * u + KRKi[1] * v + KRKi[2] * 1.0f, pr1 = KRKi[3] * u + KRKi[4] * v + KRKi[5] * 1.0f, pr2 = KRKi[6] * u + KRKi[7] * v + KRKi[8] * 1.0f;
   const float pmin0 = pr0 + Kt[0] * idepth_min, pmin1 = pr1 + Kt[1] * idepth_min, pmin2 = pr2 + Kt[2] * idepth_min;
   const float uMin = pmin0 / pmin2, vMin = pmin1 / pmin2;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
       uMax = pmax0 / pmax2; vMax = pmax1 / pmax2;
       if (!(uMax > loU && vMax > loV && uMax < hiU && vMax < hiV)) { status = IPS_OOB; done = true; }
       else {
-        // ============== check their distance. everything below 2px is OK (-> skip). ===================
+        // 2. an interval that already spans less than slackInterval pixels is left alone
         dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
         dist = sqrtf(dist);
         if (dist < S.slackInterval) { outU = (uMax + uMin) * 0.5f; outV = (vMax + vMin) * 0.5f; outInterval = dist; status = IPS_SKIPPED; done = true; }
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
   if (!done && !(idepth_min < 0 || (pmin2 > 0.75f && pmin2 < 1.5f))) { status = IPS_OOB; done = true; }
   float dx = 0.f, dy = 0.f, errorInPixel = 0.f;
   if (!done) {
-    // ============== compute error-bounds on result in pixel. if the new interval is not at least 1/2 of the old, SKIP ===================
+    // 3. localisation error from the gradient structure tensor; no trace when it cannot shrink the interval
     dx = S.stepsize * (uMax - uMin); dy = S.stepsize * (vMax - vMin);
     const float g0 = P.gradH[4 * i], g1 = P.gradH[4 * i + 1], g2 = P.gradH[4 * i + 2], g3 = P.gradH[4 * i + 3];
     const float a = (dx * g0 + dy * g2) * dx + (dx * g1 + dy * g3) * dy;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
   }
   if (!done) {
     if (errorInPixel > 10) errorInPixel = 10;
-    // ============== do the discrete search ===================
+    // 4. discrete search along the epipolar segment
     dx /= dist; dy /= dist;
     if (dist > maxPixSearch) { uMax = uMin + maxPixSearch * dx; vMax = vMin + maxPixSearch * dy; dist = maxPixSearch; }
     int numSteps = (int)(1.9999f + dist / S.stepsize);
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
       const float secondBest = waveMin(sb);
       const float newQuality = secondBest / bestEnergy;
       if (newQuality < quality || numSteps > 10) quality = newQuality;
-      // ============== do GN optimization ===================
+      // 5. Gauss-Newton refinement along the line
       float uBak = bestU, vBak = bestV, stepBack = 0.f;
       const float gnstepsize = 1;
       if (S.GNIterations > 0) bestEnergy = 1e5f;
@@ -284,14 +284,14 @@ __global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict_
         if (fabsf(stepBack) < S.GNThreshold) break;
       }
       if (!done) {
-        // ============== detect energy-based outlier. ===================
+        // 6. energy-based outlier test
         if (!(bestEnergy < P.energyTH[i] * S.extraSlackOnTH)) {
           status = (status == IPS_OUTLIER) ? IPS_OOB : IPS_OUTLIER;
           done = true;
         }
       }
       if (!done) {
-        // ============== set new interval ===================
+        // 7. new inverse-depth interval from the refined position +- the localisation error
         float nmin, nmax;
         if (dx * dx > dy * dy) {
           nmin = (pr2 * (bestU - errorInPixel * dx) - pr0) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));

@@ -59,7 +59,7 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
             float energyTH, const float* KRKi /*row-major 3x3*/, const float* Kt, const float* aff, ImmState& s) {
   if (s.lastTraceStatus == IPS_OOB) return s.lastTraceStatus;
   const float maxPixSearch = (w + h) * setting_maxPixSearch;
-  // ============== project min and max. return if one of them is OOB ===================
+  // 1. both ends of the depth interval must project inside the image
   const float pr[3] = {KRKi[0] * u + KRKi[1] * v + KRKi[2] * 1.0f, KRKi[3] * u + KRKi[4] * v + KRKi[5] * 1.0f, KRKi[6] * u + KRKi[7] * v + KRKi[8] * 1.0f};
   const float ptpMin[3] = {pr[0] + Kt[0] * s.idepth_min, pr[1] + Kt[1] * s.idepth_min, pr[2] + Kt[2] * s.idepth_min};
   const float uMin = ptpMin[0] / ptpMin[2], vMin = ptpMin[1] / ptpMin[2];
@@ -79,7 +79,7 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
     const float ptpMax[3] = {pr[0] + Kt[0] * s.idepth_max, pr[1] + Kt[1] * s.idepth_max, pr[2] + Kt[2] * s.idepth_max};
     uMax = ptpMax[0] / ptpMax[2]; vMax = ptpMax[1] / ptpMax[2];
     if (!(uMax > boundU && vMax > boundV && uMax < w - boundU - 1 && vMax < h - boundV - 1)) return oob();
-    // ============== check their distance. everything below 2px is OK (-> skip). ===================
+    // 2. an interval that already spans less than slackInterval pixels is left alone
     dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
     dist = sqrtf(dist);
     if (dist < setting_trace_slackInterval) {
@@ -99,7 +99,7 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
   }
   // set OOB if scale change too big.
   if (!(s.idepth_min < 0 || (ptpMin[2] > 0.75f && ptpMin[2] < 1.5f))) return oob();
-  // ============== compute error-bounds on result in pixel. if the new interval is not at least 1/2 of the old, SKIP ===================
+  // 3. localisation error from the gradient structure tensor; no trace when it cannot shrink the interval
   float dx = setting_trace_stepsize * (uMax - uMin), dy = setting_trace_stepsize * (vMax - vMin);
   const float a = (dx * gradH[0] + dy * gradH[2]) * dx + (dx * gradH[1] + dy * gradH[3]) * dy;
   const float b = (dy * gradH[0] + (-dx) * gradH[2]) * dy + (dy * gradH[1] + (-dx) * gradH[3]) * (-dx);
@@ -110,7 +110,7 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
     return s.lastTraceStatus = IPS_BADCONDITION;
   }
   if (errorInPixel > 10) errorInPixel = 10;
-  // ============== do the discrete search ===================
+  // 4. discrete search along the epipolar segment
   dx /= dist; dy /= dist;
   if (dist > maxPixSearch) { uMax = uMin + maxPixSearch * dx; vMax = vMin + maxPixSearch * dy; dist = maxPixSearch; }
   int numSteps = 1.9999f + dist / setting_trace_stepsize;
@@ -140,7 +140,7 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
     if ((i < bestIdx - setting_minTraceTestRadius || i > bestIdx + setting_minTraceTestRadius) && errors[i] < secondBest) secondBest = errors[i];
   const float newQuality = secondBest / bestEnergy;
   if (newQuality < s.quality || numSteps > 10) s.quality = newQuality;
-  // ============== do GN optimization ===================
+  // 5. Gauss-Newton refinement along the line
   float uBak = bestU, vBak = bestV, gnstepsize = 1, stepBack = 0;
   if (setting_trace_GNIterations > 0) bestEnergy = 1e5;
   for (int it = 0; it < setting_trace_GNIterations; it++) {
@@ -171,13 +171,13 @@ int traceOn(const float* dI, int w, int h, float u, float v, const float* color,
     }
     if (fabsf(stepBack) < setting_trace_GNThreshold) break;
   }
-  // ============== detect energy-based outlier. ===================
+  // 6. energy-based outlier test
   if (!(bestEnergy < energyTH * setting_trace_extraSlackOnTH)) {
     s.lastTracePixelInterval = 0; s.lastTraceU = -1; s.lastTraceV = -1;
     if (s.lastTraceStatus == IPS_OUTLIER) return s.lastTraceStatus = IPS_OOB;
     return s.lastTraceStatus = IPS_OUTLIER;
   }
-  // ============== set new interval ===================
+  // 7. new inverse-depth interval from the refined position +- the localisation error
   if (dx * dx > dy * dy) {
     s.idepth_min = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
     s.idepth_max = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
