@@ -368,7 +368,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
                 acc, lam, lastE = W.gn_iteration(n % 6, lam, lastE); n += 1
             res[threads] = n / (time.perf_counter() - t0)
         out["cpu_baseline"] = dict(value=round(res[6], 2), unit="GN-iters/s", cores=6, kind="port", value_1thread=round(res[1], 2),
-                                   sample="oracle gn_iteration on the same window, 6 accumulation workers (NUM_THREADS 6) and 1 thread, on %s" % _cpu_name())
+                                   sample="oracle gn_iteration on the same window: 6 workers (NUM_THREADS 6, persistent pool for linearizeAll + accumulation + resubstitution) "
+                                          "and single-threaded, on %s" % _cpu_name())
     ba.close(); ctx.close()
     return out
 

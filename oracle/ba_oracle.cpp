@@ -34,6 +34,10 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <emmintrin.h>
 #include "lie.h"
 #include "dense.h"
@@ -238,6 +242,45 @@ static inline void m33f(const float* A, const float* B, float* C) {
 
 typedef std::vector<double> Mat;  // row-major n x n or vectors
 
+// Persistent worker pool (IndexThreadReduce, src/dso/util/IndexThreadReduce.h:40-217: workers parked on a condition variable, woken per
+// reduce call) — used only by the multi-threaded timing variant of the oracle (cpu_baseline); parity tests run single-threaded.
+struct WorkerPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cvGo, cvDone;
+  std::function<void(int)> job;
+  int generation = 0, pending = 0;
+  bool stop = false;
+  explicit WorkerPool(int n) {
+    for (int t = 0; t < n; t++)
+      th.emplace_back([this, t]() {
+        int seen = 0;
+        for (;;) {
+          std::function<void(int)> fn;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cvGo.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation; fn = job;
+          }
+          fn(t);
+          { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cvDone.notify_one(); }
+        }
+      });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cvGo.notify_all();
+    for (auto& x : th) x.join();
+  }
+  void run(const std::function<void(int)>& fn) {
+    std::unique_lock<std::mutex> lk(mu);
+    job = fn; pending = (int)th.size(); generation++;
+    cvGo.notify_all();
+    cvDone.wait(lk, [&] { return pending == 0; });
+  }
+};
+
 struct OWindow {
   BASettings S;
   int w, h;
@@ -260,6 +303,7 @@ struct OWindow {
   int resInA = 0, resInL = 0;
   std::vector<Mat> ns_pose, ns_scale;
   int nThreads = 1;
+  std::unique_ptr<WorkerPool> pool;
   // statistics
   double lastEnergyTrace[64][4];
   int nIterationsDone = 0;
@@ -542,6 +586,13 @@ struct OWindow {
   }
   double linearizeAll(bool fixLinearization) {
     double lastEnergyP = 0;
+    if (!fixLinearization && nThreads > 1) {   // linearizeAll_Reductor over the worker pool (FullSystemOptimize.cpp:55-88,150-171): per-worker energy sums
+      std::vector<double> part(nThreads, 0.0);
+      parallelChunks((int)activeResiduals.size(), [&](int tid, int b0, int e0) { for (int k = b0; k < e0; k++) part[tid] += linearizeRes(res[activeResiduals[k]]); });
+      for (double v : part) lastEnergyP += v;
+      setNewFrameEnergyTH();
+      return lastEnergyP;
+    }
     for (int ri : activeResiduals) {
       ORes& r = res[ri];
       lastEnergyP += linearizeRes(r);
@@ -870,10 +921,8 @@ struct OWindow {
   template <class F>
   void parallelChunks(int n, F fn) {
     if (nThreads <= 1) { fn(0, 0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nThreads; t++)
-      th.emplace_back([&, t]() { for (int b0 = t * 50; b0 < n; b0 += nThreads * 50) fn(t, b0, std::min(n, b0 + 50)); });
-    for (auto& x : th) x.join();
+    if (!pool || (int)pool->th.size() != nThreads) pool.reset(new WorkerPool(nThreads));
+    pool->run([&](int t) { for (int b0 = t * 50; b0 < n; b0 += nThreads * 50) fn(t, b0, std::min(n, b0 + 50)); });
   }
 
   void accumulateAF(Mat& H, Mat& b) {
