@@ -53,6 +53,7 @@ def _sig(L):
     L.dmvio_hip_tracker_track_batch.argtypes = [vp, C.c_int, c_i, c_f, c_d, c_d, C.c_int, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
     L.dmvio_hip_tracker_track_batch_stage.argtypes = [vp, C.c_int, c_i, c_f, c_d, c_d, C.c_int, c_d]
     L.dmvio_hip_tracker_track_batch_launch.argtypes = [vp]
+    L.dmvio_hip_tracker_track_batch_fetch_begin.argtypes = [vp]
     L.dmvio_hip_tracker_track_batch_fetch.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
     L.dmvio_hip_make_track_hypotheses.argtypes = [c_d, c_d, c_d, c_d, C.c_int]
     L.dmvio_hip_tracker_track_new_coarse.argtypes = [vp, C.c_int, C.c_float, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, c_i, c_i, c_i]
@@ -308,6 +309,9 @@ class CoarseTrackerHip:
 
     def launch(self):
         _chk(self.L, self.L.dmvio_hip_tracker_track_batch_launch(self.p), "launch")
+
+    def fetch_begin(self):
+        _chk(self.L, self.L.dmvio_hip_tracker_track_batch_fetch_begin(self.p), "fetch_begin")
 
     def fetch(self):
         B = self._B

@@ -41,6 +41,8 @@ struct dmvio_hip_tracker {
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
   int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0;
+  hipEvent_t fetch_event = nullptr;   // marks the end of an early result download (track_batch_fetch_begin)
+  int fetch_pending_B = 0;
   float* d_cl_part = nullptr;          // cluster mode: B x 2 x C x ACC_PAD partial sums
   unsigned int* d_cl_cnt = nullptr;    // cluster mode: arrive counters
   size_t cl_part_cap = 0; int cl_cnt_cap = 0;
@@ -315,6 +317,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
   hipHostFree(t->h_tot);
   hipFree(t->d_in); hipFree(t->d_out);
+  if (t->fetch_event) hipEventDestroy(t->fetch_event);
   if (t->d_cl_part) hipFree(t->d_cl_part);
   if (t->d_cl_cnt) hipFree(t->d_cl_cnt);
   if (t->h_in) hipHostFree(t->h_in);
@@ -512,15 +515,34 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   return 0;
 }
 
+// Enqueue-only download of the results of the last launch: lets the caller queue the NEXT batch (pyramids, stage, launch) behind it
+// before blocking in _fetch, so the device never waits for the host to unpack results.
+int dmvio_hip_tracker_track_batch_fetch_begin(dmvio_hip_tracker* t) {
+  if (!t || t->staged_B <= 0) return failmsg("track_batch_fetch_begin: nothing staged");
+  dmvio_hip_ctx* c = t->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  if (!t->fetch_event) HIPCHK(hipEventCreateWithFlags(&t->fetch_event, hipEventDisableTiming));
+  HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * t->staged_B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(t->fetch_event, c->stream));
+  t->fetch_pending_B = t->staged_B;
+  return 0;
+}
+
 int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out, double* aff_out, double* lastResiduals, double* lastFlow,
                                         double* H, double* b, int* good, int* iterations) {
   if (!t || t->staged_B <= 0) return failmsg("track_batch_fetch: nothing staged");
   dmvio_hip_ctx* c = t->ctx;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  const int B = t->staged_B;
-  HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * B, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  int B = t->staged_B;
+  if (t->fetch_pending_B > 0) {   // download already queued by _fetch_begin: wait for it only
+    B = t->fetch_pending_B; t->fetch_pending_B = 0;
+    HIPCHK(hipEventSynchronize(t->fetch_event));
+  } else {
+    HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   long long ev = 0, pe = 0;
   t->last_ticks_step = t->last_ticks_eval = 0;
   for (int i = 0; i < B; i++) {
