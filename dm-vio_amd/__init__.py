@@ -87,6 +87,7 @@ def _sig(L):
     L.dmvio_hip_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
     L.dmvio_hip_ba_get_marg_prior.argtypes = [vp, c_d, c_d]
     L.dmvio_hip_ba_marginalize_points.argtypes = [vp, C.c_char_p, C.POINTER(C.c_ubyte), c_d, c_d, c_i, C.c_int]
+    L.dmvio_hip_ba_set_stream.argtypes = [vp, vp]
     L.dmvio_hip_ba_create.restype = vp
     L.dmvio_hip_ba_create.argtypes = [vp]
     L.dmvio_hip_ba_destroy.argtypes = [vp]
@@ -536,6 +537,9 @@ class BundleAdjusterHip:
         fids = np.arange(F, dtype=np.int32) if case.get("frameIDs") is None else case["frameIDs"]
         self.set_window(slots, poses, aff, expo, fids, case["K4"])
         self.set_graph(case["host"], case["u"], case["v"], idepth, case["color"], case["weights"], case.get("hasDepthPrior"), case["res_point"], case["res_target"])
+
+    def set_stream(self, stream_ptr):
+        _chk(self.L, self.L.dmvio_hip_ba_set_stream(self.p, C.c_void_p(stream_ptr)), "ba_set_stream")
 
     def set_window(self, slots, poses7_w2c, aff_ab, exposures, frameIDs, K4):
         self.F = len(slots); self.n = 4 + 8 * self.F

@@ -20,6 +20,11 @@ struct BATimes { double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n = 0; };
 static inline double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct dmvio_hip_ba {
+  // The mapping side owns a HIP stream and a lock of its own: the tracking thread (context stream, context lock) and the mapping
+  // thread (this stream, this lock) overlap on the device like coarseTracker / mapping do in the reference (FullSystem.cpp:980-985).
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::mutex mu;
   dmvio_hip_ctx* ctx = nullptr;
   BAHost H;
   BAWindow W{};
@@ -84,7 +89,6 @@ static void freeDevice(dmvio_hip_ba* b) {
 }
 
 static int uploadWindowTables(dmvio_hip_ba* b) {
-  dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   BAWindow& W = b->W;
   W.F = H.F; W.w = H.w; W.h = H.h; W.N = H.N; W.R = H.R;
@@ -96,13 +100,12 @@ static int uploadWindowTables(dmvio_hip_ba* b) {
   // two pinned staging copies: at most one earlier upload can still be in flight (every linearize ends with a stream sync)
   BAPrecalc* stage = b->h_pre[b->pre_toggle ^= 1];
   memcpy(stage, H.pre.data(), sizeof(BAPrecalc) * H.F * H.F);
-  HIPCHK(hipMemcpyAsync(b->d_pre, stage, sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b->d_pre, stage, sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, b->stream));
   return 0;
 }
 static int uploadAdjoints(dmvio_hip_ba* b) {
-  dmvio_hip_ctx* c = b->ctx;
-  HIPCHK(hipMemcpyAsync(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), hipMemcpyHostToDevice, b->stream));
   return 0;
 }
 
@@ -111,12 +114,12 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b)) return r;  // precalc + frameEnergyTH of the current state
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, c->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
-  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, c->stream, H.R, b->Rs, (const unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
+  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(b->h_newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * H.R, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(b->h_newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * H.R, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
   double e = 0;
   for (int i = 0; i < b->n_lin_blocks; i++) e += b->h_epart[i];
   *energy = e;
@@ -128,22 +131,21 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   return 0;
 }
 static int applyRes(dmvio_hip_ba* b) {
-  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->ctx->stream, b->H.R, b->Rs, (const unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->stream, b->H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
 static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P);
 static int accumulate(dmvio_hip_ba* b) {
-  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->ctx->stream, b->W, b->P, b->Rs);
+  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs);
   return accumulateViews(b, b->Rs, b->P);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
 static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV) {
-  dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   const int F = H.F, F2 = F * F, n = H.n();
-  hipStream_t s = c->stream;
+  hipStream_t s = b->stream;
   {
     AccumArgs A;
     A.F = F; A.N = H.N; A.nsTop = b->nsTop; A.nsD = b->nsD; A.nsC = b->nsC;
@@ -168,26 +170,24 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   return 0;
 }
 static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
-  dmvio_hip_ctx* c = b->ctx;
   float xc[4];
   std::vector<float> xAd;
   b->H.prepareResubstitute(x, xc, xAd);
   // pinned staging; the previous upload was consumed before the accumulate sync that produced x
   memcpy(b->h_xstage, xc, sizeof(xc));
   memcpy(b->h_xstage + 4, xAd.data(), sizeof(float) * xAd.size());
-  HIPCHK(hipMemcpyAsync(b->d_xc, b->h_xstage, sizeof(float) * (4 + xAd.size()), hipMemcpyHostToDevice, c->stream));   // d_xAd = d_xc + 4
-  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd);
+  HIPCHK(hipMemcpyAsync(b->d_xc, b->h_xstage, sizeof(float) * (4 + xAd.size()), hipMemcpyHostToDevice, b->stream));   // d_xAd = d_xc + 4
+  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd);
   HIPCHK(hipGetLastError());
   return 0;
 }
 // mode 0 backup, 1 step from backup, 2 restore; the step-norm sums (mode 1) are only fetched when the caller asks for them
 static int pointStep(dmvio_hip_ba* b, int mode, float fac, float* sumID, float* sumNID) {
-  dmvio_hip_ctx* c = b->ctx;
-  hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, c->stream, b->H.N, b->P, mode, fac, b->d_spart);
+  hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->H.N, b->P, mode, fac, b->d_spart);
   HIPCHK(hipGetLastError());
   if (mode == 1 && sumID && sumNID) {
-    HIPCHK(hipMemcpyAsync(b->h_spart, b->d_spart, sizeof(float) * 2 * b->n_pt_blocks, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(b->h_spart, b->d_spart, sizeof(float) * 2 * b->n_pt_blocks, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     float a = 0, d = 0;
     for (int i = 0; i < b->n_pt_blocks; i++) { a += b->h_spart[2 * i]; d += b->h_spart[2 * i + 1]; }
     *sumID = a / b->H.N; *sumNID = d / b->H.N;
@@ -199,8 +199,11 @@ extern "C" {
 
 dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   if (!ctx) { failmsg("ba_create: null ctx"); return nullptr; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { failmsg("ba_create: hipSetDevice failed"); return nullptr; }
   dmvio_hip_ba* b = new dmvio_hip_ba();
   b->ctx = ctx;
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { failmsg("ba_create: stream creation failed"); delete b; return nullptr; }
+  b->own_stream = true;
   b->H.w = ctx->w; b->H.h = ctx->h;
   // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
@@ -210,7 +213,7 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
 void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
-  hipStreamSynchronize(b->ctx->stream);
+  hipStreamSynchronize(b->stream);
   if (b->timing && b->tm.n > 0) {
     const char* names[8] = {"backup", "accumulate+D2H", "host solve", "resubstitute", "step frames+points", "precalc", "linearize+TH", "apply/restore"};
     fprintf(stderr, "[dmvio_hip_ba] GN iteration host-side split over %ld iterations (us/iter):", b->tm.n);
@@ -238,7 +241,20 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   }
   if (b->d_accTicks) hipFree(b->d_accTicks);
   freeDevice(b);
+  if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
   delete b;
+}
+
+// The stream the mapping side enqueues on (default: a stream owned by the handle).  NULL restores an own stream.
+int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
+  if (!b) return failmsg("null ba");
+  std::lock_guard<std::mutex> lk(b->mu);
+  HIPCHK(hipSetDevice(b->ctx->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->own_stream) { HIPCHK(hipStreamDestroy(b->stream)); b->own_stream = false; }
+  if (stream) b->stream = (hipStream_t)stream;
+  else { HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)); b->own_stream = true; }
+  return 0;
 }
 
 int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
@@ -284,10 +300,10 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   if (!candidates || !decision) return failmsg("ba_marginalize_points: null argument");
   dmvio_hip_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   BAHost& H = b->H;
   const int N = H.N, R = H.R, n = H.n();
-  hipStream_t s = c->stream;
+  hipStream_t s = b->stream;
   const float setting_minIdepthH_marg = 50, setting_idepthFixPriorMargFac = 600 * 600;
   const double setting_margWeightFac = 0.5 * 0.5;
   // deltas at the current state (EnergyFunctional::setDeltaF, EnergyFunctional.cpp:175-198)
@@ -329,9 +345,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   if (H.F < 1) return failmsg("ba_set_graph: set_window first");
   if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
   dmvio_hip_ctx* c = b->ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
   freeDevice(b);
   const int F = H.F, F2 = F * F;
   H.N = N; H.R = R;
@@ -386,7 +402,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   Rs.point = d_point; Rs.target = d_target;
   std::vector<float> prior(N, 0.0f);
   if (hasDepthPrior) for (int p = 0; p < N; p++) prior[p] = hasDepthPrior[p] ? H.S.idepthFixPrior : 0.0f;   // EFPoint::takeData
-  hipStream_t s = c->stream;
+  hipStream_t s = b->stream;
   HIPCHK(hipMemcpyAsync(d_host, host, sizeof(int) * N, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(d_point, res_point, sizeof(int) * R, hipMemcpyHostToDevice, s));
@@ -433,7 +449,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
 // activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
   BA_READY(b);
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->stream;
   HIPCHK(hipMemsetAsync(b->Rs.state, BA_IN, b->H.R, s));
   HIPCHK(hipMemsetAsync(b->Rs.newState, BA_OUTLIER, b->H.R, s));
   HIPCHK(hipMemsetAsync(b->Rs.energy, 0, sizeof(float) * b->H.R, s));
@@ -442,7 +458,7 @@ int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
 }
 int dmvio_hip_ba_linearize(dmvio_hip_ba* b, int fix, double* energy) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   double e = 0;
   if (int r = linearizeAll(b, fix != 0, &e)) return r;
   if (energy) *energy = e;
@@ -454,7 +470,7 @@ int dmvio_hip_ba_apply(dmvio_hip_ba* b) {
 }
 int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* newEnergy, float* newEnergyWO, unsigned char* active, float* center3) {
   BA_READY(b);
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->stream;
   const int R = b->H.R;
   if (newState) HIPCHK(hipMemcpyAsync(newState, b->Rs.newState, R, hipMemcpyDeviceToHost, s));
   if (newEnergy) HIPCHK(hipMemcpyAsync(newEnergy, b->Rs.newEnergy, sizeof(float) * R, hipMemcpyDeviceToHost, s));
@@ -467,8 +483,8 @@ int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* 
 // RawResidualJacobian of the LAST linearisation (74 floats per residual, RawResidualJacobian.h:32-61 order) — parity/debug
 int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
   BA_READY(b);
-  HIPCHK(hipMemcpyAsync(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, hipMemcpyDeviceToHost, b->ctx->stream));
-  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  HIPCHK(hipMemcpyAsync(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
 int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
@@ -478,7 +494,7 @@ int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
 }
 int dmvio_hip_ba_accumulate(dmvio_hip_ba* b, double* HA, double* bA, double* Hsc, double* bsc, int* resInA) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   if (int r = accumulate(b)) return r;
   const int n = b->H.n();
   const double* p = b->h_sys;
@@ -491,7 +507,7 @@ int dmvio_hip_ba_accumulate(dmvio_hip_ba* b, double* HA, double* bA, double* Hsc
 }
 int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hcd4, float* HdiF, float* bdSumF) {
   BA_READY(b);
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->stream;
   const int N = b->H.N;
   if (Hdd) HIPCHK(hipMemcpyAsync(Hdd, b->P.Hdd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
   if (bd) HIPCHK(hipMemcpyAsync(bd, b->P.bd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
@@ -505,7 +521,7 @@ int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hc
 // BAGTSAMIntegration::computeBAUpdate in VIO mode, EnergyFunctional.cpp:958-969), back-substitute on the device.
 int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_out) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   if (int r = accumulate(b)) return r;
   const int n = b->H.n();
   const double* p = b->h_sys;
@@ -517,13 +533,13 @@ int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_
 }
 int dmvio_hip_ba_resubstitute(dmvio_hip_ba* b, const double* x) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   std::vector<double> xv(x, x + b->H.n());
   return resubstitute(b, xv);
 }
 int dmvio_hip_ba_get_points(dmvio_hip_ba* b, float* idepth, float* step) {
   BA_READY(b);
-  hipStream_t s = b->ctx->stream;
+  hipStream_t s = b->stream;
   if (idepth) HIPCHK(hipMemcpyAsync(idepth, b->P.idepth, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
   if (step) HIPCHK(hipMemcpyAsync(step, b->P.step, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -541,7 +557,7 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double a
 // without keyframe `frame` ((n-8) x (n-8), n-8); also returns the current prior when HM_cur / bM_cur are given.
 int dmvio_hip_ba_marginalize_frame(dmvio_hip_ba* b, int frame, double* HM_new, double* bM_new) {
   if (!b || !HM_new || !bM_new || frame < 0 || frame >= b->H.F) return failmsg("ba_marginalize_frame: bad argument");
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   std::vector<double> Hn, bn;
   b->H.marginalizeFrame(frame, Hn, bn);
   memcpy(HM_new, Hn.data(), sizeof(double) * Hn.size());
@@ -558,7 +574,7 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
 // FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
   if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetState(b->H.fr[f], state10);
   b->H.setPrecalcValues();
   return 0;
@@ -574,7 +590,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   BAHost& H = b->H;
   const int n = H.n();
   double t0 = nowUs(), t1;
-#define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->ctx->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
+#define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
   // backupState
   H.backupFrames();
   if (int r = pointStep(b, 0, 0.f, nullptr, nullptr)) return r;
@@ -623,7 +639,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
 
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io, double lastE[3], int* accepted) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   bool acc = false;
   double lam = *lambda_io;
   if (int r = gnIteration(b, iteration, lam, lastE, acc)) return r;
@@ -636,7 +652,7 @@ int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io,
 // local systems / energies of all ranks (RCCL all-reduce) between these calls; every rank then solves the identical reduced system.
 int dmvio_hip_ba_backup(dmvio_hip_ba* b) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   b->H.backupFrames();
   float d0, d1;
   return pointStep(b, 0, 0.f, &d0, &d1);
@@ -644,7 +660,7 @@ int dmvio_hip_ba_backup(dmvio_hip_ba* b) {
 int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* x_out) {
   BA_READY(b);
   if (!HA || !bA || !Hsc || !bsc) return failmsg("ba_solve_system: null argument");
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   b->H.getNullspaces();
   std::vector<double> x;
   b->H.solveSystem(iteration, lambda, HA, bA, Hsc, bsc, x);
@@ -653,7 +669,7 @@ int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, con
 }
 int dmvio_hip_ba_step(dmvio_hip_ba* b, float stepfac, float sums6[6]) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   float fs[4], sumID = 0, sumNID = 0;
   b->H.stepFrames(stepfac, fs);
   if (int r = pointStep(b, 1, stepfac, &sumID, &sumNID)) return r;
@@ -663,7 +679,7 @@ int dmvio_hip_ba_step(dmvio_hip_ba* b, float stepfac, float sums6[6]) {
 }
 int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   b->H.restoreFrames();
   float d0, d1;
   if (int r = pointStep(b, 2, 0.f, &d0, &d1)) return r;
@@ -675,7 +691,7 @@ int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
 // gather them over all shards.
 int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   const float keep = b->H.fr[b->H.F - 1].frameEnergyTH;
   double e = 0;
   if (int r = linearizeAll(b, fix != 0, &e)) return r;
@@ -702,7 +718,7 @@ int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
 // FullSystem::optimize (FullSystemOptimize.cpp:417-647), visual-only branch.
 int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->ctx->mu);
+  std::lock_guard<std::mutex> lk(b->mu);
   BAHost& H = b->H;
   if (H.F < 2) { if (rmse) *rmse = 0; return 0; }
   if (H.F < 3) mnumOptIts = 20;

@@ -144,6 +144,11 @@ int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* trk, long long* ticks_step, 
  * Corresponds to EnergyFunctional::insertFrame + setAdjointsF + FullSystem::setPrecalcValues. */
 dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx);
 void dmvio_hip_ba_destroy(dmvio_hip_ba* ba);
+/* Every dmvio_hip_ba handle enqueues on a HIP stream of its own and has its own lock, so the mapping thread (optimize, marginalisation)
+ * overlaps on the device with the tracking thread, which uses the context's stream — the reference's two-thread structure
+ * (FullSystem.cpp:980-985: coarseTracker on the tracking thread, mapping under mapMutex).  Frames must be resident (upload calls return
+ * after their stream synchronised) before a window refers to them.  dmvio_hip_ba_set_stream replaces the stream (NULL: own stream). */
+int dmvio_hip_ba_set_stream(dmvio_hip_ba* ba, void* hip_stream);
 int dmvio_hip_ba_set_window(dmvio_hip_ba* ba, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]);
 /* Marginalisation prior HM (n x n row-major), bM (n), n = 4 + 8F (EnergyFunctional.h:129-131); zero when never called. */

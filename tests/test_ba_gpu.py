@@ -224,3 +224,43 @@ def test_marginalize_frame_parity(pkg, oracle, synth, gpu_required):
         Hn_o, bn_o = W.marginalize_frame(k)
         assert np.linalg.norm(Hn_g - Hn_o) <= 1e-7 * np.linalg.norm(Hn_o) + 1e-9
         assert np.linalg.norm(bn_g - bn_o) <= 1e-7 * np.linalg.norm(bn_o) + 1e-9
+
+
+def test_tracking_and_mapping_overlap_on_two_threads(pkg, oracle, synth, gpu_required):
+    """The mapping side (BA handle: own HIP stream, own lock) and the tracking side (context stream) run concurrently from two host
+    threads — the reference's tracking / mapping thread structure; results are identical to the sequential runs."""
+    import threading
+    w = h = 512
+    bcase = synth.ba_case(w, h, n_frames=8, n_points=2000, seed=17)
+    tcase = synth.tracking_case(w, h, n_ref=2000, n_frames=4, xi_jitter=0.3)
+    ctx = pkg.Context(w, h, n_slots=8 + 1 + 64)
+    for k in range(8):
+        ctx.frame_upload(k, bcase["imgs"][k])
+    ctx.frame_upload(8, tcase["ref_img"])
+    B = 64
+    for i in range(B):
+        ctx.frame_upload(9 + i, tcase["frames"][i % 4]["img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(tcase["K4"])
+    trk.setCoarseTrackingRef(8, tcase["u"], tcase["v"], tcase["idepth"], tcase["hdiF"])
+    ba = pkg.BundleAdjusterHip(ctx)
+    ident = np.tile(np.array([0, 0, 0, 0, 0, 0, 1.0]), (B, 1)); aff0 = np.zeros((B, 2))
+
+    def do_track(out):
+        for _ in range(6):
+            out["r"] = trk.track_batch(list(range(9, 9 + B)), ident.copy(), aff0.copy())
+
+    def do_ba(out):
+        ba.set_case(bcase, list(range(8)))
+        out["r"] = ba.optimize(6)
+        out["poses"] = [ba.frame_pose(k)[0] for k in range(8)]
+
+    seq_t, seq_b = {}, {}
+    do_track(seq_t); do_ba(seq_b)
+    par_t, par_b = {}, {}
+    th = [threading.Thread(target=do_track, args=(par_t,)), threading.Thread(target=do_ba, args=(par_b,))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert np.array_equal(par_t["r"]["pose7"], seq_t["r"]["pose7"]) and np.array_equal(par_t["r"]["good"], seq_t["r"]["good"])
+    assert par_b["r"]["iterations"] == seq_b["r"]["iterations"] and par_b["r"]["finalEnergy"] == seq_b["r"]["finalEnergy"]
+    for a, b in zip(par_b["poses"], seq_b["poses"]):
+        assert np.array_equal(a, b)
