@@ -82,7 +82,7 @@ def main():
     B = args.batch
     # ---------------- synthetic inputs (deterministic; rank-dependent jitter so ranks do not share data)
     case = synth.tracking_case(w, h, n_ref=args.points, seed=synth.SEED + 1000 * rank, n_frames=args.distinct, xi_jitter=0.35)
-    ctx = pkg.Context(w, h, n_slots=B + 1, device=local_rank)
+    ctx = pkg.Context(w, h, n_slots=B + 1 + 8, device=local_rank)   # slot 0: reference keyframe, 1..B: batch, B+1..B+8: BA window of the overlap leg
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     trk = pkg.CoarseTrackerHip(ctx)
@@ -235,6 +235,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_ba:
         trace_out = bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu=not args.no_cpu)
 
+    # ---------------- overlap leg (rank 0, N = 1): tracking thread + mapping thread on their own HIP streams (BASELINE config 5)
+    overlap_out = None
+    if rank == 0 and world == 1 and not args.no_ba:
+        overlap_out = bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h)
+
     if rank == 0:
         out = {
             "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
@@ -250,12 +255,48 @@ def main():
             "cpu_baseline": cpu,
             "ba": ba_out,
             "trace": trace_out,
+            "overlap": overlap_out,
             "lm_iterations_mean": float(np.mean(res["iterations"])),
             "max_pose_err_m": float(terr.max()),
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h):
+    """Tracking batches (context stream) and BA iterations (BA handle's own stream) issued from two host threads: wall time of both
+    together vs one after the other — the reference's tracking / mapping threads on HIP streams."""
+    import threading
+    bcase = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED)
+    bslots = list(range(B + 1, B + 9))
+    for k in range(8):
+        ctx.frame_upload(bslots[k], bcase["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx)
+    ba.set_case(bcase, bslots)
+    # a saturating tracking batch leaves no CU free for the (tiny) BA kernels; the live-tracking regime is a few frames per call
+    Bt = min(B, 64)
+    n_t, n_m = 150, 240
+
+    def T(n):
+        for _ in range(n):
+            trk.stage(slots[:Bt], poses0[:Bt], affs0[:Bt]); trk.launch(); trk.fetch()
+
+    def M(n):
+        ba.activate_all(); e = ba.linearize_all(False); ba.apply_res()
+        lam, lastE = 1e-5, [e, 0.0, 0.0]
+        for it in range(n):
+            _, lam, lastE = ba.gn_iteration(it % 6, lam, lastE)
+
+    T(2); M(20)
+    t0 = time.perf_counter(); T(n_t); t_t = time.perf_counter() - t0
+    t0 = time.perf_counter(); M(n_m); t_m = time.perf_counter() - t0
+    a = threading.Thread(target=T, args=(n_t,)); b = threading.Thread(target=M, args=(n_m,))
+    t0 = time.perf_counter(); a.start(); b.start(); a.join(); b.join(); t_p = time.perf_counter() - t0
+    ba.close()
+    return dict(tracking_calls=n_t, frames_per_call=Bt, ba_iterations=n_m, tracking_alone_ms=round(1e3 * t_t, 2), ba_alone_ms=round(1e3 * t_m, 2),
+                sequential_ms=round(1e3 * (t_t + t_m), 2), overlapped_ms=round(1e3 * t_p, 2),
+                note="tracking on the context stream, bundle adjustment on the BA handle's stream, two host threads (no pyramid builds in this leg)")
 
 
 def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
