@@ -1,0 +1,57 @@
+"""Parity at the other BASELINE.json configurations' shapes: 640x480 sliding-window BA (EuRoC, config 3) and 800x400 with ~4000
+active points (4Seasons, config 5) — non-square images, a different number of pyramid levels, twice the points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDENT = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+def test_ba_640x480_window(pkg, oracle, synth, gpu_required):
+    case = synth.ba_case(640, 480, n_frames=8, n_points=2000, seed=51)
+    ctx = pkg.Context(640, 480, n_slots=8)
+    for k in range(8):
+        ctx.frame_upload(k, case["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx); ba.set_case(case, list(range(8)))
+    W = oracle.BAWindow(case)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"]
+    assert np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3])                       # same accept / reject sequence
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    for k in range(8):
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - case["poses_true"][k][:3]) < 0.02
+
+
+def test_tracking_and_ba_800x400_4000_points(pkg, oracle, synth, gpu_required):
+    w, h = 800, 400
+    assert pkg.Context(w, h, n_slots=1).levels == oracle.pyr_levels(w, h)
+    tc = synth.tracking_case(w, h, n_ref=4000, n_frames=2, xi_jitter=0.2)
+    ctx = pkg.Context(w, h, n_slots=10)
+    ctx.frame_upload(0, tc["ref_img"])
+    for k, f in enumerate(tc["frames"]):
+        ctx.frame_upload(1 + k, f["img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(tc["K4"])
+    trk.setCoarseTrackingRef(0, tc["u"], tc["v"], tc["idepth"], tc["hdiF"])
+    dIr, _ = oracle.make_images(tc["ref_img"], w, h)
+    T = oracle.Tracker(w, h); T.make_k(tc["K4"]); T.set_ref(dIr, tc["u"], tc["v"], tc["idepth"], tc["hdiF"])
+    for lvl in range(ctx.levels):
+        assert trk.pc_n(lvl) == T.pc_n(lvl)
+    for k, f in enumerate(tc["frames"]):
+        T.set_new(oracle.make_images(f["img"], w, h)[0])
+        g = trk.trackNewestCoarse(1 + k, IDENT, [0.0, 0.0]); o = T.track(IDENT, [0.0, 0.0])
+        assert g["good"] and o["good"]
+        assert np.linalg.norm(np.asarray(g["pose7"])[:3] - np.asarray(o["pose7"])[:3]) < 1e-3
+        assert np.linalg.norm(np.asarray(g["pose7"])[:3] - f["pose7"][:3]) < 2e-3
+        lg, lo = np.asarray(g["lastResiduals"]), np.asarray(o["lastResiduals"])
+        m = np.isfinite(lo)
+        assert np.array_equal(np.isfinite(lg), m) and np.allclose(lg[m] ** 2, lo[m] ** 2, rtol=1e-4)
+    bc = synth.ba_case(w, h, n_frames=8, n_points=4000, seed=52, hosts_share=(800, 700, 600, 600, 500, 500, 300, 0))
+    for k in range(8):
+        ctx.frame_upload(2 + k, bc["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx); ba.set_case(bc, list(range(2, 10)))
+    W = oracle.BAWindow(bc)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"]
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
