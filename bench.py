@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 1090699.3 * 1024 + 768.0 * 1024)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 1092032.2 * 1024 + 768.0 * 1024)
 BYTES_PER_POINT_EVAL = 64      # 16 B template record + 4 taps x 12 B
 
 
@@ -184,7 +184,7 @@ def main():
     # 2 x FETCH_SIZE + WRITE_SIZE per launch, valid for the default workload only
     if B == 1024 and args.points == 2000 and (w, h) == (512, 512) and args.distinct == 8:
         roofline["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH
-        roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic_batch1024.md (2 x FETCH_SIZE 1,090,699 KiB + WRITE_SIZE 768 KiB per launch; below the algorithmic bytes: L2/MALL absorb neighbouring taps)"
+        roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic_batch1024.md (2 x FETCH_SIZE 1,092,032 KiB + WRITE_SIZE 768 KiB per launch; below the algorithmic bytes: L2/MALL absorb neighbouring taps)"
     pm = None
     if not args.no_pyramid:
         pms = []
@@ -426,7 +426,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
             while time.perf_counter() - t0 < max(2.0, args.cpu_seconds / 3):
                 acc, lam, lastE = W.gn_iteration(n % 6, lam, lastE); n += 1
             res[threads] = n / (time.perf_counter() - t0)
-        out["cpu_baseline"] = dict(value=round(res[6], 2), unit="GN-iters/s", cores=6, kind="port", value_1thread=round(res[1], 2),
+        best = 6 if res[6] >= res[1] else 1   # report the faster of the reference's 6-worker configuration and a single thread
+        out["cpu_baseline"] = dict(value=round(res[best], 2), unit="GN-iters/s", cores=best, kind="port", value_6workers=round(res[6], 2), value_1thread=round(res[1], 2),
                                    sample="oracle gn_iteration on the same window: 6 workers (NUM_THREADS 6, persistent pool for linearizeAll + accumulation + resubstitution) "
                                           "and single-threaded, on %s" % _cpu_name())
     ba.close(); ctx.close()
