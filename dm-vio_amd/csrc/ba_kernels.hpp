@@ -901,42 +901,52 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
   if (tid >= 2 * per) return;
   const bool sc = tid >= per;
   const int t = sc ? tid - per : tid;
+  // sum_{q < F} base[q * stride] in index order; the (up to 8) loads are issued together, only the adds are sequential
+  auto sumF = [&](const double* __restrict__ base, const int stride) {
+    double v[BA_MAXF];
+#pragma unroll
+    for (int q = 0; q < BA_MAXF; q++) v[q] = q < F ? base[(size_t)q * stride] : 0.0;
+    double acc = 0;
+#pragma unroll
+    for (int q = 0; q < BA_MAXF; q++) if (q < F) acc += v[q];
+    return acc;
+  };
   double val = 0;
   if (t < n * n) {
     const int row = t / n, col = t % n;
     if (row < 4 && col < 4) {
-      if (!sc) { for (int q = 0; q < F; q++) val += S.topCC[q * 20 + row * 4 + col]; }
+      if (!sc) val = sumF(S.topCC + row * 4 + col, 20);
       else for (int sp = 0; sp < nsC; sp++) val += (double)accC[sp * 20 + row * 4 + col];
     } else if (row < 4 || col < 4) {
       // calib cross terms: H[fIdx.., 0..4) accumulated, mirrored into H[0..4), fIdx..)
       const int cc = row < 4 ? row : col, fr = (row < 4 ? col : row) - 4;
       const int f = fr >> 3, r = fr & 7;
-      if (!sc) { val = S.topHC[f * 32 + r * 4 + cc]; for (int q = 0; q < F; q++) val += S.topTC[(q + F * f) * 32 + r * 4 + cc]; }
-      else { for (int q = 0; q < F; q++) val += S.scHC[(f + F * q) * 32 + r * 4 + cc]; for (int q = 0; q < F; q++) val += S.scTC[(q + F * f) * 32 + r * 4 + cc]; }
+      if (!sc) { val = S.topHC[f * 32 + r * 4 + cc]; val += sumF(S.topTC + (F * f) * 32 + r * 4 + cc, 32); }
+      else { val = sumF(S.scHC + f * 32 + r * 4 + cc, F * 32); val += sumF(S.scTC + (F * f) * 32 + r * 4 + cc, 32); }
     } else {
       const int bi = (row - 4) >> 3, bj = (col - 4) >> 3, r = (row - 4) & 7, c = (col - 4) & 7;
       if (!sc) {
         // H[h,h] += HH[h,t], H[t,t] += TT[h,t], H[h,t] += HT[h,t]; then (h<t): H[h,t] += H[t,h]^T, H[t,h] = H[h,t]^T
-        if (bi == bj) { val = S.topHH[bi * 64 + r * 8 + c]; for (int q = 0; q < F; q++) val += S.topTT[(q + F * bi) * 64 + r * 8 + c]; val += S.topHT[(bi + F * bi) * 64 + r * 8 + c]; }
+        if (bi == bj) { val = S.topHH[bi * 64 + r * 8 + c]; val += sumF(S.topTT + (F * bi) * 64 + r * 8 + c, 64); val += S.topHT[(bi + F * bi) * 64 + r * 8 + c]; }
         else val = S.topHT[(bi + F * bj) * 64 + r * 8 + c] + S.topHT[(bj + F * bi) * 64 + c * 8 + r];
       } else {
         // H[i,i] += HH[ij] (all j); H[j,k] += TT[ijk] (all i); H[j,i] += TH[ij]; H[i,k] += HT[ijk] (all j)
-        if (bi == bj) for (int j = 0; j < F; j++) val += S.scHH[(bi + F * j) * 64 + r * 8 + c];
-        for (int i = 0; i < F; i++) val += S.scTT[((i + F * bi) + bj * F2) * 64 + r * 8 + c];
+        if (bi == bj) val = sumF(S.scHH + bi * 64 + r * 8 + c, F * 64);
+        val += sumF(S.scTT + ((F * bi) + bj * F2) * 64 + r * 8 + c, 64);
         val += S.scTH[(bj + F * bi) * 64 + r * 8 + c];
-        for (int j = 0; j < F; j++) val += S.scHT[((bi + F * j) + bj * F2) * 64 + r * 8 + c];
+        val += sumF(S.scHT + (bi + bj * F2) * 64 + r * 8 + c, F * 64);
       }
     }
     out[(sc ? per : 0) + t] = val;
   } else {
     const int row = t - n * n;
     if (row < 4) {
-      if (!sc) { for (int q = 0; q < F; q++) val += S.topCC[q * 20 + 16 + row]; }
+      if (!sc) val = sumF(S.topCC + 16 + row, 20);
       else for (int sp = 0; sp < nsC; sp++) val += (double)accC[sp * 20 + 16 + row];
     } else {
       const int f = (row - 4) >> 3, r = (row - 4) & 7;
-      if (!sc) { val = S.topBH[f * 8 + r]; for (int q = 0; q < F; q++) val += S.topBT[(q + F * f) * 8 + r]; }
-      else { for (int q = 0; q < F; q++) val += S.scBH[(f + F * q) * 8 + r]; for (int q = 0; q < F; q++) val += S.scBT[(q + F * f) * 8 + r]; }
+      if (!sc) { val = S.topBH[f * 8 + r]; val += sumF(S.topBT + (F * f) * 8 + r, 8); }
+      else { val = sumF(S.scBH + f * 8 + r, F * 8); val += sumF(S.scBT + (F * f) * 8 + r, 8); }
     }
     out[(sc ? per : 0) + n * n + row] = val;
   }
