@@ -244,9 +244,11 @@ __global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, c
 // ------------------------------------------------------------------------------------------------ per-point sums
 // Hdd_accAF, bd_accAF, Hcd_accAF (sequential over the point's residuals) and the head of AccumulatedSCHessianSSE::addPoint:
 // HdiF, bdSumF (AccumulatedSCHessian.cpp:36-54).
-__global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs) {
+// backup != 0 fuses the point part of backupState (FullSystemOptimize.cpp:320-352): idepth_backup = idepth
+__global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const int backup) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= W.N) return;
+  if (backup) P.idepth_backup[pi] = P.idepth[pi];
   float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
   int ngood = 0;
   const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
@@ -954,13 +956,18 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
 
 // ------------------------------------------------------------------------------------------------ back-substitution / stepping
 // xAd: F*F x 8 floats, index h*F + t (EnergyFunctional.cpp:280-282), xc: 4 floats
+// apply_step != 0 fuses doStepFromBackup for stepfac = 1 (FullSystemOptimize.cpp:224-317): idepth = idepth_zero = backup + step
 __global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ xc,
-                                                          const float* __restrict__ xAd) {
+                                                          const float* __restrict__ xAd, const int apply_step) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= W.N) return;
   int ngood = 0;
   for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) if (Rs.active[ri]) ngood++;
-  if (ngood == 0) { P.step[pi] = 0; return; }
+  if (ngood == 0) {
+    P.step[pi] = 0;
+    if (apply_step) { const float v = P.idepth_backup[pi] + 1.0f * 0.0f; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
+    return;
+  }
   float b = P.bdSumF[pi];
   float dotc = 0;
 #pragma unroll
@@ -976,7 +983,9 @@ __global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const
     for (int k = 0; k < 8; k++) d += xa[k] * q[k];
     b -= d;
   }
-  P.step[pi] = -b * P.HdiF[pi];
+  const float st = -b * P.HdiF[pi];
+  P.step[pi] = st;
+  if (apply_step) { const float v = P.idepth_backup[pi] + 1.0f * st; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
 }
 
 // mode 0: backupState (idepth_backup = idepth);  mode 1: doStepFromBackup (idepth = idepth_zero = backup + fac*step),
@@ -993,7 +1002,7 @@ __global__ void __launch_bounds__(256) k_ba_point_step(const int N, const BAPoin
       s2 = st * st; sn = fabsf(bk);
     } else { const float bk = P.idepth_backup[pi]; P.idepth[pi] = bk; P.idepth_zero[pi] = bk; }
   }
-  if (mode == 1) {
+  if (mode == 1 && partials) {
     __shared__ float a[256], b[256];
     a[threadIdx.x] = s2; b[threadIdx.x] = sn;
     __syncthreads();

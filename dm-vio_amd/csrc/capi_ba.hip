@@ -137,8 +137,8 @@ static int applyRes(dmvio_hip_ba* b) {
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
 static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P);
-static int accumulate(dmvio_hip_ba* b) {
-  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs);
+static int accumulate(dmvio_hip_ba* b, bool backup_points = false) {
+  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0);
   return accumulateViews(b, b->Rs, b->P);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
@@ -169,7 +169,7 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   H.resInA = (int)b->h_sys[tot];
   return 0;
 }
-static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
+static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x, bool apply_step = false) {
   float xc[4];
   std::vector<float> xAd;
   b->H.prepareResubstitute(x, xc, xAd);
@@ -177,13 +177,13 @@ static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x) {
   memcpy(b->h_xstage, xc, sizeof(xc));
   memcpy(b->h_xstage + 4, xAd.data(), sizeof(float) * xAd.size());
   HIPCHK(hipMemcpyAsync(b->d_xc, b->h_xstage, sizeof(float) * (4 + xAd.size()), hipMemcpyHostToDevice, b->stream));   // d_xAd = d_xc + 4
-  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd);
+  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd, apply_step ? 1 : 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
 // mode 0 backup, 1 step from backup, 2 restore; the step-norm sums (mode 1) are only fetched when the caller asks for them
 static int pointStep(dmvio_hip_ba* b, int mode, float fac, float* sumID, float* sumNID) {
-  hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->H.N, b->P, mode, fac, b->d_spart);
+  hipLaunchKernelGGL(k_ba_point_step, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->H.N, b->P, mode, fac, (mode == 1 && sumID && sumNID) ? b->d_spart : (float*)nullptr);
   HIPCHK(hipGetLastError());
   if (mode == 1 && sumID && sumNID) {
     HIPCHK(hipMemcpyAsync(b->h_spart, b->d_spart, sizeof(float) * 2 * b->n_pt_blocks, hipMemcpyDeviceToHost, b->stream));
@@ -592,24 +592,22 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   double t0 = nowUs(), t1;
 #define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
   // backupState
-  H.backupFrames();
-  if (int r = pointStep(b, 0, 0.f, nullptr, nullptr)) return r;
+  H.backupFrames();   // the point part of backupState rides in the first accumulation kernel
   BA_LAP(0);
   // solveSystem
   H.getNullspaces();
-  if (int r = accumulate(b)) return r;
+  if (int r = accumulate(b, true)) return r;
   BA_LAP(1);
   const double* p = b->h_sys;
   std::vector<double> x;
   H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
   BA_LAP(2);
-  if (int r = resubstitute(b, x)) return r;
+  if (int r = resubstitute(b, x, true)) return r;   // + the point part of doStepFromBackup (stepfac 1)
   BA_LAP(3);
-  // doStepFromBackup
-  // the step norms only feed canbreak, which stays false without the GTSAM path (FullSystemOptimize.cpp:387,583): not fetched
+  // doStepFromBackup, frames and calibration; the step norms only feed canbreak, which stays false without the GTSAM path
+  // (FullSystemOptimize.cpp:387,583): not computed
   float fs[4];
   H.stepFrames(1.0f, fs);
-  if (int r = pointStep(b, 1, 1.0f, nullptr, nullptr)) return r;
   BA_LAP(4);
   H.setPrecalcValues();
   BA_LAP(5);
