@@ -85,20 +85,53 @@ struct BARes {      // SoA, R entries
 __constant__ int c_patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:296, pattern 8
 
 // ------------------------------------------------------------------------------------------------ linearize
-__global__ void __launch_bounds__(128) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
-                                                       const FrameStore fs, double* __restrict__ energy_partials, float* __restrict__ fullJ,
-                                                       const unsigned char* __restrict__ pt_mask) {
+// Eight lanes per residual: lane idx evaluates pattern pixel idx (projection, bilinear tap, weights, its products); the sums over
+// the pattern are formed in pattern order — ((((0 + v0) + v1) + v2) ...) — by seven DPP row-shift adds per quantity, so every
+// value is bit-identical to the reference's sequential loop while the eight gathers of a residual are in flight together.
+#define LIN_THREADS 256
+#define LIN_RES_PER_BLOCK (LIN_THREADS / 8)
+__device__ __forceinline__ float dppShl(const float v, const int k) {   // value of lane (l + k) of the same 16-lane row, k = 1..7
+  int r = 0;
+  const int x = __float_as_int(v);
+  switch (k) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x101, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x102, 0xF, 0xF, true); break;
+    case 3: r = __builtin_amdgcn_update_dpp(0, x, 0x103, 0xF, 0xF, true); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0xF, true); break;
+    case 5: r = __builtin_amdgcn_update_dpp(0, x, 0x105, 0xF, 0xF, true); break;
+    case 6: r = __builtin_amdgcn_update_dpp(0, x, 0x106, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x107, 0xF, 0xF, true); break;
+  }
+  return __int_as_float(r);
+}
+// in lane 0 of every 8-lane group: 0 + v(0) + v(1) + ... + v(7), added left to right
+__device__ __forceinline__ float seqSum8(const float v) {
+  float s = 0.0f + v;
+#pragma unroll
+  for (int k = 1; k < 8; k++) s = s + dppShl(v, k);
+  return s;
+}
+
+__global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
+                                                               const FrameStore fs, double* __restrict__ energy_partials, float* __restrict__ fullJ,
+                                                               const unsigned char* __restrict__ pt_mask) {
   // pt_mask != NULL: only the residuals of the flagged points, after PointFrameResidual::resetOOB (Residuals.h:82-89) — the
   // relinearisation FullSystem::flagPointsForRemoval performs before a point is marginalised (FullSystem.cpp:836-849)
-  const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ri = blockIdx.x * LIN_RES_PER_BLOCK + (threadIdx.x >> 3), idx = threadIdx.x & 7;
+  const bool lead = idx == 0;
   double myE = 0.0;
+  // all eight lanes of a residual take the same branches below (group-uniform conditions); stores come from the leading lane
   if (ri < W.R && (!pt_mask || pt_mask[Rs.point[ri]])) {
     float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
-    Rs.newEnergyWO[ri] = -1.0f;
-    if (pt_mask) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
-    const int state = Rs.state[ri];
+    int state = Rs.state[ri];
+    const float oldEnergy = pt_mask ? 0.f : Rs.energy[ri];
+    if (pt_mask) state = BA_IN;
+    if (lead) {
+      Rs.newEnergyWO[ri] = -1.0f;
+      if (pt_mask) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
+    }
     bool done = false;
-    if (state == BA_OOB) { Rs.newState[ri] = BA_OOB; myE = Rs.energy[ri]; done = true; }
+    if (state == BA_OOB) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
     const int pi = Rs.point[ri], ti = Rs.target[ri];
     const int hi = P.host[pi];
     const BAPrecalc& pc = pre[hi + W.F * ti];
@@ -117,9 +150,9 @@ __global__ void __launch_bounds__(128) k_ba_linearize(const BAWindow W, const BA
       const float u = p0 * drescale, v = p1 * drescale;
       const float Ku = u * W.fx + W.cx, Kv = v * W.fy + W.cy;
       ok = ok && (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
-      if (!ok) { Rs.newState[ri] = BA_OOB; myE = Rs.energy[ri]; done = true; }
+      if (!ok) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
       else {
-        Rs.center[3 * ri + 0] = Ku; Rs.center[3 * ri + 1] = Kv; Rs.center[3 * ri + 2] = new_idepth;
+        if (lead) { Rs.center[3 * ri + 0] = Ku; Rs.center[3 * ri + 1] = Kv; Rs.center[3 * ri + 2] = new_idepth; }
         d_d_x = drescale * (pc.t0[0] - pc.t0[2] * u) * 1.0f * W.fx;
         d_d_y = drescale * (pc.t0[1] - pc.t0[2] * v) * 1.0f * W.fy;
         d_C_x[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
@@ -141,90 +174,99 @@ __global__ void __launch_bounds__(128) k_ba_linearize(const BAWindow W, const BA
     if (!done) {
       const float* __restrict__ img = fs.level(W.slot[ti], 0);
       const float ids = P.idepth[pi];
-      float JI00 = 0, JI11 = 0, JI10 = 0, Ja00 = 0, Ja01 = 0, Ja10 = 0, Ja11 = 0, Jb00 = 0, Jb01 = 0, Jb11 = 0, wJI2 = 0;
-      float JIr0 = 0, JIr1 = 0, Jar0 = 0, Jar1 = 0, rr = 0;
-      float energyLeft = 0;
       float* fj = fullJ ? fullJ + (size_t)ri * 74 : nullptr;
-#pragma unroll 1
-      for (int idx = 0; idx < 8; idx++) {
-        const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
-        const float q0 = pc.KRKi[0] * xu + pc.KRKi[1] * xv + pc.KRKi[2] * 1.0f + pc.Kt[0] * ids;
-        const float q1 = pc.KRKi[3] * xu + pc.KRKi[4] * xv + pc.KRKi[5] * 1.0f + pc.Kt[1] * ids;
-        const float q2 = pc.KRKi[6] * xu + pc.KRKi[7] * xv + pc.KRKi[8] * 1.0f + pc.Kt[2] * ids;
-        const float Ku = q0 / q2, Kv = q1 / q2;
-        if (!(Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3)) { done = true; break; }
-        float3 hit = interp33(img, Ku, Kv, W.w);
+      // this lane's pattern pixel
+      const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
+      const float q0 = pc.KRKi[0] * xu + pc.KRKi[1] * xv + pc.KRKi[2] * 1.0f + pc.Kt[0] * ids;
+      const float q1 = pc.KRKi[3] * xu + pc.KRKi[4] * xv + pc.KRKi[5] * 1.0f + pc.Kt[1] * ids;
+      const float q2 = pc.KRKi[6] * xu + pc.KRKi[7] * xv + pc.KRKi[8] * 1.0f + pc.Kt[2] * ids;
+      const float Ku = q0 / q2, Kv = q1 / q2;
+      const bool inb = (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
+      float3 hit = interp33(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, W.w);
+      bool good = inb && isfinite(hit.x);
+      // the residual goes OOB if ANY of its pattern pixels fails (the reference breaks out of the loop at the first one)
+      {
+        const unsigned long long bad = __ballot(!good);
+        const int grp = (threadIdx.x & 63) & ~7;
+        if ((bad >> grp) & 0xFFull) good = false;
+      }
+      if (!good) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
+      else {
         const float color = P.color[pi * 8 + idx];
         const float residual = hit.x - (pc.aff0 * color + pc.aff1);
         const float drdA = (color - pc.b0);
-        if (!isfinite(hit.x)) { done = true; break; }
         float wgt = sqrtf(W.outlierTHSum / (W.outlierTHSum + (hit.y * hit.y + hit.z * hit.z)));
         wgt = 0.5f * (wgt + P.weights[pi * 8 + idx]);
         float hw = fabsf(residual) < W.huberTH ? 1.0f : W.huberTH / fabsf(residual);
-        energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
+        const float eTerm = wgt * wgt * hw * residual * residual * (2 - hw);
         if (hw < 1) hw = sqrtf(hw);
         hw = hw * wgt;
         hit.y *= hw; hit.z *= hw;
         const float resF = residual * hw;
         float jab0 = drdA * hw, jab1 = hw;
-        JI00 += hit.y * hit.y; JI11 += hit.z * hit.z; JI10 += hit.y * hit.z;
-        Ja00 += drdA * hw * hit.y; Ja01 += drdA * hw * hit.z; Ja10 += hw * hit.y; Ja11 += hw * hit.z;
-        Jb00 += drdA * drdA * hw * hw; Jb01 += drdA * hw * hw; Jb11 += hw * hw;
-        wJI2 += hw * hw * (hit.y * hit.y + hit.z * hit.z);
+        const float tJI00 = hit.y * hit.y, tJI11 = hit.z * hit.z, tJI10 = hit.y * hit.z;
+        const float tJa00 = drdA * hw * hit.y, tJa01 = drdA * hw * hit.z, tJa10 = hw * hit.y, tJa11 = hw * hit.z;
+        const float tJb00 = drdA * drdA * hw * hw, tJb01 = drdA * hw * hw, tJb11 = hw * hw;
+        const float twJI2 = hw * hw * (hit.y * hit.y + hit.z * hit.z);
         if (W.modeA < 0) jab0 = 0;
         if (W.modeB < 0) jab1 = 0;
         // accumulation-side inner products of addPoint<0> (resApprox = resF)  (AccumulatedTopHessian.cpp:103-113)
-        JIr0 += resF * hit.y; JIr1 += resF * hit.z; Jar0 += resF * jab0; Jar1 += resF * jab1; rr += resF * resF;
+        const float tJIr0 = resF * hit.y, tJIr1 = resF * hit.z, tJar0 = resF * jab0, tJar1 = resF * jab1, trr = resF * resF;
         if (fj) { fj[idx] = resF; fj[30 + idx] = hit.y; fj[38 + idx] = hit.z; fj[46 + idx] = jab0; fj[54 + idx] = jab1; }
-      }
-      if (done) { Rs.newState[ri] = BA_OOB; myE = Rs.energy[ri]; }
-      else {
-        Rs.newEnergyWO[ri] = energyLeft;
-        const float th = fmaxf(W.frameEnergyTH[hi], W.frameEnergyTH[ti]);
-        if (energyLeft > th || wJI2 < 2) { energyLeft = th; Rs.newState[ri] = BA_OUTLIER; }
-        else Rs.newState[ri] = BA_IN;
-        Rs.newEnergy[ri] = energyLeft;
-        myE = energyLeft;
-        // compact record
+        // sums over the pattern, in pattern order (valid in the leading lane)
+        float energyLeft = seqSum8(eTerm);
+        const float JI00 = seqSum8(tJI00), JI11 = seqSum8(tJI11), JI10 = seqSum8(tJI10);
+        const float Ja00 = seqSum8(tJa00), Ja01 = seqSum8(tJa01), Ja10 = seqSum8(tJa10), Ja11 = seqSum8(tJa11);
+        const float Jb00 = seqSum8(tJb00), Jb01 = seqSum8(tJb01), Jb11 = seqSum8(tJb11), wJI2 = seqSum8(twJI2);
+        const float JIr0 = seqSum8(tJIr0), JIr1 = seqSum8(tJIr1), Jar0 = seqSum8(tJar0), Jar1 = seqSum8(tJar1), rr = seqSum8(trr);
+        if (lead) {
+          Rs.newEnergyWO[ri] = energyLeft;
+          const float th = fmaxf(W.frameEnergyTH[hi], W.frameEnergyTH[ti]);
+          if (energyLeft > th || wJI2 < 2) { energyLeft = th; Rs.newState[ri] = BA_OUTLIER; }
+          else Rs.newState[ri] = BA_IN;
+          Rs.newEnergy[ri] = energyLeft;
+          myE = energyLeft;
+          // compact record
 #pragma unroll
-        for (int k = 0; k < 4; k++) { rec[REC_JPDC0 + k] = d_C_x[k]; rec[REC_JPDC1 + k] = d_C_y[k]; }
+          for (int k = 0; k < 4; k++) { rec[REC_JPDC0 + k] = d_C_x[k]; rec[REC_JPDC1 + k] = d_C_y[k]; }
 #pragma unroll
-        for (int k = 0; k < 6; k++) { rec[REC_JPDXI0 + k] = d_xi_x[k]; rec[REC_JPDXI1 + k] = d_xi_y[k]; }
-        rec[REC_JIDX2 + 0] = JI00; rec[REC_JIDX2 + 1] = JI10; rec[REC_JIDX2 + 2] = JI11;
-        rec[REC_JABJIDX + 0] = Ja00; rec[REC_JABJIDX + 1] = Ja01; rec[REC_JABJIDX + 2] = Ja10; rec[REC_JABJIDX + 3] = Ja11;
-        rec[REC_JAB2 + 0] = Jb00; rec[REC_JAB2 + 1] = Jb01; rec[REC_JAB2 + 2] = Jb11;
-        rec[REC_JI_R + 0] = JIr0; rec[REC_JI_R + 1] = JIr1; rec[REC_JAB_R + 0] = Jar0; rec[REC_JAB_R + 1] = Jar1; rec[REC_RR] = rr;
-        rec[REC_JPDD + 0] = d_d_x; rec[REC_JPDD + 1] = d_d_y;
-        // takeDataF (EnergyFunctionalStructs.cpp:39-49)
-        const float v0 = JI00 * d_d_x + JI10 * d_d_y, v1 = JI10 * d_d_x + JI11 * d_d_y;
+          for (int k = 0; k < 6; k++) { rec[REC_JPDXI0 + k] = d_xi_x[k]; rec[REC_JPDXI1 + k] = d_xi_y[k]; }
+          rec[REC_JIDX2 + 0] = JI00; rec[REC_JIDX2 + 1] = JI10; rec[REC_JIDX2 + 2] = JI11;
+          rec[REC_JABJIDX + 0] = Ja00; rec[REC_JABJIDX + 1] = Ja01; rec[REC_JABJIDX + 2] = Ja10; rec[REC_JABJIDX + 3] = Ja11;
+          rec[REC_JAB2 + 0] = Jb00; rec[REC_JAB2 + 1] = Jb01; rec[REC_JAB2 + 2] = Jb11;
+          rec[REC_JI_R + 0] = JIr0; rec[REC_JI_R + 1] = JIr1; rec[REC_JAB_R + 0] = Jar0; rec[REC_JAB_R + 1] = Jar1; rec[REC_RR] = rr;
+          rec[REC_JPDD + 0] = d_d_x; rec[REC_JPDD + 1] = d_d_y;
+          // takeDataF (EnergyFunctionalStructs.cpp:39-49)
+          const float v0 = JI00 * d_d_x + JI10 * d_d_y, v1 = JI10 * d_d_x + JI11 * d_d_y;
 #pragma unroll
-        for (int k = 0; k < 6; k++) rec[REC_JPJD + k] = d_xi_x[k] * v0 + d_xi_y[k] * v1;
-        rec[REC_JPJD + 6] = Ja00 * d_d_x + Ja01 * d_d_y;
-        rec[REC_JPJD + 7] = Ja10 * d_d_x + Ja11 * d_d_y;
-        // per-point contributions (AccumulatedTopHessian.cpp:131-134)
-        rec[REC_BD] = JIr0 * d_d_x + JIr1 * d_d_y;
-        rec[REC_HDD] = v0 * d_d_x + v1 * d_d_y;
+          for (int k = 0; k < 6; k++) rec[REC_JPJD + k] = d_xi_x[k] * v0 + d_xi_y[k] * v1;
+          rec[REC_JPJD + 6] = Ja00 * d_d_x + Ja01 * d_d_y;
+          rec[REC_JPJD + 7] = Ja10 * d_d_x + Ja11 * d_d_y;
+          // per-point contributions (AccumulatedTopHessian.cpp:131-134)
+          rec[REC_BD] = JIr0 * d_d_x + JIr1 * d_d_y;
+          rec[REC_HDD] = v0 * d_d_x + v1 * d_d_y;
 #pragma unroll
-        for (int k = 0; k < 4; k++) rec[REC_HCD + k] = d_C_x[k] * v0 + d_C_y[k] * v1;
-        if (fj) {
-          for (int k = 0; k < 6; k++) { fj[8 + k] = d_xi_x[k]; fj[14 + k] = d_xi_y[k]; }
-          for (int k = 0; k < 4; k++) { fj[20 + k] = d_C_x[k]; fj[24 + k] = d_C_y[k]; }
-          fj[28] = d_d_x; fj[29] = d_d_y;
-          fj[62] = JI00; fj[63] = JI10; fj[64] = JI10; fj[65] = JI11;
-          fj[66] = Ja00; fj[67] = Ja01; fj[68] = Ja10; fj[69] = Ja11;
-          fj[70] = Jb00; fj[71] = Jb01; fj[72] = Jb01; fj[73] = Jb11;
+          for (int k = 0; k < 4; k++) rec[REC_HCD + k] = d_C_x[k] * v0 + d_C_y[k] * v1;
+          if (fj) {
+            for (int k = 0; k < 6; k++) { fj[8 + k] = d_xi_x[k]; fj[14 + k] = d_xi_y[k]; }
+            for (int k = 0; k < 4; k++) { fj[20 + k] = d_C_x[k]; fj[24 + k] = d_C_y[k]; }
+            fj[28] = d_d_x; fj[29] = d_d_y;
+            fj[62] = JI00; fj[63] = JI10; fj[64] = JI10; fj[65] = JI11;
+            fj[66] = Ja00; fj[67] = Ja01; fj[68] = Ja10; fj[69] = Ja11;
+            fj[70] = Jb00; fj[71] = Jb01; fj[72] = Jb01; fj[73] = Jb11;
+          }
         }
       }
     }
   }
-  // block energy partial, fixed order
-  __shared__ double s_e[128];
-  s_e[threadIdx.x] = myE;
+  // block energy partial, fixed order (only the leading lane of a residual contributes)
+  __shared__ double s_e[LIN_RES_PER_BLOCK];
+  if ((threadIdx.x & 7) == 0) s_e[threadIdx.x >> 3] = myE;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0;
-    for (int k = 0; k < 128; k++) s += s_e[k];
-    energy_partials[blockIdx.x] = s;
+    double sum = 0;
+    for (int k = 0; k < LIN_RES_PER_BLOCK; k++) sum += s_e[k];
+    energy_partials[blockIdx.x] = sum;
   }
 }
 

@@ -114,7 +114,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b)) return r;  // precalc + frameEnergyTH of the current state
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, b->stream));
@@ -313,7 +313,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   HIPCHK(hipMemcpyAsync(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // adHT is local
   if (int r = uploadWindowTables(b)) return r;
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(128), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
   hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand);
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
@@ -428,7 +428,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &SB.scHC, (size_t)F2 * 32) ||
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
-  b->n_lin_blocks = (R + 127) / 128; b->n_pt_blocks = (N + 255) / 256;
+  b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256;
   if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2 * 8)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4 + (size_t)F2 * 8) ||
       dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   b->d_xAd = b->d_xc + 4;   // one staging upload fills both
