@@ -52,7 +52,7 @@ struct dmvio_hip_ba {
   BAPrecalc* h_pre[2] = {nullptr, nullptr};
   int pre_toggle = 0;
   float* d_fullJ = nullptr;
-  int n_lin_blocks = 0, n_pt_blocks = 0;
+  int n_lin_blocks = 0, n_pt_blocks = 0, n_epart = 0;
   // partial accumulators per bucket: 1 (default) replays the single-threaded reference order bit for bit; DMVIO_HIP_BA_SPLIT=k uses k
   int nsTop = 1, nsD = 1, nsC = 1;
   bool graph_ready = false;
@@ -82,7 +82,7 @@ static void freeDevice(dmvio_hip_ba* b) {
   if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
   if (b->h_epart) { hipHostFree(b->h_epart); b->h_epart = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
-  if (b->h_newEnergyWO) { hipHostFree(b->h_newEnergyWO); b->h_newEnergyWO = nullptr; }
+  b->h_newEnergyWO = nullptr;   // lives inside h_epart
   if (b->h_xstage) { hipHostFree(b->h_xstage); b->h_xstage = nullptr; }
   for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
   b->graph_ready = false;
@@ -117,8 +117,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_lin_blocks, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipMemcpyAsync(b->h_newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * H.R, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_epart + sizeof(float) * H.R, hipMemcpyDeviceToHost, b->stream));   // partials + energies
   HIPCHK(hipStreamSynchronize(b->stream));
   double e = 0;
   for (int i = 0; i < b->n_lin_blocks; i++) e += b->h_epart[i];
@@ -397,7 +396,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &b->d_cand, N) || dalloc(b, &b->d_decision, N) || dalloc(b, &b->d_mHdiF, N) || dalloc(b, &b->d_mbdSumF, N) || dalloc(b, &b->d_mHcd, (size_t)N * 4) ||
       dalloc(b, &b->d_margRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_margActive, R) || dalloc(b, &b->d_adHTdelta, (size_t)F2 * 8)) return -1;
   if (dalloc(b, &Rs.state, R) || dalloc(b, &Rs.newState, R) || dalloc(b, &Rs.active, R) || dalloc(b, &Rs.which, R) || dalloc(b, &Rs.energy, R) || dalloc(b, &Rs.newEnergy, R) ||
-      dalloc(b, &Rs.newEnergyWO, R) || dalloc(b, &Rs.center, (size_t)R * 3) || dalloc(b, &Rs.rec[0], (size_t)R * REC_FLOATS) || dalloc(b, &Rs.rec[1], (size_t)R * REC_FLOATS)) return -1;
+      dalloc(b, &Rs.center, (size_t)R * 3) || dalloc(b, &Rs.rec[0], (size_t)R * REC_FLOATS) || dalloc(b, &Rs.rec[1], (size_t)R * REC_FLOATS)) return -1;
   P.host = d_host; P.u = d_u; P.v = d_v; P.color = d_color; P.weights = d_weights; P.priorF = d_prior; P.res_begin = d_res_begin;
   Rs.point = d_point; Rs.target = d_target;
   std::vector<float> prior(N, 0.0f);
@@ -429,15 +428,23 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
   b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256;
-  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_epart, std::max(b->n_lin_blocks, F2 * 8)) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4 + (size_t)F2 * 8) ||
+  // energy partials (doubles) and the per-residual energies with outliers (floats) share one allocation: one download per linearisation
+  b->n_epart = std::max(b->n_lin_blocks, F2 * 8);
+  {
+    double* blk = nullptr;
+    if (dalloc(b, &blk, (size_t)b->n_epart + ((size_t)R + 1) / 2)) return -1;
+    b->d_epart = blk;
+    Rs.newEnergyWO = reinterpret_cast<float*>(blk + b->n_epart);
+  }
+  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4 + (size_t)F2 * 8) ||
       dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   b->d_xAd = b->d_xc + 4;   // one staging upload fills both
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_xstage, sizeof(float) * (4 + (size_t)F2 * 8), hipHostMallocDefault));
   for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * std::max(b->n_lin_blocks, F2 * 8), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2), hipHostMallocDefault));
+  b->h_newEnergyWO = reinterpret_cast<float*>(b->h_epart + b->n_epart);
   HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_newEnergyWO, sizeof(float) * R, hipHostMallocDefault));
   if (int r = uploadAdjoints(b)) return r;
   HIPCHK(hipStreamSynchronize(s));
   b->graph_ready = true;
