@@ -36,7 +36,9 @@ struct dmvio_hip_ba {
   std::vector<unsigned char> h_prior_flag;
   // device storage
   std::vector<void*> allocs;
-  BAPrecalc* d_pre = nullptr;
+  BAPrecalc* d_pre = nullptr;        // the precalc table the kernels read: one of the two halves of d_pre2
+  BAPrecalc* d_pre2 = nullptr;       // [2][F*F]: the table of the backed-up state stays resident, a rejected step switches back to it
+  int pre_half = 0;
   double *d_adHost = nullptr, *d_adTarget = nullptr;
   int *d_top_begin = nullptr, *d_top_members = nullptr, *d_scd_begin = nullptr, *d_scd_members = nullptr;
   float *d_accTop = nullptr, *d_accD = nullptr, *d_accE = nullptr, *d_accC = nullptr;
@@ -88,7 +90,8 @@ static void freeDevice(dmvio_hip_ba* b) {
   b->graph_ready = false;
 }
 
-static int uploadWindowTables(dmvio_hip_ba* b) {
+// switch_back: the state was restored to the one whose table is still in the other half (loadSateBackup after a rejected step)
+static int uploadWindowTables(dmvio_hip_ba* b, bool new_state = false, bool switch_back = false) {
   BAHost& H = b->H;
   BAWindow& W = b->W;
   W.F = H.F; W.w = H.w; W.h = H.h; W.N = H.N; W.R = H.R;
@@ -98,6 +101,9 @@ static int uploadWindowTables(dmvio_hip_ba* b) {
   W.huberTH = H.S.huberTH; W.outlierTHSum = H.S.outlierTHSumComponent; W.modeA = H.S.affineOptModeA; W.modeB = H.S.affineOptModeB;
   for (int f = 0; f < H.F; f++) { W.slot[f] = H.fr[f].slot; W.frameEnergyTH[f] = H.fr[f].frameEnergyTH; }
   // two pinned staging copies: at most one earlier upload can still be in flight (every linearize ends with a stream sync)
+  if (switch_back) { b->pre_half ^= 1; b->d_pre = b->d_pre2 + (size_t)b->pre_half * H.F * H.F; return 0; }
+  if (new_state) b->pre_half ^= 1;   // keep the previous state's table in the other half
+  b->d_pre = b->d_pre2 + (size_t)b->pre_half * H.F * H.F;
   BAPrecalc* stage = b->h_pre[b->pre_toggle ^= 1];
   memcpy(stage, H.pre.data(), sizeof(BAPrecalc) * H.F * H.F);
   HIPCHK(hipMemcpyAsync(b->d_pre, stage, sizeof(BAPrecalc) * H.F * H.F, hipMemcpyHostToDevice, b->stream));
@@ -110,10 +116,10 @@ static int uploadAdjoints(dmvio_hip_ba* b) {
 }
 
 // FullSystem::linearizeAll (FullSystemOptimize.cpp:150-218) — returns the energy sum; updates the newest frame's energy threshold
-static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy) {
+static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
-  if (int r = uploadWindowTables(b)) return r;  // precalc + frameEnergyTH of the current state
+  if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc + frameEnergyTH of the current state
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
@@ -413,7 +419,8 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipMemcpyAsync(d_prior, prior.data(), sizeof(float) * N, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(P.idepth, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(P.idepth_zero, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
-  if (dalloc(b, &b->d_pre, F2) || dalloc(b, &b->d_adHost, (size_t)F2 * 64) || dalloc(b, &b->d_adTarget, (size_t)F2 * 64) || dalloc(b, &b->d_top_begin, F2 + 1) ||
+  b->pre_half = 0;
+  if (dalloc(b, &b->d_pre2, 2 * (size_t)F2) || dalloc(b, &b->d_adHost, (size_t)F2 * 64) || dalloc(b, &b->d_adTarget, (size_t)F2 * 64) || dalloc(b, &b->d_top_begin, F2 + 1) ||
       dalloc(b, &b->d_top_members, R) || dalloc(b, &b->d_scd_begin, F2 * F + 1) || dalloc(b, &b->d_scd_members, 3 * npairs) || dalloc(b, &b->d_accTop, (size_t)F2 * 96 * b->nsTop) ||
       dalloc(b, &b->d_accD, (size_t)F2 * F * 64 * b->nsD) || dalloc(b, &b->d_accE, (size_t)F2 * 40 * b->nsTop) || dalloc(b, &b->d_accC, 20 * b->nsC) || dalloc(b, &b->d_numTop, F2 * b->nsTop) || dalloc(b, &b->d_numD, F2 * F * b->nsD)) return -1;
   HIPCHK(hipMemcpyAsync(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), hipMemcpyHostToDevice, s));
@@ -620,7 +627,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   BA_LAP(5);
   // eval new energy
   double newE = 0;
-  if (int r = linearizeAll(b, false, &newE)) return r;
+  if (int r = linearizeAll(b, false, &newE, 1)) return r;   // stepped state: its table goes into the other half
   BA_LAP(6);
   const double newL = H.calcLEnergyFrames(), newM = H.calcMEnergy();
   accepted = (newE + newL + newM < lastE[0] + lastE[1] + lastE[2]);
@@ -632,7 +639,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     H.restoreFrames();
     if (int r = pointStep(b, 2, 0.f, nullptr, nullptr)) return r;
     H.setPrecalcValues();
-    if (int r = linearizeAll(b, false, &lastE[0])) return r;
+    if (int r = linearizeAll(b, false, &lastE[0], 2)) return r;   // backed-up state: its table is still resident
     lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
     lambda *= 1e2;
   }
