@@ -999,8 +999,11 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
 // ------------------------------------------------------------------------------------------------ back-substitution / stepping
 // xAd: F*F x 8 floats, index h*F + t (EnergyFunctional.cpp:280-282), xc: 4 floats
 // apply_step != 0 fuses doStepFromBackup for stepfac = 1 (FullSystemOptimize.cpp:224-317): idepth = idepth_zero = backup + step
-__global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ xc,
-                                                          const float* __restrict__ xAd, const int apply_step) {
+// xc and xAd travel as kernel arguments (2 KB): no separate upload, no staging buffer
+struct ResubArgs { float xc[4]; float xAd[BA_MAXF * BA_MAXF * 8]; };
+__global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const ResubArgs X, const int apply_step) {
+  const float* __restrict__ xc = X.xc;
+  const float* __restrict__ xAd = X.xAd;
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= W.N) return;
   int ngood = 0;

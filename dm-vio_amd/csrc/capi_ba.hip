@@ -47,10 +47,8 @@ struct dmvio_hip_ba {
   double *d_sys = nullptr, *h_sys = nullptr;     // [H_A | b_A | H_sc | b_sc]
   double *d_epart = nullptr, *h_epart = nullptr;  // linearize energy partials
   float *d_spart = nullptr, *h_spart = nullptr;  // point-step partial sums
-  float *d_xc = nullptr, *d_xAd = nullptr;
   float *h_newEnergyWO = nullptr;
-  // pinned staging for the small per-iteration uploads (no pageable copies, no sync before the kernel that consumes them)
-  float* h_xstage = nullptr;        // [xc (4) | xAd (F*F*8)]
+  // pinned staging for the per-linearisation precalc upload (no pageable copy, no sync before the kernel that consumes it)
   BAPrecalc* h_pre[2] = {nullptr, nullptr};
   int pre_toggle = 0;
   float* d_fullJ = nullptr;
@@ -85,7 +83,6 @@ static void freeDevice(dmvio_hip_ba* b) {
   if (b->h_epart) { hipHostFree(b->h_epart); b->h_epart = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
   b->h_newEnergyWO = nullptr;   // lives inside h_epart
-  if (b->h_xstage) { hipHostFree(b->h_xstage); b->h_xstage = nullptr; }
   for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
   b->graph_ready = false;
 }
@@ -178,11 +175,11 @@ static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x, bool appl
   float xc[4];
   std::vector<float> xAd;
   b->H.prepareResubstitute(x, xc, xAd);
-  // pinned staging; the previous upload was consumed before the accumulate sync that produced x
-  memcpy(b->h_xstage, xc, sizeof(xc));
-  memcpy(b->h_xstage + 4, xAd.data(), sizeof(float) * xAd.size());
-  HIPCHK(hipMemcpyAsync(b->d_xc, b->h_xstage, sizeof(float) * (4 + xAd.size()), hipMemcpyHostToDevice, b->stream));   // d_xAd = d_xc + 4
-  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, b->d_xc, b->d_xAd, apply_step ? 1 : 0);
+  ResubArgs X;
+  memcpy(X.xc, xc, sizeof(xc));
+  memset(X.xAd, 0, sizeof(X.xAd));
+  memcpy(X.xAd, xAd.data(), sizeof(float) * xAd.size());
+  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, X, apply_step ? 1 : 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -443,11 +440,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
     b->d_epart = blk;
     Rs.newEnergyWO = reinterpret_cast<float*>(blk + b->n_epart);
   }
-  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_xc, 4 + (size_t)F2 * 8) ||
+  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) ||
       dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
-  b->d_xAd = b->d_xc + 4;   // one staging upload fills both
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_xstage, sizeof(float) * (4 + (size_t)F2 * 8), hipHostMallocDefault));
   for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2), hipHostMallocDefault));
   b->h_newEnergyWO = reinterpret_cast<float*>(b->h_epart + b->n_epart);
