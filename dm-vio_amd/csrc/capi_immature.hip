@@ -11,7 +11,7 @@ using namespace dmv;
 
 struct dmvio_hip_immature {
   dmvio_hip_ctx* ctx = nullptr;
-  int capacity = 0, n = 0;
+  int capacity = 0, n = 0, max_tag = -1;   // max_tag: largest host_tag among the points (validated against the tables of a call)
   ImmaturePts P{};
   ImmatureSettings S;
   float* d_tables = nullptr;   // [KRKi 9H | Kt 3H | aff 2H], H <= 64
@@ -65,7 +65,7 @@ void dmvio_hip_immature_destroy(dmvio_hip_immature* m) {
   if (m->h_opt_tables) hipHostFree(m->h_opt_tables);
   delete m;
 }
-int dmvio_hip_immature_clear(dmvio_hip_immature* m) { IMM_READY(m); m->n = 0; return 0; }
+int dmvio_hip_immature_clear(dmvio_hip_immature* m) { IMM_READY(m); m->n = 0; m->max_tag = -1; return 0; }
 int dmvio_hip_immature_count(dmvio_hip_immature* m) { return m ? m->n : -1; }
 
 int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_slot, int n, const int* u, const int* v) {
@@ -89,6 +89,7 @@ int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_
   hipLaunchKernelGGL(k_immature_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(host_slot, 0), c->w, first, n, m->P, host_tag, m->S);
   HIPCHK(hipGetLastError());
   m->n = first + n;
+  m->max_tag = std::max(m->max_tag, host_tag);
   return first;
 }
 
@@ -140,6 +141,7 @@ int dmvio_hip_immature_trace(dmvio_hip_immature* m, int new_slot, int n_hosts, c
   if (!KRKi9 || !Kt3 || !aff2 || n_hosts < 1 || n_hosts > IMM_MAX_HOSTS) return failmsg("immature_trace: bad argument");
   if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("immature_trace: frame slot out of range");
   if (m->n == 0) return 0;
+  if (m->max_tag >= n_hosts) return failmsg("immature_trace: a point's host_tag has no table row (host_tag >= n_hosts)");
   HIPCHK(hipStreamSynchronize(c->stream));   // the pinned tables of a previous call may still be in flight
   float* t = m->h_tables;
   memcpy(t, KRKi9, sizeof(float) * 9 * n_hosts);
@@ -203,6 +205,7 @@ int dmvio_hip_immature_optimize(dmvio_hip_immature* m, int F, const int* frame_s
   std::lock_guard<std::mutex> lk(c->mu);
   if (F < 2 || F > 8 || !frame_slots || !w2c7 || !aff2 || !exposure || !fxfycxcy || !result || !idepth) return failmsg("immature_optimize: bad argument");
   if (m->n == 0) return 0;
+  if (m->max_tag >= F) return failmsg("immature_optimize: a point's host_tag is not a keyframe index of this window (host_tag >= F)");
   HIPCHK(hipStreamSynchronize(c->stream));
   float* tb = m->h_opt_tables;
   float *R = tb, *t = tb + 9 * 64, *aff = tb + 12 * 64;

@@ -67,6 +67,11 @@ def test_immature_empty_and_initializer_empty(pkg, oracle, synth, gpu_required):
     assert len(res) == 0
     with pytest.raises(pkg.HipLibraryError):
         imm.add_points(0, 0, np.arange(40) % 100 + 10, np.arange(40) % 100 + 10)                # capacity exceeded
+    imm.add_points(3, 0, np.array([20, 30]), np.array([20, 30]))
+    with pytest.raises(pkg.HipLibraryError):
+        imm.traceNewCoarse(1, IDENT, IDENT[None], synth.default_intrinsics(w, h))               # host_tag 3 without a table row
+    with pytest.raises(pkg.HipLibraryError):
+        imm.optimize([0, 1], np.stack([IDENT, IDENT]), synth.default_intrinsics(w, h))           # host_tag 3 >= F
     ini = pkg.CoarseInitializerHip(ctx, capacity=8)
     ini.set_points(dict(u=np.zeros(0), v=np.zeros(0), iR=np.zeros(0), isGood=np.zeros(0, np.uint8), energy=np.zeros((0, 2)), outlierTH=np.zeros(0)))
     K4 = synth.default_intrinsics(w, h)
