@@ -37,11 +37,12 @@ struct dmvio_hip_tracker {
   float *d_partials = nullptr, *d_tot = nullptr, *h_tot = nullptr;
   int max_eval_blocks = 1024;
   LMProblemIn *d_in = nullptr, *h_in = nullptr;
-  LMProblemOut *d_out = nullptr, *h_out = nullptr;
+  LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
+  int out_cur = 0, out_fetch = 0;                     // half written by the last launch / half a pending fetch_begin refers to
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
   int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0;
-  hipEvent_t fetch_event = nullptr;   // marks the end of an early result download (track_batch_fetch_begin)
+  hipEvent_t done_event[2] = {nullptr, nullptr};   // recorded behind each launch: the results of that half are in host memory once it has completed
   int fetch_pending_B = 0;
   float* d_cl_part = nullptr;          // cluster mode: B x 2 x C x ACC_PAD partial sums
   unsigned int* d_cl_cnt = nullptr;    // cluster mode: arrive counters
@@ -317,7 +318,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
   hipHostFree(t->h_tot);
   hipFree(t->d_in); hipFree(t->d_out);
-  if (t->fetch_event) hipEventDestroy(t->fetch_event);
+  for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
   if (t->d_cl_part) hipFree(t->d_cl_part);
   if (t->d_cl_cnt) hipFree(t->d_cl_cnt);
   if (t->h_in) hipHostFree(t->h_in);
@@ -447,12 +448,13 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
 
 static int ensureBatch(dmvio_hip_tracker* t, int B) {
   if (B <= t->batch_cap) return 0;
+  if (t->fetch_pending_B > 0) return failmsg("track_batch_stage: a larger batch cannot be staged while the results of the previous one are still to be fetched");
   if (t->d_in) { HIPCHK(hipFree(t->d_in)); HIPCHK(hipFree(t->d_out)); HIPCHK(hipHostFree(t->h_in)); HIPCHK(hipHostFree(t->h_out)); }
   t->batch_cap = std::max(B, 64);
   HIPCHK(hipMalloc((void**)&t->d_in, sizeof(LMProblemIn) * t->batch_cap));
-  HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut) * (t->batch_cap + 1)));   // + the discard entry of cluster mode
+  HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut)));   // the discard entry of cluster mode (non-leading workgroups)
   HIPCHK(hipHostMalloc((void**)&t->h_in, sizeof(LMProblemIn) * t->batch_cap, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&t->h_out, sizeof(LMProblemOut) * t->batch_cap, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_out, sizeof(LMProblemOut) * 2 * t->batch_cap, hipHostMallocDefault));
   return 0;
 }
 
@@ -494,7 +496,8 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   if ((long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
   const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : 256));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
-  ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr;
+  ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out;
+  t->out_cur ^= 1;   // the host may still be unpacking the previous launch's half (fetch_begin pipeline)
   if (C > 1) {
     const size_t need = (size_t)B * 2 * C * ACC_PAD;
     if (need > t->cl_part_cap) { if (t->d_cl_part) HIPCHK(hipFree(t->d_cl_part)); HIPCHK(hipMalloc((void**)&t->d_cl_part, sizeof(float) * need)); t->cl_part_cap = need; }
@@ -502,7 +505,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
     HIPCHK(hipMemsetAsync(t->d_cl_cnt, 0, sizeof(unsigned int) * B, c->stream));
     cl.part = t->d_cl_part; cl.cnt = t->d_cl_cnt;
   }
-#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->d_out, t->staged_coarsest, cl)
+#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
   if (T == 1024 && C == 1) DMV_LAUNCH_LM(1024, 4);
   else if (T == 512 && W >= 6 && C == 1) DMV_LAUNCH_LM(512, 6);
   else if (T == 512 && C == 1) DMV_LAUNCH_LM(512, 4);
@@ -512,20 +515,21 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024 (cluster mode: 256)");
 #undef DMV_LAUNCH_LM
   HIPCHK(hipGetLastError());
+  if (!t->done_event[t->out_cur]) HIPCHK(hipEventCreateWithFlags(&t->done_event[t->out_cur], hipEventDisableTiming));
+  HIPCHK(hipEventRecord(t->done_event[t->out_cur], c->stream));
   return 0;
 }
 
-// Enqueue-only download of the results of the last launch: lets the caller queue the NEXT batch (pyramids, stage, launch) behind it
-// before blocking in _fetch, so the device never waits for the host to unpack results.
+// Marks the results of the last launch as "to be fetched later": the caller may queue the NEXT batch (pyramids, stage, launch) before
+// blocking in _fetch, so the device never waits for the host to unpack results.
 int dmvio_hip_tracker_track_batch_fetch_begin(dmvio_hip_tracker* t) {
   if (!t || t->staged_B <= 0) return failmsg("track_batch_fetch_begin: nothing staged");
   dmvio_hip_ctx* c = t->ctx;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  if (!t->fetch_event) HIPCHK(hipEventCreateWithFlags(&t->fetch_event, hipEventDisableTiming));
-  HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * t->staged_B, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipEventRecord(t->fetch_event, c->stream));
-  t->fetch_pending_B = t->staged_B;
+  // the kernel writes its results into pinned host memory itself and an event follows every launch: nothing to enqueue, the next
+  // launch goes into the other half and _fetch waits for this launch's event only
+  t->fetch_pending_B = t->staged_B; t->out_fetch = t->out_cur;
   return 0;
 }
 
@@ -535,18 +539,16 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
   dmvio_hip_ctx* c = t->ctx;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  int B = t->staged_B;
+  int B = t->staged_B, half = t->out_cur;
   if (t->fetch_pending_B > 0) {   // download already queued by _fetch_begin: wait for it only
-    B = t->fetch_pending_B; t->fetch_pending_B = 0;
-    HIPCHK(hipEventSynchronize(t->fetch_event));
-  } else {
-    HIPCHK(hipMemcpyAsync(t->h_out, t->d_out, sizeof(LMProblemOut) * B, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    B = t->fetch_pending_B; t->fetch_pending_B = 0; half = t->out_fetch;
   }
+  if (!t->done_event[half]) return failmsg("track_batch_fetch: nothing launched");
+  HIPCHK(hipEventSynchronize(t->done_event[half]));
   long long ev = 0, pe = 0;
   t->last_ticks_step = t->last_ticks_eval = 0;
   for (int i = 0; i < B; i++) {
-    const LMProblemOut& o = t->h_out[i];
+    const LMProblemOut& o = t->h_out[(size_t)half * t->batch_cap + i];
     if (pose7_out) memcpy(pose7_out + 7 * i, o.pose7, sizeof(double) * 7);
     if (aff_out) { aff_out[2 * i] = o.aff[0]; aff_out[2 * i + 1] = o.aff[1]; }
     if (lastResiduals) memcpy(lastResiduals + 5 * i, o.lastRes, sizeof(double) * 5);

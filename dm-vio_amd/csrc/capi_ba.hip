@@ -44,8 +44,8 @@ struct dmvio_hip_ba {
   float *d_accTop = nullptr, *d_accD = nullptr, *d_accE = nullptr, *d_accC = nullptr;
   int *d_numTop = nullptr, *d_numD = nullptr;
   StitchBufs SB{};
-  double *d_sys = nullptr, *h_sys = nullptr;     // [H_A | b_A | H_sc | b_sc]
-  double *d_epart = nullptr, *h_epart = nullptr;  // linearize energy partials
+  double *h_sys = nullptr;     // [H_A | b_A | H_sc | b_sc | resInA]: pinned host memory, written by k_ba_stitch_gather
+  double *h_epart = nullptr;   // linearize energy partials, followed by the per-residual energies (h_newEnergyWO): pinned, written by k_ba_linearize
   float *d_spart = nullptr, *h_spart = nullptr;  // point-step partial sums
   float *h_newEnergyWO = nullptr;
   // pinned staging for the per-linearisation precalc upload (no pageable copy, no sync before the kernel that consumes it)
@@ -117,11 +117,10 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc + frameEnergyTH of the current state
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->h_epart, b->d_fullJ, (const unsigned char*)nullptr);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(b->h_epart, b->d_epart, sizeof(double) * b->n_epart + sizeof(float) * H.R, hipMemcpyDeviceToHost, b->stream));   // partials + energies
-  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));   // partials + energies are in h_epart (written by the kernel)
   double e = 0;
   for (int i = 0; i < b->n_lin_blocks; i++) e += b->h_epart[i];
   *energy = e;
@@ -164,10 +163,9 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
                      b->d_adHost, b->d_adTarget, b->SB);
   const int tot = 2 * (n * n + n);
-  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys);
+  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(b->h_sys, b->d_sys, sizeof(double) * (tot + 1), hipMemcpyDeviceToHost, s));   // [H_A | b_A | H_sc | b_sc | resInA]
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipStreamSynchronize(s));   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
   H.resInA = (int)b->h_sys[tot];
   return 0;
 }
@@ -315,7 +313,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   HIPCHK(hipMemcpyAsync(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // adHT is local
   if (int r = uploadWindowTables(b)) return r;
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->h_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
   hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand);
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
@@ -434,18 +432,15 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256;
   // energy partials (doubles) and the per-residual energies with outliers (floats) share one allocation: one download per linearisation
   b->n_epart = std::max(b->n_lin_blocks, F2 * 8);
-  {
-    double* blk = nullptr;
-    if (dalloc(b, &blk, (size_t)b->n_epart + ((size_t)R + 1) / 2)) return -1;
-    b->d_epart = blk;
-    Rs.newEnergyWO = reinterpret_cast<float*>(blk + b->n_epart);
-  }
-  if (dalloc(b, &b->d_sys, tot + 1) || dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) ||
-      dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
+  if (dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
+  // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
+  // kernels straight into pinned host memory: no copy engine between the last kernel and the host's wait
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocDefault));
   for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2), hipHostMallocDefault));
   b->h_newEnergyWO = reinterpret_cast<float*>(b->h_epart + b->n_epart);
+  memset(b->h_epart, 0, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2));
+  Rs.newEnergyWO = b->h_newEnergyWO;
   HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
   if (int r = uploadAdjoints(b)) return r;
   HIPCHK(hipStreamSynchronize(s));
@@ -483,10 +478,10 @@ int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* 
   const int R = b->H.R;
   if (newState) HIPCHK(hipMemcpyAsync(newState, b->Rs.newState, R, hipMemcpyDeviceToHost, s));
   if (newEnergy) HIPCHK(hipMemcpyAsync(newEnergy, b->Rs.newEnergy, sizeof(float) * R, hipMemcpyDeviceToHost, s));
-  if (newEnergyWO) HIPCHK(hipMemcpyAsync(newEnergyWO, b->Rs.newEnergyWO, sizeof(float) * R, hipMemcpyDeviceToHost, s));
   if (active) HIPCHK(hipMemcpyAsync(active, b->Rs.active, R, hipMemcpyDeviceToHost, s));
   if (center3) HIPCHK(hipMemcpyAsync(center3, b->Rs.center, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  if (newEnergyWO) memcpy(newEnergyWO, b->h_newEnergyWO, sizeof(float) * R);   // lives in host memory
   return 0;
 }
 // RawResidualJacobian of the LAST linearisation (74 floats per residual, RawResidualJacobian.h:32-61 order) — parity/debug

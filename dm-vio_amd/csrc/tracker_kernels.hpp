@@ -630,7 +630,7 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
 // one device-scope arrive counter, every workgroup adds the C partials in rank order and runs the (deterministic) LM control
 // step redundantly — one inter-workgroup barrier per evaluation, no second one.  Partials are double-buffered by evaluation
 // parity; the launch guarantees B*C <= resident workgroups, so the spin cannot deadlock.
-struct ClusterArgs { int C; float* part; /* B x 2 x C x ACC_PAD */ unsigned int* cnt; /* B, zeroed before the launch */ };
+struct ClusterArgs { int C; float* part; /* B x 2 x C x ACC_PAD */ unsigned int* cnt; /* B, zeroed before the launch */ LMProblemOut* discard; /* device scratch entry */ };
 
 __device__ __forceinline__ void clusterExchange(float* s_tot, const ClusterArgs& cl, const int prob, const int rank, const unsigned int phase) {
   float* __restrict__ mine = cl.part + (((size_t)prob * 2 + (phase & 1u)) * cl.C + rank) * ACC_PAD;
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   __shared__ LMState S;  // written by lane 0 of wave 0 only
   const int prob = blockIdx.x / cl.C, rank = blockIdx.x % cl.C;
   const LMProblemIn& pin = in[prob];
-  LMProblemOut& pout = out[rank == 0 ? prob : (int)(gridDim.x / cl.C)];   // non-leading workgroups write into the spare entry after the batch
+  LMProblemOut& pout = rank == 0 ? out[prob] : *cl.discard;   // `out` is pinned host memory (written once, never read); non-leading workgroups write into device scratch
   unsigned int phase = 0;
   if (threadIdx.x == 0) {
     S.cur = poseFrom7(pin.pose7);

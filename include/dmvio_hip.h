@@ -113,9 +113,9 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* trk, int B, const int* new_
 int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* trk, int B, const int* new_slots, const float* new_exposures,
                                         const double* pose7_in, const double* aff_in, int coarsestLvl, const double* minResForAbort);
 int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* trk);
-/* Enqueue-only download of the last launch's results; a following _track_batch_fetch only waits for it.  Between the two calls the next
- * batch may be staged and launched (the results of the previous one are already on their way), which keeps the device busy while the
- * host unpacks results. */
+/* Marks the last launch's results as "fetched later"; a following _track_batch_fetch returns THOSE results.  Between the two calls the
+ * next batch (not a larger one) may be staged and launched: the kernel writes its results straight into one of two pinned host
+ * buffers, so the device stays busy while the host unpacks the previous batch. */
 int dmvio_hip_tracker_track_batch_fetch_begin(dmvio_hip_tracker* trk);
 int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* trk, double* pose7_out, double* aff_out, double* lastResiduals,
                                         double* lastFlow, double* H, double* b, int* good, int* iterations);

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerates the summaries committed under profiles/ (run on the GPU box through gpurun from the repo root).
+#   usage: tools/profile_round.sh r01
+# Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing).
+R=${1:-r01}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/prof_$R; rm -rf $O; mkdir -p $O
+t0=$(date +%s)
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+t1=$(date +%s); echo "default bench.py wall seconds: $((t1 - t0))" > $O/bench_wall.txt
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --no-cpu > $O/kt.log 2>&1
+python tools/rocprof_summary.py $(find $O/kt -name '*.db' | head -1) > $O/kernel_stats.md 2>> $O/kt.log
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > $O/pmc_$C.log 2>&1
+  python tools/rocprof_summary.py $(find $O/pmc_$C -name '*.db' | head -1) --counters > $O/pmc_$C.md 2>> $O/pmc_$C.log
+done
+DMVIO_HIP_BA_TIMING=1 python bench.py --no-cpu --steps 3 --warmup 1 > $O/ba_timing.log 2>&1
+rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+tail -c 600 $O/bench_n1.json; cat $O/bench_wall.txt
