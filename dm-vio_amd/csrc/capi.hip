@@ -36,9 +36,9 @@ struct dmvio_hip_tracker {
   int pts_cap = 0;
   float *d_partials = nullptr, *d_tot = nullptr, *h_tot = nullptr;
   int max_eval_blocks = 1024;
-  LMProblemIn *d_in = nullptr, *h_in = nullptr;
+  LMProblemIn *h_in = nullptr;   // 2 x batch_cap entries of pinned host memory, read by the kernel directly (each workgroup copies its 120 B into LDS)
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
-  int out_cur = 0, out_fetch = 0;                     // half written by the last launch / half a pending fetch_begin refers to
+  int out_cur = 0, out_fetch = 0, staged_half = 0;    // half of the last launch / half a pending fetch_begin refers to / half staged for the next launch
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
   int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0;
@@ -317,7 +317,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
   hipHostFree(t->h_tot);
-  hipFree(t->d_in); hipFree(t->d_out);
+  hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
   if (t->d_cl_part) hipFree(t->d_cl_part);
   if (t->d_cl_cnt) hipFree(t->d_cl_cnt);
@@ -449,11 +449,10 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
 static int ensureBatch(dmvio_hip_tracker* t, int B) {
   if (B <= t->batch_cap) return 0;
   if (t->fetch_pending_B > 0) return failmsg("track_batch_stage: a larger batch cannot be staged while the results of the previous one are still to be fetched");
-  if (t->d_in) { HIPCHK(hipFree(t->d_in)); HIPCHK(hipFree(t->d_out)); HIPCHK(hipHostFree(t->h_in)); HIPCHK(hipHostFree(t->h_out)); }
+  if (t->h_in) { HIPCHK(hipStreamSynchronize(t->ctx->stream)); HIPCHK(hipFree(t->d_out)); HIPCHK(hipHostFree(t->h_in)); HIPCHK(hipHostFree(t->h_out)); }
   t->batch_cap = std::max(B, 64);
-  HIPCHK(hipMalloc((void**)&t->d_in, sizeof(LMProblemIn) * t->batch_cap));
   HIPCHK(hipMalloc((void**)&t->d_out, sizeof(LMProblemOut)));   // the discard entry of cluster mode (non-leading workgroups)
-  HIPCHK(hipHostMalloc((void**)&t->h_in, sizeof(LMProblemIn) * t->batch_cap, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t->h_in, sizeof(LMProblemIn) * 2 * t->batch_cap, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&t->h_out, sizeof(LMProblemOut) * 2 * t->batch_cap, hipHostMallocDefault));
   return 0;
 }
@@ -468,17 +467,20 @@ int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* t, int B, const int* 
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   if (int r = ensureBatch(t, B)) return r;
+  // problems and results live in two halves of pinned host memory used alternately: the launch before the last one (same half) must have
+  // finished before its inputs are overwritten; the last launch may still be running
+  const int half = t->out_cur ^ 1;
+  if (t->done_event[half]) HIPCHK(hipEventSynchronize(t->done_event[half]));
   for (int i = 0; i < B; i++) {
     if (new_slots[i] < 0 || new_slots[i] >= c->n_slots) return failmsg("track: frame slot out of range");
-    LMProblemIn& p = t->h_in[i];
+    LMProblemIn& p = t->h_in[(size_t)half * t->batch_cap + i];
     memcpy(p.pose7, pose7_in + 7 * i, sizeof(double) * 7);
     p.aff[0] = aff_in[2 * i]; p.aff[1] = aff_in[2 * i + 1];
     for (int k = 0; k < 5; k++) p.minRes[k] = minRes ? minRes[5 * i + k] : NAN;
     p.new_slot = new_slots[i];
     p.new_exposure = new_exposures ? new_exposures[i] : 1.0f;
   }
-  HIPCHK(hipMemcpyAsync(t->d_in, t->h_in, sizeof(LMProblemIn) * B, hipMemcpyHostToDevice, c->stream));
-  t->staged_B = B; t->staged_coarsest = coarsestLvl;
+  t->staged_B = B; t->staged_coarsest = coarsestLvl; t->staged_half = half;
   return 0;
 }
 
@@ -497,7 +499,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : 256));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
   ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out;
-  t->out_cur ^= 1;   // the host may still be unpacking the previous launch's half (fetch_begin pipeline)
+  t->out_cur = t->staged_half;   // the host may still be unpacking the previous launch's half (fetch_begin pipeline)
   if (C > 1) {
     const size_t need = (size_t)B * 2 * C * ACC_PAD;
     if (need > t->cl_part_cap) { if (t->d_cl_part) HIPCHK(hipFree(t->d_cl_part)); HIPCHK(hipMalloc((void**)&t->d_cl_part, sizeof(float) * need)); t->cl_part_cap = need; }
@@ -505,7 +507,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
     HIPCHK(hipMemsetAsync(t->d_cl_cnt, 0, sizeof(unsigned int) * B, c->stream));
     cl.part = t->d_cl_part; cl.cnt = t->d_cl_cnt;
   }
-#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->d_in, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
+#define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
   if (T == 1024 && C == 1) DMV_LAUNCH_LM(1024, 4);
   else if (T == 512 && W >= 6 && C == 1) DMV_LAUNCH_LM(512, 6);
   else if (T == 512 && C == 1) DMV_LAUNCH_LM(512, 4);

@@ -663,7 +663,12 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   __shared__ int s_go, s_trk[8];
   __shared__ LMState S;  // written by lane 0 of wave 0 only
   const int prob = blockIdx.x / cl.C, rank = blockIdx.x % cl.C;
-  const LMProblemIn& pin = in[prob];
+  // `in` is pinned host memory: one read of the 120-byte record per workgroup, kept in LDS
+  __shared__ LMProblemIn s_in;
+  static_assert(sizeof(LMProblemIn) % 4 == 0 && sizeof(LMProblemIn) <= 256, "LMProblemIn is copied as dwords by one wavefront");
+  if (threadIdx.x < sizeof(LMProblemIn) / 4) reinterpret_cast<unsigned int*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned int*>(in + prob)[threadIdx.x];
+  __syncthreads();
+  const LMProblemIn& pin = s_in;
   LMProblemOut& pout = rank == 0 ? out[prob] : *cl.discard;   // `out` is pinned host memory (written once, never read); non-leading workgroups write into device scratch
   unsigned int phase = 0;
   if (threadIdx.x == 0) {

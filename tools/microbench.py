@@ -36,5 +36,10 @@ def main():
             e0.record(stream); trk.launch(); e1.record(stream); e1.synchronize(); ts.append(e0.elapsed_time(e1))
         r = trk.fetch(); ev, pe = trk.last_work(); tk = trk.last_ticks()
         print("track_lm B=%d: kernel %.1f us (min %.1f)  evals %d  in-kernel us/problem: control %.1f eval %.1f" % (B, 1e3 * np.mean(ts), 1e3 * np.min(ts), ev, tk[0] / 100 / B, tk[1] / 100 / B))
+    # whole call (stage + launch + fetch): host wall time
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for _ in range(100): trk.stage(slots, [ident] * B, [(0, 0)] * B); trk.launch(); trk.fetch()
+        print("track call B=%d: host wall %.1f us" % (B, (time.perf_counter() - t0) / 100 * 1e6))
 
 main()
