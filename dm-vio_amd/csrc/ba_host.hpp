@@ -56,6 +56,9 @@ struct BAHost {
   double cPrior[4];
   std::vector<double> HM, bM, lastX;
   std::vector<std::vector<double>> nsp;      // 7 nullspace vectors
+  std::vector<std::vector<double>> orthoBasis;   // unit left singular vectors of the nullspace matrix above the cut (prepareOrthogonalize)
+  std::vector<double> bPriorM, hfScratch, htScratch;   // bM + HM * delta (prepareSolve); scratch of solveSystem
+  bool solvePrepared = false;
   int resInA = 0;
 
   void calibSetValue(const double v[4]) {
@@ -184,8 +187,10 @@ struct BAHost {
     for (int f = 0; f < F; f++) for (int r = 0; r < 6; r++) nsp[6][4 + f * 8 + r] = fr[f].ns_scale[r];
   }
   // x -= N N^+ x : orthonormal basis of span(N) by modified Gram-Schmidt with re-orthogonalisation and the reference's
-  // relative singular-value cut (EnergyFunctional.cpp:812-824), evaluated through the Gram matrix's Jacobi eigen-decomposition
-  void orthogonalize(std::vector<double>& x) const {
+  // relative singular-value cut (EnergyFunctional.cpp:812-824), evaluated through the Gram matrix's Jacobi eigen-decomposition.
+  // The basis depends on the nullspaces only: prepareOrthogonalize() builds it (while the accumulation kernels run), orthogonalize()
+  // applies it.
+  void prepareOrthogonalize() {
     const int nn = n(), m = 7;
     std::vector<std::vector<double>> U(m);
     for (int i = 0; i < m; i++) { double s = 0; for (double v : nsp[i]) s += v * v; s = std::sqrt(s); U[i] = nsp[i]; for (auto& v : U[i]) v /= s; }
@@ -210,39 +215,111 @@ struct BAHost {
     double maxSv = 0;
     double sv[7];
     for (int i = 0; i < m; i++) { sv[i] = std::sqrt(std::max(G[i][i], 0.0)); maxSv = std::max(maxSv, sv[i]); }
-    std::vector<double> proj(nn, 0.0);
+    orthoBasis.clear();
     for (int i = 0; i < m; i++) {
       if (!(sv[i] > S.solverModeDelta * maxSv)) continue;
       // left singular vector u_i = U V_i / s_i
       std::vector<double> u(nn, 0.0);
       for (int j = 0; j < m; j++) for (int k = 0; k < nn; k++) u[k] += U[j][k] * V[j][i];
+      for (int k = 0; k < nn; k++) u[k] /= sv[i];
+      orthoBasis.push_back(std::move(u));
+    }
+  }
+  void orthogonalize(std::vector<double>& x) const {
+    const int nn = n();
+    std::vector<double> proj(nn, 0.0);
+    for (const std::vector<double>& u : orthoBasis) {
       double dot = 0;
-      for (int k = 0; k < nn; k++) { u[k] /= sv[i]; dot += u[k] * x[k]; }
+      for (int k = 0; k < nn; k++) dot += u[k] * x[k];
       for (int k = 0; k < nn; k++) proj[k] += u[k] * dot;
     }
     for (int k = 0; k < nn; k++) x[k] -= proj[k];
+  }
+
+  // Symmetric solve by LDL^T with diagonal pivoting — the arithmetic of ldltSolveInPlace (lie_dev.h), element for element and in the
+  // same order, on the TRANSPOSED triangle (m[c * ld + r] = lower[r][c]) so that the rank update of step k runs along contiguous rows:
+  // acc[r] += L[r][j] * temp[j] for j ascending, vectorised over r.  Host only (the 68x68 system of the window).
+  __attribute__((target("avx2"))) static void ldltSolveTransposed(double* m, const int ld, double* d, const int n) {
+    constexpr int NMAX = 4 + 8 * BA_MAXF;
+    int tr[NMAX];
+    double temp[NMAX], acc[NMAX];
+    bool zero = false;
+    for (int k = 0; k < n; k++) {
+      int big = k;
+      double bigv = std::fabs(m[k * ld + k]);
+      for (int i = k + 1; i < n; i++) { const double v = std::fabs(m[i * ld + i]); if (v > bigv) { bigv = v; big = i; } }
+      tr[k] = big;
+      if (k != big) {
+        for (int c = 0; c < k; c++) std::swap(m[c * ld + k], m[c * ld + big]);
+        for (int r = big + 1; r < n; r++) std::swap(m[k * ld + r], m[big * ld + r]);
+        std::swap(m[k * ld + k], m[big * ld + big]);
+        for (int i = k + 1; i < big; i++) std::swap(m[k * ld + i], m[i * ld + big]);
+      }
+      if (k > 0) {
+        for (int j = 0; j < k; j++) temp[j] = m[j * ld + j] * m[j * ld + k];
+        for (int r = k; r < n; r++) acc[r] = 0;
+        int j = 0;
+        for (; j + 4 <= k; j += 4) {
+          const double t0 = temp[j], t1 = temp[j + 1], t2 = temp[j + 2], t3 = temp[j + 3];
+          const double *r0 = m + j * ld, *r1 = r0 + ld, *r2 = r1 + ld, *r3 = r2 + ld;
+          for (int r = k; r < n; r++) acc[r] = (((acc[r] + r0[r] * t0) + r1[r] * t1) + r2[r] * t2) + r3[r] * t3;
+        }
+        for (; j < k; j++) { const double tj = temp[j]; const double* row = m + j * ld; for (int r = k; r < n; r++) acc[r] += row[r] * tj; }
+        double* rk = m + k * ld;
+        for (int r = k; r < n; r++) rk[r] -= acc[r];
+      }
+      const double akk = m[k * ld + k];
+      const bool ok = std::fabs(akk) > 0;
+      if (k == 0 && !ok) { zero = true; break; }
+      if (ok) { double* rk = m + k * ld; for (int r = k + 1; r < n; r++) rk[r] /= akk; }
+    }
+    if (zero) { for (int i = 0; i < n; i++) d[i] = 0; return; }
+    for (int k = 0; k < n; k++) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+    for (int j = 0; j < n; j++) { const double dj = d[j]; const double* row = m + j * ld; for (int i = j + 1; i < n; i++) d[i] -= row[i] * dj; }
+    for (int i = 0; i < n; i++) { if (std::fabs(m[i * ld + i]) > 2.2250738585072014e-308) d[i] /= m[i * ld + i]; else d[i] = 0; }
+    for (int i = n - 1; i >= 0; i--) { double s = d[i]; const double* row = m + i * ld; for (int j = i + 1; j < n; j++) s -= row[j] * d[j]; d[i] = s; }
+    for (int k = n - 1; k >= 0; k--) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+  }
+
+  // Everything of solveSystemF that depends on the window state only (nullspaces, orthogonalisation basis, prior right-hand side):
+  // the GN loop runs it on the host while the accumulation kernels are in flight.
+  void prepareSolve() {
+    const int nn = n();
+    getNullspaces();
+    prepareOrthogonalize();
+    std::vector<double> d(nn);
+    for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
+    bPriorM.assign(nn, 0.0);
+    const bool haveM = HM.size() == (size_t)nn * nn;
+    for (int i = 0; i < nn; i++) { double s = haveM ? bM[i] : 0.0; if (haveM) for (int j = 0; j < nn; j++) s += HM[(size_t)i * nn + j] * d[j]; bPriorM[i] = s; }
+    solvePrepared = true;
   }
 
   // EnergyFunctional::solveSystemF after the accumulations: HA,bA / Hsc,bsc come from the device; priors (accumulateLF with no
   // linearised residuals) and the marginalisation prior are added here.
   void solveSystem(int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, std::vector<double>& x) {
     const int nn = n();
-    std::vector<double> HF((size_t)nn * nn), bF(nn);
-    std::vector<double> d(nn);
-    for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
-    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
-    for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = HM[i] + HA[i];
-    for (int i = 0; i < nn; i++) { double s = bM[i]; for (int j = 0; j < nn; j++) s += HM[(size_t)i * nn + j] * d[j]; bF[i] = s + bA[i] - bsc[i]; }
+    if (!solvePrepared) prepareSolve();
+    solvePrepared = false;
+    const bool haveM = HM.size() == (size_t)nn * nn;
+    hfScratch.resize((size_t)nn * nn); htScratch.resize((size_t)nn * nn);
+    double* HF = hfScratch.data();
+    double* Ht = htScratch.data();
+    double bF[4 + 8 * BA_MAXF], sv[4 + 8 * BA_MAXF], bs[4 + 8 * BA_MAXF];
+    if (haveM) for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = HM[i] + HA[i];
+    else for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = 0.0 + HA[i];
+    for (int i = 0; i < nn; i++) bF[i] = bPriorM[i] + bA[i] - bsc[i];
     // HL_top / bL_top = priors (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302)
     for (int i = 0; i < 4; i++) { HF[(size_t)i * nn + i] += cPrior[i]; bF[i] += cPrior[i] * (double)cDeltaF[i]; }
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HF[(size_t)q * nn + q] += fr[f].prior[i]; bF[q] += fr[f].prior[i] * fr[f].delta_prior[i]; }
     for (int i = 0; i < nn; i++) HF[(size_t)i * nn + i] *= (1 + lambda);
     const double fac = 1.0f / (1 + lambda);
     for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] -= Hsc[i] * fac;
-    std::vector<double> sv(nn), Hs((size_t)nn * nn), bs(nn);
     for (int i = 0; i < nn; i++) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * nn + i] + 10);
-    for (int i = 0; i < nn; i++) { for (int j = 0; j < nn; j++) Hs[(size_t)i * nn + j] = sv[i] * HF[(size_t)i * nn + j] * sv[j]; bs[i] = sv[i] * bF[i]; }
-    ldltSolveInPlace<4 + 8 * BA_MAXF>(Hs.data(), nn, bs.data(), nn);
+    // Jacobi-scaled system, stored transposed for ldltSolveTransposed (which reads the lower triangle of the untransposed matrix)
+    for (int i = 0; i < nn; i++) { for (int j = 0; j <= i; j++) Ht[(size_t)j * nn + i] = sv[i] * HF[(size_t)i * nn + j] * sv[j]; bs[i] = sv[i] * bF[i]; }
+    ldltSolveTransposed(Ht, nn, bs, nn);
     x.resize(nn);
     for (int i = 0; i < nn; i++) x[i] = sv[i] * bs[i];
     if (iteration >= 2) orthogonalize(x);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:81)

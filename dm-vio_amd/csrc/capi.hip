@@ -34,7 +34,7 @@ struct dmvio_hip_tracker {
   float4** d_pc_ptrs = nullptr;
   float* d_pts = nullptr;
   int pts_cap = 0;
-  float *d_partials = nullptr, *d_tot = nullptr, *h_tot = nullptr;
+  float *d_partials = nullptr, *h_tot = nullptr;
   int max_eval_blocks = 1024;
   LMProblemIn *h_in = nullptr;   // 2 x batch_cap entries of pinned host memory, read by the kernel directly (each workgroup copies its 120 B into LDS)
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
@@ -300,7 +300,6 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   HIPCHKP(hipMalloc((void**)&t->d_pc_ptrs, sizeof(float4*) * DMV_MAX_LEVELS));
   HIPCHKP(hipMemcpy(t->d_pc_ptrs, t->d_pc, sizeof(float4*) * DMV_MAX_LEVELS, hipMemcpyHostToDevice));
   HIPCHKP(hipMalloc((void**)&t->d_partials, sizeof(float) * ACC_PAD * t->max_eval_blocks));
-  HIPCHKP(hipMalloc((void**)&t->d_tot, sizeof(float) * ACC_PAD));
   HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * ACC_PAD, hipHostMallocDefault));
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);
@@ -315,7 +314,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
-  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); hipFree(t->d_tot);
+  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials);
   hipHostFree(t->h_tot);
   hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
@@ -437,9 +436,8 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
   constexpr int T = 256;
   const int G = std::max(1, std::min((n + T - 1) / T, t->max_eval_blocks));
   hipLaunchKernelGGL(k_eval_partial<T>, dim3(G), dim3(T), 0, c->stream, t->dev, e, c->fs.level(new_slot, lvl), t->d_partials);
-  hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(64), 0, c->stream, t->d_partials, G, t->d_tot);
+  hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(64), 0, c->stream, t->d_partials, G, t->h_tot);   // sums stored into pinned host memory
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(t->h_tot, t->d_tot, sizeof(float) * ACC_PAD, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (res6) res6FromSums(t->h_tot, res6);
   if (H && b) systemFromSums(t->h_tot, H, b);

@@ -137,13 +137,14 @@ static int applyRes(dmvio_hip_ba* b) {
   return 0;
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
-static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P);
-static int accumulate(dmvio_hip_ba* b, bool backup_points = false) {
+static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P, bool wait = true);
+static int accumulateWait(dmvio_hip_ba* b);
+static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true) {
   hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0);
-  return accumulateViews(b, b->Rs, b->P);
+  return accumulateViews(b, b->Rs, b->P, wait);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
-static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV) {
+static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV, bool wait) {
   BAHost& H = b->H;
   const int F = H.F, F2 = F * F, n = H.n();
   hipStream_t s = b->stream;
@@ -165,8 +166,12 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   const int tot = 2 * (n * n + n);
   hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(s));   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
-  H.resInA = (int)b->h_sys[tot];
+  return wait ? accumulateWait(b) : 0;
+}
+static int accumulateWait(dmvio_hip_ba* b) {
+  const int n = b->H.n(), tot = 2 * (n * n + n);
+  HIPCHK(hipStreamSynchronize(b->stream));   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
+  b->H.resInA = (int)b->h_sys[tot];
   return 0;
 }
 static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x, bool apply_step = false) {
@@ -529,7 +534,6 @@ int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_
   if (int r = accumulate(b)) return r;
   const int n = b->H.n();
   const double* p = b->h_sys;
-  b->H.getNullspaces();
   std::vector<double> x;
   b->H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
   if (x_out) memcpy(x_out, x.data(), sizeof(double) * n);
@@ -599,8 +603,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   H.backupFrames();   // the point part of backupState rides in the first accumulation kernel
   BA_LAP(0);
   // solveSystem
-  H.getNullspaces();
-  if (int r = accumulate(b, true)) return r;
+  if (int r = accumulate(b, true, false)) return r;
+  H.prepareSolve();   // nullspaces, orthogonalisation basis, prior right-hand side: host work in the shadow of the kernels
+  if (int r = accumulateWait(b)) return r;
   BA_LAP(1);
   const double* p = b->h_sys;
   std::vector<double> x;
@@ -663,7 +668,6 @@ int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, con
   BA_READY(b);
   if (!HA || !bA || !Hsc || !bsc) return failmsg("ba_solve_system: null argument");
   std::lock_guard<std::mutex> lk(b->mu);
-  b->H.getNullspaces();
   std::vector<double> x;
   b->H.solveSystem(iteration, lambda, HA, bA, Hsc, bsc, x);
   if (x_out) memcpy(x_out, x.data(), sizeof(double) * b->H.n());
