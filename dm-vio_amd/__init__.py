@@ -59,6 +59,7 @@ def _sig(L):
     L.dmvio_hip_tracker_track_new_coarse.argtypes = [vp, C.c_int, C.c_float, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, c_i, c_i, c_i]
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.dmvio_hip_tracker_last_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     c_u8 = C.POINTER(C.c_ubyte)
     c_u8 = C.POINTER(C.c_ubyte)
     L.dmvio_hip_initializer_create.restype = vp
@@ -335,6 +336,11 @@ class CoarseTrackerHip:
     def last_ticks(self):
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_ticks(self.p, C.byref(a), C.byref(b)), "last_ticks")
+        return a.value, b.value
+
+    def last_launch(self):
+        a = C.c_int(0); b = C.c_int(0)
+        _chk(self.L, self.L.dmvio_hip_tracker_last_launch(self.p, C.byref(a), C.byref(b)), "last_launch")
         return a.value, b.value
 
     def last_work(self):

@@ -41,7 +41,7 @@ struct dmvio_hip_tracker {
   int out_cur = 0, out_fetch = 0, staged_half = 0;    // half of the last launch / half a pending fetch_begin refers to / half staged for the next launch
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
-  int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0;
+  int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0, last_cluster = 0, last_threads = 0;
   hipEvent_t done_event[2] = {nullptr, nullptr};   // recorded behind each launch: the results of that half are in host memory once it has completed
   int fetch_pending_B = 0;
   float* d_cl_part = nullptr;          // cluster mode: B x 2 x C x ACC_PAD partial sums
@@ -482,21 +482,34 @@ int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* t, int B, const int* 
   return 0;
 }
 
+// Workgroups per alignment problem.  The evaluation time falls with 1/C while every evaluation pays one device-scope barrier whose cost
+// grows with the number of workgroups in flight, so the best C grows with the template (about sqrt(points)) and shrinks with the batch;
+// the table is the argmin of a measured sweep (tools/sweep_tracking.py --cluster, profiles/r01_tracking_sweep.md) over
+// template size (level-0 points) x batch size.
+static int clusterSize(const int B, const int pc0) {
+  if (B > 128) return 1;
+  const int sz = pc0 < 20000 ? 0 : (pc0 < 70000 ? 1 : (pc0 < 180000 ? 2 : 3));
+  const int bb = B <= 4 ? 0 : (B <= 8 ? 1 : (B <= 16 ? 2 : (B <= 32 ? 3 : (B <= 64 ? 4 : 5))));
+  static const int tab[4][6] = {{8, 8, 4, 4, 4, 2}, {8, 8, 8, 4, 4, 4}, {16, 16, 8, 8, 4, 4}, {32, 16, 16, 8, 8, 4}};
+  return tab[sz][bb];
+}
+
 int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   if (!t || t->staged_B <= 0) return failmsg("track_batch_launch: nothing staged");
   dmvio_hip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
   const int B = t->staged_B;
-  // Few problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs 367 us
-  // for one 1024-thread workgroup); up to 128 problems -> one 1024-thread workgroup each; more -> 256-thread workgroups, four resident
-  // per CU (throughput).  Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES / DMVIO_HIP_LM_CLUSTER.
+  // Up to 128 problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs
+  // 367 us for one 1024-thread workgroup); more -> one 256-thread workgroup per problem, four resident per CU (throughput).
+  // Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES / DMVIO_HIP_LM_CLUSTER.
   int C = 1;
   if (t->lm_cluster_override > 0) C = t->lm_cluster_override;
-  else if (!t->lm_threads_override) C = B <= 8 ? 8 : (B <= 16 ? 4 : (B <= 32 ? 2 : 1));
+  else if (!t->lm_threads_override) C = clusterSize(B, t->dev.pc_n[0]);
   if ((long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
   const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : 256));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
   ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out;
+  t->last_cluster = C; t->last_threads = T;
   t->out_cur = t->staged_half;   // the host may still be unpacking the previous launch's half (fetch_begin pipeline)
   if (C > 1) {
     const size_t need = (size_t)B * 2 * C * ACC_PAD;
@@ -672,6 +685,13 @@ int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* t, long long* ticks_step, lo
   if (!t) return failmsg("null tracker");
   if (ticks_step) *ticks_step = t->last_ticks_step;
   if (ticks_eval) *ticks_eval = t->last_ticks_eval;
+  return 0;
+}
+
+int dmvio_hip_tracker_last_launch(dmvio_hip_tracker* t, int* workgroups_per_problem, int* threads_per_workgroup) {
+  if (!t) return failmsg("null tracker");
+  if (workgroups_per_problem) *workgroups_per_problem = t->last_cluster;
+  if (threads_per_workgroup) *threads_per_workgroup = t->last_threads;
   return 0;
 }
 

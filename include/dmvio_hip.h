@@ -134,6 +134,9 @@ int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long
 /* In-kernel time split of the last batch launch, summed over problems, in 100 MHz wall_clock64 ticks:
  * LM control steps (solve, pose update, bookkeeping) vs evaluations (calcRes+calcGS). Diagnostics only. */
 int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* trk, long long* ticks_step, long long* ticks_eval);
+/* Shape of the last batch launch: workgroups sharing one alignment problem (cluster mode for small batches) and threads per
+ * workgroup.  Diagnostics only. */
+int dmvio_hip_tracker_last_launch(dmvio_hip_tracker* trk, int* workgroups_per_problem, int* threads_per_workgroup);
 
 /* ------------------------------------------------------------------ sliding-window BA -------- */
 /* The window FullSystem::optimize works on (FullSystemOptimize.cpp:417-647): F <= 8 keyframes, N active points, R residuals.
