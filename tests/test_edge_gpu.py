@@ -78,3 +78,58 @@ def test_immature_empty_and_initializer_empty(pkg, oracle, synth, gpu_required):
     Ki = np.linalg.inv(np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1.0]]))
     g = ini.calcResAndGS(0, 0, 1, Ki, K4, IDENT, (0.0, 0.0), np.zeros(0, np.float32))
     assert not g["H"][3:, 3:].any() and g["res3"][0] == 0 and g["res3"][2] == 0
+
+
+def test_non_finite_pixels_propagate_like_the_reference(pkg, oracle, synth, gpu_required):
+    """NaN / Inf irradiance in the new frame (SURVEY §5 failure semantics): the pyramid carries them to the coarser levels exactly as
+    makeImages does, points whose interpolated colour is not finite are skipped (CoarseTracker.cpp:455), gradients that are not finite
+    count as zero (HessianBlocks.cpp:172-181) — same term counts, same sums, same alignment as the oracle."""
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=600, n_frames=1)
+    img = case["frames"][0]["img"].copy()
+    img[100:140, 60:110] = np.nan
+    img[30, 200] = np.inf; img[31, 201] = -np.inf; img[200:203, 17] = np.nan
+    ctx = pkg.Context(w, h, n_slots=2)
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, img)
+    dIr, _ = oracle.make_images(case["ref_img"], w, h); dIn, _ = oracle.make_images(img, w, h)
+    for lvl in range(ctx.levels):
+        assert np.array_equal(ctx.frame_download(1, lvl), dIn[lvl], equal_nan=True)
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    T = oracle.Tracker(w, h); T.make_k(case["K4"]); T.set_ref(dIr, case["u"], case["v"], case["idepth"], case["hdiF"]); T.set_new(dIn)
+    for lvl in range(ctx.levels):
+        rs_o = T.calc_res(lvl, case["frames"][0]["pose7"], (0.0, 0.0), 20.0)
+        H_o, b_o = T.calc_gs(lvl, (0.0, 0.0))
+        rs_g, H_g, b_g = trk.eval(lvl, 1, case["frames"][0]["pose7"], (0.0, 0.0), 20.0)
+        assert rs_g[1] == rs_o[1] and rs_o[1] < trk.pc_n(lvl)                      # the same points dropped
+        assert np.isfinite(rs_g[0]) and abs(rs_g[0] - rs_o[0]) <= 2e-5 * abs(rs_o[0]) + 1e-6
+        assert np.all(np.isfinite(H_g)) and np.allclose(H_g, H_o, rtol=1e-4, atol=1e-6 * np.abs(H_o).max())
+    g = trk.trackNewestCoarse(1, IDENT, [0.0, 0.0]); o = T.track(IDENT, [0.0, 0.0])
+    assert bool(g["good"]) == bool(o["good"])
+    assert np.linalg.norm(np.asarray(g["pose7"])[:3] - np.asarray(o["pose7"])[:3]) < 1e-3
+
+
+def test_fetch_begin_keeps_consecutive_batches_apart(pkg, oracle, synth, gpu_required):
+    """The two alternating halves of problem / result memory: batch B is staged and launched before the results of batch A are fetched."""
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=500, n_frames=6, xi_jitter=0.4)
+    ctx = pkg.Context(w, h, n_slots=7)
+    ctx.frame_upload(0, case["ref_img"])
+    for k, f in enumerate(case["frames"]):
+        ctx.frame_upload(1 + k, f["img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    A, Bb = [1, 2, 3], [4, 5, 6]
+    aff = [(0.0, 0.0)] * 3
+    trk.stage(A, [IDENT] * 3, aff); trk.launch(); refA = trk.fetch()
+    trk.stage(Bb, [IDENT] * 3, aff); trk.launch(); refB = trk.fetch()
+    assert not np.allclose(refA["pose7"], refB["pose7"])
+    for _ in range(3):   # several rounds: the halves keep alternating
+        trk.stage(A, [IDENT] * 3, aff); trk.launch(); trk.fetch_begin()
+        trk.stage(Bb, [IDENT] * 3, aff); trk.launch()
+        rA = trk.fetch(); rB = trk.fetch()
+        for k in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "good", "iterations"):
+            assert np.array_equal(rA[k], refA[k], equal_nan=True) and np.array_equal(rB[k], refB[k], equal_nan=True)
+    with pytest.raises(pkg.HipLibraryError):   # a larger batch cannot be staged while results are pending
+        trk.stage(A, [IDENT] * 3, aff); trk.launch(); trk.fetch_begin()
+        trk.stage(list(range(1, 7)) * 20, [IDENT] * 120, [(0.0, 0.0)] * 120)
