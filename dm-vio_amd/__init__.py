@@ -166,6 +166,20 @@ def _i(a):
     return a.ctypes.data_as(c_i)
 
 
+def write_result_txt(path, timestamps, camToWorld7, pose_valid=None, tracking_ref=None, camToTrackingRef7=None, firstPose7=(0, 0, 0, 0, 0, 0, 1.0)):
+    """FullSystem::printResult (FullSystem.cpp:256-298) through the library: host-only, no device needed."""
+    L = load_library()
+    ts = np.ascontiguousarray(timestamps, dtype=np.float64); P = np.ascontiguousarray(camToWorld7, dtype=np.float64).reshape(-1, 7)
+    pv = None if pose_valid is None else np.ascontiguousarray(pose_valid, dtype=np.uint8)
+    tr = None if tracking_ref is None else np.ascontiguousarray(tracking_ref, dtype=np.int32)
+    cr = None if camToTrackingRef7 is None else np.ascontiguousarray(camToTrackingRef7, dtype=np.float64)
+    fp = np.ascontiguousarray(firstPose7, dtype=np.float64)
+    L.dmvio_hip_write_result_txt.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 6
+    L.dmvio_hip_write_result_txt.restype = C.c_int
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    _chk(L, L.dmvio_hip_write_result_txt(str(path).encode(), len(ts), ptr(ts), ptr(P), ptr(pv), ptr(tr), ptr(cr), ptr(fp)), "write_result_txt")
+
+
 def make_track_hypotheses(slast_c2w, sprelast_c2w, lastF_c2w):
     """lastF_2_fh_tries of FullSystem::trackNewCoarse (host-side pose algebra of the library)."""
     L = load_library()

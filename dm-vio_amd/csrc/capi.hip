@@ -702,4 +702,30 @@ int dmvio_hip_tracker_last_work(dmvio_hip_tracker* t, long long* n_evals, long l
   return 0;
 }
 
+// FullSystem::printResult (FullSystem.cpp:256-298): one line "timestamp tx ty tz qx qy qz qw" per frame with a valid pose, 15
+// significant digits, poses relative to the first frame (camToFirst = firstPose^-1 * camToWorld); frames that are not keyframes are
+// re-based on their tracking reference's CURRENT pose when tracking_ref / camToTrackingRef7 are given (useCamToTrackingRef).
+// Host-only (no device work): the on-disk edge of the path, so that trajectories of both pipelines compare file against file.
+int dmvio_hip_write_result_txt(const char* path, int n, const double* timestamps, const double* camToWorld7, const unsigned char* pose_valid,
+                               const int* tracking_ref, const double* camToTrackingRef7, const double firstPose7[7]) {
+  if (!path || n < 0 || (n > 0 && (!timestamps || !camToWorld7)) || !firstPose7) return failmsg("write_result_txt: bad argument");
+  if (tracking_ref && !camToTrackingRef7) return failmsg("write_result_txt: tracking_ref without camToTrackingRef7");
+  FILE* f = fopen(path, "w");
+  if (!f) return failmsg("write_result_txt: cannot open the file");
+  const Pose firstInv = poseInv(poseFrom7(firstPose7));
+  for (int i = 0; i < n; i++) {
+    if (pose_valid && !pose_valid[i]) continue;
+    Pose c2w = poseFrom7(camToWorld7 + 7 * i);
+    if (tracking_ref && tracking_ref[i] >= 0) {
+      if (tracking_ref[i] >= n) { fclose(f); return failmsg("write_result_txt: tracking_ref out of range"); }
+      c2w = poseMul(poseFrom7(camToWorld7 + 7 * tracking_ref[i]), poseFrom7(camToTrackingRef7 + 7 * i));
+    }
+    double p[7];
+    poseTo7(poseMul(firstInv, c2w), p);
+    fprintf(f, "%.15g %.15g %.15g %.15g %.15g %.15g %.15g %.15g\n", timestamps[i], p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+  }
+  if (fclose(f) != 0) return failmsg("write_result_txt: write failed");
+  return 0;
+}
+
 }  // extern "C"

@@ -60,6 +60,12 @@ dmvio_hip_undistorter* dmvio_hip_undistorter_create(dmvio_hip_ctx* ctx, int wOrg
                                                     const float* remapX, const float* remapY);
 void dmvio_hip_undistorter_destroy(dmvio_hip_undistorter* und);
 int dmvio_hip_frame_upload_raw(dmvio_hip_ctx* ctx, dmvio_hip_undistorter* und, int slot, const void* raw, float factor, float* undistorted_out);
+/* FullSystem::printResult (src/dso/FullSystem/FullSystem.cpp:256-298): "timestamp tx ty tz qx qy qz qw" per frame with a valid pose,
+ * 15 significant digits, camToFirst = firstPose^-1 * camToWorld.  pose7 = [tx ty tz qx qy qz qw].  pose_valid (n, may be NULL = all
+ * valid): FrameShell::poseValid.  tracking_ref (n, may be NULL): index of the frame's tracking reference, or -1 for keyframes; when
+ * >= 0 the pose written is camToWorld[tracking_ref] * camToTrackingRef (useCamToTrackingRef).  Host-only, no device needed. */
+int dmvio_hip_write_result_txt(const char* path, int n, const double* timestamps, const double* camToWorld7, const unsigned char* pose_valid,
+                               const int* tracking_ref, const double* camToTrackingRef7, const double firstPose7[7]);
 /* makeImages for B frames in 4 launches: frame i is read from dev_base + i*stride_bytes and written to slots[i].
  * Asynchronous on the ctx stream (ordering with later tracker calls is by stream order). */
 int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);

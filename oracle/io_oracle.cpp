@@ -2,8 +2,12 @@
 // CPU restatement of the image input edge of the hot path:
 //   orc_undistort  <- PhotometricUndistorter::processFrame (src/dso/util/Undistort.cpp:214-250) + Undistort::undistort (:386-481, without the
 //                     benchmark noise options)
+//   orc_write_result_txt <- FullSystem::printResult (src/dso/FullSystem/FullSystem.cpp:256-298)
 #include <cstring>
 #include <vector>
+#include <fstream>
+#include <iomanip>
+#include "lie.h"
 
 extern "C" {
 
@@ -31,6 +35,24 @@ void orc_undistort(const void* raw, int bits, int wOrg, int hOrg, const float* G
       out[idx] = xxyy * src[1 + wOrg] + (yy - xxyy) * src[wOrg] + (xx - xxyy) * src[1] + (1 - xx - yy + xxyy) * src[0];
     }
   }
+}
+
+// FullSystem::printResult (FullSystem.cpp:256-298); std::setprecision(15) on a default-format ostream == "%.15g"
+int orc_write_result_txt(const char* path, int n, const double* timestamps, const double* camToWorld7, const unsigned char* pose_valid,
+                         const int* tracking_ref, const double* camToTrackingRef7, const double* firstPose7) {
+  std::ofstream out(path);
+  if (!out) return -1;
+  out << std::setprecision(15);
+  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qnormalize(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
+  const orc::SE3 firstInv = orc::se3Inv(from7(firstPose7));
+  for (int i = 0; i < n; i++) {
+    if (pose_valid && !pose_valid[i]) continue;
+    orc::SE3 c2w = from7(camToWorld7 + 7 * i);
+    if (tracking_ref && tracking_ref[i] >= 0) c2w = orc::se3Mul(from7(camToWorld7 + 7 * tracking_ref[i]), from7(camToTrackingRef7 + 7 * i));
+    const orc::SE3 T = orc::se3Mul(firstInv, c2w);
+    out << timestamps[i] << " " << T.t[0] << " " << T.t[1] << " " << T.t[2] << " " << T.q.x << " " << T.q.y << " " << T.q.z << " " << T.q.w << "\n";
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -194,6 +194,21 @@ def undistort(raw, G, vig, remapX, remapY, w, h, factor=1.0):
     return out
 
 
+def write_result_txt(path, timestamps, camToWorld7, pose_valid=None, tracking_ref=None, camToTrackingRef7=None, firstPose7=(0, 0, 0, 0, 0, 0, 1.0)):
+    """FullSystem::printResult."""
+    ts = np.ascontiguousarray(timestamps, dtype=np.float64); P = np.ascontiguousarray(camToWorld7, dtype=np.float64).reshape(-1, 7)
+    pv = None if pose_valid is None else np.ascontiguousarray(pose_valid, dtype=np.uint8)
+    tr = None if tracking_ref is None else np.ascontiguousarray(tracking_ref, dtype=np.int32)
+    cr = None if camToTrackingRef7 is None else np.ascontiguousarray(camToTrackingRef7, dtype=np.float64)
+    fp = np.ascontiguousarray(firstPose7, dtype=np.float64)
+    L = lib()
+    L.orc_write_result_txt.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 6
+    L.orc_write_result_txt.restype = C.c_int
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    if L.orc_write_result_txt(str(path).encode(), len(ts), ptr(ts), ptr(P), ptr(pv), ptr(tr), ptr(cr), ptr(fp)) != 0:
+        raise RuntimeError("orc_write_result_txt failed")
+
+
 def pair_precalc(target_w2c7, host_c2w7, host_exposure=1.0, target_exposure=1.0, host_aff=(0.0, 0.0), target_aff=(0.0, 0.0)):
     """FrameFramePrecalc::set: PRE_RTll (9), PRE_tTll (3), PRE_aff_mode (2) of the pair host -> target."""
     R = np.zeros(9, np.float32); t = np.zeros(3, np.float32); aff = np.zeros(2, np.float32)
