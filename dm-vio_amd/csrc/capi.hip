@@ -553,7 +553,7 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   int B = t->staged_B, half = t->out_cur;
-  if (t->fetch_pending_B > 0) {   // download already queued by _fetch_begin: wait for it only
+  if (t->fetch_pending_B > 0) {   // results marked by _fetch_begin: they belong to the launch before the last one
     B = t->fetch_pending_B; t->fetch_pending_B = 0; half = t->out_fetch;
   }
   if (!t->done_event[half]) return failmsg("track_batch_fetch: nothing launched");

@@ -220,7 +220,7 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->stream);
   if (b->timing && b->tm.n > 0) {
-    const char* names[8] = {"backup", "accumulate+D2H", "host solve", "resubstitute", "step frames+points", "precalc", "linearize+TH", "apply/restore"};
+    const char* names[8] = {"backup", "accumulate+stitch", "host solve", "resubstitute", "step frames+points", "precalc", "linearize+TH", "apply/restore"};
     fprintf(stderr, "[dmvio_hip_ba] GN iteration host-side split over %ld iterations (us/iter):", b->tm.n);
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f", names[i], b->tm.t[i] / b->tm.n);
     fprintf(stderr, "\n");
@@ -435,7 +435,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
   b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256;
-  // energy partials (doubles) and the per-residual energies with outliers (floats) share one allocation: one download per linearisation
+  // energy partials (doubles) and the per-residual energies with outliers (floats) share one pinned allocation the kernel stores into
   b->n_epart = std::max(b->n_lin_blocks, F2 * 8);
   if (dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
