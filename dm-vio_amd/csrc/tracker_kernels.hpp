@@ -210,15 +210,14 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
     P1 = pc[min(base0 + lane + stride, nm1)];
     projectPoint(P0, base0 + lane < n, eu, img, q0, t0);
   }
-  for (int base = base0; base < n; base += stride) {
+  // one pipeline step: finishes the point held in (qc, tc) while the taps of the next one are requested into (qn, tn).  The loop below is
+  // unrolled twice with the two register sets swapping roles, so the hand-over costs no register moves (19 per step otherwise).
+  auto step = [&](const PointProj& qc, const Taps33& tc, PointProj& qn, Taps33& tn, const int base) __attribute__((always_inline)) {
     const int i = base + lane;
-    PointProj q1;
-    Taps33 t1;
-    projectPoint(P1, i + stride < n, eu, img, q1, t1);     // next point: its taps are requested now, consumed next iteration
+    projectPoint(P1, i + stride < n, eu, img, qn, tn);     // next point: its taps are requested now, consumed next step
     P1 = pc[min(i + 2 * stride, nm1)];                     // unconditional (clamped) prefetch
     float J[9], w;
-    finishPoint(q0, t0, eu, st, J, w);
-    q0 = q1; t0 = t1;
+    finishPoint(qc, tc, eu, st, J, w);
 #pragma unroll
     for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
     wW[lane] = w;
@@ -236,6 +235,13 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
       accH3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, accH3, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+  };
+  PointProj q1;
+  Taps33 t1;
+  for (int base = base0; base < n; base += 2 * stride) {
+    step(q0, t0, q1, t1, base);
+    if (base + stride >= n) break;   // wave-uniform
+    step(q1, t1, q0, t0, base + stride);
   }
   if (lvl0) {
     // flow-indicator samples: dense pass over the flagged entries (bit j of word k <=> template entry 64k + j)
