@@ -69,14 +69,34 @@ __device__ __forceinline__ EvalU makeEvalU(const EvalP& e, const LevelGeom& g, c
 // Split in two so that the taps of the NEXT point are in flight while the current one is finished (software pipelining):
 // projectPoint = warp + bounds test + the four tap loads; finishPoint = everything that consumes the taps.
 struct PointProj { float u, v, Ku, Kv, new_idepth, refColor; bool inb; };
+
+// IEEE fp32 division as the compiler expands it (LLVM AMDGPU LowerFDIV32: div_scale x2, rcp, fma x2, mul, fma x3, div_fmas, div_fixup),
+// minus the range scaling and the special-case fix-up, with the refined reciprocal shared by all quotients of one denominator.
+// For operands in the normal range without an extreme exponent gap (no scaling applied by v_div_scale) the operation sequence is the
+// same, hence the same correctly rounded quotient; every surviving lane of the evaluation loop is in that range (pixel coordinates,
+// inverse depths, residuals), lanes holding 0 / Inf / NaN are masked by the tests that follow.  11 -> 3 + 5 instructions per quotient.
+struct Recip { float nb, r1; };
+__device__ __forceinline__ Recip refinedRcp(const float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, r, 1.0f);
+  return Recip{-b, __builtin_fmaf(e0, r, r)};
+}
+__device__ __forceinline__ float divBy(const float a, const Recip& R) {
+  const float q0 = a * R.r1;
+  const float e1 = __builtin_fmaf(R.nb, q0, a);
+  const float q1 = __builtin_fmaf(e1, R.r1, q0);
+  const float e2 = __builtin_fmaf(R.nb, q1, a);
+  return __builtin_fmaf(e2, R.r1, q1);
+}
 __device__ __forceinline__ void projectPoint(const float4 P, const bool live, const EvalU& e, const float* __restrict__ img, PointProj& q, Taps33& taps) {
   const float x = P.x, y = P.y, id = P.z;
   const float pt0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f + e.t[0] * id;
   const float pt1 = e.RKi[3] * x + e.RKi[4] * y + e.RKi[5] * 1.0f + e.t[1] * id;
   const float pt2 = e.RKi[6] * x + e.RKi[7] * y + e.RKi[8] * 1.0f + e.t[2] * id;
-  q.u = pt0 / pt2; q.v = pt1 / pt2;
+  const Recip rz = refinedRcp(pt2);
+  q.u = divBy(pt0, rz); q.v = divBy(pt1, rz);
   const float Ku = e.fx * q.u + e.cx, Kv = e.fy * q.v + e.cy;
-  q.new_idepth = id / pt2;
+  q.new_idepth = divBy(id, rz);
   q.refColor = P.w;
   q.inb = live && (Ku > 2 && Kv > 2 && Ku < e.wM3 && Kv < e.hM3 && q.new_idepth > 0);
   q.Ku = q.inb ? Ku : 2.5f; q.Kv = q.inb ? Kv : 2.5f;   // masked lanes tap a safe pixel
@@ -88,7 +108,7 @@ __device__ __forceinline__ void finishPoint(const PointProj& q, const Taps33& ta
   const bool fin = q.inb && isfinite(hit.x);
   const float residual = hit.x - (e.aff0 * refColor + e.aff1);
   const float ar = fabsf(residual);
-  const float hw = ar < e.huberTH ? 1.0f : e.huberTH / ar;
+  const float hw = ar < e.huberTH ? 1.0f : divBy(e.huberTH, refinedRcp(ar));
   const bool sat = ar > e.cutoff, ok = fin && !sat;
   st.nE += fin ? 1.0f : 0.0f;
   st.nSat += (fin && sat) ? 1.0f : 0.0f;
