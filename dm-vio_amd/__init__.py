@@ -232,6 +232,15 @@ class Context:
         slots = np.ascontiguousarray(slots, dtype=np.int32)
         _chk(self.L, self.L.dmvio_hip_frames_from_device_batch(self.p, len(slots), _i(slots), C.c_void_p(dev_ptr), stride_bytes), "frames_from_device_batch")
 
+    def selftest_divide(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+        qs = np.zeros_like(a); qi = np.zeros_like(a)
+        self.L.dmvio_hip_selftest_divide.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        self.L.dmvio_hip_selftest_divide.restype = C.c_int
+        _chk(self.L, self.L.dmvio_hip_selftest_divide(self.p, a.size, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                      qs.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p)), "selftest_divide")
+        return qs, qi
+
     def frame_download(self, slot, lvl):
         out = np.zeros(((self.h >> lvl), (self.w >> lvl), 3), dtype=np.float32)
         _chk(self.L, self.L.dmvio_hip_frame_download(self.p, slot, lvl, _f(out)), "frame_download")

@@ -688,6 +688,25 @@ int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* t, long long* ticks_step, lo
   return 0;
 }
 
+// Diagnostics: the evaluation loop's division (refined reciprocal shared by the quotients of one denominator) next to the compiler's
+// IEEE division, for n operand pairs — lets a test pin the claim that both give the same bits in the operand range of the path.
+int dmvio_hip_selftest_divide(dmvio_hip_ctx* c, int n, const float* a, const float* b, float* q_shared, float* q_ieee) {
+  if (!c || n <= 0 || !a || !b || !q_shared || !q_ieee) return failmsg("selftest_divide: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  float* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, sizeof(float) * 4 * (size_t)n));
+  HIPCHK(hipMemcpyAsync(d, a, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d + n, b, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_selftest_divide, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(q_shared, d + 2 * (size_t)n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(q_ieee, d + 3 * (size_t)n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
 int dmvio_hip_tracker_last_launch(dmvio_hip_tracker* t, int* workgroups_per_problem, int* threads_per_workgroup) {
   if (!t) return failmsg("null tracker");
   if (workgroups_per_problem) *workgroups_per_problem = t->last_cluster;

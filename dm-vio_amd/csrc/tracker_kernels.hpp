@@ -155,6 +155,15 @@ __device__ __forceinline__ void flowSamplePoint(const float4 P, const EvalU& e, 
   st.fN += 2.0f;
 }
 
+// Self-test of divBy: both quotients of every pair, so a test can compare them bit for bit (and against the host's IEEE division)
+__global__ void __launch_bounds__(256) k_selftest_divide(const int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ q_shared,
+                                                         float* __restrict__ q_ieee) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  q_shared[i] = divBy(a[i], refinedRcp(b[i]));
+  q_ieee[i] = a[i] / b[i];
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS staging of one wave: the 64 rows J (transposed: component-major, padded stride) + the 64 weights.

@@ -143,6 +143,9 @@ int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* trk, long long* ticks_step, 
 /* Shape of the last batch launch: workgroups sharing one alignment problem (cluster mode for small batches) and threads per
  * workgroup.  Diagnostics only. */
 int dmvio_hip_tracker_last_launch(dmvio_hip_tracker* trk, int* workgroups_per_problem, int* threads_per_workgroup);
+/* Diagnostics: for n operand pairs, the quotient a/b as the tracker's evaluation loop computes it (refined reciprocal shared by the
+ * quotients of one denominator, CoarseTracker.cpp:381-384 / :465 being the divisions in question) and as the compiler's IEEE division does. */
+int dmvio_hip_selftest_divide(dmvio_hip_ctx* ctx, int n, const float* a, const float* b, float* q_shared, float* q_ieee);
 
 /* ------------------------------------------------------------------ sliding-window BA -------- */
 /* The window FullSystem::optimize works on (FullSystemOptimize.cpp:417-647): F <= 8 keyframes, N active points, R residuals.

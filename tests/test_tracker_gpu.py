@@ -234,3 +234,23 @@ def test_track_new_coarse_try_loop(setup, oracle, pkg):
     assert o["winner"] == g["winner"] and o["tries_used"] == g["tries_used"] and o["good"] == g["good"]
     assert np.max(np.abs(g["pose7"] - o["pose7"])) < 1e-5
     assert np.allclose(g["achievedRes"], o["achievedRes"], rtol=1e-4, equal_nan=True)
+
+
+def test_shared_reciprocal_division_is_ieee_division(pkg, gpu_required):
+    """The evaluation loop divides by the projected depth through one refined reciprocal (LLVM's fdiv expansion without range scaling and
+    fix-up): in the operand range of the path the quotient has the bits of the IEEE division — of the device's own and of the host's."""
+    rng = np.random.RandomState(12)
+    n = 1 << 20
+    ctx = pkg.Context(64, 64, n_slots=1)
+    cases = [
+        (rng.uniform(-4.0, 4.0, n), rng.uniform(0.05, 8.0, n)),                     # pt0 / pt2, pt1 / pt2
+        (rng.uniform(1e-3, 10.0, n), rng.uniform(0.05, 8.0, n)),                    # id / pt2
+        (np.full(n, 9.0), rng.uniform(9.0, 255.0, n)),                              # huberTH / |residual|
+        (rng.normal(size=n) * 10.0 ** rng.uniform(-12, 12, n), rng.normal(size=n) * 10.0 ** rng.uniform(-12, 12, n)),   # wide, still unscaled
+    ]
+    for a, b in cases:
+        a = a.astype(np.float32); b = b.astype(np.float32)
+        qs, qi = ctx.selftest_divide(a, b)
+        host = a / b
+        assert np.array_equal(qi.view(np.uint32), host.view(np.uint32))             # the device's IEEE division == the host's
+        assert np.array_equal(qs.view(np.uint32), qi.view(np.uint32))               # the shared-reciprocal form == IEEE division
