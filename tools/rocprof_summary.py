@@ -16,14 +16,15 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     counters = "--counters" in sys.argv
     if not counters:
-        print("| kernel | calls | total_us | avg_us | min_us | max_us | pct | vgpr | lds | wg |")
-        print("|---|---|---|---|---|---|---|---|---|---|")
+        # one row per (kernel, grid): the same kernel launched over different problem sizes (batch 1024 vs the 64-frame overlap leg) stays apart
+        print("| kernel | workgroups | calls | total_us | avg_us | min_us | max_us | pct | vgpr | lds | wg |")
+        print("|---|---|---|---|---|---|---|---|---|---|---|")
         rows = db.execute(
-            "select name, count(*), sum(duration)/1e3, avg(duration)/1e3, min(duration)/1e3, max(duration)/1e3, max(vgpr_count), max(lds_size), max(workgroup_x) "
-            "from kernels group by name order by sum(duration) desc").fetchall()
-        tot = sum(r[2] for r in rows)
-        for r in rows:
-            print("| %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %d | %d | %d |" % (short(r[0]), r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6], r[7], r[8]))
+            "select name, (grid_x / workgroup_x) * max(grid_y / workgroup_y, 1) as wgs, count(*), sum(duration)/1e3, avg(duration)/1e3, min(duration)/1e3, max(duration)/1e3, "
+            "max(vgpr_count), max(lds_size), max(workgroup_x) from kernels group by name, wgs order by sum(duration) desc").fetchall()
+        tot = sum(r[3] for r in rows)
+        for r in rows[:40]:
+            print("| %s | %d | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %d | %d | %d |" % (short(r[0]), r[1], r[2], r[3], r[4], r[5], r[6], 100 * r[3] / tot, r[7], r[8], r[9]))
     else:
         print("| kernel | counter | dispatches | avg | min | max |")
         print("|---|---|---|---|---|---|")
