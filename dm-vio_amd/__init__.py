@@ -241,6 +241,11 @@ class Context:
                                                       qs.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p)), "selftest_divide")
         return qs, qi
 
+    def frame_mark_unclean(self, slot):
+        self.L.dmvio_hip_frame_mark_unclean.argtypes = [C.c_void_p, C.c_int]
+        self.L.dmvio_hip_frame_mark_unclean.restype = C.c_int
+        _chk(self.L, self.L.dmvio_hip_frame_mark_unclean(self.p, slot), "frame_mark_unclean")
+
     def frame_download(self, slot, lvl):
         out = np.zeros(((self.h >> lvl), (self.w >> lvl), 3), dtype=np.float32)
         _chk(self.L, self.L.dmvio_hip_frame_download(self.p, slot, lvl, _f(out)), "frame_download")

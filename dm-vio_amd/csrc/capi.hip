@@ -88,6 +88,9 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHKP(hipMalloc((void**)&c->fs.base, sizeof(float) * c->fs.slot_stride * n_frame_slots));
   HIPCHKP(hipMemsetAsync(c->fs.base, 0, sizeof(float) * c->fs.slot_stride * n_frame_slots, c->stream));
+  HIPCHKP(hipMalloc((void**)&c->fs.build_gen, sizeof(unsigned int) * 2 * n_frame_slots));   // build_gen | bad_gen: equal (0) = not known to be clean
+  HIPCHKP(hipMemsetAsync(c->fs.build_gen, 0, sizeof(unsigned int) * 2 * n_frame_slots, c->stream));
+  c->fs.bad_gen = c->fs.build_gen + n_frame_slots;
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
@@ -102,6 +105,7 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hipFree(c->fs.base);
+  hipFree(c->fs.build_gen);
   hipFree(c->d_upload);
   hipFree(c->d_f3);
   hipFree(c->d_slots);
@@ -136,7 +140,7 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
 // ------------------------------------------------------------------ frames
 static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, 1), dim3(256), 0, c->stream, d_color, (size_t)0, c->pg, c->fs,
-                     (const int*)nullptr, slot);
+                     (const int*)nullptr, slot, ++c->build_gen);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -244,8 +248,17 @@ int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots
     c->slots_valid = B;
   }
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
-                     c->pg, c->fs, (const int*)c->d_slots, 0);
+                     c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Diagnostics: withdraw the "every pixel finite" stamp of a slot, so that its consumers take the guarded code path (tests compare the two)
+int dmvio_hip_frame_mark_unclean(dmvio_hip_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= c->n_slots) return failmsg("frame_mark_unclean: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->fs.bad_gen + slot, c->fs.build_gen + slot, sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 

@@ -23,6 +23,10 @@ struct FrameStore {
   size_t slot_stride;    // floats per slot
   size_t level_off[DMV_MAX_LEVELS];
   int levels;
+  // per slot: generation stamp of the last pyramid build, and of the last build that met a pixel that is not finite or beyond 1e30
+  // (k_build_pyramids).  bad_gen[slot] != build_gen[slot]  <=>  every pixel of every level is finite and so is every central difference:
+  // consumers may then skip the reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455) — they cannot fire.
+  unsigned int *build_gen, *bad_gen;
   __host__ __device__ const float* level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
   __host__ __device__ float* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };

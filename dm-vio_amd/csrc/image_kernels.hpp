@@ -18,7 +18,7 @@ namespace dmv {
 typedef float pyr_f4 __attribute__((ext_vector_type(4)));
 #define PYR_TILE 64
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
-                                                         const FrameStore fs, const int* __restrict__ slots, const int single_slot) {
+                                                         const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen) {
   __shared__ float s_a[PYR_TILE * PYR_TILE];
   __shared__ float s_b[(PYR_TILE / 2) * (PYR_TILE / 2)];
   const int f = blockIdx.y;
@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
   const int x0 = tx * PYR_TILE, y0 = ty * PYR_TILE;
+  bool bad = false;
   // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store.
   // The raw image is read once and the level-0 plane is far larger than the caches it would pollute: non-temporal loads / stores
   // (measured: 4.4 -> 5.5 TB/s)
@@ -60,9 +61,13 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
         }
       }
       *reinterpret_cast<float4*>(&s_a[ly * PYR_TILE + lx]) = v[p];
+      // NaN fails the comparison too; out-of-image lanes hold zeros
+      bad |= !(fabsf(v[p].x) <= 1e30f) || !(fabsf(v[p].y) <= 1e30f) || !(fabsf(v[p].z) <= 1e30f) || !(fabsf(v[p].w) <= 1e30f);
     }
   }
-  __syncthreads();
+  // stamps of this build (see FrameStore): the barrier the level reduction needs anyway carries the tile's verdict
+  if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
+  if (blockIdx.x == 0 && threadIdx.x == 0) fs.build_gen[slot] = gen;
   float* cur = s_a;
   float* nxt = s_b;
   int side = PYR_TILE;

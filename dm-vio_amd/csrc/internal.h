@@ -28,6 +28,7 @@ struct dmvio_hip_ctx {
   int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
   int *d_slots = nullptr, *h_slots = nullptr;
   int slots_cap = 0, slots_valid = 0;
+  unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)
   std::mutex mu;
 };
 

@@ -9,6 +9,8 @@ namespace dmv {
 // 4x4 intensity neighbourhood: rows iy-1 (2 px), iy (4 px), iy+1 (4 px), iy+2 (2 px) = 48 B in four unaligned vector loads.
 // Callers guarantee 1 <= ix, ix+2 <= w-1, 1 <= iy, iy+2 <= h-1 (true for every in-bounds tap of tracker and BA).
 __device__ __forceinline__ float fin0(const float v) { return isfinite(v) ? v : 0.0f; }
+template <bool GUARD>
+__device__ __forceinline__ float fin0g(const float v) { return GUARD ? fin0(v) : v; }
 __device__ __forceinline__ float3 interp33(const float* __restrict__ img, const float x, const float y, const int width) {
   const int ix = (int)x, iy = (int)y;
   const float dx = x - ix, dy = y - iy;
@@ -43,6 +45,8 @@ __device__ __forceinline__ void interp33Load(const float* __restrict__ img, cons
   __builtin_memcpy(&t.C, bp + width - 1, 16);
   __builtin_memcpy(&t.D, bp + 2 * width, 8);
 }
+// GUARD = false: for planes stamped clean by k_build_pyramids (FrameStore::bad_gen) — the guards cannot fire, the values are the same
+template <bool GUARD = true>
 __device__ __forceinline__ float3 interp33Finish(const Taps33& t, const float x, const float y) {
   const int ix = (int)x, iy = (int)y;
   const float dx = x - ix, dy = y - iy;
@@ -50,10 +54,10 @@ __device__ __forceinline__ float3 interp33Finish(const Taps33& t, const float x,
   const float2 A = t.A, D = t.D;
   const float4 B = t.B, C = t.C;
   const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-  const float gx00 = fin0(0.5f * (B.z - B.x)), gx10 = fin0(0.5f * (B.w - B.y));
-  const float gx01 = fin0(0.5f * (C.z - C.x)), gx11 = fin0(0.5f * (C.w - C.y));
-  const float gy00 = fin0(0.5f * (C.y - A.x)), gy10 = fin0(0.5f * (C.z - A.y));
-  const float gy01 = fin0(0.5f * (D.x - B.y)), gy11 = fin0(0.5f * (D.y - B.z));
+  const float gx00 = fin0g<GUARD>(0.5f * (B.z - B.x)), gx10 = fin0g<GUARD>(0.5f * (B.w - B.y));
+  const float gx01 = fin0g<GUARD>(0.5f * (C.z - C.x)), gx11 = fin0g<GUARD>(0.5f * (C.w - C.y));
+  const float gy00 = fin0g<GUARD>(0.5f * (C.y - A.x)), gy10 = fin0g<GUARD>(0.5f * (C.z - A.y));
+  const float gy01 = fin0g<GUARD>(0.5f * (D.x - B.y)), gy11 = fin0g<GUARD>(0.5f * (D.y - B.z));
   float3 r;
   r.x = w11 * C.z + w01 * C.y + w10 * B.z + w00 * B.y;
   r.y = w11 * gx11 + w01 * gx01 + w10 * gx10 + w00 * gx00;

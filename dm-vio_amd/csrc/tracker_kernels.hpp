@@ -102,10 +102,11 @@ __device__ __forceinline__ void projectPoint(const float4 P, const bool live, co
   q.Ku = q.inb ? Ku : 2.5f; q.Kv = q.inb ? Kv : 2.5f;   // masked lanes tap a safe pixel
   interp33Load(img, q.Ku, q.Kv, e.w, taps);
 }
+template <bool GUARD>
 __device__ __forceinline__ void finishPoint(const PointProj& q, const Taps33& taps, const EvalU& e, EvalStats& st, float (&J)[9], float& wOut) {
   const float u = q.u, v = q.v, new_idepth = q.new_idepth, refColor = q.refColor;
-  const float3 hit = interp33Finish(taps, q.Ku, q.Kv);
-  const bool fin = q.inb && isfinite(hit.x);
+  const float3 hit = interp33Finish<GUARD>(taps, q.Ku, q.Kv);
+  const bool fin = GUARD ? (q.inb && isfinite(hit.x)) : q.inb;
   const float residual = hit.x - (e.aff0 * refColor + e.aff1);
   const float ar = fabsf(residual);
   const float hw = ar < e.huberTH ? 1.0f : divBy(e.huberTH, refinedRcp(ar));
@@ -209,7 +210,8 @@ __device__ __forceinline__ float waveReduceStats(const EvalStats& st, const int 
 // class as the reference's fp32 sums; the accumulator costs 4 registers per lane instead of 45, which is what lets
 // 4-8 waves per SIMD stay resident to hide the gather latency.  Fixed summation order (bitwise reproducible).
 // Result: s_tot[0..63] (ACC_* slots) valid for all threads after return.
-template <int T>
+// GUARD = false: the new frame is stamped clean (FrameStore::bad_gen), the isfinite guards of the taps are compiled out
+template <int T, bool GUARD = true>
 __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, const float4* __restrict__ pc, const int n,
                                           const unsigned long long* __restrict__ flow_mask, const int first, const int stride,
                                           const float* __restrict__ img, const float huberTH, float* s_stage, float* s_partH,
@@ -246,7 +248,7 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
     projectPoint(P1, i + stride < n, eu, img, qn, tn);     // next point: its taps are requested now, consumed next step
     P1 = pc[min(i + 2 * stride, nm1)];                     // unconditional (clamped) prefetch
     float J[9], w;
-    finishPoint(qc, tc, eu, st, J, w);
+    finishPoint<GUARD>(qc, tc, eu, st, J, w);
 #pragma unroll
     for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
     wW[lane] = w;
@@ -717,6 +719,8 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   if (threadIdx.x < 64) { s_H[threadIdx.x] = 0; if (threadIdx.x < 8) { s_b[threadIdx.x] = 0; s_x[threadIdx.x] = 0; } }
   initStage<T>(s_stage);
   const int slot = pin.new_slot;
+  // every pixel of the new frame finite (stamped by its pyramid build): the evaluation loop without the isfinite guards gives the same values
+  const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
   long long tStep = 0, tEval = 0;
   for (;;) {
     const long long t0 = wall_clock64();
@@ -729,8 +733,12 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     tStep += t1 - t0;
     if (!s_go) break;
     const int lvl = s_e.lvl;
-    blockEval<T>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage, s_partH,
-                 s_partS, s_tot);
+    if (clean)
+      blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage,
+                          s_partH, s_partS, s_tot);
+    else
+      blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage,
+                         s_partH, s_partS, s_tot);
     if (cl.C > 1) { clusterExchange(s_tot, cl, prob, rank, phase); phase++; }
     tEval += wall_clock64() - t1;
   }

@@ -69,6 +69,10 @@ int dmvio_hip_write_result_txt(const char* path, int n, const double* timestamps
 /* makeImages for B frames in 4 launches: frame i is read from dev_base + i*stride_bytes and written to slots[i].
  * Asynchronous on the ctx stream (ordering with later tracker calls is by stream order). */
 int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);
+/* Diagnostics.  Every pyramid build stamps its slot "clean" when all pixels are finite (|I| <= 1e30): consumers then run without the
+ * reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455), which cannot fire on such a frame.  This call withdraws
+ * the stamp so that the guarded code path runs (tests compare the two). */
+int dmvio_hip_frame_mark_unclean(dmvio_hip_ctx* ctx, int slot);
 /* dIp[lvl] back on host as w_l*h_l*3 floats (AoS, the reference's Eigen::Vector3f layout). */
 int dmvio_hip_frame_download(dmvio_hip_ctx* ctx, int slot, int lvl, float* dIp_host);
 

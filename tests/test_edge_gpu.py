@@ -133,3 +133,27 @@ def test_fetch_begin_keeps_consecutive_batches_apart(pkg, oracle, synth, gpu_req
     with pytest.raises(pkg.HipLibraryError):   # a larger batch cannot be staged while results are pending
         trk.stage(A, [IDENT] * 3, aff); trk.launch(); trk.fetch_begin()
         trk.stage(list(range(1, 7)) * 20, [IDENT] * 120, [(0.0, 0.0)] * 120)
+
+
+def test_guarded_and_guard_free_paths_agree_bit_for_bit(pkg, synth, gpu_required):
+    """A frame whose pixels are all finite is stamped clean by its pyramid build and tracked without the isfinite guards; withdrawing the
+    stamp selects the guarded loop — same bits in every output."""
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=800, n_frames=3, xi_jitter=0.3)
+    ctx = pkg.Context(w, h, n_slots=4)
+    ctx.frame_upload(0, case["ref_img"])
+    for k, f in enumerate(case["frames"]):
+        ctx.frame_upload(1 + k, f["img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    slots = [1, 2, 3]
+    a = trk.track_batch(slots, [IDENT] * 3, [(0.0, 0.0)] * 3)
+    for s in slots:
+        ctx.frame_mark_unclean(s)
+    b = trk.track_batch(slots, [IDENT] * 3, [(0.0, 0.0)] * 3)
+    assert a["good"].all()
+    for k in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "good", "iterations"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    ctx.frame_upload(1, case["frames"][0]["img"])          # a rebuild stamps the slot clean again
+    c = trk.track_batch([1], [IDENT], [(0.0, 0.0)])
+    assert np.array_equal(c["pose7"][0], a["pose7"][0])
