@@ -2,8 +2,9 @@
 """bench.py — tracked frames/s of the photometric direct-alignment hot path on N MI355X.
 
 One "step" = one batch of B independent new frames aligned against the current reference keyframe:
-per frame the image pyramid + gradients are built on the device from the resident irradiance image
-(FrameHessian::makeImages) and the full 4-level CoarseTracker::trackNewestCoarse LM loop runs
+per frame the image pyramid is built on the device from the resident irradiance image (FrameHessian::makeImages:
+the image itself serves as level 0 — the library keeps intensity planes only and rebuilds the gradient channels at the
+taps — the coarser levels are reduced from it) and the full 4-level CoarseTracker::trackNewestCoarse LM loop runs
 device-resident (calcRes + calcGSSSE fused).  Inputs are resident in HBM before the timed region.
 
 Workload (BASELINE.json configs[1]): synthetic 512x512 4-level pyramid, ~2000 reference points
@@ -91,7 +92,7 @@ def main():
     trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
     pc_n = [trk.pc_n(l) for l in range(ctx.levels)]
     # resident raw irradiance images of the batch (device memory via torch: plumbing only)
-    raw = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    raw = torch.empty((B, h, w), dtype=torch.float32, device=dev)   # attached in place: level 0 of each pyramid IS this resident image
     host_frames = np.stack([f["img"] for f in case["frames"]])
     raw_distinct = torch.from_numpy(host_frames).to(dev)
     idx = torch.arange(B, device=dev) % args.distinct
@@ -110,7 +111,7 @@ def main():
 
     def step(fetch=True):
         if not args.no_pyramid:
-            ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes)
+            ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
         trk.stage(slots, poses0, affs0)
         trk.launch()
         return trk.fetch() if fetch else None
@@ -120,7 +121,7 @@ def main():
     # host unpacks.  Work per step is unchanged: one pyramid build, one launch, one result download + unpack.
     def step_pipelined(have_prev):
         if not args.no_pyramid:
-            ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes)
+            ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
         if have_prev:
             trk.fetch_begin()
         trk.stage(slots, poses0, affs0)
@@ -189,10 +190,10 @@ def main():
     if not args.no_pyramid:
         pms = []
         for _ in range(reps):
-            ev0.record(stream); ctx.frames_from_device_batch(slots, raw_ptr, frame_bytes); ev1.record(stream)
+            ev0.record(stream); ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes); ev1.record(stream)
             ev1.synchronize(); pms.append(ev0.elapsed_time(ev1))
         pm = float(np.mean(pms))
-        pyr_bytes = B * (4 * w * h + sum(4 * (w >> l) * (h >> l) for l in range(ctx.levels)))  # read raw + write every level plane
+        pyr_bytes = B * (4 * w * h + sum(4 * (w >> l) * (h >> l) for l in range(1, ctx.levels)))  # read the resident image + write the coarser levels (level 0 is the image itself)
         roofline["pyramid_kernel_ms"] = round(pm, 4)
         roofline["pyramid_GBps"] = round(pyr_bytes / (pm * 1e-3) / 1e9, 1)
 
@@ -247,7 +248,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
-                                   "per step (%d distinct renders), makeImages%s + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
+                                   "per step (%d distinct renders), makeImages%s (level 0 = the resident image, attached in place; levels 1.. built) + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
                                    "batch k-1 while batch k runs"
                                    % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else ""),
                        "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},

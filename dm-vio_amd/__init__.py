@@ -39,6 +39,7 @@ def _sig(L):
     L.dmvio_hip_frame_upload.argtypes = [vp, C.c_int, c_f]
     L.dmvio_hip_frame_from_device.argtypes = [vp, C.c_int, vp]
     L.dmvio_hip_frames_from_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
+    L.dmvio_hip_frames_attach_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
     L.dmvio_hip_frame_download.argtypes = [vp, C.c_int, C.c_int, c_f]
     L.dmvio_hip_tracker_create.restype = vp
     L.dmvio_hip_tracker_create.argtypes = [vp]
@@ -231,6 +232,10 @@ class Context:
     def frames_from_device_batch(self, slots, dev_ptr, stride_bytes):
         slots = np.ascontiguousarray(slots, dtype=np.int32)
         _chk(self.L, self.L.dmvio_hip_frames_from_device_batch(self.p, len(slots), _i(slots), C.c_void_p(dev_ptr), stride_bytes), "frames_from_device_batch")
+
+    def frames_attach_device_batch(self, slots, dev_ptr, stride_bytes):
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        _chk(self.L, self.L.dmvio_hip_frames_attach_device_batch(self.p, len(slots), _i(slots), C.c_void_p(dev_ptr), stride_bytes), "frames_attach_device_batch")
 
     def selftest_divide(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)

@@ -91,6 +91,10 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipMalloc((void**)&c->fs.build_gen, sizeof(unsigned int) * 2 * n_frame_slots));   // build_gen | bad_gen: equal (0) = not known to be clean
   HIPCHKP(hipMemsetAsync(c->fs.build_gen, 0, sizeof(unsigned int) * 2 * n_frame_slots, c->stream));
   c->fs.bad_gen = c->fs.build_gen + n_frame_slots;
+  HIPCHKP(hipMalloc((void**)&c->fs.lvl0, sizeof(const float*) * n_frame_slots));
+  c->h_lvl0.resize(n_frame_slots);
+  for (int s = 0; s < n_frame_slots; s++) c->h_lvl0[s] = c->fs.own_level(s, 0);
+  HIPCHKP(hipMemcpyAsync(c->fs.lvl0, c->h_lvl0.data(), sizeof(const float*) * n_frame_slots, hipMemcpyHostToDevice, c->stream));
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
@@ -106,6 +110,7 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipStreamSynchronize(c->stream);
   hipFree(c->fs.base);
   hipFree(c->fs.build_gen);
+  hipFree(c->fs.lvl0);
   hipFree(c->d_upload);
   hipFree(c->d_f3);
   hipFree(c->d_slots);
@@ -140,7 +145,8 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
 // ------------------------------------------------------------------ frames
 static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, 1), dim3(256), 0, c->stream, d_color, (size_t)0, c->pg, c->fs,
-                     (const int*)nullptr, slot, ++c->build_gen);
+                     (const int*)nullptr, slot, ++c->build_gen, 0);
+  c->h_lvl0[slot] = c->fs.own_level(slot, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -224,7 +230,7 @@ int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
   return buildPyramid(c, slot, dev);  // asynchronous on the ctx stream
 }
 
-int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes) {
+static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes, const bool attach) {
   if (!c || !slots || !dev_base) return failmsg("frames_from_device_batch: null argument");
   if (B <= 0 || stride_bytes % sizeof(float)) return failmsg("frames_from_device_batch: bad B / stride");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -248,9 +254,19 @@ int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots
     c->slots_valid = B;
   }
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
-                     c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen);
+                     c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
+  for (int i = 0; i < B; i++) c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes) {
+  return framesFromDeviceBatch(c, B, slots, dev_base, stride_bytes, false);
+}
+// Zero-copy variant: the intensity plane of level 0 IS the caller's image (this library stores no gradient channels), so only the coarser
+// levels are built; the slots reference dev_base until they are rebuilt, and the caller keeps those images valid and unchanged meanwhile.
+int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes) {
+  return framesFromDeviceBatch(c, B, slots, dev_base, stride_bytes, true);
 }
 
 // Diagnostics: withdraw the "every pixel finite" stamp of a slot, so that its consumers take the guarded code path (tests compare the two)
@@ -268,7 +284,7 @@ int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   const int n = c->wl[lvl] * c->hl[lvl];
-  hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
+  hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, c->d_f3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -448,7 +464,7 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
   const int n = t->dev.pc_n[lvl];
   constexpr int T = 256;
   const int G = std::max(1, std::min((n + T - 1) / T, t->max_eval_blocks));
-  hipLaunchKernelGGL(k_eval_partial<T>, dim3(G), dim3(T), 0, c->stream, t->dev, e, c->fs.level(new_slot, lvl), t->d_partials);
+  hipLaunchKernelGGL(k_eval_partial<T>, dim3(G), dim3(T), 0, c->stream, t->dev, e, c->levelPtr(new_slot, lvl), t->d_partials);
   hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(64), 0, c->stream, t->d_partials, G, t->h_tot);   // sums stored into pinned host memory
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -86,7 +86,7 @@ int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_
   HIPCHK(hipMemcpyAsync(m->P.v + first, vf.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));   // uf / vf are local
   m->P.n = first + n;
-  hipLaunchKernelGGL(k_immature_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->fs.level(host_slot, 0), c->w, first, n, m->P, host_tag, m->S);
+  hipLaunchKernelGGL(k_immature_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(host_slot, 0), c->w, first, n, m->P, host_tag, m->S);
   HIPCHK(hipGetLastError());
   m->n = first + n;
   m->max_tag = std::max(m->max_tag, host_tag);
@@ -151,7 +151,7 @@ int dmvio_hip_immature_trace(dmvio_hip_immature* m, int new_slot, int n_hosts, c
   TraceTables T;
   T.KRKi = m->d_tables; T.Kt = m->d_tables + 9 * IMM_MAX_HOSTS; T.aff = m->d_tables + 12 * IMM_MAX_HOSTS;
   m->P.n = m->n;
-  hipLaunchKernelGGL(k_immature_trace, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->fs.level(new_slot, 0), c->w, c->h, m->P, T, m->S);
+  hipLaunchKernelGGL(k_immature_trace, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->levelPtr(new_slot, 0), c->w, c->h, m->P, T, m->S);
   HIPCHK(hipGetLastError());
   return 0;
 }

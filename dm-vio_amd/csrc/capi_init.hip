@@ -109,7 +109,7 @@ int dmvio_hip_initializer_calc_res_and_gs(dmvio_hip_initializer* m, int lvl, int
   P.n = n; P.u = m->d_u; P.v = m->d_v; P.idepth_new = m->d_idepth_new; P.iR = m->d_iR; P.energy = m->d_energy; P.outlierTH = m->d_outlierTH; P.isGood = m->d_isGood;
   P.energy_new = m->d_energy_new; P.maxstep = m->d_maxstep; P.lastHessian_new = m->d_lastHessian_new; P.JbBuffer_new = m->d_Jb; P.isGood_new = m->d_isGood_new;
   const int G = std::max(1, std::min((int)INIT_MAX_BLOCKS, (n + 255) / 256));
-  hipLaunchKernelGGL(k_init_partial, dim3(G), dim3(256), 0, s, c->fs.level(first_slot, lvl), c->fs.level(new_slot, lvl), P, A, m->d_partials);
+  hipLaunchKernelGGL(k_init_partial, dim3(G), dim3(256), 0, s, c->levelPtr(first_slot, lvl), c->levelPtr(new_slot, lvl), P, A, m->d_partials);
   hipLaunchKernelGGL(k_init_final, dim3(1), dim3(128), 0, s, m->d_partials, G, m->d_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * IN_PART, hipMemcpyDeviceToHost, s));

@@ -27,8 +27,12 @@ struct FrameStore {
   // (k_build_pyramids).  bad_gen[slot] != build_gen[slot]  <=>  every pixel of every level is finite and so is every central difference:
   // consumers may then skip the reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455) — they cannot fire.
   unsigned int *build_gen, *bad_gen;
-  __host__ __device__ const float* level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
-  __host__ __device__ float* level_mut(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
+  // level 0 of a slot is reached through a pointer table: it is either the slot's own plane or — frames attached in place
+  // (dmvio_hip_frames_attach_device_batch) — the caller's resident image itself: the intensity plane IS the input image, so nothing is copied.
+  // The table lives in device memory (written by k_build_pyramids); host code uses dmvio_hip_ctx::levelPtr.
+  const float** lvl0;
+  __device__ const float* level(int slot, int lvl) const { return lvl == 0 ? lvl0[slot] : base + (size_t)slot * slot_stride + level_off[lvl]; }
+  __host__ __device__ float* own_level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };
 
 struct PyrGeom {

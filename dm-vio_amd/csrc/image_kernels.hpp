@@ -18,7 +18,7 @@ namespace dmv {
 typedef float pyr_f4 __attribute__((ext_vector_type(4)));
 #define PYR_TILE 64
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
-                                                         const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen) {
+                                                         const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen, const int attach) {
   __shared__ float s_a[PYR_TILE * PYR_TILE];
   __shared__ float s_b[(PYR_TILE / 2) * (PYR_TILE / 2)];
   const int f = blockIdx.y;
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   // (measured: 4.4 -> 5.5 TB/s)
   {
     const int lx = (threadIdx.x & 15) * 4, lyb = threadIdx.x >> 4;
-    float* __restrict__ dst = fs.level_mut(slot, 0);
+    float* __restrict__ dst = fs.own_level(slot, 0);
     float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int x = x0 + lx, y = y0 + lyb + 16 * p, ly = lyb + 16 * p;
-      if (y < h0) {
+      if (y < h0 && !attach) {   // attached in place: level 0 is the caller's image itself
         if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = {v[p].x, v[p].y, v[p].z, v[p].w}; __builtin_nontemporal_store(t, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
         else if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
         else {
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   }
   // stamps of this build (see FrameStore): the barrier the level reduction needs anyway carries the tile's verdict
   if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
-  if (blockIdx.x == 0 && threadIdx.x == 0) fs.build_gen[slot] = gen;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = attach ? src : fs.own_level(slot, 0); }
   float* cur = s_a;
   float* nxt = s_b;
   int side = PYR_TILE;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
       const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + side] + cur[b + side + 1]);
       nxt[ly * ns + lx] = val;
       const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
-      if (x < G.w[l] && y < G.h[l]) fs.level_mut(slot, l)[(size_t)y * G.w[l] + x] = val;
+      if (x < G.w[l] && y < G.h[l]) fs.own_level(slot, l)[(size_t)y * G.w[l] + x] = val;
     }
     __syncthreads();
     float* t = cur; cur = nxt; nxt = t;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <mutex>
+#include <vector>
 #include <string>
 #include "common.h"
 
@@ -28,6 +29,8 @@ struct dmvio_hip_ctx {
   int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
   int *d_slots = nullptr, *h_slots = nullptr;
   int slots_cap = 0, slots_valid = 0;
+  std::vector<const float*> h_lvl0;   // host mirror of FrameStore::lvl0 (kept by the build entry points)
+  const float* levelPtr(int slot, int lvl) const { return lvl == 0 ? h_lvl0[slot] : fs.own_level(slot, lvl); }
   unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)
   std::mutex mu;
 };

@@ -69,6 +69,11 @@ int dmvio_hip_write_result_txt(const char* path, int n, const double* timestamps
 /* makeImages for B frames in 4 launches: frame i is read from dev_base + i*stride_bytes and written to slots[i].
  * Asynchronous on the ctx stream (ordering with later tracker calls is by stream order). */
 int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);
+/* Zero-copy form of the call above for images that stay resident: this library keeps the intensity plane only (the gradient channels of
+ * dIp are rebuilt at the taps), so level 0 of FrameHessian::makeImages IS the input image — the slots reference the caller's images in
+ * place and only the coarser levels are built (1.33 B written per input byte less).  The images (row-major, w floats per row) must stay
+ * valid and unchanged until their slots are rebuilt or the context is destroyed. */
+int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);
 /* Diagnostics.  Every pyramid build stamps its slot "clean" when all pixels are finite (|I| <= 1e30): consumers then run without the
  * reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455), which cannot fire on such a frame.  This call withdraws
  * the stamp so that the guarded code path runs (tests compare the two). */

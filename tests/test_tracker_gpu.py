@@ -58,6 +58,32 @@ def test_pyramid_batch_from_device(setup, pkg):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_frames_attached_in_place(setup, pkg):
+    """Zero-copy attach: level 0 of the slot is the caller's resident image, the coarser levels are built — same pyramids, same tracking
+    results as the copying path, bit for bit; a later upload into the slot returns it to its own storage."""
+    import torch
+    ctx, trk, case = setup["ctx"], setup["trk"], setup["case"]
+    imgs = np.stack([f["img"] for f in case["frames"]])
+    raw = torch.from_numpy(imgs).cuda()
+    torch.cuda.synchronize()
+    ref = trk.track_batch([1, 2, 3], [IDENT] * 3, [(0.0, 0.0)] * 3)
+    ctx.frames_attach_device_batch([5, 6, 7], raw.data_ptr(), imgs.shape[1] * imgs.shape[2] * 4)
+    ctx.synchronize()
+    for k in range(3):
+        for lvl in range(ctx.levels):
+            a = ctx.frame_download(5 + k, lvl); b = ctx.frame_download(1 + k, lvl)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    got = trk.track_batch([5, 6, 7], [IDENT] * 3, [(0.0, 0.0)] * 3)
+    for key in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "good", "iterations"):
+        assert np.array_equal(got[key], ref[key], equal_nan=True), key
+    # the slot really references the caller's memory ...
+    raw[0].mul_(0.5); torch.cuda.synchronize()
+    assert np.array_equal(ctx.frame_download(5, 0)[:, :, 0], imgs[0] * np.float32(0.5))
+    # ... until it is rebuilt
+    ctx.frame_upload(5, imgs[1])
+    assert np.array_equal(ctx.frame_download(5, 0).view(np.uint32), ctx.frame_download(2, 0).view(np.uint32))
+
+
 def test_set_ref_bit_exact(setup):
     """makeCoarseDepthL0: same number of template points per level, same order, same bits."""
     trk, T = setup["trk"], setup["T"]
