@@ -733,12 +733,16 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     tStep += t1 - t0;
     if (!s_go) break;
     const int lvl = s_e.lvl;
+    // the plane's address is wave-uniform (level 0 comes out of the pointer table): keep it in scalar registers
+    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
+    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
     if (clean)
-      blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage,
-                          s_partH, s_partS, s_tot);
+      blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                          s_tot);
     else
-      blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, fs.level(slot, lvl), trk.huberTH, s_stage,
-                         s_partH, s_partS, s_tot);
+      blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                         s_tot);
     if (cl.C > 1) { clusterExchange(s_tot, cl, prob, rank, phase); phase++; }
     tEval += wall_clock64() - t1;
   }
