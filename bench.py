@@ -421,6 +421,24 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
                     "linearisation (latency-bound strong scaling of a ~0.2 ms iteration); `independent_windows_value` = every GPU optimising its own window (weak scaling)")
     if replicas is not None:
         out["independent_windows_value"] = round(replicas, 1)
+    if world == 1:
+        # the reference's multi-threaded accumulation order (each worker sums its share of the points in fp32, the shares are added in double):
+        # four partial accumulators per bucket instead of the single-threaded order `value` replays bit for bit
+        keep = os.environ.get("DMVIO_HIP_BA_SPLIT")
+        os.environ["DMVIO_HIP_BA_SPLIT"] = "4"
+        ba4 = pkg.BundleAdjusterHip(ctx)
+        if keep is None: os.environ.pop("DMVIO_HIP_BA_SPLIT")
+        else: os.environ["DMVIO_HIP_BA_SPLIT"] = keep
+        ba4.set_case(case, list(range(F)))
+        ba4.activate_all(); e4 = ba4.linearize_all(False); ba4.apply_res()
+        lam4, lastE4 = 1e-5, [e4, 0.0, 0.0]
+        for it in range(12):
+            _, lam4, lastE4 = ba4.gn_iteration(it % 6, lam4, lastE4)
+        t0 = time.perf_counter()
+        for it in range(n_it):
+            _, lam4, lastE4 = ba4.gn_iteration(it % 6, lam4, lastE4)
+        out["value_4_partial_accumulators"] = round(n_it / (time.perf_counter() - t0), 1)
+        ba4.close()
     if cpu:
         O = graft.load_oracle()
         res = {}
