@@ -109,6 +109,8 @@ def main():
     raw_ptr = raw.data_ptr()
     frame_bytes = w * h * 4
 
+    ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)   # --no-pyramid runs track against these
+
     def step(fetch=True):
         if not args.no_pyramid:
             ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
