@@ -62,6 +62,9 @@ struct dmvio_hip_ba {
   double final_energy = 0;
   BATimes tm;
   bool timing = false;
+  // true only between a REJECTED step of gnIteration and the next gnIteration: the state was restored to the one the per-point sums (and the
+  // point backup) were computed at, so k_ba_point_sums would reproduce what is already there.  Every other entry point clears it.
+  bool sums_fresh = false;
   // point marginalisation scratch (dmvio_hip_ba_marginalize_points)
   unsigned char *d_cand = nullptr, *d_decision = nullptr, *d_margActive = nullptr;
   float *d_mHdiF = nullptr, *d_mbdSumF = nullptr, *d_mHcd = nullptr, *d_margRec = nullptr, *d_adHTdelta = nullptr;
@@ -139,8 +142,8 @@ static int applyRes(dmvio_hip_ba* b) {
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
 static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P, bool wait = true);
 static int accumulateWait(dmvio_hip_ba* b);
-static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true) {
-  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0);
+static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false) {
+  if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0);
   return accumulateViews(b, b->Rs, b->P, wait);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
@@ -265,6 +268,7 @@ int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
 int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]) {
   if (!b || !slots || !pose7_w2c || !fxfycxcy) return failmsg("ba_set_window: null argument");
+  b->sums_fresh = false;
   if (F < 1 || F > BA_MAXF) return failmsg("ba_set_window: 1 <= F <= 8");
   BAHost& H = b->H;
   H.F = F;
@@ -294,6 +298,7 @@ int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const doub
 
 int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double* bM) {
   if (!b || !HM || !bM) return failmsg("ba_set_marg_prior: null argument");
+  b->sums_fresh = false;
   const int n = b->H.n();
   b->H.HM.assign(HM, HM + (size_t)n * n); b->H.bM.assign(bM, bM + n);
   return 0;
@@ -302,6 +307,7 @@ int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double*
 // FullSystem::flagPointsForRemoval's relinearisation (FullSystem.cpp:829-859) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742)
 int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM, int update_prior) {
   if (!b || !b->graph_ready) return failmsg("ba_marginalize_points: window / graph not set");
+  b->sums_fresh = false;
   if (!candidates || !decision) return failmsg("ba_marginalize_points: null argument");
   dmvio_hip_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
@@ -346,6 +352,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
   if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
+  b->sums_fresh = false;
   BAHost& H = b->H;
   if (H.F < 1) return failmsg("ba_set_graph: set_window first");
   if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
@@ -453,7 +460,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   return 0;
 }
 
-#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
+#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
 
 // activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
@@ -582,6 +589,7 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
 // FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
   if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");
+  b->sums_fresh = false;
   std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetState(b->H.fr[f], state10);
   b->H.setPrecalcValues();
@@ -603,7 +611,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   H.backupFrames();   // the point part of backupState rides in the first accumulation kernel
   BA_LAP(0);
   // solveSystem
-  if (int r = accumulate(b, true, false)) return r;
+  const bool sums_fresh = b->sums_fresh;
+  b->sums_fresh = false;
+  if (int r = accumulate(b, true, false, sums_fresh)) return r;
   H.prepareSolve();   // nullspaces, orthogonalisation basis, prior right-hand side: host work in the shadow of the kernels
   if (int r = accumulateWait(b)) return r;
   BA_LAP(1);
@@ -637,6 +647,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     if (int r = linearizeAll(b, false, &lastE[0], 2)) return r;   // backed-up state: its table is still resident
     lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
     lambda *= 1e2;
+    b->sums_fresh = true;   // nothing the per-point sums depend on has changed: records, activity, idepth == idepth_zero == idepth_backup
   }
   BA_LAP(7);
   b->tm.n++;
@@ -645,8 +656,10 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
 }
 
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io, double lastE[3], int* accepted) {
+  const bool sums_fresh = b && b->sums_fresh;
   BA_READY(b);
   std::lock_guard<std::mutex> lk(b->mu);
+  b->sums_fresh = sums_fresh;
   bool acc = false;
   double lam = *lambda_io;
   if (int r = gnIteration(b, iteration, lam, lastE, acc)) return r;
@@ -711,6 +724,7 @@ int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float
 }
 int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
   if (!b) return failmsg("null ba");
+  b->sums_fresh = false;
   b->H.fr[b->H.F - 1].frameEnergyTH = th;
   return 0;
 }

@@ -155,6 +155,31 @@ def test_sharded_driver_world1_equals_gn_iteration(pkg, oracle, synth, gpu_requi
         assert np.allclose(ba.frame_pose(k)[0], ba2.frame_pose(k)[0], atol=1e-12)
 
 
+def test_gn_iterations_through_rejected_steps_match_oracle(pkg, oracle, synth, gpu_required):
+    """Thirty GN iterations on one window: once converged, steps are rejected (restore + re-linearise; the library then skips the per-point
+    sums of the next iteration because nothing they depend on has changed).  Accept sequence, damping and energies follow the oracle throughout,
+    and calls in between (a query, a re-linearisation) do not disturb the sequence."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=1000, seed=13)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba.activate_all(); e = ba.linearize_all(False); ba.apply_res()
+    W.activate_all(); eo = W.linearize_all(False); W.apply_res()
+    assert abs(e - eo) <= 1e-6 * abs(eo)
+    lam, lE = 1e-5, [e, 0.0, 0.0]
+    lamo, lEo = 1e-5, [eo, W.lenergy(), W.menergy()]
+    rejected = 0
+    for it in range(30):
+        acc, lam, lE = ba.gn_iteration(it % 6, lam, lE)
+        acco, lamo, lEo = W.gn_iteration(it % 6, lamo, lEo)
+        assert bool(acc) == bool(acco), it
+        assert lam == lamo and abs(lE[0] - lEo[0]) <= 1e-4 * abs(lEo[0]), it
+        rejected += 0 if acc else 1
+        if it % 7 == 3:
+            ba.res_state()              # any other entry point in between: the skip must not survive it
+    assert rejected >= 10
+    for k in range(8):
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+
+
 def test_shard_systems_sum_to_full_system(pkg, oracle, synth, gpu_required):
     """Rank emulation on one GPU: the packed systems of two keyframe shards add up to the full window's system."""
     import dmvio_amd.sharding as sh
