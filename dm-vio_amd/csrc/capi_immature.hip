@@ -16,6 +16,7 @@ struct dmvio_hip_immature {
   ImmatureSettings S;
   float* d_tables = nullptr;   // [KRKi 9H | Kt 3H | aff 2H], H <= 64
   float* h_tables = nullptr;   // pinned
+  int* h_counts = nullptr;     // pinned: status histogram of the last traceNewCoarse, written by k_status_hist
   int* d_uv_stage = nullptr;   // 2 x capacity ints
   float* d_opt_tables = nullptr;   // [R 9 F*F | t 3 F*F | aff 2 F*F], F <= 8
   float* h_opt_tables = nullptr;
@@ -49,7 +50,8 @@ dmvio_hip_immature* dmvio_hip_immature_create(dmvio_hip_ctx* ctx, int capacity) 
       ialloc(m, &P.energyTH, c) || ialloc(m, &P.idepth_min, c) || ialloc(m, &P.idepth_max, c) || ialloc(m, &P.quality, c) || ialloc(m, &P.lastTraceUV, 2 * c) ||
       ialloc(m, &P.lastTracePixelInterval, c) || ialloc(m, &P.lastTraceStatus, c) || ialloc(m, &m->d_tables, 14 * IMM_MAX_HOSTS) || ialloc(m, &m->d_uv_stage, 2 * c) || ialloc(m, &m->d_opt_tables, 14 * 64) || ialloc(m, &m->d_result, c) || ialloc(m, &m->d_res_state, 8 * c) ||
       ialloc(m, &m->d_idepth, c) || ialloc(m, &m->d_select, c) || hipHostMalloc((void**)&m->h_opt_tables, sizeof(float) * 14 * 64, hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&m->h_tables, sizeof(float) * 14 * IMM_MAX_HOSTS, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&m->h_tables, sizeof(float) * 14 * IMM_MAX_HOSTS, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&m->h_counts, sizeof(int) * 8, hipHostMallocDefault) != hipSuccess) {
     for (void* p : m->allocs) hipFree(p);
     delete m;
     return nullptr;
@@ -62,6 +64,7 @@ void dmvio_hip_immature_destroy(dmvio_hip_immature* m) {
   hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_tables) hipHostFree(m->h_tables);
+  if (m->h_counts) hipHostFree(m->h_counts);
   if (m->h_opt_tables) hipHostFree(m->h_opt_tables);
   delete m;
 }
@@ -142,16 +145,25 @@ int dmvio_hip_immature_trace(dmvio_hip_immature* m, int new_slot, int n_hosts, c
   if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("immature_trace: frame slot out of range");
   if (m->n == 0) return 0;
   if (m->max_tag >= n_hosts) return failmsg("immature_trace: a point's host_tag has no table row (host_tag >= n_hosts)");
-  HIPCHK(hipStreamSynchronize(c->stream));   // the pinned tables of a previous call may still be in flight
-  float* t = m->h_tables;
-  memcpy(t, KRKi9, sizeof(float) * 9 * n_hosts);
-  memcpy(t + 9 * IMM_MAX_HOSTS, Kt3, sizeof(float) * 3 * n_hosts);
-  memcpy(t + 12 * IMM_MAX_HOSTS, aff2, sizeof(float) * 2 * n_hosts);
-  HIPCHK(hipMemcpyAsync(m->d_tables, t, sizeof(float) * 14 * IMM_MAX_HOSTS, hipMemcpyHostToDevice, c->stream));
-  TraceTables T;
-  T.KRKi = m->d_tables; T.Kt = m->d_tables + 9 * IMM_MAX_HOSTS; T.aff = m->d_tables + 12 * IMM_MAX_HOSTS;
   m->P.n = m->n;
-  hipLaunchKernelGGL(k_immature_trace, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->levelPtr(new_slot, 0), c->w, c->h, m->P, T, m->S);
+  if (n_hosts <= IMM_ARG_HOSTS) {
+    TraceTablesArg T;
+    memset(&T, 0, sizeof(T));
+    memcpy(T.KRKi, KRKi9, sizeof(float) * 9 * n_hosts);
+    memcpy(T.Kt, Kt3, sizeof(float) * 3 * n_hosts);
+    memcpy(T.aff, aff2, sizeof(float) * 2 * n_hosts);
+    hipLaunchKernelGGL(k_immature_trace<TraceTablesArg>, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->levelPtr(new_slot, 0), c->w, c->h, m->P, T, m->S);
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream));   // the pinned tables of a previous call may still be in flight
+    float* t = m->h_tables;
+    memcpy(t, KRKi9, sizeof(float) * 9 * n_hosts);
+    memcpy(t + 9 * IMM_MAX_HOSTS, Kt3, sizeof(float) * 3 * n_hosts);
+    memcpy(t + 12 * IMM_MAX_HOSTS, aff2, sizeof(float) * 2 * n_hosts);
+    HIPCHK(hipMemcpyAsync(m->d_tables, t, sizeof(float) * 14 * IMM_MAX_HOSTS, hipMemcpyHostToDevice, c->stream));
+    TraceTables T;
+    T.KRKi = m->d_tables; T.Kt = m->d_tables + 9 * IMM_MAX_HOSTS; T.aff = m->d_tables + 12 * IMM_MAX_HOSTS;
+    hipLaunchKernelGGL(k_immature_trace<TraceTables>, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->levelPtr(new_slot, 0), c->w, c->h, m->P, T, m->S);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -188,10 +200,15 @@ int dmvio_hip_trace_new_coarse(dmvio_hip_immature* m, int new_slot, const double
   }
   if (int r = dmvio_hip_immature_trace(m, new_slot, n_hosts, KRKi.data(), Kt.data(), aff.data())) return r;
   if (counts6) {
-    std::vector<int> st(m->n);
-    if (int r = dmvio_hip_immature_get_state(m, nullptr, nullptr, nullptr, nullptr, nullptr, st.data())) return r;
     for (int k = 0; k < 6; k++) counts6[k] = 0;
-    for (int v : st) if (v >= 0 && v < 6) counts6[v]++;
+    if (m->n > 0) {
+      dmvio_hip_ctx* c = m->ctx;
+      std::lock_guard<std::mutex> lk(c->mu);
+      hipLaunchKernelGGL(k_status_hist, dim3(1), dim3(1024), 0, c->stream, (const int*)m->P.lastTraceStatus, m->n, m->h_counts);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+      for (int k = 0; k < 6; k++) counts6[k] = m->h_counts[k];
+    }
   }
   return 0;
 }

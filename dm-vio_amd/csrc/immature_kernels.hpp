@@ -34,7 +34,32 @@ struct ImmatureSettings {
   float stepsize = 1.0f, GNThreshold = 0.1f, extraSlackOnTH = 1.2f, slackInterval = 1.5f, minImprovementFactor = 2;
 };
 
+// status histogram of FullSystem::traceNewCoarse's printout / bookkeeping (FullSystem.cpp:562-583): one workgroup, counts stored straight into
+// pinned host memory (out6)
+__global__ void __launch_bounds__(1024) k_status_hist(const int* __restrict__ status, const int n, int* __restrict__ out6) {
+  __shared__ int s_c[6];
+  if (threadIdx.x < 6) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  int c[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int v = status[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c[k] += (v == k) ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int t = c[k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_c[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) out6[threadIdx.x] = s_c[threadIdx.x];
+}
+
 struct TraceTables { const float *KRKi /* H x 9 */, *Kt /* H x 3 */, *aff /* H x 2 */; };
+// the same tables by value, for windows of up to 16 host keyframes: they travel as kernel arguments (896 B) — no upload, no staging buffer
+enum { IMM_ARG_HOSTS = 16 };
+struct TraceTablesArg { float KRKi[IMM_ARG_HOSTS * 9], Kt[IMM_ARG_HOSTS * 3], aff[IMM_ARG_HOSTS * 2]; };
 
 __constant__ int c_pattern8[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};   // settings.cpp:296, pattern 8
 
@@ -111,8 +136,9 @@ __device__ __forceinline__ float waveMin(float v) {
   return v;
 }
 
-// traceOn: one wavefront per point (4 points per 256-thread workgroup)
-__global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict__ I, const int w, const int h, const ImmaturePts P, const TraceTables T,
+// traceOn: one wavefront per point (4 points per 256-thread workgroup); TT = TraceTables (device memory) or TraceTablesArg (kernel arguments)
+template <class TT>
+__global__ void __launch_bounds__(256) k_immature_trace(const float* __restrict__ I, const int w, const int h, const ImmaturePts P, const TT T,
                                                          const ImmatureSettings S) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);

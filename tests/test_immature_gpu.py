@@ -130,3 +130,27 @@ def test_optimize_immature_point_bit_exact(pkg, oracle, synth, gpu_required):
     sel = np.zeros(imm.n, np.uint8); sel[::2] = 1
     rg2, ig2, _ = imm.optimize(list(range(F)), np.stack(c["w2c"]), c["K4"], aff=c["aff"], exposure=c["exposure"], select=sel, min_obs=1)
     assert np.array_equal(rg2[::2], ro[::2]) and np.all(rg2[1::2] == 0)
+
+
+def test_trace_tables_as_arguments_and_in_device_memory_agree(pkg, oracle, synth, gpu_required):
+    """Up to 16 host keyframes the per-host tables travel as kernel arguments, beyond that through device memory: same bits either way."""
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=300, n_frames=1)
+    ctx = pkg.Context(w, h, n_slots=2)
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, case["frames"][0]["img"])
+    rng = np.random.RandomState(3)
+    u = rng.randint(8, w - 9, 400).astype(np.int32); v = rng.randint(8, h - 9, 400).astype(np.int32)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    KRKi, Kt, aff = oracle.trace_precalc(case["frames"][0]["pose7"], ident, case["K4"])
+    states = []
+    for n_hosts in (2, 20):
+        imm = pkg.ImmaturePointsHip(ctx, capacity=1024)
+        imm.add_points(0, 0, u[:200], v[:200]); imm.add_points(1, 0, u[200:], v[200:])
+        rows = rng.normal(size=(n_hosts, 14)).astype(np.float32)            # rows of unused tags: arbitrary
+        rows[0, :9] = rows[1, :9] = np.asarray(KRKi, np.float32).ravel(); rows[0, 9:12] = rows[1, 9:12] = np.asarray(Kt, np.float32)
+        rows[0, 12:] = rows[1, 12:] = np.asarray(aff, np.float32)
+        imm.trace(1, rows[:, :9], rows[:, 9:12], rows[:, 12:])
+        states.append(imm.get_state())
+    for k in states[0]:
+        assert np.array_equal(states[0][k], states[1][k], equal_nan=True), k
+    assert (states[0]["lastTraceStatus"] == 0).sum() > 100
