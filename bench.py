@@ -243,6 +243,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_ba:
         overlap_out = bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h)
 
+    # ---------------- live leg (rank 0, N = 1): ONE camera stream, frame after frame — the latency-bound regime of the reference's tracking thread
+    live_out = None
+    if rank == 0 and world == 1 and not args.no_ba:
+        live_out = bench_live(args, pkg, synth, ctx, trk, raw, case, w, h)
+
     if rank == 0:
         out = {
             "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
@@ -259,6 +264,7 @@ def main():
             "ba": ba_out,
             "trace": trace_out,
             "overlap": overlap_out,
+            "live": live_out,
             "lm_iterations_mean": float(np.mean(res["iterations"])),
             "max_pose_err_m": float(terr.max()),
         }
@@ -305,6 +311,47 @@ def bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h):
                 sequential_ms=round(1e3 * (t_t + t_m), 2), overlapped_ms=round(1e3 * t_p, 2),
                 overlapped_tracking_done_ms=round(1e3 * (done["t"] - t0), 2), overlapped_ba_done_ms=round(1e3 * (done["m"] - t0), 2),
                 note="tracking on the context stream, bundle adjustment on the BA handle's stream, two host threads (no pyramid builds in this leg)")
+
+
+def bench_live(args, pkg, synth, ctx, trk, raw, case, w, h):
+    """One camera stream: per frame makeImages (attached in place) -> trackNewestCoarse (one alignment problem, cluster mode) ->
+    traceNewCoarse over the window's immature points (7 hosts x 1500), each step waiting for the previous one's result as the
+    reference's tracking thread does (FullSystem::addActiveFrame).  Host wall time per frame."""
+    n_per_host, hosts = 1500, 7
+    rng = np.random.RandomState(6)
+    u, v = synth.select_points(case["ref_img"], n_per_host, rng, min_grad=8.0)
+    u = np.clip(u.astype(np.int32), 8, w - 9); v = np.clip(v.astype(np.int32), 8, h - 9)
+    imm = pkg.ImmaturePointsHip(ctx, capacity=n_per_host * hosts)
+    for tag in range(hosts):
+        imm.add_points(tag, 0, u, v)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0]); idents = np.tile(ident, (hosts, 1))
+    n = imm.n
+    st0 = (np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 10000.0, np.float32), np.full(n, 5, np.int32))
+    frame_bytes = w * h * 4
+    base = raw.data_ptr()
+    pose = ident.copy()
+    parts = np.zeros(3)
+    frames = 200
+    imm.set_state(*st0)
+    t_all = 0.0
+    for k in range(frames + 10):
+        if k == 10:
+            parts[:] = 0; t_all = 0.0
+        slot = 1 + (k % args.distinct)
+        t0 = time.perf_counter()
+        ctx.frames_attach_device_batch([slot], base + (slot - 1) * frame_bytes, frame_bytes)
+        t1 = time.perf_counter()
+        r = trk.track_batch([slot], [pose], [(0.0, 0.0)])
+        t2 = time.perf_counter()
+        imm.traceNewCoarse(slot, r["pose7"][0], idents, case["K4"])
+        t3 = time.perf_counter()
+        parts += (t1 - t0, t2 - t1, t3 - t2); t_all += t3 - t0
+        if k % 20 == 19:
+            imm.set_state(*st0)          # keep the traces doing first-trace work (outside the timed spans would be cleaner; it is 1 call in 20)
+    return dict(metric="frames/s of one live stream (makeImages + trackNewestCoarse + traceNewCoarse per frame, each waiting for the previous result)",
+                value=round(frames / t_all, 1), unit="frames/s", ms_per_frame=round(1e3 * t_all / frames, 4),
+                ms_make_images=round(1e3 * parts[0] / frames, 4), ms_track=round(1e3 * parts[1] / frames, 4), ms_trace=round(1e3 * parts[2] / frames, 4),
+                immature_points=n)
 
 
 def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
