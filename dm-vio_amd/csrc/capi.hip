@@ -529,13 +529,16 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   HIPCHK(hipSetDevice(c->device));
   const int B = t->staged_B;
   // Up to 128 problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs
-  // 367 us for one 1024-thread workgroup); more -> one 256-thread workgroup per problem, four resident per CU (throughput).
+  // 367 us for one 1024-thread workgroup); more -> one workgroup per problem (512 threads up to 512 problems, then 256 threads,
+  // four resident per CU: throughput).
   // Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES / DMVIO_HIP_LM_CLUSTER.
   int C = 1;
   if (t->lm_cluster_override > 0) C = t->lm_cluster_override;
   else if (!t->lm_threads_override) C = clusterSize(B, t->dev.pc_n[0]);
   if ((long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
-  const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : 256));
+  // threads per workgroup: 256 in cluster mode and for full batches (four workgroups per CU); batches that cannot fill the CUs that way
+  // (129..512 problems) take 512 threads per problem (measured: B=256 0.47 -> 0.40 ms, B=512 0.62 -> 0.58 ms)
+  const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : (B <= 512 ? 512 : 256)));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
   ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out;
   t->last_cluster = C; t->last_threads = T;

@@ -57,7 +57,7 @@ def test_tracking_and_ba_800x400_4000_points(pkg, oracle, synth, gpu_required):
     assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
 
 
-@pytest.mark.parametrize("n_ref,min_grad,batch,cluster", [(32000, 4.0, 1, 16), (504 * 504, -1.0, 2, 32), (8000, 8.0, 31, 4), (2000, 8.0, 100, 2)])
+@pytest.mark.parametrize("n_ref,min_grad,batch,cluster", [(32000, 4.0, 1, 16), (504 * 504, -1.0, 2, 32), (8000, 8.0, 31, 4), (2000, 8.0, 100, 2), (2000, 8.0, 200, 1)])
 def test_tracking_dense_templates_and_cluster_sizes(pkg, oracle, synth, gpu_required, n_ref, min_grad, batch, cluster):
     """Semi-dense to all-pixel templates (the bandwidth-asymptote end of SURVEY §8d) and every cluster size of the launch table:
     the same alignment as the oracle, whichever number of workgroups shares a problem."""
@@ -76,6 +76,8 @@ def test_tracking_dense_templates_and_cluster_sizes(pkg, oracle, synth, gpu_requ
     slots = [1 + (i % 2) for i in range(batch)]
     trk.stage(slots, [IDENT] * batch, [(0.0, 0.0)] * batch); trk.launch(); r = trk.fetch()
     assert trk.last_launch()[0] == cluster
+    if batch == 200:
+        assert trk.last_launch() == (1, 512)          # 129..512 problems: one 512-thread workgroup each
     ref = []
     for f in tc["frames"]:
         T.set_new(oracle.make_images(f["img"], w, h)[0]); ref.append(T.track(IDENT, [0.0, 0.0]))
