@@ -98,7 +98,7 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
-  c->pg.tiles_x = (w + 63) / 64; c->pg.tiles_y = (h + 63) / 64;
+  c->pg.tiles_x = (w + PYR_TW - 1) / PYR_TW; c->pg.tiles_y = (h + PYR_TH - 1) / PYR_TH;
   HIPCHKP(hipMalloc((void**)&c->d_f3, sizeof(float) * 3 * w * h));
   HIPCHKP(hipStreamSynchronize(c->stream));
   return c;

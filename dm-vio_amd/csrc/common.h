@@ -38,7 +38,7 @@ struct FrameStore {
 struct PyrGeom {
   int levels;
   int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
-  int tiles_x, tiles_y;  // 64x64 level-0 tiles
+  int tiles_x, tiles_y;  // level-0 tiles of k_build_pyramids (PYR_TW x PYR_TH)
 };
 
 // Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one

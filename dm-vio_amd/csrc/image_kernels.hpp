@@ -6,8 +6,8 @@
 // where they are consumed (gradAt below = the reference's formula incl. its isfinite guard); absSquaredGrad (pixel
 // selector only) is not produced.
 //
-// One launch builds ALL levels of B frames: a workgroup owns a 64x64 level-0 tile (level-1 rows of a tile are full 128-byte
-// lines), keeps the successive 2x2 reductions in LDS (64x64 -> 32x32 -> ... ) and streams each level out.  HBM traffic per frame:
+// One launch builds ALL levels of B frames: a workgroup owns a 128x32 level-0 tile (row segments of 512 / 256 / 128 / 64 bytes at
+// levels 0..3), keeps the successive 2x2 reductions in LDS (128x32 -> 64x16 -> ... ) and streams each level out.  HBM traffic per frame:
 // read 4 B/px + write 4 B/px * (1 + 1/4 + 1/16 + ...).
 #pragma once
 #include "common.h"
@@ -16,28 +16,30 @@
 namespace dmv {
 
 typedef float pyr_f4 __attribute__((ext_vector_type(4)));
-#define PYR_TILE 64
+// level-0 tile of a workgroup: 128 x 32 pixels — 512-byte row segments at level 0, 256 / 128 / 64 bytes at the next three levels
+#define PYR_TW 128
+#define PYR_TH 32
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen, const int attach) {
-  __shared__ float s_a[PYR_TILE * PYR_TILE];
-  __shared__ float s_b[(PYR_TILE / 2) * (PYR_TILE / 2)];
+  __shared__ float s_a[PYR_TW * PYR_TH];
+  __shared__ float s_b[(PYR_TW / 2) * (PYR_TH / 2)];
   const int f = blockIdx.y;
   const int slot = slots ? slots[f] : single_slot;
   const float* __restrict__ src = in_base + (size_t)f * in_stride;
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
-  const int x0 = tx * PYR_TILE, y0 = ty * PYR_TILE;
+  const int x0 = tx * PYR_TW, y0 = ty * PYR_TH;
   bool bad = false;
   // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store.
   // The raw image is read once and the level-0 plane is far larger than the caches it would pollute: non-temporal loads / stores
   // (measured: 4.4 -> 5.5 TB/s)
   {
-    const int lx = (threadIdx.x & 15) * 4, lyb = threadIdx.x >> 4;
+    const int lx = (threadIdx.x & 31) * 4, lyb = threadIdx.x >> 5;   // 32 threads x 4 pixels per row, 8 rows per pass
     float* __restrict__ dst = fs.own_level(slot, 0);
     float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int x = x0 + lx, y = y0 + lyb + 16 * p;
+      const int x = x0 + lx, y = y0 + lyb + 8 * p;
       v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y < h0) {
         if (x + 3 < w0 && ((uintptr_t)(src + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = __builtin_nontemporal_load(reinterpret_cast<const pyr_f4*>(src + (size_t)y * w0 + x)); v[p] = make_float4(t[0], t[1], t[2], t[3]); }
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
     }
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int x = x0 + lx, y = y0 + lyb + 16 * p, ly = lyb + 16 * p;
+      const int x = x0 + lx, y = y0 + lyb + 8 * p, ly = lyb + 8 * p;
       if (y < h0 && !attach) {   // attached in place: level 0 is the caller's image itself
         if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = {v[p].x, v[p].y, v[p].z, v[p].w}; __builtin_nontemporal_store(t, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
         else if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
@@ -60,7 +62,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
           for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
         }
       }
-      *reinterpret_cast<float4*>(&s_a[ly * PYR_TILE + lx]) = v[p];
+      *reinterpret_cast<float4*>(&s_a[ly * PYR_TW + lx]) = v[p];
       // NaN fails the comparison too; out-of-image lanes hold zeros
       bad |= !(fabsf(v[p].x) <= 1e30f) || !(fabsf(v[p].y) <= 1e30f) || !(fabsf(v[p].z) <= 1e30f) || !(fabsf(v[p].w) <= 1e30f);
     }
@@ -70,20 +72,20 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = attach ? src : fs.own_level(slot, 0); }
   float* cur = s_a;
   float* nxt = s_b;
-  int side = PYR_TILE;
+  int sw = PYR_TW, sh = PYR_TH;
   for (int l = 1; l < G.levels; l++) {
-    const int ns = side >> 1;
-    for (int o = threadIdx.x; o < ns * ns; o += 256) {
-      const int lx = o % ns, ly = o / ns;
-      const int b = 2 * lx + 2 * ly * side;
-      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + side] + cur[b + side + 1]);
-      nxt[ly * ns + lx] = val;
+    const int nw = sw >> 1, nh = sh >> 1;
+    for (int o = threadIdx.x; o < nw * nh; o += 256) {
+      const int lx = o % nw, ly = o / nw;
+      const int b = 2 * lx + 2 * ly * sw;
+      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + sw] + cur[b + sw + 1]);
+      nxt[ly * nw + lx] = val;
       const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
       if (x < G.w[l] && y < G.h[l]) fs.own_level(slot, l)[(size_t)y * G.w[l] + x] = val;
     }
     __syncthreads();
     float* t = cur; cur = nxt; nxt = t;
-    side = ns;
+    sw = nw; sh = nh;
   }
 }
 
