@@ -157,3 +157,14 @@ def test_guarded_and_guard_free_paths_agree_bit_for_bit(pkg, synth, gpu_required
     ctx.frame_upload(1, case["frames"][0]["img"])          # a rebuild stamps the slot clean again
     c = trk.track_batch([1], [IDENT], [(0.0, 0.0)])
     assert np.array_equal(c["pose7"][0], a["pose7"][0])
+
+
+def test_plain_c_demo_recovers_the_known_pose(pkg, gpu_required, tmp_path):
+    """examples/c_abi_demo.c run on the device: plain C, no Python in the loop, a camera translation in front of a textured wall recovered
+    through dmvio_hip_frame_upload / tracker_make_k / tracker_set_ref / tracker_track."""
+    import subprocess
+    from test_capi_cpu import _build_c_demo
+    exe = _build_c_demo(pkg, tmp_path / "c_abi_demo")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: translation error" in r.stdout
