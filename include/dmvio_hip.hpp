@@ -1,0 +1,122 @@
+/* C++11 mirror of the member surface FullSystem uses on the photometric alignment path, over the C ABI of dmvio_hip.h.
+ *
+ * The reference has no plugin / FFI interface on this path — its boundary is the C++ member surface of CoarseTracker and FrameHessian
+ * (SURVEY.md section 8b).  These classes keep the reference's names, argument meaning and error behaviour (bool results, NaN residuals, no
+ * exceptions) with plain-old-data in place of Eigen / Sophus types, so that an adapter inside the reference is a field-by-field copy:
+ *
+ *   dmvio_hip::FrameStore::makeImages(slot, color)          <- FrameHessian::makeImages(float* color, CalibHessian*)   HessianBlocks.cpp:128-191
+ *   dmvio_hip::CoarseTracker::makeK(fx, fy, cx, cy)          <- CoarseTracker::makeK(CalibHessian*)                      CoarseTracker.cpp:105-134
+ *   dmvio_hip::CoarseTracker::setCoarseTrackingRef(...)      <- CoarseTracker::setCoarseTrackingRef(frameHessians)       CoarseTracker.cpp:524-538
+ *   dmvio_hip::CoarseTracker::trackNewestCoarse(...)         <- CoarseTracker::trackNewestCoarse(newFH, lastToNew_out, aff_g2l_out, coarsestLvl,
+ *                                                               minResForAbort)                                          CoarseTracker.cpp:539-770
+ *   members lastResiduals, lastFlowIndicators, refFrameID    <- CoarseTracker.h:83-91
+ *
+ * Header-only; link with -ldmvio_hip.  Not thread-safe per object, like the reference's tracker (one tracker per thread). */
+#ifndef DMVIO_HIP_HPP
+#define DMVIO_HIP_HPP
+#include <cmath>
+#include <string>
+#include <vector>
+#include "dmvio_hip.h"
+
+namespace dmvio_hip {
+
+/* Sophus::SE3d as [translation | unit quaternion x y z w] (the pose7 of the C ABI) */
+struct SE3 {
+  double t[3];
+  double q[4];
+  SE3() { t[0] = t[1] = t[2] = 0; q[0] = q[1] = q[2] = 0; q[3] = 1; }
+  void toPose7(double p[7]) const { for (int i = 0; i < 3; i++) p[i] = t[i]; for (int i = 0; i < 4; i++) p[3 + i] = q[i]; }
+  void fromPose7(const double p[7]) { for (int i = 0; i < 3; i++) t[i] = p[i]; for (int i = 0; i < 4; i++) q[i] = p[3 + i]; }
+};
+/* dso::AffLight (util/NumType.h:166-192) */
+struct AffLight {
+  double a, b;
+  AffLight() : a(0), b(0) {}
+  AffLight(double a_, double b_) : a(a_), b(b_) {}
+};
+
+inline std::string lastError() { const char* e = dmvio_hip_last_error(); return e ? e : ""; }
+
+/* The resident image pyramids: one slot per FrameHessian that is alive (its dIp pyramid in the reference). */
+class FrameStore {
+ public:
+  FrameStore(int device, int w, int h, int n_slots) : ctx_(dmvio_hip_create(device, w, h, n_slots)), w_(w), h_(h) {}
+  ~FrameStore() { if (ctx_) dmvio_hip_destroy(ctx_); }
+  FrameStore(const FrameStore&) = delete;
+  FrameStore& operator=(const FrameStore&) = delete;
+  bool valid() const { return ctx_ != nullptr; }
+  int pyrLevelsUsed() const { return ctx_ ? dmvio_hip_pyr_levels(ctx_) : 0; }
+  int w() const { return w_; }
+  int h() const { return h_; }
+  /* FrameHessian::makeImages: irradiance image (w*h floats) -> pyramid of the slot */
+  bool makeImages(int slot, const float* color) { return ctx_ && dmvio_hip_frame_upload(ctx_, slot, color) == 0; }
+  /* the same for images that stay resident in device memory: level 0 is the image itself */
+  bool makeImagesInPlace(int n, const int* slots, const float* device_images, size_t stride_bytes) {
+    return ctx_ && dmvio_hip_frames_attach_device_batch(ctx_, n, slots, device_images, stride_bytes) == 0;
+  }
+  dmvio_hip_ctx* handle() const { return ctx_; }
+
+ private:
+  dmvio_hip_ctx* ctx_;
+  int w_, h_;
+};
+
+/* One active point of the reference keyframe as setCoarseTrackingRef reads it (CoarseTracker.cpp:144-161): centerProjectedTo of the
+ * residual that targets lastRef, and efPoint->HdiF. */
+struct RefPoint { float u, v, idepth, HdiF; };
+
+class CoarseTracker {
+ public:
+  explicit CoarseTracker(FrameStore& frames) : refFrameID(-1), frames_(frames), trk_(frames.valid() ? dmvio_hip_tracker_create(frames.handle()) : nullptr), refSlot_(-1) {
+    for (int i = 0; i < 5; i++) lastResiduals[i] = NAN;
+    for (int i = 0; i < 3; i++) lastFlowIndicators[i] = 1000;
+  }
+  ~CoarseTracker() { if (trk_) dmvio_hip_tracker_destroy(trk_); }
+  CoarseTracker(const CoarseTracker&) = delete;
+  CoarseTracker& operator=(const CoarseTracker&) = delete;
+
+  bool makeK(float fx, float fy, float cx, float cy) {
+    const float K[4] = {fx, fy, cx, cy};
+    return trk_ && dmvio_hip_tracker_make_k(trk_, K) == 0;
+  }
+  /* lastRef = the newest keyframe (its slot, frameID, ab_exposure, aff_g2l); points = the active points with an IN residual into it */
+  bool setCoarseTrackingRef(int refSlot, int frameID, float ab_exposure, const AffLight& aff_g2l, const std::vector<RefPoint>& points) {
+    if (!trk_) return false;
+    const size_t n = points.size();
+    std::vector<float> u(n), v(n), id(n), hd(n);
+    for (size_t i = 0; i < n; i++) { u[i] = points[i].u; v[i] = points[i].v; id[i] = points[i].idepth; hd[i] = points[i].HdiF; }
+    if (dmvio_hip_tracker_set_ref(trk_, refSlot, ab_exposure, aff_g2l.a, aff_g2l.b, (int)n, u.data(), v.data(), id.data(), hd.data()) != 0) return false;
+    refSlot_ = refSlot; refFrameID = frameID; lastRef_aff_g2l = aff_g2l;
+    return true;
+  }
+  /* Returns trackingGood; lastToNew_out / aff_g2l_out are written only when every level finished (CoarseTracker.cpp:731-760); a device or
+   * argument error reads as "tracking failed" (the adapter sets isLost), lastError() tells why. */
+  bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, const double minResForAbort[5]) {
+    if (!trk_) return false;
+    double pose7[7], aff[2] = {aff_g2l_out.a, aff_g2l_out.b};
+    lastToNew_out.toPose7(pose7);
+    int good = 0;
+    if (dmvio_hip_tracker_track(trk_, newSlot, new_ab_exposure, pose7, aff, coarsestLvl, minResForAbort, lastResiduals, lastFlowIndicators, lastH, lastb, &good) != 0) return false;
+    lastToNew_out.fromPose7(pose7);
+    aff_g2l_out = AffLight(aff[0], aff[1]);
+    return good != 0;
+  }
+  int pc_n(int lvl) const { return trk_ ? dmvio_hip_tracker_pc_n(trk_, lvl) : 0; }
+
+  /* CoarseTracker.h:83-91 */
+  double lastResiduals[5];
+  double lastFlowIndicators[3];
+  AffLight lastRef_aff_g2l;
+  int refFrameID;
+  /* the scaled 8x8 system at the accepted state of the last level — what IMUIntegration::addVisualToCoarseGraph receives (CoarseTracker.cpp:766) */
+  double lastH[64], lastb[8];
+
+ private:
+  FrameStore& frames_;
+  dmvio_hip_tracker* trk_;
+  int refSlot_;
+};
+
+}  // namespace dmvio_hip
+#endif

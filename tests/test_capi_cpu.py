@@ -73,6 +73,22 @@ def _build_c_demo(pkg, out):
     return out
 
 
+def _build_cpp_demo(pkg, out):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(pkg.INCLUDE_PATH))
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", os.path.join(root, "examples", "cpp_adapter_demo.cpp"),
+                           "-I" + os.path.dirname(pkg.INCLUDE_PATH), "-L" + libdir, "-ldmvio_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", str(out)])
+    return out
+
+
+def test_cpp_mirror_of_the_reference_surface_compiles(pkg, tmp_path):
+    """include/dmvio_hip.hpp (CoarseTracker / FrameStore with the reference's member names over the C ABI) and its demo build as C++11 without
+    warnings against the header and the library."""
+    exe = _build_cpp_demo(pkg, tmp_path / "cpp_adapter_demo")
+    assert os.path.getsize(exe) > 0
+
+
 def test_plain_c_demo_compiles_and_links(pkg, tmp_path):
     """examples/c_abi_demo.c — one tracked frame through the C ABI from plain C99 (what a maintainer's adapter calls) — builds against the
     header and the shared library without warnings; tests/test_edge_gpu.py runs it on the device."""
