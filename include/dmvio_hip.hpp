@@ -118,5 +118,91 @@ class CoarseTracker {
   int refSlot_;
 };
 
+/* ---- mapping side: the window FullSystem::optimize works on -------------------------------------------------------------------------
+ *   KeyFrame      <- FrameHessian (slot of its pyramid, worldToCam_evalPT, aff_g2l, ab_exposure, frameID)       HessianBlocks.h:113-307
+ *   ActivePoint   <- PointHessian (host frame index, u, v, idepth, color[8], weights[8], hasDepthPrior) with the targets of its residuals
+ *                                                                                                                HessianBlocks.h:413-508
+ *   WindowOptimizer::optimize(mnumOptIts) <- float FullSystem::optimize(int)                                     FullSystemOptimize.cpp:417-647 */
+struct KeyFrame {
+  int slot;
+  SE3 worldToCam_evalPT;
+  AffLight aff_g2l;
+  float ab_exposure;
+  int frameID;
+};
+struct ActivePoint {
+  int host;
+  float u, v, idepth;
+  float color[8], weights[8];
+  bool hasDepthPrior;
+  std::vector<int> targets;   /* frame indices of its PointFrameResiduals */
+};
+
+class WindowOptimizer {
+ public:
+  explicit WindowOptimizer(FrameStore& frames) : lastEnergy(NAN), lastIterations(0), ba_(frames.valid() ? dmvio_hip_ba_create(frames.handle()) : nullptr), F_(0), N_(0) {}
+  ~WindowOptimizer() { if (ba_) dmvio_hip_ba_destroy(ba_); }
+  WindowOptimizer(const WindowOptimizer&) = delete;
+  WindowOptimizer& operator=(const WindowOptimizer&) = delete;
+
+  /* frameHessians in window order (newest last) + Hcalib: EnergyFunctional::insertFrame / setAdjointsF / FullSystem::setPrecalcValues */
+  bool setWindow(const std::vector<KeyFrame>& frameHessians, double fx, double fy, double cx, double cy) {
+    if (!ba_) return false;
+    const int F = (int)frameHessians.size();
+    std::vector<int> slots(F), ids(F);
+    std::vector<double> poses(7 * (size_t)F), aff(2 * (size_t)F);
+    std::vector<float> expo(F);
+    for (int f = 0; f < F; f++) {
+      slots[f] = frameHessians[f].slot; ids[f] = frameHessians[f].frameID; expo[f] = frameHessians[f].ab_exposure;
+      frameHessians[f].worldToCam_evalPT.toPose7(&poses[7 * (size_t)f]);
+      aff[2 * (size_t)f] = frameHessians[f].aff_g2l.a; aff[2 * (size_t)f + 1] = frameHessians[f].aff_g2l.b;
+    }
+    const double K[4] = {fx, fy, cx, cy};
+    if (dmvio_hip_ba_set_window(ba_, F, slots.data(), poses.data(), aff.data(), expo.data(), ids.data(), K) != 0) return false;
+    F_ = F;
+    return true;
+  }
+  /* all active points in allPoints order with their residuals: EnergyFunctional::makeIDX */
+  bool setPoints(const std::vector<ActivePoint>& points) {
+    if (!ba_) return false;
+    const size_t N = points.size();
+    std::vector<int> host(N), rp, rt;
+    std::vector<float> u(N), v(N), id(N), col(8 * N), wts(8 * N);
+    std::vector<unsigned char> prior(N);
+    for (size_t i = 0; i < N; i++) {
+      host[i] = points[i].host; u[i] = points[i].u; v[i] = points[i].v; id[i] = points[i].idepth; prior[i] = points[i].hasDepthPrior ? 1 : 0;
+      for (int k = 0; k < 8; k++) { col[8 * i + k] = points[i].color[k]; wts[8 * i + k] = points[i].weights[k]; }
+      for (size_t r = 0; r < points[i].targets.size(); r++) { rp.push_back((int)i); rt.push_back(points[i].targets[r]); }
+    }
+    if (dmvio_hip_ba_set_graph(ba_, (int)N, host.data(), u.data(), v.data(), id.data(), col.data(), wts.data(), prior.data(), (int)rp.size(), rp.data(), rt.data()) != 0) return false;
+    N_ = (int)N;
+    return true;
+  }
+  /* returns sqrt(E / (patternNum * resInA)) like the reference; a negative value on a device / argument error (the adapter sets isLost) */
+  float optimize(int mnumOptIts) {
+    if (!ba_) return -1.0f;
+    float rmse = -1.0f;
+    if (dmvio_hip_ba_optimize(ba_, mnumOptIts, &rmse, &lastEnergy, &lastIterations, energyTrace) != 0) return -1.0f;
+    return rmse;
+  }
+  bool frameState(int f, SE3& worldToCam, AffLight& aff_g2l) const {
+    double p[7], a[2], st[10];
+    if (!ba_ || dmvio_hip_ba_get_frame(ba_, f, p, a, st) != 0) return false;
+    worldToCam.fromPose7(p); aff_g2l = AffLight(a[0], a[1]);
+    return true;
+  }
+  bool idepths(std::vector<float>& idepth) const {
+    idepth.resize(N_);
+    return ba_ && dmvio_hip_ba_get_points(ba_, idepth.data(), nullptr) == 0;
+  }
+  double lastEnergy;           /* E_A + E_L + E_M after the last optimize */
+  int lastIterations;
+  double energyTrace[64 * 4];  /* per iteration: E_A, E_L, E_M, accepted (row 0: before the first step) */
+
+ private:
+  dmvio_hip_ba* ba_;
+  int F_, N_;
+};
+
 }  // namespace dmvio_hip
 #endif

@@ -172,10 +172,11 @@ def test_plain_c_demo_recovers_the_known_pose(pkg, gpu_required, tmp_path):
 
 def test_cpp_adapter_demo_tracks_like_the_reference_surface(pkg, gpu_required, tmp_path):
     """examples/cpp_adapter_demo.cpp: the tracking-thread calls through the C++ mirror (makeImages, makeK, setCoarseTrackingRef,
-    trackNewestCoarse returning trackingIsGood, lastResiduals / lastFlowIndicators members); a bad slot reads as tracking failed."""
+    trackNewestCoarse returning trackingIsGood, lastResiduals / lastFlowIndicators members); a bad slot reads as tracking failed; then the
+    mapping side: a three-keyframe window through WindowOptimizer::optimize (FullSystem::optimize) brings the energy down."""
     import subprocess
     from test_capi_cpu import _build_cpp_demo
     exe = _build_cpp_demo(pkg, tmp_path / "cpp_adapter_demo")
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ok: translation error" in r.stdout and "bad slot -> false" in r.stdout
+    assert "ok: translation error" in r.stdout and "bad slot -> false" in r.stdout and "ok: energy reduced" in r.stdout
