@@ -280,3 +280,24 @@ def test_shared_reciprocal_division_is_ieee_division(pkg, gpu_required):
         host = a / b
         assert np.array_equal(qi.view(np.uint32), host.view(np.uint32))             # the device's IEEE division == the host's
         assert np.array_equal(qs.view(np.uint32), qi.view(np.uint32))               # the shared-reciprocal form == IEEE division
+
+
+def test_eval_parity_random_poses_and_brightness(setup, oracle):
+    """Sixty random evaluations: poses up to a few centimetres / degrees away (many points leave the image), affine brightness, exposure ratios,
+    cut-off thresholds, every level and frame — the same term counts as the oracle and the same sums to the tolerance of test_eval_parity."""
+    trk, T, case = setup["trk"], setup["T"], setup["case"]
+    rng = np.random.RandomState(77)
+    for trial in range(60):
+        k = int(rng.randint(0, 3)); lvl = int(rng.randint(0, 4))
+        xi = rng.normal(0, 1, 6) * np.array([0.05, 0.05, 0.05, 0.03, 0.03, 0.03]) * rng.choice([0.2, 1.0, 3.0])
+        pose = oracle.se3_exp(xi)
+        aff = (float(rng.normal(0, 0.05)), float(rng.normal(0, 5.0)))
+        cutoff = float(rng.choice([5.0, 20.0, 80.0]))
+        T.set_new(setup["dIn"][k])
+        rs_o = T.calc_res(lvl, pose, aff, cutoff)
+        H_o, b_o = T.calc_gs(lvl, aff)
+        rs_g, H_g, b_g = trk.eval(lvl, 1 + k, pose, aff, cutoff)
+        assert rs_g[1] == rs_o[1], (trial, "numTermsInE")
+        if rs_o[1] < 8:
+            continue                                   # next to nothing left in the image: counts compared, sums too small to scale
+        _cmp_eval(rs_g, H_g, b_g, rs_o, H_o, b_o, tol=5e-5)
