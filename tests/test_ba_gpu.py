@@ -50,6 +50,40 @@ def test_linearize_bit_exact(big):
         assert np.array_equal(J[ri].view(np.uint32), flat.view(np.uint32)), "residual %d" % ri
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_linearize_and_system_random_windows(pkg, oracle, synth, gpu_required, seed):
+    """Random windows: 3..8 keyframes, affine brightness and exposure times that differ per frame, 640x480 / 256x256 images — per-residual
+    linearisation bit-identical, the stitched system and one optimisation step like the oracle's."""
+    rng = np.random.RandomState(seed)
+    F = int(rng.randint(3, 9))
+    w, h = (640, 480) if seed % 2 else (256, 256)
+    case = synth.ba_case(w, h, n_frames=F, n_points=int(rng.randint(200, 500)), seed=seed)
+    case["aff"] = np.column_stack([rng.normal(0, 0.02, F), rng.normal(0, 2.0, F)])
+    case["exposure"] = rng.uniform(0.7, 1.4, F).astype(np.float32)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba.activate_all(); W.activate_all()
+    e_g = ba.linearize_all(False); e_o = W.linearize_all(False)
+    sg, so = ba.res_state(), W.res_state()
+    assert np.array_equal(sg["newState"], so["newState"].astype(np.uint8))
+    assert np.array_equal(sg["newEnergy"], so["newEnergy"].astype(np.float32))
+    assert np.array_equal(sg["newEnergyWO"], so["newEnergyWO"].astype(np.float32))
+    assert abs(e_g - e_o) <= 1e-9 * abs(e_o)
+    ba.apply_res(); W.apply_res()
+    ag, ao = ba.accumulate(), W.accumulate()
+    assert ag["resInA"] == ao["resInA"]
+    for k in ("HA", "bA", "Hsc", "bsc"):
+        scale = np.abs(ao[k]).max() + 1e-30
+        assert np.max(np.abs(ag[k] - ao[k])) <= 1e-9 * scale, k
+    EL, EM = ba.energy_terms()            # the affine priors pull a, b towards zero: with non-zero brightness parameters E_L starts above zero
+    assert abs(EL - W.lenergy()) <= 1e-9 * abs(W.lenergy()) + 1e-12 and EL > 0
+    lam, lE = 1e-5, [e_g, EL, EM]
+    lamo, lEo = 1e-5, [e_o, W.lenergy(), W.menergy()]
+    for it in range(3):
+        acc, lam, lE = ba.gn_iteration(it, lam, lE)
+        acco, lamo, lEo = W.gn_iteration(it, lamo, lEo)
+        assert bool(acc) == bool(acco) and abs(lE[0] - lEo[0]) <= 1e-4 * abs(lEo[0])
+
+
 @pytest.mark.parametrize("mode", ["exact", "fast"])
 def test_accumulate_and_solve_parity(big, pkg, oracle, mode, monkeypatch):
     """accumulateAF / accumulateSCF + adjoint stitching, solveSystemF, resubstitute.
