@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 1100552.0 * 1024)   # HBM bytes per k_track_lm launch from the committed PMC pass (results go to pinned host memory)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 1098774.5 * 1024)   # HBM bytes per k_track_lm launch from the committed PMC pass (results go to pinned host memory)
 BYTES_PER_POINT_EVAL = 64      # 16 B template record + 4 taps x 12 B
 
 
@@ -187,7 +187,7 @@ def main():
     # 2 x FETCH_SIZE + WRITE_SIZE per launch, valid for the default workload only
     if B == 1024 and args.points == 2000 and (w, h) == (512, 512) and args.distinct == 8:
         roofline["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH
-        roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic_batch1024.md (2 x FETCH_SIZE 1,100,552 KiB per launch; the 0.78 MB of results are stored into pinned host memory, not HBM; below the algorithmic bytes: L2/MALL absorb neighbouring taps)"
+        roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic_batch1024.md (2 x FETCH_SIZE 1,098,775 KiB per launch; the 0.78 MB of results are stored into pinned host memory, not HBM; below the algorithmic bytes: L2/MALL absorb neighbouring taps)"
     pm = None
     if not args.no_pyramid:
         pms = []
