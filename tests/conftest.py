@@ -14,13 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _built():
+    lib = os.path.join(ROOT, "dm-vio_amd", "lib", "libdmvio_hip.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    return os.path.exists(lib) and os.path.exists(orc)
+
+
 @pytest.fixture(scope="session")
 def pkg():
+    # a fresh checkout has no binaries (they are git-ignored): build once — cross-compiling for gfx950 needs no GPU
+    if not _built() and os.path.exists("/opt/rocm/bin/hipcc"):
+        graft.build()
     return graft.load_package()
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def oracle(pkg):
     return graft.load_oracle()
 
 
