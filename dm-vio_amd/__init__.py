@@ -41,6 +41,9 @@ def _sig(L):
     L.dmvio_hip_frames_from_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
     L.dmvio_hip_frames_attach_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
     L.dmvio_hip_frame_download.argtypes = [vp, C.c_int, C.c_int, c_f]
+    L.dmvio_hip_frame_mark_unclean.argtypes = [vp, C.c_int]
+    L.dmvio_hip_selftest_divide.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.dmvio_hip_write_result_txt.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, vp, vp]
     L.dmvio_hip_tracker_create.restype = vp
     L.dmvio_hip_tracker_create.argtypes = [vp]
     L.dmvio_hip_tracker_destroy.argtypes = [vp]
@@ -175,8 +178,6 @@ def write_result_txt(path, timestamps, camToWorld7, pose_valid=None, tracking_re
     tr = None if tracking_ref is None else np.ascontiguousarray(tracking_ref, dtype=np.int32)
     cr = None if camToTrackingRef7 is None else np.ascontiguousarray(camToTrackingRef7, dtype=np.float64)
     fp = np.ascontiguousarray(firstPose7, dtype=np.float64)
-    L.dmvio_hip_write_result_txt.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 6
-    L.dmvio_hip_write_result_txt.restype = C.c_int
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     _chk(L, L.dmvio_hip_write_result_txt(str(path).encode(), len(ts), ptr(ts), ptr(P), ptr(pv), ptr(tr), ptr(cr), ptr(fp)), "write_result_txt")
 
@@ -240,15 +241,11 @@ class Context:
     def selftest_divide(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
         qs = np.zeros_like(a); qi = np.zeros_like(a)
-        self.L.dmvio_hip_selftest_divide.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
-        self.L.dmvio_hip_selftest_divide.restype = C.c_int
         _chk(self.L, self.L.dmvio_hip_selftest_divide(self.p, a.size, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                                       qs.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p)), "selftest_divide")
         return qs, qi
 
     def frame_mark_unclean(self, slot):
-        self.L.dmvio_hip_frame_mark_unclean.argtypes = [C.c_void_p, C.c_int]
-        self.L.dmvio_hip_frame_mark_unclean.restype = C.c_int
         _chk(self.L, self.L.dmvio_hip_frame_mark_unclean(self.p, slot), "frame_mark_unclean")
 
     def frame_download(self, slot, lvl):
