@@ -14,7 +14,9 @@ SEED = 20250204
 
 
 def default_intrinsics(w=512, h=512):
-    return np.array([0.2 * w, 0.2 * h, 0.499 * w - 0.5, 0.499 * h - 0.5], dtype=np.float64)
+    # float-exact values: in the reference every calibration passes through float globals (globalCalib.cpp:79-82) before it is widened
+    # to CalibHessian::value_scaled, so intrinsics that are not representable in fp32 never reach the path
+    return np.array([0.2 * w, 0.2 * h, 0.499 * w - 0.5, 0.499 * h - 0.5], dtype=np.float32).astype(np.float64)
 
 
 def quat_to_R(q):  # q = (qx,qy,qz,qw)

@@ -1401,4 +1401,40 @@ int orc_ba_gn_iteration(void* p, int iteration, double* lambda_io, double lastE[
   return accept ? 1 : 0;
 }
 
+// --- primitives exposed for the pinning tests (same record formats as ref_accapprox_stream / ref_accxx_stream in oracle/ref_glue.cpp) ---
+void orc_accapprox_stream(int n, const float* rec35, int reps, float* H169, long* num) {
+  AccApprox acc; acc.initialize();
+  for (int rep = 0; rep < reps; rep++)
+  for (int i = 0; i < n; i++) {
+    const float* r = rec35 + 35 * i;
+    acc.update(r, r + 4, r + 10, r + 14, r[20], r[21], r[22]);
+    acc.updateTopRight(r, r + 4, r + 10, r + 14, r[23], r[24], r[25], r[26], r[27], r[28]);
+    acc.updateBotRight(r[29], r[30], r[31], r[32], r[33], r[34]);
+  }
+  acc.finish();
+  for (int r = 0; r < 13; r++) for (int c = 0; c < 13; c++) H169[r * 13 + c] = acc.H[r][c];
+  *num = (long)acc.num;
+}
+void orc_accxx_stream(int n, const float* rec21, int reps, float* A88, float* A84, float* A8, long* num) {
+  AccXX<8, 8> a88; AccXX<8, 4> a84; AccX<8> a8;
+  a88.initialize(); a84.initialize(); a8.initialize();
+  for (int rep = 0; rep < reps; rep++)
+  for (int i = 0; i < n; i++) { const float* r = rec21 + 21 * i; a88.update(r, r + 8, r[20]); a84.update(r, r + 16, r[20]); a8.update(r, r[20]); }
+  a88.finish(); a84.finish(); a8.finish();
+  memcpy(A88, a88.A1m, sizeof(a88.A1m)); memcpy(A84, a84.A1m, sizeof(a84.A1m)); memcpy(A8, a8.A1m, sizeof(a8.A1m));
+  *num = (long)a88.num;
+}
+// projectPoint, both forms, on a window that only carries the calibration (w, h, K)
+int orc_project_point_short(void* p, float u, float v, float idepth, const float KRKi[9], const float Kt[3], float out2[2]) {
+  float Ku = 0, Kv = 0;
+  bool ok = ((OWindow*)p)->projectPointK(u, v, idepth, KRKi, Kt, Ku, Kv);
+  out2[0] = Ku; out2[1] = Kv; return ok ? 1 : 0;
+}
+int orc_project_point_long(void* p, float u_pt, float v_pt, float idepth, const float R[9], const float t[3], float out9[9]) {
+  float drescale = 0, u = 0, v = 0, Ku = 0, Kv = 0, nid = 0, KliP[3] = {0, 0, 0};
+  bool ok = ((OWindow*)p)->projectPointFull(u_pt, v_pt, idepth, R, t, drescale, u, v, Ku, Kv, KliP, nid);
+  out9[0] = drescale; out9[1] = u; out9[2] = v; out9[3] = Ku; out9[4] = Kv; out9[5] = KliP[0]; out9[6] = KliP[1]; out9[7] = KliP[2]; out9[8] = nid;
+  return ok ? 1 : 0;
+}
+
 }  // extern "C"

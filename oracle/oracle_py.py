@@ -378,7 +378,9 @@ class BAWindow:
     def __init__(self, case, poses=None, idepth=None, threads=1):
         self.L = lib(); _ba_sig(self.L)
         self.case = case
-        K4 = np.ascontiguousarray(case["K4"], dtype=np.float64)
+        # the reference's calibration is born as float (globalCalib.cpp:79-82: fxG[0] = K(0,0) ...) and only then widened to the double
+        # CalibHessian::value_scaled (HessianBlocks.h:326-330): the window starts from the float-rounded intrinsics
+        K4 = np.ascontiguousarray(np.asarray(case["K4"], dtype=np.float32), dtype=np.float64)
         self.p = C.c_void_p(self.L.orc_ba_create(case["w"], case["h"], _d(K4)))
         self.L.orc_ba_set_threads(self.p, threads)
         self._dI = case["dI0"] if case.get("dI0") is not None else [make_images(img, case["w"], case["h"])[0][0] for img in case["imgs"]]

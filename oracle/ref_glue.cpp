@@ -1,0 +1,851 @@
+// ORACLE-SIDE TEST INFRASTRUCTURE — not product code.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+//
+// extern "C" entry points into the REFERENCE'S OWN, UNMODIFIED sources (compiled from /root/reference by Makefile.ref into
+// oracle/_ref/libref.so): CoarseTracker, FrameHessian::makeImages, PointFrameResidual::linearize, the accumulators,
+// EnergyFunctional, FullSystem::optimize, ImmaturePoint, CoarseInitializer and the whole visual-only FullSystem pipeline.
+// This file contains NO arithmetic of the path: it only builds the reference's own objects from flat arrays, calls the
+// reference's member functions and copies their results out, so that tests can run the same inputs through
+//   (1) this library   = the reference itself,
+//   (2) oracle/*.cpp   = the dependency-free restatement (pins the restatement),
+//   (3) libdmvio_hip.so = the product (GPU parity).
+// What sits below the reference's code here is NOT the reference's: Eigen / Sophus / Boost.Thread are stand-ins (ref_shim/),
+// IMU / GTSAM are stubs.  The hot path's arithmetic is explicit scalar / SSE code in the reference's own files, so it is pinned;
+// LDLT / SVD / inverse (Eigen) and SE3 exp / log (Sophus) run through the stand-ins and are not.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+// the reference keeps calcRes / calcGSSSE / linearizeAll / ... private; the tests call them one by one
+#define private public
+#define protected public
+#include "util/NumType.h"
+#include "util/settings.h"
+#include "util/globalCalib.h"
+#include "util/globalFuncs.h"
+#include "util/ImageAndExposure.h"
+#include "util/FrameShell.h"
+#include "OptimizationBackend/MatrixAccumulators.h"
+#include "OptimizationBackend/EnergyFunctional.h"
+#include "OptimizationBackend/EnergyFunctionalStructs.h"
+#include "OptimizationBackend/AccumulatedTopHessian.h"
+#include "OptimizationBackend/AccumulatedSCHessian.h"
+#include "FullSystem/FullSystem.h"
+#include "FullSystem/HessianBlocks.h"
+#include "FullSystem/Residuals.h"
+#include "FullSystem/ResidualProjections.h"
+#include "FullSystem/ImmaturePoint.h"
+#include "FullSystem/CoarseTracker.h"
+#include "FullSystem/CoarseInitializer.h"
+#include "FullSystem/PixelSelector2.h"
+#undef private
+#undef protected
+
+using namespace dso;
+
+namespace
+{
+// pose7 = [tx ty tz qx qy qz qw] (the convention of oracle/ and of the C ABI)
+SE3 se3From7(const double* p)
+{
+	Sophus::Quaterniond_ q(p[6], p[3], p[4], p[5]);
+	return SE3(q, Vec3(p[0], p[1], p[2]));
+}
+void se3To7(const SE3& T, double* p)
+{
+	p[0] = T.translation()[0]; p[1] = T.translation()[1]; p[2] = T.translation()[2];
+	const Sophus::Quaterniond_& q = T.unit_quaternion();
+	p[3] = q.x(); p[4] = q.y(); p[5] = q.z(); p[6] = q.w();
+}
+
+// stdout of a reference call captured into a string (FullSystem::optimize reports its accept / reject decisions only there)
+struct StdoutCapture
+{
+	int saved = -1;
+	char path[64];
+	StdoutCapture()
+	{
+		fflush(stdout);
+		strcpy(path, "/tmp/refglue_XXXXXX");
+		int fd = mkstemp(path);
+		saved = dup(1);
+		dup2(fd, 1);
+		close(fd);
+	}
+	std::string finish()
+	{
+		fflush(stdout);
+		dup2(saved, 1);
+		close(saved);
+		std::ifstream f(path);
+		std::stringstream ss; ss << f.rdbuf();
+		unlink(path);
+		return ss.str();
+	}
+};
+
+dmvio::IMUCalibration g_imuCalib;
+dmvio::IMUSettings g_imuSettings;
+
+void setCalib(int w, int h, const float K4[4])
+{
+	Eigen::Matrix3f K = Eigen::Matrix3f::Identity();
+	K(0, 0) = K4[0]; K(1, 1) = K4[1]; K(0, 2) = K4[2]; K(1, 2) = K4[3];
+	StdoutCapture cap;
+	setGlobalCalib(w, h, K);
+	cap.finish();
+}
+
+FrameHessian* newFrame(const float* img, float exposure, CalibHessian* HCalib, int id, double timestamp = 0)
+{
+	FrameHessian* fh = new FrameHessian();
+	FrameShell* shell = new FrameShell();
+	shell->camToWorld = SE3();
+	shell->aff_g2l = AffLight(0, 0);
+	shell->marginalizedAt = shell->id = id;
+	shell->timestamp = timestamp;
+	shell->incoming_id = id;
+	fh->shell = shell;
+	fh->ab_exposure = exposure;
+	std::vector<float> copy(img, img + wG[0] * hG[0]);
+	fh->makeImages(copy.data(), HCalib);
+	return fh;
+}
+void deleteFrame(FrameHessian* fh)
+{
+	fh->efFrame = 0;
+	FrameShell* s = fh->shell;
+	delete fh;
+	delete s;
+}
+}  // namespace
+
+extern "C" {
+
+int ref_version() { return 2; }
+
+// ================================================================================================= settings (util/settings.cpp)
+void ref_set_use_imu(int on) { setting_useIMU = on != 0; setting_useGTSAMIntegration = on != 0; }
+void ref_set_affine_opt_mode(double a, double b) { setting_affineOptModeA = a; setting_affineOptModeB = b; }
+void ref_set_quiet(int q) { setting_debugout_runquiet = q != 0; }
+void ref_set_multithreading(int on) { multiThreading = on != 0; }
+void ref_set_gamma_weights_pixel_select(int on) { setting_gammaWeightsPixelSelect = on; }
+int ref_pyr_levels(int w, int h, const float K4[4]) { setCalib(w, h, K4); return pyrLevelsUsed; }
+void ref_get_global_calib(int lvl, float out4[4], float Ki9[9], int wh[2])
+{
+	out4[0] = fxG[lvl]; out4[1] = fyG[lvl]; out4[2] = cxG[lvl]; out4[3] = cyG[lvl];
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ki9[r * 3 + c] = KiG[lvl](r, c);
+	wh[0] = wG[lvl]; wh[1] = hG[lvl];
+}
+
+// ================================================================================================= primitives
+// getInterpolatedElement33 (util/globalFuncs.h:103-118) at n positions of a float3 image
+void ref_interp33(const float* img3, int width, int n, const float* x, const float* y, float* out3)
+{
+	const Eigen::Vector3f* m = (const Eigen::Vector3f*)img3;
+	for (int i = 0; i < n; i++)
+	{
+		Eigen::Vector3f r = getInterpolatedElement33(m, x[i], y[i], width);
+		out3[3 * i] = r[0]; out3[3 * i + 1] = r[1]; out3[3 * i + 2] = r[2];
+	}
+}
+// getInterpolatedElement31 (globalFuncs.h:155-168), getInterpolatedElement33BiLin (:120-153)
+void ref_interp31(const float* img3, int width, int n, const float* x, const float* y, float* out)
+{
+	const Eigen::Vector3f* m = (const Eigen::Vector3f*)img3;
+	for (int i = 0; i < n; i++) out[i] = getInterpolatedElement31(m, x[i], y[i], width);
+}
+void ref_interp33_bilin(const float* img3, int width, int n, const float* x, const float* y, float* out3)
+{
+	const Eigen::Vector3f* m = (const Eigen::Vector3f*)img3;
+	for (int i = 0; i < n; i++)
+	{
+		Eigen::Vector3f r = getInterpolatedElement33BiLin(m, x[i], y[i], width);
+		out3[3 * i] = r[0]; out3[3 * i + 1] = r[1]; out3[3 * i + 2] = r[2];
+	}
+}
+// projectPoint, short form (FullSystem/ResidualProjections.h:47-58); needs ref_pyr_levels() for wG / hG.  returns the bool
+int ref_project_point_short(float u_pt, float v_pt, float idepth, const float KRKi9[9], const float Kt3[3], float out_KuKv[2])
+{
+	Mat33f KRKi; Vec3f Kt;
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KRKi(r, c) = KRKi9[r * 3 + c];
+	for (int r = 0; r < 3; r++) Kt[r] = Kt3[r];
+	float Ku = 0, Kv = 0;
+	bool ok = projectPoint(u_pt, v_pt, idepth, KRKi, Kt, Ku, Kv);
+	out_KuKv[0] = Ku; out_KuKv[1] = Kv;
+	return ok ? 1 : 0;
+}
+// projectPoint, long form (ResidualProjections.h:62-87): out = drescale, u, v, Ku, Kv, KliP(3), new_idepth
+int ref_project_point_long(float u_pt, float v_pt, float idepth, int dx, int dy, const float K4[4], const float R9[9], const float t3[3], float out9[9])
+{
+	CalibHessian HCalib;
+	VecC v; v << K4[0], K4[1], K4[2], K4[3];
+	HCalib.setValueScaled(v);
+	Mat33f R; Vec3f t;
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R(r, c) = R9[r * 3 + c];
+	for (int r = 0; r < 3; r++) t[r] = t3[r];
+	float drescale = 0, u = 0, vv = 0, Ku = 0, Kv = 0, nid = 0;
+	Vec3f KliP = Vec3f::Zero();
+	bool ok = projectPoint(u_pt, v_pt, idepth, dx, dy, &HCalib, R, t, drescale, u, vv, Ku, Kv, KliP, nid);
+	out9[0] = drescale; out9[1] = u; out9[2] = vv; out9[3] = Ku; out9[4] = Kv; out9[5] = KliP[0]; out9[6] = KliP[1]; out9[7] = KliP[2]; out9[8] = nid;
+	return ok ? 1 : 0;
+}
+// AffLight::fromToVecExposure (util/NumType.h:174-186)
+void ref_aff_from_to(float exposureF, float exposureT, double aF, double bF, double aT, double bT, double out2[2])
+{
+	Vec2 r = AffLight::fromToVecExposure(exposureF, exposureT, AffLight(aF, bF), AffLight(aT, bT));
+	out2[0] = r[0]; out2[1] = r[1];
+}
+
+// ---- accumulators fed with streams (OptimizationBackend/MatrixAccumulators.h) -------------------------------------------------
+// Accumulator9: n4 groups of 4 points through updateSSE_eighted (J: [n4*4][9], w: [n4*4]), then `nsingle` points through
+// updateSingleWeighted (J: [9], w).  out: H 9x9 row-major, num
+void ref_acc9_stream(int n4, const float* J, const float* w, int nsingle, const float* Js, const float* ws, int reps, float* H81, long* num)
+{
+	Accumulator9* acc = new Accumulator9();  // aligned operator new
+	acc->initialize();
+	for (int rep = 0; rep < reps; rep++)
+	for (int g = 0; g < n4; g++)
+	{
+		__m128 j[9];
+		for (int k = 0; k < 9; k++) j[k] = _mm_setr_ps(J[(4 * g + 0) * 9 + k], J[(4 * g + 1) * 9 + k], J[(4 * g + 2) * 9 + k], J[(4 * g + 3) * 9 + k]);
+		__m128 ww = _mm_setr_ps(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+		acc->updateSSE_eighted(j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], ww);
+	}
+	for (int i = 0; i < nsingle; i++)
+	{
+		const float* j = Js + 9 * i;
+		acc->updateSingleWeighted(j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], j[8], ws[i]);
+	}
+	acc->finish();
+	for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) H81[r * 9 + c] = acc->H(r, c);
+	*num = (long)acc->num;
+	delete acc;
+}
+// AccumulatorApprox: per update x4(4) x6(6) y4(4) y6(6) a b c | TR(6) | BR(6) = 35 floats.  out: H 13x13 row-major
+void ref_accapprox_stream(int n, const float* rec35, int reps, float* H169, long* num)
+{
+	AccumulatorApprox* acc = new AccumulatorApprox();
+	acc->initialize();
+	for (int rep = 0; rep < reps; rep++)
+	for (int i = 0; i < n; i++)
+	{
+		const float* r = rec35 + 35 * i;
+		acc->update(r, r + 4, r + 10, r + 14, r[20], r[21], r[22]);
+		acc->updateTopRight(r, r + 4, r + 10, r + 14, r[23], r[24], r[25], r[26], r[27], r[28]);
+		acc->updateBotRight(r[29], r[30], r[31], r[32], r[33], r[34]);
+	}
+	acc->finish();
+	for (int r = 0; r < 13; r++) for (int c = 0; c < 13; c++) H169[r * 13 + c] = acc->H(r, c);
+	*num = (long)acc->num;
+	delete acc;
+}
+// AccumulatorXX<8,8>, AccumulatorXX<8,4>, AccumulatorX<8>: per update L(8) R8(8) R4(4) w.  out row-major
+void ref_accxx_stream(int n, const float* rec21, int reps, float* A88, float* A84, float* A8, long* num)
+{
+	AccumulatorXX<8, 8>* a88 = new AccumulatorXX<8, 8>();
+	AccumulatorXX<8, 4>* a84 = new AccumulatorXX<8, 4>();
+	AccumulatorX<8>* a8 = new AccumulatorX<8>();
+	a88->initialize(); a84->initialize(); a8->initialize();
+	for (int rep = 0; rep < reps; rep++)
+	for (int i = 0; i < n; i++)
+	{
+		const float* r = rec21 + 21 * i;
+		Vec8f L, R8; Vec4f R4;
+		for (int k = 0; k < 8; k++) { L[k] = r[k]; R8[k] = r[8 + k]; }
+		for (int k = 0; k < 4; k++) R4[k] = r[16 + k];
+		a88->update(L, R8, r[20]);
+		a84->update(L, R4, r[20]);
+		a8->update(L, r[20]);
+	}
+	a88->finish(); a84->finish(); a8->finish();
+	for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) A88[r * 8 + c] = a88->A1m(r, c);
+	for (int r = 0; r < 8; r++) for (int c = 0; c < 4; c++) A84[r * 4 + c] = a84->A1m(r, c);
+	for (int r = 0; r < 8; r++) A8[r] = a8->A1m[r];
+	*num = (long)a88->num;
+	delete a88; delete a84; delete a8;
+}
+
+// ================================================================================================= FrameHessian::makeImages
+// (HessianBlocks.cpp:128-191).  dI_levels[l]: [h_l*w_l*3], abs_levels[l]: [h_l*w_l]; B256: optional gamma table (CalibHessian::B)
+int ref_make_images(const float* img, int w, int h, const float K4[4], const float* B256, float** dI_levels, float** abs_levels)
+{
+	setCalib(w, h, K4);
+	CalibHessian HCalib;
+	if (B256) memcpy(HCalib.B, B256, sizeof(float) * 256);
+	FrameHessian* fh = newFrame(img, 1.0f, &HCalib, 0);
+	for (int l = 0; l < pyrLevelsUsed; l++)
+	{
+		memcpy(dI_levels[l], fh->dIp[l], sizeof(float) * 3 * wG[l] * hG[l]);
+		memcpy(abs_levels[l], fh->absSquaredGrad[l], sizeof(float) * wG[l] * hG[l]);
+	}
+	int lv = pyrLevelsUsed;
+	deleteFrame(fh);
+	return lv;
+}
+
+// ================================================================================================= CoarseTracker
+struct RefTracker
+{
+	int w, h;
+	CalibHessian* HCalib = nullptr;
+	dmvio::IMUIntegration imu;
+	CoarseTracker* trk = nullptr;
+	FrameHessian* ref = nullptr;
+	FrameHessian* cur = nullptr;
+	FrameHessian* host = nullptr;  // owner of the template points
+	std::vector<PointHessian*> pts;
+	std::vector<EFPoint*> efpts;
+	std::vector<EFResidual*> efres;
+	std::vector<ImmaturePoint*> ipts;
+	// VIO hand-off log: every (H, b, lambda, extrapFac) the reference passed to computeCoarseUpdate
+	std::vector<double> vioLog;
+	int vioCalls = 0, vioAccepts = 0, vioVisual = 0;
+	std::vector<double> vioVisualHb;
+};
+
+void* ref_tracker_create(int w, int h, const float K4[4])
+{
+	setCalib(w, h, K4);
+	RefTracker* T = new RefTracker();
+	T->w = w; T->h = h;
+	T->HCalib = new CalibHessian();
+	T->trk = new CoarseTracker(w, h, T->imu);
+	T->trk->makeK(T->HCalib);
+	return T;
+}
+static void refTrackerClearRef(RefTracker* T)
+{
+	for (PointHessian* p : T->pts) { p->efPoint = 0; p->residuals.clear(); delete p->lastResiduals[0].first; delete p; }
+	for (EFPoint* e : T->efpts) delete e;
+	for (EFResidual* e : T->efres) delete e;
+	for (ImmaturePoint* i : T->ipts) delete i;
+	T->pts.clear(); T->efpts.clear(); T->efres.clear(); T->ipts.clear();
+	if (T->ref) { T->ref->pointHessians.clear(); deleteFrame(T->ref); T->ref = nullptr; }
+}
+void ref_tracker_destroy(void* p)
+{
+	RefTracker* T = (RefTracker*)p;
+	refTrackerClearRef(T);
+	if (T->cur) deleteFrame(T->cur);
+	delete T->trk;
+	delete T->HCalib;
+	delete T;
+}
+int ref_tracker_levels(void*) { return pyrLevelsUsed; }
+void ref_tracker_get_k(void* p, int lvl, float out4[4], float Ki9[9])
+{
+	CoarseTracker* t = ((RefTracker*)p)->trk;
+	out4[0] = t->fx[lvl]; out4[1] = t->fy[lvl]; out4[2] = t->cx[lvl]; out4[3] = t->cy[lvl];
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ki9[r * 3 + c] = t->Ki[lvl](r, c);
+}
+// setCoarseTrackingRef (CoarseTracker.cpp:524-538) on a keyframe built from `img` whose active points project to
+// centerProjectedTo = (u, v, idepth) with efPoint->HdiF = hdiF (the inputs makeCoarseDepthL0 reads, :144-161)
+void ref_tracker_set_ref(void* p, const float* img, float exposure, double affA, double affB, int n, const float* u, const float* v, const float* idepth, const float* hdiF)
+{
+	RefTracker* T = (RefTracker*)p;
+	refTrackerClearRef(T);
+	T->ref = newFrame(img, exposure, T->HCalib, 0);
+	T->ref->setEvalPT_scaled(SE3(), AffLight(affA, affB));
+	for (int i = 0; i < n; i++)
+	{
+		ImmaturePoint* ip = new ImmaturePoint(8, 8, T->ref, 1, T->HCalib);
+		ip->idepth_min = ip->idepth_max = idepth[i];
+		PointHessian* ph = new PointHessian(ip, T->HCalib);
+		EFPoint* efp = new EFPoint(ph, nullptr);
+		efp->HdiF = hdiF[i];
+		ph->efPoint = efp;
+		PointFrameResidual* r = new PointFrameResidual(ph, T->ref, T->ref);
+		EFResidual* efr = new EFResidual(r, efp, nullptr, nullptr);
+		efr->isActiveAndIsGoodNEW = true;
+		r->efResidual = efr;
+		r->centerProjectedTo = Vec3f(u[i], v[i], idepth[i]);
+		ph->lastResiduals[0] = std::pair<PointFrameResidual*, ResState>(r, ResState::IN);
+		T->ref->pointHessians.push_back(ph);
+		T->pts.push_back(ph); T->efpts.push_back(efp); T->efres.push_back(efr); T->ipts.push_back(ip);
+	}
+	std::vector<FrameHessian*> fhs; fhs.push_back(T->ref);
+	T->trk->setCoarseTrackingRef(fhs);
+}
+void ref_tracker_set_new(void* p, const float* img, float exposure)
+{
+	RefTracker* T = (RefTracker*)p;
+	if (T->cur) deleteFrame(T->cur);
+	T->cur = newFrame(img, exposure, T->HCalib, 1);
+	T->trk->newFrame = T->cur;
+}
+void ref_tracker_get_dIp(void* p, int which, int lvl, float* out3)
+{
+	RefTracker* T = (RefTracker*)p;
+	FrameHessian* f = which ? T->cur : T->ref;
+	memcpy(out3, f->dIp[lvl], sizeof(float) * 3 * wG[lvl] * hG[lvl]);
+}
+int ref_tracker_pc_n(void* p, int lvl) { return ((RefTracker*)p)->trk->pc_n[lvl]; }
+void ref_tracker_get_pc(void* p, int lvl, float* u, float* v, float* idepth, float* color)
+{
+	CoarseTracker* t = ((RefTracker*)p)->trk;
+	size_t n = sizeof(float) * t->pc_n[lvl];
+	memcpy(u, t->pc_u[lvl], n); memcpy(v, t->pc_v[lvl], n); memcpy(idepth, t->pc_idepth[lvl], n); memcpy(color, t->pc_color[lvl], n);
+}
+void ref_tracker_get_idepth(void* p, int lvl, float* idepth, float* weightSums)
+{
+	CoarseTracker* t = ((RefTracker*)p)->trk;
+	size_t n = sizeof(float) * t->w[lvl] * t->h[lvl];
+	memcpy(idepth, t->idepth[lvl], n); memcpy(weightSums, t->weightSums[lvl], n);
+}
+// calcRes (CoarseTracker.cpp:361-517): out6 = [E, numTermsInE, flowT, 0, flowRT, saturatedRatio]
+void ref_tracker_calc_res(void* p, int lvl, const double pose7[7], const double aff[2], float cutoffTH, double out6[6])
+{
+	RefTracker* T = (RefTracker*)p;
+	Vec6 r = T->trk->calcRes(lvl, se3From7(pose7), AffLight(aff[0], aff[1]), cutoffTH);
+	for (int i = 0; i < 6; i++) out6[i] = r[i];
+}
+int ref_tracker_warped_n(void* p) { return ((RefTracker*)p)->trk->buf_warped_n; }
+// rows: idepth, u, v, dx, dy, residual, weight, refColor
+void ref_tracker_get_warped(void* p, float* out8n)
+{
+	CoarseTracker* t = ((RefTracker*)p)->trk;
+	const int n = t->buf_warped_n;
+	const float* src[8] = {t->buf_warped_idepth, t->buf_warped_u, t->buf_warped_v, t->buf_warped_dx, t->buf_warped_dy, t->buf_warped_residual, t->buf_warped_weight, t->buf_warped_refColor};
+	for (int k = 0; k < 8; k++) memcpy(out8n + (size_t)k * n, src[k], sizeof(float) * n);
+}
+// calcGSSSE (CoarseTracker.cpp:299-356)
+void ref_tracker_calc_gs(void* p, int lvl, const double aff[2], double* H64, double* b8)
+{
+	RefTracker* T = (RefTracker*)p;
+	Mat88 H; Vec8 b;
+	T->trk->calcGSSSE(lvl, H, b, SE3(), AffLight(aff[0], aff[1]));
+	for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) H64[r * 8 + c] = H(r, c); b8[r] = b[r]; }
+}
+// trackNewestCoarse (CoarseTracker.cpp:539-770).  minRes: NaN = no abort threshold.
+// vio: 0 = the reference's own LDLT branch; 1 = setting_useIMU with a coarse-initialised IMU facade whose computeCoarseUpdate is the
+// reference's visual-only formula (damped LDLT, extrapolation, SE3::exp) evaluated in the hook, every hand-off logged.
+int ref_tracker_track(void* p, double pose7[7], double aff[2], int coarsestLvl, const double minRes[5], int vio, double lastRes[5], double flow[3], double* H64, double* b8)
+{
+	RefTracker* T = (RefTracker*)p;
+	SE3 pose = se3From7(pose7);
+	AffLight a(aff[0], aff[1]);
+	Vec5 mr; for (int i = 0; i < 5; i++) mr[i] = minRes[i];
+	const bool savedIMU = setting_useIMU;
+	T->vioLog.clear(); T->vioCalls = T->vioAccepts = T->vioVisual = 0; T->vioVisualHb.clear();
+	if (vio)
+	{
+		setting_useIMU = true;
+		T->imu.coarseInitialized = true;
+		std::shared_ptr<SE3> cur(new SE3(pose));      // the facade's copy of the current estimate (CoarseIMULogic keeps it in its graph)
+		std::shared_ptr<SE3> pending(new SE3(pose));
+		T->imu.computeCoarseUpdateHook = [T, cur, pending](const Mat88& H, const Vec8& b, float extrapFac, float lambda, double& incA, double& incB, double& incNorm) -> SE3
+		{
+			T->vioCalls++;
+			for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) T->vioLog.push_back(H(r, c));
+			for (int r = 0; r < 8; r++) T->vioLog.push_back(b[r]);
+			T->vioLog.push_back(lambda); T->vioLog.push_back(extrapFac);
+			// the visual-only step of CoarseTracker.cpp:639-682 (affineOptModeA/B >= 0 branch), so that both branches can be compared
+			Mat88 Hl = H;
+			for (int i = 0; i < 8; i++) Hl(i, i) *= (1 + lambda);
+			Vec8 inc = Hl.ldlt().solve(-b);
+			inc *= extrapFac;
+			Vec8 incScaled = inc;
+			incScaled.segment<3>(0) *= SCALE_XI_ROT;
+			incScaled.segment<3>(3) *= SCALE_XI_TRANS;
+			incScaled.segment<1>(6) *= SCALE_A;
+			incScaled.segment<1>(7) *= SCALE_B;
+			incA = inc[6]; incB = inc[7]; incNorm = inc.norm();  // unscaled: the caller applies SCALE_A / SCALE_B (CoarseTracker.cpp:633-637)
+			*pending = SE3::exp((Vec6)(incScaled.head<6>())) * (*cur);
+			return *pending;
+		};
+		T->imu.acceptCoarseUpdateHook = [T, cur, pending]() { T->vioAccepts++; *cur = *pending; };
+		T->imu.addVisualToCoarseGraphHook = [T](const Mat88& H, const Vec8& b, bool good)
+		{
+			T->vioVisual++;
+			for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) T->vioVisualHb.push_back(H(r, c));
+			for (int r = 0; r < 8; r++) T->vioVisualHb.push_back(b[r]);
+			T->vioVisualHb.push_back(good ? 1.0 : 0.0);
+		};
+	}
+	else
+	{
+		setting_useIMU = false;
+		T->imu.coarseInitialized = false;
+	}
+	bool good = T->trk->trackNewestCoarse(T->cur, pose, a, coarsestLvl, mr, 0);
+	setting_useIMU = savedIMU;
+	se3To7(pose, pose7);
+	aff[0] = a.a; aff[1] = a.b;
+	for (int i = 0; i < 5; i++) lastRes[i] = T->trk->lastResiduals[i];
+	for (int i = 0; i < 3; i++) flow[i] = T->trk->lastFlowIndicators[i];
+	if (H64)
+	{
+		// the system at the final estimate, as the caller of the VIO branch sees it last
+		Mat88 H; Vec8 b;
+		T->trk->calcGSSSE(0, H, b, pose, a);
+		for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) H64[r * 8 + c] = H(r, c); b8[r] = b[r]; }
+	}
+	return good ? 1 : 0;
+}
+int ref_tracker_vio_calls(void* p, int* accepts, int* visual) { RefTracker* T = (RefTracker*)p; *accepts = T->vioAccepts; *visual = T->vioVisual; return T->vioCalls; }
+// per call: H(64) b(8) lambda extrapFac = 74 doubles
+void ref_tracker_vio_log(void* p, double* out) { RefTracker* T = (RefTracker*)p; memcpy(out, T->vioLog.data(), sizeof(double) * T->vioLog.size()); }
+void ref_tracker_vio_visual(void* p, double* out73) { RefTracker* T = (RefTracker*)p; if (!T->vioVisualHb.empty()) memcpy(out73, T->vioVisualHb.data(), sizeof(double) * 73); }
+
+// ================================================================================================= sliding-window BA (FullSystem)
+// A FullSystem object of the reference whose window (frames, points, residuals) is filled from flat arrays in the way
+// FullSystem::makeKeyFrame / activatePointsMT fill it (FullSystem.cpp:1364-1390, 740-746); everything after that is the reference's
+// own code: linearizeAll, applyRes_Reductor, solveSystem (= EnergyFunctional::solveSystemF), optimize, marginalizePointsF, ...
+struct RefWindow
+{
+	FullSystem* fs = nullptr;
+	std::vector<PointHessian*> pts;
+	std::vector<PointFrameResidual*> res;
+	std::string log;
+	std::vector<double> trace;  // per printed optimisation line: energy A, accepted (1) / rejected (0) / initial (-1)
+	// hand-off of the GTSAM branch (EnergyFunctional.cpp:958-969): systems the reference passed to computeBAUpdate
+	std::vector<double> gtsamLog;
+	int gtsamCalls = 0;
+};
+
+void* ref_ba_create(int w, int h, const double fxfycxcy[4])
+{
+	float K4[4] = {(float)fxfycxcy[0], (float)fxfycxcy[1], (float)fxfycxcy[2], (float)fxfycxcy[3]};
+	setCalib(w, h, K4);
+	setting_useIMU = false; setting_useGTSAMIntegration = false;
+	setting_logStuff = false;
+	multiThreading = false;
+	setting_debugout_runquiet = true;
+	RefWindow* W = new RefWindow();
+	W->fs = new FullSystem(true, g_imuCalib, g_imuSettings);
+	W->fs->coarseTrackingLog = 0;
+	return W;
+}
+void ref_ba_destroy(void* p)
+{
+	RefWindow* W = (RefWindow*)p;
+	FullSystem* fs = W->fs;
+	// FullSystem::~FullSystem leaves the window's frames to its owner (the reference never tears a live window down).  ~EnergyFunctional
+	// (inside ~FullSystem) clears the efFrame / efPoint / efResidual back-pointers, so it has to run before the frames go.
+	std::vector<FrameHessian*> frames = fs->frameHessians;
+	fs->frameHessians.clear();
+	delete fs;  // also deletes the shells (allFrameHistory)
+	for (FrameHessian* fh : frames)
+	{
+		for (PointHessian* ph : fh->pointHessians) { ph->efPoint = 0; delete ph; }
+		for (PointHessian* ph : fh->pointHessiansMarginalized) { ph->efPoint = 0; delete ph; }
+		for (PointHessian* ph : fh->pointHessiansOut) { ph->efPoint = 0; delete ph; }
+		for (ImmaturePoint* ip : fh->immaturePoints) delete ip;
+		fh->pointHessians.clear(); fh->pointHessiansMarginalized.clear(); fh->pointHessiansOut.clear(); fh->immaturePoints.clear();
+		fh->efFrame = 0;
+		delete fh;
+	}
+	delete W;
+}
+// as makeKeyFrame inserts a frame (FullSystem.cpp:1364-1371); pose7 = worldToCam, aff in scaled units, img = raw irradiance image
+int ref_ba_add_frame(void* p, const double pose7_w2c[7], double aff_a, double aff_b, float exposure, int frameID, const float* img)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	FrameHessian* fh = newFrame(img, exposure, &fs->Hcalib, (int)fs->allFrameHistory.size());
+	SE3 w2c = se3From7(pose7_w2c);
+	fh->shell->camToWorld = w2c.inverse();
+	fh->shell->aff_g2l = AffLight(aff_a, aff_b);
+	fh->setEvalPT_scaled(w2c, fh->shell->aff_g2l);
+	fs->allFrameHistory.push_back(fh->shell);
+	fh->idx = fs->frameHessians.size();
+	fs->frameHessians.push_back(fh);
+	fh->frameID = frameID;
+	fh->shell->keyframeId = fh->frameID;
+	fs->allKeyFramesHistory.push_back(fh->shell);
+	fs->ef->insertFrame(fh, &fs->Hcalib);
+	fs->setPrecalcValues();
+	return fh->idx;
+}
+void ref_ba_perturb_frame(void* p, int fidx, const double d8[8])
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; FrameHessian* fh = fs->frameHessians[fidx];
+	Vec10 st = fh->get_state();
+	for (int i = 0; i < 6; i++) st[i] += d8[i];
+	st[6] += d8[6] * SCALE_A_INVERSE; st[7] += d8[7] * SCALE_B_INVERSE;
+	fh->setState(st);
+}
+void ref_ba_set_frame_state(void* p, int fidx, const double state10[10])
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	Vec10 st; for (int i = 0; i < 10; i++) st[i] = state10[i];
+	fs->frameHessians[fidx]->setState(st);
+	fs->setPrecalcValues();
+}
+// a point as activatePointsMT leaves it (PointHessian from an ImmaturePoint at (u,v), status ACTIVE, inserted into the energy
+// functional).  color_out / weights_out receive what the reference's ImmaturePoint constructor sampled (ImmaturePoint.cpp:34-62);
+// color / weights (may be NULL) then override them so that a test can feed the very same floats to every implementation.
+int ref_ba_add_point(void* p, int host, float u, float v, float idepth, const float* color, const float* weights, int hasDepthPrior, float* color_out, float* weights_out)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	FrameHessian* fh = fs->frameHessians[host];
+	ImmaturePoint* ip = new ImmaturePoint((int)u, (int)v, fh, 1, &fs->Hcalib);
+	ip->idepth_min = ip->idepth_max = idepth;
+	PointHessian* ph = new PointHessian(ip, &fs->Hcalib);
+	if (color_out) memcpy(color_out, ph->color, sizeof(float) * patternNum);
+	if (weights_out) memcpy(weights_out, ph->weights, sizeof(float) * patternNum);
+	delete ip;
+	ph->u = u; ph->v = v;
+	if (color) memcpy(ph->color, color, sizeof(float) * patternNum);
+	if (weights) memcpy(ph->weights, weights, sizeof(float) * patternNum);
+	ph->setIdepth(idepth);
+	ph->setIdepthZero(idepth);
+	ph->hasDepthPrior = hasDepthPrior != 0;
+	ph->setPointStatus(PointHessian::ACTIVE);
+	ph->lastResiduals[0].first = 0; ph->lastResiduals[0].second = ResState::OOB;
+	ph->lastResiduals[1].first = 0; ph->lastResiduals[1].second = ResState::OOB;
+	fh->pointHessians.push_back(ph);
+	fs->ef->insertPoint(ph);
+	W->pts.push_back(ph);
+	return (int)W->pts.size() - 1;
+}
+int ref_ba_add_residual(void* p, int point, int target)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	PointHessian* ph = W->pts[point];
+	PointFrameResidual* r = new PointFrameResidual(ph, ph->host, fs->frameHessians[target]);
+	r->setState(ResState::IN);
+	ph->residuals.push_back(r);
+	fs->ef->insertResidual(r);
+	ph->lastResiduals[1] = ph->lastResiduals[0];
+	ph->lastResiduals[0] = std::pair<PointFrameResidual*, ResState>(r, ResState::IN);
+	W->res.push_back(r);
+	return (int)W->res.size() - 1;
+}
+void ref_ba_finalize(void* p)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	fs->ef->makeIDX();
+	fs->ef->setAdjointsF(&fs->Hcalib);
+	fs->setPrecalcValues();
+}
+int ref_ba_nframes(void* p) { return (int)((RefWindow*)p)->fs->frameHessians.size(); }
+void ref_ba_set_marg_prior(void* p, const double* HM, const double* bM)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; const int n = CPARS + 8 * (int)fs->frameHessians.size();
+	for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) fs->ef->HM(r, c) = HM[r * n + c]; fs->ef->bM[r] = bM[r]; }
+}
+// the residual list optimize() collects (FullSystemOptimize.cpp:431-448)
+void ref_ba_activate_all(void* p)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	fs->activeResiduals.clear();
+	for (FrameHessian* fh : fs->frameHessians)
+		for (PointHessian* ph : fh->pointHessians)
+			for (PointFrameResidual* r : ph->residuals)
+				if (!r->efResidual->isLinearized) { fs->activeResiduals.push_back(r); r->resetOOB(); }
+}
+double ref_ba_linearize_all(void* p, int fix) { Vec3 e = ((RefWindow*)p)->fs->linearizeAll(fix != 0); return e[0]; }
+void ref_ba_apply_res(void* p) { FullSystem* fs = ((RefWindow*)p)->fs; fs->applyRes_Reductor(true, 0, fs->activeResiduals.size(), 0, 0); }
+void ref_ba_get_res_state(void* p, int* newState, double* newEnergy, double* newEnergyWO, int* isActive, float* center3)
+{
+	RefWindow* W = (RefWindow*)p;
+	for (size_t i = 0; i < W->res.size(); i++)
+	{
+		PointFrameResidual* r = W->res[i];
+		newState[i] = (int)r->state_NewState; newEnergy[i] = r->state_NewEnergy; newEnergyWO[i] = r->state_NewEnergyWithOutlier;
+		isActive[i] = r->efResidual->isActive() ? 1 : 0;
+		for (int k = 0; k < 3; k++) center3[3 * i + k] = r->centerProjectedTo[k];
+	}
+}
+// 74 floats: resF8, Jpdxi 2x6, Jpdc 2x4, Jpdd 2, JIdx 2x8, JabF 2x8, JIdx2 4, JabJIdx 4, Jab2 4 (row-major 2x2); which: 0 = r->J, 1 = efResidual->J
+void ref_ba_get_J(void* p, int i, int which, float* out74, float* JpJdF8)
+{
+	RefWindow* W = (RefWindow*)p;
+	PointFrameResidual* r = W->res[i];
+	const RawResidualJacobian* J = which ? r->efResidual->J : r->J;
+	int o = 0;
+	for (int k = 0; k < 8; k++) out74[o++] = J->resF[k];
+	for (int a = 0; a < 2; a++) for (int k = 0; k < 6; k++) out74[o++] = J->Jpdxi[a][k];
+	for (int a = 0; a < 2; a++) for (int k = 0; k < 4; k++) out74[o++] = J->Jpdc[a][k];
+	for (int a = 0; a < 2; a++) out74[o++] = J->Jpdd[a];
+	for (int a = 0; a < 2; a++) for (int k = 0; k < 8; k++) out74[o++] = J->JIdx[a][k];
+	for (int a = 0; a < 2; a++) for (int k = 0; k < 8; k++) out74[o++] = J->JabF[a][k];
+	for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) out74[o++] = J->JIdx2(a, b);
+	for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) out74[o++] = J->JabJIdx(a, b);
+	for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) out74[o++] = J->Jab2(a, b);
+	for (int k = 0; k < 8; k++) JpJdF8[k] = r->efResidual->JpJdF[k];
+}
+void ref_ba_get_res_to_zero(void* p, int i, float* out8, int* isLinearized)
+{
+	RefWindow* W = (RefWindow*)p;
+	for (int k = 0; k < 8; k++) out8[k] = W->res[i]->efResidual->res_toZeroF[k];
+	*isLinearized = W->res[i]->efResidual->isLinearized ? 1 : 0;
+}
+void ref_ba_get_frame_energy_th(void* p, float* out) { FullSystem* fs = ((RefWindow*)p)->fs; for (size_t i = 0; i < fs->frameHessians.size(); i++) out[i] = fs->frameHessians[i]->frameEnergyTH; }
+// 37 floats: KRKi(9) Kt(3) R0(9) t0(3) aff(2) b0 R(9)
+void ref_ba_get_precalc(void* p, int host, int target, float* out37)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	const FrameFramePrecalc& q = fs->frameHessians[host]->targetPrecalc[target];
+	int o = 0;
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out37[o++] = q.PRE_KRKiTll(r, c);
+	for (int r = 0; r < 3; r++) out37[o++] = q.PRE_KtTll[r];
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out37[o++] = q.PRE_RTll_0(r, c);
+	for (int r = 0; r < 3; r++) out37[o++] = q.PRE_tTll_0[r];
+	out37[o++] = q.PRE_aff_mode[0]; out37[o++] = q.PRE_aff_mode[1]; out37[o++] = q.PRE_b0_mode;
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out37[o++] = q.PRE_RTll(r, c);
+}
+void ref_ba_get_adjoints(void* p, double* adHost, double* adTarget, float* adHTdeltaF)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; EnergyFunctional* ef = fs->ef; const int n = ef->nFrames * ef->nFrames;
+	for (int i = 0; i < n; i++)
+	{
+		for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { adHost[i * 64 + r * 8 + c] = ef->adHost[i](r, c); adTarget[i * 64 + r * 8 + c] = ef->adTarget[i](r, c); }
+		for (int c = 0; c < 8; c++) adHTdeltaF[i * 8 + c] = ef->adHTdeltaF[i](0, c);
+	}
+}
+static void copyOut(const MatXX& H, const VecX& b, double* Ho, double* bo)
+{
+	const int n = (int)b.size();
+	for (int r = 0; r < n; r++) { for (int c = 0; c < n; c++) Ho[r * n + c] = H(r, c); bo[r] = b[r]; }
+}
+void ref_ba_accumulate(void* p, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc, int* resInA)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; EnergyFunctional* ef = fs->ef;
+	MatXX H1, H2, H3; VecX b1, b2, b3;
+	ef->accumulateAF_MT(H1, b1, multiThreading);
+	ef->accumulateLF_MT(H2, b2, multiThreading);
+	ef->accumulateSCF_MT(H3, b3, multiThreading);
+	copyOut(H1, b1, HA, bA); copyOut(H2, b2, HL, bL); copyOut(H3, b3, Hsc, bsc);
+	if (resInA) *resInA = ef->resInA;
+}
+void ref_ba_get_point_acc(void* p, float* Hdd, float* bd, float* Hcd4, float* HdiF, float* bdSumF)
+{
+	RefWindow* W = (RefWindow*)p;
+	for (size_t i = 0; i < W->pts.size(); i++)
+	{
+		const EFPoint* q = W->pts[i]->efPoint;
+		Hdd[i] = q->Hdd_accAF; bd[i] = q->bd_accAF; for (int k = 0; k < 4; k++) Hcd4[4 * i + k] = q->Hcd_accAF[k]; HdiF[i] = q->HdiF; bdSumF[i] = q->bdSumF;
+	}
+}
+// FullSystem::solveSystem (FullSystemOptimize.cpp:653-662) = getNullspaces + EnergyFunctional::solveSystemF
+void ref_ba_solve(void* p, int iteration, double lambda, double* x_out)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	fs->solveSystem(iteration, lambda);
+	for (int i = 0; i < (int)fs->ef->lastX.size(); i++) x_out[i] = fs->ef->lastX[i];
+}
+void ref_ba_get_last_system(void* p, double* HS, double* bS) { FullSystem* fs = ((RefWindow*)p)->fs; copyOut(fs->ef->lastHS, fs->ef->lastbS, HS, bS); }
+void ref_ba_resubstitute(void* p, const double* x)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; const int n = CPARS + 8 * (int)fs->frameHessians.size();
+	VecX xv(n); for (int i = 0; i < n; i++) xv[i] = x[i];
+	fs->ef->resubstituteF_MT(xv, &fs->Hcalib, multiThreading);
+}
+void ref_ba_get_point_state(void* p, float* idepth, float* step)
+{
+	RefWindow* W = (RefWindow*)p;
+	for (size_t i = 0; i < W->pts.size(); i++) { idepth[i] = W->pts[i]->idepth; step[i] = W->pts[i]->step; }
+}
+void ref_ba_get_frame_pose(void* p, int fidx, double pose7_w2c[7], double aff[2], double state10[10])
+{
+	FrameHessian* fh = ((RefWindow*)p)->fs->frameHessians[fidx];
+	se3To7(fh->PRE_worldToCam, pose7_w2c);
+	aff[0] = fh->get_state_scaled()[6]; aff[1] = fh->get_state_scaled()[7];
+	if (state10) for (int i = 0; i < 10; i++) state10[i] = fh->get_state()[i];
+}
+void ref_ba_get_frame_step(void* p, int fidx, double step10[10]) { FrameHessian* fh = ((RefWindow*)p)->fs->frameHessians[fidx]; for (int i = 0; i < 10; i++) step10[i] = fh->step[i]; }
+void ref_ba_get_calib(void* p, double value_scaled[4]) { FullSystem* fs = ((RefWindow*)p)->fs; for (int i = 0; i < 4; i++) value_scaled[i] = fs->Hcalib.value_scaled[i]; }
+void ref_ba_get_nullspaces(void* p, double* out /* 7 x n */)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; const int n = CPARS + 8 * (int)fs->frameHessians.size();
+	std::vector<VecX> np_, ns, na, nb;
+	fs->getNullspaces(np_, ns, na, nb);
+	for (int i = 0; i < 6; i++) for (int k = 0; k < n; k++) out[i * n + k] = np_[i][k];
+	for (int k = 0; k < n; k++) out[6 * n + k] = ns[0][k];
+}
+void ref_ba_orthogonalize(void* p, double* x)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; const int n = CPARS + 8 * (int)fs->frameHessians.size();
+	fs->getNullspaces(fs->ef->lastNullspaces_pose, fs->ef->lastNullspaces_scale, fs->ef->lastNullspaces_affA, fs->ef->lastNullspaces_affB);
+	VecX xv(n); for (int i = 0; i < n; i++) xv[i] = x[i];
+	fs->ef->orthogonalize(&xv, 0);
+	for (int i = 0; i < n; i++) x[i] = xv[i];
+}
+double ref_ba_calc_lenergy(void* p) { return ((RefWindow*)p)->fs->calcLEnergy(); }
+double ref_ba_calc_menergy(void* p) { return ((RefWindow*)p)->fs->calcMEnergy(false); }
+void ref_ba_backup_state(void* p, int backupLastStep) { ((RefWindow*)p)->fs->backupState(backupLastStep != 0); }
+void ref_ba_load_state_backup(void* p) { ((RefWindow*)p)->fs->loadSateBackup(); }
+int ref_ba_do_step_from_backup(void* p, float c, float t, float r, float a, float d) { return ((RefWindow*)p)->fs->doStepFromBackup(c, t, r, a, d) ? 1 : 0; }
+// FullSystem::optimize, verbatim.  The accept / reject decisions and the energies per iteration are only printed
+// (FullSystemOptimize.cpp:403-414, 541-551): they are parsed out of the captured stdout into `trace` rows [energyA, verdict].
+float ref_ba_optimize(void* p, int mnumOptIts, int* n_trace, double* trace /* up to 64 x 2 */)
+{
+	RefWindow* W = (RefWindow*)p;
+	const bool q = setting_debugout_runquiet;
+	setting_debugout_runquiet = false;
+	StdoutCapture cap;
+	float rmse = W->fs->optimize(mnumOptIts);
+	W->log = cap.finish();
+	setting_debugout_runquiet = q;
+	W->trace.clear();
+	std::istringstream in(W->log);
+	std::string line;
+	while (std::getline(in, line))
+	{
+		size_t a = line.find("A(");
+		if (a == std::string::npos) continue;
+		double e = atof(line.c_str() + a + 2);
+		double verdict = -1;
+		if (line.find("ACCEPT") != std::string::npos) verdict = 1;
+		else if (line.find("REJECT") != std::string::npos) verdict = 0;
+		W->trace.push_back(e); W->trace.push_back(verdict);
+	}
+	int n = (int)W->trace.size() / 2; if (n > 64) n = 64;
+	if (n_trace) *n_trace = n;
+	if (trace) memcpy(trace, W->trace.data(), sizeof(double) * 2 * n);
+	return rmse;
+}
+int ref_ba_log(void* p, char* out, int cap) { RefWindow* W = (RefWindow*)p; int n = std::min((int)W->log.size(), cap - 1); memcpy(out, W->log.data(), n); out[n] = 0; return n; }
+// flagPointsForRemoval + marginalizePointsF as makeKeyFrame runs them (FullSystem.cpp:1485-1492), with `flagged[k]` frames flagged
+// for marginalisation.  decision per point: 0 = kept, 1 = marginalised, 2 = dropped.  Hadd / badd = what marginalizePointsF added to HM / bM
+int ref_ba_marginalize_points(void* p, const unsigned char* flaggedFrames, unsigned char* decision, double* Hadd, double* badd)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs; EnergyFunctional* ef = fs->ef;
+	const int n = CPARS + 8 * (int)fs->frameHessians.size();
+	for (size_t k = 0; k < fs->frameHessians.size(); k++) fs->frameHessians[k]->flaggedForMarginalization = flaggedFrames[k] != 0;
+	MatXX HM0 = ef->HM; VecX bM0 = ef->bM;
+	std::map<PointHessian*, int> index;
+	for (size_t i = 0; i < W->pts.size(); i++) index[W->pts[i]] = (int)i;
+	for (size_t i = 0; i < W->pts.size(); i++) decision[i] = 0;
+	fs->flagPointsForRemoval();
+	for (FrameHessian* fh : fs->frameHessians)
+	{
+		for (PointHessian* ph : fh->pointHessiansMarginalized) if (index.count(ph)) decision[index[ph]] = 1;
+		for (PointHessian* ph : fh->pointHessiansOut) if (index.count(ph)) decision[index[ph]] = 2;
+	}
+	const int resInMBefore = ef->resInM;
+	ef->dropPointsF();
+	fs->getNullspaces(ef->lastNullspaces_pose, ef->lastNullspaces_scale, ef->lastNullspaces_affA, ef->lastNullspaces_affB);
+	ef->marginalizePointsF();
+	MatXX dH = ef->HM - HM0; VecX db = ef->bM - bM0;
+	copyOut(dH, db, Hadd, badd);
+	(void)n;
+	// the removed points are gone from the reference's structures: forget them here too
+	for (size_t i = 0; i < W->pts.size(); i++) if (decision[i]) W->pts[i] = nullptr;
+	return ef->resInM - resInMBefore;
+}
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:522-673) of frame idx (which must not host points any more): new HM / bM
+void ref_ba_marginalize_frame(void* p, int idx, double* HMn, double* bMn)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	FrameHessian* fh = fs->frameHessians[idx];
+	fs->ef->marginalizeFrame(fh->efFrame);
+	copyOut(fs->ef->HM, fs->ef->bM, HMn, bMn);
+}
+
+}  // extern "C"

@@ -1,0 +1,427 @@
+"""ctypes binding of oracle/_ref/libref.so — the REFERENCE'S OWN SOURCES compiled unmodified (oracle/Makefile.ref) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The library is built in this container
+(where /root/reference exists) and travels to the GPU box as a prebuilt file; it is never built or needed by the product path.
+The classes mirror oracle_py's (Tracker, BAWindow, ...) so that a test can run one case through the reference, the restatement and
+the HIP library.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+REFERENCE_ROOT = "/root/reference"
+
+c_f = C.POINTER(C.c_float)
+c_d = C.POINTER(C.c_double)
+c_i = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+def so_path():
+    return os.path.join(_HERE, "_ref", "libref.so")
+
+
+def available():
+    """True when the library exists or can be built here (the reference sources are present)."""
+    return os.path.exists(so_path()) or os.path.isdir(os.path.join(REFERENCE_ROOT, "src"))
+
+
+def build(force=False):
+    so = so_path()
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "src")):
+        # make decides what is stale (shim headers, glue, reference sources)
+        subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref", "-s", "-j8"] + (["-B"] if force else []))
+    if not os.path.exists(so):
+        raise RuntimeError("oracle/_ref/libref.so is missing and %s is not present to build it from" % REFERENCE_ROOT)
+    return so
+
+
+def _f(a):
+    return a.ctypes.data_as(c_f)
+
+
+def _d(a):
+    return a.ctypes.data_as(c_d)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.ref_pyr_levels.argtypes = [C.c_int, C.c_int, c_f]
+        L.ref_get_global_calib.argtypes = [C.c_int, c_f, c_f, c_i]
+        L.ref_set_affine_opt_mode.argtypes = [C.c_double, C.c_double]
+        L.ref_interp33.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, c_f]
+        L.ref_interp31.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, c_f]
+        L.ref_interp33_bilin.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, c_f]
+        L.ref_project_point_short.argtypes = [C.c_float, C.c_float, C.c_float, c_f, c_f, c_f]
+        L.ref_project_point_long.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, c_f, c_f, c_f, c_f]
+        L.ref_aff_from_to.argtypes = [C.c_float, C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, c_d]
+        L.ref_acc9_stream.argtypes = [C.c_int, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, C.POINTER(C.c_long)]
+        L.ref_accapprox_stream.argtypes = [C.c_int, c_f, C.c_int, c_f, C.POINTER(C.c_long)]
+        L.ref_accxx_stream.argtypes = [C.c_int, c_f, C.c_int, c_f, c_f, c_f, C.POINTER(C.c_long)]
+        L.ref_make_images.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, C.POINTER(c_f), C.POINTER(c_f)]
+        L.ref_tracker_create.restype = vp
+        L.ref_tracker_create.argtypes = [C.c_int, C.c_int, c_f]
+        L.ref_tracker_destroy.argtypes = [vp]
+        L.ref_tracker_levels.argtypes = [vp]
+        L.ref_tracker_get_k.argtypes = [vp, C.c_int, c_f, c_f]
+        L.ref_tracker_set_ref.argtypes = [vp, c_f, C.c_float, C.c_double, C.c_double, C.c_int, c_f, c_f, c_f, c_f]
+        L.ref_tracker_set_new.argtypes = [vp, c_f, C.c_float]
+        L.ref_tracker_get_dIp.argtypes = [vp, C.c_int, C.c_int, c_f]
+        L.ref_tracker_pc_n.argtypes = [vp, C.c_int]
+        L.ref_tracker_get_pc.argtypes = [vp, C.c_int, c_f, c_f, c_f, c_f]
+        L.ref_tracker_get_idepth.argtypes = [vp, C.c_int, c_f, c_f]
+        L.ref_tracker_calc_res.argtypes = [vp, C.c_int, c_d, c_d, C.c_float, c_d]
+        L.ref_tracker_warped_n.argtypes = [vp]
+        L.ref_tracker_get_warped.argtypes = [vp, c_f]
+        L.ref_tracker_calc_gs.argtypes = [vp, C.c_int, c_d, c_d, c_d]
+        L.ref_tracker_track.argtypes = [vp, c_d, c_d, C.c_int, c_d, C.c_int, c_d, c_d, c_d, c_d]
+        L.ref_tracker_vio_calls.argtypes = [vp, c_i, c_i]
+        L.ref_tracker_vio_log.argtypes = [vp, c_d]
+        L.ref_tracker_vio_visual.argtypes = [vp, c_d]
+    return _LIB
+
+
+# ------------------------------------------------------------------------------------------------------------ primitives
+def pyr_levels(w, h, K4=(100.0, 100.0, 50.0, 50.0)):
+    return lib().ref_pyr_levels(w, h, _f(_f32(K4)))
+
+
+def global_calib(lvl):
+    k = np.zeros(4, np.float32); ki = np.zeros(9, np.float32); wh = np.zeros(2, np.int32)
+    lib().ref_get_global_calib(lvl, _f(k), _f(ki), wh.ctypes.data_as(c_i)); return k, ki.reshape(3, 3), wh
+
+
+def interp33(img3, x, y, kind="33"):
+    img3 = _f32(img3); width = img3.shape[1]
+    x = _f32(x); y = _f32(y)
+    if kind == "31":
+        out = np.zeros(len(x), np.float32); lib().ref_interp31(_f(img3), width, len(x), _f(x), _f(y), _f(out)); return out
+    out = np.zeros((len(x), 3), np.float32)
+    (lib().ref_interp33 if kind == "33" else lib().ref_interp33_bilin)(_f(img3), width, len(x), _f(x), _f(y), _f(out))
+    return out
+
+
+def project_point_short(u, v, idepth, KRKi, Kt):
+    out = np.zeros(2, np.float32)
+    ok = lib().ref_project_point_short(u, v, idepth, _f(_f32(KRKi).reshape(-1)), _f(_f32(Kt)), _f(out))
+    return bool(ok), out
+
+
+def project_point_long(u, v, idepth, dx, dy, K4, R, t):
+    out = np.zeros(9, np.float32)
+    ok = lib().ref_project_point_long(u, v, idepth, dx, dy, _f(_f32(K4)), _f(_f32(R).reshape(-1)), _f(_f32(t)), _f(out))
+    return bool(ok), out
+
+
+def aff_from_to(eF, eT, aF, bF, aT, bT):
+    out = np.zeros(2); lib().ref_aff_from_to(eF, eT, aF, bF, aT, bT, _d(out)); return out
+
+
+def acc9_stream(J, w, Js=None, ws=None, reps=1, _fn=None):
+    """Accumulator9: `reps` times J [4k, 9] through updateSSE_eighted, then Js [m, 9] through updateSingleWeighted -> (H 9x9, num)."""
+    J = _f32(J); w = _f32(w); n4 = len(w) // 4
+    Js = np.zeros((0, 9), np.float32) if Js is None else _f32(Js); ws = np.zeros(0, np.float32) if ws is None else _f32(ws)
+    H = np.zeros((9, 9), np.float32); num = C.c_long(0)
+    (_fn or lib().ref_acc9_stream)(n4, _f(J), _f(w), len(ws), _f(Js), _f(ws), reps, _f(H), C.byref(num))
+    return H, num.value
+
+
+def accapprox_stream(rec35, reps=1, _fn=None):
+    rec = _f32(rec35); H = np.zeros((13, 13), np.float32); num = C.c_long(0)
+    (_fn or lib().ref_accapprox_stream)(len(rec), _f(rec), reps, _f(H), C.byref(num)); return H, num.value
+
+
+def accxx_stream(rec21, reps=1, _fn=None):
+    rec = _f32(rec21); a88 = np.zeros((8, 8), np.float32); a84 = np.zeros((8, 4), np.float32); a8 = np.zeros(8, np.float32); num = C.c_long(0)
+    (_fn or lib().ref_accxx_stream)(len(rec), _f(rec), reps, _f(a88), _f(a84), _f(a8), C.byref(num)); return a88, a84, a8, num.value
+
+
+def make_images(color, w, h, K4=(100.0, 100.0, 50.0, 50.0), B=None):
+    """FrameHessian::makeImages of the reference -> (dIp levels [h_l, w_l, 3], absSquaredGrad levels [h_l, w_l])."""
+    L = lib()
+    levels = pyr_levels(w, h, K4)
+    color = _f32(color).reshape(-1)
+    dI = [np.zeros(((h >> l), (w >> l), 3), np.float32) for l in range(levels)]
+    ab = [np.zeros(((h >> l), (w >> l)), np.float32) for l in range(levels)]
+    dp = (c_f * levels)(*[_f(a) for a in dI]); ap = (c_f * levels)(*[_f(a) for a in ab])
+    Bp = None if B is None else _f(_f32(B))
+    L.ref_make_images(_f(color), w, h, _f(_f32(K4)), Bp, dp, ap)
+    return dI, ab
+
+
+# ------------------------------------------------------------------------------------------------------------ CoarseTracker
+class Tracker:
+    """The reference's CoarseTracker (CoarseTracker.h:46-129).  Same surface as oracle_py.Tracker except that frames are given as
+    raw images (the reference builds its own pyramids with FrameHessian::makeImages)."""
+
+    def __init__(self, w, h, K4):
+        self.L = lib(); self.w, self.h = w, h
+        self.K4 = _f32(K4)
+        self.p = vp(self.L.ref_tracker_create(w, h, _f(self.K4)))
+        self.levels = self.L.ref_tracker_levels(self.p)
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.ref_tracker_destroy(self.p); self.p = None
+
+    def get_k(self, lvl):
+        k = np.zeros(4, np.float32); ki = np.zeros(9, np.float32)
+        self.L.ref_tracker_get_k(self.p, lvl, _f(k), _f(ki)); return k, ki.reshape(3, 3)
+
+    def set_ref(self, img, u, v, idepth, hdiF, exposure=1.0, aff=(0.0, 0.0)):
+        u, v, idepth, hdiF = _f32(u), _f32(v), _f32(idepth), _f32(hdiF)
+        self.L.ref_tracker_set_ref(self.p, _f(_f32(img).reshape(-1)), exposure, aff[0], aff[1], len(u), _f(u), _f(v), _f(idepth), _f(hdiF))
+
+    def set_new(self, img, exposure=1.0):
+        self.L.ref_tracker_set_new(self.p, _f(_f32(img).reshape(-1)), exposure)
+
+    def dIp(self, which, lvl):
+        o = np.zeros(((self.h >> lvl), (self.w >> lvl), 3), np.float32); self.L.ref_tracker_get_dIp(self.p, which, lvl, _f(o)); return o
+
+    def pc_n(self, lvl):
+        return self.L.ref_tracker_pc_n(self.p, lvl)
+
+    def get_pc(self, lvl):
+        n = self.pc_n(lvl); out = [np.zeros(n, np.float32) for _ in range(4)]
+        self.L.ref_tracker_get_pc(self.p, lvl, *[_f(a) for a in out]); return out
+
+    def get_idepth(self, lvl):
+        n = (self.w >> lvl) * (self.h >> lvl); a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        self.L.ref_tracker_get_idepth(self.p, lvl, _f(a), _f(b)); return a, b
+
+    def calc_res(self, lvl, pose7, aff, cutoff=20.0):
+        rs = np.zeros(6); self.L.ref_tracker_calc_res(self.p, lvl, _d(_f64(pose7)), _d(_f64(aff)), cutoff, _d(rs)); return rs
+
+    def get_warped(self):
+        n = self.L.ref_tracker_warped_n(self.p); out = np.zeros((8, n), np.float32)
+        self.L.ref_tracker_get_warped(self.p, _f(out)); return out
+
+    def calc_gs(self, lvl, aff):
+        H = np.zeros(64); b = np.zeros(8); self.L.ref_tracker_calc_gs(self.p, lvl, _d(_f64(aff)), _d(H), _d(b)); return H.reshape(8, 8), b
+
+    def track(self, pose7, aff, coarsest=None, min_res=None, modeA=1e12, modeB=1e8, vio=False):
+        pose = np.array(pose7, dtype=np.float64); a = np.array(aff, dtype=np.float64)
+        if coarsest is None:
+            coarsest = self.levels - 1
+        mr = np.full(5, np.nan) if min_res is None else np.array(min_res, dtype=np.float64)
+        lr = np.zeros(5); fl = np.zeros(3); H = np.zeros(64); b = np.zeros(8)
+        self.L.ref_set_affine_opt_mode(modeA, modeB)
+        good = self.L.ref_tracker_track(self.p, _d(pose), _d(a), coarsest, _d(mr), 1 if vio else 0, _d(lr), _d(fl), _d(H), _d(b))
+        r = dict(good=bool(good), pose7=pose, aff=a, lastResiduals=lr, flow=fl, H=H.reshape(8, 8), b=b)
+        if vio:
+            acc = C.c_int(0); vis = C.c_int(0)
+            n = self.L.ref_tracker_vio_calls(self.p, C.byref(acc), C.byref(vis))
+            log = np.zeros((n, 74)); self.L.ref_tracker_vio_log(self.p, _d(log))
+            r.update(vio_calls=n, vio_accepts=acc.value, vio_visual=vis.value, vio_log=log)
+            if vis.value:
+                vv = np.zeros(73); self.L.ref_tracker_vio_visual(self.p, _d(vv)); r["vio_visual_Hb"] = vv
+        return r
+
+
+# ------------------------------------------------------------------------------------------------------------ sliding-window BA
+_BA_SIG = False
+
+
+def _ba_sig(L):
+    global _BA_SIG
+    if _BA_SIG:
+        return
+    c_u8 = C.POINTER(C.c_ubyte)
+    L.ref_ba_create.restype = vp; L.ref_ba_create.argtypes = [C.c_int, C.c_int, c_d]
+    L.ref_ba_destroy.argtypes = [vp]
+    L.ref_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
+    L.ref_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
+    L.ref_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.ref_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int, c_f, c_f]
+    L.ref_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
+    L.ref_ba_finalize.argtypes = [vp]
+    L.ref_ba_set_marg_prior.argtypes = [vp, c_d, c_d]
+    L.ref_ba_activate_all.argtypes = [vp]
+    L.ref_ba_linearize_all.restype = C.c_double; L.ref_ba_linearize_all.argtypes = [vp, C.c_int]
+    L.ref_ba_apply_res.argtypes = [vp]
+    L.ref_ba_get_res_state.argtypes = [vp, c_i, c_d, c_d, c_i, c_f]
+    L.ref_ba_get_J.argtypes = [vp, C.c_int, C.c_int, c_f, c_f]
+    L.ref_ba_get_res_to_zero.argtypes = [vp, C.c_int, c_f, c_i]
+    L.ref_ba_get_frame_energy_th.argtypes = [vp, c_f]
+    L.ref_ba_get_precalc.argtypes = [vp, C.c_int, C.c_int, c_f]
+    L.ref_ba_get_adjoints.argtypes = [vp, c_d, c_d, c_f]
+    L.ref_ba_accumulate.argtypes = [vp, c_d, c_d, c_d, c_d, c_d, c_d, c_i]
+    L.ref_ba_get_point_acc.argtypes = [vp, c_f, c_f, c_f, c_f, c_f]
+    L.ref_ba_solve.argtypes = [vp, C.c_int, C.c_double, c_d]
+    L.ref_ba_get_last_system.argtypes = [vp, c_d, c_d]
+    L.ref_ba_resubstitute.argtypes = [vp, c_d]
+    L.ref_ba_get_point_state.argtypes = [vp, c_f, c_f]
+    L.ref_ba_get_frame_pose.argtypes = [vp, C.c_int, c_d, c_d, c_d]
+    L.ref_ba_get_frame_step.argtypes = [vp, C.c_int, c_d]
+    L.ref_ba_get_calib.argtypes = [vp, c_d]
+    L.ref_ba_get_nullspaces.argtypes = [vp, c_d]
+    L.ref_ba_orthogonalize.argtypes = [vp, c_d]
+    L.ref_ba_calc_lenergy.restype = C.c_double; L.ref_ba_calc_lenergy.argtypes = [vp]
+    L.ref_ba_calc_menergy.restype = C.c_double; L.ref_ba_calc_menergy.argtypes = [vp]
+    L.ref_ba_backup_state.argtypes = [vp, C.c_int]
+    L.ref_ba_load_state_backup.argtypes = [vp]
+    L.ref_ba_do_step_from_backup.argtypes = [vp] + [C.c_float] * 5
+    L.ref_ba_optimize.restype = C.c_float; L.ref_ba_optimize.argtypes = [vp, C.c_int, c_i, c_d]
+    L.ref_ba_log.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ref_ba_marginalize_points.argtypes = [vp, c_u8, c_u8, c_d, c_d]
+    L.ref_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
+    _BA_SIG = True
+
+
+class BAWindow:
+    """The reference's FullSystem with a window filled from a synth.ba_case (same constructor arguments as oracle_py.BAWindow)."""
+
+    def __init__(self, case, poses=None, idepth=None, use_case_color=True):
+        self.L = lib(); _ba_sig(self.L)
+        self.case = case
+        K4 = _f64(case["K4"])
+        self.p = vp(self.L.ref_ba_create(case["w"], case["h"], _d(K4)))
+        poses = case["poses0"] if poses is None else poses
+        idepth = case["idepth0"] if idepth is None else idepth
+        F = case["n_frames"]
+        aff = np.zeros((F, 2)) if case.get("aff") is None else np.asarray(case["aff"], dtype=np.float64)
+        expo = np.ones(F) if case.get("exposure") is None else np.asarray(case["exposure"], dtype=np.float64)
+        fids = np.arange(F) if case.get("frameIDs") is None else np.asarray(case["frameIDs"])
+        for k in range(F):
+            img = _f32(case["imgs"][k]).reshape(-1)
+            self.L.ref_ba_add_frame(self.p, _d(_f64(poses[k])), float(aff[k, 0]), float(aff[k, 1]), float(expo[k]), int(fids[k]), _f(img))
+        col = _f32(case["color"]); wts = _f32(case["weights"])
+        N = len(case["u"])
+        hdp = np.zeros(N, np.uint8) if case.get("hasDepthPrior") is None else np.asarray(case["hasDepthPrior"], dtype=np.uint8)
+        self.sampled_color = np.zeros((N, 8), np.float32); self.sampled_weights = np.zeros((N, 8), np.float32)
+        for i in range(N):
+            self.L.ref_ba_add_point(self.p, int(case["host"][i]), float(case["u"][i]), float(case["v"][i]), float(idepth[i]),
+                                    _f(col[i]) if use_case_color else None, _f(wts[i]) if use_case_color else None, int(hdp[i]),
+                                    _f(self.sampled_color[i]), _f(self.sampled_weights[i]))
+        for pi, ti in zip(case["res_point"], case["res_target"]):
+            self.L.ref_ba_add_residual(self.p, int(pi), int(ti))
+        self.L.ref_ba_finalize(self.p)
+        self.F = F; self.N = N; self.R = len(case["res_point"]); self.n = 4 + 8 * F
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.ref_ba_destroy(self.p); self.p = None
+
+    def set_frame_state(self, k, state10):
+        self.L.ref_ba_set_frame_state(self.p, k, _d(_f64(state10)))
+
+    def perturb_frame(self, k, d8):
+        self.L.ref_ba_perturb_frame(self.p, k, _d(_f64(d8)))
+
+    def activate_all(self):
+        self.L.ref_ba_activate_all(self.p)
+
+    def linearize_all(self, fix=False):
+        return self.L.ref_ba_linearize_all(self.p, 1 if fix else 0)
+
+    def apply_res(self):
+        self.L.ref_ba_apply_res(self.p)
+
+    def res_state(self):
+        ns = np.zeros(self.R, np.int32); ne = np.zeros(self.R); nw = np.zeros(self.R); ia = np.zeros(self.R, np.int32); cp = np.zeros((self.R, 3), np.float32)
+        self.L.ref_ba_get_res_state(self.p, ns.ctypes.data_as(c_i), _d(ne), _d(nw), ia.ctypes.data_as(c_i), _f(cp))
+        return dict(newState=ns, newEnergy=ne, newEnergyWO=nw, isActive=ia, center=cp)
+
+    def get_J(self, i, which=0):
+        j = np.zeros(74, np.float32); jp = np.zeros(8, np.float32)
+        self.L.ref_ba_get_J(self.p, i, which, _f(j), _f(jp))
+        o = 0; out = {}
+        for name, shape in (("resF", (8,)), ("Jpdxi", (2, 6)), ("Jpdc", (2, 4)), ("Jpdd", (2,)), ("JIdx", (2, 8)), ("JabF", (2, 8)),
+                            ("JIdx2", (2, 2)), ("JabJIdx", (2, 2)), ("Jab2", (2, 2))):
+            n = int(np.prod(shape)); out[name] = j[o:o + n].reshape(shape); o += n
+        out["JpJdF"] = jp; out["raw"] = j
+        return out
+
+    def frame_energy_th(self):
+        o = np.zeros(self.F, np.float32); self.L.ref_ba_get_frame_energy_th(self.p, _f(o)); return o
+
+    def precalc(self, h, t):
+        o = np.zeros(37, np.float32); self.L.ref_ba_get_precalc(self.p, h, t, _f(o))
+        return dict(KRKi=o[0:9].reshape(3, 3), Kt=o[9:12], R0=o[12:21].reshape(3, 3), t0=o[21:24], aff=o[24:26], b0=o[26], R=o[27:36].reshape(3, 3), raw=o)
+
+    def adjoints(self):
+        n = self.F * self.F
+        ah = np.zeros((n, 8, 8)); at = np.zeros((n, 8, 8)); d = np.zeros((n, 8), np.float32)
+        self.L.ref_ba_get_adjoints(self.p, _d(ah), _d(at), _f(d)); return ah, at, d
+
+    def accumulate(self):
+        n = self.n
+        m = [np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n)]
+        r = C.c_int(0)
+        self.L.ref_ba_accumulate(self.p, *[_d(a) for a in m], C.byref(r))
+        return dict(HA=m[0], bA=m[1], HL=m[2], bL=m[3], Hsc=m[4], bsc=m[5], resInA=r.value)
+
+    def set_marg_prior(self, HM, bM):
+        self.L.ref_ba_set_marg_prior(self.p, _d(_f64(HM)), _d(_f64(bM)))
+
+    def point_acc(self):
+        N = self.N
+        o = [np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 4), np.float32), np.zeros(N, np.float32), np.zeros(N, np.float32)]
+        self.L.ref_ba_get_point_acc(self.p, *[_f(a) for a in o])
+        return dict(Hdd=o[0], bd=o[1], Hcd=o[2], HdiF=o[3], bdSumF=o[4])
+
+    def solve(self, iteration, lam):
+        x = np.zeros(self.n); self.L.ref_ba_solve(self.p, iteration, lam, _d(x)); return x
+
+    def last_system(self):
+        H = np.zeros((self.n, self.n)); b = np.zeros(self.n); self.L.ref_ba_get_last_system(self.p, _d(H), _d(b)); return H, b
+
+    def resubstitute(self, x):
+        self.L.ref_ba_resubstitute(self.p, _d(_f64(x)))
+
+    def point_state(self):
+        a = np.zeros(self.N, np.float32); b = np.zeros(self.N, np.float32)
+        self.L.ref_ba_get_point_state(self.p, _f(a), _f(b)); return a, b
+
+    def frame_pose(self, k):
+        p = np.zeros(7); a = np.zeros(2); s = np.zeros(10)
+        self.L.ref_ba_get_frame_pose(self.p, k, _d(p), _d(a), _d(s)); return p, a, s
+
+    def nullspaces(self):
+        o = np.zeros((7, self.n)); self.L.ref_ba_get_nullspaces(self.p, _d(o)); return o
+
+    def orthogonalize(self, x):
+        x = np.array(x, dtype=np.float64); self.L.ref_ba_orthogonalize(self.p, _d(x)); return x
+
+    def lenergy(self):
+        return self.L.ref_ba_calc_lenergy(self.p)
+
+    def menergy(self):
+        return self.L.ref_ba_calc_menergy(self.p)
+
+    def optimize(self, its=6):
+        n = C.c_int(0); tr = np.zeros((64, 2))
+        rmse = self.L.ref_ba_optimize(self.p, its, C.byref(n), _d(tr))
+        tr = tr[:n.value]
+        return dict(rmse=rmse, trace=tr, iterations=int(np.sum(tr[:, 1] >= 0)), finalEnergy=float(tr[tr[:, 1] != 0][-1, 0]) if len(tr) else float("nan"))
+
+    def log(self):
+        buf = C.create_string_buffer(1 << 20); self.L.ref_ba_log(self.p, buf, len(buf)); return buf.value.decode(errors="replace")
+
+    def marginalize_points(self, flagged_frames):
+        n = self.n
+        fl = np.ascontiguousarray(flagged_frames, dtype=np.uint8)
+        dec = np.zeros(self.N, np.uint8); H = np.zeros((n, n)); b = np.zeros(n)
+        c_u8 = C.POINTER(C.c_ubyte)
+        nres = self.L.ref_ba_marginalize_points(self.p, fl.ctypes.data_as(c_u8), dec.ctypes.data_as(c_u8), _d(H), _d(b))
+        return dec, H, b, nres
+
+    def marginalize_frame(self, k):
+        n = self.n - 8
+        H = np.zeros((n, n)); b = np.zeros(n)
+        self.L.ref_ba_marginalize_frame(self.p, k, _d(H), _d(b))
+        return H, b

@@ -1,0 +1,3 @@
+// stand-in: see boost/thread.hpp
+#pragma once
+#include "boost/thread.hpp"

@@ -634,4 +634,24 @@ void orc_se3_matrix(const double a7[7], double R[9], double t[3]) { SE3 T = pose
 void orc_se3_adj(const double a7[7], double A[36]) { se3Adj(poseFrom7(a7), A); }
 void orc_ldlt_solve(const double* A, const double* rhs, double* x, int n) { ldltSolve(A, rhs, x, n); }
 
+// --- primitives exposed for the pinning tests (tests/test_ref_pin_cpu.py compares them with the reference's own compiled code) ---
+void orc_interp33(const float* img3, int width, int n, const float* x, const float* y, float* out3) {
+  for (int i = 0; i < n; i++) { V3f r = interp33((const V3f*)img3, x[i], y[i], width); out3[3 * i] = r.v[0]; out3[3 * i + 1] = r.v[1]; out3[3 * i + 2] = r.v[2]; }
+}
+void orc_aff_from_to(float eF, float eT, double aF, double bF, double aT, double bT, double out2[2]) { affFromTo(eF, eT, aF, bF, aT, bT, out2); }
+// Accumulator9 fed like ref_acc9_stream (oracle/ref_glue.cpp): n4 groups of 4 weighted points, then nsingle single weighted points
+void orc_acc9_stream(int n4, const float* J, const float* w, int nsingle, const float* Js, const float* ws, int reps, float* H81, long* num) {
+  Acc9 acc; acc.initialize();
+  for (int rep = 0; rep < reps; rep++)
+  for (int g = 0; g < n4; g++) {
+    __m128 j[9];
+    for (int k = 0; k < 9; k++) j[k] = _mm_setr_ps(J[(4 * g + 0) * 9 + k], J[(4 * g + 1) * 9 + k], J[(4 * g + 2) * 9 + k], J[(4 * g + 3) * 9 + k]);
+    acc.updateSSE_eighted(j, _mm_setr_ps(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]));
+  }
+  for (int i = 0; i < nsingle; i++) { float j[9]; memcpy(j, Js + 9 * i, 36); acc.updateSingleWeighted(j, ws[i]); }
+  acc.finish();
+  for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) H81[r * 9 + c] = acc.H[r][c];
+  *num = (long)acc.num;
+}
+
 }  // extern "C"
