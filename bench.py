@@ -248,6 +248,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_ba:
         live_out = bench_live(args, pkg, synth, ctx, trk, raw, case, w, h)
 
+    # ---------------- VIO hand-off leg (rank 0, N = 1): the reference's default branch — every LM step computed on the host
+    vio_out = None
+    if rank == 0 and world == 1 and not args.no_ba:
+        vio_out = bench_vio(args, pkg, ctx, trk, raw, case, w, h)
+
     if rank == 0:
         out = {
             "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
@@ -265,6 +270,7 @@ def main():
             "trace": trace_out,
             "overlap": overlap_out,
             "live": live_out,
+            "vio_handoff": vio_out,
             "lm_iterations_mean": float(np.mean(res["iterations"])),
             "max_pose_err_m": float(terr.max()),
         }
@@ -352,6 +358,39 @@ def bench_live(args, pkg, synth, ctx, trk, raw, case, w, h):
                 value=round(frames / t_all, 1), unit="frames/s", ms_per_frame=round(1e3 * t_all / frames, 4),
                 ms_make_images=round(1e3 * parts[0] / frames, 4), ms_track=round(1e3 * parts[1] / frames, 4), ms_trace=round(1e3 * parts[2] / frames, 4),
                 immature_points=n)
+
+
+def bench_vio(args, pkg, ctx, trk, raw, case, w, h):
+    """One frame at a time through dmvio_hip_tracker_track_vio (the reference's setting_useIMU branch, CoarseTracker.cpp:612-637: one fused
+    evaluation launch per LM iteration, the step computed on the host — here the library's visual-only step, so the work equals the
+    device-resident LM's) next to dmvio_hip_tracker_track on the same frames.  Host wall time per frame."""
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    frame_bytes = w * h * 4
+    base = raw.data_ptr()
+    nd = args.distinct
+    for slot in range(1, nd + 1):
+        ctx.frames_attach_device_batch([slot], base + (slot - 1) * frame_bytes, frame_bytes)
+    frames = 200
+    out = {}
+    for name in ("device_lm", "handoff"):
+        t_all = 0.0; evals = 0; err = 0.0
+        for k in range(frames + 10):
+            if k == 10:
+                t_all = 0.0; evals = 0
+            slot = 1 + (k % nd)
+            t0 = time.perf_counter()
+            if name == "device_lm":
+                r = trk.trackNewestCoarse(slot, ident, (0.0, 0.0)); ne = r["iterations"] + ctx.levels
+            else:
+                r = trk.trackNewestCoarseVIO(slot, ident, (0.0, 0.0)); ne = r["n_evals"]
+            t_all += time.perf_counter() - t0; evals += ne
+            err = max(err, float(np.linalg.norm(r["pose7"][:3] - case["frames"][(slot - 1) % nd]["pose7"][:3])))
+        out[name] = dict(ms_per_frame=round(1e3 * t_all / frames, 4), evals_per_frame=round(evals / frames, 2), us_per_eval=round(1e6 * t_all / max(evals, 1), 2),
+                         max_pose_err_m=err)
+    out["ratio_handoff_to_device_lm"] = round(out["handoff"]["ms_per_frame"] / out["device_lm"]["ms_per_frame"], 3)
+    out["note"] = ("handoff = dmvio_hip_tracker_track_vio with the library's visual-only LM step as computeCoarseUpdate: per LM iteration one fused launch, the "
+                   "result picked up by polling host-coherent memory; a GTSAM-backed computeCoarseUpdate adds its own host time per iteration")
+    return out
 
 
 def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):

@@ -315,6 +315,54 @@ class CoarseTrackerHip:
         return dict(good=bool(r["good"][0]), pose7=r["pose7"][0], aff=r["aff"][0], lastResiduals=r["lastResiduals"][0],
                     flow=r["flow"][0], H=r["H"][0], b=r["b"][0], iterations=int(r["iterations"][0]))
 
+    def trackNewestCoarseVIO(self, new_slot, pose7, aff, coarsestLvl=None, minResForAbort=None, new_exposure=1.0, update=None, accept=None, visual=None):
+        """trackNewestCoarse with the LM step handed to the host (the reference's setting_useIMU branch, CoarseTracker.cpp:612-637).
+        update(H[8,8], b[8], extrapFac, lambda, pose7_cur, aff_cur) -> (pose7_new, incA, incB, incNorm) plays computeCoarseUpdate; None = the
+        library's visual-only step.  accept() / visual(H, b, good) play acceptCoarseUpdate / addVisualToCoarseGraph."""
+        pose = np.array(pose7, dtype=np.float64); a = np.array(aff, dtype=np.float64)
+        if coarsestLvl is None:
+            coarsestLvl = self.ctx.levels - 1
+        mr = np.full(5, np.nan) if minResForAbort is None else np.ascontiguousarray(minResForAbort, dtype=np.float64)
+        UPD = C.CFUNCTYPE(C.c_int, C.c_void_p, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_d, c_d, c_d, c_d)
+        ACC = C.CFUNCTYPE(None, C.c_void_p)
+        VIS = C.CFUNCTYPE(None, C.c_void_p, c_d, c_d, C.c_int)
+
+        class CB(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("update", UPD), ("accept", ACC), ("visual", VIS)]
+
+        def _upd(user, H, b, extrapFac, lam, pcur, acur, pnew, incA, incB, incNorm):
+            try:
+                p, ia, ib, nrm = update(np.array(H[:64]).reshape(8, 8), np.array(b[:8]), extrapFac, lam, np.array(pcur[:7]), np.array(acur[:2]))
+                for i in range(7):
+                    pnew[i] = float(p[i])
+                incA[0] = float(ia); incB[0] = float(ib); incNorm[0] = float(nrm)
+                return 0
+            except Exception:   # an exception must not cross the C frame
+                import traceback; traceback.print_exc()
+                return 1
+
+        def _vis(user, H, b, good):
+            visual(np.array(H[:64]).reshape(8, 8), np.array(b[:8]), bool(good))
+
+        cb = CB(None, UPD(_upd) if update else UPD(), ACC(lambda user: accept()) if accept else ACC(), VIS(_vis) if visual else VIS())
+        lr = np.zeros(5); fl = np.zeros(3); H = np.zeros(64); b = np.zeros(8); good = C.c_int(0); ne = C.c_int(0)
+        fn = self.L.dmvio_hip_tracker_track_vio
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_float, c_d, c_d, C.c_int, c_d, C.POINTER(CB), c_d, c_d, c_d, c_d, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        fn.restype = C.c_int
+        _chk(self.L, fn(self.p, new_slot, new_exposure, _d(pose), _d(a), coarsestLvl, _d(mr), C.byref(cb), _d(lr), _d(fl), _d(H), _d(b), C.byref(good), C.byref(ne)),
+             "track_vio")
+        return dict(good=bool(good.value), pose7=pose, aff=a, lastResiduals=lr, flow=fl, H=H.reshape(8, 8), b=b, n_evals=ne.value)
+
+    def coarse_update_visual(self, H, b, extrapFac, lam, pose7_cur, settings=None):
+        """The library's host implementation of the visual-only LM step (CoarseTracker.cpp:639-682) -> (pose7_new, incA, incB, incNorm)."""
+        fn = self.L.dmvio_hip_coarse_update_visual
+        fn.argtypes = [c_f, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_d, c_d, c_d]; fn.restype = C.c_int
+        st = None if settings is None else _f(np.ascontiguousarray(settings, dtype=np.float32))
+        pn = np.zeros(7); ia = np.zeros(1); ib = np.zeros(1); nn = np.zeros(1)
+        _chk(self.L, fn(st, _d(np.ascontiguousarray(H, dtype=np.float64).reshape(-1)), _d(np.ascontiguousarray(b, dtype=np.float64)), extrapFac, lam,
+                        _d(np.ascontiguousarray(pose7_cur, dtype=np.float64)), _d(pn), _d(ia), _d(ib), _d(nn)), "coarse_update_visual")
+        return pn, ia[0], ib[0], nn[0]
+
     def _batch_inputs(self, slots, poses, affs, coarsestLvl, minRes, exposures):
         B = len(slots)
         slots = np.ascontiguousarray(slots, dtype=np.int32)

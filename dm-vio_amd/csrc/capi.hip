@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/dmvio_hip.h"
 #include "common.h"
@@ -35,6 +36,9 @@ struct dmvio_hip_tracker {
   float* d_pts = nullptr;
   int pts_cap = 0;
   float *d_partials = nullptr, *h_tot = nullptr;
+  unsigned int* d_arrive = nullptr;   // arrive counter of k_eval_fused (zero between launches)
+  unsigned int eval_ticket = 0;       // ticket of the last fused evaluation; the kernel stores it behind the sums in h_tot
+  int eval_blocks_override = 0;
   int max_eval_blocks = 1024;
   LMProblemIn *h_in = nullptr;   // 2 x batch_cap entries of pinned host memory, read by the kernel directly (each workgroup copies its 120 B into LDS)
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
@@ -329,7 +333,12 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   HIPCHKP(hipMalloc((void**)&t->d_pc_ptrs, sizeof(float4*) * DMV_MAX_LEVELS));
   HIPCHKP(hipMemcpy(t->d_pc_ptrs, t->d_pc, sizeof(float4*) * DMV_MAX_LEVELS, hipMemcpyHostToDevice));
   HIPCHKP(hipMalloc((void**)&t->d_partials, sizeof(float) * ACC_PAD * t->max_eval_blocks));
-  HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * ACC_PAD, hipHostMallocDefault));
+  // host-coherent (fine-grained) pinned memory: the fused evaluation stores its sums and then a ticket there, the host spins on the ticket
+  HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * (ACC_PAD + 16), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(t->h_tot, 0, sizeof(float) * (ACC_PAD + 16));
+  HIPCHKP(hipMalloc((void**)&t->d_arrive, sizeof(unsigned int)));
+  HIPCHKP(hipMemset(t->d_arrive, 0, sizeof(unsigned int)));
+  if (const char* e = getenv("DMVIO_HIP_EVAL_BLOCKS")) t->eval_blocks_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_CLUSTER")) t->lm_cluster_override = atoi(e);
@@ -344,7 +353,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials);
-  hipHostFree(t->h_tot);
+  hipHostFree(t->h_tot); hipFree(t->d_arrive);
   hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
   if (t->d_cl_part) hipFree(t->d_cl_part);
@@ -451,6 +460,31 @@ int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* t, int lvl, float* u, float* v, 
   return 0;
 }
 
+// One fused calcRes + calcGSSSE evaluation, result in t->h_tot when the call returns: ONE launch, no stream synchronisation — the
+// last workgroup stores the sums and then the launch's ticket into host-coherent memory and the host spins on the ticket.
+// G workgroups of 256 threads split the template (point index first = rank * 256 + thread, stride G * 256) and the partial sums are
+// added in rank order: with G = the cluster size of a one-problem k_track_lm launch the sums are bit-identical to the device-resident LM's.
+static int evalFused(dmvio_hip_tracker* t, int lvl, int new_slot, const EvalP& e, int G) {
+  dmvio_hip_ctx* c = t->ctx;
+  constexpr int T = 256;
+  G = std::max(1, std::min(G, t->max_eval_blocks));
+  const unsigned int ticket = ++t->eval_ticket;
+  hipLaunchKernelGGL(k_eval_fused<T>, dim3(G), dim3(T), 0, c->stream, t->dev, c->fs, new_slot, e, t->d_partials, t->d_arrive, t->h_tot, ticket);
+  HIPCHK(hipGetLastError());
+  volatile unsigned int* flag = reinterpret_cast<volatile unsigned int*>(t->h_tot) + ACC_PAD;
+  unsigned long long spins = 0;
+  while (*flag != ticket) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {   // every ~million polls (a few ms): has the launch failed instead of finishing?
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_fused", __FILE__, __LINE__, q);
+      if (q == hipSuccess && *flag != ticket) return failmsg("tracker evaluation finished without publishing its result");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float new_exposure, const double pose7[7], const double aff[2],
                            float cutoffTH, double res6[6], double H[64], double b[8]) {
   if (!t || !pose7 || !aff) return failmsg("tracker_eval: null argument");
@@ -462,12 +496,7 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
   EvalP e;
   makeEvalP(t->dev, lvl, poseFrom7(pose7), aff[0], aff[1], new_exposure, cutoffTH, e);
   const int n = t->dev.pc_n[lvl];
-  constexpr int T = 256;
-  const int G = std::max(1, std::min((n + T - 1) / T, t->max_eval_blocks));
-  hipLaunchKernelGGL(k_eval_partial<T>, dim3(G), dim3(T), 0, c->stream, t->dev, e, c->levelPtr(new_slot, lvl), t->d_partials);
-  hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(64), 0, c->stream, t->d_partials, G, t->h_tot);   // sums stored into pinned host memory
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (int r = evalFused(t, lvl, new_slot, e, (n + 255) / 256)) return r;
   if (res6) res6FromSums(t->h_tot, res6);
   if (H && b) systemFromSums(t->h_tot, H, b);
   return 0;
@@ -619,6 +648,164 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_sl
 int dmvio_hip_tracker_track(dmvio_hip_tracker* t, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
                             const double minRes[5], double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good) {
   return dmvio_hip_tracker_track_batch(t, 1, &new_slot, &new_exposure, pose7_io, aff_io, coarsestLvl, minRes, lastResiduals, lastFlow, H, b, good, nullptr);
+}
+
+// The visual-only LM step of CoarseTracker.cpp:639-682 on the host: damped H, the 6 / 7 / 8-dof LDL^T variants selected by
+// affineOptModeA / B, extrapolation, SCALE_* scaling, SE3::exp(inc) * refToNew_current.  This is what the reference itself executes
+// while the IMU is not initialised (CoarseTracker.cpp:612: !imuIntegration.isCoarseInitialized()), and the default update of
+// dmvio_hip_tracker_track_vio.  incA / incB are returned UNSCALED like computeCoarseUpdate's (the caller applies SCALE_A / SCALE_B, :633-637).
+int dmvio_hip_coarse_update_visual(const dmvio_hip_tracker_settings* st, const double H[64], const double b[8], float extrapFac, float lambda,
+                                   const double pose7_cur[7], double pose7_new[7], double* incA, double* incB, double* incNorm) {
+  if (!H || !b || !pose7_cur || !pose7_new) return failmsg("coarse_update_visual: null argument");
+  const float modeA = st ? st->affineOptModeA : 1e12f, modeB = st ? st->affineOptModeB : 1e8f;
+  double Hl[64];
+  memcpy(Hl, H, sizeof(Hl));
+  for (int i = 0; i < 8; i++) Hl[i * 9] *= (1 + lambda);
+  double inc[8];
+  const bool fixA = modeA < 0, fixB = modeB < 0;
+  if (!fixA && !fixB) {
+    double m[64]; memcpy(m, Hl, sizeof(m));
+    for (int i = 0; i < 8; i++) inc[i] = -b[i];
+    ldltSolveInPlace<8>(m, 8, inc, 8);
+  } else if (fixA && fixB) {
+    double m[64]; memcpy(m, Hl, sizeof(m));
+    for (int i = 0; i < 6; i++) inc[i] = -b[i];
+    ldltSolveInPlace<8>(m, 8, inc, 6);
+    inc[6] = inc[7] = 0;
+  } else if (!fixA && fixB) {
+    double m[64]; memcpy(m, Hl, sizeof(m));
+    for (int i = 0; i < 7; i++) inc[i] = -b[i];
+    ldltSolveInPlace<8>(m, 8, inc, 7);
+    inc[7] = 0;
+  } else {   // fix a: b's row / column take the place of a's (CoarseTracker.cpp:653-664)
+    double m[64]; memcpy(m, Hl, sizeof(m));
+    double bs[8]; memcpy(bs, b, sizeof(bs));
+    for (int r = 0; r < 8; r++) m[r * 8 + 6] = m[r * 8 + 7];
+    for (int cc = 0; cc < 8; cc++) m[6 * 8 + cc] = m[7 * 8 + cc];
+    bs[6] = bs[7];
+    double x[8];
+    for (int i = 0; i < 7; i++) x[i] = -bs[i];
+    ldltSolveInPlace<8>(m, 8, x, 7);
+    for (int i = 0; i < 6; i++) inc[i] = x[i];
+    inc[6] = 0; inc[7] = x[6];
+  }
+  for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+  double incScaled[8];
+  for (int i = 0; i < 6; i++) incScaled[i] = inc[i] * 1.0f;   // SCALE_XI_ROT / SCALE_XI_TRANS
+  incScaled[6] = inc[6] * 10.0f; incScaled[7] = inc[7] * 1000.0f;
+  double ssum = 0;
+  for (int i = 0; i < 8; i++) ssum += incScaled[i];
+  if (!std::isfinite(ssum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
+  const Pose nxt = poseMul(poseExp(incScaled), poseFrom7(pose7_cur));
+  poseTo7(nxt, pose7_new);
+  // the reference's two branches differ here: the LDLT branch adds incScaled[6..7] to the affine parameters, the IMU branch receives
+  // the unscaled increments and scales them itself — both give the same numbers as long as incScaled was not zeroed for being non-finite
+  if (incA) *incA = std::isfinite(ssum) ? inc[6] : 0.0;
+  if (incB) *incB = std::isfinite(ssum) ? inc[7] : 0.0;
+  double nn = 0;
+  for (int i = 0; i < 8; i++) nn += inc[i] * inc[i];
+  if (incNorm) *incNorm = sqrt(nn);
+  return 0;
+}
+
+// CoarseTracker::trackNewestCoarse with the LM step handed to the caller (CoarseTracker.cpp:539-770, the setting_useIMU branch
+// :612-637): the host loop of the reference over fused device evaluations.  Every iteration costs one kernel launch whose result the
+// host picks up by polling host-coherent memory (evalFused), plus the callback.
+int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
+                                const double minResForAbort[5], const dmvio_hip_coarse_callbacks* cb, double lastResiduals[5], double lastFlow[3],
+                                double H_out[64], double b_out[8], int* good, int* n_evals) {
+  if (!t || !pose7_io || !aff_io) return failmsg("track_vio: null argument");
+  dmvio_hip_ctx* c = t->ctx;
+  if (!t->haveK || !t->haveRef) return failmsg("track_vio: makeK / setCoarseTrackingRef not called");
+  if (coarsestLvl < 0 || coarsestLvl >= c->levels || coarsestLvl >= 5) return failmsg("track_vio: coarsestLvl out of range");
+  if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("track_vio: frame slot out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const TrackerDev& trk = t->dev;
+  const int G = t->eval_blocks_override > 0 ? t->eval_blocks_override : clusterSize(1, trk.pc_n[0]);
+  dmvio_hip_tracker_settings st; st.huberTH = trk.huberTH; st.coarseCutoffTH = trk.coarseCutoffTH; st.affineOptModeA = trk.modeA; st.affineOptModeB = trk.modeB;
+  double lastRes[5], flow[3] = {1000, 1000, 1000};
+  for (int i = 0; i < 5; i++) lastRes[i] = NAN;
+  const int maxIterations[5] = {10, 20, 50, 50, 50};
+  const float lambdaExtrapolationLimit = 0.001f;
+  Pose cur = poseFrom7(pose7_io);
+  double affA = aff_io[0], affB = aff_io[1];
+  bool haveRepeated = false, failed = false;
+  double H[64] = {0}, b[8] = {0};
+  int lastLvl = -1, evals = 0;
+  EvalP e;
+  for (int lvl = coarsestLvl; lvl >= 0 && !failed; lvl--) {
+    float levelCutoffRepeat = 1;
+    double resOld[6];
+    makeEvalP(trk, lvl, cur, affA, affB, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
+    if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+    evals++;
+    res6FromSums(t->h_tot, resOld);
+    while (resOld[5] > 0.6 && (levelCutoffRepeat < 50 || resOld[5] > 0.99)) {
+      levelCutoffRepeat *= 2;
+      makeEvalP(trk, lvl, cur, affA, affB, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
+      if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+      evals++;
+      res6FromSums(t->h_tot, resOld);
+    }
+    systemFromSums(t->h_tot, H, b);
+    float lambda = 0.01f;
+    for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+      float extrapFac = 1;
+      if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
+      double cur7[7], nxt7[7], incA = 0, incB = 0, incNorm = 0;
+      poseTo7(cur, cur7);
+      int rc;
+      if (cb && cb->update) {
+        const double affc[2] = {affA, affB};
+        rc = cb->update(cb->user, H, b, extrapFac, lambda, cur7, affc, nxt7, &incA, &incB, &incNorm);
+        if (rc) return failmsg("track_vio: the coarse-update callback reported an error");
+      } else if ((rc = dmvio_hip_coarse_update_visual(&st, H, b, extrapFac, lambda, cur7, nxt7, &incA, &incB, &incNorm))) return rc;
+      const Pose nxt = poseFrom7(nxt7);
+      const double affA_n = affA + incA * 10.0f, affB_n = affB + incB * 1000.0f;   // SCALE_A, SCALE_B (CoarseTracker.cpp:633-637)
+      makeEvalP(trk, lvl, nxt, affA_n, affB_n, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
+      if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+      evals++;
+      double resNew[6];
+      res6FromSums(t->h_tot, resNew);
+      const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      if (accept) {
+        systemFromSums(t->h_tot, H, b);
+        for (int i = 0; i < 6; i++) resOld[i] = resNew[i];
+        affA = affA_n; affB = affB_n; cur = nxt;
+        if (cb && cb->accept) cb->accept(cb->user);
+        lambda *= 0.5f;
+      } else {
+        lambda *= 4;
+        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+      }
+      lastLvl = lvl;
+      if (!(incNorm > 1e-3)) break;
+    }
+    lastRes[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+    flow[0] = resOld[2]; flow[1] = resOld[3]; flow[2] = resOld[4];
+    if (std::isnan(lastRes[lvl]) || (minResForAbort && lastRes[lvl] > 1.5 * minResForAbort[lvl])) { failed = true; break; }
+    if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+  }
+  if (lastResiduals) memcpy(lastResiduals, lastRes, sizeof(lastRes));
+  if (lastFlow) memcpy(lastFlow, flow, sizeof(flow));
+  if (n_evals) *n_evals = evals;
+  if (H_out) memcpy(H_out, H, sizeof(H));
+  if (b_out) memcpy(b_out, b, sizeof(b));
+  if (failed) { if (good) *good = 0; return 0; }   // the reference returns false without touching lastToNew_out / aff_g2l_out (:731-732)
+  double aff[2] = {affA, affB};
+  bool trackingGood = true;
+  if ((trk.modeA != 0 && (fabsf((float)aff[0]) > 1.2f)) || (trk.modeB != 0 && (fabsf((float)aff[1]) > 200.0f))) trackingGood = false;
+  double rel[2];
+  affFromTo(trk.ref_exposure, new_exposure, trk.ref_aff_a, trk.ref_aff_b, aff[0], aff[1], rel);
+  if ((trk.modeA == 0 && (fabsf(logf((float)rel[0])) > 1.5f)) || (trk.modeB == 0 && (fabsf((float)rel[1]) > 200.0f))) trackingGood = false;
+  if (trk.modeA < 0) aff[0] = 0;
+  if (trk.modeB < 0) aff[1] = 0;
+  poseTo7(cur, pose7_io);
+  aff_io[0] = aff[0]; aff_io[1] = aff[1];
+  if (good) *good = trackingGood ? 1 : 0;
+  if (lastLvl == 0 && cb && cb->visual) cb->visual(cb->user, H, b, trackingGood ? 1 : 0);   // addVisualToCoarseGraph (:763-767)
+  return 0;
 }
 
 // lastF_2_fh_tries of FullSystem::trackNewCoarse (FullSystem.cpp:364-402) from three camToWorld poses

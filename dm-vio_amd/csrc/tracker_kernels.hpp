@@ -339,6 +339,52 @@ __global__ void __launch_bounds__(64) k_eval_final(const float* __restrict__ par
   out[threadIdx.x] = s;
 }
 
+// The same evaluation as ONE launch whose result reaches the host without a stream synchronisation — the VIO hand-off path
+// (CoarseTracker.cpp:612-637: every LM iteration hands H, b to IMUIntegration::computeCoarseUpdate on the host and waits for the
+// pose it returns, so launch + wake-up latency is paid ~15 times per frame).  The last workgroup to arrive (one agent-scope counter)
+// adds the partial sums in rank order — a fixed order, bit-identical to k_eval_partial + k_eval_final — stores them into pinned,
+// host-coherent memory and then releases the launch's ticket next to them; the host spins on that word.
+template <int T>
+__global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const FrameStore fs, const int slot, const EvalP e, float* __restrict__ partials,
+                                                  unsigned int* __restrict__ arrive, float* __restrict__ out_host, const unsigned int ticket) {
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
+  __shared__ float s_tot[ACC_PAD];
+  __shared__ int s_last;
+  initStage<T>(s_stage);
+  const int lvl = e.lvl;
+  const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
+  const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
+  const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
+                                    (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+  if (clean)
+    blockEval<T, false>(e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH,
+                        s_stage, s_partH, s_partS, s_tot);
+  else
+    blockEval<T, true>(e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH,
+                       s_stage, s_partH, s_partS, s_tot);
+  if (gridDim.x == 1) {
+    if (threadIdx.x < ACC_PAD) __hip_atomic_store(out_host + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    if (threadIdx.x < ACC_PAD) __hip_atomic_store(partials + blockIdx.x * ACC_PAD + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < ACC_PAD) {
+      float s = 0.0f;
+      for (unsigned int g = 0; g < gridDim.x; g++) s += __hip_atomic_load(partials + g * ACC_PAD + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(out_host + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(out_host) + ACC_PAD, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // H (8x8, double, SCALE_*-scaled) and b from the 45 sums, exactly as calcGSSSE's tail does (:340-355).
 DMV_HD void systemFromSums(const float* tot, double* H, double* b) {
   const int nW = (int)tot[ACC_NW];

@@ -116,6 +116,35 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* trk, int lvl, int new_slot, float 
 int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_exposure,
                             double pose7_io[7], double aff_io[2], int coarsestLvl, const double minResForAbort[5],
                             double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good);
+/* The reference's DEFAULT tracking path (settings.cpp:36 setting_useIMU = true): trackNewestCoarse with every LM step handed to the
+ * host (CoarseTracker.cpp:612-637).  The callbacks mirror the three members of dmvio::IMUIntegration the tracker calls
+ * (src/IMU/IMUIntegration.hpp:106-112):
+ *   update  <- computeCoarseUpdate(H, b, extrapFac, lambda, incA, incB, incNorm) -> refToNew_new.  H (8x8 row-major) and b are the
+ *              SCALE_*-scaled system in the order [trans3 rot3 a b]; pose7_cur / aff_cur = the current estimate (for callers that do not
+ *              keep it themselves); pose7_new = the new refToNew; *incA, *incB = affine increments BEFORE the SCALE_A / SCALE_B the
+ *              tracker applies (CoarseTracker.cpp:633-637); *incNorm ends the level when it is not > 1e-3.  Return 0; nonzero aborts the call.
+ *   accept  <- acceptCoarseUpdate()            (may be NULL)
+ *   visual  <- addVisualToCoarseGraph(H, b, trackingGood), called when the finest level was reached (may be NULL)
+ * update == NULL (or cb == NULL) runs dmvio_hip_coarse_update_visual: the reference's own visual-only step, which is also what it
+ * executes while the IMU is not yet initialised.  One fused kernel launch per evaluation, results fetched by polling host-coherent
+ * memory (no stream synchronisation); with the default update the results are those of dmvio_hip_tracker_track. */
+typedef int (*dmvio_hip_coarse_update_fn)(void* user, const double H[64], const double b[8], float extrapFac, float lambda, const double pose7_cur[7],
+                                          const double aff_cur[2], double pose7_new[7], double* incA, double* incB, double* incNorm);
+typedef void (*dmvio_hip_coarse_accept_fn)(void* user);
+typedef void (*dmvio_hip_coarse_visual_fn)(void* user, const double H[64], const double b[8], int trackingGood);
+typedef struct dmvio_hip_coarse_callbacks {
+  void* user;
+  dmvio_hip_coarse_update_fn update;
+  dmvio_hip_coarse_accept_fn accept;
+  dmvio_hip_coarse_visual_fn visual;
+} dmvio_hip_coarse_callbacks;
+int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* trk, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
+                                const double minResForAbort[5], const dmvio_hip_coarse_callbacks* cb, double lastResiduals[5], double lastFlow[3],
+                                double H[64], double b[8], int* good, int* n_evals);
+/* The visual-only LM step of CoarseTracker.cpp:639-682 (damped H, 6 / 7 / 8-dof LDL^T by affineOptModeA / B, extrapolation, SE3::exp),
+ * host-only; st == NULL = the reference's default settings.  For callbacks that fall back to the visual step. */
+int dmvio_hip_coarse_update_visual(const dmvio_hip_tracker_settings* st, const double H[64], const double b[8], float extrapFac, float lambda,
+                                   const double pose7_cur[7], double pose7_new[7], double* incA, double* incB, double* incNorm);
 /* Same for B independent alignment problems against the current reference in one launch: the pose-hypothesis
  * list of FullSystem::trackNewCoarse (FullSystem.cpp:364-402) and/or a batch of new frames.  All arrays are
  * B-major (pose7_io[B*7], aff_io[B*2], minResForAbort[B*5], lastResiduals[B*5], lastFlow[B*3], H[B*64], b[B*8],

@@ -15,6 +15,7 @@
 #ifndef DMVIO_HIP_HPP
 #define DMVIO_HIP_HPP
 #include <cmath>
+#include <functional>
 #include <string>
 #include <vector>
 #include "dmvio_hip.h"
@@ -102,6 +103,37 @@ class CoarseTracker {
     aff_g2l_out = AffLight(aff[0], aff[1]);
     return good != 0;
   }
+  /* The reference's default branch (setting_useIMU, CoarseTracker.cpp:612-637): every LM step is computed by the caller.  The three
+   * members mirror what the tracker calls on dmvio::IMUIntegration (IMUIntegration.hpp:106-112):
+   *   computeCoarseUpdate(H, b, extrapFac, lambda, incA, incB, incNorm) -> refToNew_new      H: 8x8 row-major, scaled, [trans rot a b]
+   *   acceptCoarseUpdate()
+   *   addVisualToCoarseGraph(H, b, trackingGood)
+   * An empty computeCoarseUpdate runs the visual-only step (what the reference does while !isCoarseInitialized()). */
+  struct CoarseIMUHooks {
+    std::function<SE3(const double* H, const double* b, float extrapFac, float lambda, const SE3& refToNew_current, double& incA, double& incB, double& incNorm)>
+        computeCoarseUpdate;
+    std::function<void()> acceptCoarseUpdate;
+    std::function<void(const double* H, const double* b, bool trackingGood)> addVisualToCoarseGraph;
+  };
+  bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, const double minResForAbort[5],
+                         const CoarseIMUHooks& imu) {
+    if (!trk_) return false;
+    dmvio_hip_coarse_callbacks cb;
+    cb.user = const_cast<CoarseIMUHooks*>(&imu);
+    cb.update = imu.computeCoarseUpdate ? &CoarseTracker::updateThunk : nullptr;
+    cb.accept = imu.acceptCoarseUpdate ? &CoarseTracker::acceptThunk : nullptr;
+    cb.visual = imu.addVisualToCoarseGraph ? &CoarseTracker::visualThunk : nullptr;
+    double pose7[7], aff[2] = {aff_g2l_out.a, aff_g2l_out.b};
+    lastToNew_out.toPose7(pose7);
+    int good = 0;
+    if (dmvio_hip_tracker_track_vio(trk_, newSlot, new_ab_exposure, pose7, aff, coarsestLvl, minResForAbort, &cb, lastResiduals, lastFlowIndicators, lastH, lastb, &good,
+                                    &lastEvaluations) != 0)
+      return false;
+    lastToNew_out.fromPose7(pose7);
+    aff_g2l_out = AffLight(aff[0], aff[1]);
+    return good != 0;
+  }
+  int lastEvaluations = 0;   /* calcRes + calcGSSSE passes of the last hand-off track */
   int pc_n(int lvl) const { return trk_ ? dmvio_hip_tracker_pc_n(trk_, lvl) : 0; }
 
   /* CoarseTracker.h:83-91 */
@@ -113,6 +145,16 @@ class CoarseTracker {
   double lastH[64], lastb[8];
 
  private:
+  static int updateThunk(void* user, const double H[64], const double b[8], float extrapFac, float lambda, const double pose7_cur[7], const double*, double pose7_new[7],
+                         double* incA, double* incB, double* incNorm) {
+    const CoarseIMUHooks* h = static_cast<const CoarseIMUHooks*>(user);
+    SE3 cur; cur.fromPose7(pose7_cur);
+    const SE3 nxt = h->computeCoarseUpdate(H, b, extrapFac, lambda, cur, *incA, *incB, *incNorm);
+    nxt.toPose7(pose7_new);
+    return 0;
+  }
+  static void acceptThunk(void* user) { static_cast<const CoarseIMUHooks*>(user)->acceptCoarseUpdate(); }
+  static void visualThunk(void* user, const double H[64], const double b[8], int good) { static_cast<const CoarseIMUHooks*>(user)->addVisualToCoarseGraph(H, b, good != 0); }
   FrameStore& frames_;
   dmvio_hip_tracker* trk_;
   int refSlot_;

@@ -138,7 +138,8 @@ def test_optimize_parity(pkg, oracle, synth, gpu_required):
         assert min(np.linalg.norm(pg[3:] - po[3:]), np.linalg.norm(pg[3:] + po[3:])) < 1e-4
         assert np.allclose(ag, ao, atol=1e-3)
     ig, _ = ba.point_state(); io, _ = W.point_state()
-    assert np.median(np.abs(ig - io) / io) < 1e-4
+    seen = io != 0   # the plane world leaves a few rays without a depth: those points have no residual and keep idepth 0 on both sides
+    assert np.array_equal(ig[~seen], io[~seen]) and np.median(np.abs(ig[seen] - io[seen]) / io[seen]) < 1e-4
     # and the optimisation did its job: poses closer to the ground truth than the initial guess
     e0 = np.mean([np.linalg.norm(np.asarray(case["poses0"][k][:3]) - case["poses_true"][k][:3]) for k in range(1, 8)])
     e1 = np.mean([np.linalg.norm(ba.frame_pose(k)[0][:3] - case["poses_true"][k][:3]) for k in range(1, 8)])
