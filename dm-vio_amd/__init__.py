@@ -651,6 +651,18 @@ class BundleAdjusterHip:
     def set_frame_state(self, k, state10):
         _chk(self.L, self.L.dmvio_hip_ba_set_frame_state(self.p, k, _d(np.ascontiguousarray(state10, dtype=np.float64))), "ba_set_frame_state")
 
+    def set_frame_zero(self, k, state_zero10):
+        fn = self.L.dmvio_hip_ba_set_frame_zero; fn.argtypes = [C.c_void_p, C.c_int, c_d]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, k, _d(np.ascontiguousarray(state_zero10, dtype=np.float64))), "ba_set_frame_zero")
+
+    def set_frame_energy_th(self, th):
+        fn = self.L.dmvio_hip_ba_set_frame_energy_th; fn.argtypes = [C.c_void_p, c_f]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, _f(np.ascontiguousarray(th, dtype=np.float32))), "ba_set_frame_energy_th")
+
+    def set_calib_values(self, value4, value_zero4):
+        fn = self.L.dmvio_hip_ba_set_calib_values; fn.argtypes = [C.c_void_p, c_d, c_d]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, _d(np.ascontiguousarray(value4, dtype=np.float64)), _d(np.ascontiguousarray(value_zero4, dtype=np.float64))), "ba_set_calib_values")
+
     def marginalize_points(self, candidates, update_prior=False):
         """flagPointsForRemoval's relinearisation + EnergyFunctional::marginalizePointsF: (decision[N], Hadd, badd, resInM)."""
         n = self.n

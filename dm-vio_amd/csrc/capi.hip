@@ -822,7 +822,7 @@ int dmvio_hip_make_track_hypotheses(const double slast_c2w[7], const double spre
   tries.push_back(lastF_2_slast);                                       // zero motion
   Pose ident; ident.q.w = 1; ident.q.x = ident.q.y = ident.q.z = 0; ident.t[0] = ident.t[1] = ident.t[2] = 0;
   tries.push_back(ident);                                               // zero motion from the keyframe
-  const double d = 0.02;                                                // the reference's rotDelta loop runs exactly once (:376)
+  const double d = (double)0.02f;  /* float rotDelta widened by Sophus::Quaterniond */                                              // the reference's rotDelta loop runs exactly once (:376)
   static const int sg[26][3] = {{1,0,0},{0,1,0},{0,0,1},{-1,0,0},{0,-1,0},{0,0,-1},{1,1,0},{0,1,1},{1,0,1},{-1,1,0},{0,-1,1},{-1,0,1},{1,-1,0},{0,1,-1},{1,0,-1},
                                 {-1,-1,0},{0,-1,-1},{-1,0,-1},{-1,-1,-1},{-1,-1,1},{-1,1,-1},{-1,1,1},{1,-1,-1},{1,-1,1},{1,1,-1},{1,1,1}};
   const Pose base = poseMul(fhInv, lastF_2_slast);

@@ -595,6 +595,32 @@ int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10
   b->H.setPrecalcValues();
   return 0;
 }
+// Windows taken over from a running system (rather than built fresh): FrameHessian::state_zero (HessianBlocks.cpp:74-107), frameEnergyTH
+// of every keyframe and CalibHessian::value_zero (unscaled units) where they differ from what dmvio_hip_ba_set_window starts with.
+int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* b, int f, const double state_zero10[10]) {
+  if (!b || !state_zero10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_zero: bad argument");
+  b->sums_fresh = false;
+  std::lock_guard<std::mutex> lk(b->mu);
+  BAHost::frameSetStateZero(b->H.fr[f], state_zero10);
+  b->H.frameTakeData(b->H.fr[f]);
+  b->H.setPrecalcValues();
+  return 0;
+}
+int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
+  if (!b || !th) return failmsg("ba_set_frame_energy_th: null argument");
+  std::lock_guard<std::mutex> lk(b->mu);
+  for (int f = 0; f < b->H.F; f++) b->H.fr[f].frameEnergyTH = th[f];
+  return 0;
+}
+int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const double value_zero[4]) {
+  if (!b || !value || !value_zero) return failmsg("ba_set_calib_values: null argument");
+  b->sums_fresh = false;
+  std::lock_guard<std::mutex> lk(b->mu);
+  for (int i = 0; i < 4; i++) b->H.c_value_zero[i] = value_zero[i];
+  b->H.calibSetValue(value);
+  b->H.setPrecalcValues();
+  return 0;
+}
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
   if (!b) return failmsg("null ba");
   memcpy(fxfycxcy, b->H.c_value_scaled, sizeof(double) * 4);

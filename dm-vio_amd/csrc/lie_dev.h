@@ -158,7 +158,11 @@ DMV_HD Pose poseFrom7(const double p[7]) {
   Pose T;
   T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
   Quatd q = {p[6], p[3], p[4], p[5]};
-  T.q = qnormalize(q);
+  // A quaternion that is already unit to rounding (it came out of the reference's SE3, which normalises after every product) is taken
+  // over bit for bit: normalising it a second time would move its last bits, and the sliding-window solve amplifies such a change
+  // (condition ~1e10) into 1e-7 of the poses.  Anything else is normalised like Sophus' constructor does (so3.hpp setQuaternion).
+  const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  T.q = (fabs(n2 - 1.0) <= 1e-14) ? q : qnormalize(q);
   return T;
 }
 DMV_HD void poseTo7(const Pose& T, double p[7]) {

@@ -206,6 +206,13 @@ int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* ba, const double* HM, const double
 /* FrameHessian::setState (HessianBlocks.h:179-199): state10 = [xi (6, left increment on the evaluation point) | a, b | 0, 0] in the
  * reference's unscaled units, followed by FullSystem::setPrecalcValues (FullSystem.cpp:1670-1680). */
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* ba, int frame, const double state10[10]);
+/* For a window taken over from a running system: a keyframe's linearisation state FrameHessian::state_zero (HessianBlocks.cpp:74-107; the
+ * pose part is zero by construction, the affine part is the brightness at the evaluation point), the outlier thresholds
+ * FrameHessian::frameEnergyTH of all keyframes (th[F]) and CalibHessian::value / value_zero (the reference's unscaled units: fx,fy / SCALE_F,
+ * cx,cy / SCALE_C; `value` is the primary quantity of a running system, value_scaled its product with the float SCALE_* constants). */
+int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* ba, int frame, const double state_zero10[10]);
+int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* ba, const float* th);
+int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* ba, const double value[4], const double value_zero[4]);
 /* Point marginalisation: the relinearisation branch of FullSystem::flagPointsForRemoval (FullSystem.cpp:829-859: resetOOB, linearize,
  * applyRes, EFResidual::fixLinearizationF EnergyFunctionalStructs.cpp:76-106) for the points with candidates[i] != 0, the
  * marginalise-or-drop decision (idepth_hessian > setting_minIdepthH_marg), then EnergyFunctional::marginalizePointsF

@@ -1213,7 +1213,7 @@ int orc_ba_add_frame(void* p, const double pose7_w2c[7], double aff_a, double af
   OFrame f;
   f.ab_exposure = exposure; f.frameID = frameID; f.dI = (const V3f*)dI;
   SE3 T; T.t[0] = pose7_w2c[0]; T.t[1] = pose7_w2c[1]; T.t[2] = pose7_w2c[2];
-  T.q = qnormalize(Quat{pose7_w2c[6], pose7_w2c[3], pose7_w2c[4], pose7_w2c[5]});
+  T.q = qimport(Quat{pose7_w2c[6], pose7_w2c[3], pose7_w2c[4], pose7_w2c[5]});
   // setEvalPT_scaled (HessianBlocks.h:220-227)
   double st[10] = {0, 0, 0, 0, 0, 0, SCALE_A_INVERSE * aff_a, SCALE_B_INVERSE * aff_b, 0, 0};
   f.evalPT = T;
@@ -1236,6 +1236,19 @@ void orc_ba_set_frame_state(void* p, int fidx, const double state10[10]) {
   OWindow* W = (OWindow*)p;
   OWindow::frameSetState(W->frames[fidx], state10);
   W->setPrecalcValues();
+}
+// replay of windows recorded from a running system: a frame's state_zero (FrameHessian::setStateZero, HessianBlocks.cpp:74-107), its
+// frameEnergyTH, and CalibHessian::value_zero (unscaled) when they are not the defaults a fresh window starts with
+void orc_ba_set_frame_zero(void* p, int fidx, const double state_zero10[10]) {
+  OWindow* W = (OWindow*)p;
+  OWindow::frameSetStateZero(W->frames[fidx], state_zero10);
+}
+void orc_ba_set_frame_energy_th(void* p, const float* th) { OWindow* W = (OWindow*)p; for (int i = 0; i < W->nF; i++) W->frames[i].frameEnergyTH = th[i]; }
+void orc_ba_set_calib_values(void* p, const double value[4], const double value_zero[4]) {   // CalibHessian::value / value_zero (unscaled)
+  OWindow* W = (OWindow*)p;
+  for (int i = 0; i < 4; i++) W->c_value_zero[i] = value_zero[i];
+  W->calibSetValue(value);
+  W->setPrecalcValues();   // -> setDeltaF: cDeltaF
 }
 int orc_ba_add_point(void* p, int host, float u, float v, float idepth, const float color[8], const float weights[8], int hasDepthPrior) {
   OWindow* W = (OWindow*)p;

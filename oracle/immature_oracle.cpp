@@ -326,7 +326,7 @@ void orc_immature_trace(const float* dI_new, int w, int h, int n, const float* u
 // FullSystem::traceNewCoarse's per-host tables: hostToNew = new_w2c * host_c2w; KRKi = K R K^-1 (float), Kt = K t, aff = fromToVecExposure
 void orc_trace_precalc(const double* new_w2c7, const double* host_c2w7, const double* fxfycxcy, float new_exposure, float host_exposure,
                        const double* new_aff, const double* host_aff, float* KRKi9, float* Kt3, float* aff2) {
-  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qnormalize(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };   // tx ty tz qx qy qz qw
+  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qimport(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };   // tx ty tz qx qy qz qw
   const orc::SE3 T = orc::se3Mul(from7(new_w2c7), from7(host_c2w7));
   double Rd[9];
   orc::qToR(T.q, Rd);
@@ -354,7 +354,7 @@ void orc_trace_precalc(const double* new_w2c7, const double* host_c2w7, const do
 // FrameFramePrecalc::set (HessianBlocks.cpp:193-223): PRE_RTll, PRE_tTll (current state), PRE_aff_mode of the pair (host -> target)
 void orc_pair_precalc(const double* target_w2c7, const double* host_c2w7, float host_exposure, float target_exposure, const double* host_aff, const double* target_aff,
                       float* R9, float* t3, float* aff2) {
-  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qnormalize(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
+  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qimport(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
   const orc::SE3 T = orc::se3Mul(from7(target_w2c7), from7(host_c2w7));
   double Rd[9];
   orc::qToR(T.q, Rd);

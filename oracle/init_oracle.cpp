@@ -38,7 +38,7 @@ void orc_init_calc_res_and_gs(const float* dI_ref, const float* dI_new, int wl, 
                               float couplingWeight, double priorY, double priorX, float* H_out, float* b_out, float* H_sc, float* b_sc, float* res3,
                               float* energy_new, unsigned char* isGood_new, float* maxstep_out, float* lastHessian_new, float* JbBuffer_new) {
   orc::SE3 T; T.t[0] = refToNew7[0]; T.t[1] = refToNew7[1]; T.t[2] = refToNew7[2];
-  T.q = orc::qnormalize(orc::Quat{refToNew7[6], refToNew7[3], refToNew7[4], refToNew7[5]});
+  T.q = orc::qimport(orc::Quat{refToNew7[6], refToNew7[3], refToNew7[4], refToNew7[5]});
   double Rd[9], RKid[9];
   orc::qToR(T.q, Rd);
   orc::mat3mul(Rd, Ki9, RKid);

@@ -43,7 +43,7 @@ int orc_write_result_txt(const char* path, int n, const double* timestamps, cons
   std::ofstream out(path);
   if (!out) return -1;
   out << std::setprecision(15);
-  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qnormalize(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
+  auto from7 = [](const double* p) { orc::SE3 T; T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2]; T.q = orc::qimport(orc::Quat{p[6], p[3], p[4], p[5]}); return T; };
   const orc::SE3 firstInv = orc::se3Inv(from7(firstPose7));
   for (int i = 0; i < n; i++) {
     if (pose_valid && !pose_valid[i]) continue;

@@ -40,6 +40,13 @@ inline Quat qnormalize(const Quat& a) {
   return Quat{a.w / n, a.x / n, a.y / n, a.z / n};
 }
 inline Quat qconj(const Quat& a) { return Quat{a.w, -a.x, -a.y, -a.z}; }
+// Import of a quaternion across the test / C boundary: one that is unit already to rounding (a pose exported by a running system, whose
+// SE3 normalises after every product) keeps its bits; anything else is normalised like Sophus' constructors do.  Normalising twice moves
+// last bits, which the sliding-window solve amplifies (condition ~1e10) — see poseFrom7 in dm-vio_amd/csrc/lie_dev.h.
+inline Quat qimport(const Quat& q) {
+  const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  return (std::fabs(n2 - 1.0) <= 1e-14) ? q : qnormalize(q);
+}
 
 // Eigen QuaternionBase::toRotationMatrix
 inline void qToR(const Quat& q, double R[9]) {

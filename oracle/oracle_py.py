@@ -338,6 +338,9 @@ def _ba_sig(L):
     L.orc_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
     L.orc_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
     L.orc_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.orc_ba_set_frame_zero.argtypes = [vp, C.c_int, c_d]
+    L.orc_ba_set_frame_energy_th.argtypes = [vp, c_f]
+    L.orc_ba_set_calib_values.argtypes = [vp, c_d, c_d]
     L.orc_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
     L.orc_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int]
     L.orc_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
@@ -378,9 +381,9 @@ class BAWindow:
     def __init__(self, case, poses=None, idepth=None, threads=1):
         self.L = lib(); _ba_sig(self.L)
         self.case = case
-        # the reference's calibration is born as float (globalCalib.cpp:79-82: fxG[0] = K(0,0) ...) and only then widened to the double
-        # CalibHessian::value_scaled (HessianBlocks.h:326-330): the window starts from the float-rounded intrinsics
-        K4 = np.ascontiguousarray(np.asarray(case["K4"], dtype=np.float32), dtype=np.float64)
+        # CalibHessian::value_scaled (double).  Note that the reference's calibration is BORN as float (globalCalib.cpp:79-82) — synthetic
+        # cases use float-exact intrinsics (dmvio_amd.synth.default_intrinsics) — but is a genuine double once the optimiser has moved it
+        K4 = np.ascontiguousarray(case["K4"], dtype=np.float64)
         self.p = C.c_void_p(self.L.orc_ba_create(case["w"], case["h"], _d(K4)))
         self.L.orc_ba_set_threads(self.p, threads)
         self._dI = case["dI0"] if case.get("dI0") is not None else [make_images(img, case["w"], case["h"])[0][0] for img in case["imgs"]]
@@ -408,6 +411,15 @@ class BAWindow:
 
     def set_frame_state(self, k, state10):
         self.L.orc_ba_set_frame_state(self.p, k, _d(np.ascontiguousarray(state10, dtype=np.float64)))
+
+    def set_frame_zero(self, k, state_zero10):
+        self.L.orc_ba_set_frame_zero(self.p, k, _d(np.ascontiguousarray(state_zero10, dtype=np.float64)))
+
+    def set_frame_energy_th(self, th):
+        self.L.orc_ba_set_frame_energy_th(self.p, _f(np.ascontiguousarray(th, dtype=np.float32)))
+
+    def set_calib_values(self, value4, value_zero4):
+        self.L.orc_ba_set_calib_values(self.p, _d(np.ascontiguousarray(value4, dtype=np.float64)), _d(np.ascontiguousarray(value_zero4, dtype=np.float64)))
 
     def perturb_frame(self, k, d8):
         self.L.orc_ba_perturb_frame(self.p, k, _d(np.ascontiguousarray(d8, dtype=np.float64)))

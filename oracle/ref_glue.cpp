@@ -62,7 +62,10 @@ namespace
 SE3 se3From7(const double* p)
 {
 	Sophus::Quaterniond_ q(p[6], p[3], p[4], p[5]);
-	return SE3(q, Vec3(p[0], p[1], p[2]));
+	SE3 T(q, Vec3(p[0], p[1], p[2]));   // normalises, like Sophus
+	// a quaternion that is unit already (exported from a running system) keeps its bits — see poseFrom7 in dm-vio_amd/csrc/lie_dev.h
+	if (std::fabs(q.squaredNorm() - 1.0) <= 1e-14) T.so3().setQuaternionRaw(q);
+	return T;
 }
 void se3To7(const SE3& T, double* p)
 {
@@ -320,6 +323,7 @@ struct RefTracker
 void* ref_tracker_create(int w, int h, const float K4[4])
 {
 	setCalib(w, h, K4);
+	setting_debugout_runquiet = true;   // CoarseTracker::trackNewestCoarse prints every LM iteration otherwise (debugPrint)
 	RefTracker* T = new RefTracker();
 	T->w = w; T->h = h;
 	T->HCalib = new CalibHessian();
@@ -528,6 +532,11 @@ void* ref_ba_create(int w, int h, const double fxfycxcy[4])
 	RefWindow* W = new RefWindow();
 	W->fs = new FullSystem(true, g_imuCalib, g_imuSettings);
 	W->fs->coarseTrackingLog = 0;
+	// the calibration of a window taken over from a running system is a genuine double (the optimiser has moved it); a fresh one is float-exact
+	VecC vs; vs << fxfycxcy[0], fxfycxcy[1], fxfycxcy[2], fxfycxcy[3];
+	W->fs->Hcalib.setValueScaled(vs);
+	W->fs->Hcalib.value_zero = W->fs->Hcalib.value;
+	W->fs->Hcalib.value_minus_value_zero.setZero();
 	return W;
 }
 void ref_ba_destroy(void* p)
@@ -583,6 +592,24 @@ void ref_ba_set_frame_state(void* p, int fidx, const double state10[10])
 	FullSystem* fs = ((RefWindow*)p)->fs;
 	Vec10 st; for (int i = 0; i < 10; i++) st[i] = state10[i];
 	fs->frameHessians[fidx]->setState(st);
+	fs->setPrecalcValues();   // -> ef->setDeltaF: delta, delta_prior of every frame
+}
+// replay of recorded windows: FrameHessian::setStateZero, frameEnergyTH, CalibHessian::value_zero
+void ref_ba_set_frame_zero(void* p, int fidx, const double state_zero10[10])
+{
+	FullSystem* fs = ((RefWindow*)p)->fs; FrameHessian* fh = fs->frameHessians[fidx];
+	Vec10 st; for (int i = 0; i < 10; i++) st[i] = state_zero10[i];
+	fh->setStateZero(st);
+	fh->efFrame->takeData();
+	fs->setPrecalcValues();
+}
+void ref_ba_set_frame_energy_th(void* p, const float* th) { FullSystem* fs = ((RefWindow*)p)->fs; for (size_t i = 0; i < fs->frameHessians.size(); i++) fs->frameHessians[i]->frameEnergyTH = th[i]; }
+void ref_ba_set_calib_values(void* p, const double value[4], const double value_zero[4])
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	VecC v; v << value[0], value[1], value[2], value[3];
+	for (int i = 0; i < 4; i++) fs->Hcalib.value_zero[i] = value_zero[i];
+	fs->Hcalib.setValue(v);   // value_scaled, value_scaledf / i, value_minus_value_zero
 	fs->setPrecalcValues();
 }
 // a point as activatePointsMT leaves it (PointHessian from an ImmaturePoint at (u,v), status ACTIVE, inserted into the energy
@@ -846,6 +873,248 @@ void ref_ba_marginalize_frame(void* p, int idx, double* HMn, double* bMn)
 	FrameHessian* fh = fs->frameHessians[idx];
 	fs->ef->marginalizeFrame(fh->efFrame);
 	copyOut(fs->ef->HM, fs->ef->bM, HMn, bMn);
+}
+
+// ================================================================================================= the whole visual-only FullSystem
+// The reference's pipeline, unmodified, frame by frame (FullSystem::addActiveFrame, FullSystem.cpp:882-1123, non-realtime mode
+// linearizeOperation = true as dmvio_dataset runs with preset=0): initializer, coarse tracking, keyframe decision, point activation,
+// sliding-window optimisation, marginalisation.  The profiler scopes the reference puts around its stages (see ref_timing.cpp) are used
+// to RECORD what goes into and comes out of trackNewCoarse, optimize and setCoarseTrackingRef, so that tests can replay exactly those
+// calls through the oracle and through the HIP library and compare with what the reference itself produced.
+extern "C" void (*ref_scope_hook)(const char* name, int phase);
+
+struct RefEvent
+{
+	int kind;   // 1 setref, 2 track_in, 3 track_out, 4 opt_in, 5 opt_out
+	std::vector<double> d;
+	std::vector<float> f;
+	std::vector<int> i;
+};
+struct RefSystem
+{
+	FullSystem* fs = nullptr;
+	int w = 0, h = 0;
+	std::vector<RefEvent> events;
+	bool record = true;
+};
+static RefSystem* g_sys = nullptr;
+
+static void pushPose(std::vector<double>& d, const SE3& T) { double p[7]; se3To7(T, p); d.insert(d.end(), p, p + 7); }
+
+static void snapshotSetRef(RefSystem* S)
+{
+	FullSystem* fs = S->fs;
+	RefEvent e; e.kind = 1;
+	FrameHessian* lastRef = fs->frameHessians.back();
+	e.i.push_back(lastRef->shell->id);
+	e.d.push_back(lastRef->ab_exposure); e.d.push_back(lastRef->aff_g2l().a); e.d.push_back(lastRef->aff_g2l().b);
+	for (int k = 0; k < 4; k++) e.d.push_back(fs->Hcalib.value_scaledf[k]);   // what makeK reads (CoarseTracker.cpp:110-113)
+	// the points makeCoarseDepthL0 reads (CoarseTracker.cpp:144-161), in its iteration order
+	for (FrameHessian* fh : fs->frameHessians)
+		for (PointHessian* ph : fh->pointHessians)
+			if (ph->lastResiduals[0].first != 0 && ph->lastResiduals[0].second == ResState::IN)
+			{
+				PointFrameResidual* r = ph->lastResiduals[0].first;
+				e.f.push_back(r->centerProjectedTo[0]); e.f.push_back(r->centerProjectedTo[1]); e.f.push_back(r->centerProjectedTo[2]); e.f.push_back(ph->efPoint->HdiF);
+			}
+	S->events.push_back(e);
+}
+static void snapshotTrack(RefSystem* S, bool entry)
+{
+	FullSystem* fs = S->fs;
+	RefEvent e; e.kind = entry ? 2 : 3;
+	const int n = (int)fs->allFrameHistory.size();
+	FrameShell* cur = fs->allFrameHistory[n - 1];
+	e.i.push_back(cur->id);
+	e.i.push_back(fs->coarseTracker->refFrameID);
+	if (entry)
+	{
+		FrameHessian* lastF = fs->coarseTracker->lastRef;
+		e.i.push_back(n);
+		if (n == 2) { pushPose(e.d, SE3()); pushPose(e.d, SE3()); }
+		else { pushPose(e.d, fs->allFrameHistory[n - 2]->camToWorld); pushPose(e.d, fs->allFrameHistory[n - 3]->camToWorld); }
+		pushPose(e.d, lastF->shell->camToWorld);
+		FrameShell* slast = n >= 3 ? fs->allFrameHistory[n - 2] : lastF->shell;
+		e.d.push_back(n >= 3 ? slast->aff_g2l.a : 0.0); e.d.push_back(n >= 3 ? slast->aff_g2l.b : 0.0);
+		for (int k = 0; k < 5; k++) e.d.push_back(fs->lastCoarseRMSE[k]);
+		e.d.push_back(setting_reTrackThreshold);
+		e.i.push_back((n >= 3 && fs->allFrameHistory[n - 2]->poseValid && fs->allFrameHistory[n - 3]->poseValid && lastF->shell->poseValid) ? 1 : 0);
+	}
+	else
+	{
+		pushPose(e.d, cur->camToTrackingRef.inverse());   // lastF_2_fh of the winning try
+		e.d.push_back(cur->aff_g2l.a); e.d.push_back(cur->aff_g2l.b);
+		for (int k = 0; k < 5; k++) e.d.push_back(fs->lastCoarseRMSE[k]);
+		for (int k = 0; k < 5; k++) e.d.push_back(fs->coarseTracker->lastResiduals[k]);
+		for (int k = 0; k < 3; k++) e.d.push_back(fs->coarseTracker->lastFlowIndicators[k]);
+		e.i.push_back(cur->trackingWasGood ? 1 : 0);
+	}
+	S->events.push_back(e);
+}
+static void snapshotOptimize(RefSystem* S, bool entry)
+{
+	FullSystem* fs = S->fs;
+	RefEvent e; e.kind = entry ? 4 : 5;
+	const int F = (int)fs->frameHessians.size();
+	e.i.push_back(F);
+	for (int k = 0; k < 4; k++) e.d.push_back(fs->Hcalib.value_scaled[k]);
+	for (int k = 0; k < 4; k++) e.d.push_back(fs->Hcalib.value_zero[k]);
+	for (int k = 0; k < 4; k++) e.d.push_back(fs->Hcalib.value[k]);
+	for (FrameHessian* fh : fs->frameHessians)
+	{
+		e.i.push_back(fh->shell->id); e.i.push_back(fh->frameID); e.i.push_back(fh->flaggedForMarginalization ? 1 : 0);
+		pushPose(e.d, fh->get_worldToCam_evalPT());
+		pushPose(e.d, fh->PRE_worldToCam);
+		for (int k = 0; k < 10; k++) e.d.push_back(fh->get_state()[k]);
+		for (int k = 0; k < 10; k++) e.d.push_back(fh->get_state_zero()[k]);
+		e.d.push_back(fh->ab_exposure); e.d.push_back(fh->frameEnergyTH);
+	}
+	if (entry)
+	{
+		const int n = CPARS + 8 * F;
+		for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) e.d.push_back(fs->ef->HM(r, c));
+		for (int r = 0; r < n; r++) e.d.push_back(fs->ef->bM[r]);
+	}
+	else
+	{
+		e.d.push_back(fs->statistics_lastFineTrackRMSE);
+		e.d.push_back(fs->ef->resInA);
+	}
+	int np_ = 0, nr = 0;
+	std::map<FrameHessian*, int> fidx;
+	for (int k = 0; k < F; k++) fidx[fs->frameHessians[k]] = k;
+	// points in the order of EnergyFunctional::allPoints (makeIDX, EnergyFunctional.cpp:997-1017: frames, then EFFrame::points) — the order
+	// the fp32 accumulators see them in; FrameHessian::pointHessians holds the same points, possibly permuted by its own swap-deletes
+	for (EFFrame* eff : fs->ef->frames)
+		for (EFPoint* efp : eff->points)
+		{
+			PointHessian* ph = efp->data;
+			e.i.push_back(fidx[ph->host]); e.i.push_back(ph->hasDepthPrior ? 1 : 0); e.i.push_back((int)ph->efPoint->residualsAll.size()); e.i.push_back(ph->numGoodResiduals);
+			e.f.push_back(ph->u); e.f.push_back(ph->v); e.f.push_back(ph->idepth); e.f.push_back(ph->idepth_zero);
+			for (int k = 0; k < 8; k++) e.f.push_back(ph->color[k]);
+			for (int k = 0; k < 8; k++) e.f.push_back(ph->weights[k]);
+			e.f.push_back(ph->idepth_hessian); e.f.push_back(ph->maxRelBaseline);
+			// in the order of EFPoint::residualsAll — the order the accumulators add them in (AccumulatedTopHessian.cpp:57, AccumulatedSCHessian.cpp:53);
+			// PointHessian::residuals holds the same residuals, possibly permuted by its own swap-deletes
+			for (EFResidual* er : ph->efPoint->residualsAll)
+			{
+				PointFrameResidual* r = er->data;
+				e.i.push_back(fidx[r->target]); e.i.push_back((int)r->state_state); e.i.push_back(er->isLinearized ? 1 : 0);
+				e.i.push_back(er->isActive() ? 1 : 0);
+				nr++;
+			}
+			np_++;
+		}
+	e.i.insert(e.i.begin() + 1, np_);
+	e.i.insert(e.i.begin() + 2, nr);
+	S->events.push_back(e);
+}
+static void scopeHook(const char* name, int phase)
+{
+	RefSystem* S = g_sys;
+	if (!S || !S->record) return;
+	if (!strcmp(name, "makeKeyframeChangeTrackingRef") && phase > 0) snapshotSetRef(S);
+	else if (!strcmp(name, "FullSystem::trackNewCoarseNoIMU")) snapshotTrack(S, phase > 0);
+	else if (!strcmp(name, "FullSystemOptimize") && S->fs->frameHessians.size() >= 2) snapshotOptimize(S, phase > 0);
+}
+
+// settings as dmvio_dataset's preset=0 leaves them (util/MainSettings.cpp:206-231) unless overridden; useimu=0
+void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensity, int maxFrames, int maxOptIterations, int minOptIterations)
+{
+	setCalib(w, h, K4);
+	setting_useIMU = false; setting_useGTSAMIntegration = false;
+	setting_logStuff = false;
+	multiThreading = false;
+	setting_debugout_runquiet = true;
+	setting_desiredPointDensity = desiredPointDensity > 0 ? desiredPointDensity : 1000;
+	setting_desiredImmatureDensity = desiredPointDensity > 0 ? desiredPointDensity * 1.5f : 1500;
+	setting_minFrames = 5;
+	setting_maxFrames = maxFrames > 0 ? maxFrames : 7;
+	setting_maxOptIterations = maxOptIterations > 0 ? maxOptIterations : 6;
+	setting_minOptIterations = minOptIterations > 0 ? minOptIterations : 1;
+	setting_affineOptModeA = 1e12; setting_affineOptModeB = 1e8;
+	setting_photometricCalibration = 0;   // no gamma / vignette: the synthetic images are irradiance already
+	RefSystem* S = new RefSystem();
+	S->w = w; S->h = h;
+	StdoutCapture cap;
+	S->fs = new FullSystem(true, g_imuCalib, g_imuSettings);
+	cap.finish();
+	S->fs->coarseTrackingLog = 0;
+	g_sys = S;
+	ref_scope_hook = scopeHook;
+	return S;
+}
+void ref_system_destroy(void* p)
+{
+	RefSystem* S = (RefSystem*)p;
+	if (g_sys == S) { g_sys = nullptr; ref_scope_hook = nullptr; }
+	FullSystem* fs = S->fs;
+	std::vector<FrameHessian*> frames = fs->frameHessians;
+	fs->frameHessians.clear();
+	StdoutCapture cap;
+	delete fs;
+	for (FrameHessian* fh : frames)
+	{
+		for (PointHessian* ph : fh->pointHessians) { ph->efPoint = 0; delete ph; }
+		for (PointHessian* ph : fh->pointHessiansMarginalized) { ph->efPoint = 0; delete ph; }
+		for (PointHessian* ph : fh->pointHessiansOut) { ph->efPoint = 0; delete ph; }
+		for (ImmaturePoint* ip : fh->immaturePoints) delete ip;
+		fh->pointHessians.clear(); fh->pointHessiansMarginalized.clear(); fh->pointHessiansOut.clear(); fh->immaturePoints.clear();
+		fh->efFrame = 0;
+		delete fh;
+	}
+	cap.finish();
+	delete S;
+}
+// FullSystem::addActiveFrame.  status out: [initialized, isLost, initFailed, n keyframes in the window, n frames so far]
+int ref_system_add_frame(void* p, const float* img, float exposure, double timestamp, int id, int* status5, char* log, int logcap)
+{
+	RefSystem* S = (RefSystem*)p;
+	g_sys = S; ref_scope_hook = scopeHook;
+	ImageAndExposure* im = new ImageAndExposure(S->w, S->h, timestamp);
+	memcpy(im->image, img, sizeof(float) * S->w * S->h);
+	im->exposure_time = exposure;
+	StdoutCapture cap;
+	S->fs->addActiveFrame(im, id, nullptr, nullptr);
+	std::string out = cap.finish();
+	delete im;
+	if (log && logcap > 0) { int n = std::min((int)out.size(), logcap - 1); memcpy(log, out.data(), n); log[n] = 0; }
+	status5[0] = S->fs->initialized ? 1 : 0; status5[1] = S->fs->isLost ? 1 : 0; status5[2] = S->fs->initFailed ? 1 : 0;
+	status5[3] = (int)S->fs->frameHessians.size(); status5[4] = (int)S->fs->allFrameHistory.size();
+	return 0;
+}
+// camToWorld of every frame so far (allFrameHistory order), with poseValid / keyframe id / tracking reference id
+int ref_system_get_trajectory(void* p, double* pose7, int* valid, int* keyframeId, int* trackingRefId, double* aff2)
+{
+	RefSystem* S = (RefSystem*)p;
+	int n = 0;
+	for (FrameShell* s : S->fs->allFrameHistory)
+	{
+		se3To7(s->camToWorld, pose7 + 7 * n);
+		valid[n] = s->poseValid ? 1 : 0; keyframeId[n] = s->keyframeId; trackingRefId[n] = s->trackingRef ? s->trackingRef->id : -1;
+		aff2[2 * n] = s->aff_g2l.a; aff2[2 * n + 1] = s->aff_g2l.b;
+		n++;
+	}
+	return n;
+}
+// FullSystem::printResult (FullSystem.cpp:256-298)
+void ref_system_print_result(void* p, const char* path, int onlyLogKFPoses, int useCamToTrackingRef)
+{
+	RefSystem* S = (RefSystem*)p;
+	S->fs->printResult(path, onlyLogKFPoses != 0, false, useCamToTrackingRef != 0);
+}
+int ref_system_n_events(void* p) { return (int)((RefSystem*)p)->events.size(); }
+void ref_system_event_sizes(void* p, int k, int* kind, int* nd, int* nf, int* ni)
+{
+	const RefEvent& e = ((RefSystem*)p)->events[k];
+	*kind = e.kind; *nd = (int)e.d.size(); *nf = (int)e.f.size(); *ni = (int)e.i.size();
+}
+void ref_system_event_data(void* p, int k, double* d, float* f, int* i)
+{
+	const RefEvent& e = ((RefSystem*)p)->events[k];
+	if (!e.d.empty()) memcpy(d, e.d.data(), sizeof(double) * e.d.size());
+	if (!e.f.empty()) memcpy(f, e.f.data(), sizeof(float) * e.f.size());
+	if (!e.i.empty()) memcpy(i, e.i.data(), sizeof(int) * e.i.size());
 }
 
 }  // extern "C"

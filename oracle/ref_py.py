@@ -246,6 +246,9 @@ def _ba_sig(L):
     L.ref_ba_add_frame.argtypes = [vp, c_d, C.c_double, C.c_double, C.c_float, C.c_int, c_f]
     L.ref_ba_perturb_frame.argtypes = [vp, C.c_int, c_d]
     L.ref_ba_set_frame_state.argtypes = [vp, C.c_int, c_d]
+    L.ref_ba_set_frame_zero.argtypes = [vp, C.c_int, c_d]
+    L.ref_ba_set_frame_energy_th.argtypes = [vp, c_f]
+    L.ref_ba_set_calib_values.argtypes = [vp, c_d, c_d]
     L.ref_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int, c_f, c_f]
     L.ref_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
     L.ref_ba_finalize.argtypes = [vp]
@@ -318,6 +321,15 @@ class BAWindow:
 
     def set_frame_state(self, k, state10):
         self.L.ref_ba_set_frame_state(self.p, k, _d(_f64(state10)))
+
+    def set_frame_zero(self, k, state_zero10):
+        self.L.ref_ba_set_frame_zero(self.p, k, _d(_f64(state_zero10)))
+
+    def set_frame_energy_th(self, th):
+        self.L.ref_ba_set_frame_energy_th(self.p, _f(_f32(th)))
+
+    def set_calib_values(self, value4, value_zero4):
+        self.L.ref_ba_set_calib_values(self.p, _d(_f64(value4)), _d(_f64(value_zero4)))
 
     def perturb_frame(self, k, d8):
         self.L.ref_ba_perturb_frame(self.p, k, _d(_f64(d8)))
@@ -425,3 +437,96 @@ class BAWindow:
         H = np.zeros((n, n)); b = np.zeros(n)
         self.L.ref_ba_marginalize_frame(self.p, k, _d(H), _d(b))
         return H, b
+
+
+# ------------------------------------------------------------------------------------------------------------ the whole FullSystem
+class System:
+    """The reference's visual-only FullSystem, frame by frame (FullSystem::addActiveFrame), with the inputs / outputs of its
+    trackNewCoarse, optimize and setCoarseTrackingRef calls recorded (see oracle/ref_glue.cpp, oracle/ref_timing.cpp)."""
+
+    def __init__(self, w, h, K4, point_density=1000, max_frames=7, max_opt_its=6, min_opt_its=1):
+        self.L = lib(); L = self.L
+        L.ref_system_create.restype = vp
+        L.ref_system_create.argtypes = [C.c_int, C.c_int, c_f, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.ref_system_destroy.argtypes = [vp]
+        L.ref_system_add_frame.argtypes = [vp, c_f, C.c_float, C.c_double, C.c_int, c_i, C.c_char_p, C.c_int]
+        L.ref_system_get_trajectory.argtypes = [vp, c_d, c_i, c_i, c_i, c_d]
+        L.ref_system_print_result.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.ref_system_n_events.argtypes = [vp]
+        L.ref_system_event_sizes.argtypes = [vp, C.c_int, c_i, c_i, c_i, c_i]
+        L.ref_system_event_data.argtypes = [vp, C.c_int, c_d, c_f, c_i]
+        self.w, self.h = w, h
+        self.K4 = _f32(K4)
+        self.p = vp(L.ref_system_create(w, h, _f(self.K4), point_density, max_frames, max_opt_its, min_opt_its))
+        self.n = 0
+        self.logs = []
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.ref_system_destroy(self.p); self.p = None
+
+    def add_frame(self, img, exposure=1.0, timestamp=None):
+        st = np.zeros(5, np.int32); buf = C.create_string_buffer(1 << 16)
+        self.L.ref_system_add_frame(self.p, _f(_f32(img).reshape(-1)), exposure, float(self.n * 0.05 if timestamp is None else timestamp), self.n, st.ctypes.data_as(c_i), buf, len(buf))
+        self.n += 1
+        self.logs.append(buf.value.decode(errors="replace"))
+        return dict(initialized=bool(st[0]), isLost=bool(st[1]), initFailed=bool(st[2]), window=int(st[3]), frames=int(st[4]))
+
+    def trajectory(self):
+        n = self.n
+        P = np.zeros((n, 7)); v = np.zeros(n, np.int32); kf = np.zeros(n, np.int32); tr = np.zeros(n, np.int32); aff = np.zeros((n, 2))
+        m = self.L.ref_system_get_trajectory(self.p, _d(P), v.ctypes.data_as(c_i), kf.ctypes.data_as(c_i), tr.ctypes.data_as(c_i), _d(aff))
+        return dict(camToWorld=P[:m], valid=v[:m], keyframeId=kf[:m], trackingRef=tr[:m], aff=aff[:m])
+
+    def print_result(self, path, only_kf=False, use_cam_to_tracking_ref=True):
+        self.L.ref_system_print_result(self.p, str(path).encode(), 1 if only_kf else 0, 1 if use_cam_to_tracking_ref else 0)
+
+    def events(self):
+        """The recorded calls, decoded into dictionaries (kinds: setref, track_in, track_out, opt_in, opt_out)."""
+        out = []
+        for k in range(self.L.ref_system_n_events(self.p)):
+            kind = C.c_int(0); nd = C.c_int(0); nf = C.c_int(0); ni = C.c_int(0)
+            self.L.ref_system_event_sizes(self.p, k, C.byref(kind), C.byref(nd), C.byref(nf), C.byref(ni))
+            d = np.zeros(max(nd.value, 1)); f = np.zeros(max(nf.value, 1), np.float32); i = np.zeros(max(ni.value, 1), np.int32)
+            self.L.ref_system_event_data(self.p, k, _d(d), _f(f), i.ctypes.data_as(c_i))
+            out.append(decode_event(kind.value, d[:nd.value], f[:nf.value], i[:ni.value]))
+        return out
+
+
+def decode_event(kind, d, f, i):
+    if kind == 1:
+        pts = f.reshape(-1, 4)
+        return dict(kind="setref", ref_id=int(i[0]), exposure=float(d[0]), aff=d[1:3].copy(), K4=d[3:7].copy(), u=pts[:, 0].copy(), v=pts[:, 1].copy(), idepth=pts[:, 2].copy(), hdiF=pts[:, 3].copy())
+    if kind == 2:
+        return dict(kind="track_in", frame_id=int(i[0]), ref_id=int(i[1]), n_history=int(i[2]), poses_valid=bool(i[3]), slast_c2w=d[0:7].copy(), sprelast_c2w=d[7:14].copy(),
+                    lastF_c2w=d[14:21].copy(), aff_last=d[21:23].copy(), lastCoarseRMSE=d[23:28].copy(), reTrackThreshold=float(d[28]))
+    if kind == 3:
+        return dict(kind="track_out", frame_id=int(i[0]), ref_id=int(i[1]), good=bool(i[2]), refToNew=d[0:7].copy(), aff=d[7:9].copy(), lastCoarseRMSE=d[9:14].copy(),
+                    lastResiduals=d[14:19].copy(), flow=d[19:22].copy())
+    F, N, Rn = int(i[0]), int(i[1]), int(i[2])
+    e = dict(kind="opt_in" if kind == 4 else "opt_out", F=F, N=N, R=Rn, calib=d[0:4].copy(), calib_zero=d[4:8].copy(), calib_value=d[8:12].copy())
+    o = 12; ii = 3
+    fr = []
+    for k in range(F):
+        fr.append(dict(shell_id=int(i[ii]), frameID=int(i[ii + 1]), flagged=bool(i[ii + 2]), evalPT=d[o:o + 7].copy(), w2c=d[o + 7:o + 14].copy(), state=d[o + 14:o + 24].copy(),
+                       state_zero=d[o + 24:o + 34].copy(), exposure=float(d[o + 34]), frameEnergyTH=float(d[o + 35])))
+        o += 36; ii += 3
+    e["frames"] = fr
+    n = 4 + 8 * F
+    if kind == 4:
+        e["HM"] = d[o:o + n * n].reshape(n, n).copy(); o += n * n
+        e["bM"] = d[o:o + n].copy(); o += n
+    else:
+        e["rmse"] = float(d[o]); e["resInA"] = int(d[o + 1]); o += 2
+    host = np.zeros(N, np.int32); prior = np.zeros(N, np.uint8); nres = np.zeros(N, np.int32); ngood = np.zeros(N, np.int32)
+    pf = f.reshape(N, 22) if N else np.zeros((0, 22), np.float32)
+    rp, rt, rs, rl, ra = [], [], [], [], []
+    for p_ in range(N):
+        host[p_], prior[p_], nres[p_], ngood[p_] = i[ii], i[ii + 1], i[ii + 2], i[ii + 3]; ii += 4
+        for _ in range(nres[p_]):
+            rp.append(p_); rt.append(int(i[ii])); rs.append(int(i[ii + 1])); rl.append(int(i[ii + 2])); ra.append(int(i[ii + 3])); ii += 4
+    e.update(host=host, hasDepthPrior=prior, numGoodResiduals=ngood, u=pf[:, 0].copy(), v=pf[:, 1].copy(), idepth=pf[:, 2].copy(), idepth_zero=pf[:, 3].copy(),
+             color=pf[:, 4:12].copy(), weights=pf[:, 12:20].copy(), idepth_hessian=pf[:, 20].copy(), maxRelBaseline=pf[:, 21].copy(),
+             res_point=np.array(rp, np.int32), res_target=np.array(rt, np.int32), res_state=np.array(rs, np.int32), res_linearized=np.array(rl, np.int32),
+             res_active=np.array(ra, np.int32))
+    return e

@@ -102,6 +102,7 @@ public:
 	Vector3d_ operator*(const Vector3d_& p) const { return q_ * p; }
 	const Quaterniond_& unit_quaternion() const { return q_; }
 	void setQuaternion(const Quaterniond_& q) { q_ = q.normalized(); }
+	void setQuaternionRaw(const Quaterniond_& q) { q_ = q; }   // stand-in only: takes a unit quaternion over bit for bit (test glue)
 	static Matrix3d_ hat(const Vector3d_& o)
 	{
 		Matrix3d_ O;

@@ -529,7 +529,7 @@ void orc_tracker_get_idepth(void* p, int lvl, float* idepth, float* weightSums) 
 }
 static SE3 poseFrom7(const double p7[7]) {  // tx ty tz qx qy qz qw
   SE3 T; T.t[0] = p7[0]; T.t[1] = p7[1]; T.t[2] = p7[2];
-  T.q = qnormalize(Quat{p7[6], p7[3], p7[4], p7[5]});
+  T.q = qimport(Quat{p7[6], p7[3], p7[4], p7[5]});
   return T;
 }
 static void poseTo7(const SE3& T, double p7[7]) {
@@ -580,7 +580,7 @@ int orc_make_track_hypotheses(const double slast_c2w[7], const double sprelast_c
   { double lg[6]; se3Log(fh_2_slast, lg); for (int i = 0; i < 6; i++) lg[i] *= 0.5; tries.push_back(se3Mul(se3Inv(se3Exp(lg)), lastF_2_slast)); }
   tries.push_back(lastF_2_slast);
   tries.push_back(SE3());
-  const double d = 0.02;
+  const double d = (double)0.02f;   // `float rotDelta=0.02` widened by Sophus::Quaterniond (FullSystem.cpp:376)
   const double rot[26][3] = {{d,0,0},{0,d,0},{0,0,d},{-d,0,0},{0,-d,0},{0,0,-d},{d,d,0},{0,d,d},{d,0,d},{-d,d,0},{0,-d,d},{-d,0,d},{d,-d,0},{0,d,-d},{d,0,-d},
                              {-d,-d,0},{0,-d,-d},{-d,0,-d},{-d,-d,-d},{-d,-d,d},{-d,d,-d},{-d,d,d},{d,-d,-d},{d,-d,d},{d,d,-d},{d,d,d}};
   SE3 base = se3Mul(fhInv, lastF_2_slast);
