@@ -592,13 +592,21 @@ class ImmaturePointsHip:
 class BundleAdjusterHip:
     """The sliding window FullSystem::optimize works on, over the C ABI (include/dmvio_hip.h, "sliding-window BA")."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, accumulators=None, keep_jacobians=False):
+        """accumulators: partial accumulators per bucket (1 = the reference's single-threaded order, bit for bit; None = library default, 4);
+        keep_jacobians: materialise the 74-float RawResidualJacobian per residual for jacobians()."""
         self.ctx = ctx
         self.L = ctx.L
         p = self.L.dmvio_hip_ba_create(ctx.p)
         if not p:
             raise HipLibraryError("ba_create: " + (self.L.dmvio_hip_last_error() or b"").decode())
         self.p = C.c_void_p(p)
+        if accumulators is not None:
+            fn = self.L.dmvio_hip_ba_set_accumulators; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+            _chk(self.L, fn(self.p, int(accumulators)), "ba_set_accumulators")
+        if keep_jacobians:
+            fn = self.L.dmvio_hip_ba_keep_jacobians; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+            _chk(self.L, fn(self.p, 1), "ba_keep_jacobians")
 
     def close(self):
         if getattr(self, "p", None):

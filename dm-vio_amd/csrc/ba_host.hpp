@@ -38,6 +38,7 @@ struct BAFrameHost {
   Pose evalPT, w2c, c2w;
   double state[10], state_zero[10], state_scaled[10], step[10], state_backup[10];
   float ab_exposure = 1, frameEnergyTH = 8 * 8 * 8;
+  unsigned long long zero_stamp = 0;   // changes whenever frameSetStateZero recomputed this frame's nullspaces
   int frameID = 0, slot = 0;
   double ns_pose[6][6], ns_scale[6];
   double prior[8], delta[8], delta_prior[8];
@@ -59,6 +60,7 @@ struct BAHost {
   std::vector<std::vector<double>> orthoBasis;   // unit left singular vectors of the nullspace matrix above the cut (prepareOrthogonalize)
   std::vector<double> bPriorM, hfScratch, htScratch;   // bM + HM * delta (prepareSolve); scratch of solveSystem
   bool solvePrepared = false;
+  unsigned long long orthoKey = 0;
   int resInA = 0;
 
   void calibSetValue(const double v[4]) {
@@ -83,6 +85,7 @@ struct BAHost {
   }
   static void frameSetStateZero(BAFrameHost& f, const double st0[10]) {
     for (int i = 0; i < 10; i++) f.state_zero[i] = st0[i];
+    { static unsigned long long stamp = 0; f.zero_stamp = ++stamp; }   // the nullspaces below change: cached orthogonalisation bases are stale
     const Pose Tinv = poseInv(f.evalPT);
     for (int i = 0; i < 6; i++) {
       double ep[6] = {0, 0, 0, 0, 0, 0}, em[6] = {0, 0, 0, 0, 0, 0};
@@ -192,6 +195,12 @@ struct BAHost {
   // applies it.
   void prepareOrthogonalize() {
     const int nn = n(), m = 7;
+    {   // the basis is a function of the frames' nullspaces only (fixed while a window is optimised): rebuild it when one of them changed
+      unsigned long long key = (unsigned long long)F * 0x9E3779B97F4A7C15ull;
+      for (int f = 0; f < F; f++) key = key * 1099511628211ull + fr[f].zero_stamp;
+      if (key == orthoKey && !orthoBasis.empty()) return;
+      orthoKey = key;
+    }
     std::vector<std::vector<double>> U(m);
     for (int i = 0; i < m; i++) { double s = 0; for (double v : nsp[i]) s += v * v; s = std::sqrt(s); U[i] = nsp[i]; for (auto& v : U[i]) v /= s; }
     // G = U^T U (7x7), Jacobi eigenvalue iteration: G = V diag(s^2) V^T

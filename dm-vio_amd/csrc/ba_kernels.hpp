@@ -53,6 +53,13 @@ struct BAPrecalc {  // FrameFramePrecalc (HessianBlocks.h:80-107), the members l
   float KRKi[9], Kt[3], R0[9], t0[3], aff0, aff1, b0, pad;
 };
 
+// The members of BAPrecalc that change with every step of the GN loop (PRE_KRKiTll, PRE_KtTll, PRE_aff_mode) for the F*(F-1) ordered pairs
+// h != t, passed as kernel arguments: the loop's linearisations then need no table upload between the host's step and the launch (R0, t0,
+// b0 — functions of the evaluation point — stay in the device table of the last full upload).
+struct BAPreDyn { float v[BA_MAXF * (BA_MAXF - 1)][14]; };
+__host__ __device__ __forceinline__ int baPairIndex(const int h, const int t, const int F) { return h * (F - 1) + (t < h ? t : t - 1); }
+// back-substitution inputs: xc (4 floats) and xAd (F*F x 8 floats, index h*F + t; EnergyFunctional.cpp:280-282), passed as kernel arguments
+struct ResubArgs { float xc[4]; float xAd[BA_MAXF * BA_MAXF * 8]; };
 struct BAWindow {
   int F, w, h, N, R;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;  // CalibHessian::fxl().. / fxli()..
@@ -79,10 +86,156 @@ struct BARes {      // SoA, R entries
   unsigned char *state, *newState, *active, *which;  // which: buffer (0/1) holding the APPLIED record
   float *energy, *newEnergy, *newEnergyWO;
   float* center;   // R x 3 centerProjectedTo
+  const int* newestSlot;   // R: position of the residual among those that target the newest keyframe, or -1
+  float* newestE;          // state_NewEnergyWithOutlier of exactly those residuals, contiguous (what setNewFrameEnergyTH looks at)
   float* rec[2];   // R x REC_FLOATS
 };
 
 __constant__ int c_patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:296, pattern 8
+
+// ------------------------------------------------------------------------------------------------ device-side decisions
+// The GN loop of FullSystem::optimize (FullSystemOptimize.cpp:485-586) needs three small decisions after every linearisation: the energy
+// sum, the newest keyframe's outlier threshold (setNewFrameEnergyTH, :96-149: an nth_element over the residuals that target it) and
+// accept / reject.  They are taken by the LAST workgroup of the linearisation kernel to finish, so that the kernels that follow in the
+// stream (apply + per-point sums + accumulation + stitching when accepted, restore + relinearisation when rejected) can be enqueued
+// without the host in between; each of them starts by reading BACtl::accept and returns at once when it is not its turn.
+struct BACtl {
+  unsigned int cnt_lin;      // arrive counters of the last-workgroup patterns (reset by the last arrival)
+  unsigned int cnt_gather;
+  int accept;                // decision of the last accept test
+  int pad;
+};
+struct BAHostRes {           // host-coherent pinned memory, polled by the host
+  double E[2];               // [0] energy of the last plain / stepped-state linearisation, [1] of the relinearisation after a rejected step
+  float th[2];               // newest keyframe's threshold after each of them
+  int accept;
+  unsigned int ticket;       // published last (release, system scope) by the final kernel of a chain
+  int ticks[6];              // diagnostics: 100 MHz wall-clock ticks since the deciding workgroup started its own residuals: decision pass begin, energy
+                             // summed, threshold keys loaded, threshold selected (dmvio_hip_ba_last_decide_ticks)
+};
+struct BADecide {
+  const float* newestE;      // state_NewEnergyWithOutlier of the residuals that target the newest keyframe (BARes::newestE)
+  int n_newest, newestFrame;
+  float* frameTH;            // [BA_MAXF] FrameHessian::frameEnergyTH, device copy read by the linearisation
+  double* epart;             // per-workgroup energy partials
+  float thN, thFacMedian, thConstWeight, overallW, thCap;   // setting_frameEnergyTHN / FacMedian / ConstWeight, setting_overallEnergyTHWeight, IMU cap (<= 0: none)
+  int mode;                  // -1 no decision pass at all, 0 energy + threshold, 1 + accept test of a stepped state, 2 relinearisation after a rejected step
+  int update_th;
+  double lastE0, lastL, lastM, newL, newM;
+  BACtl* ctl;
+  BAHostRes* host;
+  unsigned int ticket;
+  int publish;               // this kernel is the last of its chain: store the ticket
+};
+enum { BA_GATE_ALWAYS = 0, BA_GATE_ACCEPTED = 1, BA_GATE_REJECTED = 2 };
+__device__ __forceinline__ bool baGateClosed(const BACtl* ctl, const int gate) {
+  if (gate == BA_GATE_ALWAYS) return false;
+  const int a = __hip_atomic_load(&ctl->accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return gate == BA_GATE_ACCEPTED ? a == 0 : a != 0;
+}
+#define BA_DECIDE_KEYS 4096
+// executed by all 256 threads of the last workgroup of a linearisation
+__device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nblocks, const long long t_start) {
+  __shared__ unsigned int s_keys[BA_DECIDE_KEYS];
+  __shared__ unsigned int s_scan[256];
+  __shared__ double s_red[256];
+  __shared__ unsigned int s_cnt, s_prefix, s_k;
+  __shared__ double s_E;
+  const int tid = threadIdx.x;
+  const long long tk0 = wall_clock64();
+  long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
+  // energy: every thread adds a contiguous run of the per-workgroup partials, the 256 runs are combined by a fixed pairwise tree — one fixed
+  // order for every launch (a single thread walking hundreds of partials would cost tens of microseconds of dependent loads)
+  {
+    const int chunk = (nblocks + 255) / 256;
+    double e = 0;
+    for (int i = tid * chunk; i < min((tid + 1) * chunk, nblocks); i++) e += __hip_atomic_load(D.epart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_red[tid] = e;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) s_red[tid] += s_red[tid + w]; __syncthreads(); }
+    if (tid == 0) s_E = s_red[0];
+  }
+  __syncthreads();
+  tk1 = wall_clock64();
+  float th = __hip_atomic_load(D.frameTH + D.newestFrame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (D.update_th) {
+    const int n = D.n_newest;
+    auto key = [&](const int i) -> unsigned int {
+      if (i < BA_DECIDE_KEYS) return s_keys[i];
+      const float v = __hip_atomic_load(D.newestE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return v >= 0 ? __float_as_uint(v) : 0xFFFFFFFFu;
+    };
+    unsigned int mine = 0;
+    for (int base = 0; base < n; base += 8 * 256) {   // eight independent loads per thread in flight (an atomic load per loop trip would serialise on its latency)
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const int i = base + q * 256 + tid; v[q] = i < n ? __hip_atomic_load(D.newestE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0f; }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int i = base + q * 256 + tid;
+        const unsigned int k = v[q] >= 0 ? __float_as_uint(v[q]) : 0xFFFFFFFFu;   // non-negative floats order like their bit patterns; skipped residuals sort last
+        if (i < n && i < BA_DECIDE_KEYS) s_keys[i] = k;
+        if (v[q] >= 0) mine++;
+      }
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    tk2 = wall_clock64();
+    const unsigned int m = s_cnt;
+    if (m == 0) th = 12 * 12 * 8;   // "should never happen, but lets make sure" (FullSystemOptimize.cpp:112-116)
+    else {
+      if (tid == 0) { s_prefix = 0; s_k = (unsigned int)(int)(D.thN * m); }   // nthIdx = setting_frameEnergyTHN * allResVec.size() (float product, truncated)
+      unsigned int mask = 0;
+      for (int shift = 24; shift >= 0; shift -= 8) {   // radix select: the nthIdx-th smallest key, 8 bits per pass
+        s_scan[tid] = 0;
+        __syncthreads();
+        const unsigned int prefix = s_prefix, kk = s_k;
+        for (int i = tid; i < n; i += 256) { const unsigned int k = key(i); if ((k & mask) == prefix) atomicAdd(&s_scan[(k >> shift) & 255u], 1u); }
+        __syncthreads();
+        // wavefront 0: lane l owns bins 4l..4l+3; inclusive scan over the lanes by six shuffles, then the bin whose range holds index kk
+        if (tid < 64) {
+          const unsigned int c0 = s_scan[4 * tid], c1 = s_scan[4 * tid + 1], c2 = s_scan[4 * tid + 2], c3 = s_scan[4 * tid + 3];
+          const unsigned int tot = c0 + c1 + c2 + c3;
+          unsigned int incl = tot;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) { const unsigned int up = __shfl_up(incl, off, 64); if (tid >= off) incl += up; }
+          const unsigned int excl = incl - tot;
+          if (kk >= excl && kk < incl) {
+            unsigned int r = kk - excl, bin = 4 * tid;
+            if (r >= c0) { r -= c0; bin++; if (r >= c1) { r -= c1; bin++; if (r >= c2) { r -= c2; bin++; } } }
+            s_k = r; s_prefix = prefix | (bin << shift);
+          }
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+      }
+      const float nthElement = sqrtf(__uint_as_float(s_prefix));
+      th = nthElement * D.thFacMedian;
+      th = 26.0f * D.thConstWeight + th * (1 - D.thConstWeight);
+      th = th * th;
+      th *= D.overallW * D.overallW;
+      if (D.thCap > 0 && th > D.thCap) th = D.thCap;   // IMUIntegration::newFrameEnergyTH (FullSystemOptimize.cpp:136-140)
+    }
+  }
+  tk3 = wall_clock64();
+  if (tid == 0) {
+    D.host->ticks[0] = (int)(tk0 - t_start); D.host->ticks[1] = (int)(tk1 - t_start); D.host->ticks[2] = (int)(tk2 - t_start); D.host->ticks[3] = (int)(tk3 - t_start);
+    const double E = s_E;
+    const int slot = D.mode == 2 ? 1 : 0;
+    if (D.update_th) __hip_atomic_store(D.frameTH + D.newestFrame, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (D.mode == 1) {
+      const int acc = (E + D.newL + D.newM < D.lastE0 + D.lastL + D.lastM) ? 1 : 0;   // FullSystemOptimize.cpp:553-554 (energy[1] = 0, dynamic weight 1)
+      __hip_atomic_store(&D.ctl->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&D.host->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (D.mode == 0) {
+      __hip_atomic_store(&D.ctl->accept, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(&D.host->E[slot], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&D.host->th[slot], th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (D.publish) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ linearize
 // Eight lanes per residual: lane idx evaluates pattern pixel idx (projection, bilinear tap, weights, its products); the sums over
@@ -112,9 +265,19 @@ __device__ __forceinline__ float seqSum8(const float v) {
   return s;
 }
 
+// gate: BA_GATE_REJECTED = this launch is the relinearisation that follows a rejected step (loadSateBackup + linearizeAll,
+// FullSystemOptimize.cpp:575-581): it returns at once when the step was accepted.  use_backup: the point part of loadSateBackup rides along
+// (idepth = idepth_zero = idepth_backup, written back by the group of the point's first residual).
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
-                                                               const FrameStore fs, double* __restrict__ energy_partials, float* __restrict__ fullJ,
-                                                               const unsigned char* __restrict__ pt_mask) {
+                                                               const FrameStore fs, float* __restrict__ fullJ,
+                                                               const unsigned char* __restrict__ pt_mask, const BADecide D, const int gate, const int use_backup,
+                                                               const BAPreDyn T, const int use_dyn, const ResubArgs X, const int do_resub) {
+  if (baGateClosed(D.ctl, gate)) {
+    if (D.publish && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  double* __restrict__ energy_partials = D.epart;
+  const long long t_kernel0 = wall_clock64();
   // pt_mask != NULL: only the residuals of the flagged points, after PointFrameResidual::resetOOB (Residuals.h:82-89) — the
   // relinearisation FullSystem::flagPointsForRemoval performs before a point is marginalised (FullSystem.cpp:836-849)
   const int ri = blockIdx.x * LIN_RES_PER_BLOCK + (threadIdx.x >> 3), idx = threadIdx.x & 7;
@@ -128,18 +291,62 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
     if (pt_mask) state = BA_IN;
     if (lead) {
       Rs.newEnergyWO[ri] = -1.0f;
+      { const int sl = Rs.newestSlot[ri]; if (sl >= 0) __hip_atomic_store(Rs.newestE + sl, -1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       if (pt_mask) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
     }
     bool done = false;
     if (state == BA_OOB) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
     const int pi = Rs.point[ri], ti = Rs.target[ri];
     const int hi = P.host[pi];
-    const BAPrecalc& pc = pre[hi + W.F * ti];
+    BAPrecalc pc = pre[hi + W.F * ti];
+    if (use_dyn) {
+      const float* __restrict__ dv = T.v[baPairIndex(hi, ti, W.F)];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pc.KRKi[k] = dv[k];
+      pc.Kt[0] = dv[9]; pc.Kt[1] = dv[10]; pc.Kt[2] = dv[11]; pc.aff0 = dv[12]; pc.aff1 = dv[13];
+    }
     const float pu = P.u[pi], pv = P.v[pi];
+    // do_resub: EnergyFunctional::resubstituteFPt (EnergyFunctional.cpp:295-321) + the point part of doStepFromBackup for this residual's point,
+    // fused in front of the linearisation of the stepped state (every group of a point's residuals computes the same step — lane q takes the
+    // point's q-th residual, the products are subtracted in residual order like k_ba_resubstitute does; the group of the first residual
+    // stores it).  Saves a kernel and its launch gap per Gauss-Newton iteration.
+    float id_new = 0.0f;
+    if (do_resub) {
+      const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
+      const float bk = P.idepth_backup[pi];
+      float bsum = P.bdSumF[pi];
+      {
+        float dotc = 0;
+        dotc += X.xc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += X.xc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
+        dotc += X.xc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += X.xc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
+        bsum -= dotc;
+      }
+      const int grp = (threadIdx.x & 63) & ~7;
+      int ngood = 0;
+      for (int rb = r0; rb < r1; rb += 8) {
+        const int rq = min(rb + idx, r1 - 1);
+        const bool act = rb + idx < r1 && Rs.active[rq] != 0;
+        const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
+        const float* __restrict__ xa = X.xAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
+        float d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
+        if (!act) d = 0.0f;
+        bsum = bsum - d;
+#pragma unroll
+        for (int k = 1; k < 8; k++) bsum = bsum - dppShl(d, k);
+        ngood += __popcll((__ballot(act) >> grp) & 0xFFull);
+      }
+      float st = ngood == 0 ? 0.0f : -bsum * P.HdiF[pi];
+      // the leading lane holds the ordered sum: hand its step to the group's other lanes
+      st = __shfl(st, (threadIdx.x & 63) & ~7, 64);
+      id_new = bk + 1.0f * st;
+      if (lead && r0 == ri) { P.step[pi] = st; P.idepth[pi] = id_new; P.idepth_zero[pi] = id_new; }
+    }
     float d_xi_x[6], d_xi_y[6], d_C_x[4], d_C_y[4], d_d_x = 0, d_d_y = 0;
     if (!done) {
       // centre pixel at the LINEARISATION point (idepth_zero, evalPT poses)
-      const float idz = P.idepth_zero[pi];
+      const float idz = do_resub ? id_new : (use_backup ? P.idepth_backup[pi] : P.idepth_zero[pi]);
       const float Kx = (pu + 0 - W.cx) * W.fxi, Ky = (pv + 0 - W.cy) * W.fyi;
       const float p0 = pc.R0[0] * Kx + pc.R0[1] * Ky + pc.R0[2] * 1.0f + pc.t0[0] * idz;
       const float p1 = pc.R0[3] * Kx + pc.R0[4] * Ky + pc.R0[5] * 1.0f + pc.t0[1] * idz;
@@ -173,7 +380,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
     }
     if (!done) {
       const float* __restrict__ img = fs.level(W.slot[ti], 0);
-      const float ids = P.idepth[pi];
+      const float ids = do_resub ? id_new : (use_backup ? P.idepth_backup[pi] : P.idepth[pi]);
       float* fj = fullJ ? fullJ + (size_t)ri * 74 : nullptr;
       // this lane's pattern pixel
       const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
@@ -221,7 +428,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
         const float JIr0 = seqSum8(tJIr0), JIr1 = seqSum8(tJIr1), Jar0 = seqSum8(tJar0), Jar1 = seqSum8(tJar1), rr = seqSum8(trr);
         if (lead) {
           Rs.newEnergyWO[ri] = energyLeft;
-          const float th = fmaxf(W.frameEnergyTH[hi], W.frameEnergyTH[ti]);
+          { const int sl = Rs.newestSlot[ri]; if (sl >= 0) __hip_atomic_store(Rs.newestE + sl, energyLeft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          const float th = fmaxf(D.frameTH[hi], D.frameTH[ti]);
           if (energyLeft > th || wJI2 < 2) { energyLeft = th; Rs.newState[ri] = BA_OUTLIER; }
           else Rs.newState[ri] = BA_IN;
           Rs.newEnergy[ri] = energyLeft;
@@ -266,8 +474,28 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
   if (threadIdx.x == 0) {
     double sum = 0;
     for (int k = 0; k < LIN_RES_PER_BLOCK; k++) sum += s_e[k];
-    energy_partials[blockIdx.x] = sum;
+    __hip_atomic_store(energy_partials + blockIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // loadSateBackup, point part: the group of a point's first residual restores it (a point without residuals never left its backup: its step is 0)
+  if (use_backup && ri < W.R && lead) {
+    const int pi = Rs.point[ri];
+    if (P.res_begin[pi] == ri) { const float bk = P.idepth_backup[pi]; P.idepth[pi] = bk; P.idepth_zero[pi] = bk; }
+  }
+  if (D.mode < 0) return;
+  // the last workgroup to arrive takes the decisions (energy sum, threshold of the newest keyframe, accept / reject)
+  // What the deciding workgroup reads (energy partials, per-residual energies) was stored with agent-scope atomic stores, i.e. written
+  // through to the device's coherence point; waiting for those stores (workgroup-scope release = s_waitcnt) before a RELAXED arrive is enough.
+  // An agent-scope release / acquire here would write back and invalidate the whole L2 of the XCD — once per workgroup, with megabytes of
+  // freshly written records in it (measured: +40 us per launch).
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&D.ctl->cnt_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (threadIdx.x == 0) __hip_atomic_store(&D.ctl->cnt_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  baDecideBlock(D, gridDim.x, t_kernel0);
 }
 
 // applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector
@@ -287,46 +515,61 @@ __global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, c
 // Hdd_accAF, bd_accAF, Hcd_accAF (sequential over the point's residuals) and the head of AccumulatedSCHessianSSE::addPoint:
 // HdiF, bdSumF (AccumulatedSCHessian.cpp:36-54).
 // backup != 0 fuses the point part of backupState (FullSystemOptimize.cpp:320-352): idepth_backup = idepth
-__global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const int backup) {
-  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= W.N) return;
-  if (backup) P.idepth_backup[pi] = P.idepth[pi];
-  float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
-  int ngood = 0;
+// Eight lanes per point: lane q fetches the six contributions of the point's q-th residual (all loads of a point in flight together — a point
+// has at most F-1 <= 7 residuals), the sums are then formed in residual order by DPP row shifts in the leading lane, exactly like the
+// reference's sequential loop (an inactive residual contributes +0.0f, which leaves an fp32 sum unchanged).  The kernel is latency-bound
+// (2000 points): what matters is the length of the dependent load chain, which is res_begin -> which -> record here.
+// running sum s (leading lane) + the values of lanes 0..7 of the group, left to right
+__device__ __forceinline__ float seqAdd8(float s, const float v) {
+  s = s + v;
+#pragma unroll
+  for (int k = 1; k < 8; k++) s = s + dppShl(v, k);
+  return s;
+}
+#define PT_GROUPS_PER_BLOCK 32
+// apply != 0 fuses applyRes_Reductor(true) (FullSystemOptimize.cpp:91-95, Residuals.cpp:306-328) for the point's residuals: every residual
+// belongs to exactly one lane of one group.  gate: see BACtl.
+__global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const int backup, const int apply, const BACtl* __restrict__ ctl,
+                                                        const int gate) {
+  if (baGateClosed(ctl, gate)) return;
+  const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;
+  if (pi >= W.N) return;   // group-uniform
+  const bool lead = q == 0;
   const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
-  // the 6 floats of up to 8 residuals are requested together (independent loads), then added in residual order
+  const float id = P.idepth[pi], idz = P.idepth_zero[pi], prior = P.priorF[pi];
+  if (backup && lead) P.idepth_backup[pi] = id;
+  float Hdd = 0, bd = 0, Hcd0 = 0, Hcd1 = 0, Hcd2 = 0, Hcd3 = 0;
+  int ngood = 0;
+  const int grp = (threadIdx.x & 63) & ~7;
   for (int rb = r0; rb < r1; rb += 8) {
-    float v[8][6];
-    bool act[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int ri = min(rb + q, r1 - 1);
-      act[q] = rb + q < r1 && Rs.active[ri] != 0;
-      const float* __restrict__ rec = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
-      v[q][0] = rec[REC_BD]; v[q][1] = rec[REC_HDD];
-#pragma unroll
-      for (int k = 0; k < 4; k++) v[q][2 + k] = rec[REC_HCD + k];
+    const int ri = min(rb + q, r1 - 1);
+    const bool mine = rb + q < r1;
+    int isAct = Rs.active[ri], wh = Rs.which[ri];
+    if (apply && mine && Rs.state[ri] != BA_OOB) {   // can never go back from OOB
+      const int ns = Rs.newState[ri];
+      if (ns == BA_IN) { isAct = 1; wh ^= 1; Rs.which[ri] = (unsigned char)wh; } else isAct = 0;
+      Rs.active[ri] = (unsigned char)isAct;
+      Rs.state[ri] = (unsigned char)ns;
+      Rs.energy[ri] = Rs.newEnergy[ri];
     }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (!act[q]) continue;
-      bd += v[q][0];
-      Hdd += v[q][1];
-#pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] += v[q][2 + k];
-      ngood++;
-    }
+    const bool act = mine && isAct != 0;
+    const float* __restrict__ rec = Rs.rec[wh] + (size_t)ri * REC_FLOATS;
+    const float v0 = act ? rec[REC_BD] : 0.0f, v1 = act ? rec[REC_HDD] : 0.0f;
+    const float h0 = act ? rec[REC_HCD + 0] : 0.0f, h1 = act ? rec[REC_HCD + 1] : 0.0f, h2 = act ? rec[REC_HCD + 2] : 0.0f, h3 = act ? rec[REC_HCD + 3] : 0.0f;
+    bd = seqAdd8(bd, v0); Hdd = seqAdd8(Hdd, v1);
+    Hcd0 = seqAdd8(Hcd0, h0); Hcd1 = seqAdd8(Hcd1, h1); Hcd2 = seqAdd8(Hcd2, h2); Hcd3 = seqAdd8(Hcd3, h3);
+    ngood += __popcll((__ballot(act) >> grp) & 0xFFull);
   }
+  if (!lead) return;
   P.Hdd[pi] = Hdd; P.bd[pi] = bd;
-#pragma unroll
-  for (int k = 0; k < 4; k++) P.Hcd[4 * pi + k] = Hcd[k];
+  P.Hcd[4 * pi + 0] = Hcd0; P.Hcd[4 * pi + 1] = Hcd1; P.Hcd[4 * pi + 2] = Hcd2; P.Hcd[4 * pi + 3] = Hcd3;
   if (ngood == 0) { P.HdiF[pi] = 0; P.bdSumF[pi] = 0; P.idepth_hessian[pi] = 0; return; }
-  float H = Hdd + 0.0f + P.priorF[pi];
+  float H = Hdd + 0.0f + prior;
   if (H < 1e-10) H = 1e-10;
   P.idepth_hessian[pi] = H;
   P.HdiF[pi] = 1.0 / H;
-  const float deltaF = P.idepth[pi] - P.idepth_zero[pi];
-  P.bdSumF[pi] = (bd + 0.0f) + P.priorF[pi] * deltaF;  // shiftPriorToZero = true
+  const float deltaF = id - idz;
+  P.bdSumF[pi] = (bd + 0.0f) + prior * deltaF;  // shiftPriorToZero = true
 }
 
 // ------------------------------------------------------------------------------------------------ point marginalisation
@@ -746,7 +989,8 @@ struct AccumArgs {
   long long* ticks;   // optional [gridDim.x][2] start / end wall-clock stamps per block (DMVIO_HIP_BA_TIMING), else null
 };
 #define ACC_LDS_FLOATS (20 * SCC_STRIDE + 8)
-__global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const BARes Rs, const BAPoints P) {
+__global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const BARes Rs, const BAPoints P, const BACtl* __restrict__ ctl, const int gate) {
+  if (baGateClosed(ctl, gate)) return;
   __shared__ float s_buf[ACC_LDS_FLOATS];
   static_assert(ACC_LDS_FLOATS >= HT_TILE * HT_STRIDE + 8 && ACC_LDS_FLOATS >= 4 * 64 * SCD_STRIDE, "LDS carve-up");
   const int F2 = A.F * A.F;
@@ -873,7 +1117,9 @@ __device__ __forceinline__ void stitchScWave(StitchWave& W, const int F, const i
 
 __global__ void __launch_bounds__(512) k_ba_stitch(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
                                                     const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE /* F*F x nsTop x 40 */,
-                                                    const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S) {
+                                                    const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S,
+                                                    const BACtl* __restrict__ ctl, const int gate) {
+  if (baGateClosed(ctl, gate)) return;
   extern __shared__ double s_dyn[];
   StitchWave* Ws = reinterpret_cast<StitchWave*>(s_dyn);
   const int wave = threadIdx.x >> 6, e = threadIdx.x & 63, r = e >> 3, c = e & 7;
@@ -931,10 +1177,32 @@ __global__ void __launch_bounds__(512) k_ba_stitch(const int F, const int nsTop,
 
 // step 2: one thread per element of H_A, H_sc (n x n, n = 4+8F) and b_A, b_sc; fixed summation order.
 // Output layout: out[0 .. n*n) = H_A, then b_A (n), then H_sc (n*n), then b_sc (n).
+// `out` is host-coherent pinned memory.  The last workgroup to finish publishes the chain's ticket behind the data (system-scope release); a
+// gated-off launch (rejected step: the system of the restored state is the one the host already holds) publishes at once.
+__device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
+                                              const int nNum, double* __restrict__ out, const int tid);
 __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs S,
-                                                           const int* __restrict__ numTop, const int nNum, double* __restrict__ out) {
+                                                           const int* __restrict__ numTop, const int nNum, double* __restrict__ out, BACtl* __restrict__ ctl, const int gate,
+                                                           BAHostRes* __restrict__ host, const unsigned int ticket) {
+  if (baGateClosed(ctl, gate)) {
+    if (host && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&host->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  gatherElement(F, nsC, accC, S, numTop, nNum, out, blockIdx.x * blockDim.x + threadIdx.x);
+  if (!host) return;
+  __shared__ int s_last;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctl->cnt_gather, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __hip_atomic_store(&ctl->cnt_gather, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&host->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
+                                              const int nNum, double* __restrict__ out, const int tid) {
   const int n = 4 + 8 * F, F2 = F * F;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int per = n * n + n;
   if (tid == 2 * per) {   // resInA: number of active residuals that entered the top accumulation, appended to the system
     int cnt = 0;
@@ -1000,37 +1268,50 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
 // xAd: F*F x 8 floats, index h*F + t (EnergyFunctional.cpp:280-282), xc: 4 floats
 // apply_step != 0 fuses doStepFromBackup for stepfac = 1 (FullSystemOptimize.cpp:224-317): idepth = idepth_zero = backup + step
 // xc and xAd travel as kernel arguments (2 KB): no separate upload, no staging buffer
-struct ResubArgs { float xc[4]; float xAd[BA_MAXF * BA_MAXF * 8]; };
+// Eight lanes per point like k_ba_point_sums: lane q forms xAd[h,t_q] . JpJdF of the point's q-th residual (sequential over the 8 entries), the
+// leading lane subtracts the products in residual order (an inactive residual subtracts +0.0f: no change).
 __global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const ResubArgs X, const int apply_step) {
   const float* __restrict__ xc = X.xc;
   const float* __restrict__ xAd = X.xAd;
-  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= W.N) return;
-  int ngood = 0;
-  for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) if (Rs.active[ri]) ngood++;
-  if (ngood == 0) {
-    P.step[pi] = 0;
-    if (apply_step) { const float v = P.idepth_backup[pi] + 1.0f * 0.0f; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
-    return;
-  }
-  float b = P.bdSumF[pi];
-  float dotc = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) dotc += xc[k] * (P.Hcd[4 * pi + k] + 0.0f);
-  b -= dotc;
+  const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;
+  if (pi >= W.N) return;   // group-uniform
+  const bool lead = q == 0;
+  const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
   const int hi = P.host[pi];
-  for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) {
-    if (!Rs.active[ri]) continue;
-    const float* __restrict__ q = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS + REC_JPJD;
+  const float bdSum = P.bdSumF[pi], HdiF = P.HdiF[pi], bk = P.idepth_backup[pi];
+  const float hc0 = P.Hcd[4 * pi + 0], hc1 = P.Hcd[4 * pi + 1], hc2 = P.Hcd[4 * pi + 2], hc3 = P.Hcd[4 * pi + 3];
+  const int grp = (threadIdx.x & 63) & ~7;
+  float b = bdSum;
+  {
+    float dotc = 0;
+    dotc += xc[0] * (hc0 + 0.0f); dotc += xc[1] * (hc1 + 0.0f); dotc += xc[2] * (hc2 + 0.0f); dotc += xc[3] * (hc3 + 0.0f);
+    b -= dotc;
+  }
+  int ngood = 0;
+  for (int rb = r0; rb < r1; rb += 8) {
+    const int ri = min(rb + q, r1 - 1);
+    const bool act = rb + q < r1 && Rs.active[ri] != 0;
+    const float* __restrict__ jp = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS + REC_JPJD;
     const float* __restrict__ xa = xAd + (size_t)(hi * W.F + Rs.target[ri]) * 8;
     float d = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) d += xa[k] * q[k];
-    b -= d;
+    for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
+    if (!act) d = 0.0f;
+    // b -= d_0; b -= d_1; ... in residual order (leading lane)
+    b = b - d;
+#pragma unroll
+    for (int k = 1; k < 8; k++) b = b - dppShl(d, k);
+    ngood += __popcll((__ballot(act) >> grp) & 0xFFull);
   }
-  const float st = -b * P.HdiF[pi];
+  if (!lead) return;
+  if (ngood == 0) {
+    P.step[pi] = 0;
+    if (apply_step) { const float v = bk + 1.0f * 0.0f; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
+    return;
+  }
+  const float st = -b * HdiF;
   P.step[pi] = st;
-  if (apply_step) { const float v = P.idepth_backup[pi] + 1.0f * st; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
+  if (apply_step) { const float v = bk + 1.0f * st; P.idepth[pi] = v; P.idepth_zero[pi] = v; }
 }
 
 // mode 0: backupState (idepth_backup = idepth);  mode 1: doStepFromBackup (idepth = idepth_zero = backup + fac*step),

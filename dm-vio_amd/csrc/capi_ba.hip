@@ -6,6 +6,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/dmvio_hip.h"
 #include "internal.h"
@@ -45,16 +46,32 @@ struct dmvio_hip_ba {
   int *d_numTop = nullptr, *d_numD = nullptr;
   StitchBufs SB{};
   double *h_sys = nullptr;     // [H_A | b_A | H_sc | b_sc | resInA]: pinned host memory, written by k_ba_stitch_gather
-  double *h_epart = nullptr;   // linearize energy partials, followed by the per-residual energies (h_newEnergyWO): pinned, written by k_ba_linearize
   float *d_spart = nullptr, *h_spart = nullptr;  // point-step partial sums
-  float *h_newEnergyWO = nullptr;
   // pinned staging for the per-linearisation precalc upload (no pageable copy, no sync before the kernel that consumes it)
   BAPrecalc* h_pre[2] = {nullptr, nullptr};
   int pre_toggle = 0;
   float* d_fullJ = nullptr;
-  int n_lin_blocks = 0, n_pt_blocks = 0, n_epart = 0;
+  // device-side decisions (ba_kernels.hpp, BACtl): control block, host-coherent result block, device copies of what the decisions read
+  BACtl* d_ctl = nullptr;
+  BAHostRes* h_res = nullptr;
+  float *d_frameTH = nullptr, *h_frameTH = nullptr;   // FrameHessian::frameEnergyTH of every keyframe (the newest one is updated on the device)
+  bool th_dirty = true;        // the host changed a threshold: upload before the next linearisation
+  double* d_epart = nullptr;
+  int* d_newestSlot = nullptr;   // per residual: its position among the residuals that target the newest keyframe, or -1
+  float* d_newestE = nullptr;    // their state_NewEnergyWithOutlier, contiguous
+  ResubArgs x_none{};            // placeholder argument of linearisations without the fused back-substitution
+  BAPreDyn dyn_cur;              // step-dependent precalc members of the CURRENT state (kernel argument of the GN loop's linearisations)
+  bool pre_static_valid = false; // the device table holds the evaluation-point members (R0, t0, b0) of the current window
+  float* d_newEnergyWO = nullptr;
+  unsigned int ticket = 0, acc_ticket = 0;
+  float th_cap = -1.0f;        // IMUIntegration::newFrameEnergyTH cap (<= 0: none)
+  bool sys_ready = false;      // h_sys holds the stitched system of the CURRENT state (left behind by the previous GN iteration's chain)
+  int n_lin_blocks = 0, n_pt_blocks = 0, n_pt8_blocks = 0, n_epart = 0;   // n_pt8: kernels with eight lanes per point
+  bool keep_fullJ = false;   // the 74-float RawResidualJacobian is only materialised on request (dmvio_hip_ba_keep_jacobians) and for marginalisation
   // partial accumulators per bucket: 1 (default) replays the single-threaded reference order bit for bit; DMVIO_HIP_BA_SPLIT=k uses k
-  int nsTop = 1, nsD = 1, nsC = 1;
+  // partial accumulators per bucket: k > 1 = the structure of the reference's multi-threaded accumulation (per-worker fp32 accumulators summed
+  // in double, AccumulatedTopHessian.h:91-139) with a FIXED assignment of members to partials; 1 = the reference's single-threaded order, bit for bit
+  int nsTop = 4, nsD = 4, nsC = 16;
   bool graph_ready = false;
   // energies of the last optimize
   double trace[64][4];
@@ -83,17 +100,38 @@ static void freeDevice(dmvio_hip_ba* b) {
   for (void* p : b->allocs) hipFree(p);
   b->allocs.clear();
   if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
-  if (b->h_epart) { hipHostFree(b->h_epart); b->h_epart = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
-  b->h_newEnergyWO = nullptr;   // lives inside h_epart
+  if (b->h_res) { hipHostFree(b->h_res); b->h_res = nullptr; }
+  if (b->h_frameTH) { hipHostFree(b->h_frameTH); b->h_frameTH = nullptr; }
   for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
   b->graph_ready = false;
 }
 
 // switch_back: the state was restored to the one whose table is still in the other half (loadSateBackup after a rejected step)
+static void fillWindow(dmvio_hip_ba* b) {
+  BAHost& H = b->H;
+  BAWindow& W = b->W;
+  W.F = H.F; W.w = H.w; W.h = H.h; W.N = H.N; W.R = H.R;
+  W.fx = H.c_f[0]; W.fy = H.c_f[1]; W.cx = H.c_f[2]; W.cy = H.c_f[3];
+  W.fxi = H.c_i[0]; W.fyi = H.c_i[1]; W.cxi = H.c_i[2]; W.cyi = H.c_i[3];
+  W.wM3 = H.w - 3; W.hM3 = H.h - 3;
+  W.huberTH = H.S.huberTH; W.outlierTHSum = H.S.outlierTHSumComponent; W.modeA = H.S.affineOptModeA; W.modeB = H.S.affineOptModeB;
+  for (int f = 0; f < H.F; f++) { W.slot[f] = H.fr[f].slot; W.frameEnergyTH[f] = H.fr[f].frameEnergyTH; }
+}
+static void dynFromHost(const BAHost& H, BAPreDyn& T) {
+  for (int hh = 0; hh < H.F; hh++)
+    for (int t = 0; t < H.F; t++) {
+      if (hh == t) continue;
+      const BAPrecalc& pc = H.pre[hh + H.F * t];
+      float* v = T.v[baPairIndex(hh, t, H.F)];
+      for (int k = 0; k < 9; k++) v[k] = pc.KRKi[k];
+      v[9] = pc.Kt[0]; v[10] = pc.Kt[1]; v[11] = pc.Kt[2]; v[12] = pc.aff0; v[13] = pc.aff1;
+    }
+}
 static int uploadWindowTables(dmvio_hip_ba* b, bool new_state = false, bool switch_back = false) {
   BAHost& H = b->H;
   BAWindow& W = b->W;
+  b->pre_static_valid = true;
   W.F = H.F; W.w = H.w; W.h = H.h; W.N = H.N; W.R = H.R;
   W.fx = H.c_f[0]; W.fy = H.c_f[1]; W.cx = H.c_f[2]; W.cy = H.c_f[3];
   W.fxi = H.c_i[0]; W.fyi = H.c_i[1]; W.cxi = H.c_i[2]; W.cyi = H.c_i[3];
@@ -115,23 +153,61 @@ static int uploadAdjoints(dmvio_hip_ba* b) {
   return 0;
 }
 
+// Completion of a chain of kernels: its last kernel stores the chain's ticket into host-coherent memory behind its results; the host spins
+// on that word instead of paying a stream synchronisation (wake-up latency) per Gauss-Newton iteration.
+static int waitTicket(dmvio_hip_ba* b, const unsigned int ticket) {
+  volatile unsigned int* flag = &b->h_res->ticket;
+  unsigned long long spins = 0;
+  while (*flag != ticket) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      const hipError_t q = hipStreamQuery(b->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail("BA kernel chain", __FILE__, __LINE__, q);
+      if (q == hipSuccess && *flag != ticket) return failmsg("BA kernel chain finished without publishing its ticket");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+static int uploadThresholds(dmvio_hip_ba* b) {
+  if (!b->th_dirty) return 0;
+  for (int f = 0; f < BA_MAXF; f++) b->h_frameTH[f] = f < b->H.F ? b->H.fr[f].frameEnergyTH : 0.0f;
+  HIPCHK(hipMemcpyAsync(b->d_frameTH, b->h_frameTH, sizeof(float) * BA_MAXF, hipMemcpyHostToDevice, b->stream));
+  b->th_dirty = false;
+  return 0;
+}
+static BADecide makeDecide(dmvio_hip_ba* b, int mode, bool update_th, bool publish) {
+  BADecide D;
+  memset(&D, 0, sizeof(D));
+  const BAHost& H = b->H;
+  D.newestE = b->d_newestE; D.n_newest = (int)b->h_newest.size(); D.newestFrame = H.F - 1;
+  D.frameTH = b->d_frameTH; D.epart = b->d_epart;
+  D.thN = H.S.frameEnergyTHN; D.thFacMedian = H.S.frameEnergyTHFacMedian; D.thConstWeight = H.S.frameEnergyTHConstWeight; D.overallW = H.S.overallEnergyTHWeight;
+  D.thCap = b->th_cap;
+  D.mode = mode; D.update_th = update_th ? 1 : 0;
+  { static const int dbg = getenv("DMVIO_HIP_BA_DBG") ? atoi(getenv("DMVIO_HIP_BA_DBG")) : 0; if (dbg & 1) D.update_th = 0; if (dbg & 2) D.mode = -1; }
+  D.ctl = b->d_ctl; D.host = b->h_res;
+  D.publish = publish ? 1 : 0;
+  if (publish) D.ticket = ++b->ticket;
+  return D;
+}
+
 // FullSystem::linearizeAll (FullSystemOptimize.cpp:150-218) — returns the energy sum; updates the newest frame's energy threshold
-static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */) {
+// (setNewFrameEnergyTH, on the device by the kernel's last workgroup) unless keep_threshold.
+static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */, bool keep_threshold = false) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
-  if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc + frameEnergyTH of the current state
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->h_epart, b->d_fullJ, (const unsigned char*)nullptr);
+  if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc of the current state
+  if (int r = uploadThresholds(b)) return r;
+  const BADecide D = makeDecide(b, 0, !keep_threshold, !fix);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
+                     (const unsigned char*)nullptr, D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(b->stream));   // partials + energies are in h_epart (written by the kernel)
-  double e = 0;
-  for (int i = 0; i < b->n_lin_blocks; i++) e += b->h_epart[i];
-  *energy = e;
-  // setNewFrameEnergyTH (FullSystemOptimize.cpp:96-149)
-  std::vector<float> all;
-  all.reserve(b->h_newest.size());
-  for (int ri : b->h_newest) if (b->h_newEnergyWO[ri] >= 0) all.push_back(b->h_newEnergyWO[ri]);
-  H.fr[H.F - 1].frameEnergyTH = H.newFrameEnergyTH(all);
+  if (fix) HIPCHK(hipStreamSynchronize(b->stream));
+  else if (int r = waitTicket(b, D.ticket)) return r;
+  *energy = b->h_res->E[0];
+  if (!keep_threshold) H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
   return 0;
 }
 static int applyRes(dmvio_hip_ba* b) {
@@ -140,14 +216,16 @@ static int applyRes(dmvio_hip_ba* b) {
   return 0;
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
-static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P, bool wait = true);
+static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P, bool wait = true, int gate = BA_GATE_ALWAYS);
 static int accumulateWait(dmvio_hip_ba* b);
-static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false) {
-  if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0);
-  return accumulateViews(b, b->Rs, b->P, wait);
+// apply_first: applyRes_Reductor(true) fused into the per-point sums; gate: the whole chain only runs when the last accept test says so
+static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false, bool apply_first = false, int gate = BA_GATE_ALWAYS) {
+  if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0, apply_first ? 1 : 0,
+                                      (const BACtl*)b->d_ctl, gate);
+  return accumulateViews(b, b->Rs, b->P, wait, gate);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
-static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV, bool wait) {
+static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV, bool wait, int gate) {
   BAHost& H = b->H;
   const int F = H.F, F2 = F * F, n = H.n();
   hipStream_t s = b->stream;
@@ -162,18 +240,20 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
       if (b->accTicksBlocks != nblk) { if (b->d_accTicks) hipFree(b->d_accTicks); HIPCHK(hipMalloc((void**)&b->d_accTicks, sizeof(long long) * 2 * nblk)); b->accTicksBlocks = nblk; }
       A.ticks = b->d_accTicks;
     }
-    hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV);
+    hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV, (const BACtl*)b->d_ctl, gate);
   }
   hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
-                     b->d_adHost, b->d_adTarget, b->SB);
+                     b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
   const int tot = 2 * (n * n + n);
-  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys);
+  b->acc_ticket = ++b->ticket;
+  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys, b->d_ctl, gate, b->h_res,
+                     b->acc_ticket);
   HIPCHK(hipGetLastError());
   return wait ? accumulateWait(b) : 0;
 }
 static int accumulateWait(dmvio_hip_ba* b) {
   const int n = b->H.n(), tot = 2 * (n * n + n);
-  HIPCHK(hipStreamSynchronize(b->stream));   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
+  if (int r = waitTicket(b, b->acc_ticket)) return r;   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
   b->H.resInA = (int)b->h_sys[tot];
   return 0;
 }
@@ -185,7 +265,7 @@ static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x, bool appl
   memcpy(X.xc, xc, sizeof(xc));
   memset(X.xAd, 0, sizeof(X.xAd));
   memcpy(X.xAd, xAd.data(), sizeof(float) * xAd.size());
-  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, X, apply_step ? 1 : 0);
+  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, X, apply_step ? 1 : 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -216,6 +296,7 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
   if (const char* e = getenv("DMVIO_HIP_BA_SPLIT")) { const int k = atoi(e); if (k >= 1 && k <= 8) { b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = 4 * k; } }
+  if (const char* e = getenv("DMVIO_HIP_BA_EXACT")) { if (atoi(e) != 0) { b->nsTop = b->nsD = b->nsC = 1; } }
   return b;
 }
 void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
@@ -223,8 +304,8 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->stream);
   if (b->timing && b->tm.n > 0) {
-    const char* names[8] = {"backup", "accumulate+stitch", "host solve", "resubstitute", "step frames+points", "precalc", "linearize+TH", "apply/restore"};
-    fprintf(stderr, "[dmvio_hip_ba] GN iteration host-side split over %ld iterations (us/iter):", b->tm.n);
+    const char* names[8] = {"backup+prepare", "host solve", "step+precalc+energies+args", "launch", "wait for the decision", "accepted: sums+accumulate+stitch / rejected: relinearise", "-", "-"};
+    fprintf(stderr, "[dmvio_hip_ba] GN iteration, host clock between phases (no synchronisation added) over %ld iterations (us/iter):", b->tm.n);
     for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f", names[i], b->tm.t[i] / b->tm.n);
     fprintf(stderr, "\n");
     if (b->d_accTicks) {   // block timeline of the LAST k_ba_accumulate launch (wall_clock64 = 100 MHz)
@@ -253,6 +334,21 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   delete b;
 }
 
+// Accumulation order (takes effect with the next dmvio_hip_ba_set_graph): k partial accumulators per bucket, 1 <= k <= 8.
+int dmvio_hip_ba_set_accumulators(dmvio_hip_ba* b, int k) {
+  if (!b || k < 1 || k > 8) return failmsg("ba_set_accumulators: 1 <= k <= 8");
+  std::lock_guard<std::mutex> lk(b->mu);
+  b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = k == 1 ? 1 : 4 * k;
+  b->graph_ready = false;
+  return 0;
+}
+// The 74-float RawResidualJacobian per residual (dmvio_hip_ba_get_jacobians) is written by the linearisation only while this is on.
+int dmvio_hip_ba_keep_jacobians(dmvio_hip_ba* b, int on) {
+  if (!b) return failmsg("null ba");
+  b->keep_fullJ = on != 0;
+  return 0;
+}
+
 // The stream the mapping side enqueues on (default: a stream owned by the handle).  NULL restores an own stream.
 int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
   if (!b) return failmsg("null ba");
@@ -268,7 +364,7 @@ int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
 int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]) {
   if (!b || !slots || !pose7_w2c || !fxfycxcy) return failmsg("ba_set_window: null argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   if (F < 1 || F > BA_MAXF) return failmsg("ba_set_window: 1 <= F <= 8");
   BAHost& H = b->H;
   H.F = F;
@@ -293,12 +389,13 @@ int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const doub
   H.setAdjointsF();
   H.setPrecalcValues();
   b->graph_ready = false;
+  b->th_dirty = true;
   return 0;
 }
 
 int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double* bM) {
   if (!b || !HM || !bM) return failmsg("ba_set_marg_prior: null argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   const int n = b->H.n();
   b->H.HM.assign(HM, HM + (size_t)n * n); b->H.bM.assign(bM, bM + n);
   return 0;
@@ -307,7 +404,7 @@ int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double*
 // FullSystem::flagPointsForRemoval's relinearisation (FullSystem.cpp:829-859) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742)
 int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM, int update_prior) {
   if (!b || !b->graph_ready) return failmsg("ba_marginalize_points: window / graph not set");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   if (!candidates || !decision) return failmsg("ba_marginalize_points: null argument");
   dmvio_hip_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
@@ -324,7 +421,12 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   HIPCHK(hipMemcpyAsync(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // adHT is local
   if (int r = uploadWindowTables(b)) return r;
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->h_epart, b->d_fullJ, (const unsigned char*)b->d_cand);
+  if (int r = uploadThresholds(b)) return r;
+  {
+    const BADecide D = makeDecide(b, -1, false, false);   // masked relinearisation: no energy / threshold / accept pass
+    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_fullJ, (const unsigned char*)b->d_cand, D,
+                       (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+  }
   hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand);
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
@@ -352,7 +454,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
   if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   BAHost& H = b->H;
   if (H.F < 1) return failmsg("ba_set_graph: set_window first");
   if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
@@ -441,18 +543,28 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &SB.scHC, (size_t)F2 * 32) ||
       dalloc(b, &SB.scTC, (size_t)F2 * 32) || dalloc(b, &SB.scBH, (size_t)F2 * 8) || dalloc(b, &SB.scBT, (size_t)F2 * 8)) return -1;
   const int n = H.n(), tot = 2 * (n * n + n);
-  b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256;
+  b->n_lin_blocks = (R + LIN_RES_PER_BLOCK - 1) / LIN_RES_PER_BLOCK; b->n_pt_blocks = (N + 255) / 256; b->n_pt8_blocks = (N + PT_GROUPS_PER_BLOCK - 1) / PT_GROUPS_PER_BLOCK;
   // energy partials (doubles) and the per-residual energies with outliers (floats) share one pinned allocation the kernel stores into
   b->n_epart = std::max(b->n_lin_blocks, F2 * 8);
   if (dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
   // kernels straight into pinned host memory: no copy engine between the last kernel and the host's wait
-  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent
+  HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(b->h_res, 0, sizeof(BAHostRes));
+  HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
+  if (dalloc(b, &b->d_ctl, 1) || dalloc(b, &b->d_frameTH, BA_MAXF) || dalloc(b, &b->d_epart, (size_t)b->n_epart) || dalloc(b, &b->d_newestSlot, (size_t)R) || dalloc(b, &b->d_newestE, b->h_newest.size()) ||
+      dalloc(b, &b->d_newEnergyWO, (size_t)R)) return -1;
+  {
+    std::vector<int> slot(R, -1);
+    for (size_t k = 0; k < b->h_newest.size(); k++) slot[b->h_newest[k]] = (int)k;
+    if (R) HIPCHK(hipMemcpy(b->d_newestSlot, slot.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    Rs.newestSlot = b->d_newestSlot; Rs.newestE = b->d_newestE;
+  }
+  b->pre_static_valid = false;
+  b->th_dirty = true; b->sys_ready = false;
   for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_epart, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2), hipHostMallocDefault));
-  b->h_newEnergyWO = reinterpret_cast<float*>(b->h_epart + b->n_epart);
-  memset(b->h_epart, 0, sizeof(double) * ((size_t)b->n_epart + ((size_t)R + 1) / 2));
-  Rs.newEnergyWO = b->h_newEnergyWO;
+  Rs.newEnergyWO = b->d_newEnergyWO;
   HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
   if (int r = uploadAdjoints(b)) return r;
   HIPCHK(hipStreamSynchronize(s));
@@ -460,7 +572,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   return 0;
 }
 
-#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
+#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
 
 // activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
@@ -492,13 +604,14 @@ int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* 
   if (newEnergy) HIPCHK(hipMemcpyAsync(newEnergy, b->Rs.newEnergy, sizeof(float) * R, hipMemcpyDeviceToHost, s));
   if (active) HIPCHK(hipMemcpyAsync(active, b->Rs.active, R, hipMemcpyDeviceToHost, s));
   if (center3) HIPCHK(hipMemcpyAsync(center3, b->Rs.center, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, s));
+  if (newEnergyWO) HIPCHK(hipMemcpyAsync(newEnergyWO, b->d_newEnergyWO, sizeof(float) * R, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (newEnergyWO) memcpy(newEnergyWO, b->h_newEnergyWO, sizeof(float) * R);   // lives in host memory
   return 0;
 }
 // RawResidualJacobian of the LAST linearisation (74 floats per residual, RawResidualJacobian.h:32-61 order) — parity/debug
 int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
   BA_READY(b);
+  if (!b->keep_fullJ) return failmsg("ba_get_jacobians: call dmvio_hip_ba_keep_jacobians(ba, 1) before the linearisation");
   HIPCHK(hipMemcpyAsync(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
@@ -589,7 +702,7 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
 // FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
   if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetState(b->H.fr[f], state10);
   b->H.setPrecalcValues();
@@ -599,9 +712,10 @@ int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10
 // of every keyframe and CalibHessian::value_zero (unscaled units) where they differ from what dmvio_hip_ba_set_window starts with.
 int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* b, int f, const double state_zero10[10]) {
   if (!b || !state_zero10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_zero: bad argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetStateZero(b->H.fr[f], state_zero10);
+  b->pre_static_valid = false;
   b->H.frameTakeData(b->H.fr[f]);
   b->H.setPrecalcValues();
   return 0;
@@ -610,11 +724,12 @@ int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
   if (!b || !th) return failmsg("ba_set_frame_energy_th: null argument");
   std::lock_guard<std::mutex> lk(b->mu);
   for (int f = 0; f < b->H.F; f++) b->H.fr[f].frameEnergyTH = th[f];
+  b->th_dirty = true;
   return 0;
 }
 int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const double value_zero[4]) {
   if (!b || !value || !value_zero) return failmsg("ba_set_calib_values: null argument");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   std::lock_guard<std::mutex> lk(b->mu);
   for (int i = 0; i < 4; i++) b->H.c_value_zero[i] = value_zero[i];
   b->H.calibSetValue(value);
@@ -628,64 +743,116 @@ int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
 }
 
 // One Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586).
+//
+// The host solves the 68x68 system (the hand-off point of the reference's GTSAM branch, EnergyFunctional.cpp:958-969) and steps the
+// frames; everything else is ONE chain of kernels enqueued without waiting in between:
+//   resubstitute + point step  ->  linearise the stepped state, its last workgroup sums the energy, sets the newest keyframe's threshold
+//   and takes the accept / reject decision  ->  [rejected only] restore the points and relinearise the backed-up state  ->  [accepted only]
+//   applyRes + per-point sums + point backup -> accumulation -> adjoint stitching -> the stitched system of the NEW state in host memory.
+// The host waits once per iteration, by polling the ticket the chain's last kernel stores behind its results.  After a rejected step the
+// system in host memory is still the one of the (restored) state, so the next iteration goes straight to its solve with the larger lambda.
 static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted) {
   BAHost& H = b->H;
+  dmvio_hip_ctx* c = b->ctx;
   const int n = H.n();
-  double t0 = nowUs(), t1;
-#define BA_LAP(i) do { if (b->timing) { hipStreamSynchronize(b->stream); t1 = nowUs(); b->tm.t[i] += t1 - t0; t0 = t1; } } while (0)
-  // backupState
-  H.backupFrames();   // the point part of backupState rides in the first accumulation kernel
-  BA_LAP(0);
+  // backupState (the point part rode in the per-point sums that produced the system at hand)
+  double tq0 = b->timing ? nowUs() : 0, tq1;
+#define BA_PH(i) do { if (b->timing) { tq1 = nowUs(); b->tm.t[i] += tq1 - tq0; tq0 = tq1; } } while (0)
+  H.backupFrames();
+  H.prepareSolve();   // nullspaces, orthogonalisation basis, prior right-hand side
+  if (!b->sys_ready) {
+    const bool sums_fresh = b->sums_fresh;
+    b->sums_fresh = false;
+    if (int r = accumulate(b, true, true, sums_fresh)) return r;
+  }
+  b->sys_ready = false;
+  BA_PH(0);
   // solveSystem
-  const bool sums_fresh = b->sums_fresh;
-  b->sums_fresh = false;
-  if (int r = accumulate(b, true, false, sums_fresh)) return r;
-  H.prepareSolve();   // nullspaces, orthogonalisation basis, prior right-hand side: host work in the shadow of the kernels
-  if (int r = accumulateWait(b)) return r;
-  BA_LAP(1);
   const double* p = b->h_sys;
   std::vector<double> x;
   H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
-  BA_LAP(2);
-  if (int r = resubstitute(b, x, true)) return r;   // + the point part of doStepFromBackup (stepfac 1)
-  BA_LAP(3);
+  BA_PH(1);
+  // resubstituteF_MT + the point part of doStepFromBackup (stepfac 1) ride in front of the linearisation of the stepped state
+  ResubArgs X;
+  {
+    float xc[4];
+    std::vector<float> xAd;
+    H.prepareResubstitute(x, xc, xAd);
+    memcpy(X.xc, xc, sizeof(xc));
+    memset(X.xAd, 0, sizeof(X.xAd));
+    memcpy(X.xAd, xAd.data(), sizeof(float) * xAd.size());
+  }
   // doStepFromBackup, frames and calibration; the step norms only feed canbreak, which stays false without the GTSAM path
   // (FullSystemOptimize.cpp:387,583): not computed
+  if (!b->pre_static_valid) { if (int r = uploadWindowTables(b)) return r; }   // evaluation-point members of the table (R0, t0, b0): once per window
+  fillWindow(b);
+  dynFromHost(H, b->dyn_cur);         // backed-up state: calibration (W) and step-dependent precalc members, for a relinearisation after a rejected step
+  const BAWindow W_backup = b->W;
+  const BAPreDyn dyn_backup = b->dyn_cur;
   float fs[4];
   H.stepFrames(1.0f, fs);
-  BA_LAP(4);
   H.setPrecalcValues();
-  BA_LAP(5);
-  // eval new energy
-  double newE = 0;
-  if (int r = linearizeAll(b, false, &newE, 1)) return r;   // stepped state: its table goes into the other half
-  BA_LAP(6);
   const double newL = H.calcLEnergyFrames(), newM = H.calcMEnergy();
-  accepted = (newE + newL + newM < lastE[0] + lastE[1] + lastE[2]);
+  // linearise the stepped state; the kernel's last workgroup sums the energy, sets the newest keyframe's threshold and decides
+  fillWindow(b);
+  dynFromHost(H, b->dyn_cur);
+  if (int r = uploadThresholds(b)) return r;
+  {
+    BA_PH(2);
+    BADecide D = makeDecide(b, 1, true, true);
+    D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2]; D.newL = newL; D.newM = newM;
+    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
+                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
+    HIPCHK(hipGetLastError());
+    BA_PH(3);
+    if (int r = waitTicket(b, D.ticket)) return r;   // energy, threshold and the accept / reject decision are in host memory
+    BA_PH(4);
+  }
+  accepted = b->h_res->accept != 0;
   if (accepted) {
-    if (int r = applyRes(b)) return r;
-    lastE[0] = newE; lastE[1] = newL; lastE[2] = newM;
+    // applyRes + per-point sums + point backup -> accumulation -> stitching: the system of the new state, for the next iteration's solve.
+    // (Enqueuing this branch speculatively behind the linearisation, gated on the device-side decision, was measured: no gain — the four
+    // launches, not the host round trip, set its length.)
+    if (int r = accumulate(b, true, true, false, true, BA_GATE_ALWAYS)) return r;
+    lastE[0] = b->h_res->E[0]; lastE[1] = newL; lastE[2] = newM;
+    H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
     lambda = std::max(lambda * 0.25, 1e-5);
   } else {
+    // loadSateBackup + linearizeAll (FullSystemOptimize.cpp:575-581): the points are restored by the relinearisation kernel itself; the
+    // system in host memory is still the one of the restored state
+    const BADecide D2 = makeDecide(b, 2, true, true);
+    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, W_backup, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
+                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, D2, (int)BA_GATE_ALWAYS, 1, dyn_backup, 1, b->x_none, 0);
+    HIPCHK(hipGetLastError());
     H.restoreFrames();
-    if (int r = pointStep(b, 2, 0.f, nullptr, nullptr)) return r;
     H.setPrecalcValues();
-    if (int r = linearizeAll(b, false, &lastE[0], 2)) return r;   // backed-up state: its table is still resident
-    lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
+    fillWindow(b);
+    b->dyn_cur = dyn_backup;
+    const double oldL = H.calcLEnergyFrames(), oldM = H.calcMEnergy();
+    if (int r = waitTicket(b, D2.ticket)) return r;
+    lastE[0] = b->h_res->E[1]; lastE[1] = oldL; lastE[2] = oldM;
+    H.fr[H.F - 1].frameEnergyTH = b->h_res->th[1];
     lambda *= 1e2;
-    b->sums_fresh = true;   // nothing the per-point sums depend on has changed: records, activity, idepth == idepth_zero == idepth_backup
   }
-  BA_LAP(7);
+  BA_PH(5);
+#undef BA_PH
+  b->sys_ready = true;   // accepted: the chain left the system of the new state behind; rejected: the one at hand still is the restored state's
   b->tm.n++;
-#undef BA_LAP
+  return 0;
+}
+
+// diagnostics: in-kernel timeline of the last decision pass, 100 MHz ticks since its workgroup started (begin, energy, keys, selected)
+int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* b, int ticks4[4]) {
+  if (!b || !b->h_res || !ticks4) return failmsg("null argument");
+  for (int i = 0; i < 4; i++) ticks4[i] = b->h_res->ticks[i];
   return 0;
 }
 
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io, double lastE[3], int* accepted) {
-  const bool sums_fresh = b && b->sums_fresh;
+  const bool sums_fresh = b && b->sums_fresh, sys_ready = b && b->sys_ready;
   BA_READY(b);
   std::lock_guard<std::mutex> lk(b->mu);
-  b->sums_fresh = sums_fresh;
+  b->sums_fresh = sums_fresh; b->sys_ready = sys_ready;
   bool acc = false;
   double lam = *lambda_io;
   if (int r = gnIteration(b, iteration, lam, lastE, acc)) return r;
@@ -737,21 +904,23 @@ int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
 int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies) {
   BA_READY(b);
   std::lock_guard<std::mutex> lk(b->mu);
-  const float keep = b->H.fr[b->H.F - 1].frameEnergyTH;
   double e = 0;
-  if (int r = linearizeAll(b, fix != 0, &e)) return r;
-  b->H.fr[b->H.F - 1].frameEnergyTH = keep;   // the threshold is set by the caller from the gathered energies
+  if (int r = linearizeAll(b, fix != 0, &e, 0, true)) return r;   // the threshold is set by the caller from the energies gathered over all shards
   if (energy) *energy = e;
+  std::vector<float> wo(b->H.R);
+  if (b->H.R) HIPCHK(hipMemcpyAsync(wo.data(), b->d_newEnergyWO, sizeof(float) * b->H.R, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
   int n = 0;
-  for (int ri = 0; ri < b->H.R; ri++)
-    if (b->h_newEnergyWO[ri] >= 0 && b->h_target[ri] == b->H.F - 1) { if (new_frame_energies) new_frame_energies[n] = b->h_newEnergyWO[ri]; n++; }
+  for (int ri : b->h_newest)
+    if (wo[ri] >= 0) { if (new_frame_energies) new_frame_energies[n] = wo[ri]; n++; }
   if (n_new_frame_energies) *n_new_frame_energies = n;
   return 0;
 }
 int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
   if (!b) return failmsg("null ba");
-  b->sums_fresh = false;
+  b->sums_fresh = false; b->sys_ready = false;
   b->H.fr[b->H.F - 1].frameEnergyTH = th;
+  b->th_dirty = true;
   return 0;
 }
 int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {

@@ -242,8 +242,16 @@ int dmvio_hip_ba_linearize(dmvio_hip_ba* ba, int fix, double* energy);
 int dmvio_hip_ba_apply(dmvio_hip_ba* ba);
 /* per-residual state_NewState (0 IN, 1 OOB, 2 OUTLIER), state_NewEnergy, state_NewEnergyWithOutlier, efResidual->isActive(), centerProjectedTo */
 int dmvio_hip_ba_get_res_state(dmvio_hip_ba* ba, unsigned char* newState, float* newEnergy, float* newEnergyWO, unsigned char* active, float* center3);
-/* RawResidualJacobian of the last linearisation, 74 floats per residual in the member order of RawResidualJacobian.h:32-61 (parity / debug) */
+/* RawResidualJacobian of the last linearisation, 74 floats per residual in the member order of RawResidualJacobian.h:32-61 (parity / debug).
+ * The accumulation works on a 52-float compact record; the full Jacobian is only written while dmvio_hip_ba_keep_jacobians(ba, 1) is on. */
+int dmvio_hip_ba_keep_jacobians(dmvio_hip_ba* ba, int on);
 int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* ba, float* J74);
+/* Order of the fp32 accumulation (AccumulatedTopHessianSSE / AccumulatedSCHessianSSE): k partial accumulators per (host,target) /
+ * (host,t1,t2) bucket, added in double like the per-worker accumulators of the reference's multi-threaded mode
+ * (AccumulatedTopHessian.h:91-139, NUM_THREADS 6) but with a fixed member-to-partial assignment, so results are reproducible run to run.
+ * k = 1 replays the reference's single-threaded order bit for bit (incl. the 1k / 1M shift-up) at the price of a k-times longer dependent
+ * chain per bucket.  Default 4 (DMVIO_HIP_BA_EXACT=1 in the environment makes 1 the default).  Takes effect with the next set_graph. */
+int dmvio_hip_ba_set_accumulators(dmvio_hip_ba* ba, int k);
 int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* ba, float* th);
 /* accumulateAF_MT + accumulateSCF_MT with adjoint stitching (EnergyFunctional.cpp:201-265): H_A, b_A, H_sc, b_sc ((4+8F)^2 / (4+8F), double)
  * — the matrices handed to BAGTSAMIntegration::computeBAUpdate in VIO mode; resInA = number of active residuals. */
@@ -260,6 +268,9 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* ba, int f, double pose7_w2c[7], double 
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* ba, double fxfycxcy[4]);
 /* one Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586); lastE = {E_A, E_L, E_M} in/out */
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io, double lastE[3], int* accepted);
+/* Diagnostics: in-kernel timeline of the last decision pass (energy sum, newest keyframe's threshold, accept test — taken by the last
+ * workgroup of the linearisation kernel): 100 MHz ticks since that workgroup started: pass begin, energy summed, threshold keys loaded, done. */
+int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* ba, int ticks4[4]);
 /* Building blocks of a SHARDED GN iteration (points of one keyframe per GPU; the packed systems / energies are summed by the caller
  * with one RCCL all-reduce): backupState, solve of an externally reduced system + resubstitute, doStepFromBackup (sums6 = frame sums
  * A,B,T,R and the local point sums step^2, |idepth_backup|), loadSateBackup, linearizeAll without the setNewFrameEnergyTH tail

@@ -10,12 +10,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _window(pkg, oracle, case, n_extra_slots=0):
+def _window(pkg, oracle, case, n_extra_slots=0, accumulators=1):
+    """accumulators=1: the reference's single-threaded accumulation order, which these tests compare bit for bit / to double rounding;
+    the library's default (4 partial accumulators per bucket) is covered by test_default_accumulation_order_*"""
     F = case["n_frames"]
     ctx = pkg.Context(case["w"], case["h"], n_slots=F + n_extra_slots)
     for k in range(F):
         ctx.frame_upload(k, case["imgs"][k])
-    ba = pkg.BundleAdjusterHip(ctx)
+    ba = pkg.BundleAdjusterHip(ctx, accumulators=accumulators, keep_jacobians=True)
     ba.set_case(case, list(range(F)))
     W = oracle.BAWindow(case)
     return ctx, ba, W
@@ -87,15 +89,12 @@ def test_linearize_and_system_random_windows(pkg, oracle, synth, gpu_required, s
 @pytest.mark.parametrize("mode", ["exact", "fast"])
 def test_accumulate_and_solve_parity(big, pkg, oracle, mode, monkeypatch):
     """accumulateAF / accumulateSCF + adjoint stitching, solveSystemF, resubstitute.
-    exact (default): one accumulator per bucket replays the single-threaded reference order (incl. 1k/1M shift-up) -> systems agree
-    to double rounding.  fast (DMVIO_HIP_BA_SPLIT=6): several partial accumulators per bucket, summed in double like the reference's
-    six per-worker accumulators -> agreement at fp32 summation level."""
-    if mode == "exact":
-        monkeypatch.delenv("DMVIO_HIP_BA_SPLIT", raising=False)
-    else:
-        monkeypatch.setenv("DMVIO_HIP_BA_SPLIT", "6")
+    exact (dmvio_hip_ba_set_accumulators(1)): one accumulator per bucket replays the single-threaded reference order (incl. 1k/1M shift-up)
+    -> systems agree to double rounding.  fast (the library's default, 4 partial accumulators per bucket, summed in double like the
+    reference's six per-worker accumulators) -> agreement at fp32 summation level."""
+    monkeypatch.delenv("DMVIO_HIP_BA_SPLIT", raising=False); monkeypatch.delenv("DMVIO_HIP_BA_EXACT", raising=False)
     case = big["case"]
-    ba = pkg.BundleAdjusterHip(big["ctx"])
+    ba = pkg.BundleAdjusterHip(big["ctx"], accumulators=1 if mode == "exact" else None)
     ba.set_case(case, list(range(case["n_frames"])))
     W = oracle.BAWindow(case)
     tolH, tolx = (1e-11, 1e-6) if mode == "exact" else (2e-6, 1e-2)
@@ -176,7 +175,7 @@ def test_sharded_driver_world1_equals_gn_iteration(pkg, oracle, synth, gpu_requi
     import dmvio_amd.sharding as sh
     case = synth.ba_case(512, 512, n_frames=8, n_points=1000, seed=11)
     ctx, ba, W = _window(pkg, oracle, case)
-    ba2 = pkg.BundleAdjusterHip(ctx); ba2.set_case(case, list(range(8)))
+    ba2 = pkg.BundleAdjusterHip(ctx, accumulators=1); ba2.set_case(case, list(range(8)))
     s = sh.ShardedBA(ba, sh.Collective(None, None))
     lastE = list(s.begin())
     ba2.activate_all(); e = ba2.linearize_all(False); ba2.apply_res()
@@ -225,7 +224,7 @@ def test_shard_systems_sum_to_full_system(pkg, oracle, synth, gpu_required):
     tot, e_sum = None, 0.0
     for idx in parts:
         sub = sh.shard_case(case, idx)
-        b = pkg.BundleAdjusterHip(ctx); b.set_case(sub, list(range(8)))
+        b = pkg.BundleAdjusterHip(ctx, accumulators=1); b.set_case(sub, list(range(8)))
         b.activate_all(); e_loc, _ = b.linearize_local(False); b.apply_res(); a = b.accumulate()
         buf = sh.pack_system(a["HA"], a["bA"], a["Hsc"], a["bsc"], e_loc, a["resInA"])
         tot = buf if tot is None else tot + buf
@@ -324,3 +323,21 @@ def test_tracking_and_mapping_overlap_on_two_threads(pkg, oracle, synth, gpu_req
     assert par_b["r"]["iterations"] == seq_b["r"]["iterations"] and par_b["r"]["finalEnergy"] == seq_b["r"]["finalEnergy"]
     for a, b in zip(par_b["poses"], seq_b["poses"]):
         assert np.array_equal(a, b)
+
+
+def test_default_accumulation_order_optimize_parity(pkg, oracle, synth, gpu_required):
+    """The library's default accumulation (4 partial accumulators per bucket — the structure of the reference's multi-threaded mode with a
+    fixed assignment) through the whole FullSystem::optimize: same accept / reject sequence, final energy within 1e-4, poses within 1e-3 m of
+    the single-threaded oracle; and reproducible run to run."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=2000, seed=4321)
+    ctx, ba, W = _window(pkg, oracle, case, accumulators=None)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"] == 6
+    assert np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3])
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"] and abs(rg["rmse"] - ro["rmse"]) <= 1e-4 * ro["rmse"]
+    for k in range(8):
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+    ba2 = pkg.BundleAdjusterHip(ctx); ba2.set_case(case, list(range(8)))
+    r2 = ba2.optimize(6)
+    assert np.array_equal(r2["trace"], rg["trace"]) and all(np.array_equal(ba2.frame_pose(k)[0], ba.frame_pose(k)[0]) for k in range(8))
+    ba.close(); ba2.close(); ctx.close()

@@ -1,0 +1,14 @@
+#!/usr/bin/env python
+"""Prints a slice of the kernel timeline of a rocprofv3 rocpd database: start offset, duration and the gap to the previous kernel (us).
+usage: rocprof_timeline.py <results.db> [first_row] [n_rows]"""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+rows = db.execute("select name, start, end, grid_x / workgroup_x from kernels order by start").fetchall()
+rows = rows[first:first + n]
+t0 = rows[0][1]; prev_end = rows[0][1]
+for name, s, e, wg in rows:
+    nm = name.replace("void ", "").split("(")[0]
+    print("%9.2f  dur %7.2f  gap %7.2f  wg %5d  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, wg, nm))
+    prev_end = e
