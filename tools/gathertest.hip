@@ -7,7 +7,7 @@
 #include <algorithm>
 #include <random>
 
-enum { ROWMAJOR_VEC = 0, ROWMAJOR_SCALAR = 1, TILED84_SCALAR = 2, ROWPAIR_VEC = 3, TILED84_ROWVEC = 4 };
+enum { ROWMAJOR_VEC = 0, ROWMAJOR_SCALAR = 1, TILED84_SCALAR = 2, ROWPAIR_VEC = 3, TILED84_ROWVEC = 4, ROWMAJOR_VEC_X2 = 5, ROWMAJOR_VEC_NT = 6, ROWMAJOR_VEC_X4 = 7 };
 
 __device__ __forceinline__ int tiled84(int x, int y, int tilesPerRow) { return (((y >> 2) * tilesPerRow + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7); }
 
@@ -22,6 +22,19 @@ __global__ void __launch_bounds__(256, 4) k_gather(const float* __restrict__ img
       const float2 P = pts[i];
       const float x = fminf(fmaxf(P.x + sx, 2.5f), w - 3.5f), y = fminf(fmaxf(P.y + sy, 2.5f), h - 3.5f);
       const int ix = (int)x, iy = (int)y;
+      if (MODE == ROWMAJOR_VEC_X2 || MODE == ROWMAJOR_VEC_X4) {
+        // U points of one lane in flight at once (memory-level parallelism test): handled in the strided loop below
+        continue;
+      }
+      if (MODE == ROWMAJOR_VEC_NT) {
+        const float* bp = img + ix + iy * w;
+        typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+        typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+        const f2 A = __builtin_nontemporal_load((const f2*)(bp - w)); const f4 Bv = __builtin_nontemporal_load((const f4*)(bp - 1));
+        const f4 C = __builtin_nontemporal_load((const f4*)(bp + w - 1)); const f2 D = __builtin_nontemporal_load((const f2*)(bp + 2 * w));
+        acc += A.x + A.y + Bv.x + Bv.y + Bv.z + Bv.w + C.x + C.y + C.z + C.w + D.x + D.y;
+        continue;
+      }
       float s = 0.f;
       if (MODE == ROWMAJOR_VEC) {
         const float* bp = img + ix + iy * w;
@@ -55,6 +68,22 @@ __global__ void __launch_bounds__(256, 4) k_gather(const float* __restrict__ img
         s = A.x + A.y + B.x + B.y + B.z + B.w + C.x + C.y + C.z + C.w + D.x + D.y;
       }
       acc += s;
+    }
+    if (MODE == ROWMAJOR_VEC_X2 || MODE == ROWMAJOR_VEC_X4) {
+      constexpr int U = MODE == ROWMAJOR_VEC_X2 ? 2 : 4;
+      for (int i = threadIdx.x; i < n; i += 256 * U) {
+        float2 A[U], D[U]; float4 Bq[U], C[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int j = min(i + 256 * u, n - 1);
+          const float2 P = pts[j];
+          const float x = fminf(fmaxf(P.x + sx, 2.5f), w - 3.5f), y = fminf(fmaxf(P.y + sy, 2.5f), h - 3.5f);
+          const float* bp = img + (int)x + (int)y * w;
+          __builtin_memcpy(&A[u], bp - w, 8); __builtin_memcpy(&Bq[u], bp - 1, 16); __builtin_memcpy(&C[u], bp + w - 1, 16); __builtin_memcpy(&D[u], bp + 2 * w, 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += A[u].x + A[u].y + Bq[u].x + Bq[u].y + Bq[u].z + Bq[u].w + C[u].x + C[u].y + C[u].z + C[u].w + D[u].x + D[u].y;
+      }
     }
   }
   out[blockIdx.x * 256 + threadIdx.x] = acc;
@@ -105,9 +134,15 @@ int main() {
     const float t2 = run<TILED84_SCALAR>(imgs, stride, dp, n, w, h, passes, B, out);
     const float t3 = run<ROWPAIR_VEC>(imgs, stride, dp, n, w, h, passes, B, out);
     const float t4 = run<TILED84_ROWVEC>(imgs, stride, dp, n, w, h, passes, B, out);
+    const float t5 = run<ROWMAJOR_VEC_X2>(imgs, stride, dp, n, w, h, passes, B, out);
+    const float t6 = run<ROWMAJOR_VEC_NT>(imgs, stride, dp, n, w, h, passes, B, out);
+    const float t7 = run<ROWMAJOR_VEC_X4>(imgs, stride, dp, n, w, h, passes, B, out);
+    const float t8 = run<ROWMAJOR_VEC>(imgs, stride, dp, n, w, h, passes, B / 2, out) * 2;   // 2 waves per SIMD
+    const float t9 = run<ROWMAJOR_VEC_X4>(imgs, stride, dp, n, w, h, passes, B / 2, out) * 2;
     auto cyc = [&](float ms) { return ms * 1e-3 * 2.4e9 * 256.0 / evals; };   // CU-cycles per point-evaluation at 2.4 GHz, 256 CUs
     printf("lvl %d (%dx%d, n=%d): CU-cycles/point  rowmajor-vec %.2f | rowmajor-scalar %.2f | tiled8x4-scalar %.2f | rowpair16x2-vec %.2f | tiled8x4-rowvec %.2f\n",
            lvl, w, h, n, cyc(t0), cyc(t1), cyc(t2), cyc(t3), cyc(t4));
+    printf("        two points in flight %.2f | four %.2f | non-temporal %.2f | 2 waves/SIMD: %.2f, with four in flight %.2f\n", cyc(t5), cyc(t7), cyc(t6), cyc(t8), cyc(t9));
     hipFree(dp); hipFree(imgs); hipFree(out);
   }
   return 0;
