@@ -26,6 +26,16 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+
+_ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class CommCallbacks(C.Structure):
+    """dmvio_hip_comm_callbacks (include/dmvio_hip.h): a caller-provided transport for the sharded BA iteration."""
+    _fields_ = [("user", C.c_void_p), ("allreduce_sum_f64", _ALLREDUCE_F64), ("allgather", _ALLGATHER)]
+
+
 def _sig(L):
     vp = C.c_void_p
     L.dmvio_hip_last_error.restype = C.c_char_p
@@ -121,6 +131,11 @@ def _sig(L):
     L.dmvio_hip_ba_linearize_local.argtypes = [vp, C.c_int, c_d, c_f, c_i]
     L.dmvio_hip_ba_set_new_frame_energy_th.argtypes = [vp, C.c_float]
     L.dmvio_hip_ba_energy_terms.argtypes = [vp, c_d, c_d]
+    L.dmvio_hip_ba_set_comm.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.dmvio_hip_ba_set_comm_callbacks.argtypes = [vp, C.POINTER(CommCallbacks), C.c_int, C.c_int]
+    L.dmvio_hip_comm_unique_id.argtypes = [c_u8]
+    L.dmvio_hip_comm_init_rank.argtypes = [vp, c_u8, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.dmvio_hip_comm_destroy.argtypes = [vp]
 
 
 def load_library():
@@ -589,6 +604,30 @@ class ImmaturePointsHip:
         return dict(zip(("good", "oob", "outlier", "skipped", "badcondition", "uninitialized"), counts.tolist()))
 
 
+class RcclCommunicator:
+    """ncclComm_t created through the library's wrappers (dmvio_hip_comm_*): rank `rank` of `world` on the context's device.
+    unique_id(): 128 bytes from one rank, to be handed to all ranks (e.g. torch.distributed broadcast) before construction."""
+
+    @staticmethod
+    def unique_id(L):
+        buf = (C.c_ubyte * 128)()
+        _chk(L, L.dmvio_hip_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.L = ctx.L
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        out = C.c_void_p()
+        _chk(self.L, self.L.dmvio_hip_comm_init_rank(ctx.p, buf, int(rank), int(world), C.byref(out)), "comm_init_rank")
+        self.p = out
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_comm_destroy(self.p)
+            self.p = None
+
+
 class BundleAdjusterHip:
     """The sliding window FullSystem::optimize works on, over the C ABI (include/dmvio_hip.h, "sliding-window BA")."""
 
@@ -783,6 +822,40 @@ class BundleAdjusterHip:
         l = C.c_double(lam); e = np.array(lastE, dtype=np.float64); acc = C.c_int(0)
         _chk(self.L, self.L.dmvio_hip_ba_gn_iteration(self.p, iteration, C.byref(l), _d(e), C.byref(acc)), "ba_gn_iteration")
         return bool(acc.value), l.value, e
+
+    # ---- one window over several GPUs: this handle holds the rank's points; the library runs the exchanges itself (include/dmvio_hip.h)
+    def set_comm(self, comm, rank, world):
+        """comm: an RcclCommunicator (or a raw ncclComm_t address); None detaches."""
+        addr = getattr(comm, "p", comm)
+        _chk(self.L, self.L.dmvio_hip_ba_set_comm(self.p, addr, int(rank), int(world)), "ba_set_comm")
+        self._comm_keep = comm
+
+    def set_comm_torch(self, dist, group=None):
+        """The same protocol over torch.distributed CPU collectives (gloo), staged through host memory: for tests and hosts without RCCL peers."""
+        import torch
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def allreduce(_user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:       # never unwind through the C frames
+                return 1
+
+        def allgather(_user, src, dst, nbytes):
+            try:
+                a = np.ctypeslib.as_array(C.cast(src, C.POINTER(C.c_ubyte)), shape=(nbytes,))
+                o = np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_ubyte)), shape=(nbytes * world,))
+                dist.all_gather_into_tensor(torch.from_numpy(o), torch.from_numpy(a.copy()), group=group)
+                return 0
+            except Exception:
+                return 1
+
+        cb = CommCallbacks(None, _ALLREDUCE_F64(allreduce), _ALLGATHER(allgather))
+        self._comm_keep = cb      # the C side stores the function pointers: keep the thunks alive
+        _chk(self.L, self.L.dmvio_hip_ba_set_comm_callbacks(self.p, C.byref(cb), rank, world), "ba_set_comm_callbacks")
 
     def optimize(self, its=6):
         rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))

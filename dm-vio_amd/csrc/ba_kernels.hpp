@@ -126,12 +126,41 @@ struct BADecide {
   BAHostRes* host;
   unsigned int ticket;
   int publish;               // this kernel is the last of its chain: store the ticket
+  // points sharded over ranks (dmvio_hip_ba_set_comm): the linearisation's last workgroup only PACKS this rank's record
+  // [fp64 local energy | n_newest | pad | n_newest energies | -1 padding] (mode 3); the records of all ranks are all-gathered and
+  // k_ba_decide_global takes the decisions over their union, identically on every rank
+  float* xchg_local;         // this rank's record (xchg_width floats)
+  const float* xchg_all;     // world x xchg_width floats, rank order
+  int xchg_width, world;
 };
+#define BA_XCHG_HEADER 4
 enum { BA_GATE_ALWAYS = 0, BA_GATE_ACCEPTED = 1, BA_GATE_REJECTED = 2 };
 __device__ __forceinline__ bool baGateClosed(const BACtl* ctl, const int gate) {
   if (gate == BA_GATE_ALWAYS) return false;
   const int a = __hip_atomic_load(&ctl->accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return gate == BA_GATE_ACCEPTED ? a == 0 : a != 0;
+}
+// sum of the per-workgroup energy partials by all 256 threads of a workgroup: every thread adds a contiguous run, the 256 runs are combined by a
+// fixed pairwise tree — one fixed order for every launch (a single thread walking hundreds of partials would cost tens of microseconds of
+// dependent loads).  Result valid in thread 0.
+__device__ __forceinline__ double baEnergyTree(const double* epart, const int nblocks, double* s_red /*[256]*/) {
+  const int tid = threadIdx.x;
+  const int chunk = (nblocks + 255) / 256;
+  double e = 0;
+  for (int i = tid * chunk; i < min((tid + 1) * chunk, nblocks); i++) e += __hip_atomic_load(epart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s_red[tid] = e;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (tid < w) s_red[tid] += s_red[tid + w]; __syncthreads(); }
+  return s_red[0];
+}
+// mode 3: this rank's record for the all-gather, written by the last workgroup of a linearisation
+__device__ __forceinline__ void baPackBlock(const BADecide& D, const int nblocks) {
+  __shared__ double s_red[256];
+  const int tid = threadIdx.x;
+  const double e = baEnergyTree(D.epart, nblocks, s_red);
+  if (tid == 0) { __builtin_memcpy(D.xchg_local, &e, 8); D.xchg_local[2] = __int_as_float(D.n_newest); D.xchg_local[3] = 0.0f; }
+  for (int i = tid; i < D.xchg_width - BA_XCHG_HEADER; i += 256)
+    D.xchg_local[BA_XCHG_HEADER + i] = i < D.n_newest ? __hip_atomic_load(D.newestE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0f;
 }
 #define BA_DECIDE_KEYS 4096
 // executed by all 256 threads of the last workgroup of a linearisation
@@ -146,31 +175,37 @@ __device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nbloc
   long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
   // energy: every thread adds a contiguous run of the per-workgroup partials, the 256 runs are combined by a fixed pairwise tree — one fixed
   // order for every launch (a single thread walking hundreds of partials would cost tens of microseconds of dependent loads)
-  {
-    const int chunk = (nblocks + 255) / 256;
-    double e = 0;
-    for (int i = tid * chunk; i < min((tid + 1) * chunk, nblocks); i++) e += __hip_atomic_load(D.epart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_red[tid] = e;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) { if (tid < w) s_red[tid] += s_red[tid + w]; __syncthreads(); }
-    if (tid == 0) s_E = s_red[0];
+  const bool gathered = D.world > 0;   // decisions over the all-gathered records of all ranks (k_ba_decide_global)
+  if (!gathered) {
+    const double e = baEnergyTree(D.epart, nblocks, s_red);
+    if (tid == 0) { s_E = e; s_cnt = 0; }
+  } else if (tid == 0) {
+    double e = 0;                        // rank order: the same sum on every rank
+    for (int r = 0; r < D.world; r++) { double v; __builtin_memcpy(&v, D.xchg_all + (size_t)r * D.xchg_width, 8); e += v; }
+    s_E = e; s_cnt = 0;
   }
   __syncthreads();
   tk1 = wall_clock64();
+  const float* const keys_src = gathered ? D.xchg_all : D.newestE;
+  const int keys_n = gathered ? D.world * D.xchg_width : D.n_newest;
+  const int rec_w = gathered ? D.xchg_width : 0;
+  auto loadE = [&](const int i) -> float {   // record headers are not energies
+    if (rec_w && (i % rec_w) < BA_XCHG_HEADER) return -1.0f;
+    return __hip_atomic_load(keys_src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   float th = __hip_atomic_load(D.frameTH + D.newestFrame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (D.update_th) {
-    const int n = D.n_newest;
+    const int n = keys_n;
     auto key = [&](const int i) -> unsigned int {
       if (i < BA_DECIDE_KEYS) return s_keys[i];
-      const float v = __hip_atomic_load(D.newestE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float v = loadE(i);
       return v >= 0 ? __float_as_uint(v) : 0xFFFFFFFFu;
     };
     unsigned int mine = 0;
     for (int base = 0; base < n; base += 8 * 256) {   // eight independent loads per thread in flight (an atomic load per loop trip would serialise on its latency)
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) { const int i = base + q * 256 + tid; v[q] = i < n ? __hip_atomic_load(D.newestE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0f; }
+      for (int q = 0; q < 8; q++) { const int i = base + q * 256 + tid; v[q] = i < n ? loadE(i) : -1.0f; }
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const int i = base + q * 256 + tid;
@@ -495,7 +530,19 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (threadIdx.x == 0) __hip_atomic_store(&D.ctl->cnt_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  baDecideBlock(D, gridDim.x, t_kernel0);
+  if (D.mode == 3) baPackBlock(D, gridDim.x);
+  else baDecideBlock(D, gridDim.x, t_kernel0);
+}
+
+// the decisions of a linearisation whose points are sharded over ranks: one workgroup over the all-gathered records
+__global__ void __launch_bounds__(256) k_ba_decide_global(const BADecide D) { baDecideBlock(D, 0, wall_clock64()); }
+// the all-reduced system -> host-coherent memory, then the chain's ticket
+__global__ void __launch_bounds__(1024) k_ba_publish_sys(const double* __restrict__ src, double* __restrict__ dst, const int count, BAHostRes* __restrict__ host,
+                                                          const unsigned int ticket) {
+  for (int i = threadIdx.x; i < count; i += 1024) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&host->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector

@@ -338,6 +338,7 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   memset(t->h_tot, 0, sizeof(float) * (ACC_PAD + 16));
   HIPCHKP(hipMalloc((void**)&t->d_arrive, sizeof(unsigned int)));
   HIPCHKP(hipMemset(t->d_arrive, 0, sizeof(unsigned int)));
+  HIPCHKP(hipStreamSynchronize(nullptr));   // the clears above run on the NULL stream; the context's stream does not wait for it
   if (const char* e = getenv("DMVIO_HIP_EVAL_BLOCKS")) t->eval_blocks_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);

@@ -1,5 +1,6 @@
 // libdmvio_hip.so — C ABI of the bundle-adjustment path (include/dmvio_hip.h, "sliding-window BA" section).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -7,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <atomic>
+#include <string>
 
 #include "../../include/dmvio_hip.h"
 #include "internal.h"
@@ -87,12 +89,25 @@ struct dmvio_hip_ba {
   float *d_mHdiF = nullptr, *d_mbdSumF = nullptr, *d_mHcd = nullptr, *d_margRec = nullptr, *d_adHTdelta = nullptr;
   long long* d_accTicks = nullptr;   // per-block stamps of k_ba_accumulate (timing mode only)
   int accTicksBlocks = 0;
+  // ---- points sharded over ranks (dmvio_hip_ba_set_comm): every rank holds all keyframes and ITS points; the stitched system is summed by
+  // an all-reduce in HBM on this handle's stream, the accept / threshold decisions are taken over the all-gathered per-rank records
+  int rank = 0, world = 0;           // world == 0: no communicator
+  ncclComm_t nccl = nullptr;         // RCCL communicator (not owned)
+  dmvio_hip_comm_callbacks comm_cb{};   // host-staged transport (MPI, gloo, ...) when nccl == NULL
+  double* d_sys = nullptr;           // [H_A | b_A | H_sc | b_sc | resInA] of this rank's points, all-reduced in place
+  float *d_xchg_local = nullptr, *d_xchg_all = nullptr;
+  int xchg_width = 0;                // floats per rank record: BA_XCHG_HEADER + the largest per-rank count of residuals that target the newest keyframe
+  std::vector<double> h_stage;       // callback transport only
 };
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #x).c_str()); } while (0)
 
 template <class T>
 static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
   HIPCHK(hipMemset(*p, 0, sizeof(T) * std::max<size_t>(n, 1)));
+  // hipMemset clears on the NULL stream without blocking the host, and the handle's stream is non-blocking: without this wait an upload enqueued next could
+  // land before the clear does (seen with two processes sharing a GPU)
+  HIPCHK(hipStreamSynchronize(nullptr));
   b->allocs.push_back((void*)*p);
   return 0;
 }
@@ -185,11 +200,68 @@ static BADecide makeDecide(dmvio_hip_ba* b, int mode, bool update_th, bool publi
   D.thN = H.S.frameEnergyTHN; D.thFacMedian = H.S.frameEnergyTHFacMedian; D.thConstWeight = H.S.frameEnergyTHConstWeight; D.overallW = H.S.overallEnergyTHWeight;
   D.thCap = b->th_cap;
   D.mode = mode; D.update_th = update_th ? 1 : 0;
-  { static const int dbg = getenv("DMVIO_HIP_BA_DBG") ? atoi(getenv("DMVIO_HIP_BA_DBG")) : 0; if (dbg & 1) D.update_th = 0; if (dbg & 2) D.mode = -1; }
   D.ctl = b->d_ctl; D.host = b->h_res;
   D.publish = publish ? 1 : 0;
   if (publish) D.ticket = ++b->ticket;
   return D;
+}
+
+// ---- exchange steps of the sharded iteration.  With an RCCL communicator they are enqueued on the handle's stream between the kernels that produce
+// and consume the buffers (no host hop); the callback transport stages them through host memory.
+static bool sharded(const dmvio_hip_ba* b) { return b->world > 0; }
+static int commAllReduceSum(dmvio_hip_ba* b, double* d_buf, size_t count) {
+  if (b->nccl) { NCCLCHK(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, b->nccl, b->stream)); return 0; }
+  b->h_stage.resize(count);
+  HIPCHK(hipMemcpyAsync(b->h_stage.data(), d_buf, sizeof(double) * count, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->comm_cb.allreduce_sum_f64(b->comm_cb.user, b->h_stage.data(), count) != 0) return failmsg("comm callback allreduce_sum_f64 failed");
+  HIPCHK(hipMemcpyAsync(d_buf, b->h_stage.data(), sizeof(double) * count, hipMemcpyHostToDevice, b->stream));
+  return 0;
+}
+static int commAllGather(dmvio_hip_ba* b, const float* d_in, float* d_out, size_t count_per_rank) {
+  if (b->nccl) { NCCLCHK(ncclAllGather(d_in, d_out, count_per_rank, ncclFloat, b->nccl, b->stream)); return 0; }
+  const size_t bytes = sizeof(float) * count_per_rank;
+  b->h_stage.resize((bytes * (b->world + 1) + 7) / 8);
+  char* in = (char*)b->h_stage.data(); char* out = in + bytes;
+  HIPCHK(hipMemcpyAsync(in, d_in, bytes, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->comm_cb.allgather(b->comm_cb.user, in, out, bytes) != 0) return failmsg("comm callback allgather failed");
+  HIPCHK(hipMemcpyAsync(d_out, out, bytes * b->world, hipMemcpyHostToDevice, b->stream));
+  return 0;
+}
+// record width of the decision exchange: agreed on once per graph (the largest per-rank number of residuals that target the newest keyframe)
+static int ensureExchange(dmvio_hip_ba* b) {
+  if (b->xchg_width) return 0;
+  int mine = (int)b->h_newest.size(), widest = mine;
+  if (b->world > 1) {
+    float* d_tmp = nullptr;
+    if (dalloc(b, &d_tmp, (size_t)b->world + 1)) return -1;
+    const float v = (float)mine;   // exact below 2^24 residuals
+    HIPCHK(hipMemcpyAsync(d_tmp, &v, sizeof(float), hipMemcpyHostToDevice, b->stream));
+    if (int r = commAllGather(b, d_tmp, d_tmp + 1, 1)) return r;
+    std::vector<float> all(b->world);
+    HIPCHK(hipMemcpyAsync(all.data(), d_tmp + 1, sizeof(float) * b->world, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (float a : all) widest = std::max(widest, (int)a);
+  }
+  b->xchg_width = BA_XCHG_HEADER + ((widest + 1) & ~1);   // even: the fp64 energy of every record stays 8-byte aligned
+  if (dalloc(b, &b->d_xchg_local, (size_t)b->xchg_width) || dalloc(b, &b->d_xchg_all, (size_t)b->xchg_width * b->world)) return -1;
+  return 0;
+}
+// tail of a sharded linearisation: the linearisation's last workgroup packed this rank's record (mode 3); gather the records of all ranks and take
+// the decisions of `D` over their union
+static int decideGlobal(dmvio_hip_ba* b, BADecide D) {
+  if (int r = commAllGather(b, b->d_xchg_local, b->d_xchg_all, (size_t)b->xchg_width)) return r;
+  D.xchg_all = b->d_xchg_all; D.xchg_width = b->xchg_width; D.world = b->world;
+  hipLaunchKernelGGL(k_ba_decide_global, dim3(1), dim3(256), 0, b->stream, D);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// the linearisation kernel's view of a decision block when the points are sharded: pack only
+static BADecide packOnly(dmvio_hip_ba* b, const BADecide& D) {
+  BADecide Dp = D;
+  Dp.mode = 3; Dp.publish = 0; Dp.xchg_local = b->d_xchg_local; Dp.xchg_width = b->xchg_width;
+  return Dp;
 }
 
 // FullSystem::linearizeAll (FullSystemOptimize.cpp:150-218) — returns the energy sum; updates the newest frame's energy threshold
@@ -199,12 +271,15 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc of the current state
   if (int r = uploadThresholds(b)) return r;
-  const BADecide D = makeDecide(b, 0, !keep_threshold, !fix);
+  const bool shard = sharded(b);
+  if (shard) { if (int r = ensureExchange(b)) return r; }
+  const BADecide D = makeDecide(b, 0, !keep_threshold, shard || !fix);
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
-                     (const unsigned char*)nullptr, D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+                     (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
-  if (fix) HIPCHK(hipStreamSynchronize(b->stream));
+  if (shard) { if (int r = decideGlobal(b, D)) return r; }
+  if (fix && !shard) HIPCHK(hipStreamSynchronize(b->stream));
   else if (int r = waitTicket(b, D.ticket)) return r;
   *energy = b->h_res->E[0];
   if (!keep_threshold) H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
@@ -245,9 +320,20 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
                      b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
   const int tot = 2 * (n * n + n);
-  b->acc_ticket = ++b->ticket;
-  hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys, b->d_ctl, gate, b->h_res,
-                     b->acc_ticket);
+  if (!sharded(b)) {
+    b->acc_ticket = ++b->ticket;
+    hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys, b->d_ctl, gate, b->h_res,
+                       b->acc_ticket);
+  } else {
+    // this rank's part of the system stays in HBM, is summed over the ranks in place and only then published to the host
+    if (gate != BA_GATE_ALWAYS) return failmsg("sharded accumulation cannot be gated: every rank must enter the collective");
+    hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys, b->d_ctl, gate,
+                       (BAHostRes*)nullptr, 0u);
+    HIPCHK(hipGetLastError());
+    if (int r = commAllReduceSum(b, b->d_sys, (size_t)tot + 1)) return r;
+    b->acc_ticket = ++b->ticket;
+    hipLaunchKernelGGL(k_ba_publish_sys, dim3(1), dim3(1024), 0, s, (const double*)b->d_sys, b->h_sys, tot + 1, b->h_res, b->acc_ticket);
+  }
   HIPCHK(hipGetLastError());
   return wait ? accumulateWait(b) : 0;
 }
@@ -346,6 +432,51 @@ int dmvio_hip_ba_set_accumulators(dmvio_hip_ba* b, int k) {
 int dmvio_hip_ba_keep_jacobians(dmvio_hip_ba* b, int on) {
   if (!b) return failmsg("null ba");
   b->keep_fullJ = on != 0;
+  return 0;
+}
+
+// ---- communicator of a window whose points are sharded over ranks (include/dmvio_hip.h)
+static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callbacks* cb, int rank, int world) {
+  if (!b) return failmsg("null ba");
+  std::lock_guard<std::mutex> lk(b->mu);
+  if (world == 0 || (!comm && !cb)) { b->world = 0; b->rank = 0; b->nccl = nullptr; b->comm_cb = dmvio_hip_comm_callbacks{}; b->sys_ready = false; b->sums_fresh = false; return 0; }
+  if (world < 1 || rank < 0 || rank >= world) return failmsg("ba_set_comm: 0 <= rank < world");
+  if (cb && (!cb->allreduce_sum_f64 || !cb->allgather)) return failmsg("ba_set_comm_callbacks: both callbacks are required");
+  if (comm) {
+    int n = 0, r = -1;
+    NCCLCHK(ncclCommCount(comm, &n));
+    NCCLCHK(ncclCommUserRank(comm, &r));
+    if (n != world || r != rank) return failmsg("ba_set_comm: rank / world do not match the communicator");
+  }
+  b->rank = rank; b->world = world; b->nccl = comm;
+  b->comm_cb = cb ? *cb : dmvio_hip_comm_callbacks{};
+  b->xchg_width = 0;            // agreed on at the next linearisation
+  b->sys_ready = false; b->sums_fresh = false;
+  return 0;
+}
+int dmvio_hip_ba_set_comm(dmvio_hip_ba* b, void* nccl_comm, int rank, int world) { return setComm(b, (ncclComm_t)nccl_comm, nullptr, rank, world); }
+int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* b, const dmvio_hip_comm_callbacks* cb, int rank, int world) { return setComm(b, nullptr, cb, rank, world); }
+int dmvio_hip_comm_unique_id(unsigned char id128[128]) {
+  if (!id128) return failmsg("null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128], int rank, int world, void** out) {
+  if (!ctx || !id128 || !out) return failmsg("null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(ncclCommInitRank(&comm, world, id, rank));
+  *out = (void*)comm;
+  return 0;
+}
+int dmvio_hip_comm_destroy(void* comm) {
+  if (!comm) return 0;
+  NCCLCHK(ncclCommDestroy((ncclComm_t)comm));
   return 0;
 }
 
@@ -550,6 +681,8 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
   // kernels straight into pinned host memory: no copy engine between the last kernel and the host's wait
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent
+  if (dalloc(b, &b->d_sys, (size_t)tot + 1)) return -1;
+  b->xchg_width = 0; b->d_xchg_local = b->d_xchg_all = nullptr;
   HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
   memset(b->h_res, 0, sizeof(BAHostRes));
   HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
@@ -755,6 +888,8 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   BAHost& H = b->H;
   dmvio_hip_ctx* c = b->ctx;
   const int n = H.n();
+  const bool shard = sharded(b);
+  if (shard) { if (int r = ensureExchange(b)) return r; }
   // backupState (the point part rode in the per-point sums that produced the system at hand)
   double tq0 = b->timing ? nowUs() : 0, tq1;
 #define BA_PH(i) do { if (b->timing) { tq1 = nowUs(); b->tm.t[i] += tq1 - tq0; tq0 = tq1; } } while (0)
@@ -802,8 +937,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     BADecide D = makeDecide(b, 1, true, true);
     D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2]; D.newL = newL; D.newM = newM;
     hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
-                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
+                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
     HIPCHK(hipGetLastError());
+    if (shard) { if (int r = decideGlobal(b, D)) return r; }
     BA_PH(3);
     if (int r = waitTicket(b, D.ticket)) return r;   // energy, threshold and the accept / reject decision are in host memory
     BA_PH(4);
@@ -822,8 +958,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     // system in host memory is still the one of the restored state
     const BADecide D2 = makeDecide(b, 2, true, true);
     hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, W_backup, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
-                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, D2, (int)BA_GATE_ALWAYS, 1, dyn_backup, 1, b->x_none, 0);
+                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D2) : D2, (int)BA_GATE_ALWAYS, 1, dyn_backup, 1, b->x_none, 0);
     HIPCHK(hipGetLastError());
+    if (shard) { if (int r = decideGlobal(b, D2)) return r; }
     H.restoreFrames();
     H.setPrecalcValues();
     fillWindow(b);

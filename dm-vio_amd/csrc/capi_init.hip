@@ -24,6 +24,9 @@ template <class T>
 static int nalloc(dmvio_hip_initializer* m, T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
   HIPCHK(hipMemset(*p, 0, sizeof(T) * std::max<size_t>(n, 1)));
+  // hipMemset clears on the NULL stream without blocking the host, and the handle's stream is non-blocking: without this wait an upload enqueued next could
+  // land before the clear does (seen with two processes sharing a GPU)
+  HIPCHK(hipStreamSynchronize(nullptr));
   m->allocs.push_back(*p);
   return 0;
 }

@@ -271,7 +271,33 @@ int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io
 /* Diagnostics: in-kernel timeline of the last decision pass (energy sum, newest keyframe's threshold, accept test — taken by the last
  * workgroup of the linearisation kernel): 100 MHz ticks since that workgroup started: pass begin, energy summed, threshold keys loaded, done. */
 int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* ba, int ticks4[4]);
-/* Building blocks of a SHARDED GN iteration (points of one keyframe per GPU; the packed systems / energies are summed by the caller
+/* ---- One window over several GPUs: every rank holds all keyframes of the window and ITS share of the points (set_graph with the
+ * rank's points only).  With a communicator set, dmvio_hip_ba_linearize / _accumulate / _gn_iteration / _optimize run the sharded iteration
+ * themselves: per linearisation ONE all-gather of the per-rank records [local energy | residual energies of the newest keyframe] (the accept
+ * test and setNewFrameEnergyTH, FullSystemOptimize.cpp:96-149,553, are evaluated over their union, identically on every rank), per accumulation ONE
+ * all-reduce (fp64 sum) of the packed system [H_A | b_A | H_sc | b_sc | resInA] in HBM — both enqueued on the handle's stream between the
+ * kernels that produce and consume the buffers.  Every rank then solves the identical reduced system (EnergyFunctional::solveSystemF replaces
+ * nothing here: the reference has no multi-device path; its multi-THREADED accumulation, IndexThreadReduce + per-thread accumulators summed in
+ * AccumulatedTopHessian::stitchDoubleMT, AccumulatedTopHessian.h:91-139, is the structure this follows).
+ *   nccl_comm: an ncclComm_t of RCCL whose rank `rank` lives on this handle's device (not owned; NULL with world 0 detaches).
+ *   Every rank must issue the same sequence of BA calls. */
+int dmvio_hip_ba_set_comm(dmvio_hip_ba* ba, void* nccl_comm, int rank, int world);
+/* Same protocol over a caller-provided transport (MPI, gloo, ...): buffers are staged through host memory.  Both callbacks return 0 on success.
+ *   allreduce_sum_f64: element-wise sum over all ranks, in place, identical result on every rank.
+ *   allgather: `bytes` bytes per rank, rank order, into out[world * bytes]. */
+typedef struct dmvio_hip_comm_callbacks {
+  void* user;
+  int (*allreduce_sum_f64)(void* user, double* buf, size_t count);
+  int (*allgather)(void* user, const void* in, void* out, size_t bytes);
+} dmvio_hip_comm_callbacks;
+int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* ba, const dmvio_hip_comm_callbacks* cb, int rank, int world);
+/* Convenience wrappers over RCCL for callers without their own communicator: ncclGetUniqueId (128 bytes, to be distributed to all ranks by
+ * the caller), ncclCommInitRank on the context's device, ncclCommDestroy. */
+int dmvio_hip_comm_unique_id(unsigned char id128[128]);
+int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128], int rank, int world, void** nccl_comm_out);
+int dmvio_hip_comm_destroy(void* nccl_comm);
+
+/* Building blocks of a SHARDED GN iteration driven by the caller (points of one keyframe per GPU; the packed systems / energies are summed by the caller
  * with one RCCL all-reduce): backupState, solve of an externally reduced system + resubstitute, doStepFromBackup (sums6 = frame sums
  * A,B,T,R and the local point sums step^2, |idepth_backup|), loadSateBackup, linearizeAll without the setNewFrameEnergyTH tail
  * (returns the newest-frame energies it would use), the threshold setter and the prior / marginalisation energy terms. */

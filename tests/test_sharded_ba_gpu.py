@@ -1,0 +1,72 @@
+"""One BA window over several ranks with the exchanges behind the C ABI (dmvio_hip_ba_set_comm / _set_comm_callbacks)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(pkg, case, ctx, setup=None, its=6):
+    ba = pkg.BundleAdjusterHip(ctx)
+    ba.set_case(case, list(range(case["n_frames"])))
+    if setup:
+        setup(ba)
+    out = ba.optimize(its)
+    poses = np.stack([ba.frame_pose(k)[0] for k in range(case["n_frames"])])
+    idepth = ba.point_state()[0]
+    ba.close()
+    return out, poses, idepth
+
+
+def test_rccl_world1_runs_the_sharded_path_bit_identically(pkg, synth, gpu_required):
+    """An RCCL communicator of one rank: all-reduce and all-gather degenerate to copies, so optimize through the sharded code path (records packed,
+    gathered, decided by k_ba_decide_global; system reduced in HBM and published) must reproduce the single-GPU path bit for bit."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=1500, seed=21)
+    ctx = pkg.Context(case["w"], case["h"], n_slots=8)
+    for k in range(8):
+        ctx.frame_upload(k, case["imgs"][k])
+    ref, rposes, rid = _run(pkg, case, ctx)
+    comm = pkg.RcclCommunicator(ctx, pkg.RcclCommunicator.unique_id(ctx.L), 0, 1)
+    try:
+        out, poses, idepth = _run(pkg, case, ctx, lambda ba: ba.set_comm(comm, 0, 1))
+    finally:
+        comm.close()
+    assert out["iterations"] == ref["iterations"] and out["rmse"] == ref["rmse"] and out["finalEnergy"] == ref["finalEnergy"]
+    assert np.array_equal(out["trace"], ref["trace"])
+    assert np.array_equal(poses, rposes) and np.array_equal(idepth, rid)
+
+
+def test_set_comm_validates_rank_and_world(pkg, synth, gpu_required):
+    ctx = pkg.Context(64, 64, n_slots=2)
+    ba = pkg.BundleAdjusterHip(ctx)
+    comm = pkg.RcclCommunicator(ctx, pkg.RcclCommunicator.unique_id(ctx.L), 0, 1)
+    try:
+        with pytest.raises(pkg.HipLibraryError):
+            ba.set_comm(comm, 1, 2)          # does not match the communicator
+        with pytest.raises(pkg.HipLibraryError):
+            ba.set_comm(comm, 3, 1)
+        ba.set_comm(comm, 0, 1)
+        ba.set_comm(None, 0, 0)              # detach
+    finally:
+        ba.close(); comm.close()
+
+
+def test_sharded_optimize_world2_on_a_shared_device(gpu_required):
+    """Two processes on one GPU, each with its share of the points: identical decisions and frame states on both ranks, the unsharded result within
+    the rounding of a different summation order (tests/dist_worker_gpu.py)."""
+    port = _free_port()
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("OK") == 2, r.stdout
