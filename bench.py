@@ -29,18 +29,22 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int(2 * 1098774.5 * 1024)   # HBM bytes per k_track_lm launch from the committed PMC pass (results go to pinned host memory)
+SETTLE_STEPS = 40              # untimed steps between the warm-up and the timed region (see main)
 BYTES_PER_POINT_EVAL = 64      # 16 B template record + 4 taps x 12 B
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DMVIO_BENCH_BATCH", "1024")), help="frames per step per GPU")
     ap.add_argument("--points", type=int, default=2000, help="reference points (active points of the window)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct rendered frames (replicated into the batch slots)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct rendered frames (0 = one per batch slot: every frame of the batch is its own render at its own pose)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep (256 ... 4096 frames per step)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the leg that uploads the raw frames from pinned host memory inside the step")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child run that measures the HBM traffic of k_track_lm")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -81,8 +85,18 @@ def main():
 
     w = h = args.size
     B = args.batch
-    # ---------------- synthetic inputs (deterministic; rank-dependent jitter so ranks do not share data)
-    case = synth.tracking_case(w, h, n_ref=args.points, seed=synth.SEED + 1000 * rank, n_frames=args.distinct, xi_jitter=0.35)
+    # ---------------- synthetic inputs (deterministic; rank-dependent jitter so ranks do not share data): every frame of the batch is its own render
+    # of the plane world at its own pose (rendered on the device with torch: plumbing)
+    if args.distinct <= 0:
+        args.distinct = B
+    case = synth.tracking_case(w, h, n_ref=args.points, seed=synth.SEED + 1000 * rank, n_frames=1, xi_jitter=0.35)
+    rngx = np.random.RandomState(synth.SEED + 1000 * rank + 2)
+    xi0 = case["frames"][0]["xi"]
+    frames_meta = []
+    for k in range(args.distinct):
+        xi = xi0 if k == 0 else xi0 * (1.0 + 0.35 * rngx.standard_normal(6))
+        R, t = synth.se3_exp(xi)
+        frames_meta.append(dict(R=R, t=t, pose7=synth.pose7(R, t), xi=xi))
     ctx = pkg.Context(w, h, n_slots=B + 1 + 8, device=local_rank)   # slot 0: reference keyframe, 1..B: batch, B+1..B+8: BA window of the overlap leg
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
@@ -93,10 +107,16 @@ def main():
     pc_n = [trk.pc_n(l) for l in range(ctx.levels)]
     # resident raw irradiance images of the batch (device memory via torch: plumbing only)
     raw = torch.empty((B, h, w), dtype=torch.float32, device=dev)   # attached in place: level 0 of each pyramid IS this resident image
-    host_frames = np.stack([f["img"] for f in case["frames"]])
-    raw_distinct = torch.from_numpy(host_frames).to(dev)
+    raw_distinct = synth.render_batch_torch(case["world"], case["K4"], [f["R"] for f in frames_meta], [f["t"] for f in frames_meta], w, h, dev)
     idx = torch.arange(B, device=dev) % args.distinct
     raw.copy_(raw_distinct[idx])
+    n_host = min(args.distinct, 64)                                   # host copies for the CPU baseline and the single-stream legs
+    host_frames = raw_distinct[:n_host].cpu().numpy()
+    for k in range(n_host):
+        frames_meta[k]["img"] = host_frames[k]
+    case["frames"] = frames_meta
+    if args.distinct < B:
+        del raw_distinct
     torch.cuda.synchronize(dev)
     slots = np.arange(1, B + 1, dtype=np.int32)
     rng = np.random.RandomState(99 + rank)
@@ -134,7 +154,7 @@ def main():
     res = None
     for _ in range(max(args.warmup, 1)):
         res = step()
-    truth = np.stack([case["frames"][i % args.distinct]["pose7"] for i in range(B)])
+    truth = np.stack([frames_meta[i % args.distinct]["pose7"] for i in range(B)])
     terr = np.linalg.norm(res["pose7"][:, :3] - truth[:, :3], axis=1)
     n_evals, n_point_evals = trk.last_work()
     if not (res["good"].all() and terr.max() < 5e-3):
@@ -145,7 +165,11 @@ def main():
         if dist is not None:
             dist.barrier()
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
-    step_pipelined(False)                               # untimed: fills the pipeline (its results are unpacked by the first timed step)
+    # untimed: the device settles (clocks, first touches of the freshly allocated pyramids and result buffers: the first ~40 steps after start-up run up to
+    # 2.5x slower), then the pipeline is filled (the results of that launch are unpacked by the first timed step)
+    for _ in range(SETTLE_STEPS):
+        step()
+    step_pipelined(False)
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,11 +207,14 @@ def main():
                     kernel_ms=round(k_ms, 4), algorithmic_bytes_per_launch=int(alg_bytes),
                     point_evals_per_launch=int(n_point_evals), evals_per_launch=int(n_evals),
                     in_kernel_us_per_problem=dict(lm_control=round(tk_step / 100.0 / B, 2), evaluation=round(tk_eval / 100.0 / B, 2)))
-    # HBM traffic of k_track_lm from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the timed process):
-    # 2 x FETCH_SIZE + WRITE_SIZE per launch, valid for the default workload only
-    if B == 1024 and args.points == 2000 and (w, h) == (512, 512) and args.distinct == 8:
-        roofline["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH
-        roofline["traffic_source"] = "profiles/r01_pmc_hbm_traffic_batch1024.md (2 x FETCH_SIZE 1,098,775 KiB per launch; the 0.78 MB of results are stored into pinned host memory, not HBM; below the algorithmic bytes: L2/MALL absorb neighbouring taps)"
+    # HBM traffic of k_track_lm: measured now, by a rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this very workload (rank 0, N = 1), calibrated on
+    # k_build_pyramids of the same run, whose read volume is known exactly (MI355X_MICROARCH.md: gfx950 tallies wide reads at half their size)
+    if rank == 0 and world == 1 and not args.no_traffic and not args.traffic_child:
+        tr = measure_traffic(args, B, w, h)
+        if tr is not None:
+            roofline["traffic"] = tr["traffic"]
+            roofline["traffic_source"] = tr["source"]
+            roofline["frac_hbm_counter"] = round(tr["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     pm = None
     if not args.no_pyramid:
         pms = []
@@ -211,7 +238,7 @@ def main():
         while True:
             i = n_done % B
             tA = time.perf_counter()
-            dIn = O.make_images(host_frames[i % args.distinct], w, h)[0]
+            dIn = O.make_images(host_frames[i % n_host], w, h)[0]
             T.set_new(dIn)
             o = T.track(poses0[i], affs0[i])
             n_done += 1
@@ -221,6 +248,68 @@ def main():
         cpu = dict(value=round(n_done / t_cpu, 2), unit="frames/s", cores=1, kind="port",
                    sample="%d frames of the same batch (makeImages + trackNewestCoarse), oracle -O3 -msse2, 1 thread "
                           "(the reference tracks single-threaded), %.1f s on %s" % (n_done, t_cpu, _cpu_name()))
+
+    out = {
+        "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
+        "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
+                               "per step (%d distinct renders, each at its own pose), makeImages%s (level 0 = the resident image, attached in place; levels 1.. built) + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
+                               "batch k-1 while batch k runs"
+                               % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else ""),
+                   "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "settle_steps": SETTLE_STEPS,
+        "lm_iterations_mean": float(np.mean(res["iterations"])),
+        "max_pose_err_m": float(terr.max()),
+    }
+
+    # the legs below are secondary: if one of them hangs at N > 1 (a rank lost in a collective), the headline line is still printed
+    def _watchdog(signum, frame):
+        if rank == 0:
+            out["ba"] = dict(error="secondary legs timed out")
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    if world > 1:
+        import signal
+        signal.signal(signal.SIGALRM, _watchdog)
+        signal.alarm(240)
+
+    # ---------------- PCIe-inclusive leg (rank 0, N = 1): the same step with the raw frames coming from pinned host memory inside the timed region
+    pcie_out = None
+    if rank == 0 and world == 1 and not args.no_pcie and not args.traffic_child:
+        pinned = torch.empty((B, h, w), dtype=torch.float32, pin_memory=True)
+        pinned.copy_(raw)
+        torch.cuda.synchronize(dev)
+        n_p = max(5, min(args.steps, 20))
+
+        def step_pcie():
+            with torch.cuda.stream(stream):
+                raw.copy_(pinned, non_blocking=True)
+            return step()
+        step_pcie()
+        torch.cuda.synchronize(dev)
+        t0p = time.perf_counter()
+        for _ in range(n_p):
+            rp = step_pcie()
+        torch.cuda.synchronize(dev)
+        tp = (time.perf_counter() - t0p) / n_p
+        ev0.record(stream)
+        with torch.cuda.stream(stream):
+            raw.copy_(pinned, non_blocking=True)
+        ev1.record(stream); ev1.synchronize()
+        h2d_ms = ev0.elapsed_time(ev1)
+        pcie_out = dict(value=round(B / tp, 1), unit="frames/s", ms_per_step=round(1e3 * tp, 4), steps=n_p, h2d_ms=round(h2d_ms, 3),
+                        h2d_GBps=round(B * frame_bytes / (h2d_ms * 1e-3) / 1e9, 2), good=bool(rp["good"].all()),
+                        note="per step: %d x %d B fp32 frames copied from pinned host memory to HBM, then makeImages + trackNewestCoarse + result fetch, not pipelined" % (B, frame_bytes))
+        del pinned
+
+    # ---------------- batch-size sweep (rank 0, N = 1): frames per step from a quarter of the resident workgroup slots to four times their number
+    sweep_out = None
+    if rank == 0 and world == 1 and not args.no_sweep and not args.traffic_child:
+        sweep_out = bench_sweep(args, pkg, torch, dev, stream, case, raw, frames_meta, poses0, w, h)
 
     # ---------------- BA leg: Gauss-Newton iterations / s of the 8-keyframe sliding-window photometric BA (rank 0 window per rank)
     ba_out = None
@@ -254,29 +343,103 @@ def main():
         vio_out = bench_vio(args, pkg, ctx, trk, raw, case, w, h)
 
     if rank == 0:
-        out = {
-            "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
-            "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
-                                   "per step (%d distinct renders), makeImages%s (level 0 = the resident image, attached in place; levels 1.. built) + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
-                                   "batch k-1 while batch k runs"
-                                   % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else ""),
-                       "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "ba": ba_out,
-            "trace": trace_out,
-            "overlap": overlap_out,
-            "live": live_out,
-            "vio_handoff": vio_out,
-            "lm_iterations_mean": float(np.mean(res["iterations"])),
-            "max_pose_err_m": float(terr.max()),
-        }
-        print(json.dumps(out))
+        out.update(ba=ba_out, trace=trace_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        signal.alarm(0)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_traffic(args, B, w, h):
+    """HBM bytes per k_track_lm launch from a `rocprofv3 --kernel-trace --pmc FETCH_SIZE` child run of this workload (counters only, no other tracing)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    d = tempfile.mkdtemp(prefix="dmvio_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ); env["TMPDIR"] = "/tmp"
+        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--no-cpu", "--no-ba",
+               "--no-sweep", "--no-pcie", "--no-traffic", "--steps", "3", "--warmup", "1", "--batch", str(B), "--points", str(args.points), "--size", str(args.size),
+               "--distinct", str(args.distinct)]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if not dbs:
+            return None
+        db = sqlite3.connect(dbs[0])
+        rows = db.execute("select kernel_name, avg(value), max(value), count(*) from counters_collection where counter_name = 'FETCH_SIZE' group by kernel_name").fetchall()
+        lm = [x for x in rows if "k_track_lm" in x[0]]
+        pyr = [x for x in rows if "k_build_pyramids" in x[0]]
+        if not lm or not pyr:
+            return None
+        # calibration: the full-batch pyramid build reads B raw images exactly once (its largest dispatch); FETCH_SIZE is reported in KiB
+        factor = (B * w * h * 4) / (pyr[0][2] * 1024.0)
+        traffic = int(lm[0][1] * 1024.0 * factor)
+        return dict(traffic=traffic, source="rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this workload: %d k_track_lm dispatches, FETCH_SIZE %.1f KiB each, x %.3f "
+                                            "(calibrated in the same run on k_build_pyramids, which reads %d B per launch and reports %.1f KiB)"
+                                            % (lm[0][3], lm[0][1], factor, B * w * h * 4, pyr[0][2]))
+    except Exception as ex:      # a diagnostic must not take the bench down
+        sys.stderr.write("bench: traffic measurement skipped (%s: %s)\n" % (type(ex).__name__, ex))
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def bench_sweep(args, pkg, torch, dev, stream, case, raw, frames_meta, poses0, w, h):
+    """makeImages + trackNewestCoarse for batches of 256 ... 4096 frames (same renders, replicated beyond the distinct ones): where the device fills up
+    (1024 = one 256-thread workgroup in each of the 4 slots of all 256 CUs), what a half-filled second wave costs (1536) and the steady state beyond."""
+    B0 = raw.shape[0]
+    sizes = [256, 512, 1024, 1536, 2048, 4096]
+    Bmax = max(sizes)
+    ctx2 = pkg.Context(w, h, n_slots=Bmax + 1, device=dev.index)
+    ctx2.set_stream(stream.cuda_stream)
+    trk2 = pkg.CoarseTrackerHip(ctx2)
+    trk2.makeK(case["K4"])
+    ctx2.frame_upload(0, case["ref_img"])
+    trk2.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    big = torch.empty((Bmax, h, w), dtype=torch.float32, device=dev)
+    idx = torch.arange(Bmax, device=dev) % B0
+    for c0 in range(0, Bmax, 512):
+        big[c0:c0 + 512] = raw[idx[c0:c0 + 512]]
+    torch.cuda.synchronize(dev)
+    p0 = poses0[np.arange(Bmax) % B0]
+    a0 = np.zeros((Bmax, 2))
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    frame_bytes = w * h * 4
+    rows = []
+    for Bs in sizes:
+        sl = np.arange(1, Bs + 1, dtype=np.int32)
+
+        def one(fetch_prev):
+            ctx2.frames_attach_device_batch(sl, big.data_ptr(), frame_bytes)
+            if fetch_prev:
+                trk2.fetch_begin()
+            trk2.stage(sl, p0[:Bs], a0[:Bs]); trk2.launch()
+            return trk2.fetch() if fetch_prev else None
+        one(False); trk2.fetch(); one(False)
+        torch.cuda.synchronize(dev)
+        n = max(5, min(args.steps, 50))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = one(True)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        trk2.fetch()
+        trk2.stage(sl, p0[:Bs], a0[:Bs])
+        kms = []
+        for _ in range(5):
+            ev0.record(stream); trk2.launch(); ev1.record(stream); ev1.synchronize(); kms.append(ev0.elapsed_time(ev1))
+        trk2.fetch()
+        rows.append(dict(frames_per_step=Bs, value=round(Bs / dt, 1), ms_per_step=round(1e3 * dt, 4), track_kernel_ms=round(float(np.mean(kms)), 4),
+                         track_kernel_us_per_frame=round(1e3 * float(np.mean(kms)) / Bs, 4), good=bool(r["good"].all())))
+    trk2.close() if hasattr(trk2, "close") else None
+    ctx2.close()
+    return dict(unit="frames/s", distinct_frames=int(B0), resident_workgroup_slots=1024, points=rows)
 
 
 def bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h):
@@ -367,7 +530,7 @@ def bench_vio(args, pkg, ctx, trk, raw, case, w, h):
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
     frame_bytes = w * h * 4
     base = raw.data_ptr()
-    nd = args.distinct
+    nd = min(args.distinct, 64)
     for slot in range(1, nd + 1):
         ctx.frames_attach_device_batch([slot], base + (slot - 1) * frame_bytes, frame_bytes)
     frames = 200
@@ -440,7 +603,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
     import dmvio_amd.sharding as sh
     w = h = args.size
     # N == 1: the rank optimises the whole window.  N > 1: ONE window, its points sharded by host keyframe over the ranks
-    # (north_star: "one keyframe per GPU"), the packed dense system all-reduced over RCCL every iteration (strong scaling).
+    # (north_star: "one keyframe per GPU"); the exchanges of the sharded iteration run behind the C ABI (dmvio_hip_ba_set_comm: RCCL
+    # all-reduce of the packed system in HBM + all-gather of the decision records, on the BA handle's stream) — strong scaling.
     case_full = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED)
     parts = sh.partition_points_by_host(case_full["host"], world)
     case = sh.shard_case(case_full, parts[rank]) if world > 1 else case_full
@@ -449,15 +613,21 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
     for k in range(F):
         ctx.frame_upload(k, case["imgs"][k])
     ba = pkg.BundleAdjusterHip(ctx)
-    coll = sh.Collective(dist, coll_dev if coll_dev.type != "cpu" else None)
     ba.set_case(case, list(range(F)))
+    optimize_ms = None
     if world == 1:
-        # correctness guard: the full optimize must decrease the energy
+        # correctness guard: the full optimize must decrease the energy; timed on fresh windows (every step accepted until convergence)
         r = ba.optimize(6)
         if not (r["trace"][-1, 0] < 0.7 * r["trace"][0, 0]):
             raise SystemExit("bench: BA did not converge")
+        ts = []
+        for _ in range(10):
+            ba.set_case(case, list(range(F)))
+            t0 = time.perf_counter(); ba.optimize(6); ts.append(time.perf_counter() - t0)
+        optimize_ms = 1e3 * float(np.median(ts))
         ba.set_case(case, list(range(F)))
     replicas = None
+    comm = None
     if world > 1:
         # reference point for the sharded figure: every rank optimising its OWN whole window (independent windows, no exchange)
         ba_full = pkg.BundleAdjusterHip(ctx)
@@ -475,13 +645,25 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         replicas = world * args.ba_iters / float(tr.item())
         ba_full.close()
-    sba = sh.ShardedBA(ba, coll)
-    e0 = sba.begin()[0]
+        if coll_dev.type != "cpu":
+            # the library's own RCCL communicator: the unique id travels over the process group that launched us
+            uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(pkg.RcclCommunicator.unique_id(ctx.L)), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            torch.cuda.synchronize(dev)
+            comm = pkg.RcclCommunicator(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
+            ba.set_comm(comm, rank, world)
+            transport = "RCCL (ncclAllReduce fp64 sum + ncclAllGather on the BA stream)"
+        else:
+            ba.set_comm_torch(dist)    # single-GPU test hook (gloo, all ranks on one device): RCCL refuses two ranks per device
+            transport = "host-staged callbacks over gloo (test hook)"
+    ba.activate_all(); e0 = ba.linearize_all(False); ba.apply_res()
+    lam, lastE = 1e-5, [e0, 0.0, 0.0]
     for it in range(12):  # warmup (first touches of the freshly allocated window buffers)
-        sba.iteration(it % 6)
-    if not (sba.lastE[0] < 0.8 * e0):
-        raise SystemExit("bench: sharded BA did not reduce the energy (%g -> %g)" % (e0, sba.lastE[0]))
-    lam, lastE = sba.lam, list(sba.lastE)
+        _, lam, lastE = ba.gn_iteration(it % 6, lam, lastE)
+    if not (lastE[0] < 0.8 * e0):
+        raise SystemExit("bench: BA did not reduce the energy (%g -> %g)" % (e0, lastE[0]))
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -489,10 +671,7 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
     t0 = time.perf_counter()
     done = 0
     while done < n_it:   # keep iterating on the same window (accepted or rejected, an iteration does the same work) — like the CPU leg below
-        if world == 1:
-            acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
-        else:
-            sba.iteration(done % 6)
+        acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
         done += 1
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -505,28 +684,28 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
                scaling="strong" if world > 1 else None, shard_points=[int(len(p)) for p in parts],
                window=dict(frames=F, points=int(len(case["u"])), residuals=int(len(case["res_point"]))),
                algorithmic_bytes_per_iter=int(len(case["res_point"]) * 464),
-               note="N=1: whole window on the GPU; N>1: `value` = ONE window, points sharded by host keyframe, one RCCL all-reduce of the packed 68x68 systems + one all-gather per "
-                    "linearisation (latency-bound strong scaling of a ~0.2 ms iteration); `independent_windows_value` = every GPU optimising its own window (weak scaling)")
+               accumulation="4 partial accumulators per bucket (the structure of the reference's multi-threaded accumulation); "
+                            "`value_single_threaded_order` replays the reference's single-threaded summation order bit for bit",
+               note="N=1: whole window on the GPU; N>1: `value` = ONE window, points sharded by host keyframe, per iteration one all-reduce of the packed 68x68 systems + one all-gather per "
+                    "linearisation, both inside dmvio_hip_ba_gn_iteration (latency-bound strong scaling of a <0.1 ms iteration); `independent_windows_value` = every GPU optimising its own window (weak scaling)")
+    if world > 1:
+        out["transport"] = transport
+    if optimize_ms is not None:
+        out["optimize6_ms"] = round(optimize_ms, 4)      # FullSystem::optimize(6) on a fresh window: initial linearisation + 6 iterations + the final fix-linearisation
     if replicas is not None:
         out["independent_windows_value"] = round(replicas, 1)
     if world == 1:
-        # the reference's multi-threaded accumulation order (each worker sums its share of the points in fp32, the shares are added in double):
-        # four partial accumulators per bucket instead of the single-threaded order `value` replays bit for bit
-        keep = os.environ.get("DMVIO_HIP_BA_SPLIT")
-        os.environ["DMVIO_HIP_BA_SPLIT"] = "4"
-        ba4 = pkg.BundleAdjusterHip(ctx)
-        if keep is None: os.environ.pop("DMVIO_HIP_BA_SPLIT")
-        else: os.environ["DMVIO_HIP_BA_SPLIT"] = keep
-        ba4.set_case(case, list(range(F)))
-        ba4.activate_all(); e4 = ba4.linearize_all(False); ba4.apply_res()
-        lam4, lastE4 = 1e-5, [e4, 0.0, 0.0]
+        ba1 = pkg.BundleAdjusterHip(ctx, accumulators=1)
+        ba1.set_case(case, list(range(F)))
+        ba1.activate_all(); e1 = ba1.linearize_all(False); ba1.apply_res()
+        lam1, lastE1 = 1e-5, [e1, 0.0, 0.0]
         for it in range(12):
-            _, lam4, lastE4 = ba4.gn_iteration(it % 6, lam4, lastE4)
+            _, lam1, lastE1 = ba1.gn_iteration(it % 6, lam1, lastE1)
         t0 = time.perf_counter()
         for it in range(n_it):
-            _, lam4, lastE4 = ba4.gn_iteration(it % 6, lam4, lastE4)
-        out["value_4_partial_accumulators"] = round(n_it / (time.perf_counter() - t0), 1)
-        ba4.close()
+            _, lam1, lastE1 = ba1.gn_iteration(it % 6, lam1, lastE1)
+        out["value_single_threaded_order"] = round(n_it / (time.perf_counter() - t0), 1)
+        ba1.close()
     if cpu:
         O = graft.load_oracle()
         res = {}
@@ -542,7 +721,10 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         out["cpu_baseline"] = dict(value=round(res[best], 2), unit="GN-iters/s", cores=best, kind="port", value_6workers=round(res[6], 2), value_1thread=round(res[1], 2),
                                    sample="oracle gn_iteration on the same window: 6 workers (NUM_THREADS 6, persistent pool for linearizeAll + accumulation + resubstitution) "
                                           "and single-threaded, on %s" % _cpu_name())
-    ba.close(); ctx.close()
+    ba.close()
+    if comm is not None:
+        comm.close()
+    ctx.close()
     return out
 
 

@@ -565,7 +565,9 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   int C = 1;
   if (t->lm_cluster_override > 0) C = t->lm_cluster_override;
   else if (!t->lm_threads_override) C = clusterSize(B, t->dev.pc_n[0]);
-  if ((long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
+  // cluster mode synchronises the workgroups of a problem with a device-scope barrier: all of them must be resident at once (256 CUs x 4); one
+  // workgroup per problem has no such limit — batches beyond the resident slots simply queue
+  if (C > 1 && (long)B * C > 1024) return failmsg("track_batch_launch: cluster size too large for the batch (B*C must be <= 1024 resident workgroups)");
   // threads per workgroup: 256 in cluster mode and for full batches (four workgroups per CU); batches that cannot fill the CUs that way
   // (129..512 problems) take 512 threads per problem (measured: B=256 0.47 -> 0.40 ms, B=512 0.62 -> 0.58 ms)
   const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : (B <= 512 ? 512 : 256)));

@@ -147,6 +147,41 @@ def tracking_case(w=512, h=512, n_ref=2000, seed=SEED, xi_true=(0.03, -0.02, 0.0
                 hdiF=np.full(n_ref, 1e-4, dtype=np.float32), frames=frames, world=world)
 
 
+def render_batch_torch(world, K4, Rs, ts, w, h, device, chunk=16, aff=(0.0, 0.0)):
+    """PlaneWorld.render for a batch of cameras, evaluated with torch on `device` (fp64, same formula; plumbing for benchmarks that need thousands
+    of distinct frames — the numpy renderer takes 0.25 s per frame).  Returns a float32 tensor [n, h, w] on the device."""
+    import torch
+    fx, fy, cx, cy = [float(x) for x in K4]
+    f64 = dict(dtype=torch.float64, device=device)
+    ys, xs = torch.meshgrid(torch.arange(h, **f64), torch.arange(w, **f64), indexing="ij")
+    d_c = torch.stack([(xs - cx) / fx, (ys - cy) / fy, torch.ones_like(xs)], -1)
+    n = len(Rs)
+    out = torch.empty((n, h, w), dtype=torch.float32, device=device)
+    for c0 in range(0, n, chunk):
+        R = torch.as_tensor(np.stack(Rs[c0:c0 + chunk]), **f64)
+        t = torch.as_tensor(np.stack(ts[c0:c0 + chunk]), **f64)
+        m = R.shape[0]
+        c_w = -torch.einsum("mji,mj->mi", R, t)
+        d_w = torch.einsum("hwj,mji->mhwi", d_c, R)
+        best_s = torch.full((m, h, w), float("inf"), **f64)
+        img = torch.full((m, h, w), 128.0, **f64)
+        for (nrm, d0), (a, b), (fa, fb, amp, ph) in zip(world.planes, world.bases, world.waves):
+            nrm_t = torch.as_tensor(nrm, **f64); a_t = torch.as_tensor(a, **f64); b_t = torch.as_tensor(b, **f64)
+            denom = d_w @ nrm_t
+            s = ((d0 - c_w @ nrm_t)[:, None, None]) / denom
+            ok = (s > 0.05) & (s < best_s) & torch.isfinite(s)
+            X = c_w[:, None, None, :] + s[..., None] * d_w
+            pa = X @ a_t; pb = X @ b_t
+            val = torch.full((m, h, w), 128.0, **f64)
+            for k in range(len(fa)):
+                val += float(amp[k]) * torch.sin(float(fa[k]) * pa + float(fb[k]) * pb + float(ph[k]))
+            img = torch.where(ok, val, img)
+            best_s = torch.where(ok, s, best_s)
+        img = float(np.exp(aff[0])) * img + float(aff[1])
+        out[c0:c0 + m] = img.clamp(1.0, 254.0).to(torch.float32)
+    return out
+
+
 PATTERN8 = np.array([[0, -2], [-1, -1], [1, -1], [-2, 0], [0, 0], [2, 0], [-1, 1], [0, 2]], dtype=np.int32)  # settings.cpp:296, pattern 8
 
 
