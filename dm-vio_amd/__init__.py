@@ -51,6 +51,7 @@ def _sig(L):
     L.dmvio_hip_frames_from_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
     L.dmvio_hip_frames_attach_device_batch.argtypes = [vp, C.c_int, c_i, vp, C.c_size_t]
     L.dmvio_hip_frame_download.argtypes = [vp, C.c_int, C.c_int, c_f]
+    L.dmvio_hip_frame_abs_squared_grad.argtypes = [vp, C.c_int, C.c_int, c_f, C.POINTER(c_f)]
     L.dmvio_hip_frame_mark_unclean.argtypes = [vp, C.c_int]
     L.dmvio_hip_selftest_divide.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.dmvio_hip_write_result_txt.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, vp, vp]
@@ -267,6 +268,19 @@ class Context:
         out = np.zeros(((self.h >> lvl), (self.w >> lvl), 3), dtype=np.float32)
         _chk(self.L, self.L.dmvio_hip_frame_download(self.p, slot, lvl, _f(out)), "frame_download")
         return out
+
+    def abs_squared_grad(self, slot, n_levels=3, B=None):
+        """FrameHessian::absSquaredGrad[0..n_levels-1] of a resident frame (the pixel selector's input); B = CalibHessian::B (256 floats) or None."""
+        outs = [np.zeros(((self.h >> l), (self.w >> l)), dtype=np.float32) for l in range(n_levels)]
+        ptrs = (C.POINTER(C.c_float) * n_levels)(*[_f(o) for o in outs])
+        Bp = None
+        if B is not None:
+            Bf = np.ascontiguousarray(B, dtype=np.float32)
+            if Bf.size != 256:
+                raise ValueError("B must hold 256 floats")
+            Bp = _f(Bf)
+        _chk(self.L, self.L.dmvio_hip_frame_abs_squared_grad(self.p, slot, n_levels, Bp, ptrs), "frame_abs_squared_grad")
+        return outs
 
 
 class CoarseTrackerHip:

@@ -41,6 +41,10 @@ struct dmvio_hip_tracker {
   int eval_blocks_override = 0;
   int max_eval_blocks = 1024;
   LMProblemIn *h_in = nullptr;   // 2 x batch_cap entries of pinned host memory, read by the kernel directly (each workgroup copies its 120 B into LDS)
+  std::vector<int> h_rank_keys, h_rank_cnt;    // set_ref: host-side ranking of the points that share a pixel
+  std::vector<unsigned char> h_rank;
+  std::vector<int> last_repeat_lvl;            // per problem of the last fetch: the level that ran twice (or -1) ...
+  std::vector<double> last_first_pass_res;     // ... and its residual after the first pass
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
   int out_cur = 0, out_fetch = 0, staged_half = 0;    // half of the last launch / half a pending fetch_begin refers to / half staged for the next launch
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
@@ -179,6 +183,19 @@ dmvio_hip_undistorter* dmvio_hip_undistorter_create(dmvio_hip_ctx* c, int wOrg, 
   if (!c || wOrg < 1 || hOrg < 1 || (bits != 8 && bits != 16)) { failmsg("undistorter_create: bad argument"); return nullptr; }
   if ((remapX == nullptr) != (remapY == nullptr)) { failmsg("undistorter_create: remapX / remapY must both be given or both be NULL"); return nullptr; }
   if (!remapX && (wOrg != c->w || hOrg != c->h)) { failmsg("undistorter_create: passthrough needs wOrg x hOrg == w x h"); return nullptr; }
+  if (remapX) {
+    // the bilinear taps of a remapped pixel are (x, y), (x+1, y), (x, y+1), (x+1, y+1) of the raw image: the reference's remap generation marks everything
+    // outside [0, wOrg-2] x [0, hOrg-2] with -1 (Undistort.cpp, "make rounding resistant"); a table that does not would read out of bounds
+    const size_t nOutChk = (size_t)c->w * c->h;
+    for (size_t i = 0; i < nOutChk; i++) {
+      const float x = remapX[i], y = remapY[i];
+      if (x < 0) continue;
+      if (!(x <= (float)(wOrg - 2)) || !(y >= 0) || !(y <= (float)(hOrg - 2)) || (int)x + 1 >= wOrg || (int)y + 1 >= hOrg) {
+        failmsg("undistorter_create: remap entry outside the raw image (mark invalid pixels with remapX = -1)");
+        return nullptr;
+      }
+    }
+  }
   if (hipSetDevice(c->device) != hipSuccess) { failmsg("undistorter_create: hipSetDevice failed"); return nullptr; }
   dmvio_hip_undistorter* u = new dmvio_hip_undistorter();
   u->ctx = c; u->bytes_per_px = bits / 8;
@@ -291,6 +308,32 @@ int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
   hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, c->d_f3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// FrameHessian::makeImages' absSquaredGrad planes (the input of PixelSelector::makeMaps / makeHists) of a resident frame
+int dmvio_hip_frame_abs_squared_grad(dmvio_hip_ctx* c, int slot, int n_levels, const float* B_lut256, float* const* out_host) {
+  if (!c || !out_host) return failmsg("frame_abs_squared_grad: null argument");
+  if (slot < 0 || slot >= c->n_slots || n_levels < 1 || n_levels > c->levels) return failmsg("frame_abs_squared_grad: out of range");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  // scratch layout inside d_f3 (3*w*h floats): [256-entry response table | level 0 | level 1 | ...]  (sum of the levels < 1.34 w*h)
+  float* d_lut = nullptr;
+  float* d_out = c->d_f3 + 256;
+  if ((size_t)256 + (size_t)c->wl[0] * c->hl[0] * 4 / 3 + 16 > (size_t)3 * c->wl[0] * c->hl[0]) return failmsg("frame_abs_squared_grad: frame too small");
+  if (B_lut256) {
+    d_lut = c->d_f3;
+    HIPCHK(hipMemcpyAsync(d_lut, B_lut256, sizeof(float) * 256, hipMemcpyHostToDevice, c->stream));
+  }
+  size_t off = 0;
+  for (int l = 0; l < n_levels; l++) {
+    const int n = c->wl[l] * c->hl[l];
+    hipLaunchKernelGGL(k_abs_squared_grad, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, l), c->wl[l], c->hl[l], (const float*)d_lut, d_out + off);
+    if (out_host[l]) HIPCHK(hipMemcpyAsync(out_host[l], d_out + off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    off += n;
+  }
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -408,7 +451,7 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
   if (n > t->pts_cap) {
     if (t->d_pts) HIPCHK(hipFree(t->d_pts));
     t->pts_cap = std::max(n, 4096);
-    HIPCHK(hipMalloc((void**)&t->d_pts, sizeof(float) * 4 * t->pts_cap));
+    HIPCHK(hipMalloc((void**)&t->d_pts, sizeof(float) * 5 * t->pts_cap));   // u, v, idepth, hdiF, [per-pixel rank bytes]
   }
   const RefLevels& R = t->R;
   HIPCHK(hipMemsetAsync(t->d_idp, 0, sizeof(float) * R.w[0] * R.h[0], s));
@@ -418,8 +461,33 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
     HIPCHK(hipMemcpyAsync(t->d_pts + 1 * (size_t)t->pts_cap, v, sizeof(float) * n, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(t->d_pts + 2 * (size_t)t->pts_cap, idepth, sizeof(float) * n, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(t->d_pts + 3 * (size_t)t->pts_cap, hdiF, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_ref_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, t->d_pts, t->d_pts + t->pts_cap, t->d_pts + 2 * (size_t)t->pts_cap,
-                       t->d_pts + 3 * (size_t)t->pts_cap, t->d_idp, t->d_wsp, R.w[0], R.h[0]);
+    // rank of every point among the points of its pixel (index order), by open addressing on the host: pixels with more than two points are scattered
+    // rank by rank (k_ref_scatter)
+    int maxRank = 0;
+    {
+      size_t cap = 64;
+      while (cap < 2 * (size_t)n + 16) cap <<= 1;
+      t->h_rank_keys.assign(cap, -1); t->h_rank_cnt.assign(cap, 0); t->h_rank.resize(n);
+      for (int i = 0; i < n; i++) {
+        const int ui = (int)(u[i] + 0.5f), vi = (int)(v[i] + 0.5f);
+        if (ui < 0 || vi < 0 || ui >= R.w[0] || vi >= R.h[0]) { t->h_rank[i] = 0; continue; }
+        const int key = ui + R.w[0] * vi;
+        size_t hpos = ((unsigned)key * 2654435761u) & (cap - 1);
+        while (t->h_rank_keys[hpos] != -1 && t->h_rank_keys[hpos] != key) hpos = (hpos + 1) & (cap - 1);
+        t->h_rank_keys[hpos] = key;
+        const int r = t->h_rank_cnt[hpos]++;
+        t->h_rank[i] = (unsigned char)std::min(r, 255);
+        maxRank = std::max(maxRank, std::min(r, 255));
+      }
+    }
+    const unsigned char* d_rank = nullptr;
+    if (maxRank >= 2) {
+      HIPCHK(hipMemcpyAsync(t->d_pts + 4 * (size_t)t->pts_cap, t->h_rank.data(), (size_t)n, hipMemcpyHostToDevice, s));
+      d_rank = (const unsigned char*)(t->d_pts + 4 * (size_t)t->pts_cap);
+    }
+    for (int r = 1; r <= std::max(maxRank, 1); r++)
+      hipLaunchKernelGGL(k_ref_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, t->d_pts, t->d_pts + t->pts_cap, t->d_pts + 2 * (size_t)t->pts_cap,
+                         t->d_pts + 3 * (size_t)t->pts_cap, t->d_idp, t->d_wsp, R.w[0], R.h[0], d_rank, r == 1 ? 0 : r, r);
   }
   if (R.levels > 1) {
     const size_t npool = R.total - R.off[1];
@@ -527,6 +595,10 @@ int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* t, int B, const int* 
   // problems and results live in two halves of pinned host memory used alternately: the launch before the last one (same half) must have
   // finished before its inputs are overwritten; the last launch may still be running
   const int half = t->out_cur ^ 1;
+  // ... and its results must have been picked up: with a fetch_begin outstanding on that half, a second batch staged behind it would have the kernel
+  // overwrite results nobody has read yet
+  if (t->fetch_pending_B > 0 && half == t->out_fetch)
+    return failmsg("track_batch_stage: the results marked by track_batch_fetch_begin have not been fetched yet (one batch may be staged behind them, not two)");
   if (t->done_event[half]) HIPCHK(hipEventSynchronize(t->done_event[half]));
   for (int i = 0; i < B; i++) {
     if (new_slots[i] < 0 || new_slots[i] >= c->n_slots) return failmsg("track: frame slot out of range");
@@ -634,6 +706,8 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
     if (b) memcpy(b + 8 * i, o.b, sizeof(double) * 8);
     if (good) good[i] = o.good;
     if (iterations) iterations[i] = o.iterations;
+    if ((int)t->last_repeat_lvl.size() < B) { t->last_repeat_lvl.resize(B); t->last_first_pass_res.resize(B); }
+    t->last_repeat_lvl[i] = o.repeated_lvl; t->last_first_pass_res[i] = o.first_pass_res;
     ev += o.n_evals; pe += o.n_point_evals; t->last_ticks_step += o.ticks_step; t->last_ticks_eval += o.ticks_eval;
   }
   t->last_evals = ev; t->last_point_evals = pe;
@@ -844,7 +918,8 @@ int dmvio_hip_make_track_hypotheses(const double slast_c2w[7], const double spre
 // the best residuals so far (achievedRes) to the next try as abort thresholds.  Here try 0 runs alone (the usual winner); only if it
 // misses the re-track threshold the remaining tries run as ONE batch without thresholds, and the sequential rule is replayed on
 // their per-level residuals: a level residual above 1.5x the running threshold marks the try as aborted at that level, exactly as
-// CoarseTracker.cpp:731-732 would have — per-level results do not depend on the thresholds, so the outcome is identical.
+// CoarseTracker.cpp:731-732 would have (a level repeated after levelCutoffRepeat is tested with the residual of each of its two passes) — per-level
+// results do not depend on the thresholds, so the outcome is identical.
 int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float new_exposure, int n_tries, const double* tries7, const double aff_last[2],
                                        double lastCoarseRMSE_io[5], double reTrackThreshold, double pose7_out[7], double aff_out[2], double flow_out[3],
                                        int* winner, int* tries_used, int* tracking_good) {
@@ -852,7 +927,8 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
   if (n_tries < 1) return failmsg("track_new_coarse: no hypotheses");
   const int L = t->ctx->levels;
   std::vector<double> poses(tries7, tries7 + 7 * (size_t)n_tries), affs(2 * (size_t)n_tries), lr(5 * (size_t)n_tries), fl(3 * (size_t)n_tries);
-  std::vector<int> good(n_tries), slots(n_tries, new_slot);
+  std::vector<int> good(n_tries), slots(n_tries, new_slot), rep_lvl(n_tries, -1);
+  std::vector<double> rep_first(n_tries, NAN);
   std::vector<float> exps(n_tries, new_exposure);
   for (int i = 0; i < n_tries; i++) { affs[2 * i] = aff_last[0]; affs[2 * i + 1] = aff_last[1]; }
   double achieved[5];
@@ -867,6 +943,7 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
       const int first = computed, cnt = (first == 0) ? 1 : n_tries - first;
       if (int r = dmvio_hip_tracker_track_batch(t, cnt, slots.data() + first, exps.data() + first, poses.data() + 7 * first, affs.data() + 2 * first, L - 1, nullptr,
                                                 lr.data() + 5 * first, fl.data() + 3 * first, nullptr, nullptr, good.data() + first, nullptr)) return r;
+      for (int k = 0; k < cnt; k++) { rep_lvl[first + k] = t->last_repeat_lvl[k]; rep_first[first + k] = t->last_first_pass_res[k]; }
       computed = first + cnt;
     }
     used++;
@@ -875,6 +952,12 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
     for (int k = 0; k < 5; k++) res[k] = NAN;
     bool ok = good[i] != 0, aborted = false;
     for (int lvl = L - 1; lvl >= 0; lvl--) {
+      // a level that ran twice (levelCutoffRepeat) met the abort test after each pass, the first time with the residual the repeat later overwrote
+      if (lvl == rep_lvl[i]) {
+        const double r1 = rep_first[i];
+        res[lvl] = r1;
+        if (std::isnan(r1) || r1 > 1.5 * achieved[lvl]) { aborted = true; break; }
+      }
       const double rv = lr[5 * i + lvl];
       res[lvl] = rv;
       if (std::isnan(rv) || rv > 1.5 * achieved[lvl]) { aborted = true; break; }

@@ -97,9 +97,10 @@ struct LMProblemOut {
   int good;
   int iterations;
   int n_evals;
-  int pad_;
+  int repeated_lvl;        // the level that ran twice (levelCutoffRepeat, CoarseTracker.cpp:735-739) or -1
   long long n_point_evals;
   long long ticks_step, ticks_eval;  // wall_clock64 (100 MHz) spent in LM control steps / evaluations
+  double first_pass_res;   // lastResiduals[repeated_lvl] after its FIRST pass (the abort rule :731 saw that value before the repeat overwrote it)
 };
 
 }  // namespace dmv

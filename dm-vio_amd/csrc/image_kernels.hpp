@@ -132,4 +132,24 @@ __global__ void __launch_bounds__(256) k_level_to_f3(const float* __restrict__ I
   }
 }
 
+// absSquaredGrad[lvl] of FrameHessian::makeImages (HessianBlocks.cpp:169-189): dx*dx + dy*dy, times (B[c+1] - B[c])^2 of CalibHessian::getBGradOnly
+// (HessianBlocks.h:394-400) when a response table is given (setting_gammaWeightsPixelSelect == 1).  Rows 0 and h-1, which the reference never writes, are zero.
+__global__ void __launch_bounds__(256) k_abs_squared_grad(const float* __restrict__ I, const int w, const int h, const float* __restrict__ B, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= w * h) return;
+  float v = 0.f;
+  if (idx >= w && idx < w * (h - 1)) {
+    const float2 g = gradAt(I, w, h, idx % w, idx / w);
+    v = g.x * g.x + g.y * g.y;
+    if (B) {
+      int c = (int)(I[idx] + 0.5f);
+      if (c < 5) c = 5;
+      if (c > 250) c = 250;
+      const float gw = B[c + 1] - B[c];
+      v *= gw * gw;
+    }
+  }
+  out[idx] = v;
+}
+
 }  // namespace dmv

@@ -24,11 +24,16 @@ struct RefLevels {
   size_t total;                    // total pixels over all levels
 };
 
+// The reference adds the points of a pixel one after the other (CoarseTracker.cpp:151-165).  Two float atomics on one pixel commute (0 + a + b); a third
+// would make the sum depend on the arrival order, so the host ranks the points of every pixel by index (`rank`, NULL when no pixel holds more than two) and
+// launches ranks [0,1] together and every further rank as its own launch behind them: sequential order, no data race.
 __global__ void __launch_bounds__(256) k_ref_scatter(const int n, const float* __restrict__ u, const float* __restrict__ v,
                                                       const float* __restrict__ idepth, const float* __restrict__ hdiF,
-                                                      float* __restrict__ id0, float* __restrict__ ws0, const int w0, const int h0) {
+                                                      float* __restrict__ id0, float* __restrict__ ws0, const int w0, const int h0,
+                                                      const unsigned char* __restrict__ rank, const int rank_lo, const int rank_hi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (rank) { const int r = rank[i]; if (r < rank_lo || r > rank_hi) return; }
   const int ui = (int)(u[i] + 0.5f);
   const int vi = (int)(v[i] + 0.5f);
   if (ui < 0 || vi < 0 || ui >= w0 || vi >= h0) return;  // the reference would write out of bounds here

@@ -600,7 +600,7 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
             action = ACT_DONE;
             break;
           }
-          if (S.cutoffRepeat > 1 && !S.haveRepeated) { S.lvl++; S.haveRepeated = 1; }
+          if (S.cutoffRepeat > 1 && !S.haveRepeated) { out.repeated_lvl = S.lvl; out.first_pass_res = S.lastRes[S.lvl]; S.lvl++; S.haveRepeated = 1; }
           S.lvl--;
           S.st = LM_LEVEL_BEGIN;
           continue;
@@ -761,6 +761,7 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     for (int i = 0; i < 3; i++) S.flow[i] = 1000;
     S.lvl = coarsestLvl; S.st = LM_LEVEL_BEGIN; S.totalIts = 0; S.nEvals = 0; S.nPointEvals = 0; S.haveRepeated = 0;
     S.iteration = 0; S.lambda = 0.01f; S.cutoffRepeat = 1; S.incNorm = 0;
+    pout.repeated_lvl = -1; pout.first_pass_res = __builtin_nan("");
   }
   if (threadIdx.x < 64) { s_H[threadIdx.x] = 0; if (threadIdx.x < 8) { s_b[threadIdx.x] = 0; s_x[threadIdx.x] = 0; } }
   initStage<T>(s_stage);

@@ -80,6 +80,11 @@ int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* ctx, int B, const int* s
 int dmvio_hip_frame_mark_unclean(dmvio_hip_ctx* ctx, int slot);
 /* dIp[lvl] back on host as w_l*h_l*3 floats (AoS, the reference's Eigen::Vector3f layout). */
 int dmvio_hip_frame_download(dmvio_hip_ctx* ctx, int slot, int lvl, float* dIp_host);
+/* absSquaredGrad[0..n_levels-1] of FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:169-189) — the planes PixelSelector::makeMaps /
+ * makeHists read (src/dso/FullSystem/PixelSelector2.cpp) — computed from the resident intensity planes of `slot` and copied to out_host[l] (w_l*h_l floats each,
+ * NULL entries are skipped).  B_lut256 = CalibHessian::B (256 floats) applies the getBGradOnly weights of setting_gammaWeightsPixelSelect == 1
+ * (HessianBlocks.h:394-400); NULL = no response weighting.  Rows 0 and h_l-1 (never written by the reference) are zero.  Bit-identical to the CPU path. */
+int dmvio_hip_frame_abs_squared_grad(dmvio_hip_ctx* ctx, int slot, int n_levels, const float* B_lut256, float* const* out_host);
 
 /* ------------------------------------------------------------------ coarse tracker ----------- */
 typedef struct dmvio_hip_tracker_settings {

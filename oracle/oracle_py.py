@@ -82,8 +82,9 @@ def pyr_levels(w, h):
     return lib().orc_pyr_levels(w, h)
 
 
-def make_images(color, w, h):
-    """FrameHessian::makeImages -> (list of [h_l,w_l,3] f32, list of [h_l,w_l] f32 absSquaredGrad)."""
+def make_images(color, w, h, B=None):
+    """FrameHessian::makeImages -> (list of [h_l,w_l,3] f32, list of [h_l,w_l] f32 absSquaredGrad); B = CalibHessian::B (256 floats) weights
+    absSquaredGrad by getBGradOnly^2 (setting_gammaWeightsPixelSelect == 1)."""
     L = lib()
     levels = L.orc_pyr_levels(w, h)
     color = np.ascontiguousarray(color, dtype=np.float32).reshape(-1)
@@ -91,7 +92,12 @@ def make_images(color, w, h):
     ab = [np.zeros(((h >> l), (w >> l)), dtype=np.float32) for l in range(levels)]
     dp = (c_f * levels)(*[_f(a) for a in dI])
     ap = (c_f * levels)(*[_f(a) for a in ab])
-    L.orc_make_images(_f(color), w, h, levels, dp, ap)
+    if B is None:
+        L.orc_make_images(_f(color), w, h, levels, dp, ap)
+    else:
+        Bf = np.ascontiguousarray(B, dtype=np.float32)
+        assert Bf.size == 256
+        L.orc_make_images_gamma(_f(color), w, h, levels, dp, ap, _f(Bf))
     return dI, ab
 
 

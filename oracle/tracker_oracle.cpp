@@ -475,7 +475,10 @@ int orc_pyr_levels(int w, int h) {
 // makeImages: color[w*h] -> per level dIp (float3 AoS), abs (absSquaredGrad, identity gamma).
 // dIp_out[l] must hold 3*w_l*h_l floats; abs_out[l] w_l*h_l floats (may be NULL).
 // Rows 0 and h-1 of dx/dy (never written by the reference) are zero here.
-void orc_make_images(const float* color, int w0, int h0, int levels, float** dIp_out, float** abs_out) {
+void orc_make_images_gamma(const float* color, int w0, int h0, int levels, float** dIp_out, float** abs_out, const float* B256);
+void orc_make_images(const float* color, int w0, int h0, int levels, float** dIp_out, float** abs_out) { orc_make_images_gamma(color, w0, h0, levels, dIp_out, abs_out, nullptr); }
+// B256 = CalibHessian::B: absSquaredGrad is weighted by getBGradOnly(color)^2 (HessianBlocks.cpp:184-188, HessianBlocks.h:394-400); NULL = unweighted
+void orc_make_images_gamma(const float* color, int w0, int h0, int levels, float** dIp_out, float** abs_out, const float* B256) {
   for (int lvl = 0; lvl < levels; lvl++) {
     int wl = w0 >> lvl, hl = h0 >> lvl;
     V3f* dI_l = (V3f*)dIp_out[lvl];
@@ -498,7 +501,16 @@ void orc_make_images(const float* color, int w0, int h0, int levels, float** dIp
       if (!std::isfinite(dx)) dx = 0;
       if (!std::isfinite(dy)) dy = 0;
       dI_l[idx].v[1] = dx; dI_l[idx].v[2] = dy;
-      if (dabs_l) dabs_l[idx] = dx * dx + dy * dy;  // gamma weight B[c+1]-B[c] == 1 for the identity response
+      if (dabs_l) {
+        dabs_l[idx] = dx * dx + dy * dy;
+        if (B256) {
+          int c = dI_l[idx].v[0] + 0.5f;
+          if (c < 5) c = 5;
+          if (c > 250) c = 250;
+          float gw = B256[c + 1] - B256[c];
+          dabs_l[idx] *= gw * gw;
+        }
+      }
     }
   }
 }

@@ -135,6 +135,26 @@ def test_fetch_begin_keeps_consecutive_batches_apart(pkg, oracle, synth, gpu_req
         trk.stage(list(range(1, 7)) * 20, [IDENT] * 120, [(0.0, 0.0)] * 120)
 
 
+def test_second_batch_behind_an_unfetched_one_is_refused(pkg, synth, gpu_required):
+    """fetch_begin keeps the results of launch k in one pinned half while launch k+1 runs into the other; staging launch k+2 before fetching k would
+    overwrite them: the library refuses instead."""
+    case = synth.tracking_case(256, 256, n_ref=400, seed=3, n_frames=2)
+    ctx = pkg.Context(256, 256, n_slots=3)
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, case["frames"][0]["img"]); ctx.frame_upload(2, case["frames"][1]["img"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    ident = np.array([[0, 0, 0, 0, 0, 0, 1.0]]); aff = np.zeros((1, 2))
+    trk.stage([1], ident, aff); trk.launch()
+    trk.fetch_begin()
+    trk.stage([2], ident, aff); trk.launch()
+    with pytest.raises(pkg.HipLibraryError):
+        trk.stage([1], ident, aff)
+    a = trk.fetch()                      # results of the first launch, intact
+    b = trk.fetch()                      # then those of the second
+    ra = trk.track_batch([1], ident, aff); rb = trk.track_batch([2], ident, aff)
+    assert np.array_equal(a["pose7"], ra["pose7"]) and np.array_equal(b["pose7"], rb["pose7"])
+
+
 def test_guarded_and_guard_free_paths_agree_bit_for_bit(pkg, synth, gpu_required):
     """A frame whose pixels are all finite is stamped clean by its pyramid build and tracked without the isfinite guards; withdrawing the
     stamp selects the guarded loop — same bits in every output."""

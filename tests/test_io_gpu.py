@@ -25,3 +25,9 @@ def test_upload_raw_bit_exact(pkg, oracle, gpu_required, bits):
     assert np.array_equal(img2, oracle.undistort(c2["raw"], None, None, None, None, c["w"], c["h"], factor=0.25))
     with pytest.raises(pkg.HipLibraryError):
         pkg.UndistorterHip(ctx, c["wOrg"], c["hOrg"], bits)      # passthrough with a different raw size
+    # a remap entry whose bilinear taps would leave the raw image is refused when the table is handed over (the kernel does not bounds-check per tap)
+    for bad_x, bad_y in ((c["wOrg"] - 1.0, 3.0), (5.0, c["hOrg"] - 1.0), (5.0, -0.5), (float("nan"), 2.0)):
+        rx, ry = c["rx"].copy(), c["ry"].copy()
+        rx.flat[17] = bad_x; ry.flat[17] = bad_y
+        with pytest.raises(pkg.HipLibraryError):
+            pkg.UndistorterHip(ctx, c["wOrg"], c["hOrg"], bits, c["G"], c["vig"], rx, ry)

@@ -146,6 +146,20 @@ def test_make_images_bitwise(O, synth, wh):
         assert same(abr[l][1:-1], abo[l][1:-1])
 
 
+def test_abs_squared_grad_with_response_table_bitwise(O, synth):
+    """absSquaredGrad weighted by CalibHessian::getBGradOnly^2 (setting_gammaWeightsPixelSelect == 1, HessianBlocks.cpp:184-188) for a non-linear response."""
+    w, h = 320, 240
+    rng = np.random.default_rng(6)
+    img = (rng.random((h, w)) * 255).astype(np.float32)
+    B = (255.0 * (np.arange(256) / 255.0) ** 0.7).astype(np.float32)
+    _, abr = R.make_images(img, w, h, B=B)
+    _, abo = O.make_images(img, w, h, B=B)
+    _, plain = O.make_images(img, w, h)
+    for l in range(len(abr)):
+        assert same(abr[l][1:-1], abo[l][1:-1])
+    assert not same(abo[0][1:-1], plain[0][1:-1])
+
+
 # ---------------------------------------------------------------------------------------------------------------- tracker
 def _trackers(O, synth, w, h, n_ref, seed=0, exposure=(1.0, 1.0), aff_ref=(0.0, 0.0)):
     case = synth.tracking_case(w, h, n_ref=n_ref, seed=seed) if seed else synth.tracking_case(w, h, n_ref=n_ref)

@@ -43,6 +43,26 @@ def test_pyramid_bit_exact(setup):
         assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), "level %d differs" % lvl
 
 
+@pytest.mark.parametrize("wh", [(512, 512), (640, 480), (200, 120)])
+def test_abs_squared_grad_bit_exact(pkg, oracle, gpu_required, wh):
+    """FrameHessian::absSquaredGrad of levels 0..2 (the pixel selector's input), with and without the response-table weights: identical to the CPU path,
+    rows 0 and h-1 zero."""
+    w, h = wh
+    rng = np.random.default_rng(8)
+    img = (rng.random((h, w)) * 255).astype(np.float32)
+    img[5, 7] = 0.2; img[9, 3] = 254.9          # clamp ends of getBGradOnly
+    ctx = pkg.Context(w, h, n_slots=1)
+    ctx.frame_upload(0, img)
+    B = (255.0 * (np.arange(256) / 255.0) ** 0.7).astype(np.float32)
+    for lut in (None, B):
+        got = ctx.abs_squared_grad(0, 3, B=lut)
+        _, want = oracle.make_images(img, w, h, B=lut)
+        for l in range(3):
+            assert got[l].tobytes() == want[l].tobytes(), (l, lut is not None)
+            assert not got[l][0].any() and not got[l][-1].any()
+    ctx.close()
+
+
 def test_pyramid_batch_from_device(setup, pkg):
     """Batched makeImages from device-resident raw images == per-frame upload path, bit for bit."""
     import torch
@@ -93,6 +113,36 @@ def test_set_ref_bit_exact(setup):
         o = T.get_pc(lvl)
         for a, b, name in zip(g, o, "u v idepth color".split()):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "pc_%s level %d" % (name, lvl)
+
+
+def test_set_ref_many_points_on_one_pixel_follow_the_reference_order(pkg, oracle, synth, gpu_required):
+    """Three and more points that round to the same pixel: makeCoarseDepthL0 adds them in index order (CoarseTracker.cpp:151-165); float sums of three
+    terms do not commute, so the template must come out identical to the sequential CPU loop run after run."""
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=600, seed=77, n_frames=1)
+    rng = np.random.RandomState(4)
+    u, v, idp, hd = [np.array(case[k], dtype=np.float32) for k in ("u", "v", "idepth", "hdiF")]
+    # pile groups of 3..7 points onto single pixels, with idepths / weights spread over several orders of magnitude
+    pos = 0
+    for g in range(40):
+        m = 3 + g % 5
+        sel = np.arange(pos, pos + m); pos += m
+        u[sel] = u[sel[0]] + rng.uniform(-0.4, 0.4, m).astype(np.float32); v[sel] = v[sel[0]] + rng.uniform(-0.4, 0.4, m).astype(np.float32)
+        u[sel] = np.round(u[sel[0]]) + rng.uniform(-0.45, 0.45, m).astype(np.float32); v[sel] = np.round(v[sel[0]]) + rng.uniform(-0.45, 0.45, m).astype(np.float32)
+        idp[sel] = (10.0 ** rng.uniform(-2, 0.5, m)).astype(np.float32); hd[sel] = (10.0 ** rng.uniform(-6, -1, m)).astype(np.float32)
+    perm = rng.permutation(len(u))          # the groups' members far apart in index
+    u, v, idp, hd = u[perm], v[perm], idp[perm], hd[perm]
+    ctx = pkg.Context(w, h, n_slots=1)
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"])
+    T = oracle.Tracker(w, h); T.make_k(case["K4"])
+    T.set_ref(oracle.make_images(case["ref_img"], w, h)[0], u, v, idp, hd)
+    for rep in range(3):
+        trk.setCoarseTrackingRef(0, u, v, idp, hd)
+        for lvl in range(ctx.levels):
+            assert trk.pc_n(lvl) == T.pc_n(lvl)
+            for a, b, name in zip(trk.get_pc(lvl), T.get_pc(lvl), "u v idepth color".split()):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "pc_%s level %d, repetition %d" % (name, lvl, rep)
 
 
 def _cmp_eval(rs_g, H_g, b_g, rs_o, H_o, b_o, tol=2e-5):
