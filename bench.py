@@ -674,13 +674,30 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         acc, lam, lastE = ba.gn_iteration(done % 6, lam, lastE)
         done += 1
     torch.cuda.synchronize(dev)
+    elapsed_calls = time.perf_counter() - t0
+    # the same iterations inside the library's own FullSystem::optimize loop (the reference's call surface): no foreign-function call per iteration, and after a
+    # rejected step the host goes on to the next solve while the restored state is still being relinearised (its energy stays on the device for the accept test)
+    per_call = 50
+    n_calls = max(1, n_it // per_call)
+    ba.optimize(per_call)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_calls):
+        ba.optimize(per_call)
+    torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    done = n_calls * per_call
     case = case_full
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     out = dict(metric="BA GN-iterations/sec (8-KF window)", value=round(done / elapsed, 1), unit="GN-iters/s", ms_per_iter=round(1e3 * elapsed / done, 4),
+               value_per_call_api=round(n_it / elapsed_calls, 1),
+               loop="`value`: %d x dmvio_hip_ba_optimize(%d) on the converged window (each call: initial linearisation, %d GN iterations, final fix-linearisation; all of it "
+                    "charged to the iterations); `value_per_call_api`: one dmvio_hip_ba_gn_iteration call per iteration from the harness (round-1 definition)" % (n_calls, per_call, per_call),
                scaling="strong" if world > 1 else None, shard_points=[int(len(p)) for p in parts],
                window=dict(frames=F, points=int(len(case["u"])), residuals=int(len(case["res_point"]))),
                algorithmic_bytes_per_iter=int(len(case["res_point"]) * 464),

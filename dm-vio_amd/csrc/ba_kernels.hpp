@@ -104,6 +104,8 @@ struct BACtl {
   unsigned int cnt_gather;
   int accept;                // decision of the last accept test
   int pad;
+  double lastE0;             // photometric energy of the state the window stands at: set by every decision pass (an accepted step's energy, a plain or a
+                             // restored state's), read by the next accept test — the host need not wait for a rejected step's relinearisation
 };
 struct BAHostRes {           // host-coherent pinned memory, polled by the host
   double E[2];               // [0] energy of the last plain / stepped-state linearisation, [1] of the relinearisation after a rejected step
@@ -122,6 +124,7 @@ struct BADecide {
   int mode;                  // -1 no decision pass at all, 0 energy + threshold, 1 + accept test of a stepped state, 2 relinearisation after a rejected step
   int update_th;
   double lastE0, lastL, lastM, newL, newM;
+  int lastE0_from_ctl;       // the accept test compares with BACtl::lastE0 instead of the host's copy
   BACtl* ctl;
   BAHostRes* host;
   unsigned int ticket;
@@ -260,11 +263,16 @@ __device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nbloc
     const int slot = D.mode == 2 ? 1 : 0;
     if (D.update_th) __hip_atomic_store(D.frameTH + D.newestFrame, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (D.mode == 1) {
-      const int acc = (E + D.newL + D.newM < D.lastE0 + D.lastL + D.lastM) ? 1 : 0;   // FullSystemOptimize.cpp:553-554 (energy[1] = 0, dynamic weight 1)
+      const double lastE0 = D.lastE0_from_ctl ? __hip_atomic_load(&D.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.lastE0;
+      const int acc = (E + D.newL + D.newM < lastE0 + D.lastL + D.lastM) ? 1 : 0;   // FullSystemOptimize.cpp:553-554 (energy[1] = 0, dynamic weight 1)
+      if (acc) __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&D.ctl->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&D.host->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if (D.mode == 0) {
       __hip_atomic_store(&D.ctl->accept, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (D.mode == 2) {
+      __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __hip_atomic_store(&D.host->E[slot], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&D.host->th[slot], th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

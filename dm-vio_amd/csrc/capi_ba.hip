@@ -67,6 +67,10 @@ struct dmvio_hip_ba {
   float* d_newEnergyWO = nullptr;
   unsigned int ticket = 0, acc_ticket = 0;
   float th_cap = -1.0f;        // IMUIntegration::newFrameEnergyTH cap (<= 0: none)
+  // a rejected step whose relinearisation the host has not waited for (the loop inside dmvio_hip_ba_optimize): its energy / threshold are picked up at the next wait
+  bool pending_reject = false;
+  unsigned int pending_ticket = 0;
+  int pending_trace = -1;
   bool sys_ready = false;      // h_sys holds the stitched system of the CURRENT state (left behind by the previous GN iteration's chain)
   int n_lin_blocks = 0, n_pt_blocks = 0, n_pt8_blocks = 0, n_epart = 0;   // n_pt8: kernels with eight lanes per point
   bool keep_fullJ = false;   // the 74-float RawResidualJacobian is only materialised on request (dmvio_hip_ba_keep_jacobians) and for marginalisation
@@ -683,6 +687,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent
   if (dalloc(b, &b->d_sys, (size_t)tot + 1)) return -1;
   b->xchg_width = 0; b->d_xchg_local = b->d_xchg_all = nullptr;
+  b->pending_reject = false; b->pending_trace = -1;
   HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
   memset(b->h_res, 0, sizeof(BAHostRes));
   HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
@@ -884,7 +889,19 @@ int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
 //   applyRes + per-point sums + point backup -> accumulation -> adjoint stitching -> the stitched system of the NEW state in host memory.
 // The host waits once per iteration, by polling the ticket the chain's last kernel stores behind its results.  After a rejected step the
 // system in host memory is still the one of the (restored) state, so the next iteration goes straight to its solve with the larger lambda.
-static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted) {
+// the energy / threshold of a relinearisation the host did not wait for, once a later ticket of the same stream has been seen (or after waiting for its own)
+static int settleReject(dmvio_hip_ba* b, double lastE[3], bool wait) {
+  if (!b->pending_reject) return 0;
+  if (wait) { if (int r = waitTicket(b, b->pending_ticket)) return r; }
+  lastE[0] = b->h_res->E[1];
+  b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[1];
+  if (b->pending_trace >= 0 && b->pending_trace < 64) b->trace[b->pending_trace][0] = lastE[0];
+  b->pending_reject = false; b->pending_trace = -1;
+  return 0;
+}
+// defer: after a rejected step return without waiting for the relinearisation of the restored state (its energy stays on the device for the next accept
+// test, BACtl::lastE0); lastE[0] is then filled in by the next call's wait or by settleReject
+static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted, bool defer = false, int trace_slot = -1) {
   BAHost& H = b->H;
   dmvio_hip_ctx* c = b->ctx;
   const int n = H.n();
@@ -936,12 +953,14 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     BA_PH(2);
     BADecide D = makeDecide(b, 1, true, true);
     D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2]; D.newL = newL; D.newM = newM;
+    D.lastE0_from_ctl = b->pending_reject ? 1 : 0;   // the host has not seen the restored state's energy yet: the device has
     hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
                        b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
     HIPCHK(hipGetLastError());
     if (shard) { if (int r = decideGlobal(b, D)) return r; }
     BA_PH(3);
     if (int r = waitTicket(b, D.ticket)) return r;   // energy, threshold and the accept / reject decision are in host memory
+    if (int r = settleReject(b, lastE, false)) return r;   // ... and so are those of an earlier relinearisation on the same stream
     BA_PH(4);
   }
   accepted = b->h_res->accept != 0;
@@ -966,9 +985,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     fillWindow(b);
     b->dyn_cur = dyn_backup;
     const double oldL = H.calcLEnergyFrames(), oldM = H.calcMEnergy();
-    if (int r = waitTicket(b, D2.ticket)) return r;
-    lastE[0] = b->h_res->E[1]; lastE[1] = oldL; lastE[2] = oldM;
-    H.fr[H.F - 1].frameEnergyTH = b->h_res->th[1];
+    lastE[1] = oldL; lastE[2] = oldM;
+    b->pending_reject = true; b->pending_ticket = D2.ticket; b->pending_trace = trace_slot;
+    if (!defer) { if (int r = settleReject(b, lastE, true)) return r; }
     lambda *= 1e2;
   }
   BA_PH(5);
@@ -1085,11 +1104,12 @@ int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* 
   b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;
   for (int iteration = 0; iteration < mnumOptIts; iteration++) {
     bool acc = false;
-    if (int r = gnIteration(b, iteration, lambda, lastE, acc)) return r;
+    if (int r = gnIteration(b, iteration, lambda, lastE, acc, true, done + 1)) return r;
     done++;
     if (done < 64) { b->trace[done][0] = lastE[0]; b->trace[done][1] = lastE[1]; b->trace[done][2] = lastE[2]; b->trace[done][3] = acc ? 1 : 0; }
     // canbreak && iteration >= setting_minOptIterations: baIntegration->canBreak() stays false without the GTSAM path
   }
+  if (int r = settleReject(b, lastE, true)) return r;
   // fix the newest frame's linearisation point, re-linearise with applyRes (FullSystemOptimize.cpp:596-609)
   BAFrameHost& last = H.fr[H.F - 1];
   double newStateZero[10] = {0, 0, 0, 0, 0, 0, last.state[6], last.state[7], 0, 0};

@@ -244,6 +244,7 @@ typedef std::vector<double> Mat;  // row-major n x n or vectors
 
 // Persistent worker pool (IndexThreadReduce, src/dso/util/IndexThreadReduce.h:40-217: workers parked on a condition variable, woken per
 // reduce call) — used only by the multi-threaded timing variant of the oracle (cpu_baseline); parity tests run single-threaded.
+struct alignas(64) PaddedDouble { double v = 0; };   // one cache line per worker
 struct WorkerPool {
   std::vector<std::thread> th;
   std::mutex mu;
@@ -587,9 +588,14 @@ struct OWindow {
   double linearizeAll(bool fixLinearization) {
     double lastEnergyP = 0;
     if (!fixLinearization && nThreads > 1) {   // linearizeAll_Reductor over the worker pool (FullSystemOptimize.cpp:55-88,150-171): per-worker energy sums
-      std::vector<double> part(nThreads, 0.0);
-      parallelChunks((int)activeResiduals.size(), [&](int tid, int b0, int e0) { for (int k = b0; k < e0; k++) part[tid] += linearizeRes(res[activeResiduals[k]]); });
-      for (double v : part) lastEnergyP += v;
+      // per-worker sums on their own cache lines (the reference's per-thread Vec10 stats are 80 B apart, IndexThreadReduce.h:53-57)
+      std::vector<PaddedDouble> part(nThreads);
+      parallelChunks((int)activeResiduals.size(), [&](int tid, int b0, int e0) {
+        double e = 0;
+        for (int k = b0; k < e0; k++) e += linearizeRes(res[activeResiduals[k]]);
+        part[tid].v += e;
+      });
+      for (const PaddedDouble& v : part) lastEnergyP += v.v;
       setNewFrameEnergyTH();
       return lastEnergyP;
     }
@@ -782,7 +788,21 @@ struct OWindow {
   void topStitch(std::vector<std::vector<AccApprox>>& accs, Mat& H, Mat& b, bool usePrior) {
     const int n = nF * 8 + CPARS;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
-    for (int k = 0; k < nF * nF; k++) {
+    if (nThreads > 1) {   // stitchDoubleMT (AccumulatedTopHessian.h:91-139): the (host,target) pairs split over the workers, per-worker H / b summed afterwards
+      mtH.resize(nThreads); mtB.resize(nThreads);
+      runWorkers([&](int tid) {
+        mtH[tid].assign((size_t)n * n, 0); mtB[tid].assign(n, 0);
+        for (int k = tid; k < nF * nF; k += nThreads) topStitchPair(accs, k, mtH[tid], mtB[tid]);
+      });
+      for (int t = 0; t < nThreads; t++) { for (size_t q = 0; q < H.size(); q++) H[q] += mtH[t][q]; for (int q = 0; q < n; q++) b[q] += mtB[t][q]; }
+    } else {
+      for (int k = 0; k < nF * nF; k++) topStitchPair(accs, k, H, b);
+    }
+    topStitchTail(H, b, usePrior);
+  }
+  void topStitchPair(std::vector<std::vector<AccApprox>>& accs, const int k, Mat& H, Mat& b) {
+    const int n = nF * 8 + CPARS;
+    {
       const int hh = k % nF, t = k / nF;
       const int hIdx = CPARS + hh * 8, tIdx = CPARS + t * 8;
       double accH[13][13];
@@ -811,6 +831,9 @@ struct OWindow {
       }
       for (int i = 0; i < 4; i++) b[i] += accH[i][CPARS + 8];
     }
+  }
+  void topStitchTail(Mat& H, Mat& b, bool usePrior) {
+    const int n = nF * 8 + CPARS;
     if (usePrior) {
       for (int i = 0; i < 4; i++) { H[(size_t)i * n + i] += cPrior[i]; b[i] += cPrior[i] * (double)cDeltaF[i]; }
       for (int hh = 0; hh < nF; hh++)
@@ -869,9 +892,23 @@ struct OWindow {
     }
   }
   void scStitch(std::vector<SCAcc>& As, Mat& H, Mat& b) {
-    const int n = nF * 8 + CPARS, nf = nF, nframes2 = nF * nF;
+    const int n = nF * 8 + CPARS, nf = nF;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
-    for (int k = 0; k < nf * nf; k++) {
+    if (nThreads > 1) {   // AccumulatedSCHessianSSE::stitchDoubleMT (AccumulatedSCHessian.h:93-133)
+      mtH.resize(nThreads); mtB.resize(nThreads);
+      runWorkers([&](int tid) {
+        mtH[tid].assign((size_t)n * n, 0); mtB[tid].assign(n, 0);
+        for (int k = tid; k < nf * nf; k += nThreads) scStitchPair(As, k, mtH[tid], mtB[tid]);
+      });
+      for (int t = 0; t < nThreads; t++) { for (size_t q = 0; q < H.size(); q++) H[q] += mtH[t][q]; for (int q = 0; q < n; q++) b[q] += mtB[t][q]; }
+    } else {
+      for (int k = 0; k < nf * nf; k++) scStitchPair(As, k, H, b);
+    }
+    scStitchTail(As, H, b);
+  }
+  void scStitchPair(std::vector<SCAcc>& As, const int k, Mat& H, Mat& b) {
+    const int n = nF * 8 + CPARS, nf = nF, nframes2 = nF * nF;
+    {
       const int i = k % nf, j = k / nf;
       const int iIdx = CPARS + i * 8, jIdx = CPARS + j * 8, ijIdx = i + nf * j;
       double Hpc[32], bp[8];
@@ -907,6 +944,9 @@ struct OWindow {
         blkMulAdd(H, n, iIdx, kIdx, AH, accDM, ATk);
       }
     }
+  }
+  void scStitchTail(std::vector<SCAcc>& As, Mat& H, Mat& b) {
+    const int n = nF * 8 + CPARS, nf = nF;
     for (auto& A : As) {
       A.accHcc.finish(); A.accbc.finish();
       for (int r = 0; r < 4; r++) { for (int c = 0; c < 4; c++) H[(size_t)r * n + c] += (double)A.accHcc.A1m[r][c]; b[r] += (double)A.accbc.A1m[r]; }
@@ -921,17 +961,31 @@ struct OWindow {
   template <class F>
   void parallelChunks(int n, F fn) {
     if (nThreads <= 1) { fn(0, 0, n); return; }
-    if (!pool || (int)pool->th.size() != nThreads) pool.reset(new WorkerPool(nThreads));
-    pool->run([&](int t) { for (int b0 = t * 50; b0 < n; b0 += nThreads * 50) fn(t, b0, std::min(n, b0 + 50)); });
+    runWorkers([&](int t) { for (int b0 = t * 50; b0 < n; b0 += nThreads * 50) fn(t, b0, std::min(n, b0 + 50)); });
   }
+  template <class F>
+  void runWorkers(F fn) {
+    if (!pool || (int)pool->th.size() != nThreads) pool.reset(new WorkerPool(nThreads));
+    pool->run(fn);
+  }
+  // per-worker state of the multi-threaded variant, kept between calls like the reference's acc[tid] members
+  std::vector<Mat> mtH, mtB;
+  std::vector<std::vector<AccApprox>> mtTop;
+  std::vector<SCAcc> mtSC;
 
   void accumulateAF(Mat& H, Mat& b) {
-    std::vector<std::vector<AccApprox>> accs(nThreads, std::vector<AccApprox>((size_t)nF * nF));
-    std::vector<int> nres(nThreads, 0);
-    for (auto& a : accs) for (auto& x : a) x.initialize();
-    parallelChunks((int)points.size(), [&](int tid, int b0, int e0) { for (int i = b0; i < e0; i++) topAddPoint(0, points[i], accs[tid], nres[tid]); });
+    if ((int)mtTop.size() != nThreads || mtTop[0].size() != (size_t)nF * nF) mtTop.assign(nThreads, std::vector<AccApprox>((size_t)nF * nF));
+    std::vector<std::vector<AccApprox>>& accs = mtTop;
+    std::vector<PaddedDouble> nres(nThreads);
+    if (nThreads > 1) runWorkers([&](int tid) { for (auto& x : accs[tid]) x.initialize(); });   // setZero runs on the workers too (EnergyFunctional.cpp:252)
+    else for (auto& x : accs[0]) x.initialize();
+    parallelChunks((int)points.size(), [&](int tid, int b0, int e0) {
+      int cnt = 0;
+      for (int i = b0; i < e0; i++) topAddPoint(0, points[i], accs[tid], cnt);
+      nres[tid].v += cnt;
+    });
     topStitch(accs, H, b, false);
-    resInA = 0; for (int v : nres) resInA += v;
+    resInA = 0; for (const PaddedDouble& v : nres) resInA += (int)v.v;
   }
   void accumulateLF(Mat& H, Mat& b) {
     std::vector<std::vector<AccApprox>> accs(1, std::vector<AccApprox>((size_t)nF * nF));
@@ -942,8 +996,10 @@ struct OWindow {
     resInL = nres;
   }
   void accumulateSCF(Mat& H, Mat& b) {
-    std::vector<SCAcc> As(nThreads);
-    for (auto& A : As) A.init(nF);
+    if ((int)mtSC.size() != nThreads) mtSC.assign(nThreads, SCAcc());
+    std::vector<SCAcc>& As = mtSC;
+    if (nThreads > 1) runWorkers([&](int tid) { As[tid].init(nF); });
+    else As[0].init(nF);
     parallelChunks((int)points.size(), [&](int tid, int b0, int e0) { for (int i = b0; i < e0; i++) scAddPoint(points[i], true, As[tid]); });
     scStitch(As, H, b);
   }

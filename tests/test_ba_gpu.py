@@ -214,6 +214,26 @@ def test_gn_iterations_through_rejected_steps_match_oracle(pkg, oracle, synth, g
         assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
 
 
+def test_optimize_loop_equals_iteration_calls_through_rejected_steps(pkg, oracle, synth, gpu_required):
+    """dmvio_hip_ba_optimize does not wait for the relinearisation that follows a rejected step (the restored state's energy stays on the device for the next
+    accept test); the per-iteration entry point does.  Thirty iterations, most of them rejected: same accept sequence, same energies, bit for bit."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=1000, seed=13)
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba2 = pkg.BundleAdjusterHip(ctx, accumulators=1); ba2.set_case(case, list(range(8)))
+    out = ba.optimize(30)
+    ba2.activate_all(); e = ba2.linearize_all(False); ba2.apply_res()
+    lam, lE = 1e-5, [e, 0.0, 0.0]
+    tr = [[e, 0.0, 0.0, 1.0]]
+    for it in range(30):
+        acc, lam, lE = ba2.gn_iteration(it, lam, lE)
+        tr.append([lE[0], lE[1], lE[2], 1.0 if acc else 0.0])
+    tr = np.array(tr)
+    assert out["iterations"] == 30 and (tr[:, 3] == 0).sum() >= 10
+    assert np.array_equal(out["trace"], tr), np.abs(out["trace"] - tr).max()
+    for k in range(8):
+        assert np.array_equal(ba.frame_pose(k)[0][:3], ba2.frame_pose(k)[0][:3])
+
+
 def test_shard_systems_sum_to_full_system(pkg, oracle, synth, gpu_required):
     """Rank emulation on one GPU: the packed systems of two keyframe shards add up to the full window's system."""
     import dmvio_amd.sharding as sh

@@ -28,3 +28,23 @@ def test_sequence_trajectory_matches_oracle(pkg, oracle, synth, gpu_required):
         assert abs(lg["energy"] - lo["energy"]) <= 0.15 * lo["energy"]      # different candidate sets -> different residual counts
     assert vo_g.prior is not None and vo_g.prior[0].shape == vo_o.prior[0].shape
     print("trajectory difference GPU vs oracle [m]: rmse %.2e max %.2e; error vs ground truth: gpu %.4f oracle %.4f of a %.3f m path" % (np.sqrt(np.mean(d ** 2)), d.max(), e_g.max(), e_o.max(), path))
+
+
+def test_long_vga_sequence_matches_oracle(pkg, oracle, synth, gpu_required):
+    """120 frames at 640x480 on a closed 3 m path (30 keyframes, sliding window of 6, marginalisation of 24 of them): the HIP path stays on the CPU
+    path's trajectory to a millimetre, with the reference's single-threaded summation order (what the oracle replays) and with the library's default
+    accumulation order; both stay within 1 % of the path length of the ground truth."""
+    import vo_harness as vh
+    w, h, n = 640, 480, 120
+    K4, imgs, id0, c2w_true = vh.make_sequence(synth, w, h, n, motion="orbit", device="cuda")
+    kw = dict(kf_every=4, max_kf=6, n_new=500)
+    vo_o = vh.run(vh.OracleBackend(oracle, w, h, K4), synth, K4, imgs, id0, w, h, **kw)
+    path = sum(np.linalg.norm(c2w_true[k + 1][:3] - c2w_true[k][:3]) for k in range(n - 1))
+    e_o = np.array([np.linalg.norm(vo_o.traj[k][:3] - c2w_true[k][:3]) for k in range(n)])
+    assert path > 2.5 and e_o.max() < 0.01 * path
+    for accumulators, rmse_tol, max_tol in ((1, 1.5e-3, 3e-3), (4, 2e-3, 4e-3)):
+        vo_g = vh.run(vh.HipBackend(pkg, w, h, K4, accumulators=accumulators), synth, K4, imgs, id0, w, h, **kw)
+        d = np.array([np.linalg.norm(vo_g.traj[k][:3] - vo_o.traj[k][:3]) for k in range(n)])
+        e_g = np.array([np.linalg.norm(vo_g.traj[k][:3] - c2w_true[k][:3]) for k in range(n)])
+        assert np.sqrt(np.mean(d ** 2)) < rmse_tol and d.max() < max_tol, (accumulators, np.sqrt(np.mean(d ** 2)), d.max())
+        assert e_g.max() < 0.01 * path

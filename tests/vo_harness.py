@@ -42,12 +42,12 @@ def p7_inv(a):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, pkg, w, h, K4, n_slots=64):
+    def __init__(self, pkg, w, h, K4, n_slots=64, accumulators=1):
         self.pkg, self.w, self.h, self.K4 = pkg, w, h, K4
         self.ctx = pkg.Context(w, h, n_slots=n_slots)
         self.trk = pkg.CoarseTrackerHip(self.ctx); self.trk.makeK(K4)
         self.imm = pkg.ImmaturePointsHip(self.ctx, capacity=32768)
-        self.ba = pkg.BundleAdjusterHip(self.ctx)
+        self.ba = pkg.BundleAdjusterHip(self.ctx, accumulators=accumulators)   # 1 = the oracle's (single-threaded) summation order
         self.slot_of = {}
 
     def upload(self, fid, img):
@@ -387,18 +387,27 @@ class MiniVO:
         self.log and self.log[-1].update(ref_points=int(len(u)))
 
 
-def make_sequence(synth, w, h, n, seed=3):
-    """Smooth forward / sideways motion over the plane world; returns images, inverse depth of frame 0, ground-truth camToWorld poses."""
+def make_sequence(synth, w, h, n, seed=3, motion="drift", device=None):
+    """Smooth motion over the plane world; returns images, inverse depth of frame 0, ground-truth camToWorld poses.
+    motion: "drift" = forward / sideways drift (short sequences); "orbit" = a closed, bounded path with the same ~3 cm step per frame (long sequences)."""
     world = synth.PlaneWorld(synth.SEED + seed, fmax=20.0)
     K4 = synth.default_intrinsics(w, h)
-    imgs, c2w, id0 = [], [], None
+    imgs, c2w, id0, Rs, ts = [], [], None, [], []
     for k in range(n):
-        xi = np.array([0.035 * k, -0.012 * k + 0.01 * np.sin(0.5 * k), 0.015 * k, 0.004 * np.sin(0.4 * k), -0.003 * k, 0.002 * k])
+        if motion == "orbit":
+            xi = np.array([0.6 * np.sin(0.05 * k), -0.08 * np.sin(0.08 * k), 0.4 * (1 - np.cos(0.05 * k)),
+                           0.03 * np.sin(0.07 * k), -0.06 * np.sin(0.05 * k), 0.02 * np.sin(0.09 * k)])
+        else:
+            xi = np.array([0.035 * k, -0.012 * k + 0.01 * np.sin(0.5 * k), 0.015 * k, 0.004 * np.sin(0.4 * k), -0.003 * k, 0.002 * k])
         R, t = synth.se3_exp(xi)
-        img, idm = world.render(K4, R, t, w, h)
-        imgs.append(img); c2w.append(p7_inv(synth.pose7(R, t)))
-        if k == 0:
-            id0 = idm
+        Rs.append(R); ts.append(t); c2w.append(p7_inv(synth.pose7(R, t)))
+        if device is None or k == 0:
+            img, idm = world.render(K4, R, t, w, h)
+            imgs.append(img)
+            if k == 0:
+                id0 = idm
+    if device is not None:     # long sequences: the frames rendered with torch on the device (same formula; both back ends get the same images)
+        imgs = list(synth.render_batch_torch(world, K4, Rs, ts, w, h, device).cpu().numpy())
     return K4, imgs, id0, c2w
 
 
