@@ -162,16 +162,17 @@ def render_batch_torch(world, K4, Rs, ts, w, h, device, chunk=16, aff=(0.0, 0.0)
         t = torch.as_tensor(np.stack(ts[c0:c0 + chunk]), **f64)
         m = R.shape[0]
         c_w = -torch.einsum("mji,mj->mi", R, t)
-        d_w = torch.einsum("hwj,mji->mhwi", d_c, R)
+        d_w = torch.stack([sum(d_c[None, :, :, j] * R[:, j, i, None, None] for j in range(3)) for i in range(3)], -1)
         best_s = torch.full((m, h, w), float("inf"), **f64)
         img = torch.full((m, h, w), 128.0, **f64)
         for (nrm, d0), (a, b), (fa, fb, amp, ph) in zip(world.planes, world.bases, world.waves):
             nrm_t = torch.as_tensor(nrm, **f64); a_t = torch.as_tensor(a, **f64); b_t = torch.as_tensor(b, **f64)
-            denom = d_w @ nrm_t
-            s = ((d0 - c_w @ nrm_t)[:, None, None]) / denom
+            dot3 = lambda V, q: V[..., 0] * q[0] + V[..., 1] * q[1] + V[..., 2] * q[2]      # elementwise (a matmul with a 3-vector lands on a slow fp64 gemv)
+            denom = dot3(d_w, nrm_t)
+            s = ((d0 - dot3(c_w, nrm_t))[:, None, None]) / denom
             ok = (s > 0.05) & (s < best_s) & torch.isfinite(s)
             X = c_w[:, None, None, :] + s[..., None] * d_w
-            pa = X @ a_t; pb = X @ b_t
+            pa = dot3(X, a_t); pb = dot3(X, b_t)
             val = torch.full((m, h, w), 128.0, **f64)
             for k in range(len(fa)):
                 val += float(amp[k]) * torch.sin(float(fa[k]) * pa + float(fb[k]) * pb + float(ph[k]))

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$R; mkdir -p $O
 run() {  # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d $O/c_$name -o c -- python bench.py --no-cpu --no-ba --steps 3 --warmup 1 > $O/c_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $O/c_$name -o c -- python bench.py --no-cpu --no-ba --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 > $O/c_$name.log 2>&1
   python tools/rocprof_summary.py $(find $O/c_$name -name '*.db' | head -1) --counters 2>> $O/c_$name.log | grep -E "kernel|---|k_track_lm<256|k_build_pyramids" > $O/counters_$name.md
   rm -rf $O/c_$name
   cat $O/counters_$name.md | cut -c1-40,118-220

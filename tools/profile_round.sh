@@ -8,12 +8,15 @@ O=gpurun_out/prof_$R; rm -rf $O; mkdir -p $O
 t0=$(date +%s)
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 t1=$(date +%s); echo "default bench.py wall seconds: $((t1 - t0))" > $O/bench_wall.txt
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --no-cpu > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --no-cpu --no-traffic > $O/kt.log 2>&1
 python tools/rocprof_summary.py $(find $O/kt -name '*.db' | head -1) > $O/kernel_stats.md 2>> $O/kt.log
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --no-cpu --steps 3 --warmup 1 --ba-iters 20 > $O/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 --ba-iters 20 > $O/pmc_$C.log 2>&1
   python tools/rocprof_summary.py $(find $O/pmc_$C -name '*.db' | head -1) --counters > $O/pmc_$C.md 2>> $O/pmc_$C.log
 done
-DMVIO_HIP_BA_TIMING=1 python bench.py --no-cpu --steps 3 --warmup 1 > $O/ba_timing.log 2>&1
+DMVIO_HIP_BA_TIMING=1 python bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 > $O/ba_timing.log 2>&1
+rocprofv3 --kernel-trace -d $O/ba_kt -o kt -- python tools/ba_loop.py 300 > $O/ba_loop.log 2>&1
+python tools/rocprof_timeline.py $(find $O/ba_kt -name '*.db' | head -1) 1500 40 > $O/ba_timeline.txt 2>> $O/ba_loop.log
+rm -rf $O/ba_kt
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -c 600 $O/bench_n1.json; cat $O/bench_wall.txt
