@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see lie.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lie.h header).  UNPINNED third-party arithmetic: the compiled reference (oracle/_ref) uses the same restatement through oracle/ref_shim, so upstream Eigen's last bits are not checked.
 //
 // Small dense double-precision helpers restating the Eigen 3 routines the reference calls at the
 // edge of the hot path.  Eigen is a system dependency of the reference (version unpinned by

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED: the reference holds no golden vector for this path.
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY: traceOn / the ImmaturePoint constructor run inside the recorded live run of the reference (tests/test_ref_replay_cpu.py); no function-level pin — validated by construction (tests/test_immature_cpu.py).
 // CPU restatement of the immature-point path of DM-VIO / DSO:
 //   orc_immature_init   <- ImmaturePoint::ImmaturePoint        src/dso/FullSystem/ImmaturePoint.cpp:34-62
 //   orc_immature_trace  <- ImmaturePoint::traceOn              src/dso/FullSystem/ImmaturePoint.cpp:76-437

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY: not pinned against oracle/_ref (Undistort.cpp needs OpenCV-free IO stubs that are not built) — validated by construction (tests/test_io_cpu.py).
 // CPU restatement of the image input edge of the hot path:
 //   orc_undistort  <- PhotometricUndistorter::processFrame (src/dso/util/Undistort.cpp:214-250) + Undistort::undistort (:386-481, without the
 //                     benchmark noise options)

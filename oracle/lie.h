@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
-// PARITY UNPINNED: the reference ships no golden vectors for this path and cannot be
-// built in this environment (Eigen/Boost/GTSAM absent) — see DESIGN.md §Oracle.
+// UNPINNED third-party arithmetic: restated from the vendored Sophus; the compiled reference (oracle/_ref) reaches the same code
+// through oracle/ref_shim/sophus, so only the construction checks (power series, round trips, Sophus' own test tangents) vouch for it — DESIGN.md §2.
 //
 // Minimal double-precision SO3/SE3 restating the vendored Sophus v0.9a used by the
 // reference (thirdparty/Sophus/sophus/so3.hpp, se3.hpp).  Quaternion-backed like Sophus:

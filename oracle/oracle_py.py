@@ -1,7 +1,7 @@
 """ctypes binding of oracle/_build/liboracle.so — ORACLE = TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED (see oracle/tracker_oracle.cpp header and DESIGN.md).
+Pinned against oracle/_ref (the reference's own sources, oracle/Makefile.ref) — see oracle/tracker_oracle.cpp header and DESIGN.md §2.
 """
 import ctypes as C
 import os

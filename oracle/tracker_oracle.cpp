@@ -1,9 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path: only tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
-// PARITY UNPINNED: the reference holds no golden vectors / KATs for this path (test/ covers IMU
-// interpolation and a GTSAM factor only) and cannot be compiled here (Eigen, Boost, GTSAM, OpenCV,
-// Pangolin absent), so this file is a from-scratch CPU restatement validated by construction
-// (tests/test_oracle_*.py: finite differences, float64 NumPy cross-check, identity cases).
+// PARITY PINNED: interpolation, projection, accumulators, makeImages, makeCoarseDepthL0, calcRes, calcGSSSE and trackNewestCoarse agree bit for bit with the
+// reference's own sources compiled by oracle/Makefile.ref (oracle/_ref/libref.so; tests/test_ref_pin_cpu.py), all 53 trackNewCoarse calls of a recorded live run of
+// the reference are reproduced to the last bit (tests/test_ref_replay_cpu.py); unpinned only for Eigen's ldlt and Sophus' exp / log.
 //
 // Restates the TRACKING half of the hot path of lukasvst/dm-vio, function by function:
 //   orc_make_images        <- FrameHessian::makeImages           src/dso/FullSystem/HessianBlocks.cpp:128-191

@@ -1,8 +1,8 @@
 """CPU tests (no GPU): validate the ORACLE by construction.
 
-The reference holds no golden vectors / KATs for the photometric-alignment path ("parity
-unpinned"), and cannot be built here.  The oracle (oracle/*.cpp, an fp32/SSE restatement of the reference) is
-therefore pinned against
+The reference holds no golden vectors / KATs for the photometric-alignment path.  The pin against the reference's own
+compiled sources lives in tests/test_ref_pin_cpu.py / test_ref_replay_cpu.py; here the oracle (oracle/*.cpp, an fp32/SSE restatement of the reference) is
+checked by construction against
   * an independent float64 NumPy restatement (tests/np_ref.py) and committed fixtures made from it
     (tests/golden/, generator tests/golden/make_golden.py),
   * analytic identities (exp/log round trips, Adj, power-series matrix exponential),
