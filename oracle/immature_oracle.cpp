@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY: traceOn / the ImmaturePoint constructor run inside the recorded live run of the reference (tests/test_ref_replay_cpu.py); no function-level pin — validated by construction (tests/test_immature_cpu.py).
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY PINNED: constructor, traceNewCoarse tables + traceOn through four keyframes and optimizeImmaturePoint agree bit for bit with the reference's own members run on its own FullSystem (oracle/_ref, tests/test_ref_pin_cpu.py::test_immature_points_bitwise).
 // CPU restatement of the immature-point path of DM-VIO / DSO:
 //   orc_immature_init   <- ImmaturePoint::ImmaturePoint        src/dso/FullSystem/ImmaturePoint.cpp:34-62
 //   orc_immature_trace  <- ImmaturePoint::traceOn              src/dso/FullSystem/ImmaturePoint.cpp:76-437

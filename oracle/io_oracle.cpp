@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY: not pinned against oracle/_ref (Undistort.cpp needs OpenCV-free IO stubs that are not built) — validated by construction (tests/test_io_cpu.py).
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY PINNED: bit / byte identical to the reference's util/Undistort.cpp (own tables from getUndistorterForFile; the OpenCV image reader replaced by oracle/ref_imagerw.cpp) and to FullSystem::printResult of a live run (oracle/_ref, tests/test_ref_pin_cpu.py::test_undistort_bitwise, ::test_print_result_bytes).
 // CPU restatement of the image input edge of the hot path:
 //   orc_undistort  <- PhotometricUndistorter::processFrame (src/dso/util/Undistort.cpp:214-250) + Undistort::undistort (:386-481, without the
 //                     benchmark noise options)

@@ -45,6 +45,8 @@
 #include "OptimizationBackend/AccumulatedSCHessian.h"
 #include "FullSystem/FullSystem.h"
 #include "FullSystem/HessianBlocks.h"
+#include "util/Undistort.h"
+#include "util/MinimalImage.h"
 #include "FullSystem/Residuals.h"
 #include "FullSystem/ResidualProjections.h"
 #include "FullSystem/ImmaturePoint.h"
@@ -298,6 +300,108 @@ int ref_make_images(const float* img, int w, int h, const float K4[4], const flo
 	int lv = pyrLevelsUsed;
 	deleteFrame(fh);
 	return lv;
+}
+
+// ================================================================================================= input edge (util/Undistort.cpp)
+// Undistort::getUndistorterForFile (Undistort.cpp:266-384) on a camera file, a response file and a vignette image registered with ref_register_image16:
+// the reference builds its own response table (normalised G), inverse vignette and remap tables
+void* ref_undistort_create(const char* config_txt, const char* gamma_txt, const char* vignette_name)
+{
+	StdoutCapture cap;
+	Undistort* u = Undistort::getUndistorterForFile(config_txt, gamma_txt, vignette_name);
+	cap.finish();
+	return u;
+}
+void ref_undistort_destroy(void* p) { delete (Undistort*)p; }
+// sizes: w, h (output), wOrg, hOrg (raw), GDepth, photometric tables valid, passthrough
+void ref_undistort_info(void* p, int out7[7])
+{
+	Undistort* u = (Undistort*)p;
+	out7[0] = u->w; out7[1] = u->h; out7[2] = u->wOrg; out7[3] = u->hOrg;
+	out7[4] = u->photometricUndist->GDepth; out7[5] = u->photometricUndist->valid ? 1 : 0; out7[6] = u->passthrough ? 1 : 0;
+}
+void ref_undistort_tables(void* p, float* remapX, float* remapY, float* G, float* vignetteMapInv, double K9[9])
+{
+	Undistort* u = (Undistort*)p;
+	memcpy(remapX, u->remapX, sizeof(float) * u->w * u->h); memcpy(remapY, u->remapY, sizeof(float) * u->w * u->h);
+	memcpy(G, u->photometricUndist->G, sizeof(float) * u->photometricUndist->GDepth);
+	if (u->photometricUndist->valid) memcpy(vignetteMapInv, u->photometricUndist->vignetteMapInv, sizeof(float) * u->wOrg * u->hOrg);
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) K9[r * 3 + c] = u->K(r, c);
+}
+// Undistort::undistort<T> (Undistort.cpp:386-481): PhotometricUndistorter::processFrame (:214-250) + the bilinear remap; out = w*h floats
+int ref_undistort_run(void* p, const void* raw, int bits, float exposure, float factor, float* out, float* exposure_out)
+{
+	Undistort* u = (Undistort*)p;
+	ImageAndExposure* r = 0;
+	if (bits == 8) { MinimalImageB img(u->wOrg, u->hOrg, (unsigned char*)raw); r = u->undistort<unsigned char>(&img, exposure, 0.0, factor); }
+	else { MinimalImage<unsigned short> img(u->wOrg, u->hOrg, (unsigned short*)raw); r = u->undistort<unsigned short>(&img, exposure, 0.0, factor); }
+	memcpy(out, r->image, sizeof(float) * u->w * u->h);
+	if (exposure_out) *exposure_out = r->exposure_time;
+	delete r;
+	return 0;
+}
+
+// ================================================================================================= CoarseInitializer
+// CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624) on level `lvl` of the pyramids of two images, for npts points given as flat arrays of the Pnt members it
+// reads (CoarseInitializer.h:44-83).  Outputs as orc_init_calc_res_and_gs: H / Hsc 8x8 row-major, b / bsc, res3, and the Pnt members / JbBuffer_new rows it writes.
+int ref_init_calc_res_and_gs(const float* img_ref, const float* img_new, int w, int h, const float K4[4], int lvl, const double refToNew7[7], double aff_a, double aff_b,
+                             int npts, const float* u, const float* v, const float* idepth_new, const float* iR, const unsigned char* isGood, const float* energy2,
+                             const float* outlierTH, float alphaW, float alphaK, float couplingWeight, double priorY, double priorX, float* H_out, float* b_out, float* H_sc,
+                             float* b_sc, float* res3, float* energy_new2, unsigned char* isGood_new, float* maxstep, float* lastHessian_new, float* JbBuffer_new10)
+{
+	setCalib(w, h, K4);
+	if (lvl < 0 || lvl >= pyrLevelsUsed) return -1;
+	multiThreading = false;
+	setting_weightZeroPriorDSOInitY = priorY; setting_weightZeroPriorDSOInitX = priorX;
+	CalibHessian HCalib;
+	VecC kv; kv << K4[0], K4[1], K4[2], K4[3];
+	HCalib.setValueScaled(kv);
+	FrameHessian* f0 = newFrame(img_ref, 1.0f, &HCalib, 0);
+	FrameHessian* f1 = newFrame(img_new, 1.0f, &HCalib, 1);
+	{
+		CoarseInitializer ci(w, h);
+		ci.makeK(&HCalib);
+		ci.firstFrame = f0; ci.newFrame = f1;
+		ci.alphaW = alphaW; ci.alphaK = alphaK; ci.couplingWeight = couplingWeight;
+		ci.points[lvl] = new Pnt[npts];
+		ci.numPoints[lvl] = npts;
+		for (int i = 0; i < npts; i++)
+		{
+			Pnt& q = ci.points[lvl][i];
+			memset((void*)&q, 0, sizeof(Pnt));
+			q.u = u[i]; q.v = v[i]; q.idepth = q.idepth_new = idepth_new[i]; q.iR = iR[i]; q.isGood = isGood[i] != 0;
+			q.energy = Eigen::Vector2f(energy2[2 * i], energy2[2 * i + 1]); q.outlierTH = outlierTH[i];
+			q.lastHessian_new = lastHessian_new[i];
+		}
+		Mat88f H, Hsc; Vec8f b, bsc;
+		Vec3f r = ci.calcResAndGS(lvl, H, b, Hsc, bsc, se3From7(refToNew7), AffLight(aff_a, aff_b), false);
+		for (int a = 0; a < 8; a++) { for (int c = 0; c < 8; c++) { H_out[a * 8 + c] = H(a, c); H_sc[a * 8 + c] = Hsc(a, c); } b_out[a] = b[a]; b_sc[a] = bsc[a]; }
+		for (int k = 0; k < 3; k++) res3[k] = r[k];
+		for (int i = 0; i < npts; i++)
+		{
+			const Pnt& q = ci.points[lvl][i];
+			energy_new2[2 * i] = q.energy_new[0]; energy_new2[2 * i + 1] = q.energy_new[1];
+			isGood_new[i] = q.isGood_new ? 1 : 0; maxstep[i] = q.maxstep; lastHessian_new[i] = q.lastHessian_new;
+			for (int k = 0; k < 10; k++) JbBuffer_new10[10 * i + k] = ci.JbBuffer_new[i][k];
+		}
+	}
+	deleteFrame(f0); deleteFrame(f1);
+	return 0;
+}
+
+// CoarseInitializer::makeK (CoarseInitializer.cpp:793-826): intrinsics of level lvl and their inverse as the initializer holds them (doubles)
+int ref_init_make_k(int w, int h, const float K4[4], int lvl, double out4[4], double Ki9[9])
+{
+	setCalib(w, h, K4);
+	if (lvl < 0 || lvl >= pyrLevelsUsed) return -1;
+	CalibHessian HCalib;
+	VecC kv; kv << K4[0], K4[1], K4[2], K4[3];
+	HCalib.setValueScaled(kv);
+	CoarseInitializer ci(w, h);
+	ci.makeK(&HCalib);
+	out4[0] = ci.fx[lvl]; out4[1] = ci.fy[lvl]; out4[2] = ci.cx[lvl]; out4[3] = ci.cy[lvl];
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ki9[r * 3 + c] = ci.Ki[lvl](r, c);
+	return 0;
 }
 
 // ================================================================================================= CoarseTracker
@@ -560,6 +664,60 @@ void ref_ba_destroy(void* p)
 	}
 	delete W;
 }
+// ---- immature points of a window (ImmaturePoint.cpp, FullSystem::traceNewCoarse, FullSystem::optimizeImmaturePoint)
+// ImmaturePoint constructor for n integer pixels of keyframe `host` (FullSystem::makeNewTraces, FullSystem.cpp:1509-1527); returns the number now held by that frame
+int ref_ba_immature_add(void* p, int host, int n, const int* u, const int* v)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	FrameHessian* fh = fs->frameHessians[host];
+	for (int i = 0; i < n; i++) fh->immaturePoints.push_back(new ImmaturePoint(u[i], v[i], fh, 1.0f, &fs->Hcalib));
+	return (int)fh->immaturePoints.size();
+}
+void ref_ba_immature_get(void* p, int host, float* color8, float* weights8, float* gradH4, float* energyTH, float* idepth_min, float* idepth_max, float* quality,
+                         float* lastTraceUV2, float* lastTracePixelInterval, int* lastTraceStatus)
+{
+	FrameHessian* fh = ((RefWindow*)p)->fs->frameHessians[host];
+	for (size_t i = 0; i < fh->immaturePoints.size(); i++)
+	{
+		const ImmaturePoint* ip = fh->immaturePoints[i];
+		for (int k = 0; k < 8; k++) { color8[8 * i + k] = ip->color[k]; weights8[8 * i + k] = ip->weights[k]; }
+		gradH4[4 * i] = ip->gradH(0, 0); gradH4[4 * i + 1] = ip->gradH(0, 1); gradH4[4 * i + 2] = ip->gradH(1, 0); gradH4[4 * i + 3] = ip->gradH(1, 1);
+		energyTH[i] = ip->energyTH; idepth_min[i] = ip->idepth_min; idepth_max[i] = ip->idepth_max; quality[i] = ip->quality;
+		lastTraceUV2[2 * i] = ip->lastTraceUV[0]; lastTraceUV2[2 * i + 1] = ip->lastTraceUV[1]; lastTracePixelInterval[i] = ip->lastTracePixelInterval;
+		lastTraceStatus[i] = (int)ip->lastTraceStatus;
+	}
+}
+void ref_ba_immature_set_interval(void* p, int host, const float* idepth_min, const float* idepth_max)
+{
+	FrameHessian* fh = ((RefWindow*)p)->fs->frameHessians[host];
+	for (size_t i = 0; i < fh->immaturePoints.size(); i++) { fh->immaturePoints[i]->idepth_min = idepth_min[i]; fh->immaturePoints[i]->idepth_max = idepth_max[i]; }
+}
+// FullSystem::traceNewCoarse (FullSystem.cpp:541-584) with keyframe `target` of the window as the new frame: per-host KRKi / Kt / affine + traceOn of every immature point
+void ref_ba_trace_new_coarse(void* p, int target) { FullSystem* fs = ((RefWindow*)p)->fs; fs->traceNewCoarse(fs->frameHessians[target]); }
+// FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:51-205) for every immature point of `host`: result 1 activated / 0 skip / -1 delete, the activated point's
+// idepth, and the ResState of the temporary residual to every other keyframe (window order)
+void ref_ba_optimize_immature(void* p, int host, int minObs, int* result, float* idepth, int* res_state)
+{
+	FullSystem* fs = ((RefWindow*)p)->fs;
+	FrameHessian* fh = fs->frameHessians[host];
+	const int nres = (int)fs->frameHessians.size() - 1;
+	std::vector<ImmaturePointTemporaryResidual> tr(fs->frameHessians.size());
+	for (size_t i = 0; i < fh->immaturePoints.size(); i++)
+	{
+		PointHessian* ph = fs->optimizeImmaturePoint(fh->immaturePoints[i], minObs, tr.data());
+		for (int k = 0; k < nres; k++) res_state[i * nres + k] = (int)tr[k].state_state;
+		if (ph == 0) { result[i] = 0; idepth[i] = 0; }
+		else if (ph == (PointHessian*)((long)(-1))) { result[i] = -1; idepth[i] = 0; }
+		else
+		{
+			result[i] = 1; idepth[i] = ph->idepth;
+			for (PointFrameResidual* r : ph->residuals) delete r;
+			ph->residuals.clear();
+			delete ph;
+		}
+	}
+}
+
 // as makeKeyFrame inserts a frame (FullSystem.cpp:1364-1371); pose7 = worldToCam, aff in scaled units, img = raw irradiance image
 int ref_ba_add_frame(void* p, const double pose7_w2c[7], double aff_a, double aff_b, float exposure, int frameID, const float* img)
 {
@@ -1095,6 +1253,20 @@ int ref_system_get_trajectory(void* p, double* pose7, int* valid, int* keyframeI
 		aff2[2 * n] = s->aff_g2l.a; aff2[2 * n + 1] = s->aff_g2l.b;
 		n++;
 	}
+	return n;
+}
+// what FullSystem::printResult reads besides the above: timestamp, marginalizedAt == id, camToTrackingRef of every shell, and FullSystem::firstPose
+int ref_system_get_shells(void* p, double* timestamp, int* never_marginalized, double* camToTrackingRef7, double firstPose7[7])
+{
+	RefSystem* S = (RefSystem*)p;
+	int n = 0;
+	for (FrameShell* s : S->fs->allFrameHistory)
+	{
+		timestamp[n] = s->timestamp; never_marginalized[n] = (s->marginalizedAt == s->id) ? 1 : 0;
+		se3To7(s->camToTrackingRef, camToTrackingRef7 + 7 * n);
+		n++;
+	}
+	se3To7(S->fs->firstPose, firstPose7);
 	return n;
 }
 // FullSystem::printResult (FullSystem.cpp:256-298)

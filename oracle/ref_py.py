@@ -163,6 +163,72 @@ def make_images(color, w, h, K4=(100.0, 100.0, 50.0, 50.0), B=None):
     return dI, ab
 
 
+# ------------------------------------------------------------------------------------------------------------ input edge
+class Undistorter:
+    """The reference's Undistort (+ its PhotometricUndistorter) built by Undistort::getUndistorterForFile from a camera file, a response file and a vignette image
+    (registered in memory: the OpenCV reader is replaced by oracle/ref_imagerw.cpp)."""
+
+    def __init__(self, config_txt, gamma_txt, vignette16):
+        L = self.L = lib()
+        c_u16 = C.POINTER(C.c_ushort)
+        L.ref_register_image16.argtypes = [C.c_char_p, c_u16, C.c_int, C.c_int]
+        L.ref_undistort_create.restype = vp; L.ref_undistort_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        L.ref_undistort_destroy.argtypes = [vp]; L.ref_undistort_info.argtypes = [vp, c_i]
+        L.ref_undistort_tables.argtypes = [vp, c_f, c_f, c_f, c_f, c_d]
+        L.ref_undistort_run.argtypes = [vp, C.c_void_p, C.c_int, C.c_float, C.c_float, c_f, c_f]
+        vig = np.ascontiguousarray(vignette16, dtype=np.uint16)
+        name = b"vignette@%d" % id(self)
+        L.ref_register_image16(name, vig.ctypes.data_as(c_u16), vig.shape[1], vig.shape[0])
+        self.p = vp(L.ref_undistort_create(str(config_txt).encode(), str(gamma_txt).encode(), name))
+        assert self.p, "getUndistorterForFile failed"
+        info = np.zeros(7, np.int32); L.ref_undistort_info(self.p, info.ctypes.data_as(c_i))
+        self.w, self.h, self.wOrg, self.hOrg, self.GDepth, self.valid, self.passthrough = [int(x) for x in info]
+        self.remapX = np.zeros((self.h, self.w), np.float32); self.remapY = np.zeros((self.h, self.w), np.float32)
+        self.G = np.zeros(self.GDepth, np.float32); self.vignetteMapInv = np.zeros((self.hOrg, self.wOrg), np.float32); self.K = np.zeros(9)
+        L.ref_undistort_tables(self.p, _f(self.remapX), _f(self.remapY), _f(self.G), _f(self.vignetteMapInv), _d(self.K))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.ref_undistort_destroy(self.p); self.p = None
+
+    def undistort(self, raw, exposure=1.0, factor=1.0):
+        raw = np.ascontiguousarray(raw)
+        bits = 8 if raw.dtype == np.uint8 else 16
+        out = np.zeros((self.h, self.w), np.float32); e = C.c_float(0)
+        self.L.ref_undistort_run(self.p, raw.ctypes.data_as(C.c_void_p), bits, exposure, factor, _f(out), C.byref(e))
+        return out, e.value
+
+
+# ------------------------------------------------------------------------------------------------------------ CoarseInitializer
+def init_make_k(w, h, K4, lvl):
+    """CoarseInitializer::makeK: (fx, fy, cx, cy) of level lvl and Ki[lvl] (3x3) as float64."""
+    L = lib()
+    L.ref_init_make_k.argtypes = [C.c_int, C.c_int, c_f, C.c_int, c_d, c_d]
+    out4 = np.zeros(4); Ki = np.zeros(9)
+    assert L.ref_init_make_k(w, h, _f(_f32(K4)), lvl, _d(out4), _d(Ki)) == 0
+    return out4, Ki.reshape(3, 3)
+
+
+def init_calc_res_and_gs(img_ref, img_new, w, h, K4, lvl, refToNew7, aff_ab, pts, idepth_new, alphaW=150 * 150, alphaK=2.5 * 2.5, couplingWeight=1.0, priorY=0.0, priorX=0.0):
+    """The reference's CoarseInitializer::calcResAndGS on level lvl; same outputs as oracle_py.init_calc_res_and_gs."""
+    L = lib()
+    c_u8 = C.POINTER(C.c_ubyte)
+    L.ref_init_calc_res_and_gs.argtypes = [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, c_d, C.c_double, C.c_double, C.c_int, c_f, c_f, c_f, c_f, c_u8, c_f, c_f,
+                                           C.c_float, C.c_float, C.c_float, C.c_double, C.c_double, c_f, c_f, c_f, c_f, c_f, c_f, c_u8, c_f, c_f, c_f]
+    n = len(pts["u"])
+    u, v, iR, en, oth, idn = _f32(pts["u"]), _f32(pts["v"]), _f32(pts["iR"]), _f32(pts["energy"]), _f32(pts["outlierTH"]), _f32(idepth_new)
+    good = np.ascontiguousarray(pts["isGood"], dtype=np.uint8)
+    o = dict(H=np.zeros((8, 8), np.float32), b=np.zeros(8, np.float32), Hsc=np.zeros((8, 8), np.float32), bsc=np.zeros(8, np.float32), res3=np.zeros(3, np.float32),
+             energy_new=np.zeros((n, 2), np.float32), isGood_new=np.zeros(n, np.uint8), maxstep=np.zeros(n, np.float32), lastHessian_new=np.zeros(n, np.float32),
+             JbBuffer_new=np.zeros((n, 10), np.float32))
+    r = L.ref_init_calc_res_and_gs(_f(_f32(img_ref).reshape(-1)), _f(_f32(img_new).reshape(-1)), w, h, _f(_f32(K4)), lvl, _d(_f64(refToNew7)), float(aff_ab[0]), float(aff_ab[1]), n,
+                                   _f(u), _f(v), _f(idn), _f(iR), good.ctypes.data_as(c_u8), _f(en), _f(oth), alphaW, alphaK, couplingWeight, priorY, priorX,
+                                   _f(o["H"]), _f(o["b"]), _f(o["Hsc"]), _f(o["bsc"]), _f(o["res3"]), _f(o["energy_new"]), o["isGood_new"].ctypes.data_as(c_u8), _f(o["maxstep"]),
+                                   _f(o["lastHessian_new"]), _f(o["JbBuffer_new"]))
+    assert r == 0
+    return o
+
+
 # ------------------------------------------------------------------------------------------------------------ CoarseTracker
 class Tracker:
     """The reference's CoarseTracker (CoarseTracker.h:46-129).  Same surface as oracle_py.Tracker except that frames are given as
@@ -249,6 +315,12 @@ def _ba_sig(L):
     L.ref_ba_set_frame_zero.argtypes = [vp, C.c_int, c_d]
     L.ref_ba_set_frame_energy_th.argtypes = [vp, c_f]
     L.ref_ba_set_calib_values.argtypes = [vp, c_d, c_d]
+    c_i = C.POINTER(C.c_int)
+    L.ref_ba_immature_add.argtypes = [vp, C.c_int, C.c_int, c_i, c_i]
+    L.ref_ba_immature_get.argtypes = [vp, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i]
+    L.ref_ba_immature_set_interval.argtypes = [vp, C.c_int, c_f, c_f]
+    L.ref_ba_trace_new_coarse.argtypes = [vp, C.c_int]
+    L.ref_ba_optimize_immature.argtypes = [vp, C.c_int, C.c_int, c_i, c_f, c_i]
     L.ref_ba_add_point.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, c_f, c_f, C.c_int, c_f, c_f]
     L.ref_ba_add_residual.argtypes = [vp, C.c_int, C.c_int]
     L.ref_ba_finalize.argtypes = [vp]
@@ -318,6 +390,35 @@ class BAWindow:
     def __del__(self):
         if getattr(self, "p", None):
             self.L.ref_ba_destroy(self.p); self.p = None
+
+    # ---- immature points (ImmaturePoint constructor, FullSystem::traceNewCoarse, FullSystem::optimizeImmaturePoint — the reference's own members)
+    def immature_add(self, host, u, v):
+        u = np.ascontiguousarray(u, dtype=np.int32); v = np.ascontiguousarray(v, dtype=np.int32)
+        c_i = C.POINTER(C.c_int)
+        self._n_imm = getattr(self, "_n_imm", {})
+        self._n_imm[host] = self.L.ref_ba_immature_add(self.p, host, len(u), u.ctypes.data_as(c_i), v.ctypes.data_as(c_i))
+
+    def immature_get(self, host):
+        n = self._n_imm[host]
+        o = dict(color=np.zeros((n, 8), np.float32), weights=np.zeros((n, 8), np.float32), gradH=np.zeros((n, 4), np.float32), energyTH=np.zeros(n, np.float32),
+                 idepth_min=np.zeros(n, np.float32), idepth_max=np.zeros(n, np.float32), quality=np.zeros(n, np.float32), lastTraceUV=np.zeros((n, 2), np.float32),
+                 lastTracePixelInterval=np.zeros(n, np.float32), lastTraceStatus=np.zeros(n, np.int32))
+        self.L.ref_ba_immature_get(self.p, host, _f(o["color"]), _f(o["weights"]), _f(o["gradH"]), _f(o["energyTH"]), _f(o["idepth_min"]), _f(o["idepth_max"]),
+                                   _f(o["quality"]), _f(o["lastTraceUV"]), _f(o["lastTracePixelInterval"]), o["lastTraceStatus"].ctypes.data_as(C.POINTER(C.c_int)))
+        return o
+
+    def immature_set_interval(self, host, idepth_min, idepth_max):
+        self.L.ref_ba_immature_set_interval(self.p, host, _f(_f32(idepth_min)), _f(_f32(idepth_max)))
+
+    def trace_new_coarse(self, target):
+        self.L.ref_ba_trace_new_coarse(self.p, target)
+
+    def optimize_immature(self, host, min_obs=1):
+        n = self._n_imm[host]; nres = self.F - 1
+        result = np.zeros(n, np.int32); idepth = np.zeros(n, np.float32); st = np.zeros((n, nres), np.int32)
+        c_i = C.POINTER(C.c_int)
+        self.L.ref_ba_optimize_immature(self.p, host, min_obs, result.ctypes.data_as(c_i), _f(idepth), st.ctypes.data_as(c_i))
+        return result, idepth, st
 
     def set_frame_state(self, k, state10):
         self.L.ref_ba_set_frame_state(self.p, k, _d(_f64(state10)))
@@ -477,6 +578,13 @@ class System:
         P = np.zeros((n, 7)); v = np.zeros(n, np.int32); kf = np.zeros(n, np.int32); tr = np.zeros(n, np.int32); aff = np.zeros((n, 2))
         m = self.L.ref_system_get_trajectory(self.p, _d(P), v.ctypes.data_as(c_i), kf.ctypes.data_as(c_i), tr.ctypes.data_as(c_i), _d(aff))
         return dict(camToWorld=P[:m], valid=v[:m], keyframeId=kf[:m], trackingRef=tr[:m], aff=aff[:m])
+
+    def shells(self):
+        n = self.n
+        self.L.ref_system_get_shells.argtypes = [vp, c_d, c_i, c_d, c_d]
+        ts = np.zeros(n); nm = np.zeros(n, np.int32); cr = np.zeros((n, 7)); fp = np.zeros(7)
+        m = self.L.ref_system_get_shells(self.p, _d(ts), nm.ctypes.data_as(c_i), _d(cr), _d(fp))
+        return dict(timestamp=ts[:m], never_marginalized=nm[:m], camToTrackingRef=cr[:m], firstPose=fp)
 
     def print_result(self, path, only_kf=False, use_cam_to_tracking_ref=True):
         self.L.ref_system_print_result(self.p, str(path).encode(), 1 if only_kf else 0, 1 if use_cam_to_tracking_ref else 0)

@@ -325,3 +325,122 @@ def test_full_system_optimize_bitwise(O, synth, kw):
         assert np.abs(po[0] - pr[0]).max() < 1e-13 and np.abs(po[1] - pr[1]).max() < 1e-13 and np.abs(po[2] - pr[2]).max() < 1e-13
     io, so_ = WO.point_state(); ir, sr_ = WR.point_state()
     assert np.abs(io - ir).max() < 1e-6 * np.abs(io).max() and np.mean(io == ir) > 0.98
+
+
+# ---------------------------------------------------------------------------------------------------------------- immature points
+def test_immature_points_bitwise(O, synth):
+    """ImmaturePoint::ImmaturePoint, FullSystem::traceNewCoarse (per-host KRKi / Kt / affine + ImmaturePoint::traceOn) through four keyframes with exposure / affine
+    changes, then FullSystem::optimizeImmaturePoint against the window — the reference's own members on its own FullSystem vs the oracle: every output bit for bit."""
+    w, h, F = 320, 256, 5
+    world = synth.PlaneWorld(synth.SEED + 6, fmax=22.0)
+    K4 = synth.default_intrinsics(w, h)
+    rng = np.random.RandomState(6)
+    imgs, w2c = [], []
+    affs = np.array([[0.01 * k, 0.5 * k] for k in range(F)]); expo = np.array([1.0, 0.9, 1.1, 1.0, 1.2], np.float32)
+    for k in range(F):
+        R_, t_ = synth.se3_exp(np.array([0.05 * k, -0.02 * k, 0.012 * k, 0.003 * k, -0.004 * k, 0.0015 * k]))
+        imgs.append(world.render(K4, R_, t_, w, h, aff=tuple(affs[k]))[0]); w2c.append(synth.pose7(R_, t_))
+    u, v = synth.select_points(imgs[0], 400, rng, min_grad=8.0)
+    u = u.astype(np.int32); v = v.astype(np.int32)
+    keep = (u >= 8) & (v >= 8) & (u < w - 8) & (v < h - 8)
+    u, v = u[keep], v[keep]
+    case = dict(w=w, h=h, K4=K4, n_frames=F, imgs=imgs, poses0=np.array(w2c), idepth0=np.zeros(0, np.float32), aff=affs, exposure=expo,
+                u=np.zeros(0, np.float32), v=np.zeros(0, np.float32), host=np.zeros(0, np.int32), color=np.zeros((0, 8), np.float32), weights=np.zeros((0, 8), np.float32),
+                res_point=np.zeros(0, np.int32), res_target=np.zeros(0, np.int32))
+    Wr = R.BAWindow(case)
+    Wr.immature_add(0, u, v)
+    dIs = [O.make_images(im, w, h)[0][0] for im in imgs]
+    P = O.ImmaturePoints(dIs[0], w, h, u, v)
+    g = Wr.immature_get(0)
+    for k in ("color", "weights", "gradH", "energyTH"):
+        assert same(g[k], getattr(P, k)), k
+    c2w0 = O.se3_inv(w2c[0])
+    for k in range(1, F):
+        Wr.trace_new_coarse(k)
+        KRKi, Kt, aff = O.trace_precalc(w2c[k], c2w0, K4, float(expo[k]), float(expo[0]), tuple(affs[k]), tuple(affs[0]))
+        P.trace_on(dIs[k], KRKi, Kt, aff)
+        g = Wr.immature_get(0)
+        assert np.array_equal(g["lastTraceStatus"], P.lastTraceStatus), k
+        for name in ("idepth_min", "idepth_max", "quality", "lastTraceUV", "lastTracePixelInterval"):
+            assert same(g[name], getattr(P, name)), (k, name)
+    assert (P.lastTraceStatus == 0).sum() > 100
+    usable = np.isfinite(P.idepth_max) & (P.lastTraceStatus != 1)
+    P.idepth_max[~usable] = 0.5; P.idepth_min[~usable] = 0.1
+    Wr.immature_set_interval(0, P.idepth_min, P.idepth_max)
+    res_r, id_r, st_r = Wr.optimize_immature(0, min_obs=1)
+    pre = [O.pair_precalc(w2c[k], c2w0, float(expo[0]), float(expo[k]), tuple(affs[0]), tuple(affs[k])) for k in range(1, F)]
+    Rm = np.stack([q[0] for q in pre]); tm = np.stack([q[1] for q in pre]); am = np.stack([q[2] for q in pre])
+    res_o, id_o, st_o = O.immature_optimize(P, K4, dIs[1:], Rm, tm, am, min_obs=1)
+    assert np.array_equal(res_r, res_o) and (res_o == 1).sum() > 100
+    act = res_o == 1
+    assert same(id_r[act], id_o[act])
+    assert np.array_equal(st_r[act], st_o[act])
+
+
+# ---------------------------------------------------------------------------------------------------------------- initializer
+@pytest.mark.parametrize("lvl", [0, 1, 2])
+def test_initializer_calc_res_and_gs_bitwise(O, synth, lvl):
+    """CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624), single worker: both 9x9 systems, the energy triple, every per-point output and JbBuffer_new."""
+    from test_init_cpu import init_case
+    for kw in (dict(), dict(alphaW=0.0, alphaK=1e9, couplingWeight=0.0), dict(priorY=3.0, priorX=0.5)):
+        c = init_case(synth, O, lvl=lvl, n=700, seed=12 + lvl)
+        K4 = synth.default_intrinsics(c["w"], c["h"])
+        K_lvl, Ki = R.init_make_k(c["w"], c["h"], K4, lvl)
+        r = R.init_calc_res_and_gs(c["img0"], c["img1"], c["w"], c["h"], K4, lvl, c["pose7"], c["aff"], c["pts"], c["idepth_new"], **kw)
+        dI0 = O.make_images(c["img0"], c["w"], c["h"])[0]; dI1 = O.make_images(c["img1"], c["w"], c["h"])[0]
+        o = O.init_calc_res_and_gs(dI0[lvl], dI1[lvl], c["wl"], c["hl"], Ki, K_lvl, c["pose7"], c["aff"], c["pts"], c["idepth_new"], **kw)
+        good = o["isGood_new"].astype(bool)
+        assert np.array_equal(r["isGood_new"], o["isGood_new"]) and good.sum() > 400
+        for k in ("H", "b", "Hsc", "bsc", "res3", "energy_new", "maxstep"):
+            assert same(r[k], o[k]), (k, kw)
+        assert same(r["lastHessian_new"][good], o["lastHessian_new"][good]) and same(r["JbBuffer_new"][good], o["JbBuffer_new"][good])
+
+
+# ---------------------------------------------------------------------------------------------------------------- result.txt
+def test_print_result_bytes(O, synth, tmp_path):
+    """FullSystem::printResult (FullSystem.cpp:256-298) of a live run of the reference (keyframes with their optimised camToWorld, the other frames re-based on their
+    tracking reference, invalid poses skipped) vs the oracle's writer fed with the shells' data: the files are identical byte for byte."""
+    import replay
+    run = replay.run_reference(R, synth, 256, 192, 40, step=1.0, point_density=600)
+    S = run["system"]
+    tr = S.trajectory(); sh = S.shells()
+    assert tr["valid"].sum() > 20 and (tr["keyframeId"] >= 0).sum() >= 3
+    ref_idx = np.where(tr["keyframeId"] == -1, tr["trackingRef"], -1).astype(np.int32)
+    a, b = tmp_path / "ref.txt", tmp_path / "orc.txt"
+    S.print_result(a, only_kf=False, use_cam_to_tracking_ref=True)
+    O.write_result_txt(b, sh["timestamp"], tr["camToWorld"], pose_valid=tr["valid"].astype(np.uint8), tracking_ref=ref_idx, camToTrackingRef7=sh["camToTrackingRef"],
+                       firstPose7=sh["firstPose"])
+    assert a.read_bytes() == b.read_bytes() and len(a.read_bytes().splitlines()) == int(tr["valid"].sum())
+    S.print_result(a, only_kf=False, use_cam_to_tracking_ref=False)
+    O.write_result_txt(b, sh["timestamp"], tr["camToWorld"], pose_valid=tr["valid"].astype(np.uint8), firstPose7=sh["firstPose"])
+    assert a.read_bytes() == b.read_bytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------- input edge
+@pytest.mark.parametrize("bits,model", [(8, "RadTan"), (16, "RadTan"), (8, "FOV")])
+def test_undistort_bitwise(O, tmp_path, bits, model):
+    """PhotometricUndistorter::processFrame (Undistort.cpp:214-250) + Undistort::undistort (:386-481) on the reference's own tables — response table normalised by its
+    constructor, inverse vignette from a 16-bit image, remap of a radial-tangential / FOV camera cropped to 320x240: the oracle fed with those tables returns the same
+    image bit for bit, with the photometric calibration and with the exposure-less fall-back (factor * raw)."""
+    wOrg, hOrg, w, h = 376, 288, 320, 240
+    rng = np.random.default_rng(3 + bits)
+    cam = tmp_path / "camera.txt"
+    if model == "RadTan":
+        cam.write_text("RadTan 0.535 0.669 0.493 0.505 -0.28 0.07 0.0002 -0.0003\n%d %d\ncrop\n%d %d\n" % (wOrg, hOrg, w, h))
+    else:
+        cam.write_text("0.535 0.669 0.493 0.505 0.897\n%d %d\ncrop\n%d %d\n" % (wOrg, hOrg, w, h))
+    depth = 256 if bits == 8 else 65536
+    g = np.cumsum(rng.uniform(0.5, 1.5, depth)) ** 1.1
+    gam = tmp_path / "pcalib.txt"
+    gam.write_text(" ".join("%.9g" % x for x in g) + "\n")
+    yy, xx = np.mgrid[0:hOrg, 0:wOrg]
+    vig = (65535 * (1 - 0.4 * (((xx - wOrg / 2) / wOrg) ** 2 + ((yy - hOrg / 2) / hOrg) ** 2))).astype(np.uint16)
+    U = R.Undistorter(cam, gam, vig)
+    assert (U.w, U.h, U.wOrg, U.hOrg, U.GDepth, U.valid, U.passthrough) == (w, h, wOrg, hOrg, depth, 1, 0)
+    assert (U.remapX >= 0).mean() > 0.99
+    raw = rng.integers(0, depth, (hOrg, wOrg)).astype(np.uint8 if bits == 8 else np.uint16)
+    ref_img, _ = U.undistort(raw, exposure=0.02)
+    orc_img = O.undistort(raw, U.G, U.vignetteMapInv, U.remapX, U.remapY, w, h)
+    assert same(ref_img, orc_img) and ref_img.std() > 10
+    ref_img, _ = U.undistort(raw, exposure=0.0, factor=0.25)          # exposure <= 0: no photometric calibration, data = factor * raw (:222-229)
+    assert same(ref_img, O.undistort(raw, None, None, U.remapX, U.remapY, w, h, factor=0.25))
