@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY PINNED: bit-identical to the reference's CoarseInitializer::calcResAndGS compiled from its own source (oracle/_ref, tests/test_ref_pin_cpu.py::test_initializer_calc_res_and_gs_bitwise).
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY PINNED against the reference's CoarseInitializer::calcResAndGS compiled from its own source (oracle/_ref, tests/test_ref_pin_cpu.py::test_initializer_calc_res_and_gs_bitwise):
+// per-point outputs, JbBuffer_new, Hsc, bsc bit for bit; H, b, energy to rounding (the reference's own six-worker sums are run-dependent).
 // CPU restatement of CoarseInitializer::calcResAndGS (src/dso/FullSystem/CoarseInitializer.cpp:331-624), single worker
 // (the reference's IndexThreadReduce splits the points in chunks of 50 over its workers, each with its own Accumulator9; run with
 // one worker the order below is the reference's).  Accumulators: oracle/acc9.h.  Interpolators: globalFuncs.h:103-118,160-176.

@@ -307,6 +307,7 @@ int ref_make_images(const float* img, int w, int h, const float K4[4], const flo
 // the reference builds its own response table (normalised G), inverse vignette and remap tables
 void* ref_undistort_create(const char* config_txt, const char* gamma_txt, const char* vignette_name)
 {
+	setting_photometricCalibration = 2; setting_useExposure = true;   // the reference's defaults (settings.cpp); a RefSystem created earlier switches the calibration off
 	StdoutCapture cap;
 	Undistort* u = Undistort::getUndistorterForFile(config_txt, gamma_txt, vignette_name);
 	cap.finish();

@@ -380,7 +380,8 @@ def test_immature_points_bitwise(O, synth):
 # ---------------------------------------------------------------------------------------------------------------- initializer
 @pytest.mark.parametrize("lvl", [0, 1, 2])
 def test_initializer_calc_res_and_gs_bitwise(O, synth, lvl):
-    """CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624), single worker: both 9x9 systems, the energy triple, every per-point output and JbBuffer_new."""
+    """CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624): every per-point output, JbBuffer_new and the Schur system bit for bit; H, b and the energy — which the
+    reference itself sums in a run-dependent order — to rounding."""
     from test_init_cpu import init_case
     for kw in (dict(), dict(alphaW=0.0, alphaK=1e9, couplingWeight=0.0), dict(priorY=3.0, priorX=0.5)):
         c = init_case(synth, O, lvl=lvl, n=700, seed=12 + lvl)
@@ -391,8 +392,15 @@ def test_initializer_calc_res_and_gs_bitwise(O, synth, lvl):
         o = O.init_calc_res_and_gs(dI0[lvl], dI1[lvl], c["wl"], c["hl"], Ki, K_lvl, c["pose7"], c["aff"], c["pts"], c["idepth_new"], **kw)
         good = o["isGood_new"].astype(bool)
         assert np.array_equal(r["isGood_new"], o["isGood_new"]) and good.sum() > 400
-        for k in ("H", "b", "Hsc", "bsc", "res3", "energy_new", "maxstep"):
-            assert same(r[k], o[k]), (k, kw)
+        # deterministic in the reference: everything per point and the Schur system (one sequential loop over the points, CoarseInitializer.cpp:557-583)
+        for k in ("Hsc", "bsc", "energy_new", "maxstep"):
+            assert same(r[k], o[k]), (k, kw, float(np.abs(r[k] - o[k]).max()))
+        assert same(r["res3"][1:], o["res3"][1:])
+        # H, b and the energy are summed by the reference's IndexThreadReduce, whose six workers take the 50-point chunks as they come (the single-threaded shortcut is
+        # commented out, util/IndexThreadReduce.h:83-87): its own sums vary in the last bits from run to run.  The oracle is the one-worker order.
+        sc = np.sqrt(np.outer(np.abs(np.diag(o["H"])), np.abs(np.diag(o["H"])))) + 1e-30
+        assert np.max(np.abs(r["H"] - o["H"]) / sc) < 2e-5 and np.allclose(r["b"], o["b"], rtol=1e-4, atol=1e-5 * np.abs(o["b"]).max())
+        assert abs(r["res3"][0] - o["res3"][0]) <= 1e-5 * o["res3"][0]
         assert same(r["lastHessian_new"][good], o["lastHessian_new"][good]) and same(r["JbBuffer_new"][good], o["JbBuffer_new"][good])
 
 
