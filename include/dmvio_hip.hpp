@@ -56,6 +56,9 @@ class FrameStore {
   bool makeImagesInPlace(int n, const int* slots, const float* device_images, size_t stride_bytes) {
     return ctx_ && dmvio_hip_frames_attach_device_batch(ctx_, n, slots, device_images, stride_bytes) == 0;
   }
+  /* FrameHessian::absSquaredGrad[0..2] of a resident frame (HessianBlocks.cpp:169-189), what PixelSelector::makeMaps reads; B = CalibHessian::B (256 floats) for the
+   * getBGradOnly weights of setting_gammaWeightsPixelSelect == 1, or NULL.  out[l] must hold (w >> l) * (h >> l) floats. */
+  bool absSquaredGrad(int slot, const float* B, float* const out[3]) { return ctx_ && dmvio_hip_frame_abs_squared_grad(ctx_, slot, 3, B, out) == 0; }
   dmvio_hip_ctx* handle() const { return ctx_; }
 
  private:
@@ -227,6 +230,11 @@ class WindowOptimizer {
     if (dmvio_hip_ba_optimize(ba_, mnumOptIts, &rmse, &lastEnergy, &lastIterations, energyTrace) != 0) return -1.0f;
     return rmse;
   }
+  /* one window over several GPUs: this optimizer holds all keyframes and the rank's share of the points; with a communicator set, optimize() is collective (every rank
+   * calls it) and runs the all-reduce of the system and the all-gather of the decision records itself, on its own stream (include/dmvio_hip.h, dmvio_hip_ba_set_comm) */
+  bool setCommunicator(void* ncclComm, int rank, int world) { return ba_ && dmvio_hip_ba_set_comm(ba_, ncclComm, rank, world) == 0; }
+  /* 1 = the reference's single-threaded accumulation order (bit-identical sums); default 4 partial accumulators per bucket = its multi-threaded structure */
+  bool setAccumulators(int k) { return ba_ && dmvio_hip_ba_set_accumulators(ba_, k) == 0; }
   bool frameState(int f, SE3& worldToCam, AffLight& aff_g2l) const {
     double p[7], a[2], st[10];
     if (!ba_ || dmvio_hip_ba_get_frame(ba_, f, p, a, st) != 0) return false;
