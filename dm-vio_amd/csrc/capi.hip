@@ -986,6 +986,14 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
   return 0;
 }
 
+#ifdef DMV_LM_TICKS
+extern "C" int dmvio_hip_debug_lm_ticks(double out8[8], int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lm_ticks), sizeof(double) * 8));
+  if (reset) { double z[8] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lm_ticks), z, sizeof(z))); }
+  return 0;
+}
+#endif
 int dmvio_hip_tracker_last_ticks(dmvio_hip_tracker* t, long long* ticks_step, long long* ticks_eval) {
   if (!t) return failmsg("null tracker");
   if (ticks_step) *ticks_step = t->last_ticks_step;

@@ -453,6 +453,9 @@ struct LMState {
 };
 
 // H(r,c) (SCALE_*-scaled, double) of lane = r*8+c from the 45 sums — calcGSSSE's tail (CoarseTracker.cpp:340-355).
+#ifdef DMV_LM_TICKS
+__device__ double g_lm_ticks[8];   // experiment only: solve, lane-0 part 1, lane-0 part 2, whole step (100 MHz ticks), solves, steps
+#endif
 __device__ __forceinline__ double systemEntryFromSums(const float* tot, const int r, const int c) {
   const int nW = (int)tot[ACC_NW];
   const int n = (nW + 3) & ~3;
@@ -549,6 +552,9 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
   const int maxIterations[5] = {10, 20, 50, 50, 50};
   const float lambdaExtrapolationLimit = 0.001f;
   int takeH = 0, action = ACT_DONE;
+#ifdef DMV_LM_TICKS
+  const long long q0 = wall_clock64();
+#endif
   if (lane == 0) {
     // (1) consume the evaluation that just finished
     if (S.st == LM_INIT_EVAL) {
@@ -631,6 +637,9 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
   }
   takeH = __builtin_amdgcn_readfirstlane(takeH);
   action = __builtin_amdgcn_readfirstlane(action);
+#ifdef DMV_LM_TICKS
+  const long long q1 = wall_clock64();
+#endif
 
   const int r = lane >> 3, c = lane & 7;
   double hv, bv;
@@ -659,7 +668,13 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
     const int nact = (fixA && fixB) ? 6 : ((fixA || fixB) ? 7 : 8);
     if (r >= nact || c >= nact) { m = (r == c) ? 1.0 : 0.0; }
     if (r >= nact) dv = 0.0;
+#ifdef DMV_LM_TICKS
+    const long long q2 = wall_clock64();
+#endif
     double x = waveLdltSolve8(m, dv, lane, s_trk);
+#ifdef DMV_LM_TICKS
+    if (lane == 0) { atomicAdd(&g_lm_ticks[0], (double)(wall_clock64() - q2)); atomicAdd(&g_lm_ticks[4], 1.0); }
+#endif
     if (fixA && !fixB) {
       // inc[7] = incStitch[6]; inc[6] = 0
       const double x6 = __shfl(x, 6 * 8, 64);
@@ -670,6 +685,9 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef DMV_LM_TICKS
+  const long long q3 = wall_clock64();
+#endif
 
   if (lane == 0) {
     if (action == ACT_SOLVE) {
@@ -703,6 +721,9 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
     }
     if (action != ACT_DONE) { S.nEvals++; S.nPointEvals += trk.pc_n[S.lvl]; }
   }
+#ifdef DMV_LM_TICKS
+  if (lane == 0 && action != ACT_DONE) { const long long q4 = wall_clock64(); atomicAdd(&g_lm_ticks[1], (double)(q1 - q0)); atomicAdd(&g_lm_ticks[2], (double)(q4 - q3)); atomicAdd(&g_lm_ticks[3], (double)(q4 - q0)); atomicAdd(&g_lm_ticks[5], 1.0); }
+#endif
   return action != ACT_DONE;
 }
 
