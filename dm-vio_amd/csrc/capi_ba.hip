@@ -270,23 +270,30 @@ static BADecide packOnly(dmvio_hip_ba* b, const BADecide& D) {
 
 // FullSystem::linearizeAll (FullSystemOptimize.cpp:150-218) — returns the energy sum; updates the newest frame's energy threshold
 // (setNewFrameEnergyTH, on the device by the kernel's last workgroup) unless keep_threshold.
-static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */, bool keep_threshold = false) {
+// defer: enqueue only — the caller waits for a LATER ticket of the same stream (kernels it enqueues behind this one) and then picks the results up with linearizePickUp
+static void linearizePickUp(dmvio_hip_ba* b, double* energy, bool keep_threshold) {
+  *energy = b->h_res->E[0];
+  if (!keep_threshold) b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[0];
+}
+static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */, bool keep_threshold = false,
+                        bool defer = false) {
   dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc of the current state
   if (int r = uploadThresholds(b)) return r;
   const bool shard = sharded(b);
   if (shard) { if (int r = ensureExchange(b)) return r; }
-  const BADecide D = makeDecide(b, 0, !keep_threshold, shard || !fix);
+  // the decision pass (last workgroup of the linearisation) publishes the ticket the host polls; the applyRes kernel of a fix-linearisation runs behind it on the
+  // same stream and nothing it writes is read by the host, so no stream synchronisation is needed for it either
+  const BADecide D = makeDecide(b, 0, !keep_threshold, true);
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
                      (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   if (shard) { if (int r = decideGlobal(b, D)) return r; }
-  if (fix && !shard) HIPCHK(hipStreamSynchronize(b->stream));
-  else if (int r = waitTicket(b, D.ticket)) return r;
-  *energy = b->h_res->E[0];
-  if (!keep_threshold) H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
+  if (defer) return 0;
+  if (int r = waitTicket(b, D.ticket)) return r;
+  linearizePickUp(b, energy, keep_threshold);
   return 0;
 }
 static int applyRes(dmvio_hip_ba* b) {
@@ -1096,9 +1103,14 @@ int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* 
   if (H.F < 4) mnumOptIts = 15;
   if (int r = dmvio_hip_ba_activate_all(b)) return r;
   double lastE[3];
-  if (int r = linearizeAll(b, false, &lastE[0])) return r;
-  lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
+  // initial linearisation, applyRes and the first system (per-point sums → accumulation → stitching) go out as ONE chain: nothing in it waits for the host, which
+  // picks the energy and the threshold up behind the chain's last ticket
+  if (int r = linearizeAll(b, false, &lastE[0], 0, false, true)) return r;
   if (int r = applyRes(b)) return r;
+  if (int r = accumulate(b, true, true, false)) return r;   // backupState of the points rides in the per-point sums; the frames are backed up by the first iteration
+  linearizePickUp(b, &lastE[0], false);
+  b->sys_ready = true;
+  lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
   double lambda = 1e-5;
   int done = 0;
   b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;
