@@ -73,6 +73,7 @@ def _sig(L):
     L.dmvio_hip_make_track_hypotheses.argtypes = [c_d, c_d, c_d, c_d, C.c_int]
     L.dmvio_hip_tracker_track_new_coarse.argtypes = [vp, C.c_int, C.c_float, C.c_int, c_d, c_d, c_d, C.c_double, c_d, c_d, c_d, c_i, c_i, c_i]
     L.dmvio_hip_tracker_last_ticks.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.dmvio_hip_tracker_set_single_frame_mode.argtypes = [vp, C.c_int]
     L.dmvio_hip_tracker_last_work.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.dmvio_hip_tracker_last_launch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     c_u8 = C.POINTER(C.c_ubyte)
@@ -343,6 +344,10 @@ class CoarseTrackerHip:
         self.lastFlowIndicators = r["flow"][0]
         return dict(good=bool(r["good"][0]), pose7=r["pose7"][0], aff=r["aff"][0], lastResiduals=r["lastResiduals"][0],
                     flow=r["flow"][0], H=r["H"][0], b=r["b"][0], iterations=int(r["iterations"][0]))
+
+    def set_single_frame_mode(self, host_lm=True):
+        """One alignment problem per call: host LM against the evaluation server (default) or the device-resident LM."""
+        _chk(self.L, self.L.dmvio_hip_tracker_set_single_frame_mode(self.p, 1 if host_lm else 0), "tracker_set_single_frame_mode")
 
     def trackNewestCoarseVIO(self, new_slot, pose7, aff, coarsestLvl=None, minResForAbort=None, new_exposure=1.0, update=None, accept=None, visual=None):
         """trackNewestCoarse with the LM step handed to the host (the reference's setting_useIMU branch, CoarseTracker.cpp:612-637).

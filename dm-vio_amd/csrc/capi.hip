@@ -38,6 +38,14 @@ struct dmvio_hip_tracker {
   float *d_partials = nullptr, *h_tot = nullptr;
   unsigned int* d_arrive = nullptr;   // arrive counter of k_eval_fused (zero between launches)
   unsigned int eval_ticket = 0;       // ticket of the last fused evaluation; the kernel stores it behind the sums in h_tot
+  // evaluation server (k_eval_server): one launch per tracked frame, requests through a mailbox in host-coherent memory
+  unsigned int* h_mail = nullptr;     // EVAL_MAIL_DWORDS dwords: [0] request ticket, [1..] EvalP, [last] the ticket again (written before [0])
+  unsigned int* d_mail = nullptr;     // device copy workgroup 0 hands the request to the other workgroups through
+  bool server_on = false;             // a server kernel was launched for server_slot and has not been told to quit
+  int server_slot = -1, server_G = 0;
+  int use_server = 1;                 // DMVIO_HIP_EVAL_SERVER=0: one k_eval_fused launch per evaluation instead
+  int single_host_lm = 1;             // DMVIO_HIP_SINGLE_HOST_LM=0: a single alignment problem runs the device-resident LM (cluster mode) instead of the host LM + server
+  int last_vio_iterations = 0;
   int eval_blocks_override = 0;
   int max_eval_blocks = 1024;
   LMProblemIn *h_in = nullptr;   // 2 x batch_cap entries of pinned host memory, read by the kernel directly (each workgroup copies its 120 B into LDS)
@@ -379,6 +387,12 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   // host-coherent (fine-grained) pinned memory: the fused evaluation stores its sums and then a ticket there, the host spins on the ticket
   HIPCHKP(hipHostMalloc((void**)&t->h_tot, sizeof(float) * (ACC_PAD + 16), hipHostMallocCoherent | hipHostMallocMapped));
   memset(t->h_tot, 0, sizeof(float) * (ACC_PAD + 16));
+  HIPCHKP(hipHostMalloc((void**)&t->h_mail, sizeof(unsigned int) * EVAL_MAIL_DWORDS, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(t->h_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS);
+  HIPCHKP(hipMalloc((void**)&t->d_mail, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
+  HIPCHKP(hipMemset(t->d_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
+  if (const char* e = getenv("DMVIO_HIP_EVAL_SERVER")) t->use_server = atoi(e);
+  if (const char* e = getenv("DMVIO_HIP_SINGLE_HOST_LM")) t->single_host_lm = atoi(e);
   HIPCHKP(hipMalloc((void**)&t->d_arrive, sizeof(unsigned int)));
   HIPCHKP(hipMemset(t->d_arrive, 0, sizeof(unsigned int)));
   HIPCHKP(hipStreamSynchronize(nullptr));   // the clears above run on the NULL stream; the context's stream does not wait for it
@@ -396,7 +410,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
-  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials);
+  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->d_mail) hipFree(t->d_mail);
   hipHostFree(t->h_tot); hipFree(t->d_arrive);
   hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
@@ -548,6 +562,63 @@ static int evalFused(dmvio_hip_tracker* t, int lvl, int new_slot, const EvalP& e
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_fused", __FILE__, __LINE__, q);
       if (q == hipSuccess && *flag != ticket) return failmsg("tracker evaluation finished without publishing its result");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+// ---- evaluation server session: serverStart launches k_eval_server for one frame slot, serverEval posts a request and polls the sums, serverStop tells the kernel to leave.
+// The kernel also leaves by itself after 5 ms without a request (a callback that takes longer — a factor-graph solve — simply finds it gone: serverEval relaunches it).
+// ticket into the mailbox: the copy in the last dword first, then the first dword (the device accepts a read only when both show the same new value)
+static void mailTicket(dmvio_hip_tracker* t, unsigned int v) {
+  __atomic_store_n(&t->h_mail[EVAL_MAIL_DWORDS - 1], v, __ATOMIC_RELEASE);
+  __atomic_store_n(&t->h_mail[0], v, __ATOMIC_RELEASE);
+}
+static int serverLaunch(dmvio_hip_tracker* t) {
+  dmvio_hip_ctx* c = t->ctx;
+  hipLaunchKernelGGL(k_eval_server<256>, dim3(t->server_G), dim3(256), 0, c->stream, t->dev, c->fs, t->server_slot, (const unsigned int*)t->h_mail, t->d_mail, t->eval_ticket,
+                     (long long)500000 /* 5 ms at 100 MHz */, t->d_partials, t->d_arrive, t->h_tot);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int serverStart(dmvio_hip_tracker* t, int new_slot, int G) {
+  t->server_G = std::max(1, std::min(G, t->max_eval_blocks));
+  t->server_slot = new_slot;
+  t->eval_ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;   // a number of its own for the launch: values an earlier launch left in the device mailbox are older
+  mailTicket(t, t->eval_ticket);   // "nothing new" for the kernel about to start
+  if (int r = serverLaunch(t)) return r;
+  t->server_on = true;
+  return 0;
+}
+static void serverStop(dmvio_hip_tracker* t) {
+  if (!t->server_on) return;
+  mailTicket(t, t->eval_ticket | EVAL_QUIT_BIT);
+  t->server_on = false;
+}
+static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
+  dmvio_hip_ctx* c = t->ctx;
+  unsigned int ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;
+  if (ticket == 0) ticket = 1;
+  t->eval_ticket = ticket;
+  static_assert(sizeof(EvalP) / 4 + 2 <= EVAL_MAIL_DWORDS, "EvalP must fit the mailbox");
+  memcpy((void*)(t->h_mail + 1), &e, sizeof(EvalP));
+  mailTicket(t, ticket);
+  volatile unsigned int* flag = reinterpret_cast<volatile unsigned int*>(t->h_tot) + ACC_PAD;
+  unsigned long long spins = 0;
+  while (*flag != ticket) {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3FFFF) == 0) {   // every ~quarter million polls (about a millisecond): is the server still there?
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_server", __FILE__, __LINE__, q);
+      if (q == hipSuccess && *flag != ticket) {
+        // the kernel left (idle time-out) before it saw this request: start it again; it picks the pending ticket up at once
+        t->eval_ticket = ticket - 1;
+        mailTicket(t, ticket - 1);
+        if (int r = serverLaunch(t)) return r;
+        t->eval_ticket = ticket;
+        mailTicket(t, ticket);
+      }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -717,6 +788,19 @@ int dmvio_hip_tracker_track_batch_fetch(dmvio_hip_tracker* t, double* pose7_out,
 int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_slots, const float* new_exposures, double* pose7_io, double* aff_io,
                                   int coarsestLvl, const double* minRes, double* lastResiduals, double* lastFlow, double* H, double* b,
                                   int* good, int* iterations) {
+  // ONE alignment problem: the LM control step (8x8 pivoted LDL^T, SE3 exp: one dependent chain) takes 6.5 us per iteration on a wavefront and well under a microsecond on
+  // the host, so the loop runs on the host against the evaluation server (one launch per frame, requests through host-coherent memory).  Same split of the template and
+  // same order of the partial sums as the device-resident LM's cluster mode, same arithmetic in the step: identical sums, residuals, H, b and iteration counts, the pose
+  // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.19 instead of 0.26 ms per frame.
+  if (B == 1 && t && t->single_host_lm && t->use_server && !t->lm_threads_override && !t->lm_cluster_override && t->fetch_pending_B == 0 && new_slots && pose7_io && aff_io) {
+    int g = 0, ne = 0;
+    const float ex = new_exposures ? new_exposures[0] : 1.0f;
+    if (int r = dmvio_hip_tracker_track_vio(t, new_slots[0], ex, pose7_io, aff_io, coarsestLvl, minRes, nullptr, lastResiduals, lastFlow, H, b, &g, &ne)) return r;
+    if (good) good[0] = g;
+    if (iterations) iterations[0] = t->last_vio_iterations;
+    t->last_evals = ne; t->staged_B = 0;
+    return 0;
+  }
   if (int r = dmvio_hip_tracker_track_batch_stage(t, B, new_slots, new_exposures, pose7_io, aff_io, coarsestLvl, minRes)) return r;
   if (int r = dmvio_hip_tracker_track_batch_launch(t)) return r;
   return dmvio_hip_tracker_track_batch_fetch(t, pose7_io, aff_io, lastResiduals, lastFlow, H, b, good, iterations);
@@ -788,6 +872,12 @@ int dmvio_hip_coarse_update_visual(const dmvio_hip_tracker_settings* st, const d
 // CoarseTracker::trackNewestCoarse with the LM step handed to the caller (CoarseTracker.cpp:539-770, the setting_useIMU branch
 // :612-637): the host loop of the reference over fused device evaluations.  Every iteration costs one kernel launch whose result the
 // host picks up by polling host-coherent memory (evalFused), plus the callback.
+int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* t, int host_lm) {
+  if (!t) return failmsg("null tracker");
+  t->single_host_lm = host_lm ? 1 : 0;
+  return 0;
+}
+
 int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_exposure, double pose7_io[7], double aff_io[2], int coarsestLvl,
                                 const double minResForAbort[5], const dmvio_hip_coarse_callbacks* cb, double lastResiduals[5], double lastFlow[3],
                                 double H_out[64], double b_out[8], int* good, int* n_evals) {
@@ -809,19 +899,27 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
   double affA = aff_io[0], affB = aff_io[1];
   bool haveRepeated = false, failed = false;
   double H[64] = {0}, b[8] = {0};
-  int lastLvl = -1, evals = 0;
+  int lastLvl = -1, evals = 0, totalIts = 0, repeatedLvl = -1;
+  double firstPassRes = NAN;
   EvalP e;
+  // one server launch for the whole call (requests through the mailbox) or one fused launch per evaluation
+  struct Session {
+    dmvio_hip_tracker* t; bool on;
+    ~Session() { if (on) serverStop(t); }
+  } session{t, false};
+  if (t->use_server) { if (int r = serverStart(t, new_slot, G)) return r; session.on = true; }
+  auto evaluate = [&](const EvalP& ep, int lv) -> int { return session.on ? serverEval(t, ep) : evalFused(t, lv, new_slot, ep, G); };
   for (int lvl = coarsestLvl; lvl >= 0 && !failed; lvl--) {
     float levelCutoffRepeat = 1;
     double resOld[6];
     makeEvalP(trk, lvl, cur, affA, affB, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
-    if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+    if (int r = evaluate(e, lvl)) return r;
     evals++;
     res6FromSums(t->h_tot, resOld);
     while (resOld[5] > 0.6 && (levelCutoffRepeat < 50 || resOld[5] > 0.99)) {
       levelCutoffRepeat *= 2;
       makeEvalP(trk, lvl, cur, affA, affB, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
-      if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+      if (int r = evaluate(e, lvl)) return r;
       evals++;
       res6FromSums(t->h_tot, resOld);
     }
@@ -841,7 +939,7 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
       const Pose nxt = poseFrom7(nxt7);
       const double affA_n = affA + incA * 10.0f, affB_n = affB + incB * 1000.0f;   // SCALE_A, SCALE_B (CoarseTracker.cpp:633-637)
       makeEvalP(trk, lvl, nxt, affA_n, affB_n, new_exposure, trk.coarseCutoffTH * levelCutoffRepeat, e);
-      if (int r = evalFused(t, lvl, new_slot, e, G)) return r;
+      if (int r = evaluate(e, lvl)) return r;
       evals++;
       double resNew[6];
       res6FromSums(t->h_tot, resNew);
@@ -857,13 +955,17 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
         if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
       }
       lastLvl = lvl;
+      totalIts++;
       if (!(incNorm > 1e-3)) break;
     }
     lastRes[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
     flow[0] = resOld[2]; flow[1] = resOld[3]; flow[2] = resOld[4];
     if (std::isnan(lastRes[lvl]) || (minResForAbort && lastRes[lvl] > 1.5 * minResForAbort[lvl])) { failed = true; break; }
-    if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+    if (levelCutoffRepeat > 1 && !haveRepeated) { repeatedLvl = lvl; firstPassRes = lastRes[lvl]; lvl++; haveRepeated = true; }
   }
+  t->last_vio_iterations = totalIts;
+  if (t->last_repeat_lvl.empty()) { t->last_repeat_lvl.resize(1); t->last_first_pass_res.resize(1); }
+  t->last_repeat_lvl[0] = repeatedLvl; t->last_first_pass_res[0] = firstPassRes;
   if (lastResiduals) memcpy(lastResiduals, lastRes, sizeof(lastRes));
   if (lastFlow) memcpy(lastFlow, flow, sizeof(flow));
   if (n_evals) *n_evals = evals;

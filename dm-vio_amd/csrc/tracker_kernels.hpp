@@ -339,6 +339,20 @@ __global__ void __launch_bounds__(64) k_eval_final(const float* __restrict__ par
   out[threadIdx.x] = s;
 }
 
+// sum_{g < n} base[g * ACC_PAD] added in index order (the fixed order every multi-workgroup evaluation shares), with the loads of eight partials in flight at a time:
+// a load per loop trip would wait for each one's full L2 latency in turn (measured: ≈0.65 µs per workgroup of the evaluation)
+__device__ __forceinline__ float sumPartialsInOrder(const float* base, const int n) {
+  float s = 0.0f;
+  for (int g0 = 0; g0 < n; g0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = (g0 + q < n) ? __hip_atomic_load(base + (size_t)(g0 + q) * ACC_PAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (g0 + q < n) s += v[q];
+  }
+  return s;
+}
+
 // The same evaluation as ONE launch whose result reaches the host without a stream synchronisation — the VIO hand-off path
 // (CoarseTracker.cpp:612-637: every LM iteration hands H, b to IMUIntegration::computeCoarseUpdate on the host and waits for the
 // pose it returns, so launch + wake-up latency is paid ~15 times per frame).  The last workgroup to arrive (one agent-scope counter)
@@ -373,8 +387,7 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x < ACC_PAD) {
-      float s = 0.0f;
-      for (unsigned int g = 0; g < gridDim.x; g++) s += __hip_atomic_load(partials + g * ACC_PAD + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float s = sumPartialsInOrder(partials + threadIdx.x, (int)gridDim.x);
       __hip_atomic_store(out_host + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -382,6 +395,103 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
   if (threadIdx.x == 0) {
     __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(reinterpret_cast<unsigned int*>(out_host) + ACC_PAD, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Evaluation server of the host-driven LM (dmvio_hip_tracker_track_vio and single-frame tracking): ONE launch per tracked frame instead of one per evaluation.  The host posts
+// the parameters of an evaluation into a 128-byte mailbox in host-coherent memory (19 dwords of EvalP, then the request ticket — written last), the workgroups poll the ticket,
+// evaluate exactly like k_eval_fused (same split of the template, same rank-order sum: bit-identical sums) and the last one to arrive stores the sums and the ticket into
+// host-coherent memory, where the host polls them.  A request costs two PCIe round trips and the evaluation itself; no launch, no stream synchronisation.
+// Termination: a ticket with the top bit set, or `idle_ticks` (100 MHz) without a new request — the host relaunches the server if it finds it gone.
+#define EVAL_MAIL_DWORDS 32
+#define EVAL_QUIT_BIT 0x80000000u
+template <int T>
+__global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const FrameStore fs, const int slot, const unsigned int* __restrict__ mail, unsigned int* __restrict__ dmail,
+                                                   const unsigned int first_seen, const long long idle_ticks, float* __restrict__ partials, unsigned int* __restrict__ arrive,
+                                                   float* __restrict__ out_host) {
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
+  __shared__ float s_tot[ACC_PAD];
+  __shared__ EvalP s_e;
+  __shared__ unsigned int s_tk;
+  __shared__ int s_last;
+  initStage<T>(s_stage);
+  const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
+  unsigned int seen = first_seen;
+  constexpr int EP = (int)(sizeof(EvalP) / 4);
+  for (;;) {
+    if (blockIdx.x == 0) {
+      // workgroup 0 is the only one that talks to the host: its first wavefront reads the whole 128-byte mailbox with one load per poll.  The host writes the
+      // parameters, then the ticket's copy in the last dword, then the ticket in the first: a read that shows the same new ticket at both ends has the parameters
+      // that belong to it, however the 128 bytes were fetched.  The request is then handed to the other workgroups through device memory.
+      if (threadIdx.x < 64) {
+        const long long t0 = wall_clock64();
+        unsigned int v, front, back;
+        bool timeout = false;
+        for (;;) {
+          v = threadIdx.x < EVAL_MAIL_DWORDS ? __hip_atomic_load(mail + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+          front = __builtin_amdgcn_readlane(v, 0); back = __builtin_amdgcn_readlane(v, EVAL_MAIL_DWORDS - 1);
+          if (front == back && front != seen) break;
+          if (wall_clock64() - t0 >= idle_ticks) { timeout = true; break; }
+        }
+        const unsigned int tk = timeout ? (seen | EVAL_QUIT_BIT) : front;
+        if (threadIdx.x >= 1 && threadIdx.x <= EP) {
+          reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x - 1] = v;
+          if (gridDim.x > 1) __hip_atomic_store(dmail + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0) s_tk = tk;
+        if (gridDim.x > 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (threadIdx.x == 0) __hip_atomic_store(dmail, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    } else {
+      if (threadIdx.x == 0) {
+        unsigned int tk;
+        // tickets only grow, also from one server launch to the next: whatever an earlier launch left in dmail is older than `seen` and is ignored
+        do { tk = __hip_atomic_load(dmail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (!((tk & ~EVAL_QUIT_BIT) > seen || tk == (seen | EVAL_QUIT_BIT)));
+        s_tk = tk;
+      }
+      __syncthreads();
+      if (!(s_tk & EVAL_QUIT_BIT) && threadIdx.x < EP)
+        reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x] = __hip_atomic_load(dmail + 1 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned int tk = s_tk;
+    if (tk & EVAL_QUIT_BIT) return;
+    seen = tk;
+    const int lvl = s_e.lvl;
+    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
+    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+    if (clean)
+      blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                          s_tot);
+    else
+      blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                         s_tot);
+    bool publish = true;
+    if (gridDim.x == 1) {
+      if (threadIdx.x < ACC_PAD) __hip_atomic_store(out_host + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      // partial sums double-buffered by ticket parity: a workgroup may already be storing the partials of request n+1 while a slow last workgroup still adds those of n?
+      // No: the host posts request n+1 only after the sums of n are published, i.e. after the last workgroup has read every partial of n.
+      if (threadIdx.x < ACC_PAD) __hip_atomic_store(partials + blockIdx.x * ACC_PAD + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+      __syncthreads();
+      publish = s_last != 0;
+      if (publish && threadIdx.x < ACC_PAD) {
+        const float sum = sumPartialsInOrder(partials + threadIdx.x, (int)gridDim.x);
+        __hip_atomic_store(out_host + threadIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();
+    if (publish && threadIdx.x == 0) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned int*>(out_host) + ACC_PAD, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -748,9 +858,7 @@ __device__ __forceinline__ void clusterExchange(float* s_tot, const ClusterArgs&
   __syncthreads();
   if (threadIdx.x < ACC_PAD) {
     const float* __restrict__ all = cl.part + ((size_t)prob * 2 + (phase & 1u)) * cl.C * ACC_PAD;
-    float s = 0.0f;
-    for (int r = 0; r < cl.C; r++) s += __hip_atomic_load(all + r * ACC_PAD + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_tot[threadIdx.x] = s;
+    s_tot[threadIdx.x] = sumPartialsInOrder(all + threadIdx.x, cl.C);
   }
   __syncthreads();
 }

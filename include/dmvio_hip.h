@@ -121,6 +121,10 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* trk, int lvl, int new_slot, float 
 int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_exposure,
                             double pose7_io[7], double aff_io[2], int coarsestLvl, const double minResForAbort[5],
                             double lastResiduals[5], double lastFlow[3], double H[64], double b[8], int* good);
+/* How ONE alignment problem (dmvio_hip_tracker_track, or a batch of one) is run: 1 (default) = the LM loop on the host against the evaluation server — one kernel launch per
+ * frame, every calcRes + calcGSSSE evaluation a request through host-coherent memory, the 8x8 solve / SE3 exp on the CPU (sub-microsecond there, 6.5 us per iteration on one
+ * wavefront); 0 = the device-resident LM (cluster mode).  Same evaluation sums and iteration counts either way; batches of two and more always run device-resident. */
+int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm);
 /* The reference's DEFAULT tracking path (settings.cpp:36 setting_useIMU = true): trackNewestCoarse with every LM step handed to the
  * host (CoarseTracker.cpp:612-637).  The callbacks mirror the three members of dmvio::IMUIntegration the tracker calls
  * (src/IMU/IMUIntegration.hpp:106-112):
@@ -131,8 +135,8 @@ int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_expo
  *   accept  <- acceptCoarseUpdate()            (may be NULL)
  *   visual  <- addVisualToCoarseGraph(H, b, trackingGood), called when the finest level was reached (may be NULL)
  * update == NULL (or cb == NULL) runs dmvio_hip_coarse_update_visual: the reference's own visual-only step, which is also what it
- * executes while the IMU is not yet initialised.  One fused kernel launch per evaluation, results fetched by polling host-coherent
- * memory (no stream synchronisation); with the default update the results are those of dmvio_hip_tracker_track. */
+ * executes while the IMU is not yet initialised.  One kernel launch per CALL (the evaluation server, k_eval_server): every evaluation is a request posted into host-coherent
+ * memory and its sums are polled from there — no launch, no stream synchronisation per LM iteration; with the default update the results are those of dmvio_hip_tracker_track. */
 typedef int (*dmvio_hip_coarse_update_fn)(void* user, const double H[64], const double b[8], float extrapFac, float lambda, const double pose7_cur[7],
                                           const double aff_cur[2], double pose7_new[7], double* incA, double* incB, double* incNorm);
 typedef void (*dmvio_hip_coarse_accept_fn)(void* user);

@@ -152,7 +152,10 @@ def test_second_batch_behind_an_unfetched_one_is_refused(pkg, synth, gpu_require
     a = trk.fetch()                      # results of the first launch, intact
     b = trk.fetch()                      # then those of the second
     ra = trk.track_batch([1], ident, aff); rb = trk.track_batch([2], ident, aff)
-    assert np.array_equal(a["pose7"], ra["pose7"]) and np.array_equal(b["pose7"], rb["pose7"])
+    # (a, b: the device-resident LM through stage / launch; ra, rb: single problems run the host LM against the evaluation server — same evaluation sums, the pose
+    # agrees to the last bit or two of its fp64 components)
+    assert np.abs(a["pose7"] - ra["pose7"]).max() < 1e-14 and np.abs(b["pose7"] - rb["pose7"]).max() < 1e-14
+    assert np.array_equal(a["lastResiduals"], ra["lastResiduals"], equal_nan=True) and np.array_equal(b["H"], rb["H"])
 
 
 def test_guarded_and_guard_free_paths_agree_bit_for_bit(pkg, synth, gpu_required):
@@ -175,8 +178,8 @@ def test_guarded_and_guard_free_paths_agree_bit_for_bit(pkg, synth, gpu_required
     for k in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "good", "iterations"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     ctx.frame_upload(1, case["frames"][0]["img"])          # a rebuild stamps the slot clean again
-    c = trk.track_batch([1], [IDENT], [(0.0, 0.0)])
-    assert np.array_equal(c["pose7"][0], a["pose7"][0])
+    c = trk.track_batch([1], [IDENT], [(0.0, 0.0)])          # a single problem: host LM + evaluation server, same sums, pose to the last bit or two
+    assert np.abs(c["pose7"][0] - a["pose7"][0]).max() < 1e-14 and np.array_equal(c["H"][0], a["H"][0]) and c["iterations"][0] == a["iterations"][0]
 
 
 def test_plain_c_demo_recovers_the_known_pose(pkg, gpu_required, tmp_path):
