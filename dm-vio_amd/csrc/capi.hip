@@ -41,6 +41,7 @@ struct dmvio_hip_tracker {
   // evaluation server (k_eval_server): one launch per tracked frame, requests through a mailbox in host-coherent memory
   unsigned int* h_mail = nullptr;     // EVAL_MAIL_DWORDS dwords: [0] request ticket, [1..] EvalP, [last] the ticket again (written before [0])
   unsigned int* d_mail = nullptr;     // device copy workgroup 0 hands the request to the other workgroups through
+  float* h_rec = nullptr;             // EVAL_SERVER_MAX_BLOCKS records of EVAL_RECORD_FLOATS floats: every server workgroup stores its partial sums + the ticket into its own
   bool server_on = false;             // a server kernel was launched for server_slot and has not been told to quit
   int server_slot = -1, server_G = 0;
   int use_server = 1;                 // DMVIO_HIP_EVAL_SERVER=0: one k_eval_fused launch per evaluation instead
@@ -389,6 +390,8 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   memset(t->h_tot, 0, sizeof(float) * (ACC_PAD + 16));
   HIPCHKP(hipHostMalloc((void**)&t->h_mail, sizeof(unsigned int) * EVAL_MAIL_DWORDS, hipHostMallocCoherent | hipHostMallocMapped));
   memset(t->h_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS);
+  HIPCHKP(hipHostMalloc((void**)&t->h_rec, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(t->h_rec, 0, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS);
   HIPCHKP(hipMalloc((void**)&t->d_mail, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
   HIPCHKP(hipMemset(t->d_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
   if (const char* e = getenv("DMVIO_HIP_EVAL_SERVER")) t->use_server = atoi(e);
@@ -410,7 +413,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
-  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->d_mail) hipFree(t->d_mail);
+  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->d_mail) hipFree(t->d_mail); if (t->h_rec) hipHostFree(t->h_rec);
   hipHostFree(t->h_tot); hipFree(t->d_arrive);
   hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
@@ -578,12 +581,12 @@ static void mailTicket(dmvio_hip_tracker* t, unsigned int v) {
 static int serverLaunch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
   hipLaunchKernelGGL(k_eval_server<256>, dim3(t->server_G), dim3(256), 0, c->stream, t->dev, c->fs, t->server_slot, (const unsigned int*)t->h_mail, t->d_mail, t->eval_ticket,
-                     (long long)500000 /* 5 ms at 100 MHz */, t->d_partials, t->d_arrive, t->h_tot);
+                     (long long)500000 /* 5 ms at 100 MHz */, t->h_rec);
   HIPCHK(hipGetLastError());
   return 0;
 }
 static int serverStart(dmvio_hip_tracker* t, int new_slot, int G) {
-  t->server_G = std::max(1, std::min(G, t->max_eval_blocks));
+  t->server_G = std::max(1, std::min(G, (int)EVAL_SERVER_MAX_BLOCKS));
   t->server_slot = new_slot;
   t->eval_ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;   // a number of its own for the launch: values an earlier launch left in the device mailbox are older
   mailTicket(t, t->eval_ticket);   // "nothing new" for the kernel about to start
@@ -604,14 +607,20 @@ static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
   static_assert(sizeof(EvalP) / 4 + 2 <= EVAL_MAIL_DWORDS, "EvalP must fit the mailbox");
   memcpy((void*)(t->h_mail + 1), &e, sizeof(EvalP));
   mailTicket(t, ticket);
-  volatile unsigned int* flag = reinterpret_cast<volatile unsigned int*>(t->h_tot) + ACC_PAD;
+  // wait for the record of every workgroup (ticket behind its sums), last rank first: the others are usually there by then
+  const int G = t->server_G;
+  auto pending = [&]() -> bool {
+    for (int g = G - 1; g >= 0; g--)
+      if (reinterpret_cast<volatile unsigned int*>(t->h_rec + (size_t)g * EVAL_RECORD_FLOATS)[ACC_PAD] != ticket) return true;
+    return false;
+  };
   unsigned long long spins = 0;
-  while (*flag != ticket) {
+  while (pending()) {
     __builtin_ia32_pause();
     if ((++spins & 0x3FFFF) == 0) {   // every ~quarter million polls (about a millisecond): is the server still there?
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_server", __FILE__, __LINE__, q);
-      if (q == hipSuccess && *flag != ticket) {
+      if (q == hipSuccess && pending()) {
         // the kernel left (idle time-out) before it saw this request: start it again; it picks the pending ticket up at once
         t->eval_ticket = ticket - 1;
         mailTicket(t, ticket - 1);
@@ -622,6 +631,12 @@ static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  // the sums of the evaluation: the partial sums added in rank order — ((0 + p0) + p1) + ... per slot, exactly what the device-side reductions compute
+  for (int k = 0; k < ACC_PAD; k++) {
+    float sacc = 0.0f;
+    for (int g = 0; g < G; g++) sacc += t->h_rec[(size_t)g * EVAL_RECORD_FLOATS + k];
+    t->h_tot[k] = sacc;
+  }
   return 0;
 }
 
@@ -791,7 +806,7 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_sl
   // ONE alignment problem: the LM control step (8x8 pivoted LDL^T, SE3 exp: one dependent chain) takes 6.5 us per iteration on a wavefront and well under a microsecond on
   // the host, so the loop runs on the host against the evaluation server (one launch per frame, requests through host-coherent memory).  Same split of the template and
   // same order of the partial sums as the device-resident LM's cluster mode, same arithmetic in the step: identical sums, residuals, H, b and iteration counts, the pose
-  // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.19 instead of 0.26 ms per frame.
+  // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.18 instead of 0.25 ms per frame.
   if (B == 1 && t && t->single_host_lm && t->use_server && !t->lm_threads_override && !t->lm_cluster_override && t->fetch_pending_B == 0 && new_slots && pose7_io && aff_io) {
     int g = 0, ne = 0;
     const float ex = new_exposures ? new_exposures[0] : 1.0f;

@@ -404,18 +404,18 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
 // host-coherent memory, where the host polls them.  A request costs two PCIe round trips and the evaluation itself; no launch, no stream synchronisation.
 // Termination: a ticket with the top bit set, or `idle_ticks` (100 MHz) without a new request — the host relaunches the server if it finds it gone.
 #define EVAL_MAIL_DWORDS 32
+#define EVAL_RECORD_FLOATS (ACC_PAD + 16)   // per-workgroup result record in host-coherent memory: ACC_PAD sums, then the ticket
+#define EVAL_SERVER_MAX_BLOCKS 64
 #define EVAL_QUIT_BIT 0x80000000u
 template <int T>
 __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const FrameStore fs, const int slot, const unsigned int* __restrict__ mail, unsigned int* __restrict__ dmail,
-                                                   const unsigned int first_seen, const long long idle_ticks, float* __restrict__ partials, unsigned int* __restrict__ arrive,
-                                                   float* __restrict__ out_host) {
+                                                   const unsigned int first_seen, const long long idle_ticks, float* __restrict__ out_host) {
   __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
   __shared__ float s_partH[(T / 64) * 256];
   __shared__ float s_partS[T / 64][8];
   __shared__ float s_tot[ACC_PAD];
   __shared__ EvalP s_e;
   __shared__ unsigned int s_tk;
-  __shared__ int s_last;
   initStage<T>(s_stage);
   const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
   unsigned int seen = first_seen;
@@ -471,27 +471,14 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
     else
       blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH, s_stage, s_partH, s_partS,
                          s_tot);
-    bool publish = true;
-    if (gridDim.x == 1) {
-      if (threadIdx.x < ACC_PAD) __hip_atomic_store(out_host + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      // partial sums double-buffered by ticket parity: a workgroup may already be storing the partials of request n+1 while a slow last workgroup still adds those of n?
-      // No: the host posts request n+1 only after the sums of n are published, i.e. after the last workgroup has read every partial of n.
-      if (threadIdx.x < ACC_PAD) __hip_atomic_store(partials + blockIdx.x * ACC_PAD + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
-      __syncthreads();
-      publish = s_last != 0;
-      if (publish && threadIdx.x < ACC_PAD) {
-        const float sum = sumPartialsInOrder(partials + threadIdx.x, (int)gridDim.x);
-        __hip_atomic_store(out_host + threadIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    // every workgroup stores its own partial sums and then the request's ticket into ITS record of host-coherent memory; the host waits for all records and adds them in
+    // rank order (the same fp32 additions in the same order as the device-side reduction of cluster mode / k_eval_fused: the same bits) — no arrive counter, no second pass
+    // over the partials on the device
+    float* mine = out_host + (size_t)blockIdx.x * EVAL_RECORD_FLOATS;
+    if (threadIdx.x < ACC_PAD) __hip_atomic_store(mine + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (publish && threadIdx.x == 0) {
-      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(reinterpret_cast<unsigned int*>(out_host) + ACC_PAD, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(mine) + ACC_PAD, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
