@@ -345,6 +345,48 @@ def test_tracking_and_mapping_overlap_on_two_threads(pkg, oracle, synth, gpu_req
         assert np.array_equal(a, b)
 
 
+def test_live_tracking_server_and_mapping_overlap(pkg, synth, gpu_required):
+    """One frame at a time on the tracking thread — the host LM against the resident evaluation kernel, which keeps eight workgroups on the device for the length of a
+    frame — while the mapping thread optimises a window on its own stream: neither waits for the other to finish, results identical to the sequential runs."""
+    import threading
+    w = h = 512
+    bcase = synth.ba_case(w, h, n_frames=8, n_points=2000, seed=19)
+    tcase = synth.tracking_case(w, h, n_ref=2000, n_frames=4, xi_jitter=0.3)
+    ctx = pkg.Context(w, h, n_slots=8 + 1 + 4)
+    for k in range(8):
+        ctx.frame_upload(k, bcase["imgs"][k])
+    ctx.frame_upload(8, tcase["ref_img"])
+    for i in range(4):
+        ctx.frame_upload(9 + i, tcase["frames"][i]["img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(tcase["K4"])
+    trk.setCoarseTrackingRef(8, tcase["u"], tcase["v"], tcase["idepth"], tcase["hdiF"])
+    ba = pkg.BundleAdjusterHip(ctx)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+    def do_track(out):
+        res = []
+        for k in range(200):
+            res.append(trk.trackNewestCoarse(9 + k % 4, ident, (0.0, 0.0))["pose7"])
+        out["r"] = np.array(res)
+
+    def do_ba(out):
+        for _ in range(8):
+            ba.set_case(bcase, list(range(8)))
+            out["r"] = ba.optimize(6)
+        out["poses"] = [ba.frame_pose(k)[0] for k in range(8)]
+
+    seq_t, seq_b = {}, {}
+    do_track(seq_t); do_ba(seq_b)
+    par_t, par_b = {}, {}
+    th = [threading.Thread(target=do_track, args=(par_t,)), threading.Thread(target=do_ba, args=(par_b,))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert np.array_equal(par_t["r"], seq_t["r"])
+    assert par_b["r"]["finalEnergy"] == seq_b["r"]["finalEnergy"] and all(np.array_equal(a, b) for a, b in zip(par_b["poses"], seq_b["poses"]))
+    for k in range(4):
+        assert np.linalg.norm(seq_t["r"][k][:3] - tcase["frames"][k]["pose7"][:3]) < 5e-3
+
+
 def test_default_accumulation_order_optimize_parity(pkg, oracle, synth, gpu_required):
     """The library's default accumulation (4 partial accumulators per bucket — the structure of the reference's multi-threaded mode with a
     fixed assignment) through the whole FullSystem::optimize: same accept / reject sequence, final energy within 1e-4, poses within 1e-3 m of
