@@ -601,31 +601,33 @@ static void serverStop(dmvio_hip_tracker* t) {
 }
 static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
   dmvio_hip_ctx* c = t->ctx;
-  unsigned int ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;
-  if (ticket == 0) ticket = 1;
-  t->eval_ticket = ticket;
   static_assert(sizeof(EvalP) / 4 + 2 <= EVAL_MAIL_DWORDS, "EvalP must fit the mailbox");
+  const int G = t->server_G;
+  auto nextTicket = [&]() { unsigned int v = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT; if (v == 0) v = 1; t->eval_ticket = v; return v; };
   memcpy((void*)(t->h_mail + 1), &e, sizeof(EvalP));
+  unsigned int ticket = nextTicket();
   mailTicket(t, ticket);
   // wait for the record of every workgroup (ticket behind its sums), last rank first: the others are usually there by then
-  const int G = t->server_G;
   auto pending = [&]() -> bool {
     for (int g = G - 1; g >= 0; g--)
       if (reinterpret_cast<volatile unsigned int*>(t->h_rec + (size_t)g * EVAL_RECORD_FLOATS)[ACC_PAD] != ticket) return true;
     return false;
   };
   unsigned long long spins = 0;
+  int restarts = 0;
   while (pending()) {
     __builtin_ia32_pause();
-    if ((++spins & 0x3FFFF) == 0) {   // every ~quarter million polls (about a millisecond): is the server still there?
+    if ((++spins & 0x7FFF) == 0) {   // a request takes ~12 us; every ~30 thousand polls (about a hundred microseconds) ask whether the server is still there
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_server", __FILE__, __LINE__, q);
       if (q == hipSuccess && pending()) {
-        // the kernel left (idle time-out) before it saw this request: start it again; it picks the pending ticket up at once
-        t->eval_ticket = ticket - 1;
-        mailTicket(t, ticket - 1);
-        if (int r = serverLaunch(t)) return r;
-        t->eval_ticket = ticket;
+        // the kernel left (idle time-out) without serving this request.  Start it again under a ticket number of its own — the device mailbox still holds the old
+        // kernel's "I am leaving" mark, which must stay OLDER than anything the new one has seen — and post the request again under the next number
+        if (++restarts > 8) return failmsg("evaluation server keeps leaving before it serves the request");
+        const unsigned int launchTicket = ticket;          // nothing new for the kernel about to start ...
+        if (int r = serverLaunch(t)) return r;             // ... (first_seen = eval_ticket = launchTicket)
+        (void)launchTicket;
+        ticket = nextTicket();                             // ... and the request itself under a fresh number
         mailTicket(t, ticket);
       }
     }

@@ -151,3 +151,25 @@ int main(int argc, char** argv) {
                            "-Wl,-rpath," + os.path.join(ROOT, "dm-vio_amd", "lib")])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_evaluation_server_restarts_after_a_slow_callback(setup):
+    """The resident evaluation kernel leaves by itself after 5 ms without a request; a computeCoarseUpdate that takes longer (a factor-graph solve) finds it gone, the library
+    starts it again and the call goes on: same result as with a fast callback."""
+    import time
+    trk = setup["trk"]
+    ref = trk.trackNewestCoarseVIO(1, IDENT, [0.0, 0.0])
+    calls = []
+
+    def slow_update(H, b, ef, lam, pc, ac):
+        calls.append(lam)
+        if len(calls) in (2, 5):
+            time.sleep(0.02)
+        return trk.coarse_update_visual(H, b, ef, lam, pc)
+
+    r = trk.trackNewestCoarseVIO(1, IDENT, [0.0, 0.0], update=slow_update)
+    assert len(calls) >= 6 and r["good"] == ref["good"]
+    assert np.array_equal(r["pose7"], ref["pose7"]) and np.array_equal(r["lastResiduals"], ref["lastResiduals"], equal_nan=True)
+    # and a batch launched right after a server session runs behind it on the same stream
+    b = trk.track_batch([1, 2, 3], [IDENT] * 3, [(0.0, 0.0)] * 3)
+    assert b["good"].all() and np.abs(b["pose7"][0] - ref["pose7"]).max() < 1e-14
