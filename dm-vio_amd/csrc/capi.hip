@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 
@@ -615,9 +616,15 @@ static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
   };
   unsigned long long spins = 0;
   int restarts = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
   while (pending()) {
     __builtin_ia32_pause();
     if ((++spins & 0x7FFF) == 0) {   // a request takes ~12 us; every ~30 thousand polls (about a hundred microseconds) ask whether the server is still there
+      if (std::chrono::steady_clock::now() - t_begin > std::chrono::seconds(5)) {   // never spin forever: report, and let the kernel leave
+        mailTicket(t, t->eval_ticket | EVAL_QUIT_BIT);
+        t->server_on = false;
+        return failmsg("evaluation server did not answer within 5 s");
+      }
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_server", __FILE__, __LINE__, q);
       if (q == hipSuccess && pending()) {
