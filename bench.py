@@ -249,6 +249,26 @@ def main():
         cpu = dict(value=round(n_done / t_cpu, 2), unit="frames/s", cores=1, kind="port",
                    sample="%d frames of the same batch (makeImages + trackNewestCoarse), oracle -O3 -msse2, 1 thread "
                           "(the reference tracks single-threaded), %.1f s on %s" % (n_done, t_cpu, _cpu_name()))
+        # the reference's OWN sources, compiled by oracle/Makefile.ref (oracle/_ref/libref.so), when that library travelled with the tree: same frames, same calls
+        try:
+            Rf = graft.load_reference()
+            if Rf.available():
+                RT = Rf.Tracker(w, h, case["K4"])
+                RT.set_ref(case["ref_img"], case["u"], case["v"], case["idepth"], case["hdiF"])
+                n_ref = 0; t_r0 = time.perf_counter()
+                while time.perf_counter() - t_r0 < max(2.0, args.cpu_seconds / 2):
+                    i = n_ref % B
+                    RT.set_new(host_frames[i % n_host])
+                    RT.track(poses0[i], affs0[i])
+                    n_ref += 1
+                t_r = time.perf_counter() - t_r0
+                cpu["value_port"] = cpu["value"]
+                cpu["value"] = round(n_ref / t_r, 2); cpu["kind"] = "reference"
+                cpu["sample"] = ("%d frames of the same batch through the reference's own FrameHessian::makeImages + CoarseTracker::trackNewestCoarse (its sources compiled -O3 -msse2 by "
+                                 "oracle/Makefile.ref against stand-in Eigen / Sophus headers), 1 thread (the reference tracks single-threaded), %.1f s on %s; `value_port` = the "
+                                 "oracle restatement on %d frames in %.1f s" % (n_ref, t_r, _cpu_name(), n_done, t_cpu))
+        except Exception as ex:      # the port's figure stands
+            sys.stderr.write("bench: reference build not timed (%s: %s)\n" % (type(ex).__name__, ex))
 
     out = {
         "metric": "tracked frames/sec (512x512, CoarseTracker direct image alignment, 4 pyramid levels)",
