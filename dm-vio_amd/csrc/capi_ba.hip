@@ -348,9 +348,30 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   HIPCHK(hipGetLastError());
   return wait ? accumulateWait(b) : 0;
 }
+// the gather kernel publishes per workgroup (BAHostRes::gticket): wait until every slot shows the chain's ticket
+static int waitGather(dmvio_hip_ba* b, const unsigned int ticket, const int nblk) {
+  volatile unsigned int* slots = b->h_res->gticket;
+  unsigned long long spins = 0;
+  for (;;) {
+    bool all = true;
+    for (int k = nblk - 1; k >= 0; k--) if (slots[k] != ticket) { all = false; break; }
+    if (all) break;
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      const hipError_t q = hipStreamQuery(b->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail("BA kernel chain", __FILE__, __LINE__, q);
+      if (q == hipSuccess) {
+        for (int k = 0; k < nblk; k++) if (slots[k] != ticket) return failmsg("BA accumulation chain finished without publishing its system");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
 static int accumulateWait(dmvio_hip_ba* b) {
   const int n = b->H.n(), tot = 2 * (n * n + n);
-  if (int r = waitTicket(b, b->acc_ticket)) return r;   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
+  if (!sharded(b)) { if (int r = waitGather(b, b->acc_ticket, (tot + 256) / 256)) return r; }
+  else if (int r = waitTicket(b, b->acc_ticket)) return r;   // h_sys = [H_A | b_A | H_sc | b_sc | resInA]
   b->H.resInA = (int)b->h_sys[tot];
   return 0;
 }
