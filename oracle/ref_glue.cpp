@@ -999,6 +999,8 @@ float ref_ba_optimize(void* p, int mnumOptIts, int* n_trace, double* trace /* up
 int ref_ba_log(void* p, char* out, int cap) { RefWindow* W = (RefWindow*)p; int n = std::min((int)W->log.size(), cap - 1); memcpy(out, W->log.data(), n); out[n] = 0; return n; }
 // flagPointsForRemoval + marginalizePointsF as makeKeyFrame runs them (FullSystem.cpp:1485-1492), with `flagged[k]` frames flagged
 // for marginalisation.  decision per point: 0 = kept, 1 = marginalised, 2 = dropped.  Hadd / badd = what marginalizePointsF added to HM / bM
+// PointHessian::numGoodResiduals (HessianBlocks.h; counted up by FullSystem::optimize's final linearisation of new residuals): the bookkeeping half of isInlierNew
+void ref_ba_set_num_good_residuals(void* p, int v) { for (PointHessian* ph : ((RefWindow*)p)->pts) if (ph) ph->numGoodResiduals = v; }
 int ref_ba_marginalize_points(void* p, const unsigned char* flaggedFrames, unsigned char* decision, double* Hadd, double* badd)
 {
 	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs; EnergyFunctional* ef = fs->ef;

@@ -525,6 +525,10 @@ class BAWindow:
     def log(self):
         buf = C.create_string_buffer(1 << 20); self.L.ref_ba_log(self.p, buf, len(buf)); return buf.value.decode(errors="replace")
 
+    def set_num_good_residuals(self, v):
+        self.L.ref_ba_set_num_good_residuals.argtypes = [vp, C.c_int]
+        self.L.ref_ba_set_num_good_residuals(self.p, int(v))
+
     def marginalize_points(self, flagged_frames):
         n = self.n
         fl = np.ascontiguousarray(flagged_frames, dtype=np.uint8)

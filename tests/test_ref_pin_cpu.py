@@ -327,6 +327,54 @@ def test_full_system_optimize_bitwise(O, synth, kw):
     assert np.abs(io - ir).max() < 1e-6 * np.abs(io).max() and np.mean(io == ir) > 0.98
 
 
+def _marg_pair(O, synth, case, perturb):
+    Wr = R.BAWindow(case); Wo = O.BAWindow(case)
+    rng = np.random.RandomState(3)
+    if perturb:
+        for k in range(1, case["n_frames"]):
+            st = np.zeros(10); st[:3] = 2e-3 * rng.standard_normal(3); st[3:6] = 1e-3 * rng.standard_normal(3); st[6] = 1e-3 * rng.standard_normal(); st[7] = 1e-4 * rng.standard_normal()
+            Wr.set_frame_state(k, st); Wo.set_frame_state(k, st)
+    for X in (Wr, Wo):
+        X.activate_all(); X.linearize_all(False); X.apply_res(); X.accumulate()
+    Wr.set_num_good_residuals(100)      # every point has been an inlier for long: isInlierNew then only asks for >= setting_minGoodActiveResForMarg (3) residuals
+    dr, Hr, br, nr = Wr.marginalize_points(np.array([0, 1, 0, 0, 0], np.uint8))
+    # the caller's candidate list (FullSystem.cpp:785-827): the points of the flagged keyframe plus the few the reference's own PointHessian::isOOB test selects (host code
+    # in an integration, HessianBlocks.h:196-215) — taken from the reference's run; candidates that fail isInlierNew (host bookkeeping) are dropped without device work
+    cand = (np.asarray(case["host"]) == 1).astype(np.uint8)
+    cand[(dr != 0) & (cand == 0)] = 1
+    n_res = np.bincount(case["res_point"], minlength=len(cand))
+    few = (cand == 1) & (n_res < 3)
+    assert np.all(dr[few] == 2)
+    cand[few] = 0
+    do, Ho, bo, no = Wo.marginalize_points(cand)
+    do[few] = 2
+    assert np.array_equal(dr, do) and nr == no
+    return Wr, Wo, dr, (Hr, br), (Ho, bo)
+
+
+def test_marginalisation_against_the_reference(O, synth):
+    """FullSystem::flagPointsForRemoval (relinearisation of the points of a keyframe flagged for marginalisation, inlier test), EnergyFunctional::marginalizePointsF
+    (addPoint<2> + Schur complement into HM / bM) and EnergyFunctional::marginalizeFrame — the reference's own members vs the oracle.  Decisions and residual counts are
+    identical.  The prior's increment agrees to double rounding when the order of the fp32 sums is forced (a handful of points: every (host, target) accumulator sees one
+    or two); with 145 candidates the reference adds them in the order its dropPointsF left them in (removal swaps the last point into the hole, EnergyFunctional.cpp:644-676),
+    the oracle in index order: same values to fp32 summation rounding."""
+    small = synth.ba_case(320, 256, n_frames=5, n_points=400, hosts_share=(200, 1, 110, 89, 0), seed=35)
+    Wr, Wo, dr, (Hr, br), (Ho, bo) = _marg_pair(O, synth, small, perturb=True)
+    assert (dr == 1).sum() >= 2
+    assert np.linalg.norm(Hr - Ho) <= 1e-13 * np.linalg.norm(Hr) and np.linalg.norm(br - bo) <= 1e-12 * np.linalg.norm(br)
+    Wo.set_marg_prior(Ho, bo)
+    Hn_r, bn_r = Wr.marginalize_frame(1); Hn_o, bn_o = Wo.marginalize_frame(1)
+    # marginalizeFrame inverts the frame's 8x8 block (EnergyFunctional.cpp:619): the stand-in header's inverse and the oracle's are different elimination orders
+    assert np.linalg.norm(Hn_r - Hn_o) <= 1e-7 * np.linalg.norm(Hn_r) and np.linalg.norm(bn_r - bn_o) <= 1e-7 * np.linalg.norm(bn_r)
+    big = synth.ba_case(320, 256, n_frames=5, n_points=500, hosts_share=(160, 140, 110, 90, 0), seed=33)
+    Wr, Wo, dr, (Hr, br), (Ho, bo) = _marg_pair(O, synth, big, perturb=True)
+    assert (dr == 1).sum() > 50 and (dr == 2).sum() > 20
+    assert np.linalg.norm(Hr - Ho) <= 2e-6 * np.linalg.norm(Hr) and np.linalg.norm(br - bo) <= 2e-6 * np.linalg.norm(br)
+    Wo.set_marg_prior(Hr, br)          # the same prior on both sides: marginalizeFrame itself
+    Hn_r, bn_r = Wr.marginalize_frame(1); Hn_o, bn_o = Wo.marginalize_frame(1)
+    assert np.linalg.norm(Hn_r - Hn_o) <= 1e-7 * np.linalg.norm(Hn_r) and np.linalg.norm(bn_r - bn_o) <= 1e-7 * np.linalg.norm(bn_r)
+
+
 # ---------------------------------------------------------------------------------------------------------------- immature points
 def test_immature_points_bitwise(O, synth):
     """ImmaturePoint::ImmaturePoint, FullSystem::traceNewCoarse (per-host KRKi / Kt / affine + ImmaturePoint::traceOn) through four keyframes with exposure / affine
