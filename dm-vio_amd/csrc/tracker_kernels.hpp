@@ -32,6 +32,11 @@
 
 namespace dmv {
 
+#ifdef DMV_LM_TICKS
+__device__ double g_lm_ticks[8];   // experiment only (profiles/r02_lm_control_step.md): LM control step — solve, lane-0 part 1, lane-0 part 2, whole step (100 MHz ticks), solves, steps; evaluation server — [6] seen -> evaluated, [7] evaluated -> stored
+#endif
+
+
 // Accumulator9 slot of H(r,c), r <= c: rows of the upper triangle back to back (MatrixAccumulators.h:1091-1166).
 __host__ __device__ constexpr int accIdx(int r, int c) { return ACC_H + r * 9 - (r * (r - 1)) / 2 + (c - r); }
 
@@ -461,6 +466,9 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
     const unsigned int tk = s_tk;
     if (tk & EVAL_QUIT_BIT) return;
     seen = tk;
+#ifdef DMV_LM_TICKS
+    const long long q_seen = wall_clock64();
+#endif
     const int lvl = s_e.lvl;
     const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
     const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
@@ -474,11 +482,17 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
     // every workgroup stores its own partial sums and then the request's ticket into ITS record of host-coherent memory; the host waits for all records and adds them in
     // rank order (the same fp32 additions in the same order as the device-side reduction of cluster mode / k_eval_fused: the same bits) — no arrive counter, no second pass
     // over the partials on the device
+#ifdef DMV_LM_TICKS
+    const long long q_eval = wall_clock64();
+#endif
     float* mine = out_host + (size_t)blockIdx.x * EVAL_RECORD_FLOATS;
     if (threadIdx.x < ACC_PAD) __hip_atomic_store(mine + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned int*>(mine) + ACC_PAD, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef DMV_LM_TICKS
+    if (threadIdx.x == 0) { const long long q_done = wall_clock64(); atomicAdd(&g_lm_ticks[6], (double)(q_eval - q_seen)); atomicAdd(&g_lm_ticks[7], (double)(q_done - q_eval)); atomicAdd(&g_lm_ticks[5], 1.0); }
+#endif
   }
 }
 
@@ -550,9 +564,6 @@ struct LMState {
 };
 
 // H(r,c) (SCALE_*-scaled, double) of lane = r*8+c from the 45 sums — calcGSSSE's tail (CoarseTracker.cpp:340-355).
-#ifdef DMV_LM_TICKS
-__device__ double g_lm_ticks[8];   // experiment only: solve, lane-0 part 1, lane-0 part 2, whole step (100 MHz ticks), solves, steps
-#endif
 __device__ __forceinline__ double systemEntryFromSums(const float* tot, const int r, const int c) {
   const int nW = (int)tot[ACC_NW];
   const int n = (nW + 3) & ~3;
