@@ -38,10 +38,10 @@ struct dmvio_hip_tracker {
   int pts_cap = 0;
   float *d_partials = nullptr, *h_tot = nullptr;
   unsigned int* d_arrive = nullptr;   // arrive counter of k_eval_fused (zero between launches)
+  unsigned int* d_leave = nullptr;    // evaluation server: the launch (by its first ticket) whose workgroups have been told to leave by an idle time-out
   unsigned int eval_ticket = 0;       // ticket of the last fused evaluation; the kernel stores it behind the sums in h_tot
   // evaluation server (k_eval_server): one launch per tracked frame, requests through a mailbox in host-coherent memory
   unsigned int* h_mail = nullptr;     // EVAL_MAIL_DWORDS dwords: [0] request ticket, [1..] EvalP, [last] the ticket again (written before [0])
-  unsigned int* d_mail = nullptr;     // device copy workgroup 0 hands the request to the other workgroups through
   float* h_rec = nullptr;             // EVAL_SERVER_MAX_BLOCKS records of EVAL_RECORD_FLOATS floats: every server workgroup stores its partial sums + the ticket into its own
   bool server_on = false;             // a server kernel was launched for server_slot and has not been told to quit
   int server_slot = -1, server_G = 0;
@@ -393,12 +393,12 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   memset(t->h_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS);
   HIPCHKP(hipHostMalloc((void**)&t->h_rec, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS, hipHostMallocCoherent | hipHostMallocMapped));
   memset(t->h_rec, 0, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS);
-  HIPCHKP(hipMalloc((void**)&t->d_mail, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
-  HIPCHKP(hipMemset(t->d_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS));
   if (const char* e = getenv("DMVIO_HIP_EVAL_SERVER")) t->use_server = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_SINGLE_HOST_LM")) t->single_host_lm = atoi(e);
   HIPCHKP(hipMalloc((void**)&t->d_arrive, sizeof(unsigned int)));
   HIPCHKP(hipMemset(t->d_arrive, 0, sizeof(unsigned int)));
+  HIPCHKP(hipMalloc((void**)&t->d_leave, sizeof(unsigned int)));
+  HIPCHKP(hipMemset(t->d_leave, 0xFF, sizeof(unsigned int)));
   HIPCHKP(hipStreamSynchronize(nullptr));   // the clears above run on the NULL stream; the context's stream does not wait for it
   if (const char* e = getenv("DMVIO_HIP_EVAL_BLOCKS")) t->eval_blocks_override = atoi(e);
   if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
@@ -414,8 +414,8 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
-  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->d_mail) hipFree(t->d_mail); if (t->h_rec) hipHostFree(t->h_rec);
-  hipHostFree(t->h_tot); hipFree(t->d_arrive);
+  hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->h_rec) hipHostFree(t->h_rec);
+  hipHostFree(t->h_tot); hipFree(t->d_arrive); hipFree(t->d_leave);
   hipFree(t->d_out);
   for (hipEvent_t e : t->done_event) if (e) hipEventDestroy(e);
   if (t->d_cl_part) hipFree(t->d_cl_part);
@@ -581,7 +581,7 @@ static void mailTicket(dmvio_hip_tracker* t, unsigned int v) {
 }
 static int serverLaunch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
-  hipLaunchKernelGGL(k_eval_server<256>, dim3(t->server_G), dim3(256), 0, c->stream, t->dev, c->fs, t->server_slot, (const unsigned int*)t->h_mail, t->d_mail, t->eval_ticket,
+  hipLaunchKernelGGL(k_eval_server<256>, dim3(t->server_G), dim3(256), 0, c->stream, t->dev, c->fs, t->server_slot, (const unsigned int*)t->h_mail, t->d_leave, t->eval_ticket,
                      (long long)500000 /* 5 ms at 100 MHz */, t->h_rec);
   HIPCHK(hipGetLastError());
   return 0;
@@ -589,7 +589,7 @@ static int serverLaunch(dmvio_hip_tracker* t) {
 static int serverStart(dmvio_hip_tracker* t, int new_slot, int G) {
   t->server_G = std::max(1, std::min(G, (int)EVAL_SERVER_MAX_BLOCKS));
   t->server_slot = new_slot;
-  t->eval_ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;   // a number of its own for the launch: values an earlier launch left in the device mailbox are older
+  t->eval_ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;   // a number of its own for the launch
   mailTicket(t, t->eval_ticket);   // "nothing new" for the kernel about to start
   if (int r = serverLaunch(t)) return r;
   t->server_on = true;
@@ -628,8 +628,8 @@ static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail("k_eval_server", __FILE__, __LINE__, q);
       if (q == hipSuccess && pending()) {
-        // the kernel left (idle time-out) without serving this request.  Start it again under a ticket number of its own — the device mailbox still holds the old
-        // kernel's "I am leaving" mark, which must stay OLDER than anything the new one has seen — and post the request again under the next number
+        // the kernel left (idle time-out) without serving this request: start it again (it takes the mailbox's current ticket as seen) and post the request again under
+        // the next number
         if (++restarts > 8) return failmsg("evaluation server keeps leaving before it serves the request");
         const unsigned int launchTicket = ticket;          // nothing new for the kernel about to start ...
         if (int r = serverLaunch(t)) return r;             // ... (first_seen = eval_ticket = launchTicket)
@@ -815,7 +815,7 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_sl
   // ONE alignment problem: the LM control step (8x8 pivoted LDL^T, SE3 exp: one dependent chain) takes 6.5 us per iteration on a wavefront and well under a microsecond on
   // the host, so the loop runs on the host against the evaluation server (one launch per frame, requests through host-coherent memory).  Same split of the template and
   // same order of the partial sums as the device-resident LM's cluster mode, same arithmetic in the step: identical sums, residuals, H, b and iteration counts, the pose
-  // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.18 instead of 0.25 ms per frame.
+  // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.165 instead of 0.25 ms per frame.
   if (B == 1 && t && t->single_host_lm && t->use_server && !t->lm_threads_override && !t->lm_cluster_override && t->fetch_pending_B == 0 && new_slots && pose7_io && aff_io) {
     int g = 0, ne = 0;
     const float ex = new_exposures ? new_exposures[0] : 1.0f;

@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
 }
 
 // Evaluation server of the host-driven LM (dmvio_hip_tracker_track_vio and single-frame tracking): ONE launch per tracked frame instead of one per evaluation.  The host posts
-// the parameters of an evaluation into a 128-byte mailbox in host-coherent memory (19 dwords of EvalP, then the request ticket — written last), the workgroups poll the ticket,
+// the parameters of an evaluation into a 128-byte mailbox in host-coherent memory (19 dwords of EvalP, then the request ticket — written last), every workgroup polls the ticket,
 // evaluate exactly like k_eval_fused (same split of the template, same rank-order sum: bit-identical sums) and the last one to arrive stores the sums and the ticket into
 // host-coherent memory, where the host polls them.  A request costs two PCIe round trips and the evaluation itself; no launch, no stream synchronisation.
 // Termination: a ticket with the top bit set, or `idle_ticks` (100 MHz) without a new request — the host relaunches the server if it finds it gone.
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
 #define EVAL_SERVER_MAX_BLOCKS 64
 #define EVAL_QUIT_BIT 0x80000000u
 template <int T>
-__global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const FrameStore fs, const int slot, const unsigned int* __restrict__ mail, unsigned int* __restrict__ dmail,
+__global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const FrameStore fs, const int slot, const unsigned int* __restrict__ mail, unsigned int* __restrict__ leave,
                                                    const unsigned int first_seen, const long long idle_ticks, float* __restrict__ out_host) {
   __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
   __shared__ float s_partH[(T / 64) * 256];
@@ -426,41 +426,24 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
   unsigned int seen = first_seen;
   constexpr int EP = (int)(sizeof(EvalP) / 4);
   for (;;) {
-    if (blockIdx.x == 0) {
-      // workgroup 0 is the only one that talks to the host: its first wavefront reads the whole 128-byte mailbox with one load per poll.  The host writes the
-      // parameters, then the ticket's copy in the last dword, then the ticket in the first: a read that shows the same new ticket at both ends has the parameters
-      // that belong to it, however the 128 bytes were fetched.  The request is then handed to the other workgroups through device memory.
-      if (threadIdx.x < 64) {
-        const long long t0 = wall_clock64();
-        unsigned int v, front, back;
-        bool timeout = false;
-        for (;;) {
-          v = threadIdx.x < EVAL_MAIL_DWORDS ? __hip_atomic_load(mail + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-          front = __builtin_amdgcn_readlane(v, 0); back = __builtin_amdgcn_readlane(v, EVAL_MAIL_DWORDS - 1);
-          if (front == back && front != seen) break;
-          if (wall_clock64() - t0 >= idle_ticks) { timeout = true; break; }
-        }
-        const unsigned int tk = timeout ? (seen | EVAL_QUIT_BIT) : front;
-        if (threadIdx.x >= 1 && threadIdx.x <= EP) {
-          reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x - 1] = v;
-          if (gridDim.x > 1) __hip_atomic_store(dmail + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (threadIdx.x == 0) s_tk = tk;
-        if (gridDim.x > 1) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          if (threadIdx.x == 0) __hip_atomic_store(dmail, tk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    // every workgroup polls the mailbox itself: its first wavefront reads the whole 128 bytes with one load per poll.  The host writes the parameters, then the ticket's copy
+    // in the last dword, then the ticket in the first: a read that shows the same new ticket at both ends has the parameters that belong to it, however the 128 bytes were
+    // fetched.  (Workgroup 0 polling alone and handing the request on through device memory: +0.7 us per request.)
+    if (threadIdx.x < 64) {
+      const long long t0 = wall_clock64();
+      unsigned int v, front, back;
+      bool timeout = false;
+      for (;;) {
+        v = threadIdx.x < EVAL_MAIL_DWORDS ? __hip_atomic_load(mail + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+        front = __builtin_amdgcn_readlane(v, 0); back = __builtin_amdgcn_readlane(v, EVAL_MAIL_DWORDS - 1);
+        if (front == back && front != seen) break;
+        // leaving is collective: the first workgroup whose idle limit expires marks this launch (its first ticket is unique to it) and the others follow at their next
+        // poll — a request that arrives at that very moment may be picked up by some workgroups only; the host then finds the kernel gone and posts it again
+        if (__hip_atomic_load(leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == first_seen) { timeout = true; break; }
+        if (wall_clock64() - t0 >= idle_ticks) { __hip_atomic_store(leave, first_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); timeout = true; break; }
       }
-    } else {
-      if (threadIdx.x == 0) {
-        unsigned int tk;
-        // tickets only grow, also from one server launch to the next: whatever an earlier launch left in dmail is older than `seen` and is ignored
-        do { tk = __hip_atomic_load(dmail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (!((tk & ~EVAL_QUIT_BIT) > seen || tk == (seen | EVAL_QUIT_BIT)));
-        s_tk = tk;
-      }
-      __syncthreads();
-      if (!(s_tk & EVAL_QUIT_BIT) && threadIdx.x < EP)
-        reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x] = __hip_atomic_load(dmail + 1 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x >= 1 && threadIdx.x <= EP) reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x - 1] = v;
+      if (threadIdx.x == 0) s_tk = timeout ? (seen | EVAL_QUIT_BIT) : front;
     }
     __syncthreads();
     const unsigned int tk = s_tk;
