@@ -716,7 +716,7 @@ static int clusterSize(const int B, const int pc0) {
   if (B > 128) return 1;
   const int sz = pc0 < 20000 ? 0 : (pc0 < 70000 ? 1 : (pc0 < 180000 ? 2 : 3));
   const int bb = B <= 4 ? 0 : (B <= 8 ? 1 : (B <= 16 ? 2 : (B <= 32 ? 3 : (B <= 64 ? 4 : 5))));
-  static const int tab[4][6] = {{8, 8, 4, 4, 4, 2}, {8, 8, 8, 4, 4, 4}, {16, 16, 8, 8, 4, 4}, {32, 16, 16, 8, 8, 4}};
+  static const int tab[4][6] = {{8, 8, 4, 4, 4, 1}, {8, 8, 8, 4, 4, 4}, {32, 16, 8, 8, 4, 4}, {32, 16, 16, 8, 8, 4}};   // re-measured in round 2 (profiles/r02_tracking_cluster_sweep.md)
   return tab[sz][bb];
 }
 

@@ -57,7 +57,7 @@ def test_tracking_and_ba_800x400_4000_points(pkg, oracle, synth, gpu_required):
     assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
 
 
-@pytest.mark.parametrize("n_ref,min_grad,batch,cluster", [(32000, 4.0, 1, 16), (504 * 504, -1.0, 2, 32), (8000, 8.0, 31, 4), (2000, 8.0, 100, 2), (2000, 8.0, 200, 1)])
+@pytest.mark.parametrize("n_ref,min_grad,batch,cluster", [(32000, 4.0, 1, 32), (504 * 504, -1.0, 2, 32), (8000, 8.0, 31, 4), (2000, 8.0, 100, 1), (2000, 8.0, 200, 1)])
 def test_tracking_dense_templates_and_cluster_sizes(pkg, oracle, synth, gpu_required, n_ref, min_grad, batch, cluster):
     """Semi-dense to all-pixel templates (the bandwidth-asymptote end of SURVEY §8d) and every cluster size of the launch table:
     the same alignment as the oracle, whichever number of workgroups shares a problem."""
