@@ -326,6 +326,73 @@ def main():
                         h2d_GBps=round(B * frame_bytes / (h2d_ms * 1e-3) / 1e9, 2), good=bool(rp["good"].all()),
                         note="per step: %d x %d B fp32 frames copied from pinned host memory to HBM, then makeImages + trackNewestCoarse + result fetch, not pipelined" % (B, frame_bytes))
         del pinned
+        # the same leg with the frames entering as the camera delivers them: 8-bit raw images, photometric undistortion (passthrough geometry, factor 1) fused
+        # into the pyramid build (dmvio_hip_frames_from_raw_device_batch) — a quarter of the bytes over PCIe
+        try:
+            und = pkg.UndistorterHip(ctx, w, h, 8)
+            raw8 = torch.clamp(torch.round(raw), 0, 255).to(torch.uint8)
+            pinned8 = torch.empty((B, h, w), dtype=torch.uint8, pin_memory=True)
+            pinned8.copy_(raw8)
+            torch.cuda.synchronize(dev)
+
+            def step_pcie8():
+                with torch.cuda.stream(stream):
+                    raw8.copy_(pinned8, non_blocking=True)
+                und.from_raw_device_batch(slots, raw8.data_ptr(), w * h)
+                trk.stage(slots, poses0, affs0)
+                trk.launch()
+                return trk.fetch()
+            step_pcie8()
+            torch.cuda.synchronize(dev)
+            t0p = time.perf_counter()
+            for _ in range(n_p):
+                rp8 = step_pcie8()
+            torch.cuda.synchronize(dev)
+            tp8 = (time.perf_counter() - t0p) / n_p
+            ev0.record(stream); und.from_raw_device_batch(slots, raw8.data_ptr(), w * h); ev1.record(stream); ev1.synchronize()
+            k8_ms = ev0.elapsed_time(ev1)
+            terr8 = np.linalg.norm(rp8["pose7"][:, :3] - truth[:, :3], axis=1)
+            # pipelined form: a copy stream brings batch k+1 into the other of two device buffers while batch k is undistorted, built and tracked
+            copy_stream = torch.cuda.Stream(device=dev)
+            bufs = [raw8, torch.empty_like(raw8)]
+            ev_copied = [torch.cuda.Event(), torch.cuda.Event()]
+            ev_built = [torch.cuda.Event(), torch.cuda.Event()]
+            built_once = [False, False]
+
+            def enqueue_copy(k):
+                with torch.cuda.stream(copy_stream):
+                    if built_once[k % 2]:
+                        copy_stream.wait_event(ev_built[k % 2])
+                    bufs[k % 2].copy_(pinned8, non_blocking=True)
+                    ev_copied[k % 2].record(copy_stream)
+
+            def step_pipe8(k):
+                enqueue_copy(k + 1)
+                stream.wait_event(ev_copied[k % 2])
+                und.from_raw_device_batch(slots, bufs[k % 2].data_ptr(), w * h)
+                ev_built[k % 2].record(stream); built_once[k % 2] = True
+                trk.stage(slots, poses0, affs0)
+                trk.launch()
+                return trk.fetch()
+            enqueue_copy(0)
+            step_pipe8(0)
+            torch.cuda.synchronize(dev)
+            t0p = time.perf_counter()
+            for k in range(1, n_p + 1):
+                rq8 = step_pipe8(k)
+            torch.cuda.synchronize(dev)
+            tq8 = (time.perf_counter() - t0p) / n_p
+            pcie_out["raw_u8"] = dict(value=round(B / tq8, 1), unit="frames/s", ms_per_step=round(1e3 * tq8, 4), steps=n_p, good=bool(rp8["good"].all() and rq8["good"].all()),
+                                      value_not_pipelined=round(B / tp8, 1), ms_per_step_not_pipelined=round(1e3 * tp8, 4),
+                                      max_pose_err_m=float(terr8.max()), undistort_pyramid_kernel_ms=round(k8_ms, 4),
+                                      undistort_pyramid_GBps=round(B * (w * h + sum(4 * (w >> l) * (h >> l) for l in range(ctx.levels))) / (k8_ms * 1e-3) / 1e9, 1),
+                                      note="frames cross PCIe as %d-byte 8-bit raw images; undistortion + makeImages fused in one launch (dmvio_hip_frames_from_raw_device_batch), then trackNewestCoarse "
+                                           "+ result fetch; `value`: the copy of batch k+1 on a second stream overlaps batch k (two device buffers), `value_not_pipelined`: copy, build, track in sequence" % (w * h))
+            del bufs, copy_stream
+            und.close(); del pinned8, raw8
+        except Exception as ex:
+            pcie_out["raw_u8"] = dict(error="%s: %s" % (type(ex).__name__, ex))
+        ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
 
     # ---------------- batch-size sweep (rank 0, N = 1): frames per step from a quarter of the resident workgroup slots to four times their number
     sweep_out = None

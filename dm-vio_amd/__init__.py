@@ -88,6 +88,7 @@ def _sig(L):
     L.dmvio_hip_undistorter_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f]
     L.dmvio_hip_undistorter_destroy.argtypes = [vp]
     L.dmvio_hip_frame_upload_raw.argtypes = [vp, vp, C.c_int, C.c_void_p, C.c_float, c_f]
+    L.dmvio_hip_frames_from_raw_device_batch.argtypes = [vp, vp, C.c_int, c_i, vp, C.c_size_t, C.c_float]
     L.dmvio_hip_immature_create.restype = vp
     L.dmvio_hip_immature_create.argtypes = [vp, C.c_int]
     L.dmvio_hip_immature_destroy.argtypes = [vp]
@@ -490,6 +491,12 @@ class UndistorterHip:
         _chk(self.L, self.L.dmvio_hip_frame_upload_raw(self.ctx.p, self.p, slot, raw.ctypes.data_as(C.c_void_p), factor, None if out is None else _f(out)),
              "frame_upload_raw")
         return out
+
+    def from_raw_device_batch(self, slots, raw_dev_ptr, stride_bytes, factor=1.0):
+        """B raw images resident in device memory -> undistorted level 0 + pyramids of `slots` in one launch (asynchronous on the ctx stream)."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        _chk(self.L, self.L.dmvio_hip_frames_from_raw_device_batch(self.ctx.p, self.p, len(slots), _i(slots), C.c_void_p(raw_dev_ptr), stride_bytes, factor),
+             "frames_from_raw_device_batch")
 
 
 class CoarseInitializerHip:

@@ -261,11 +261,8 @@ int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
   return buildPyramid(c, slot, dev);  // asynchronous on the ctx stream
 }
 
-static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes, const bool attach) {
-  if (!c || !slots || !dev_base) return failmsg("frames_from_device_batch: null argument");
-  if (B <= 0 || stride_bytes % sizeof(float)) return failmsg("frames_from_device_batch: bad B / stride");
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCHK(hipSetDevice(c->device));
+// slot list of a batched build -> device (kept while the same list comes again); caller holds c->mu
+static int stageSlots(dmvio_hip_ctx* c, int B, const int* slots) {
   if (B > c->slots_cap) {
     if (c->d_slots) { HIPCHK(hipFree(c->d_slots)); HIPCHK(hipHostFree(c->h_slots)); }
     c->slots_cap = std::max(B, 64); c->slots_valid = 0;
@@ -274,7 +271,7 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
   }
   bool same = (B == c->slots_valid);
   for (int i = 0; i < B; i++) {
-    if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frames_from_device_batch: slot out of range");
+    if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frame batch: slot out of range");
     if (same && c->h_slots[i] != slots[i]) same = false;
   }
   if (!same) {
@@ -284,9 +281,39 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
     HIPCHK(hipMemcpyAsync(c->d_slots, c->h_slots, sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
     c->slots_valid = B;
   }
+  return 0;
+}
+
+static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, const float* dev_base, size_t stride_bytes, const bool attach) {
+  if (!c || !slots || !dev_base) return failmsg("frames_from_device_batch: null argument");
+  if (B <= 0 || stride_bytes % sizeof(float)) return failmsg("frames_from_device_batch: bad B / stride");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  if (int r = stageSlots(c, B, slots)) return r;
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
                      c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
   for (int i = 0; i < B; i++) c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// B raw camera images already on the device (the caller's own pinned buffers / copy stream brought them there, 1 or 2 bytes per pixel) -> undistorted level 0
+// + pyramids of B slots in one launch; asynchronous on the ctx stream like the fp32 variants.  Undistort::undistort + FrameHessian::makeImages per frame.
+int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistorter* u, int B, const int* slots, const void* raw_dev_base, size_t stride_bytes, float factor) {
+  if (!c || !u || !slots || !raw_dev_base || u->ctx != c) return failmsg("frames_from_raw_device_batch: bad argument");
+  const size_t nOrg = (size_t)u->U.wOrg * u->U.hOrg;
+  if (B <= 0 || stride_bytes % u->bytes_per_px || stride_bytes < nOrg * u->bytes_per_px) return failmsg("frames_from_raw_device_batch: bad B / stride");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  if (int r = stageSlots(c, B, slots)) return r;
+  UndistortDev U = u->U;
+  U.factor = factor;
+  const dim3 grid(c->pg.tiles_x * c->pg.tiles_y, B);
+  if (u->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+  else
+    hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+  for (int i = 0; i < B; i++) c->h_lvl0[slots[i]] = c->fs.own_level(slots[i], 0);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -19,6 +19,27 @@ typedef float pyr_f4 __attribute__((ext_vector_type(4)));
 // level-0 tile of a workgroup: 128 x 32 pixels — 512-byte row segments at level 0, 256 / 128 / 64 bytes at the next three levels
 #define PYR_TW 128
 #define PYR_TH 32
+// levels 1.. of a workgroup's tile: successive 2x2 means of the level-0 tile in s_a (the caller's barrier has made it visible), streamed out level by level
+__device__ __forceinline__ void pyrReduceLevels(float* s_a, float* s_b, const PyrGeom& G, const FrameStore& fs, const int slot, const int x0, const int y0) {
+  float* cur = s_a;
+  float* nxt = s_b;
+  int sw = PYR_TW, sh = PYR_TH;
+  for (int l = 1; l < G.levels; l++) {
+    const int nw = sw >> 1, nh = sh >> 1;
+    for (int o = threadIdx.x; o < nw * nh; o += 256) {
+      const int lx = o % nw, ly = o / nw;
+      const int b = 2 * lx + 2 * ly * sw;
+      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + sw] + cur[b + sw + 1]);
+      nxt[ly * nw + lx] = val;
+      const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
+      if (x < G.w[l] && y < G.h[l]) fs.own_level(slot, l)[(size_t)y * G.w[l] + x] = val;
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+    sw = nw; sh = nh;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen, const int attach) {
   __shared__ float s_a[PYR_TW * PYR_TH];
@@ -70,23 +91,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   // stamps of this build (see FrameStore): the barrier the level reduction needs anyway carries the tile's verdict
   if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
   if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = attach ? src : fs.own_level(slot, 0); }
-  float* cur = s_a;
-  float* nxt = s_b;
-  int sw = PYR_TW, sh = PYR_TH;
-  for (int l = 1; l < G.levels; l++) {
-    const int nw = sw >> 1, nh = sh >> 1;
-    for (int o = threadIdx.x; o < nw * nh; o += 256) {
-      const int lx = o % nw, ly = o / nw;
-      const int b = 2 * lx + 2 * ly * sw;
-      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + sw] + cur[b + sw + 1]);
-      nxt[ly * nw + lx] = val;
-      const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
-      if (x < G.w[l] && y < G.h[l]) fs.own_level(slot, l)[(size_t)y * G.w[l] + x] = val;
-    }
-    __syncthreads();
-    float* t = cur; cur = nxt; nxt = t;
-    sw = nw; sh = nh;
-  }
+  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0);
 }
 
 // Photometric + geometric undistortion of a raw camera image on the upload path:
@@ -109,18 +114,76 @@ __device__ __forceinline__ float photoAt(const T* __restrict__ raw, const Undist
   return v;
 }
 template <typename T>
-__global__ void __launch_bounds__(256) k_undistort(const T* __restrict__ raw, const UndistortDev U, float* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= U.w * U.h) return;
-  if (!U.remapX) { out[idx] = photoAt(raw, U, idx); return; }
+__device__ __forceinline__ float undistortPixel(const T* __restrict__ raw, const UndistortDev& U, const int idx) {
+  if (!U.remapX) return photoAt(raw, U, idx);
   float xx = U.remapX[idx], yy = U.remapY[idx];
-  if (xx < 0) { out[idx] = 0; return; }
+  if (xx < 0) return 0.f;
   const int xxi = (int)xx, yyi = (int)yy;
   xx -= xxi; yy -= yyi;
   const float xxyy = xx * yy;
   const int base = xxi + yyi * U.wOrg;
-  out[idx] = xxyy * photoAt(raw, U, base + 1 + U.wOrg) + (yy - xxyy) * photoAt(raw, U, base + U.wOrg) + (xx - xxyy) * photoAt(raw, U, base + 1) +
-             (1 - xx - yy + xxyy) * photoAt(raw, U, base);
+  return xxyy * photoAt(raw, U, base + 1 + U.wOrg) + (yy - xxyy) * photoAt(raw, U, base + U.wOrg) + (xx - xxyy) * photoAt(raw, U, base + 1) +
+         (1 - xx - yy + xxyy) * photoAt(raw, U, base);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_undistort(const T* __restrict__ raw, const UndistortDev U, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= U.w * U.h) return;
+  out[idx] = undistortPixel(raw, U, idx);
+}
+
+// Raw camera images of B frames -> undistorted level 0 + all coarser levels in ONE launch (k_undistort fused into the level-0 pass of k_build_pyramids: the
+// fp32 image is never staged, a frame enters as 1 or 2 bytes per pixel).  Same per-pixel arithmetic as the two kernels in sequence, so the same bits.
+template <typename T>
+__global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict__ raw_base, const size_t raw_stride, const UndistortDev U, const PyrGeom G,
+                                                             const FrameStore fs, const int* __restrict__ slots, const unsigned int gen) {
+  __shared__ float s_a[PYR_TW * PYR_TH];
+  __shared__ float s_b[(PYR_TW / 2) * (PYR_TH / 2)];
+  const int f = blockIdx.y;
+  const int slot = slots[f];
+  const T* __restrict__ raw = raw_base + (size_t)f * raw_stride;
+  const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
+  const int w0 = G.w[0], h0 = G.h[0];
+  const int x0 = tx * PYR_TW, y0 = ty * PYR_TH;
+  bool bad = false;
+  {
+    const int lx = (threadIdx.x & 31) * 4, lyb = threadIdx.x >> 5;
+    float* __restrict__ dst = fs.own_level(slot, 0);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int x = x0 + lx, y = y0 + lyb + 8 * p, ly = lyb + 8 * p;
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      if (y < h0) {
+        const int i0 = y * w0 + x;
+        if (!U.remapX && x + 3 < w0 && ((uintptr_t)(raw + i0) & (4 * sizeof(T) - 1)) == 0) {
+          // passthrough geometry: the four raw values of this thread are one aligned 4- / 8-byte load
+          T r4[4];
+          __builtin_memcpy(r4, __builtin_assume_aligned(raw + i0, 4 * sizeof(T)), 4 * sizeof(T));
+          if (!U.G) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = U.factor * r4[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = U.G[r4[k]];
+            if (U.vignetteMapInv) {
+#pragma unroll
+              for (int k = 0; k < 4; k++) t[k] *= U.vignetteMapInv[i0 + k];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (x + k < w0) t[k] = undistortPixel(raw, U, i0 + k);
+        }
+        if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 v = {t[0], t[1], t[2], t[3]}; __builtin_nontemporal_store(v, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
+        else for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
+      }
+      *reinterpret_cast<float4*>(&s_a[ly * PYR_TW + lx]) = make_float4(t[0], t[1], t[2], t[3]);
+      bad |= !(fabsf(t[0]) <= 1e30f) || !(fabsf(t[1]) <= 1e30f) || !(fabsf(t[2]) <= 1e30f) || !(fabsf(t[3]) <= 1e30f);
+    }
+  }
+  if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = fs.own_level(slot, 0); }
+  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0);
 }
 
 // level plane -> the reference's Eigen::Vector3f AoS (I, dx, dy)   (parity tests / debug download)

@@ -74,6 +74,12 @@ int dmvio_hip_frames_from_device_batch(dmvio_hip_ctx* ctx, int B, const int* slo
  * place and only the coarser levels are built (1.33 B written per input byte less).  The images (row-major, w floats per row) must stay
  * valid and unchanged until their slots are rebuilt or the context is destroyed. */
 int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* ctx, int B, const int* slots, const float* dev_base, size_t stride_bytes);
+/* Raw-image form of the batched build: B raw camera images (8- or 16-bit as the undistorter was created, wOrg x hOrg each, frame i at
+ * raw_dev_base + i * stride_bytes) ALREADY IN DEVICE MEMORY -> PhotometricUndistorter::processFrame + Undistort::undistort (src/dso/util/Undistort.cpp:214-250,
+ * 386-481) + FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:128-191) of slots[i], fused into one launch: a frame crosses PCIe and
+ * enters the kernel as 1 (2) bytes per pixel instead of 4, and the undistorted fp32 image is written once, as level 0.  `factor` as in
+ * dmvio_hip_frame_upload_raw.  Bit-identical to B calls of dmvio_hip_frame_upload_raw.  Asynchronous on the ctx stream. */
+int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* ctx, dmvio_hip_undistorter* und, int B, const int* slots, const void* raw_dev_base, size_t stride_bytes, float factor);
 /* Diagnostics.  Every pyramid build stamps its slot "clean" when all pixels are finite (|I| <= 1e30): consumers then run without the
  * reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455), which cannot fire on such a frame.  This call withdraws
  * the stamp so that the guarded code path runs (tests compare the two). */

@@ -31,3 +31,45 @@ def test_upload_raw_bit_exact(pkg, oracle, gpu_required, bits):
         rx.flat[17] = bad_x; ry.flat[17] = bad_y
         with pytest.raises(pkg.HipLibraryError):
             pkg.UndistorterHip(ctx, c["wOrg"], c["hOrg"], bits, c["G"], c["vig"], rx, ry)
+
+
+@pytest.mark.parametrize("bits,size", [(8, (640, 480, 512, 384)), (16, (640, 480, 512, 384)), (8, (300, 210, 250, 170))])
+def test_raw_device_batch_equals_single_uploads(pkg, oracle, gpu_required, bits, size):
+    """The fused batched build (raw images resident on the device -> undistortion + every pyramid level in one launch) gives the bits of the
+    per-frame upload path for every frame and level, with geometric maps and in passthrough; sizes that are no multiple of the 128x32 tile too."""
+    import torch
+    from test_io_cpu import io_case
+    wOrg, hOrg, w, h = size
+    B = 5
+    cases = [io_case(seed=40 + 3 * i + bits, wOrg=wOrg, hOrg=hOrg, w=w, h=h, bits=bits) for i in range(B)]
+    c = cases[0]
+    ctx = pkg.Context(w, h, n_slots=2 * B)
+    und = pkg.UndistorterHip(ctx, wOrg, hOrg, bits, c["G"], c["vig"], c["rx"], c["ry"])
+    raws = np.stack([k["raw"].reshape(hOrg, wOrg) for k in cases]).astype(und.dtype)
+    stride = raws[0].nbytes + 64                          # frames need not be packed
+    host = np.zeros((B, stride), np.uint8)
+    host[:, :raws[0].nbytes] = raws.reshape(B, -1).view(np.uint8)
+    dev = torch.from_numpy(host).to("cuda:0")
+    torch.cuda.synchronize()
+    und.from_raw_device_batch(list(range(B, 2 * B)), dev.data_ptr(), stride)
+    ctx.synchronize()
+    for i in range(B):
+        ref = oracle.undistort(cases[i]["raw"], c["G"], c["vig"], c["rx"], c["ry"], w, h)
+        und.upload(i, cases[i]["raw"], want_image=False)
+        for lvl in range(ctx.levels):
+            a, b = ctx.frame_download(B + i, lvl), ctx.frame_download(i, lvl)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (i, lvl)
+        assert np.array_equal(ctx.frame_download(B + i, 0)[..., 0].reshape(h, w).view(np.uint32), ref.reshape(h, w).view(np.uint32))
+    # passthrough with a factor
+    ctx2 = pkg.Context(wOrg, hOrg, n_slots=2 * B)
+    und2 = pkg.UndistorterHip(ctx2, wOrg, hOrg, bits)
+    und2.from_raw_device_batch(list(range(B, 2 * B)), dev.data_ptr(), stride, factor=0.5)
+    ctx2.synchronize()
+    for i in range(B):
+        und2.upload(i, cases[i]["raw"], factor=0.5, want_image=False)
+        for lvl in range(ctx2.levels):
+            assert np.array_equal(ctx2.frame_download(B + i, lvl).view(np.uint32), ctx2.frame_download(i, lvl).view(np.uint32))
+    with pytest.raises(pkg.HipLibraryError):
+        und.from_raw_device_batch([0, 2 * B], dev.data_ptr(), stride)            # slot out of range
+    with pytest.raises(pkg.HipLibraryError):
+        und.from_raw_device_batch([0, 1], dev.data_ptr(), raws[0].nbytes - 2)    # frames would overlap
