@@ -134,7 +134,9 @@ DMV_HD Pose poseMul(const Pose& a, const Pose& b) {
 
 DMV_HD Pose poseInv(const Pose& a) {
   Pose r;
-  r.q.w = a.q.w; r.q.x = -a.q.x; r.q.y = -a.q.y; r.q.z = -a.q.z;
+  // SO3Group::inverse() builds SO3Group(conjugate), whose constructor normalises (thirdparty/Sophus/sophus/so3.hpp:173-175, 631-633)
+  const Quatd c = {a.q.w, -a.q.x, -a.q.y, -a.q.z};
+  r.q = qnormalize(c);
   const double nt[3] = {-a.t[0], -a.t[1], -a.t[2]};
   quatRotate(r.q, nt, r.t);
   return r;

@@ -165,7 +165,9 @@ inline SE3 se3Mul(const SE3& a, const SE3& b) {
 }
 inline SE3 se3Inv(const SE3& a) {
   SE3 r;
-  r.q = qconj(a.q);
+  // so3.hpp:173-175: SO3Group(unit_quaternion().conjugate()) — the constructor from a quaternion normalises (so3.hpp:631-633), so the inverse of a pose
+  // whose quaternion is unit only to rounding moves in its last bits (found by the pin against the vendored Sophus, tests/test_ref_pin_cpu.py)
+  r.q = qnormalize(qconj(a.q));
   double nt[3] = {-a.t[0], -a.t[1], -a.t[2]};
   qRot(r.q, nt, r.t);
   return r;

@@ -63,16 +63,17 @@ namespace
 // pose7 = [tx ty tz qx qy qz qw] (the convention of oracle/ and of the C ABI)
 SE3 se3From7(const double* p)
 {
-	Sophus::Quaterniond_ q(p[6], p[3], p[4], p[5]);
-	SE3 T(q, Vec3(p[0], p[1], p[2]));   // normalises, like Sophus
-	// a quaternion that is unit already (exported from a running system) keeps its bits — see poseFrom7 in dm-vio_amd/csrc/lie_dev.h
-	if (std::fabs(q.squaredNorm() - 1.0) <= 1e-14) T.so3().setQuaternionRaw(q);
+	Eigen::Quaterniond q(p[6], p[3], p[4], p[5]);
+	SE3 T(q, Vec3(p[0], p[1], p[2]));   // Sophus' constructor normalises
+	// a quaternion that is unit already (exported from a running system) keeps its bits — see poseFrom7 in dm-vio_amd/csrc/lie_dev.h; written through
+	// SO3Group::data() (the coefficient array x, y, z, w), the one raw mutator Sophus offers
+	if (std::fabs(q.squaredNorm() - 1.0) <= 1e-14) { double* c = T.so3().data(); c[0] = p[3]; c[1] = p[4]; c[2] = p[5]; c[3] = p[6]; }
 	return T;
 }
 void se3To7(const SE3& T, double* p)
 {
 	p[0] = T.translation()[0]; p[1] = T.translation()[1]; p[2] = T.translation()[2];
-	const Sophus::Quaterniond_& q = T.unit_quaternion();
+	const Eigen::Quaterniond& q = T.unit_quaternion();
 	p[3] = q.x(); p[4] = q.y(); p[5] = q.z(); p[6] = q.w();
 }
 

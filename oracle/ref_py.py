@@ -39,6 +39,46 @@ def build(force=False):
     return so
 
 
+_SOPHUS = None
+
+
+def sophus_pin():
+    """oracle/_ref/libsophus_pin.so: the reference's vendored Sophus (so3.hpp / se3.hpp) compiled unmodified (oracle/sophus_pin.cpp); poses = t(3), q xyzw."""
+    global _SOPHUS
+    if _SOPHUS is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libsophus_pin.so"))
+        for name, args in (("sophus_se3_exp", [c_d, c_d]), ("sophus_se3_log", [c_d, c_d]), ("sophus_se3_mul", [c_d, c_d, c_d]), ("sophus_se3_inverse", [c_d, c_d]),
+                           ("sophus_se3_adj", [c_d, c_d]), ("sophus_se3_matrix3x4", [c_d, c_d]), ("sophus_se3_transform", [c_d, c_d, c_d]),
+                           ("sophus_se3_from_quaternion", [c_d, c_d]), ("sophus_se3_from_matrix", [c_d, c_d, c_d]), ("sophus_so3_exp", [c_d, c_d, c_d])):
+            getattr(L, name).argtypes = args
+        L.sophus_se3_log.restype = C.c_int
+
+        class S:
+            @staticmethod
+            def _call(fn, n_out, *ins):
+                out = np.zeros(n_out)
+                fn(*[_d(np.ascontiguousarray(a, dtype=np.float64)) for a in ins], _d(out))
+                return out
+            exp = staticmethod(lambda a: S._call(L.sophus_se3_exp, 7, a))
+            mul = staticmethod(lambda a, b: S._call(L.sophus_se3_mul, 7, a, b))
+            inverse = staticmethod(lambda a: S._call(L.sophus_se3_inverse, 7, a))
+            adj = staticmethod(lambda a: S._call(L.sophus_se3_adj, 36, a).reshape(6, 6))
+            matrix3x4 = staticmethod(lambda a: S._call(L.sophus_se3_matrix3x4, 12, a).reshape(3, 4))
+            transform = staticmethod(lambda a, p: S._call(L.sophus_se3_transform, 3, a, p))
+            from_quaternion = staticmethod(lambda a: S._call(L.sophus_se3_from_quaternion, 7, a))
+            from_matrix = staticmethod(lambda Rm, t: S._call(L.sophus_se3_from_matrix, 7, Rm, t))
+
+            @staticmethod
+            def log(a):
+                out = np.zeros(6)
+                if L.sophus_se3_log(_d(np.ascontiguousarray(a, dtype=np.float64)), _d(out)) != 0:
+                    raise ValueError("SophusException")
+                return out
+        _SOPHUS = S
+    return _SOPHUS
+
+
 def _f(a):
     return a.ctypes.data_as(c_f)
 

@@ -500,3 +500,51 @@ def test_undistort_bitwise(O, tmp_path, bits, model):
     assert same(ref_img, orc_img) and ref_img.std() > 10
     ref_img, _ = U.undistort(raw, exposure=0.0, factor=0.25)          # exposure <= 0: no photometric calibration, data = factor * raw (:222-229)
     assert same(ref_img, O.undistort(raw, None, None, U.remapX, U.remapY, w, h, factor=0.25))
+
+
+def test_lie_algebra_against_the_vendored_sophus(oracle):
+    """oracle/lie.h — the SE3 / SO3 arithmetic behind every oracle AND behind the stand-in sophus/se3.hpp the reference's sources are compiled against — equals the reference's
+    vendored Sophus (thirdparty/Sophus/sophus/so3.hpp + se3.hpp, compiled unmodified into oracle/_ref/libsophus_pin.so) bit for bit: exp incl. the small-angle series branch,
+    log incl. its small-angle branch, products (normalisation after every product), inverse, Adj, the 3x4 matrix, point transforms, the normalising constructor."""
+    S = R.sophus_pin()
+    rng = np.random.RandomState(11)
+    tangents = [np.zeros(6)]
+    for scale in (1.0, 0.1, 1e-3, 1e-6, 3e-9, 1e-11, 1e-13, 0.0):       # 1e-10 = SophusConstants<double>::epsilon(): both branches of exp / log / V
+        for _ in range(40):
+            a = rng.standard_normal(6); a[3:] *= scale
+            tangents.append(a)
+    for k in range(40):                                                      # large rotations up to just below pi (log's atan branch near w = 0)
+        w = rng.standard_normal(3); w *= (np.pi * (1 - 10.0 ** -(k % 8 + 1))) / np.linalg.norm(w)
+        tangents.append(np.r_[rng.standard_normal(3), w])
+    # the tangent set of the reference's sophus/test_se3.cpp
+    for a in ([0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0], [0, 1, 0, 1, 0, 0], [0, -5, 10, 0, 0, 0], [-1, 1, 0, 0, 0, 1], [20, -1, 0, -1, 1, 0], [30, 5, -1, 20, -1, 0]):
+        tangents.append(np.array(a, dtype=np.float64))
+    poses = []
+    for a in tangents:
+        p_o, p_s = oracle.se3_exp(a), S.exp(a)
+        assert same(p_o, p_s), a
+        poses.append(p_s)
+    for p in poses:
+        assert same(oracle.se3_log(p), S.log(p))
+        assert same(oracle.se3_inv(p), S.inverse(p))
+        assert same(oracle.se3_adj(p), S.adj(p))
+        Rm, t = oracle.se3_matrix(p)
+        assert same(np.c_[Rm, t], S.matrix3x4(p))
+    # transformation of points: Sophus computes unit_quaternion()._transformVector(p) + translation, the oracle's trackers use the rotation matrix (as the
+    # reference's CoarseTracker does: rotationMatrix().cast<float>()); the pin here is of the product, whose translation is exactly such a transform
+    idx = rng.randint(0, len(poses), (400, 2))
+    for i, j in idx:
+        ab_o, ab_s = oracle.se3_mul(poses[i], poses[j]), S.mul(poses[i], poses[j])
+        assert same(ab_o, ab_s)
+        assert same(oracle.se3_log(ab_o), S.log(ab_s))
+    # chains (a trajectory: every product renormalises) stay identical
+    T_o, T_s = poses[1].copy(), poses[1].copy()
+    for i in rng.randint(0, len(poses), 300):
+        T_o, T_s = oracle.se3_mul(T_o, poses[i]), S.mul(T_s, poses[i])
+        T_o, T_s = oracle.se3_mul(oracle.se3_inv(poses[(i * 7) % len(poses)]), T_o), S.mul(S.inverse(poses[(i * 7) % len(poses)]), T_s)
+    assert same(T_o, T_s)
+    # a pose built from stored numbers that are not unit to rounding is normalised by the constructor, one that is unit keeps its bits through the oracle's import
+    q = np.r_[rng.standard_normal(3), rng.standard_normal(4)]
+    norm_s = S.from_quaternion(q)
+    assert same(oracle.se3_mul(q, np.r_[0, 0, 0, 0, 0, 0, 1.0])[:3], norm_s[:3])
+    assert np.allclose(oracle.se3_inv(oracle.se3_inv(q)), norm_s, rtol=0, atol=1e-15)
