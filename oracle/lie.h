@@ -1,7 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
-// UNPINNED third-party arithmetic: restated from the vendored Sophus; the compiled reference (oracle/_ref) reaches the same code
-// through oracle/ref_shim/sophus, so only the construction checks (power series, round trips, Sophus' own test tangents) vouch for it — DESIGN.md §2.
+// PINNED to the reference's vendored Sophus: thirdparty/Sophus/sophus/so3.hpp + se3.hpp compile unmodified (oracle/Makefile.ref -> oracle/_ref/libsophus_pin.so, and
+// as part of oracle/_ref/libref.so) and every function below equals them bit for bit (tests/test_ref_pin_cpu.py::test_lie_algebra_against_the_vendored_sophus).
+// Unpinned underneath: Eigen's quaternion leaf arithmetic (product, toRotationMatrix, _transformVector, the order in which norm() adds the four squares), which the
+// stand-in Eigen/src/QuaternionStandin.h and this file restate alike — DESIGN.md §2.
 //
 // Minimal double-precision SO3/SE3 restating the vendored Sophus v0.9a used by the
 // reference (thirdparty/Sophus/sophus/so3.hpp, se3.hpp).  Quaternion-backed like Sophus:
