@@ -658,9 +658,7 @@ static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
         // the kernel left (idle time-out) without serving this request: start it again (it takes the mailbox's current ticket as seen) and post the request again under
         // the next number
         if (++restarts > 8) return failmsg("evaluation server keeps leaving before it serves the request");
-        const unsigned int launchTicket = ticket;          // nothing new for the kernel about to start ...
-        if (int r = serverLaunch(t)) return r;             // ... (first_seen = eval_ticket = launchTicket)
-        (void)launchTicket;
+        if (int r = serverLaunch(t)) return r;             // first_seen = eval_ticket = the unanswered ticket: nothing new for the kernel about to start ...
         ticket = nextTicket();                             // ... and the request itself under a fresh number
         mailTicket(t, ticket);
       }

@@ -142,7 +142,9 @@ int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm)
  *   visual  <- addVisualToCoarseGraph(H, b, trackingGood), called when the finest level was reached (may be NULL)
  * update == NULL (or cb == NULL) runs dmvio_hip_coarse_update_visual: the reference's own visual-only step, which is also what it
  * executes while the IMU is not yet initialised.  One kernel launch per CALL (the evaluation server, k_eval_server): every evaluation is a request posted into host-coherent
- * memory and its sums are polled from there — no launch, no stream synchronisation per LM iteration; with the default update the results are those of dmvio_hip_tracker_track. */
+ * memory and its sums are polled from there — no launch, no stream synchronisation per LM iteration; with the default update the results are those of dmvio_hip_tracker_track.
+ * The callbacks run on the calling thread with the context locked and the server resident on the context's stream: they must not call entry points of the SAME context
+ * (dmvio_hip_coarse_update_visual and other contexts are fine).  A callback that takes longer than the server's 5 ms idle limit only costs a relaunch of the kernel. */
 typedef int (*dmvio_hip_coarse_update_fn)(void* user, const double H[64], const double b[8], float extrapFac, float lambda, const double pose7_cur[7],
                                           const double aff_cur[2], double pose7_new[7], double* incA, double* incB, double* incNorm);
 typedef void (*dmvio_hip_coarse_accept_fn)(void* user);
