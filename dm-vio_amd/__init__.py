@@ -63,6 +63,7 @@ def _sig(L):
     L.dmvio_hip_tracker_set_ref.argtypes = [vp, C.c_int, C.c_float, C.c_double, C.c_double, C.c_int, c_f, c_f, c_f, c_f]
     L.dmvio_hip_tracker_pc_n.argtypes = [vp, C.c_int]
     L.dmvio_hip_tracker_get_pc.argtypes = [vp, C.c_int, c_f, c_f, c_f, c_f]
+    L.dmvio_hip_tracker_get_idepth_map.argtypes = [vp, C.c_int, c_f, c_f]
     L.dmvio_hip_tracker_eval.argtypes = [vp, C.c_int, C.c_int, C.c_float, c_d, c_d, C.c_float, c_d, c_d, c_d]
     L.dmvio_hip_tracker_track.argtypes = [vp, C.c_int, C.c_float, c_d, c_d, C.c_int, c_d, c_d, c_d, c_d, c_d, c_i]
     L.dmvio_hip_tracker_track_batch.argtypes = [vp, C.c_int, c_i, c_f, c_d, c_d, C.c_int, c_d, c_d, c_d, c_d, c_d, c_i, c_i]
@@ -331,6 +332,13 @@ class CoarseTrackerHip:
         out = [np.zeros(n, dtype=np.float32) for _ in range(4)]
         _chk(self.L, self.L.dmvio_hip_tracker_get_pc(self.p, lvl, *[_f(a) for a in out]), "get_pc")
         return out
+
+    def get_idepth_map(self, lvl):
+        """CoarseTracker::idepth[lvl], weightSums[lvl] after makeCoarseDepthL0 (what debugPlotIDepthMap reads)."""
+        n = (self.ctx.w >> lvl) * (self.ctx.h >> lvl)
+        a = np.zeros(n, dtype=np.float32); b = np.zeros(n, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_tracker_get_idepth_map(self.p, lvl, _f(a), _f(b)), "get_idepth_map")
+        return a, b
 
     def eval(self, lvl, new_slot, pose7, aff, cutoffTH=20.0, new_exposure=1.0):
         """calcRes + calcGSSSE at refToNew=pose7 -> (res6, H[8,8], b[8])."""

@@ -574,6 +574,40 @@ int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* t, int lvl, float* u, float* v, 
   return 0;
 }
 
+// The dense maps CoarseTracker keeps next to the template: idepth[lvl] and weightSums[lvl] as makeCoarseDepthL0 leaves them (CoarseTracker.cpp:249-293; read by
+// debugPlotIDepthMap / debugPlotIDepthMapFloat, :772-880, when output wrappers exist).  Debug path: the dilated planes come back from the device and the normalisation loop is
+// replayed on the host; whether a pixel with weight became a template point (finite reference colour, idepth > 0) is taken from the template itself.
+int dmvio_hip_tracker_get_idepth_map(dmvio_hip_tracker* t, int lvl, float* idepth_out, float* weightSums_out) {
+  if (!t || lvl < 0 || lvl >= t->ctx->levels || !idepth_out) return failmsg("tracker_get_idepth_map: bad argument");
+  if (!t->haveRef) return failmsg("tracker_get_idepth_map: setCoarseTrackingRef not called");
+  dmvio_hip_ctx* c = t->ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  const RefLevels& R = t->R;
+  const int wl = R.w[lvl], hl = R.h[lvl], n = t->dev.pc_n[lvl];
+  const size_t npx = (size_t)wl * hl;
+  std::vector<float> ws(npx);
+  std::vector<float4> pc(n);
+  HIPCHK(hipMemcpyAsync(idepth_out, t->d_idp2 + R.off[lvl], sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ws.data(), t->d_wsp2 + R.off[lvl], sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+  if (n) HIPCHK(hipMemcpyAsync(pc.data(), t->d_pc[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<unsigned char> kept(npx, 0);
+  for (int i = 0; i < n; i++) kept[(size_t)pc[i].x + (size_t)pc[i].y * wl] = 1;
+  for (int y = 2; y < hl - 2; y++)
+    for (int x = 2; x < wl - 2; x++) {
+      const size_t i = (size_t)x + (size_t)y * wl;
+      if (ws[i] > 0) {
+        idepth_out[i] /= ws[i];
+        if (!kept[i]) { idepth_out[i] = -1; continue; }   // the reference's "just skip if something is wrong": weightSums keeps its value
+      } else
+        idepth_out[i] = -1;
+      ws[i] = 1;
+    }
+  if (weightSums_out) memcpy(weightSums_out, ws.data(), sizeof(float) * npx);
+  return 0;
+}
+
 // One fused calcRes + calcGSSSE evaluation, result in t->h_tot when the call returns: ONE launch, no stream synchronisation — the
 // last workgroup stores the sums and then the launch's ticket into host-coherent memory and the host spins on the ticket.
 // G workgroups of 256 threads split the template (point index first = rank * 256 + thread, stride G * 256) and the partial sums are

@@ -114,6 +114,9 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* trk, int ref_slot, float ref_ex
 /* pc_n[lvl] / pc_u,pc_v,pc_idepth,pc_color[lvl] (CoarseTracker.h:113-118) — parity / debugPlotIDepthMap */
 int dmvio_hip_tracker_pc_n(dmvio_hip_tracker* trk, int lvl);
 int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* trk, int lvl, float* u, float* v, float* idepth, float* color);
+/* CoarseTracker::idepth[lvl] / weightSums[lvl] (w_lvl * h_lvl floats each) as makeCoarseDepthL0 leaves them (CoarseTracker.cpp:249-293): what debugPlotIDepthMap /
+ * debugPlotIDepthMapFloat (:772-880) read when output wrappers exist.  Debug path (two plane downloads); weightSums_out may be NULL. */
+int dmvio_hip_tracker_get_idepth_map(dmvio_hip_tracker* trk, int lvl, float* idepth_out, float* weightSums_out);
 /* One fused CoarseTracker::calcRes + calcGSSSE evaluation (CoarseTracker.cpp:361-517, 299-356) at refToNew.
  * res6 = {E, numTermsInE, flowT, 0, flowRT, saturatedRatio}; H (8x8 row-major) and b are the SCALE_*-scaled
  * system handed to IMUIntegration::computeCoarseUpdate in VIO mode (CoarseTracker.cpp:612-637). */

@@ -94,6 +94,13 @@ class CoarseTracker {
     refSlot_ = refSlot; refFrameID = frameID; lastRef_aff_g2l = aff_g2l;
     return true;
   }
+  /* idepth[lvl] / weightSums[lvl] of the current template (w_lvl * h_lvl floats each): the arrays debugPlotIDepthMap / debugPlotIDepthMapFloat read (CoarseTracker.cpp:772-880) */
+  bool idepthMap(int lvl, std::vector<float>& idepth, std::vector<float>& weightSums) const {
+    if (!trk_ || lvl < 0 || lvl >= frames_.pyrLevelsUsed()) return false;
+    const size_t n = (size_t)(frames_.w() >> lvl) * (frames_.h() >> lvl);
+    idepth.resize(n); weightSums.resize(n);
+    return dmvio_hip_tracker_get_idepth_map(trk_, lvl, idepth.data(), weightSums.data()) == 0;
+  }
   /* Returns trackingGood; lastToNew_out / aff_g2l_out are written only when every level finished (CoarseTracker.cpp:731-760); a device or
    * argument error reads as "tracking failed" (the adapter sets isLost), lastError() tells why. */
   bool trackNewestCoarse(int newSlot, float new_ab_exposure, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, const double minResForAbort[5]) {

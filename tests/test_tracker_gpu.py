@@ -113,6 +113,9 @@ def test_set_ref_bit_exact(setup):
         o = T.get_pc(lvl)
         for a, b, name in zip(g, o, "u v idepth color".split()):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "pc_%s level %d" % (name, lvl)
+        # the dense maps next to the template (CoarseTracker::idepth / weightSums, what debugPlotIDepthMap reads): every pixel, borders and invalid ones included
+        for a, b, name in zip(trk.get_idepth_map(lvl), T.get_idepth(lvl), ("idepth", "weightSums")):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dense %s level %d" % (name, lvl)
 
 
 def test_set_ref_many_points_on_one_pixel_follow_the_reference_order(pkg, oracle, synth, gpu_required):
