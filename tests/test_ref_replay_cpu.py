@@ -46,7 +46,8 @@ def replay_windows(make_window, events, imgs, w, h):
         r = W.optimize(6)
         dpose = max(np.abs(W.frame_pose(k)[0] - b["frames"][k]["w2c"]).max() for k in range(a["F"]))
         daff = max(np.abs(W.frame_pose(k)[1] - np.array([b["frames"][k]["state"][6] * 10.0, b["frames"][k]["state"][7] * 1000.0])).max() for k in range(a["F"]))
-        out.append(dict(F=a["F"], N=a["N"], R=a["R"], rmse=r["rmse"], rmse_ref=b["rmse"], dpose=dpose, daff=daff, prior=float(np.abs(a["HM"]).max())))
+        out.append(dict(F=a["F"], N=a["N"], R=a["R"], rmse=r["rmse"], rmse_ref=b["rmse"], dpose=dpose, daff=daff, prior=float(np.abs(a["HM"]).max()),
+                        poses=np.array([W.frame_pose(k)[0] for k in range(a["F"])])))
     return out
 
 
@@ -78,12 +79,19 @@ def test_oracle_replays_a_fresh_reference_run(oracle, synth):
     assert len(tr) >= 40 and all(ok and dp < 1e-15 and da == 0.0 and dr == 0.0 for dp, da, dr, ok in tr)
     ws = replay_windows(oracle.BAWindow, run["events"], run["imgs"], w, h)
     assert max(x["F"] for x in ws) >= 7
-    for x in ws:
-        assert abs(x["rmse"] - x["rmse_ref"]) < 2e-5 * x["rmse_ref"] and x["dpose"] < 2e-6 and x["daff"] < 1e-4, x
-    # the same windows through the reference's own optimize, re-created from the recorded state the same way: same agreement
+    # the same windows through the reference's own optimize, re-created from the recorded state the same way
     wr = replay_windows(R.BAWindow, run["events"], run["imgs"], w, h)
-    for x in wr:
-        assert abs(x["rmse"] - x["rmse_ref"]) < 2e-5 * x["rmse_ref"] and x["dpose"] < 2e-6, x
+    # (1) oracle == the reference's own code on the SAME re-created window (no live state involved)
+    for xo, xr in zip(ws, wr):
+        assert abs(xo["rmse"] - xr["rmse"]) <= 1e-6 * xr["rmse"] and np.abs(xo["poses"] - xr["poses"]).max() < 1e-9, (xo, xr)
+    # (2) both against what the LIVE system produced.  The live run is multi-threaded (its sums change in the last bits from run to run) and the re-created window starts from
+    # recorded state; the 68x68 solve (condition ~1e10) amplifies an ulp to the sixth digit, and once in a few dozen runs an accept / reject decision of one window flips
+    # (seen: rmse apart by 4e-5 relative, affine by 0.015) — for the reference's own re-creation exactly as for the oracle.  So: every window close, all but at most one tight.
+    def tight(x):
+        return abs(x["rmse"] - x["rmse_ref"]) < 2e-5 * x["rmse_ref"] and x["dpose"] < 2e-6 and x["daff"] < 1e-4
+    for x in ws + wr:
+        assert abs(x["rmse"] - x["rmse_ref"]) < 1e-3 * x["rmse_ref"] and x["dpose"] < 1e-4, x
+    assert sum(not tight(x) for x in ws) <= 1 and [tight(x) for x in ws] == [tight(x) for x in wr]
 
 
 def test_reference_trajectory_follows_the_rendered_motion(synth):
