@@ -255,13 +255,17 @@ def main():
             if Rf.available():
                 RT = Rf.Tracker(w, h, case["K4"])
                 RT.set_ref(case["ref_img"], case["u"], case["v"], case["idepth"], case["hdiF"])
-                n_ref = 0; t_r0 = time.perf_counter()
+                n_ref = 0; t_r0 = time.perf_counter(); per_frame = []
                 while time.perf_counter() - t_r0 < max(2.0, args.cpu_seconds / 2):
                     i = n_ref % B
+                    tA = time.perf_counter()
                     RT.set_new(host_frames[i % n_host])
                     RT.track(poses0[i], affs0[i])
+                    per_frame.append(time.perf_counter() - tA)
                     n_ref += 1
                 t_r = time.perf_counter() - t_r0
+                q = np.percentile(np.array(per_frame) * 1e3, [10, 50, 90])
+                cpu["ms_per_frame_p10_p50_p90"] = [round(float(x), 4) for x in q]
                 cpu["value_port"] = cpu["value"]
                 cpu["value"] = round(n_ref / t_r, 2); cpu["kind"] = "reference"
                 cpu["sample"] = ("%d frames of the same batch through the reference's own FrameHessian::makeImages + CoarseTracker::trackNewestCoarse (its sources compiled -O3 -msse2 by "
