@@ -1,0 +1,39 @@
+"""The driver's contract with bench.py: ONE JSON line on stdout, BASELINE.json's metric on the named workload, whole-job value consistent with its own step time, a
+roofline object whose fraction follows from its own numbers and a cpu_baseline object timed on this box (reduced sizes here; the default run is the judged one)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract(gpu_required):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "256", "--no-sweep", "--no-traffic",
+           "--cpu-seconds", "2", "--ba-iters", "50"]
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["frames_per_step_per_gpu"] == 256
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]                 # whole-job frames/s == frames per step / step time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_track_lm"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 64 * r["point_evals_per_launch"]                 # 64 B per template-point evaluation
+    assert r["kernel_ms"] < d["ms_per_step"] and r["traffic"] is None                           # --no-traffic: not measured, not invented
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "frames/s" and c["value"] > 0 and "frames" in c["sample"]
+    assert d["value"] > 20 * c["value"]
+    assert d["ba"]["value"] > 0 and d["ba"]["unit"] == "GN-iters/s" and d["ba"]["cpu_baseline"]["value"] > 0
+    assert d["pcie"]["good"] and d["pcie"]["raw_u8"]["good"] and d["pcie"]["raw_u8"]["value"] > d["pcie"]["value"]
+    assert d["max_pose_err_m"] < 5e-3
