@@ -302,7 +302,8 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
 int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistorter* u, int B, const int* slots, const void* raw_dev_base, size_t stride_bytes, float factor) {
   if (!c || !u || !slots || !raw_dev_base || u->ctx != c) return failmsg("frames_from_raw_device_batch: bad argument");
   const size_t nOrg = (size_t)u->U.wOrg * u->U.hOrg;
-  if (B <= 0 || stride_bytes % u->bytes_per_px || stride_bytes < nOrg * u->bytes_per_px) return failmsg("frames_from_raw_device_batch: bad B / stride");
+  if (B <= 0 || stride_bytes % u->bytes_per_px || stride_bytes < nOrg * u->bytes_per_px || (uintptr_t)raw_dev_base % u->bytes_per_px)
+    return failmsg("frames_from_raw_device_batch: bad B / stride / alignment");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   if (int r = stageSlots(c, B, slots)) return r;
