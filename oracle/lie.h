@@ -28,17 +28,31 @@ struct SE3 {
   double t[3]{0, 0, 0};
 };
 
+// ORC_ALT_EIGEN_LEAF (oracle/_build/liboracle_altleaf.so only; tests/test_leaf_sensitivity_cpu.py): the two quaternion leaf operations with the sums associated the
+// way a packet (SSE2) implementation pairs them — products (ww*x + yy*z) -/+ (zz*y - xx*w) per lane pair, the norm as (x2 + z2) + (y2 + w2).  Eigen's own order is
+// unpinned (no Eigen on this image); the variant exists to MEASURE how far a different leaf rounding can move tracking / BA results.
 inline Quat qmul(const Quat& a, const Quat& b) {
-  // Eigen quat_product: a*b
   Quat r;
+#ifdef ORC_ALT_EIGEN_LEAF
+  r.x = (a.w * b.x + a.y * b.z) - (a.z * b.y - a.x * b.w);
+  r.y = (a.w * b.y + a.y * b.w) + (a.z * b.x - a.x * b.z);
+  r.z = (a.w * b.z - a.y * b.x) + (a.z * b.w + a.x * b.y);
+  r.w = (a.w * b.w - a.y * b.y) - (a.z * b.z + a.x * b.x);
+#else
+  // Eigen quat_product (generic path): a*b
   r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
   r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
   r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
   r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+#endif
   return r;
 }
 inline Quat qnormalize(const Quat& a) {
+#ifdef ORC_ALT_EIGEN_LEAF
+  double n = std::sqrt((a.x * a.x + a.z * a.z) + (a.y * a.y + a.w * a.w));
+#else
   double n = std::sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+#endif
   return Quat{a.w / n, a.x / n, a.y / n, a.z / n};
 }
 inline Quat qconj(const Quat& a) { return Quat{a.w, -a.x, -a.y, -a.z}; }

@@ -16,7 +16,9 @@ c_d = C.POINTER(C.c_double)
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "_build", "liboracle.so")
+    # DMVIO_ORACLE_VARIANT=altleaf: the build with the quaternion leaf sums associated differently (tests/test_leaf_sensitivity_cpu.py runs it in a child process)
+    variant = os.environ.get("DMVIO_ORACLE_VARIANT", "")
+    so = os.path.join(_HERE, "_build", "liboracle_%s.so" % variant if variant else "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h")) or f == "Makefile"]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
