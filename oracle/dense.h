@@ -15,6 +15,28 @@
 namespace orc {
 
 // Solve A x = rhs with Eigen-style pivoted LDLT.  A is n x n row-major symmetric (only lower read).
+#ifdef ORC_ALT_EIGEN_LEAF
+// oracle/_build/liboracle_altleaf.so only (tests/test_leaf_sensitivity_cpu.py): a DIFFERENT factorisation of the same systems — LDL^T without pivoting, the inner products
+// accumulated from the far end — to measure how far the solver's internal rounding can move tracking / BA results.  The systems are symmetric positive definite (damped).
+inline void ldltSolve(const double* Ain, const double* rhs, double* x, int n) {
+  std::vector<double> L(Ain, Ain + n * n), d(n), y(rhs, rhs + n);
+  auto M = [&](int r, int c) -> double& { return L[r * n + c]; };
+  for (int j = 0; j < n; j++) {
+    double s = 0;
+    for (int k = j - 1; k >= 0; k--) s += M(j, k) * M(j, k) * d[k];
+    d[j] = M(j, j) - s;
+    for (int i = j + 1; i < n; i++) {
+      double t = 0;
+      for (int k = j - 1; k >= 0; k--) t += M(i, k) * M(j, k) * d[k];
+      M(i, j) = d[j] != 0 ? (M(i, j) - t) / d[j] : 0.0;
+    }
+  }
+  for (int i = 0; i < n; i++) { double s = y[i]; for (int k = i - 1; k >= 0; k--) s -= M(i, k) * y[k]; y[i] = s; }
+  for (int i = 0; i < n; i++) y[i] = d[i] != 0 ? y[i] / d[i] : 0.0;
+  for (int i = n - 1; i >= 0; i--) { double s = y[i]; for (int k = n - 1; k > i; k--) s -= M(k, i) * y[k]; y[i] = s; }
+  for (int i = 0; i < n; i++) x[i] = y[i];
+}
+#else
 inline void ldltSolve(const double* Ain, const double* rhs, double* x, int n) {
   std::vector<double> m(Ain, Ain + n * n);
   std::vector<int> tr(n);
@@ -77,5 +99,6 @@ inline void ldltSolve(const double* Ain, const double* rhs, double* x, int n) {
   for (int k = n - 1; k >= 0; k--) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
   for (int i = 0; i < n; i++) x[i] = d[i];
 }
+#endif
 
 }  // namespace orc

@@ -39,7 +39,15 @@ def main(out):
     # a 14-frame sequence: tracking + tracing + activation + BA + marginalisation chained
     K4, imgs, id0, c2w_true = vh.make_sequence(synth, 256, 192, 14)
     vo = vh.run(vh.OracleBackend(O, 256, 192, K4), synth, K4, imgs, id0, 256, 192, kf_every=3, max_kf=3, n_new=250)
-    res["traj"] = np.array([np.asarray(p) for p in vo.traj])
+    res["traj"] = np.array([np.asarray(vo.traj[k]) for k in sorted(vo.traj)])
+    # the windows the reference's own FullSystem optimised in the recorded live run (2 ... 8 keyframes, marginalisation priors ~1e8..1e10: the worst-conditioned solves at hand)
+    import replay
+    import test_ref_replay_cpu as rr
+    g = replay.load_golden(rr.GOLDEN)
+    _, gi, _ = replay.make_sequence(synth, g["w"], g["h"], g["n_frames"], g["step"])
+    ws = rr.replay_windows(O.BAWindow, g["events"], gi, g["w"], g["h"])
+    res["recorded_rmse"] = np.array([x["rmse"] for x in ws])
+    res["recorded_poses"] = np.concatenate([x["poses"].ravel() for x in ws])
     np.savez(out, **res)
 
 

@@ -1,7 +1,8 @@
-"""How much can the one UNPINNED piece of arithmetic under the oracle move a result?  Eigen is not on this image, so the order in which its quaternion product and norm
-add their terms (version- and instruction-set dependent) is restated, not pinned.  oracle/_build/liboracle_altleaf.so is the same oracle with those leaf sums
-associated the way a two-lane packet implementation pairs them; every pose product, inverse, exp and normalisation in tracking, BA and the VO chain then rounds differently.
-The results must agree far inside the north-star tolerances (1e-3 m, 1e-4 relative energy): measured here ~1e-13."""
+"""How much can the UNPINNED arithmetic under the oracle move a result?  Eigen is not on this image, so (a) the order in which its quaternion product and norm add their
+terms (version- and instruction-set dependent) and (b) the internals of its LDL^T are restated, not pinned.  oracle/_build/liboracle_altleaf.so is the same oracle
+with (a) the leaf sums associated the way a two-lane packet implementation pairs them and (b) a different factorisation (no pivoting, inner products accumulated from the far
+end) behind every 6x6 ... 68x68 solve; every pose product, inverse, exp, normalisation and LM / GN step in tracking, BA and the VO chain then rounds differently.
+The results must agree far inside the north-star tolerances (1e-3 m, 1e-4 relative energy): measured here <= 3e-14."""
 import os
 import subprocess
 import sys
@@ -33,9 +34,11 @@ def test_results_do_not_depend_on_the_quaternion_leaf_order(oracle, tmp_path):
         assert np.array_equal(m, np.isfinite(y)), k
         worst[k] = float(np.abs(x[m] - y[m]).max() / max(1.0, np.abs(x[m]).max()))
     print("max deviation default vs alternative leaf order:", {k: "%.1e" % v for k, v in worst.items()})
-    # ... and nothing downstream moves beyond the rounding of a handful of ulps amplified by the solves (condition ~1e10 in the BA)
+    # ... and nothing downstream moves beyond a handful of ulps
     assert worst["hypotheses"] < 1e-14
     for k in ("track0_pose", "track1_pose", "track0_res", "track1_res", "track0_aff", "track1_aff"):
         assert worst[k] < 1e-10, (k, worst[k])
     assert a["ba_iterations"][0] == b["ba_iterations"][0] and worst["ba_energy"] < 1e-8 and worst["ba_poses"] < 1e-8
     assert worst["traj"] < 1e-6      # 14 frames, 3 keyframes, marginalisation: still three orders below the 1e-3 m bar
+    # the windows of the recorded live run (2 ... 8 keyframes, marginalisation priors up to ~1e10) — the Jacobi-scaled 68x68 systems are solved stably by either factorisation
+    assert worst["recorded_rmse"] < 1e-8 and worst["recorded_poses"] < 1e-8
