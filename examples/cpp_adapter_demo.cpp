@@ -1,5 +1,6 @@
 // The same frame as c_abi_demo.c through the C++ mirror of the reference's member surface (include/dmvio_hip.hpp): code that reads like
-// the tracking thread of FullSystem — makeImages, makeK, setCoarseTrackingRef, trackNewestCoarse — with the wall and the motion known.
+// the tracking thread of FullSystem — makeImages, makeK, setCoarseTrackingRef, trackNewestCoarse (visual-only and with the IMU hooks of the reference's default
+// branch) — with the wall and the motion known.
 //
 //   g++ -std=c++11 -O2 examples/cpp_adapter_demo.cpp -Iinclude -Ldm-vio_amd/lib -ldmvio_hip -o cpp_adapter_demo
 #include <cmath>
@@ -90,5 +91,31 @@ int main() {
   dmvio_hip::SE3 T; dmvio_hip::AffLight a;
   if (coarseTracker.trackNewestCoarse(7, 1.0f, T, a, frames.pyrLevelsUsed() - 1, achievedRes)) { std::fprintf(stderr, "bad slot accepted\n"); return 4; }
   std::printf("ok: translation error %.2e m; bad slot -> false (%s)\n", err, dmvio_hip::lastError().c_str());
+
+  // The reference's DEFAULT branch (setting_useIMU, CoarseTracker.cpp:612-637): every LM step comes from the host — here a stand-in for dmvio::IMUIntegration that
+  // computes the visual-only step (what the reference runs until the IMU is initialised) and counts what the tracker calls on it.
+  struct FakeIMUIntegration { int updates = 0, accepts = 0, visuals = 0; bool lastGood = false; } imu;
+  dmvio_hip::CoarseTracker::CoarseIMUHooks hooks;
+  hooks.computeCoarseUpdate = [&imu](const double* H, const double* b, float extrapFac, float lambda, const dmvio_hip::SE3& refToNew_current, double& incA, double& incB,
+                                     double& incNorm) {
+    double cur[7], nxt[7];
+    refToNew_current.toPose7(cur);
+    dmvio_hip_coarse_update_visual(nullptr, H, b, extrapFac, lambda, cur, nxt, &incA, &incB, &incNorm);
+    imu.updates++;
+    dmvio_hip::SE3 r; r.fromPose7(nxt);
+    return r;
+  };
+  hooks.acceptCoarseUpdate = [&imu]() { imu.accepts++; };
+  hooks.addVisualToCoarseGraph = [&imu](const double*, const double*, bool trackingGood) { imu.visuals++; imu.lastGood = trackingGood; };
+  dmvio_hip::SE3 T_vio; dmvio_hip::AffLight aff_vio;
+  const bool goodVio = coarseTracker.trackNewestCoarse(1, 1.0f, T_vio, aff_vio, frames.pyrLevelsUsed() - 1, achievedRes, hooks);
+  double dT = 0;
+  for (int i = 0; i < 3; i++) dT = std::fmax(dT, std::fabs(T_vio.t[i] - lastF_2_fh.t[i]));
+  std::printf("hand-off: good %d, %d computeCoarseUpdate, %d acceptCoarseUpdate, %d addVisualToCoarseGraph, %d evaluations, max |dt| vs the visual-only call %.1e\n", (int)goodVio,
+              imu.updates, imu.accepts, imu.visuals, coarseTracker.lastEvaluations, dT);
+  if (!goodVio || imu.updates < 4 || imu.accepts < 1 || imu.accepts > imu.updates || imu.visuals != 1 || !imu.lastGood || dT > 1e-12) {
+    std::fprintf(stderr, "hand-off path disagrees with the visual-only path\n");
+    return 6;
+  }
   return mappingDemo();
 }
