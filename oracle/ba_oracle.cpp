@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path: only tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg may load this library.  PARITY PINNED against the reference's own compiled sources (oracle/_ref/libref.so, oracle/Makefile.ref): precalc, adjoints,
 // linearize, thresholds, accumulation, solve, optimize bit for bit (tests/test_ref_pin_cpu.py), 7 recorded windows of a live run (tests/test_ref_replay_cpu.py);
-// unpinned only for Eigen's ldlt / SVD and Sophus' exp.  Construction checks: tests/test_oracle_ba_cpu.py.
+// unpinned only for Eigen's ldlt / SVD / inverse (Sophus is pinned through lie.h).  Construction checks: tests/test_oracle_ba_cpu.py.
 //
 // Restates the MAPPING half of the hot path of lukasvst/dm-vio (sliding-window photometric bundle adjustment):
 //   OWindow::setPrecalcValues   <- FullSystem::setPrecalcValues        src/dso/FullSystem/FullSystem.cpp:1670-1680

@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE (oracle/).  The reference's VENDORED Sophus (thirdparty/Sophus/sophus/so3.hpp + se3.hpp, v0.9a), compiled unmodified from where it lies
-// under /root/reference against the stand-in Eigen of oracle/ref_shim + oracle/sophus_pin/Eigen/Geometry, exported as plain C so that tests/test_ref_pin_cpu.py can
-// hold oracle/lie.h (the restatement every oracle and the compiled reference use) against Sophus' own code.  Built by oracle/Makefile.ref into
+// under /root/reference (through oracle/ref_shim/sophus/se3.hpp) against the stand-in Eigen of oracle/ref_shim (Core + src/QuaternionStandin.h), exported as plain C so that
+// tests/test_ref_pin_cpu.py can hold oracle/lie.h (the restatement every oracle uses) against Sophus' own code.  Built by oracle/Makefile.ref into
 // oracle/_ref/libsophus_pin.so (git-ignored, travels with gpurun).  Poses cross the boundary as 7 doubles: translation(3), quaternion x, y, z, w.
 #include <sophus/se3.hpp>
 #include <cstring>
