@@ -1029,6 +1029,26 @@ struct OWindow {
     const int n = (int)x.size(), m = (int)ns.size();
     std::vector<Mat> U(m);
     for (int i = 0; i < m; i++) { double nn = 0; for (double v : ns[i]) nn += v * v; nn = std::sqrt(nn); U[i] = ns[i]; for (auto& v : U[i]) v /= nn; }
+#ifdef ORC_ALT_EIGEN_LEAF
+    // liboracle_altleaf.so only (tests/test_leaf_sensitivity_cpu.py): the same projector x -= N (N^T N)^+ N^T x built WITHOUT an SVD — modified Gram-Schmidt over the
+    // normalised nullspace vectors (a vector whose remainder falls below solverModeDelta is dropped) — to measure how far the SVD's internals can move a result
+    {
+      std::vector<Mat> Q;
+      for (int i = 0; i < m; i++) {
+        Mat v = U[i];
+        for (int pass = 0; pass < 2; pass++)
+          for (const Mat& q : Q) { double d = 0; for (int k = n - 1; k >= 0; k--) d += q[k] * v[k]; for (int k = 0; k < n; k++) v[k] -= d * q[k]; }
+        double nn = 0; for (int k = n - 1; k >= 0; k--) nn += v[k] * v[k]; nn = std::sqrt(nn);
+        if (!(nn > S.solverModeDelta)) continue;
+        for (auto& e : v) e /= nn;
+        Q.push_back(v);
+      }
+      Mat proj(n, 0.0);
+      for (const Mat& q : Q) { double d = 0; for (int k = n - 1; k >= 0; k--) d += q[k] * x[k]; for (int k = 0; k < n; k++) proj[k] += d * q[k]; }
+      for (int k = 0; k < n; k++) x[k] -= proj[k];
+      return;
+    }
+#endif
     // Hestenes: orthogonalise the columns by plane rotations; column norms converge to the singular values
     for (int sweep = 0; sweep < 60; sweep++) {
       double off = 0;

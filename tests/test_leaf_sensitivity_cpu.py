@@ -1,7 +1,7 @@
 """How much can the UNPINNED arithmetic under the oracle move a result?  Eigen is not on this image, so (a) the order in which its quaternion product and norm add their
-terms (version- and instruction-set dependent) and (b) the internals of its LDL^T are restated, not pinned.  oracle/_build/liboracle_altleaf.so is the same oracle
-with (a) the leaf sums associated the way a two-lane packet implementation pairs them and (b) a different factorisation (no pivoting, inner products accumulated from the far
-end) behind every 6x6 ... 68x68 solve; every pose product, inverse, exp, normalisation and LM / GN step in tracking, BA and the VO chain then rounds differently.
+terms (version- and instruction-set dependent), (b) the internals of its LDL^T and (c) of its JacobiSVD are restated, not pinned.  oracle/_build/liboracle_altleaf.so is the same oracle
+with (a) the leaf sums associated the way a two-lane packet implementation pairs them, (b) a different factorisation (no pivoting, inner products accumulated from the far
+end) behind every 6x6 ... 68x68 solve and (c) the gauge projector of EnergyFunctional::orthogonalize built by Gram-Schmidt instead of an SVD; every pose product, inverse, exp, normalisation and LM / GN step in tracking, BA and the VO chain then rounds differently.
 The results must agree far inside the north-star tolerances (1e-3 m, 1e-4 relative energy): measured here <= 3e-14."""
 import os
 import subprocess
