@@ -60,7 +60,8 @@ def test_oracle_replays_the_committed_reference_run(oracle, synth):
     for dp, da, dr, ok in tr:
         assert ok and dp < 1e-15 and da == 0.0 and dr == 0.0      # the recorded pose went through one SE3 inversion: last-bit differences only
     ws = replay_windows(oracle.BAWindow, g["events"], imgs, w, h)
-    assert [x["F"] for x in ws] == [2, 3, 4, 5, 6, 7, 8] and ws[-1]["prior"] > 1e8
+    fs = [x["F"] for x in ws]      # the live run is multi-threaded: a regenerated recording holds 7 or 8 optimisations (one more full window)
+    assert fs[:7] == [2, 3, 4, 5, 6, 7, 8] and all(f == 8 for f in fs[7:]) and ws[-1]["prior"] > 1e8
     for x in ws:
         # the windows are re-created from recorded state; an ulp somewhere in that state is amplified by the 68x68 solve (condition ~1e10)
         assert abs(x["rmse"] - x["rmse_ref"]) < 2e-5 * x["rmse_ref"] and x["dpose"] < 2e-6 and x["daff"] < 1e-4, x

@@ -75,5 +75,6 @@ def test_hip_replays_every_recorded_optimize(pkg, golden, gpu_required):
         assert abs(r["rmse"] - b["rmse"]) < 1e-4 * b["rmse"] and dpose < 1e-3 and daff < 1e-2, seen[-1]
         ba.close()
     print("\n".join("F=%d R=%d rmse %.6f (reference %.6f) dpose %.2e daff %.2e" % s for s in seen))
-    assert [s[0] for s in seen] == [2, 3, 4, 5, 6, 7, 8]
+    fs = [s[0] for s in seen]
+    assert fs[:7] == [2, 3, 4, 5, 6, 7, 8] and all(f == 8 for f in fs[7:])
     ctx.close()
