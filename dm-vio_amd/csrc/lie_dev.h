@@ -17,8 +17,14 @@ namespace dmv {
 // control step shares its kernel with the evaluation loop, that footprint would halve the occupancy of every wave.
 // These are the classic fdlibm kernels (Sun Microsystems' freely distributable libm: k_sin.c, k_cos.c, e_exp.c) with a
 // Cody-Waite reduction — ~1 ulp for the |x| < 1e5 arguments that occur here (rotation increments, affine exponents).
-// The same code runs on the host side of the C ABI, so host-driven and device-resident paths agree bit for bit.
+// DEVICE code only.  The host side of the C ABI (motion hypotheses, the BA's frame states and precalc tables, the host-driven LM of single frames and of the VIO hand-off)
+// calls the C library's sin / cos / exp like the reference's Sophus and AffLight do: its pose algebra equals the reference's bit for bit
+// (tests/test_ref_pin_cpu.py::test_track_new_coarse_hypothesis_list_bitwise); the device-resident LM can differ from it by an ulp of a pose coefficient per exp.
 DMV_HD void dsincos(const double x, double* sn, double* cs) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  ::sincos(x, sn, cs);   // one call, as g++ compiles Sophus' sin(h) / cos(h) pairs: glibc's sincos and its separate sin / cos differ in the last bit for ~0.1 % of arguments near 1 rad
+  return;
+#else
   const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
   const double n = rint(x * invpio2);
   double r = x - n * pio2_1;
@@ -34,8 +40,12 @@ DMV_HD void dsincos(const double x, double* sn, double* cs) {
   const double s0 = (q & 1) ? kc : ks, c0 = (q & 1) ? ks : kc;
   *sn = (q & 2) ? -s0 : s0;
   *cs = ((q + 1) & 2) ? -c0 : c0;
+#endif
 }
 DMV_HD double dexp(const double x) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return exp(x);
+#else
   if (!(x < 709.0)) return x != x ? x : __builtin_huge_val();
   if (x < -745.0) return 0.0;
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
@@ -48,6 +58,7 @@ DMV_HD double dexp(const double x) {
   const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
   const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   return ldexp(y, (int)k);
+#endif
 }
 
 struct Quatd { double w, x, y, z; };
@@ -111,8 +122,9 @@ DMV_HD Pose poseExp(const double a[6]) {
   } else {
     double sth, cth;
     dsincos(theta, &sth, &cth);
-    const double c1 = (1.0 - cth) / theta_sq;
-    const double c2 = (theta - sth) / (theta_sq * theta);
+    const double tsq = theta * theta;   // se3.hpp:417 squares the theta that so3's expAndTheta returned (sqrt of the sum of squares): not the sum itself in the last bit
+    const double c1 = (1.0 - cth) / tsq;
+    const double c2 = (theta - sth) / (tsq * theta);
     const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
     double O2[9];
     for (int i = 0; i < 3; i++)

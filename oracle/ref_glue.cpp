@@ -139,6 +139,16 @@ void deleteFrame(FrameHessian* fh)
 }
 }  // namespace
 
+// the real CoarseTracker::trackNewestCoarse for oracle/ref_trackhook.cpp (this file sees the member under its own name)
+namespace dso
+{
+bool ref_real_trackNewestCoarse(CoarseTracker* ct, FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort,
+                                IOWrap::Output3DWrapper* wrap)
+{
+	return ct->trackNewestCoarse(newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
+}
+}
+
 extern "C" {
 
 int ref_version() { return 2; }

@@ -39,6 +39,21 @@ def build(force=False):
     return so
 
 
+def enumerate_tries(on):
+    """ENUMERATE mode of the trackNewestCoarse hook (oracle/ref_trackhook.cpp): every try of FullSystem::trackNewCoarse records its initial guess and fails."""
+    L = lib()
+    L.ref_enumerate_tries.argtypes = [C.c_int]
+    L.ref_enumerate_tries(1 if on else 0)
+
+
+def enumerated_tries(max_tries=64):
+    L = lib()
+    L.ref_enumerated_tries.argtypes = [c_d, C.c_int]
+    out = np.zeros((max_tries, 7))
+    n = L.ref_enumerated_tries(_d(out), max_tries)
+    return out[:min(n, max_tries)].copy()
+
+
 _SOPHUS = None
 
 

@@ -548,3 +548,36 @@ def test_lie_algebra_against_the_vendored_sophus(oracle):
     norm_s = S.from_quaternion(q)
     assert same(oracle.se3_mul(q, np.r_[0, 0, 0, 0, 0, 0, 1.0])[:3], norm_s[:3])
     assert np.allclose(oracle.se3_inv(oracle.se3_inv(q)), norm_s, rtol=0, atol=1e-15)
+
+
+def test_track_new_coarse_hypothesis_list_bitwise(oracle, synth, pkg):
+    """The motion hypotheses of FullSystem::trackNewCoarse (lastF_2_fh_tries, FullSystem.cpp:364-402) as the reference's own loop hands them to trackNewestCoarse, one try
+    after the other: FullSystem.cpp is compiled so that its calls go through oracle/ref_trackhook.cpp, which in ENUMERATE mode records each initial guess and reports failure,
+    so the unmodified loop walks its whole list.  The oracle's make_track_hypotheses (and, in tests/test_tracker_gpu.py, the HIP library's) must give the same 31 poses in
+    the same order, bit for bit, from the same three camera poses."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import replay
+    w, h = 256, 192
+    K4, imgs, _ = replay.make_sequence(synth, w, h, 40, 1.6)
+    S = R.System(w, h, K4, point_density=600, max_frames=7)
+    checked = 0
+    for k, img in enumerate(imgs):
+        probe = k == 25                           # well after initialisation: three frames in the history, a reference keyframe set
+        if probe:
+            R.enumerate_tries(True)
+        S.add_frame(img)
+        if not probe:
+            continue
+        tries = R.enumerated_tries()
+        R.enumerate_tries(False)
+        ti = [e for e in S.events() if e["kind"] == "track_in"][-1]
+        assert ti["frame_id"] == k and ti["n_history"] > 2 and ti["poses_valid"]
+        mine = np.asarray(oracle.make_track_hypotheses(ti["slast_c2w"], ti["sprelast_c2w"], ti["lastF_c2w"]))
+        assert len(tries) == 31 and mine.shape == (31, 7)
+        assert same(mine, tries), np.abs(mine - tries).max()
+        # the product's own list (dmvio_hip_make_track_hypotheses: host pose algebra of csrc/lie_dev.h, no device involved) against the reference directly
+        hip = np.asarray(pkg.make_track_hypotheses(ti["slast_c2w"], ti["sprelast_c2w"], ti["lastF_c2w"]))
+        assert same(hip, tries), [(i, np.abs(hip[i] - tries[i]).tolist()) for i in range(31) if not same(hip[i], tries[i])]
+        checked += 1
+        break                                      # the enumerated frame was "lost" on purpose: the run ends here
+    assert checked == 1
