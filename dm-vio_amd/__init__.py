@@ -210,6 +210,19 @@ def make_track_hypotheses(slast_c2w, sprelast_c2w, lastF_c2w):
     return out[:n]
 
 
+def coarse_update_visual(H, b, extrapFac, lam, pose7_cur, settings=None):
+    """dmvio_hip_coarse_update_visual — the host implementation of the visual-only LM step (CoarseTracker.cpp:639-682), no handle needed -> (pose7_new, incA, incB, incNorm).
+    settings = (huberTH, coarseCutoffTH, affineOptModeA, affineOptModeB) or None for the reference's defaults."""
+    L = load_library()
+    fn = L.dmvio_hip_coarse_update_visual
+    fn.argtypes = [c_f, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_d, c_d, c_d]; fn.restype = C.c_int
+    st = None if settings is None else _f(np.ascontiguousarray(settings, dtype=np.float32))
+    pn = np.zeros(7); ia = np.zeros(1); ib = np.zeros(1); nn = np.zeros(1)
+    _chk(L, fn(st, _d(np.ascontiguousarray(H, dtype=np.float64).reshape(-1)), _d(np.ascontiguousarray(b, dtype=np.float64)), extrapFac, lam,
+               _d(np.ascontiguousarray(pose7_cur, dtype=np.float64)), _d(pn), _d(ia), _d(ib), _d(nn)), "coarse_update_visual")
+    return pn, float(ia[0]), float(ib[0]), float(nn[0])
+
+
 class Context:
     """dmvio_hip_ctx: device, stream and the resident image pyramids (frame slots)."""
 

@@ -103,6 +103,16 @@ def make_images(color, w, h, B=None):
     return dI, ab
 
 
+def coarse_update_visual(H, b, extrapFac, lam, pose7_cur, affineOptModeA=1e12, affineOptModeB=1e8):
+    """The visual-only LM step of trackNewestCoarse (CoarseTracker.cpp:639-682) as OrcTracker::track runs it every iteration -> (pose7_new, incA, incB, incNorm)."""
+    L = lib()
+    L.orc_coarse_update_visual.argtypes = [C.c_float, C.c_float, c_d, c_d, C.c_float, C.c_float, c_d, c_d, c_d, c_d, c_d]
+    out = np.zeros(7); ia = np.zeros(1); ib = np.zeros(1); nn = np.zeros(1)
+    L.orc_coarse_update_visual(affineOptModeA, affineOptModeB, _d(np.ascontiguousarray(H, dtype=np.float64)), _d(np.ascontiguousarray(b, dtype=np.float64)), extrapFac, lam,
+                               _d(np.ascontiguousarray(pose7_cur, dtype=np.float64)), _d(out), _d(ia), _d(ib), _d(nn))
+    return out, float(ia[0]), float(ib[0]), float(nn[0])
+
+
 def se3_exp(xi):
     out = np.zeros(7); lib().orc_se3_exp(_d(np.ascontiguousarray(xi, dtype=np.float64)), _d(out)); return out
 

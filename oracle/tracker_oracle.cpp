@@ -56,6 +56,52 @@ static inline V3f interp33(const V3f* mat, float x, float y, int width) {
 }
 
 // Accumulator9: 45 upper-triangular sums x 4 SSE lanes, hierarchical 1k/1M shift-up.
+// The visual-only LM step of trackNewestCoarse (CoarseTracker.cpp:639-682): damped system, 8 / 7 / 6-dof LDL^T by affineOptModeA / B, extrapolation, scaling, SE3::exp * current.
+// inc = the extrapolated increment before the SCALE_* factors, incScaled = after them (zeroed when not finite).  OrcTracker::track calls it every iteration.
+static bool coarseUpdateVisual(float affineOptModeA, float affineOptModeB, const double H[64], const double b[8], float extrapFac, float lambda, const SE3& refToNew_current,
+                               SE3& refToNew_new, double inc[8], double incScaled[8], double& incNorm) {
+  double Hl[64]; memcpy(Hl, H, sizeof(Hl));
+  for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda);
+  double nb[8]; for (int i = 0; i < 8; i++) nb[i] = -b[i];
+  ldltSolve(Hl, nb, inc, 8);
+  if (affineOptModeA < 0 && affineOptModeB < 0) {  // fix a, b
+    double H6[36], x6[6];
+    for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) H6[r * 6 + c] = Hl[r * 8 + c];
+    ldltSolve(H6, nb, x6, 6);
+    for (int i = 0; i < 6; i++) inc[i] = x6[i];
+    inc[6] = inc[7] = 0;
+  }
+  if (!(affineOptModeA < 0) && affineOptModeB < 0) {  // fix b
+    double H7[49], x7[7];
+    for (int r = 0; r < 7; r++) for (int c = 0; c < 7; c++) H7[r * 7 + c] = Hl[r * 8 + c];
+    ldltSolve(H7, nb, x7, 7);
+    for (int i = 0; i < 7; i++) inc[i] = x7[i];
+    inc[7] = 0;
+  }
+  if (affineOptModeA < 0 && !(affineOptModeB < 0)) {  // fix a
+    double Hs[64], bs[8]; memcpy(Hs, Hl, sizeof(Hs)); memcpy(bs, b, sizeof(bs));
+    for (int r = 0; r < 8; r++) Hs[r * 8 + 6] = Hs[r * 8 + 7];
+    for (int c = 0; c < 8; c++) Hs[6 * 8 + c] = Hs[7 * 8 + c];
+    bs[6] = bs[7];
+    double H7[49], nb7[7], x7[7];
+    for (int r = 0; r < 7; r++) { for (int c = 0; c < 7; c++) H7[r * 7 + c] = Hs[r * 8 + c]; nb7[r] = -bs[r]; }
+    ldltSolve(H7, nb7, x7, 7);
+    for (int i = 0; i < 8; i++) inc[i] = 0;
+    for (int i = 0; i < 6; i++) inc[i] = x7[i];
+    inc[6] = 0; inc[7] = x7[6];
+  }
+  for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+  for (int i = 0; i < 3; i++) incScaled[i] = inc[i] * SCALE_XI_ROT;
+  for (int i = 3; i < 6; i++) incScaled[i] = inc[i] * SCALE_XI_TRANS;
+  incScaled[6] = inc[6] * SCALE_A; incScaled[7] = inc[7] * SCALE_B;
+  double ssum = 0; for (int i = 0; i < 8; i++) ssum += incScaled[i];
+  if (!std::isfinite(ssum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
+  refToNew_new = se3Mul(se3Exp(incScaled), refToNew_current);
+  incNorm = 0; for (int i = 0; i < 8; i++) incNorm += inc[i] * inc[i];
+  incNorm = std::sqrt(incNorm);
+  return std::isfinite(ssum);
+}
+
 struct OrcTracker {
   int w[PYR_LEVELS], h[PYR_LEVELS], levels;
   float fx[PYR_LEVELS], fy[PYR_LEVELS], cx[PYR_LEVELS], cy[PYR_LEVELS];
@@ -372,50 +418,12 @@ struct OrcTracker {
       calcGS(lvl, affA_cur, affB_cur, H, b);
       float lambda = 0.01;
       for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
-        double Hl[64]; memcpy(Hl, H, sizeof(Hl));
-        for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda);
         float extrapFac = 1;
         if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
-        double nb[8]; for (int i = 0; i < 8; i++) nb[i] = -b[i];
-        double inc[8];
-        ldltSolve(Hl, nb, inc, 8);
-        if (affineOptModeA < 0 && affineOptModeB < 0) {  // fix a, b
-          double H6[36], x6[6];
-          for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) H6[r * 6 + c] = Hl[r * 8 + c];
-          ldltSolve(H6, nb, x6, 6);
-          for (int i = 0; i < 6; i++) inc[i] = x6[i];
-          inc[6] = inc[7] = 0;
-        }
-        if (!(affineOptModeA < 0) && affineOptModeB < 0) {  // fix b
-          double H7[49], x7[7];
-          for (int r = 0; r < 7; r++) for (int c = 0; c < 7; c++) H7[r * 7 + c] = Hl[r * 8 + c];
-          ldltSolve(H7, nb, x7, 7);
-          for (int i = 0; i < 7; i++) inc[i] = x7[i];
-          inc[7] = 0;
-        }
-        if (affineOptModeA < 0 && !(affineOptModeB < 0)) {  // fix a
-          double Hs[64], bs[8]; memcpy(Hs, Hl, sizeof(Hs)); memcpy(bs, b, sizeof(bs));
-          for (int r = 0; r < 8; r++) Hs[r * 8 + 6] = Hs[r * 8 + 7];
-          for (int c = 0; c < 8; c++) Hs[6 * 8 + c] = Hs[7 * 8 + c];
-          bs[6] = bs[7];
-          double H7[49], nb7[7], x7[7];
-          for (int r = 0; r < 7; r++) { for (int c = 0; c < 7; c++) H7[r * 7 + c] = Hs[r * 8 + c]; nb7[r] = -bs[r]; }
-          ldltSolve(H7, nb7, x7, 7);
-          for (int i = 0; i < 8; i++) inc[i] = 0;
-          for (int i = 0; i < 6; i++) inc[i] = x7[i];
-          inc[6] = 0; inc[7] = x7[6];
-        }
-        for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
-        double incScaled[8];
-        for (int i = 0; i < 3; i++) incScaled[i] = inc[i] * SCALE_XI_ROT;
-        for (int i = 3; i < 6; i++) incScaled[i] = inc[i] * SCALE_XI_TRANS;
-        incScaled[6] = inc[6] * SCALE_A; incScaled[7] = inc[7] * SCALE_B;
-        double ssum = 0; for (int i = 0; i < 8; i++) ssum += incScaled[i];
-        if (!std::isfinite(ssum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
-        SE3 refToNew_new = se3Mul(se3Exp(incScaled), refToNew_current);
+        double inc[8], incScaled[8], incNorm;
+        SE3 refToNew_new;
+        coarseUpdateVisual(affineOptModeA, affineOptModeB, H, b, extrapFac, lambda, refToNew_current, refToNew_new, inc, incScaled, incNorm);
         double affA_new = affA_cur + incScaled[6], affB_new = affB_cur + incScaled[7];
-        double incNorm = 0; for (int i = 0; i < 8; i++) incNorm += inc[i] * inc[i];
-        incNorm = std::sqrt(incNorm);
 
         double resNew[6];
         calcRes(lvl, refToNew_new, affA_new, affB_new, setting_coarseCutoffTH * levelCutoffRepeat, resNew);
@@ -637,6 +645,13 @@ int orc_tracker_track_new_coarse(void* p, int n_tries, const double* tries7, con
 }
 
 // --- Lie helpers exposed for tests ---
+void orc_coarse_update_visual(float affineOptModeA, float affineOptModeB, const double H[64], const double b[8], float extrapFac, float lambda, const double pose7_cur[7],
+                               double pose7_new[7], double* incA, double* incB, double* incNorm) {
+  double inc[8], incScaled[8], nn; SE3 nxt;
+  const bool finite = coarseUpdateVisual(affineOptModeA, affineOptModeB, H, b, extrapFac, lambda, poseFrom7(pose7_cur), nxt, inc, incScaled, nn);
+  poseTo7(nxt, pose7_new);
+  *incA = finite ? inc[6] : 0.0; *incB = finite ? inc[7] : 0.0; *incNorm = nn;
+}
 void orc_se3_exp(const double a[6], double pose7[7]) { poseTo7(se3Exp(a), pose7); }
 void orc_se3_log(const double pose7[7], double a[6]) { se3Log(poseFrom7(pose7), a); }
 void orc_se3_mul(const double a7[7], const double b7[7], double out7[7]) { poseTo7(se3Mul(poseFrom7(a7), poseFrom7(b7)), out7); }
