@@ -316,12 +316,17 @@ struct BAHost {
     double* HF = hfScratch.data();
     double* Ht = htScratch.data();
     double bF[4 + 8 * BA_MAXF], sv[4 + 8 * BA_MAXF], bs[4 + 8 * BA_MAXF];
-    if (haveM) for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = HM[i] + HA[i];
-    else for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] = 0.0 + HA[i];
-    for (int i = 0; i < nn; i++) bF[i] = bPriorM[i] + bA[i] - bsc[i];
-    // HL_top / bL_top = priors (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302)
-    for (int i = 0; i < 4; i++) { HF[(size_t)i * nn + i] += cPrior[i]; bF[i] += cPrior[i] * (double)cDeltaF[i]; }
-    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HF[(size_t)q * nn + q] += fr[f].prior[i]; bF[q] += fr[f].prior[i] * fr[f].delta_prior[i]; }
+    // HFinal_top = HL_top + HM + HA_top, bFinal_top = bL_top + bM_top + bA_top - b_sc (EnergyFunctional.cpp:906-907), summed in that order: HL_top / bL_top hold only the priors
+    // (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302; no linearised residuals outside marginalisation), zero elsewhere
+    double HLd[4 + 8 * BA_MAXF], bL[4 + 8 * BA_MAXF];
+    for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
+    for (int i = 0; i < nn; i++)
+      for (int j = 0; j < nn; j++) {
+        const size_t o = (size_t)i * nn + j;
+        HF[o] = ((i == j ? HLd[i] : 0.0) + (haveM ? HM[o] : 0.0)) + HA[o];
+      }
+    for (int i = 0; i < nn; i++) bF[i] = ((bL[i] + bPriorM[i]) + bA[i]) - bsc[i];
     for (int i = 0; i < nn; i++) HF[(size_t)i * nn + i] *= (1 + lambda);
     const double fac = 1.0f / (1 + lambda);
     for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] -= Hsc[i] * fac;
