@@ -38,3 +38,23 @@ def test_visual_lm_step_equals_the_oracle_bitwise(pkg, oracle):
     pg, ag, bg, ng = pkg.coarse_update_visual(H, b, 1.0, 0.01, cur)
     po, ao, bo, no = oracle.coarse_update_visual(H, b, 1.0, 0.01, cur)
     assert np.array_equal(po.view(np.uint64), pg.view(np.uint64)) and ag == 0.0 and bg == 0.0 and ao == 0.0
+
+
+def test_lie_dev_host_functions_equal_lie_h_bitwise(tmp_path, oracle):
+    """csrc/lie_dev.h compiled for the host (hipcc, the flags of csrc/Makefile) against oracle/lie.h as g++ compiled it (liboracle.so's orc_se3_*), function by function: exp,
+    log, product, inverse, Adj over 200000 random tangents — the pose algebra every host path of the library uses is the oracle's, hence the vendored Sophus', bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path / "lie_compare")
+    libdir = os.path.dirname(oracle.build())
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "dm-vio_amd", "csrc"),
+                           os.path.join(root, "tests", "lie_compare.hip"), "-L" + libdir, "-loracle", "-Wl,-rpath," + libdir, "-o", exe])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stdout.decode()
+    assert b"exp 0 log 0 mul 0 inv 0 adj 0" in p.stdout
