@@ -58,3 +58,82 @@ def test_lie_dev_host_functions_equal_lie_h_bitwise(tmp_path, oracle):
     p = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120)
     assert p.returncode == 0, p.stdout.decode()
     assert b"exp 0 log 0 mul 0 inv 0 adj 0" in p.stdout
+
+
+def test_ba_host_algebra_equals_the_oracle_bitwise(tmp_path, oracle, synth):
+    """csrc/ba_host.hpp's BAHost — everything the library computes on the host around the BA kernels — compiled host-only (tests/ba_host_harness.hip) and set up like
+    dmvio_hip_ba_set_window does: FrameFramePrecalc tables, adjoints, gauge nullspaces, frame poses after state changes, prior / marginalisation energies and the damped
+    Jacobi-scaled solve of solveSystemF (with and without a marginalisation prior) equal the oracle's — which is pinned to the reference's — bit for bit; behind the SVD-based
+    orthogonalisation (iteration >= 2, unpinned Eigen arithmetic) the step agrees to 1e-14."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    so = str(tmp_path / "libbah.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + os.path.join(root, "dm-vio_amd", "csrc"),
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "ba_host_harness.hip"), "-o", so])
+    L = C.CDLL(so)
+    cd, cf, ci = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.bah_create.restype = C.c_void_p; L.bah_create.argtypes = [C.c_int, cd, cd, cf, ci, cd]
+    L.bah_destroy.argtypes = [C.c_void_p]
+    L.bah_get_precalc.argtypes = [C.c_void_p, C.c_int, C.c_int, cf]; L.bah_get_adjoints.argtypes = [C.c_void_p, cd, cd]; L.bah_get_nullspaces.argtypes = [C.c_void_p, cd]
+    L.bah_set_frame_state.argtypes = [C.c_void_p, C.c_int, cd]; L.bah_get_frame.argtypes = [C.c_void_p, C.c_int, cd, cd]; L.bah_energies.argtypes = [C.c_void_p, cd, cd]
+    L.bah_set_marg_prior.argtypes = [C.c_void_p, cd, cd]; L.bah_solve_system.argtypes = [C.c_void_p, C.c_int, C.c_double, cd, cd, cd, cd, cd]
+
+    def d(a):
+        return a.ctypes.data_as(cd)
+
+    def same(a, b):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    case = synth.ba_case(320, 256, n_frames=5, n_points=400, hosts_share=(130, 110, 90, 70, 0), seed=31)
+    F = case["n_frames"]; n = 4 + 8 * F
+    W = oracle.BAWindow(case)
+    poses = np.ascontiguousarray(np.array(case["poses0"], dtype=np.float64).reshape(F, 7))
+    aff = np.zeros((F, 2)); ex = np.ones(F, np.float32); ids = np.arange(F, dtype=np.int32)
+    K = np.ascontiguousarray(np.array(case["K4"], dtype=np.float64))
+    H = L.bah_create(F, d(poses), d(aff), ex.ctypes.data_as(cf), ids.ctypes.data_as(ci), d(K))
+
+    def tables(tag):
+        for h in range(F):
+            for t in range(F):
+                if h == t:
+                    continue
+                o = np.zeros(28, np.float32); L.bah_get_precalc(H, h, t, o.ctypes.data_as(cf)); p = W.precalc(h, t)
+                ref = np.r_[p["KRKi"].ravel(), p["Kt"], p["R0"].ravel(), p["t0"], p["aff"], p["b0"]].astype(np.float32)
+                assert same(o[:27], ref), (tag, "precalc", h, t)
+        ah = np.zeros((F * F, 8, 8)); at = np.zeros((F * F, 8, 8)); L.bah_get_adjoints(H, d(ah), d(at)); oh, ot, _ = W.adjoints()
+        assert same(ah, oh) and same(at, ot), (tag, "adjoints")
+        ns = np.zeros((7, n)); L.bah_get_nullspaces(H, d(ns))
+        assert same(ns, W.nullspaces()), (tag, "nullspaces")
+    tables("initial")
+    rng = np.random.RandomState(2)
+    for k in range(1, F):                                   # FrameHessian::setState with a moved pose and brightness
+        _, _, s = W.frame_pose(k)
+        st = s.copy(); st[:6] += 1e-3 * rng.standard_normal(6); st[6] += 1e-3 * rng.standard_normal(); st[7] += 1e-4 * rng.standard_normal()
+        W.set_frame_state(k, st); L.bah_set_frame_state(H, k, d(np.ascontiguousarray(st)))
+        pp = np.zeros(7); ss = np.zeros(10); L.bah_get_frame(H, k, d(pp), d(ss))
+        assert same(pp, W.frame_pose(k)[0]), ("w2c", k)
+    tables("stepped")
+    W.activate_all(); W.linearize_all(False); W.apply_res()
+    for with_prior in (False, True):
+        if with_prior:                                      # a marginalisation prior: HM enters HFinal, bM + HM * delta enters bFinal, and E_M is no longer zero
+            A = rng.standard_normal((n, n + 8)) * 30.0; HM = A @ A.T; bM = 50.0 * rng.standard_normal(n)
+            W.set_marg_prior(HM, bM); L.bah_set_marg_prior(H, d(np.ascontiguousarray(HM)), d(np.ascontiguousarray(bM)))
+        EL = np.zeros(1); EM = np.zeros(1); L.bah_energies(H, d(EL), d(EM))
+        assert EL[0] == W.lenergy() and EM[0] == W.menergy() and (EM[0] != 0.0) == with_prior
+        ao = W.accumulate()
+        sysm = [np.ascontiguousarray(ao[k]) for k in ("HA", "bA", "Hsc", "bsc")]
+        for it, lam in ((0, 1e-5), (1, 1e-4), (2, 1e-3), (4, 1e-1)):
+            xo = W.solve(it, lam); x = np.zeros(n)
+            L.bah_solve_system(H, it, lam, d(sysm[0]), d(sysm[1]), d(sysm[2]), d(sysm[3]), d(x))
+            if it < 2:
+                assert same(x, xo), (with_prior, it, np.abs(x - xo).max())
+            else:
+                assert np.abs(x - xo).max() <= 1e-14 * np.abs(xo).max(), (with_prior, it)
+    L.bah_destroy(H)
