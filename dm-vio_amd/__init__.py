@@ -36,6 +36,31 @@ class CommCallbacks(C.Structure):
     _fields_ = [("user", C.c_void_p), ("allreduce_sum_f64", _ALLREDUCE_F64), ("allgather", _ALLGATHER)]
 
 
+class BAFrameView(C.Structure):
+    """dmvio_hip_ba_frame_view (include/dmvio_hip.h): what the BA hooks read of a keyframe."""
+    _fields_ = [("frameID", C.c_int), ("index", C.c_int), ("PRE_worldToCam7", C.c_double * 7), ("worldToCam_evalPT7", C.c_double * 7),
+                ("state10", C.c_double * 10), ("state_zero10", C.c_double * 10)]
+
+
+_BA_COMPUTE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, c_d, c_d, C.c_double, c_d, C.c_int, C.POINTER(BAFrameView), c_d, c_d)
+_BA_ACCEPT = C.CFUNCTYPE(None, C.c_void_p, C.c_double)
+_BA_ENERGY = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int)
+_BA_VALUES = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(BAFrameView), c_d)
+_BA_WEIGHT = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_int)
+_BA_BREAK = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class BACallbacks(C.Structure):
+    """dmvio_hip_ba_callbacks: the members of dmvio::BAGTSAMIntegration the BA loop calls."""
+    _fields_ = [("user", C.c_void_p), ("computeBAUpdate", _BA_COMPUTE), ("acceptBAUpdate", _BA_ACCEPT), ("getBAEnergy", _BA_ENERGY), ("updateBAValues", _BA_VALUES),
+                ("updateDynamicWeight", _BA_WEIGHT), ("canBreak", _BA_BREAK), ("postOptimization", _BA_VALUES)]
+
+
+class BAVioOptions(C.Structure):
+    _fields_ = [("coarseTrackingWasGood", C.c_int), ("updateDynamicWeightDuringOptimization", C.c_int), ("minOptIterations", C.c_int), ("resInA_at_entry", C.c_int),
+                ("HMForGTSAM", c_d), ("bMForGTSAM", c_d)]
+
+
 def _sig(L):
     vp = C.c_void_p
     L.dmvio_hip_last_error.restype = C.c_char_p
@@ -137,6 +162,9 @@ def _sig(L):
     L.dmvio_hip_ba_energy_terms.argtypes = [vp, c_d, c_d]
     L.dmvio_hip_ba_set_comm.argtypes = [vp, vp, C.c_int, C.c_int]
     L.dmvio_hip_ba_set_comm_callbacks.argtypes = [vp, C.POINTER(CommCallbacks), C.c_int, C.c_int]
+    L.dmvio_hip_ba_optimize_vio.argtypes = [vp, C.c_int, C.POINTER(BACallbacks), C.POINTER(BAVioOptions), C.POINTER(C.c_float), c_d, c_i, c_d]
+    L.dmvio_hip_ba_solve_ldlt.argtypes = [C.c_int, c_d, c_d, c_d]
+    L.dmvio_hip_ba_get_point_hessian.argtypes = [vp, c_f]
     L.dmvio_hip_comm_unique_id.argtypes = [c_u8]
     L.dmvio_hip_comm_init_rank.argtypes = [vp, c_u8, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.dmvio_hip_comm_destroy.argtypes = [vp]
@@ -903,6 +931,64 @@ class BundleAdjusterHip:
         cb = CommCallbacks(None, _ALLREDUCE_F64(allreduce), _ALLGATHER(allgather))
         self._comm_keep = cb      # the C side stores the function pointers: keep the thunks alive
         _chk(self.L, self.L.dmvio_hip_ba_set_comm_callbacks(self.p, C.byref(cb), rank, world), "ba_set_comm_callbacks")
+
+    def point_hessian(self):
+        o = np.zeros(self.N, dtype=np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_get_point_hessian(self.p, _f(o)), "ba_get_point_hessian"); return o
+
+    def solve_ldlt(self, HPassed, b):
+        """The reference's non-GTSAM solve (diagonal pre-scaling + pivoted LDL^T), host-only."""
+        H = np.ascontiguousarray(HPassed, dtype=np.float64); bb = np.ascontiguousarray(b, dtype=np.float64); x = np.zeros(len(bb))
+        _chk(self.L, self.L.dmvio_hip_ba_solve_ldlt(len(bb), _d(H), _d(bb), _d(x)), "ba_solve_ldlt"); return x
+
+    def optimize_vio(self, its, hooks, trackingWasGood=True, updateDuring=False, minOptIterations=-1, resInA_at_entry=-1, HMForGTSAM=None, bMForGTSAM=None):
+        """FullSystem::optimize with the reference's default (GTSAM) solver branch.  `hooks`: an object with the methods of dmvio::BAGTSAMIntegration the loop calls —
+        computeBAUpdate(HPassed, b, lam, HNoLambda, frames, calib) -> x (required), and optionally acceptBAUpdate(E), getBAEnergy(useNew), updateBAValues(frames, calib),
+        updateDynamicWeight(E, rmse, good), canBreak(), postOptimization(frames, calib); frames = list of dicts (frameID, PRE_worldToCam, evalPT, state, state_zero)."""
+        n = self.n
+        err = []
+
+        def views(F, fr):
+            return [dict(frameID=fr[k].frameID, index=fr[k].index, PRE_worldToCam=np.array(fr[k].PRE_worldToCam7[:]), evalPT=np.array(fr[k].worldToCam_evalPT7[:]),
+                         state=np.array(fr[k].state10[:]), state_zero=np.array(fr[k].state_zero10[:])) for k in range(F)]
+
+        def compute(_u, nn, HP, bP, lam, HN, F, fr, calib, xo):
+            try:       # never unwind through the C frames
+                x = hooks.computeBAUpdate(np.ctypeslib.as_array(HP, shape=(nn, nn)).copy(), np.ctypeslib.as_array(bP, shape=(nn,)).copy(), lam,
+                                          np.ctypeslib.as_array(HN, shape=(nn, nn)).copy(), views(F, fr), np.ctypeslib.as_array(calib, shape=(4,)).copy())
+                np.ctypeslib.as_array(xo, shape=(nn,))[:] = x
+                return 0
+            except Exception as e:
+                err.append(e); return 1
+
+        def guard(fn, default=None):
+            def g(*a):
+                try:
+                    return fn(*a)
+                except Exception as e:
+                    err.append(e); return default
+            return g
+        has = lambda name: getattr(hooks, name, None) is not None
+        cb = BACallbacks()
+        cb.user = None
+        cb.computeBAUpdate = _BA_COMPUTE(compute)
+        if has("acceptBAUpdate"): cb.acceptBAUpdate = _BA_ACCEPT(guard(lambda _u, e: hooks.acceptBAUpdate(e)))
+        if has("getBAEnergy"): cb.getBAEnergy = _BA_ENERGY(guard(lambda _u, new: float(hooks.getBAEnergy(bool(new))), 0.0))
+        if has("updateBAValues"): cb.updateBAValues = _BA_VALUES(guard(lambda _u, F, fr, c: hooks.updateBAValues(views(F, fr), np.ctypeslib.as_array(c, shape=(4,)).copy())))
+        if has("updateDynamicWeight"): cb.updateDynamicWeight = _BA_WEIGHT(guard(lambda _u, e, r, g: float(hooks.updateDynamicWeight(e, r, bool(g))), 1.0))
+        if has("canBreak"): cb.canBreak = _BA_BREAK(guard(lambda _u: 1 if hooks.canBreak() else 0, 0))
+        if has("postOptimization"): cb.postOptimization = _BA_VALUES(guard(lambda _u, F, fr, c: hooks.postOptimization(views(F, fr), np.ctypeslib.as_array(c, shape=(4,)).copy())))
+        opt = BAVioOptions(1 if trackingWasGood else 0, 1 if updateDuring else 0, int(minOptIterations), int(resInA_at_entry), None, None)
+        keep = []
+        if HMForGTSAM is not None:
+            HMg = np.ascontiguousarray(HMForGTSAM, dtype=np.float64).reshape(n, n); bMg = np.ascontiguousarray(bMForGTSAM, dtype=np.float64).reshape(n)
+            keep = [HMg, bMg]; opt.HMForGTSAM = _d(HMg); opt.bMForGTSAM = _d(bMg)
+        rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))
+        rc = self.L.dmvio_hip_ba_optimize_vio(self.p, its, C.byref(cb), C.byref(opt), C.byref(rm), C.byref(fe), C.byref(it), _d(tr))
+        if err:
+            raise err[0]
+        _chk(self.L, rc, "ba_optimize_vio")
+        return dict(rmse=rm.value, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])
 
     def optimize(self, its=6):
         rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))

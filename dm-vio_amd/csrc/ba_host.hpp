@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include "common.h"
 #include "lie_dev.h"
 #include "ba_kernels.hpp"
@@ -56,6 +57,12 @@ struct BAHost {
   float cDeltaF[4], cPriorF[4];
   double cPrior[4];
   std::vector<double> HM, bM, lastX;
+  // EnergyFunctional::HMForGTSAM / bMForGTSAM (EnergyFunctional.h:108-111): the marginalisation prior the GTSAM branch of solveSystemF / calcMEnergyF uses instead
+  // of HM / bM (only the points marginalised since the last keyframe marginalisation; the rest lives in the GTSAM graph).  Used while `gtsam` is set.
+  std::vector<double> HMG, bMG;
+  bool gtsam = false;
+  const std::vector<double>& priorH() const { return gtsam ? HMG : HM; }
+  const std::vector<double>& priorb() const { return gtsam ? bMG : bM; }
   std::vector<std::vector<double>> nsp;      // 7 nullspace vectors
   std::vector<std::vector<double>> orthoBasis;   // unit left singular vectors of the nullspace matrix above the cut (prepareOrthogonalize)
   std::vector<double> bPriorM, hfScratch, htScratch;   // bM + HM * delta (prepareSolve); scratch of solveSystem
@@ -85,7 +92,7 @@ struct BAHost {
   }
   static void frameSetStateZero(BAFrameHost& f, const double st0[10]) {
     for (int i = 0; i < 10; i++) f.state_zero[i] = st0[i];
-    { static unsigned long long stamp = 0; f.zero_stamp = ++stamp; }   // the nullspaces below change: cached orthogonalisation bases are stale
+    { static std::atomic<unsigned long long> stamp{0}; f.zero_stamp = ++stamp; }   // the nullspaces below change: cached orthogonalisation bases are stale (atomic: handles on several threads)
     const Pose Tinv = poseInv(f.evalPT);
     for (int i = 0; i < 6; i++) {
       double ep[6] = {0, 0, 0, 0, 0, 0}, em[6] = {0, 0, 0, 0, 0, 0};
@@ -198,6 +205,7 @@ struct BAHost {
     {   // the basis is a function of the frames' nullspaces only (fixed while a window is optimised): rebuild it when one of them changed
       unsigned long long key = (unsigned long long)F * 0x9E3779B97F4A7C15ull;
       for (int f = 0; f < F; f++) key = key * 1099511628211ull + fr[f].zero_stamp;
+      { unsigned long long dbits; static_assert(sizeof(dbits) == sizeof(S.solverModeDelta), "double"); memcpy(&dbits, &S.solverModeDelta, 8); key = key * 1099511628211ull + dbits; }   // the cut enters the basis
       if (key == orthoKey && !orthoBasis.empty()) return;
       orthoKey = key;
     }
@@ -300,8 +308,9 @@ struct BAHost {
     for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
     bPriorM.assign(nn, 0.0);
-    const bool haveM = HM.size() == (size_t)nn * nn;
-    for (int i = 0; i < nn; i++) { double s = haveM ? bM[i] : 0.0; if (haveM) for (int j = 0; j < nn; j++) s += HM[(size_t)i * nn + j] * d[j]; bPriorM[i] = s; }
+    const std::vector<double>&HMs = priorH(), &bMs = priorb();   // bM_top resp. bMGTSAM_top (EnergyFunctional.cpp:864-865)
+    const bool haveM = HMs.size() == (size_t)nn * nn;
+    for (int i = 0; i < nn; i++) { double s = haveM ? bMs[i] : 0.0; if (haveM) for (int j = 0; j < nn; j++) s += HMs[(size_t)i * nn + j] * d[j]; bPriorM[i] = s; }
     solvePrepared = true;
   }
 
@@ -337,6 +346,35 @@ struct BAHost {
     x.resize(nn);
     for (int i = 0; i < nn; i++) x[i] = sv[i] * bs[i];
     if (iteration >= 2) orthogonalize(x);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:81)
+    lastX = x;
+  }
+  // The GTSAM branch of solveSystemF (EnergyFunctional.cpp:958-969): what the reference hands to BAGTSAMIntegration::computeBAUpdate —
+  //   HPassed   = (HL_top + HMForGTSAM + HA_top) with the diagonal times (1 + lambda), minus H_sc / (1 + lambda)
+  //   bPassed   = bL_top + bMGTSAM_top + bA_top - b_sc
+  //   HNoLambda = HL_top + HMForGTSAM + HA_top - H_sc
+  // each summed in the reference's order.  n x n row-major (the matrices are symmetric).  Requires gtsam == true before prepareSolve().
+  void buildGtsamSystem(double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* HPassed, double* bPassed, double* HNoLambda) {
+    const int nn = n();
+    if (!solvePrepared) prepareSolve();
+    solvePrepared = false;
+    const std::vector<double>& HMs = priorH();
+    const bool haveM = HMs.size() == (size_t)nn * nn;
+    double HLd[4 + 8 * BA_MAXF], bL[4 + 8 * BA_MAXF];
+    for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
+    const double fac = 1.0f / (1 + lambda);
+    for (int i = 0; i < nn; i++)
+      for (int j = 0; j < nn; j++) {
+        const size_t o = (size_t)i * nn + j;
+        const double top = ((i == j ? HLd[i] : 0.0) + (haveM ? HMs[o] : 0.0)) + HA[o];
+        HNoLambda[o] = top - Hsc[o];
+        HPassed[o] = (i == j ? top * (1 + lambda) : top) - Hsc[o] * fac;
+      }
+    for (int i = 0; i < nn; i++) bPassed[i] = ((bL[i] + bPriorM[i]) + bA[i]) - bsc[i];
+  }
+  // tail of solveSystemF for a step that came from outside (EnergyFunctional.cpp:977-985): orthogonalisation from iteration 2, lastX
+  void finishExternalSolve(int iteration, std::vector<double>& x) {
+    if (iteration >= 2) orthogonalize(x);
     lastX = x;
   }
   // EnergyFunctional::marginalizeFrame, visual-only branch (EnergyFunctional.cpp:570-640): returns the prior of the window without
@@ -425,8 +463,10 @@ struct BAHost {
     std::vector<double> d(nn);
     for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) d[4 + 8 * f + i] = fr[f].delta[i];
+    const std::vector<double>&HMs = priorH(), &bMs = priorb();   // delta.dot(2 bM + HM delta) resp. the ForGTSAM pair (EnergyFunctional.cpp:332-341)
+    if (HMs.size() != (size_t)nn * nn) return 0.0;
     double s = 0;
-    for (int i = 0; i < nn; i++) { double t = 2 * bM[i]; for (int j = 0; j < nn; j++) t += HM[(size_t)i * nn + j] * d[j]; s += d[i] * t; }
+    for (int i = 0; i < nn; i++) { double t = 2 * bMs[i]; for (int j = 0; j < nn; j++) t += HMs[(size_t)i * nn + j] * d[j]; s += d[i] * t; }
     return s;
   }
   void backupFrames() {

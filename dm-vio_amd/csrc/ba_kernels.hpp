@@ -586,15 +586,17 @@ __device__ __forceinline__ float seqAdd8(float s, const float v) {
 #define PT_GROUPS_PER_BLOCK 32
 // apply != 0 fuses applyRes_Reductor(true) (FullSystemOptimize.cpp:91-95, Residuals.cpp:306-328) for the point's residuals: every residual
 // belongs to exactly one lane of one group.  gate: see BACtl.
+// host_backup (may be NULL): host-coherent mirror of idepth_backup — doStepFromBackup's canbreak test sums |idepth_backup| over the points on the host, in
+// the reference's order (FullSystemOptimize.cpp:269-291), when the GTSAM branch can end the loop early
 __global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const int backup, const int apply, const BACtl* __restrict__ ctl,
-                                                        const int gate) {
+                                                        const int gate, float* __restrict__ host_backup) {
   if (baGateClosed(ctl, gate)) return;
   const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;
   if (pi >= W.N) return;   // group-uniform
   const bool lead = q == 0;
   const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
   const float id = P.idepth[pi], idz = P.idepth_zero[pi], prior = P.priorF[pi];
-  if (backup && lead) P.idepth_backup[pi] = id;
+  if (backup && lead) { P.idepth_backup[pi] = id; if (host_backup) __hip_atomic_store(host_backup + pi, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   float Hdd = 0, bd = 0, Hcd0 = 0, Hcd1 = 0, Hcd2 = 0, Hcd3 = 0;
   int ngood = 0;
   const int grp = (threadIdx.x & 63) & ~7;

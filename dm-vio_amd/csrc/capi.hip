@@ -45,6 +45,8 @@ struct dmvio_hip_tracker {
   float* h_rec = nullptr;             // EVAL_SERVER_MAX_BLOCKS records of EVAL_RECORD_FLOATS floats: every server workgroup stores its partial sums + the ticket into its own
   bool server_on = false;             // a server kernel was launched for server_slot and has not been told to quit
   int server_slot = -1, server_G = 0;
+  unsigned int server_session = 0;    // identity of the current serverStart .. serverStop session (mailbox dword EVAL_MAIL_SESSION, kernel argument)
+  long long server_idle_ticks = 500000;   // the server leaves after this long without a request (100 MHz ticks: 5 ms); dmvio_hip_tracker_set_server_idle_us
   int use_server = 1;                 // DMVIO_HIP_EVAL_SERVER=0: one k_eval_fused launch per evaluation instead
   int single_host_lm = 1;             // DMVIO_HIP_SINGLE_HOST_LM=0: a single alignment problem runs the device-resident LM (cluster mode) instead of the host LM + server
   int last_vio_iterations = 0;
@@ -194,13 +196,14 @@ dmvio_hip_undistorter* dmvio_hip_undistorter_create(dmvio_hip_ctx* c, int wOrg, 
   if ((remapX == nullptr) != (remapY == nullptr)) { failmsg("undistorter_create: remapX / remapY must both be given or both be NULL"); return nullptr; }
   if (!remapX && (wOrg != c->w || hOrg != c->h)) { failmsg("undistorter_create: passthrough needs wOrg x hOrg == w x h"); return nullptr; }
   if (remapX) {
-    // the bilinear taps of a remapped pixel are (x, y), (x+1, y), (x, y+1), (x+1, y+1) of the raw image: the reference's remap generation marks everything
-    // outside [0, wOrg-2] x [0, hOrg-2] with -1 (Undistort.cpp, "make rounding resistant"); a table that does not would read out of bounds
+    // the bilinear taps of a remapped pixel are (xi, yi), (xi+1, yi), (xi, yi+1), (xi+1, yi+1) of the raw image with xi = (int)x, yi = (int)y: they are in bounds
+    // exactly when 0 <= x < wOrg-1 and 0 <= y < hOrg-1.  The reference's remap generation keeps 0 < x < wOrg-1, 0 < y < hOrg-1 and marks everything else with -1
+    // (Undistort.cpp:920-942, "make rounding resistant"), so its tables always pass; a table that does not would read out of bounds.
     const size_t nOutChk = (size_t)c->w * c->h;
     for (size_t i = 0; i < nOutChk; i++) {
       const float x = remapX[i], y = remapY[i];
       if (x < 0) continue;
-      if (!(x <= (float)(wOrg - 2)) || !(y >= 0) || !(y <= (float)(hOrg - 2)) || (int)x + 1 >= wOrg || (int)y + 1 >= hOrg) {
+      if (!(x < (float)(wOrg - 1)) || !(y >= 0) || !(y < (float)(hOrg - 1)) || (int)x + 1 > wOrg - 1 || (int)y + 1 > hOrg - 1) {
         failmsg("undistorter_create: remap entry outside the raw image (mark invalid pixels with remapX = -1)");
         return nullptr;
       }
@@ -644,7 +647,7 @@ static void mailTicket(dmvio_hip_tracker* t, unsigned int v) {
 static int serverLaunch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
   hipLaunchKernelGGL(k_eval_server<256>, dim3(t->server_G), dim3(256), 0, c->stream, t->dev, c->fs, t->server_slot, (const unsigned int*)t->h_mail, t->d_leave, t->eval_ticket,
-                     (long long)500000 /* 5 ms at 100 MHz */, t->h_rec);
+                     t->server_idle_ticks, t->h_rec, t->server_session);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -652,6 +655,10 @@ static int serverStart(dmvio_hip_tracker* t, int new_slot, int G) {
   t->server_G = std::max(1, std::min(G, (int)EVAL_SERVER_MAX_BLOCKS));
   t->server_slot = new_slot;
   t->eval_ticket = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT;   // a number of its own for the launch
+  // a session number of its own too: a workgroup of the PREVIOUS launch that has not polled its quit ticket yet (serverStop does not wait) must not take this
+  // session's tickets for requests — it compares the mailbox's session dword with its own and leaves
+  t->server_session++;
+  __atomic_store_n(&t->h_mail[EVAL_MAIL_SESSION], t->server_session, __ATOMIC_RELEASE);
   mailTicket(t, t->eval_ticket);   // "nothing new" for the kernel about to start
   if (int r = serverLaunch(t)) return r;
   t->server_on = true;
@@ -664,7 +671,7 @@ static void serverStop(dmvio_hip_tracker* t) {
 }
 static int serverEval(dmvio_hip_tracker* t, const EvalP& e) {
   dmvio_hip_ctx* c = t->ctx;
-  static_assert(sizeof(EvalP) / 4 + 2 <= EVAL_MAIL_DWORDS, "EvalP must fit the mailbox");
+  static_assert(sizeof(EvalP) / 4 + 3 <= EVAL_MAIL_DWORDS, "EvalP must fit the mailbox between the ticket and the session / ticket copy");
   const int G = t->server_G;
   auto nextTicket = [&]() { unsigned int v = (t->eval_ticket + 1) & ~EVAL_QUIT_BIT; if (v == 0) v = 1; t->eval_ticket = v; return v; };
   memcpy((void*)(t->h_mail + 1), &e, sizeof(EvalP));
@@ -959,6 +966,14 @@ int dmvio_hip_coarse_update_visual(const dmvio_hip_tracker_settings* st, const d
 int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* t, int host_lm) {
   if (!t) return failmsg("null tracker");
   t->single_host_lm = host_lm ? 1 : 0;
+  return 0;
+}
+
+// How long the evaluation server of a single-frame track / track_vio call stays resident without a request (default 5000 us).  A computeCoarseUpdate hook that regularly
+// takes longer (a factor-graph solve) would otherwise pay a relaunch of the kernel per LM iteration.
+int dmvio_hip_tracker_set_server_idle_us(dmvio_hip_tracker* t, int microseconds) {
+  if (!t || microseconds < 100 || microseconds > 2000000) return failmsg("tracker_set_server_idle_us: 100 us .. 2 s");
+  t->server_idle_ticks = (long long)microseconds * 100;   // wall_clock64 runs at 100 MHz
   return 0;
 }
 

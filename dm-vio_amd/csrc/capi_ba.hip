@@ -102,6 +102,14 @@ struct dmvio_hip_ba {
   float *d_xchg_local = nullptr, *d_xchg_all = nullptr;
   int xchg_width = 0;                // floats per rank record: BA_XCHG_HEADER + the largest per-rank count of residuals that target the newest keyframe
   std::vector<double> h_stage;       // callback transport only
+  // ---- the reference's DEFAULT solver branch (setting_useGTSAMIntegration, dmvio_hip_ba_optimize_vio): hooks of the running call, the dynamic weight,
+  // PointHessian::idepth_backup mirrored into host-coherent memory by the per-point sums (the |idepth_backup| sum of doStepFromBackup's canbreak test)
+  const dmvio_hip_ba_callbacks* vio = nullptr;
+  const dmvio_hip_ba_vio_options* vio_opt = nullptr;
+  double dynW = 1.0;
+  int resInA_solve = 0;              // ef->resInA as the reference holds it: set by the accumulation of the last solveSystemF
+  float* h_idepth_backup = nullptr;
+  std::vector<dmvio_hip_ba_frame_view> vio_frames;
 };
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #x).c_str()); } while (0)
 
@@ -122,6 +130,7 @@ static void freeDevice(dmvio_hip_ba* b) {
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
   if (b->h_res) { hipHostFree(b->h_res); b->h_res = nullptr; }
   if (b->h_frameTH) { hipHostFree(b->h_frameTH); b->h_frameTH = nullptr; }
+  if (b->h_idepth_backup) { hipHostFree(b->h_idepth_backup); b->h_idepth_backup = nullptr; }
   for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
   b->graph_ready = false;
 }
@@ -307,7 +316,7 @@ static int accumulateWait(dmvio_hip_ba* b);
 // apply_first: applyRes_Reductor(true) fused into the per-point sums; gate: the whole chain only runs when the last accept test says so
 static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false, bool apply_first = false, int gate = BA_GATE_ALWAYS) {
   if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0, apply_first ? 1 : 0,
-                                      (const BACtl*)b->d_ctl, gate);
+                                      (const BACtl*)b->d_ctl, gate, (backup_points && b->vio) ? b->h_idepth_backup : (float*)nullptr);
   return accumulateViews(b, b->Rs, b->P, wait, gate);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
@@ -719,6 +728,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
   memset(b->h_res, 0, sizeof(BAHostRes));
   HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&b->h_idepth_backup, sizeof(float) * std::max(N, 1), hipHostMallocCoherent | hipHostMallocMapped));
   if (dalloc(b, &b->d_ctl, 1) || dalloc(b, &b->d_frameTH, BA_MAXF) || dalloc(b, &b->d_epart, (size_t)b->n_epart) || dalloc(b, &b->d_newestSlot, (size_t)R) || dalloc(b, &b->d_newestE, b->h_newest.size()) ||
       dalloc(b, &b->d_newEnergyWO, (size_t)R)) return -1;
   {
@@ -831,6 +841,13 @@ int dmvio_hip_ba_resubstitute(dmvio_hip_ba* b, const double* x) {
   std::vector<double> xv(x, x + b->H.n());
   return resubstitute(b, xv);
 }
+int dmvio_hip_ba_get_point_hessian(dmvio_hip_ba* b, float* idepth_hessian) {
+  if (!b || !b->graph_ready || !idepth_hessian) return failmsg("ba_get_point_hessian: bad argument");   // a pure read: the loop state (sys_ready) is left alone
+  HIPCHK(hipSetDevice(b->ctx->device));
+  HIPCHK(hipMemcpyAsync(idepth_hessian, b->P.idepth_hessian, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
 int dmvio_hip_ba_get_points(dmvio_hip_ba* b, float* idepth, float* step) {
   BA_READY(b);
   hipStream_t s = b->stream;
@@ -927,13 +944,44 @@ static int settleReject(dmvio_hip_ba* b, double lastE[3], bool wait) {
   b->pending_reject = false; b->pending_trace = -1;
   return 0;
 }
+// ---- the reference's default solver branch (setting_useGTSAMIntegration): views of the window for the hooks, calcMEnergyF with the GTSAM term
+static void fillFrameViews(dmvio_hip_ba* b) {
+  const BAHost& H = b->H;
+  b->vio_frames.resize(H.F);
+  for (int f = 0; f < H.F; f++) {
+    dmvio_hip_ba_frame_view& v = b->vio_frames[f];
+    const BAFrameHost& fr = H.fr[f];
+    v.frameID = fr.frameID; v.index = f;
+    poseTo7(fr.w2c, v.PRE_worldToCam7); poseTo7(fr.evalPT, v.worldToCam_evalPT7);
+    memcpy(v.state10, fr.state, sizeof(v.state10)); memcpy(v.state_zero10, fr.state_zero, sizeof(v.state_zero10));
+  }
+}
+// EnergyFunctional::calcMEnergyF (EnergyFunctional.cpp:322-345): without hooks delta.dot(2 bM + HM delta); with them updateBAValues(frames) when the current values are
+// asked for, then getBAEnergy(useNewValues) + delta.dot(2 bMForGTSAM + HMForGTSAM delta)
+static double calcMEnergy(dmvio_hip_ba* b, bool useNewValues) {
+  if (!b->vio) return b->H.calcMEnergy();
+  if (!useNewValues && b->vio->updateBAValues) { fillFrameViews(b); b->vio->updateBAValues(b->vio->user, b->H.F, b->vio_frames.data(), b->H.c_value); }
+  const double g = b->vio->getBAEnergy ? b->vio->getBAEnergy(b->vio->user, useNewValues ? 1 : 0) : 0.0;
+  return g + b->H.calcMEnergy();
+}
+static double vioDynamicWeight(dmvio_hip_ba* b, double E0, int resInA) {
+  if (!b->vio || !b->vio->updateDynamicWeight) return 1.0;
+  const float rmse = sqrtf((float)(E0 / (8 * resInA)));   // patternNum * ef->resInA (FullSystemOptimize.cpp:495-498)
+  return b->vio->updateDynamicWeight(b->vio->user, E0, (double)rmse, b->vio_opt ? b->vio_opt->coarseTrackingWasGood : 1);
+}
 // defer: after a rejected step return without waiting for the relinearisation of the restored state (its energy stays on the device for the next accept
-// test, BACtl::lastE0); lastE[0] is then filled in by the next call's wait or by settleReject
-static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted, bool defer = false, int trace_slot = -1) {
+// test, BACtl::lastE0); lastE[0] is then filled in by the next call's wait or by settleReject.
+// last: the caller will not iterate again — an accepted step is applied, but the system of the new state (which only the next solve would read) is not
+// accumulated: the per-point sums (HdiF, idepth_hessian) and resInA then stay those of the last solveSystemF, as in the reference.
+// canbreak_out: doStepFromBackup's return value && baIntegration->canBreak() (FullSystemOptimize.cpp:520-523); only evaluated with hooks (false otherwise).
+static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted, bool defer = false, int trace_slot = -1, bool last = false,
+                       bool* canbreak_out = nullptr) {
   BAHost& H = b->H;
   dmvio_hip_ctx* c = b->ctx;
-  const int n = H.n();
+  const int n = H.n(), tot = 2 * (n * n + n);
   const bool shard = sharded(b);
+  const dmvio_hip_ba_callbacks* vio = b->vio;
+  const bool dynDuring = vio && b->vio_opt && b->vio_opt->updateDynamicWeightDuringOptimization;
   if (shard) { if (int r = ensureExchange(b)) return r; }
   // backupState (the point part rode in the per-point sums that produced the system at hand)
   double tq0 = b->timing ? nowUs() : 0, tq1;
@@ -946,11 +994,30 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     if (int r = accumulate(b, true, true, sums_fresh)) return r;
   }
   b->sys_ready = false;
+  if (vio && (dynDuring || iteration == 0)) {
+    // the weight of the photometric energy against the GTSAM factors, updated before solving (FullSystemOptimize.cpp:491-503); ef->resInA is the count the LAST
+    // solveSystemF left behind — before the first solve of this call the caller's (vio_options::resInA_at_entry) or, without one, the current system's
+    if (b->pending_reject) { if (int r = settleReject(b, lastE, true)) return r; }
+    const int resInA_ref = iteration == 0 ? ((b->vio_opt && b->vio_opt->resInA_at_entry >= 0) ? b->vio_opt->resInA_at_entry : (int)b->h_sys[tot]) : b->resInA_solve;
+    b->dynW = vioDynamicWeight(b, lastE[0], resInA_ref);
+  }
   BA_PH(0);
   // solveSystem
   const double* p = b->h_sys;
+  b->resInA_solve = (int)p[tot];
   std::vector<double> x;
-  H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
+  if (!vio) H.solveSystem(iteration, lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, x);
+  else {
+    // hand-over of EnergyFunctional.cpp:958-969: the damped Schur system, its right-hand side and the undamped system go to the caller's solver
+    std::vector<double> HP((size_t)n * n), bP(n), HN((size_t)n * n);
+    H.buildGtsamSystem(lambda, p, p + n * n, p + n * n + n, p + 2 * n * n + n, HP.data(), bP.data(), HN.data());
+    fillFrameViews(b);
+    x.assign(n, 0.0);
+    if (!vio->computeBAUpdate) return failmsg("ba_optimize_vio: computeBAUpdate hook missing");
+    if (vio->computeBAUpdate(vio->user, n, HP.data(), bP.data(), lambda, HN.data(), H.F, b->vio_frames.data(), H.c_value, x.data()) != 0)
+      return failmsg("ba_optimize_vio: computeBAUpdate hook reported an error");
+    H.finishExternalSolve(iteration, x);
+  }
   BA_PH(1);
   // resubstituteF_MT + the point part of doStepFromBackup (stepfac 1) ride in front of the linearisation of the stepped state
   ResubArgs X;
@@ -962,8 +1029,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     memset(X.xAd, 0, sizeof(X.xAd));
     memcpy(X.xAd, xAd.data(), sizeof(float) * xAd.size());
   }
-  // doStepFromBackup, frames and calibration; the step norms only feed canbreak, which stays false without the GTSAM path
-  // (FullSystemOptimize.cpp:387,583): not computed
+  // doStepFromBackup, frames and calibration; the step norms only feed canbreak, which stays false without the GTSAM hooks (FullSystemOptimize.cpp:387,523,583)
   if (!b->pre_static_valid) { if (int r = uploadWindowTables(b)) return r; }   // evaluation-point members of the table (R0, t0, b0): once per window
   fillWindow(b);
   dynFromHost(H, b->dyn_cur);         // backed-up state: calibration (W) and step-dependent precalc members, for a relinearisation after a rejected step
@@ -972,7 +1038,21 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   float fs[4];
   H.stepFrames(1.0f, fs);
   H.setPrecalcValues();
-  const double newL = H.calcLEnergyFrames(), newM = H.calcMEnergy();
+  bool canbreak = false;
+  if (vio) {
+    // FullSystemOptimize.cpp:269-313: sumNID = mean |idepth_backup| over the points in window order (the per-point sums mirrored idepth_backup into host memory)
+    float sumNID = 0, numID = 0;
+    for (int pi = 0; pi < H.N; pi++) { sumNID += fabsf(b->h_idepth_backup[pi]); numID++; }
+    sumNID /= numID;
+    const float thOpt = H.S.thOptIterations;
+    canbreak = sqrtf(fs[0]) < 0.0005 * thOpt && sqrtf(fs[1]) < 0.00005 * thOpt && sqrtf(fs[3]) < 0.00005 * thOpt && sqrtf(fs[2]) * sumNID < 0.00005 * thOpt;
+    canbreak = canbreak && vio->canBreak && vio->canBreak(vio->user) != 0;
+  }
+  if (canbreak_out) *canbreak_out = canbreak;
+  const int minOpt = (b->vio_opt && b->vio_opt->minOptIterations >= 0) ? b->vio_opt->minOptIterations : H.S.minOptIterations;
+  if (canbreak && iteration >= minOpt) last = true;
+  const double newL = H.calcLEnergyFrames(), newM = calcMEnergy(b, true);
+  if (dynDuring) b->dynW = vioDynamicWeight(b, lastE[0], b->resInA_solve);   // before deciding whether to accept the step (FullSystemOptimize.cpp:534-538)
   // linearise the stepped state; the kernel's last workgroup sums the energy, sets the newest keyframe's threshold and decides
   fillWindow(b);
   dynFromHost(H, b->dyn_cur);
@@ -980,7 +1060,8 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   {
     BA_PH(2);
     BADecide D = makeDecide(b, 1, true, true);
-    D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2]; D.newL = newL; D.newM = newM;
+    // newEnergy[0] + newEnergy[1] + newEnergyL + newEnergyM / dynamicGTSAMWeight (FullSystemOptimize.cpp:553-554): the quotients are formed here (x / 1.0 == x without hooks)
+    D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2] / b->dynW; D.newL = newL; D.newM = newM / b->dynW;
     D.lastE0_from_ctl = b->pending_reject ? 1 : 0;   // the host has not seen the restored state's energy yet: the device has
     hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
                        b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
@@ -996,10 +1077,12 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     // applyRes + per-point sums + point backup -> accumulation -> stitching: the system of the new state, for the next iteration's solve.
     // (Enqueuing this branch speculatively behind the linearisation, gated on the device-side decision, was measured: no gain — the four
     // launches, not the host round trip, set its length.)
-    if (int r = accumulate(b, true, true, false, true, BA_GATE_ALWAYS)) return r;
+    if (!last) { if (int r = accumulate(b, true, true, false, true, BA_GATE_ALWAYS)) return r; }
+    else { if (int r = applyRes(b)) return r; }
     lastE[0] = b->h_res->E[0]; lastE[1] = newL; lastE[2] = newM;
     H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
     lambda = std::max(lambda * 0.25, 1e-5);
+    if (vio && vio->acceptBAUpdate) vio->acceptBAUpdate(vio->user, lastE[0]);   // FullSystemOptimize.cpp:569-572
   } else {
     // loadSateBackup + linearizeAll (FullSystemOptimize.cpp:575-581): the points are restored by the relinearisation kernel itself; the
     // system in host memory is still the one of the restored state
@@ -1012,7 +1095,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     H.setPrecalcValues();
     fillWindow(b);
     b->dyn_cur = dyn_backup;
-    const double oldL = H.calcLEnergyFrames(), oldM = H.calcMEnergy();
+    const double oldL = H.calcLEnergyFrames(), oldM = calcMEnergy(b, false);
     lastE[1] = oldL; lastE[2] = oldM;
     b->pending_reject = true; b->pending_ticket = D2.ticket; b->pending_trace = trace_slot;
     if (!defer) { if (int r = settleReject(b, lastE, true)) return r; }
@@ -1020,7 +1103,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   }
   BA_PH(5);
 #undef BA_PH
-  b->sys_ready = true;   // accepted: the chain left the system of the new state behind; rejected: the one at hand still is the restored state's
+  b->sys_ready = !(accepted && last);   // accepted: the chain left the system of the new state behind; rejected: the one at hand still is the restored state's
   b->tm.n++;
   return 0;
 }
@@ -1114,14 +1197,25 @@ int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
   return 0;
 }
 
-// FullSystem::optimize (FullSystemOptimize.cpp:417-647), visual-only branch.
-int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
-  BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
+// FullSystem::optimize (FullSystemOptimize.cpp:417-647).  vio == NULL: the library's own damped LDLT (the reference's solver with setting_useGTSAMIntegration off);
+// otherwise every solve, the M-energy term, the dynamic weight and the early exit go through the caller's hooks, in the order the reference calls BAGTSAMIntegration.
+static int optimizeImpl(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_callbacks* vio, const dmvio_hip_ba_vio_options* opt, float* rmse, double* finalEnergy, int* iterations,
+                        double* trace /* 64x4 or NULL */) {
   BAHost& H = b->H;
   if (H.F < 2) { if (rmse) *rmse = 0; return 0; }
   if (H.F < 3) mnumOptIts = 20;
   if (H.F < 4) mnumOptIts = 15;
+  struct VioScope {   // the hooks are those of this call only
+    dmvio_hip_ba* b;
+    ~VioScope() { b->vio = nullptr; b->vio_opt = nullptr; b->H.gtsam = false; b->dynW = 1.0; }
+  } scope{b};
+  b->vio = vio; b->vio_opt = vio ? opt : nullptr; b->dynW = 1.0;
+  const int n = H.n();
+  if (vio) {
+    H.gtsam = true;
+    if (opt && opt->HMForGTSAM && opt->bMForGTSAM) { H.HMG.assign(opt->HMForGTSAM, opt->HMForGTSAM + (size_t)n * n); H.bMG.assign(opt->bMForGTSAM, opt->bMForGTSAM + n); }
+    else { H.HMG.assign((size_t)n * n, 0.0); H.bMG.assign(n, 0.0); }
+  }
   if (int r = dmvio_hip_ba_activate_all(b)) return r;
   double lastE[3];
   // initial linearisation, applyRes and the first system (per-point sums → accumulation → stitching) go out as ONE chain: nothing in it waits for the host, which
@@ -1131,18 +1225,21 @@ int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* 
   if (int r = accumulate(b, true, true, false)) return r;   // backupState of the points rides in the per-point sums; the frames are backed up by the first iteration
   linearizePickUp(b, &lastE[0], false);
   b->sys_ready = true;
-  lastE[1] = H.calcLEnergyFrames(); lastE[2] = H.calcMEnergy();
+  lastE[1] = H.calcLEnergyFrames(); lastE[2] = calcMEnergy(b, false);
   double lambda = 1e-5;
   int done = 0;
   b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;
   for (int iteration = 0; iteration < mnumOptIts; iteration++) {
-    bool acc = false;
-    if (int r = gnIteration(b, iteration, lambda, lastE, acc, true, done + 1)) return r;
+    bool acc = false, canbreak = false;
+    if (int r = gnIteration(b, iteration, lambda, lastE, acc, true, done + 1, iteration == mnumOptIts - 1, &canbreak)) return r;
     done++;
     if (done < 64) { b->trace[done][0] = lastE[0]; b->trace[done][1] = lastE[1]; b->trace[done][2] = lastE[2]; b->trace[done][3] = acc ? 1 : 0; }
-    // canbreak && iteration >= setting_minOptIterations: baIntegration->canBreak() stays false without the GTSAM path
+    // canbreak && iteration >= setting_minOptIterations (FullSystemOptimize.cpp:586): baIntegration->canBreak() stays false without the GTSAM hooks
+    const int minOpt = (opt && vio && opt->minOptIterations >= 0) ? opt->minOptIterations : H.S.minOptIterations;
+    if (canbreak && iteration >= minOpt) break;
   }
   if (int r = settleReject(b, lastE, true)) return r;
+  if (vio) b->dynW = vioDynamicWeight(b, lastE[0], b->resInA_solve);   // "Update again!" (FullSystemOptimize.cpp:594)
   // fix the newest frame's linearisation point, re-linearise with applyRes (FullSystemOptimize.cpp:596-609)
   BAFrameHost& last = H.fr[H.F - 1];
   double newStateZero[10] = {0, 0, 0, 0, 0, 0, last.state[6], last.state[7], 0, 0};
@@ -1159,6 +1256,34 @@ int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* 
   if (finalEnergy) *finalEnergy = fe;
   if (iterations) *iterations = done;
   if (trace) memcpy(trace, b->trace, sizeof(b->trace));
+  if (vio && vio->postOptimization) { fillFrameViews(b); vio->postOptimization(vio->user, H.F, b->vio_frames.data(), H.c_value); }   // FullSystemOptimize.cpp:641
+  return 0;
+}
+int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
+  BA_READY(b);
+  std::lock_guard<std::mutex> lk(b->mu);
+  return optimizeImpl(b, mnumOptIts, nullptr, nullptr, rmse, finalEnergy, iterations, trace);
+}
+// FullSystem::optimize with the reference's DEFAULT solver branch (settings.cpp:37 setting_useGTSAMIntegration = true): the same device-resident loop, the solve and
+// the GTSAM energy term handed to the caller (include/dmvio_hip.h).
+int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_callbacks* cb, const dmvio_hip_ba_vio_options* opt, float* rmse, double* finalEnergy,
+                              int* iterations, double* trace) {
+  BA_READY(b);
+  if (!cb || !cb->computeBAUpdate) return failmsg("ba_optimize_vio: the computeBAUpdate hook is required (dmvio_hip_ba_optimize runs the library's own solver)");
+  if (sharded(b)) return failmsg("ba_optimize_vio: not available for a window sharded over ranks (every rank would have to run identical hooks)");
+  std::lock_guard<std::mutex> lk(b->mu);
+  return optimizeImpl(b, mnumOptIts, cb, opt, rmse, finalEnergy, iterations, trace);
+}
+// The library's own solver as a computeBAUpdate hook (EnergyFunctional.cpp:971-973: diagonal pre-scaling (H_ii + 10)^-1/2, pivoted LDL^T): for hooks that fall back to the
+// visual-only step, and the check that the hook path reproduces dmvio_hip_ba_optimize bit for bit.  HPassed is n x n row-major; host-only.
+int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b_in, double* x_out) {
+  if (!HPassed || !b_in || !x_out || n < 1 || n > 4 + 8 * BA_MAXF) return failmsg("ba_solve_ldlt: bad argument");
+  std::vector<double> Ht((size_t)n * n, 0.0);
+  double sv[4 + 8 * BA_MAXF], bs[4 + 8 * BA_MAXF];
+  for (int i = 0; i < n; i++) sv[i] = 1.0 / std::sqrt(HPassed[(size_t)i * n + i] + 10);
+  for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) Ht[(size_t)j * n + i] = sv[i] * HPassed[(size_t)i * n + j] * sv[j]; bs[i] = sv[i] * b_in[i]; }
+  BAHost::ldltSolveTransposed(Ht.data(), n, bs, n);
+  for (int i = 0; i < n; i++) x_out[i] = sv[i] * bs[i];
   return 0;
 }
 

@@ -412,9 +412,13 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
 #define EVAL_RECORD_FLOATS (ACC_PAD + 16)   // per-workgroup result record in host-coherent memory: ACC_PAD sums, then the ticket
 #define EVAL_SERVER_MAX_BLOCKS 64
 #define EVAL_QUIT_BIT 0x80000000u
+// session: the identity of this launch's SESSION (serverStart .. serverStop on the host), also kept in dword EVAL_MAIL_SESSION of the mailbox.  serverStop only posts the quit
+// ticket and returns; when the next session's first tickets overwrite it before every workgroup of this launch has polled it, those tickets carry another session
+// number — a workgroup that reads one leaves instead of serving the next frame against this launch's slot and template.
+#define EVAL_MAIL_SESSION (EVAL_MAIL_DWORDS - 2)
 template <int T>
 __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const FrameStore fs, const int slot, const unsigned int* __restrict__ mail, unsigned int* __restrict__ leave,
-                                                   const unsigned int first_seen, const long long idle_ticks, float* __restrict__ out_host) {
+                                                   const unsigned int first_seen, const long long idle_ticks, float* __restrict__ out_host, const unsigned int session) {
   __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
   __shared__ float s_partH[(T / 64) * 256];
   __shared__ float s_partS[T / 64][8];
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
       for (;;) {
         v = threadIdx.x < EVAL_MAIL_DWORDS ? __hip_atomic_load(mail + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
         front = __builtin_amdgcn_readlane(v, 0); back = __builtin_amdgcn_readlane(v, EVAL_MAIL_DWORDS - 1);
-        if (front == back && front != seen) break;
+        if (front == back && front != seen) { if (__builtin_amdgcn_readlane(v, EVAL_MAIL_SESSION) != session) timeout = true; break; }
         // leaving is collective: the first workgroup whose idle limit expires marks this launch (its first ticket is unique to it) and the others follow at their next
         // poll — a request that arrives at that very moment may be picked up by some workgroups only; the host then finds the kernel gone and posts it again
         if (__hip_atomic_load(leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == first_seen) { timeout = true; break; }

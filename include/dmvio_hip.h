@@ -134,6 +134,10 @@ int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_expo
  * frame, every calcRes + calcGSSSE evaluation a request through host-coherent memory, the 8x8 solve / SE3 exp on the CPU (sub-microsecond there, 6.5 us per iteration on one
  * wavefront); 0 = the device-resident LM (cluster mode).  Same evaluation sums and iteration counts either way; batches of two and more always run device-resident. */
 int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm);
+/* Idle limit of the evaluation server (the resident kernel behind a single-frame dmvio_hip_tracker_track / _track_vio call): it leaves after this long without a request
+ * and is started again by the next one.  Default 5000 us; raise it when the computeCoarseUpdate hook (IMUIntegration's factor-graph solve) regularly takes longer, so
+ * that an LM iteration does not pay a relaunch.  100 us .. 2 s. */
+int dmvio_hip_tracker_set_server_idle_us(dmvio_hip_tracker* trk, int microseconds);
 /* The reference's DEFAULT tracking path (settings.cpp:36 setting_useIMU = true): trackNewestCoarse with every LM step handed to the
  * host (CoarseTracker.cpp:612-637).  The callbacks mirror the three members of dmvio::IMUIntegration the tracker calls
  * (src/IMU/IMUIntegration.hpp:106-112):
@@ -328,8 +332,55 @@ int dmvio_hip_ba_restore(dmvio_hip_ba* ba);
 int dmvio_hip_ba_linearize_local(dmvio_hip_ba* ba, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies);
 int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* ba, float th);
 int dmvio_hip_ba_energy_terms(dmvio_hip_ba* ba, double* EL, double* EM);
-/* FullSystem::optimize(mnumOptIts) (FullSystemOptimize.cpp:417-647): returns statistics_lastFineTrackRMSE in *rmse */
+/* FullSystem::optimize(mnumOptIts) (FullSystemOptimize.cpp:417-647): returns statistics_lastFineTrackRMSE in *rmse; the solver is the reference's
+ * non-GTSAM branch (EnergyFunctional.cpp:971-973).  trace (may be NULL): 64 rows [E_A, E_L, E_M, accepted], row 0 = the initial state.  After the call the
+ * per-point sums (dmvio_hip_ba_get_point_acc / _get_point_hessian) and resInA are those of the LAST solveSystemF, as in the reference. */
 int dmvio_hip_ba_optimize(dmvio_hip_ba* ba, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
+/* The reference's DEFAULT solver branch (settings.cpp:37 setting_useGTSAMIntegration = true) inside the same device-resident loop.  The hooks mirror the members of
+ * dmvio::BAGTSAMIntegration that EnergyFunctional / FullSystem::optimize call (src/GTSAMIntegration/BAGTSAMIntegration.h), in the reference's call order:
+ *   updateBAValues(frames)                          EnergyFunctional.cpp:339 (calcMEnergyF(false): before the loop and after every rejected step)
+ *   getBAEnergy(useNewValues)                       EnergyFunctional.cpp:341; the library adds delta.dot(2 bMForGTSAM + HMForGTSAM delta)
+ *   updateDynamicWeight(energy, rmse, trackingGood) FullSystemOptimize.cpp:491-503 (iteration 0, or every iteration and once more before the accept test with
+ *                                                   updateDynamicWeightDuringOptimization), :594 after the loop; the accept test divides both M-energies by it (:553)
+ *   computeBAUpdate(HPassed, b, lambda, frames, HNoLambda) -> x   EnergyFunctional.cpp:958-969.  n = 4 + 8F, matrices n x n row-major, order [calib4 | per frame
+ *                                                   trans3 rot3 a b] in the reference's unscaled units; x = MINUS the step; nonzero return aborts the call.  The
+ *                                                   library then orthogonalises x from iteration 2 on (:977-981) and back-substitutes on the device
+ *   canBreak()                                      FullSystemOptimize.cpp:523 (and-ed with doStepFromBackup's step-norm test; ends the loop from minOptIterations on)
+ *   acceptBAUpdate(energy)                          FullSystemOptimize.cpp:569-572
+ *   postOptimization(frames)                        FullSystemOptimize.cpp:641
+ * `frames` is what the hooks read through std::vector<EFFrame*> in the reference (BAGTSAMIntegration.cpp:97-120, computeEvaluationPointValues): per keyframe
+ * PRE_worldToCam, worldToCam_evalPT, get_state(), get_state_zero(), FrameHessian::frameID; calib_value = CalibHessian::value.  Every hook except computeBAUpdate may
+ * be NULL (no-op / 0 energy / weight 1 / never break).  The hooks run on the calling thread with the handle locked: they must not call entry points of this handle.
+ * dmvio_hip_ba_solve_ldlt is the reference's own solve of that branch's `else` (diagonal pre-scaling + pivoted LDL^T) for hooks that fall back to it. */
+typedef struct dmvio_hip_ba_frame_view {
+  int frameID, index;
+  double PRE_worldToCam7[7], worldToCam_evalPT7[7], state10[10], state_zero10[10];
+} dmvio_hip_ba_frame_view;
+typedef struct dmvio_hip_ba_callbacks {
+  void* user;
+  int (*computeBAUpdate)(void* user, int n, const double* HPassed, const double* b, double lambda, const double* HNoLambda, int F, const dmvio_hip_ba_frame_view* frames,
+                         const double calib_value[4], double* x_out);
+  void (*acceptBAUpdate)(void* user, double energy);
+  double (*getBAEnergy)(void* user, int useNewValues);
+  void (*updateBAValues)(void* user, int F, const dmvio_hip_ba_frame_view* frames, const double calib_value[4]);
+  double (*updateDynamicWeight)(void* user, double energy, double rmse, int coarseTrackingWasGood);
+  int (*canBreak)(void* user);
+  void (*postOptimization)(void* user, int F, const dmvio_hip_ba_frame_view* frames, const double calib_value[4]);
+} dmvio_hip_ba_callbacks;
+typedef struct dmvio_hip_ba_vio_options {
+  int coarseTrackingWasGood;                  /* frameHessians.back()->shell->trackingWasGood */
+  int updateDynamicWeightDuringOptimization;  /* IMUSettings::updateDynamicWeightDuringOptimization */
+  int minOptIterations;                       /* setting_minOptIterations (settings.cpp:101, 1); < 0 = that default */
+  int resInA_at_entry;                        /* ef->resInA before the call (left by the previous solveSystemF; enters the rmse of the first updateDynamicWeight; 0 before the
+                                                 very first solve, which makes that rmse inf in the reference too); < 0: the current count */
+  const double* HMForGTSAM;                   /* EnergyFunctional::HMForGTSAM / bMForGTSAM (n x n row-major / n), NULL = zero */
+  const double* bMForGTSAM;
+} dmvio_hip_ba_vio_options;
+int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* ba, int mnumOptIts, const dmvio_hip_ba_callbacks* cb, const dmvio_hip_ba_vio_options* opt, float* rmse, double* finalEnergy,
+                              int* iterations, double* trace);
+int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b, double* x_out);
+/* PointHessian::idepth_hessian (set by AccumulatedSCHessianSSE::addPoint, AccumulatedSCHessian.cpp:42,50; read by FullSystem::flagPointsForRemoval, FullSystem.cpp:825) */
+int dmvio_hip_ba_get_point_hessian(dmvio_hip_ba* ba, float* idepth_hessian);
 
 /* ------------------------------------------------------------------------------------------------------------------------
  * Immature points: candidate points traced along their epipolar line in every new frame.

@@ -1007,6 +1007,120 @@ float ref_ba_optimize(void* p, int mnumOptIts, int* n_trace, double* trace /* up
 	if (trace) memcpy(trace, W->trace.data(), sizeof(double) * 2 * n);
 	return rmse;
 }
+// ---- the DEFAULT solver branch of the reference (settings.cpp:37 setting_useGTSAMIntegration = true; EnergyFunctional.cpp:335-341, 958-969; FullSystemOptimize.cpp:491-503,
+// 523, 534-538, 569-572, 594, 641) driven by a small stand-in for the GTSAM graph: ONE independent quadratic factor  E(s) = sum_i w_i (s_i - g_i)^2  over the stacked
+// window state s = [CalibHessian::value | per keyframe get_state().head<8>()] (H = diag(w), b = w .* (s - g): a prior pulling the keyframes towards g), solved together
+// with the photometric system exactly like BAGTSAMIntegration::computeBAUpdate does (add the Hessians, damp the extra one by (1 + lambda), precondition by
+// (diag + 10)^-1/2, LDL^T; BAGTSAMIntegration.cpp:160-186).  The SAME object serves both sides of a test: the reference calls it through the facade's hooks
+// (ref_ba_optimize_gtsam), the HIP library's callbacks call it through the extern "C" functions below — so identical hand-overs produce identical steps, and the
+// event logs of the two runs can be compared entry by entry.
+struct GtsamFacade
+{
+	int n = 0;
+	std::vector<double> w, goal, cur, nxt;
+	bool haveGoal = false, canBreakFlag = false;
+	double goalOffset = 0, weightValue = 1, breakBelow = 0;
+	std::vector<double> log;     // per computeBAUpdate: lambda, HPassed (n*n), b (n), HNoLambda (n*n)
+	std::vector<double> events;  // per hook call: code, a, b, c  (1 updateBAValues, 2 computeBAUpdate(lambda, |x|max), 3 getBAEnergy(useNew -> value), 4 acceptBAUpdate(E),
+	                             // 5 updateDynamicWeight(E, rmse, good), 6 canBreak, 7 postOptimization)
+	void ev(double c, double a = 0, double b = 0, double d = 0) { events.push_back(c); events.push_back(a); events.push_back(b); events.push_back(d); }
+	void setValues(const double* states)
+	{
+		cur.assign(states, states + n);
+		if (!haveGoal)
+		{
+			goal = cur;
+			for (int i = 4; i < n; i++) { const int d = (i - 4) % 8; if (d < 6) goal[i] += goalOffset * (((i * 7) % 5) - 2) * 0.5; }
+			haveGoal = true;
+		}
+	}
+	double energy(const std::vector<double>& s) const { double e = 0; for (int i = 0; i < n; i++) e += w[i] * (s[i] - goal[i]) * (s[i] - goal[i]); return e; }
+};
+static void statesOf(FullSystem* fs, std::vector<EFFrame*>& frames, std::vector<double>& out)
+{
+	out.assign(CPARS + 8 * frames.size(), 0.0);
+	for (int i = 0; i < CPARS; i++) out[i] = fs->Hcalib.value[i];
+	for (EFFrame* h : frames) { Vec10 st = h->data->get_state(); for (int i = 0; i < 8; i++) out[CPARS + 8 * h->idx + i] = st[i]; }
+}
+void* ref_facade_create(int n, const double* w, double goalOffset, double dynWeight, double breakBelow)
+{
+	GtsamFacade* f = new GtsamFacade();
+	f->n = n; f->w.assign(w, w + n); f->goalOffset = goalOffset; f->weightValue = dynWeight; f->breakBelow = breakBelow;
+	return f;
+}
+void ref_facade_destroy(void* p) { delete (GtsamFacade*)p; }
+void ref_facade_update_values(void* p, const double* states) { GtsamFacade* f = (GtsamFacade*)p; f->setValues(states); f->ev(1); }
+int ref_facade_compute(void* p, const double* HP, const double* b, double lambda, const double* HN, const double* states, double* x_out)
+{
+	GtsamFacade* f = (GtsamFacade*)p; const int n = f->n;
+	f->setValues(states);   // computeBAUpdate starts with updateBAValues(frames) (BAGTSAMIntegration.cpp:130)
+	f->log.push_back(lambda);
+	f->log.insert(f->log.end(), HP, HP + (size_t)n * n); f->log.insert(f->log.end(), b, b + n); f->log.insert(f->log.end(), HN, HN + (size_t)n * n);
+	MatXX HFull = MatXX::Zero(n, n); VecX bFull = VecX::Zero(n);
+	for (int i = 0; i < n; i++) { HFull(i, i) = f->w[i]; bFull[i] = f->w[i] * (f->cur[i] - f->goal[i]); }
+	for (int i = 0; i < n; i++) HFull(i, i) *= (1 + lambda);
+	for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HFull(i, j) += HP[(size_t)i * n + j]; bFull[i] += b[i]; }
+	VecX SVecI = (HFull.diagonal() + VecX::Constant(HFull.cols(), 10)).cwiseSqrt().cwiseInverse();
+	MatXX H_scaled = SVecI.asDiagonal() * HFull * SVecI.asDiagonal();
+	VecX inc = SVecI.asDiagonal() * H_scaled.ldlt().solve(SVecI.asDiagonal() * bFull);
+	f->nxt = f->cur;
+	double xmax = 0;
+	for (int i = 0; i < n; i++) { x_out[i] = inc[i]; f->nxt[i] = f->cur[i] - inc[i]; if (i >= 4) xmax = std::max(xmax, std::fabs(inc[i])); }
+	f->canBreakFlag = xmax < f->breakBelow;
+	f->ev(2, lambda, xmax);
+	return 0;
+}
+double ref_facade_energy(void* p, int useNew) { GtsamFacade* f = (GtsamFacade*)p; const double e = f->energy(useNew ? f->nxt : f->cur); f->ev(3, useNew, e); return e; }
+void ref_facade_accept(void* p, double E) { GtsamFacade* f = (GtsamFacade*)p; f->cur = f->nxt; f->ev(4, E); }
+double ref_facade_weight(void* p, double E, double rmse, int good) { GtsamFacade* f = (GtsamFacade*)p; f->ev(5, E, rmse, good); return f->weightValue; }
+int ref_facade_can_break(void* p) { GtsamFacade* f = (GtsamFacade*)p; f->ev(6, f->canBreakFlag); return f->canBreakFlag ? 1 : 0; }
+void ref_facade_post(void* p, const double* states) { GtsamFacade* f = (GtsamFacade*)p; f->setValues(states); f->ev(7); }
+int ref_facade_n_events(void* p) { return (int)((GtsamFacade*)p)->events.size() / 4; }
+void ref_facade_get_events(void* p, double* out) { GtsamFacade* f = (GtsamFacade*)p; memcpy(out, f->events.data(), sizeof(double) * f->events.size()); }
+int ref_facade_n_log(void* p) { GtsamFacade* f = (GtsamFacade*)p; return (int)(f->log.size() / (1 + 2 * (size_t)f->n * f->n + f->n)); }
+void ref_facade_get_log(void* p, double* out) { GtsamFacade* f = (GtsamFacade*)p; memcpy(out, f->log.data(), sizeof(double) * f->log.size()); }
+void ref_facade_get_goal(void* p, double* out) { GtsamFacade* f = (GtsamFacade*)p; memcpy(out, f->goal.data(), sizeof(double) * f->goal.size()); }
+// EnergyFunctional::HMForGTSAM / bMForGTSAM (EnergyFunctional.h:108-111)
+void ref_ba_set_marg_prior_gtsam(void* p, const double* HM, const double* bM)
+{
+	EnergyFunctional* ef = ((RefWindow*)p)->fs->ef;
+	const int n = CPARS + 8 * ef->nFrames;
+	ef->HMForGTSAM = MatXX::Zero(n, n); ef->bMForGTSAM = VecX::Zero(n);
+	for (int i = 0; i < n; i++) { ef->bMForGTSAM[i] = bM[i]; for (int j = 0; j < n; j++) ef->HMForGTSAM(i, j) = HM[(size_t)i * n + j]; }
+}
+void ref_ba_set_resInA(void* p, int v) { ((RefWindow*)p)->fs->ef->resInA = v; }
+int ref_ba_get_resInA(void* p) { return ((RefWindow*)p)->fs->ef->resInA; }
+float ref_ba_optimize(void* p, int mnumOptIts, int* n_trace, double* trace);
+// FullSystem::optimize, verbatim, on its default branch: setting_useGTSAMIntegration = true with `facade` behind every BAGTSAMIntegration member the loop calls
+float ref_ba_optimize_gtsam(void* p, int mnumOptIts, void* facade, int updateDuring, int trackingWasGood, int minOptIterations, int* n_trace, double* trace)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	GtsamFacade* f = (GtsamFacade*)facade;
+	dmvio::BAGTSAMIntegration* ba = fs->baIntegration;
+	ba->computeBAUpdateFramesHook = [fs, f](const MatXX& H, const VecX& b, double lambda, std::vector<EFFrame*>& frames, const MatXX& HNoLambda) {
+		const int n = (int)b.size();
+		std::vector<double> HP((size_t)n * n), HN((size_t)n * n), bb(n), st, x(n);
+		for (int i = 0; i < n; i++) { bb[i] = b[i]; for (int j = 0; j < n; j++) { HP[(size_t)i * n + j] = H(i, j); HN[(size_t)i * n + j] = HNoLambda(i, j); } }
+		statesOf(fs, frames, st);
+		ref_facade_compute(f, HP.data(), bb.data(), lambda, HN.data(), st.data(), x.data());
+		VecX xv(n); for (int i = 0; i < n; i++) xv[i] = x[i];
+		return xv;
+	};
+	ba->updateBAValuesHook = [fs, f](std::vector<EFFrame*>& frames) { std::vector<double> st; statesOf(fs, frames, st); ref_facade_update_values(f, st.data()); };
+	ba->postOptimizationHook = [fs, f](std::vector<EFFrame*>& frames) { std::vector<double> st; statesOf(fs, frames, st); ref_facade_post(f, st.data()); };
+	ba->getBAEnergyHook = [f](bool useNew) { return ref_facade_energy(f, useNew ? 1 : 0); };
+	ba->acceptBAUpdateHook = [f](double e) { ref_facade_accept(f, e); };
+	ba->updateDynamicWeightHook = [f](double e, double rmse, bool good) { return ref_facade_weight(f, e, rmse, good ? 1 : 0); };
+	ba->canBreakHook = [f]() { return ref_facade_can_break(f) != 0; };
+	const bool g0 = setting_useGTSAMIntegration, d0 = g_imuSettings.updateDynamicWeightDuringOptimization; const int m0 = setting_minOptIterations;
+	setting_useGTSAMIntegration = true; g_imuSettings.updateDynamicWeightDuringOptimization = updateDuring != 0;
+	if (minOptIterations >= 0) setting_minOptIterations = minOptIterations;
+	fs->frameHessians.back()->shell->trackingWasGood = trackingWasGood != 0;
+	const float rmse = ref_ba_optimize(p, mnumOptIts, n_trace, trace);
+	setting_useGTSAMIntegration = g0; g_imuSettings.updateDynamicWeightDuringOptimization = d0; setting_minOptIterations = m0;
+	*ba = dmvio::BAGTSAMIntegration();
+	return rmse;
+}
 int ref_ba_log(void* p, char* out, int cap) { RefWindow* W = (RefWindow*)p; int n = std::min((int)W->log.size(), cap - 1); memcpy(out, W->log.data(), n); out[n] = 0; return n; }
 // flagPointsForRemoval + marginalizePointsF as makeKeyFrame runs them (FullSystem.cpp:1485-1492), with `flagged[k]` frames flagged
 // for marginalisation.  decision per point: 0 = kept, 1 = marginalised, 2 = dropped.  Hadd / badd = what marginalizePointsF added to HM / bM

@@ -409,7 +409,81 @@ def _ba_sig(L):
     L.ref_ba_log.argtypes = [vp, C.c_char_p, C.c_int]
     L.ref_ba_marginalize_points.argtypes = [vp, c_u8, c_u8, c_d, c_d]
     L.ref_ba_marginalize_frame.argtypes = [vp, C.c_int, c_d, c_d]
+    L.ref_facade_create.restype = vp; L.ref_facade_create.argtypes = [C.c_int, c_d, C.c_double, C.c_double, C.c_double]
+    L.ref_facade_destroy.argtypes = [vp]
+    L.ref_facade_update_values.argtypes = [vp, c_d]
+    L.ref_facade_compute.argtypes = [vp, c_d, c_d, C.c_double, c_d, c_d, c_d]
+    L.ref_facade_energy.restype = C.c_double; L.ref_facade_energy.argtypes = [vp, C.c_int]
+    L.ref_facade_accept.argtypes = [vp, C.c_double]
+    L.ref_facade_weight.restype = C.c_double; L.ref_facade_weight.argtypes = [vp, C.c_double, C.c_double, C.c_int]
+    L.ref_facade_can_break.argtypes = [vp]
+    L.ref_facade_post.argtypes = [vp, c_d]
+    L.ref_facade_n_events.argtypes = [vp]; L.ref_facade_get_events.argtypes = [vp, c_d]
+    L.ref_facade_n_log.argtypes = [vp]; L.ref_facade_get_log.argtypes = [vp, c_d]
+    L.ref_facade_get_goal.argtypes = [vp, c_d]
+    L.ref_ba_set_marg_prior_gtsam.argtypes = [vp, c_d, c_d]
+    L.ref_ba_set_resInA.argtypes = [vp, C.c_int]; L.ref_ba_get_resInA.argtypes = [vp]
+    L.ref_ba_optimize_gtsam.restype = C.c_float; L.ref_ba_optimize_gtsam.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, c_i, c_d]
     _BA_SIG = True
+
+
+class GtsamFacade:
+    """Stand-in for the GTSAM graph behind dmvio::BAGTSAMIntegration (oracle/ref_glue.cpp, GtsamFacade): one quadratic factor over the stacked window state
+    [calib value (4) | per keyframe state (8)], solved together with the photometric system the way BAGTSAMIntegration::computeBAUpdate does.  The reference calls it
+    through the shim's hooks (BAWindow.optimize_gtsam); its methods have the signatures dmvio_amd.BundleAdjusterHip.optimize_vio expects of `hooks`, so the very same
+    arithmetic answers the HIP library's callbacks.  events(): one row [code, a, b, c] per hook call; handovers(): what computeBAUpdate received."""
+
+    def __init__(self, n, w, goal_offset=0.0, dyn_weight=1.0, break_below=0.0):
+        self.L = lib(); _ba_sig(self.L)
+        self.n = n
+        self.p = vp(self.L.ref_facade_create(n, _d(_f64(w)), float(goal_offset), float(dyn_weight), float(break_below)))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.ref_facade_destroy(self.p); self.p = None
+
+    def _states(self, frames, calib):
+        s = np.zeros(self.n); s[:4] = calib
+        for f in frames:
+            s[4 + 8 * f["index"]:12 + 8 * f["index"]] = f["state"][:8]
+        return s
+
+    # hooks of BundleAdjusterHip.optimize_vio
+    def computeBAUpdate(self, HPassed, b, lam, HNoLambda, frames, calib):
+        x = np.zeros(self.n)
+        self.L.ref_facade_compute(self.p, _d(_f64(HPassed)), _d(_f64(b)), float(lam), _d(_f64(HNoLambda)), _d(self._states(frames, calib)), _d(x))
+        return x
+
+    def updateBAValues(self, frames, calib):
+        self.L.ref_facade_update_values(self.p, _d(self._states(frames, calib)))
+
+    def postOptimization(self, frames, calib):
+        self.L.ref_facade_post(self.p, _d(self._states(frames, calib)))
+
+    def getBAEnergy(self, useNew):
+        return self.L.ref_facade_energy(self.p, 1 if useNew else 0)
+
+    def acceptBAUpdate(self, e):
+        self.L.ref_facade_accept(self.p, float(e))
+
+    def updateDynamicWeight(self, e, rmse, good):
+        return self.L.ref_facade_weight(self.p, float(e), float(rmse), 1 if good else 0)
+
+    def canBreak(self):
+        return self.L.ref_facade_can_break(self.p) != 0
+
+    def events(self):
+        n = self.L.ref_facade_n_events(self.p); o = np.zeros((n, 4))
+        if n:
+            self.L.ref_facade_get_events(self.p, _d(o))
+        return o
+
+    def handovers(self):
+        k = self.L.ref_facade_n_log(self.p); n = self.n; w = 1 + 2 * n * n + n
+        o = np.zeros((k, w))
+        if k:
+            self.L.ref_facade_get_log(self.p, _d(o))
+        return [dict(lam=r[0], HPassed=r[1:1 + n * n].reshape(n, n), b=r[1 + n * n:1 + n * n + n], HNoLambda=r[1 + n * n + n:].reshape(n, n)) for r in o]
 
 
 class BAWindow:
@@ -576,6 +650,21 @@ class BAWindow:
         rmse = self.L.ref_ba_optimize(self.p, its, C.byref(n), _d(tr))
         tr = tr[:n.value]
         return dict(rmse=rmse, trace=tr, iterations=int(np.sum(tr[:, 1] >= 0)), finalEnergy=float(tr[tr[:, 1] != 0][-1, 0]) if len(tr) else float("nan"))
+
+    def optimize_gtsam(self, its, facade, update_during=False, tracking_was_good=True, min_opt_its=-1):
+        """FullSystem::optimize on the reference's default branch (setting_useGTSAMIntegration) with `facade` (GtsamFacade) behind BAGTSAMIntegration."""
+        n = C.c_int(0); tr = np.zeros((64, 2))
+        rmse = self.L.ref_ba_optimize_gtsam(self.p, its, facade.p, 1 if update_during else 0, 1 if tracking_was_good else 0, int(min_opt_its), C.byref(n), _d(tr))
+        tr = tr[:n.value]
+        return dict(rmse=rmse, trace=tr, iterations=int(np.sum(tr[:, 1] >= 0)), finalEnergy=float(tr[tr[:, 1] != 0][-1, 0]) if len(tr) else float("nan"))
+
+    def set_marg_prior_gtsam(self, HM, bM):
+        self.L.ref_ba_set_marg_prior_gtsam(self.p, _d(_f64(HM)), _d(_f64(bM)))
+
+    def resInA(self, v=None):
+        if v is not None:
+            self.L.ref_ba_set_resInA(self.p, int(v))
+        return self.L.ref_ba_get_resInA(self.p)
 
     def log(self):
         buf = C.create_string_buffer(1 << 20); self.L.ref_ba_log(self.p, buf, len(buf)); return buf.value.decode(errors="replace")

@@ -35,16 +35,24 @@ struct TransformDSOToIMU
 class BAGTSAMIntegration
 {
 public:
-	// hooks
+	// hooks: every member of the real class that EnergyFunctional / FullSystem::optimize call on the default (setting_useGTSAMIntegration) branch can be observed / driven
+	// by a test (src/GTSAMIntegration/BAGTSAMIntegration.cpp:97-120 updateBAValues, :124-251 computeBAUpdate, :358 acceptBAUpdate, :442 getBAEnergy, :453 canBreak,
+	// :508 postOptimization, :526 updateDynamicWeight).  Unset hooks behave like a graph without factors.
 	std::function<dso::VecX(const dso::MatXX&, const dso::VecX&, double, const dso::MatXX&)> computeBAUpdateHook;
+	std::function<dso::VecX(const dso::MatXX&, const dso::VecX&, double, std::vector<dso::EFFrame*>&, const dso::MatXX&)> computeBAUpdateFramesHook;
+	std::function<double(double, double, bool)> updateDynamicWeightHook;
+	std::function<void(double)> acceptBAUpdateHook;
+	std::function<void(std::vector<dso::EFFrame*>&)> updateBAValuesHook, postOptimizationHook;
+	std::function<double(bool)> getBAEnergyHook;
+	std::function<bool()> canBreakHook;
 	bool canBreakValue = false;  // BAGTSAMIntegration.h:225: canBreakOptimization starts false and only computeBAUpdate sets it
 
-	double updateDynamicWeight(double, double, bool) { return 1.0; }
-	bool canBreak() { return canBreakValue; }
-	void acceptBAUpdate(double) {}
-	void postOptimization(std::vector<dso::EFFrame*>&) {}
-	void updateBAValues(std::vector<dso::EFFrame*>&) {}
-	double getBAEnergy(bool) { return 0.0; }
+	double updateDynamicWeight(double e, double rmse, bool good) { return updateDynamicWeightHook ? updateDynamicWeightHook(e, rmse, good) : 1.0; }
+	bool canBreak() { return canBreakHook ? canBreakHook() : canBreakValue; }
+	void acceptBAUpdate(double e) { if (acceptBAUpdateHook) acceptBAUpdateHook(e); }
+	void postOptimization(std::vector<dso::EFFrame*>& f) { if (postOptimizationHook) postOptimizationHook(f); }
+	void updateBAValues(std::vector<dso::EFFrame*>& f) { if (updateBAValuesHook) updateBAValuesHook(f); }
+	double getBAEnergy(bool useNew) { return getBAEnergyHook ? getBAEnergyHook(useNew) : 0.0; }
 	void addMarginalizedPointsBA(const dso::MatXX&, const dso::VecX&, std::vector<dso::EFFrame*>&) {}
 	void addPriorBA(dso::EFFrame*, const dso::MatXX&, const dso::VecX&) {}
 	template<typename A, typename B> void addPriorBA(dso::EFFrame*, const A&, const B&) {}
@@ -52,8 +60,9 @@ public:
 	void addKeyframeToBA(int, const Sophus::SE3d&, std::vector<dso::EFFrame*>&) {}
 	void updateBAOrdering(std::vector<dso::EFFrame*>&) {}
 	void addFirstBAFrame(int) {}
-	dso::VecX computeBAUpdate(const dso::MatXX& H, const dso::VecX& b, double lambda, std::vector<dso::EFFrame*>&, const dso::MatXX& HNoLambda)
+	dso::VecX computeBAUpdate(const dso::MatXX& H, const dso::VecX& b, double lambda, std::vector<dso::EFFrame*>& frames, const dso::MatXX& HNoLambda)
 	{
+		if (computeBAUpdateFramesHook) return computeBAUpdateFramesHook(H, b, lambda, frames, HNoLambda);
 		return computeBAUpdateHook(H, b, lambda, HNoLambda);
 	}
 };

@@ -73,3 +73,39 @@ def test_raw_device_batch_equals_single_uploads(pkg, oracle, gpu_required, bits,
         und.from_raw_device_batch([0, 2 * B], dev.data_ptr(), stride)            # slot out of range
     with pytest.raises(pkg.HipLibraryError):
         und.from_raw_device_batch([0, 1], dev.data_ptr(), raws[0].nbytes - 2)    # frames would overlap
+
+
+def test_reference_generated_remap_tables_are_accepted(pkg, oracle, gpu_required, tmp_path):
+    """The tables Undistort::getUndistorterForFile builds itself (Undistort.cpp:266-384, 900-942: entries with 0 < x < wOrg-1, 0 < y < hOrg-1, everything else -1) — a `crop`
+    rectification whose border pixels map into the last raw row — are taken by the HIP undistorter and give the reference's own image bit for bit.  Entries inside
+    (wOrg-2, wOrg-1): their taps (int)x, (int)x+1 <= wOrg-1 are in bounds."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_py as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libref.so not built and /root/reference absent")
+    wOrg, hOrg, w, h = 376, 288, 320, 240
+    rng = np.random.default_rng(17)
+    cam = tmp_path / "camera.txt"
+    cam.write_text("RadTan 0.535 0.669 0.493 0.505 -0.28 0.07 0.0002 -0.0003\n%d %d\ncrop\n%d %d\n" % (wOrg, hOrg, w, h))
+    g = np.cumsum(rng.uniform(0.5, 1.5, 256)) ** 1.1
+    gam = tmp_path / "pcalib.txt"
+    gam.write_text(" ".join("%.9g" % x for x in g) + "\n")
+    yy, xx = np.mgrid[0:hOrg, 0:wOrg]
+    vig = (65535 * (1 - 0.4 * (((xx - wOrg / 2) / wOrg) ** 2 + ((yy - hOrg / 2) / hOrg) ** 2))).astype(np.uint16)
+    U = R.Undistorter(cam, gam, vig)
+    rx, ry = np.array(U.remapX, np.float32).copy(), np.array(U.remapY, np.float32).copy()
+    assert ((ry > hOrg - 2) & (ry < hOrg - 1)).sum() > 10      # the reference's own table has entries in the last raw row's interval
+    # make sure the open intervals next to the last column / row are populated (what a crop / full calibration produces at its borders)
+    valid = np.nonzero(rx.reshape(-1) >= 0)[0]
+    rx.flat[valid[5]] = wOrg - 1.5; ry.flat[valid[9]] = hOrg - 1.25; rx.flat[valid[11]] = np.nextafter(np.float32(wOrg - 1), np.float32(0)); ry.flat[valid[11]] = np.nextafter(np.float32(hOrg - 1), np.float32(0))
+    raw = rng.integers(0, 256, (hOrg, wOrg)).astype(np.uint8)
+    ctx = pkg.Context(w, h, n_slots=1)
+    und = pkg.UndistorterHip(ctx, wOrg, hOrg, 8, U.G, U.vignetteMapInv, rx, ry)
+    img = und.upload(0, raw)
+    ref = oracle.undistort(raw, U.G, U.vignetteMapInv, rx, ry, w, h)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    # and the unmodified tables against the reference's own undistort
+    und2 = pkg.UndistorterHip(ctx, wOrg, hOrg, 8, U.G, U.vignetteMapInv, U.remapX, U.remapY)
+    ref_img, _ = U.undistort(raw, exposure=0.02)
+    assert np.array_equal(und2.upload(0, raw).view(np.uint32), np.asarray(ref_img, np.float32).view(np.uint32))
