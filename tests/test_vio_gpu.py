@@ -173,3 +173,17 @@ def test_evaluation_server_restarts_after_a_slow_callback(setup):
     # and a batch launched right after a server session runs behind it on the same stream
     b = trk.track_batch([1, 2, 3], [IDENT] * 3, [(0.0, 0.0)] * 3)
     assert b["good"].all() and np.abs(b["pose7"][0] - ref["pose7"]).max() < 1e-14
+
+
+def test_back_to_back_single_frame_tracks_from_c_keep_their_sessions_apart(pkg, gpu_required, tmp_path):
+    """tests/server_session_harness.c: 400 dmvio_hip_tracker_track calls in a C loop, two different new frames alternating — the evaluation server of one call must never
+    serve a request of the next (each launch carries a session number)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    exe = tmp_path / "server_session_harness"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "server_session_harness.c"), "-I" + os.path.dirname(pkg.INCLUDE_PATH),
+                           "-o", str(exe), "-L" + libdir, "-ldmvio_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
