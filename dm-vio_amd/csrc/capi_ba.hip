@@ -919,6 +919,17 @@ int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const 
   b->H.setPrecalcValues();
   return 0;
 }
+int dmvio_hip_ba_get_calib_values(dmvio_hip_ba* b, double value[4], double value_zero[4]) {
+  if (!b) return failmsg("null ba");
+  if (value) memcpy(value, b->H.c_value, sizeof(double) * 4);
+  if (value_zero) memcpy(value_zero, b->H.c_value_zero, sizeof(double) * 4);
+  return 0;
+}
+int dmvio_hip_ba_get_res_in_a(dmvio_hip_ba* b, int* resInA) {
+  if (!b || !resInA) return failmsg("null argument");
+  *resInA = b->H.resInA;
+  return 0;
+}
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
   if (!b) return failmsg("null ba");
   memcpy(fxfycxcy, b->H.c_value_scaled, sizeof(double) * 4);

@@ -290,6 +290,11 @@ int dmvio_hip_ba_resubstitute(dmvio_hip_ba* ba, const double* x);
 int dmvio_hip_ba_get_points(dmvio_hip_ba* ba, float* idepth, float* step);
 int dmvio_hip_ba_get_frame(dmvio_hip_ba* ba, int f, double pose7_w2c[7], double aff[2], double state10[10]);
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* ba, double fxfycxcy[4]);
+/* CalibHessian::value / value_zero in the reference's unscaled units (what dmvio_hip_ba_set_calib_values takes; value_scaled = SCALE_* x value is dmvio_hip_ba_get_calib) */
+int dmvio_hip_ba_get_calib_values(dmvio_hip_ba* ba, double value[4], double value_zero[4]);
+/* EnergyFunctional::resInA: the number of active residuals the accumulation of the last solveSystemF saw (EnergyFunctional.cpp:209; the denominator of
+ * statistics_lastFineTrackRMSE, FullSystemOptimize.cpp:620) */
+int dmvio_hip_ba_get_res_in_a(dmvio_hip_ba* ba, int* resInA);
 /* one Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586); lastE = {E_A, E_L, E_M} in/out */
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io, double lastE[3], int* accepted);
 /* Diagnostics: in-kernel timeline of the last decision pass (energy sum, newest keyframe's threshold, accept test — taken by the last

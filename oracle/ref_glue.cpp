@@ -1352,6 +1352,20 @@ void ref_system_destroy(void* p)
 	cap.finish();
 	delete S;
 }
+// CoarseInitializer state after a frame: idepth / iR / isGood of the level's points and thisToNext (debugging the reference's run-to-run variation, tests/test_dropin_cpu.py)
+int ref_system_initializer_state(void* p, int lvl, float* idepth, float* iR, unsigned char* isGood, int cap, double thisToNext7[7], int* frameID, int* snapped)
+{
+	FullSystem* fs = ((RefSystem*)p)->fs;
+	CoarseInitializer* ci = fs->coarseInitializer;
+	if (!ci) return -1;
+	const int n = std::min(cap, ci->numPoints[lvl]);
+	for (int i = 0; i < n; i++) { idepth[i] = ci->points[lvl][i].idepth; iR[i] = ci->points[lvl][i].iR; isGood[i] = ci->points[lvl][i].isGood ? 1 : 0; }
+	se3To7(ci->thisToNext, thisToNext7);
+	*frameID = ci->frameID; *snapped = ci->snapped ? 1 : 0;
+	return ci->numPoints[lvl];
+}
+// the FullSystem behind a RefSystem (tests/dropin: the adapter wants to know whose frames its slots belong to)
+void* ref_system_fullsystem(void* p) { return ((RefSystem*)p)->fs; }
 // FullSystem::addActiveFrame.  status out: [initialized, isLost, initFailed, n keyframes in the window, n frames so far]
 int ref_system_add_frame(void* p, const float* img, float exposure, double timestamp, int id, int* status5, char* log, int logcap)
 {

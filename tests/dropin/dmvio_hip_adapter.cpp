@@ -1,0 +1,567 @@
+// The adapter of INTEGRATION.md, compiled for real against the reference's own headers: replacement definitions of the five members through which
+// FullSystem reaches the photometric hot path —
+//     FrameHessian::makeImages              src/dso/FullSystem/HessianBlocks.cpp:128-191
+//     CoarseTracker::setCoarseTrackingRef   src/dso/FullSystem/CoarseTracker.cpp:524-538 (+ makeCoarseDepthL0 :138-295)
+//     CoarseTracker::trackNewestCoarse      src/dso/FullSystem/CoarseTracker.cpp:539-770
+//     FullSystem::traceNewCoarse            src/dso/FullSystem/FullSystem.cpp:541-584
+//     FullSystem::optimize                  src/dso/FullSystem/FullSystemOptimize.cpp:417-647
+//     CoarseInitializer::calcResAndGS       src/dso/FullSystem/CoarseInitializer.cpp:331-624   (optional: dropin_set_initializer)
+// — each forwarding to the C ABI of include/dmvio_hip.h (libdmvio_hip.so) and writing the results back into the reference's pointer graph, so that the rest of
+// FullSystem (initialiser, pixel selector, activation, marginalisation policy, keyframe management: all unmodified reference code) runs on unchanged.
+//
+// HOW IT GETS INTO THE REFERENCE WITHOUT EDITING IT (test infrastructure; a maintainer would simply replace the five definitions): this file is built into
+// oracle/_ref/libdropin_hip.so, which is loaded BEFORE oracle/_ref/libref.so (the reference's sources compiled unmodified by oracle/Makefile.ref).  libref.so calls
+// these members through its PLT (default visibility, -fPIC, not -Bsymbolic — checked by tests/test_dropin_cpu.py), so the dynamic linker binds the calls inside the
+// reference's FullSystem to the definitions below: ELF symbol interposition, the reference's object files stay byte for byte what Makefile.ref produced.  The
+// originals remain reachable through dlsym(RTLD_NEXT, mangled name); with the adapter switched off (dropin_enable(0, ...)) every member forwards to its original,
+// which is how the all-CPU run of the comparison is made with the same binary.
+//
+// What stays on the CPU even with the adapter on: FrameHessian::makeImages ALSO runs the reference's own pyramid build, because the initialiser, the pixel selector,
+// ImmaturePoint's constructor, optimizeImmaturePoint and flagPointsForRemoval's relinearisation — all left to the reference here — read FrameHessian::dIp.
+// Only tests/ and bench.py's drop_in leg use this file; the product (libdmvio_hip.so) never links the reference.
+#include <dlfcn.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <complex>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+// like a maintainer's edit, the replacement members live inside the classes: private members are theirs to use
+#define private public
+#define protected public
+#include "util/NumType.h"
+#include "util/settings.h"
+#include "util/globalCalib.h"
+#include "util/FrameShell.h"
+#include "OptimizationBackend/EnergyFunctional.h"
+#include "OptimizationBackend/EnergyFunctionalStructs.h"
+#include "FullSystem/FullSystem.h"
+#include "FullSystem/HessianBlocks.h"
+#include "FullSystem/Residuals.h"
+#include "FullSystem/ImmaturePoint.h"
+#include "FullSystem/CoarseTracker.h"
+#include "FullSystem/CoarseInitializer.h"
+#include "util/TimeMeasurement.h"
+#undef private
+#undef protected
+
+#include "dmvio_hip.h"
+
+using namespace dso;
+
+namespace
+{
+struct Stats { double seconds[5] = {0, 0, 0, 0, 0}; long calls[5] = {0, 0, 0, 0, 0}; };   // makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize
+struct Timer
+{
+	Stats& s; int k; std::chrono::steady_clock::time_point t0;
+	Timer(Stats& s_, int k_) : s(s_), k(k_), t0(std::chrono::steady_clock::now()) {}
+	~Timer() { s.seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); s.calls[k]++; }
+};
+
+struct Backend
+{
+	bool on = false;
+	int accumulators = 0;          // 0 = the library's default
+	dmvio_hip_ctx* ctx = nullptr;
+	dmvio_hip_ba* ba = nullptr;
+	dmvio_hip_immature* imm = nullptr;
+	int n_slots = 0;
+	std::map<const FrameHessian*, int> slotOf;
+	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
+	FullSystem* fs = nullptr;      // learnt from the first FullSystem member that comes by
+	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
+	// CoarseInitializer.cpp:507 / util/IndexThreadReduce.h:83-87 — the sums, and with them everything downstream, vary in the last bits from run to run);
+	// 1 = the oracle's single-threaded restatement (oracle/init_oracle.cpp, per-point bit-identical to the reference: the sums one worker taking every chunk would form)
+	//     — a DETERMINISTIC all-CPU run to compare against; 2 = libdmvio_hip.so (dmvio_hip_initializer_calc_res_and_gs)
+	int init_mode = 0;
+	dmvio_hip_initializer* ini = nullptr;
+	void* oracle_lib = nullptr;
+	Stats stats;
+	char error[512] = "";
+	long failures = 0;
+};
+Backend g;
+
+void fail(const char* what)
+{
+	snprintf(g.error, sizeof(g.error), "%s: %s", what, dmvio_hip_last_error());
+	g.failures++;
+	fprintf(stderr, "[dropin] %s\n", g.error);
+}
+#define HIP_OK(call) ((call) >= 0 ? true : (fail(#call), false))
+
+template <class Fn> Fn original(const char* mangled)
+{
+	void* p = dlsym(RTLD_NEXT, mangled);
+	if (!p) { fprintf(stderr, "[dropin] the reference's own %s is not loaded behind the adapter\n", mangled); abort(); }
+	return (Fn)p;
+}
+
+void toPose7(const SE3& T, double* p)
+{
+	p[0] = T.translation()[0]; p[1] = T.translation()[1]; p[2] = T.translation()[2];
+	const Eigen::Quaterniond& q = T.unit_quaternion();
+	p[3] = q.x(); p[4] = q.y(); p[5] = q.z(); p[6] = q.w();
+}
+SE3 fromPose7(const double* p)
+{
+	Eigen::Quaterniond q(p[6], p[3], p[4], p[5]);
+	return SE3(q, Vec3(p[0], p[1], p[2]));
+}
+
+// frame slots of the HIP context: a frame keeps its slot while the reference can still refer to it (window keyframes, the trackers' reference frames, the frame being
+// added); slots of frames the reference has deleted are handed out again
+int acquireSlot(const FrameHessian* fh)
+{
+	auto it = g.slotOf.find(fh);
+	if (it != g.slotOf.end()) return it->second;      // a new frame at the address of a deleted one: its slot is rebuilt by the upload that follows
+	std::set<int> used;
+	if ((int)g.slotOf.size() >= g.n_slots / 2 && g.fs)
+	{
+		std::set<const FrameHessian*> live(g.fs->frameHessians.begin(), g.fs->frameHessians.end());
+		if (g.fs->coarseTracker) live.insert(g.fs->coarseTracker->lastRef);
+		if (g.fs->coarseTracker_forNewKF) live.insert(g.fs->coarseTracker_forNewKF->lastRef);
+		if (g.fs->coarseInitializer) { live.insert(g.fs->coarseInitializer->firstFrame); live.insert(g.fs->coarseInitializer->newFrame); }
+		for (auto i = g.slotOf.begin(); i != g.slotOf.end();) { if (!live.count(i->first)) i = g.slotOf.erase(i); else ++i; }
+	}
+	for (auto& kv : g.slotOf) used.insert(kv.second);
+	for (int s = 0; s < g.n_slots; s++) if (!used.count(s)) { g.slotOf[fh] = s; return s; }
+	fprintf(stderr, "[dropin] out of frame slots\n"); abort();
+}
+int slotFor(const FrameHessian* fh)
+{
+	auto it = g.slotOf.find(fh);
+	if (it == g.slotOf.end()) { fprintf(stderr, "[dropin] frame without a slot (makeImages did not come through the adapter)\n"); abort(); }
+	return it->second;
+}
+dmvio_hip_tracker* trackerFor(const CoarseTracker* ct)
+{
+	auto it = g.trackerOf.find(ct);
+	if (it != g.trackerOf.end()) return it->second;
+	dmvio_hip_tracker* t = dmvio_hip_tracker_create(g.ctx);
+	if (!t) { fail("dmvio_hip_tracker_create"); abort(); }
+	dmvio_hip_tracker_settings st;
+	st.huberTH = setting_huberTH; st.coarseCutoffTH = setting_coarseCutoffTH; st.affineOptModeA = setting_affineOptModeA; st.affineOptModeB = setting_affineOptModeB;
+	dmvio_hip_tracker_set_settings(t, &st);
+	g.trackerOf[ct] = t;
+	return t;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+// on != 0: forward the five members to libdmvio_hip.so (context of w x h frames on `device`; accumulators: dmvio_hip_ba_set_accumulators, 0 = default);
+// on == 0: every member calls the reference's own definition.  Returns 0, or -1 when the HIP context cannot be created.
+int dropin_enable(int on, int device, int w, int h, int accumulators)
+{
+	if (g.ctx)
+	{
+		for (auto& kv : g.trackerOf) dmvio_hip_tracker_destroy(kv.second);
+		g.trackerOf.clear();
+		if (g.ba) dmvio_hip_ba_destroy(g.ba);
+		if (g.imm) dmvio_hip_immature_destroy(g.imm);
+		if (g.ini) dmvio_hip_initializer_destroy(g.ini);
+		dmvio_hip_destroy(g.ctx);
+		g.ba = nullptr; g.imm = nullptr; g.ini = nullptr; g.ctx = nullptr; g.init_mode = 0;
+	}
+	g.slotOf.clear(); g.fs = nullptr; g.on = false; g.stats = Stats(); g.failures = 0; g.error[0] = 0;
+	if (!on) return 0;
+	g.n_slots = 48;
+	g.ctx = dmvio_hip_create(device, w, h, g.n_slots);
+	if (!g.ctx) { fail("dmvio_hip_create"); return -1; }
+	g.ba = dmvio_hip_ba_create(g.ctx);
+	g.imm = dmvio_hip_immature_create(g.ctx, 1 << 16);
+	if (!g.ba || !g.imm) { fail("dmvio_hip_ba_create / dmvio_hip_immature_create"); return -1; }
+	g.accumulators = accumulators;
+	if (accumulators > 0 && !HIP_OK(dmvio_hip_ba_set_accumulators(g.ba, accumulators))) return -1;
+	g.on = true;
+	return 0;
+}
+// CoarseInitializer::calcResAndGS: 0 the reference's own (multi-threaded, run-to-run noise), 1 oracle/_build/liboracle.so's single-threaded restatement (path given),
+// 2 libdmvio_hip.so (needs dropin_enable(1, ...) first)
+int dropin_set_initializer(int mode, const char* liboracle_path)
+{
+	if (mode == 1)
+	{
+		if (!g.oracle_lib) g.oracle_lib = dlopen(liboracle_path, RTLD_NOW | RTLD_LOCAL);
+		if (!g.oracle_lib || !dlsym(g.oracle_lib, "orc_init_calc_res_and_gs")) { fprintf(stderr, "[dropin] cannot load %s\n", liboracle_path ? liboracle_path : "(null)"); return -1; }
+	}
+	if (mode == 2)
+	{
+		if (!g.on) return -1;
+		if (!g.ini) g.ini = dmvio_hip_initializer_create(g.ctx, 1 << 17);
+		if (!g.ini) { fail("dmvio_hip_initializer_create"); return -1; }
+	}
+	g.init_mode = mode;
+	return 0;
+}
+int dropin_is_on() { return g.on ? 1 : 0; }
+// the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
+void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
+// seconds[5], calls[5] in the order makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize — counted in both modes
+void dropin_get_stats(double* seconds5, long* calls5) { for (int k = 0; k < 5; k++) { seconds5[k] = g.stats.seconds[k]; calls5[k] = g.stats.calls[k]; } }
+void dropin_reset_stats() { g.stats = Stats(); }
+long dropin_failures(char* msg, int cap) { if (msg && cap > 0) { strncpy(msg, g.error, cap - 1); msg[cap - 1] = 0; } return g.failures; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+namespace dso
+{
+
+// ---- FrameHessian::makeImages (HessianBlocks.cpp:128-191)
+void FrameHessian::makeImages(float* color, CalibHessian* HCalib)
+{
+	typedef void (*Fn)(FrameHessian*, float*, CalibHessian*);
+	static Fn orig = original<Fn>("_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE");
+	Timer tm(g.stats, 0);
+	orig(this, color, HCalib);   // dIp / absSquaredGrad for the parts of the pipeline that stay on the CPU (see the header comment)
+	if (!g.on) return;
+	const int slot = acquireSlot(this);
+	HIP_OK(dmvio_hip_frame_upload(g.ctx, slot, color));
+}
+
+// ---- CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624): the point arrays of the level flattened (struct Pnt, CoarseInitializer.h:44-83), the evaluation on
+// the device (or by the oracle's sequential restatement), the per-point results written back into Pnt / JbBuffer_new
+Vec3f CoarseInitializer::calcResAndGS(int lvl, Mat88f& H_out, Vec8f& b_out, Mat88f& H_out_sc, Vec8f& b_out_sc, const SE3& refToNew, AffLight refToNew_aff, bool plot)
+{
+	typedef Vec3f (*Fn)(CoarseInitializer*, int, Mat88f&, Vec8f&, Mat88f&, Vec8f&, const SE3&, AffLight, bool);
+	static Fn orig = original<Fn>("_ZN3dso17CoarseInitializer12calcResAndGSEiRN5Eigen6MatrixIfLi8ELi8ELi0ELi8ELi8EEERNS2_IfLi8ELi1ELi0ELi8ELi1EEES4_S6_RKN6Sophus8SE3GroupIdLi0EEENS_8AffLightEb");
+	if (g.init_mode == 0) return orig(this, lvl, H_out, b_out, H_out_sc, b_out_sc, refToNew, refToNew_aff, plot);
+	const int n = numPoints[lvl];
+	Pnt* pts = points[lvl];
+	std::vector<float> u(n), v(n), iR(n), idn(n), en(2 * (size_t)n), oth(n), en_new(2 * (size_t)n), maxstep(n), lastH(n), Jb(10 * (size_t)n);
+	std::vector<unsigned char> good(n), good_new(n);
+	for (int i = 0; i < n; i++)
+	{
+		const Pnt& q = pts[i];
+		u[i] = q.u; v[i] = q.v; iR[i] = q.iR; idn[i] = q.idepth_new; en[2 * i] = q.energy[0]; en[2 * i + 1] = q.energy[1]; oth[i] = q.outlierTH; good[i] = q.isGood ? 1 : 0;
+		lastH[i] = q.lastHessian_new;
+	}
+	double Ki9[9], pose7[7], aff[2] = {refToNew_aff.a, refToNew_aff.b};
+	for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ki9[3 * r + c] = Ki[lvl](r, c);
+	toPose7(refToNew, pose7);
+	const float k4[4] = {(float)fx[lvl], (float)fy[lvl], (float)cx[lvl], (float)cy[lvl]};
+	float H64[64], b8[8], Hsc64[64], bsc8[8], res3[3];
+	if (g.init_mode == 2)
+	{
+		bool ok = HIP_OK(dmvio_hip_initializer_set_points(g.ini, n, u.data(), v.data(), iR.data(), good.data(), en.data(), oth.data()));
+		ok = ok && HIP_OK(dmvio_hip_initializer_calc_res_and_gs(g.ini, lvl, slotFor(firstFrame), slotFor(newFrame), Ki9, k4, pose7, aff, idn.data(), alphaW, alphaK, couplingWeight,
+		                                                        setting_weightZeroPriorDSOInitY, setting_weightZeroPriorDSOInitX, H64, b8, Hsc64, bsc8, res3, en_new.data(),
+		                                                        good_new.data(), maxstep.data(), lastH.data(), Jb.data()));
+		if (!ok) return orig(this, lvl, H_out, b_out, H_out_sc, b_out_sc, refToNew, refToNew_aff, plot);
+	}
+	else
+	{
+		typedef void (*Orc)(const float*, const float*, int, int, const double*, float, float, float, float, const double*, double, double, int, const float*, const float*, const float*,
+		                    const float*, const unsigned char*, const float*, const float*, float, float, float, double, double, float*, float*, float*, float*, float*, float*,
+		                    unsigned char*, float*, float*, float*);
+		static Orc orc = (Orc)dlsym(g.oracle_lib, "orc_init_calc_res_and_gs");
+		orc((const float*)firstFrame->dIp[lvl], (const float*)newFrame->dIp[lvl], w[lvl], h[lvl], Ki9, k4[0], k4[1], k4[2], k4[3], pose7, aff[0], aff[1], n, u.data(), v.data(), idn.data(),
+		    iR.data(), good.data(), en.data(), oth.data(), alphaW, alphaK, couplingWeight, setting_weightZeroPriorDSOInitY, setting_weightZeroPriorDSOInitX, H64, b8, Hsc64, bsc8, res3,
+		    en_new.data(), good_new.data(), maxstep.data(), lastH.data(), Jb.data());
+	}
+	for (int i = 0; i < n; i++)
+	{
+		Pnt& q = pts[i];
+		q.maxstep = maxstep[i]; q.energy_new = Eigen::Vector2f(en_new[2 * i], en_new[2 * i + 1]); q.isGood_new = good_new[i] != 0;
+		if (q.isGood_new) q.lastHessian_new = lastH[i];
+		if (good[i]) for (int k = 0; k < 10; k++) JbBuffer_new[i][k] = Jb[10 * (size_t)i + k];
+	}
+	for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) { H_out(r, c) = H64[8 * r + c]; H_out_sc(r, c) = Hsc64[8 * r + c]; } b_out[r] = b8[r]; b_out_sc[r] = bsc8[r]; }
+	return Vec3f(res3[0], res3[1], res3[2]);
+}
+
+// ---- CoarseTracker::setCoarseTrackingRef (CoarseTracker.cpp:524-538) with makeCoarseDepthL0 (:138-295) on the device
+void CoarseTracker::setCoarseTrackingRef(std::vector<FrameHessian*> frameHessians)
+{
+	typedef void (*Fn)(CoarseTracker*, std::vector<FrameHessian*>);
+	static Fn orig = original<Fn>("_ZN3dso13CoarseTracker20setCoarseTrackingRefESt6vectorIPNS_12FrameHessianESaIS3_EE");
+	Timer tm(g.stats, 1);
+	if (!g.on) { orig(this, frameHessians); return; }
+	assert(frameHessians.size() > 0);
+	lastRef = frameHessians.back();
+	// the points makeCoarseDepthL0 scatters (:144-161): active points whose newest residual is IN, at the pixel it projects to in lastRef, weighted by HdiF
+	std::vector<float> u, v, id, hdi;
+	for (FrameHessian* fh : frameHessians)
+		for (PointHessian* ph : fh->pointHessians)
+			if (ph->lastResiduals[0].first != 0 && ph->lastResiduals[0].second == ResState::IN)
+			{
+				PointFrameResidual* r = ph->lastResiduals[0].first;
+				assert(r->efResidual->isActive() && r->target == lastRef);
+				u.push_back(r->centerProjectedTo[0]); v.push_back(r->centerProjectedTo[1]); id.push_back(r->centerProjectedTo[2]); hdi.push_back(ph->efPoint->HdiF);
+			}
+	dmvio_hip_tracker* trk = trackerFor(this);
+	const float k4[4] = {fx[0], fy[0], cx[0], cy[0]};   // makeK(&Hcalib) ran just before (FullSystem.cpp:1459): level-0 intrinsics as the tracker holds them
+	lastRef_aff_g2l = lastRef->aff_g2l();
+	HIP_OK(dmvio_hip_tracker_make_k(trk, k4));
+	HIP_OK(dmvio_hip_tracker_set_ref(trk, slotFor(lastRef), lastRef->ab_exposure, lastRef_aff_g2l.a, lastRef_aff_g2l.b, (int)u.size(), u.data(), v.data(), id.data(), hdi.data()));
+	refFrameID = lastRef->shell->id;
+	firstCoarseRMSE = -1;
+}
+
+// ---- CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:539-770), visual-only branch (the runs of the comparison have no IMU; the default VIO branch is
+// dmvio_hip_tracker_track_vio with the three IMUIntegration members as callbacks — INTEGRATION.md section 3)
+bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort, IOWrap::Output3DWrapper* wrap)
+{
+	typedef bool (*Fn)(CoarseTracker*, FrameHessian*, SE3&, AffLight&, int, Vec5, IOWrap::Output3DWrapper*);
+	static Fn orig = original<Fn>("_ZN3dso13CoarseTracker17trackNewestCoarseEPNS_12FrameHessianERN6Sophus8SE3GroupIdLi0EEERNS_8AffLightEiN5Eigen6MatrixIdLi5ELi1ELi0ELi5ELi1EEEPNS_6IOWrap15Output3DWrapperE");
+	Timer tm(g.stats, 2);
+	if (!g.on) return orig(this, newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
+	assert(coarsestLvl < 5 && coarsestLvl < pyrLevelsUsed);
+	lastResiduals.setConstant(NAN);
+	lastFlowIndicators.setConstant(1000);
+	newFrame = newFrameHessian;
+	double pose7[7], aff[2] = {aff_g2l_out.a, aff_g2l_out.b}, minRes[5], lastRes[5], flow[3], H[64], b[8];
+	toPose7(lastToNew_out, pose7);
+	for (int i = 0; i < 5; i++) minRes[i] = minResForAbort[i];
+	int good = 0;
+	if (!HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good)))
+		return false;   // a device error reads as "tracking failed" 
+	for (int i = 0; i < 5; i++) lastResiduals[i] = lastRes[i];
+	// an aborted level leaves the outputs untouched and the flow indicators of the levels it finished (:729-733); otherwise they are the finest level's
+	bool finished = true;
+	for (int l = 0; l <= coarsestLvl; l++) if (!std::isfinite(lastRes[l])) finished = false;
+	lastFlowIndicators = Vec3(flow[0], flow[1], flow[2]);   // the library mirrors the member: 1000 until a level finished, then that level's indicators
+	if (!finished) return false;
+	lastToNew_out = fromPose7(pose7);
+	aff_g2l_out = AffLight(aff[0], aff[1]);
+	return good != 0;
+}
+
+// ---- FullSystem::traceNewCoarse (FullSystem.cpp:541-584): the per-host tables exactly as the reference forms them, ImmaturePoint::traceOn of every point on the device
+void FullSystem::traceNewCoarse(FrameHessian* fh)
+{
+	typedef void (*Fn)(FullSystem*, FrameHessian*);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem14traceNewCoarseEPNS_12FrameHessianE");
+	Timer tm(g.stats, 3);
+	g.fs = this;
+	if (!g.on) { orig(this, fh); return; }
+	dmvio::TimeMeasurement timeMeasurement("traceNewCoarse");   // the profiler scopes the reference opens (:543, FullSystemOptimize.cpp:419) stay where they were
+	boost::unique_lock<boost::mutex> lock(mapMutex);
+	Mat33f K = Mat33f::Identity();
+	K(0, 0) = Hcalib.fxl(); K(1, 1) = Hcalib.fyl(); K(0, 2) = Hcalib.cxl(); K(1, 2) = Hcalib.cyl();
+	const int nH = (int)frameHessians.size();
+	std::vector<float> KRKi9(9 * nH), Kt3(3 * nH), aff2(2 * nH);
+	std::vector<ImmaturePoint*> pts;
+	if (!HIP_OK(dmvio_hip_immature_clear(g.imm))) return;
+	for (int hI = 0; hI < nH; hI++)
+	{
+		FrameHessian* host = frameHessians[hI];
+		SE3 hostToNew = fh->PRE_worldToCam * host->PRE_camToWorld;
+		Mat33f KRKi = K * hostToNew.rotationMatrix().cast<float>() * K.inverse();
+		Vec3f Kt = K * hostToNew.translation().cast<float>();
+		Vec2f aff = AffLight::fromToVecExposure(host->ab_exposure, fh->ab_exposure, host->aff_g2l(), fh->aff_g2l()).cast<float>();
+		for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) KRKi9[9 * hI + 3 * r + c] = KRKi(r, c); Kt3[3 * hI + r] = Kt[r]; }
+		aff2[2 * hI] = aff[0]; aff2[2 * hI + 1] = aff[1];
+		// the points of this host: constructed on the device from its image (bit-identical to ImmaturePoint::ImmaturePoint, ImmaturePoint.cpp:34-62), state from the objects
+		std::vector<int> ui, vi;
+		for (ImmaturePoint* ip : host->immaturePoints) { ui.push_back((int)ip->u); vi.push_back((int)ip->v); pts.push_back(ip); }
+		if (!ui.empty() && !HIP_OK(dmvio_hip_immature_add_points(g.imm, hI, slotFor(host), (int)ui.size(), ui.data(), vi.data()))) return;
+	}
+	const int n = (int)pts.size();
+	if (n == 0) return;
+	std::vector<float> imin(n), imax(n), qual(n), uv(2 * n), interval(n);
+	std::vector<int> status(n);
+	for (int i = 0; i < n; i++) { imin[i] = pts[i]->idepth_min; imax[i] = pts[i]->idepth_max; qual[i] = pts[i]->quality; status[i] = (int)pts[i]->lastTraceStatus; }
+	if (!HIP_OK(dmvio_hip_immature_set_state(g.imm, imin.data(), imax.data(), qual.data(), status.data()))) return;
+	if (!HIP_OK(dmvio_hip_immature_trace(g.imm, slotFor(fh), nH, KRKi9.data(), Kt3.data(), aff2.data()))) return;
+	if (!HIP_OK(dmvio_hip_immature_get_state(g.imm, imin.data(), imax.data(), qual.data(), uv.data(), interval.data(), status.data()))) return;
+	for (int i = 0; i < n; i++)
+	{
+		ImmaturePoint* ip = pts[i];
+		ip->idepth_min = imin[i]; ip->idepth_max = imax[i]; ip->quality = qual[i];
+		ip->lastTraceUV = Vec2f(uv[2 * i], uv[2 * i + 1]); ip->lastTracePixelInterval = interval[i];
+		ip->lastTraceStatus = (ImmaturePointStatus)status[i];
+	}
+}
+
+// ---- FullSystem::optimize (FullSystemOptimize.cpp:417-647): the window flattened once, the whole Gauss-Newton loop and the final fix-linearisation on the device,
+// the results written back into FrameHessian / PointHessian / PointFrameResidual with the bookkeeping linearizeAll(true) does (:150-218, :51-85)
+float FullSystem::optimize(int mnumOptIts)
+{
+	typedef float (*Fn)(FullSystem*, int);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem8optimizeEi");
+	Timer tm(g.stats, 4);
+	g.fs = this;
+	if (!g.on) return orig(this, mnumOptIts);
+	dmvio::TimeMeasurement timeMeasurement("FullSystemOptimize");
+	if (setting_useGTSAMIntegration) { fprintf(stderr, "[dropin] GTSAM runs: use dmvio_hip_ba_optimize_vio with the BAGTSAMIntegration members as hooks\n"); abort(); }
+	const int F = (int)frameHessians.size();
+	if (F < 2) return 0;
+	// ---- statistics and active residuals (:429-448)
+	activeResiduals.clear();
+	for (FrameHessian* fh : frameHessians)
+		for (PointHessian* ph : fh->pointHessians)
+			for (PointFrameResidual* r : ph->residuals)
+			{
+				if (r->efResidual->isLinearized) { fprintf(stderr, "[dropin] linearised residual inside optimize\n"); abort(); }   // they only exist between flagPointsForRemoval and marginalizePointsF
+				activeResiduals.push_back(r);
+				r->resetOOB();
+			}
+	// ---- the window: keyframes in frameHessians order, points in EnergyFunctional::allPoints order (makeIDX, EnergyFunctional.cpp:997-1017), residuals in
+	// EFPoint::residualsAll order — the orders the reference's accumulators add in
+	std::vector<int> slots(F), frameIDs(F);
+	std::vector<double> evalPT7(7 * F), affZero(2 * F);
+	std::vector<float> expo(F), th(F);
+	for (int f = 0; f < F; f++)
+	{
+		FrameHessian* fh = frameHessians[f];
+		assert(fh->idx == f);
+		slots[f] = slotFor(fh); frameIDs[f] = fh->frameID; expo[f] = fh->ab_exposure; th[f] = fh->frameEnergyTH;
+		toPose7(fh->get_worldToCam_evalPT(), &evalPT7[7 * f]);
+		affZero[2 * f] = fh->get_state_zero()[6] * SCALE_A; affZero[2 * f + 1] = fh->get_state_zero()[7] * SCALE_B;
+	}
+	std::vector<int> host, resPoint, resTarget;
+	std::vector<float> pu, pv, pid, color, weights;
+	std::vector<unsigned char> prior;
+	std::vector<PointHessian*> points;
+	std::map<PointFrameResidual*, int> resIndex;
+	for (EFFrame* eff : ef->frames)
+		for (EFPoint* efp : eff->points)
+		{
+			PointHessian* ph = efp->data;
+			const int pi = (int)points.size();
+			points.push_back(ph);
+			host.push_back(ph->host->idx); pu.push_back(ph->u); pv.push_back(ph->v); pid.push_back(ph->idepth); prior.push_back(ph->hasDepthPrior ? 1 : 0);
+			for (int k = 0; k < 8; k++) { color.push_back(ph->color[k]); weights.push_back(ph->weights[k]); }
+			for (EFResidual* er : efp->residualsAll)
+			{
+				resIndex[er->data] = (int)resPoint.size();
+				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx);
+			}
+		}
+	const int N = (int)points.size(), R = (int)resPoint.size(), n = CPARS + 8 * F;
+	if (N < 1 || R < 1 || resIndex.size() != activeResiduals.size()) { fprintf(stderr, "[dropin] window without points / residual lists disagree\n"); abort(); }
+	dmvio_hip_ba* ba = g.ba;
+	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), Hcalib.value_scaled.data()));
+	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), R, resPoint.data(), resTarget.data()));
+	for (int f = 0; ok && f < F; f++)
+	{
+		Vec10 sz = frameHessians[f]->get_state_zero(), st = frameHessians[f]->get_state();
+		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_zero(ba, f, sz.data())) && HIP_OK(dmvio_hip_ba_set_frame_state(ba, f, st.data()));
+	}
+	ok = ok && HIP_OK(dmvio_hip_ba_set_frame_energy_th(ba, th.data())) && HIP_OK(dmvio_hip_ba_set_calib_values(ba, Hcalib.value.data(), Hcalib.value_zero.data()));
+	{
+		std::vector<double> HM((size_t)n * n), bM(n);
+		for (int r = 0; r < n; r++) { bM[r] = ef->bM[r]; for (int c = 0; c < n; c++) HM[(size_t)r * n + c] = ef->HM(r, c); }
+		ok = ok && HIP_OK(dmvio_hip_ba_set_marg_prior(ba, HM.data(), bM.data()));
+	}
+	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
+	float rmse = 0; double finalEnergy = 0; int iterations = 0;
+	ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));
+	if (!ok) { isLost = true; return 0; }   // a failure inside optimize reads as isLost (:613-617)
+	// ---- write-back: calibration, keyframe states (the newest one re-anchored like :596-603), thresholds
+	{
+		double value[4], value_zero[4];
+		HIP_OK(dmvio_hip_ba_get_calib_values(ba, value, value_zero));
+		VecC v; for (int i = 0; i < 4; i++) v[i] = value[i];
+		Hcalib.setValue(v);
+	}
+	for (int f = 0; f < F; f++)
+	{
+		double pose7[7], aff[2], st10[10];
+		HIP_OK(dmvio_hip_ba_get_frame(ba, f, pose7, aff, st10));
+		Vec10 st; for (int i = 0; i < 10; i++) st[i] = st10[i];
+		if (f < F - 1) frameHessians[f]->setState(st);
+		else frameHessians[f]->setEvalPT(fromPose7(pose7), st);   // newStateZero = (0, .., a, b, 0, 0) at the optimised pose
+	}
+	HIP_OK(dmvio_hip_ba_get_frame_energy_th(ba, th.data()));
+	for (int f = 0; f < F; f++) frameHessians[f]->frameEnergyTH = th[f];
+	EFDeltaValid = false; EFAdjointsValid = false;
+	ef->setAdjointsF(&Hcalib);
+	setPrecalcValues();
+	// ---- points: idepth (= idepth_zero, doStepFromBackup :283-291), and what the LAST solveSystemF's accumulation left in PointHessian / EFPoint
+	// (idepth_hessian, HdiF: AccumulatedSCHessian.cpp:42-54; read by flagPointsForRemoval and makeCoarseDepthL0)
+	{
+		std::vector<float> idepth(N), step(N), hess(N), Hdd(N), bd(N), Hcd(4 * (size_t)N), HdiF(N), bdSumF(N);
+		HIP_OK(dmvio_hip_ba_get_points(ba, idepth.data(), step.data()));
+		HIP_OK(dmvio_hip_ba_get_point_hessian(ba, hess.data()));
+		HIP_OK(dmvio_hip_ba_get_point_acc(ba, Hdd.data(), bd.data(), Hcd.data(), HdiF.data(), bdSumF.data()));
+		for (int pi = 0; pi < N; pi++)
+		{
+			PointHessian* ph = points[pi];
+			ph->setIdepth(idepth[pi]); ph->setIdepthZero(idepth[pi]); ph->step = step[pi];
+			ph->idepth_hessian = hess[pi];
+			ph->efPoint->HdiF = HdiF[pi]; ph->efPoint->bdSumF = bdSumF[pi]; ph->efPoint->Hdd_accAF = Hdd[pi]; ph->efPoint->bd_accAF = bd[pi];
+			for (int k = 0; k < 4; k++) ph->efPoint->Hcd_accAF[k] = Hcd[4 * pi + k];
+		}
+	}
+	// ---- residuals: what linearize + applyRes(true) of the final linearizeAll(true) leave behind (Residuals.cpp:78-328), then linearizeAll's own tail
+	{
+		std::vector<unsigned char> newState(R), active(R);
+		std::vector<float> newEnergy(R), newEnergyWO(R), center(3 * (size_t)R);
+		HIP_OK(dmvio_hip_ba_get_res_state(ba, newState.data(), newEnergy.data(), newEnergyWO.data(), active.data(), center.data()));
+		std::vector<PointFrameResidual*> toRemove;
+		for (PointFrameResidual* r : activeResiduals)
+		{
+			const int ri = resIndex[r];
+			const ResState ns = newState[ri] == 0 ? ResState::IN : (newState[ri] == 1 ? ResState::OOB : ResState::OUTLIER);
+			r->state_NewState = ns; r->state_NewEnergy = newEnergy[ri]; r->state_NewEnergyWithOutlier = newEnergyWO[ri];
+			if (ns != ResState::OOB) r->centerProjectedTo = Vec3f(center[3 * ri], center[3 * ri + 1], center[3 * ri + 2]);
+			r->efResidual->isActiveAndIsGoodNEW = active[ri] != 0;   // applyRes(true); the Jacobians stay on the device (marginalisation relinearises its points itself, FullSystem.cpp:836-849)
+			r->setState(ns);
+			r->state_energy = newEnergy[ri];
+			if (r->efResidual->isActive())
+			{
+				if (r->isNew)
+				{
+					PointHessian* p = r->point;
+					Vec3f ptp_inf = r->host->targetPrecalc[r->target->idx].PRE_KRKiTll * Vec3f(p->u, p->v, 1);
+					Vec3f ptp = ptp_inf + r->host->targetPrecalc[r->target->idx].PRE_KtTll * p->idepth_scaled;
+					float relBS = 0.01 * ((ptp_inf.head<2>() / ptp_inf[2]) - (ptp.head<2>() / ptp[2])).norm();
+					if (relBS > p->maxRelBaseline) p->maxRelBaseline = relBS;
+					p->numGoodResiduals++;
+				}
+			}
+			else toRemove.push_back(r);
+		}
+		for (PointFrameResidual* r : activeResiduals)
+		{
+			PointHessian* ph = r->point;
+			if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
+			else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+		}
+		for (PointFrameResidual* r : toRemove)
+		{
+			PointHessian* ph = r->point;
+			if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
+			else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
+			for (unsigned int k = 0; k < ph->residuals.size(); k++)
+				if (ph->residuals[k] == r)
+				{
+					ef->dropResidual(r->efResidual);
+					deleteOut<PointFrameResidual>(ph->residuals, k);
+					break;
+				}
+		}
+	}
+	// ---- tail of optimize (:611-645)
+	HIP_OK(dmvio_hip_ba_get_res_in_a(ba, &ef->resInA));   // the count the last solveSystemF's accumulation left behind (EnergyFunctional.cpp:209)
+	if (!std::isfinite(finalEnergy)) { std::cout << "Tracking lost after bundle adjustment!" << std::endl; isLost = true; }
+	statistics_lastFineTrackRMSE = rmse;
+	{
+		boost::unique_lock<boost::mutex> crlock(shellPoseMutex);
+		for (FrameHessian* fh : frameHessians)
+		{
+			fh->shell->camToWorld = fh->PRE_camToWorld;
+			fh->shell->aff_g2l = fh->aff_g2l();
+		}
+	}
+	return statistics_lastFineTrackRMSE;
+}
+
+}  // namespace dso

@@ -1,0 +1,114 @@
+"""Runs the REFERENCE'S OWN FullSystem (oracle/_ref/libref.so: FullSystem.cpp, FullSystemOptimize.cpp, ... compiled unmodified) over a synthetic sequence with
+oracle/_ref/libdropin_hip.so (tests/dropin/dmvio_hip_adapter.cpp) loaded in front of it, and writes what came out to an .npz:
+
+    python tests/dropin/run_dropin.py --mode cpu|hip|plain --out run.npz [--w 256 --h 192 --frames 62 --step 1.6 --density 300 --accumulators 0]
+
+  plain: libref.so alone (no adapter in the process);
+  cpu:   the adapter loaded and interposed, switched off — its five members forward to the reference's own definitions;
+  hip:   makeImages / setCoarseTrackingRef / trackNewestCoarse / traceNewCoarse / optimize run on libdmvio_hip.so (needs the MI355X).
+Test infrastructure (tests/test_dropin_*.py, bench.py's drop_in leg); one mode per process because symbol interposition is decided at load time."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "libdropin_hip.so")
+
+
+def main():
+    # The reference reads heap memory it never wrote: PixelSelector::select (PixelSelector2.cpp:418) looks at rows 0 and h-1 of FrameHessian::absSquaredGrad, which makeImages
+    # allocates with new[] and fills for rows 1..h-2 only (HessianBlocks.cpp:134, 169-189) — found with MemorySanitizer on the sources compiled by oracle/Makefile.ref.  What a
+    # run selects therefore depends on what the allocator hands out.  glibc's MALLOC_PERTURB_=255 makes every fresh allocation zero-filled: the same memory image in every mode.
+    if os.environ.get("MALLOC_PERTURB_") != "255":
+        os.environ["MALLOC_PERTURB_"] = "255"
+        os.execv(sys.executable, [sys.executable] + sys.argv)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["plain", "cpu", "hip"], required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--w", type=int, default=256); ap.add_argument("--h", type=int, default=192)
+    ap.add_argument("--frames", type=int, default=62); ap.add_argument("--step", type=float, default=1.6)
+    ap.add_argument("--density", type=int, default=300); ap.add_argument("--accumulators", type=int, default=0)
+    ap.add_argument("--result-txt", default=None)
+    ap.add_argument("--cache", default=None, help="directory that keeps the rendered sequence between runs (rendering 512x512 frames costs more than tracking them)")
+    ap.add_argument("--init", choices=["ref", "seq", "hip"], default="ref",
+                    help="CoarseInitializer::calcResAndGS: the reference's own (multi-threaded: run-to-run noise), the oracle's single-threaded restatement (deterministic "
+                         "CPU baseline), or libdmvio_hip.so (mode hip only)")
+    a = ap.parse_args()
+    pkg = graft.load_package()
+    import dmvio_amd.synth as synth
+    D = None
+    if a.mode != "plain":
+        if a.mode == "hip":
+            pkg.load_library()                       # torch first (one HIP runtime per process), then libdmvio_hip.so
+        D = C.CDLL(DROPIN, mode=C.RTLD_GLOBAL)       # BEFORE libref.so is looked at: its definitions of the five members come first in the lookup order
+        D.dropin_enable.argtypes = [C.c_int] * 5
+        D.dropin_attach.argtypes = [C.c_void_p]
+        D.dropin_set_initializer.argtypes = [C.c_int, C.c_char_p]
+        D.dropin_get_stats.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        D.dropin_failures.argtypes = [C.c_char_p, C.c_int]; D.dropin_failures.restype = C.c_long
+    import ref_py as R
+    import replay
+    cache = os.path.join(a.cache, "seq_%dx%d_%d_%g.npz" % (a.w, a.h, a.frames, a.step)) if a.cache else None
+    if cache and os.path.exists(cache):
+        z = np.load(cache); K4, imgs, poses_true = z["K4"], list(z["imgs"]), list(z["poses"])
+    else:
+        K4, imgs, poses_true = replay.make_sequence(synth, a.w, a.h, a.frames, a.step)
+        if cache:
+            os.makedirs(a.cache, exist_ok=True)
+            np.savez(cache + ".tmp.npz", K4=np.asarray(K4), imgs=np.asarray(imgs, np.float32), poses=np.asarray(poses_true)); os.replace(cache + ".tmp.npz", cache)
+    if D is not None and D.dropin_enable(1 if a.mode == "hip" else 0, 0, a.w, a.h, a.accumulators) != 0:
+        raise SystemExit("dropin_enable failed")
+    # the reference draws from the C library's rand() (PixelSelector's random pattern, CoarseInitializer's point selection): the same sequence in every mode, whatever the
+    # static initialisers of the libraries loaded so far have consumed
+    C.CDLL(None).srand(1)
+    if a.init != "ref":
+        if D is None or (a.init == "hip" and a.mode != "hip"):
+            raise SystemExit("--init %s needs the adapter (mode cpu / hip)" % a.init)
+        graft.load_oracle().lib()     # builds oracle/_build/liboracle.so when missing
+        if D.dropin_set_initializer({"seq": 1, "hip": 2}[a.init], os.path.join(ROOT, "oracle", "_build", "liboracle.so").encode()) != 0:
+            raise SystemExit("dropin_set_initializer failed")
+    S = R.System(a.w, a.h, K4, point_density=a.density)
+    if D is not None:
+        R.lib().ref_system_fullsystem.restype = C.c_void_p; R.lib().ref_system_fullsystem.argtypes = [C.c_void_p]
+        D.dropin_attach(R.lib().ref_system_fullsystem(S.p))
+    t0 = time.perf_counter()
+    status = [S.add_frame(img) for img in imgs]
+    wall = time.perf_counter() - t0
+    tr = S.trajectory()
+    ev = S.events()
+    opt = [e for e in ev if e["kind"] == "opt_out"]
+    opt_in = [e for e in ev if e["kind"] == "opt_in"]
+    # what the initialiser handed over (its calcResAndGS always runs on NUM_THREADS workers that take 50-point chunks as they come, CoarseInitializer.cpp:507 /
+    # util/IndexThreadReduce.h:83-87, whatever `multiThreading` says: the reference's own result varies in the last bits from run to run, and with it every discrete
+    # decision downstream).  Runs with the same signature started from the same initialisation; everything after it is single-threaded and deterministic.
+    import hashlib
+    sig = hashlib.md5(np.ascontiguousarray(opt_in[0]["idepth"]).tobytes() + np.ascontiguousarray(opt_in[0]["frames"][1]["evalPT"]).tobytes()).hexdigest() if opt_in else ""
+    out = dict(init_signature=np.array([sig]), camToWorld=tr["camToWorld"], valid=tr["valid"], keyframeId=tr["keyframeId"], trackingRef=tr["trackingRef"], aff=tr["aff"],
+               poses_true=np.array(poses_true), wall_s=np.array([wall]), initialized=np.array([s["initialized"] for s in status]), lost=np.array([s["isLost"] for s in status]),
+               window=np.array([s["window"] for s in status]), opt_rmse=np.array([e["rmse"] for e in opt]), opt_resInA=np.array([e["resInA"] for e in opt]),
+               opt_F=np.array([e["F"] for e in opt_in]), opt_N=np.array([e["N"] for e in opt_in]), opt_R=np.array([e["R"] for e in opt_in]),
+               n_tracks=np.array([sum(1 for e in ev if e["kind"] == "track_out")]))
+    if D is not None:
+        sec = (C.c_double * 5)(); calls = (C.c_long * 5)()
+        D.dropin_get_stats(sec, calls)
+        out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
+        msg = C.create_string_buffer(512)
+        out["failures"] = np.array([D.dropin_failures(msg, 512)])
+        if out["failures"][0]:
+            print("adapter failures:", msg.value.decode(errors="replace"))
+    if a.result_txt:
+        S.print_result(a.result_txt)
+    np.savez(a.out, **out)
+    print("signature", sig)
+    print("%s: %d frames in %.2f s, %d keyframe optimisations, initialised %s, lost %s" % (a.mode, len(imgs), wall, len(opt), status[-1]["initialized"], status[-1]["isLost"]))
+
+
+if __name__ == "__main__":
+    main()
