@@ -88,6 +88,13 @@ struct Backend
 	// 1 = the oracle's single-threaded restatement (oracle/init_oracle.cpp, per-point bit-identical to the reference: the sums one worker taking every chunk would form)
 	//     — a DETERMINISTIC all-CPU run to compare against; 2 = libdmvio_hip.so (dmvio_hip_initializer_calc_res_and_gs)
 	int init_mode = 0;
+	// shadow: the reference's own members stay in charge of the pipeline (so the two sides never drift apart through a flipped discrete decision); every call is ALSO run on
+	// libdmvio_hip.so from the same inputs and the two answers are compared — per-call parity on the live windows / frames of a run of the reference's FullSystem
+	bool shadow = false;
+	struct Shadow {
+		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_opt_iter_diff = 0;
+		double opt_rmse_rel = 0, opt_energy_rel = 0, opt_pose = 0, opt_aff = 0, opt_idepth_med = 0, track_pose = 0, track_aff_a = 0, track_aff_b = 0, track_res_rel = 0;
+	} sh;
 	dmvio_hip_initializer* ini = nullptr;
 	void* oracle_lib = nullptr;
 	Stats stats;
@@ -209,6 +216,18 @@ int dropin_set_initializer(int mode, const char* liboracle_path)
 	g.init_mode = mode;
 	return 0;
 }
+// shadow mode (needs dropin_enable(1, ...)): the reference's own members run the pipeline, the HIP library runs every call beside them, deviations are recorded
+void dropin_set_shadow(int on) { g.shadow = on != 0; g.sh = Backend::Shadow(); }
+// out[16]: n_opt, n_track, n_trace_pts, n_trace_diff, n_track_good_diff, n_opt_iter_diff, max over calls of: optimize rmse (relative), final energy (relative), keyframe
+// translation (m), affine a|b (scaled units), median relative idepth difference; trackNewestCoarse translation (m), affine a, affine b, lastResiduals[0] (relative)
+void dropin_get_shadow(double* out)
+{
+	const Backend::Shadow& h = g.sh;
+	const double v[15] = {(double)h.n_opt, (double)h.n_track, (double)h.n_trace_pts, (double)h.n_trace_diff, (double)h.n_track_good_diff, (double)h.n_opt_iter_diff, h.opt_rmse_rel,
+	                      h.opt_energy_rel, h.opt_pose, h.opt_aff, h.opt_idepth_med, h.track_pose, h.track_aff_a, h.track_aff_b, h.track_res_rel};
+	for (int i = 0; i < 15; i++) out[i] = v[i];
+	out[15] = 0;
+}
 int dropin_is_on() { return g.on ? 1 : 0; }
 // the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
 void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
@@ -292,6 +311,7 @@ void CoarseTracker::setCoarseTrackingRef(std::vector<FrameHessian*> frameHessian
 	static Fn orig = original<Fn>("_ZN3dso13CoarseTracker20setCoarseTrackingRefESt6vectorIPNS_12FrameHessianESaIS3_EE");
 	Timer tm(g.stats, 1);
 	if (!g.on) { orig(this, frameHessians); return; }
+	if (g.shadow) orig(this, frameHessians);   // the CPU template for the reference's own trackNewestCoarse; the device template below for the shadow call
 	assert(frameHessians.size() > 0);
 	lastRef = frameHessians.back();
 	// the points makeCoarseDepthL0 scatters (:144-161): active points whose newest residual is IN, at the pixel it projects to in lastRef, weighted by HdiF
@@ -321,6 +341,30 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
 	static Fn orig = original<Fn>("_ZN3dso13CoarseTracker17trackNewestCoarseEPNS_12FrameHessianERN6Sophus8SE3GroupIdLi0EEERNS_8AffLightEiN5Eigen6MatrixIdLi5ELi1ELi0ELi5ELi1EEEPNS_6IOWrap15Output3DWrapperE");
 	Timer tm(g.stats, 2);
 	if (!g.on) return orig(this, newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
+	if (g.shadow)
+	{
+		double pose7[7], aff[2] = {aff_g2l_out.a, aff_g2l_out.b}, minRes[5], lastRes[5], flow[3], H[64], b[8];
+		toPose7(lastToNew_out, pose7);
+		for (int i = 0; i < 5; i++) minRes[i] = minResForAbort[i];
+		int good = 0;
+		const bool ok = HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good));
+		const bool ret = orig(this, newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
+		if (ok)
+		{
+			g.sh.n_track++;
+			bool finished = true, finishedRef = true;
+			for (int l = 0; l <= coarsestLvl; l++) { if (!std::isfinite(lastRes[l])) finished = false; if (!std::isfinite(lastResiduals[l])) finishedRef = false; }
+			if (finished != finishedRef || (finished && (good != 0) != ret)) g.sh.n_track_good_diff++;
+			else if (finished)
+			{
+				double p7[7]; toPose7(lastToNew_out, p7);
+				for (int i = 0; i < 3; i++) g.sh.track_pose = std::max(g.sh.track_pose, std::fabs(p7[i] - pose7[i]));
+				g.sh.track_aff_a = std::max(g.sh.track_aff_a, std::fabs(aff[0] - aff_g2l_out.a)); g.sh.track_aff_b = std::max(g.sh.track_aff_b, std::fabs(aff[1] - aff_g2l_out.b));
+				g.sh.track_res_rel = std::max(g.sh.track_res_rel, std::fabs(lastRes[0] - lastResiduals[0]) / lastResiduals[0]);
+			}
+		}
+		return ret;
+	}
 	assert(coarsestLvl < 5 && coarsestLvl < pyrLevelsUsed);
 	lastResiduals.setConstant(NAN);
 	lastFlowIndicators.setConstant(1000);
@@ -350,8 +394,9 @@ void FullSystem::traceNewCoarse(FrameHessian* fh)
 	Timer tm(g.stats, 3);
 	g.fs = this;
 	if (!g.on) { orig(this, fh); return; }
-	dmvio::TimeMeasurement timeMeasurement("traceNewCoarse");   // the profiler scopes the reference opens (:543, FullSystemOptimize.cpp:419) stay where they were
-	boost::unique_lock<boost::mutex> lock(mapMutex);
+	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;   // the profiler scopes the reference opens (:543, FullSystemOptimize.cpp:419) stay where they were
+	if (!g.shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("traceNewCoarse"));
+	std::unique_ptr<boost::unique_lock<boost::mutex>> lock(new boost::unique_lock<boost::mutex>(mapMutex));
 	Mat33f K = Mat33f::Identity();
 	K(0, 0) = Hcalib.fxl(); K(1, 1) = Hcalib.fyl(); K(0, 2) = Hcalib.cxl(); K(1, 2) = Hcalib.cyl();
 	const int nH = (int)frameHessians.size();
@@ -373,16 +418,40 @@ void FullSystem::traceNewCoarse(FrameHessian* fh)
 		if (!ui.empty() && !HIP_OK(dmvio_hip_immature_add_points(g.imm, hI, slotFor(host), (int)ui.size(), ui.data(), vi.data()))) return;
 	}
 	const int n = (int)pts.size();
-	if (n == 0) return;
+	if (n == 0) { if (g.shadow) { lock.reset(); orig(this, fh); } return; }
 	std::vector<float> imin(n), imax(n), qual(n), uv(2 * n), interval(n);
 	std::vector<int> status(n);
-	for (int i = 0; i < n; i++) { imin[i] = pts[i]->idepth_min; imax[i] = pts[i]->idepth_max; qual[i] = pts[i]->quality; status[i] = (int)pts[i]->lastTraceStatus; }
+	std::vector<unsigned char> wasOOB(n);   // traceOn returns at once for a point that is OOB already (:79): nothing of it changes
+	for (int i = 0; i < n; i++) { imin[i] = pts[i]->idepth_min; imax[i] = pts[i]->idepth_max; qual[i] = pts[i]->quality; status[i] = (int)pts[i]->lastTraceStatus; wasOOB[i] = pts[i]->lastTraceStatus == IPS_OOB; }
 	if (!HIP_OK(dmvio_hip_immature_set_state(g.imm, imin.data(), imax.data(), qual.data(), status.data()))) return;
 	if (!HIP_OK(dmvio_hip_immature_trace(g.imm, slotFor(fh), nH, KRKi9.data(), Kt3.data(), aff2.data()))) return;
 	if (!HIP_OK(dmvio_hip_immature_get_state(g.imm, imin.data(), imax.data(), qual.data(), uv.data(), interval.data(), status.data()))) return;
+	if (g.shadow)
+	{
+		lock.reset();
+		orig(this, fh);   // the reference's own traceOn of every point; then field by field, bit by bit
+		for (int i = 0; i < n; i++)
+		{
+			ImmaturePoint* ip = pts[i];
+			if (wasOOB[i]) continue;
+			const float ruv[2] = {ip->lastTraceUV[0], ip->lastTraceUV[1]};
+			const bool same = (int)ip->lastTraceStatus == status[i] && memcmp(&ip->idepth_min, &imin[i], 4) == 0 && memcmp(&ip->idepth_max, &imax[i], 4) == 0 &&
+			                  memcmp(&ip->quality, &qual[i], 4) == 0 && memcmp(ruv, &uv[2 * i], 8) == 0 && memcmp(&ip->lastTracePixelInterval, &interval[i], 4) == 0;
+			g.sh.n_trace_pts++;
+			if (!same)
+			{
+				if (g.sh.n_trace_diff < 8 && getenv("DROPIN_DEBUG"))
+					fprintf(stderr, "[dropin] trace diff: status %d / %d, idepth [%g %g] / [%g %g], quality %g / %g, uv (%g %g) / (%g %g), interval %g / %g\n", (int)ip->lastTraceStatus, status[i],
+					        ip->idepth_min, ip->idepth_max, imin[i], imax[i], ip->quality, qual[i], ruv[0], ruv[1], uv[2 * i], uv[2 * i + 1], ip->lastTracePixelInterval, interval[i]);
+				g.sh.n_trace_diff++;
+			}
+		}
+		return;
+	}
 	for (int i = 0; i < n; i++)
 	{
 		ImmaturePoint* ip = pts[i];
+		if (wasOOB[i]) continue;
 		ip->idepth_min = imin[i]; ip->idepth_max = imax[i]; ip->quality = qual[i];
 		ip->lastTraceUV = Vec2f(uv[2 * i], uv[2 * i + 1]); ip->lastTracePixelInterval = interval[i];
 		ip->lastTraceStatus = (ImmaturePointStatus)status[i];
@@ -398,7 +467,8 @@ float FullSystem::optimize(int mnumOptIts)
 	Timer tm(g.stats, 4);
 	g.fs = this;
 	if (!g.on) return orig(this, mnumOptIts);
-	dmvio::TimeMeasurement timeMeasurement("FullSystemOptimize");
+	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;
+	if (!g.shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("FullSystemOptimize"));
 	if (setting_useGTSAMIntegration) { fprintf(stderr, "[dropin] GTSAM runs: use dmvio_hip_ba_optimize_vio with the BAGTSAMIntegration members as hooks\n"); abort(); }
 	const int F = (int)frameHessians.size();
 	if (F < 2) return 0;
@@ -463,7 +533,34 @@ float FullSystem::optimize(int mnumOptIts)
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
 	float rmse = 0; double finalEnergy = 0; int iterations = 0;
 	ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));
+	if (!ok && g.shadow) return orig(this, mnumOptIts);
 	if (!ok) { isLost = true; return 0; }   // a failure inside optimize reads as isLost (:613-617)
+	if (g.shadow)
+	{
+		// the reference's own optimize on the same window; then its results against the device's
+		std::vector<double> hp(7 * (size_t)F), ha(2 * (size_t)F);
+		std::vector<float> hid(N), hstep(N);
+		for (int f = 0; f < F; f++) { double st10[10]; HIP_OK(dmvio_hip_ba_get_frame(ba, f, &hp[7 * f], &ha[2 * f], st10)); }
+		HIP_OK(dmvio_hip_ba_get_points(ba, hid.data(), hstep.data()));
+		int resInA_hip = 0; HIP_OK(dmvio_hip_ba_get_res_in_a(ba, &resInA_hip));
+		const float r0 = orig(this, mnumOptIts);
+		g.sh.n_opt++;
+		g.sh.opt_rmse_rel = std::max(g.sh.opt_rmse_rel, (double)std::fabs(rmse - r0) / r0);
+		const double Eref = (double)r0 * r0 * patternNum * ef->resInA;
+		g.sh.opt_energy_rel = std::max(g.sh.opt_energy_rel, std::fabs(finalEnergy - Eref) / Eref);
+		if (resInA_hip != ef->resInA) g.sh.n_opt_iter_diff++;
+		for (int f = 0; f < F; f++)
+		{
+			double p7[7]; toPose7(frameHessians[f]->PRE_worldToCam, p7);
+			for (int i = 0; i < 3; i++) g.sh.opt_pose = std::max(g.sh.opt_pose, std::fabs(p7[i] - hp[7 * f + i]));
+			g.sh.opt_aff = std::max(g.sh.opt_aff, std::max(std::fabs(frameHessians[f]->aff_g2l().a - ha[2 * f]), std::fabs(frameHessians[f]->aff_g2l().b - ha[2 * f + 1]) / 100.0));
+		}
+		std::vector<double> rel(N);
+		for (int pi = 0; pi < N; pi++) rel[pi] = std::fabs(points[pi]->idepth - hid[pi]) / std::max(1e-3f, std::fabs(points[pi]->idepth));
+		std::nth_element(rel.begin(), rel.begin() + N / 2, rel.end());
+		g.sh.opt_idepth_med = std::max(g.sh.opt_idepth_med, rel[N / 2]);
+		return r0;
+	}
 	// ---- write-back: calibration, keyframe states (the newest one re-anchored like :596-603), thresholds
 	{
 		double value[4], value_zero[4];

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--frames", type=int, default=62); ap.add_argument("--step", type=float, default=1.6)
     ap.add_argument("--density", type=int, default=300); ap.add_argument("--accumulators", type=int, default=0)
     ap.add_argument("--result-txt", default=None)
+    ap.add_argument("--shadow", action="store_true", help="mode hip: the reference's own members run the pipeline, libdmvio_hip.so runs every call beside them from the same "
+                                                         "inputs; the deviations per call are recorded (no drift through flipped discrete decisions)")
     ap.add_argument("--cache", default=None, help="directory that keeps the rendered sequence between runs (rendering 512x512 frames costs more than tracking them)")
     ap.add_argument("--init", choices=["ref", "seq", "hip"], default="ref",
                     help="CoarseInitializer::calcResAndGS: the reference's own (multi-threaded: run-to-run noise), the oracle's single-threaded restatement (deterministic "
@@ -51,6 +53,7 @@ def main():
         D.dropin_enable.argtypes = [C.c_int] * 5
         D.dropin_attach.argtypes = [C.c_void_p]
         D.dropin_set_initializer.argtypes = [C.c_int, C.c_char_p]
+        D.dropin_set_shadow.argtypes = [C.c_int]; D.dropin_get_shadow.argtypes = [C.POINTER(C.c_double)]
         D.dropin_get_stats.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_long)]
         D.dropin_failures.argtypes = [C.c_char_p, C.c_int]; D.dropin_failures.restype = C.c_long
     import ref_py as R
@@ -68,6 +71,10 @@ def main():
     # the reference draws from the C library's rand() (PixelSelector's random pattern, CoarseInitializer's point selection): the same sequence in every mode, whatever the
     # static initialisers of the libraries loaded so far have consumed
     C.CDLL(None).srand(1)
+    if a.shadow:
+        if a.mode != "hip":
+            raise SystemExit("--shadow needs --mode hip")
+        D.dropin_set_shadow(1)
     if a.init != "ref":
         if D is None or (a.init == "hip" and a.mode != "hip"):
             raise SystemExit("--init %s needs the adapter (mode cpu / hip)" % a.init)
@@ -98,6 +105,9 @@ def main():
     if D is not None:
         sec = (C.c_double * 5)(); calls = (C.c_long * 5)()
         D.dropin_get_stats(sec, calls)
+        if a.shadow:
+            sh = (C.c_double * 16)(); D.dropin_get_shadow(sh)
+            out["shadow"] = np.array(list(sh))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
         msg = C.create_string_buffer(512)
         out["failures"] = np.array([D.dropin_failures(msg, 512)])
