@@ -697,6 +697,13 @@ class RcclCommunicator:
         self.p = out
         self.rank, self.world = rank, world
 
+    def info(self):
+        """(ncclCommCount, ncclCommUserRank): what RCCL itself reports for this communicator."""
+        n = C.c_int(0); r = C.c_int(-1)
+        fn = self.L.dmvio_hip_comm_info; fn.argtypes = [C.c_void_p, c_i, c_i]
+        _chk(self.L, fn(self.p, C.byref(n), C.byref(r)), "comm_info")
+        return n.value, r.value
+
     def close(self):
         if getattr(self, "p", None):
             self.L.dmvio_hip_comm_destroy(self.p)
@@ -932,6 +939,13 @@ class BundleAdjusterHip:
         self._comm_keep = cb      # the C side stores the function pointers: keep the thunks alive
         _chk(self.L, self.L.dmvio_hip_ba_set_comm_callbacks(self.p, C.byref(cb), rank, world), "ba_set_comm_callbacks")
 
+    def profile_chain(self, reps=20):
+        """Mean microseconds of the five kernels of an accepted GN iteration (linearise, per-point sums, accumulate, stitch, gather), HIP events on the handle's stream."""
+        us = np.zeros(5, dtype=np.float32)
+        fn = self.L.dmvio_hip_ba_profile_chain; fn.argtypes = [C.c_void_p, C.c_int, c_f]
+        _chk(self.L, fn(self.p, int(reps), _f(us)), "ba_profile_chain")
+        return dict(zip(("k_ba_linearize", "k_ba_point_sums", "k_ba_accumulate", "k_ba_stitch", "k_ba_stitch_gather"), [float(x) for x in us]))
+
     def point_hessian(self):
         o = np.zeros(self.N, dtype=np.float32)
         _chk(self.L, self.L.dmvio_hip_ba_get_point_hessian(self.p, _f(o)), "ba_get_point_hessian"); return o
@@ -940,6 +954,20 @@ class BundleAdjusterHip:
         """The reference's non-GTSAM solve (diagonal pre-scaling + pivoted LDL^T), host-only."""
         H = np.ascontiguousarray(HPassed, dtype=np.float64); bb = np.ascontiguousarray(b, dtype=np.float64); x = np.zeros(len(bb))
         _chk(self.L, self.L.dmvio_hip_ba_solve_ldlt(len(bb), _d(H), _d(bb), _d(x)), "ba_solve_ldlt"); return x
+
+    def optimize_vio_own_solver(self, its=6, HMForGTSAM=None, bMForGTSAM=None):
+        """dmvio_hip_ba_optimize_vio with dmvio_hip_ba_hook_ldlt (the library's own solve, a C function) as computeBAUpdate: the hand-off path without Python in the loop."""
+        n = self.n
+        cb = BACallbacks()
+        cb.computeBAUpdate = C.cast(self.L.dmvio_hip_ba_hook_ldlt, _BA_COMPUTE)
+        opt = BAVioOptions(1, 0, -1, -1, None, None)
+        keep = []
+        if HMForGTSAM is not None:
+            HMg = np.ascontiguousarray(HMForGTSAM, dtype=np.float64).reshape(n, n); bMg = np.ascontiguousarray(bMForGTSAM, dtype=np.float64).reshape(n)
+            keep = [HMg, bMg]; opt.HMForGTSAM = _d(HMg); opt.bMForGTSAM = _d(bMg)
+        rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))
+        _chk(self.L, self.L.dmvio_hip_ba_optimize_vio(self.p, its, C.byref(cb), C.byref(opt), C.byref(rm), C.byref(fe), C.byref(it), _d(tr)), "ba_optimize_vio")
+        return dict(rmse=rm.value, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])
 
     def optimize_vio(self, its, hooks, trackingWasGood=True, updateDuring=False, minOptIterations=-1, resInA_at_entry=-1, HMForGTSAM=None, bMForGTSAM=None):
         """FullSystem::optimize with the reference's default (GTSAM) solver branch.  `hooks`: an object with the methods of dmvio::BAGTSAMIntegration the loop calls —

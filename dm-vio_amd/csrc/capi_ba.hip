@@ -110,7 +110,9 @@ struct dmvio_hip_ba {
   int resInA_solve = 0;              // ef->resInA as the reference holds it: set by the accumulation of the last solveSystemF
   float* h_idepth_backup = nullptr;
   std::vector<dmvio_hip_ba_frame_view> vio_frames;
+  hipEvent_t* prof = nullptr;        // dmvio_hip_ba_profile_chain: six events recorded between the launches of linearise -> per-point sums -> accumulate -> stitch -> gather
 };
+#define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #x).c_str()); } while (0)
 
 template <class T>
@@ -295,8 +297,10 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   // the decision pass (last workgroup of the linearisation) publishes the ticket the host polls; the applyRes kernel of a fix-linearisation runs behind it on the
   // same stream and nothing it writes is read by the host, so no stream synchronisation is needed for it either
   const BADecide D = makeDecide(b, 0, !keep_threshold, true);
+  BA_PROF(b, 0);
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
                      (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+  BA_PROF(b, 1);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
   HIPCHK(hipGetLastError());
   if (shard) { if (int r = decideGlobal(b, D)) return r; }
@@ -317,6 +321,7 @@ static int accumulateWait(dmvio_hip_ba* b);
 static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false, bool apply_first = false, int gate = BA_GATE_ALWAYS) {
   if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0, apply_first ? 1 : 0,
                                       (const BACtl*)b->d_ctl, gate, (backup_points && b->vio) ? b->h_idepth_backup : (float*)nullptr);
+  BA_PROF(b, 2);
   return accumulateViews(b, b->Rs, b->P, wait, gate);
 }
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
@@ -337,8 +342,10 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
     }
     hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV, (const BACtl*)b->d_ctl, gate);
   }
+  BA_PROF(b, 3);
   hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
                      b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
+  BA_PROF(b, 4);
   const int tot = 2 * (n * n + n);
   if (!sharded(b)) {
     b->acc_ticket = ++b->ticket;
@@ -355,6 +362,7 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
     hipLaunchKernelGGL(k_ba_publish_sys, dim3(1), dim3(1024), 0, s, (const double*)b->d_sys, b->h_sys, tot + 1, b->h_res, b->acc_ticket);
   }
   HIPCHK(hipGetLastError());
+  BA_PROF(b, 5);
   return wait ? accumulateWait(b) : 0;
 }
 // the gather kernel publishes per workgroup (BAHostRes::gticket): wait until every slot shows the chain's ticket
@@ -513,6 +521,16 @@ int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128],
   ncclComm_t comm = nullptr;
   NCCLCHK(ncclCommInitRank(&comm, world, id, rank));
   *out = (void*)comm;
+  return 0;
+}
+// ncclCommCount / ncclCommUserRank of a communicator: what RCCL itself says about the group (bench.py prints it in the N > 1 line)
+int dmvio_hip_comm_info(void* comm, int* n_ranks, int* rank) {
+  if (!comm) return failmsg("null communicator");
+  int n = 0, r = -1;
+  NCCLCHK(ncclCommCount((ncclComm_t)comm, &n));
+  NCCLCHK(ncclCommUserRank((ncclComm_t)comm, &r));
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
   return 0;
 }
 int dmvio_hip_comm_destroy(void* comm) {
@@ -1119,6 +1137,32 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   return 0;
 }
 
+// Measurement: the kernel chain of an ACCEPTED Gauss-Newton iteration on the current state — linearise (+ energy / threshold decision pass) -> applyRes + per-point sums
+// -> accumulate -> adjoint stitch -> gather — `reps` times, with HIP events recorded on the handle's stream between the launches; us5 = mean microseconds of the five
+// kernels (each figure includes the gap to the next launch: what the chain costs on the stream).  The window state is left as a linearise + applyRes + accumulate leaves it.
+int dmvio_hip_ba_profile_chain(dmvio_hip_ba* b, int reps, float us5[5]) {
+  BA_READY(b);
+  if (!us5 || reps < 1) return failmsg("ba_profile_chain: bad argument");
+  if (sharded(b)) return failmsg("ba_profile_chain: single-device windows only");
+  std::lock_guard<std::mutex> lk(b->mu);
+  hipEvent_t ev[6];
+  for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k]));
+  double acc[5] = {0, 0, 0, 0, 0};
+  int rc = 0;
+  for (int r = 0; r < reps && rc == 0; r++) {
+    double e = 0;
+    b->prof = ev;
+    rc = linearizeAll(b, false, &e, 0, false, true);   // enqueue only
+    if (rc == 0) rc = accumulate(b, true, true, false, true);
+    b->prof = nullptr;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < 5; k++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += 1e3 * ms; }
+  }
+  for (int k = 0; k < 6; k++) hipEventDestroy(ev[k]);
+  for (int k = 0; k < 5; k++) us5[k] = (float)(acc[k] / reps);
+  return rc;
+}
+
 // diagnostics: in-kernel timeline of the last decision pass, 100 MHz ticks since its workgroup started (begin, energy, keys, selected)
 int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* b, int ticks4[4]) {
   if (!b || !b->h_res || !ticks4) return failmsg("null argument");
@@ -1284,6 +1328,12 @@ int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_b
   if (sharded(b)) return failmsg("ba_optimize_vio: not available for a window sharded over ranks (every rank would have to run identical hooks)");
   std::lock_guard<std::mutex> lk(b->mu);
   return optimizeImpl(b, mnumOptIts, cb, opt, rmse, finalEnergy, iterations, trace);
+}
+// dmvio_hip_ba_solve_ldlt with the signature of the computeBAUpdate hook: a ready-made hook for callers that fall back to the visual-only solve (user is ignored)
+int dmvio_hip_ba_hook_ldlt(void* user, int n, const double* HPassed, const double* b_in, double lambda, const double* HNoLambda, int F, const dmvio_hip_ba_frame_view* frames,
+                           const double calib_value[4], double* x_out) {
+  (void)user; (void)lambda; (void)HNoLambda; (void)F; (void)frames; (void)calib_value;
+  return dmvio_hip_ba_solve_ldlt(n, HPassed, b_in, x_out);
 }
 // The library's own solver as a computeBAUpdate hook (EnergyFunctional.cpp:971-973: diagonal pre-scaling (H_ii + 10)^-1/2, pivoted LDL^T): for hooks that fall back to the
 // visual-only step, and the check that the hook path reproduces dmvio_hip_ba_optimize bit for bit.  HPassed is n x n row-major; host-only.

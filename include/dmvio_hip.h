@@ -297,6 +297,10 @@ int dmvio_hip_ba_get_calib_values(dmvio_hip_ba* ba, double value[4], double valu
 int dmvio_hip_ba_get_res_in_a(dmvio_hip_ba* ba, int* resInA);
 /* one Gauss-Newton iteration = the loop body of FullSystem::optimize (FullSystemOptimize.cpp:485-586); lastE = {E_A, E_L, E_M} in/out */
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* ba, int iteration, double* lambda_io, double lastE[3], int* accepted);
+/* Measurement: the five kernels of an ACCEPTED Gauss-Newton iteration on the current state (linearise + decision pass, applyRes + per-point sums, accumulate, adjoint
+ * stitch, gather), `reps` times with HIP events recorded on the handle's stream between the launches; us5 = mean microseconds per kernel (each includes the gap to
+ * the next launch).  What bench.py's ba.roofline is computed from. */
+int dmvio_hip_ba_profile_chain(dmvio_hip_ba* ba, int reps, float us5[5]);
 /* Diagnostics: in-kernel timeline of the last decision pass (energy sum, newest keyframe's threshold, accept test — taken by the last
  * workgroup of the linearisation kernel): 100 MHz ticks since that workgroup started: pass begin, energy summed, threshold keys loaded, done. */
 int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* ba, int ticks4[4]);
@@ -324,6 +328,7 @@ int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* ba, const dmvio_hip_comm_callb
  * the caller), ncclCommInitRank on the context's device, ncclCommDestroy. */
 int dmvio_hip_comm_unique_id(unsigned char id128[128]);
 int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128], int rank, int world, void** nccl_comm_out);
+int dmvio_hip_comm_info(void* nccl_comm, int* n_ranks, int* rank);   /* ncclCommCount, ncclCommUserRank */
 int dmvio_hip_comm_destroy(void* nccl_comm);
 
 /* Building blocks of a SHARDED GN iteration driven by the caller (points of one keyframe per GPU; the packed systems / energies are summed by the caller
@@ -384,6 +389,9 @@ typedef struct dmvio_hip_ba_vio_options {
 int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* ba, int mnumOptIts, const dmvio_hip_ba_callbacks* cb, const dmvio_hip_ba_vio_options* opt, float* rmse, double* finalEnergy,
                               int* iterations, double* trace);
 int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b, double* x_out);
+/* the same with the signature of dmvio_hip_ba_callbacks::computeBAUpdate (user, lambda, HNoLambda, frames, calib_value ignored): usable as the hook itself */
+int dmvio_hip_ba_hook_ldlt(void* user, int n, const double* HPassed, const double* b, double lambda, const double* HNoLambda, int F, const dmvio_hip_ba_frame_view* frames,
+                           const double calib_value[4], double* x_out);
 /* PointHessian::idepth_hessian (set by AccumulatedSCHessianSSE::addPoint, AccumulatedSCHessian.cpp:42,50; read by FullSystem::flagPointsForRemoval, FullSystem.cpp:825) */
 int dmvio_hip_ba_get_point_hessian(dmvio_hip_ba* ba, float* idepth_hessian);
 

@@ -704,6 +704,12 @@ void ref_ba_immature_set_interval(void* p, int host, const float* idepth_min, co
 	FrameHessian* fh = ((RefWindow*)p)->fs->frameHessians[host];
 	for (size_t i = 0; i < fh->immaturePoints.size(); i++) { fh->immaturePoints[i]->idepth_min = idepth_min[i]; fh->immaturePoints[i]->idepth_max = idepth_max[i]; }
 }
+// every immature point of the window back to the state its constructor leaves (ImmaturePoint.cpp:34-62: interval [0, NaN], quality 10000, never traced) — a repeatable first trace
+void ref_ba_immature_reset(void* p)
+{
+	for (FrameHessian* fh : ((RefWindow*)p)->fs->frameHessians)
+		for (ImmaturePoint* ip : fh->immaturePoints) { ip->idepth_min = 0; ip->idepth_max = NAN; ip->quality = 10000; ip->lastTraceStatus = IPS_UNINITIALIZED; }
+}
 // FullSystem::traceNewCoarse (FullSystem.cpp:541-584) with keyframe `target` of the window as the new frame: per-host KRKi / Kt / affine + traceOn of every immature point
 void ref_ba_trace_new_coarse(void* p, int target) { FullSystem* fs = ((RefWindow*)p)->fs; fs->traceNewCoarse(fs->frameHessians[target]); }
 // FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:51-205) for every immature point of `host`: result 1 activated / 0 skip / -1 delete, the activated point's
@@ -1121,6 +1127,8 @@ float ref_ba_optimize_gtsam(void* p, int mnumOptIts, void* facade, int updateDur
 	*ba = dmvio::BAGTSAMIntegration();
 	return rmse;
 }
+// FullSystem::optimize without the stdout capture of ref_ba_optimize (timing: bench.py's ba.cpu_baseline)
+float ref_ba_optimize_quiet(void* p, int mnumOptIts) { return ((RefWindow*)p)->fs->optimize(mnumOptIts); }
 int ref_ba_log(void* p, char* out, int cap) { RefWindow* W = (RefWindow*)p; int n = std::min((int)W->log.size(), cap - 1); memcpy(out, W->log.data(), n); out[n] = 0; return n; }
 // flagPointsForRemoval + marginalizePointsF as makeKeyFrame runs them (FullSystem.cpp:1485-1492), with `flagged[k]` frames flagged
 // for marginalisation.  decision per point: 0 = kept, 1 = marginalised, 2 = dropped.  Hadd / badd = what marginalizePointsF added to HM / bM

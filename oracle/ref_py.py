@@ -151,6 +151,11 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------------------------ primitives
+def set_multithreading(on):
+    """settings.cpp `multiThreading`: linearizeAll, applyRes and the accumulators of EnergyFunctional on NUM_THREADS (6) workers."""
+    lib().ref_set_multithreading(1 if on else 0)
+
+
 def pyr_levels(w, h, K4=(100.0, 100.0, 50.0, 50.0)):
     return lib().ref_pyr_levels(w, h, _f(_f32(K4)))
 
@@ -539,6 +544,10 @@ class BAWindow:
     def immature_set_interval(self, host, idepth_min, idepth_max):
         self.L.ref_ba_immature_set_interval(self.p, host, _f(_f32(idepth_min)), _f(_f32(idepth_max)))
 
+    def immature_reset(self):
+        self.L.ref_ba_immature_reset.argtypes = [vp]
+        self.L.ref_ba_immature_reset(self.p)
+
     def trace_new_coarse(self, target):
         self.L.ref_ba_trace_new_coarse(self.p, target)
 
@@ -650,6 +659,11 @@ class BAWindow:
         rmse = self.L.ref_ba_optimize(self.p, its, C.byref(n), _d(tr))
         tr = tr[:n.value]
         return dict(rmse=rmse, trace=tr, iterations=int(np.sum(tr[:, 1] >= 0)), finalEnergy=float(tr[tr[:, 1] != 0][-1, 0]) if len(tr) else float("nan"))
+
+    def optimize_quiet(self, its=6):
+        """FullSystem::optimize, nothing captured or parsed (timing)."""
+        self.L.ref_ba_optimize_quiet.restype = C.c_float; self.L.ref_ba_optimize_quiet.argtypes = [vp, C.c_int]
+        return self.L.ref_ba_optimize_quiet(self.p, int(its))
 
     def optimize_gtsam(self, its, facade, update_during=False, tracking_was_good=True, min_opt_its=-1):
         """FullSystem::optimize on the reference's default branch (setting_useGTSAMIntegration) with `facade` (GtsamFacade) behind BAGTSAMIntegration."""

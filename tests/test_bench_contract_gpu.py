@@ -34,6 +34,19 @@ def test_bench_line_contract(gpu_required):
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == "frames/s" and c["value"] > 0 and "frames" in c["sample"]
     assert d["value"] > 20 * c["value"]
-    assert d["ba"]["value"] > 0 and d["ba"]["unit"] == "GN-iters/s" and d["ba"]["cpu_baseline"]["value"] > 0
+    ba = d["ba"]
+    assert ba["value"] > 0 and ba["unit"] == "GN-iters/s" and ba["cpu_baseline"]["value"] > 0
+    # the BA half of the metric: accepted iterations on fresh windows, its own roofline object, the reference's own compiled optimize as the CPU baseline
+    assert abs(ba["value"] - 6.0 / (ba["optimize6_ms"] * 1e-3)) < 1e-3 * ba["value"] and ba["accepted_in_fresh_window"].startswith(("5", "6"))
+    assert ba["value_converged_loop"] > 0 and ba["gtsam_handoff"]["ratio_to_builtin"] < 1.5
+    rb = ba["roofline"]
+    assert rb["bound"] == "hbm" and rb["kernel"] == "k_ba_linearize" and rb["peak"] == 8000.0 and abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-4
+    assert rb["algorithmic_bytes_per_launch"] == 464 * ba["window"]["residuals"]
+    assert abs(rb["achieved"] - rb["algorithmic_bytes_per_launch"] / (rb["kernel_us"] * 1e-6) / 1e9) < 2e-3 * rb["achieved"]
+    assert set(rb["chain_us"]) == {"k_ba_linearize", "k_ba_point_sums", "k_ba_accumulate", "k_ba_stitch", "k_ba_stitch_gather"} and rb["iteration"]["kernels_us"] < rb["iteration"]["wall_us"] * 1.2
+    cb = ba["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["unit"] == "GN-iters/s"
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
+        assert cb["kind"] == "reference" and cb["cores"] in (1, 6) and d["trace"]["cpu_baseline"]["kind"] == "reference"
     assert d["pcie"]["good"] and d["pcie"]["raw_u8"]["good"] and d["pcie"]["raw_u8"]["value"] > d["pcie"]["value"]
     assert d["max_pose_err_m"] < 5e-3
