@@ -57,6 +57,16 @@ static int mappingDemo() {
   std::printf("optimize: %d points, %d iterations, rmse %.3f, energy %.1f -> %.1f, mean idepth %.4f (start %.4f)\n", N, ef.lastIterations, rmse, E0, ef.lastEnergy, mean, idepth * 1.08);
   if (!(rmse >= 0) || !(ef.lastEnergy < 0.5 * E0)) { std::fprintf(stderr, "bundle adjustment did not reduce the energy\n"); return 5; }
   std::printf("ok: energy reduced to %.0f %%\n", 100.0 * ef.lastEnergy / E0);
+  // the reference's default branch: every solve handed to a hook (here the library's own LDLT, so the result must be the one above)
+  dmvio_hip::WindowOptimizer ef2(frames);
+  if (!ef2.setWindow(frameHessians, fx, fy, cx, cy) || !ef2.setPoints(points)) return 1;
+  dmvio_hip_ba_callbacks hooks = dmvio_hip_ba_callbacks();
+  hooks.computeBAUpdate = dmvio_hip_ba_hook_ldlt;
+  dmvio_hip_ba_vio_options opt = dmvio_hip_ba_vio_options();
+  opt.coarseTrackingWasGood = 1; opt.minOptIterations = -1; opt.resInA_at_entry = -1;
+  const float rmse2 = ef2.optimize(6, hooks, opt);
+  if (rmse2 != rmse || ef2.lastEnergy != ef.lastEnergy) { std::fprintf(stderr, "hook path differs: rmse %.9g vs %.9g, energy %.9g vs %.9g\n", rmse2, rmse, ef2.lastEnergy, ef.lastEnergy); return 6; }
+  std::printf("ok: the same window through the computeBAUpdate hook: identical result\n");
   return 0;
 }
 

@@ -237,6 +237,15 @@ class WindowOptimizer {
     if (dmvio_hip_ba_optimize(ba_, mnumOptIts, &rmse, &lastEnergy, &lastIterations, energyTrace) != 0) return -1.0f;
     return rmse;
   }
+  /* FullSystem::optimize on the reference's default branch (setting_useGTSAMIntegration): the members of dmvio::BAGTSAMIntegration the loop calls as hooks
+   * (computeBAUpdate / getBAEnergy / updateBAValues / updateDynamicWeight / canBreak / acceptBAUpdate / postOptimization, include/dmvio_hip.h), the options what the
+   * reference reads beside them (shell->trackingWasGood, updateDynamicWeightDuringOptimization, setting_minOptIterations, ef->resInA, HMForGTSAM / bMForGTSAM) */
+  float optimize(int mnumOptIts, const dmvio_hip_ba_callbacks& hooks, const dmvio_hip_ba_vio_options& options) {
+    if (!ba_) return -1.0f;
+    float rmse = -1.0f;
+    if (dmvio_hip_ba_optimize_vio(ba_, mnumOptIts, &hooks, &options, &rmse, &lastEnergy, &lastIterations, energyTrace) != 0) return -1.0f;
+    return rmse;
+  }
   /* one window over several GPUs: this optimizer holds all keyframes and the rank's share of the points; with a communicator set, optimize() is collective (every rank
    * calls it) and runs the all-reduce of the system and the all-gather of the decision records itself, on its own stream (include/dmvio_hip.h, dmvio_hip_ba_set_comm) */
   bool setCommunicator(void* ncclComm, int rank, int world) { return ba_ && dmvio_hip_ba_set_comm(ba_, ncclComm, rank, world) == 0; }
