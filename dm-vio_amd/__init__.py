@@ -495,6 +495,29 @@ class CoarseTrackerHip:
                                                                _d(pose), _d(aff), _d(flow), C.byref(w), C.byref(used), C.byref(good)), "trackNewCoarse")
         return dict(winner=w.value, pose7=pose, aff=aff, achievedRes=rm, flow=flow, tries_used=used.value, good=bool(good.value))
 
+    # ---- hypothesis-parallel trackNewCoarse over several GPUs (include/dmvio_hip.h)
+    def set_comm(self, comm, rank, world):
+        """comm: an RcclCommunicator (or a raw ncclComm_t address); None detaches."""
+        fn = self.L.dmvio_hip_tracker_set_comm; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _chk(self.L, fn(self.p, getattr(comm, "p", comm), int(rank), int(world)), "tracker_set_comm")
+        self._comm_keep = comm
+
+    def set_comm_allreduce(self, allreduce, rank, world):
+        """allreduce(numpy float64 array) sums the array over all ranks IN PLACE (any transport: torch.distributed / gloo, MPI, threads); None detaches."""
+        fn = self.L.dmvio_hip_tracker_set_comm_callbacks; fn.argtypes = [C.c_void_p, C.POINTER(CommCallbacks), C.c_int, C.c_int]
+        if allreduce is None:
+            _chk(self.L, fn(self.p, None, 0, 0), "tracker_set_comm_callbacks"); self._comm_keep = None; return
+
+        def thunk(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:       # never unwind through the C frames
+                return 1
+        cb = CommCallbacks(None, _ALLREDUCE_F64(thunk), _ALLGATHER(lambda *a: 1))
+        self._comm_keep = cb
+        _chk(self.L, fn(self.p, C.byref(cb), int(rank), int(world)), "tracker_set_comm_callbacks")
+
     def last_ticks(self):
         a = C.c_longlong(0); b = C.c_longlong(0)
         _chk(self.L, self.L.dmvio_hip_tracker_last_ticks(self.p, C.byref(a), C.byref(b)), "last_ticks")

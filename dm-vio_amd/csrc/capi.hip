@@ -45,6 +45,10 @@ struct dmvio_hip_tracker {
   float* h_rec = nullptr;             // EVAL_SERVER_MAX_BLOCKS records of EVAL_RECORD_FLOATS floats: every server workgroup stores its partial sums + the ticket into its own
   bool server_on = false;             // a server kernel was launched for server_slot and has not been told to quit
   int server_slot = -1, server_G = 0;
+  // hypothesis-parallel trackNewCoarse: the tries after the first are split over `xworld` ranks, their per-try records summed over the ranks (every record is written by
+  // exactly one rank, the others add zeros) by `xchg`
+  std::function<int(double*, size_t)> xchg;
+  int xrank = 0, xworld = 0;
   unsigned int server_session = 0;    // identity of the current serverStart .. serverStop session (mailbox dword EVAL_MAIL_SESSION, kernel argument)
   long long server_idle_ticks = 500000;   // the server leaves after this long without a request (100 MHz ticks: 5 ms); dmvio_hip_tracker_set_server_idle_us
   int use_server = 1;                 // DMVIO_HIP_EVAL_SERVER=0: one k_eval_fused launch per evaluation instead
@@ -1139,12 +1143,46 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
   double flow[3] = {100, 100, 100}, bestPose[7], bestAff[2] = {0, 0};
   memcpy(bestPose, tries7, sizeof(bestPose));
   int computed = 0;
+  const bool split = t->xworld > 1 && (bool)t->xchg;
   for (int i = 0; i < n_tries; i++) {
     if (i >= computed) {
       const int first = computed, cnt = (first == 0) ? 1 : n_tries - first;
-      if (int r = dmvio_hip_tracker_track_batch(t, cnt, slots.data() + first, exps.data() + first, poses.data() + 7 * first, affs.data() + 2 * first, L - 1, nullptr,
-                                                lr.data() + 5 * first, fl.data() + 3 * first, nullptr, nullptr, good.data() + first, nullptr)) return r;
-      for (int k = 0; k < cnt; k++) { rep_lvl[first + k] = t->last_repeat_lvl[k]; rep_first[first + k] = t->last_first_pass_res[k]; }
+      if (first == 0 || !split) {
+        if (int r = dmvio_hip_tracker_track_batch(t, cnt, slots.data() + first, exps.data() + first, poses.data() + 7 * first, affs.data() + 2 * first, L - 1, nullptr,
+                                                  lr.data() + 5 * first, fl.data() + 3 * first, nullptr, nullptr, good.data() + first, nullptr)) return r;
+        for (int k = 0; k < cnt; k++) { rep_lvl[first + k] = t->last_repeat_lvl[k]; rep_first[first + k] = t->last_first_pass_res[k]; }
+      } else {
+        // the remaining hypotheses over the ranks (try 0 ran on every rank: same inputs, same bits, no exchange when it already ends the loop): rank r takes the tries
+        // first + r, first + r + world, ...; one record of 20 doubles per try [pose7 | aff2 | lastResiduals5 | flow3 | good | repeated level | its first-pass residual],
+        // written by its owner, zero elsewhere; the fp64 sum over the ranks (x + 0 = x, NaN stays NaN) hands every rank the complete list, and the sequential
+        // abort / winner rule below is replayed identically everywhere
+        enum { REC = 20 };
+        std::vector<int> mine;
+        for (int j = first + t->xrank; j < n_tries; j += t->xworld) mine.push_back(j);
+        const int m = (int)mine.size();
+        std::vector<double> rec((size_t)REC * cnt, 0.0);
+        if (m > 0) {
+          std::vector<double> mp(7 * (size_t)m), ma(2 * (size_t)m), mlr(5 * (size_t)m), mfl(3 * (size_t)m);
+          std::vector<int> mg(m), ms(m, new_slot);
+          std::vector<float> me(m, new_exposure);
+          for (int k = 0; k < m; k++) { memcpy(&mp[7 * (size_t)k], &poses[7 * (size_t)mine[k]], sizeof(double) * 7); ma[2 * k] = aff_last[0]; ma[2 * k + 1] = aff_last[1]; }
+          if (int r = dmvio_hip_tracker_track_batch(t, m, ms.data(), me.data(), mp.data(), ma.data(), L - 1, nullptr, mlr.data(), mfl.data(), nullptr, nullptr, mg.data(), nullptr)) return r;
+          for (int k = 0; k < m; k++) {
+            double* q = &rec[(size_t)REC * (mine[k] - first)];
+            memcpy(q, &mp[7 * (size_t)k], sizeof(double) * 7); q[7] = ma[2 * k]; q[8] = ma[2 * k + 1];
+            memcpy(q + 9, &mlr[5 * (size_t)k], sizeof(double) * 5); memcpy(q + 14, &mfl[3 * (size_t)k], sizeof(double) * 3);
+            q[17] = mg[k]; q[18] = t->last_repeat_lvl[k]; q[19] = t->last_first_pass_res[k];
+          }
+        }
+        if (int r = t->xchg(rec.data(), rec.size())) return r;
+        for (int k = 0; k < cnt; k++) {
+          const double* q = &rec[(size_t)REC * k];
+          const int j = first + k;
+          memcpy(&poses[7 * (size_t)j], q, sizeof(double) * 7); affs[2 * j] = q[7]; affs[2 * j + 1] = q[8];
+          memcpy(&lr[5 * (size_t)j], q + 9, sizeof(double) * 5); memcpy(&fl[3 * (size_t)j], q + 14, sizeof(double) * 3);
+          good[j] = q[17] != 0; rep_lvl[j] = (int)q[18]; rep_first[j] = q[19];
+        }
+      }
       computed = first + cnt;
     }
     used++;
@@ -1187,6 +1225,17 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
   return 0;
 }
 
+}  // extern "C"
+int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, size_t)> allreduce_sum, int rank, int world) {
+  if (!t) return failmsg("null tracker");
+  if (world <= 1 || !allreduce_sum) { t->xchg = nullptr; t->xrank = 0; t->xworld = 0; return 0; }
+  if (rank < 0 || rank >= world) return failmsg("tracker_set_comm: 0 <= rank < world");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->xchg = std::move(allreduce_sum); t->xrank = rank; t->xworld = world;
+  return 0;
+}
+dmvio_hip_ctx* dmv_tracker_ctx(dmvio_hip_tracker* t) { return t ? t->ctx : nullptr; }
+extern "C" {
 #ifdef DMV_LM_TICKS
 extern "C" int dmvio_hip_debug_lm_ticks(double out8[8], int reset) {
   HIPCHK(hipDeviceSynchronize());

@@ -523,6 +523,40 @@ int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128],
   *out = (void*)comm;
   return 0;
 }
+// ---- hypothesis-parallel FullSystem::trackNewCoarse (include/dmvio_hip.h): the per-try records of dmvio_hip_tracker_track_new_coarse summed over the ranks
+int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, int world) {
+  dmvio_hip_ctx* c = dmv_tracker_ctx(t);
+  if (!c) return failmsg("null tracker");
+  if (!nccl_comm || world <= 1) return dmv_tracker_set_exchange(t, nullptr, 0, world == 1 && nccl_comm ? 1 : 0);
+  ncclComm_t comm = (ncclComm_t)nccl_comm;
+  int n = 0, r = -1;
+  NCCLCHK(ncclCommCount(comm, &n));
+  NCCLCHK(ncclCommUserRank(comm, &r));
+  if (n != world || r != rank) return failmsg("tracker_set_comm: rank / world do not match the communicator");
+  return dmv_tracker_set_exchange(t, [c, comm](double* buf, size_t count) -> int {
+    double* d = nullptr;   // 20 doubles per hypothesis: a few KB, staged through device memory for RCCL on the context's stream
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc((void**)&d, sizeof(double) * count));
+    hipError_t e = hipMemcpyAsync(d, buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream);
+    ncclResult_t nr = ncclSuccess;
+    if (e == hipSuccess) nr = ncclAllReduce(d, d, count, ncclDouble, ncclSum, comm, c->stream);
+    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(buf, d, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (nr != ncclSuccess) return failmsg(std::string("RCCL: ") + ncclGetErrorString(nr) + " in the hypothesis exchange");
+    if (e != hipSuccess) return fail("hypothesis exchange", __FILE__, __LINE__, e);
+    return 0;
+  }, rank, world);
+}
+int dmvio_hip_tracker_set_comm_callbacks(dmvio_hip_tracker* t, const dmvio_hip_comm_callbacks* cb, int rank, int world) {
+  if (!dmv_tracker_ctx(t)) return failmsg("null tracker");
+  if (!cb || world <= 1) return dmv_tracker_set_exchange(t, nullptr, 0, 0);
+  if (!cb->allreduce_sum_f64) return failmsg("tracker_set_comm_callbacks: allreduce_sum_f64 is required");
+  const dmvio_hip_comm_callbacks k = *cb;
+  return dmv_tracker_set_exchange(t, [k](double* buf, size_t count) -> int {
+    return k.allreduce_sum_f64(k.user, buf, count) == 0 ? 0 : failmsg("comm callback allreduce_sum_f64 failed");
+  }, rank, world);
+}
 // ncclCommCount / ncclCommUserRank of a communicator: what RCCL itself says about the group (bench.py prints it in the N > 1 line)
 int dmvio_hip_comm_info(void* comm, int* n_ranks, int* rank) {
   if (!comm) return failmsg("null communicator");

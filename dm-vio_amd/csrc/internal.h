@@ -5,6 +5,7 @@
 #include <mutex>
 #include <vector>
 #include <string>
+#include <functional>
 #include "common.h"
 
 std::string& dmv_err();
@@ -35,3 +36,9 @@ struct dmvio_hip_ctx {
   std::mutex mu;
 };
 
+
+// hypothesis-parallel trackNewCoarse: the element-wise fp64 sum over all ranks of a small HOST buffer, in place (set by dmvio_hip_tracker_set_comm /
+// _set_comm_callbacks in capi_ba.hip, which owns the RCCL calls; used by dmvio_hip_tracker_track_new_coarse in capi.hip)
+struct dmvio_hip_tracker;
+int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, size_t)> allreduce_sum, int rank, int world);
+dmvio_hip_ctx* dmv_tracker_ctx(dmvio_hip_tracker* t);

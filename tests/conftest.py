@@ -12,6 +12,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multigpu: needs at least two MI355X on one node (real RCCL at world size > 1); skipped elsewhere")
 
 
 def _built():

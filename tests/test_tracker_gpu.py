@@ -354,3 +354,60 @@ def test_eval_parity_random_poses_and_brightness(setup, oracle):
         if rs_o[1] < 8:
             continue                                   # next to nothing left in the image: counts compared, sums too small to scale
         _cmp_eval(rs_g, H_g, b_g, rs_o, H_o, b_o, tol=5e-5)
+
+
+def test_track_new_coarse_hypotheses_split_over_ranks(pkg, synth, oracle, gpu_required):
+    """SURVEY 8e, the one split coarse tracking has: the tries of FullSystem::trackNewCoarse over ranks (dmvio_hip_tracker_set_comm*).  Two ranks emulated by two threads of
+    this process, each with a context and tracker of its own on the device, the all-reduce of the per-try records done between the threads: both ranks return the same bits,
+    and the unsplit call's answer within the rounding of a different cluster size (batches of 15 instead of 30 problems group their partial sums differently)."""
+    import threading
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=600, n_frames=1)
+    f = case["frames"][0]
+    slast = oracle.se3_exp(-0.5 * f["xi"]); ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    bad = oracle.se3_exp(np.array([0.0, 0, 0, 0.0, 0.35, 0.0]))
+    tries = np.concatenate([bad[None], oracle.se3_mul(bad, bad)[None], pkg.make_track_hypotheses(slast, ident, ident)])     # a wrong motion model first: later tries decide
+
+    def make():
+        ctx = pkg.Context(w, h, n_slots=2)
+        trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+        ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, f["img"])
+        trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+        return ctx, trk
+    ctx0, trk0 = make()
+    single = [trk0.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2), trk0.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 1e-3))]
+    world = 2
+    bar = threading.Barrier(world); bufs = [None] * world; calls = [0] * world
+
+    def allreduce_for(rank):
+        def allreduce(a):
+            calls[rank] += 1
+            bufs[rank] = a.copy(); bar.wait()
+            tot = bufs[0].copy()
+            for r in range(1, world):
+                tot = tot + bufs[r]
+            bar.wait()
+            a[:] = tot
+        return allreduce
+    out = [None] * world; err = []
+
+    def rank_main(rank):
+        try:
+            ctx, trk = make()
+            trk.set_comm_allreduce(allreduce_for(rank), rank, world)
+            out[rank] = [trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2), trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 1e-3))]
+        except Exception as e:      # a dead rank would leave the other at the barrier
+            err.append(e); bar.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(300) for t in th]
+    assert not err, err
+    assert calls == [2, 2]                                            # one exchange per call (the loop went past try 0 both times)
+    for k in range(2):
+        a, b = out[0][k], out[1][k]
+        for key in ("pose7", "aff", "achievedRes", "flow"):
+            assert np.array_equal(np.asarray(a[key]).view(np.uint64), np.asarray(b[key]).view(np.uint64)), key
+        assert a["winner"] == b["winner"] and a["tries_used"] == b["tries_used"] and a["good"] == b["good"]
+        s = single[k]
+        assert a["tries_used"] == s["tries_used"] and a["good"] == s["good"]
+        assert np.max(np.abs(a["pose7"] - s["pose7"])) < 1e-5 and np.allclose(a["achievedRes"], s["achievedRes"], rtol=1e-4, equal_nan=True)
+    assert out[0][0]["winner"] == single[0]["winner"] >= 2             # well-conditioned: a later try wins
