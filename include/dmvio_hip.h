@@ -196,15 +196,6 @@ int dmvio_hip_make_track_hypotheses(const double slast_c2w[7], const double spre
 int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* trk, int new_slot, float new_exposure, int n_tries, const double* tries7, const double aff_last[2],
                                        double lastCoarseRMSE_io[5], double reTrackThreshold, double pose7_out[7], double aff_out[2], double flow_out[3],
                                        int* winner, int* tries_used, int* tracking_good);
-/* Hypothesis-parallel FullSystem::trackNewCoarse over several GPUs (SURVEY.md 8e — the one split coarse tracking has: it does not shard by point): every rank holds the
- * same reference template and the same new frame; with a communicator set, dmvio_hip_tracker_track_new_coarse runs try 0 on every rank (identical bits; no exchange when
- * it already ends the loop) and splits the remaining tries round-robin over the ranks, ONE all-reduce (fp64 sum of 20 doubles per try, each written by exactly one rank)
- * hands every rank all results, and the reference's sequential abort / winner rule (FullSystem.cpp:419-489) is replayed identically everywhere.  nccl_comm: an
- * ncclComm_t whose rank `rank` lives on this tracker's device (not owned); world <= 1 or NULL detaches.  The callbacks form uses allreduce_sum_f64 of
- * dmvio_hip_comm_callbacks (declared with the BA's sharding below).  Collective: every rank must make the same call. */
-int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* trk, void* nccl_comm, int rank, int world);
-struct dmvio_hip_comm_callbacks;
-int dmvio_hip_tracker_set_comm_callbacks(dmvio_hip_tracker* trk, const struct dmvio_hip_comm_callbacks* cb, int rank, int world);
 /* Work counters of the last batch launch: evals (calcRes+calcGS passes) and point-evaluations
  * (sum over evals of pc_n[lvl]) — the unit count behind the roofline's algorithmic bytes. */
 int dmvio_hip_tracker_last_work(dmvio_hip_tracker* trk, long long* n_evals, long long* n_point_evals);
@@ -333,6 +324,14 @@ typedef struct dmvio_hip_comm_callbacks {
   int (*allgather)(void* user, const void* in, void* out, size_t bytes);
 } dmvio_hip_comm_callbacks;
 int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* ba, const dmvio_hip_comm_callbacks* cb, int rank, int world);
+/* Hypothesis-parallel FullSystem::trackNewCoarse over several GPUs (SURVEY.md 8e — the one split coarse tracking has: it does not shard by point): every rank holds the
+ * same reference template and the same new frame; with a communicator set, dmvio_hip_tracker_track_new_coarse runs try 0 on every rank (identical bits; no exchange when
+ * it already ends the loop) and splits the remaining tries round-robin over the ranks, ONE all-reduce (fp64 sum of 20 doubles per try, each written by exactly one rank)
+ * hands every rank all results, and the reference's sequential abort / winner rule (FullSystem.cpp:419-489) is replayed identically everywhere.  nccl_comm: an
+ * ncclComm_t whose rank `rank` lives on this tracker's device (not owned); world <= 1 or NULL detaches.  The callbacks form uses allreduce_sum_f64 of
+ * the dmvio_hip_comm_callbacks struct above.  Collective: every rank must make the same call. */
+int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* trk, void* nccl_comm, int rank, int world);
+int dmvio_hip_tracker_set_comm_callbacks(dmvio_hip_tracker* trk, const dmvio_hip_comm_callbacks* cb, int rank, int world);
 /* Convenience wrappers over RCCL for callers without their own communicator: ncclGetUniqueId (128 bytes, to be distributed to all ranks by
  * the caller), ncclCommInitRank on the context's device, ncclCommDestroy. */
 int dmvio_hip_comm_unique_id(unsigned char id128[128]);

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--result-txt", default=None)
     ap.add_argument("--shadow", action="store_true", help="mode hip: the reference's own members run the pipeline, libdmvio_hip.so runs every call beside them from the same "
                                                          "inputs; the deviations per call are recorded (no drift through flipped discrete decisions)")
+    ap.add_argument("--window", action="store_true", help="instead of the whole FullSystem: one window through the reference's members one by one (makeImages, traceNewCoarse, "
+                                                         "optimize, setCoarseTrackingRef + trackNewestCoarse) — single-threaded code only, deterministic")
     ap.add_argument("--cache", default=None, help="directory that keeps the rendered sequence between runs (rendering 512x512 frames costs more than tracking them)")
     ap.add_argument("--init", choices=["ref", "seq", "hip"], default="ref",
                     help="CoarseInitializer::calcResAndGS: the reference's own (multi-threaded: run-to-run noise), the oracle's single-threaded restatement (deterministic "
@@ -58,6 +60,8 @@ def main():
         D.dropin_failures.argtypes = [C.c_char_p, C.c_int]; D.dropin_failures.restype = C.c_long
     import ref_py as R
     import replay
+    if a.window:
+        return window_run(a, D, R, synth)
     cache = os.path.join(a.cache, "seq_%dx%d_%d_%g.npz" % (a.w, a.h, a.frames, a.step)) if a.cache else None
     if cache and os.path.exists(cache):
         z = np.load(cache); K4, imgs, poses_true = z["K4"], list(z["imgs"]), list(z["poses"])
@@ -118,6 +122,37 @@ def main():
     np.savez(a.out, **out)
     print("signature", sig)
     print("%s: %d frames in %.2f s, %d keyframe optimisations, initialised %s, lost %s" % (a.mode, len(imgs), wall, len(opt), status[-1]["initialized"], status[-1]["isLost"]))
+
+
+def window_run(a, D, R, synth):
+    """The members the adapter replaces, called one by one on a synthetic window through oracle/ref_py.py (no initialiser: nothing multi-threaded)."""
+    if D is not None and D.dropin_enable(1 if a.mode == "hip" else 0, 0, 256, 192, a.accumulators) != 0:
+        raise SystemExit("dropin_enable failed")
+    case = synth.ba_case(256, 192, n_frames=4, n_points=150, hosts_share=(60, 50, 40, 0), seed=7)
+    W = R.BAWindow(case)                                          # FrameHessian::makeImages per keyframe
+    rng = np.random.RandomState(3)
+    u, v = synth.select_points(case["imgs"][0], 200, rng, min_grad=8.0)
+    u = np.clip(u.astype(np.int32), 8, 256 - 9); v = np.clip(v.astype(np.int32), 8, 192 - 9)
+    for host in range(3):
+        W.immature_add(host, u, v)
+    W.trace_new_coarse(3)                                         # FullSystem::traceNewCoarse
+    imm = W.immature_get(0)
+    ro = W.optimize_quiet(6)                                      # FullSystem::optimize
+    poses = np.stack([W.frame_pose(k)[0] for k in range(4)]); idepth = W.point_state()[0]
+    tc = synth.tracking_case(256, 256, n_ref=400, n_frames=1)
+    T = R.Tracker(256, 256, tc["K4"])
+    T.set_ref(tc["ref_img"], tc["u"], tc["v"], tc["idepth"], tc["hdiF"])      # CoarseTracker::setCoarseTrackingRef
+    T.set_new(tc["frames"][0]["img"])
+    tr = T.track(np.array([0, 0, 0, 0, 0, 0, 1.0]), [0.0, 0.0])               # CoarseTracker::trackNewestCoarse
+    out = dict(rmse=np.array([ro]), poses=poses, idepth=idepth, imm_min=np.asarray(imm["idepth_min"]), imm_max=np.asarray(imm["idepth_max"]),
+               imm_status=np.asarray(imm["lastTraceStatus"]), track_pose=np.asarray(tr["pose7"]), track_res=np.asarray(tr["lastResiduals"]))
+    if D is not None:
+        sec = (C.c_double * 5)(); calls = (C.c_long * 5)()
+        D.dropin_get_stats(sec, calls)
+        out["stat_calls"] = np.array(list(calls))
+        out["failures"] = np.array([D.dropin_failures(None, 0)])
+    np.savez(a.out, **out)
+    print("%s window: rmse %.6f" % (a.mode, ro))
 
 
 if __name__ == "__main__":
