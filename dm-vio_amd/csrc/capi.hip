@@ -64,6 +64,7 @@ struct dmvio_hip_tracker {
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
   int out_cur = 0, out_fetch = 0, staged_half = 0;    // half of the last launch / half a pending fetch_begin refers to / half staged for the next launch
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
+  bool staged_unlaunched = false;   // _track_batch_stage ran and _track_batch_launch has not yet: a single-frame call must not slip in front of that batch
   long long last_evals = 0, last_point_evals = 0, last_ticks_step = 0, last_ticks_eval = 0;
   int lm_threads_override = 0, lm_waves_override = 0, lm_cluster_override = 0, last_cluster = 0, last_threads = 0;
   hipEvent_t done_event[2] = {nullptr, nullptr};   // recorded behind each launch: the results of that half are in host memory once it has completed
@@ -775,7 +776,7 @@ int dmvio_hip_tracker_track_batch_stage(dmvio_hip_tracker* t, int B, const int* 
     p.new_slot = new_slots[i];
     p.new_exposure = new_exposures ? new_exposures[i] : 1.0f;
   }
-  t->staged_B = B; t->staged_coarsest = coarsestLvl; t->staged_half = half;
+  t->staged_B = B; t->staged_coarsest = coarsestLvl; t->staged_half = half; t->staged_unlaunched = true;
   return 0;
 }
 
@@ -796,6 +797,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   dmvio_hip_ctx* c = t->ctx;
   HIPCHK(hipSetDevice(c->device));
   const int B = t->staged_B;
+  t->staged_unlaunched = false;
   // Up to 128 problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs
   // 367 us for one 1024-thread workgroup); more -> one workgroup per problem (512 threads up to 512 problems, then 256 threads,
   // four resident per CU: throughput).
@@ -887,13 +889,14 @@ int dmvio_hip_tracker_track_batch(dmvio_hip_tracker* t, int B, const int* new_sl
   // the host, so the loop runs on the host against the evaluation server (one launch per frame, requests through host-coherent memory).  Same split of the template and
   // same order of the partial sums as the device-resident LM's cluster mode, same arithmetic in the step: identical sums, residuals, H, b and iteration counts, the pose
   // to the last bit or two of its fp64 components (tests/test_vio_gpu.py, tests/test_edge_gpu.py); 0.165 instead of 0.25 ms per frame.
-  if (B == 1 && t && t->single_host_lm && t->use_server && !t->lm_threads_override && !t->lm_cluster_override && t->fetch_pending_B == 0 && new_slots && pose7_io && aff_io) {
+  // (not while a staged batch waits for its launch: the single-frame path would run in front of it and the caller's later _launch would find nothing)
+  if (B == 1 && t && t->single_host_lm && t->use_server && !t->lm_threads_override && !t->lm_cluster_override && t->fetch_pending_B == 0 && !t->staged_unlaunched && new_slots && pose7_io &&
+      aff_io) {
     int g = 0, ne = 0;
     const float ex = new_exposures ? new_exposures[0] : 1.0f;
     if (int r = dmvio_hip_tracker_track_vio(t, new_slots[0], ex, pose7_io, aff_io, coarsestLvl, minRes, nullptr, lastResiduals, lastFlow, H, b, &g, &ne)) return r;
     if (good) good[0] = g;
     if (iterations) iterations[0] = t->last_vio_iterations;
-    t->last_evals = ne; t->staged_B = 0;
     return 0;
   }
   if (int r = dmvio_hip_tracker_track_batch_stage(t, B, new_slots, new_exposures, pose7_io, aff_io, coarsestLvl, minRes)) return r;
@@ -1011,7 +1014,8 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
     ~Session() { if (on) serverStop(t); }
   } session{t, false};
   if (t->use_server) { if (int r = serverStart(t, new_slot, G)) return r; session.on = true; }
-  auto evaluate = [&](const EvalP& ep, int lv) -> int { return session.on ? serverEval(t, ep) : evalFused(t, lv, new_slot, ep, G); };
+  long long point_evals = 0;   // sum over evaluations of pc_n[lvl]: the unit count behind the roofline's algorithmic bytes (dmvio_hip_tracker_last_work)
+  auto evaluate = [&](const EvalP& ep, int lv) -> int { point_evals += trk.pc_n[lv]; return session.on ? serverEval(t, ep) : evalFused(t, lv, new_slot, ep, G); };
   for (int lvl = coarsestLvl; lvl >= 0 && !failed; lvl--) {
     float levelCutoffRepeat = 1;
     double resOld[6];
@@ -1067,6 +1071,9 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
     if (levelCutoffRepeat > 1 && !haveRepeated) { repeatedLvl = lvl; firstPassRes = lastRes[lvl]; lvl++; haveRepeated = true; }
   }
   t->last_vio_iterations = totalIts;
+  // bookkeeping of the "last launch" queries: this call's own numbers, not those of an earlier batch
+  t->last_evals = evals; t->last_point_evals = point_evals; t->last_ticks_step = t->last_ticks_eval = 0;
+  t->last_cluster = session.on ? t->server_G : G; t->last_threads = 256;
   if (t->last_repeat_lvl.empty()) { t->last_repeat_lvl.resize(1); t->last_first_pass_res.resize(1); }
   t->last_repeat_lvl[0] = repeatedLvl; t->last_first_pass_res[0] = firstPassRes;
   if (lastResiduals) memcpy(lastResiduals, lastRes, sizeof(lastRes));

@@ -1,6 +1,7 @@
 // libdmvio_hip.so — C ABI of the bundle-adjustment path (include/dmvio_hip.h, "sliding-window BA" section).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (below)
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,41 @@
 #include "ba_host.hpp"
 
 using namespace dmv;
+
+// RCCL is bound at RUN time, on the first call that needs a communicator: libdmvio_hip.so itself has no link dependency on librccl.so, so hosts without RCCL (a single-GPU
+// workstation, a CPU-only build box) load the library and run everything but the multi-GPU entry points, which then fail with a message instead of a loader error.
+namespace {
+struct RcclApi {
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclAllGather) allGather = nullptr;
+  decltype(&ncclCommCount) commCount = nullptr;
+  decltype(&ncclCommUserRank) commUserRank = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclGetErrorString) getErrorString = nullptr;
+  bool ok = false;
+  std::string why;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { api.why = std::string("librccl.so cannot be loaded (") + (dlerror() ? dlerror() : "?") + ")"; return; }
+    bool all = true;
+    auto get = [&](const char* sym) { void* p = dlsym(h, sym); if (!p) { all = false; api.why = std::string("librccl.so lacks ") + sym; } return p; };
+    api.allReduce = (decltype(api.allReduce))get("ncclAllReduce"); api.allGather = (decltype(api.allGather))get("ncclAllGather");
+    api.commCount = (decltype(api.commCount))get("ncclCommCount"); api.commUserRank = (decltype(api.commUserRank))get("ncclCommUserRank");
+    api.getUniqueId = (decltype(api.getUniqueId))get("ncclGetUniqueId"); api.commInitRank = (decltype(api.commInitRank))get("ncclCommInitRank");
+    api.commDestroy = (decltype(api.commDestroy))get("ncclCommDestroy"); api.getErrorString = (decltype(api.getErrorString))get("ncclGetErrorString");
+    api.ok = all;
+  });
+  return api;
+}
+}  // namespace
+#define RCCL_READY() do { if (!rccl().ok) return failmsg("RCCL is not available: " + rccl().why); } while (0)
 
 #include <chrono>
 // optional host-side time split of the GN iteration (DMVIO_HIP_BA_TIMING=1 prints it when the handle is destroyed)
@@ -113,7 +149,7 @@ struct dmvio_hip_ba {
   hipEvent_t* prof = nullptr;        // dmvio_hip_ba_profile_chain: six events recorded between the launches of linearise -> per-point sums -> accumulate -> stitch -> gather
 };
 #define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
-#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #x).c_str()); } while (0)
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + rccl().getErrorString(r_) + " in " #x).c_str()); } while (0)
 
 template <class T>
 static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
@@ -225,7 +261,7 @@ static BADecide makeDecide(dmvio_hip_ba* b, int mode, bool update_th, bool publi
 // and consume the buffers (no host hop); the callback transport stages them through host memory.
 static bool sharded(const dmvio_hip_ba* b) { return b->world > 0; }
 static int commAllReduceSum(dmvio_hip_ba* b, double* d_buf, size_t count) {
-  if (b->nccl) { NCCLCHK(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, b->nccl, b->stream)); return 0; }
+  if (b->nccl) { NCCLCHK(rccl().allReduce(d_buf, d_buf, count, ncclDouble, ncclSum, b->nccl, b->stream)); return 0; }
   b->h_stage.resize(count);
   HIPCHK(hipMemcpyAsync(b->h_stage.data(), d_buf, sizeof(double) * count, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -234,7 +270,7 @@ static int commAllReduceSum(dmvio_hip_ba* b, double* d_buf, size_t count) {
   return 0;
 }
 static int commAllGather(dmvio_hip_ba* b, const float* d_in, float* d_out, size_t count_per_rank) {
-  if (b->nccl) { NCCLCHK(ncclAllGather(d_in, d_out, count_per_rank, ncclFloat, b->nccl, b->stream)); return 0; }
+  if (b->nccl) { NCCLCHK(rccl().allGather(d_in, d_out, count_per_rank, ncclFloat, b->nccl, b->stream)); return 0; }
   const size_t bytes = sizeof(float) * count_per_rank;
   b->h_stage.resize((bytes * (b->world + 1) + 7) / 8);
   char* in = (char*)b->h_stage.data(); char* out = in + bytes;
@@ -430,7 +466,8 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   b->H.w = ctx->w; b->H.h = ctx->h;
   // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
-  if (const char* e = getenv("DMVIO_HIP_BA_SPLIT")) { const int k = atoi(e); if (k >= 1 && k <= 8) { b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = 4 * k; } }
+  // the same mapping as dmvio_hip_ba_set_accumulators (k = 1: every accumulator single, the reference's single-threaded order bit for bit)
+  if (const char* e = getenv("DMVIO_HIP_BA_SPLIT")) { const int k = atoi(e); if (k >= 1 && k <= 8) { b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = k == 1 ? 1 : 4 * k; } }
   if (const char* e = getenv("DMVIO_HIP_BA_EXACT")) { if (atoi(e) != 0) { b->nsTop = b->nsD = b->nsC = 1; } }
   return b;
 }
@@ -492,9 +529,10 @@ static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callba
   if (world < 1 || rank < 0 || rank >= world) return failmsg("ba_set_comm: 0 <= rank < world");
   if (cb && (!cb->allreduce_sum_f64 || !cb->allgather)) return failmsg("ba_set_comm_callbacks: both callbacks are required");
   if (comm) {
+    RCCL_READY();
     int n = 0, r = -1;
-    NCCLCHK(ncclCommCount(comm, &n));
-    NCCLCHK(ncclCommUserRank(comm, &r));
+    NCCLCHK(rccl().commCount(comm, &n));
+    NCCLCHK(rccl().commUserRank(comm, &r));
     if (n != world || r != rank) return failmsg("ba_set_comm: rank / world do not match the communicator");
   }
   b->rank = rank; b->world = world; b->nccl = comm;
@@ -508,18 +546,20 @@ int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* b, const dmvio_hip_comm_callba
 int dmvio_hip_comm_unique_id(unsigned char id128[128]) {
   if (!id128) return failmsg("null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  RCCL_READY();
   ncclUniqueId id;
-  NCCLCHK(ncclGetUniqueId(&id));
+  NCCLCHK(rccl().getUniqueId(&id));
   memcpy(id128, &id, 128);
   return 0;
 }
 int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128], int rank, int world, void** out) {
   if (!ctx || !id128 || !out) return failmsg("null argument");
   HIPCHK(hipSetDevice(ctx->device));
+  RCCL_READY();
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm = nullptr;
-  NCCLCHK(ncclCommInitRank(&comm, world, id, rank));
+  NCCLCHK(rccl().commInitRank(&comm, world, id, rank));
   *out = (void*)comm;
   return 0;
 }
@@ -529,9 +569,10 @@ int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, 
   if (!c) return failmsg("null tracker");
   if (!nccl_comm || world <= 1) return dmv_tracker_set_exchange(t, nullptr, 0, world == 1 && nccl_comm ? 1 : 0);
   ncclComm_t comm = (ncclComm_t)nccl_comm;
+  RCCL_READY();
   int n = 0, r = -1;
-  NCCLCHK(ncclCommCount(comm, &n));
-  NCCLCHK(ncclCommUserRank(comm, &r));
+  NCCLCHK(rccl().commCount(comm, &n));
+  NCCLCHK(rccl().commUserRank(comm, &r));
   if (n != world || r != rank) return failmsg("tracker_set_comm: rank / world do not match the communicator");
   return dmv_tracker_set_exchange(t, [c, comm](double* buf, size_t count) -> int {
     double* d = nullptr;   // 20 doubles per hypothesis: a few KB, staged through device memory for RCCL on the context's stream
@@ -539,11 +580,11 @@ int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, 
     HIPCHK(hipMalloc((void**)&d, sizeof(double) * count));
     hipError_t e = hipMemcpyAsync(d, buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream);
     ncclResult_t nr = ncclSuccess;
-    if (e == hipSuccess) nr = ncclAllReduce(d, d, count, ncclDouble, ncclSum, comm, c->stream);
+    if (e == hipSuccess) nr = rccl().allReduce(d, d, count, ncclDouble, ncclSum, comm, c->stream);
     if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(buf, d, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d);
-    if (nr != ncclSuccess) return failmsg(std::string("RCCL: ") + ncclGetErrorString(nr) + " in the hypothesis exchange");
+    if (nr != ncclSuccess) return failmsg(std::string("RCCL: ") + rccl().getErrorString(nr) + " in the hypothesis exchange");
     if (e != hipSuccess) return fail("hypothesis exchange", __FILE__, __LINE__, e);
     return 0;
   }, rank, world);
@@ -560,16 +601,18 @@ int dmvio_hip_tracker_set_comm_callbacks(dmvio_hip_tracker* t, const dmvio_hip_c
 // ncclCommCount / ncclCommUserRank of a communicator: what RCCL itself says about the group (bench.py prints it in the N > 1 line)
 int dmvio_hip_comm_info(void* comm, int* n_ranks, int* rank) {
   if (!comm) return failmsg("null communicator");
+  RCCL_READY();
   int n = 0, r = -1;
-  NCCLCHK(ncclCommCount((ncclComm_t)comm, &n));
-  NCCLCHK(ncclCommUserRank((ncclComm_t)comm, &r));
+  NCCLCHK(rccl().commCount((ncclComm_t)comm, &n));
+  NCCLCHK(rccl().commUserRank((ncclComm_t)comm, &r));
   if (n_ranks) *n_ranks = n;
   if (rank) *rank = r;
   return 0;
 }
 int dmvio_hip_comm_destroy(void* comm) {
   if (!comm) return 0;
-  NCCLCHK(ncclCommDestroy((ncclComm_t)comm));
+  RCCL_READY();
+  NCCLCHK(rccl().commDestroy((ncclComm_t)comm));
   return 0;
 }
 
