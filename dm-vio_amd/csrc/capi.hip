@@ -123,7 +123,15 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
-  c->pg.tiles_x = (w + PYR_TW - 1) / PYR_TW; c->pg.tiles_y = (h + PYR_TH - 1) / PYR_TH;
+  {
+    // tile shape of the pyramid build: as wide as the image (contiguous level-0 memory per workgroup), at least 2^(levels-1) rows for the 2x2 reductions
+    int twl = 9;
+    while (twl > 7 && ((1 << (twl - 1)) >= w || (PYR_TILE_PX >> twl) < (1 << (c->levels - 1)))) twl--;
+    if (const char* e = getenv("DMVIO_HIP_PYR_TILE_LOG2")) { const int v = atoi(e); if (v >= 7 && v <= 9 && (PYR_TILE_PX >> v) >= (1 << (c->levels - 1))) twl = v; }
+    c->pg.tw_log2 = twl;
+    const int TW = 1 << twl, TH = PYR_TILE_PX >> twl;
+    c->pg.tiles_x = (w + TW - 1) / TW; c->pg.tiles_y = (h + TH - 1) / TH;
+  }
   HIPCHKP(hipMalloc((void**)&c->d_f3, sizeof(float) * 3 * w * h));
   HIPCHKP(hipStreamSynchronize(c->stream));
   return c;

@@ -38,7 +38,8 @@ struct FrameStore {
 struct PyrGeom {
   int levels;
   int w[DMV_MAX_LEVELS], h[DMV_MAX_LEVELS];
-  int tiles_x, tiles_y;  // level-0 tiles of k_build_pyramids (PYR_TW x PYR_TH)
+  int tiles_x, tiles_y;  // level-0 tiles of k_build_pyramids (2^tw_log2 x 4096 / 2^tw_log2 pixels)
+  int tw_log2;           // log2 of the tile width: 7..9
 };
 
 // Reference template of the coarse tracker on the device (pc_* of CoarseTracker.h:113-118 as one

@@ -6,8 +6,8 @@
 // where they are consumed (gradAt below = the reference's formula incl. its isfinite guard); absSquaredGrad (pixel
 // selector only) is not produced.
 //
-// One launch builds ALL levels of B frames: a workgroup owns a 128x32 level-0 tile (row segments of 512 / 256 / 128 / 64 bytes at
-// levels 0..3), keeps the successive 2x2 reductions in LDS (128x32 -> 64x16 -> ... ) and streams each level out.  HBM traffic per frame:
+// One launch builds ALL levels of B frames: a workgroup owns a level-0 tile of 4096 pixels (512x8 for a 512-wide, 4-level pyramid: see PYR_TILE_PX),
+// keeps the successive 2x2 reductions in LDS and streams each level out.  HBM traffic per frame:
 // read 4 B/px + write 4 B/px * (1 + 1/4 + 1/16 + ...).
 #pragma once
 #include "common.h"
@@ -16,14 +16,15 @@
 namespace dmv {
 
 typedef float pyr_f4 __attribute__((ext_vector_type(4)));
-// level-0 tile of a workgroup: 128 x 32 pixels — 512-byte row segments at level 0, 256 / 128 / 64 bytes at the next three levels
-#define PYR_TW 128
-#define PYR_TH 32
+// level-0 tile of a workgroup: PYR_TILE_PX pixels, 2^tw_log2 wide (PyrGeom::tw_log2, chosen per context: as wide as the image allows — a 512-pixel-wide tile of a
+// 512-pixel-wide image is 8 rows x 2 KB = 16 KB of CONTIGUOUS level-0 memory per workgroup, where a 128 x 32 tile wrote 32 separate 512-byte pieces — and as high as the
+// 2x2 reductions of the coarser levels need: 2^(levels-1) rows)
+#define PYR_TILE_PX 4096
 // levels 1.. of a workgroup's tile: successive 2x2 means of the level-0 tile in s_a (the caller's barrier has made it visible), streamed out level by level
 __device__ __forceinline__ void pyrReduceLevels(float* s_a, float* s_b, const PyrGeom& G, const FrameStore& fs, const int slot, const int x0, const int y0) {
   float* cur = s_a;
   float* nxt = s_b;
-  int sw = PYR_TW, sh = PYR_TH;
+  int sw = 1 << G.tw_log2, sh = PYR_TILE_PX >> G.tw_log2;
   for (int l = 1; l < G.levels; l++) {
     const int nw = sw >> 1, nh = sh >> 1;
     for (int o = threadIdx.x; o < nw * nh; o += 256) {
@@ -42,25 +43,26 @@ __device__ __forceinline__ void pyrReduceLevels(float* s_a, float* s_b, const Py
 
 __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G,
                                                          const FrameStore fs, const int* __restrict__ slots, const int single_slot, const unsigned int gen, const int attach) {
-  __shared__ float s_a[PYR_TW * PYR_TH];
-  __shared__ float s_b[(PYR_TW / 2) * (PYR_TH / 2)];
+  __shared__ float s_a[PYR_TILE_PX];
+  __shared__ float s_b[PYR_TILE_PX / 4];
   const int f = blockIdx.y;
   const int slot = slots ? slots[f] : single_slot;
   const float* __restrict__ src = in_base + (size_t)f * in_stride;
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
-  const int x0 = tx * PYR_TW, y0 = ty * PYR_TH;
+  const int TW = 1 << G.tw_log2, rowsPerPass = 1024 >> G.tw_log2;   // 256 threads x 4 pixels = 1024 pixels per pass, four passes per tile
+  const int x0 = tx * TW, y0 = ty * (PYR_TILE_PX >> G.tw_log2);
   bool bad = false;
   // level 0: 256 threads x 4 passes x 4 consecutive pixels; all four 16-byte loads of a thread are issued before the first store.
   // The raw image is read once and the level-0 plane is far larger than the caches it would pollute: non-temporal loads / stores
   // (measured: 4.4 -> 5.5 TB/s)
   {
-    const int lx = (threadIdx.x & 31) * 4, lyb = threadIdx.x >> 5;   // 32 threads x 4 pixels per row, 8 rows per pass
+    const int lx = (threadIdx.x & ((TW >> 2) - 1)) * 4, lyb = threadIdx.x >> (G.tw_log2 - 2);   // TW / 4 threads x 4 pixels per row, rowsPerPass rows per pass
     float* __restrict__ dst = fs.own_level(slot, 0);
     float4 v[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int x = x0 + lx, y = y0 + lyb + 8 * p;
+      const int x = x0 + lx, y = y0 + lyb + rowsPerPass * p;
       v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y < h0) {
         if (x + 3 < w0 && ((uintptr_t)(src + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = __builtin_nontemporal_load(reinterpret_cast<const pyr_f4*>(src + (size_t)y * w0 + x)); v[p] = make_float4(t[0], t[1], t[2], t[3]); }
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
     }
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int x = x0 + lx, y = y0 + lyb + 8 * p, ly = lyb + 8 * p;
+      const int x = x0 + lx, y = y0 + lyb + rowsPerPass * p, ly = lyb + rowsPerPass * p;
       if (y < h0 && !attach) {   // attached in place: level 0 is the caller's image itself
         if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 t = {v[p].x, v[p].y, v[p].z, v[p].w}; __builtin_nontemporal_store(t, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
         else if (x + 3 < w0) __builtin_memcpy(dst + (size_t)y * w0 + x, &v[p], 16);
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
           for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
         }
       }
-      *reinterpret_cast<float4*>(&s_a[ly * PYR_TW + lx]) = v[p];
+      *reinterpret_cast<float4*>(&s_a[ly * TW + lx]) = v[p];
       // NaN fails the comparison too; out-of-image lanes hold zeros
       bad |= !(fabsf(v[p].x) <= 1e30f) || !(fabsf(v[p].y) <= 1e30f) || !(fabsf(v[p].z) <= 1e30f) || !(fabsf(v[p].w) <= 1e30f);
     }
@@ -137,21 +139,22 @@ __global__ void __launch_bounds__(256) k_undistort(const T* __restrict__ raw, co
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict__ raw_base, const size_t raw_stride, const UndistortDev U, const PyrGeom G,
                                                              const FrameStore fs, const int* __restrict__ slots, const unsigned int gen) {
-  __shared__ float s_a[PYR_TW * PYR_TH];
-  __shared__ float s_b[(PYR_TW / 2) * (PYR_TH / 2)];
+  __shared__ float s_a[PYR_TILE_PX];
+  __shared__ float s_b[PYR_TILE_PX / 4];
   const int f = blockIdx.y;
   const int slot = slots[f];
   const T* __restrict__ raw = raw_base + (size_t)f * raw_stride;
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
-  const int x0 = tx * PYR_TW, y0 = ty * PYR_TH;
+  const int TW = 1 << G.tw_log2, rowsPerPass = 1024 >> G.tw_log2;   // 256 threads x 4 pixels = 1024 pixels per pass, four passes per tile
+  const int x0 = tx * TW, y0 = ty * (PYR_TILE_PX >> G.tw_log2);
   bool bad = false;
   {
-    const int lx = (threadIdx.x & 31) * 4, lyb = threadIdx.x >> 5;
+    const int lx = (threadIdx.x & ((TW >> 2) - 1)) * 4, lyb = threadIdx.x >> (G.tw_log2 - 2);
     float* __restrict__ dst = fs.own_level(slot, 0);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int x = x0 + lx, y = y0 + lyb + 8 * p, ly = lyb + 8 * p;
+      const int x = x0 + lx, y = y0 + lyb + rowsPerPass * p, ly = lyb + rowsPerPass * p;
       float t[4] = {0.f, 0.f, 0.f, 0.f};
       if (y < h0) {
         const int i0 = y * w0 + x;
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict_
         if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 v = {t[0], t[1], t[2], t[3]}; __builtin_nontemporal_store(v, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
         else for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
       }
-      *reinterpret_cast<float4*>(&s_a[ly * PYR_TW + lx]) = make_float4(t[0], t[1], t[2], t[3]);
+      *reinterpret_cast<float4*>(&s_a[ly * TW + lx]) = make_float4(t[0], t[1], t[2], t[3]);
       bad |= !(fabsf(t[0]) <= 1e30f) || !(fabsf(t[1]) <= 1e30f) || !(fabsf(t[2]) <= 1e30f) || !(fabsf(t[3]) <= 1e30f);
     }
   }

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--result-txt", default=None)
     ap.add_argument("--shadow", action="store_true", help="mode hip: the reference's own members run the pipeline, libdmvio_hip.so runs every call beside them from the same "
                                                          "inputs; the deviations per call are recorded (no drift through flipped discrete decisions)")
+    ap.add_argument("--brightness", action="store_true", help="exposure times that change from frame to frame (handed to addActiveFrame, images scaled accordingly) plus an affine "
+                                                             "brightness drift the exposure does not explain: the AffLight / exposure path of tracker, tracer and BA on live data")
     ap.add_argument("--window", action="store_true", help="instead of the whole FullSystem: one window through the reference's members one by one (makeImages, traceNewCoarse, "
                                                          "optimize, setCoarseTrackingRef + trackNewestCoarse) — single-threaded code only, deterministic")
     ap.add_argument("--cache", default=None, help="directory that keeps the rendered sequence between runs (rendering 512x512 frames costs more than tracking them)")
@@ -89,8 +91,12 @@ def main():
     if D is not None:
         R.lib().ref_system_fullsystem.restype = C.c_void_p; R.lib().ref_system_fullsystem.argtypes = [C.c_void_p]
         D.dropin_attach(R.lib().ref_system_fullsystem(S.p))
+    expo = [1.0] * len(imgs)
+    if a.brightness:
+        expo = [float(1.0 + 0.2 * np.sin(0.13 * k)) for k in range(len(imgs))]
+        imgs = [np.float32(expo[k] * (1.0 + 0.03 * np.sin(0.31 * k))) * img + np.float32(4.0 * np.sin(0.2 * k)) for k, img in enumerate(imgs)]
     t0 = time.perf_counter()
-    status = [S.add_frame(img) for img in imgs]
+    status = [S.add_frame(img, exposure=expo[k]) for k, img in enumerate(imgs)]
     wall = time.perf_counter() - t0
     tr = S.trajectory()
     ev = S.events()

@@ -85,17 +85,20 @@ SHADOW_FIELDS = ["n_opt", "n_track", "n_trace_pts", "n_trace_diff", "n_track_goo
 
 
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("shape,accumulators", [("512x512", 0), ("512x512", 1), ("640x480", 0)])
-def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path, shape, accumulators):
+@pytest.mark.parametrize("shape,accumulators,brightness", [("512x512", 0, False), ("512x512", 1, False), ("640x480", 0, False), ("640x480", 0, True), ("512x512", 1, True)])
+def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path, shape, accumulators, brightness):
     """Shadow mode: the reference's own members run its FullSystem (so the run cannot drift through a flipped activation / keyframe decision); every trackNewestCoarse,
     traceNewCoarse and optimize call is ALSO executed on libdmvio_hip.so from the very same inputs — live windows with marginalisation priors, FEJ points, changing thresholds,
     at BASELINE shapes (config 2: 512x512 / ~2000 points; config 3: 640x480) — and the answers are compared call by call.  North-star bars: 1e-3 m on poses, 1e-4 relative on
     the final photometric energy."""
     w, h = shape.split("x")
     seq = ["--w", w, "--h", h, "--frames", "100", "--step", "1.6", "--density", "2000"]
-    r = _run(tmp_path, "shadow", "--mode", "hip", "--init", "seq", "--shadow", "--accumulators", str(accumulators), *seq)
+    # brightness: exposure times changing by +-20 % from frame to frame plus an affine drift the exposure does not explain (AffLight::fromToVecExposure in tracker, tracer, BA)
+    r = _run(tmp_path, "shadow", "--mode", "hip", "--init", "seq", "--shadow", "--accumulators", str(accumulators), *(seq + (["--brightness"] if brightness else [])))
     sh = dict(zip(SHADOW_FIELDS, r["shadow"]))
-    print(shape, "accumulators", accumulators or "default (4)", {k: (int(v) if k.startswith("n_") else float("%.3g" % v)) for k, v in sh.items()})
+    if brightness:
+        assert np.abs(r["aff"]).max() > 0.02      # the run really estimated brightness changes
+    print(shape, "accumulators", accumulators or "default (4)", "brightness" if brightness else "", {k: (int(v) if k.startswith("n_") else float("%.3g" % v)) for k, v in sh.items()})
     assert r["failures"][0] == 0 and not r["lost"][-1] and r["initialized"][-1]
     assert sh["n_opt"] >= 8 and sh["n_track"] >= 80 and sh["n_trace_pts"] > 50000
     # traceNewCoarse: ImmaturePoint::traceOn of every immature point — status, interval, quality, position bit for bit

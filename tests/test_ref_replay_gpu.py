@@ -46,17 +46,22 @@ def test_hip_replays_every_recorded_track_new_coarse(pkg, golden, gpu_required):
         r = trk.trackNewCoarse(int(ti["frame_id"]), tries, aff_last=ti["aff_last"], lastCoarseRMSE=ti["lastCoarseRMSE"], reTrackThreshold=float(ti["reTrackThreshold"]))
         assert r["good"] == bool(to["good"])
         dp = np.abs(r["pose7"] - to["refToNew"]).max(); da = np.abs(r["aff"] - to["aff"]) / np.array([1.0, 100.0])
-        dr = np.nanmax(np.abs(r["achievedRes"] - to["lastCoarseRMSE"]) / np.abs(to["lastCoarseRMSE"]))
+        # what north_star bounds is the ENERGY: per-level photometric energy (achieved residual squared) within 1e-4 relative of the reference's own
+        dr = np.nanmax(np.abs(r["achievedRes"] ** 2 - to["lastCoarseRMSE"] ** 2) / to["lastCoarseRMSE"] ** 2)
         worst = np.maximum(worst, [dp, da.max(), dr])
-        # affine brightness: gain a and offset b trade against each other along a flat valley of the photometric energy (residual equal to ~3e-6 relative either way);
-        # the fp32 sums of the two implementations stop at slightly different points of it — seen up to 1.7e-3 in a, 0.23 grey values in b on early frames with few points
-        assert dp < 1e-4 and da[0] < 5e-3 and da[1] < 5e-3 and dr < 1e-4, (ti["frame_id"], dp, da, dr)
+        # affine brightness is only sanity-checked: gain a and offset b trade against each other along a flat valley of the photometric energy (the energy is equal to ~6e-6
+        # relative either way — asserted above); the fp32 sums of the two implementations stop at slightly different points of it — seen up to 1.7e-3 in a, 0.23 grey values
+        # in b on early frames with few points
+        assert dp < 1e-4 and dr < 1e-4 and da[0] < 2e-2 and da[1] < 2e-2, (ti["frame_id"], dp, da, dr)
     print("worst over %d recorded calls: pose %.2e, affine %.2e, residual %.2e (relative)" % (len(tracks), worst[0], worst[1], worst[2]))
     assert len(tracks) >= 50 and worst[0] < 1e-4      # bar: 1e-3 m; most calls agree to < 1e-6, early frames right after the initialiser (few points, weak geometry) to ~5e-5
     trk.close(); ctx.close()
 
 
-def test_hip_replays_every_recorded_optimize(pkg, golden, gpu_required):
+@pytest.mark.parametrize("accumulators", [None, 1], ids=["default-4-partials", "single-threaded-order"])
+def test_hip_replays_every_recorded_optimize(pkg, golden, gpu_required, accumulators):
+    """Both accumulation orders of the library: its default (4 partial accumulators per bucket — the structure of the reference's multi-threaded mode) and the reference's
+    single-threaded order (what the recording was made with)."""
     w, h = golden["w"], golden["h"]
     _, opts = replay.pair_events(golden["events"])
     ctx = pkg.Context(w, h, n_slots=8)
@@ -65,7 +70,7 @@ def test_hip_replays_every_recorded_optimize(pkg, golden, gpu_required):
         case = replay.window_case(a, golden["imgs"], w, h)
         for k in range(a["F"]):
             ctx.frame_upload(k, case["imgs"][k])
-        ba = pkg.BundleAdjusterHip(ctx)
+        ba = pkg.BundleAdjusterHip(ctx, accumulators=accumulators)
         ba.set_case(case, list(range(a["F"])))
         replay.apply_window_state(ba, a)
         r = ba.optimize(6)
