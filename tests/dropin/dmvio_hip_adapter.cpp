@@ -5,6 +5,7 @@
 //     CoarseTracker::trackNewestCoarse      src/dso/FullSystem/CoarseTracker.cpp:539-770
 //     FullSystem::traceNewCoarse            src/dso/FullSystem/FullSystem.cpp:541-584
 //     FullSystem::optimize                  src/dso/FullSystem/FullSystemOptimize.cpp:417-647
+//     FullSystem::activatePointsMT_Reductor src/dso/FullSystem/FullSystem.cpp:589-601 (-> FullSystem::optimizeImmaturePoint, FullSystemOptPoint.cpp:51-205, for a range of candidates)
 //     CoarseInitializer::calcResAndGS       src/dso/FullSystem/CoarseInitializer.cpp:331-624   (optional: dropin_set_initializer)
 // — each forwarding to the C ABI of include/dmvio_hip.h (libdmvio_hip.so) and writing the results back into the reference's pointer graph, so that the rest of
 // FullSystem (initialiser, pixel selector, activation, marginalisation policy, keyframe management: all unmodified reference code) runs on unchanged.
@@ -64,7 +65,8 @@ using namespace dso;
 
 namespace
 {
-struct Stats { double seconds[5] = {0, 0, 0, 0, 0}; long calls[5] = {0, 0, 0, 0, 0}; };   // makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize
+enum { N_STATS = 6 };
+struct Stats { double seconds[N_STATS] = {0, 0, 0, 0, 0, 0}; long calls[N_STATS] = {0, 0, 0, 0, 0, 0}; };   // makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor
 struct Timer
 {
 	Stats& s; int k; std::chrono::steady_clock::time_point t0;
@@ -92,7 +94,7 @@ struct Backend
 	// libdmvio_hip.so from the same inputs and the two answers are compared — per-call parity on the live windows / frames of a run of the reference's FullSystem
 	bool shadow = false;
 	struct Shadow {
-		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_opt_iter_diff = 0;
+		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_opt_iter_diff = 0, n_act_pts = 0, n_act_diff = 0;
 		double opt_rmse_rel = 0, opt_energy_rel = 0, opt_pose = 0, opt_aff = 0, opt_idepth_med = 0, track_pose = 0, track_aff_a = 0, track_aff_b = 0, track_res_rel = 0;
 	} sh;
 	dmvio_hip_initializer* ini = nullptr;
@@ -228,11 +230,14 @@ void dropin_get_shadow(double* out)
 	for (int i = 0; i < 15; i++) out[i] = v[i];
 	out[15] = 0;
 }
+// n_candidates, n_differing of the shadowed FullSystem::optimizeImmaturePoint calls (result class, idepth bits, the targets of the residuals created)
+void dropin_get_shadow_activation(long* out2) { out2[0] = g.sh.n_act_pts; out2[1] = g.sh.n_act_diff;
+}
 int dropin_is_on() { return g.on ? 1 : 0; }
 // the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
 void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
-// seconds[5], calls[5] in the order makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize — counted in both modes
-void dropin_get_stats(double* seconds5, long* calls5) { for (int k = 0; k < 5; k++) { seconds5[k] = g.stats.seconds[k]; calls5[k] = g.stats.calls[k]; } }
+// seconds[6], calls[6] in the order makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor — counted in both modes
+void dropin_get_stats(double* seconds6, long* calls6) { for (int k = 0; k < N_STATS; k++) { seconds6[k] = g.stats.seconds[k]; calls6[k] = g.stats.calls[k]; } }
 void dropin_reset_stats() { g.stats = Stats(); }
 long dropin_failures(char* msg, int cap) { if (msg && cap > 0) { strncpy(msg, g.error, cap - 1); msg[cap - 1] = 0; } return g.failures; }
 }
@@ -455,6 +460,109 @@ void FullSystem::traceNewCoarse(FrameHessian* fh)
 		ip->idepth_min = imin[i]; ip->idepth_max = imax[i]; ip->quality = qual[i];
 		ip->lastTraceUV = Vec2f(uv[2 * i], uv[2 * i + 1]); ip->lastTracePixelInterval = interval[i];
 		ip->lastTraceStatus = (ImmaturePointStatus)status[i];
+	}
+}
+
+// ---- FullSystem::activatePointsMT_Reductor (FullSystem.cpp:589-601): FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:51-205) for the candidates [min, max) — the Gauss-Newton
+// on the inverse depth of every candidate on the device in ONE call, then the tail of optimizeImmaturePoint (:165-203: the PointHessian and its residuals) for those it activates
+namespace {
+struct Activated { int result; float idepth; std::vector<int> targets; };   // targets: frame indices of the residuals that are IN
+bool hipActivate(FullSystem* fs, const std::vector<ImmaturePoint*>& cand, std::vector<Activated>& out)
+{
+	const int F = (int)fs->frameHessians.size(), n = (int)cand.size();
+	out.assign(n, Activated{0, 0.f, {}});
+	if (n == 0) return true;
+	if (!HIP_OK(dmvio_hip_immature_clear(g.imm))) return false;
+	// the handle keeps its points grouped by host keyframe: candidates of host h, in candidate order
+	std::vector<int> order;
+	for (int h = 0; h < F; h++)
+	{
+		std::vector<int> ui, vi;
+		for (int k = 0; k < n; k++) if (cand[k]->host == fs->frameHessians[h]) { ui.push_back((int)cand[k]->u); vi.push_back((int)cand[k]->v); order.push_back(k); }
+		if (!ui.empty() && !HIP_OK(dmvio_hip_immature_add_points(g.imm, h, slotFor(fs->frameHessians[h]), (int)ui.size(), ui.data(), vi.data()))) return false;
+	}
+	if ((int)order.size() != n) { fprintf(stderr, "[dropin] activation candidate without a keyframe in the window\n"); abort(); }
+	std::vector<float> imin(n), imax(n), qual(n), idepth(n), expo(F);
+	std::vector<int> status(n), slots(F), result(n), rstate((size_t)n * F);
+	std::vector<double> w2c(7 * (size_t)F), aff(2 * (size_t)F);
+	for (int j = 0; j < n; j++) { const ImmaturePoint* ip = cand[order[j]]; imin[j] = ip->idepth_min; imax[j] = ip->idepth_max; qual[j] = ip->quality; status[j] = (int)ip->lastTraceStatus; }
+	for (int f = 0; f < F; f++)
+	{
+		FrameHessian* fh = fs->frameHessians[f];
+		slots[f] = slotFor(fh); expo[f] = fh->ab_exposure; toPose7(fh->PRE_worldToCam, &w2c[7 * f]); aff[2 * f] = fh->aff_g2l().a; aff[2 * f + 1] = fh->aff_g2l().b;
+	}
+	if (!HIP_OK(dmvio_hip_immature_set_state(g.imm, imin.data(), imax.data(), qual.data(), status.data()))) return false;
+	if (!HIP_OK(dmvio_hip_immature_optimize(g.imm, F, slots.data(), w2c.data(), aff.data(), expo.data(), fs->Hcalib.value_scaled.data(), nullptr, 1, result.data(), idepth.data(), rstate.data())))
+		return false;
+	for (int j = 0; j < n; j++)
+	{
+		Activated& a = out[order[j]];
+		a.result = result[j]; a.idepth = idepth[j];
+		if (result[j] == 1) for (int t = 0; t < F; t++) if (rstate[(size_t)j * F + t] == 0) a.targets.push_back(t);
+	}
+	return true;
+}
+}  // namespace
+void FullSystem::activatePointsMT_Reductor(std::vector<PointHessian*>* optimized, std::vector<ImmaturePoint*>* toOptimize, int min, int max, Vec10* stats, int tid)
+{
+	typedef void (*Fn)(FullSystem*, std::vector<PointHessian*>*, std::vector<ImmaturePoint*>*, int, int, Vec10*, int);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem25activatePointsMT_ReductorEPSt6vectorIPNS_12PointHessianESaIS3_EEPS1_IPNS_13ImmaturePointESaIS8_EEiiPN5Eigen6MatrixIdLi10ELi1ELi0ELi10ELi1EEEi");
+	Timer tm(g.stats, 5);
+	g.fs = this;
+	if (!g.on) { orig(this, optimized, toOptimize, min, max, stats, tid); return; }
+	std::vector<ImmaturePoint*> cand(toOptimize->begin() + min, toOptimize->begin() + max);
+	std::vector<Activated> act;
+	const bool ok = hipActivate(this, cand, act);
+	if (!ok || g.shadow)
+	{
+		orig(this, optimized, toOptimize, min, max, stats, tid);
+		if (!ok) return;
+		for (int k = 0; k < (int)cand.size(); k++)
+		{
+			PointHessian* p = (*optimized)[min + k];
+			const int cls = p == 0 ? 0 : (p == (PointHessian*)((long)(-1)) ? -1 : 1);
+			bool same = cls == act[k].result;
+			if (same && cls == 1)
+			{
+				same = memcmp(&p->idepth, &act[k].idepth, 4) == 0 && p->residuals.size() == act[k].targets.size();
+				for (size_t i = 0; same && i < p->residuals.size(); i++) same = p->residuals[i]->target->idx == act[k].targets[i];
+			}
+			g.sh.n_act_pts++;
+			if (!same)
+			{
+				if (g.sh.n_act_diff < 8 && getenv("DROPIN_DEBUG"))
+					fprintf(stderr, "[dropin] activation diff: class %d / %d, idepth %g / %g, residuals %zu / %zu\n", cls, act[k].result, cls == 1 ? p->idepth : 0.f, act[k].idepth,
+					        cls == 1 ? p->residuals.size() : (size_t)0, act[k].targets.size());
+				g.sh.n_act_diff++;
+			}
+		}
+		return;
+	}
+	for (int k = 0; k < (int)cand.size(); k++)
+	{
+		const Activated& a = act[k];
+		if (a.result == 0) { (*optimized)[min + k] = 0; continue; }
+		if (a.result < 0 || !std::isfinite(a.idepth)) { (*optimized)[min + k] = (PointHessian*)((long)(-1)); continue; }
+		// FullSystemOptPoint.cpp:165-203
+		PointHessian* p = new PointHessian(cand[k], &Hcalib);
+		if (!std::isfinite(p->energyTH)) { delete p; (*optimized)[min + k] = (PointHessian*)((long)(-1)); continue; }
+		p->lastResiduals[0].first = 0; p->lastResiduals[0].second = ResState::OOB;
+		p->lastResiduals[1].first = 0; p->lastResiduals[1].second = ResState::OOB;
+		p->setIdepthZero(a.idepth);
+		p->setIdepth(a.idepth);
+		p->setPointStatus(PointHessian::ACTIVE);
+		for (int t : a.targets)
+		{
+			PointFrameResidual* r = new PointFrameResidual(p, p->host, frameHessians[t]);
+			r->state_NewEnergy = r->state_energy = 0;
+			r->state_NewState = ResState::OUTLIER;
+			r->setState(ResState::IN);
+			p->residuals.push_back(r);
+			if (r->target == frameHessians.back()) { p->lastResiduals[0].first = r; p->lastResiduals[0].second = ResState::IN; }
+			else if (r->target == (frameHessians.size() < 2 ? 0 : frameHessians[frameHessians.size() - 2])) { p->lastResiduals[1].first = r; p->lastResiduals[1].second = ResState::IN; }
+		}
+		statistics_numActivatedPoints++;
+		(*optimized)[min + k] = p;
 	}
 }
 

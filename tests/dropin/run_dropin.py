@@ -113,11 +113,13 @@ def main():
                opt_F=np.array([e["F"] for e in opt_in]), opt_N=np.array([e["N"] for e in opt_in]), opt_R=np.array([e["R"] for e in opt_in]),
                n_tracks=np.array([sum(1 for e in ev if e["kind"] == "track_out")]))
     if D is not None:
-        sec = (C.c_double * 5)(); calls = (C.c_long * 5)()
+        sec = (C.c_double * 6)(); calls = (C.c_long * 6)()
         D.dropin_get_stats(sec, calls)
         if a.shadow:
             sh = (C.c_double * 16)(); D.dropin_get_shadow(sh)
             out["shadow"] = np.array(list(sh))
+            act = (C.c_long * 2)(); D.dropin_get_shadow_activation.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_shadow_activation(act)
+            out["shadow_activation"] = np.array(list(act))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
         msg = C.create_string_buffer(512)
         out["failures"] = np.array([D.dropin_failures(msg, 512)])
@@ -153,7 +155,7 @@ def window_run(a, D, R, synth):
     out = dict(rmse=np.array([ro]), poses=poses, idepth=idepth, imm_min=np.asarray(imm["idepth_min"]), imm_max=np.asarray(imm["idepth_max"]),
                imm_status=np.asarray(imm["lastTraceStatus"]), track_pose=np.asarray(tr["pose7"]), track_res=np.asarray(tr["lastResiduals"]))
     if D is not None:
-        sec = (C.c_double * 5)(); calls = (C.c_long * 5)()
+        sec = (C.c_double * 6)(); calls = (C.c_long * 6)()
         D.dropin_get_stats(sec, calls)
         out["stat_calls"] = np.array(list(calls))
         out["failures"] = np.array([D.dropin_failures(None, 0)])

@@ -15,7 +15,9 @@ import ref_py as R  # noqa: E402
 
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 DROPIN = os.path.join(REF_DIR, "libdropin_hip.so")
-MEMBERS = ["_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE",
+MEMBERS = ["_ZN3dso10FullSystem25activatePointsMT_ReductorEPSt6vectorIPNS_12PointHessianESaIS3_EEPS1_IPNS_13ImmaturePointESaIS8_EEiiPN5Eigen6MatrixIdLi10ELi1ELi0ELi10ELi1EEEi",
+           "_ZN3dso17CoarseInitializer12calcResAndGSEiRN5Eigen6MatrixIfLi8ELi8ELi0ELi8ELi8EEERNS2_IfLi8ELi1ELi0ELi8ELi1EEES4_S6_RKN6Sophus8SE3GroupIdLi0EEENS_8AffLightEb",
+           "_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE",
            "_ZN3dso13CoarseTracker20setCoarseTrackingRefESt6vectorIPNS_12FrameHessianESaIS3_EE",
            "_ZN3dso13CoarseTracker17trackNewestCoarseEPNS_12FrameHessianERN6Sophus8SE3GroupIdLi0EEERNS_8AffLightEiN5Eigen6MatrixIdLi5ELi1ELi0ELi5ELi1EEEPNS_6IOWrap15Output3DWrapperE",
            "_ZN3dso10FullSystem14traceNewCoarseEPNS_12FrameHessianE",
@@ -49,7 +51,7 @@ def test_adapter_defines_the_members_under_the_references_names(dropin):
     # ... and calls the members through the PLT (relocations against the member symbols)
     rel = subprocess.check_output(["readelf", "-r", "-W", os.path.join(REF_DIR, "libref.so")], text=True)
     for m in MEMBERS:
-        assert any("JUMP_SLO" in line and m in line for line in rel.splitlines()), m
+        assert any(("JUMP_SLO" in line or "GLOB_DAT" in line) and m in line for line in rel.splitlines()), m    # (GLOB_DAT: a member whose address is also taken, bound through the GOT)
     # the adapter needs libdmvio_hip.so and libref.so, and nothing of the product needs the reference
     need = subprocess.check_output(["readelf", "-d", dropin], text=True)
     assert "libdmvio_hip.so" in need and "libref.so" in need
@@ -69,7 +71,7 @@ def test_switched_off_the_adapter_is_transparent(dropin, tmp_path):
     one through oracle/ref_py.py: single-threaded code, deterministic)."""
     a = _run("plain", tmp_path / "plain.npz", "--window")
     b = _run("cpu", tmp_path / "cpu.npz", "--window")
-    assert b["stat_calls"].min() > 0 and b["failures"][0] == 0           # all five members were reached through the adapter
+    assert b["stat_calls"][:5].min() > 0 and b["failures"][0] == 0       # the five members this sequence uses were reached through the adapter
     assert b["stat_calls"][0] >= 4 and b["stat_calls"][4] == 1
     for k in ("rmse", "poses", "idepth", "imm_min", "imm_max", "imm_status", "track_pose", "track_res"):
         assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k

@@ -1,12 +1,12 @@
 """The drop-in, proven with the reference's own FullSystem (north_star: "keeping the FullSystem::trackNewCoarse / FullSystem::optimize call surface so it drops into
 dmvio_dataset unchanged").  oracle/_ref/libref.so holds FullSystem.cpp, FullSystemOptimize.cpp, CoarseTracker.cpp, ... compiled UNMODIFIED from /root/reference;
 oracle/_ref/libdropin_hip.so (tests/dropin/dmvio_hip_adapter.cpp, the INTEGRATION.md adapter compiled against the reference's headers) is loaded in front of it and takes
-over FrameHessian::makeImages, CoarseTracker::setCoarseTrackingRef / trackNewestCoarse, FullSystem::traceNewCoarse, FullSystem::optimize and
-CoarseInitializer::calcResAndGS by symbol interposition.  The reference's FullSystem::addActiveFrame is then run over a synthetic sequence twice —
+over FrameHessian::makeImages, CoarseTracker::setCoarseTrackingRef / trackNewestCoarse, FullSystem::traceNewCoarse, FullSystem::activatePointsMT_Reductor
+(= optimizeImmaturePoint of every activation candidate), FullSystem::optimize and CoarseInitializer::calcResAndGS by symbol interposition.  The reference's FullSystem::addActiveFrame is then run over a synthetic sequence twice —
 
   all-CPU:     every member forwards to the reference's own definition; the initialiser's calcResAndGS alone runs through the oracle's single-threaded restatement, because the
                reference's own is multi-threaded with dynamic chunking and makes two runs of the reference differ (measured below as `spread`);
-  HIP-backed:  the six members run on libdmvio_hip.so
+  HIP-backed:  the seven members run on libdmvio_hip.so
 
 — and the trajectories / window energies are compared.  What the reference keeps doing itself in both runs: initialiser driver, pixel selection, point activation,
 marginalisation policy, keyframe decisions.  Those decisions are discrete: a last-bit difference in a pose can flip the activation of a point, after which the two runs
@@ -61,7 +61,7 @@ def test_reference_fullsystem_runs_on_the_hip_library(gpu_required, tmp_path, sh
     report = ["%s: reference's own spread (multi-threaded initialiser vs sequential) rmse %.2e max %.2e m" % ((shape,) + _traj_diff(cpu, noisy))]
     for name, r in (("hip", hip), ("hip_exact", hip_exact)):
         assert r["failures"][0] == 0 and not r["lost"][-1] and r["initialized"][-1], name
-        assert r["stat_calls"].min() > 0 and r["stat_calls"][4] == len(r["opt_rmse"]) >= 5, name
+        assert r["stat_calls"].min() > 0 and r["stat_calls"][4] == len(r["opt_rmse"]) >= 5, name     # all six members (incl. activation) were on the call path
         rmse, mx = _traj_diff(cpu, r)
         n = min(len(cpu["opt_rmse"]), len(r["opt_rmse"]))
         same = (cpu["opt_N"][:n] == r["opt_N"][:n]) & (cpu["opt_R"][:n] == r["opt_R"][:n])
@@ -105,5 +105,9 @@ def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path,
     assert sh["n_trace_diff"] == 0
     # trackNewestCoarse: same converged / aborted / good verdict, pose and achieved residual
     assert sh["n_track_good_diff"] == 0 and sh["track_pose"] < 1e-4 and sh["track_res_rel"] < 1e-4, sh
+    # optimizeImmaturePoint of every activation candidate (FullSystem::activatePointsMT_Reductor): result class, inverse depth and the targets of the residuals created
+    na, nd = r["shadow_activation"]
+    print("activation candidates %d, differing %d" % (na, nd))
+    assert na > 1000 and nd == 0
     # optimize: every live window
     assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh
