@@ -84,6 +84,8 @@ struct BAPoints {   // SoA, N entries
 struct BARes {      // SoA, R entries
   const int *point, *target;
   unsigned char *state, *newState, *active, *which;  // which: buffer (0/1) holding the APPLIED record
+  unsigned char* removed;   // the residual left the graph: FullSystem::linearizeAll(true) deletes every residual that is not active after its applyRes (FullSystemOptimize.cpp:176-212);
+                            // it stays OOB / inactive for every later linearisation, resetOOB and marginalisation of this graph
   float *energy, *newEnergy, *newEnergyWO;
   float* center;   // R x 3 centerProjectedTo
   const int* newestSlot;   // R: position of the residual among those that target the newest keyframe, or -1
@@ -333,11 +335,12 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
     float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
     int state = Rs.state[ri];
     const float oldEnergy = pt_mask ? 0.f : Rs.energy[ri];
-    if (pt_mask) state = BA_IN;
+    const bool gone = Rs.removed[ri] != 0;   // deleted by an earlier fix-linearisation: the reference has no such residual any more (state stays OOB below)
+    if (pt_mask && !gone) state = BA_IN;
     if (lead) {
       Rs.newEnergyWO[ri] = -1.0f;
       { const int sl = Rs.newestSlot[ri]; if (sl >= 0) __hip_atomic_store(Rs.newestE + sl, -1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      if (pt_mask) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
+      if (pt_mask && !gone) { Rs.state[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; Rs.newState[ri] = BA_OUTLIER; }
     }
     bool done = false;
     if (state == BA_OOB) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
@@ -555,17 +558,29 @@ __global__ void __launch_bounds__(1024) k_ba_publish_sys(const double* __restric
   if (threadIdx.x == 0) __hip_atomic_store(&host->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector
-__global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, const unsigned char* __restrict__ pt_mask) {
+// applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector.
+// mark_removed: the tail of FullSystem::linearizeAll(true) (FullSystemOptimize.cpp:176-212) — a residual that is not active after this applyRes is deleted from the graph
+__global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, const unsigned char* __restrict__ pt_mask, const int mark_removed) {
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= R) return;
   if (pt_mask && !pt_mask[Rs.point[ri]]) return;
-  if (Rs.state[ri] == BA_OOB) return;  // can never go back from OOB
-  const int ns = Rs.newState[ri];
-  if (ns == BA_IN) { Rs.active[ri] = 1; Rs.which[ri] ^= 1; }
-  else Rs.active[ri] = 0;
-  Rs.state[ri] = (unsigned char)ns;
-  Rs.energy[ri] = Rs.newEnergy[ri];
+  if (Rs.state[ri] != BA_OOB) {  // can never go back from OOB
+    const int ns = Rs.newState[ri];
+    if (ns == BA_IN) { Rs.active[ri] = 1; Rs.which[ri] ^= 1; }
+    else Rs.active[ri] = 0;
+    Rs.state[ri] = (unsigned char)ns;
+    Rs.energy[ri] = Rs.newEnergy[ri];
+  }
+  if (mark_removed && !Rs.active[ri]) { Rs.removed[ri] = 1; Rs.state[ri] = BA_OOB; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f; }
+}
+// PointFrameResidual::resetOOB of every residual still in the graph (FullSystemOptimize.cpp:431-448)
+__global__ void __launch_bounds__(256) k_ba_reset_oob(const int R, const BARes Rs) {
+  const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= R) return;
+  const bool gone = Rs.removed[ri] != 0;
+  Rs.state[ri] = gone ? BA_OOB : BA_IN;
+  Rs.newState[ri] = gone ? BA_OOB : BA_OUTLIER;
+  Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ per-point sums

@@ -337,7 +337,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
                      (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   BA_PROF(b, 1);
-  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr);
+  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr, 1);   // + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
   if (shard) { if (int r = decideGlobal(b, D)) return r; }
   if (defer) return 0;
@@ -346,7 +346,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   return 0;
 }
 static int applyRes(dmvio_hip_ba* b) {
-  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->stream, b->H.R, b->Rs, (const unsigned char*)nullptr);
+  hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->stream, b->H.R, b->Rs, (const unsigned char*)nullptr, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -694,7 +694,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
     hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_fullJ, (const unsigned char*)b->d_cand, D,
                        (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   }
-  hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand);
+  hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand, 0);
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
   hipLaunchKernelGGL(k_ba_fix_linearization, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, b->d_fullJ, b->d_decision, b->d_adHTdelta, cd, b->d_margRec,
@@ -777,7 +777,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &P.Hcd, (size_t)N * 4) || dalloc(b, &P.HdiF, N) || dalloc(b, &P.bdSumF, N) || dalloc(b, &P.idepth_hessian, N) ||
       dalloc(b, &b->d_cand, N) || dalloc(b, &b->d_decision, N) || dalloc(b, &b->d_mHdiF, N) || dalloc(b, &b->d_mbdSumF, N) || dalloc(b, &b->d_mHcd, (size_t)N * 4) ||
       dalloc(b, &b->d_margRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_margActive, R) || dalloc(b, &b->d_adHTdelta, (size_t)F2 * 8)) return -1;
-  if (dalloc(b, &Rs.state, R) || dalloc(b, &Rs.newState, R) || dalloc(b, &Rs.active, R) || dalloc(b, &Rs.which, R) || dalloc(b, &Rs.energy, R) || dalloc(b, &Rs.newEnergy, R) ||
+  if (dalloc(b, &Rs.removed, R) || dalloc(b, &Rs.state, R) || dalloc(b, &Rs.newState, R) || dalloc(b, &Rs.active, R) || dalloc(b, &Rs.which, R) || dalloc(b, &Rs.energy, R) || dalloc(b, &Rs.newEnergy, R) ||
       dalloc(b, &Rs.center, (size_t)R * 3) || dalloc(b, &Rs.rec[0], (size_t)R * REC_FLOATS) || dalloc(b, &Rs.rec[1], (size_t)R * REC_FLOATS)) return -1;
   P.host = d_host; P.u = d_u; P.v = d_v; P.color = d_color; P.weights = d_weights; P.priorF = d_prior; P.res_begin = d_res_begin;
   Rs.point = d_point; Rs.target = d_target;
@@ -849,10 +849,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
   BA_READY(b);
   hipStream_t s = b->stream;
-  HIPCHK(hipMemsetAsync(b->Rs.state, BA_IN, b->H.R, s));
-  HIPCHK(hipMemsetAsync(b->Rs.newState, BA_OUTLIER, b->H.R, s));
-  HIPCHK(hipMemsetAsync(b->Rs.energy, 0, sizeof(float) * b->H.R, s));
-  HIPCHK(hipMemsetAsync(b->Rs.newEnergy, 0, sizeof(float) * b->H.R, s));
+  // every residual still in the graph; those an earlier fix-linearisation deleted (FullSystemOptimize.cpp:195-212) stay out
+  hipLaunchKernelGGL(k_ba_reset_oob, dim3((b->H.R + 255) / 256), dim3(256), 0, s, b->H.R, b->Rs);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 int dmvio_hip_ba_linearize(dmvio_hip_ba* b, int fix, double* energy) {

@@ -260,7 +260,8 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* ba, int N, const int* host, const float
 /* resetOOB of every residual (FullSystemOptimize.cpp:431-448) */
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* ba);
 /* FullSystem::linearizeAll(fixLinearization) (FullSystemOptimize.cpp:150-218): PointFrameResidual::linearize over all residuals,
- * energy sum, setNewFrameEnergyTH; fix != 0 also applies the results (applyRes(true)). */
+ * energy sum, setNewFrameEnergyTH; fix != 0 also applies the results (applyRes(true)) and — like the reference (:176-212) — takes every residual that is not active
+ * afterwards out of the graph: it stays OOB / inactive for all later linearisations, activate_all and marginalisations until the next dmvio_hip_ba_set_graph. */
 int dmvio_hip_ba_linearize(dmvio_hip_ba* ba, int fix, double* energy);
 /* FullSystem::applyRes_Reductor(true) (FullSystemOptimize.cpp:91-95) */
 int dmvio_hip_ba_apply(dmvio_hip_ba* ba);

@@ -85,6 +85,7 @@ struct Backend
 	std::map<const FrameHessian*, int> slotOf;
 	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
 	FullSystem* fs = nullptr;      // learnt from the first FullSystem member that comes by
+	std::map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
 	// CoarseInitializer.cpp:507 / util/IndexThreadReduce.h:83-87 — the sums, and with them everything downstream, vary in the last bits from run to run);
 	// 1 = the oracle's single-threaded restatement (oracle/init_oracle.cpp, per-point bit-identical to the reference: the sums one worker taking every chunk would form)
@@ -95,6 +96,8 @@ struct Backend
 	bool shadow = false;
 	struct Shadow {
 		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_opt_iter_diff = 0, n_act_pts = 0, n_act_diff = 0;
+		long n_marg = 0, n_marg_pts = 0, n_marg_decision_diff = 0, n_marg_res_diff = 0;
+		double marg_H_rel = 0, marg_b_rel = 0;
 		double opt_rmse_rel = 0, opt_energy_rel = 0, opt_pose = 0, opt_aff = 0, opt_idepth_med = 0, track_pose = 0, track_aff_a = 0, track_aff_b = 0, track_res_rel = 0;
 	} sh;
 	dmvio_hip_initializer* ini = nullptr;
@@ -229,6 +232,13 @@ void dropin_get_shadow(double* out)
 	                      h.opt_energy_rel, h.opt_pose, h.opt_aff, h.opt_idepth_med, h.track_pose, h.track_aff_a, h.track_aff_b, h.track_res_rel};
 	for (int i = 0; i < 15; i++) out[i] = v[i];
 	out[15] = 0;
+}
+// shadowed EnergyFunctional::marginalizePointsF calls: n_calls, n_points, points the device would have dropped instead, calls whose residual count differs; max relative
+// deviation of the increment of HM / of bM
+void dropin_get_shadow_marginalization(double* out6)
+{
+	out6[0] = (double)g.sh.n_marg; out6[1] = (double)g.sh.n_marg_pts; out6[2] = (double)g.sh.n_marg_decision_diff; out6[3] = (double)g.sh.n_marg_res_diff;
+	out6[4] = g.sh.marg_H_rel; out6[5] = g.sh.marg_b_rel;
 }
 // n_candidates, n_differing of the shadowed FullSystem::optimizeImmaturePoint calls (result class, idepth bits, the targets of the residuals created)
 void dropin_get_shadow_activation(long* out2) { out2[0] = g.sh.n_act_pts; out2[1] = g.sh.n_act_diff;
@@ -566,6 +576,122 @@ void FullSystem::activatePointsMT_Reductor(std::vector<PointHessian*>* optimized
 	}
 }
 
+// ---- the window of the reference's FullSystem handed to the BA handle: keyframes in frameHessians order, points in EnergyFunctional::allPoints order (makeIDX,
+// EnergyFunctional.cpp:997-1017), residuals in EFPoint::residualsAll order — the orders the reference's accumulators add in — with the states, FEJ points, thresholds,
+// calibration and marginalisation prior the reference holds at this moment
+namespace {
+struct FlatWindow
+{
+	int F = 0, N = 0, R = 0, n = 0;
+	std::vector<PointHessian*> points;
+	std::map<PointFrameResidual*, int> resIndex;
+};
+bool uploadWindow(FullSystem* fs, FlatWindow& W)
+{
+	const int F = (int)fs->frameHessians.size();
+	std::vector<int> slots(F), frameIDs(F);
+	std::vector<double> evalPT7(7 * F), affZero(2 * F);
+	std::vector<float> expo(F), th(F);
+	for (int f = 0; f < F; f++)
+	{
+		FrameHessian* fh = fs->frameHessians[f];
+		assert(fh->idx == f);
+		slots[f] = slotFor(fh); frameIDs[f] = fh->frameID; expo[f] = fh->ab_exposure; th[f] = fh->frameEnergyTH;
+		toPose7(fh->get_worldToCam_evalPT(), &evalPT7[7 * f]);
+		affZero[2 * f] = fh->get_state_zero()[6] * SCALE_A; affZero[2 * f + 1] = fh->get_state_zero()[7] * SCALE_B;
+	}
+	std::vector<int> host, resPoint, resTarget;
+	std::vector<float> pu, pv, pid, color, weights;
+	std::vector<unsigned char> prior;
+	W.points.clear(); W.resIndex.clear();
+	for (EFFrame* eff : fs->ef->frames)
+		for (EFPoint* efp : eff->points)
+		{
+			PointHessian* ph = efp->data;
+			const int pi = (int)W.points.size();
+			W.points.push_back(ph);
+			host.push_back(ph->host->idx); pu.push_back(ph->u); pv.push_back(ph->v); pid.push_back(ph->idepth); prior.push_back(ph->hasDepthPrior ? 1 : 0);
+			for (int k = 0; k < 8; k++) { color.push_back(ph->color[k]); weights.push_back(ph->weights[k]); }
+			for (EFResidual* er : efp->residualsAll)
+			{
+				W.resIndex[er->data] = (int)resPoint.size();
+				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx);
+			}
+		}
+	W.F = F; W.N = (int)W.points.size(); W.R = (int)resPoint.size(); W.n = CPARS + 8 * F;
+	if (W.N < 1 || W.R < 1) return false;
+	g.windowPoint.clear();
+	for (size_t pi = 0; pi < W.points.size(); pi++) g.windowPoint[W.points[pi]] = (int)pi;
+	dmvio_hip_ba* ba = g.ba;
+	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), fs->Hcalib.value_scaled.data()));
+	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, W.N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), W.R, resPoint.data(), resTarget.data()));
+	for (int f = 0; ok && f < F; f++)
+	{
+		Vec10 sz = fs->frameHessians[f]->get_state_zero(), st = fs->frameHessians[f]->get_state();
+		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_zero(ba, f, sz.data())) && HIP_OK(dmvio_hip_ba_set_frame_state(ba, f, st.data()));
+	}
+	ok = ok && HIP_OK(dmvio_hip_ba_set_frame_energy_th(ba, th.data())) && HIP_OK(dmvio_hip_ba_set_calib_values(ba, fs->Hcalib.value.data(), fs->Hcalib.value_zero.data()));
+	{
+		const int n = W.n;
+		std::vector<double> HM((size_t)n * n), bM(n);
+		for (int r = 0; r < n; r++) { bM[r] = fs->ef->bM[r]; for (int c = 0; c < n; c++) HM[(size_t)r * n + c] = fs->ef->HM(r, c); }
+		ok = ok && HIP_OK(dmvio_hip_ba_set_marg_prior(ba, HM.data(), bM.data()));
+	}
+	return ok;
+}
+}  // namespace
+
+// ---- EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742) with the relinearisation FullSystem::flagPointsForRemoval ran just before it (FullSystem.cpp:836-849).
+// The reference's own code stays in charge (the point lists, removePoint, connectivity bookkeeping are host structure); in shadow mode the increment of the marginalisation
+// prior is ALSO formed on the device, from the window the BA handle still holds since the optimize of this keyframe: masked relinearisation of the points the reference flagged,
+// fixLinearizationF, addPoint<2> + the Schur side, stitched — and compared
+}  // namespace dso
+namespace dso
+{
+void EnergyFunctional::marginalizePointsF()
+{
+	typedef void (*Fn)(EnergyFunctional*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional18marginalizePointsFEv");
+	if (!g.on || !g.shadow || !g.fs) { orig(this); return; }
+	// the window as the reference holds it NOW (after optimize, removeOutliers, flagPointsForRemoval's relinearisation, dropPointsF): identical states on both sides; one
+	// linearisation + accumulation gives the device the per-point Hessians its marginalise-or-drop rule reads
+	FlatWindow FW;
+	double e0 = 0;
+	if (!uploadWindow(g.fs, FW) || !HIP_OK(dmvio_hip_ba_activate_all(g.ba)) || !HIP_OK(dmvio_hip_ba_linearize_local(g.ba, 0, &e0, nullptr, nullptr)) /* thresholds stay the reference's */ || !HIP_OK(dmvio_hip_ba_apply(g.ba)) ||
+	    !HIP_OK(dmvio_hip_ba_accumulate(g.ba, nullptr, nullptr, nullptr, nullptr, nullptr))) { orig(this); return; }
+	const int N = FW.N, n = CPARS + 8 * nFrames;
+	std::vector<unsigned char> cand(N, 0), decision(N, 0);
+	int nc = 0;
+	bool known = true;
+	for (EFFrame* f : frames)
+		for (EFPoint* p : f->points)
+			if (p->stateFlag == EFPointStatus::PS_MARGINALIZE)
+			{
+				auto it = g.windowPoint.find(p->data);
+				if (it == g.windowPoint.end()) { known = false; break; }
+				cand[it->second] = 1; nc++;
+			}
+	if (!known || nc == 0) { orig(this); return; }
+	std::vector<double> Hadd((size_t)n * n), badd(n);
+	int resInMdev = 0;
+	const bool ok = HIP_OK(dmvio_hip_ba_marginalize_points(g.ba, cand.data(), decision.data(), Hadd.data(), badd.data(), &resInMdev, 0));
+	const MatXX HM0 = HM; const VecX bM0 = bM; const int resInM0 = resInM;
+	orig(this);
+	if (!ok || HM.rows() != n) return;
+	g.sh.n_marg++; g.sh.n_marg_pts += nc;
+	for (int i = 0; i < N; i++) if (cand[i] && decision[i] != 1) g.sh.n_marg_decision_diff++;
+	if (resInM - resInM0 != resInMdev) g.sh.n_marg_res_diff++;
+	if (getenv("DROPIN_DEBUG")) fprintf(stderr, "[dropin] marginalizePointsF: %d points, residuals reference %d device %d\n", nc, resInM - resInM0, resInMdev);
+	double dH = 0, sH = 0, db = 0, sb = 0;
+	for (int r = 0; r < n; r++)
+	{
+		for (int c = 0; c < n; c++) { const double v = HM(r, c) - HM0(r, c); dH = std::max(dH, std::fabs(v - Hadd[(size_t)r * n + c])); sH = std::max(sH, std::fabs(v)); }
+		const double v = bM[r] - bM0[r]; db = std::max(db, std::fabs(v - badd[r])); sb = std::max(sb, std::fabs(v));
+	}
+	if (sH > 0) g.sh.marg_H_rel = std::max(g.sh.marg_H_rel, dH / sH);
+	if (sb > 0) g.sh.marg_b_rel = std::max(g.sh.marg_b_rel, db / sb);
+}
+
 // ---- FullSystem::optimize (FullSystemOptimize.cpp:417-647): the window flattened once, the whole Gauss-Newton loop and the final fix-linearisation on the device,
 // the results written back into FrameHessian / PointHessian / PointFrameResidual with the bookkeeping linearizeAll(true) does (:150-218, :51-85)
 float FullSystem::optimize(int mnumOptIts)
@@ -590,54 +716,14 @@ float FullSystem::optimize(int mnumOptIts)
 				activeResiduals.push_back(r);
 				r->resetOOB();
 			}
-	// ---- the window: keyframes in frameHessians order, points in EnergyFunctional::allPoints order (makeIDX, EnergyFunctional.cpp:997-1017), residuals in
-	// EFPoint::residualsAll order — the orders the reference's accumulators add in
-	std::vector<int> slots(F), frameIDs(F);
-	std::vector<double> evalPT7(7 * F), affZero(2 * F);
-	std::vector<float> expo(F), th(F);
-	for (int f = 0; f < F; f++)
-	{
-		FrameHessian* fh = frameHessians[f];
-		assert(fh->idx == f);
-		slots[f] = slotFor(fh); frameIDs[f] = fh->frameID; expo[f] = fh->ab_exposure; th[f] = fh->frameEnergyTH;
-		toPose7(fh->get_worldToCam_evalPT(), &evalPT7[7 * f]);
-		affZero[2 * f] = fh->get_state_zero()[6] * SCALE_A; affZero[2 * f + 1] = fh->get_state_zero()[7] * SCALE_B;
-	}
-	std::vector<int> host, resPoint, resTarget;
-	std::vector<float> pu, pv, pid, color, weights;
-	std::vector<unsigned char> prior;
-	std::vector<PointHessian*> points;
-	std::map<PointFrameResidual*, int> resIndex;
-	for (EFFrame* eff : ef->frames)
-		for (EFPoint* efp : eff->points)
-		{
-			PointHessian* ph = efp->data;
-			const int pi = (int)points.size();
-			points.push_back(ph);
-			host.push_back(ph->host->idx); pu.push_back(ph->u); pv.push_back(ph->v); pid.push_back(ph->idepth); prior.push_back(ph->hasDepthPrior ? 1 : 0);
-			for (int k = 0; k < 8; k++) { color.push_back(ph->color[k]); weights.push_back(ph->weights[k]); }
-			for (EFResidual* er : efp->residualsAll)
-			{
-				resIndex[er->data] = (int)resPoint.size();
-				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx);
-			}
-		}
-	const int N = (int)points.size(), R = (int)resPoint.size(), n = CPARS + 8 * F;
-	if (N < 1 || R < 1 || resIndex.size() != activeResiduals.size()) { fprintf(stderr, "[dropin] window without points / residual lists disagree\n"); abort(); }
+	FlatWindow FW;
+	bool ok = uploadWindow(this, FW);
+	const int N = FW.N, R = FW.R;
+	std::vector<PointHessian*>& points = FW.points;
+	std::map<PointFrameResidual*, int>& resIndex = FW.resIndex;
+	if (ok && resIndex.size() != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
 	dmvio_hip_ba* ba = g.ba;
-	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), Hcalib.value_scaled.data()));
-	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), R, resPoint.data(), resTarget.data()));
-	for (int f = 0; ok && f < F; f++)
-	{
-		Vec10 sz = frameHessians[f]->get_state_zero(), st = frameHessians[f]->get_state();
-		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_zero(ba, f, sz.data())) && HIP_OK(dmvio_hip_ba_set_frame_state(ba, f, st.data()));
-	}
-	ok = ok && HIP_OK(dmvio_hip_ba_set_frame_energy_th(ba, th.data())) && HIP_OK(dmvio_hip_ba_set_calib_values(ba, Hcalib.value.data(), Hcalib.value_zero.data()));
-	{
-		std::vector<double> HM((size_t)n * n), bM(n);
-		for (int r = 0; r < n; r++) { bM[r] = ef->bM[r]; for (int c = 0; c < n; c++) HM[(size_t)r * n + c] = ef->HM(r, c); }
-		ok = ok && HIP_OK(dmvio_hip_ba_set_marg_prior(ba, HM.data(), bM.data()));
-	}
+	std::vector<float> th(F);
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
 	float rmse = 0; double finalEnergy = 0; int iterations = 0;
 	ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));

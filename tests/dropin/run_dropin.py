@@ -120,6 +120,8 @@ def main():
             out["shadow"] = np.array(list(sh))
             act = (C.c_long * 2)(); D.dropin_get_shadow_activation.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_shadow_activation(act)
             out["shadow_activation"] = np.array(list(act))
+            mg = (C.c_double * 6)(); D.dropin_get_shadow_marginalization.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_shadow_marginalization(mg)
+            out["shadow_marginalization"] = np.array(list(mg))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
         msg = C.create_string_buffer(512)
         out["failures"] = np.array([D.dropin_failures(msg, 512)])

@@ -109,5 +109,9 @@ def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path,
     na, nd = r["shadow_activation"]
     print("activation candidates %d, differing %d" % (na, nd))
     assert na > 1000 and nd == 0
+    # marginalizePointsF (+ the relinearisation of flagPointsForRemoval) of every keyframe: the increment of the marginalisation prior HM / bM
+    mg = r["shadow_marginalization"]
+    print("marginalisations %d (%d points): device would drop %d, residual counts differ in %d calls, increment of HM within %.1e, of bM within %.1e (relative to the largest entry)" % tuple(mg))
+    assert mg[0] >= 5 and mg[1] > 500 and mg[2] <= 0.01 * mg[1] and mg[4] < 1e-4 and mg[5] < 1e-4, mg
     # optimize: every live window
     assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh
