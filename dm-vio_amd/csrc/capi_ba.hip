@@ -73,8 +73,11 @@ struct dmvio_hip_ba {
   std::vector<int> h_host, h_point, h_target, h_res_begin;
   std::vector<int> h_newest;   // residuals that target the newest keyframe (inputs of setNewFrameEnergyTH), ascending
   std::vector<unsigned char> h_prior_flag;
-  // device storage
+  // device storage.  The window is rebuilt for every keyframe (dmvio_hip_ba_set_graph): its ~75 device arrays are carved out of a few large chunks that stay with the
+  // handle and are cleared with one memset each — not allocated, cleared and freed one by one (that cost milliseconds per keyframe, more than optimize(6) itself)
   std::vector<void*> allocs;
+  struct Arena { std::vector<std::pair<char*, size_t>> chunks; size_t cur = 0, off = 0; bool on = false; } arena;
+  size_t cap_spart = 0, cap_idepth_backup = 0;   // capacities of the grow-only pinned host buffers
   BAPrecalc* d_pre = nullptr;        // the precalc table the kernels read: one of the two halves of d_pre2
   BAPrecalc* d_pre2 = nullptr;       // [2][F*F]: the table of the backed-up state stays resident, a rejected step switches back to it
   int pre_half = 0;
@@ -153,6 +156,23 @@ struct dmvio_hip_ba {
 
 template <class T>
 static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
+  if (b->arena.on) {   // inside dmvio_hip_ba_set_graph: a zeroed piece of the handle's arena
+    dmvio_hip_ba::Arena& A = b->arena;
+    const size_t bytes = (sizeof(T) * std::max<size_t>(n, 1) + 255) & ~(size_t)255;
+    while (A.cur < A.chunks.size() && A.off + bytes > A.chunks[A.cur].second) { A.cur++; A.off = 0; }
+    if (A.cur == A.chunks.size()) {
+      const size_t size = std::max<size_t>(bytes, (size_t)16 << 20);
+      char* base = nullptr;
+      HIPCHK(hipMalloc((void**)&base, size));
+      HIPCHK(hipMemset(base, 0, size));
+      HIPCHK(hipStreamSynchronize(nullptr));
+      A.chunks.push_back(std::make_pair(base, size));
+      A.off = 0;
+    }
+    *p = reinterpret_cast<T*>(A.chunks[A.cur].first + A.off);
+    A.off += bytes;
+    return 0;
+  }
   HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
   HIPCHK(hipMemset(*p, 0, sizeof(T) * std::max<size_t>(n, 1)));
   // hipMemset clears on the NULL stream without blocking the host, and the handle's stream is non-blocking: without this wait an upload enqueued next could
@@ -161,16 +181,23 @@ static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
   b->allocs.push_back((void*)*p);
   return 0;
 }
+// what a new graph replaces: the arrays allocated outside the arena (exchange buffers of a sharded window); the arena's chunks and the pinned host buffers stay
 static void freeDevice(dmvio_hip_ba* b) {
   for (void* p : b->allocs) hipFree(p);
   b->allocs.clear();
+  b->graph_ready = false;
+}
+static void freeAll(dmvio_hip_ba* b) {
+  freeDevice(b);
+  for (auto& ch : b->arena.chunks) hipFree(ch.first);
+  b->arena.chunks.clear(); b->arena.cur = b->arena.off = 0;
   if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
   if (b->h_res) { hipHostFree(b->h_res); b->h_res = nullptr; }
   if (b->h_frameTH) { hipHostFree(b->h_frameTH); b->h_frameTH = nullptr; }
   if (b->h_idepth_backup) { hipHostFree(b->h_idepth_backup); b->h_idepth_backup = nullptr; }
   for (int k = 0; k < 2; k++) if (b->h_pre[k]) { hipHostFree(b->h_pre[k]); b->h_pre[k] = nullptr; }
-  b->graph_ready = false;
+  b->cap_spart = b->cap_idepth_backup = 0;
 }
 
 // switch_back: the state was restored to the one whose table is still in the other half (loadSateBackup after a rejected step)
@@ -501,7 +528,7 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
     }
   }
   if (b->d_accTicks) hipFree(b->d_accTicks);
-  freeDevice(b);
+  freeAll(b);
   if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
   delete b;
 }
@@ -730,6 +757,12 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   freeDevice(b);
+  // the arena of the previous graph, cleared for this one (one memset per chunk on the handle's stream, one wait — the uploads below also use the NULL stream)
+  for (auto& ch : b->arena.chunks) HIPCHK(hipMemsetAsync(ch.first, 0, ch.second, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->arena.cur = 0; b->arena.off = 0;
+  struct ArenaScope { dmvio_hip_ba* b; ~ArenaScope() { b->arena.on = false; } } arenaScope{b};
+  b->arena.on = true;
   const int F = H.F, F2 = F * F;
   H.N = N; H.R = R;
   b->h_host.assign(host, host + N); b->h_point.assign(res_point, res_point + R); b->h_target.assign(res_target, res_target + R);
@@ -816,14 +849,19 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   if (dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
   // kernels straight into pinned host memory: no copy engine between the last kernel and the host's wait
-  HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (tot + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent
+  constexpr int NMAXF = 4 + 8 * BA_MAXF;
+  if (!b->h_sys) HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (2 * (NMAXF * NMAXF + NMAXF) + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent; sized for BA_MAXF keyframes once
   if (dalloc(b, &b->d_sys, (size_t)tot + 1)) return -1;
   b->xchg_width = 0; b->d_xchg_local = b->d_xchg_all = nullptr;
   b->pending_reject = false; b->pending_trace = -1;
-  HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
+  if (!b->h_res) HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
   memset(b->h_res, 0, sizeof(BAHostRes));
-  HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&b->h_idepth_backup, sizeof(float) * std::max(N, 1), hipHostMallocCoherent | hipHostMallocMapped));
+  if (!b->h_frameTH) HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
+  if ((size_t)N > b->cap_idepth_backup) {
+    if (b->h_idepth_backup) HIPCHK(hipHostFree(b->h_idepth_backup));
+    b->cap_idepth_backup = (size_t)N + (size_t)N / 2 + 256;
+    HIPCHK(hipHostMalloc((void**)&b->h_idepth_backup, sizeof(float) * b->cap_idepth_backup, hipHostMallocCoherent | hipHostMallocMapped));
+  }
   if (dalloc(b, &b->d_ctl, 1) || dalloc(b, &b->d_frameTH, BA_MAXF) || dalloc(b, &b->d_epart, (size_t)b->n_epart) || dalloc(b, &b->d_newestSlot, (size_t)R) || dalloc(b, &b->d_newestE, b->h_newest.size()) ||
       dalloc(b, &b->d_newEnergyWO, (size_t)R)) return -1;
   {
@@ -834,9 +872,13 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   }
   b->pre_static_valid = false;
   b->th_dirty = true; b->sys_ready = false;
-  for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * F2, hipHostMallocDefault));
+  for (int k = 0; k < 2; k++) if (!b->h_pre[k]) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * BA_MAXF * BA_MAXF, hipHostMallocDefault));
   Rs.newEnergyWO = b->d_newEnergyWO;
-  HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * 2 * b->n_pt_blocks, hipHostMallocDefault));
+  if ((size_t)2 * b->n_pt_blocks > b->cap_spart) {
+    if (b->h_spart) HIPCHK(hipHostFree(b->h_spart));
+    b->cap_spart = (size_t)2 * b->n_pt_blocks + 64;
+    HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * b->cap_spart, hipHostMallocDefault));
+  }
   if (int r = uploadAdjoints(b)) return r;
   HIPCHK(hipStreamSynchronize(s));
   b->graph_ready = true;

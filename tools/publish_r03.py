@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Copies the summaries of gpurun_out/prof_r03 (tools/profile_round.sh r03 + the driver's own bench command) into profiles/r03_*."""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "prof_r03"); P = os.path.join(ROOT, "profiles")
+d = json.loads(open(O + "/bench_n1.json").read().strip().splitlines()[-1])
+json.dump(d, open(P + "/r03_bench_n1.json", "w"), indent=1)
+dd = json.loads(open(O + "/bench_driver_cmd.json").read().strip().splitlines()[-1])
+json.dump(dd, open(P + "/r03_bench_n1_driver_command.json", "w"), indent=1)
+rf = d["roofline"]; ba = d["ba"]
+lines = open(O + "/kernel_stats.md").read().splitlines()
+body = [l for l in lines[2:] if ("dmv::" in l or "__amd_rocclr_copyBuffer" in l)]
+head = ("# r03 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-traffic` (defaults: 4096 frames per step, 200 steps, batch sweep, PCIe legs, BA / trace / overlap / live / "
+        "VIO legs), 1x MI355X\n\nProduced by `tools/profile_round.sh r03` + `tools/publish_r03.py`; durations in microseconds from the rocpd database (`tools/rocprof_summary.py`).  The dominant kernel of "
+        "the headline step is `k_track_lm<256, 4>` with 4096 workgroups (one per frame): avg below vs %.4f ms by HIP events on its stream in the un-profiled run (`profiles/r03_bench_n1.json`: "
+        "%.0f frames/s, algorithmic fraction %.3f, HBM-counter fraction %.3f).  BA kernels: `k_ba_linearize` avg below vs %.1f us by HIP events incl. the gap to the next launch "
+        "(`ba.roofline.chain_us`); `ba.value` = %.0f accepted GN iterations/s on fresh windows (optimize(6) = %.3f ms), %.0f/s on the converged (reject-dominated) loop.\n\n"
+        % (rf["kernel_ms"], d["value"], rf["frac"], rf.get("frac_hbm_counter", float("nan")), ba["roofline"]["kernel_us"], ba["value"], ba["optimize6_ms"], ba["value_converged_loop"]))
+open(P + "/r03_kernel_stats.md", "w").write(head + "\n".join(lines[:2] + body[:80]) + "\n")
+def filt(path):
+    return [l for l in open(path).read().splitlines() if l.startswith("| kernel") or l.startswith("|---") or "dmv::" in l]
+head = ("# r03 — HBM traffic counters (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, no other tracing), 1x MI355X\n\n"
+        "`bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 --ba-iters 20`.  Values are KiB as the counter reports them; on gfx950 FETCH_SIZE tallies 128-byte reads at half "
+        "their size (MI355X_MICROARCH.md): the in-run calibration on `k_build_pyramids` (reads exactly B x w x h x 4 bytes per launch) gives the factor 2.000 that `bench.py` applies "
+        "(`roofline.traffic_source`).  `k_track_lm<256,4>` with 4096 workgroups: %.2f GB per launch by the counter = %.2fx its %.2f GB of algorithmic bytes.\n\n"
+        % (rf["traffic"] / 1e9, rf["traffic"] / rf["algorithmic_bytes_per_launch"], rf["algorithmic_bytes_per_launch"] / 1e9))
+open(P + "/r03_pmc_hbm_traffic.md", "w").write(head + "## FETCH_SIZE\n" + "\n".join(filt(O + "/pmc_FETCH_SIZE.md")) + "\n\n## WRITE_SIZE\n" + "\n".join(filt(O + "/pmc_WRITE_SIZE.md")) + "\n")
+out = ["# r03 — BA: host-side split of the GN iteration (DMVIO_HIP_BA_TIMING=1, no synchronisation added) and kernel timeline (rocprofv3 --kernel-trace of tools/ba_loop.py, 1x MI355X)", ""]
+out += [l for l in open(O + "/ba_timing.log").read().splitlines() if l.startswith("[dmvio_hip_ba]")]
+out += ["", "## tools/ba_loop.py under rocprofv3 (one dmvio_hip_ba_gn_iteration call per iteration from Python; optimize(6) on fresh windows; the profiler adds ~15 % to these host-clock figures)"]
+out += [l for l in open(O + "/ba_loop.log").read().splitlines() if ("GN-iter" in l or "decision" in l or "optimize(" in l)]
+out += ["", "## kernel timeline (us): start, duration, gap to the previous kernel, workgroups — set-up, then accepted iterations of the first optimize"]
+out += open(O + "/ba_timeline.txt").read().splitlines()
+open(P + "/r03_ba_host_split_and_timeline.txt", "w").write("\n".join(out) + "\n")
+print(json.dumps({k: d[k] for k in ("value", "ms_per_step")}), json.dumps(rf)[:300])
+print("driver cmd:", dd["value"], dd["ms_per_step"], dd["roofline"]["frac"])
+for k in ("value", "optimize6_ms", "value_converged_loop", "value_per_call_api", "value_single_threaded_order", "gtsam_handoff"):
+    print("ba", k, ba.get(k))
+print("ba roofline", json.dumps(ba["roofline"])[:500]); print("ba cpu", json.dumps(ba["cpu_baseline"])[:300])
+print("live", d["live"]["value"], "vio", d["vio_handoff"]["handoff"]["ms_per_frame"], "pcie", d["pcie"]["value"], d["pcie"]["raw_u8"]["value"], "cpu", d["cpu_baseline"]["value"], "trace", d["trace"]["value"], d["trace"]["cpu_baseline"]["value"])
