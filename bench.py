@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true", help="exclude makeImages from the step (track only)")
     ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop_in leg (the reference's own FullSystem all-CPU vs with its hot-path members on libdmvio_hip.so)")
+    ap.add_argument("--dropin-frames", type=int, default=100)
     ap.add_argument("--ba-points", type=int, default=2000)
     ap.add_argument("--ba-iters", type=int, default=300, help="timed GN iterations of the BA leg")
     return ap.parse_args()
@@ -451,8 +453,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_ba:
         vio_out = bench_vio(args, pkg, ctx, trk, raw, case, w, h)
 
+    # ---------------- drop-in leg (rank 0, N = 1): the reference's own FullSystem::addActiveFrame over a synthetic sequence, all-CPU and HIP-backed
+    dropin_out = None
+    if rank == 0 and world == 1 and not args.no_ba and not args.no_cpu and not args.no_dropin and not args.traffic_child:
+        try:
+            dropin_out = bench_dropin(args, w, h)
+        except Exception as ex:
+            dropin_out = dict(error="%s: %s" % (type(ex).__name__, ex))
+
     if rank == 0:
-        out.update(ba=ba_out, trace=trace_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
+        out.update(ba=ba_out, trace=trace_out, drop_in=dropin_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
         emit(json.dumps(out))
     if world > 1:
         signal.alarm(0)
@@ -955,6 +965,62 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         comm.close()
     ctx.close()
     return out
+
+
+def bench_dropin(args, w, h):
+    """the reference's OWN FullSystem (oracle/_ref/libref.so: its sources compiled unmodified) run over one synthetic sequence in child processes —
+    all-CPU, and with the seven hot-path members (FrameHessian::makeImages, CoarseTracker::setCoarseTrackingRef / trackNewestCoarse, FullSystem::traceNewCoarse /
+    activatePointsMT_Reductor / optimize, CoarseInitializer::calcResAndGS) re-defined on top of libdmvio_hip.so by the compiled INTEGRATION.md adapter
+    (oracle/_ref/libdropin_hip.so, tests/dropin/).  Wall clock = the loop of addActiveFrame calls alone (sequence rendered before, recording of the run switched off)."""
+    import subprocess
+    import tempfile
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not (os.path.exists(os.path.join(ref_dir, "libref.so")) and os.path.exists(os.path.join(ref_dir, "libdropin_hip.so"))):
+        return dict(error="oracle/_ref/libref.so / libdropin_hip.so not built (they are built where /root/reference exists and travel with the tree)")
+    tmp = tempfile.mkdtemp(prefix="dmvio_dropin_")
+    seq = ["--w", str(w), "--h", str(h), "--frames", str(args.dropin_frames), "--step", "1.6", "--density", "2000", "--cache", tmp, "--scopes"]
+
+    def run(name, *extra):
+        outp = os.path.join(tmp, name + ".npz")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin", "run_dropin.py"), "--out", outp] + seq + list(extra), capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("run_dropin %s failed: %s" % (name, (r.stdout + r.stderr)[-400:]))
+        return np.load(outp)
+
+    def scopes(z, names):
+        t = dict(zip(map(str, z["scope_labels"]), z["scope_seconds"]))
+        return {k: round(float(t.get(k, 0.0)), 4) for k in names}
+    cpu_mt = run("cpu_mt", "--mode", "cpu", "--init", "ref", "--mt")     # the reference as it ships: multiThreading = true (6 workers), its own initialiser
+    cpu_st = run("cpu_st", "--mode", "cpu", "--init", "seq")             # deterministic single-threaded baseline (the trajectory the HIP-backed run is compared with)
+    hip = run("hip", "--mode", "hip", "--init", "hip")
+    v = (cpu_st["valid"] != 0) & (hip["valid"] != 0)
+    d = cpu_st["camToWorld"][v, :3] - hip["camToWorld"][v, :3]
+    v2 = (cpu_st["valid"] != 0) & (cpu_mt["valid"] != 0)
+    d2 = cpu_st["camToWorld"][v2, :3] - cpu_mt["camToWorld"][v2, :3]
+    names = ["InitializerOtherFrames", "initObjectsAndMakeImage", "fullCoarseTracking", "traceNewCoarse", "FullSystemOptimize", "makeKeyframe", "makeNewTraces", "activatePointsMT",
+             "marginalizeAndRemovePoints"]
+    n_init = int(np.argmax(hip["initialized"] != 0)) + 1 if (hip["initialized"] != 0).any() else 0
+
+    def steady(z):   # seconds per frame once the initialiser has handed over: everything outside the initialiser's scopes
+        t = dict(zip(map(str, z["scope_labels"]), z["scope_seconds"]))
+        n = len(z["valid"]) - n_init
+        return (float(z["wall_s"][0]) - t.get("InitializerOtherFrames", 0.0) - t.get("InitializerFirstFrame", 0.0)) / max(n, 1)
+    return dict(what="the reference's own FullSystem::addActiveFrame over %d synthetic %dx%d frames (~2000 active points, 7-keyframe window, visual-only, linearizeOperation): "
+                     "all-CPU vs its seven hot-path members on libdmvio_hip.so through the compiled adapter (tests/dropin/dmvio_hip_adapter.cpp, ELF interposition in front of "
+                     "oracle/_ref/libref.so)" % (len(hip["valid"]), w, h),
+                frames=int(len(hip["valid"])), keyframe_optimisations=int(hip["stat_calls"][4]),
+                all_cpu_s=round(float(cpu_mt["wall_s"][0]), 3), all_cpu_single_threaded_s=round(float(cpu_st["wall_s"][0]), 3), hip_backed_s=round(float(hip["wall_s"][0]), 3),
+                speedup_vs_reference_default=round(float(cpu_mt["wall_s"][0]) / float(hip["wall_s"][0]), 2),
+                ms_per_frame_after_initialisation=dict(all_cpu=round(1e3 * steady(cpu_mt), 3), all_cpu_single_threaded=round(1e3 * steady(cpu_st), 3), hip_backed=round(1e3 * steady(hip), 3)),
+                traj_rmse_m=float(np.sqrt((d ** 2).sum(1).mean())), traj_max_m=float(np.abs(d).max()),
+                reference_own_spread_rmse_m=float(np.sqrt((d2 ** 2).sum(1).mean())),
+                adapter_failures=int(hip["failures"][0]), lost=bool(hip["lost"][-1]),
+                seconds_in_replaced_members=dict(zip(["makeImages", "setCoarseTrackingRef", "trackNewestCoarse", "traceNewCoarse", "optimize", "activatePoints", "calcResAndGS"],
+                                                     [round(float(x), 4) for x in hip["stat_seconds"]])),
+                scopes_all_cpu=scopes(cpu_mt, names), scopes_hip_backed=scopes(hip, names),
+                note="all_cpu_s: multiThreading = true and the reference's own thread-pooled initialiser (settings.cpp defaults), %d host threads available; all_cpu_single_threaded_s: "
+                     "multiThreading = false with the oracle's sequential CoarseInitializer::calcResAndGS (bit-reproducible: the trajectory baseline); reference_own_spread = "
+                     "those two all-CPU runs against each other; scopes = inclusive seconds under the reference's own util/TimeMeasurement labels" % (os.cpu_count() or 0))
 
 
 def _cpu_name():

@@ -145,6 +145,7 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipFree(c->fs.build_gen);
   hipFree(c->fs.lvl0);
   hipFree(c->d_upload);
+  c->bounce.release();
   hipFree(c->d_f3);
   hipFree(c->d_slots);
   if (c->h_slots) hipHostFree(c->h_slots);
@@ -189,9 +190,9 @@ int dmvio_hip_frame_upload(dmvio_hip_ctx* c, int slot, const float* host) {
   if (slot < 0 || slot >= c->n_slots) return failmsg("frame_upload: slot out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipMemcpyAsync(c->d_upload, host, sizeof(float) * c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c->bounce.h2d(c->d_upload, host, sizeof(float) * c->w * c->h, c->stream));   // a pageable 1 MB source costs ~0.27 ms per copy, a memcpy + a pinned copy ~0.07 ms
   if (int r = buildPyramid(c, slot, c->d_upload)) return r;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   return 0;
 }
 
@@ -264,8 +265,8 @@ int dmvio_hip_frame_upload_raw(dmvio_hip_ctx* c, dmvio_hip_undistorter* u, int s
   else hipLaunchKernelGGL((k_undistort<unsigned short>), dim3((nOut + 255) / 256), dim3(256), 0, c->stream, (const unsigned short*)u->d_raw, U, c->d_upload);
   HIPCHK(hipGetLastError());
   if (int r = buildPyramid(c, slot, c->d_upload)) return r;
-  if (undistorted_out) HIPCHK(hipMemcpyAsync(undistorted_out, c->d_upload, sizeof(float) * nOut, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (undistorted_out) HIPCHK(c->bounce.d2h(undistorted_out, c->d_upload, sizeof(float) * nOut, c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   return 0;
 }
 
@@ -361,8 +362,8 @@ int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
   const int n = c->wl[lvl] * c->hl[lvl];
   hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, c->d_f3, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.d2h(out, c->d_f3, sizeof(float) * 3 * n, c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   return 0;
 }
 
@@ -378,17 +379,17 @@ int dmvio_hip_frame_abs_squared_grad(dmvio_hip_ctx* c, int slot, int n_levels, c
   if ((size_t)256 + (size_t)c->wl[0] * c->hl[0] * 4 / 3 + 16 > (size_t)3 * c->wl[0] * c->hl[0]) return failmsg("frame_abs_squared_grad: frame too small");
   if (B_lut256) {
     d_lut = c->d_f3;
-    HIPCHK(hipMemcpyAsync(d_lut, B_lut256, sizeof(float) * 256, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c->bounce.h2d(d_lut, B_lut256, sizeof(float) * 256, c->stream));
   }
   size_t off = 0;
   for (int l = 0; l < n_levels; l++) {
     const int n = c->wl[l] * c->hl[l];
     hipLaunchKernelGGL(k_abs_squared_grad, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, l), c->wl[l], c->hl[l], (const float*)d_lut, d_out + off);
-    if (out_host[l]) HIPCHK(hipMemcpyAsync(out_host[l], d_out + off, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_host[l]) HIPCHK(c->bounce.d2h(out_host[l], d_out + off, sizeof(float) * n, c->stream));
     off += n;
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   return 0;
 }
 
@@ -519,10 +520,10 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
   HIPCHK(hipMemsetAsync(t->d_idp, 0, sizeof(float) * R.w[0] * R.h[0], s));
   HIPCHK(hipMemsetAsync(t->d_wsp, 0, sizeof(float) * R.w[0] * R.h[0], s));
   if (n > 0) {
-    HIPCHK(hipMemcpyAsync(t->d_pts + 0 * (size_t)t->pts_cap, u, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(t->d_pts + 1 * (size_t)t->pts_cap, v, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(t->d_pts + 2 * (size_t)t->pts_cap, idepth, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(t->d_pts + 3 * (size_t)t->pts_cap, hdiF, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(c->bounce.h2d(t->d_pts + 0 * (size_t)t->pts_cap, u, sizeof(float) * n, s));      // through the library's pinned memory (internal.h: DmvBounce)
+    HIPCHK(c->bounce.h2d(t->d_pts + 1 * (size_t)t->pts_cap, v, sizeof(float) * n, s));
+    HIPCHK(c->bounce.h2d(t->d_pts + 2 * (size_t)t->pts_cap, idepth, sizeof(float) * n, s));
+    HIPCHK(c->bounce.h2d(t->d_pts + 3 * (size_t)t->pts_cap, hdiF, sizeof(float) * n, s));
     // rank of every point among the points of its pixel (index order), by open addressing on the host: pixels with more than two points are scattered
     // rank by rank (k_ref_scatter)
     int maxRank = 0;
@@ -544,7 +545,7 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
     }
     const unsigned char* d_rank = nullptr;
     if (maxRank >= 2) {
-      HIPCHK(hipMemcpyAsync(t->d_pts + 4 * (size_t)t->pts_cap, t->h_rank.data(), (size_t)n, hipMemcpyHostToDevice, s));
+      HIPCHK(c->bounce.h2d(t->d_pts + 4 * (size_t)t->pts_cap, t->h_rank.data(), (size_t)n, s));
       d_rank = (const unsigned char*)(t->d_pts + 4 * (size_t)t->pts_cap);
     }
     for (int r = 1; r <= std::max(maxRank, 1); r++)
@@ -563,8 +564,8 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
                      t->d_dense, t->d_flow_mask);
   HIPCHK(hipGetLastError());
   int pcn[DMV_MAX_LEVELS] = {};
-  HIPCHK(hipMemcpyAsync(pcn, t->d_pc_n, sizeof(int) * R.levels, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(c->bounce.d2h(pcn, t->d_pc_n, sizeof(int) * R.levels, s));
+  HIPCHK(c->bounce.finish(s));
   for (int l = 0; l < R.levels; l++) { t->dev.pc_n[l] = pcn[l]; t->dev.pc[l] = t->d_pc[l]; }
   t->dev.ref_exposure = ref_exposure; t->dev.ref_aff_a = aff_a; t->dev.ref_aff_b = aff_b;
   t->haveRef = true;

@@ -65,6 +65,7 @@ struct dmvio_hip_ba {
   bool own_stream = false;
   std::mutex mu;
   dmvio_hip_ctx* ctx = nullptr;
+  DmvBounce bounce;   // caller-owned arrays (and this file's short-lived host vectors) cross PCIe through the library's pinned memory (internal.h), on `stream`, under `mu`
   BAHost H;
   BAWindow W{};
   BAPoints P{};
@@ -191,6 +192,7 @@ static void freeAll(dmvio_hip_ba* b) {
   freeDevice(b);
   for (auto& ch : b->arena.chunks) hipFree(ch.first);
   b->arena.chunks.clear(); b->arena.cur = b->arena.off = 0;
+  b->bounce.release();
   if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
   if (b->h_res) { hipHostFree(b->h_res); b->h_res = nullptr; }
@@ -711,9 +713,9 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   // deltas at the current state (EnergyFunctional::setDeltaF, EnergyFunctional.cpp:175-198)
   std::vector<float> adHT;
   H.adHTdeltaF(adHT);
-  HIPCHK(hipMemcpyAsync(b->d_cand, candidates, N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));   // adHT is local
+  HIPCHK(b->bounce.h2d(b->d_cand, candidates, N, s));
+  HIPCHK(b->bounce.h2d(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), s));
+  // (adHT is staged in the pinned bounce: no wait)
   if (int r = uploadWindowTables(b)) return r;
   if (int r = uploadThresholds(b)) return r;
   {
@@ -735,8 +737,8 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   if (int r = accumulateViews(b, RsV, PV)) return r;
   const int nres = H.resInA;
   H.resInA = resInA_keep;
-  HIPCHK(hipMemcpyAsync(decision, b->d_decision, N, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(b->bounce.d2h(decision, b->d_decision, N, s));
+  HIPCHK(b->bounce.finish(s));
   const double* M = b->h_sys; const double* Mb = M + (size_t)n * n; const double* Msc = Mb + n; const double* Mbsc = Msc + (size_t)n * n;
   if (H.HM.size() != (size_t)n * n) { H.HM.assign((size_t)n * n, 0.0); H.bM.assign(n, 0.0); }
   for (size_t k = 0; k < (size_t)n * n; k++) { const double v = setting_margWeightFac * (M[k] - Msc[k]); if (Hadd) Hadd[k] = v; if (update_prior) H.HM[k] += v; }
@@ -817,25 +819,25 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   std::vector<float> prior(N, 0.0f);
   if (hasDepthPrior) for (int p = 0; p < N; p++) prior[p] = hasDepthPrior[p] ? H.S.idepthFixPrior : 0.0f;   // EFPoint::takeData
   hipStream_t s = b->stream;
-  HIPCHK(hipMemcpyAsync(d_host, host, sizeof(int) * N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_point, res_point, sizeof(int) * R, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_target, res_target, sizeof(int) * R, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_u, u, sizeof(float) * N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_v, v, sizeof(float) * N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_color, color8, sizeof(float) * N * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_weights, weights8, sizeof(float) * N * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(d_prior, prior.data(), sizeof(float) * N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(P.idepth, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(P.idepth_zero, idepth, sizeof(float) * N, hipMemcpyHostToDevice, s));
+  HIPCHK(b->bounce.h2d(d_host, host, sizeof(int) * N, s));
+  HIPCHK(b->bounce.h2d(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), s));
+  HIPCHK(b->bounce.h2d(d_point, res_point, sizeof(int) * R, s));
+  HIPCHK(b->bounce.h2d(d_target, res_target, sizeof(int) * R, s));
+  HIPCHK(b->bounce.h2d(d_u, u, sizeof(float) * N, s));
+  HIPCHK(b->bounce.h2d(d_v, v, sizeof(float) * N, s));
+  HIPCHK(b->bounce.h2d(d_color, color8, sizeof(float) * N * 8, s));
+  HIPCHK(b->bounce.h2d(d_weights, weights8, sizeof(float) * N * 8, s));
+  HIPCHK(b->bounce.h2d(d_prior, prior.data(), sizeof(float) * N, s));
+  HIPCHK(b->bounce.h2d(P.idepth, idepth, sizeof(float) * N, s));
+  HIPCHK(b->bounce.h2d(P.idepth_zero, idepth, sizeof(float) * N, s));
   b->pre_half = 0;
   if (dalloc(b, &b->d_pre2, 2 * (size_t)F2) || dalloc(b, &b->d_adHost, (size_t)F2 * 64) || dalloc(b, &b->d_adTarget, (size_t)F2 * 64) || dalloc(b, &b->d_top_begin, F2 + 1) ||
       dalloc(b, &b->d_top_members, R) || dalloc(b, &b->d_scd_begin, F2 * F + 1) || dalloc(b, &b->d_scd_members, 3 * npairs) || dalloc(b, &b->d_accTop, (size_t)F2 * 96 * b->nsTop) ||
       dalloc(b, &b->d_accD, (size_t)F2 * F * 64 * b->nsD) || dalloc(b, &b->d_accE, (size_t)F2 * 40 * b->nsTop) || dalloc(b, &b->d_accC, 20 * b->nsC) || dalloc(b, &b->d_numTop, F2 * b->nsTop) || dalloc(b, &b->d_numD, F2 * F * b->nsD)) return -1;
-  HIPCHK(hipMemcpyAsync(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(b->d_top_members, top_members.data(), sizeof(int) * R, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, hipMemcpyHostToDevice, s));
+  HIPCHK(b->bounce.h2d(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), s));
+  HIPCHK(b->bounce.h2d(b->d_top_members, top_members.data(), sizeof(int) * R, s));
+  HIPCHK(b->bounce.h2d(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), s));
+  HIPCHK(b->bounce.h2d(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, s));
   StitchBufs& SB = b->SB;
   if (dalloc(b, &SB.topHH, (size_t)F * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F * 32) ||
       dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.topCC, (size_t)F * 20) ||
@@ -912,20 +914,20 @@ int dmvio_hip_ba_get_res_state(dmvio_hip_ba* b, unsigned char* newState, float* 
   BA_READY(b);
   hipStream_t s = b->stream;
   const int R = b->H.R;
-  if (newState) HIPCHK(hipMemcpyAsync(newState, b->Rs.newState, R, hipMemcpyDeviceToHost, s));
-  if (newEnergy) HIPCHK(hipMemcpyAsync(newEnergy, b->Rs.newEnergy, sizeof(float) * R, hipMemcpyDeviceToHost, s));
-  if (active) HIPCHK(hipMemcpyAsync(active, b->Rs.active, R, hipMemcpyDeviceToHost, s));
-  if (center3) HIPCHK(hipMemcpyAsync(center3, b->Rs.center, sizeof(float) * 3 * R, hipMemcpyDeviceToHost, s));
-  if (newEnergyWO) HIPCHK(hipMemcpyAsync(newEnergyWO, b->d_newEnergyWO, sizeof(float) * R, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (newState) HIPCHK(b->bounce.d2h(newState, b->Rs.newState, R, s));
+  if (newEnergy) HIPCHK(b->bounce.d2h(newEnergy, b->Rs.newEnergy, sizeof(float) * R, s));
+  if (active) HIPCHK(b->bounce.d2h(active, b->Rs.active, R, s));
+  if (center3) HIPCHK(b->bounce.d2h(center3, b->Rs.center, sizeof(float) * 3 * R, s));
+  if (newEnergyWO) HIPCHK(b->bounce.d2h(newEnergyWO, b->d_newEnergyWO, sizeof(float) * R, s));
+  HIPCHK(b->bounce.finish(s));
   return 0;
 }
 // RawResidualJacobian of the LAST linearisation (74 floats per residual, RawResidualJacobian.h:32-61 order) — parity/debug
 int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
   BA_READY(b);
   if (!b->keep_fullJ) return failmsg("ba_get_jacobians: call dmvio_hip_ba_keep_jacobians(ba, 1) before the linearisation");
-  HIPCHK(hipMemcpyAsync(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(b->bounce.d2h(J74, b->d_fullJ, sizeof(float) * 74 * b->H.R, b->stream));
+  HIPCHK(b->bounce.finish(b->stream));
   return 0;
 }
 int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
@@ -950,12 +952,12 @@ int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hc
   BA_READY(b);
   hipStream_t s = b->stream;
   const int N = b->H.N;
-  if (Hdd) HIPCHK(hipMemcpyAsync(Hdd, b->P.Hdd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
-  if (bd) HIPCHK(hipMemcpyAsync(bd, b->P.bd, sizeof(float) * N, hipMemcpyDeviceToHost, s));
-  if (Hcd4) HIPCHK(hipMemcpyAsync(Hcd4, b->P.Hcd, sizeof(float) * 4 * N, hipMemcpyDeviceToHost, s));
-  if (HdiF) HIPCHK(hipMemcpyAsync(HdiF, b->P.HdiF, sizeof(float) * N, hipMemcpyDeviceToHost, s));
-  if (bdSumF) HIPCHK(hipMemcpyAsync(bdSumF, b->P.bdSumF, sizeof(float) * N, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (Hdd) HIPCHK(b->bounce.d2h(Hdd, b->P.Hdd, sizeof(float) * N, s));
+  if (bd) HIPCHK(b->bounce.d2h(bd, b->P.bd, sizeof(float) * N, s));
+  if (Hcd4) HIPCHK(b->bounce.d2h(Hcd4, b->P.Hcd, sizeof(float) * 4 * N, s));
+  if (HdiF) HIPCHK(b->bounce.d2h(HdiF, b->P.HdiF, sizeof(float) * N, s));
+  if (bdSumF) HIPCHK(b->bounce.d2h(bdSumF, b->P.bdSumF, sizeof(float) * N, s));
+  HIPCHK(b->bounce.finish(s));
   return 0;
 }
 // EnergyFunctional::solveSystemF: accumulate on the device, solve on the host (the hand-off point of
@@ -980,16 +982,16 @@ int dmvio_hip_ba_resubstitute(dmvio_hip_ba* b, const double* x) {
 int dmvio_hip_ba_get_point_hessian(dmvio_hip_ba* b, float* idepth_hessian) {
   if (!b || !b->graph_ready || !idepth_hessian) return failmsg("ba_get_point_hessian: bad argument");   // a pure read: the loop state (sys_ready) is left alone
   HIPCHK(hipSetDevice(b->ctx->device));
-  HIPCHK(hipMemcpyAsync(idepth_hessian, b->P.idepth_hessian, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(b->bounce.d2h(idepth_hessian, b->P.idepth_hessian, sizeof(float) * b->H.N, b->stream));
+  HIPCHK(b->bounce.finish(b->stream));
   return 0;
 }
 int dmvio_hip_ba_get_points(dmvio_hip_ba* b, float* idepth, float* step) {
   BA_READY(b);
   hipStream_t s = b->stream;
-  if (idepth) HIPCHK(hipMemcpyAsync(idepth, b->P.idepth, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
-  if (step) HIPCHK(hipMemcpyAsync(step, b->P.step, sizeof(float) * b->H.N, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (idepth) HIPCHK(b->bounce.d2h(idepth, b->P.idepth, sizeof(float) * b->H.N, s));
+  if (step) HIPCHK(b->bounce.d2h(step, b->P.step, sizeof(float) * b->H.N, s));
+  HIPCHK(b->bounce.finish(s));
   return 0;
 }
 int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double aff[2], double state10[10]) {
@@ -1348,8 +1350,8 @@ int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float
   if (int r = linearizeAll(b, fix != 0, &e, 0, true)) return r;   // the threshold is set by the caller from the energies gathered over all shards
   if (energy) *energy = e;
   std::vector<float> wo(b->H.R);
-  if (b->H.R) HIPCHK(hipMemcpyAsync(wo.data(), b->d_newEnergyWO, sizeof(float) * b->H.R, hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->H.R) HIPCHK(b->bounce.d2h(wo.data(), b->d_newEnergyWO, sizeof(float) * b->H.R, b->stream));
+  HIPCHK(b->bounce.finish(b->stream));
   int n = 0;
   for (int ri : b->h_newest)
     if (wo[ri] >= 0) { if (new_frame_energies) new_frame_energies[n] = wo[ri]; n++; }

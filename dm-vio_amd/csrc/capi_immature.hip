@@ -23,6 +23,7 @@ struct dmvio_hip_immature {
   int *d_result = nullptr, *d_res_state = nullptr;
   float* d_idepth = nullptr;
   unsigned char* d_select = nullptr;
+  DmvBounce bounce;            // caller-owned arrays cross PCIe through the library's pinned memory (internal.h)
   std::vector<void*> allocs;
 };
 
@@ -69,6 +70,7 @@ void dmvio_hip_immature_destroy(dmvio_hip_immature* m) {
   if (m->h_tables) hipHostFree(m->h_tables);
   if (m->h_counts) hipHostFree(m->h_counts);
   if (m->h_opt_tables) hipHostFree(m->h_opt_tables);
+  m->bounce.release();
   delete m;
 }
 int dmvio_hip_immature_clear(dmvio_hip_immature* m) { IMM_READY(m); m->n = 0; m->max_tag = -1; return 0; }
@@ -86,11 +88,16 @@ int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_
     if (u[i] < 2 || v[i] < 2 || u[i] + 3 >= c->w || v[i] + 3 >= c->h) return failmsg("immature_add_points: point closer than 3 px to the border");
   if (n == 0) return m->n;
   const int first = m->n;
-  std::vector<float> uf(n), vf(n);
-  for (int i = 0; i < n; i++) { uf[i] = (float)u[i]; vf[i] = (float)v[i]; }
-  HIPCHK(hipMemcpyAsync(m->P.u + first, uf.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(m->P.v + first, vf.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));   // uf / vf are local
+  {
+    // the integer pixel positions become the float arrays the kernels read, written straight into the pinned staging memory (no wait: the copies are ordered before the
+    // constructor kernel on the stream, and the staging area is not reused before the next synchronisation)
+    size_t offu, offv;
+    HIPCHK(m->bounce.reserve(sizeof(float) * n, c->stream, &offu)); HIPCHK(m->bounce.reserve(sizeof(float) * n, c->stream, &offv));
+    float* uf = reinterpret_cast<float*>(m->bounce.h + offu); float* vf = reinterpret_cast<float*>(m->bounce.h + offv);
+    for (int i = 0; i < n; i++) { uf[i] = (float)u[i]; vf[i] = (float)v[i]; }
+    HIPCHK(hipMemcpyAsync(m->P.u + first, uf, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(m->P.v + first, vf, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  }
   m->P.n = first + n;
   hipLaunchKernelGGL(k_immature_init, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(host_slot, 0), c->w, first, n, m->P, host_tag, m->S);
   HIPCHK(hipGetLastError());
@@ -103,14 +110,14 @@ int dmvio_hip_immature_get_static(dmvio_hip_immature* m, float* u, float* v, int
   IMM_READY(m);
   hipStream_t s = m->ctx->stream;
   const size_t n = m->n;
-  if (u) HIPCHK(hipMemcpyAsync(u, m->P.u, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (v) HIPCHK(hipMemcpyAsync(v, m->P.v, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (host_tag) HIPCHK(hipMemcpyAsync(host_tag, m->P.host, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-  if (color8) HIPCHK(hipMemcpyAsync(color8, m->P.color, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, s));
-  if (weights8) HIPCHK(hipMemcpyAsync(weights8, m->P.weights, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, s));
-  if (gradH4) HIPCHK(hipMemcpyAsync(gradH4, m->P.gradH, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, s));
-  if (energyTH) HIPCHK(hipMemcpyAsync(energyTH, m->P.energyTH, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (u) HIPCHK(m->bounce.d2h(u, m->P.u, sizeof(float) * n, s));
+  if (v) HIPCHK(m->bounce.d2h(v, m->P.v, sizeof(float) * n, s));
+  if (host_tag) HIPCHK(m->bounce.d2h(host_tag, m->P.host, sizeof(int) * n, s));
+  if (color8) HIPCHK(m->bounce.d2h(color8, m->P.color, sizeof(float) * 8 * n, s));
+  if (weights8) HIPCHK(m->bounce.d2h(weights8, m->P.weights, sizeof(float) * 8 * n, s));
+  if (gradH4) HIPCHK(m->bounce.d2h(gradH4, m->P.gradH, sizeof(float) * 4 * n, s));
+  if (energyTH) HIPCHK(m->bounce.d2h(energyTH, m->P.energyTH, sizeof(float) * n, s));
+  HIPCHK(m->bounce.finish(s));
   return 0;
 }
 int dmvio_hip_immature_get_state(dmvio_hip_immature* m, float* idepth_min, float* idepth_max, float* quality, float* lastTraceUV2, float* lastTracePixelInterval,
@@ -118,24 +125,24 @@ int dmvio_hip_immature_get_state(dmvio_hip_immature* m, float* idepth_min, float
   IMM_READY(m);
   hipStream_t s = m->ctx->stream;
   const size_t n = m->n;
-  if (idepth_min) HIPCHK(hipMemcpyAsync(idepth_min, m->P.idepth_min, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (idepth_max) HIPCHK(hipMemcpyAsync(idepth_max, m->P.idepth_max, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (quality) HIPCHK(hipMemcpyAsync(quality, m->P.quality, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (lastTraceUV2) HIPCHK(hipMemcpyAsync(lastTraceUV2, m->P.lastTraceUV, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
-  if (lastTracePixelInterval) HIPCHK(hipMemcpyAsync(lastTracePixelInterval, m->P.lastTracePixelInterval, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (lastTraceStatus) HIPCHK(hipMemcpyAsync(lastTraceStatus, m->P.lastTraceStatus, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (idepth_min) HIPCHK(m->bounce.d2h(idepth_min, m->P.idepth_min, sizeof(float) * n, s));
+  if (idepth_max) HIPCHK(m->bounce.d2h(idepth_max, m->P.idepth_max, sizeof(float) * n, s));
+  if (quality) HIPCHK(m->bounce.d2h(quality, m->P.quality, sizeof(float) * n, s));
+  if (lastTraceUV2) HIPCHK(m->bounce.d2h(lastTraceUV2, m->P.lastTraceUV, sizeof(float) * 2 * n, s));
+  if (lastTracePixelInterval) HIPCHK(m->bounce.d2h(lastTracePixelInterval, m->P.lastTracePixelInterval, sizeof(float) * n, s));
+  if (lastTraceStatus) HIPCHK(m->bounce.d2h(lastTraceStatus, m->P.lastTraceStatus, sizeof(int) * n, s));
+  HIPCHK(m->bounce.finish(s));
   return 0;
 }
 int dmvio_hip_immature_set_state(dmvio_hip_immature* m, const float* idepth_min, const float* idepth_max, const float* quality, const int* lastTraceStatus) {
   IMM_READY(m);
   hipStream_t s = m->ctx->stream;
   const size_t n = m->n;
-  if (idepth_min) HIPCHK(hipMemcpyAsync(m->P.idepth_min, idepth_min, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  if (idepth_max) HIPCHK(hipMemcpyAsync(m->P.idepth_max, idepth_max, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  if (quality) HIPCHK(hipMemcpyAsync(m->P.quality, quality, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  if (lastTraceStatus) HIPCHK(hipMemcpyAsync(m->P.lastTraceStatus, lastTraceStatus, sizeof(int) * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (idepth_min) HIPCHK(m->bounce.h2d(m->P.idepth_min, idepth_min, sizeof(float) * n, s));
+  if (idepth_max) HIPCHK(m->bounce.h2d(m->P.idepth_max, idepth_max, sizeof(float) * n, s));
+  if (quality) HIPCHK(m->bounce.h2d(m->P.quality, quality, sizeof(float) * n, s));
+  if (lastTraceStatus) HIPCHK(m->bounce.h2d(m->P.lastTraceStatus, lastTraceStatus, sizeof(int) * n, s));
+  HIPCHK(m->bounce.finish(s));
   return 0;
 }
 
@@ -254,15 +261,15 @@ int dmvio_hip_immature_optimize(dmvio_hip_immature* m, int F, const int* frame_s
   T.R = m->d_opt_tables; T.t = m->d_opt_tables + 9 * 64; T.aff = m->d_opt_tables + 12 * 64;
   T.fxl = (float)fxfycxcy[0]; T.fyl = (float)fxfycxcy[1]; T.cxl = (float)fxfycxcy[2]; T.cyl = (float)fxfycxcy[3];
   T.fxli = 1.0f / T.fxl; T.fyli = 1.0f / T.fyl;   // CalibHessian::setValueScaled (HessianBlocks.h:373-387)
-  if (select) HIPCHK(hipMemcpyAsync(m->d_select, select, m->n, hipMemcpyHostToDevice, c->stream));
+  if (select) HIPCHK(m->bounce.h2d(m->d_select, select, m->n, c->stream));
   m->P.n = m->n;
   hipLaunchKernelGGL(k_immature_optimize, dim3((m->n + 3) / 4), dim3(256), 0, c->stream, c->fs, c->w, c->h, m->P, T, select ? m->d_select : nullptr, minObs,
                      100.0f /* setting_minIdepthH_act */, 3 /* setting_GNItsOnPointActivation */, m->S.huberTH, m->d_result, m->d_idepth, m->d_res_state);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(result, m->d_result, sizeof(int) * m->n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(idepth, m->d_idepth, sizeof(float) * m->n, hipMemcpyDeviceToHost, c->stream));
-  if (res_state) HIPCHK(hipMemcpyAsync(res_state, m->d_res_state, sizeof(int) * (size_t)m->n * F, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(m->bounce.d2h(result, m->d_result, sizeof(int) * m->n, c->stream));
+  HIPCHK(m->bounce.d2h(idepth, m->d_idepth, sizeof(float) * m->n, c->stream));
+  if (res_state) HIPCHK(m->bounce.d2h(res_state, m->d_res_state, sizeof(int) * (size_t)m->n * F, c->stream));
+  HIPCHK(m->bounce.finish(c->stream));
   return 0;
 }
 

@@ -12,12 +12,16 @@ using namespace dmv;
 struct dmvio_hip_initializer {
   dmvio_hip_ctx* ctx = nullptr;
   int capacity = 0, n = 0;
-  float *d_u = nullptr, *d_v = nullptr, *d_idepth_new = nullptr, *d_iR = nullptr, *d_energy = nullptr, *d_outlierTH = nullptr;
-  unsigned char *d_isGood = nullptr, *d_isGood_new = nullptr;
-  float *d_energy_new = nullptr, *d_maxstep = nullptr, *d_lastHessian_new = nullptr, *d_Jb = nullptr;
+  // ONE device slab for the inputs and one for the per-point results, laid out per call for the n points of the level ([u | v | iR | outlierTH | energy(2) | idepth_new | isGood]
+  // and [energy_new(2) | maxstep | lastHessian_new | JbBuffer_new(10) | isGood_new]); each crosses PCIe as ONE copy from / into pinned staging memory — a calcResAndGS call of
+  // the initializer's LM loop is ~15 us of kernels, thirteen separate pageable copies cost ten times that
+  float *d_in = nullptr, *d_res = nullptr, *h_in = nullptr, *h_res = nullptr;
   float *d_partials = nullptr, *d_out = nullptr, *h_out = nullptr;
+  bool upload_pending = false;
   std::vector<void*> allocs;
 };
+static inline size_t padn(int n) { return ((size_t)n + 63) & ~(size_t)63; }   // every array of a slab starts on a 256-byte boundary
+enum { IN_FLOATS = 7, RES_FLOATS = 14 };   // per point, + one byte each (isGood / isGood_new) at the end of the slab
 enum { INIT_MAX_BLOCKS = 256 };
 
 template <class T>
@@ -39,12 +43,15 @@ dmvio_hip_initializer* dmvio_hip_initializer_create(dmvio_hip_ctx* ctx, int capa
   if (hipSetDevice(ctx->device) != hipSuccess) { failmsg("initializer_create: hipSetDevice failed"); return nullptr; }
   dmvio_hip_initializer* m = new dmvio_hip_initializer();
   m->ctx = ctx; m->capacity = capacity;
-  const size_t c = capacity;
-  if (nalloc(m, &m->d_u, c) || nalloc(m, &m->d_v, c) || nalloc(m, &m->d_idepth_new, c) || nalloc(m, &m->d_iR, c) || nalloc(m, &m->d_energy, 2 * c) ||
-      nalloc(m, &m->d_outlierTH, c) || nalloc(m, &m->d_isGood, c) || nalloc(m, &m->d_isGood_new, c) || nalloc(m, &m->d_energy_new, 2 * c) ||
-      nalloc(m, &m->d_maxstep, c) || nalloc(m, &m->d_lastHessian_new, c) || nalloc(m, &m->d_Jb, 10 * c) || nalloc(m, &m->d_partials, (size_t)INIT_MAX_BLOCKS * IN_PART) ||
-      nalloc(m, &m->d_out, IN_PART) || hipHostMalloc((void**)&m->h_out, sizeof(float) * IN_PART, hipHostMallocDefault) != hipSuccess) {
+  const size_t c = padn(capacity);
+  if (nalloc(m, &m->d_in, (IN_FLOATS + 1) * c) || nalloc(m, &m->d_res, (RES_FLOATS + 1) * c) || nalloc(m, &m->d_partials, (size_t)INIT_MAX_BLOCKS * IN_PART) ||
+      nalloc(m, &m->d_out, IN_PART) || hipHostMalloc((void**)&m->h_out, sizeof(float) * IN_PART, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&m->h_in, sizeof(float) * (IN_FLOATS + 1) * c, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&m->h_res, sizeof(float) * (RES_FLOATS + 1) * c, hipHostMallocDefault) != hipSuccess) {
     for (void* p : m->allocs) hipFree(p);
+    if (m->h_out) hipHostFree(m->h_out);
+    if (m->h_in) hipHostFree(m->h_in);
+    if (m->h_res) hipHostFree(m->h_res);
     delete m;
     return nullptr;
   }
@@ -56,6 +63,8 @@ void dmvio_hip_initializer_destroy(dmvio_hip_initializer* m) {
   hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->allocs) hipFree(p);
   if (m->h_out) hipHostFree(m->h_out);
+  if (m->h_in) hipHostFree(m->h_in);
+  if (m->h_res) hipHostFree(m->h_res);
   delete m;
 }
 
@@ -65,13 +74,15 @@ int dmvio_hip_initializer_set_points(dmvio_hip_initializer* m, int n, const floa
   INIT_READY(m);
   if (n < 0 || n > m->capacity || !u || !v || !iR || !isGood || !energy2 || !outlierTH) return failmsg("initializer_set_points: bad argument");
   hipStream_t s = m->ctx->stream;
-  HIPCHK(hipMemcpyAsync(m->d_u, u, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->d_v, v, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->d_iR, iR, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->d_isGood, isGood, n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->d_energy, energy2, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(m->d_outlierTH, outlierTH, sizeof(float) * n, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));
+  if (m->upload_pending) { HIPCHK(hipStreamSynchronize(s)); m->upload_pending = false; }   // the staging buffer is still being read by the previous upload
+  const size_t P = padn(n);
+  memcpy(m->h_in, u, sizeof(float) * n); memcpy(m->h_in + P, v, sizeof(float) * n); memcpy(m->h_in + 2 * P, iR, sizeof(float) * n);
+  memcpy(m->h_in + 3 * P, outlierTH, sizeof(float) * n); memcpy(m->h_in + 4 * P, energy2, sizeof(float) * 2 * n);
+  memcpy(m->h_in + 7 * P, isGood, n);
+  // [u | v | iR | outlierTH | energy] and, behind the gap idepth_new fills per evaluation, isGood: two copies, no wait — the evaluation's own synchronisation covers them
+  HIPCHK(hipMemcpyAsync(m->d_in, m->h_in, sizeof(float) * 6 * P, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(m->d_in + 7 * P, m->h_in + 7 * P, n, hipMemcpyHostToDevice, s));
+  m->upload_pending = true;
   m->n = n;
   return 0;
 }
@@ -107,21 +118,28 @@ int dmvio_hip_initializer_calc_res_and_gs(dmvio_hip_initializer* m, int lvl, int
   if (alphaEnergy > alphaK * n) { alphaOpt = 0; alphaEnergy = alphaK * n; }
   else alphaOpt = alphaW;
   A.alphaOpt = alphaOpt;
-  HIPCHK(hipMemcpyAsync(m->d_idepth_new, idepth_new, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  const size_t PN = padn(n);
+  memcpy(m->h_in + 6 * PN, idepth_new, sizeof(float) * n);
+  HIPCHK(hipMemcpyAsync(m->d_in + 6 * PN, m->h_in + 6 * PN, sizeof(float) * n, hipMemcpyHostToDevice, s));
   InitPts P;
-  P.n = n; P.u = m->d_u; P.v = m->d_v; P.idepth_new = m->d_idepth_new; P.iR = m->d_iR; P.energy = m->d_energy; P.outlierTH = m->d_outlierTH; P.isGood = m->d_isGood;
-  P.energy_new = m->d_energy_new; P.maxstep = m->d_maxstep; P.lastHessian_new = m->d_lastHessian_new; P.JbBuffer_new = m->d_Jb; P.isGood_new = m->d_isGood_new;
+  P.n = n; P.u = m->d_in; P.v = m->d_in + PN; P.iR = m->d_in + 2 * PN; P.outlierTH = m->d_in + 3 * PN; P.energy = m->d_in + 4 * PN; P.idepth_new = m->d_in + 6 * PN;
+  P.isGood = reinterpret_cast<unsigned char*>(m->d_in + 7 * PN);
+  P.energy_new = m->d_res; P.maxstep = m->d_res + 2 * PN; P.lastHessian_new = m->d_res + 3 * PN; P.JbBuffer_new = m->d_res + 4 * PN;
+  P.isGood_new = reinterpret_cast<unsigned char*>(m->d_res + 14 * PN);
   const int G = std::max(1, std::min((int)INIT_MAX_BLOCKS, (n + 255) / 256));
   hipLaunchKernelGGL(k_init_partial, dim3(G), dim3(256), 0, s, c->levelPtr(first_slot, lvl), c->levelPtr(new_slot, lvl), P, A, m->d_partials);
   hipLaunchKernelGGL(k_init_final, dim3(1), dim3(128), 0, s, m->d_partials, G, m->d_out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(m->h_out, m->d_out, sizeof(float) * IN_PART, hipMemcpyDeviceToHost, s));
-  if (energy_new2) HIPCHK(hipMemcpyAsync(energy_new2, m->d_energy_new, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
-  if (isGood_new) HIPCHK(hipMemcpyAsync(isGood_new, m->d_isGood_new, n, hipMemcpyDeviceToHost, s));
-  if (maxstep) HIPCHK(hipMemcpyAsync(maxstep, m->d_maxstep, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (lastHessian_new) HIPCHK(hipMemcpyAsync(lastHessian_new, m->d_lastHessian_new, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  if (JbBuffer_new10) HIPCHK(hipMemcpyAsync(JbBuffer_new10, m->d_Jb, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, s));
+  const bool want = energy_new2 || isGood_new || maxstep || lastHessian_new || JbBuffer_new10;
+  if (want) HIPCHK(hipMemcpyAsync(m->h_res, m->d_res, sizeof(float) * 14 * PN + n, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  m->upload_pending = false;
+  if (energy_new2) memcpy(energy_new2, m->h_res, sizeof(float) * 2 * n);
+  if (maxstep) memcpy(maxstep, m->h_res + 2 * PN, sizeof(float) * n);
+  if (lastHessian_new) memcpy(lastHessian_new, m->h_res + 3 * PN, sizeof(float) * n);
+  if (JbBuffer_new10) memcpy(JbBuffer_new10, m->h_res + 4 * PN, sizeof(float) * 10 * n);
+  if (isGood_new) memcpy(isGood_new, m->h_res + 14 * PN, n);
   // unpack the two upper triangles, then the tail of calcResAndGS (:582-613)
   float M[2][9][9];
   for (int w = 0; w < 2; w++) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -19,6 +20,53 @@ static inline int failmsg(const std::string& m) { dmv_err() = m; return -2; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, __FILE__, __LINE__, _e); } while (0)
 #define HIPCHKP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fail(#x, __FILE__, __LINE__, _e); return nullptr; } } while (0)
 
+// Host <-> device copies of caller-owned arrays go through pinned memory the LIBRARY owns.  Handing a pageable pointer to hipMemcpyAsync makes the runtime pin the caller's pages
+// for larger transfers and keep that registration cached; when the caller later frees the array (the reference deletes a FrameHessian, a std::vector goes out of scope) and the
+// C library returns the pages to the kernel, the MMU notifier evicts the process's GPU queues and the NEXT submission waits 8-20 ms for their restore (measured inside the
+// reference's FullSystem: every frame marginalisation was followed by one such stall in dmvio_hip_frame_upload; GPU_PINNED_MIN_XFER_SIZE=<huge> removes it, as does this).
+// One Bounce per handle (context, tracker, immature set, initializer, window optimiser): h2d() stages the source and enqueues the copy, d2h() enqueues the copy into the
+// bounce and remembers where the caller wants it, finish() waits for the stream and delivers.  Staged sources stay intact until the next finish().
+struct DmvBounce {
+  char* h = nullptr;
+  size_t cap = 0, used = 0;
+  struct Out { void* dst; size_t off, bytes; };
+  std::vector<Out> outs;
+  hipError_t reserve(size_t bytes, hipStream_t s, size_t* off) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (used + need > cap) {
+      if (used || !outs.empty()) { hipError_t e = finish(s); if (e != hipSuccess) return e; }
+      if (need > cap) {
+        if (h) { hipError_t e = hipHostFree(h); h = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        const size_t want = need > ((size_t)4 << 20) ? need + need / 2 : ((size_t)4 << 20);
+        hipError_t e = hipHostMalloc((void**)&h, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        cap = want;
+      }
+    }
+    *off = used; used += need;
+    return hipSuccess;
+  }
+  hipError_t h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    size_t off; hipError_t e = reserve(bytes, s, &off); if (e != hipSuccess) return e;
+    memcpy(h + off, h_src, bytes);
+    return hipMemcpyAsync(d_dst, h + off, bytes, hipMemcpyHostToDevice, s);
+  }
+  hipError_t d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    size_t off; hipError_t e = reserve(bytes, s, &off); if (e != hipSuccess) return e;
+    outs.push_back({h_dst, off, bytes});
+    return hipMemcpyAsync(h + off, d_src, bytes, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t finish(hipStream_t s) {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) for (const Out& o : outs) memcpy(o.dst, h + o.off, o.bytes);
+    outs.clear(); used = 0;
+    return e;
+  }
+  void release() { if (h) hipHostFree(h); h = nullptr; cap = used = 0; outs.clear(); }
+};
+
 struct dmvio_hip_ctx {
   int device = 0, w = 0, h = 0, levels = 0, n_slots = 0;
   hipStream_t stream = nullptr;
@@ -33,6 +81,7 @@ struct dmvio_hip_ctx {
   std::vector<const float*> h_lvl0;   // host mirror of FrameStore::lvl0 (kept by the build entry points)
   const float* levelPtr(int slot, int lvl) const { return lvl == 0 ? h_lvl0[slot] : fs.own_level(slot, lvl); }
   unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)
+  DmvBounce bounce;             // caller-owned arrays cross PCIe through here (used under `mu`)
   std::mutex mu;
 };
 

@@ -28,6 +28,7 @@
 #include <thread>
 #include <unistd.h>
 #include <vector>
+#include <chrono>
 
 // the reference keeps calcRes / calcGSSSE / linearizeAll / ... private; the tests call them one by one
 #define private public
@@ -1303,8 +1304,26 @@ static void snapshotOptimize(RefSystem* S, bool entry)
 	e.i.insert(e.i.begin() + 2, nr);
 	S->events.push_back(e);
 }
+// inclusive wall time per profiler label of the reference (tests/dropin/run_dropin.py --scopes: where an all-CPU and a HIP-backed run of the same FullSystem spend their time)
+struct ScopeTotal { double seconds = 0; long calls = 0; };
+static std::map<std::string, ScopeTotal> g_scopeTotals;
+static std::vector<std::pair<std::string, std::chrono::steady_clock::time_point>> g_scopeStack;
+static bool g_scopeTiming = false;
+static void scopeTime(const char* name, int phase)
+{
+	if (phase > 0) { g_scopeStack.emplace_back(name, std::chrono::steady_clock::now()); return; }
+	for (int i = (int)g_scopeStack.size() - 1; i >= 0; i--)
+		if (g_scopeStack[i].first == name)
+		{
+			ScopeTotal& t = g_scopeTotals[name];
+			t.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - g_scopeStack[i].second).count(); t.calls++;
+			g_scopeStack.erase(g_scopeStack.begin() + i);
+			break;
+		}
+}
 static void scopeHook(const char* name, int phase)
 {
+	if (g_scopeTiming) scopeTime(name, phase);
 	RefSystem* S = g_sys;
 	if (!S || !S->record) return;
 	if (!strcmp(name, "makeKeyframeChangeTrackingRef") && phase > 0) snapshotSetRef(S);
@@ -1374,6 +1393,20 @@ int ref_system_initializer_state(void* p, int lvl, float* idepth, float* iR, uns
 }
 // the FullSystem behind a RefSystem (tests/dropin: the adapter wants to know whose frames its slots belong to)
 void* ref_system_fullsystem(void* p) { return ((RefSystem*)p)->fs; }
+// profiler-scope totals: on = 1 starts collecting (and clears), record = 0 switches the event recording of the run off (its snapshots cost time)
+void ref_system_scope_timing(void* p, int on, int record)
+{
+	g_scopeTiming = on != 0; g_scopeTotals.clear(); g_scopeStack.clear();
+	if (p) ((RefSystem*)p)->record = record != 0;
+}
+// "label seconds calls\n" per line; returns the number of bytes the full table needs
+int ref_system_scope_totals(char* buf, int cap)
+{
+	std::string out;
+	for (auto& kv : g_scopeTotals) { char line[256]; snprintf(line, sizeof(line), "%s %.6f %ld\n", kv.first.c_str(), kv.second.seconds, kv.second.calls); out += line; }
+	if (buf && cap > 0) { int n = std::min((int)out.size(), cap - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
+	return (int)out.size() + 1;
+}
 // FullSystem::addActiveFrame.  status out: [initialized, isLost, initFailed, n keyframes in the window, n frames so far]
 int ref_system_add_frame(void* p, const float* img, float exposure, double timestamp, int id, int* status5, char* log, int logcap)
 {

@@ -32,6 +32,7 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -65,8 +66,8 @@ using namespace dso;
 
 namespace
 {
-enum { N_STATS = 6 };
-struct Stats { double seconds[N_STATS] = {0, 0, 0, 0, 0, 0}; long calls[N_STATS] = {0, 0, 0, 0, 0, 0}; };   // makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor
+enum { N_STATS = 7 };
+struct Stats { double seconds[N_STATS] = {0, 0, 0, 0, 0, 0, 0}; long calls[N_STATS] = {0, 0, 0, 0, 0, 0, 0}; };   // makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor, calcResAndGS
 struct Timer
 {
 	Stats& s; int k; std::chrono::steady_clock::time_point t0;
@@ -85,7 +86,8 @@ struct Backend
 	std::map<const FrameHessian*, int> slotOf;
 	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
 	FullSystem* fs = nullptr;      // learnt from the first FullSystem member that comes by
-	std::map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
+	double opt_split[3] = {0, 0, 0};   // FullSystem::optimize member: flatten + upload, dmvio_hip_ba_optimize, write-back (seconds)
+	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
 	// CoarseInitializer.cpp:507 / util/IndexThreadReduce.h:83-87 — the sums, and with them everything downstream, vary in the last bits from run to run);
 	// 1 = the oracle's single-threaded restatement (oracle/init_oracle.cpp, per-point bit-identical to the reference: the sums one worker taking every chunk would form)
@@ -247,7 +249,8 @@ int dropin_is_on() { return g.on ? 1 : 0; }
 // the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
 void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
 // seconds[6], calls[6] in the order makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor — counted in both modes
-void dropin_get_stats(double* seconds6, long* calls6) { for (int k = 0; k < N_STATS; k++) { seconds6[k] = g.stats.seconds[k]; calls6[k] = g.stats.calls[k]; } }
+void dropin_get_optimize_split(double* out3) { for (int k = 0; k < 3; k++) out3[k] = g.opt_split[k]; }
+void dropin_get_stats(double* seconds7, long* calls7) { for (int k = 0; k < N_STATS; k++) { seconds7[k] = g.stats.seconds[k]; calls7[k] = g.stats.calls[k]; } }
 void dropin_reset_stats() { g.stats = Stats(); }
 long dropin_failures(char* msg, int cap) { if (msg && cap > 0) { strncpy(msg, g.error, cap - 1); msg[cap - 1] = 0; } return g.failures; }
 }
@@ -262,10 +265,17 @@ void FrameHessian::makeImages(float* color, CalibHessian* HCalib)
 	typedef void (*Fn)(FrameHessian*, float*, CalibHessian*);
 	static Fn orig = original<Fn>("_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE");
 	Timer tm(g.stats, 0);
+	const auto tq0 = std::chrono::steady_clock::now();
 	orig(this, color, HCalib);   // dIp / absSquaredGrad for the parts of the pipeline that stay on the CPU (see the header comment)
 	if (!g.on) return;
+	const auto tq1 = std::chrono::steady_clock::now();
 	const int slot = acquireSlot(this);
+	if (getenv("DROPIN_DEBUG_TIMING")) { typedef int (*DS)(); static DS ds = (DS)dlsym(RTLD_DEFAULT, "hipDeviceSynchronize"); if (ds) ds(); }
+	const auto tq2 = std::chrono::steady_clock::now();
 	HIP_OK(dmvio_hip_frame_upload(g.ctx, slot, color));
+	const auto tq3 = std::chrono::steady_clock::now();
+	if (getenv("DROPIN_DEBUG_TIMING")) fprintf(stderr, "[dropin] makeImages: host pyramids %.0f us, slot %.0f us, upload %.0f us\n", 1e6 * std::chrono::duration<double>(tq1 - tq0).count(),
+	                                          1e6 * std::chrono::duration<double>(tq2 - tq1).count(), 1e6 * std::chrono::duration<double>(tq3 - tq2).count());
 }
 
 // ---- CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624): the point arrays of the level flattened (struct Pnt, CoarseInitializer.h:44-83), the evaluation on
@@ -274,11 +284,15 @@ Vec3f CoarseInitializer::calcResAndGS(int lvl, Mat88f& H_out, Vec8f& b_out, Mat8
 {
 	typedef Vec3f (*Fn)(CoarseInitializer*, int, Mat88f&, Vec8f&, Mat88f&, Vec8f&, const SE3&, AffLight, bool);
 	static Fn orig = original<Fn>("_ZN3dso17CoarseInitializer12calcResAndGSEiRN5Eigen6MatrixIfLi8ELi8ELi0ELi8ELi8EEERNS2_IfLi8ELi1ELi0ELi8ELi1EEES4_S6_RKN6Sophus8SE3GroupIdLi0EEENS_8AffLightEb");
+	Timer tm(g.stats, 6);
 	if (g.init_mode == 0) return orig(this, lvl, H_out, b_out, H_out_sc, b_out_sc, refToNew, refToNew_aff, plot);
 	const int n = numPoints[lvl];
 	Pnt* pts = points[lvl];
-	std::vector<float> u(n), v(n), iR(n), idn(n), en(2 * (size_t)n), oth(n), en_new(2 * (size_t)n), maxstep(n), lastH(n), Jb(10 * (size_t)n);
-	std::vector<unsigned char> good(n), good_new(n);
+	// scratch that stays with the thread: the initialiser's LM loop calls this a few hundred times per frame
+	static thread_local std::vector<float> u, v, iR, idn, en, oth, en_new, maxstep, lastH, Jb;
+	static thread_local std::vector<unsigned char> good, good_new;
+	u.resize(n); v.resize(n); iR.resize(n); idn.resize(n); en.resize(2 * (size_t)n); oth.resize(n); en_new.resize(2 * (size_t)n); maxstep.resize(n); lastH.resize(n);
+	Jb.resize(10 * (size_t)n); good.resize(n); good_new.resize(n);
 	for (int i = 0; i < n; i++)
 	{
 		const Pnt& q = pts[i];
@@ -584,7 +598,7 @@ struct FlatWindow
 {
 	int F = 0, N = 0, R = 0, n = 0;
 	std::vector<PointHessian*> points;
-	std::map<PointFrameResidual*, int> resIndex;
+	std::unordered_map<PointFrameResidual*, int> resIndex;
 };
 bool uploadWindow(FullSystem* fs, FlatWindow& W)
 {
@@ -604,6 +618,12 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 	std::vector<float> pu, pv, pid, color, weights;
 	std::vector<unsigned char> prior;
 	W.points.clear(); W.resIndex.clear();
+	{
+		size_t np = 0, nr = 0;
+		for (EFFrame* eff : fs->ef->frames) { np += eff->points.size(); for (EFPoint* efp : eff->points) nr += efp->residualsAll.size(); }
+		W.points.reserve(np); W.resIndex.reserve(2 * nr); host.reserve(np); pu.reserve(np); pv.reserve(np); pid.reserve(np); prior.reserve(np); color.reserve(8 * np); weights.reserve(8 * np);
+		resPoint.reserve(nr); resTarget.reserve(nr);
+	}
 	for (EFFrame* eff : fs->ef->frames)
 		for (EFPoint* efp : eff->points)
 		{
@@ -620,7 +640,7 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 		}
 	W.F = F; W.N = (int)W.points.size(); W.R = (int)resPoint.size(); W.n = CPARS + 8 * F;
 	if (W.N < 1 || W.R < 1) return false;
-	g.windowPoint.clear();
+	g.windowPoint.clear(); g.windowPoint.reserve(2 * W.points.size());
 	for (size_t pi = 0; pi < W.points.size(); pi++) g.windowPoint[W.points[pi]] = (int)pi;
 	dmvio_hip_ba* ba = g.ba;
 	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), fs->Hcalib.value_scaled.data()));
@@ -717,16 +737,19 @@ float FullSystem::optimize(int mnumOptIts)
 				r->resetOOB();
 			}
 	FlatWindow FW;
+	const auto tq0 = std::chrono::steady_clock::now();
 	bool ok = uploadWindow(this, FW);
+	const auto tq1 = std::chrono::steady_clock::now();
 	const int N = FW.N, R = FW.R;
 	std::vector<PointHessian*>& points = FW.points;
-	std::map<PointFrameResidual*, int>& resIndex = FW.resIndex;
+	std::unordered_map<PointFrameResidual*, int>& resIndex = FW.resIndex;
 	if (ok && resIndex.size() != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
 	dmvio_hip_ba* ba = g.ba;
 	std::vector<float> th(F);
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
 	float rmse = 0; double finalEnergy = 0; int iterations = 0;
 	ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));
+	const auto tq2 = std::chrono::steady_clock::now();
 	if (!ok && g.shadow) return orig(this, mnumOptIts);
 	if (!ok) { isLost = true; return 0; }   // a failure inside optimize reads as isLost (:613-617)
 	if (g.shadow)
@@ -852,6 +875,9 @@ float FullSystem::optimize(int mnumOptIts)
 			fh->shell->aff_g2l = fh->aff_g2l();
 		}
 	}
+	const auto tq3 = std::chrono::steady_clock::now();
+	g.opt_split[0] += std::chrono::duration<double>(tq1 - tq0).count(); g.opt_split[1] += std::chrono::duration<double>(tq2 - tq1).count();
+	g.opt_split[2] += std::chrono::duration<double>(tq3 - tq2).count();
 	return statistics_lastFineTrackRMSE;
 }
 

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--init", choices=["ref", "seq", "hip"], default="ref",
                     help="CoarseInitializer::calcResAndGS: the reference's own (multi-threaded: run-to-run noise), the oracle's single-threaded restatement (deterministic "
                          "CPU baseline), or libdmvio_hip.so (mode hip only)")
+    ap.add_argument("--mt", action="store_true", help="settings.cpp multiThreading = true (the reference's default: linearizeAll, applyRes, the accumulators on 6 workers)")
+    ap.add_argument("--scopes", action="store_true", help="inclusive wall time per profiler label of the reference (util/TimeMeasurement scopes) for this run; switches the "
+                                                           "event recording of the run off, so wall_s is the pipeline alone")
     a = ap.parse_args()
     pkg = graft.load_package()
     import dmvio_amd.synth as synth
@@ -91,6 +94,11 @@ def main():
     if D is not None:
         R.lib().ref_system_fullsystem.restype = C.c_void_p; R.lib().ref_system_fullsystem.argtypes = [C.c_void_p]
         D.dropin_attach(R.lib().ref_system_fullsystem(S.p))
+    if a.mt:
+        R.set_multithreading(True)
+    if a.scopes:
+        R.lib().ref_system_scope_timing.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        R.lib().ref_system_scope_timing(S.p, 1, 0)
     expo = [1.0] * len(imgs)
     if a.brightness:
         expo = [float(1.0 + 0.2 * np.sin(0.13 * k)) for k in range(len(imgs))]
@@ -113,7 +121,7 @@ def main():
                opt_F=np.array([e["F"] for e in opt_in]), opt_N=np.array([e["N"] for e in opt_in]), opt_R=np.array([e["R"] for e in opt_in]),
                n_tracks=np.array([sum(1 for e in ev if e["kind"] == "track_out")]))
     if D is not None:
-        sec = (C.c_double * 6)(); calls = (C.c_long * 6)()
+        sec = (C.c_double * 7)(); calls = (C.c_long * 7)()
         D.dropin_get_stats(sec, calls)
         if a.shadow:
             sh = (C.c_double * 16)(); D.dropin_get_shadow(sh)
@@ -123,12 +131,23 @@ def main():
             mg = (C.c_double * 6)(); D.dropin_get_shadow_marginalization.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_shadow_marginalization(mg)
             out["shadow_marginalization"] = np.array(list(mg))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
+        sp = (C.c_double * 3)(); D.dropin_get_optimize_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_optimize_split(sp)
+        out["optimize_split_seconds"] = np.array(list(sp))      # flatten + upload, dmvio_hip_ba_optimize, write-back
         msg = C.create_string_buffer(512)
         out["failures"] = np.array([D.dropin_failures(msg, 512)])
         if out["failures"][0]:
             print("adapter failures:", msg.value.decode(errors="replace"))
     if a.result_txt:
         S.print_result(a.result_txt)
+    if a.scopes:
+        buf = C.create_string_buffer(1 << 16)
+        R.lib().ref_system_scope_totals.argtypes = [C.c_char_p, C.c_int]
+        R.lib().ref_system_scope_totals(buf, len(buf))
+        rows = [ln.rsplit(" ", 2) for ln in buf.value.decode().splitlines() if ln.strip()]
+        rows.sort(key=lambda r: -float(r[1]))
+        out["scope_labels"] = np.array([r[0] for r in rows]); out["scope_seconds"] = np.array([float(r[1]) for r in rows]); out["scope_calls"] = np.array([int(r[2]) for r in rows])
+        for r in rows:
+            print("scope %-40s %9.4f s %6d calls" % (r[0], float(r[1]), int(r[2])))
     np.savez(a.out, **out)
     print("signature", sig)
     print("%s: %d frames in %.2f s, %d keyframe optimisations, initialised %s, lost %s" % (a.mode, len(imgs), wall, len(opt), status[-1]["initialized"], status[-1]["isLost"]))
@@ -157,7 +176,7 @@ def window_run(a, D, R, synth):
     out = dict(rmse=np.array([ro]), poses=poses, idepth=idepth, imm_min=np.asarray(imm["idepth_min"]), imm_max=np.asarray(imm["idepth_max"]),
                imm_status=np.asarray(imm["lastTraceStatus"]), track_pose=np.asarray(tr["pose7"]), track_res=np.asarray(tr["lastResiduals"]))
     if D is not None:
-        sec = (C.c_double * 6)(); calls = (C.c_long * 6)()
+        sec = (C.c_double * 7)(); calls = (C.c_long * 7)()
         D.dropin_get_stats(sec, calls)
         out["stat_calls"] = np.array(list(calls))
         out["failures"] = np.array([D.dropin_failures(None, 0)])

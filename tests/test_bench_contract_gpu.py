@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract(gpu_required):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "256", "--no-sweep", "--no-traffic",
-           "--cpu-seconds", "2", "--ba-iters", "50"]
-    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+           "--cpu-seconds", "2", "--ba-iters", "50", "--dropin-frames", "60"]
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -48,5 +48,12 @@ def test_bench_line_contract(gpu_required):
     assert cb["kind"] in ("reference", "port") and cb["unit"] == "GN-iters/s"
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
         assert cb["kind"] == "reference" and cb["cores"] in (1, 6) and d["trace"]["cpu_baseline"]["kind"] == "reference"
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdropin_hip.so")):
+        # the drop_in leg: the reference's own FullSystem all-CPU vs with its hot-path members on the library
+        di = d["drop_in"]
+        assert "error" not in di, di
+        assert di["frames"] == 60 and di["keyframe_optimisations"] >= 3 and di["adapter_failures"] == 0 and not di["lost"]
+        assert di["traj_rmse_m"] < 1e-3 and 0 < di["hip_backed_s"] < di["all_cpu_s"] <= di["all_cpu_single_threaded_s"] * 1.2
+        assert di["ms_per_frame_after_initialisation"]["hip_backed"] < di["ms_per_frame_after_initialisation"]["all_cpu"]
     assert d["pcie"]["good"] and d["pcie"]["raw_u8"]["good"] and d["pcie"]["raw_u8"]["value"] > d["pcie"]["value"]
     assert d["max_pose_err_m"] < 5e-3
