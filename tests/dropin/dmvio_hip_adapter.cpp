@@ -86,6 +86,10 @@ struct Backend
 	std::map<const FrameHessian*, int> slotOf;
 	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
 	FullSystem* fs = nullptr;      // learnt from the first FullSystem member that comes by
+	std::deque<std::pair<const FrameHessian*, std::vector<float>>> pendingImages;   // frames whose host pyramids were not built (see FrameHessian::makeImages below)
+	bool imm_valid = false;        // the immature handle holds exactly imm_pts (of the keyframes imm_hostIDs) with the state the objects have
+	std::vector<ImmaturePoint*> imm_pts;
+	std::vector<int> imm_hostIDs;
 	double opt_split[3] = {0, 0, 0};   // FullSystem::optimize member: flatten + upload, dmvio_hip_ba_optimize, write-back (seconds)
 	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
@@ -265,17 +269,40 @@ void FrameHessian::makeImages(float* color, CalibHessian* HCalib)
 	typedef void (*Fn)(FrameHessian*, float*, CalibHessian*);
 	static Fn orig = original<Fn>("_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE");
 	Timer tm(g.stats, 0);
-	const auto tq0 = std::chrono::steady_clock::now();
-	orig(this, color, HCalib);   // dIp / absSquaredGrad for the parts of the pipeline that stay on the CPU (see the header comment)
+	// The reference's own pyramids (dIp, absSquaredGrad) are read by the parts of the pipeline that stay on the CPU: the initialiser's driver, and — for KEYFRAMES only — the pixel
+	// selector, the ImmaturePoint constructor, the relinearisation before marginalisation.  While the system is tracking, a new frame therefore only goes to the device here;
+	// its host pyramids are built when (and if) FullSystem::makeKeyFrame is entered for it (below), from a copy of the image kept until then.  Shadow mode builds them always
+	// (the reference's own members read them for every frame).
+	const bool lazy = g.on && !g.shadow && g.fs && g.fs->initialized && !getenv("DROPIN_EAGER_PYRAMIDS");
+	if (!lazy) orig(this, color, HCalib);
 	if (!g.on) return;
-	const auto tq1 = std::chrono::steady_clock::now();
+	if (lazy)
+	{
+		for (int i = 0; i < PYR_LEVELS; i++) { dIp[i] = nullptr; absSquaredGrad[i] = nullptr; }   // the constructor leaves them unset; the destructor delete[]s them
+		dI = nullptr;
+		if (g.pendingImages.size() >= 8) g.pendingImages.pop_front();
+		g.pendingImages.emplace_back(this, std::vector<float>(color, color + (size_t)wG[0] * hG[0]));
+	}
 	const int slot = acquireSlot(this);
-	if (getenv("DROPIN_DEBUG_TIMING")) { typedef int (*DS)(); static DS ds = (DS)dlsym(RTLD_DEFAULT, "hipDeviceSynchronize"); if (ds) ds(); }
-	const auto tq2 = std::chrono::steady_clock::now();
 	HIP_OK(dmvio_hip_frame_upload(g.ctx, slot, color));
-	const auto tq3 = std::chrono::steady_clock::now();
-	if (getenv("DROPIN_DEBUG_TIMING")) fprintf(stderr, "[dropin] makeImages: host pyramids %.0f us, slot %.0f us, upload %.0f us\n", 1e6 * std::chrono::duration<double>(tq1 - tq0).count(),
-	                                          1e6 * std::chrono::duration<double>(tq2 - tq1).count(), 1e6 * std::chrono::duration<double>(tq3 - tq2).count());
+}
+
+// ---- FullSystem::makeKeyFrame (FullSystem.cpp:1228-1390): unchanged, but the frame's host pyramids are built first if makeImages skipped them (see there)
+void FullSystem::makeKeyFrame(FrameHessian* fh)
+{
+	typedef void (*Fn)(FullSystem*, FrameHessian*);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem12makeKeyFrameEPNS_12FrameHessianE");
+	if (g.on && fh->dI == nullptr)
+	{
+		typedef void (*MI)(FrameHessian*, float*, CalibHessian*);
+		static MI makeImagesOrig = original<MI>("_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE");
+		bool found = false;
+		for (auto it = g.pendingImages.rbegin(); it != g.pendingImages.rend(); ++it)
+			if (it->first == fh) { Timer tm(g.stats, 0); makeImagesOrig(fh, it->second.data(), &Hcalib); found = true; break; }
+		if (!found) { fprintf(stderr, "[dropin] makeKeyFrame for a frame whose image is gone\n"); abort(); }
+	}
+	for (auto it = g.pendingImages.begin(); it != g.pendingImages.end();) { if (it->first == fh) it = g.pendingImages.erase(it); else ++it; }
+	orig(this, fh);
 }
 
 // ---- CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624): the point arrays of the level flattened (struct Pnt, CoarseInitializer.h:44-83), the evaluation on
@@ -431,28 +458,44 @@ void FullSystem::traceNewCoarse(FrameHessian* fh)
 	const int nH = (int)frameHessians.size();
 	std::vector<float> KRKi9(9 * nH), Kt3(3 * nH), aff2(2 * nH);
 	std::vector<ImmaturePoint*> pts;
-	if (!HIP_OK(dmvio_hip_immature_clear(g.imm))) return;
+	std::vector<int> hostIDs(nH);
 	for (int hI = 0; hI < nH; hI++)
 	{
 		FrameHessian* host = frameHessians[hI];
+		hostIDs[hI] = host->frameID;
 		SE3 hostToNew = fh->PRE_worldToCam * host->PRE_camToWorld;
 		Mat33f KRKi = K * hostToNew.rotationMatrix().cast<float>() * K.inverse();
 		Vec3f Kt = K * hostToNew.translation().cast<float>();
 		Vec2f aff = AffLight::fromToVecExposure(host->ab_exposure, fh->ab_exposure, host->aff_g2l(), fh->aff_g2l()).cast<float>();
 		for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) KRKi9[9 * hI + 3 * r + c] = KRKi(r, c); Kt3[3 * hI + r] = Kt[r]; }
 		aff2[2 * hI] = aff[0]; aff2[2 * hI + 1] = aff[1];
-		// the points of this host: constructed on the device from its image (bit-identical to ImmaturePoint::ImmaturePoint, ImmaturePoint.cpp:34-62), state from the objects
-		std::vector<int> ui, vi;
-		for (ImmaturePoint* ip : host->immaturePoints) { ui.push_back((int)ip->u); vi.push_back((int)ip->v); pts.push_back(ip); }
-		if (!ui.empty() && !HIP_OK(dmvio_hip_immature_add_points(g.imm, hI, slotFor(host), (int)ui.size(), ui.data(), vi.data()))) return;
+		for (ImmaturePoint* ip : host->immaturePoints) pts.push_back(ip);
 	}
 	const int n = (int)pts.size();
 	if (n == 0) { if (g.shadow) { lock.reset(); orig(this, fh); } return; }
 	std::vector<float> imin(n), imax(n), qual(n), uv(2 * n), interval(n);
 	std::vector<int> status(n);
 	std::vector<unsigned char> wasOOB(n);   // traceOn returns at once for a point that is OOB already (:79): nothing of it changes
-	for (int i = 0; i < n; i++) { imin[i] = pts[i]->idepth_min; imax[i] = pts[i]->idepth_max; qual[i] = pts[i]->quality; status[i] = (int)pts[i]->lastTraceStatus; wasOOB[i] = pts[i]->lastTraceStatus == IPS_OOB; }
-	if (!HIP_OK(dmvio_hip_immature_set_state(g.imm, imin.data(), imax.data(), qual.data(), status.data()))) return;
+	for (int i = 0; i < n; i++) wasOOB[i] = pts[i]->lastTraceStatus == IPS_OOB;
+	// Between two keyframes nothing but traceOn touches the immature points, and the device holds what the last call left: the set stays resident.  It is rebuilt when the
+	// window or a point list changed (every keyframe: activation and optimize invalidate it) and always in shadow mode, where the reference's own traceOn writes the objects.
+	const bool resident = !g.shadow && g.imm_valid && pts == g.imm_pts && hostIDs == g.imm_hostIDs;
+	if (!resident)
+	{
+		g.imm_valid = false;
+		if (!HIP_OK(dmvio_hip_immature_clear(g.imm))) return;
+		for (int hI = 0; hI < nH; hI++)
+		{
+			// the points of this host: constructed on the device from its image (bit-identical to ImmaturePoint::ImmaturePoint, ImmaturePoint.cpp:34-62), state from the objects
+			FrameHessian* host = frameHessians[hI];
+			std::vector<int> ui, vi;
+			for (ImmaturePoint* ip : host->immaturePoints) { ui.push_back((int)ip->u); vi.push_back((int)ip->v); }
+			if (!ui.empty() && !HIP_OK(dmvio_hip_immature_add_points(g.imm, hI, slotFor(host), (int)ui.size(), ui.data(), vi.data()))) return;
+		}
+		for (int i = 0; i < n; i++) { imin[i] = pts[i]->idepth_min; imax[i] = pts[i]->idepth_max; qual[i] = pts[i]->quality; status[i] = (int)pts[i]->lastTraceStatus; }
+		if (!HIP_OK(dmvio_hip_immature_set_state(g.imm, imin.data(), imax.data(), qual.data(), status.data()))) return;
+		g.imm_pts = pts; g.imm_hostIDs = hostIDs; g.imm_valid = true;
+	}
 	if (!HIP_OK(dmvio_hip_immature_trace(g.imm, slotFor(fh), nH, KRKi9.data(), Kt3.data(), aff2.data()))) return;
 	if (!HIP_OK(dmvio_hip_immature_get_state(g.imm, imin.data(), imax.data(), qual.data(), uv.data(), interval.data(), status.data()))) return;
 	if (g.shadow)
@@ -496,6 +539,7 @@ bool hipActivate(FullSystem* fs, const std::vector<ImmaturePoint*>& cand, std::v
 	const int F = (int)fs->frameHessians.size(), n = (int)cand.size();
 	out.assign(n, Activated{0, 0.f, {}});
 	if (n == 0) return true;
+	g.imm_valid = false;
 	if (!HIP_OK(dmvio_hip_immature_clear(g.imm))) return false;
 	// the handle keeps its points grouped by host keyframe: candidates of host h, in candidate order
 	std::vector<int> order;
@@ -720,6 +764,7 @@ float FullSystem::optimize(int mnumOptIts)
 	static Fn orig = original<Fn>("_ZN3dso10FullSystem8optimizeEi");
 	Timer tm(g.stats, 4);
 	g.fs = this;
+	g.imm_valid = false;   // a keyframe: immature points are about to be activated, dropped and created
 	if (!g.on) return orig(this, mnumOptIts);
 	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;
 	if (!g.shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("FullSystemOptimize"));
