@@ -203,3 +203,26 @@ def test_cpp_adapter_demo_tracks_like_the_reference_surface(pkg, gpu_required, t
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok: translation error" in r.stdout and "bad slot -> false" in r.stdout and "ok: energy reduced" in r.stdout
+
+
+def test_host_arrays_larger_than_the_pinned_staging_area(pkg, oracle, gpu_required):
+    """Caller-owned arrays cross PCIe through pinned memory the library owns (csrc/internal.h: DmvBounce, 4 MB to begin with).  A 1280x1024 frame is 5 MB up and 15.7 MB down
+    (level 0 as Vec3f): the staging area has to drain and grow in the middle of a call, several downloads of one call have to land in their own arrays, and the same handle
+    has to keep working afterwards.  Checked bit for bit against the oracle's makeImages."""
+    w, h = 1280, 1024
+    rng = np.random.RandomState(4)
+    img = (rng.rand(h, w) * 255).astype(np.float32)
+    ctx = pkg.Context(w, h, n_slots=2)
+    for rep in range(2):
+        src = img.copy()
+        ctx.frame_upload(rep, src)
+        src[:] = -1.0                                           # the call has returned: the caller's array is its own again
+    ref, ref_abs = oracle.make_images(img, w, h)
+    for lvl in (0, 2):
+        for slot in (0, 1):
+            got = ctx.frame_download(slot, lvl)
+            assert np.array_equal(got.view(np.uint32), ref[lvl].view(np.uint32)), (slot, lvl)
+    g = ctx.abs_squared_grad(1, n_levels=3)                     # three arrays out of one call
+    for lvl in range(3):
+        inner = (slice(1, -1), slice(1, -1))                    # makeImages writes rows 1 .. h-2 (HessianBlocks.cpp:169-189)
+        assert np.array_equal(g[lvl][inner].view(np.uint32), ref_abs[lvl][inner].view(np.uint32)), lvl

@@ -16,7 +16,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 DMVIO_HIP_BA_TIMING=1 python bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 > $O/ba_timing.log 2>&1
 rocprofv3 --kernel-trace -d $O/ba_kt -o kt -- python tools/ba_loop.py 300 > $O/ba_loop.log 2>&1
-python tools/rocprof_timeline.py $(find $O/ba_kt -name '*.db' | head -1) 1500 40 > $O/ba_timeline.txt 2>> $O/ba_loop.log
+python tools/rocprof_timeline.py $(find $O/ba_kt -name '*.db' | head -1) k_ba_point_sums 34 2 > $O/ba_timeline.txt 2>> $O/ba_loop.log
 rm -rf $O/ba_kt
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+python bench.py --steps 20 --warmup 3 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 tail -c 600 $O/bench_n1.json; cat $O/bench_wall.txt

@@ -32,6 +32,24 @@ out += [l for l in open(O + "/ba_loop.log").read().splitlines() if ("GN-iter" in
 out += ["", "## kernel timeline (us): start, duration, gap to the previous kernel, workgroups — set-up, then accepted iterations of the first optimize"]
 out += open(O + "/ba_timeline.txt").read().splitlines()
 open(P + "/r03_ba_host_split_and_timeline.txt", "w").write("\n".join(out) + "\n")
+di = d.get("drop_in")
+if di and "error" not in di:
+    rows = ["# r03 — the reference's own FullSystem, all-CPU vs with its hot-path members on libdmvio_hip.so (`bench.py` -> `drop_in`, 1x MI355X box)", "",
+            di["what"] + ".", "",
+            "| run | wall clock of the %d addActiveFrame calls (s) | ms per frame after initialisation |" % di["frames"], "|---|---|---|",
+            "| all-CPU, the reference's default threading (multiThreading = true, its own thread-pooled initialiser) | %.3f | %.2f |" % (di["all_cpu_s"], di["ms_per_frame_after_initialisation"]["all_cpu"]),
+            "| all-CPU, single-threaded, sequential initialiser (bit-reproducible: the trajectory baseline) | %.3f | %.2f |" % (di["all_cpu_single_threaded_s"], di["ms_per_frame_after_initialisation"]["all_cpu_single_threaded"]),
+            "| HIP-backed (seven members + makeKeyFrame through tests/dropin/dmvio_hip_adapter.cpp) | %.3f | %.2f |" % (di["hip_backed_s"], di["ms_per_frame_after_initialisation"]["hip_backed"]),
+            "", "Trajectory HIP-backed vs the single-threaded baseline: rmse %.2e m, max %.2e m (bar 1e-3 m); the two all-CPU runs against each other: rmse %.2e m.  %d keyframe optimisations, adapter failures %d."
+            % (di["traj_rmse_m"], di["traj_max_m"], di["reference_own_spread_rmse_m"], di["keyframe_optimisations"], di["adapter_failures"]), "",
+            "## inclusive seconds under the reference's own profiler labels (util/TimeMeasurement scopes)", "", "| scope | all-CPU (default threading) | HIP-backed |", "|---|---|---|"]
+    for k in di["scopes_all_cpu"]:
+        rows.append("| %s | %.4f | %.4f |" % (k, di["scopes_all_cpu"][k], di["scopes_hip_backed"].get(k, 0.0)))
+    rows += ["", "## seconds inside the replaced members, HIP-backed run", "", "| member | seconds |", "|---|---|"]
+    for k, v in di["seconds_in_replaced_members"].items():
+        rows.append("| %s | %.4f |" % (k, v))
+    rows += ["", di["note"]]
+    open(P + "/r03_fullsystem_scopes.md", "w").write("\n".join(rows) + "\n")
 print(json.dumps({k: d[k] for k in ("value", "ms_per_step")}), json.dumps(rf)[:300])
 print("driver cmd:", dd["value"], dd["ms_per_step"], dd["roofline"]["frac"])
 for k in ("value", "optimize6_ms", "value_converged_loop", "value_per_call_api", "value_single_threaded_order", "gtsam_handoff"):
