@@ -1041,6 +1041,18 @@ int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* b, int f, const double state_zero1
   b->H.setPrecalcValues();
   return 0;
 }
+int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* b, const double* state_zero10, const double* state10) {
+  if (!b || b->H.F < 1) return failmsg("ba_set_frame_states: bad argument");
+  b->sums_fresh = false; b->sys_ready = false;
+  std::lock_guard<std::mutex> lk(b->mu);
+  for (int f = 0; f < b->H.F; f++) {
+    if (state_zero10) { BAHost::frameSetStateZero(b->H.fr[f], state_zero10 + 10 * f); b->H.frameTakeData(b->H.fr[f]); }
+    if (state10) BAHost::frameSetState(b->H.fr[f], state10 + 10 * f);
+  }
+  if (state_zero10) b->pre_static_valid = false;
+  b->H.setPrecalcValues();
+  return 0;
+}
 int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
   if (!b || !th) return failmsg("ba_set_frame_energy_th: null argument");
   std::lock_guard<std::mutex> lk(b->mu);

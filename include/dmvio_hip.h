@@ -235,6 +235,9 @@ int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* ba, int frame, const double state
  * FrameHessian::frameEnergyTH of all keyframes (th[F]) and CalibHessian::value / value_zero (the reference's unscaled units: fx,fy / SCALE_F,
  * cx,cy / SCALE_C; `value` is the primary quantity of a running system, value_scaled its product with the float SCALE_* constants). */
 int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* ba, int frame, const double state_zero10[10]);
+/* The two calls above for ALL keyframes of the window at once (state_zero10 / state10: F x 10 doubles each, either may be NULL): one setPrecalcValues instead of one per call —
+ * what an adapter that takes a window over from a running FullSystem uses (tests/dropin). */
+int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* ba, const double* state_zero10, const double* state10);
 int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* ba, const float* th);
 int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* ba, const double value[4], const double value_zero[4]);
 /* Point marginalisation: the relinearisation branch of FullSystem::flagPointsForRemoval (FullSystem.cpp:829-859: resetOOB, linearize,

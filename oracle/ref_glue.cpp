@@ -1337,6 +1337,7 @@ void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensi
 	setCalib(w, h, K4);
 	setting_useIMU = false; setting_useGTSAMIntegration = false;
 	setting_logStuff = false;
+	disableAllDisplay = true;   // nogui=1 (util/MainSettings.cpp:83), as BASELINE config 1 runs dmvio_dataset: FullSystem::debugPlot returns at once
 	multiThreading = false;
 	setting_debugout_runquiet = true;
 	setting_desiredPointDensity = desiredPointDensity > 0 ? desiredPointDensity : 1000;

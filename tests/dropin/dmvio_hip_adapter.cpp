@@ -642,7 +642,14 @@ struct FlatWindow
 {
 	int F = 0, N = 0, R = 0, n = 0;
 	std::vector<PointHessian*> points;
-	std::unordered_map<PointFrameResidual*, int> resIndex;
+	// flat position of a residual without a look-up table: the EnergyFunctional keeps the indices itself (EFFrame::idx, EFPoint::idxInPoints, EFResidual::idxInAll,
+	// EnergyFunctional.cpp:438, 488, 503-506, 772-773)
+	std::vector<int> frameFirstPoint, pointFirstRes;
+	int resIndex(const PointFrameResidual* r) const
+	{
+		const EFPoint* efp = r->point->efPoint;
+		return pointFirstRes[frameFirstPoint[efp->host->idx] + efp->idxInPoints] + r->efResidual->idxInAll;
+	}
 };
 bool uploadWindow(FullSystem* fs, FlatWindow& W)
 {
@@ -661,27 +668,34 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 	std::vector<int> host, resPoint, resTarget;
 	std::vector<float> pu, pv, pid, color, weights;
 	std::vector<unsigned char> prior;
-	W.points.clear(); W.resIndex.clear();
+	W.points.clear(); W.frameFirstPoint.assign(fs->ef->frames.size() + 1, 0); W.pointFirstRes.clear();
 	{
 		size_t np = 0, nr = 0;
 		for (EFFrame* eff : fs->ef->frames) { np += eff->points.size(); for (EFPoint* efp : eff->points) nr += efp->residualsAll.size(); }
-		W.points.reserve(np); W.resIndex.reserve(2 * nr); host.reserve(np); pu.reserve(np); pv.reserve(np); pid.reserve(np); prior.reserve(np); color.reserve(8 * np); weights.reserve(8 * np);
+		W.points.reserve(np); W.pointFirstRes.reserve(np + 1); host.reserve(np); pu.reserve(np); pv.reserve(np); pid.reserve(np); prior.reserve(np); color.reserve(8 * np); weights.reserve(8 * np);
 		resPoint.reserve(nr); resTarget.reserve(nr);
 	}
 	for (EFFrame* eff : fs->ef->frames)
+	{
+		assert(fs->ef->frames[eff->idx] == eff);
+		W.frameFirstPoint[eff->idx] = (int)W.points.size();
 		for (EFPoint* efp : eff->points)
 		{
 			PointHessian* ph = efp->data;
 			const int pi = (int)W.points.size();
+			assert(eff->points[efp->idxInPoints] == efp);
 			W.points.push_back(ph);
+			W.pointFirstRes.push_back((int)resPoint.size());
 			host.push_back(ph->host->idx); pu.push_back(ph->u); pv.push_back(ph->v); pid.push_back(ph->idepth); prior.push_back(ph->hasDepthPrior ? 1 : 0);
 			for (int k = 0; k < 8; k++) { color.push_back(ph->color[k]); weights.push_back(ph->weights[k]); }
 			for (EFResidual* er : efp->residualsAll)
 			{
-				W.resIndex[er->data] = (int)resPoint.size();
+				assert((int)resPoint.size() - W.pointFirstRes.back() == er->idxInAll);
 				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx);
 			}
 		}
+	}
+	W.pointFirstRes.push_back((int)resPoint.size());
 	W.F = F; W.N = (int)W.points.size(); W.R = (int)resPoint.size(); W.n = CPARS + 8 * F;
 	if (W.N < 1 || W.R < 1) return false;
 	g.windowPoint.clear(); g.windowPoint.reserve(2 * W.points.size());
@@ -689,10 +703,14 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 	dmvio_hip_ba* ba = g.ba;
 	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), fs->Hcalib.value_scaled.data()));
 	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, W.N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), W.R, resPoint.data(), resTarget.data()));
-	for (int f = 0; ok && f < F; f++)
 	{
-		Vec10 sz = fs->frameHessians[f]->get_state_zero(), st = fs->frameHessians[f]->get_state();
-		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_zero(ba, f, sz.data())) && HIP_OK(dmvio_hip_ba_set_frame_state(ba, f, st.data()));
+		std::vector<double> sz(10 * (size_t)F), st(10 * (size_t)F);
+		for (int f = 0; f < F; f++)
+		{
+			const Vec10 z = fs->frameHessians[f]->get_state_zero(), c = fs->frameHessians[f]->get_state();
+			for (int i = 0; i < 10; i++) { sz[10 * f + i] = z[i]; st[10 * f + i] = c[i]; }
+		}
+		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_states(ba, sz.data(), st.data()));
 	}
 	ok = ok && HIP_OK(dmvio_hip_ba_set_frame_energy_th(ba, th.data())) && HIP_OK(dmvio_hip_ba_set_calib_values(ba, fs->Hcalib.value.data(), fs->Hcalib.value_zero.data()));
 	{
@@ -787,8 +805,7 @@ float FullSystem::optimize(int mnumOptIts)
 	const auto tq1 = std::chrono::steady_clock::now();
 	const int N = FW.N, R = FW.R;
 	std::vector<PointHessian*>& points = FW.points;
-	std::unordered_map<PointFrameResidual*, int>& resIndex = FW.resIndex;
-	if (ok && resIndex.size() != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
+	if (ok && (size_t)R != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
 	dmvio_hip_ba* ba = g.ba;
 	std::vector<float> th(F);
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
@@ -867,7 +884,7 @@ float FullSystem::optimize(int mnumOptIts)
 		std::vector<PointFrameResidual*> toRemove;
 		for (PointFrameResidual* r : activeResiduals)
 		{
-			const int ri = resIndex[r];
+			const int ri = FW.resIndex(r);
 			const ResState ns = newState[ri] == 0 ? ResState::IN : (newState[ri] == 1 ? ResState::OOB : ResState::OUTLIER);
 			r->state_NewState = ns; r->state_NewEnergy = newEnergy[ri]; r->state_NewEnergyWithOutlier = newEnergyWO[ri];
 			if (ns != ResState::OOB) r->centerProjectedTo = Vec3f(center[3 * ri], center[3 * ri + 1], center[3 * ri + 2]);
