@@ -80,6 +80,30 @@ def test_reference_fullsystem_runs_on_the_hip_library(gpu_required, tmp_path, sh
     print("all-CPU   members:", np.round(cpu["stat_seconds"], 4), "HIP-backed members:", np.round(hip["stat_seconds"], 4))
 
 
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name,seq", [("640x480, exposure / affine brightness changing from frame to frame (BASELINE config 3's shape)",
+                                       ["--w", "640", "--h", "480", "--density", "2000", "--brightness"]),
+                                      ("800x400, ~4000-4900 active points, up to 31k residuals per window (BASELINE config 5's shape)",
+                                       ["--w", "800", "--h", "400", "--density", "4000"])], ids=["640x480-brightness", "800x400-4000pts"])
+def test_reference_fullsystem_on_the_hip_library_at_the_other_baseline_shapes(gpu_required, tmp_path, name, seq):
+    """The same whole-run comparison at BASELINE configs 3 and 5: the reference's FullSystem all-CPU (deterministic baseline) vs with its hot-path members on the library."""
+    seq = seq + ["--frames", "100", "--step", "1.6"]
+    cpu = _run(tmp_path, "cpu", "--mode", "cpu", "--init", "seq", *seq)
+    hip = _run(tmp_path, "hip", "--mode", "hip", "--init", "hip", *seq)
+    assert hip["failures"][0] == 0 and not hip["lost"][-1] and hip["initialized"][-1] and not cpu["lost"][-1]
+    assert hip["stat_calls"].min() > 0 and hip["stat_calls"][4] == len(hip["opt_rmse"]) >= 8
+    rmse, mx = _traj_diff(cpu, hip)
+    n = min(len(cpu["opt_rmse"]), len(hip["opt_rmse"]))
+    dE = np.abs(_energies(cpu)[:n] - _energies(hip)[:n]) / _energies(cpu)[:n]
+    print("%s: trajectory rmse %.2e max %.2e m; %d / %d optimisations, windows of up to %d points / %d residuals, first window's energy within %.1e, all within %.1e; "
+          "wall %.2f s vs %.2f s (single-threaded baseline)" % (name, rmse, mx, len(hip["opt_rmse"]), len(cpu["opt_rmse"]), int(hip["opt_N"].max()), int(hip["opt_R"].max()), dE[0], dE.max(),
+                                                                float(hip["wall_s"][0]), float(cpu["wall_s"][0])))
+    assert rmse < 1e-3 and mx < 3e-3                              # north_star: 1e-3 m on the trajectory RMSE
+    assert dE[0] < 1e-4 and dE.max() < 0.08                       # the initialiser's window: same points on both sides; later windows differ by a few activated points
+    assert abs(len(hip["opt_rmse"]) - len(cpu["opt_rmse"])) <= 1
+    assert float(hip["wall_s"][0]) < float(cpu["wall_s"][0])
+
+
 SHADOW_FIELDS = ["n_opt", "n_track", "n_trace_pts", "n_trace_diff", "n_track_good_diff", "n_resInA_diff", "opt_rmse_rel", "opt_energy_rel", "opt_pose", "opt_aff", "opt_idepth_med",
                  "track_pose", "track_aff_a", "track_aff_b", "track_res_rel"]
 
