@@ -1191,6 +1191,7 @@ struct RefSystem
 	int w = 0, h = 0;
 	std::vector<RefEvent> events;
 	bool record = true;
+	bool realtime = false;   // FullSystem(linearizeOperation = false): tracking on the caller's thread, mapping on the reference's own mapping thread
 };
 static RefSystem* g_sys = nullptr;
 
@@ -1331,6 +1332,9 @@ static void scopeHook(const char* name, int phase)
 	else if (!strcmp(name, "FullSystemOptimize") && S->fs->frameHessians.size() >= 2) snapshotOptimize(S, phase > 0);
 }
 
+// linearizeOperation of the systems created from now on (dmvio_dataset: true unless a playback speed is given; false = the two-thread real-time pipeline)
+static bool g_linearizeOperation = true;
+void ref_set_linearize_operation(int on) { g_linearizeOperation = on != 0; }
 // settings as dmvio_dataset's preset=0 leaves them (util/MainSettings.cpp:206-231) unless overridden; useimu=0
 void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensity, int maxFrames, int maxOptIterations, int minOptIterations)
 {
@@ -1351,7 +1355,9 @@ void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensi
 	RefSystem* S = new RefSystem();
 	S->w = w; S->h = h;
 	StdoutCapture cap;
-	S->fs = new FullSystem(true, g_imuCalib, g_imuSettings);
+	S->realtime = !g_linearizeOperation;
+	if (S->realtime) S->record = false;   // the recording hooks are not written for two threads
+	S->fs = new FullSystem(g_linearizeOperation, g_imuCalib, g_imuSettings);
 	cap.finish();
 	S->fs->coarseTrackingLog = 0;
 	g_sys = S;
@@ -1394,6 +1400,21 @@ int ref_system_initializer_state(void* p, int lvl, float* idepth, float* iR, uns
 }
 // the FullSystem behind a RefSystem (tests/dropin: the adapter wants to know whose frames its slots belong to)
 void* ref_system_fullsystem(void* p) { return ((RefSystem*)p)->fs; }
+// FullSystem::blockUntilMappingIsFinished (FullSystem.cpp:1311-1320: what dmvio_dataset calls behind the last frame) — the mapping thread finishes the frame it is working on
+// and leaves.  The destructor calls it again and std::thread cannot be joined twice: a thread that ends at once takes the place of the joined one.
+void ref_system_finish(void* p)
+{
+	FullSystem* fs = ((RefSystem*)p)->fs;
+	fs->blockUntilMappingIsFinished();
+	fs->mappingThread = boost::thread([] {});
+}
+// frames the mapping thread has not taken yet (real-time mode)
+int ref_system_unmapped(void* p)
+{
+	FullSystem* fs = ((RefSystem*)p)->fs;
+	boost::unique_lock<boost::mutex> lock(fs->trackMapSyncMutex);
+	return (int)fs->unmappedTrackedFrames.size();
+}
 // profiler-scope totals: on = 1 starts collecting (and clears), record = 0 switches the event recording of the run off (its snapshots cost time)
 void ref_system_scope_timing(void* p, int on, int record)
 {
@@ -1416,9 +1437,14 @@ int ref_system_add_frame(void* p, const float* img, float exposure, double times
 	ImageAndExposure* im = new ImageAndExposure(S->w, S->h, timestamp);
 	memcpy(im->image, img, sizeof(float) * S->w * S->h);
 	im->exposure_time = exposure;
-	StdoutCapture cap;
-	S->fs->addActiveFrame(im, id, nullptr, nullptr);
-	std::string out = cap.finish();
+	std::string out;
+	if (S->realtime) S->fs->addActiveFrame(im, id, nullptr, nullptr);   // the mapping thread prints too: stdout is left alone
+	else
+	{
+		StdoutCapture cap;
+		S->fs->addActiveFrame(im, id, nullptr, nullptr);
+		out = cap.finish();
+	}
 	delete im;
 	if (log && logcap > 0) { int n = std::min((int)out.size(), logcap - 1); memcpy(log, out.data(), n); log[n] = 0; }
 	status5[0] = S->fs->initialized ? 1 : 0; status5[1] = S->fs->isLost ? 1 : 0; status5[2] = S->fs->initFailed ? 1 : 0;

@@ -31,6 +31,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <atomic>
 #include <map>
 #include <unordered_map>
 #include <memory>
@@ -72,7 +73,7 @@ struct Timer
 {
 	Stats& s; int k; std::chrono::steady_clock::time_point t0;
 	Timer(Stats& s_, int k_) : s(s_), k(k_), t0(std::chrono::steady_clock::now()) {}
-	~Timer() { s.seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); s.calls[k]++; }
+	~Timer();
 };
 
 struct Backend
@@ -83,7 +84,11 @@ struct Backend
 	dmvio_hip_ba* ba = nullptr;
 	dmvio_hip_immature* imm = nullptr;
 	int n_slots = 0;
+	std::recursive_mutex mu;       // the adapter's own containers (real-time mode: makeImages / trackNewestCoarse on the tracking thread, everything else on the mapping thread)
 	std::map<const FrameHessian*, int> slotOf;
+	std::map<int, long> slotAge;   // slot -> value of slotClock when it was last handed out
+	long slotClock = 0;
+	std::atomic<const FrameHessian*> mappingFrame{nullptr};   // the frame makeKeyFrame / makeNonKeyFrame is working on: taken from the mapper's queue, not (yet) in the window
 	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
 	FullSystem* fs = nullptr;      // learnt from the first FullSystem member that comes by
 	std::deque<std::pair<const FrameHessian*, std::vector<float>>> pendingImages;   // frames whose host pyramids were not built (see FrameHessian::makeImages below)
@@ -113,6 +118,7 @@ struct Backend
 	long failures = 0;
 };
 Backend g;
+Timer::~Timer() { std::lock_guard<std::recursive_mutex> lk(g.mu); s.seconds[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); s.calls[k]++; }
 
 void fail(const char* what)
 {
@@ -145,29 +151,51 @@ SE3 fromPose7(const double* p)
 // added); slots of frames the reference has deleted are handed out again
 int acquireSlot(const FrameHessian* fh)
 {
-	auto it = g.slotOf.find(fh);
-	if (it != g.slotOf.end()) return it->second;      // a new frame at the address of a deleted one: its slot is rebuilt by the upload that follows
-	std::set<int> used;
-	if ((int)g.slotOf.size() >= g.n_slots / 2 && g.fs)
+	bool needGC = false;
 	{
-		std::set<const FrameHessian*> live(g.fs->frameHessians.begin(), g.fs->frameHessians.end());
-		if (g.fs->coarseTracker) live.insert(g.fs->coarseTracker->lastRef);
-		if (g.fs->coarseTracker_forNewKF) live.insert(g.fs->coarseTracker_forNewKF->lastRef);
-		if (g.fs->coarseInitializer) { live.insert(g.fs->coarseInitializer->firstFrame); live.insert(g.fs->coarseInitializer->newFrame); }
-		for (auto i = g.slotOf.begin(); i != g.slotOf.end();) { if (!live.count(i->first)) i = g.slotOf.erase(i); else ++i; }
+		std::lock_guard<std::recursive_mutex> lk(g.mu);
+		auto it = g.slotOf.find(fh);
+		if (it != g.slotOf.end()) { g.slotAge[it->second] = ++g.slotClock; return it->second; }      // a new frame at the address of a deleted one: its slot is rebuilt by the upload that follows
+		needGC = (int)g.slotOf.size() >= g.n_slots / 2 && g.fs;
 	}
+	// the frames the reference can still refer to, read under ITS locks (the mapping thread changes these containers in real-time mode) and before the adapter's own lock is
+	// taken again: the mapping thread calls slotFor() while it holds mapMutex
+	std::set<const FrameHessian*> live;
+	if (needGC)
+	{
+		{
+			boost::unique_lock<boost::mutex> lock(g.fs->mapMutex);
+			live.insert(g.fs->frameHessians.begin(), g.fs->frameHessians.end());
+			if (g.fs->coarseTracker) live.insert(g.fs->coarseTracker->lastRef);
+			if (g.fs->coarseTracker_forNewKF) live.insert(g.fs->coarseTracker_forNewKF->lastRef);
+			if (g.fs->coarseInitializer) { live.insert(g.fs->coarseInitializer->firstFrame); live.insert(g.fs->coarseInitializer->newFrame); }
+		}
+		{
+			boost::unique_lock<boost::mutex> lock(g.fs->trackMapSyncMutex);
+			live.insert(g.fs->unmappedTrackedFrames.begin(), g.fs->unmappedTrackedFrames.end());
+		}
+	}
+	std::lock_guard<std::recursive_mutex> lk(g.mu);
+	if (needGC)   // the youngest slots are never reclaimed: between leaving the mapper's queue and entering makeKeyFrame / makeNonKeyFrame a frame is in none of the containers
+	{
+		live.insert(g.mappingFrame.load());
+		for (auto i = g.slotOf.begin(); i != g.slotOf.end();) { if (!live.count(i->first) && g.slotClock - g.slotAge[i->second] > 4) i = g.slotOf.erase(i); else ++i; }
+	}
+	std::set<int> used;
 	for (auto& kv : g.slotOf) used.insert(kv.second);
-	for (int s = 0; s < g.n_slots; s++) if (!used.count(s)) { g.slotOf[fh] = s; return s; }
+	for (int s = 0; s < g.n_slots; s++) if (!used.count(s)) { g.slotOf[fh] = s; g.slotAge[s] = ++g.slotClock; return s; }
 	fprintf(stderr, "[dropin] out of frame slots\n"); abort();
 }
 int slotFor(const FrameHessian* fh)
 {
+	std::lock_guard<std::recursive_mutex> lk(g.mu);
 	auto it = g.slotOf.find(fh);
 	if (it == g.slotOf.end()) { fprintf(stderr, "[dropin] frame without a slot (makeImages did not come through the adapter)\n"); abort(); }
 	return it->second;
 }
 dmvio_hip_tracker* trackerFor(const CoarseTracker* ct)
 {
+	std::lock_guard<std::recursive_mutex> lk(g.mu);
 	auto it = g.trackerOf.find(ct);
 	if (it != g.trackerOf.end()) return it->second;
 	dmvio_hip_tracker* t = dmvio_hip_tracker_create(g.ctx);
@@ -198,7 +226,7 @@ int dropin_enable(int on, int device, int w, int h, int accumulators)
 	}
 	g.slotOf.clear(); g.fs = nullptr; g.on = false; g.stats = Stats(); g.failures = 0; g.error[0] = 0;
 	if (!on) return 0;
-	g.n_slots = 48;
+	g.n_slots = 96;
 	g.ctx = dmvio_hip_create(device, w, h, g.n_slots);
 	if (!g.ctx) { fail("dmvio_hip_create"); return -1; }
 	g.ba = dmvio_hip_ba_create(g.ctx);
@@ -280,7 +308,8 @@ void FrameHessian::makeImages(float* color, CalibHessian* HCalib)
 	{
 		for (int i = 0; i < PYR_LEVELS; i++) { dIp[i] = nullptr; absSquaredGrad[i] = nullptr; }   // the constructor leaves them unset; the destructor delete[]s them
 		dI = nullptr;
-		if (g.pendingImages.size() >= 8) g.pendingImages.pop_front();
+		std::lock_guard<std::recursive_mutex> lk(g.mu);
+		if (g.pendingImages.size() >= 16) g.pendingImages.pop_front();
 		g.pendingImages.emplace_back(this, std::vector<float>(color, color + (size_t)wG[0] * hG[0]));
 	}
 	const int slot = acquireSlot(this);
@@ -292,17 +321,49 @@ void FullSystem::makeKeyFrame(FrameHessian* fh)
 {
 	typedef void (*Fn)(FullSystem*, FrameHessian*);
 	static Fn orig = original<Fn>("_ZN3dso10FullSystem12makeKeyFrameEPNS_12FrameHessianE");
+	struct InMapping { InMapping(const FrameHessian* f) { g.mappingFrame = f; } ~InMapping() { g.mappingFrame = nullptr; } } inMapping(fh);
 	if (g.on && fh->dI == nullptr)
 	{
 		typedef void (*MI)(FrameHessian*, float*, CalibHessian*);
 		static MI makeImagesOrig = original<MI>("_ZN3dso12FrameHessian10makeImagesEPfPNS_12CalibHessianE");
-		bool found = false;
-		for (auto it = g.pendingImages.rbegin(); it != g.pendingImages.rend(); ++it)
-			if (it->first == fh) { Timer tm(g.stats, 0); makeImagesOrig(fh, it->second.data(), &Hcalib); found = true; break; }
-		if (!found) { fprintf(stderr, "[dropin] makeKeyFrame for a frame whose image is gone\n"); abort(); }
+		std::vector<float> image;
+		{
+			std::lock_guard<std::recursive_mutex> lk(g.mu);
+			for (auto it = g.pendingImages.rbegin(); it != g.pendingImages.rend(); ++it)
+				if (it->first == fh) { image.swap(it->second); break; }
+		}
+		if (image.empty()) { fprintf(stderr, "[dropin] makeKeyFrame for a frame whose image is gone\n"); abort(); }
+		Timer tm(g.stats, 0);
+		makeImagesOrig(fh, image.data(), &Hcalib);
 	}
-	for (auto it = g.pendingImages.begin(); it != g.pendingImages.end();) { if (it->first == fh) it = g.pendingImages.erase(it); else ++it; }
+	{
+		std::lock_guard<std::recursive_mutex> lk(g.mu);
+		for (auto it = g.pendingImages.begin(); it != g.pendingImages.end();) { if (it->first == fh) it = g.pendingImages.erase(it); else ++it; }
+	}
 	orig(this, fh);
+}
+
+// ---- FullSystem::makeNonKeyFrame (FullSystem.cpp:1322-1336): unchanged; the frame is deleted at its end, so its device slot and the copy of its image are given back
+void FullSystem::makeNonKeyFrame(FrameHessian* fh)
+{
+	typedef void (*Fn)(FullSystem*, FrameHessian*);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem15makeNonKeyFrameEPNS_12FrameHessianE");
+	g.mappingFrame = fh;
+	long stamp = -1;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g.mu);
+		auto it = g.slotOf.find(fh);
+		if (it != g.slotOf.end()) stamp = g.slotAge[it->second];
+		for (auto pi = g.pendingImages.begin(); pi != g.pendingImages.end();) { if (pi->first == fh) pi = g.pendingImages.erase(pi); else ++pi; }   // it will not become a keyframe
+	}
+	orig(this, fh);      // ... traceNewCoarse(fh); delete fh;
+	{
+		// the tracking thread may already have built a NEW frame at the address of the deleted one (its upload restamps the slot): only an untouched entry is the dead frame's
+		std::lock_guard<std::recursive_mutex> lk(g.mu);
+		auto it = g.slotOf.find(fh);
+		if (it != g.slotOf.end() && g.slotAge[it->second] == stamp) g.slotOf.erase(it);
+	}
+	g.mappingFrame = nullptr;
 }
 
 // ---- CoarseInitializer::calcResAndGS (CoarseInitializer.cpp:331-624): the point arrays of the level flattened (struct Pnt, CoarseInitializer.h:44-83), the evaluation on

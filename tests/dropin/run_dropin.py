@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--init", choices=["ref", "seq", "hip"], default="ref",
                     help="CoarseInitializer::calcResAndGS: the reference's own (multi-threaded: run-to-run noise), the oracle's single-threaded restatement (deterministic "
                          "CPU baseline), or libdmvio_hip.so (mode hip only)")
+    ap.add_argument("--realtime", type=float, default=0.0, metavar="FPS",
+                    help="FullSystem(linearizeOperation = false): frames arrive at FPS on this thread (tracking), the reference's own mapping thread makes the keyframes — "
+                         "tracking and mapping overlap like in a live system; nothing is recorded, the run is not reproducible bit for bit")
     ap.add_argument("--mt", action="store_true", help="settings.cpp multiThreading = true (the reference's default: linearizeAll, applyRes, the accumulators on 6 workers)")
     ap.add_argument("--scopes", action="store_true", help="inclusive wall time per profiler label of the reference (util/TimeMeasurement scopes) for this run; switches the "
                                                            "event recording of the run off, so wall_s is the pipeline alone")
@@ -90,6 +93,8 @@ def main():
         graft.load_oracle().lib()     # builds oracle/_build/liboracle.so when missing
         if D.dropin_set_initializer({"seq": 1, "hip": 2}[a.init], os.path.join(ROOT, "oracle", "_build", "liboracle.so").encode()) != 0:
             raise SystemExit("dropin_set_initializer failed")
+    if a.realtime > 0:
+        R.lib().ref_set_linearize_operation(0)
     S = R.System(a.w, a.h, K4, point_density=a.density)
     if D is not None:
         R.lib().ref_system_fullsystem.restype = C.c_void_p; R.lib().ref_system_fullsystem.argtypes = [C.c_void_p]
@@ -104,8 +109,25 @@ def main():
         expo = [float(1.0 + 0.2 * np.sin(0.13 * k)) for k in range(len(imgs))]
         imgs = [np.float32(expo[k] * (1.0 + 0.03 * np.sin(0.31 * k))) * img + np.float32(4.0 * np.sin(0.2 * k)) for k, img in enumerate(imgs)]
     t0 = time.perf_counter()
-    status = [S.add_frame(img, exposure=expo[k]) for k, img in enumerate(imgs)]
-    wall = time.perf_counter() - t0
+    if a.realtime > 0:
+        R.lib().ref_system_unmapped.argtypes = [C.c_void_p]; R.lib().ref_system_finish.argtypes = [C.c_void_p]
+        status = []; busy = 0.0
+        for k, img in enumerate(imgs):
+            due = t0 + k / a.realtime
+            while time.perf_counter() < due:
+                time.sleep(2e-4)
+            t1 = time.perf_counter()
+            status.append(S.add_frame(img, exposure=expo[k]))
+            busy += time.perf_counter() - t1
+        t_end = time.perf_counter() + 5.0
+        while R.lib().ref_system_unmapped(S.p) > 0 and time.perf_counter() < t_end:      # let the mapping thread take what is queued, as a live system would
+            time.sleep(1e-3)
+        time.sleep(0.05)
+        R.lib().ref_system_finish(S.p)                                                    # FullSystem::blockUntilMappingIsFinished
+        wall = busy                                                                       # seconds inside addActiveFrame (the tracking thread's share of the frame period)
+    else:
+        status = [S.add_frame(img, exposure=expo[k]) for k, img in enumerate(imgs)]
+        wall = time.perf_counter() - t0
     tr = S.trajectory()
     ev = S.events()
     opt = [e for e in ev if e["kind"] == "opt_out"]

@@ -87,3 +87,17 @@ def test_whole_run_through_the_switched_off_adapter(dropin, tmp_path):
     assert a["stat_calls"].min() > 0 and a["stat_calls"][0] == 30 and a["stat_calls"][4] == len(a["opt_rmse"])
     for k in ("camToWorld", "opt_rmse", "opt_N", "opt_R", "init_signature"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_real_time_mode_through_the_switched_off_adapter(dropin, tmp_path):
+    """FullSystem(linearizeOperation = false): frames arrive on one thread (tracking), the reference's own mapping thread makes the keyframes.  The adapter's definitions are then
+    entered from two threads at once (makeImages / trackNewestCoarse on one, makeKeyFrame / makeNonKeyFrame / traceNewCoarse / optimize / setCoarseTrackingRef on the other);
+    switched off they only forward, but its bookkeeping (slots, timers, pending images) runs.  Timing decides which frames become keyframes: the run is compared with the
+    linearised one loosely."""
+    a = _run("cpu", tmp_path / "lin.npz", "--init", "seq")
+    b = _run("cpu", tmp_path / "rt.npz", "--init", "ref", "--realtime", "60")
+    assert b["initialized"][-1] and not b["lost"][-1] and b["failures"][0] == 0
+    assert b["stat_calls"][0] == len(b["valid"]) and b["stat_calls"][4] >= 3 and b["stat_calls"][1] >= 3       # frames, keyframe optimisations, tracking references
+    v = (a["valid"] != 0) & (b["valid"] != 0)
+    d = a["camToWorld"][v, :3] - b["camToWorld"][v, :3]
+    assert v.sum() >= 40 and np.sqrt((d ** 2).sum(1).mean()) < 2e-2

@@ -104,6 +104,26 @@ def test_reference_fullsystem_on_the_hip_library_at_the_other_baseline_shapes(gp
     assert float(hip["wall_s"][0]) < float(cpu["wall_s"][0])
 
 
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("fps", [60, 400])
+def test_real_time_pipeline_tracking_and_mapping_threads_on_the_library(gpu_required, tmp_path, fps):
+    """BASELINE config 5's regime inside the reference itself: FullSystem(linearizeOperation = false) — frames arrive on one thread (makeImages + trackNewestCoarse on the
+    context's stream), the reference's OWN mapping thread runs makeKeyFrame / makeNonKeyFrame (traceNewCoarse, activation, optimize on the BA handle's stream,
+    setCoarseTrackingRef) at the same time, with the reference's locks (trackMutex, mapMutex, coarseTrackerSwapMutex, trackMapSyncMutex) where it takes them.  At 60 frames/s the
+    mapper keeps up; at 400 it cannot: frames queue up, the reference drops them from mapping and makes fewer keyframes (FullSystem.cpp:1251-1283) while tracking goes on.
+    Timing decides which frames become keyframes, so the run is compared with the linearised all-CPU one loosely (measured: 1.5-3.3 mm; the all-CPU real-time run: 1.5-1.8 mm)."""
+    seq = ["--w", "512", "--h", "512", "--frames", "100", "--step", "1.6", "--density", "2000"]
+    cpu = _run(tmp_path, "cpu", "--mode", "cpu", "--init", "seq", *seq)
+    rt = _run(tmp_path, "rt", "--mode", "hip", "--init", "hip", "--realtime", str(fps), *seq)
+    assert rt["failures"][0] == 0 and not rt["lost"][-1] and rt["initialized"][-1]
+    calls = rt["stat_calls"]
+    assert calls[2] >= 85 and calls[4] >= 3 and calls[1] >= 3 and calls[3] >= 30, calls          # every frame tracked; keyframes made, references set, frames traced by the mapper
+    rmse, mx = _traj_diff(cpu, rt)
+    print("real time at %d frames/s: %d keyframe optimisations, %d traced frames, trajectory vs the linearised all-CPU run rmse %.2e max %.2e m; %.3f s inside addActiveFrame for %d frames"
+          % (fps, calls[4], calls[3], rmse, mx, float(rt["wall_s"][0]), len(rt["valid"])))
+    assert rmse < 1e-2
+
+
 SHADOW_FIELDS = ["n_opt", "n_track", "n_trace_pts", "n_trace_diff", "n_track_good_diff", "n_resInA_diff", "opt_rmse_rel", "opt_energy_rel", "opt_pose", "opt_aff", "opt_idepth_med",
                  "track_pose", "track_aff_a", "track_aff_b", "track_res_rel"]
 
