@@ -87,6 +87,8 @@ struct Backend
 	std::recursive_mutex mu;       // the adapter's own containers (real-time mode: makeImages / trackNewestCoarse on the tracking thread, everything else on the mapping thread)
 	std::map<const FrameHessian*, int> slotOf;
 	std::map<int, long> slotAge;   // slot -> value of slotClock when it was last handed out
+	std::map<int, int> slotShellId;   // slot -> FrameShell::id of the frame it was handed to
+	std::atomic<int> lastMappedId{-1};   // FrameShell::id of the last frame makeKeyFrame / makeNonKeyFrame finished: younger frames are queued, in flight, or not yet seen by the mapper
 	long slotClock = 0;
 	std::atomic<const FrameHessian*> mappingFrame{nullptr};   // the frame makeKeyFrame / makeNonKeyFrame is working on: taken from the mapper's queue, not (yet) in the window
 	std::map<const CoarseTracker*, dmvio_hip_tracker*> trackerOf;
@@ -151,46 +153,69 @@ SE3 fromPose7(const double* p)
 // added); slots of frames the reference has deleted are handed out again
 int acquireSlot(const FrameHessian* fh)
 {
-	bool needGC = false;
+	for (int attempt = 0;; attempt++)
 	{
-		std::lock_guard<std::recursive_mutex> lk(g.mu);
-		auto it = g.slotOf.find(fh);
-		if (it != g.slotOf.end()) { g.slotAge[it->second] = ++g.slotClock; return it->second; }      // a new frame at the address of a deleted one: its slot is rebuilt by the upload that follows
-		needGC = (int)g.slotOf.size() >= g.n_slots / 2 && g.fs;
-	}
-	// the frames the reference can still refer to, read under ITS locks (the mapping thread changes these containers in real-time mode) and before the adapter's own lock is
-	// taken again: the mapping thread calls slotFor() while it holds mapMutex
-	std::set<const FrameHessian*> live;
-	if (needGC)
-	{
+		bool needGC = false;
 		{
-			boost::unique_lock<boost::mutex> lock(g.fs->mapMutex);
-			live.insert(g.fs->frameHessians.begin(), g.fs->frameHessians.end());
-			if (g.fs->coarseTracker) live.insert(g.fs->coarseTracker->lastRef);
-			if (g.fs->coarseTracker_forNewKF) live.insert(g.fs->coarseTracker_forNewKF->lastRef);
-			if (g.fs->coarseInitializer) { live.insert(g.fs->coarseInitializer->firstFrame); live.insert(g.fs->coarseInitializer->newFrame); }
+			std::lock_guard<std::recursive_mutex> lk(g.mu);
+			auto it = g.slotOf.find(fh);
+			if (it != g.slotOf.end()) { g.slotAge[it->second] = ++g.slotClock; g.slotShellId[it->second] = fh->shell ? fh->shell->id : -1; return it->second; }      // a new frame at the address of a deleted one: its slot is rebuilt by the upload that follows
+			needGC = ((int)g.slotOf.size() >= g.n_slots / 2 || attempt > 0) && g.fs;
+		}
+		// the frames the reference can still refer to, read under ITS locks (the mapping thread changes these containers in real-time mode) and before the adapter's own lock is
+		// taken again: the mapping thread calls slotFor() while it holds mapMutex
+		std::set<const FrameHessian*> live;
+		if (needGC)
+		{
+			{
+				boost::unique_lock<boost::mutex> lock(g.fs->mapMutex);
+				live.insert(g.fs->frameHessians.begin(), g.fs->frameHessians.end());
+				if (g.fs->coarseTracker) live.insert(g.fs->coarseTracker->lastRef);
+				if (g.fs->coarseTracker_forNewKF) live.insert(g.fs->coarseTracker_forNewKF->lastRef);
+				if (g.fs->coarseInitializer) { live.insert(g.fs->coarseInitializer->firstFrame); live.insert(g.fs->coarseInitializer->newFrame); }
+			}
+			{
+				boost::unique_lock<boost::mutex> lock(g.fs->trackMapSyncMutex);
+				live.insert(g.fs->unmappedTrackedFrames.begin(), g.fs->unmappedTrackedFrames.end());
+			}
 		}
 		{
-			boost::unique_lock<boost::mutex> lock(g.fs->trackMapSyncMutex);
-			live.insert(g.fs->unmappedTrackedFrames.begin(), g.fs->unmappedTrackedFrames.end());
+			std::lock_guard<std::recursive_mutex> lk(g.mu);
+			if (needGC)
+			{
+				// Reclaimed: slots of frames the reference no longer holds.  A frame on its way through the mapper (queued, or taken from the queue and inside makeKeyFrame /
+				// makeNonKeyFrame, or between the two) is in none of the containers for a moment: while the system is mapping, only frames the mapper is DONE with
+				// (FrameShell::id <= that of the last frame it finished) are candidates
+				live.insert(g.mappingFrame.load());
+				const int done = g.lastMappedId.load();
+				const bool mapping = g.fs->initialized;
+				for (auto i = g.slotOf.begin(); i != g.slotOf.end();)
+				{
+					const bool dead = !live.count(i->first) && g.slotClock - g.slotAge[i->second] > 4 && (!mapping || g.slotShellId[i->second] <= done);
+					if (dead) i = g.slotOf.erase(i); else ++i;
+				}
+			}
+			std::set<int> used;
+			for (auto& kv : g.slotOf) used.insert(kv.second);
+			for (int s = 0; s < g.n_slots; s++) if (!used.count(s)) { g.slotOf[fh] = s; g.slotAge[s] = ++g.slotClock; g.slotShellId[s] = fh->shell ? fh->shell->id : -1; return s; }
 		}
+		// every slot belongs to a frame the mapper has not finished: the tracking thread is that many frames ahead of it.  A live system is paced by its camera; here the frame
+		// buffer is simply full, and the new frame waits for the mapper
+		if (attempt > 20000) { fprintf(stderr, "[dropin] out of frame slots\n"); abort(); }
+		std::this_thread::sleep_for(std::chrono::microseconds(500));
 	}
-	std::lock_guard<std::recursive_mutex> lk(g.mu);
-	if (needGC)   // the youngest slots are never reclaimed: between leaving the mapper's queue and entering makeKeyFrame / makeNonKeyFrame a frame is in none of the containers
-	{
-		live.insert(g.mappingFrame.load());
-		for (auto i = g.slotOf.begin(); i != g.slotOf.end();) { if (!live.count(i->first) && g.slotClock - g.slotAge[i->second] > 4) i = g.slotOf.erase(i); else ++i; }
-	}
-	std::set<int> used;
-	for (auto& kv : g.slotOf) used.insert(kv.second);
-	for (int s = 0; s < g.n_slots; s++) if (!used.count(s)) { g.slotOf[fh] = s; g.slotAge[s] = ++g.slotClock; return s; }
-	fprintf(stderr, "[dropin] out of frame slots\n"); abort();
 }
-int slotFor(const FrameHessian* fh)
+#define slotFor(fh) slotForAt(fh, __LINE__)
+int slotForAt(const FrameHessian* fh, int line)
 {
 	std::lock_guard<std::recursive_mutex> lk(g.mu);
 	auto it = g.slotOf.find(fh);
-	if (it == g.slotOf.end()) { fprintf(stderr, "[dropin] frame without a slot (makeImages did not come through the adapter)\n"); abort(); }
+	if (it == g.slotOf.end())
+	{
+		fprintf(stderr, "[dropin] frame without a slot (makeImages did not come through the adapter): adapter line %d, frame %p shell id %d frameID %d, %zu slots in use, mapping frame %p\n", line,
+		        (const void*)fh, fh && fh->shell ? fh->shell->id : -1, fh ? fh->frameID : -1, g.slotOf.size(), (const void*)g.mappingFrame.load());
+		abort();
+	}
 	return it->second;
 }
 dmvio_hip_tracker* trackerFor(const CoarseTracker* ct)
@@ -321,7 +346,7 @@ void FullSystem::makeKeyFrame(FrameHessian* fh)
 {
 	typedef void (*Fn)(FullSystem*, FrameHessian*);
 	static Fn orig = original<Fn>("_ZN3dso10FullSystem12makeKeyFrameEPNS_12FrameHessianE");
-	struct InMapping { InMapping(const FrameHessian* f) { g.mappingFrame = f; } ~InMapping() { g.mappingFrame = nullptr; } } inMapping(fh);
+	struct InMapping { int id; InMapping(const FrameHessian* f) : id(f->shell ? f->shell->id : -1) { g.mappingFrame = f; } ~InMapping() { g.lastMappedId = std::max(g.lastMappedId.load(), id); g.mappingFrame = nullptr; } } inMapping(fh);
 	if (g.on && fh->dI == nullptr)
 	{
 		typedef void (*MI)(FrameHessian*, float*, CalibHessian*);
@@ -349,6 +374,7 @@ void FullSystem::makeNonKeyFrame(FrameHessian* fh)
 	typedef void (*Fn)(FullSystem*, FrameHessian*);
 	static Fn orig = original<Fn>("_ZN3dso10FullSystem15makeNonKeyFrameEPNS_12FrameHessianE");
 	g.mappingFrame = fh;
+	const int shellId = fh->shell ? fh->shell->id : -1;
 	long stamp = -1;
 	{
 		std::lock_guard<std::recursive_mutex> lk(g.mu);
@@ -363,6 +389,7 @@ void FullSystem::makeNonKeyFrame(FrameHessian* fh)
 		auto it = g.slotOf.find(fh);
 		if (it != g.slotOf.end() && g.slotAge[it->second] == stamp) g.slotOf.erase(it);
 	}
+	g.lastMappedId = std::max(g.lastMappedId.load(), shellId);
 	g.mappingFrame = nullptr;
 }
 
