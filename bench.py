@@ -229,6 +229,7 @@ def main():
                     in_kernel_us_per_problem=dict(lm_control=round(tk_step / 100.0 / B, 2), evaluation=round(tk_eval / 100.0 / B, 2)))
     # HBM traffic of k_track_lm: measured now, by a rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this very workload (rank 0, N = 1), calibrated on
     # k_build_pyramids of the same run, whose read volume is known exactly (MI355X_MICROARCH.md: gfx950 tallies wide reads at half their size)
+    tr = None
     if rank == 0 and world == 1 and not args.no_traffic and not args.traffic_child:
         tr = measure_traffic(args, B, w, h)
         if tr is not None:
@@ -435,22 +436,22 @@ def main():
 
     # ---------------- trace leg (rank 0, N = 1): FullSystem::traceNewCoarse over 7 hosts x 1500 immature points
     trace_out = None
-    if rank == 0 and world == 1 and not args.no_ba:
+    if rank == 0 and world == 1 and not args.no_ba and not args.traffic_child:
         trace_out = bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu=not args.no_cpu)
 
     # ---------------- overlap leg (rank 0, N = 1): tracking thread + mapping thread on their own HIP streams (BASELINE config 5)
     overlap_out = None
-    if rank == 0 and world == 1 and not args.no_ba:
+    if rank == 0 and world == 1 and not args.no_ba and not args.traffic_child:
         overlap_out = bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h)
 
     # ---------------- live leg (rank 0, N = 1): ONE camera stream, frame after frame — the latency-bound regime of the reference's tracking thread
     live_out = None
-    if rank == 0 and world == 1 and not args.no_ba:
+    if rank == 0 and world == 1 and not args.no_ba and not args.traffic_child:
         live_out = bench_live(args, pkg, synth, ctx, trk, raw, case, w, h)
 
     # ---------------- VIO hand-off leg (rank 0, N = 1): the reference's default branch — every LM step computed on the host
     vio_out = None
-    if rank == 0 and world == 1 and not args.no_ba:
+    if rank == 0 and world == 1 and not args.no_ba and not args.traffic_child:
         vio_out = bench_vio(args, pkg, ctx, trk, raw, case, w, h)
 
     # ---------------- drop-in leg (rank 0, N = 1): the reference's own FullSystem::addActiveFrame over a synthetic sequence, all-CPU and HIP-backed
@@ -461,6 +462,13 @@ def main():
         except Exception as ex:
             dropin_out = dict(error="%s: %s" % (type(ex).__name__, ex))
 
+    if rank == 0 and tr is not None and tr.get("ba_linearize") and ba_out and isinstance(ba_out.get("roofline"), dict):
+        t = tr["ba_linearize"]; rb = ba_out["roofline"]
+        rb["traffic"] = t["traffic"]
+        rb["traffic_source"] = ("the same rocprofv3 --pmc FETCH_SIZE child run as roofline.traffic_source: %d k_ba_linearize dispatches, FETCH_SIZE %.1f KiB each, x %.3f = %.2fx the "
+                                "algorithmic bytes (a 128-byte line per tap row for 16 useful bytes); FETCH_SIZE counts what L2 requests from the fabric, the 256 MB Infinity Cache behind "
+                                "it holds the window's eight images between launches" % (t["dispatches"], t["fetch_kib"], t["factor"], t["traffic"] / max(rb["algorithmic_bytes_per_launch"], 1)))
+        rb["frac_hbm_counter"] = round(t["traffic"] / (rb["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
     if rank == 0:
         out.update(ba=ba_out, trace=trace_out, drop_in=dropin_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
         emit(json.dumps(out))
@@ -483,8 +491,8 @@ def measure_traffic(args, B, w, h):
     d = tempfile.mkdtemp(prefix="dmvio_pmc_", dir="/tmp")
     try:
         env = dict(os.environ); env["TMPDIR"] = "/tmp"
-        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--no-cpu", "--no-ba",
-               "--no-sweep", "--no-pcie", "--no-traffic", "--steps", "3", "--warmup", "1", "--batch", str(B), "--points", str(args.points), "--size", str(args.size),
+        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--no-cpu"] + \
+              (["--no-ba"] if args.no_ba else ["--ba-iters", "60", "--ba-points", str(args.ba_points)]) + ["--no-sweep", "--no-pcie", "--no-traffic", "--steps", "3", "--warmup", "1", "--batch", str(B), "--points", str(args.points), "--size", str(args.size),
                "--distinct", str(args.distinct)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -499,7 +507,11 @@ def measure_traffic(args, B, w, h):
         # calibration: the full-batch pyramid build reads B raw images exactly once (its largest dispatch); FETCH_SIZE is reported in KiB
         factor = (B * w * h * 4) / (pyr[0][2] * 1024.0)
         traffic = int(lm[0][1] * 1024.0 * factor)
-        return dict(traffic=traffic, source="rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this workload: %d k_track_lm dispatches, FETCH_SIZE %.1f KiB each, x %.3f "
+        ba_lin = [x for x in rows if "k_ba_linearize" in x[0]]
+        ba = None
+        if ba_lin:     # the BA leg of the same child run: every k_ba_linearize dispatch reads the same window (taps, point and residual tables)
+            ba = dict(traffic=int(ba_lin[0][1] * 1024.0 * factor), dispatches=int(ba_lin[0][3]), fetch_kib=float(ba_lin[0][1]), factor=float(factor))
+        return dict(traffic=traffic, ba_linearize=ba, source="rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this workload: %d k_track_lm dispatches, FETCH_SIZE %.1f KiB each, x %.3f "
                                             "(calibrated in the same run on k_build_pyramids, which reads %d B per launch and reports %.1f KiB)"
                                             % (lm[0][3], lm[0][1], factor, B * w * h * 4, pyr[0][2]))
     except Exception as ex:      # a diagnostic must not take the bench down
