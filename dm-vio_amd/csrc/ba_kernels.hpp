@@ -114,7 +114,9 @@ struct BAHostRes {           // host-coherent pinned memory, polled by the host
   double E[2];               // [0] energy of the last plain / stepped-state linearisation, [1] of the relinearisation after a rejected step
   float th[2];               // newest keyframe's threshold after each of them
   int accept;
-  unsigned int ticket;       // published last (release, system scope) by the final kernel of a chain
+  unsigned int ticket;       // published (release, system scope) by the final kernel of a chain — for an accept test as soon as the decision stands, BEFORE the threshold
+                             // selection of the same pass (which nobody waits for: the next linearisation reads it in stream order); otherwise last
+  unsigned int th_ticket;    // the same ticket once th[] of that pass is stored
   unsigned int gticket[BA_GATHER_MAX_BLOCKS];   // k_ba_stitch_gather: one slot per workgroup, the chain's ticket behind the workgroup's slice of the system
   int ticks[6];              // diagnostics: 100 MHz wall-clock ticks since the deciding workgroup started its own residuals: decision pass begin, energy
                              // summed, threshold keys loaded, threshold selected (dmvio_hip_ba_last_decide_ticks)
@@ -193,6 +195,18 @@ __device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nbloc
   }
   __syncthreads();
   tk1 = wall_clock64();
+  if (D.mode == 1 && tid == 0) {
+    // the accept test needs the energy only (FullSystemOptimize.cpp:553-554): decide and tell the host NOW; the threshold selection below (3 + 5 us) then runs while the host
+    // reads the decision and enqueues the kernels of its branch, which start in stream order behind this one
+    const double E = s_E;
+    const double lastE0 = D.lastE0_from_ctl ? __hip_atomic_load(&D.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.lastE0;
+    const int acc = (E + D.newL + D.newM < lastE0 + D.lastL + D.lastM) ? 1 : 0;   // energy[1] = 0, dynamic weight folded into lastM / newM by the host
+    if (acc) __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&D.ctl->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&D.host->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&D.host->E[0], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (D.publish) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const float* const keys_src = gathered ? D.xchg_all : D.newestE;
   const int keys_n = gathered ? D.world * D.xchg_width : D.n_newest;
   const int rec_w = gathered ? D.xchg_width : 0;
@@ -266,21 +280,18 @@ __device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nbloc
     const double E = s_E;
     const int slot = D.mode == 2 ? 1 : 0;
     if (D.update_th) __hip_atomic_store(D.frameTH + D.newestFrame, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (D.mode == 1) {
-      const double lastE0 = D.lastE0_from_ctl ? __hip_atomic_load(&D.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.lastE0;
-      const int acc = (E + D.newL + D.newM < lastE0 + D.lastL + D.lastM) ? 1 : 0;   // FullSystemOptimize.cpp:553-554 (energy[1] = 0, dynamic weight 1)
-      if (acc) __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&D.ctl->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&D.host->accept, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else if (D.mode == 0) {
+    if (D.mode == 0) {
       __hip_atomic_store(&D.ctl->accept, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (D.mode == 2) {
       __hip_atomic_store(&D.ctl->lastE0, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(&D.host->E[slot], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (D.mode != 1) __hip_atomic_store(&D.host->E[slot], E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // mode 1: stored with the decision, above
     __hip_atomic_store(&D.host->th[slot], th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (D.publish) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (D.publish) {
+      __hip_atomic_store(&D.host->th_ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (D.mode != 1) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

@@ -96,6 +96,8 @@ struct dmvio_hip_ba {
   // device-side decisions (ba_kernels.hpp, BACtl): control block, host-coherent result block, device copies of what the decisions read
   BACtl* d_ctl = nullptr;
   BAHostRes* h_res = nullptr;
+  bool th_pending = false;            // the newest keyframe's threshold of the last accept-test pass is stored a few microseconds behind its decision (BAHostRes::th_ticket)
+  unsigned int th_pending_ticket = 0;
   float *d_frameTH = nullptr, *h_frameTH = nullptr;   // FrameHessian::frameEnergyTH of every keyframe (the newest one is updated on the device)
   bool th_dirty = true;        // the host changed a threshold: upload before the next linearisation
   double* d_epart = nullptr;
@@ -264,7 +266,26 @@ static int waitTicket(dmvio_hip_ba* b, const unsigned int ticket) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return 0;
 }
+// the host's mirror of the newest keyframe's threshold after an accepted step: the decision pass publishes its decision first and the threshold behind it
+static int resolveTh(dmvio_hip_ba* b) {
+  if (!b->th_pending) return 0;
+  volatile unsigned int* flag = &b->h_res->th_ticket;
+  unsigned long long spins = 0;
+  while ((int)(*flag - b->th_pending_ticket) < 0) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFF) == 0) {
+      const hipError_t q = hipStreamQuery(b->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail("BA decision pass", __FILE__, __LINE__, q);
+      if (q == hipSuccess && (int)(*flag - b->th_pending_ticket) < 0) return failmsg("BA decision pass finished without publishing its threshold");
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[0];
+  b->th_pending = false;
+  return 0;
+}
 static int uploadThresholds(dmvio_hip_ba* b) {
+  if (int r = resolveTh(b)) return r;
   if (!b->th_dirty) return 0;
   for (int f = 0; f < BA_MAXF; f++) b->h_frameTH[f] = f < b->H.F ? b->H.fr[f].frameEnergyTH : 0.0f;
   HIPCHK(hipMemcpyAsync(b->d_frameTH, b->h_frameTH, sizeof(float) * BA_MAXF, hipMemcpyHostToDevice, b->stream));
@@ -349,7 +370,7 @@ static BADecide packOnly(dmvio_hip_ba* b, const BADecide& D) {
 // defer: enqueue only — the caller waits for a LATER ticket of the same stream (kernels it enqueues behind this one) and then picks the results up with linearizePickUp
 static void linearizePickUp(dmvio_hip_ba* b, double* energy, bool keep_threshold) {
   *energy = b->h_res->E[0];
-  if (!keep_threshold) b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[0];
+  if (!keep_threshold) { b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[0]; b->th_pending = false; }
 }
 static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */, bool keep_threshold = false,
                         bool defer = false) {
@@ -932,6 +953,7 @@ int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
 }
 int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
   if (!b || !th) return failmsg("null argument");
+  if (int r = resolveTh(b)) return r;
   for (int f = 0; f < b->H.F; f++) th[f] = b->H.fr[f].frameEnergyTH;
   return 0;
 }
@@ -1056,6 +1078,7 @@ int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* b, const double* state_zero10, c
 int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
   if (!b || !th) return failmsg("ba_set_frame_energy_th: null argument");
   std::lock_guard<std::mutex> lk(b->mu);
+  b->th_pending = false;
   for (int f = 0; f < b->H.F; f++) b->H.fr[f].frameEnergyTH = th[f];
   b->th_dirty = true;
   return 0;
@@ -1100,7 +1123,7 @@ static int settleReject(dmvio_hip_ba* b, double lastE[3], bool wait) {
   if (!b->pending_reject) return 0;
   if (wait) { if (int r = waitTicket(b, b->pending_ticket)) return r; }
   lastE[0] = b->h_res->E[1];
-  b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[1];
+  b->H.fr[b->H.F - 1].frameEnergyTH = b->h_res->th[1]; b->th_pending = false;
   if (b->pending_trace >= 0 && b->pending_trace < 64) b->trace[b->pending_trace][0] = lastE[0];
   b->pending_reject = false; b->pending_trace = -1;
   return 0;
@@ -1218,9 +1241,11 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   fillWindow(b);
   dynFromHost(H, b->dyn_cur);
   if (int r = uploadThresholds(b)) return r;
+  unsigned int D_ticket = 0;
   {
     BA_PH(2);
     BADecide D = makeDecide(b, 1, true, true);
+    D_ticket = D.ticket;
     // newEnergy[0] + newEnergy[1] + newEnergyL + newEnergyM / dynamicGTSAMWeight (FullSystemOptimize.cpp:553-554): the quotients are formed here (x / 1.0 == x without hooks)
     D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2] / b->dynW; D.newL = newL; D.newM = newM / b->dynW;
     D.lastE0_from_ctl = b->pending_reject ? 1 : 0;   // the host has not seen the restored state's energy yet: the device has
@@ -1229,7 +1254,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     HIPCHK(hipGetLastError());
     if (shard) { if (int r = decideGlobal(b, D)) return r; }
     BA_PH(3);
-    if (int r = waitTicket(b, D.ticket)) return r;   // energy, threshold and the accept / reject decision are in host memory
+    if (int r = waitTicket(b, D.ticket)) return r;   // energy and the accept / reject decision are in host memory (the threshold follows: resolveTh)
     if (int r = settleReject(b, lastE, false)) return r;   // ... and so are those of an earlier relinearisation on the same stream
     BA_PH(4);
   }
@@ -1241,7 +1266,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     if (!last) { if (int r = accumulate(b, true, true, false, true, BA_GATE_ALWAYS)) return r; }
     else { if (int r = applyRes(b)) return r; }
     lastE[0] = b->h_res->E[0]; lastE[1] = newL; lastE[2] = newM;
-    H.fr[H.F - 1].frameEnergyTH = b->h_res->th[0];
+    b->th_pending = true; b->th_pending_ticket = D_ticket;   // the threshold follows its decision by a few microseconds: picked up by resolveTh before anything reads it
     lambda = std::max(lambda * 0.25, 1e-5);
     if (vio && vio->acceptBAUpdate) vio->acceptBAUpdate(vio->user, lastE[0]);   // FullSystemOptimize.cpp:569-572
   } else {
