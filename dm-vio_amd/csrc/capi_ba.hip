@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library itself is loaded on first use (below)
 #include <dlfcn.h>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -624,18 +625,23 @@ int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, 
   NCCLCHK(rccl().commCount(comm, &n));
   NCCLCHK(rccl().commUserRank(comm, &r));
   if (n != world || r != rank) return failmsg("tracker_set_comm: rank / world do not match the communicator");
-  return dmv_tracker_set_exchange(t, [c, comm](double* buf, size_t count) -> int {
-    double* d = nullptr;   // 20 doubles per hypothesis: a few KB, staged through device memory for RCCL on the context's stream
+  // 20 doubles per hypothesis: a few KB, staged through a device buffer that stays with the exchange (and through the context's pinned staging area) for RCCL on the context's stream
+  struct XchgBuf { double* d = nullptr; size_t cap = 0; int device = 0; ~XchgBuf() { if (d) { hipSetDevice(device); hipFree(d); } } };
+  std::shared_ptr<XchgBuf> st = std::make_shared<XchgBuf>();
+  st->device = c->device;
+  return dmv_tracker_set_exchange(t, [c, comm, st](double* buf, size_t count) -> int {
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMalloc((void**)&d, sizeof(double) * count));
-    hipError_t e = hipMemcpyAsync(d, buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream);
-    ncclResult_t nr = ncclSuccess;
-    if (e == hipSuccess) nr = rccl().allReduce(d, d, count, ncclDouble, ncclSum, comm, c->stream);
-    if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(buf, d, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
+    if (count > st->cap) {
+      if (st->d) { HIPCHK(hipFree(st->d)); st->d = nullptr; st->cap = 0; }
+      HIPCHK(hipMalloc((void**)&st->d, sizeof(double) * 2 * count));
+      st->cap = 2 * count;
+    }
+    HIPCHK(c->bounce.h2d(st->d, buf, sizeof(double) * count, c->stream));
+    const ncclResult_t nr = rccl().allReduce(st->d, st->d, count, ncclDouble, ncclSum, comm, c->stream);
     if (nr != ncclSuccess) return failmsg(std::string("RCCL: ") + rccl().getErrorString(nr) + " in the hypothesis exchange");
-    if (e != hipSuccess) return fail("hypothesis exchange", __FILE__, __LINE__, e);
+    HIPCHK(c->bounce.d2h(buf, st->d, sizeof(double) * count, c->stream));
+    HIPCHK(c->bounce.finish(c->stream));
     return 0;
   }, rank, world);
 }
@@ -1302,8 +1308,13 @@ int dmvio_hip_ba_profile_chain(dmvio_hip_ba* b, int reps, float us5[5]) {
   if (!us5 || reps < 1) return failmsg("ba_profile_chain: bad argument");
   if (sharded(b)) return failmsg("ba_profile_chain: single-device windows only");
   std::lock_guard<std::mutex> lk(b->mu);
-  hipEvent_t ev[6];
+  struct Events {   // destroyed on every way out
+    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~Events() { for (int k = 0; k < 6; k++) if (e[k]) hipEventDestroy(e[k]); }
+  } evs;
+  hipEvent_t* ev = evs.e;
   for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k]));
+  struct ProfScope { dmvio_hip_ba* b; ~ProfScope() { b->prof = nullptr; } } profScope{b};
   double acc[5] = {0, 0, 0, 0, 0};
   int rc = 0;
   for (int r = 0; r < reps && rc == 0; r++) {
@@ -1315,7 +1326,6 @@ int dmvio_hip_ba_profile_chain(dmvio_hip_ba* b, int reps, float us5[5]) {
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int k = 0; k < 5; k++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += 1e3 * ms; }
   }
-  for (int k = 0; k < 6; k++) hipEventDestroy(ev[k]);
   for (int k = 0; k < 5; k++) us5[k] = (float)(acc[k] / reps);
   return rc;
 }
