@@ -91,9 +91,9 @@ int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_
   {
     // the integer pixel positions become the float arrays the kernels read, written straight into the pinned staging memory (no wait: the copies are ordered before the
     // constructor kernel on the stream, and the staging area is not reused before the next synchronisation)
-    size_t offu, offv;
-    HIPCHK(m->bounce.reserve(sizeof(float) * n, c->stream, &offu)); HIPCHK(m->bounce.reserve(sizeof(float) * n, c->stream, &offv));
-    float* uf = reinterpret_cast<float*>(m->bounce.h + offu); float* vf = reinterpret_cast<float*>(m->bounce.h + offv);
+    size_t off;   // ONE reservation for both arrays: a second one could drain and rewind the staging area under the first
+    HIPCHK(m->bounce.reserve(sizeof(float) * 2 * (size_t)n, c->stream, &off));
+    float* uf = reinterpret_cast<float*>(m->bounce.h + off); float* vf = uf + n;
     for (int i = 0; i < n; i++) { uf[i] = (float)u[i]; vf[i] = (float)v[i]; }
     HIPCHK(hipMemcpyAsync(m->P.u + first, uf, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(m->P.v + first, vf, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
