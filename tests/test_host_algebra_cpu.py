@@ -137,3 +137,30 @@ def test_ba_host_algebra_equals_the_oracle_bitwise(tmp_path, oracle, synth):
             else:
                 assert np.abs(x - xo).max() <= 1e-14 * np.abs(xo).max(), (with_prior, it)
     L.bah_destroy(H)
+
+
+def test_ba_solve_ldlt_is_the_references_non_gtsam_solve(pkg, oracle):
+    """dmvio_hip_ba_solve_ldlt / dmvio_hip_ba_hook_ldlt (host-only: what a computeBAUpdate hook falls back to): EnergyFunctional.cpp:971-973 — scale by (H_ii + 10)^-1/2 from both
+    sides, pivoted LDL^T, scale back.  Against the oracle's LDL^T (oracle/dense.h) on the scaled system bit for bit, and against a float64 dense solve to rounding."""
+    import ctypes as C
+    L = pkg.load_library()
+    c_d = C.POINTER(C.c_double)
+    L.dmvio_hip_ba_solve_ldlt.argtypes = [C.c_int, c_d, c_d, c_d]; L.dmvio_hip_ba_solve_ldlt.restype = C.c_int
+    rng = np.random.RandomState(12)
+    for n in (12, 36, 68):
+        A = rng.standard_normal((n, 3 * n)); H = A @ A.T + np.diag(rng.uniform(0.0, 50.0, n)); H = 0.5 * (H + H.T)
+        b = rng.standard_normal(n) * 10.0
+        x = np.zeros(n)
+        Hc = np.ascontiguousarray(H); bc = np.ascontiguousarray(b)
+        assert L.dmvio_hip_ba_solve_ldlt(n, Hc.ctypes.data_as(c_d), bc.ctypes.data_as(c_d), x.ctypes.data_as(c_d)) == 0
+        sv = 1.0 / np.sqrt(np.diag(H) + 10.0)
+        Hs = sv[:, None] * H * sv[None, :]                       # SVecI.asDiagonal() * HFinal_top * SVecI.asDiagonal()
+        # the library forms sv_i * H_ij * sv_j left to right over the lower triangle and mirrors it
+        Hs_lib = np.zeros_like(H)
+        for i in range(n):
+            for j in range(i + 1):
+                Hs_lib[i, j] = Hs_lib[j, i] = (sv[i] * H[i, j]) * sv[j]
+        want = sv * oracle.ldlt_solve(Hs_lib, sv * b)
+        assert np.array_equal(x.view(np.uint64), want.view(np.uint64)), n
+        assert np.allclose(x, np.linalg.solve(H, b), rtol=1e-8, atol=1e-10)
+    assert L.dmvio_hip_ba_solve_ldlt(0, Hc.ctypes.data_as(c_d), bc.ctypes.data_as(c_d), x.ctypes.data_as(c_d)) < 0
