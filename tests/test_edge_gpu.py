@@ -226,3 +226,9 @@ def test_host_arrays_larger_than_the_pinned_staging_area(pkg, oracle, gpu_requir
     for lvl in range(3):
         inner = (slice(1, -1), slice(1, -1))                    # makeImages writes rows 1 .. h-2 (HessianBlocks.cpp:169-189)
         assert np.array_equal(g[lvl][inner].view(np.uint32), ref_abs[lvl][inner].view(np.uint32)), lvl
+
+
+def test_graft_entry_smoke(gpu_required):
+    """__graft_entry__.smoke(): what the driver runs on the GPU box before the bench — one small tracking problem and one small window against the oracle."""
+    import __graft_entry__ as graft
+    graft.smoke()
