@@ -1159,7 +1159,7 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
   double flow[3] = {100, 100, 100}, bestPose[7], bestAff[2] = {0, 0};
   memcpy(bestPose, tries7, sizeof(bestPose));
   int computed = 0;
-  const bool split = t->xworld > 1 && (bool)t->xchg;
+  const bool split = t->xworld >= 1 && (bool)t->xchg;   // xworld == 1 only through the test hook of dmv_tracker_set_exchange: the whole exchange path on one device
   for (int i = 0; i < n_tries; i++) {
     if (i >= computed) {
       const int first = computed, cnt = (first == 0) ? 1 : n_tries - first;
@@ -1244,7 +1244,10 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
 }  // extern "C"
 int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, size_t)> allreduce_sum, int rank, int world) {
   if (!t) return failmsg("null tracker");
-  if (world <= 1 || !allreduce_sum) { t->xchg = nullptr; t->xrank = 0; t->xworld = 0; return 0; }
+  // DMVIO_HIP_TEST_SPLIT_WORLD1=1 (tests): a group of ONE rank still takes the split path — every try is "mine", the all-reduce is the identity — so that the exchange
+  // (RCCL on the context's stream included) runs on a one-device box
+  const bool force1 = world == 1 && allreduce_sum && getenv("DMVIO_HIP_TEST_SPLIT_WORLD1") && atoi(getenv("DMVIO_HIP_TEST_SPLIT_WORLD1")) != 0;
+  if ((world <= 1 && !force1) || !allreduce_sum) { t->xchg = nullptr; t->xrank = 0; t->xworld = 0; return 0; }
   if (rank < 0 || rank >= world) return failmsg("tracker_set_comm: 0 <= rank < world");
   std::lock_guard<std::mutex> lk(t->ctx->mu);
   t->xchg = std::move(allreduce_sum); t->xrank = rank; t->xworld = world;

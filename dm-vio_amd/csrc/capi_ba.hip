@@ -618,7 +618,8 @@ int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128],
 int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, int world) {
   dmvio_hip_ctx* c = dmv_tracker_ctx(t);
   if (!c) return failmsg("null tracker");
-  if (!nccl_comm || world <= 1) return dmv_tracker_set_exchange(t, nullptr, 0, world == 1 && nccl_comm ? 1 : 0);
+  const bool force1 = world == 1 && nccl_comm && getenv("DMVIO_HIP_TEST_SPLIT_WORLD1") && atoi(getenv("DMVIO_HIP_TEST_SPLIT_WORLD1")) != 0;   // test hook, see dmv_tracker_set_exchange
+  if (!nccl_comm || (world <= 1 && !force1)) return dmv_tracker_set_exchange(t, nullptr, 0, 0);
   ncclComm_t comm = (ncclComm_t)nccl_comm;
   RCCL_READY();
   int n = 0, r = -1;

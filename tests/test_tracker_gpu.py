@@ -411,3 +411,31 @@ def test_track_new_coarse_hypotheses_split_over_ranks(pkg, synth, oracle, gpu_re
         assert a["tries_used"] == s["tries_used"] and a["good"] == s["good"]
         assert np.max(np.abs(a["pose7"] - s["pose7"])) < 1e-5 and np.allclose(a["achievedRes"], s["achievedRes"], rtol=1e-4, equal_nan=True)
     assert out[0][0]["winner"] == single[0]["winner"] >= 2             # well-conditioned: a later try wins
+
+
+def test_track_new_coarse_exchange_over_rccl_on_one_device(pkg, synth, oracle, gpu_required, monkeypatch):
+    """The RCCL transport of the hypothesis split (dmvio_hip_tracker_set_comm) on a one-device box: a communicator of ONE rank, the split path forced by the library's test hook
+    (every try is this rank's, the all-reduce over one rank is the identity): the records go through the pinned staging area, the device buffer and ncclAllReduce on the
+    context's stream and come back — the answer must be the unsplit call's, within the rounding of a different cluster size (one batch of 32 instead of 1 + 32)."""
+    monkeypatch.setenv("DMVIO_HIP_TEST_SPLIT_WORLD1", "1")
+    w = h = 256
+    case = synth.tracking_case(w, h, n_ref=600, n_frames=1)
+    f = case["frames"][0]
+    slast = oracle.se3_exp(-0.5 * f["xi"]); ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    bad = oracle.se3_exp(np.array([0.0, 0, 0, 0.0, 0.35, 0.0]))
+    tries = np.concatenate([bad[None], oracle.se3_mul(bad, bad)[None], pkg.make_track_hypotheses(slast, ident, ident)])
+    ctx = pkg.Context(w, h, n_slots=2)
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    ctx.frame_upload(0, case["ref_img"]); ctx.frame_upload(1, f["img"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    single = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    comm = pkg.RcclCommunicator(ctx, pkg.RcclCommunicator.unique_id(ctx.L), 0, 1)
+    assert comm.info() == (1, 0)
+    trk.set_comm(comm, 0, 1)
+    a = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    b = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    trk.set_comm(None, 0, 0)
+    for key in ("pose7", "aff", "achievedRes", "flow"):
+        assert np.array_equal(np.asarray(a[key]).view(np.uint64), np.asarray(b[key]).view(np.uint64)), key          # run to run: the same bits
+    assert a["winner"] == single["winner"] >= 2 and a["tries_used"] == single["tries_used"] and a["good"] == single["good"]
+    assert np.max(np.abs(a["pose7"] - single["pose7"])) < 1e-5 and np.allclose(a["achievedRes"], single["achievedRes"], rtol=1e-4, equal_nan=True)
