@@ -584,8 +584,8 @@ int dmvio_hip_tracker_get_pc(dmvio_hip_tracker* t, int lvl, float* u, float* v, 
   HIPCHK(hipSetDevice(c->device));
   const int n = t->dev.pc_n[lvl];
   std::vector<float4> tmp(n);
-  HIPCHK(hipMemcpyAsync(tmp.data(), t->d_pc[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.d2h(tmp.data(), t->d_pc[lvl], sizeof(float4) * n, c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   // the device keeps the template in tile order; hand it out in the reference's row-major order (y, then x)
   std::sort(tmp.begin(), tmp.end(), [](const float4& a, const float4& b) { return a.y < b.y || (a.y == b.y && a.x < b.x); });
   for (int i = 0; i < n; i++) { u[i] = tmp[i].x; v[i] = tmp[i].y; idepth[i] = tmp[i].z; color[i] = tmp[i].w; }
@@ -606,10 +606,10 @@ int dmvio_hip_tracker_get_idepth_map(dmvio_hip_tracker* t, int lvl, float* idept
   const size_t npx = (size_t)wl * hl;
   std::vector<float> ws(npx);
   std::vector<float4> pc(n);
-  HIPCHK(hipMemcpyAsync(idepth_out, t->d_idp2 + R.off[lvl], sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(ws.data(), t->d_wsp2 + R.off[lvl], sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
-  if (n) HIPCHK(hipMemcpyAsync(pc.data(), t->d_pc[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.d2h(idepth_out, t->d_idp2 + R.off[lvl], sizeof(float) * npx, c->stream));
+  HIPCHK(c->bounce.d2h(ws.data(), t->d_wsp2 + R.off[lvl], sizeof(float) * npx, c->stream));
+  if (n) HIPCHK(c->bounce.d2h(pc.data(), t->d_pc[lvl], sizeof(float4) * n, c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   std::vector<unsigned char> kept(npx, 0);
   for (int i = 0; i < n; i++) kept[(size_t)pc[i].x + (size_t)pc[i].y * wl] = 1;
   for (int y = 2; y < hl - 2; y++)
@@ -1278,13 +1278,13 @@ int dmvio_hip_selftest_divide(dmvio_hip_ctx* c, int n, const float* a, const flo
   HIPCHK(hipSetDevice(c->device));
   float* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, sizeof(float) * 4 * (size_t)n));
-  HIPCHK(hipMemcpyAsync(d, a, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(d + n, b, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c->bounce.h2d(d, a, sizeof(float) * n, c->stream));
+  HIPCHK(c->bounce.h2d(d + n, b, sizeof(float) * n, c->stream));
   hipLaunchKernelGGL(k_selftest_divide, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(q_shared, d + 2 * (size_t)n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(q_ieee, d + 3 * (size_t)n, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(c->bounce.d2h(q_shared, d + 2 * (size_t)n, sizeof(float) * n, c->stream));
+  HIPCHK(c->bounce.d2h(q_ieee, d + 3 * (size_t)n, sizeof(float) * n, c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
   HIPCHK(hipFree(d));
   return 0;
 }
