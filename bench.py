@@ -69,8 +69,36 @@ def emit(line):
         os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (the driver's plain command form): start N ranks of this very command under torch.distributed.run — one process per
+    GPU, rendezvous on 127.0.0.1 — and hand their exit code on.  Rank 0 of the children prints the one JSON line (the children inherit this process's stdout).  Fewer than
+    N visible devices is an error, never a silent 1-GPU number (DMVIO_BENCH_SHARE_DEVICE=1, the one-GPU test hook, lets the ranks share devices)."""
+    import socket
+    import subprocess
+    if not os.environ.get("DMVIO_BENCH_SHARE_DEVICE"):
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.stderr.write("bench: --gpus %d asked for, %d device(s) visible: refusing to report a %d-GPU number as %d GPUs\n" % (args.gpus, n_dev, n_dev, args.gpus))
+            raise SystemExit(2)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env["DMVIO_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1 and not args.traffic_child:
+            self_launch(args)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     # stdout carries exactly one JSON line.  The CPU baselines run the reference's own compiled sources (oracle/_ref/libref.so), which print from C++ (PixelSelector's block
     # sizes, "destroyed ThreadReduce" from static destructors at exit, ...): file descriptor 1 is pointed at stderr for the whole run, the JSON line goes to a saved copy of it
     global _REAL_STDOUT
@@ -199,10 +227,12 @@ def main():
     if not res_pipe["good"].all():
         raise SystemExit("bench: a pipelined step lost tracking")
     trk.fetch()                                         # drain the last launch (outside the timed region: K launches, K unpacks inside)
+    rank_ms = [1e3 * elapsed / args.steps]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([elapsed], dtype=torch.float64, device=coll_dev))
+        rank_ms = [1e3 * float(t.item()) / args.steps for t in tall]
+        elapsed = max(float(t.item()) for t in tall)       # MAX over ranks
     ms_per_step = 1e3 * elapsed / args.steps
     frames_per_s = world * B * args.steps / elapsed
 
@@ -299,6 +329,9 @@ def main():
         "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+        "launcher": ("bench.py --gpus N (self-launched torch.distributed.run)" if os.environ.get("DMVIO_BENCH_SELF_LAUNCHED") else
+                     ("torch.distributed.run" if world > 1 else "single process")),
         "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
                                "per step (%d distinct renders, each at its own pose), makeImages%s (level 0 = the resident image, attached in place; levels 1.. built) + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
                                "batch k-1 while batch k runs"
@@ -470,6 +503,10 @@ def main():
                                 "it holds the window's eight images between launches" % (t["dispatches"], t["fetch_kib"], t["factor"], t["traffic"] / max(rb["algorithmic_bytes_per_launch"], 1)))
         rb["frac_hbm_counter"] = round(t["traffic"] / (rb["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
     if rank == 0:
+        if world > 1:
+            # ranks that really exchanged over RCCL: ncclCommCount of the library's own communicator (the sharded window ran on it); the launcher's process group otherwise
+            out["rccl_ranks"] = int((ba_out or {}).get("rccl_ranks", world if backend == "nccl" else 0))
+            out["process_group"] = backend
         out.update(ba=ba_out, trace=trace_out, drop_in=dropin_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
         emit(json.dumps(out))
     if world > 1:

@@ -593,6 +593,36 @@ static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callba
   return 0;
 }
 int dmvio_hip_ba_set_comm(dmvio_hip_ba* b, void* nccl_comm, int rank, int world) { return setComm(b, (ncclComm_t)nccl_comm, nullptr, rank, world); }
+int dmvio_hip_ba_partition_points(const int* host, int N, int world, double max_imbalance, int* owner_out) {
+  if (N < 0 || world < 1 || (N > 0 && (!host || !owner_out))) return failmsg("dmvio_hip_ba_partition_points: bad argument");
+  if (max_imbalance <= 0) max_imbalance = 1.25;
+  int nkf = 0;
+  for (int i = 0; i < N; i++) {
+    if (host[i] < 0) return failmsg("dmvio_hip_ba_partition_points: negative host keyframe index");
+    nkf = std::max(nkf, host[i] + 1);
+  }
+  if (world == 1) { for (int i = 0; i < N; i++) owner_out[i] = 0; return 0; }
+  std::vector<long long> counts(nkf, 0), load(world, 0);
+  for (int i = 0; i < N; i++) counts[host[i]]++;
+  std::vector<int> order(nkf), owner(nkf, 0);
+  for (int k = 0; k < nkf; k++) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });   // largest keyframe first, ties in index order
+  for (int kf : order) {
+    int r = 0;
+    for (int q = 1; q < world; q++) if (load[q] < load[r]) r = q;                                       // the lightest rank, the lowest one among equals
+    owner[kf] = r; load[r] += counts[kf];
+  }
+  const long long heaviest = *std::max_element(load.begin(), load.end());
+  if ((double)heaviest > max_imbalance * std::max((double)N / world, 1.0)) {
+    for (int r = 0; r < world; r++) {
+      const long long lo = ((long long)N * r) / world, hi = ((long long)N * (r + 1)) / world;
+      for (long long i = lo; i < hi; i++) owner_out[i] = r;
+    }
+    return 1;
+  }
+  for (int i = 0; i < N; i++) owner_out[i] = owner[host[i]];
+  return 0;
+}
 int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* b, const dmvio_hip_comm_callbacks* cb, int rank, int world) { return setComm(b, nullptr, cb, rank, world); }
 int dmvio_hip_comm_unique_id(unsigned char id128[128]) {
   if (!id128) return failmsg("null argument");

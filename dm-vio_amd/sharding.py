@@ -16,24 +16,21 @@ import numpy as np
 
 
 def partition_points_by_host(host, world, max_imbalance=1.25):
-    """Point indices owned by every rank: whole keyframes per rank (largest first, greedy); falls back to equal contiguous
-    point ranges when the keyframe split is more unbalanced than max_imbalance (newest keyframe hosts no points, old ones few)."""
-    host = np.asarray(host)
+    """Point indices owned by every rank — the library's policy (dmvio_hip_ba_partition_points, include/dmvio_hip.h: whole keyframes per rank, largest first, greedy; equal
+    contiguous point ranges when the keyframe split is more unbalanced than max_imbalance).  This is only a caller: a C++ host gets the same split from the same entry point."""
+    import ctypes
+    from . import load_library, HipLibraryError
+    host = np.ascontiguousarray(host, dtype=np.int32)
     n = len(host)
-    if world <= 1:
-        return [np.arange(n)]
-    counts = np.bincount(host)
-    order = np.argsort(-counts, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    owner = np.zeros(len(counts), dtype=np.int64)
-    for kf in order:
-        r = int(np.argmin(load))
-        owner[kf] = r
-        load[r] += counts[kf]
-    if load.max() > max_imbalance * max(n / world, 1.0):
-        bounds = [(n * r) // world for r in range(world + 1)]
-        return [np.arange(bounds[r], bounds[r + 1]) for r in range(world)]
-    return [np.nonzero(owner[host] == r)[0] for r in range(world)]
+    owner = np.zeros(n, dtype=np.int32)
+    L = load_library()
+    L.dmvio_hip_ba_partition_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    L.dmvio_hip_ba_partition_points.restype = ctypes.c_int
+    r = L.dmvio_hip_ba_partition_points(host.ctypes.data, n, int(world), float(max_imbalance), owner.ctypes.data)
+    if r < 0:
+        L.dmvio_hip_last_error.restype = ctypes.c_char_p
+        raise HipLibraryError("dmvio_hip_ba_partition_points: %s" % (L.dmvio_hip_last_error() or b"").decode())
+    return [np.nonzero(owner == q)[0] for q in range(world)]
 
 
 def shard_case(case, idx):

@@ -319,6 +319,13 @@ int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* ba, int ticks4[4]);
  *   nccl_comm: an ncclComm_t of RCCL whose rank `rank` lives on this handle's device (not owned; NULL with world 0 detaches).
  *   Every rank must issue the same sequence of BA calls. */
 int dmvio_hip_ba_set_comm(dmvio_hip_ba* ba, void* nccl_comm, int rank, int world);
+/* The partition policy of the sharded window (north_star: "one keyframe per GPU"): which rank owns which point.  Points follow their HOST keyframe
+ * (FrameHessian::pointHessians, HessianBlocks.h:138; EFFrame::points, EnergyFunctionalStructs.h:160): whole keyframes are dealt to the ranks, largest first, each to the
+ * currently lightest rank (ties: lower keyframe index / lower rank first); when the heaviest rank would then hold more than max_imbalance x N / world points (the newest
+ * keyframe hosts no active points, old ones few: typical for world > 4) the split falls back to `world` equal contiguous point ranges [N r / world, N (r + 1) / world).
+ * host[N]: host keyframe index per point (>= 0); owner_out[N]: owning rank per point.  Host-only, needs no device.  Returns 0 (split by keyframe), 1 (equal ranges), < 0 on
+ * error.  max_imbalance <= 0 selects the default 1.25.  A rank then passes ITS points (and their residuals) to dmvio_hip_ba_set_graph. */
+int dmvio_hip_ba_partition_points(const int* host, int N, int world, double max_imbalance, int* owner_out);
 /* Same protocol over a caller-provided transport (MPI, gloo, ...): buffers are staged through host memory.  Both callbacks return 0 on success.
  *   allreduce_sum_f64: element-wise sum over all ranks, in place, identical result on every rank.
  *   allgather: `bytes` bytes per rank, rank order, into out[world * bytes]. */

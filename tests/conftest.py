@@ -15,6 +15,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "multigpu: needs at least two MI355X on one node (real RCCL at world size > 1); skipped elsewhere")
 
 
+def shadowed_definitions(path):
+    """Top-level functions / classes (and methods of one class) that a module defines more than once: Python keeps the last definition, so an
+    earlier test of the same name silently never runs (round 3: the 256-render full-size test was shadowed by its 8-render predecessor)."""
+    import ast
+    dup = []
+
+    def scan(body, where):
+        seen = {}
+        for node in body:
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                if node.name in seen:
+                    dup.append("%s%s (lines %d and %d)" % (where, node.name, seen[node.name], node.lineno))
+                seen[node.name] = node.lineno
+                if isinstance(node, ast.ClassDef):
+                    scan(node.body, where + node.name + ".")
+    scan(ast.parse(open(path).read(), path).body, "")
+    return dup
+
+
+def pytest_collectstart(collector):
+    # collection-time guard: a test module with shadowed definitions fails to collect
+    path = getattr(collector, "path", None)
+    if path is not None and str(path).endswith(".py") and type(collector).__name__ == "Module":
+        dup = shadowed_definitions(str(path))
+        if dup:
+            raise pytest.UsageError("%s: shadowed definitions (only the last one would run): %s" % (path, "; ".join(dup)))
+
+
 def _built():
     lib = os.path.join(ROOT, "dm-vio_amd", "lib", "libdmvio_hip.so")
     orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")

@@ -99,6 +99,7 @@ struct Backend
 	std::vector<int> imm_hostIDs;
 	double opt_split[3] = {0, 0, 0};   // FullSystem::optimize member: flatten + upload, dmvio_hip_ba_optimize, write-back (seconds)
 	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
+	std::unordered_map<const PointHessian*, float> deviceHessian;   // shadow mode: idepth_hessian the DEVICE's optimize of this keyframe left behind
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
 	// CoarseInitializer.cpp:507 / util/IndexThreadReduce.h:83-87 — the sums, and with them everything downstream, vary in the last bits from run to run);
 	// 1 = the oracle's single-threaded restatement (oracle/init_oracle.cpp, per-point bit-identical to the reference: the sums one worker taking every chunk would form)
@@ -108,9 +109,13 @@ struct Backend
 	// libdmvio_hip.so from the same inputs and the two answers are compared — per-call parity on the live windows / frames of a run of the reference's FullSystem
 	bool shadow = false;
 	struct Shadow {
-		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_opt_iter_diff = 0, n_act_pts = 0, n_act_diff = 0;
-		long n_marg = 0, n_marg_pts = 0, n_marg_decision_diff = 0, n_marg_res_diff = 0;
-		double marg_H_rel = 0, marg_b_rel = 0;
+		long n_opt = 0, n_track = 0, n_trace_pts = 0, n_trace_diff = 0, n_track_good_diff = 0, n_resInA_diff = 0, n_opt_iter_diff = 0, n_act_pts = 0, n_act_diff = 0;
+		// marginalisation: n_marg_decision_diff = marginalise-or-drop decisions (flagPointsForRemoval, FullSystem.cpp:846: idepth_hessian of the LAST solveSystemF of this
+		// keyframe's optimize > setting_minIdepthH_marg) that the device's own optimize would have taken differently; n_marg_reacc_diff = the same rule on a Hessian
+		// RE-accumulated at the post-optimisation state (what dmvio_hip_ba_marginalize_points sees in this shadow set-up: another linearisation point, informational)
+		long n_marg = 0, n_marg_pts = 0, n_marg_decision_diff = 0, n_marg_reacc_diff = 0, n_marg_res_diff = 0, n_marg_unknown = 0;
+		double marg_H_rel = 0, marg_b_rel = 0, opt_hessian_rel = 0;
+		long solve_calls = 0;   // EnergyFunctional::solveSystemF calls of the reference's own optimize = its Gauss-Newton iterations
 		double opt_rmse_rel = 0, opt_energy_rel = 0, opt_pose = 0, opt_aff = 0, opt_idepth_med = 0, track_pose = 0, track_aff_a = 0, track_aff_b = 0, track_res_rel = 0;
 	} sh;
 	dmvio_hip_initializer* ini = nullptr;
@@ -282,22 +287,28 @@ int dropin_set_initializer(int mode, const char* liboracle_path)
 }
 // shadow mode (needs dropin_enable(1, ...)): the reference's own members run the pipeline, the HIP library runs every call beside them, deviations are recorded
 void dropin_set_shadow(int on) { g.shadow = on != 0; g.sh = Backend::Shadow(); }
-// out[16]: n_opt, n_track, n_trace_pts, n_trace_diff, n_track_good_diff, n_opt_iter_diff, max over calls of: optimize rmse (relative), final energy (relative), keyframe
+// out[16]: n_opt, n_track, n_trace_pts, n_trace_diff, n_track_good_diff, n_resInA_diff (windows whose EnergyFunctional::resInA differs), max over calls of: optimize rmse (relative), final energy (relative), keyframe
 // translation (m), affine a|b (scaled units), median relative idepth difference; trackNewestCoarse translation (m), affine a, affine b, lastResiduals[0] (relative)
 void dropin_get_shadow(double* out)
 {
 	const Backend::Shadow& h = g.sh;
-	const double v[15] = {(double)h.n_opt, (double)h.n_track, (double)h.n_trace_pts, (double)h.n_trace_diff, (double)h.n_track_good_diff, (double)h.n_opt_iter_diff, h.opt_rmse_rel,
+	const double v[15] = {(double)h.n_opt, (double)h.n_track, (double)h.n_trace_pts, (double)h.n_trace_diff, (double)h.n_track_good_diff, (double)h.n_resInA_diff, h.opt_rmse_rel,
 	                      h.opt_energy_rel, h.opt_pose, h.opt_aff, h.opt_idepth_med, h.track_pose, h.track_aff_a, h.track_aff_b, h.track_res_rel};
 	for (int i = 0; i < 15; i++) out[i] = v[i];
-	out[15] = 0;
+	out[15] = (double)h.n_opt_iter_diff;   // windows in which the device ran another number of Gauss-Newton iterations than the reference's own optimize
 }
-// shadowed EnergyFunctional::marginalizePointsF calls: n_calls, n_points, points the device would have dropped instead, calls whose residual count differs; max relative
-// deviation of the increment of HM / of bM
+// shadowed EnergyFunctional::marginalizePointsF calls: n_calls, n_points, points the device's optimize would have DROPPED instead (its own idepth_hessian against
+// setting_minIdepthH_marg), calls whose residual count differs; max relative deviation of the increment of HM / of bM
 void dropin_get_shadow_marginalization(double* out6)
 {
 	out6[0] = (double)g.sh.n_marg; out6[1] = (double)g.sh.n_marg_pts; out6[2] = (double)g.sh.n_marg_decision_diff; out6[3] = (double)g.sh.n_marg_res_diff;
 	out6[4] = g.sh.marg_H_rel; out6[5] = g.sh.marg_b_rel;
+}
+// more of the same: decisions that differ on the RE-accumulated Hessian (informational), marginalised points the device's optimize never saw, max relative difference of
+// PointHessian::idepth_hessian after optimize (device vs reference) over all windows
+void dropin_get_shadow_marginalization2(double* out3)
+{
+	out3[0] = (double)g.sh.n_marg_reacc_diff; out3[1] = (double)g.sh.n_marg_unknown; out3[2] = g.sh.opt_hessian_rel;
 }
 // n_candidates, n_differing of the shadowed FullSystem::optimizeImmaturePoint calls (result class, idepth bits, the targets of the residuals created)
 void dropin_get_shadow_activation(long* out2) { out2[0] = g.sh.n_act_pts; out2[1] = g.sh.n_act_diff;
@@ -849,7 +860,14 @@ void EnergyFunctional::marginalizePointsF()
 	orig(this);
 	if (!ok || HM.rows() != n) return;
 	g.sh.n_marg++; g.sh.n_marg_pts += nc;
-	for (int i = 0; i < N; i++) if (cand[i] && decision[i] != 1) g.sh.n_marg_decision_diff++;
+	for (int i = 0; i < N; i++) if (cand[i] && decision[i] != 1) g.sh.n_marg_reacc_diff++;
+	for (int i = 0; i < N; i++)
+		if (cand[i])
+		{
+			auto it = g.deviceHessian.find(FW.points[i]);
+			if (it == g.deviceHessian.end()) g.sh.n_marg_unknown++;
+			else if (!(it->second > setting_minIdepthH_marg)) g.sh.n_marg_decision_diff++;
+		}
 	if (resInM - resInM0 != resInMdev) g.sh.n_marg_res_diff++;
 	if (getenv("DROPIN_DEBUG")) fprintf(stderr, "[dropin] marginalizePointsF: %d points, residuals reference %d device %d\n", nc, resInM - resInM0, resInMdev);
 	double dH = 0, sH = 0, db = 0, sb = 0;
@@ -860,6 +878,16 @@ void EnergyFunctional::marginalizePointsF()
 	}
 	if (sH > 0) g.sh.marg_H_rel = std::max(g.sh.marg_H_rel, dH / sH);
 	if (sb > 0) g.sh.marg_b_rel = std::max(g.sh.marg_b_rel, db / sb);
+}
+
+// ---- EnergyFunctional::solveSystemF (EnergyFunctional.cpp:841-996): forwarded unchanged; counted, so that shadow mode can compare the number of Gauss-Newton iterations the
+// reference's own optimize ran (one solveSystemF per iteration, FullSystemOptimize.cpp:485-486 -> :661) with the device's
+void EnergyFunctional::solveSystemF(int iteration, double lambda, CalibHessian* HCalib)
+{
+	typedef void (*Fn)(EnergyFunctional*, int, double, CalibHessian*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional12solveSystemFEidPNS_12CalibHessianE");
+	g.sh.solve_calls++;
+	orig(this, iteration, lambda, HCalib);
 }
 
 // ---- FullSystem::optimize (FullSystemOptimize.cpp:417-647): the window flattened once, the whole Gauss-Newton loop and the final fix-linearisation on the device,
@@ -910,12 +938,22 @@ float FullSystem::optimize(int mnumOptIts)
 		for (int f = 0; f < F; f++) { double st10[10]; HIP_OK(dmvio_hip_ba_get_frame(ba, f, &hp[7 * f], &ha[2 * f], st10)); }
 		HIP_OK(dmvio_hip_ba_get_points(ba, hid.data(), hstep.data()));
 		int resInA_hip = 0; HIP_OK(dmvio_hip_ba_get_res_in_a(ba, &resInA_hip));
+		std::vector<float> hhess(N); HIP_OK(dmvio_hip_ba_get_point_hessian(ba, hhess.data()));
+		g.sh.solve_calls = 0;
 		const float r0 = orig(this, mnumOptIts);
 		g.sh.n_opt++;
+		if (g.sh.solve_calls != iterations) { g.sh.n_opt_iter_diff++; if (getenv("DROPIN_DEBUG")) fprintf(stderr, "[dropin] optimize: reference %ld iterations, device %d\n", g.sh.solve_calls, iterations); }
+		g.deviceHessian.clear();
+		for (int pi = 0; pi < N; pi++)
+		{
+			g.deviceHessian[points[pi]] = hhess[pi];
+			const double href = points[pi]->idepth_hessian;
+			g.sh.opt_hessian_rel = std::max(g.sh.opt_hessian_rel, std::fabs(href - hhess[pi]) / std::max(1.0, std::fabs(href)));
+		}
 		g.sh.opt_rmse_rel = std::max(g.sh.opt_rmse_rel, (double)std::fabs(rmse - r0) / r0);
 		const double Eref = (double)r0 * r0 * patternNum * ef->resInA;
 		g.sh.opt_energy_rel = std::max(g.sh.opt_energy_rel, std::fabs(finalEnergy - Eref) / Eref);
-		if (resInA_hip != ef->resInA) g.sh.n_opt_iter_diff++;
+		if (resInA_hip != ef->resInA) g.sh.n_resInA_diff++;
 		for (int f = 0; f < F; f++)
 		{
 			double p7[7]; toPose7(frameHessians[f]->PRE_worldToCam, p7);

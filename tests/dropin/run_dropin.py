@@ -152,6 +152,8 @@ def main():
             out["shadow_activation"] = np.array(list(act))
             mg = (C.c_double * 6)(); D.dropin_get_shadow_marginalization.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_shadow_marginalization(mg)
             out["shadow_marginalization"] = np.array(list(mg))
+            mg2 = (C.c_double * 3)(); D.dropin_get_shadow_marginalization2.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_shadow_marginalization2(mg2)
+            out["shadow_marginalization2"] = np.array(list(mg2))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
         sp = (C.c_double * 3)(); D.dropin_get_optimize_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_optimize_split(sp)
         out["optimize_split_seconds"] = np.array(list(sp))      # flatten + upload, dmvio_hip_ba_optimize, write-back

@@ -59,24 +59,41 @@ def test_bench_line_contract(gpu_required):
     assert d["max_pose_err_m"] < 5e-3
 
 
-def test_bench_two_ranks_share_the_device(gpu_required):
-    """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per rank), on a one-GPU box: both ranks on device 0, collectives over gloo
-    (bench.py's test hooks — RCCL refuses two ranks per device).  One JSON line from rank 0, whole-job value = N x frames per step / max-over-ranks step time, the BA leg
-    sharded over the two ranks through the library's callback transport."""
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "plain"])
+def test_bench_two_ranks_share_the_device(gpu_required, launcher):
+    """The N > 1 code path of bench.py in BOTH forms the driver uses — under torch.distributed.run (one process per rank) and as plain `python bench.py --gpus 2`, which starts
+    its own ranks — on a one-GPU box: both ranks on device 0, collectives over gloo (bench.py's test hooks — RCCL refuses two ranks per device).  One JSON line from rank 0,
+    whole-job value = N x frames per step / max-over-ranks step time, the BA leg sharded over the two ranks through the library's callback transport."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, DMVIO_BENCH_BACKEND="gloo", DMVIO_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256", "--ba-iters", "50"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256", "--ba-iters", "50"]
+    if launcher == "plain":
+        cmd = [sys.executable] + bench
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + bench
     p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400, env=env)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert ("self-launched" in d["launcher"]) == (launcher == "plain") and d["rccl_ranks"] == 0 and d["process_group"] == "gloo"     # gloo hook: no rank exchanged over RCCL
+    assert d["ms_per_step_ranks"]["min"] <= d["ms_per_step_ranks"]["max"] == d["ms_per_step"]
     assert abs(d["value"] - 2 * 256 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     assert d["config"]["frames_per_step_per_gpu"] == 256 and "x2" in d["config"]["parallelism"]
     ba = d["ba"]
     assert "error" not in ba and ba["value"] > 0 and len(ba["shard_points"]) == 2 and sum(ba["shard_points"]) == ba["window"]["points"]
     assert ba["independent_windows_value"] > 0 and "gloo" in ba["transport"]
     assert d["max_pose_err_m"] < 5e-3
+
+
+def test_bench_refuses_more_gpus_than_visible(gpu_required):
+    """`--gpus N` with fewer than N devices visible exits non-zero with a message and prints no line (never a 1-GPU number labelled N)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DMVIO_BENCH_SHARE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200, env=env)
+    assert p.returncode != 0 and not p.stdout.strip() and b"device(s) visible" in p.stderr

@@ -15,6 +15,18 @@ def test_library_exports_every_declared_symbol(pkg):
     assert not missing, missing
 
 
+def test_no_test_module_shadows_a_definition():
+    """No test / helper is defined twice in one module (the later definition would silently replace the earlier test); conftest.py
+    enforces the same at collection time."""
+    import glob
+    from conftest import shadowed_definitions
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "*.py")) + glob.glob(os.path.join(here, "dropin", "*.py")))
+    assert len(files) > 30
+    dup = {os.path.basename(f): shadowed_definitions(f) for f in files}
+    assert not any(dup.values()), {k: v for k, v in dup.items() if v}
+
+
 def test_header_cites_reference_lines(pkg):
     txt = open(pkg.INCLUDE_PATH).read()
     assert len(re.findall(r"\.(?:cpp|h):\d+", txt)) >= 15, "every entry point names the reference interface it replaces"

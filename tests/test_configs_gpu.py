@@ -149,75 +149,3 @@ def test_full_size_batch_properties(pkg, oracle, synth, gpu_required):
     rg = ba.optimize(6); ro = W.optimize(6)
     assert rg["iterations"] == ro["iterations"]
     assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
-
-
-@pytest.mark.parametrize("n_ref,min_grad,batch,cluster", [(32000, 4.0, 1, 32), (504 * 504, -1.0, 2, 32), (8000, 8.0, 31, 4), (2000, 8.0, 100, 1), (2000, 8.0, 200, 1)])
-def test_tracking_dense_templates_and_cluster_sizes(pkg, oracle, synth, gpu_required, n_ref, min_grad, batch, cluster):
-    """Semi-dense to all-pixel templates (the bandwidth-asymptote end of SURVEY §8d) and every cluster size of the launch table:
-    the same alignment as the oracle, whichever number of workgroups shares a problem."""
-    w = h = 512
-    tc = synth.tracking_case(w, h, n_ref=n_ref, n_frames=2, xi_jitter=0.2, min_grad=min_grad)
-    ctx = pkg.Context(w, h, n_slots=3)
-    ctx.frame_upload(0, tc["ref_img"])
-    for k, f in enumerate(tc["frames"]):
-        ctx.frame_upload(1 + k, f["img"])
-    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(tc["K4"])
-    trk.setCoarseTrackingRef(0, tc["u"], tc["v"], tc["idepth"], tc["hdiF"])
-    dIr, _ = oracle.make_images(tc["ref_img"], w, h)
-    T = oracle.Tracker(w, h); T.make_k(tc["K4"]); T.set_ref(dIr, tc["u"], tc["v"], tc["idepth"], tc["hdiF"])
-    for lvl in range(ctx.levels):
-        assert trk.pc_n(lvl) == T.pc_n(lvl)
-    slots = [1 + (i % 2) for i in range(batch)]
-    trk.stage(slots, [IDENT] * batch, [(0.0, 0.0)] * batch); trk.launch(); r = trk.fetch()
-    assert trk.last_launch()[0] == cluster
-    if batch == 200:
-        assert trk.last_launch() == (1, 512)          # 129..512 problems: one 512-thread workgroup each
-    ref = []
-    for f in tc["frames"]:
-        T.set_new(oracle.make_images(f["img"], w, h)[0]); ref.append(T.track(IDENT, [0.0, 0.0]))
-    for i in range(batch):
-        o = ref[i % 2]; f = tc["frames"][i % 2]
-        assert r["good"][i] and o["good"]
-        assert np.linalg.norm(r["pose7"][i][:3] - np.asarray(o["pose7"])[:3]) < 1e-3
-        assert np.linalg.norm(r["pose7"][i][:3] - f["pose7"][:3]) < 2e-3
-        lg, lo = np.asarray(r["lastResiduals"][i]), np.asarray(o["lastResiduals"])
-        m = np.isfinite(lo)
-        # 256k-point sums in fp32: the two summation orders can part by one accepted LM step at the finest level (poses agree to the bar above)
-        rtol = 1e-4 if n_ref < 100000 else 2e-3
-        assert np.array_equal(np.isfinite(lg), m) and np.allclose(lg[m] ** 2, lo[m] ** 2, rtol=rtol)
-
-
-def test_full_size_batch_properties(pkg, oracle, synth, gpu_required):
-    """BASELINE configuration 2 at the bench's full size (1024 frames of 512x512 in one launch, frames attached in place): the problems of a
-    batch are independent — replicas of one render give the same bits whatever their slot and position in the batch — and every distinct
-    render aligns like the oracle."""
-    import torch
-    w = h = 512
-    B, distinct = 1024, 8
-    case = synth.tracking_case(w, h, n_ref=2000, n_frames=distinct, xi_jitter=0.35)
-    ctx = pkg.Context(w, h, n_slots=B + 1)
-    ctx.frame_upload(0, case["ref_img"])
-    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
-    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
-    rng = np.random.RandomState(5)
-    which = rng.randint(0, distinct, B)                                  # which render sits in which slot
-    raw = torch.from_numpy(np.stack([f["img"] for f in case["frames"]])).cuda()[torch.from_numpy(which).cuda()].contiguous()
-    torch.cuda.synchronize()
-    slots = np.arange(1, B + 1)
-    ctx.frames_attach_device_batch(slots, raw.data_ptr(), w * h * 4)
-    order = rng.permutation(B)                                           # batch position != slot order
-    r = trk.track_batch(slots[order], [IDENT] * B, [(0.0, 0.0)] * B)
-    assert trk.last_launch() == (1, 256) and r["good"].all()
-    dIr, _ = oracle.make_images(case["ref_img"], w, h)
-    T = oracle.Tracker(w, h); T.make_k(case["K4"]); T.set_ref(dIr, case["u"], case["v"], case["idepth"], case["hdiF"])
-    for d in range(distinct):
-        idx = np.nonzero(which[order] == d)[0]
-        assert len(idx) > 1
-        for k in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "iterations"):
-            assert all(np.array_equal(r[k][i], r[k][idx[0]], equal_nan=True) for i in idx), (d, k)
-        T.set_new(oracle.make_images(case["frames"][d]["img"], w, h)[0])
-        o = T.track(IDENT, [0.0, 0.0])
-        assert o["good"] and np.linalg.norm(r["pose7"][idx[0]][:3] - np.asarray(o["pose7"])[:3]) < 1e-3
-        lg, lo = np.asarray(r["lastResiduals"][idx[0]]), np.asarray(o["lastResiduals"])
-        m = np.isfinite(lo)
-        assert np.array_equal(np.isfinite(lg), m) and np.allclose(lg[m] ** 2, lo[m] ** 2, rtol=1e-4)

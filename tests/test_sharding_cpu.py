@@ -29,6 +29,60 @@ def test_partition_by_host_covers_and_balances(pkg):
     assert not (hs[0] & hs[1])
 
 
+def _partition_numpy(host, world, max_imbalance=1.25):
+    """Independent statement of the policy the C entry point is held against."""
+    host = np.asarray(host)
+    n = len(host)
+    if world <= 1:
+        return [np.arange(n)], 0
+    counts = np.bincount(host) if n else np.zeros(0, dtype=np.int64)
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.zeros(len(counts), dtype=np.int64)
+    for kf in np.argsort(-counts, kind="stable"):
+        r = int(np.argmin(load)); owner[kf] = r; load[r] += counts[kf]
+    if n and load.max() > max_imbalance * max(n / world, 1.0):
+        bounds = [(n * r) // world for r in range(world + 1)]
+        return [np.arange(bounds[r], bounds[r + 1]) for r in range(world)], 1
+    return [np.nonzero(owner[host] == r)[0] for r in range(world)], 0
+
+
+def test_partition_entry_point_equals_the_stated_policy(pkg):
+    """dmvio_hip_ba_partition_points (C ABI, host-only: runs without a device) against the numpy statement of the policy: random windows, every world size up to 9,
+    several imbalance bounds, both outcomes (by keyframe / equal ranges); error returns for bad arguments."""
+    import ctypes
+    import dmvio_amd.sharding as sh
+    L = pkg.load_library()
+    L.dmvio_hip_ba_partition_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    L.dmvio_hip_ba_partition_points.restype = ctypes.c_int
+    rng = np.random.RandomState(3)
+    seen = set()
+    for trial in range(300):
+        F = int(rng.randint(1, 13))
+        n = int(rng.choice([0, 1, 7, 500, 2000, 4001]))
+        weights = rng.rand(F) ** 2 + (trial % 3 == 0) * 0.5
+        host = np.sort(rng.choice(F, size=n, p=weights / weights.sum())).astype(np.int32)
+        if trial % 5 == 0:
+            host = rng.permutation(host).astype(np.int32)            # points need not be grouped by host
+        for world in (1, 2, 3, 4, 8, 9):
+            for imb in (1.0, 1.25, 2.0):
+                ref, kind = _partition_numpy(host, world, imb)
+                owner = np.full(n, -1, dtype=np.int32)
+                r = L.dmvio_hip_ba_partition_points(host.ctypes.data, n, world, imb, owner.ctypes.data)
+                assert r == kind, (trial, world, imb, r, kind)
+                for q in range(world):
+                    assert np.array_equal(np.nonzero(owner == q)[0], ref[q]), (trial, world, imb, q)
+                assert all(np.array_equal(a, b) for a, b in zip(sh.partition_points_by_host(host, world, imb), ref))
+                seen.add((kind, world > 1))
+    assert {(0, True), (1, True), (0, False)} <= seen
+    host = np.array([0, 1, -1], dtype=np.int32); owner = np.zeros(3, dtype=np.int32)
+    assert L.dmvio_hip_ba_partition_points(host.ctypes.data, 3, 2, 1.25, owner.ctypes.data) < 0
+    assert L.dmvio_hip_ba_partition_points(host.ctypes.data, 3, 0, 1.25, owner.ctypes.data) < 0
+    assert L.dmvio_hip_ba_partition_points(None, 3, 2, 1.25, owner.ctypes.data) < 0
+    host = np.repeat(np.arange(8), [400, 350, 300, 300, 250, 250, 150, 0]).astype(np.int32); owner = np.zeros(len(host), dtype=np.int32)
+    assert L.dmvio_hip_ba_partition_points(host.ctypes.data, len(host), 2, 0.0, owner.ctypes.data) == 0        # max_imbalance <= 0: the default 1.25
+    assert L.dmvio_hip_ba_partition_points(host.ctypes.data, len(host), 8, 0.0, owner.ctypes.data) == 1        # one keyframe per GPU at 8 GPUs: 400 > 1.25 x 250 -> equal ranges
+
+
 def test_pack_unpack_roundtrip(pkg):
     import dmvio_amd.sharding as sh
     n = 36
