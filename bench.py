@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop_in leg (the reference's own FullSystem all-CPU vs with its hot-path members on libdmvio_hip.so)")
     ap.add_argument("--dropin-frames", type=int, default=100)
+    ap.add_argument("--no-concurrent", action="store_true", help="skip ba.concurrent_windows (several windows in flight on one GPU)")
     ap.add_argument("--ba-points", type=int, default=2000)
     ap.add_argument("--ba-iters", type=int, default=300, help="timed GN iterations of the BA leg")
     return ap.parse_args()
@@ -529,7 +530,7 @@ def measure_traffic(args, B, w, h):
     try:
         env = dict(os.environ); env["TMPDIR"] = "/tmp"
         cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", d, "-o", "c", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--no-cpu"] + \
-              (["--no-ba"] if args.no_ba else ["--ba-iters", "60", "--ba-points", str(args.ba_points)]) + ["--no-sweep", "--no-pcie", "--no-traffic", "--steps", "3", "--warmup", "1", "--batch", str(B), "--points", str(args.points), "--size", str(args.size),
+              (["--no-ba"] if args.no_ba else ["--ba-iters", "60", "--ba-points", str(args.ba_points)]) + ["--no-sweep", "--no-pcie", "--no-traffic", "--no-concurrent", "--steps", "3", "--warmup", "1", "--batch", str(B), "--points", str(args.points), "--size", str(args.size),
                "--distinct", str(args.distinct)]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
         dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -794,6 +795,67 @@ def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
     return out
 
 
+def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev):
+    """What ONE GPU sustains with several windows in flight — the BA analogue of the tracker's 4096-frame batch.  A single window is a chain of dependent sub-10-us
+    launches on a 256-CU device (latency-bound: `ba.value`); K host threads, each optimising its own fresh windows through its own dmvio_hip_ba handles (own HIP stream, own
+    lock, own pinned result block), overlap those chains.  Every thread owns M windows, all set up BEFORE the timed region (set_graph is per-keyframe set-up, not iteration
+    work); timed: every thread runs dmvio_hip_ba_optimize(6) on its M windows one after the other.  value = accepted iterations of all threads / wall time."""
+    import threading
+    n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    M = 6
+    levels = [k for k in (1, 2, 4, 8, 16) if k <= max(1, n_cpu - 1)]       # the waits are polls of host-coherent memory: one core per thread
+    slots = list(range(F))
+    pool = []
+    rows = []
+    best = None
+    try:
+        for K in levels:
+            while len(pool) < K * M:
+                pool.append(pkg.BundleAdjusterHip(ctx))
+            for h in pool[:K * M]:
+                h.set_case(case, slots)                                      # fresh window: every step of optimize(6) is accepted until convergence
+            torch.cuda.synchronize(dev)
+            accepted = [0] * K
+            errors = []
+            start = threading.Barrier(K + 1)
+
+            def work(t):
+                try:
+                    start.wait()
+                    n = 0
+                    for h in pool[t * M:(t + 1) * M]:
+                        n += int(h.optimize(6)["trace"][1:, 3].sum())
+                    accepted[t] = n
+                except Exception as ex:   # reported, never swallowed
+                    errors.append("%s: %s" % (type(ex).__name__, ex))
+            th = [threading.Thread(target=work, args=(t,)) for t in range(K)]
+            for x in th:
+                x.start()
+            start.wait()
+            t0 = time.perf_counter()
+            for x in th:
+                x.join()
+            wall = time.perf_counter() - t0
+            if errors:
+                return dict(error=errors[0], threads=K)
+            n_acc = sum(accepted)
+            val = n_acc / wall
+            rows.append(dict(threads=K, windows=K * M, accepted_iterations=n_acc, wall_ms=round(1e3 * wall, 3), value=round(val, 1),
+                             us_per_iteration_per_window=round(1e6 * wall * K / max(n_acc, 1), 2)))
+            if best is None or val > best["value"]:
+                best = rows[-1]
+    finally:
+        for h in pool:
+            h.close()
+    ach = bytes_iter * best["value"] / 1e9
+    return dict(unit="GN-iters/s", value=best["value"], at_threads=best["threads"], sweep=rows, host_cores_available=n_cpu,
+                roofline=dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                              k_ba_linearize_achieved=round(bytes_lin * best["value"] / 1e9, 2),
+                              what="algorithmic bytes of an accepted iteration (and of its k_ba_linearize launch alone) x accepted iterations per second at saturation"),
+                what="K host threads x %d fresh windows each (own handle, own stream), dmvio_hip_ba_optimize(6) per window, all windows set up before the timed region; "
+                     "accepted Gauss-Newton iterations of all threads / wall time.  `ba.value` is the K = 1 latency figure of the same call" % M)
+
+
 def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):
     """GN iterations / s of FullSystem::optimize's loop body (solveSystemF + doStepFromBackup + linearizeAll + energies + applyRes)
     on an 8-keyframe, ~2000-point, ~12k-residual window."""
@@ -961,6 +1023,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
                                     "not by HBM — the fraction says how far from the HBM roofline a latency-bound path sits")
     if replicas is not None:
         out["independent_windows_value"] = round(replicas, 1)
+    if world == 1 and not getattr(args, "no_concurrent", False):
+        out["concurrent_windows"] = bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
     if world == 1:
         ba1 = pkg.BundleAdjusterHip(ctx, accumulators=1)
         ba1.set_case(case, list(range(F)))

@@ -502,6 +502,10 @@ class CoarseTrackerHip:
         _chk(self.L, fn(self.p, getattr(comm, "p", comm), int(rank), int(world)), "tracker_set_comm")
         self._comm_keep = comm
 
+    def debug_split_single_rank(self, on):
+        fn = self.L.dmvio_hip_tracker_debug_split_single_rank; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if on else 0), "tracker_debug_split_single_rank")
+
     def set_comm_allreduce(self, allreduce, rank, world):
         """allreduce(numpy float64 array) sums the array over all ranks IN PLACE (any transport: torch.distributed / gloo, MPI, threads); None detaches."""
         fn = self.L.dmvio_hip_tracker_set_comm_callbacks; fn.argtypes = [C.c_void_p, C.POINTER(CommCallbacks), C.c_int, C.c_int]

@@ -49,6 +49,7 @@ struct dmvio_hip_tracker {
   // exactly one rank, the others add zeros) by `xchg`
   std::function<int(double*, size_t)> xchg;
   int xrank = 0, xworld = 0;
+  bool debug_split1 = false;          // dmvio_hip_tracker_debug_split_single_rank: a group of ONE rank still takes the split path (tests of the transport on a one-device box)
   unsigned int server_session = 0;    // identity of the current serverStart .. serverStop session (mailbox dword EVAL_MAIL_SESSION, kernel argument)
   long long server_idle_ticks = 500000;   // the server leaves after this long without a request (100 MHz ticks: 5 ms); dmvio_hip_tracker_set_server_idle_us
   int use_server = 1;                 // DMVIO_HIP_EVAL_SERVER=0: one k_eval_fused launch per evaluation instead
@@ -75,6 +76,7 @@ struct dmvio_hip_tracker {
 };
 
 std::string& dmv_err() { static thread_local std::string e; return e; }
+unsigned int& dmv_err_epoch() { static thread_local unsigned int n = 0; return n; }
 
 extern "C" {
 
@@ -456,6 +458,7 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   if (!t) return;
   hipSetDevice(t->ctx->device);
   hipStreamSynchronize(t->ctx->stream);
+  t->xchg = nullptr;   // the exchange owns a device buffer (RCCL transport): released now, while the context it was allocated under is still alive
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
@@ -1176,21 +1179,33 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
         std::vector<int> mine;
         for (int j = first + t->xrank; j < n_tries; j += t->xworld) mine.push_back(j);
         const int m = (int)mine.size();
-        std::vector<double> rec((size_t)REC * cnt, 0.0);
+        // one extra slot behind the records counts the ranks whose share FAILED locally: a rank must never leave before the exchange (its peers would wait in the
+        // all-reduce for ever) — it enters with its error flagged, and every rank fails together afterwards
+        std::vector<double> rec((size_t)REC * cnt + 1, 0.0);
+        int local_rc = 0;
+        std::string local_err;
         if (m > 0) {
           std::vector<double> mp(7 * (size_t)m), ma(2 * (size_t)m), mlr(5 * (size_t)m), mfl(3 * (size_t)m);
           std::vector<int> mg(m), ms(m, new_slot);
           std::vector<float> me(m, new_exposure);
           for (int k = 0; k < m; k++) { memcpy(&mp[7 * (size_t)k], &poses[7 * (size_t)mine[k]], sizeof(double) * 7); ma[2 * k] = aff_last[0]; ma[2 * k + 1] = aff_last[1]; }
-          if (int r = dmvio_hip_tracker_track_batch(t, m, ms.data(), me.data(), mp.data(), ma.data(), L - 1, nullptr, mlr.data(), mfl.data(), nullptr, nullptr, mg.data(), nullptr)) return r;
-          for (int k = 0; k < m; k++) {
-            double* q = &rec[(size_t)REC * (mine[k] - first)];
-            memcpy(q, &mp[7 * (size_t)k], sizeof(double) * 7); q[7] = ma[2 * k]; q[8] = ma[2 * k + 1];
-            memcpy(q + 9, &mlr[5 * (size_t)k], sizeof(double) * 5); memcpy(q + 14, &mfl[3 * (size_t)k], sizeof(double) * 3);
-            q[17] = mg[k]; q[18] = t->last_repeat_lvl[k]; q[19] = t->last_first_pass_res[k];
-          }
+          // a share of ONE try runs the device-resident LM like the batch of the unsplit call does (never the host LM of single-frame tracking)
+          const int keep_mode = t->single_host_lm;
+          t->single_host_lm = 0;
+          local_rc = dmvio_hip_tracker_track_batch(t, m, ms.data(), me.data(), mp.data(), ma.data(), L - 1, nullptr, mlr.data(), mfl.data(), nullptr, nullptr, mg.data(), nullptr);
+          t->single_host_lm = keep_mode;
+          if (local_rc) { local_err = dmv_err(); rec.back() = 1.0; }
+          else
+            for (int k = 0; k < m; k++) {
+              double* q = &rec[(size_t)REC * (mine[k] - first)];
+              memcpy(q, &mp[7 * (size_t)k], sizeof(double) * 7); q[7] = ma[2 * k]; q[8] = ma[2 * k + 1];
+              memcpy(q + 9, &mlr[5 * (size_t)k], sizeof(double) * 5); memcpy(q + 14, &mfl[3 * (size_t)k], sizeof(double) * 3);
+              q[17] = mg[k]; q[18] = t->last_repeat_lvl[k]; q[19] = t->last_first_pass_res[k];
+            }
         }
         if (int r = t->xchg(rec.data(), rec.size())) return r;
+        if (local_rc) return failmsg("track_new_coarse: this rank's share of the hypotheses failed (" + local_err + ")");
+        if (rec.back() != 0.0) return failmsg("track_new_coarse: the share of the hypotheses of " + std::to_string((int)rec.back()) + " other rank(s) failed");
         for (int k = 0; k < cnt; k++) {
           const double* q = &rec[(size_t)REC * k];
           const int j = first + k;
@@ -1244,9 +1259,9 @@ int dmvio_hip_tracker_track_new_coarse(dmvio_hip_tracker* t, int new_slot, float
 }  // extern "C"
 int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, size_t)> allreduce_sum, int rank, int world) {
   if (!t) return failmsg("null tracker");
-  // DMVIO_HIP_TEST_SPLIT_WORLD1=1 (tests): a group of ONE rank still takes the split path — every try is "mine", the all-reduce is the identity — so that the exchange
-  // (RCCL on the context's stream included) runs on a one-device box
-  const bool force1 = world == 1 && allreduce_sum && getenv("DMVIO_HIP_TEST_SPLIT_WORLD1") && atoi(getenv("DMVIO_HIP_TEST_SPLIT_WORLD1")) != 0;
+  // dmvio_hip_tracker_debug_split_single_rank(t, 1) (tests): a group of ONE rank still takes the split path — every try is "mine", the all-reduce is the identity — so
+  // that the exchange (RCCL on the context's stream included) runs on a one-device box.  An explicit call on THIS tracker, never the environment.
+  const bool force1 = world == 1 && allreduce_sum && t->debug_split1;
   if ((world <= 1 && !force1) || !allreduce_sum) { t->xchg = nullptr; t->xrank = 0; t->xworld = 0; return 0; }
   if (rank < 0 || rank >= world) return failmsg("tracker_set_comm: 0 <= rank < world");
   std::lock_guard<std::mutex> lk(t->ctx->mu);
@@ -1254,6 +1269,12 @@ int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, si
   return 0;
 }
 dmvio_hip_ctx* dmv_tracker_ctx(dmvio_hip_tracker* t) { return t ? t->ctx : nullptr; }
+bool dmv_tracker_debug_split1(dmvio_hip_tracker* t) { return t && t->debug_split1; }
+extern "C" int dmvio_hip_tracker_debug_split_single_rank(dmvio_hip_tracker* t, int on) {
+  if (!t) return failmsg("null tracker");
+  t->debug_split1 = on != 0;
+  return 0;
+}
 extern "C" {
 #ifdef DMV_LM_TICKS
 extern "C" int dmvio_hip_debug_lm_ticks(double out8[8], int reset) {

@@ -64,7 +64,7 @@ struct dmvio_hip_ba {
   // thread (this stream, this lock) overlap on the device like coarseTracker / mapping do in the reference (FullSystem.cpp:980-985).
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  std::mutex mu;
+  std::recursive_mutex mu;   // every entry point that takes the handle holds it from its first line (entry points may call each other: recursive)
   dmvio_hip_ctx* ctx = nullptr;
   DmvBounce bounce;   // caller-owned arrays (and this file's short-lived host vectors) cross PCIe through the library's pinned memory (internal.h), on `stream`, under `mu`
   BAHost H;
@@ -155,6 +155,7 @@ struct dmvio_hip_ba {
   std::vector<dmvio_hip_ba_frame_view> vio_frames;
   hipEvent_t* prof = nullptr;        // dmvio_hip_ba_profile_chain: six events recorded between the launches of linearise -> per-point sums -> accumulate -> stitch -> gather
 };
+#define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
 #define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + rccl().getErrorString(r_) + " in " #x).c_str()); } while (0)
 
@@ -560,7 +561,7 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
 // Accumulation order (takes effect with the next dmvio_hip_ba_set_graph): k partial accumulators per bucket, 1 <= k <= 8.
 int dmvio_hip_ba_set_accumulators(dmvio_hip_ba* b, int k) {
   if (!b || k < 1 || k > 8) return failmsg("ba_set_accumulators: 1 <= k <= 8");
-  std::lock_guard<std::mutex> lk(b->mu);
+  BA_LOCK(b);
   b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = k == 1 ? 1 : 4 * k;
   b->graph_ready = false;
   return 0;
@@ -568,6 +569,7 @@ int dmvio_hip_ba_set_accumulators(dmvio_hip_ba* b, int k) {
 // The 74-float RawResidualJacobian per residual (dmvio_hip_ba_get_jacobians) is written by the linearisation only while this is on.
 int dmvio_hip_ba_keep_jacobians(dmvio_hip_ba* b, int on) {
   if (!b) return failmsg("null ba");
+  BA_LOCK(b);
   b->keep_fullJ = on != 0;
   return 0;
 }
@@ -575,7 +577,7 @@ int dmvio_hip_ba_keep_jacobians(dmvio_hip_ba* b, int on) {
 // ---- communicator of a window whose points are sharded over ranks (include/dmvio_hip.h)
 static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callbacks* cb, int rank, int world) {
   if (!b) return failmsg("null ba");
-  std::lock_guard<std::mutex> lk(b->mu);
+  BA_LOCK(b);
   if (world == 0 || (!comm && !cb)) { b->world = 0; b->rank = 0; b->nccl = nullptr; b->comm_cb = dmvio_hip_comm_callbacks{}; b->sys_ready = false; b->sums_fresh = false; return 0; }
   if (world < 1 || rank < 0 || rank >= world) return failmsg("ba_set_comm: 0 <= rank < world");
   if (cb && (!cb->allreduce_sum_f64 || !cb->allgather)) return failmsg("ba_set_comm_callbacks: both callbacks are required");
@@ -648,7 +650,7 @@ int dmvio_hip_comm_init_rank(dmvio_hip_ctx* ctx, const unsigned char id128[128],
 int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* t, void* nccl_comm, int rank, int world) {
   dmvio_hip_ctx* c = dmv_tracker_ctx(t);
   if (!c) return failmsg("null tracker");
-  const bool force1 = world == 1 && nccl_comm && getenv("DMVIO_HIP_TEST_SPLIT_WORLD1") && atoi(getenv("DMVIO_HIP_TEST_SPLIT_WORLD1")) != 0;   // test hook, see dmv_tracker_set_exchange
+  const bool force1 = world == 1 && nccl_comm && dmv_tracker_debug_split1(t);   // test hook (dmvio_hip_tracker_debug_split_single_rank), see dmv_tracker_set_exchange
   if (!nccl_comm || (world <= 1 && !force1)) return dmv_tracker_set_exchange(t, nullptr, 0, 0);
   ncclComm_t comm = (ncclComm_t)nccl_comm;
   RCCL_READY();
@@ -706,7 +708,7 @@ int dmvio_hip_comm_destroy(void* comm) {
 // The stream the mapping side enqueues on (default: a stream owned by the handle).  NULL restores an own stream.
 int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
   if (!b) return failmsg("null ba");
-  std::lock_guard<std::mutex> lk(b->mu);
+  BA_LOCK(b);
   HIPCHK(hipSetDevice(b->ctx->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (b->own_stream) { HIPCHK(hipStreamDestroy(b->stream)); b->own_stream = false; }
@@ -718,8 +720,12 @@ int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
 int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]) {
   if (!b || !slots || !pose7_w2c || !fxfycxcy) return failmsg("ba_set_window: null argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
   if (F < 1 || F > BA_MAXF) return failmsg("ba_set_window: 1 <= F <= 8");
+  // a threshold still on its way from the previous window's last accepted step (th_ticket follows the decision) belongs to THAT window: it must neither be waited for
+  // after the host-coherent record is cleared (set_graph) nor land in the new window's newest keyframe
+  b->th_pending = false;
   BAHost& H = b->H;
   H.F = F;
   H.calibInitScaled(fxfycxcy);
@@ -749,6 +755,7 @@ int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const doub
 
 int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double* bM) {
   if (!b || !HM || !bM) return failmsg("ba_set_marg_prior: null argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
   const int n = b->H.n();
   b->H.HM.assign(HM, HM + (size_t)n * n); b->H.bM.assign(bM, bM + n);
@@ -758,11 +765,11 @@ int dmvio_hip_ba_set_marg_prior(dmvio_hip_ba* b, const double* HM, const double*
 // FullSystem::flagPointsForRemoval's relinearisation (FullSystem.cpp:829-859) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:678-742)
 int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candidates, unsigned char* decision, double* Hadd, double* badd, int* resInM, int update_prior) {
   if (!b || !b->graph_ready) return failmsg("ba_marginalize_points: window / graph not set");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
   if (!candidates || !decision) return failmsg("ba_marginalize_points: null argument");
   dmvio_hip_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
-  std::lock_guard<std::mutex> lk(b->mu);
   BAHost& H = b->H;
   const int N = H.N, R = H.R, n = H.n();
   hipStream_t s = b->stream;
@@ -808,14 +815,15 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
   if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
   BAHost& H = b->H;
   if (H.F < 1) return failmsg("ba_set_graph: set_window first");
   if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
   dmvio_hip_ctx* c = b->ctx;
-  std::lock_guard<std::mutex> lk(b->mu);
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->th_pending = false;   // the stream is drained and h_res is cleared below (th_ticket restarts at 0 while b->ticket keeps counting): nothing of the old graph may be awaited
   freeDevice(b);
   // the arena of the previous graph, cleared for this one (one memset per chunk on the handle's stream, one wait — the uploads below also use the NULL stream)
   for (auto& ch : b->arena.chunks) HIPCHK(hipMemsetAsync(ch.first, 0, ch.second, b->stream));
@@ -945,7 +953,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   return 0;
 }
 
-#define BA_READY(b) do { if (!(b) || !(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
+#define BA_READY_LOCKED(b) do { if (!(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
+// first statement of an entry point: null check, the handle's lock for the whole call (declares a guard in the function's scope), then the state checks
+#define BA_READY(b) if (!(b)) return failmsg("ba: null handle"); BA_LOCK(b); BA_READY_LOCKED(b)
 
 // activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
@@ -958,7 +968,6 @@ int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
 }
 int dmvio_hip_ba_linearize(dmvio_hip_ba* b, int fix, double* energy) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   double e = 0;
   if (int r = linearizeAll(b, fix != 0, &e)) return r;
   if (energy) *energy = e;
@@ -990,13 +999,13 @@ int dmvio_hip_ba_get_jacobians(dmvio_hip_ba* b, float* J74) {
 }
 int dmvio_hip_ba_get_frame_energy_th(dmvio_hip_ba* b, float* th) {
   if (!b || !th) return failmsg("null argument");
+  BA_LOCK(b);
   if (int r = resolveTh(b)) return r;
   for (int f = 0; f < b->H.F; f++) th[f] = b->H.fr[f].frameEnergyTH;
   return 0;
 }
 int dmvio_hip_ba_accumulate(dmvio_hip_ba* b, double* HA, double* bA, double* Hsc, double* bsc, int* resInA) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   if (int r = accumulate(b)) return r;
   const int n = b->H.n();
   const double* p = b->h_sys;
@@ -1023,7 +1032,6 @@ int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hc
 // BAGTSAMIntegration::computeBAUpdate in VIO mode, EnergyFunctional.cpp:958-969), back-substitute on the device.
 int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_out) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   if (int r = accumulate(b)) return r;
   const int n = b->H.n();
   const double* p = b->h_sys;
@@ -1034,12 +1042,12 @@ int dmvio_hip_ba_solve(dmvio_hip_ba* b, int iteration, double lambda, double* x_
 }
 int dmvio_hip_ba_resubstitute(dmvio_hip_ba* b, const double* x) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   std::vector<double> xv(x, x + b->H.n());
   return resubstitute(b, xv);
 }
 int dmvio_hip_ba_get_point_hessian(dmvio_hip_ba* b, float* idepth_hessian) {
   if (!b || !b->graph_ready || !idepth_hessian) return failmsg("ba_get_point_hessian: bad argument");   // a pure read: the loop state (sys_ready) is left alone
+  BA_LOCK(b);
   HIPCHK(hipSetDevice(b->ctx->device));
   HIPCHK(b->bounce.d2h(idepth_hessian, b->P.idepth_hessian, sizeof(float) * b->H.N, b->stream));
   HIPCHK(b->bounce.finish(b->stream));
@@ -1055,6 +1063,7 @@ int dmvio_hip_ba_get_points(dmvio_hip_ba* b, float* idepth, float* step) {
 }
 int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double aff[2], double state10[10]) {
   if (!b || f < 0 || f >= b->H.F) return failmsg("ba_get_frame: bad argument");
+  BA_LOCK(b);
   const BAFrameHost& fr = b->H.fr[f];
   if (pose7_w2c) poseTo7(fr.w2c, pose7_w2c);
   if (aff) { aff[0] = fr.state_scaled[6]; aff[1] = fr.state_scaled[7]; }
@@ -1065,7 +1074,7 @@ int dmvio_hip_ba_get_frame(dmvio_hip_ba* b, int f, double pose7_w2c[7], double a
 // without keyframe `frame` ((n-8) x (n-8), n-8); also returns the current prior when HM_cur / bM_cur are given.
 int dmvio_hip_ba_marginalize_frame(dmvio_hip_ba* b, int frame, double* HM_new, double* bM_new) {
   if (!b || !HM_new || !bM_new || frame < 0 || frame >= b->H.F) return failmsg("ba_marginalize_frame: bad argument");
-  std::lock_guard<std::mutex> lk(b->mu);
+  BA_LOCK(b);
   std::vector<double> Hn, bn;
   b->H.marginalizeFrame(frame, Hn, bn);
   memcpy(HM_new, Hn.data(), sizeof(double) * Hn.size());
@@ -1074,6 +1083,7 @@ int dmvio_hip_ba_marginalize_frame(dmvio_hip_ba* b, int frame, double* HM_new, d
 }
 int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
   if (!b || !HM || !bM) return failmsg("ba_get_marg_prior: null argument");
+  BA_LOCK(b);
   const int n = b->H.n();
   if (b->H.HM.size() != (size_t)n * n) { memset(HM, 0, sizeof(double) * n * n); memset(bM, 0, sizeof(double) * n); return 0; }
   memcpy(HM, b->H.HM.data(), sizeof(double) * n * n); memcpy(bM, b->H.bM.data(), sizeof(double) * n);
@@ -1082,8 +1092,8 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* b, double* HM, double* bM) {
 // FrameHessian::setState (HessianBlocks.h:179-199) for one keyframe of the window, followed by FullSystem::setPrecalcValues
 int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10]) {
   if (!b || !state10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_state: bad argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
-  std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetState(b->H.fr[f], state10);
   b->H.setPrecalcValues();
   return 0;
@@ -1092,8 +1102,8 @@ int dmvio_hip_ba_set_frame_state(dmvio_hip_ba* b, int f, const double state10[10
 // of every keyframe and CalibHessian::value_zero (unscaled units) where they differ from what dmvio_hip_ba_set_window starts with.
 int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* b, int f, const double state_zero10[10]) {
   if (!b || !state_zero10 || f < 0 || f >= b->H.F) return failmsg("ba_set_frame_zero: bad argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
-  std::lock_guard<std::mutex> lk(b->mu);
   BAHost::frameSetStateZero(b->H.fr[f], state_zero10);
   b->pre_static_valid = false;
   b->H.frameTakeData(b->H.fr[f]);
@@ -1102,8 +1112,8 @@ int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* b, int f, const double state_zero1
 }
 int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* b, const double* state_zero10, const double* state10) {
   if (!b || b->H.F < 1) return failmsg("ba_set_frame_states: bad argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
-  std::lock_guard<std::mutex> lk(b->mu);
   for (int f = 0; f < b->H.F; f++) {
     if (state_zero10) { BAHost::frameSetStateZero(b->H.fr[f], state_zero10 + 10 * f); b->H.frameTakeData(b->H.fr[f]); }
     if (state10) BAHost::frameSetState(b->H.fr[f], state10 + 10 * f);
@@ -1114,7 +1124,7 @@ int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* b, const double* state_zero10, c
 }
 int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
   if (!b || !th) return failmsg("ba_set_frame_energy_th: null argument");
-  std::lock_guard<std::mutex> lk(b->mu);
+  BA_LOCK(b);
   b->th_pending = false;
   for (int f = 0; f < b->H.F; f++) b->H.fr[f].frameEnergyTH = th[f];
   b->th_dirty = true;
@@ -1122,8 +1132,8 @@ int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
 }
 int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const double value_zero[4]) {
   if (!b || !value || !value_zero) return failmsg("ba_set_calib_values: null argument");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
-  std::lock_guard<std::mutex> lk(b->mu);
   for (int i = 0; i < 4; i++) b->H.c_value_zero[i] = value_zero[i];
   b->H.calibSetValue(value);
   b->H.setPrecalcValues();
@@ -1131,17 +1141,20 @@ int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const 
 }
 int dmvio_hip_ba_get_calib_values(dmvio_hip_ba* b, double value[4], double value_zero[4]) {
   if (!b) return failmsg("null ba");
+  BA_LOCK(b);
   if (value) memcpy(value, b->H.c_value, sizeof(double) * 4);
   if (value_zero) memcpy(value_zero, b->H.c_value_zero, sizeof(double) * 4);
   return 0;
 }
 int dmvio_hip_ba_get_res_in_a(dmvio_hip_ba* b, int* resInA) {
   if (!b || !resInA) return failmsg("null argument");
+  BA_LOCK(b);
   *resInA = b->H.resInA;
   return 0;
 }
 int dmvio_hip_ba_get_calib(dmvio_hip_ba* b, double fxfycxcy[4]) {
   if (!b) return failmsg("null ba");
+  BA_LOCK(b);
   memcpy(fxfycxcy, b->H.c_value_scaled, sizeof(double) * 4);
   return 0;
 }
@@ -1338,7 +1351,6 @@ int dmvio_hip_ba_profile_chain(dmvio_hip_ba* b, int reps, float us5[5]) {
   BA_READY(b);
   if (!us5 || reps < 1) return failmsg("ba_profile_chain: bad argument");
   if (sharded(b)) return failmsg("ba_profile_chain: single-device windows only");
-  std::lock_guard<std::mutex> lk(b->mu);
   struct Events {   // destroyed on every way out
     hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Events() { for (int k = 0; k < 6; k++) if (e[k]) hipEventDestroy(e[k]); }
@@ -1364,14 +1376,16 @@ int dmvio_hip_ba_profile_chain(dmvio_hip_ba* b, int reps, float us5[5]) {
 // diagnostics: in-kernel timeline of the last decision pass, 100 MHz ticks since its workgroup started (begin, energy, keys, selected)
 int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* b, int ticks4[4]) {
   if (!b || !b->h_res || !ticks4) return failmsg("null argument");
+  BA_LOCK(b);
   for (int i = 0; i < 4; i++) ticks4[i] = b->h_res->ticks[i];
   return 0;
 }
 
 int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io, double lastE[3], int* accepted) {
-  const bool sums_fresh = b && b->sums_fresh, sys_ready = b && b->sys_ready;
-  BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
+  if (!b) return failmsg("ba: null handle");
+  BA_LOCK(b);
+  const bool sums_fresh = b->sums_fresh, sys_ready = b->sys_ready;
+  BA_READY_LOCKED(b);
   b->sums_fresh = sums_fresh; b->sys_ready = sys_ready;
   bool acc = false;
   double lam = *lambda_io;
@@ -1385,7 +1399,6 @@ int dmvio_hip_ba_gn_iteration(dmvio_hip_ba* b, int iteration, double* lambda_io,
 // local systems / energies of all ranks (RCCL all-reduce) between these calls; every rank then solves the identical reduced system.
 int dmvio_hip_ba_backup(dmvio_hip_ba* b) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   b->H.backupFrames();
   float d0, d1;
   return pointStep(b, 0, 0.f, &d0, &d1);
@@ -1393,7 +1406,6 @@ int dmvio_hip_ba_backup(dmvio_hip_ba* b) {
 int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* x_out) {
   BA_READY(b);
   if (!HA || !bA || !Hsc || !bsc) return failmsg("ba_solve_system: null argument");
-  std::lock_guard<std::mutex> lk(b->mu);
   std::vector<double> x;
   b->H.solveSystem(iteration, lambda, HA, bA, Hsc, bsc, x);
   if (x_out) memcpy(x_out, x.data(), sizeof(double) * b->H.n());
@@ -1401,7 +1413,6 @@ int dmvio_hip_ba_solve_system(dmvio_hip_ba* b, int iteration, double lambda, con
 }
 int dmvio_hip_ba_step(dmvio_hip_ba* b, float stepfac, float sums6[6]) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   float fs[4], sumID = 0, sumNID = 0;
   b->H.stepFrames(stepfac, fs);
   if (int r = pointStep(b, 1, stepfac, &sumID, &sumNID)) return r;
@@ -1411,7 +1422,6 @@ int dmvio_hip_ba_step(dmvio_hip_ba* b, float stepfac, float sums6[6]) {
 }
 int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   b->H.restoreFrames();
   float d0, d1;
   if (int r = pointStep(b, 2, 0.f, &d0, &d1)) return r;
@@ -1423,7 +1433,6 @@ int dmvio_hip_ba_restore(dmvio_hip_ba* b) {
 // gather them over all shards.
 int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float* new_frame_energies, int* n_new_frame_energies) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   double e = 0;
   if (int r = linearizeAll(b, fix != 0, &e, 0, true)) return r;   // the threshold is set by the caller from the energies gathered over all shards
   if (energy) *energy = e;
@@ -1438,6 +1447,7 @@ int dmvio_hip_ba_linearize_local(dmvio_hip_ba* b, int fix, double* energy, float
 }
 int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
   if (!b) return failmsg("null ba");
+  BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
   b->H.fr[b->H.F - 1].frameEnergyTH = th;
   b->th_dirty = true;
@@ -1445,6 +1455,7 @@ int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
 }
 int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
   if (!b) return failmsg("null ba");
+  BA_LOCK(b);
   if (EL) *EL = b->H.calcLEnergyFrames();
   if (EM) *EM = b->H.calcMEnergy();
   return 0;
@@ -1514,7 +1525,6 @@ static int optimizeImpl(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_call
 }
 int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
   BA_READY(b);
-  std::lock_guard<std::mutex> lk(b->mu);
   return optimizeImpl(b, mnumOptIts, nullptr, nullptr, rmse, finalEnergy, iterations, trace);
 }
 // FullSystem::optimize with the reference's DEFAULT solver branch (settings.cpp:37 setting_useGTSAMIntegration = true): the same device-resident loop, the solve and
@@ -1524,7 +1534,6 @@ int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_b
   BA_READY(b);
   if (!cb || !cb->computeBAUpdate) return failmsg("ba_optimize_vio: the computeBAUpdate hook is required (dmvio_hip_ba_optimize runs the library's own solver)");
   if (sharded(b)) return failmsg("ba_optimize_vio: not available for a window sharded over ranks (every rank would have to run identical hooks)");
-  std::lock_guard<std::mutex> lk(b->mu);
   return optimizeImpl(b, mnumOptIts, cb, opt, rmse, finalEnergy, iterations, trace);
 }
 // dmvio_hip_ba_solve_ldlt with the signature of the computeBAUpdate hook: a ready-made hook for callers that fall back to the visual-only solve (user is ignored)

@@ -10,13 +10,17 @@
 #include "common.h"
 
 std::string& dmv_err();
+// counts the errors recorded on this thread: a download registered with DmvBounce::d2h is only delivered by a finish() of the SAME error epoch — an entry point that
+// failed between its d2h() and its finish() returns early and leaves registrations that point at dead stack buffers or at caller arrays that may be gone by then
+unsigned int& dmv_err_epoch();
 static inline int fail(const char* what, const char* file, int line, hipError_t e) {
   char buf[512];
   snprintf(buf, sizeof(buf), "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
   dmv_err() = buf;
+  dmv_err_epoch()++;
   return -1;
 }
-static inline int failmsg(const std::string& m) { dmv_err() = m; return -2; }
+static inline int failmsg(const std::string& m) { dmv_err() = m; dmv_err_epoch()++; return -2; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(#x, __FILE__, __LINE__, _e); } while (0)
 #define HIPCHKP(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fail(#x, __FILE__, __LINE__, _e); return nullptr; } } while (0)
 
@@ -29,7 +33,7 @@ static inline int failmsg(const std::string& m) { dmv_err() = m; return -2; }
 struct DmvBounce {
   char* h = nullptr;
   size_t cap = 0, used = 0;
-  struct Out { void* dst; size_t off, bytes; };
+  struct Out { void* dst; size_t off, bytes; unsigned int epoch; };
   std::vector<Out> outs;
   hipError_t reserve(size_t bytes, hipStream_t s, size_t* off) {
     const size_t need = (bytes + 255) & ~(size_t)255;
@@ -55,12 +59,14 @@ struct DmvBounce {
   hipError_t d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
     size_t off; hipError_t e = reserve(bytes, s, &off); if (e != hipSuccess) return e;
-    outs.push_back({h_dst, off, bytes});
-    return hipMemcpyAsync(h + off, d_src, bytes, hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(h + off, d_src, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) outs.push_back({h_dst, off, bytes, dmv_err_epoch()});   // registered only once the copy is really on its way
+    return e;
   }
   hipError_t finish(hipStream_t s) {
     hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) for (const Out& o : outs) memcpy(o.dst, h + o.off, o.bytes);
+    const unsigned int now = dmv_err_epoch();
+    if (e == hipSuccess) for (const Out& o : outs) if (o.epoch == now) memcpy(o.dst, h + o.off, o.bytes);   // registrations of a call that failed since are dropped
     outs.clear(); used = 0;
     return e;
   }
@@ -91,3 +97,4 @@ struct dmvio_hip_ctx {
 struct dmvio_hip_tracker;
 int dmv_tracker_set_exchange(dmvio_hip_tracker* t, std::function<int(double*, size_t)> allreduce_sum, int rank, int world);
 dmvio_hip_ctx* dmv_tracker_ctx(dmvio_hip_tracker* t);
+bool dmv_tracker_debug_split1(dmvio_hip_tracker* t);

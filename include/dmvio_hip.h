@@ -340,9 +340,15 @@ int dmvio_hip_ba_set_comm_callbacks(dmvio_hip_ba* ba, const dmvio_hip_comm_callb
  * it already ends the loop) and splits the remaining tries round-robin over the ranks, ONE all-reduce (fp64 sum of 20 doubles per try, each written by exactly one rank)
  * hands every rank all results, and the reference's sequential abort / winner rule (FullSystem.cpp:419-489) is replayed identically everywhere.  nccl_comm: an
  * ncclComm_t whose rank `rank` lives on this tracker's device (not owned); world <= 1 or NULL detaches.  The callbacks form uses allreduce_sum_f64 of
- * the dmvio_hip_comm_callbacks struct above.  Collective: every rank must make the same call. */
+ * the dmvio_hip_comm_callbacks struct above.  Collective: every rank must make the same call.  Every rank ends with the same bits; against the single-device call the
+ * winner and the number of tries are the same and the pose agrees to ~1e-5 (a share of 31 / world tries runs with another cluster size, i.e. another grouping of the fp32
+ * partial sums, than one batch of 30).  A rank whose share fails still enters the exchange with its error flagged, and the call then fails on EVERY rank. */
 int dmvio_hip_tracker_set_comm(dmvio_hip_tracker* trk, void* nccl_comm, int rank, int world);
 int dmvio_hip_tracker_set_comm_callbacks(dmvio_hip_tracker* trk, const dmvio_hip_comm_callbacks* cb, int rank, int world);
+/* Test hook (no counterpart in the reference): with on != 0 a LATER dmvio_hip_tracker_set_comm / _set_comm_callbacks with world == 1 keeps the split path — every try is
+ * this rank's, the all-reduce over one rank is the identity — so the whole exchange (pinned staging, device buffer, ncclAllReduce on the context's stream) can be
+ * exercised on a one-device box.  Off by default; nothing in the environment switches it on. */
+int dmvio_hip_tracker_debug_split_single_rank(dmvio_hip_tracker* trk, int on);
 /* Convenience wrappers over RCCL for callers without their own communicator: ncclGetUniqueId (128 bytes, to be distributed to all ranks by
  * the caller), ncclCommInitRank on the context's device, ncclCommDestroy. */
 int dmvio_hip_comm_unique_id(unsigned char id128[128]);

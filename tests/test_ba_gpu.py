@@ -214,6 +214,28 @@ def test_gn_iterations_through_rejected_steps_match_oracle(pkg, oracle, synth, g
         assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
 
 
+def test_new_graph_right_after_an_accepted_iteration_call(pkg, oracle, synth, gpu_required):
+    """An accepted dmvio_hip_ba_gn_iteration leaves the newest keyframe's threshold "on its way" (published a few microseconds behind the decision).  A NEW window set on
+    the same handle right afterwards must neither wait for that threshold (the host-coherent record is cleared, its ticket restarts) nor inherit it: the new window
+    linearises like a fresh handle does, twenty times in a row."""
+    a = synth.ba_case(256, 256, n_frames=5, n_points=300, seed=31)
+    b = synth.ba_case(256, 256, n_frames=5, n_points=320, seed=32)
+    ctx = pkg.Context(256, 256, n_slots=10)
+    for k in range(5):
+        ctx.frame_upload(k, a["imgs"][k]); ctx.frame_upload(5 + k, b["imgs"][k])
+    fresh = pkg.BundleAdjusterHip(ctx, accumulators=1); fresh.set_case(b, list(range(5, 10)))
+    fresh.activate_all(); e_fresh = fresh.linearize_all(False); th_fresh = fresh.frame_energy_th()
+    ba = pkg.BundleAdjusterHip(ctx, accumulators=1)
+    for rep in range(20):
+        ba.set_case(a, list(range(5)))
+        ba.activate_all(); e = ba.linearize_all(False); ba.apply_res()
+        acc, lam, lE = ba.gn_iteration(0, 1e-5, [e, 0.0, 0.0])
+        assert acc                                         # an accepted step: its threshold is still pending when the next graph arrives
+        ba.set_case(b, list(range(5, 10)))
+        ba.activate_all()
+        assert ba.linearize_all(False) == e_fresh and np.array_equal(ba.frame_energy_th(), th_fresh), rep
+
+
 def test_optimize_loop_equals_iteration_calls_through_rejected_steps(pkg, oracle, synth, gpu_required):
     """dmvio_hip_ba_optimize does not wait for the relinearisation that follows a rejected step (the restored state's energy stays on the device for the next
     accept test); the per-iteration entry point does.  Thirty iterations, most of them rejected: same accept sequence, same energies, bit for bit."""

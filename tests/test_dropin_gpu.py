@@ -163,11 +163,16 @@ def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path,
           "entry); idepth_hessian after optimize within %.1e; decisions on a Hessian re-accumulated at the post-optimisation state differ for %d points" % (tuple(mg) + (hess_rel, reacc)))
     assert mg[0] >= 5 and mg[1] > 500 and unknown == 0 and mg[4] < 1e-4 and mg[5] < 1e-4, (mg, unknown)
     # the marginalise-or-drop rule (FullSystem.cpp:846) reads the idepth_hessian the last solveSystemF of this keyframe's optimize left behind: the device's own value takes the
-    # same decision for every point, and the same residuals enter the prior in every call
-    # (idepth_hessian itself — a sum of squared image-gradient projections at a state that agrees to ~1e-6 — measured: worst point of ~20k within 1.6e-3 relative)
-    assert mg[2] == 0 and mg[3] == 0 and hess_rel < 1e-2, (mg, hess_rel)
-    # (the shadow's own marginalize_points call sees a Hessian accumulated at ANOTHER linearisation point — the state after the last accepted step —: a few decisions near the threshold differ there)
+    # same decision for every point, and the same residuals enter the prior in every call; every live window runs the same number of Gauss-Newton iterations (solveSystemF
+    # calls of the reference's own run) and ends with the same residual count in the last accumulation.
+    # With the reference's single-threaded summation order (accumulators = 1) all of that holds exactly.  The library's default order (4 partial accumulators per bucket, the
+    # structure of the reference's multi-threaded mode) differs from it in the last bits of H and b, i.e. of the step: measured, in ONE of 50 windows ONE residual whose energy
+    # sits at the outlier threshold ends on the other side (resInA differs by one; that point's idepth_hessian then differs by its whole contribution) — bounded, not exact.
+    exact = accumulators == 1
+    assert sh["n_opt_iter_diff"] == 0, sh
+    assert mg[2] <= (0 if exact else 1) and mg[3] <= (0 if exact else 1), mg
+    assert sh["n_resInA_diff"] <= (0 if exact else 1), sh
+    assert hess_rel < 1e-2 or (not exact and sh["n_resInA_diff"] > 0), hess_rel       # worst point of ~20k per run; measured 1.6e-3 without a flipped residual
+    # (the shadow's own marginalize_points call sees a Hessian accumulated at ANOTHER linearisation point — the state after the last accepted step —: decisions near the threshold may differ there)
     assert reacc <= 0.01 * mg[1]
-    # optimize: every live window — same number of Gauss-Newton iterations (solveSystemF calls of the reference's own run), same residual count in the last accumulation
-    assert sh["n_opt_iter_diff"] == 0 and sh["n_resInA_diff"] == 0, sh
     assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh

@@ -413,11 +413,10 @@ def test_track_new_coarse_hypotheses_split_over_ranks(pkg, synth, oracle, gpu_re
     assert out[0][0]["winner"] == single[0]["winner"] >= 2             # well-conditioned: a later try wins
 
 
-def test_track_new_coarse_exchange_over_rccl_on_one_device(pkg, synth, oracle, gpu_required, monkeypatch):
+def test_track_new_coarse_exchange_over_rccl_on_one_device(pkg, synth, oracle, gpu_required):
     """The RCCL transport of the hypothesis split (dmvio_hip_tracker_set_comm) on a one-device box: a communicator of ONE rank, the split path forced by the library's test hook
     (every try is this rank's, the all-reduce over one rank is the identity): the records go through the pinned staging area, the device buffer and ncclAllReduce on the
     context's stream and come back — the answer must be the unsplit call's, within the rounding of a different cluster size (one batch of 32 instead of 1 + 32)."""
-    monkeypatch.setenv("DMVIO_HIP_TEST_SPLIT_WORLD1", "1")
     w = h = 256
     case = synth.tracking_case(w, h, n_ref=600, n_frames=1)
     f = case["frames"][0]
@@ -431,6 +430,10 @@ def test_track_new_coarse_exchange_over_rccl_on_one_device(pkg, synth, oracle, g
     single = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
     comm = pkg.RcclCommunicator(ctx, pkg.RcclCommunicator.unique_id(ctx.L), 0, 1)
     assert comm.info() == (1, 0)
+    trk.set_comm(comm, 0, 1)                         # world 1 without the hook: no exchange is installed, the call is the unsplit one bit for bit
+    plain = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
+    assert all(np.array_equal(np.asarray(plain[k]), np.asarray(single[k]), equal_nan=True) for k in ("pose7", "aff", "achievedRes", "flow"))
+    trk.debug_split_single_rank(True)                # the library's explicit test hook (an environment variable cannot switch it on)
     trk.set_comm(comm, 0, 1)
     a = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
     b = trk.trackNewCoarse(1, tries, lastCoarseRMSE=np.full(5, 100.0), reTrackThreshold=0.2)
