@@ -795,14 +795,13 @@ def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
     return out
 
 
-def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev):
+def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev, M=8):
     """What ONE GPU sustains with several windows in flight — the BA analogue of the tracker's 4096-frame batch.  A single window is a chain of dependent sub-10-us
     launches on a 256-CU device (latency-bound: `ba.value`); K host threads, each optimising its own fresh windows through its own dmvio_hip_ba handles (own HIP stream, own
     lock, own pinned result block), overlap those chains.  Every thread owns M windows, all set up BEFORE the timed region (set_graph is per-keyframe set-up, not iteration
     work); timed: every thread runs dmvio_hip_ba_optimize(6) on its M windows one after the other.  value = accepted iterations of all threads / wall time."""
     import threading
     n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    M = 6
     levels = [k for k in (1, 2, 4, 8, 16) if k <= max(1, n_cpu - 1)]       # the waits are polls of host-coherent memory: one core per thread
     slots = list(range(F))
     pool = []

@@ -50,7 +50,7 @@ struct BAHost {
   int w = 0, h = 0, F = 0, N = 0, R = 0;
   double c_value[4], c_value_zero[4], c_value_scaled[4], c_step[4], c_value_backup[4], c_vmz[4];
   float c_f[4], c_i[4];
-  BAFrameHost fr[BA_MAXF];
+  BAFrameHost fr[BA_MAXF_CAP];
   std::vector<double> adHost, adTarget;      // F*F x 64, index h + t*F
   std::vector<float> adHostF, adTargetF;
   std::vector<BAPrecalc> pre;                // F*F, index h + F*t
@@ -257,7 +257,7 @@ struct BAHost {
   // same order, on the TRANSPOSED triangle (m[c * ld + r] = lower[r][c]) so that the rank update of step k runs along contiguous rows:
   // acc[r] += L[r][j] * temp[j] for j ascending, vectorised over r.  Host only (the 68x68 system of the window).
   __attribute__((target("avx2"))) static void ldltSolveTransposed(double* m, const int ld, double* d, const int n) {
-    constexpr int NMAX = 4 + 8 * BA_MAXF;
+    constexpr int NMAX = 4 + 8 * BA_MAXF_CAP;
     int tr[NMAX];
     double temp[NMAX], acc[NMAX];
     bool zero = false;
@@ -324,10 +324,10 @@ struct BAHost {
     hfScratch.resize((size_t)nn * nn); htScratch.resize((size_t)nn * nn);
     double* HF = hfScratch.data();
     double* Ht = htScratch.data();
-    double bF[4 + 8 * BA_MAXF], sv[4 + 8 * BA_MAXF], bs[4 + 8 * BA_MAXF];
+    double bF[4 + 8 * BA_MAXF_CAP], sv[4 + 8 * BA_MAXF_CAP], bs[4 + 8 * BA_MAXF_CAP];
     // HFinal_top = HL_top + HM + HA_top, bFinal_top = bL_top + bM_top + bA_top - b_sc (EnergyFunctional.cpp:906-907), summed in that order: HL_top / bL_top hold only the priors
     // (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302; no linearised residuals outside marginalisation), zero elsewhere
-    double HLd[4 + 8 * BA_MAXF], bL[4 + 8 * BA_MAXF];
+    double HLd[4 + 8 * BA_MAXF_CAP], bL[4 + 8 * BA_MAXF_CAP];
     for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
     for (int i = 0; i < nn; i++)
@@ -359,7 +359,7 @@ struct BAHost {
     solvePrepared = false;
     const std::vector<double>& HMs = priorH();
     const bool haveM = HMs.size() == (size_t)nn * nn;
-    double HLd[4 + 8 * BA_MAXF], bL[4 + 8 * BA_MAXF];
+    double HLd[4 + 8 * BA_MAXF_CAP], bL[4 + 8 * BA_MAXF_CAP];
     for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
     const double fac = 1.0f / (1 + lambda);

@@ -28,7 +28,11 @@
 
 namespace dmv {
 
+// Window size (the reference's setting_maxFrames, util/settings.cpp:100, a run-time setting registered in util/MainSettings.cpp:223,246): F is a run-time value of every
+// kernel.  Two compiled sizes of the per-pair kernel ARGUMENTS (BAPreDyn, ResubArgs travel as kernel arguments so that no upload sits between the host's step and the
+// launch): windows of up to BA_MAXF keyframes (the reference's default 7 + the newest) use the compact ones, larger windows up to BA_MAXF_CAP the wide ones.
 #define BA_MAXF 8
+#define BA_MAXF_CAP 12
 enum { BA_IN = 0, BA_OOB = 1, BA_OUTLIER = 2 };
 enum { REC_FLOATS = 52 };
 // compact residual record layout (floats)
@@ -56,17 +60,20 @@ struct BAPrecalc {  // FrameFramePrecalc (HessianBlocks.h:80-107), the members l
 // The members of BAPrecalc that change with every step of the GN loop (PRE_KRKiTll, PRE_KtTll, PRE_aff_mode) for the F*(F-1) ordered pairs
 // h != t, passed as kernel arguments: the loop's linearisations then need no table upload between the host's step and the launch (R0, t0,
 // b0 — functions of the evaluation point — stay in the device table of the last full upload).
-struct BAPreDyn { float v[BA_MAXF * (BA_MAXF - 1)][14]; };
+template <int MF> struct BAPreDynT { float v[MF * (MF - 1)][14]; };
+typedef BAPreDynT<BA_MAXF_CAP> BAPreDyn;   // the host keeps the wide form; baNarrow() cuts it down for a launch (pair index h (F-1) + t' < F (F-1): a prefix)
 __host__ __device__ __forceinline__ int baPairIndex(const int h, const int t, const int F) { return h * (F - 1) + (t < h ? t : t - 1); }
 // back-substitution inputs: xc (4 floats) and xAd (F*F x 8 floats, index h*F + t; EnergyFunctional.cpp:280-282), passed as kernel arguments
-struct ResubArgs { float xc[4]; float xAd[BA_MAXF * BA_MAXF * 8]; };
+template <int MF> struct ResubArgsT { float xc[4]; float xAd[MF * MF * 8]; };
+typedef ResubArgsT<BA_MAXF_CAP> ResubArgs;
+template <class Narrow, class Wide> static inline Narrow baNarrow(const Wide& w) { Narrow n; static_assert(sizeof(Narrow) <= sizeof(Wide), "prefix"); __builtin_memcpy(&n, &w, sizeof(Narrow)); return n; }
 struct BAWindow {
   int F, w, h, N, R;
   float fx, fy, cx, cy, fxi, fyi, cxi, cyi;  // CalibHessian::fxl().. / fxli()..
   float wM3, hM3;
   float huberTH, outlierTHSum, modeA, modeB;
-  int slot[BA_MAXF];
-  float frameEnergyTH[BA_MAXF];
+  int slot[BA_MAXF_CAP];
+  float frameEnergyTH[BA_MAXF_CAP];
 };
 
 struct BAPoints {   // SoA, N entries
@@ -109,7 +116,7 @@ struct BACtl {
   double lastE0;             // photometric energy of the state the window stands at: set by every decision pass (an accepted step's energy, a plain or a
                              // restored state's), read by the next accept test — the host need not wait for a rejected step's relinearisation
 };
-#define BA_GATHER_MAX_BLOCKS 64
+#define BA_GATHER_MAX_BLOCKS 96   // (2 (n^2 + n) + 256) / 256 workgroups of k_ba_stitch_gather, n = 4 + 8 BA_MAXF_CAP = 100: 80
 struct BAHostRes {           // host-coherent pinned memory, polled by the host
   double E[2];               // [0] energy of the last plain / stepped-state linearisation, [1] of the relinearisation after a rejected step
   float th[2];               // newest keyframe's threshold after each of them
@@ -124,7 +131,7 @@ struct BAHostRes {           // host-coherent pinned memory, polled by the host
 struct BADecide {
   const float* newestE;      // state_NewEnergyWithOutlier of the residuals that target the newest keyframe (BARes::newestE)
   int n_newest, newestFrame;
-  float* frameTH;            // [BA_MAXF] FrameHessian::frameEnergyTH, device copy read by the linearisation
+  float* frameTH;            // [BA_MAXF_CAP] FrameHessian::frameEnergyTH, device copy read by the linearisation
   double* epart;             // per-workgroup energy partials
   float thN, thFacMedian, thConstWeight, overallW, thCap;   // setting_frameEnergyTHN / FacMedian / ConstWeight, setting_overallEnergyTHWeight, IMU cap (<= 0: none)
   int mode;                  // -1 no decision pass at all, 0 energy + threshold, 1 + accept test of a stepped state, 2 relinearisation after a rejected step
@@ -326,10 +333,11 @@ __device__ __forceinline__ float seqSum8(const float v) {
 // gate: BA_GATE_REJECTED = this launch is the relinearisation that follows a rejected step (loadSateBackup + linearizeAll,
 // FullSystemOptimize.cpp:575-581): it returns at once when the step was accepted.  use_backup: the point part of loadSateBackup rides along
 // (idepth = idepth_zero = idepth_backup, written back by the group of the point's first residual).
+template <int MF>
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
                                                                const FrameStore fs, float* __restrict__ fullJ,
                                                                const unsigned char* __restrict__ pt_mask, const BADecide D, const int gate, const int use_backup,
-                                                               const BAPreDyn T, const int use_dyn, const ResubArgs X, const int do_resub) {
+                                                               const BAPreDynT<MF> T, const int use_dyn, const ResubArgsT<MF> X, const int do_resub) {
   if (baGateClosed(D.ctl, gate)) {
     if (D.publish && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
@@ -1200,7 +1208,8 @@ __device__ __forceinline__ void stitchScWave(StitchWave& W, const int F, const i
   W.T1[e] = hh; W.T2[e] = th;
 }
 
-__global__ void __launch_bounds__(512) k_ba_stitch(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
+template <int MF>
+__global__ void __launch_bounds__(64 * MF) k_ba_stitch(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
                                                     const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE /* F*F x nsTop x 40 */,
                                                     const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S,
                                                     const BACtl* __restrict__ ctl, const int gate) {
@@ -1264,8 +1273,10 @@ __global__ void __launch_bounds__(512) k_ba_stitch(const int F, const int nsTop,
 // Output layout: out[0 .. n*n) = H_A, then b_A (n), then H_sc (n*n), then b_sc (n).
 // `out` is host-coherent pinned memory.  The last workgroup to finish publishes the chain's ticket behind the data (system-scope release); a
 // gated-off launch (rejected step: the system of the restored state is the one the host already holds) publishes at once.
+template <int MF>
 __device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
                                               const int nNum, double* __restrict__ out, const int tid, const bool sys);
+template <int MF>
 __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs S,
                                                            const int* __restrict__ numTop, const int nNum, double* __restrict__ out, BACtl* __restrict__ ctl, const int gate,
                                                            BAHostRes* __restrict__ host, const unsigned int ticket) {
@@ -1273,7 +1284,7 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
     if (host && threadIdx.x == 0) __hip_atomic_store(&host->gticket[blockIdx.x], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  gatherElement(F, nsC, accC, S, numTop, nNum, out, blockIdx.x * blockDim.x + threadIdx.x, host != nullptr);
+  gatherElement<MF>(F, nsC, accC, S, numTop, nNum, out, blockIdx.x * blockDim.x + threadIdx.x, host != nullptr);
   if (!host) return;
   // every workgroup publishes its own slice: write-through stores, a workgroup-scope release (its stores are acknowledged), then the chain's ticket into the
   // workgroup's slot of host-coherent memory; the host waits for all slots.  (A last-workgroup pattern needed a system-scope fence per thread and an agent-scope
@@ -1282,6 +1293,7 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&host->gticket[blockIdx.x], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+template <int MF>
 __device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
                                               const int nNum, double* __restrict__ out, const int tid, const bool sys) {
   // sys: `out` is host-coherent memory the host polls — write through (system-scope stores) instead of a system-scope fence per thread
@@ -1299,12 +1311,12 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
   const int t = sc ? tid - per : tid;
   // sum_{q < F} base[q * stride] in index order; the (up to 8) loads are issued together, only the adds are sequential
   auto sumF = [&](const double* __restrict__ base, const int stride) {
-    double v[BA_MAXF];
+    double v[MF];
 #pragma unroll
-    for (int q = 0; q < BA_MAXF; q++) v[q] = q < F ? base[(size_t)q * stride] : 0.0;
+    for (int q = 0; q < MF; q++) v[q] = q < F ? base[(size_t)q * stride] : 0.0;
     double acc = 0;
 #pragma unroll
-    for (int q = 0; q < BA_MAXF; q++) if (q < F) acc += v[q];
+    for (int q = 0; q < MF; q++) if (q < F) acc += v[q];
     return acc;
   };
   double val = 0;
@@ -1354,7 +1366,8 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
 // xc and xAd travel as kernel arguments (2 KB): no separate upload, no staging buffer
 // Eight lanes per point like k_ba_point_sums: lane q forms xAd[h,t_q] . JpJdF of the point's q-th residual (sequential over the 8 entries), the
 // leading lane subtracts the products in residual order (an inactive residual subtracts +0.0f: no change).
-__global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const ResubArgs X, const int apply_step) {
+template <int MF>
+__global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const ResubArgsT<MF> X, const int apply_step) {
   const float* __restrict__ xc = X.xc;
   const float* __restrict__ xAd = X.xAd;
   const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;

@@ -157,6 +157,14 @@ struct dmvio_hip_ba {
 };
 #define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
 #define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
+// The kernels whose ARGUMENTS are sized by the window (ba_kernels.hpp: BAPreDynT / ResubArgsT, the stitch workgroup of 64 F threads): windows of up to BA_MAXF keyframes
+// take the compact instantiation (the host's wide structs cut down to their prefix), larger ones (up to BA_MAXF_CAP) the wide one.
+#define BA_LAUNCH_LINEARIZE(b, W_, fullJ_, mask_, D_, gate_, use_backup_, T_, use_dyn_, X_, do_resub_) do { \
+    if ((b)->H.F <= BA_MAXF) hipLaunchKernelGGL((k_ba_linearize<BA_MAXF>), dim3((b)->n_lin_blocks), dim3(LIN_THREADS), 0, (b)->stream, W_, (b)->P, (b)->Rs, (const BAPrecalc*)(b)->d_pre, \
+        (b)->ctx->fs, fullJ_, mask_, D_, (int)(gate_), (int)(use_backup_), baNarrow<BAPreDynT<BA_MAXF>>(T_), (int)(use_dyn_), baNarrow<ResubArgsT<BA_MAXF>>(X_), (int)(do_resub_)); \
+    else hipLaunchKernelGGL((k_ba_linearize<BA_MAXF_CAP>), dim3((b)->n_lin_blocks), dim3(LIN_THREADS), 0, (b)->stream, W_, (b)->P, (b)->Rs, (const BAPrecalc*)(b)->d_pre, \
+        (b)->ctx->fs, fullJ_, mask_, D_, (int)(gate_), (int)(use_backup_), T_, (int)(use_dyn_), X_, (int)(do_resub_)); \
+  } while (0)
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + rccl().getErrorString(r_) + " in " #x).c_str()); } while (0)
 
 template <class T>
@@ -289,8 +297,8 @@ static int resolveTh(dmvio_hip_ba* b) {
 static int uploadThresholds(dmvio_hip_ba* b) {
   if (int r = resolveTh(b)) return r;
   if (!b->th_dirty) return 0;
-  for (int f = 0; f < BA_MAXF; f++) b->h_frameTH[f] = f < b->H.F ? b->H.fr[f].frameEnergyTH : 0.0f;
-  HIPCHK(hipMemcpyAsync(b->d_frameTH, b->h_frameTH, sizeof(float) * BA_MAXF, hipMemcpyHostToDevice, b->stream));
+  for (int f = 0; f < BA_MAXF_CAP; f++) b->h_frameTH[f] = f < b->H.F ? b->H.fr[f].frameEnergyTH : 0.0f;
+  HIPCHK(hipMemcpyAsync(b->d_frameTH, b->h_frameTH, sizeof(float) * BA_MAXF_CAP, hipMemcpyHostToDevice, b->stream));
   b->th_dirty = false;
   return 0;
 }
@@ -376,7 +384,6 @@ static void linearizePickUp(dmvio_hip_ba* b, double* energy, bool keep_threshold
 }
 static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mode = 0 /* 0 re-upload in place, 1 new state, 2 switch back */, bool keep_threshold = false,
                         bool defer = false) {
-  dmvio_hip_ctx* c = b->ctx;
   BAHost& H = b->H;
   if (int r = uploadWindowTables(b, table_mode == 1, table_mode == 2)) return r;  // precalc of the current state
   if (int r = uploadThresholds(b)) return r;
@@ -386,8 +393,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   // same stream and nothing it writes is read by the host, so no stream synchronisation is needed for it either
   const BADecide D = makeDecide(b, 0, !keep_threshold, true);
   BA_PROF(b, 0);
-  hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, b->d_pre, c->fs, b->keep_fullJ ? b->d_fullJ : (float*)nullptr,
-                     (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+  BA_LAUNCH_LINEARIZE(b, b->W, b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   BA_PROF(b, 1);
   if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr, 1);   // + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
@@ -431,19 +437,25 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
     hipLaunchKernelGGL(k_ba_accumulate, dim3(nblk), dim3(256), 0, s, A, RsV, PV, (const BACtl*)b->d_ctl, gate);
   }
   BA_PROF(b, 3);
-  hipLaunchKernelGGL(k_ba_stitch, dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD, b->d_accE,
-                     b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
+  if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch<BA_MAXF>), dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD,
+                                       b->d_accE, b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
+  else hipLaunchKernelGGL((k_ba_stitch<BA_MAXF_CAP>), dim3(F + F2), dim3(64 * F), sizeof(StitchWave) * F, s, F, b->nsTop, b->nsD, b->d_accTop, b->d_numTop, b->d_accD, b->d_numD,
+                          b->d_accE, b->d_adHost, b->d_adTarget, b->SB, (const BACtl*)b->d_ctl, gate);
   BA_PROF(b, 4);
   const int tot = 2 * (n * n + n);
   if (!sharded(b)) {
     b->acc_ticket = ++b->ticket;
-    hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys, b->d_ctl, gate, b->h_res,
-                       b->acc_ticket);
+    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather<BA_MAXF>), dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys,
+                                         b->d_ctl, gate, b->h_res, b->acc_ticket);
+    else hipLaunchKernelGGL((k_ba_stitch_gather<BA_MAXF_CAP>), dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->h_sys,
+                            b->d_ctl, gate, b->h_res, b->acc_ticket);
   } else {
     // this rank's part of the system stays in HBM, is summed over the ranks in place and only then published to the host
     if (gate != BA_GATE_ALWAYS) return failmsg("sharded accumulation cannot be gated: every rank must enter the collective");
-    hipLaunchKernelGGL(k_ba_stitch_gather, dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys, b->d_ctl, gate,
-                       (BAHostRes*)nullptr, 0u);
+    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather<BA_MAXF>), dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys,
+                                         b->d_ctl, gate, (BAHostRes*)nullptr, 0u);
+    else hipLaunchKernelGGL((k_ba_stitch_gather<BA_MAXF_CAP>), dim3((tot + 256) / 256), dim3(256), 0, s, F, b->nsC, b->d_accC, b->SB, b->d_numTop, F2 * b->nsTop, b->d_sys,
+                            b->d_ctl, gate, (BAHostRes*)nullptr, 0u);
     HIPCHK(hipGetLastError());
     if (int r = commAllReduceSum(b, b->d_sys, (size_t)tot + 1)) return r;
     b->acc_ticket = ++b->ticket;
@@ -488,7 +500,8 @@ static int resubstitute(dmvio_hip_ba* b, const std::vector<double>& x, bool appl
   memcpy(X.xc, xc, sizeof(xc));
   memset(X.xAd, 0, sizeof(X.xAd));
   memcpy(X.xAd, xAd.data(), sizeof(float) * xAd.size());
-  hipLaunchKernelGGL(k_ba_resubstitute, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, X, apply_step ? 1 : 0);
+  if (b->H.F <= BA_MAXF) hipLaunchKernelGGL((k_ba_resubstitute<BA_MAXF>), dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, baNarrow<ResubArgsT<BA_MAXF>>(X), apply_step ? 1 : 0);
+  else hipLaunchKernelGGL((k_ba_resubstitute<BA_MAXF_CAP>), dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, X, apply_step ? 1 : 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -717,12 +730,13 @@ int dmvio_hip_ba_set_stream(dmvio_hip_ba* b, void* stream) {
   return 0;
 }
 
+int dmvio_hip_ba_max_frames(void) { return BA_MAXF_CAP; }
 int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]) {
   if (!b || !slots || !pose7_w2c || !fxfycxcy) return failmsg("ba_set_window: null argument");
   BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
-  if (F < 1 || F > BA_MAXF) return failmsg("ba_set_window: 1 <= F <= 8");
+  if (F < 1 || F > BA_MAXF_CAP) return failmsg("ba_set_window: 1 <= F <= " + std::to_string(BA_MAXF_CAP) + " keyframes (dmvio_hip_ba_max_frames)");
   // a threshold still on its way from the previous window's last accepted step (th_ticket follows the decision) belongs to THAT window: it must neither be waited for
   // after the host-coherent record is cleared (set_graph) nor land in the new window's newest keyframe
   b->th_pending = false;
@@ -785,8 +799,7 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   if (int r = uploadThresholds(b)) return r;
   {
     const BADecide D = makeDecide(b, -1, false, false);   // masked relinearisation: no energy / threshold / accept pass
-    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, s, b->W, b->P, b->Rs, b->d_pre, c->fs, b->d_fullJ, (const unsigned char*)b->d_cand, D,
-                       (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+    BA_LAUNCH_LINEARIZE(b, b->W, b->d_fullJ, (const unsigned char*)b->d_cand, D, BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   }
   hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand, 0);
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
@@ -917,20 +930,20 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   if (dalloc(b, &b->d_spart, 2 * b->n_pt_blocks) || dalloc(b, &b->d_fullJ, (size_t)R * 74)) return -1;
   // what the host reads back every iteration (the stitched system, the energy partials, the per-residual energies) is written by the
   // kernels straight into pinned host memory: no copy engine between the last kernel and the host's wait
-  constexpr int NMAXF = 4 + 8 * BA_MAXF;
-  if (!b->h_sys) HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (2 * (NMAXF * NMAXF + NMAXF) + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent; sized for BA_MAXF keyframes once
+  constexpr int NMAXF = 4 + 8 * BA_MAXF_CAP;
+  if (!b->h_sys) HIPCHK(hipHostMalloc((void**)&b->h_sys, sizeof(double) * (2 * (NMAXF * NMAXF + NMAXF) + 1), hipHostMallocCoherent | hipHostMallocMapped));   // polled: host-coherent; sized for BA_MAXF_CAP keyframes once
   if (dalloc(b, &b->d_sys, (size_t)tot + 1)) return -1;
   b->xchg_width = 0; b->d_xchg_local = b->d_xchg_all = nullptr;
   b->pending_reject = false; b->pending_trace = -1;
   if (!b->h_res) HIPCHK(hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped));
   memset(b->h_res, 0, sizeof(BAHostRes));
-  if (!b->h_frameTH) HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF, hipHostMallocDefault));
+  if (!b->h_frameTH) HIPCHK(hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF_CAP, hipHostMallocDefault));
   if ((size_t)N > b->cap_idepth_backup) {
     if (b->h_idepth_backup) HIPCHK(hipHostFree(b->h_idepth_backup));
     b->cap_idepth_backup = (size_t)N + (size_t)N / 2 + 256;
     HIPCHK(hipHostMalloc((void**)&b->h_idepth_backup, sizeof(float) * b->cap_idepth_backup, hipHostMallocCoherent | hipHostMallocMapped));
   }
-  if (dalloc(b, &b->d_ctl, 1) || dalloc(b, &b->d_frameTH, BA_MAXF) || dalloc(b, &b->d_epart, (size_t)b->n_epart) || dalloc(b, &b->d_newestSlot, (size_t)R) || dalloc(b, &b->d_newestE, b->h_newest.size()) ||
+  if (dalloc(b, &b->d_ctl, 1) || dalloc(b, &b->d_frameTH, BA_MAXF_CAP) || dalloc(b, &b->d_epart, (size_t)b->n_epart) || dalloc(b, &b->d_newestSlot, (size_t)R) || dalloc(b, &b->d_newestE, b->h_newest.size()) ||
       dalloc(b, &b->d_newEnergyWO, (size_t)R)) return -1;
   {
     std::vector<int> slot(R, -1);
@@ -940,7 +953,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   }
   b->pre_static_valid = false;
   b->th_dirty = true; b->sys_ready = false;
-  for (int k = 0; k < 2; k++) if (!b->h_pre[k]) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * BA_MAXF * BA_MAXF, hipHostMallocDefault));
+  for (int k = 0; k < 2; k++) if (!b->h_pre[k]) HIPCHK(hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * BA_MAXF_CAP * BA_MAXF_CAP, hipHostMallocDefault));
   Rs.newEnergyWO = b->d_newEnergyWO;
   if ((size_t)2 * b->n_pt_blocks > b->cap_spart) {
     if (b->h_spart) HIPCHK(hipHostFree(b->h_spart));
@@ -1211,7 +1224,6 @@ static double vioDynamicWeight(dmvio_hip_ba* b, double E0, int resInA) {
 static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double lastE[3], bool& accepted, bool defer = false, int trace_slot = -1, bool last = false,
                        bool* canbreak_out = nullptr) {
   BAHost& H = b->H;
-  dmvio_hip_ctx* c = b->ctx;
   const int n = H.n(), tot = 2 * (n * n + n);
   const bool shard = sharded(b);
   const dmvio_hip_ba_callbacks* vio = b->vio;
@@ -1299,8 +1311,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     // newEnergy[0] + newEnergy[1] + newEnergyL + newEnergyM / dynamicGTSAMWeight (FullSystemOptimize.cpp:553-554): the quotients are formed here (x / 1.0 == x without hooks)
     D.lastE0 = lastE[0]; D.lastL = lastE[1]; D.lastM = lastE[2] / b->dynW; D.newL = newL; D.newM = newM / b->dynW;
     D.lastE0_from_ctl = b->pending_reject ? 1 : 0;   // the host has not seen the restored state's energy yet: the device has
-    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, b->W, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
-                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, (int)BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
+    BA_LAUNCH_LINEARIZE(b, b->W, b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, BA_GATE_ALWAYS, 0, b->dyn_cur, 1, X, 1);
     HIPCHK(hipGetLastError());
     if (shard) { if (int r = decideGlobal(b, D)) return r; }
     BA_PH(3);
@@ -1323,8 +1334,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     // loadSateBackup + linearizeAll (FullSystemOptimize.cpp:575-581): the points are restored by the relinearisation kernel itself; the
     // system in host memory is still the one of the restored state
     const BADecide D2 = makeDecide(b, 2, true, true);
-    hipLaunchKernelGGL(k_ba_linearize, dim3(b->n_lin_blocks), dim3(LIN_THREADS), 0, b->stream, W_backup, b->P, b->Rs, (const BAPrecalc*)b->d_pre, c->fs,
-                       b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D2) : D2, (int)BA_GATE_ALWAYS, 1, dyn_backup, 1, b->x_none, 0);
+    BA_LAUNCH_LINEARIZE(b, W_backup, b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D2) : D2, BA_GATE_ALWAYS, 1, dyn_backup, 1, b->x_none, 0);
     HIPCHK(hipGetLastError());
     if (shard) { if (int r = decideGlobal(b, D2)) return r; }
     H.restoreFrames();
@@ -1545,9 +1555,9 @@ int dmvio_hip_ba_hook_ldlt(void* user, int n, const double* HPassed, const doubl
 // The library's own solver as a computeBAUpdate hook (EnergyFunctional.cpp:971-973: diagonal pre-scaling (H_ii + 10)^-1/2, pivoted LDL^T): for hooks that fall back to the
 // visual-only step, and the check that the hook path reproduces dmvio_hip_ba_optimize bit for bit.  HPassed is n x n row-major; host-only.
 int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b_in, double* x_out) {
-  if (!HPassed || !b_in || !x_out || n < 1 || n > 4 + 8 * BA_MAXF) return failmsg("ba_solve_ldlt: bad argument");
+  if (!HPassed || !b_in || !x_out || n < 1 || n > 4 + 8 * BA_MAXF_CAP) return failmsg("ba_solve_ldlt: bad argument");
   std::vector<double> Ht((size_t)n * n, 0.0);
-  double sv[4 + 8 * BA_MAXF], bs[4 + 8 * BA_MAXF];
+  double sv[4 + 8 * BA_MAXF_CAP], bs[4 + 8 * BA_MAXF_CAP];
   for (int i = 0; i < n; i++) sv[i] = 1.0 / std::sqrt(HPassed[(size_t)i * n + i] + 10);
   for (int i = 0; i < n; i++) { for (int j = 0; j <= i; j++) Ht[(size_t)j * n + i] = sv[i] * HPassed[(size_t)i * n + j] * sv[j]; bs[i] = sv[i] * b_in[i]; }
   BAHost::ldltSolveTransposed(Ht.data(), n, bs, n);

@@ -223,6 +223,11 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* ba);
  * (FullSystem.cpp:980-985: coarseTracker on the tracking thread, mapping under mapMutex).  Frames must be resident (upload calls return
  * after their stream synchronised) before a window refers to them.  dmvio_hip_ba_set_stream replaces the stream (NULL: own stream). */
 int dmvio_hip_ba_set_stream(dmvio_hip_ba* ba, void* hip_stream);
+/* The window: F keyframes, oldest first (FullSystem::frameHessians), 1 <= F <= dmvio_hip_ba_max_frames().  The window size is a RUN-TIME setting of the reference
+ * (setting_maxFrames, util/settings.cpp:100, registered as `maxFrames` in util/MainSettings.cpp:223,246; default 7, i.e. 8 keyframes while the newest is optimised):
+ * every kernel takes F at run time; dmvio_hip_ba_max_frames() is the library's upper bound (12: the per-pair kernel arguments exist in an 8- and a 12-keyframe form,
+ * the stitch workgroup is 64 F threads).  A larger F is refused with an error (never truncated). */
+int dmvio_hip_ba_max_frames(void);
 int dmvio_hip_ba_set_window(dmvio_hip_ba* ba, int F, const int* slots, const double* pose7_w2c, const double* aff_ab, const float* exposures,
                             const int* frameIDs, const double fxfycxcy[4]);
 /* Marginalisation prior HM (n x n row-major), bM (n), n = 4 + 8F (EnergyFunctional.h:129-131); zero when never called. */

@@ -46,7 +46,7 @@ namespace orc {
 
 static const float SCALE_IDEPTH = 1.0f, SCALE_XI_ROT = 1.0f, SCALE_XI_TRANS = 1.0f, SCALE_F = 50.0f, SCALE_C = 50.0f, SCALE_A = 10.0f, SCALE_B = 1000.0f;
 static const float SCALE_F_INVERSE = 1.0f / SCALE_F, SCALE_C_INVERSE = 1.0f / SCALE_C, SCALE_A_INVERSE = 1.0f / SCALE_A, SCALE_B_INVERSE = 1.0f / SCALE_B;
-static const int CPARS = 4, PATTERN = 8, MAXF = 8;
+static const int CPARS = 4, PATTERN = 8, MAXF = 16;   // MAXF: capacity of the per-frame precalc table (setting_maxFrames is a run-time setting, settings.cpp:100)
 static const int patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:296 pattern 8
 
 struct BASettings {

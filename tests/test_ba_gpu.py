@@ -214,6 +214,50 @@ def test_gn_iterations_through_rejected_steps_match_oracle(pkg, oracle, synth, g
         assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
 
 
+@pytest.mark.parametrize("F", [5, 8, 10, 12])
+def test_window_size_is_a_runtime_setting(pkg, oracle, synth, gpu_required, F):
+    """setting_maxFrames is a run-time setting of the reference (util/settings.cpp:100, `maxFrames=` on the command line, util/MainSettings.cpp:223,246): windows of 5, 8, 10
+    and 12 keyframes (n = 44 ... 100) on the same handle type — linearisation bit for bit, accumulated + stitched system to double rounding (single-threaded order), the whole
+    optimize(6) like the oracle; F = dmvio_hip_ba_max_frames() + 1 is refused with an error."""
+    share = tuple([400, 350, 300, 300, 250, 250, 200, 200, 150, 150, 100, 0][:F - 1] + [0]) if F > 2 else (1, 0)
+    case = synth.ba_case(384, 320, n_frames=F, n_points=900, seed=60 + F, hosts_share=share, step_t=0.06, step_r=np.deg2rad(1.2))
+    assert case["n_frames"] == F and len(set(case["host"].tolist())) == F - 1
+    ctx, ba, W = _window(pkg, oracle, case)
+    ba.activate_all(); W.activate_all()
+    e_g = ba.linearize_all(False); e_o = W.linearize_all(False)
+    sg, so = ba.res_state(), W.res_state()
+    assert np.array_equal(sg["newState"], so["newState"].astype(np.uint8)) and np.array_equal(sg["newEnergy"], so["newEnergy"].astype(np.float32))
+    assert np.array_equal(sg["newEnergyWO"], so["newEnergyWO"].astype(np.float32)) and np.array_equal(ba.frame_energy_th(), W.frame_energy_th())
+    J = ba.jacobians()                                                                    # the 74-float RawResidualJacobian, bit for bit
+    for ri in np.random.RandomState(F).choice(np.nonzero(so["newState"] == 0)[0], 100, replace=False):
+        Jo = W.get_J(int(ri), 0)
+        flat = np.concatenate([Jo[k].reshape(-1) for k in ("resF", "Jpdxi", "Jpdc", "Jpdd", "JIdx", "JabF", "JIdx2", "JabJIdx", "Jab2")])
+        assert np.array_equal(J[ri].view(np.uint32), flat.view(np.uint32)), "residual %d" % ri
+    assert abs(e_g - e_o) <= 1e-9 * abs(e_o)
+    ba.apply_res(); W.apply_res()
+    ag, ao = ba.accumulate(), W.accumulate()
+    n = 4 + 8 * F
+    assert ag["HA"].shape == (n, n) and ag["resInA"] == ao["resInA"]
+    for k in ("HA", "bA", "Hsc", "bsc"):
+        assert np.max(np.abs(ag[k] - ao[k])) <= 1e-9 * (np.abs(ao[k]).max() + 1e-30), k
+    ba.set_case(case, list(range(F))); W = oracle.BAWindow(case)
+    rg = ba.optimize(6); ro = W.optimize(6)
+    assert rg["iterations"] == ro["iterations"] and np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3])
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    for k in range(F):
+        assert np.linalg.norm(ba.frame_pose(k)[0][:3] - W.frame_pose(k)[0][:3]) < 1e-3
+    # the library's default accumulation order on the same window: same decisions, energy within the bar
+    ba4 = pkg.BundleAdjusterHip(ctx); ba4.set_case(case, list(range(F)))
+    r4 = ba4.optimize(6)
+    assert np.array_equal(r4["trace"][:, 3], ro["trace"][:, 3]) and abs(r4["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    if F == 12:
+        L = pkg.load_library()
+        assert L.dmvio_hip_ba_max_frames() == 12
+        big = synth.ba_case(128, 96, n_frames=13, n_points=60, seed=3, hosts_share=tuple([5] * 12 + [0]), step_t=0.02, step_r=np.deg2rad(0.4))
+        with pytest.raises(pkg.HipLibraryError, match="dmvio_hip_ba_max_frames"):
+            ba4.set_case(big, [0] * 13)
+
+
 def test_new_graph_right_after_an_accepted_iteration_call(pkg, oracle, synth, gpu_required):
     """An accepted dmvio_hip_ba_gn_iteration leaves the newest keyframe's threshold "on its way" (published a few microseconds behind the decision).  A NEW window set on
     the same handle right afterwards must neither wait for that threshold (the host-coherent record is cleared, its ticket restarts) nor inherit it: the new window
