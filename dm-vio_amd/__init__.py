@@ -778,6 +778,11 @@ class BundleAdjusterHip:
         self.set_window(slots, poses, aff, expo, fids, case["K4"])
         self.set_graph(case["host"], case["u"], case["v"], idepth, case["color"], case["weights"], case.get("hasDepthPrior"), case["res_point"], case["res_target"])
 
+    def set_residual_flags(self, is_linearized):
+        fl = np.ascontiguousarray(is_linearized, dtype=np.uint8)
+        fn = self.L.dmvio_hip_ba_set_residual_flags; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, len(fl), fl.ctypes.data), "ba_set_residual_flags")
+
     def set_stream(self, stream_ptr):
         _chk(self.L, self.L.dmvio_hip_ba_set_stream(self.p, C.c_void_p(stream_ptr)), "ba_set_stream")
 

@@ -970,6 +970,20 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
 // first statement of an entry point: null check, the handle's lock for the whole call (declares a guard in the function's scope), then the state checks
 #define BA_READY(b) if (!(b)) return failmsg("ba: null handle"); BA_LOCK(b); BA_READY_LOCKED(b)
 
+int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* b, int R, const unsigned char* isLinearized) {
+  if (!b || !isLinearized) return failmsg("ba_set_residual_flags: null argument");
+  BA_LOCK(b);
+  if (!b->graph_ready) return failmsg("ba: set_window + set_graph first");
+  if (R != b->H.R) return failmsg("ba_set_residual_flags: R differs from the graph's residual count");
+  for (int ri = 0; ri < R; ri++)
+    if (isLinearized[ri]) {
+      b->graph_ready = false;   // refused as a whole: nothing may run on a graph whose linearised energy term (accumulateLF_MT) would be missing
+      return failmsg("ba_set_residual_flags: residual " + std::to_string(ri) + " is linearised (EFResidual::isLinearized) outside a marginalisation: accumulateLF_MT / "
+                     "addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:84-98) is not built — the graph is refused");
+    }
+  return 0;
+}
+
 // activeResiduals of FullSystem::optimize: every residual is (re)activated: resetOOB (FullSystemOptimize.cpp:431-448)
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* b) {
   BA_READY(b);

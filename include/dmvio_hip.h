@@ -265,6 +265,13 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* ba, double* HM, double* bM);
  * res_point[r] in frame res_target[r].  Residuals must be sorted by point (points in allPoints order). */
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* ba, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target);
+/* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  The library accumulates ACTIVE residuals only
+ * (accumulateAF_MT / addPoint<0>) and, inside dmvio_hip_ba_marginalize_points, the residuals it fix-linearised itself (addPoint<2>); the reference's third accumulator —
+ * accumulateLF_MT / addPoint<1> / calcLEnergyPt over residuals that are linearised but NOT being marginalised (EnergyFunctional.cpp:223-233, 349-431,
+ * AccumulatedTopHessian.cpp:84-98) — is not built, because the reference never produces such a residual: it linearises only inside FullSystem::flagPointsForRemoval,
+ * immediately before marginalizePointsF removes the point (FullSystem.cpp:836-849).  A graph that does contain one is REFUSED: the call returns an error, the graph is
+ * dropped (every later call on it fails until the next dmvio_hip_ba_set_graph) — it is never silently optimised without that energy term.  All flags zero: no effect. */
+int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* ba, int R, const unsigned char* isLinearized);
 /* resetOOB of every residual (FullSystemOptimize.cpp:431-448) */
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* ba);
 /* FullSystem::linearizeAll(fixLinearization) (FullSystemOptimize.cpp:150-218): PointFrameResidual::linearize over all residuals,

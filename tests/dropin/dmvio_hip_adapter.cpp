@@ -750,7 +750,8 @@ struct FlatWindow
 		return pointFirstRes[frameFirstPoint[efp->host->idx] + efp->idxInPoints] + r->efResidual->idxInAll;
 	}
 };
-bool uploadWindow(FullSystem* fs, FlatWindow& W)
+// checkLinearised: hand EFResidual::isLinearized to the library, which refuses a window with linearised residuals outside a marginalisation (dmvio_hip_ba_set_residual_flags)
+bool uploadWindow(FullSystem* fs, FlatWindow& W, bool checkLinearised = false)
 {
 	const int F = (int)fs->frameHessians.size();
 	std::vector<int> slots(F), frameIDs(F);
@@ -766,7 +767,7 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 	}
 	std::vector<int> host, resPoint, resTarget;
 	std::vector<float> pu, pv, pid, color, weights;
-	std::vector<unsigned char> prior;
+	std::vector<unsigned char> prior, linearised;
 	W.points.clear(); W.frameFirstPoint.assign(fs->ef->frames.size() + 1, 0); W.pointFirstRes.clear();
 	{
 		size_t np = 0, nr = 0;
@@ -790,7 +791,7 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 			for (EFResidual* er : efp->residualsAll)
 			{
 				assert((int)resPoint.size() - W.pointFirstRes.back() == er->idxInAll);
-				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx);
+				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx); linearised.push_back(er->isLinearized ? 1 : 0);
 			}
 		}
 	}
@@ -802,6 +803,7 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W)
 	dmvio_hip_ba* ba = g.ba;
 	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), fs->Hcalib.value_scaled.data()));
 	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, W.N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), W.R, resPoint.data(), resTarget.data()));
+	if (checkLinearised) ok = ok && HIP_OK(dmvio_hip_ba_set_residual_flags(ba, W.R, linearised.data()));
 	{
 		std::vector<double> sz(10 * (size_t)F), st(10 * (size_t)F);
 		for (int f = 0; f < F; f++)
@@ -911,13 +913,12 @@ float FullSystem::optimize(int mnumOptIts)
 		for (PointHessian* ph : fh->pointHessians)
 			for (PointFrameResidual* r : ph->residuals)
 			{
-				if (r->efResidual->isLinearized) { fprintf(stderr, "[dropin] linearised residual inside optimize\n"); abort(); }   // they only exist between flagPointsForRemoval and marginalizePointsF
 				activeResiduals.push_back(r);
 				r->resetOOB();
 			}
 	FlatWindow FW;
 	const auto tq0 = std::chrono::steady_clock::now();
-	bool ok = uploadWindow(this, FW);
+	bool ok = uploadWindow(this, FW, true);   // linearised residuals only exist between flagPointsForRemoval and marginalizePointsF: the library refuses a window that holds one
 	const auto tq1 = std::chrono::steady_clock::now();
 	const int N = FW.N, R = FW.R;
 	std::vector<PointHessian*>& points = FW.points;

@@ -258,6 +258,27 @@ def test_window_size_is_a_runtime_setting(pkg, oracle, synth, gpu_required, F):
             ba4.set_case(big, [0] * 13)
 
 
+def test_graph_with_a_linearised_residual_is_refused(pkg, synth, gpu_required):
+    """accumulateLF_MT / addPoint<1> (linearised residuals that are not being marginalised) is not built, because the reference's flow never produces one; a graph that
+    contains one is refused with an error instead of being optimised without that term, and stays refused until a new graph is set."""
+    case = synth.ba_case(256, 256, n_frames=4, n_points=120, seed=9, hosts_share=(50, 40, 30, 0))
+    ctx = pkg.Context(256, 256, n_slots=4)
+    for k in range(4):
+        ctx.frame_upload(k, case["imgs"][k])
+    ba = pkg.BundleAdjusterHip(ctx); ba.set_case(case, [0, 1, 2, 3])
+    R = len(case["res_point"])
+    ba.set_residual_flags(np.zeros(R, dtype=np.uint8))             # nothing linearised: accepted
+    r0 = ba.optimize(2)
+    flags = np.zeros(R, dtype=np.uint8); flags[R // 2] = 1
+    ba.set_case(case, [0, 1, 2, 3])
+    with pytest.raises(pkg.HipLibraryError, match="accumulateLF_MT"):
+        ba.set_residual_flags(flags)
+    with pytest.raises(pkg.HipLibraryError, match="set_graph first"):
+        ba.optimize(2)
+    ba.set_case(case, [0, 1, 2, 3])
+    assert ba.optimize(2)["finalEnergy"] == r0["finalEnergy"]
+
+
 def test_new_graph_right_after_an_accepted_iteration_call(pkg, oracle, synth, gpu_required):
     """An accepted dmvio_hip_ba_gn_iteration leaves the newest keyframe's threshold "on its way" (published a few microseconds behind the decision).  A NEW window set on
     the same handle right afterwards must neither wait for that threshold (the host-coherent record is cleared, its ticket restarts) nor inherit it: the new window
