@@ -538,6 +538,17 @@ class CoarseTrackerHip:
         return a.value, b.value
 
 
+def set_raw_batch_layout(ctx, tiled):
+    """What UndistorterHip.from_raw_device_batch writes as level 0: 8x4 tiles (True, the default) or row-major (dmvio_hip_set_raw_batch_layout)."""
+    fn = ctx.L.dmvio_hip_set_raw_batch_layout; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+    _chk(ctx.L, fn(ctx.p, 1 if tiled else 0), "set_raw_batch_layout")
+
+
+def frame_level0_is_tiled(ctx, slot):
+    fn = ctx.L.dmvio_hip_frame_level0_is_tiled; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+    return bool(_chk(ctx.L, fn(ctx.p, int(slot)), "frame_level0_is_tiled"))
+
+
 class UndistorterHip:
     """Raw camera image -> PhotometricUndistorter::processFrame + Undistort::undistort on the device (upload path)."""
 

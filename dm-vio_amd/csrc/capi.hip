@@ -122,6 +122,10 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   c->h_lvl0.resize(n_frame_slots);
   for (int s = 0; s < n_frame_slots; s++) c->h_lvl0[s] = c->fs.own_level(s, 0);
   HIPCHKP(hipMemcpyAsync(c->fs.lvl0, c->h_lvl0.data(), sizeof(const float*) * n_frame_slots, hipMemcpyHostToDevice, c->stream));
+  HIPCHKP(hipMalloc((void**)&c->fs.tiled0, n_frame_slots));
+  HIPCHKP(hipMemsetAsync(c->fs.tiled0, 0, n_frame_slots, c->stream));
+  c->h_tiled.assign(n_frame_slots, 0);
+  if (const char* e = getenv("DMVIO_HIP_RAW_TILED")) c->raw_batch_tiled = atoi(e) != 0;
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
@@ -146,6 +150,7 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipFree(c->fs.base);
   hipFree(c->fs.build_gen);
   hipFree(c->fs.lvl0);
+  hipFree(c->fs.tiled0);
   hipFree(c->d_upload);
   c->bounce.release();
   hipFree(c->d_f3);
@@ -182,9 +187,42 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
 static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, 1), dim3(256), 0, c->stream, d_color, (size_t)0, c->pg, c->fs,
                      (const int*)nullptr, slot, ++c->build_gen, 0);
-  c->h_lvl0[slot] = c->fs.own_level(slot, 0);
+  c->h_lvl0[slot] = c->fs.own_level(slot, 0); c->h_tiled[slot] = 0;
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// see internal.h
+int dmv_ensure_row_major_locked(dmvio_hip_ctx* c, int slot) {
+  if (slot < 0 || slot >= c->n_slots || !c->h_tiled[slot]) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  const int n = c->w * c->h;
+  float* own = c->fs.own_level(slot, 0);
+  hipLaunchKernelGGL(k_untile_level0, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float*)own, c->w, c->h, c->d_upload);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(own, c->d_upload, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->fs.tiled0 + slot, 0, 1, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // consumers on other streams (a window optimiser's) read the plane next
+  c->h_tiled[slot] = 0;
+  return 0;
+}
+int dmv_ensure_row_major(dmvio_hip_ctx* c, int slot) {
+  if (!c) return failmsg("null ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  return dmv_ensure_row_major_locked(c, slot);
+}
+// What dmvio_hip_frames_from_raw_device_batch writes as level 0: 1 = 8x4 tiles (the coarse tracker's batch kernel reads them natively; other consumers convert the slot
+// back on first use), 0 = row-major.  Tiles need w % 8 == 0 and h % 4 == 0; other sizes are always row-major.
+int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* c, int tiled) {
+  if (!c) return failmsg("null ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->raw_batch_tiled = tiled ? 1 : 0;
+  return 0;
+}
+int dmvio_hip_frame_level0_is_tiled(dmvio_hip_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= c->n_slots) return failmsg("frame_level0_is_tiled: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  return c->h_tiled[slot] ? 1 : 0;
 }
 
 int dmvio_hip_frame_upload(dmvio_hip_ctx* c, int slot, const float* host) {
@@ -311,7 +349,7 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
   if (int r = stageSlots(c, B, slots)) return r;
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
                      c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
-  for (int i = 0; i < B; i++) c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0);
+  for (int i = 0; i < B; i++) { c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0); c->h_tiled[slots[i]] = 0; }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -329,11 +367,17 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistort
   UndistortDev U = u->U;
   U.factor = factor;
   const dim3 grid(c->pg.tiles_x * c->pg.tiles_y, B);
-  if (u->bytes_per_px == 1)
-    hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
-  else
-    hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
-  for (int i = 0; i < B; i++) c->h_lvl0[slots[i]] = c->fs.own_level(slots[i], 0);
+  // level 0 in 8x4 tiles (this kernel writes level 0 anyway, so the layout is free): what the coarse tracker's batch kernel gathers from with 2.4 instead of 4.3 missed
+  // lines per tap
+  const bool tiled = c->raw_batch_tiled && (c->w % 8) == 0 && (c->h % 4) == 0;
+  if (u->bytes_per_px == 1) {
+    if (tiled) hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char, true>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+    else hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char, false>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+  } else {
+    if (tiled) hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short, true>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+    else hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short, false>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+  }
+  for (int i = 0; i < B; i++) { c->h_lvl0[slots[i]] = c->fs.own_level(slots[i], 0); c->h_tiled[slots[i]] = tiled ? 1 : 0; }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -362,6 +406,7 @@ int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   const int n = c->wl[lvl] * c->hl[lvl];
+  if (lvl == 0) { if (int r = dmv_ensure_row_major_locked(c, slot)) return r; }
   hipLaunchKernelGGL(k_level_to_f3, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->levelPtr(slot, lvl), c->wl[lvl], c->hl[lvl], c->d_f3);
   HIPCHK(hipGetLastError());
   HIPCHK(c->bounce.d2h(out, c->d_f3, sizeof(float) * 3 * n, c->stream));
@@ -375,6 +420,7 @@ int dmvio_hip_frame_abs_squared_grad(dmvio_hip_ctx* c, int slot, int n_levels, c
   if (slot < 0 || slot >= c->n_slots || n_levels < 1 || n_levels > c->levels) return failmsg("frame_abs_squared_grad: out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
+  if (int r = dmv_ensure_row_major_locked(c, slot)) return r;
   // scratch layout inside d_f3 (3*w*h floats): [256-entry response table | level 0 | level 1 | ...]  (sum of the levels < 1.34 w*h)
   float* d_lut = nullptr;
   float* d_out = c->d_f3 + 256;
@@ -513,6 +559,7 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
   if (n < 0 || (n > 0 && (!u || !v || !idepth || !hdiF))) return failmsg("tracker_set_ref: bad point arrays");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
+  if (int r = dmv_ensure_row_major_locked(c, ref_slot)) return r;
   hipStream_t s = c->stream;
   if (n > t->pts_cap) {
     if (t->d_pts) HIPCHK(hipFree(t->d_pts));
@@ -741,6 +788,7 @@ int dmvio_hip_tracker_eval(dmvio_hip_tracker* t, int lvl, int new_slot, float ne
   if (lvl < 0 || lvl >= c->levels || new_slot < 0 || new_slot >= c->n_slots) return failmsg("tracker_eval: out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
+  if (int r = dmv_ensure_row_major_locked(c, new_slot)) return r;
   EvalP e;
   makeEvalP(t->dev, lvl, poseFrom7(pose7), aff[0], aff[1], new_exposure, cutoffTH, e);
   const int n = t->dev.pc_n[lvl];
@@ -834,8 +882,24 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
     HIPCHK(hipMemsetAsync(t->d_cl_cnt, 0, sizeof(unsigned int) * B, c->stream));
     cl.part = t->d_cl_part; cl.cnt = t->d_cl_cnt;
   }
+  // frames whose level 0 the batched raw-image build stored in 8x4 tiles: the (256, 4) and (512, 4) configurations have an instantiation that gathers from them directly
+  // (decided per problem inside the kernel); any other configuration has those slots converted back first
+  bool any_tiled = false;
+  {
+    const LMProblemIn* pin = t->h_in + (size_t)t->out_cur * t->batch_cap;
+    for (int i = 0; i < B && !any_tiled; i++) any_tiled = c->h_tiled[pin[i].new_slot] != 0;
+    const bool has_variant = (T == 256 && W < 6) || (T == 512 && W < 6 && C == 1);
+    if (any_tiled && !has_variant) {
+      std::lock_guard<std::mutex> lk(c->mu);
+      for (int i = 0; i < B; i++) if (int r = dmv_ensure_row_major_locked(c, pin[i].new_slot)) return r;
+      any_tiled = false;
+    }
+  }
 #define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
-  if (T == 1024 && C == 1) DMV_LAUNCH_LM(1024, 4);
+#define DMV_LAUNCH_LM_TILED(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW, true>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
+  if (any_tiled && T == 256) DMV_LAUNCH_LM_TILED(256, 4);
+  else if (any_tiled && T == 512) DMV_LAUNCH_LM_TILED(512, 4);
+  else if (T == 1024 && C == 1) DMV_LAUNCH_LM(1024, 4);
   else if (T == 512 && W >= 6 && C == 1) DMV_LAUNCH_LM(512, 6);
   else if (T == 512 && C == 1) DMV_LAUNCH_LM(512, 4);
   else if (T == 256 && W >= 6) DMV_LAUNCH_LM(256, 6);
@@ -843,6 +907,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   else if (T == 128 && C == 1) DMV_LAUNCH_LM(128, 4);
   else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024 (cluster mode: 256)");
 #undef DMV_LAUNCH_LM
+#undef DMV_LAUNCH_LM_TILED
   HIPCHK(hipGetLastError());
   if (!t->done_event[t->out_cur]) HIPCHK(hipEventCreateWithFlags(&t->done_event[t->out_cur], hipEventDisableTiming));
   HIPCHK(hipEventRecord(t->done_event[t->out_cur], c->stream));
@@ -1006,6 +1071,7 @@ int dmvio_hip_tracker_track_vio(dmvio_hip_tracker* t, int new_slot, float new_ex
   if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("track_vio: frame slot out of range");
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
+  if (int r = dmv_ensure_row_major_locked(c, new_slot)) return r;   // the evaluation server reads row-major planes
   const TrackerDev& trk = t->dev;
   const int G = t->eval_blocks_override > 0 ? t->eval_blocks_override : clusterSize(1, trk.pc_n[0]);
   dmvio_hip_tracker_settings st; st.huberTH = trk.huberTH; st.coarseCutoffTH = trk.coarseCutoffTH; st.affineOptModeA = trk.modeA; st.affineOptModeB = trk.modeB;

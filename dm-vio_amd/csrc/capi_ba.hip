@@ -745,6 +745,7 @@ int dmvio_hip_ba_set_window(dmvio_hip_ba* b, int F, const int* slots, const doub
   H.calibInitScaled(fxfycxcy);
   for (int f = 0; f < F; f++) {
     if (slots[f] < 0 || slots[f] >= b->ctx->n_slots) return failmsg("ba_set_window: frame slot out of range");
+    if (int r = dmv_ensure_row_major(b->ctx, slots[f])) return r;   // the linearisation taps row-major level-0 planes (a slot the batched raw build left in tiles is converted once)
     BAFrameHost& fr = H.fr[f];
     fr = BAFrameHost();
     fr.slot = slots[f];

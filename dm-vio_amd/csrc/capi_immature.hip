@@ -83,6 +83,7 @@ int dmvio_hip_immature_add_points(dmvio_hip_immature* m, int host_tag, int host_
   if (n < 0 || !u || !v) return failmsg("immature_add_points: bad argument");
   if (m->n + n > m->capacity) return failmsg("immature_add_points: capacity exceeded");
   if (host_slot < 0 || host_slot >= c->n_slots || host_tag < 0 || host_tag >= IMM_MAX_HOSTS) return failmsg("immature_add_points: slot / tag out of range");
+  if (int r = dmv_ensure_row_major_locked(c, host_slot)) return r;
   // the constructor reads the 2x2 cell of every pattern pixel: u +- 2 .. +1 must be inside the image (pixel selector margin, PixelSelector2.cpp)
   for (int i = 0; i < n; i++)
     if (u[i] < 2 || v[i] < 2 || u[i] + 3 >= c->w || v[i] + 3 >= c->h) return failmsg("immature_add_points: point closer than 3 px to the border");
@@ -153,6 +154,7 @@ int dmvio_hip_immature_trace(dmvio_hip_immature* m, int new_slot, int n_hosts, c
   std::lock_guard<std::mutex> lk(c->mu);
   if (!KRKi9 || !Kt3 || !aff2 || n_hosts < 1 || n_hosts > IMM_MAX_HOSTS) return failmsg("immature_trace: bad argument");
   if (new_slot < 0 || new_slot >= c->n_slots) return failmsg("immature_trace: frame slot out of range");
+  if (int r = dmv_ensure_row_major_locked(c, new_slot)) return r;
   if (m->n == 0) return 0;
   if (m->max_tag >= n_hosts) return failmsg("immature_trace: a point's host_tag has no table row (host_tag >= n_hosts)");
   m->P.n = m->n;
@@ -241,6 +243,7 @@ int dmvio_hip_immature_optimize(dmvio_hip_immature* m, int F, const int* frame_s
   for (int f = 0; f < 8; f++) T.slot[f] = 0;
   for (int f = 0; f < F; f++) {
     if (frame_slots[f] < 0 || frame_slots[f] >= c->n_slots) return failmsg("immature_optimize: frame slot out of range");
+    if (int r = dmv_ensure_row_major_locked(c, frame_slots[f])) return r;
     T.slot[f] = frame_slots[f];
   }
   for (int hI = 0; hI < F; hI++) {

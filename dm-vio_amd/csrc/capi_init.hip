@@ -96,6 +96,7 @@ int dmvio_hip_initializer_calc_res_and_gs(dmvio_hip_initializer* m, int lvl, int
   std::lock_guard<std::mutex> lk(c->mu);
   if (!Ki9 || !fxfycxcy_lvl || !refToNew7 || !aff_ab || !idepth_new || !H_out64 || !b_out8 || !H_sc64 || !b_sc8 || !res3) return failmsg("initializer_calc: null argument");
   if (lvl < 0 || lvl >= c->levels || first_slot < 0 || first_slot >= c->n_slots || new_slot < 0 || new_slot >= c->n_slots) return failmsg("initializer_calc: level / slot out of range");
+  if (lvl == 0) { if (int r = dmv_ensure_row_major_locked(c, first_slot)) return r; if (int r = dmv_ensure_row_major_locked(c, new_slot)) return r; }
   const int n = m->n;
   hipStream_t s = c->stream;
   const Pose T = poseFrom7(refToNew7);

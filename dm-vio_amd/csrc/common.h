@@ -31,9 +31,19 @@ struct FrameStore {
   // (dmvio_hip_frames_attach_device_batch) — the caller's resident image itself: the intensity plane IS the input image, so nothing is copied.
   // The table lives in device memory (written by k_build_pyramids); host code uses dmvio_hip_ctx::levelPtr.
   const float** lvl0;
+  // tiled0[slot] != 0: the slot's OWN level-0 plane is stored in 8x4-pixel tiles (32 floats = one 128-byte line per tile, tiles row-major, w/8 per tile row) instead of
+  // row-major — written so by the batched raw-image build (k_build_pyramids_raw<T, true>), which produces level 0 anyway, for the coarse tracker's level-0 gather:
+  // the 4x4 footprint of a bilinear tap then touches 2.4 lines on average instead of 4.3.  Only k_track_lm's tiled instantiation reads such a plane; every other
+  // consumer has the slot converted back first (dmv_ensure_row_major, host side).  Every build stamps the flag of its slot.
+  unsigned char* tiled0;
   __device__ const float* level(int slot, int lvl) const { return lvl == 0 ? lvl0[slot] : base + (size_t)slot * slot_stride + level_off[lvl]; }
   __host__ __device__ float* own_level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };
+
+// element (x, y) of a level-0 plane stored in 8x4 tiles (tpr = w / 8 tiles per tile row): float offset from the plane's base
+__host__ __device__ __forceinline__ unsigned int tiled84Offset(const int x, const int y, const int tpr) {
+  return ((((unsigned int)(y >> 2) * (unsigned int)tpr) + (unsigned int)(x >> 3)) << 5) + (unsigned int)(((y & 3) << 3) + (x & 7));
+}
 
 struct PyrGeom {
   int levels;

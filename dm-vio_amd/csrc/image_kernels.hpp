@@ -21,16 +21,18 @@ typedef float pyr_f4 __attribute__((ext_vector_type(4)));
 // 2x2 reductions of the coarser levels need: 2^(levels-1) rows)
 #define PYR_TILE_PX 4096
 // levels 1.. of a workgroup's tile: successive 2x2 means of the level-0 tile in s_a (the caller's barrier has made it visible), streamed out level by level
-__device__ __forceinline__ void pyrReduceLevels(float* s_a, float* s_b, const PyrGeom& G, const FrameStore& fs, const int slot, const int x0, const int y0) {
+// pitch0: row pitch (floats) of the level-0 tile in s_a (the tiled build pads it, see k_build_pyramids_raw)
+__device__ __forceinline__ void pyrReduceLevels(float* s_a, float* s_b, const PyrGeom& G, const FrameStore& fs, const int slot, const int x0, const int y0, const int pitch0) {
   float* cur = s_a;
   float* nxt = s_b;
   int sw = 1 << G.tw_log2, sh = PYR_TILE_PX >> G.tw_log2;
   for (int l = 1; l < G.levels; l++) {
     const int nw = sw >> 1, nh = sh >> 1;
+    const int pitch = l == 1 ? pitch0 : sw;
     for (int o = threadIdx.x; o < nw * nh; o += 256) {
       const int lx = o % nw, ly = o / nw;
-      const int b = 2 * lx + 2 * ly * sw;
-      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + sw] + cur[b + sw + 1]);
+      const int b = 2 * lx + 2 * ly * pitch;
+      const float val = 0.25f * (cur[b] + cur[b + 1] + cur[b + pitch] + cur[b + pitch + 1]);
       nxt[ly * nw + lx] = val;
       const int x = (x0 >> l) + lx, y = (y0 >> l) + ly;
       if (x < G.w[l] && y < G.h[l]) fs.own_level(slot, l)[(size_t)y * G.w[l] + x] = val;
@@ -92,8 +94,8 @@ __global__ void __launch_bounds__(256) k_build_pyramids(const float* __restrict_
   }
   // stamps of this build (see FrameStore): the barrier the level reduction needs anyway carries the tile's verdict
   if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = attach ? src : fs.own_level(slot, 0); }
-  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = attach ? src : fs.own_level(slot, 0); fs.tiled0[slot] = 0; }
+  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0, TW);
 }
 
 // Photometric + geometric undistortion of a raw camera image on the upload path:
@@ -136,10 +138,15 @@ __global__ void __launch_bounds__(256) k_undistort(const T* __restrict__ raw, co
 
 // Raw camera images of B frames -> undistorted level 0 + all coarser levels in ONE launch (k_undistort fused into the level-0 pass of k_build_pyramids: the
 // fp32 image is never staged, a frame enters as 1 or 2 bytes per pixel).  Same per-pixel arithmetic as the two kernels in sequence, so the same bits.
-template <typename T>
+// TILED: level 0 is written in 8x4-pixel tiles (FrameStore::tiled0; needs w % 8 == 0, h % 4 == 0) for the coarse tracker's gather.  The level-0 values pass through
+// LDS for the coarser levels anyway; the tiled store is issued from there, behind the barrier, chunk c of 16 bytes -> lane c: a wavefront writes 1 KB of CONTIGUOUS
+// tiled memory per instruction (storing from the computing thread would write 32-byte pieces of 32 different lines).  The LDS rows are padded by 8 floats so that the
+// eight 16-byte reads of a tile (4 rows x 2 halves) fall into eight different bank groups.
+#define PYR_TILED_PAD 8
+template <typename T, bool TILED = false>
 __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict__ raw_base, const size_t raw_stride, const UndistortDev U, const PyrGeom G,
                                                              const FrameStore fs, const int* __restrict__ slots, const unsigned int gen) {
-  __shared__ float s_a[PYR_TILE_PX];
+  __shared__ float s_a[PYR_TILE_PX + (TILED ? PYR_TILED_PAD * 32 : 0)];   // at most 32 tile rows (128-pixel-wide tiles)
   __shared__ float s_b[PYR_TILE_PX / 4];
   const int f = blockIdx.y;
   const int slot = slots[f];
@@ -147,11 +154,12 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict_
   const int tx = blockIdx.x % G.tiles_x, ty = blockIdx.x / G.tiles_x;
   const int w0 = G.w[0], h0 = G.h[0];
   const int TW = 1 << G.tw_log2, rowsPerPass = 1024 >> G.tw_log2;   // 256 threads x 4 pixels = 1024 pixels per pass, four passes per tile
+  const int pitch = TILED ? TW + PYR_TILED_PAD : TW;
   const int x0 = tx * TW, y0 = ty * (PYR_TILE_PX >> G.tw_log2);
   bool bad = false;
+  float* __restrict__ dst = fs.own_level(slot, 0);
   {
     const int lx = (threadIdx.x & ((TW >> 2) - 1)) * 4, lyb = threadIdx.x >> (G.tw_log2 - 2);
-    float* __restrict__ dst = fs.own_level(slot, 0);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int x = x0 + lx, y = y0 + lyb + rowsPerPass * p, ly = lyb + rowsPerPass * p;
@@ -177,16 +185,41 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict_
 #pragma unroll
           for (int k = 0; k < 4; k++) if (x + k < w0) t[k] = undistortPixel(raw, U, i0 + k);
         }
-        if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 v = {t[0], t[1], t[2], t[3]}; __builtin_nontemporal_store(v, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
-        else for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
+        if (!TILED) {
+          if (x + 3 < w0 && ((uintptr_t)(dst + (size_t)y * w0 + x) & 15) == 0) { const pyr_f4 v = {t[0], t[1], t[2], t[3]}; __builtin_nontemporal_store(v, reinterpret_cast<pyr_f4*>(dst + (size_t)y * w0 + x)); }
+          else for (int k = 0; k < 4; k++) if (x + k < w0) dst[(size_t)y * w0 + x + k] = t[k];
+        }
       }
-      *reinterpret_cast<float4*>(&s_a[ly * TW + lx]) = make_float4(t[0], t[1], t[2], t[3]);
+      *reinterpret_cast<float4*>(&s_a[ly * pitch + lx]) = make_float4(t[0], t[1], t[2], t[3]);
       bad |= !(fabsf(t[0]) <= 1e30f) || !(fabsf(t[1]) <= 1e30f) || !(fabsf(t[2]) <= 1e30f) || !(fabsf(t[3]) <= 1e30f);
     }
   }
   if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) fs.bad_gen[slot] = gen;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = fs.own_level(slot, 0); }
-  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = fs.own_level(slot, 0); fs.tiled0[slot] = TILED ? 1 : 0; }
+  if (TILED) {
+    // the workgroup's 2^tw_log2 x (4096 >> tw_log2) pixels = strips of four rows, TW / 8 tiles each; chunk c = (strip, tile, row in tile, half): consecutive chunks are
+    // consecutive 16-byte pieces of the tiled plane within a strip
+    const int tpr = w0 >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int c = p * 256 + threadIdx.x;
+      const int strip = c >> G.tw_log2, cs = c & (TW - 1);
+      const int lx = ((cs >> 3) << 3) + ((cs & 1) << 2), ly = (strip << 2) + ((cs & 7) >> 1);
+      const int x = x0 + lx, y = y0 + ly;
+      if (x < w0 && y < h0) {   // w0 % 8 == 0, h0 % 4 == 0: a chunk is inside or outside as a whole
+        const float4 v = *reinterpret_cast<const float4*>(&s_a[ly * pitch + lx]);
+        const pyr_f4 q = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(q, reinterpret_cast<pyr_f4*>(dst + tiled84Offset(x, y, tpr)));
+      }
+    }
+  }
+  pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0, pitch);
+}
+
+// level 0 of a slot out of the 8x4-tile layout into a row-major plane (consumers other than the coarse tracker's batch kernel: dmv_ensure_row_major)
+__global__ void __launch_bounds__(256) k_untile_level0(const float* __restrict__ tiled, const int w, const int h, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < w * h) out[idx] = tiled[tiled84Offset(idx % w, idx / w, w >> 3)];
 }
 
 // level plane -> the reference's Eigen::Vector3f AoS (I, dx, dy)   (parity tests / debug download)

@@ -87,10 +87,18 @@ struct dmvio_hip_ctx {
   std::vector<const float*> h_lvl0;   // host mirror of FrameStore::lvl0 (kept by the build entry points)
   const float* levelPtr(int slot, int lvl) const { return lvl == 0 ? h_lvl0[slot] : fs.own_level(slot, lvl); }
   unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)
+  std::vector<unsigned char> h_tiled;   // host mirror of FrameStore::tiled0: level 0 of the slot is stored in 8x4 tiles (written so by the batched raw-image build)
+  int raw_batch_tiled = 1;              // dmvio_hip_set_raw_batch_layout: what dmvio_hip_frames_from_raw_device_batch writes (1 = tiles where the image size allows)
   DmvBounce bounce;             // caller-owned arrays cross PCIe through here (used under `mu`)
   std::mutex mu;
 };
 
+
+// Level 0 of `slot` back into the row-major layout if the batched raw-image build stored it in 8x4 tiles (FrameStore::tiled0): called by every consumer of a level-0 plane
+// other than the coarse tracker's batch kernel (reference template, single-frame tracking, window optimiser, immature points, initializer, downloads) before it reads the
+// slot.  No-op (one host-side flag test) for every other slot.  _locked: the caller holds c->mu; the conversion runs on the context's stream and is waited for.
+extern "C" int dmv_ensure_row_major_locked(dmvio_hip_ctx* c, int slot);
+extern "C" int dmv_ensure_row_major(dmvio_hip_ctx* c, int slot);
 
 // hypothesis-parallel trackNewCoarse: the element-wise fp64 sum over all ranks of a small HOST buffer, in place (set by dmvio_hip_tracker_set_comm /
 // _set_comm_callbacks in capi_ba.hip, which owns the RCCL calls; used by dmvio_hip_tracker_track_new_coarse in capi.hip)

@@ -45,6 +45,24 @@ __device__ __forceinline__ void interp33Load(const float* __restrict__ img, cons
   __builtin_memcpy(&t.C, bp + width - 1, 16);
   __builtin_memcpy(&t.D, bp + 2 * width, 8);
 }
+// The same twelve values out of a plane stored in 8x4 tiles (FrameStore::tiled0): one dword load per element, each with its own tile address — a 4-pixel row segment
+// crosses a tile column for 3/8 of the taps, a row pair a tile row for 3/4, so no vector load is safe; what the layout buys is lines per tap (2.4 instead of 4.3), and
+// the level-0 gather is bound by missed lines, not by load instructions (profiles/r02_gather_bounds.md: 12 scalar loads cost 4 % more than 4 vector loads).
+__device__ __forceinline__ void interp33LoadTiled(const float* __restrict__ img, const float x, const float y, const int tpr, Taps33& t) {
+  const int ix = (int)x, iy = (int)y;
+  const unsigned int strip = (unsigned int)tpr << 5;   // floats per strip of four image rows
+  unsigned int ro[4], co[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = iy - 1 + k, c = ix - 1 + k;
+    ro[k] = (unsigned int)(r >> 2) * strip + (unsigned int)((r & 3) << 3);
+    co[k] = ((unsigned int)(c >> 3) << 5) + (unsigned int)(c & 7);
+  }
+  t.A.x = img[ro[0] + co[1]]; t.A.y = img[ro[0] + co[2]];
+  t.B.x = img[ro[1] + co[0]]; t.B.y = img[ro[1] + co[1]]; t.B.z = img[ro[1] + co[2]]; t.B.w = img[ro[1] + co[3]];
+  t.C.x = img[ro[2] + co[0]]; t.C.y = img[ro[2] + co[1]]; t.C.z = img[ro[2] + co[2]]; t.C.w = img[ro[2] + co[3]];
+  t.D.x = img[ro[3] + co[1]]; t.D.y = img[ro[3] + co[2]];
+}
 // GUARD = false: for planes stamped clean by k_build_pyramids (FrameStore::bad_gen) — the guards cannot fire, the values are the same
 template <bool GUARD = true>
 __device__ __forceinline__ float3 interp33Finish(const Taps33& t, const float x, const float y) {

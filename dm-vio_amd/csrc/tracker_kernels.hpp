@@ -93,6 +93,7 @@ __device__ __forceinline__ float divBy(const float a, const Recip& R) {
   const float e2 = __builtin_fmaf(R.nb, q1, a);
   return __builtin_fmaf(e2, R.r1, q1);
 }
+template <bool TILED = false>
 __device__ __forceinline__ void projectPoint(const float4 P, const bool live, const EvalU& e, const float* __restrict__ img, PointProj& q, Taps33& taps) {
   const float x = P.x, y = P.y, id = P.z;
   const float pt0 = e.RKi[0] * x + e.RKi[1] * y + e.RKi[2] * 1.0f + e.t[0] * id;
@@ -105,7 +106,8 @@ __device__ __forceinline__ void projectPoint(const float4 P, const bool live, co
   q.refColor = P.w;
   q.inb = live && (Ku > 2 && Kv > 2 && Ku < e.wM3 && Kv < e.hM3 && q.new_idepth > 0);
   q.Ku = q.inb ? Ku : 2.5f; q.Kv = q.inb ? Kv : 2.5f;   // masked lanes tap a safe pixel
-  interp33Load(img, q.Ku, q.Kv, e.w, taps);
+  if (TILED) interp33LoadTiled(img, q.Ku, q.Kv, e.w >> 3, taps);
+  else interp33Load(img, q.Ku, q.Kv, e.w, taps);
 }
 template <bool GUARD>
 __device__ __forceinline__ void finishPoint(const PointProj& q, const Taps33& taps, const EvalU& e, EvalStats& st, float (&J)[9], float& wOut) {
@@ -216,7 +218,8 @@ __device__ __forceinline__ float waveReduceStats(const EvalStats& st, const int 
 // 4-8 waves per SIMD stay resident to hide the gather latency.  Fixed summation order (bitwise reproducible).
 // Result: s_tot[0..63] (ACC_* slots) valid for all threads after return.
 // GUARD = false: the new frame is stamped clean (FrameStore::bad_gen), the isfinite guards of the taps are compiled out
-template <int T, bool GUARD = true>
+// TILED: `img` is a level-0 plane stored in 8x4 tiles (FrameStore::tiled0) — same twelve values per tap, other addresses
+template <int T, bool GUARD = true, bool TILED = false>
 __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, const float4* __restrict__ pc, const int n,
                                           const unsigned long long* __restrict__ flow_mask, const int first, const int stride,
                                           const float* __restrict__ img, const float huberTH, float* s_stage, float* s_partH,
@@ -244,13 +247,13 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
   if (n > 0) {
     const float4 P0 = pc[min(base0 + lane, nm1)];
     P1 = pc[min(base0 + lane + stride, nm1)];
-    projectPoint(P0, base0 + lane < n, eu, img, q0, t0);
+    projectPoint<TILED>(P0, base0 + lane < n, eu, img, q0, t0);
   }
   // one pipeline step: finishes the point held in (qc, tc) while the taps of the next one are requested into (qn, tn).  The loop below is
   // unrolled twice with the two register sets swapping roles, so the hand-over costs no register moves (19 per step otherwise).
   auto step = [&](const PointProj& qc, const Taps33& tc, PointProj& qn, Taps33& tn, const int base) __attribute__((always_inline)) {
     const int i = base + lane;
-    projectPoint(P1, i + stride < n, eu, img, qn, tn);     // next point: its taps are requested now, consumed next step
+    projectPoint<TILED>(P1, i + stride < n, eu, img, qn, tn);     // next point: its taps are requested now, consumed next step
     P1 = pc[min(i + 2 * stride, nm1)];                     // unconditional (clamped) prefetch
     float J[9], w;
     finishPoint<GUARD>(qc, tc, eu, st, J, w);
@@ -848,7 +851,9 @@ __device__ __forceinline__ void clusterExchange(float* s_tot, const ClusterArgs&
   __syncthreads();
 }
 
-template <int T, int W>
+// TL: the instantiation that can read level-0 planes stored in 8x4 tiles (FrameStore::tiled0, decided per problem at run time); launched only when a batch holds
+// such a slot, so the plain instantiation's register budget is untouched
+template <int T, int W, bool TL = false>
 __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in,
                                                  LMProblemOut* __restrict__ out, const int coarsestLvl, const ClusterArgs cl) {
   __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
@@ -882,6 +887,7 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   const int slot = pin.new_slot;
   // every pixel of the new frame finite (stamped by its pyramid build): the evaluation loop without the isfinite guards gives the same values
   const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
+  const bool tiled0 = TL && __builtin_amdgcn_readfirstlane((int)fs.tiled0[slot]) != 0;
   long long tStep = 0, tEval = 0;
   for (;;) {
     const long long t0 = wall_clock64();
@@ -898,7 +904,14 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
     const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
                                       (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
-    if (clean)
+    if (TL && tiled0 && lvl == 0) {   // workgroup-uniform
+      if (clean)
+        blockEval<T, false, TL>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                                s_tot);
+      else
+        blockEval<T, true, TL>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
+                               s_tot);
+    } else if (clean)
       blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
                           s_tot);
     else

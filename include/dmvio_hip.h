@@ -80,6 +80,13 @@ int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* ctx, int B, const int* s
  * enters the kernel as 1 (2) bytes per pixel instead of 4, and the undistorted fp32 image is written once, as level 0.  `factor` as in
  * dmvio_hip_frame_upload_raw.  Bit-identical to B calls of dmvio_hip_frame_upload_raw.  Asynchronous on the ctx stream. */
 int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* ctx, dmvio_hip_undistorter* und, int B, const int* slots, const void* raw_dev_base, size_t stride_bytes, float factor);
+/* Layout of the level-0 plane dmvio_hip_frames_from_raw_device_batch writes: tiled != 0 (default): 8x4-pixel tiles (one 128-byte line each), which the coarse tracker's
+ * batch kernel (dmvio_hip_tracker_track_batch with >= 2 problems) gathers from directly — the 4x4 footprint of a bilinear tap (getInterpolatedElement33,
+ * util/globalFuncs.h:103-118) then touches 2.4 lines on average instead of 4.3; the build writes level 0 anyway, so the layout costs nothing.  Needs w % 8 == 0 and
+ * h % 4 == 0 (other sizes are always row-major).  Every other consumer of such a slot (setCoarseTrackingRef, single-frame tracking, the window optimiser, immature
+ * points, the initializer, downloads) converts it back to row-major on first use — same values, bit for bit.  dmvio_hip_frame_level0_is_tiled reports a slot's state. */
+int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* ctx, int tiled);
+int dmvio_hip_frame_level0_is_tiled(dmvio_hip_ctx* ctx, int slot);
 /* Diagnostics.  Every pyramid build stamps its slot "clean" when all pixels are finite (|I| <= 1e30): consumers then run without the
  * reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455), which cannot fire on such a frame.  This call withdraws
  * the stamp so that the guarded code path runs (tests compare the two). */

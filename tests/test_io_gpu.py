@@ -75,6 +75,60 @@ def test_raw_device_batch_equals_single_uploads(pkg, oracle, gpu_required, bits,
         und.from_raw_device_batch([0, 1], dev.data_ptr(), raws[0].nbytes - 2)    # frames would overlap
 
 
+@pytest.mark.parametrize("B,launch", [(6, None), (200, (1, 512)), (600, (1, 256))])
+def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_required, B, launch):
+    """dmvio_hip_frames_from_raw_device_batch stores level 0 in 8x4-pixel tiles (it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per
+    tap from other addresses, so every result — pose, affine, residuals, flow indicators, H, b, iteration count — equals the row-major layout's BIT FOR BIT, in cluster mode
+    (B = 6), with 512-thread (B = 200) and 256-thread workgroups (B = 600); every other consumer converts such a slot back on first use (download, reference template,
+    single-frame tracking, a window of the optimiser)."""
+    import torch
+    w, h = 256, 192
+    case = synth.tracking_case(w, h, n_ref=700, n_frames=4, xi_jitter=0.3)
+    ctx = pkg.Context(w, h, n_slots=2 * B + 1)
+    ctx.frame_upload(0, case["ref_img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    und = pkg.UndistorterHip(ctx, w, h, 8)                                   # passthrough geometry, no photometric calibration: image = factor * raw
+    raws = np.stack([np.clip(np.rint(case["frames"][i % 4]["img"]), 0, 255).astype(np.uint8) for i in range(B)])
+    dev = torch.from_numpy(raws.reshape(B, -1)).to("cuda:0"); torch.cuda.synchronize()
+    tiled_slots, plain_slots = list(range(1, B + 1)), list(range(B + 1, 2 * B + 1))
+    und.from_raw_device_batch(tiled_slots, dev.data_ptr(), w * h)
+    pkg.set_raw_batch_layout(ctx, False)
+    und.from_raw_device_batch(plain_slots, dev.data_ptr(), w * h)
+    pkg.set_raw_batch_layout(ctx, True)
+    ctx.synchronize()
+    assert all(pkg.frame_level0_is_tiled(ctx, s) for s in tiled_slots) and not any(pkg.frame_level0_is_tiled(ctx, s) for s in plain_slots)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    rt = trk.track_batch(tiled_slots, [ident] * B, [(0.0, 0.0)] * B)
+    if launch:
+        assert trk.last_launch() == launch
+    assert all(pkg.frame_level0_is_tiled(ctx, s) for s in tiled_slots)                         # the batch kernel read the tiles in place
+    rp = trk.track_batch(plain_slots, [ident] * B, [(0.0, 0.0)] * B)
+    assert rt["good"].all() and rp["good"].all()
+    for k in ("pose7", "aff", "lastResiduals", "flow", "H", "b", "iterations"):
+        assert np.array_equal(rt[k], rp[k], equal_nan=True), k
+    # mixed batch: tiled and row-major slots side by side in one launch
+    mixed = [tiled_slots[i] if i % 2 else plain_slots[i] for i in range(B)]
+    rm = trk.track_batch(mixed, [ident] * B, [(0.0, 0.0)] * B)
+    assert all(np.array_equal(rm[k], rp[k], equal_nan=True) for k in ("pose7", "lastResiduals", "H", "b"))
+    # every other consumer converts the slot back: download (all levels equal the row-major build's), single-frame tracking, the reference template, a BA window
+    for lvl in range(ctx.levels):
+        assert np.array_equal(ctx.frame_download(tiled_slots[0], lvl).view(np.uint32), ctx.frame_download(plain_slots[0], lvl).view(np.uint32))
+    assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[0]) and pkg.frame_level0_is_tiled(ctx, tiled_slots[1])
+    a = trk.trackNewestCoarse(tiled_slots[1], ident, [0.0, 0.0]); b = trk.trackNewestCoarse(plain_slots[1], ident, [0.0, 0.0])
+    assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[1]) and np.array_equal(np.asarray(a["pose7"]), np.asarray(b["pose7"]))
+    trk2 = pkg.CoarseTrackerHip(ctx); trk2.makeK(case["K4"])
+    trk2.setCoarseTrackingRef(tiled_slots[2], case["u"], case["v"], case["idepth"], case["hdiF"])
+    trk3 = pkg.CoarseTrackerHip(ctx); trk3.makeK(case["K4"])
+    trk3.setCoarseTrackingRef(plain_slots[2], case["u"], case["v"], case["idepth"], case["hdiF"])
+    assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[2])
+    for lvl in range(ctx.levels):
+        assert np.array_equal(trk2.get_pc(lvl).view(np.uint32), trk3.get_pc(lvl).view(np.uint32))
+    # a rebuilt slot is row-major again
+    ctx.frame_upload(tiled_slots[3], case["ref_img"])
+    assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[3])
+
+
 def test_reference_generated_remap_tables_are_accepted(pkg, oracle, gpu_required, tmp_path):
     """The tables Undistort::getUndistorterForFile builds itself (Undistort.cpp:266-384, 900-942: entries with 0 < x < wOrg-1, 0 < y < hOrg-1, everything else -1) — a `crop`
     rectification whose border pixels map into the last raw row — are taken by the HIP undistorter and give the reference's own image bit for bit.  Entries inside
