@@ -544,6 +544,13 @@ def set_raw_batch_layout(ctx, tiled):
     _chk(ctx.L, fn(ctx.p, 1 if tiled else 0), "set_raw_batch_layout")
 
 
+def set_raw_batch_kernel(ctx, variant):
+    """Kernel behind UndistorterHip.from_raw_device_batch: 1 = a 4 x 8 pixel block per thread, levels in registers (default where the geometry allows), 0 = the LDS-tile build
+    (dmvio_hip_set_raw_batch_kernel)."""
+    fn = ctx.L.dmvio_hip_set_raw_batch_kernel; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+    _chk(ctx.L, fn(ctx.p, int(variant)), "set_raw_batch_kernel")
+
+
 def frame_level0_is_tiled(ctx, slot):
     fn = ctx.L.dmvio_hip_frame_level0_is_tiled; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
     return bool(_chk(ctx.L, fn(ctx.p, int(slot)), "frame_level0_is_tiled"))

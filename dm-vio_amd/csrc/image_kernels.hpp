@@ -216,6 +216,139 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict_
   pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0, pitch);
 }
 
+// The same build without workgroup coupling — the default of dmvio_hip_frames_from_raw_device_batch for pyramids of at most four levels on images whose sides are
+// multiples of 8 (512x512, 640x480, 800x400 ...).  A thread owns a 4 x 8 pixel block: its eight level-0 rows, the 2 x 4 values of level 1 and the two of level 2 they
+// reduce to never leave registers, level 3 is formed by the even lane of a lane pair (one cross-lane read).  No barrier and — row-major level 0 — no LDS: a wavefront
+// streams 256 x 8 pixels in and four levels out on its own (the LDS-tile kernel above held every store of a tile behind three workgroup barriers and kept 7 workgroups of
+// 20 KB per CU; profiles/r04_pyramid_build.md).  Per wave instruction the lanes write consecutive pieces: 16 B (level 0), 8 B (level 1), 4 B (levels 2, 3).
+// Same per-pixel arithmetic and the same 0.25f * (((a + b) + c) + d) per level: bit-identical planes.
+// TILED: level 0 in 8x4 tiles; the four rows of a strip pass through a wave-private LDS transpose (row stride 68 float4: the sixteen 16-byte reads of a quarter wave fall
+// into sixteen different bank groups) so that instruction k of a wave still writes 1 KB of contiguous tiled memory.
+#define PYR_REG_ROWF4 68
+template <typename T, bool TILED>
+__global__ void __launch_bounds__(256) k_build_pyramids_raw_reg(const T* __restrict__ raw_base, const size_t raw_stride, const UndistortDev U, const PyrGeom G,
+                                                                 const FrameStore fs, const int* __restrict__ slots, const unsigned int gen) {
+  __shared__ float4 s_rows[TILED ? 4 * 4 * PYR_REG_ROWF4 : 1];
+  __shared__ unsigned int s_off[TILED ? 256 : 1];
+  const int f = blockIdx.y;
+  const int slot = slots[f];
+  const T* __restrict__ raw = raw_base + (size_t)f * raw_stride;
+  const int w0 = G.w[0], h0 = G.h[0];
+  const int tpr4 = w0 >> 2, nthr = tpr4 * (h0 >> 3);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < nthr;
+  const int tx = live ? t % tpr4 : 0, ty = live ? t / tpr4 : 0;
+  const int x = 4 * tx, y = 8 * ty;
+  const int lane = threadIdx.x & 63;
+  float v[8][4];
+  {
+    const int i0 = y * w0 + x;
+    if (!U.remapX && ((uintptr_t)(raw + i0) & (4 * sizeof(T) - 1)) == 0) {   // i0 % 4 == 0 and w0 % 8 == 0: the alignment of the frame's base decides, for all rows
+      // passthrough geometry: the four raw values of a row are one aligned 4- / 8-byte load; all eight rows are requested before the first conversion
+      T r4[8][4];
+#pragma unroll
+      for (int r = 0; r < 8; r++) __builtin_memcpy(r4[r], __builtin_assume_aligned(raw + i0 + r * w0, 4 * sizeof(T)), 4 * sizeof(T));
+      if (!U.G) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[r][k] = U.factor * r4[r][k];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[r][k] = U.G[r4[r][k]];
+        if (U.vignetteMapInv) {
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            float4 g;
+            __builtin_memcpy(&g, U.vignetteMapInv + i0 + r * w0, 16);
+            v[r][0] *= g.x; v[r][1] *= g.y; v[r][2] *= g.z; v[r][3] *= g.w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[r][k] = undistortPixel(raw, U, i0 + r * w0 + k);
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) bad |= !(fabsf(v[r][k]) <= 1e30f);   // NaN fails the comparison too
+  if (__any(bad && live) && lane == 0) fs.bad_gen[slot] = gen;
+  if (t == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = fs.own_level(slot, 0); fs.tiled0[slot] = TILED ? 1 : 0; }
+  float* __restrict__ dst0 = fs.own_level(slot, 0);
+  if (!TILED) {
+    if (live) {
+      if (((uintptr_t)dst0 & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const pyr_f4 q = {v[r][0], v[r][1], v[r][2], v[r][3]}; __builtin_nontemporal_store(q, reinterpret_cast<pyr_f4*>(dst0 + (size_t)(y + r) * w0 + x)); }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) dst0[(size_t)(y + r) * w0 + x + k] = v[r][k];
+      }
+    }
+  } else {
+    float4* __restrict__ wrow = s_rows + (threadIdx.x >> 6) * (4 * PYR_REG_ROWF4);
+    unsigned int* __restrict__ woff = s_off + (threadIdx.x & ~63);
+    const int tpr = w0 >> 3;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      // offset of this lane's half row 0 inside its tile of strip s (rows add 8 floats each); 0xffffffff: nothing to write
+      woff[lane] = live ? tiled84Offset(x, y + 4 * s, tpr) : 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 4; r++) wrow[r * PYR_REG_ROWF4 + lane] = make_float4(v[4 * s + r][0], v[4 * s + r][1], v[4 * s + r][2], v[4 * s + r][3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // chunk c of the wave's 32 tiles: tile c / 8, row (c % 8) / 2, half c % 2 — consecutive chunks are consecutive 16-byte pieces of the tiled plane
+        const int c = 64 * k + lane;
+        const int r = (c & 7) >> 1, src = ((c >> 3) << 1) + (c & 1);
+        const unsigned int o = woff[src];
+        const float4 q4 = wrow[r * PYR_REG_ROWF4 + src];
+        if (o != 0xffffffffu) { const pyr_f4 q = {q4.x, q4.y, q4.z, q4.w}; __builtin_nontemporal_store(q, reinterpret_cast<pyr_f4*>(dst0 + o + 8 * r)); }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (G.levels < 2) return;
+  float l1[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 2; c++) l1[r][c] = 0.25f * (v[2 * r][2 * c] + v[2 * r][2 * c + 1] + v[2 * r + 1][2 * c] + v[2 * r + 1][2 * c + 1]);
+  if (live) {
+    float* __restrict__ d1 = fs.own_level(slot, 1);
+    const int w1 = G.w[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float2 q = make_float2(l1[r][0], l1[r][1]); __builtin_memcpy(d1 + (size_t)(4 * ty + r) * w1 + 2 * tx, &q, 8); }
+  }
+  if (G.levels < 3) return;
+  float l2[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) l2[r] = 0.25f * (l1[2 * r][0] + l1[2 * r][1] + l1[2 * r + 1][0] + l1[2 * r + 1][1]);
+  if (live) {
+    float* __restrict__ d2 = fs.own_level(slot, 2);
+    const int w2 = G.w[2];
+    d2[(size_t)(2 * ty) * w2 + tx] = l2[0];
+    d2[(size_t)(2 * ty + 1) * w2 + tx] = l2[1];
+  }
+  if (G.levels < 4) return;
+  // level 3: the 2 x 2 block of level 2 = this lane's two values and those of the lane to its right (w0 % 8 == 0: a lane pair never straddles a block row)
+  const float nb0 = __shfl_down(l2[0], 1, 64), nb1 = __shfl_down(l2[1], 1, 64);
+  if (live && !(lane & 1)) fs.own_level(slot, 3)[(size_t)ty * G.w[3] + (tx >> 1)] = 0.25f * (l2[0] + nb0 + l2[1] + nb1);
+}
+
 // level 0 of a slot out of the 8x4-tile layout into a row-major plane (consumers other than the coarse tracker's batch kernel: dmv_ensure_row_major)
 __global__ void __launch_bounds__(256) k_untile_level0(const float* __restrict__ tiled, const int w, const int h, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

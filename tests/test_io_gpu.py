@@ -75,6 +75,42 @@ def test_raw_device_batch_equals_single_uploads(pkg, oracle, gpu_required, bits,
         und.from_raw_device_batch([0, 1], dev.data_ptr(), raws[0].nbytes - 2)    # frames would overlap
 
 
+@pytest.mark.parametrize("bits,size,calib", [(8, (512, 512), False), (8, (640, 480), True), (16, (256, 192), True), (8, (128, 64), False)])
+def test_raw_batch_register_build_equals_the_lds_tile_build(pkg, gpu_required, bits, size, calib):
+    """dmvio_hip_frames_from_raw_device_batch has two kernels: the wave-autonomous build (a 4 x 8 pixel block per thread, every level formed in registers, no barrier; the
+    default for pyramids of <= 4 levels on images whose sides are multiples of 8) and the general LDS-tile build.  Every level of every frame is the same, bit for bit, in both
+    level-0 layouts (8x4 tiles / row-major), with and without photometric tables, for frames whose base is not 4-pixel aligned (the unaligned load path), and at a size whose
+    pyramid has fewer than four levels."""
+    import torch
+    from test_io_cpu import io_case
+    w, h = size
+    B = 7
+    cases = [io_case(seed=70 + i + bits, wOrg=w, hOrg=h, bits=bits) for i in range(B)]
+    ctx = pkg.Context(w, h, n_slots=4 * B)
+    und = pkg.UndistorterHip(ctx, w, h, bits, cases[0]["G"] if calib else None, cases[0]["vig"] if calib else None)
+    raws = np.stack([k["raw"].reshape(h, w) for k in cases]).astype(und.dtype)
+    for pad in (64, 64 + raws.itemsize):                    # frame bases aligned to 4 pixels / not aligned
+        stride = raws[0].nbytes + pad
+        host = np.zeros((B, stride), np.uint8)
+        host[:, :raws[0].nbytes] = raws.reshape(B, -1).view(np.uint8)
+        dev = torch.from_numpy(host).to("cuda:0"); torch.cuda.synchronize()
+        k = 0
+        for variant in (0, 1):
+            for tiled in (False, True):
+                pkg.set_raw_batch_kernel(ctx, variant); pkg.set_raw_batch_layout(ctx, tiled)
+                und.from_raw_device_batch(list(range(k * B, (k + 1) * B)), dev.data_ptr(), stride, factor=0.5)
+                k += 1
+        ctx.synchronize()
+        if w % 8 == 0 and h % 4 == 0:
+            assert pkg.frame_level0_is_tiled(ctx, B) and pkg.frame_level0_is_tiled(ctx, 3 * B) and not pkg.frame_level0_is_tiled(ctx, 2 * B)
+        for i in range(B):
+            for lvl in range(ctx.levels):
+                ref = ctx.frame_download(i, lvl).view(np.uint32)
+                for kk in (1, 2, 3):
+                    assert np.array_equal(ctx.frame_download(kk * B + i, lvl).view(np.uint32), ref), (pad, i, lvl, kk)
+    pkg.set_raw_batch_kernel(ctx, 1); pkg.set_raw_batch_layout(ctx, True)
+
+
 @pytest.mark.parametrize("B,launch", [(6, None), (200, (1, 512)), (600, (1, 256))])
 def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_required, B, launch):
     """dmvio_hip_frames_from_raw_device_batch stores level 0 in 8x4-pixel tiles (it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per
@@ -123,7 +159,7 @@ def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_
     trk3.setCoarseTrackingRef(plain_slots[2], case["u"], case["v"], case["idepth"], case["hdiF"])
     assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[2])
     for lvl in range(ctx.levels):
-        assert np.array_equal(trk2.get_pc(lvl).view(np.uint32), trk3.get_pc(lvl).view(np.uint32))
+        assert np.array_equal(np.stack(trk2.get_pc(lvl)).view(np.uint32), np.stack(trk3.get_pc(lvl)).view(np.uint32))
     # a rebuilt slot is row-major again
     ctx.frame_upload(tiled_slots[3], case["ref_img"])
     assert not pkg.frame_level0_is_tiled(ctx, tiled_slots[3])

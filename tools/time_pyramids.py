@@ -24,9 +24,13 @@ print("attach  fp32: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (ta, B *
 tc = t(lambda: ctx.frames_from_device_batch(slots, raw.data_ptr(), w * h * 4))
 print("copy    fp32: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (tc, B * (8 * w * h + lv) / tc / 1e9, 4 * w * h, 4 * w * h + lv))
 und = P.UndistorterHip(ctx, w, h, 8)
-tr = t(lambda: und.from_raw_device_batch(slots, raw8.data_ptr(), w * h, factor=1.0))
-print("raw u8 (factor): %.3f ms  %.2f TB/s (read %d + write %d B/frame), written at %.2f TB/s" % (tr, B * (w * h + 4 * w * h + lv) / tr / 1e9, w * h, 4 * w * h + lv, B * (4 * w * h + lv) / tr / 1e9))
 G = np.linspace(0, 255, 256).astype(np.float32); vig = np.ones((h, w), np.float32)
 und2 = P.UndistorterHip(ctx, w, h, 8, G, vig)
-tg = t(lambda: und2.from_raw_device_batch(slots, raw8.data_ptr(), w * h, factor=1.0))
-print("raw u8 (G + vignette): %.3f ms  %.2f TB/s" % (tg, B * (w * h + 4 * w * h + 4 * w * h + lv) / tg / 1e9))
+for variant, vname in ((0, "LDS-tile build"), (1, "register build")):
+    for tiled in (0, 1):
+        P.set_raw_batch_kernel(ctx, variant); P.set_raw_batch_layout(ctx, bool(tiled))
+        tr = t(lambda: und.from_raw_device_batch(slots, raw8.data_ptr(), w * h, factor=1.0))
+        tg = t(lambda: und2.from_raw_device_batch(slots, raw8.data_ptr(), w * h, factor=1.0))
+        print("raw u8, %s, level 0 %s: factor %.3f ms = %.2f TB/s moved (read %d + write %d B/frame), %.2f TB/s written;  G + vignette %.3f ms = %.2f TB/s moved"
+              % (vname, "8x4 tiles" if tiled else "row-major", tr, B * (w * h + 4 * w * h + lv) / tr / 1e9, w * h, 4 * w * h + lv, B * (4 * w * h + lv) / tr / 1e9,
+                 tg, B * (w * h + 4 * w * h + 4 * w * h + lv) / tg / 1e9))
