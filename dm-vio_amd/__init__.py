@@ -305,6 +305,10 @@ class Context:
                                                       qs.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p)), "selftest_divide")
         return qs, qi
 
+    def frame_is_clean(self, slot):
+        self.L.dmvio_hip_frame_is_clean.argtypes = [C.c_void_p, C.c_int]; self.L.dmvio_hip_frame_is_clean.restype = C.c_int
+        return bool(_chk(self.L, self.L.dmvio_hip_frame_is_clean(self.p, int(slot)), "frame_is_clean"))
+
     def frame_mark_unclean(self, slot):
         _chk(self.L, self.L.dmvio_hip_frame_mark_unclean(self.p, slot), "frame_mark_unclean")
 

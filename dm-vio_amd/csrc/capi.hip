@@ -184,6 +184,10 @@ int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
 }
 
 // ------------------------------------------------------------------ frames
+// the wave-autonomous builds (a 4 x 8 pixel block per thread, levels in registers: image_kernels.hpp) take pyramids of at most four levels on images whose sides are
+// multiples of 8; everything else (and dmvio_hip_set_raw_batch_kernel(ctx, 0)) goes to the LDS-tile builds
+static bool regBuild(const dmvio_hip_ctx* c) { return c->raw_batch_kernel && c->levels <= 4 && (c->w % 8) == 0 && (c->h % 8) == 0; }
+static dim3 regGrid(const dmvio_hip_ctx* c, int B) { return dim3(((c->w / 4) * (c->h / 8) + 255) / 256, B); }
 static int buildPyramid(dmvio_hip_ctx* c, int slot, const float* d_color) {
   hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, 1), dim3(256), 0, c->stream, d_color, (size_t)0, c->pg, c->fs,
                      (const int*)nullptr, slot, ++c->build_gen, 0);
@@ -219,8 +223,8 @@ int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* c, int tiled) {
   c->raw_batch_tiled = tiled ? 1 : 0;
   return 0;
 }
-// Which kernel dmvio_hip_frames_from_raw_device_batch launches: 1 (default) = the wave-autonomous register build where the geometry allows it (at most four pyramid
-// levels, both sides multiples of 8), 0 = always the LDS-tile build.  Both write the same bits; the switch exists for A/B measurements and the parity test of the two.
+// Which kernels build the pyramids of the raw-image batch and of frames attached in place: 1 (default) = the wave-autonomous register builds where the geometry allows it
+// (at most four pyramid levels, both sides multiples of 8), 0 = always the LDS-tile builds.  Both write the same bits; the switch exists for A/B measurements and the parity test of the two.
 int dmvio_hip_set_raw_batch_kernel(dmvio_hip_ctx* c, int variant) {
   if (!c) return failmsg("null ctx");
   if (variant != 0 && variant != 1) return failmsg("set_raw_batch_kernel: variant must be 0 or 1");
@@ -356,8 +360,12 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(hipSetDevice(c->device));
   if (int r = stageSlots(c, B, slots)) return r;
-  hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
-                     c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
+  // attached in place: the register build (read-dominated: 5 % ahead); level 0 copied: the LDS-tile build (4 % ahead there) — both measured, tools/time_pyramids.py
+  if (regBuild(c) && attach)
+    hipLaunchKernelGGL((k_build_pyramids_reg<true>), regGrid(c, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float), c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen);
+  else
+    hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
+                       c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
   for (int i = 0; i < B; i++) { c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0); c->h_tiled[slots[i]] = 0; }
   HIPCHK(hipGetLastError());
   return 0;
@@ -379,8 +387,8 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistort
   // lines per tap
   const bool tiled = c->raw_batch_tiled && (c->w % 8) == 0 && (c->h % 4) == 0;
   // the wave-autonomous build (a 4 x 8 pixel block per thread, levels in registers) where the pyramid allows it, the LDS-tile build otherwise
-  const bool reg = c->raw_batch_kernel && c->levels <= 4 && (c->w % 8) == 0 && (c->h % 8) == 0;
-  const dim3 grid(reg ? ((c->w / 4) * (c->h / 8) + 255) / 256 : c->pg.tiles_x * c->pg.tiles_y, B);
+  const bool reg = regBuild(c);
+  const dim3 grid = reg ? regGrid(c, B) : dim3(c->pg.tiles_x * c->pg.tiles_y, B);
 #define DMV_LAUNCH_RAW(K, T, TILED, stride) hipLaunchKernelGGL((K<T, TILED>), grid, dim3(256), 0, c->stream, (const T*)raw_dev_base, stride, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen)
   if (u->bytes_per_px == 1) {
     if (reg) { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, true, stride_bytes); else DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, false, stride_bytes); }
@@ -411,6 +419,18 @@ int dmvio_hip_frame_mark_unclean(dmvio_hip_ctx* c, int slot) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(c->fs.bad_gen + slot, c->fs.build_gen + slot, sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
   return 0;
+}
+
+// Diagnostics: 1 when the slot's last build stamped it clean (every pixel finite, |I| <= 1e30), 0 when not, < 0 on error.  Waits for the context's stream.
+int dmvio_hip_frame_is_clean(dmvio_hip_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= c->n_slots) return failmsg("frame_is_clean: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  unsigned int g[2] = {0, 0};
+  HIPCHK(c->bounce.d2h(&g[0], c->fs.build_gen + slot, sizeof(unsigned int), c->stream));
+  HIPCHK(c->bounce.d2h(&g[1], c->fs.bad_gen + slot, sizeof(unsigned int), c->stream));
+  HIPCHK(c->bounce.finish(c->stream));
+  return g[0] != g[1] ? 1 : 0;
 }
 
 int dmvio_hip_frame_download(dmvio_hip_ctx* c, int slot, int lvl, float* out) {

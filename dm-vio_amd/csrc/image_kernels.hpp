@@ -216,6 +216,37 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw(const T* __restrict_
   pyrReduceLevels(s_a, s_b, G, fs, slot, x0, y0, pitch);
 }
 
+// Levels 1..3 of a thread's 4 x 8 pixel block (k_build_pyramids_raw_reg, k_build_pyramids_reg): 2 x 4 values of level 1 and two of level 2 in registers, level 3 by the even
+// lane of a lane pair.  0.25f * (((a + b) + c) + d) per level, the reference's operand order (HessianBlocks.cpp:150-166).
+__device__ __forceinline__ void pyrRegCoarse(const float (&v)[8][4], const PyrGeom& G, const FrameStore& fs, const int slot, const int tx, const int ty, const bool live, const int lane) {
+  if (G.levels < 2) return;
+  float l1[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 2; c++) l1[r][c] = 0.25f * (v[2 * r][2 * c] + v[2 * r][2 * c + 1] + v[2 * r + 1][2 * c] + v[2 * r + 1][2 * c + 1]);
+  if (live) {
+    float* __restrict__ d1 = fs.own_level(slot, 1);
+    const int w1 = G.w[1];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float2 q = make_float2(l1[r][0], l1[r][1]); __builtin_memcpy(d1 + (size_t)(4 * ty + r) * w1 + 2 * tx, &q, 8); }
+  }
+  if (G.levels < 3) return;
+  float l2[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) l2[r] = 0.25f * (l1[2 * r][0] + l1[2 * r][1] + l1[2 * r + 1][0] + l1[2 * r + 1][1]);
+  if (live) {
+    float* __restrict__ d2 = fs.own_level(slot, 2);
+    const int w2 = G.w[2];
+    d2[(size_t)(2 * ty) * w2 + tx] = l2[0];
+    d2[(size_t)(2 * ty + 1) * w2 + tx] = l2[1];
+  }
+  if (G.levels < 4) return;
+  // level 3: the 2 x 2 block of level 2 = this lane's two values and those of the lane to its right (w0 % 8 == 0: a lane pair never straddles a block row)
+  const float nb0 = __shfl_down(l2[0], 1, 64), nb1 = __shfl_down(l2[1], 1, 64);
+  if (live && !(lane & 1)) fs.own_level(slot, 3)[(size_t)ty * G.w[3] + (tx >> 1)] = 0.25f * (l2[0] + nb0 + l2[1] + nb1);
+}
+
 // The same build without workgroup coupling — the default of dmvio_hip_frames_from_raw_device_batch for pyramids of at most four levels on images whose sides are
 // multiples of 8 (512x512, 640x480, 800x400 ...).  A thread owns a 4 x 8 pixel block: its eight level-0 rows, the 2 x 4 values of level 1 and the two of level 2 they
 // reduce to never leave registers, level 3 is formed by the even lane of a lane pair (one cross-lane read).  No barrier and — row-major level 0 — no LDS: a wavefront
@@ -321,32 +352,52 @@ __global__ void __launch_bounds__(256) k_build_pyramids_raw_reg(const T* __restr
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
-  if (G.levels < 2) return;
-  float l1[4][2];
+  pyrRegCoarse(v, G, fs, slot, tx, ty, live, lane);
+}
+
+// fp32 images resident on the device: the same wave-autonomous build.  ATTACH: level 0 is the caller's image itself (nothing stored for it) — the case the library launches
+// this kernel for (dmvio_hip_frames_attach_device_batch: 1.075 -> 1.023 ms per 4096 frames of 512x512); with level 0 copied the LDS-tile build stays 4 % ahead
+// (1.74 vs 1.81 ms) and keeps that path.  Rows are read with non-temporal 16-byte loads where the frame's base allows.
+template <bool ATTACH>
+__global__ void __launch_bounds__(256) k_build_pyramids_reg(const float* __restrict__ in_base, const size_t in_stride, const PyrGeom G, const FrameStore fs,
+                                                             const int* __restrict__ slots, const int single_slot, const unsigned int gen) {
+  const int f = blockIdx.y;
+  const int slot = slots ? slots[f] : single_slot;
+  const float* __restrict__ src = in_base + (size_t)f * in_stride;
+  const int w0 = G.w[0], h0 = G.h[0];
+  const int tpr4 = w0 >> 2, nthr = tpr4 * (h0 >> 3);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const bool live = t < nthr;
+  const int tx = live ? t % tpr4 : 0, ty = live ? t / tpr4 : 0;
+  const int x = 4 * tx, y = 8 * ty;
+  const int lane = threadIdx.x & 63;
+  float v[8][4];
+  const float* __restrict__ p0 = src + (size_t)y * w0 + x;
+  if (((uintptr_t)src & 15) == 0) {   // x % 4 == 0, w0 % 8 == 0: the frame's base decides for every row
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+    for (int r = 0; r < 8; r++) { const pyr_f4 q = __builtin_nontemporal_load(reinterpret_cast<const pyr_f4*>(p0 + (size_t)r * w0)); v[r][0] = q[0]; v[r][1] = q[1]; v[r][2] = q[2]; v[r][3] = q[3]; }
+  } else {
 #pragma unroll
-    for (int c = 0; c < 2; c++) l1[r][c] = 0.25f * (v[2 * r][2 * c] + v[2 * r][2 * c + 1] + v[2 * r + 1][2 * c] + v[2 * r + 1][2 * c + 1]);
-  if (live) {
-    float* __restrict__ d1 = fs.own_level(slot, 1);
-    const int w1 = G.w[1];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const float2 q = make_float2(l1[r][0], l1[r][1]); __builtin_memcpy(d1 + (size_t)(4 * ty + r) * w1 + 2 * tx, &q, 8); }
+    for (int r = 0; r < 8; r++) __builtin_memcpy(v[r], p0 + (size_t)r * w0, 16);
   }
-  if (G.levels < 3) return;
-  float l2[2];
+  bool bad = false;
 #pragma unroll
-  for (int r = 0; r < 2; r++) l2[r] = 0.25f * (l1[2 * r][0] + l1[2 * r][1] + l1[2 * r + 1][0] + l1[2 * r + 1][1]);
-  if (live) {
-    float* __restrict__ d2 = fs.own_level(slot, 2);
-    const int w2 = G.w[2];
-    d2[(size_t)(2 * ty) * w2 + tx] = l2[0];
-    d2[(size_t)(2 * ty + 1) * w2 + tx] = l2[1];
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) bad |= !(fabsf(v[r][k]) <= 1e30f);
+  if (__any(bad && live) && lane == 0) fs.bad_gen[slot] = gen;
+  if (t == 0) { fs.build_gen[slot] = gen; fs.lvl0[slot] = ATTACH ? src : fs.own_level(slot, 0); fs.tiled0[slot] = 0; }
+  if (!ATTACH && live) {
+    float* __restrict__ dst0 = fs.own_level(slot, 0);
+    if (((uintptr_t)dst0 & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) { const pyr_f4 q = {v[r][0], v[r][1], v[r][2], v[r][3]}; __builtin_nontemporal_store(q, reinterpret_cast<pyr_f4*>(dst0 + (size_t)(y + r) * w0 + x)); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; r++) __builtin_memcpy(dst0 + (size_t)(y + r) * w0 + x, v[r], 16);
+    }
   }
-  if (G.levels < 4) return;
-  // level 3: the 2 x 2 block of level 2 = this lane's two values and those of the lane to its right (w0 % 8 == 0: a lane pair never straddles a block row)
-  const float nb0 = __shfl_down(l2[0], 1, 64), nb1 = __shfl_down(l2[1], 1, 64);
-  if (live && !(lane & 1)) fs.own_level(slot, 3)[(size_t)ty * G.w[3] + (tx >> 1)] = 0.25f * (l2[0] + nb0 + l2[1] + nb1);
+  pyrRegCoarse(v, G, fs, slot, tx, ty, live, lane);
 }
 
 // level 0 of a slot out of the 8x4-tile layout into a row-major plane (consumers other than the coarse tracker's batch kernel: dmv_ensure_row_major)

@@ -87,13 +87,16 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* ctx, dmvio_hip_undisto
  * points, the initializer, downloads) converts it back to row-major on first use — same values, bit for bit.  dmvio_hip_frame_level0_is_tiled reports a slot's state. */
 int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* ctx, int tiled);
 int dmvio_hip_frame_level0_is_tiled(dmvio_hip_ctx* ctx, int slot);
-/* Kernel behind dmvio_hip_frames_from_raw_device_batch: variant 1 (default) = a 4 x 8 pixel block per thread, every level formed in registers, no workgroup barrier (pyramids
- * of at most four levels on images whose sides are multiples of 8); variant 0 = the general LDS-tile build.  Identical output, bit for bit; for A/B measurements. */
+/* Kernels behind dmvio_hip_frames_from_raw_device_batch and dmvio_hip_frames_attach_device_batch: variant 1 (default) = a 4 x 8 pixel block per thread, every level formed
+ * in registers, no workgroup barrier (pyramids of at most four levels on images whose sides are multiples of 8; other geometries always take variant 0); variant 0 = the
+ * general LDS-tile builds (which also serve single uploads and dmvio_hip_frames_from_device_batch).  Identical output, bit for bit; for A/B measurements. */
 int dmvio_hip_set_raw_batch_kernel(dmvio_hip_ctx* ctx, int variant);
 /* Diagnostics.  Every pyramid build stamps its slot "clean" when all pixels are finite (|I| <= 1e30): consumers then run without the
  * reference's isfinite guards (HessianBlocks.cpp:172-181, CoarseTracker.cpp:455), which cannot fire on such a frame.  This call withdraws
  * the stamp so that the guarded code path runs (tests compare the two). */
 int dmvio_hip_frame_mark_unclean(dmvio_hip_ctx* ctx, int slot);
+/* 1: the slot carries the clean stamp of its last build, 0: it does not (a pixel was not finite, or the stamp was withdrawn), < 0: error.  Waits for the context's stream. */
+int dmvio_hip_frame_is_clean(dmvio_hip_ctx* ctx, int slot);
 /* dIp[lvl] back on host as w_l*h_l*3 floats (AoS, the reference's Eigen::Vector3f layout). */
 int dmvio_hip_frame_download(dmvio_hip_ctx* ctx, int slot, int lvl, float* dIp_host);
 /* absSquaredGrad[0..n_levels-1] of FrameHessian::makeImages (src/dso/FullSystem/HessianBlocks.cpp:169-189) — the planes PixelSelector::makeMaps /

@@ -111,6 +111,42 @@ def test_raw_batch_register_build_equals_the_lds_tile_build(pkg, gpu_required, b
     pkg.set_raw_batch_kernel(ctx, 1); pkg.set_raw_batch_layout(ctx, True)
 
 
+@pytest.mark.parametrize("size", [(512, 512), (640, 480), (128, 64)])
+def test_fp32_register_build_equals_the_lds_tile_build(pkg, gpu_required, size):
+    """The same two kernels behind the fp32 entry points: single upload, batch copied from device memory, batch attached in place (level 0 = the caller's image) — with frame
+    bases that are 16-byte aligned and that are not.  Every level the same bits; a NaN pixel withdraws the slot's clean stamp in both."""
+    import torch
+    w, h = size
+    B = 5
+    rng = np.random.RandomState(3)
+    imgs = (rng.rand(B, h * w) * 255).astype(np.float32)
+    ctx = pkg.Context(w, h, n_slots=6 * B + 2)
+    for pad in (0, 1):                                       # floats between frames: bases aligned to 16 bytes / to 4
+        host = np.zeros((B, h * w + 4 + pad), np.float32); host[:, :h * w] = imgs
+        dev = torch.from_numpy(host).to("cuda:0"); torch.cuda.synchronize()
+        k = 0
+        for variant in (0, 1):
+            pkg.set_raw_batch_kernel(ctx, variant)
+            ctx.frames_from_device_batch(list(range(k * B, (k + 1) * B)), dev.data_ptr(), host.shape[1] * 4); k += 1
+            ctx.frames_attach_device_batch(list(range(k * B, (k + 1) * B)), dev.data_ptr(), host.shape[1] * 4); k += 1
+            for i in range(B):
+                ctx.frame_upload(k * B + i, imgs[i])
+            k += 1
+        ctx.synchronize()
+        for i in range(B):
+            for lvl in range(ctx.levels):
+                ref = ctx.frame_download(i, lvl).view(np.uint32)
+                for kk in range(1, 6):
+                    assert np.array_equal(ctx.frame_download(kk * B + i, lvl).view(np.uint32), ref), (pad, i, lvl, kk)
+    bad = imgs[0].copy(); bad[h * w // 2 + 3] = np.nan
+    for variant in (0, 1):
+        pkg.set_raw_batch_kernel(ctx, variant)
+        ctx.frame_upload(6 * B + variant, bad)
+    ctx.synchronize()
+    assert not ctx.frame_is_clean(6 * B) and not ctx.frame_is_clean(6 * B + 1) and ctx.frame_is_clean(0)
+    pkg.set_raw_batch_kernel(ctx, 1)
+
+
 @pytest.mark.parametrize("B,launch", [(6, None), (200, (1, 512)), (600, (1, 256))])
 def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_required, B, launch):
     """dmvio_hip_frames_from_raw_device_batch stores level 0 in 8x4-pixel tiles (it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per

@@ -19,10 +19,12 @@ def t(fn, reps=8):
         ev0.record(stream); fn(); ev1.record(stream); ev1.synchronize(); ts.append(ev0.elapsed_time(ev1))
     return float(np.median(ts))
 lv = sum(4 * (w >> l) * (h >> l) for l in range(1, ctx.levels))
-ta = t(lambda: ctx.frames_attach_device_batch(slots, raw.data_ptr(), w * h * 4))
-print("attach  fp32: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (ta, B * (4 * w * h + lv) / ta / 1e9, 4 * w * h, lv))
-tc = t(lambda: ctx.frames_from_device_batch(slots, raw.data_ptr(), w * h * 4))
-print("copy    fp32: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (tc, B * (8 * w * h + lv) / tc / 1e9, 4 * w * h, 4 * w * h + lv))
+for variant, vname in ((0, "LDS-tile build"), (1, "register build")):
+    P.set_raw_batch_kernel(ctx, variant)
+    ta = t(lambda: ctx.frames_attach_device_batch(slots, raw.data_ptr(), w * h * 4))
+    print("fp32 attached in place, %s: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (vname, ta, B * (4 * w * h + lv) / ta / 1e9, 4 * w * h, lv))
+    tc = t(lambda: ctx.frames_from_device_batch(slots, raw.data_ptr(), w * h * 4))
+    print("fp32 copied, %s: %.3f ms  %.2f TB/s (read %d + write %d B/frame)" % (vname, tc, B * (8 * w * h + lv) / tc / 1e9, 4 * w * h, 4 * w * h + lv))
 und = P.UndistorterHip(ctx, w, h, 8)
 G = np.linspace(0, 255, 256).astype(np.float32); vig = np.ones((h, w), np.float32)
 und2 = P.UndistorterHip(ctx, w, h, 8, G, vig)
