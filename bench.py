@@ -446,8 +446,9 @@ def main():
                                       undistort_pyramid_GBps=round(B * (w * h + sum(4 * (w >> l) * (h >> l) for l in range(ctx.levels))) / (k8_ms * 1e-3) / 1e9, 1),
                                       note="frames cross PCIe as %d-byte 8-bit raw images; undistortion + makeImages fused in one launch (dmvio_hip_frames_from_raw_device_batch), then trackNewestCoarse "
                                            "+ result fetch; `value`: the copy of batch k+1 on a second stream overlaps batch k (two device buffers), `value_not_pipelined`: copy, build, track in sequence" % (w * h))
-            # the same frames RESIDENT in HBM as 8-bit raw images (no copy in the step): undistortion + pyramid build + tracking, with level 0 written in 8x4 tiles
-            # (the default: the coarse tracker gathers 2.4 instead of 4.3 lines per tap) and row-major; kernel times by HIP events on the stream
+            # the same frames RESIDENT in HBM as 8-bit raw images (no copy in the step): undistortion + pyramid build + tracking, with level 0 written row-major (the default)
+            # and in 8x4 tiles (2.4 instead of 4.3 lines per tap, but twelve dword loads with their own tile addresses per tap: measured slower in k_track_lm);
+            # kernel times by HIP events on the stream
             try:
                 res = {}
                 for name, tiled in (("tiled_8x4", True), ("row_major", False)):
@@ -472,7 +473,7 @@ def main():
                                      value=round(B / tr_, 1), good=bool(r0["good"].all()), max_pose_err_m=float(np.linalg.norm(r0["pose7"][:, :3] - truth[:, :3], axis=1).max()),
                                      k_track_lm_roofline_frac=round(BYTES_PER_POINT_EVAL * npe / (float(np.mean(kt)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                      build_GBps=round(B * (w * h + sum(4 * (w >> l) * (h >> l) for l in range(ctx.levels))) / (float(np.mean(kb)) * 1e-3) / 1e9, 1))
-                pkg.set_raw_batch_layout(ctx, True)
+                pkg.set_raw_batch_layout(ctx, False)
                 res["k_track_lm_speedup_tiled"] = round(res["row_major"]["k_track_lm_ms"] / res["tiled_8x4"]["k_track_lm_ms"], 4)
                 res["what"] = ("%d 8-bit raw frames resident in HBM per step: dmvio_hip_frames_from_raw_device_batch (undistortion + all pyramid levels) + trackNewestCoarse, not "
                                "pipelined; level 0 in 8x4-pixel tiles vs row-major — identical results bit for bit (tests/test_io_gpu.py), other addresses" % B)

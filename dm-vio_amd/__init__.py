@@ -543,7 +543,7 @@ class CoarseTrackerHip:
 
 
 def set_raw_batch_layout(ctx, tiled):
-    """What UndistorterHip.from_raw_device_batch writes as level 0: 8x4 tiles (True, the default) or row-major (dmvio_hip_set_raw_batch_layout)."""
+    """What UndistorterHip.from_raw_device_batch writes as level 0: 8x4 tiles (True) or row-major (False, the default) (dmvio_hip_set_raw_batch_layout)."""
     fn = ctx.L.dmvio_hip_set_raw_batch_layout; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
     _chk(ctx.L, fn(ctx.p, 1 if tiled else 0), "set_raw_batch_layout")
 

@@ -125,7 +125,6 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipMalloc((void**)&c->fs.tiled0, n_frame_slots));
   HIPCHKP(hipMemsetAsync(c->fs.tiled0, 0, n_frame_slots, c->stream));
   c->h_tiled.assign(n_frame_slots, 0);
-  if (const char* e = getenv("DMVIO_HIP_RAW_TILED")) c->raw_batch_tiled = atoi(e) != 0;
   HIPCHKP(hipMalloc((void**)&c->d_upload, sizeof(float) * w * h));
   c->pg.levels = c->levels;
   for (int l = 0; l < c->levels; l++) { c->pg.w[l] = c->wl[l]; c->pg.h[l] = c->hl[l]; }
@@ -215,8 +214,9 @@ int dmv_ensure_row_major(dmvio_hip_ctx* c, int slot) {
   std::lock_guard<std::mutex> lk(c->mu);
   return dmv_ensure_row_major_locked(c, slot);
 }
-// What dmvio_hip_frames_from_raw_device_batch writes as level 0: 1 = 8x4 tiles (the coarse tracker's batch kernel reads them natively; other consumers convert the slot
-// back on first use), 0 = row-major.  Tiles need w % 8 == 0 and h % 4 == 0; other sizes are always row-major.
+// What dmvio_hip_frames_from_raw_device_batch writes as level 0: 0 = row-major (default), 1 = 8x4 tiles (the coarse tracker's batch kernel reads them natively; other consumers
+// convert the slot back on first use).  Tiles need w % 8 == 0 and h % 4 == 0; other sizes are always row-major.  Measured (profiles/r04_*): the tiled plane saves lines per tap
+// (2.4 instead of 4.3) but costs twelve dword loads with their own tile addresses instead of four vector loads — k_track_lm 3.78 vs 3.50 ms per 4096 frames — hence not the default.
 int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* c, int tiled) {
   if (!c) return failmsg("null ctx");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -383,8 +383,7 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistort
   if (int r = stageSlots(c, B, slots)) return r;
   UndistortDev U = u->U;
   U.factor = factor;
-  // level 0 in 8x4 tiles (this kernel writes level 0 anyway, so the layout is free): what the coarse tracker's batch kernel gathers from with 2.4 instead of 4.3 missed
-  // lines per tap
+  // level 0 in 8x4 tiles on request (dmvio_hip_set_raw_batch_layout)
   const bool tiled = c->raw_batch_tiled && (c->w % 8) == 0 && (c->h % 4) == 0;
   // the wave-autonomous build (a 4 x 8 pixel block per thread, levels in registers) where the pyramid allows it, the LDS-tile build otherwise
   const bool reg = regBuild(c);

@@ -89,7 +89,7 @@ struct dmvio_hip_ctx {
   unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)
   std::vector<unsigned char> h_tiled;   // host mirror of FrameStore::tiled0: level 0 of the slot is stored in 8x4 tiles (written so by the batched raw-image build)
   int raw_batch_kernel = 1;             // dmvio_hip_set_raw_batch_kernel: 1 = the wave-autonomous register build where the geometry allows (<= 4 levels, sides % 8 == 0), 0 = the LDS-tile build
-  int raw_batch_tiled = 1;              // dmvio_hip_set_raw_batch_layout: what dmvio_hip_frames_from_raw_device_batch writes (1 = tiles where the image size allows)
+  int raw_batch_tiled = 0;              // dmvio_hip_set_raw_batch_layout: what dmvio_hip_frames_from_raw_device_batch writes (1 = tiles where the image size allows)
   DmvBounce bounce;             // caller-owned arrays cross PCIe through here (used under `mu`)
   std::mutex mu;
 };

@@ -80,11 +80,12 @@ int dmvio_hip_frames_attach_device_batch(dmvio_hip_ctx* ctx, int B, const int* s
  * enters the kernel as 1 (2) bytes per pixel instead of 4, and the undistorted fp32 image is written once, as level 0.  `factor` as in
  * dmvio_hip_frame_upload_raw.  Bit-identical to B calls of dmvio_hip_frame_upload_raw.  Asynchronous on the ctx stream. */
 int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* ctx, dmvio_hip_undistorter* und, int B, const int* slots, const void* raw_dev_base, size_t stride_bytes, float factor);
-/* Layout of the level-0 plane dmvio_hip_frames_from_raw_device_batch writes: tiled != 0 (default): 8x4-pixel tiles (one 128-byte line each), which the coarse tracker's
- * batch kernel (dmvio_hip_tracker_track_batch with >= 2 problems) gathers from directly — the 4x4 footprint of a bilinear tap (getInterpolatedElement33,
- * util/globalFuncs.h:103-118) then touches 2.4 lines on average instead of 4.3; the build writes level 0 anyway, so the layout costs nothing.  Needs w % 8 == 0 and
- * h % 4 == 0 (other sizes are always row-major).  Every other consumer of such a slot (setCoarseTrackingRef, single-frame tracking, the window optimiser, immature
- * points, the initializer, downloads) converts it back to row-major on first use — same values, bit for bit.  dmvio_hip_frame_level0_is_tiled reports a slot's state. */
+/* Layout of the level-0 plane dmvio_hip_frames_from_raw_device_batch writes: tiled == 0 (default): row-major; tiled != 0: 8x4-pixel tiles (one 128-byte line each), which the
+ * coarse tracker's batch kernel (dmvio_hip_tracker_track_batch with >= 2 problems) gathers from directly — the 4x4 footprint of a bilinear tap (getInterpolatedElement33,
+ * util/globalFuncs.h:103-118) then touches 2.4 lines on average instead of 4.3, at the price of twelve single loads with their own tile addresses per tap.  Measured on MI355X
+ * the price is the larger term (k_track_lm 8 % slower at 4096 frames), which is why the layout is an option and not the default.  Needs w % 8 == 0 and h % 4 == 0 (other sizes
+ * are always row-major).  Every other consumer of a tiled slot (setCoarseTrackingRef, single-frame tracking, the window optimiser, immature points, the initializer, downloads)
+ * converts it back to row-major on first use — same values, bit for bit.  dmvio_hip_frame_level0_is_tiled reports a slot's state. */
 int dmvio_hip_set_raw_batch_layout(dmvio_hip_ctx* ctx, int tiled);
 int dmvio_hip_frame_level0_is_tiled(dmvio_hip_ctx* ctx, int slot);
 /* Kernels behind dmvio_hip_frames_from_raw_device_batch and dmvio_hip_frames_attach_device_batch: variant 1 (default) = a 4 x 8 pixel block per thread, every level formed

@@ -108,7 +108,7 @@ def test_raw_batch_register_build_equals_the_lds_tile_build(pkg, gpu_required, b
                 ref = ctx.frame_download(i, lvl).view(np.uint32)
                 for kk in (1, 2, 3):
                     assert np.array_equal(ctx.frame_download(kk * B + i, lvl).view(np.uint32), ref), (pad, i, lvl, kk)
-    pkg.set_raw_batch_kernel(ctx, 1); pkg.set_raw_batch_layout(ctx, True)
+    pkg.set_raw_batch_kernel(ctx, 1); pkg.set_raw_batch_layout(ctx, False)
 
 
 @pytest.mark.parametrize("size", [(512, 512), (640, 480), (128, 64)])
@@ -149,7 +149,7 @@ def test_fp32_register_build_equals_the_lds_tile_build(pkg, gpu_required, size):
 
 @pytest.mark.parametrize("B,launch", [(6, None), (200, (1, 512)), (600, (1, 256))])
 def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_required, B, launch):
-    """dmvio_hip_frames_from_raw_device_batch stores level 0 in 8x4-pixel tiles (it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per
+    """dmvio_hip_frames_from_raw_device_batch can store level 0 in 8x4-pixel tiles (dmvio_hip_set_raw_batch_layout; it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per
     tap from other addresses, so every result — pose, affine, residuals, flow indicators, H, b, iteration count — equals the row-major layout's BIT FOR BIT, in cluster mode
     (B = 6), with 512-thread (B = 200) and 256-thread workgroups (B = 600); every other consumer converts such a slot back on first use (download, reference template,
     single-frame tracking, a window of the optimiser)."""
@@ -164,10 +164,10 @@ def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_
     raws = np.stack([np.clip(np.rint(case["frames"][i % 4]["img"]), 0, 255).astype(np.uint8) for i in range(B)])
     dev = torch.from_numpy(raws.reshape(B, -1)).to("cuda:0"); torch.cuda.synchronize()
     tiled_slots, plain_slots = list(range(1, B + 1)), list(range(B + 1, 2 * B + 1))
+    und.from_raw_device_batch(plain_slots, dev.data_ptr(), w * h)                              # row-major is the default
+    pkg.set_raw_batch_layout(ctx, True)
     und.from_raw_device_batch(tiled_slots, dev.data_ptr(), w * h)
     pkg.set_raw_batch_layout(ctx, False)
-    und.from_raw_device_batch(plain_slots, dev.data_ptr(), w * h)
-    pkg.set_raw_batch_layout(ctx, True)
     ctx.synchronize()
     assert all(pkg.frame_level0_is_tiled(ctx, s) for s in tiled_slots) and not any(pkg.frame_level0_is_tiled(ctx, s) for s in plain_slots)
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
