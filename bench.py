@@ -1139,6 +1139,7 @@ def bench_dropin(args, w, h):
     cpu_mt = run("cpu_mt", "--mode", "cpu", "--init", "ref", "--mt")     # the reference as it ships: multiThreading = true (6 workers), its own initialiser
     cpu_st = run("cpu_st", "--mode", "cpu", "--init", "seq")             # deterministic single-threaded baseline (the trajectory the HIP-backed run is compared with)
     hip = run("hip", "--mode", "hip", "--init", "hip")
+    hip_mt = run("hip_mt", "--mode", "hip", "--init", "hip", "--mt")     # what the reference keeps doing itself on its 6 workers, like cpu_mt: the like-for-like wall clock
     v = (cpu_st["valid"] != 0) & (hip["valid"] != 0)
     d = cpu_st["camToWorld"][v, :3] - hip["camToWorld"][v, :3]
     v2 = (cpu_st["valid"] != 0) & (cpu_mt["valid"] != 0)
@@ -1156,7 +1157,13 @@ def bench_dropin(args, w, h):
                      "oracle/_ref/libref.so)" % (len(hip["valid"]), w, h),
                 frames=int(len(hip["valid"])), keyframe_optimisations=int(hip["stat_calls"][4]),
                 all_cpu_s=round(float(cpu_mt["wall_s"][0]), 3), all_cpu_single_threaded_s=round(float(cpu_st["wall_s"][0]), 3), hip_backed_s=round(float(hip["wall_s"][0]), 3),
+                hip_backed_default_threading_s=round(float(hip_mt["wall_s"][0]), 3),
                 speedup_vs_reference_default=round(float(cpu_mt["wall_s"][0]) / float(hip["wall_s"][0]), 2),
+                speedup_vs_reference_default_same_threading=round(float(cpu_mt["wall_s"][0]) / float(hip_mt["wall_s"][0]), 2),
+                adapter_ms_per_keyframe=dict(zip(["hand_over", "dmvio_hip_ba_optimize", "write_back"], [round(1e3 * float(x) / max(int(hip["stat_calls"][4]), 1), 4) for x in hip["optimize_split_seconds"]])),
+                adapter_ms_per_keyframe_default_threading=dict(zip(["hand_over", "dmvio_hip_ba_optimize", "write_back"],
+                                                                   [round(1e3 * float(x) / max(int(hip_mt["stat_calls"][4]), 1), 4) for x in hip_mt["optimize_split_seconds"]])),
+                window_graph=dict(zip(["forwarded_mutations", "resyncs"], [int(hip["resident"][0]), int(hip["resident"][1])])),
                 ms_per_frame_after_initialisation=dict(all_cpu=round(1e3 * steady(cpu_mt), 3), all_cpu_single_threaded=round(1e3 * steady(cpu_st), 3), hip_backed=round(1e3 * steady(hip), 3)),
                 traj_rmse_m=float(np.sqrt((d ** 2).sum(1).mean())), traj_max_m=float(np.abs(d).max()),
                 reference_own_spread_rmse_m=float(np.sqrt((d2 ** 2).sum(1).mean())),

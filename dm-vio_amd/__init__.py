@@ -759,6 +759,81 @@ class RcclCommunicator:
             self.p = None
 
 
+class WindowGraph:
+    """dmvio_hip_graph: the host-side mirror of the window's point / residual graph with EnergyFunctional's own mutators (insertFrame / insertPoint / insertResidual /
+    dropResidual / removePoint / marginalizeFrame, EnergyFunctional.cpp:435-518, 641-646, 766-782).  Host only: needs the library, no device."""
+
+    def __init__(self, L=None):
+        self.L = L or load_library()
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        self.L.dmvio_hip_graph_create.restype = vp
+        for name, args in (("destroy", [vp]), ("clear", [vp]), ("insert_frame", [vp]), ("remove_frame", [vp, ci]), ("insert_point", [vp, ci, cf, cf, cf, fp, fp, ci]),
+                           ("remove_point", [vp, ci, ci]), ("insert_residual", [vp, ci, ci, ci]), ("drop_residual", [vp, ci, ci, ci]), ("set_idepth", [vp, ci, ci, cf]),
+                           ("set_idepths", [vp, ci, fp]), ("counts", [vp, ip, ip, ip]), ("frame_points", [vp, ci]), ("point_residuals", [vp, ci, ci]),
+                           ("export", [vp, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_ubyte), ip, ip])):
+            fn = getattr(self.L, "dmvio_hip_graph_" + name); fn.argtypes = args; fn.restype = None if name == "destroy" else ci
+        self.p = C.c_void_p(self.L.dmvio_hip_graph_create())
+        if not self.p:
+            raise HipLibraryError("dmvio_hip_graph_create failed")
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_graph_destroy(self.p); self.p = None
+
+    def _c(self, name, *a):
+        return _chk(self.L, getattr(self.L, "dmvio_hip_graph_" + name)(self.p, *a), "graph_" + name)
+
+    def clear(self): self._c("clear")
+    def insert_frame(self): return self._c("insert_frame")
+    def remove_frame(self, idx): self._c("remove_frame", int(idx))
+
+    def insert_point(self, host, u, v, idepth, color8, weights8, prior=False):
+        c = np.ascontiguousarray(color8, dtype=np.float32); w = np.ascontiguousarray(weights8, dtype=np.float32)
+        return self._c("insert_point", int(host), float(u), float(v), float(idepth), _f(c), _f(w), 1 if prior else 0)
+
+    def remove_point(self, host, idx): self._c("remove_point", int(host), int(idx))
+    def insert_residual(self, host, idx, target): return self._c("insert_residual", int(host), int(idx), int(target))
+    def drop_residual(self, host, idx, k): self._c("drop_residual", int(host), int(idx), int(k))
+    def set_idepth(self, host, idx, idepth): self._c("set_idepth", int(host), int(idx), float(idepth))
+
+    def set_idepths(self, idepth):
+        a = np.ascontiguousarray(idepth, dtype=np.float32)
+        self._c("set_idepths", len(a), _f(a))
+
+    def counts(self):
+        F, N, R = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._c("counts", C.byref(F), C.byref(N), C.byref(R))
+        return F.value, N.value, R.value
+
+    def frame_points(self, host): return self._c("frame_points", int(host))
+    def point_residuals(self, host, idx): return self._c("point_residuals", int(host), int(idx))
+
+    def export(self):
+        """The flat arrays of BundleAdjusterHip.set_graph, in makeIDX order."""
+        _, N, R = self.counts()
+        o = dict(host=np.zeros(N, np.int32), u=np.zeros(N, np.float32), v=np.zeros(N, np.float32), idepth=np.zeros(N, np.float32), color=np.zeros((N, 8), np.float32),
+                 weights=np.zeros((N, 8), np.float32), hasDepthPrior=np.zeros(N, np.uint8), res_point=np.zeros(R, np.int32), res_target=np.zeros(R, np.int32))
+        self._c("export", _i(o["host"]), _f(o["u"]), _f(o["v"]), _f(o["idepth"]), _f(o["color"]), _f(o["weights"]), o["hasDepthPrior"].ctypes.data_as(C.POINTER(C.c_ubyte)),
+                _i(o["res_point"]), _i(o["res_target"]))
+        return o
+
+    @classmethod
+    def from_case(cls, case, L=None):
+        """The graph of a synth.ba_case dictionary, built through the mutators."""
+        g = cls(L)
+        for _ in range(case["n_frames"]):
+            g.insert_frame()
+        hp = case.get("hasDepthPrior")
+        idx = []
+        for p in range(len(case["u"])):
+            idx.append(g.insert_point(case["host"][p], case["u"][p], case["v"][p], case["idepth0"][p], case["color"][p], case["weights"][p], bool(hp[p]) if hp is not None else False))
+        for r in range(len(case["res_point"])):
+            p = case["res_point"][r]
+            g.insert_residual(case["host"][p], idx[p], case["res_target"][r])
+        return g
+
+
 class BundleAdjusterHip:
     """The sliding window FullSystem::optimize works on, over the C ABI (include/dmvio_hip.h, "sliding-window BA")."""
 
@@ -865,6 +940,13 @@ class BundleAdjusterHip:
         u8 = C.POINTER(C.c_ubyte)
         _chk(self.L, self.L.dmvio_hip_ba_set_graph(self.p, self.N, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), _f(a[4]), _f(a[5]),
                                                    None if hp is None else hp.ctypes.data_as(u8), self.R, _i(rp), _i(rt)), "ba_set_graph")
+
+    def set_graph_from(self, graph):
+        """dmvio_hip_ba_set_graph_from: the device arrays from a resident WindowGraph (after set_window)."""
+        fn = self.L.dmvio_hip_ba_set_graph_from; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, graph.p), "ba_set_graph_from")
+        _, self.N, self.R = graph.counts()
+        self._n_newest = int((graph.export()["res_target"] == self.F - 1).sum())
 
     def activate_all(self):
         _chk(self.L, self.L.dmvio_hip_ba_activate_all(self.p), "ba_activate_all")

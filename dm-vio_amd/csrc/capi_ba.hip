@@ -78,7 +78,7 @@ struct dmvio_hip_ba {
   // device storage.  The window is rebuilt for every keyframe (dmvio_hip_ba_set_graph): its ~75 device arrays are carved out of a few large chunks that stay with the
   // handle and are cleared with one memset each — not allocated, cleared and freed one by one (that cost milliseconds per keyframe, more than optimize(6) itself)
   std::vector<void*> allocs;
-  struct Arena { std::vector<std::pair<char*, size_t>> chunks; size_t cur = 0, off = 0; bool on = false; } arena;
+  struct Arena { std::vector<std::pair<char*, size_t>> chunks; std::vector<size_t> used; size_t cur = 0, off = 0; bool on = false; } arena;   // used[k]: bytes of chunk k handed out since it was last cleared
   size_t cap_spart = 0, cap_idepth_backup = 0;   // capacities of the grow-only pinned host buffers
   BAPrecalc* d_pre = nullptr;        // the precalc table the kernels read: one of the two halves of d_pre2
   BAPrecalc* d_pre2 = nullptr;       // [2][F*F]: the table of the backed-up state stays resident, a rejected step switches back to it
@@ -128,6 +128,7 @@ struct dmvio_hip_ba {
   double final_energy = 0;
   BATimes tm;
   bool timing = false;
+  double tm_graph[6] = {0, 0, 0, 0, 0, 0}; long tm_graph_n = 0;   // dmvio_hip_ba_set_graph: drain + arena memset, host lists, allocation, uploads, pinned buffers + slot table, adjoints + final wait
   // true only between a REJECTED step of gnIteration and the next gnIteration: the state was restored to the one the per-point sums (and the
   // point backup) were computed at, so k_ba_point_sums would reproduce what is already there.  Every other entry point clears it.
   bool sums_fresh = false;
@@ -136,6 +137,8 @@ struct dmvio_hip_ba {
   float *d_mHdiF = nullptr, *d_mbdSumF = nullptr, *d_mHcd = nullptr, *d_margRec = nullptr, *d_adHTdelta = nullptr;
   long long* d_accTicks = nullptr;   // per-block stamps of k_ba_accumulate (timing mode only)
   int accTicksBlocks = 0;
+  // flat arrays of dmvio_hip_ba_set_graph_from (kept between keyframes: no allocation in the steady state)
+  struct GraphScratch { std::vector<int> host, res_point, res_target; std::vector<float> u, v, idepth, color, weights; std::vector<unsigned char> prior; } gscratch;
   // ---- points sharded over ranks (dmvio_hip_ba_set_comm): every rank holds all keyframes and ITS points; the stitched system is summed by
   // an all-reduce in HBM on this handle's stream, the accept / threshold decisions are taken over the all-gathered per-rank records
   int rank = 0, world = 0;           // world == 0: no communicator
@@ -167,6 +170,9 @@ struct dmvio_hip_ba {
   } while (0)
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return failmsg((std::string("RCCL: ") + rccl().getErrorString(r_) + " in " #x).c_str()); } while (0)
 
+// one chunk holds the ~75 arrays of a window of 8 keyframes / 4000 points / 30k residuals; allocated (and the pinned host buffers with it) when the handle is created, so that
+// no keyframe of a live system pays for hipMalloc / hipHostMalloc (seen in tests/dropin: 1.2 ms per keyframe on average over the first ten, 0.4 ms in the steady state)
+static constexpr size_t BA_ARENA_CHUNK = (size_t)48 << 20;
 template <class T>
 static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
   if (b->arena.on) {   // inside dmvio_hip_ba_set_graph: a zeroed piece of the handle's arena
@@ -174,16 +180,17 @@ static int dalloc(dmvio_hip_ba* b, T** p, size_t n) {
     const size_t bytes = (sizeof(T) * std::max<size_t>(n, 1) + 255) & ~(size_t)255;
     while (A.cur < A.chunks.size() && A.off + bytes > A.chunks[A.cur].second) { A.cur++; A.off = 0; }
     if (A.cur == A.chunks.size()) {
-      const size_t size = std::max<size_t>(bytes, (size_t)16 << 20);
+      const size_t size = std::max<size_t>(bytes, BA_ARENA_CHUNK);
       char* base = nullptr;
       HIPCHK(hipMalloc((void**)&base, size));
       HIPCHK(hipMemset(base, 0, size));
       HIPCHK(hipStreamSynchronize(nullptr));
-      A.chunks.push_back(std::make_pair(base, size));
+      A.chunks.push_back(std::make_pair(base, size)); A.used.push_back(0);
       A.off = 0;
     }
     *p = reinterpret_cast<T*>(A.chunks[A.cur].first + A.off);
     A.off += bytes;
+    A.used[A.cur] = std::max(A.used[A.cur], A.off);
     return 0;
   }
   HIPCHK(hipMalloc((void**)p, sizeof(T) * std::max<size_t>(n, 1)));
@@ -203,7 +210,7 @@ static void freeDevice(dmvio_hip_ba* b) {
 static void freeAll(dmvio_hip_ba* b) {
   freeDevice(b);
   for (auto& ch : b->arena.chunks) hipFree(ch.first);
-  b->arena.chunks.clear(); b->arena.cur = b->arena.off = 0;
+  b->arena.chunks.clear(); b->arena.used.clear(); b->arena.cur = b->arena.off = 0;
   b->bounce.release();
   if (b->h_sys) { hipHostFree(b->h_sys); b->h_sys = nullptr; }
   if (b->h_spart) { hipHostFree(b->h_spart); b->h_spart = nullptr; }
@@ -529,6 +536,25 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { failmsg("ba_create: stream creation failed"); delete b; return nullptr; }
   b->own_stream = true;
   b->H.w = ctx->w; b->H.h = ctx->h;
+  {
+    // everything a first keyframe would otherwise allocate: the first arena chunk, the pinned buffers the kernels store into, the staging area of the uploads
+    constexpr int NMAXF = 4 + 8 * BA_MAXF_CAP;
+    char* base = nullptr;
+    bool ok = hipMalloc((void**)&base, BA_ARENA_CHUNK) == hipSuccess && hipMemset(base, 0, BA_ARENA_CHUNK) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+    if (ok) { b->arena.chunks.push_back(std::make_pair(base, BA_ARENA_CHUNK)); b->arena.used.push_back(0); }
+    ok = ok && hipHostMalloc((void**)&b->h_sys, sizeof(double) * (2 * (NMAXF * NMAXF + NMAXF) + 1), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&b->h_res, sizeof(BAHostRes), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&b->h_frameTH, sizeof(float) * BA_MAXF_CAP, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) ok = hipHostMalloc((void**)&b->h_pre[k], sizeof(BAPrecalc) * BA_MAXF_CAP * BA_MAXF_CAP, hipHostMallocDefault) == hipSuccess;
+    b->cap_idepth_backup = 8192;
+    ok = ok && hipHostMalloc((void**)&b->h_idepth_backup, sizeof(float) * b->cap_idepth_backup, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+    b->cap_spart = 4096;
+    ok = ok && hipHostMalloc((void**)&b->h_spart, sizeof(float) * b->cap_spart, hipHostMallocDefault) == hipSuccess;
+    size_t off = 0;
+    ok = ok && b->bounce.reserve((size_t)8 << 20, b->stream, &off) == hipSuccess;
+    b->bounce.used = 0;
+    if (!ok) { failmsg("ba_create: device / pinned allocation failed"); freeAll(b); hipStreamDestroy(b->stream); delete b; return nullptr; }
+  }
   // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
   // the same mapping as dmvio_hip_ba_set_accumulators (k = 1: every accumulator single, the reference's single-threaded order bit for bit)
@@ -540,6 +566,9 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->stream);
+  if (b->timing && b->tm_graph_n > 0)
+    fprintf(stderr, "[dmvio_hip_ba] set_graph over %ld calls (us/call): drain + arena memset=%.1f host lists=%.1f allocation=%.1f uploads=%.1f pinned buffers + slot table=%.1f adjoints + wait=%.1f\n", b->tm_graph_n,
+            b->tm_graph[0] / b->tm_graph_n, b->tm_graph[1] / b->tm_graph_n, b->tm_graph[2] / b->tm_graph_n, b->tm_graph[3] / b->tm_graph_n, b->tm_graph[4] / b->tm_graph_n, b->tm_graph[5] / b->tm_graph_n);
   if (b->timing && b->tm.n > 0) {
     const char* names[8] = {"backup+prepare", "host solve", "step+precalc+energies+args", "launch", "wait for the decision", "accepted: sums+accumulate+stitch / rejected: relinearise", "-", "-"};
     fprintf(stderr, "[dmvio_hip_ba] GN iteration, host clock between phases (no synchronisation added) over %ld iterations (us/iter):", b->tm.n);
@@ -836,12 +865,15 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
   dmvio_hip_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
+  double tg0 = b->timing ? nowUs() : 0, tg1;
+#define SG_PH(i) do { if (b->timing) { tg1 = nowUs(); b->tm_graph[i] += tg1 - tg0; tg0 = tg1; } } while (0)
   HIPCHK(hipStreamSynchronize(b->stream));
   b->th_pending = false;   // the stream is drained and h_res is cleared below (th_ticket restarts at 0 while b->ticket keeps counting): nothing of the old graph may be awaited
   freeDevice(b);
   // the arena of the previous graph, cleared for this one (one memset per chunk on the handle's stream, one wait — the uploads below also use the NULL stream)
-  for (auto& ch : b->arena.chunks) HIPCHK(hipMemsetAsync(ch.first, 0, ch.second, b->stream));
+  for (size_t k = 0; k < b->arena.chunks.size(); k++) if (b->arena.used[k]) { HIPCHK(hipMemsetAsync(b->arena.chunks[k].first, 0, b->arena.used[k], b->stream)); b->arena.used[k] = 0; }   // what the previous graph used, not the whole chunk
   HIPCHK(hipStreamSynchronize(b->stream));
+  SG_PH(0);
   b->arena.cur = 0; b->arena.off = 0;
   struct ArenaScope { dmvio_hip_ba* b; ~ArenaScope() { b->arena.on = false; } } arenaScope{b};
   b->arena.on = true;
@@ -882,6 +914,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
           scd_members[3 * o] = r1; scd_members[3 * o + 1] = r2; scd_members[3 * o + 2] = p;
         }
   }
+  SG_PH(1);
   // ---- device arrays
   int *d_host, *d_res_begin, *d_point, *d_target;
   float *d_u, *d_v, *d_color, *d_weights, *d_prior;
@@ -899,6 +932,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   std::vector<float> prior(N, 0.0f);
   if (hasDepthPrior) for (int p = 0; p < N; p++) prior[p] = hasDepthPrior[p] ? H.S.idepthFixPrior : 0.0f;   // EFPoint::takeData
   hipStream_t s = b->stream;
+  SG_PH(2);
   HIPCHK(b->bounce.h2d(d_host, host, sizeof(int) * N, s));
   HIPCHK(b->bounce.h2d(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), s));
   HIPCHK(b->bounce.h2d(d_point, res_point, sizeof(int) * R, s));
@@ -918,6 +952,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(b->bounce.h2d(b->d_top_members, top_members.data(), sizeof(int) * R, s));
   HIPCHK(b->bounce.h2d(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), s));
   HIPCHK(b->bounce.h2d(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, s));
+  SG_PH(3);
   StitchBufs& SB = b->SB;
   if (dalloc(b, &SB.topHH, (size_t)F * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F * 32) ||
       dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.topCC, (size_t)F * 20) ||
@@ -949,7 +984,7 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   {
     std::vector<int> slot(R, -1);
     for (size_t k = 0; k < b->h_newest.size(); k++) slot[b->h_newest[k]] = (int)k;
-    if (R) HIPCHK(hipMemcpy(b->d_newestSlot, slot.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    if (R) HIPCHK(b->bounce.h2d(b->d_newestSlot, slot.data(), sizeof(int) * R, s));   // staged (the vector may go): asynchronous like the other uploads
     Rs.newestSlot = b->d_newestSlot; Rs.newestE = b->d_newestE;
   }
   b->pre_static_valid = false;
@@ -961,10 +996,42 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
     b->cap_spart = (size_t)2 * b->n_pt_blocks + 64;
     HIPCHK(hipHostMalloc((void**)&b->h_spart, sizeof(float) * b->cap_spart, hipHostMallocDefault));
   }
+  SG_PH(4);
   if (int r = uploadAdjoints(b)) return r;
   HIPCHK(hipStreamSynchronize(s));
+  SG_PH(5);
+#undef SG_PH
+  b->tm_graph_n++;
   b->graph_ready = true;
   return 0;
+}
+
+// dmvio_hip_ba_set_graph from a resident graph (capi_graph.hip): the mirror flattened in makeIDX order — compact records, a few tens of microseconds — instead of arrays
+// the caller rebuilt from its pointer graph.  The window (dmvio_hip_ba_set_window) must have as many keyframes as the graph.  The scratch arrays stay with the handle.
+int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
+  if (!b || !g) return failmsg("ba_set_graph_from: null argument");
+  BA_LOCK(b);
+  int N = 0, R = 0;
+  {
+    std::lock_guard<std::mutex> lg(g->mu);
+    if ((int)g->frames.size() != b->H.F) return failmsg("ba_set_graph_from: the graph has " + std::to_string(g->frames.size()) + " keyframes, the window " + std::to_string(b->H.F));
+    if (g->nDangling) return failmsg("ba_set_graph_from: " + std::to_string(g->nDangling) + " residuals still target a removed keyframe (their dropResidual has not been forwarded)");
+    N = g->nPoints; R = g->nRes;
+    if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
+    auto& S = b->gscratch;
+    S.host.resize(N); S.u.resize(N); S.v.resize(N); S.idepth.resize(N); S.color.resize(8 * (size_t)N); S.weights.resize(8 * (size_t)N); S.prior.resize(N);
+    S.res_point.resize(R); S.res_target.resize(R);
+    int pi = 0, ri = 0;
+    for (int f = 0; f < (int)g->frames.size(); f++)
+      for (const DmvGraphPoint& P : g->frames[f]) {
+        S.host[pi] = f; S.u[pi] = P.u; S.v[pi] = P.v; S.idepth[pi] = P.idepth; S.prior[pi] = P.prior;
+        memcpy(&S.color[8 * (size_t)pi], P.color, sizeof(P.color)); memcpy(&S.weights[8 * (size_t)pi], P.weights, sizeof(P.weights));
+        for (int k = 0; k < P.nres; k++, ri++) { S.res_point[ri] = pi; S.res_target[ri] = P.target[k]; }
+        pi++;
+      }
+  }
+  const auto& S = b->gscratch;
+  return dmvio_hip_ba_set_graph(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data());
 }
 
 #define BA_READY_LOCKED(b) do { if (!(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)

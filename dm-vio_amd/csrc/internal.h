@@ -101,6 +101,22 @@ struct dmvio_hip_ctx {
 extern "C" int dmv_ensure_row_major_locked(dmvio_hip_ctx* c, int slot);
 extern "C" int dmv_ensure_row_major(dmvio_hip_ctx* c, int slot);
 
+// Host-side mirror of the window's point / residual graph, mutated the way EnergyFunctional mutates its own (capi_graph.hip; include/dmvio_hip.h "window graph").
+#define DMV_GRAPH_MAX_FRAMES 16   // keyframes of a window, and residuals of a point (one per other keyframe)
+struct DmvGraphPoint {
+  float u, v, idepth;
+  float color[8], weights[8];
+  short target[DMV_GRAPH_MAX_FRAMES];   // EFPoint::residualsAll order: frame index of each residual's target; -1 = its frame was removed, the residual not yet dropped
+  int nres;
+  unsigned char prior;
+};
+struct dmvio_hip_graph {
+  std::mutex mu;
+  std::vector<std::vector<DmvGraphPoint>> frames;   // EnergyFunctional::frames -> EFFrame::points
+  int nPoints = 0, nRes = 0, nDangling = 0;
+  unsigned long long version = 0;                    // counts structural changes (not value updates)
+};
+
 // hypothesis-parallel trackNewCoarse: the element-wise fp64 sum over all ranks of a small HOST buffer, in place (set by dmvio_hip_tracker_set_comm /
 // _set_comm_callbacks in capi_ba.hip, which owns the RCCL calls; used by dmvio_hip_tracker_track_new_coarse in capi.hip)
 struct dmvio_hip_tracker;

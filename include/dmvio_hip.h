@@ -30,6 +30,7 @@ extern "C" {
 typedef struct dmvio_hip_ctx dmvio_hip_ctx;
 typedef struct dmvio_hip_tracker dmvio_hip_tracker;
 typedef struct dmvio_hip_ba dmvio_hip_ba;
+typedef struct dmvio_hip_graph dmvio_hip_graph;   /* host-side mirror of the window's point / residual graph ("window graph" below) */
 
 /* ------------------------------------------------------------------ context ------------------ */
 const char* dmvio_hip_last_error(void);
@@ -279,6 +280,39 @@ int dmvio_hip_ba_get_marg_prior(dmvio_hip_ba* ba, double* HM, double* bM);
  * res_point[r] in frame res_target[r].  Residuals must be sorted by point (points in allPoints order). */
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* ba, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target);
+/* ---- window graph: the point / residual graph kept RESIDENT across keyframes -----------------------------------------------------------------------------------------
+ * The reference never rebuilds its graph; EnergyFunctional mutates it in place (EnergyFunctional.cpp: insertResidual :435-446, insertFrame :447-484, insertPoint :485-499,
+ * dropResidual :500-518, removePoint :766-782, marginalizeFrame :641-646, makeIDX :997-1017).  A dmvio_hip_graph is a host-side mirror with exactly those mutators,
+ * addressed the way the reference addresses its own objects — a keyframe by EFFrame::idx, a point by (host keyframe, EFPoint::idxInPoints), a residual by (point,
+ * EFResidual::idxInAll) — and with the reference's order semantics (append; the LAST element takes a removed one's place; frames keep their order).  An adapter forwards
+ * each EnergyFunctional call with the indices it already holds (one line per member) and calls dmvio_hip_ba_set_graph_from once per keyframe
+ * instead of flattening its pointer graph for dmvio_hip_ba_set_graph: the library walks compact records in makeIDX order, which is the order every accumulator adds in.
+ * Host only: none of the dmvio_hip_graph_* calls needs a device.  One graph may be used from several threads (internally locked).
+ *   insert_* return the new element's index (>= 0); every call returns < 0 on error (dmvio_hip_last_error). */
+dmvio_hip_graph* dmvio_hip_graph_create(void);
+void dmvio_hip_graph_destroy(dmvio_hip_graph* g);
+int dmvio_hip_graph_clear(dmvio_hip_graph* g);
+int dmvio_hip_graph_insert_frame(dmvio_hip_graph* g);                                           /* EnergyFunctional::insertFrame: appended; returns EFFrame::idx */
+/* EnergyFunctional::marginalizeFrame's effect on the graph: keyframe idx leaves (it must host no point any more), later keyframes move down by one.  Residuals that still
+ * target it — FullSystem::marginalizeFrame drops them right AFTER ef->marginalizeFrame (FullSystemMarginalize.cpp:162-196) — stay as dangling until their
+ * dmvio_hip_graph_drop_residual arrives; dmvio_hip_ba_set_graph_from refuses a graph that still has one. */
+int dmvio_hip_graph_remove_frame(dmvio_hip_graph* g, int idx);
+/* EnergyFunctional::insertPoint (+ EFPoint::takeData): PointHessian::u, v, idepth, color[8], weights[8], hasDepthPrior; appended to its host's points; returns idxInPoints */
+int dmvio_hip_graph_insert_point(dmvio_hip_graph* g, int host, float u, float v, float idepth, const float* color8, const float* weights8, int hasDepthPrior);
+int dmvio_hip_graph_remove_point(dmvio_hip_graph* g, int host, int idxInPoints);                /* EnergyFunctional::removePoint: its residuals go with it, the host's last point takes its index */
+int dmvio_hip_graph_insert_residual(dmvio_hip_graph* g, int host, int idxInPoints, int target);  /* EnergyFunctional::insertResidual: appended; returns idxInAll */
+int dmvio_hip_graph_drop_residual(dmvio_hip_graph* g, int host, int idxInPoints, int idxInAll);  /* EnergyFunctional::dropResidual: the point's last residual takes its index */
+int dmvio_hip_graph_set_idepth(dmvio_hip_graph* g, int host, int idxInPoints, float idepth);     /* PointHessian::setIdepth of one point */
+int dmvio_hip_graph_set_idepths(dmvio_hip_graph* g, int N, const float* idepth);                /* ... of all points in makeIDX order: what dmvio_hip_ba_get_points returns after an optimisation */
+int dmvio_hip_graph_counts(dmvio_hip_graph* g, int* F, int* N, int* R);                         /* EnergyFunctional::nFrames, nPoints, nResiduals */
+int dmvio_hip_graph_frame_points(dmvio_hip_graph* g, int host);                                 /* EFFrame::points.size() */
+int dmvio_hip_graph_point_residuals(dmvio_hip_graph* g, int host, int idxInPoints);             /* EFPoint::residualsAll.size() */
+/* The graph as the flat arrays dmvio_hip_ba_set_graph takes, in makeIDX order (any output may be NULL; sizes from dmvio_hip_graph_counts; a dangling residual has target -1). */
+int dmvio_hip_graph_export(dmvio_hip_graph* g, int* host, float* u, float* v, float* idepth, float* color8, float* weights8, unsigned char* hasDepthPrior, int* res_point,
+                           int* res_target);
+/* dmvio_hip_ba_set_graph from the resident graph (the window set by dmvio_hip_ba_set_window must have the graph's number of keyframes).  After an optimisation the caller
+ * hands the new inverse depths back with dmvio_hip_graph_set_idepths(g, N, <idepth of dmvio_hip_ba_get_points>): same order. */
+int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* ba, dmvio_hip_graph* g);
 /* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  The library accumulates ACTIVE residuals only
  * (accumulateAF_MT / addPoint<0>) and, inside dmvio_hip_ba_marginalize_points, the residuals it fix-linearised itself (addPoint<2>); the reference's third accumulator —
  * accumulateLF_MT / addPoint<1> / calcLEnergyPt over residuals that are linearised but NOT being marginalised (EnergyFunctional.cpp:223-233, 349-431,

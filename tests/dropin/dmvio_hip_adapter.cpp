@@ -98,6 +98,16 @@ struct Backend
 	std::vector<ImmaturePoint*> imm_pts;
 	std::vector<int> imm_hostIDs;
 	double opt_split[3] = {0, 0, 0};   // FullSystem::optimize member: flatten + upload, dmvio_hip_ba_optimize, write-back (seconds)
+	// the window graph kept resident across keyframes (dmvio_hip_graph, include/dmvio_hip.h): the EnergyFunctional mutators below forward every change with the indices the
+	// reference holds itself, FullSystem::optimize hands the mirror over instead of flattening the pointer graph.  resident: 0 = flatten every keyframe (rounds 1-3),
+	// 1 = resident, 2 = resident AND flattened, the two compared element for element (tests)
+	dmvio_hip_graph* graph = nullptr;
+	const EnergyFunctional* graph_ef = nullptr;   // the EnergyFunctional the mirror follows
+	bool graph_valid = false;
+	int resident = 1;
+	long graph_ops = 0, graph_resyncs = 0, graph_verified = 0, graph_mismatch = 0;
+	double wb_split[5] = {0, 0, 0, 0, 0};   // write-back of optimize: calibration + keyframe states + adjoints / precalc, the downloads, the per-point pass, the removals, the tail
+	double up_split[6] = {0, 0, 0, 0, 0, 0};   // uploadWindow: frame tables, graph walk (index / flatten / verify), set_window, set_graph(_from), frame states + thresholds + calibration, marginalisation prior
 	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
 	std::unordered_map<const PointHessian*, float> deviceHessian;   // shadow mode: idepth_hessian the DEVICE's optimize of this keyframe left behind
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
@@ -255,7 +265,10 @@ int dropin_enable(int on, int device, int w, int h, int accumulators)
 		g.ba = nullptr; g.imm = nullptr; g.ini = nullptr; g.ctx = nullptr; g.init_mode = 0;
 	}
 	g.slotOf.clear(); g.fs = nullptr; g.on = false; g.stats = Stats(); g.failures = 0; g.error[0] = 0;
+	if (g.graph) { dmvio_hip_graph_destroy(g.graph); g.graph = nullptr; }
+	g.graph_ef = nullptr; g.graph_valid = false; g.graph_ops = g.graph_resyncs = g.graph_verified = g.graph_mismatch = 0;
 	if (!on) return 0;
+	g.graph = dmvio_hip_graph_create();
 	g.n_slots = 96;
 	g.ctx = dmvio_hip_create(device, w, h, g.n_slots);
 	if (!g.ctx) { fail("dmvio_hip_create"); return -1; }
@@ -313,6 +326,13 @@ void dropin_get_shadow_marginalization2(double* out3)
 // n_candidates, n_differing of the shadowed FullSystem::optimizeImmaturePoint calls (result class, idepth bits, the targets of the residuals created)
 void dropin_get_shadow_activation(long* out2) { out2[0] = g.sh.n_act_pts; out2[1] = g.sh.n_act_diff;
 }
+// how FullSystem::optimize hands the window over: 0 = the pointer graph flattened every keyframe, 1 (default) = the resident window graph, 2 = both, compared
+void dropin_set_resident(int mode) { g.resident = mode; }
+// forwarded EnergyFunctional mutations, keyframes at which the mirror had to be rebuilt from the pointer graph (0 in a run that went through the adapter from its first
+// frame), keyframes verified against the flattened pointer graph (mode 2), keyframes at which the two differed
+void dropin_get_writeback_split(double* out5) { for (int k = 0; k < 5; k++) out5[k] = g.wb_split[k]; }
+void dropin_get_upload_split(double* out6) { for (int k = 0; k < 6; k++) out6[k] = g.up_split[k]; }
+void dropin_get_resident(long* out4) { out4[0] = g.graph_ops; out4[1] = g.graph_resyncs; out4[2] = g.graph_verified; out4[3] = g.graph_mismatch; }
 int dropin_is_on() { return g.on ? 1 : 0; }
 // the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
 void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
@@ -679,7 +699,13 @@ void FullSystem::activatePointsMT_Reductor(std::vector<PointHessian*>* optimized
 	if (!g.on) { orig(this, optimized, toOptimize, min, max, stats, tid); return; }
 	std::vector<ImmaturePoint*> cand(toOptimize->begin() + min, toOptimize->begin() + max);
 	std::vector<Activated> act;
-	const bool ok = hipActivate(this, cand, act);
+	bool ok;
+	{
+		// multiThreading = true: the reference's worker pool enters this member from six threads at once, 50 candidates each (FullSystem.cpp:744); the immature handle is one
+		static std::mutex activateMu;
+		std::lock_guard<std::mutex> lk(activateMu);
+		ok = hipActivate(this, cand, act);
+	}
 	if (!ok || g.shadow)
 	{
 		orig(this, optimized, toOptimize, min, max, stats, tid);
@@ -733,6 +759,74 @@ void FullSystem::activatePointsMT_Reductor(std::vector<PointHessian*>* optimized
 	}
 }
 
+// ---- EnergyFunctional's mutators (EnergyFunctional.cpp:435-518, 641-646, 766-782), each forwarded to the resident window graph with the indices the reference keeps in
+// its own objects (EFFrame::idx, EFPoint::idxInPoints, EFResidual::idxInAll) — what a maintainer adds as ONE line at the end of each member.  The reference's definition
+// runs unchanged; the mirror answers with the index the reference just assigned, which is checked (a disagreement invalidates the mirror: the next optimize rebuilds it
+// from the pointer graph and counts a resync).
+namespace {
+bool graphFollows(const EnergyFunctional* ef) { return g.graph && g.graph_valid && g.graph_ef == ef; }
+void graphCheck(bool ok, const char* what)
+{
+	g.graph_ops++;
+	if (!ok) { g.graph_valid = false; fprintf(stderr, "[dropin] window graph out of step at %s: %s\n", what, dmvio_hip_last_error()); }
+}
+}  // namespace
+}  // namespace dso
+namespace dso
+{
+EFFrame* EnergyFunctional::insertFrame(FrameHessian* fh, CalibHessian* Hcalib)
+{
+	typedef EFFrame* (*Fn)(EnergyFunctional*, FrameHessian*, CalibHessian*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional11insertFrameEPNS_12FrameHessianEPNS_12CalibHessianE");
+	// a fresh EnergyFunctional (a new FullSystem): the mirror starts over with it
+	if (g.graph && frames.empty() && nPoints == 0) { dmvio_hip_graph_clear(g.graph); g.graph_ef = this; g.graph_valid = true; }
+	EFFrame* eff = orig(this, fh, Hcalib);
+	if (graphFollows(this)) graphCheck(dmvio_hip_graph_insert_frame(g.graph) == eff->idx, "insertFrame");
+	return eff;
+}
+EFPoint* EnergyFunctional::insertPoint(PointHessian* ph)
+{
+	typedef EFPoint* (*Fn)(EnergyFunctional*, PointHessian*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional11insertPointEPNS_12PointHessianE");
+	EFPoint* efp = orig(this, ph);
+	if (graphFollows(this))
+		graphCheck(dmvio_hip_graph_insert_point(g.graph, efp->host->idx, ph->u, ph->v, ph->idepth, ph->color, ph->weights, ph->hasDepthPrior ? 1 : 0) == efp->idxInPoints, "insertPoint");
+	return efp;
+}
+EFResidual* EnergyFunctional::insertResidual(PointFrameResidual* r)
+{
+	typedef EFResidual* (*Fn)(EnergyFunctional*, PointFrameResidual*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional14insertResidualEPNS_18PointFrameResidualE");
+	EFResidual* efr = orig(this, r);
+	if (graphFollows(this))
+		graphCheck(dmvio_hip_graph_insert_residual(g.graph, efr->point->host->idx, efr->point->idxInPoints, efr->target->idx) == efr->idxInAll, "insertResidual");
+	return efr;
+}
+void EnergyFunctional::dropResidual(EFResidual* r)
+{
+	typedef void (*Fn)(EnergyFunctional*, EFResidual*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional12dropResidualEPNS_10EFResidualE");
+	const int h = r->point->host->idx, i = r->point->idxInPoints, k = r->idxInAll;   // r is deleted by the call
+	orig(this, r);
+	if (graphFollows(this)) graphCheck(dmvio_hip_graph_drop_residual(g.graph, h, i, k) >= 0, "dropResidual");
+}
+void EnergyFunctional::removePoint(EFPoint* p)
+{
+	typedef void (*Fn)(EnergyFunctional*, EFPoint*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional11removePointEPNS_7EFPointE");
+	const int h = p->host->idx, i = p->idxInPoints;
+	orig(this, p);   // drops the point's residuals through dropResidual above, one by one, then moves the frame's last point into its place
+	if (graphFollows(this)) graphCheck(dmvio_hip_graph_remove_point(g.graph, h, i) >= 0, "removePoint");
+}
+void EnergyFunctional::marginalizeFrame(EFFrame* fh)
+{
+	typedef void (*Fn)(EnergyFunctional*, EFFrame*);
+	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional16marginalizeFrameEPNS_7EFFrameE");
+	const int idx = fh->idx;
+	orig(this, fh);
+	if (graphFollows(this)) graphCheck(dmvio_hip_graph_remove_frame(g.graph, idx) >= 0, "marginalizeFrame");   // the residuals that target it are dropped next (FullSystemMarginalize.cpp:169-196)
+}
+
 // ---- the window of the reference's FullSystem handed to the BA handle: keyframes in frameHessians order, points in EnergyFunctional::allPoints order (makeIDX,
 // EnergyFunctional.cpp:997-1017), residuals in EFPoint::residualsAll order — the orders the reference's accumulators add in — with the states, FEJ points, thresholds,
 // calibration and marginalisation prior the reference holds at this moment
@@ -750,9 +844,93 @@ struct FlatWindow
 		return pointFirstRes[frameFirstPoint[efp->host->idx] + efp->idxInPoints] + r->efResidual->idxInAll;
 	}
 };
-// checkLinearised: hand EFResidual::isLinearized to the library, which refuses a window with linearised residuals outside a marginalisation (dmvio_hip_ba_set_residual_flags)
-bool uploadWindow(FullSystem* fs, FlatWindow& W, bool checkLinearised = false)
+// the pointer graph flattened into the arrays of dmvio_hip_ba_set_graph (what every keyframe cost before the window graph was kept resident; still the path of shadow
+// mode, of resident mode 0, of the verification in mode 2 and of a resync)
+struct FlatArrays
 {
+	std::vector<int> host, resPoint, resTarget;
+	std::vector<float> pu, pv, pid, color, weights;
+	std::vector<unsigned char> prior, linearised;
+};
+void flattenGraph(FullSystem* fs, FlatWindow& W, FlatArrays& A)
+{
+	W.points.clear(); W.frameFirstPoint.assign(fs->ef->frames.size() + 1, 0); W.pointFirstRes.clear();
+	{
+		size_t np = 0, nr = 0;
+		for (EFFrame* eff : fs->ef->frames) { np += eff->points.size(); for (EFPoint* efp : eff->points) nr += efp->residualsAll.size(); }
+		W.points.reserve(np); W.pointFirstRes.reserve(np + 1); A.host.reserve(np); A.pu.reserve(np); A.pv.reserve(np); A.pid.reserve(np); A.prior.reserve(np); A.color.reserve(8 * np); A.weights.reserve(8 * np);
+		A.resPoint.reserve(nr); A.resTarget.reserve(nr); A.linearised.reserve(nr);
+	}
+	for (EFFrame* eff : fs->ef->frames)
+	{
+		assert(fs->ef->frames[eff->idx] == eff);
+		W.frameFirstPoint[eff->idx] = (int)W.points.size();
+		for (EFPoint* efp : eff->points)
+		{
+			PointHessian* ph = efp->data;
+			const int pi = (int)W.points.size();
+			assert(eff->points[efp->idxInPoints] == efp);
+			W.points.push_back(ph);
+			W.pointFirstRes.push_back((int)A.resPoint.size());
+			A.host.push_back(ph->host->idx); A.pu.push_back(ph->u); A.pv.push_back(ph->v); A.pid.push_back(ph->idepth); A.prior.push_back(ph->hasDepthPrior ? 1 : 0);
+			for (int k = 0; k < 8; k++) { A.color.push_back(ph->color[k]); A.weights.push_back(ph->weights[k]); }
+			for (EFResidual* er : efp->residualsAll)
+			{
+				assert((int)A.resPoint.size() - W.pointFirstRes.back() == er->idxInAll);
+				A.resPoint.push_back(pi); A.resTarget.push_back(er->data->target->idx); A.linearised.push_back(er->isLinearized ? 1 : 0);
+			}
+		}
+	}
+	W.pointFirstRes.push_back((int)A.resPoint.size());
+	W.N = (int)W.points.size(); W.R = (int)A.resPoint.size();
+}
+// resident mode: only the index tables of the write-back are formed here (one pass over the EFPoints: their PointHessian and the size of residualsAll) — no per-residual walk
+void indexGraph(FullSystem* fs, FlatWindow& W)
+{
+	W.points.clear(); W.frameFirstPoint.assign(fs->ef->frames.size() + 1, 0); W.pointFirstRes.clear();
+	W.points.reserve(fs->ef->nPoints); W.pointFirstRes.reserve(fs->ef->nPoints + 1);
+	int nr = 0;
+	for (EFFrame* eff : fs->ef->frames)
+	{
+		W.frameFirstPoint[eff->idx] = (int)W.points.size();
+		for (EFPoint* efp : eff->points) { W.points.push_back(efp->data); W.pointFirstRes.push_back(nr); nr += (int)efp->residualsAll.size(); }
+	}
+	W.pointFirstRes.push_back(nr);
+	W.N = (int)W.points.size(); W.R = nr;
+}
+// the mirror rebuilt from the pointer graph (the adapter was switched on in the middle of a run, or a forwarded call disagreed)
+bool resyncGraph(FullSystem* fs, const FlatWindow& W, const FlatArrays& A)
+{
+	bool ok = HIP_OK(dmvio_hip_graph_clear(g.graph));
+	for (size_t f = 0; ok && f < fs->ef->frames.size(); f++) ok = HIP_OK(dmvio_hip_graph_insert_frame(g.graph));
+	std::vector<int> idxIn(W.N);
+	for (int pi = 0; ok && pi < W.N; pi++)
+	{
+		idxIn[pi] = dmvio_hip_graph_insert_point(g.graph, A.host[pi], A.pu[pi], A.pv[pi], A.pid[pi], &A.color[8 * (size_t)pi], &A.weights[8 * (size_t)pi], A.prior[pi]);
+		ok = idxIn[pi] >= 0;
+	}
+	for (int ri = 0; ok && ri < W.R; ri++) ok = dmvio_hip_graph_insert_residual(g.graph, A.host[A.resPoint[ri]], idxIn[A.resPoint[ri]], A.resTarget[ri]) >= 0;
+	g.graph_ef = fs->ef; g.graph_valid = ok; g.graph_resyncs++;
+	return ok;
+}
+bool graphEqualsFlat(const FlatWindow& W, const FlatArrays& A)
+{
+	int F = 0, N = 0, R = 0;
+	dmvio_hip_graph_counts(g.graph, &F, &N, &R);
+	if (N != W.N || R != W.R) return false;
+	FlatArrays B;
+	B.host.resize(N); B.pu.resize(N); B.pv.resize(N); B.pid.resize(N); B.color.resize(8 * (size_t)N); B.weights.resize(8 * (size_t)N); B.prior.resize(N); B.resPoint.resize(R); B.resTarget.resize(R);
+	dmvio_hip_graph_export(g.graph, B.host.data(), B.pu.data(), B.pv.data(), B.pid.data(), B.color.data(), B.weights.data(), B.prior.data(), B.resPoint.data(), B.resTarget.data());
+	return B.host == A.host && B.resPoint == A.resPoint && B.resTarget == A.resTarget && B.prior == A.prior && !memcmp(B.pu.data(), A.pu.data(), 4 * (size_t)N) && !memcmp(B.pv.data(), A.pv.data(), 4 * (size_t)N) &&
+	       !memcmp(B.pid.data(), A.pid.data(), 4 * (size_t)N) && !memcmp(B.color.data(), A.color.data(), 32 * (size_t)N) && !memcmp(B.weights.data(), A.weights.data(), 32 * (size_t)N);
+}
+// checkLinearised: hand EFResidual::isLinearized to the library, which refuses a window with linearised residuals outside a marginalisation (dmvio_hip_ba_set_residual_flags).
+// resident: take the graph from the mirror (FullSystem::optimize outside shadow mode); the per-residual flags are then only checked when the pointer graph is walked anyway
+// (mode 2, resync) — the reference sets EFResidual::isLinearized in one place, right before it removes the point (FullSystem.cpp:836-849).
+bool uploadWindow(FullSystem* fs, FlatWindow& W, bool checkLinearised = false, bool resident = false)
+{
+	auto tprev = std::chrono::steady_clock::now();
+	auto lap = [&](int k) { const auto t = std::chrono::steady_clock::now(); g.up_split[k] += std::chrono::duration<double>(t - tprev).count(); tprev = t; };
 	const int F = (int)fs->frameHessians.size();
 	std::vector<int> slots(F), frameIDs(F);
 	std::vector<double> evalPT7(7 * F), affZero(2 * F);
@@ -765,45 +943,39 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W, bool checkLinearised = false)
 		toPose7(fh->get_worldToCam_evalPT(), &evalPT7[7 * f]);
 		affZero[2 * f] = fh->get_state_zero()[6] * SCALE_A; affZero[2 * f + 1] = fh->get_state_zero()[7] * SCALE_B;
 	}
-	std::vector<int> host, resPoint, resTarget;
-	std::vector<float> pu, pv, pid, color, weights;
-	std::vector<unsigned char> prior, linearised;
-	W.points.clear(); W.frameFirstPoint.assign(fs->ef->frames.size() + 1, 0); W.pointFirstRes.clear();
+	lap(0);
+	resident = resident && g.graph && g.resident != 0;
+	FlatArrays A;
+	bool walked = false;
+	if (resident)
 	{
-		size_t np = 0, nr = 0;
-		for (EFFrame* eff : fs->ef->frames) { np += eff->points.size(); for (EFPoint* efp : eff->points) nr += efp->residualsAll.size(); }
-		W.points.reserve(np); W.pointFirstRes.reserve(np + 1); host.reserve(np); pu.reserve(np); pv.reserve(np); pid.reserve(np); prior.reserve(np); color.reserve(8 * np); weights.reserve(8 * np);
-		resPoint.reserve(nr); resTarget.reserve(nr);
-	}
-	for (EFFrame* eff : fs->ef->frames)
-	{
-		assert(fs->ef->frames[eff->idx] == eff);
-		W.frameFirstPoint[eff->idx] = (int)W.points.size();
-		for (EFPoint* efp : eff->points)
+		indexGraph(fs, W);
+		int gF = 0, gN = 0, gR = 0;
+		dmvio_hip_graph_counts(g.graph, &gF, &gN, &gR);
+		const bool inStep = g.graph_valid && g.graph_ef == fs->ef && gF == F && gN == W.N && gR == W.R;
+		if (!inStep || g.resident == 2)
 		{
-			PointHessian* ph = efp->data;
-			const int pi = (int)W.points.size();
-			assert(eff->points[efp->idxInPoints] == efp);
-			W.points.push_back(ph);
-			W.pointFirstRes.push_back((int)resPoint.size());
-			host.push_back(ph->host->idx); pu.push_back(ph->u); pv.push_back(ph->v); pid.push_back(ph->idepth); prior.push_back(ph->hasDepthPrior ? 1 : 0);
-			for (int k = 0; k < 8; k++) { color.push_back(ph->color[k]); weights.push_back(ph->weights[k]); }
-			for (EFResidual* er : efp->residualsAll)
-			{
-				assert((int)resPoint.size() - W.pointFirstRes.back() == er->idxInAll);
-				resPoint.push_back(pi); resTarget.push_back(er->data->target->idx); linearised.push_back(er->isLinearized ? 1 : 0);
-			}
+			flattenGraph(fs, W, A); walked = true;
+			if (!inStep) { if (!resyncGraph(fs, W, A)) return false; }
+			else { g.graph_verified++; if (!graphEqualsFlat(W, A)) { g.graph_mismatch++; fprintf(stderr, "[dropin] the resident window graph differs from the flattened pointer graph\n"); if (!resyncGraph(fs, W, A)) return false; } }
 		}
 	}
-	W.pointFirstRes.push_back((int)resPoint.size());
-	W.F = F; W.N = (int)W.points.size(); W.R = (int)resPoint.size(); W.n = CPARS + 8 * F;
+	else { flattenGraph(fs, W, A); walked = true; }
+	W.F = F; W.n = CPARS + 8 * F;
 	if (W.N < 1 || W.R < 1) return false;
-	g.windowPoint.clear(); g.windowPoint.reserve(2 * W.points.size());
-	for (size_t pi = 0; pi < W.points.size(); pi++) g.windowPoint[W.points[pi]] = (int)pi;
+	if (!resident)
+	{
+		g.windowPoint.clear(); g.windowPoint.reserve(2 * W.points.size());
+		for (size_t pi = 0; pi < W.points.size(); pi++) g.windowPoint[W.points[pi]] = (int)pi;
+	}
 	dmvio_hip_ba* ba = g.ba;
+	lap(1);
 	bool ok = HIP_OK(dmvio_hip_ba_set_window(ba, F, slots.data(), evalPT7.data(), affZero.data(), expo.data(), frameIDs.data(), fs->Hcalib.value_scaled.data()));
-	ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, W.N, host.data(), pu.data(), pv.data(), pid.data(), color.data(), weights.data(), prior.data(), W.R, resPoint.data(), resTarget.data()));
-	if (checkLinearised) ok = ok && HIP_OK(dmvio_hip_ba_set_residual_flags(ba, W.R, linearised.data()));
+	lap(2);
+	if (resident) ok = ok && HIP_OK(dmvio_hip_ba_set_graph_from(ba, g.graph));
+	else ok = ok && HIP_OK(dmvio_hip_ba_set_graph(ba, W.N, A.host.data(), A.pu.data(), A.pv.data(), A.pid.data(), A.color.data(), A.weights.data(), A.prior.data(), W.R, A.resPoint.data(), A.resTarget.data()));
+	if (checkLinearised && walked) ok = ok && HIP_OK(dmvio_hip_ba_set_residual_flags(ba, W.R, A.linearised.data()));
+	lap(3);
 	{
 		std::vector<double> sz(10 * (size_t)F), st(10 * (size_t)F);
 		for (int f = 0; f < F; f++)
@@ -814,12 +986,14 @@ bool uploadWindow(FullSystem* fs, FlatWindow& W, bool checkLinearised = false)
 		ok = ok && HIP_OK(dmvio_hip_ba_set_frame_states(ba, sz.data(), st.data()));
 	}
 	ok = ok && HIP_OK(dmvio_hip_ba_set_frame_energy_th(ba, th.data())) && HIP_OK(dmvio_hip_ba_set_calib_values(ba, fs->Hcalib.value.data(), fs->Hcalib.value_zero.data()));
+	lap(4);
 	{
 		const int n = W.n;
 		std::vector<double> HM((size_t)n * n), bM(n);
 		for (int r = 0; r < n; r++) { bM[r] = fs->ef->bM[r]; for (int c = 0; c < n; c++) HM[(size_t)r * n + c] = fs->ef->HM(r, c); }
 		ok = ok && HIP_OK(dmvio_hip_ba_set_marg_prior(ba, HM.data(), bM.data()));
 	}
+	lap(5);
 	return ok;
 }
 }  // namespace
@@ -907,22 +1081,26 @@ float FullSystem::optimize(int mnumOptIts)
 	if (setting_useGTSAMIntegration) { fprintf(stderr, "[dropin] GTSAM runs: use dmvio_hip_ba_optimize_vio with the BAGTSAMIntegration members as hooks\n"); abort(); }
 	const int F = (int)frameHessians.size();
 	if (F < 2) return 0;
-	// ---- statistics and active residuals (:429-448)
+	// ---- statistics and active residuals (:429-448).  With the window graph resident nothing below needs the list (the write-back goes point by point), and resetOOB's
+	// effects are all overwritten by it: the 12.8k-object walk is left out
+	const bool resident = !g.shadow && g.graph && g.resident != 0;
 	activeResiduals.clear();
-	for (FrameHessian* fh : frameHessians)
-		for (PointHessian* ph : fh->pointHessians)
-			for (PointFrameResidual* r : ph->residuals)
-			{
-				activeResiduals.push_back(r);
-				r->resetOOB();
-			}
+	if (!resident)
+		for (FrameHessian* fh : frameHessians)
+			for (PointHessian* ph : fh->pointHessians)
+				for (PointFrameResidual* r : ph->residuals)
+				{
+					activeResiduals.push_back(r);
+					r->resetOOB();
+				}
 	FlatWindow FW;
 	const auto tq0 = std::chrono::steady_clock::now();
-	bool ok = uploadWindow(this, FW, true);   // linearised residuals only exist between flagPointsForRemoval and marginalizePointsF: the library refuses a window that holds one
+	bool ok = uploadWindow(this, FW, true, resident);   // linearised residuals only exist between flagPointsForRemoval and marginalizePointsF: the library refuses a window that holds one
 	const auto tq1 = std::chrono::steady_clock::now();
 	const int N = FW.N, R = FW.R;
 	std::vector<PointHessian*>& points = FW.points;
-	if (ok && (size_t)R != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
+	if (ok && !resident && (size_t)R != activeResiduals.size()) { fprintf(stderr, "[dropin] residual lists disagree\n"); abort(); }
+	if (ok && resident && R != ef->nResiduals) { fprintf(stderr, "[dropin] residual counts disagree\n"); abort(); }
 	dmvio_hip_ba* ba = g.ba;
 	std::vector<float> th(F);
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
@@ -967,6 +1145,8 @@ float FullSystem::optimize(int mnumOptIts)
 		g.sh.opt_idepth_med = std::max(g.sh.opt_idepth_med, rel[N / 2]);
 		return r0;
 	}
+	auto wprev = std::chrono::steady_clock::now();
+	auto wlap = [&](int k) { const auto t = std::chrono::steady_clock::now(); g.wb_split[k] += std::chrono::duration<double>(t - wprev).count(); wprev = t; };
 	// ---- write-back: calibration, keyframe states (the newest one re-anchored like :596-603), thresholds
 	{
 		double value[4], value_zero[4];
@@ -988,70 +1168,88 @@ float FullSystem::optimize(int mnumOptIts)
 	ef->setAdjointsF(&Hcalib);
 	setPrecalcValues();
 	// ---- points: idepth (= idepth_zero, doStepFromBackup :283-291), and what the LAST solveSystemF's accumulation left in PointHessian / EFPoint
-	// (idepth_hessian, HdiF: AccumulatedSCHessian.cpp:42-54; read by flagPointsForRemoval and makeCoarseDepthL0)
+	// (idepth_hessian, HdiF: AccumulatedSCHessian.cpp:42-54; read by flagPointsForRemoval and makeCoarseDepthL0);
+	// ---- residuals: what linearize + applyRes(true) of the final linearizeAll(true) leave behind (Residuals.cpp:78-328), then linearizeAll's own tail (:176-212).
+	// One pass, point by point: a point's residuals are visited in PointHessian::residuals order (the order activeResiduals lists them in), so the removals leave
+	// EFPoint::residualsAll in the order the reference's loop leaves it; across points the order is immaterial (dropResidual touches the point's own list and counters).
 	{
 		std::vector<float> idepth(N), step(N), hess(N), Hdd(N), bd(N), Hcd(4 * (size_t)N), HdiF(N), bdSumF(N);
 		HIP_OK(dmvio_hip_ba_get_points(ba, idepth.data(), step.data()));
 		HIP_OK(dmvio_hip_ba_get_point_hessian(ba, hess.data()));
 		HIP_OK(dmvio_hip_ba_get_point_acc(ba, Hdd.data(), bd.data(), Hcd.data(), HdiF.data(), bdSumF.data()));
-		for (int pi = 0; pi < N; pi++)
-		{
-			PointHessian* ph = points[pi];
-			ph->setIdepth(idepth[pi]); ph->setIdepthZero(idepth[pi]); ph->step = step[pi];
-			ph->idepth_hessian = hess[pi];
-			ph->efPoint->HdiF = HdiF[pi]; ph->efPoint->bdSumF = bdSumF[pi]; ph->efPoint->Hdd_accAF = Hdd[pi]; ph->efPoint->bd_accAF = bd[pi];
-			for (int k = 0; k < 4; k++) ph->efPoint->Hcd_accAF[k] = Hcd[4 * pi + k];
-		}
-	}
-	// ---- residuals: what linearize + applyRes(true) of the final linearizeAll(true) leave behind (Residuals.cpp:78-328), then linearizeAll's own tail
-	{
+		wlap(0);
+		if (resident) HIP_OK(dmvio_hip_graph_set_idepths(g.graph, N, idepth.data()));   // the mirror's values follow the optimisation; its structure follows the dropResidual calls below
 		std::vector<unsigned char> newState(R), active(R);
 		std::vector<float> newEnergy(R), newEnergyWO(R), center(3 * (size_t)R);
 		HIP_OK(dmvio_hip_ba_get_res_state(ba, newState.data(), newEnergy.data(), newEnergyWO.data(), active.data(), center.data()));
-		std::vector<PointFrameResidual*> toRemove;
-		for (PointFrameResidual* r : activeResiduals)
+		wlap(1);
+		// the per-point part (21 ns per residual on one thread; dealt out over the reference's worker pool, FullSystem::treadReduce, it took LONGER — 0.32 vs 0.27 ms for 2000
+		// points: waking six workers costs more than the loop); the removals (they go through EnergyFunctional::dropResidual) follow, points ascending
+		std::vector<int> pending[1];
+		auto perPoint = [&](int first, int end, Vec10* /*stats*/, int tid)
 		{
-			const int ri = FW.resIndex(r);
-			const ResState ns = newState[ri] == 0 ? ResState::IN : (newState[ri] == 1 ? ResState::OOB : ResState::OUTLIER);
-			r->state_NewState = ns; r->state_NewEnergy = newEnergy[ri]; r->state_NewEnergyWithOutlier = newEnergyWO[ri];
-			if (ns != ResState::OOB) r->centerProjectedTo = Vec3f(center[3 * ri], center[3 * ri + 1], center[3 * ri + 2]);
-			r->efResidual->isActiveAndIsGoodNEW = active[ri] != 0;   // applyRes(true); the Jacobians stay on the device (marginalisation relinearises its points itself, FullSystem.cpp:836-849)
-			r->setState(ns);
-			r->state_energy = newEnergy[ri];
-			if (r->efResidual->isActive())
+			for (int pi = first; pi < end; pi++)
 			{
-				if (r->isNew)
+				PointHessian* ph = points[pi];
+				ph->setIdepth(idepth[pi]); ph->setIdepthZero(idepth[pi]); ph->step = step[pi];
+				ph->idepth_hessian = hess[pi];
+				EFPoint* efp = ph->efPoint;
+				efp->HdiF = HdiF[pi]; efp->bdSumF = bdSumF[pi]; efp->Hdd_accAF = Hdd[pi]; efp->bd_accAF = bd[pi];
+				for (int k = 0; k < 4; k++) efp->Hcd_accAF[k] = Hcd[4 * pi + k];
+				const int base = FW.pointFirstRes[pi];
+				bool removes = false;
+				for (PointFrameResidual* r : ph->residuals)
 				{
-					PointHessian* p = r->point;
-					Vec3f ptp_inf = r->host->targetPrecalc[r->target->idx].PRE_KRKiTll * Vec3f(p->u, p->v, 1);
-					Vec3f ptp = ptp_inf + r->host->targetPrecalc[r->target->idx].PRE_KtTll * p->idepth_scaled;
-					float relBS = 0.01 * ((ptp_inf.head<2>() / ptp_inf[2]) - (ptp.head<2>() / ptp[2])).norm();
-					if (relBS > p->maxRelBaseline) p->maxRelBaseline = relBS;
-					p->numGoodResiduals++;
+					const int ri = base + r->efResidual->idxInAll;
+					const ResState ns = newState[ri] == 0 ? ResState::IN : (newState[ri] == 1 ? ResState::OOB : ResState::OUTLIER);
+					r->state_NewState = ns; r->state_NewEnergy = newEnergy[ri]; r->state_NewEnergyWithOutlier = newEnergyWO[ri];
+					if (ns != ResState::OOB) r->centerProjectedTo = Vec3f(center[3 * ri], center[3 * ri + 1], center[3 * ri + 2]);
+					r->efResidual->isActiveAndIsGoodNEW = active[ri] != 0;   // applyRes(true); the Jacobians stay on the device (marginalisation relinearises its points itself, FullSystem.cpp:836-849)
+					r->setState(ns);
+					r->state_energy = newEnergy[ri];
+					if (r->efResidual->isActive())
+					{
+						if (r->isNew)
+						{
+							Vec3f ptp_inf = r->host->targetPrecalc[r->target->idx].PRE_KRKiTll * Vec3f(ph->u, ph->v, 1);
+							Vec3f ptp = ptp_inf + r->host->targetPrecalc[r->target->idx].PRE_KtTll * ph->idepth_scaled;
+							float relBS = 0.01 * ((ptp_inf.head<2>() / ptp_inf[2]) - (ptp.head<2>() / ptp[2])).norm();
+							if (relBS > ph->maxRelBaseline) ph->maxRelBaseline = relBS;
+							ph->numGoodResiduals++;
+						}
+					}
+					else removes = true;
+					if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
+					else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
 				}
+				if (removes) pending[tid].push_back(pi);
 			}
-			else toRemove.push_back(r);
-		}
-		for (PointFrameResidual* r : activeResiduals)
+		};
+		perPoint(0, N, nullptr, 0);
+		wlap(2);
+		std::vector<int> withRemovals;
+		withRemovals = pending[0];
+		std::vector<PointFrameResidual*> toRemove;
+		for (int pi : withRemovals)
 		{
-			PointHessian* ph = r->point;
-			if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
-			else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
-		}
-		for (PointFrameResidual* r : toRemove)
-		{
-			PointHessian* ph = r->point;
-			if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
-			else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
-			for (unsigned int k = 0; k < ph->residuals.size(); k++)
-				if (ph->residuals[k] == r)
-				{
-					ef->dropResidual(r->efResidual);
-					deleteOut<PointFrameResidual>(ph->residuals, k);
-					break;
-				}
+			PointHessian* ph = points[pi];
+			toRemove.clear();
+			for (PointFrameResidual* r : ph->residuals) if (!r->efResidual->isActive()) toRemove.push_back(r);
+			for (PointFrameResidual* r : toRemove)
+			{
+				if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
+				else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
+				for (unsigned int k = 0; k < ph->residuals.size(); k++)
+					if (ph->residuals[k] == r)
+					{
+						ef->dropResidual(r->efResidual);
+						deleteOut<PointFrameResidual>(ph->residuals, k);
+						break;
+					}
+			}
 		}
 	}
+	wlap(3);
 	// ---- tail of optimize (:611-645)
 	HIP_OK(dmvio_hip_ba_get_res_in_a(ba, &ef->resInA));   // the count the last solveSystemF's accumulation left behind (EnergyFunctional.cpp:209)
 	if (!std::isfinite(finalEnergy)) { std::cout << "Tracking lost after bundle adjustment!" << std::endl; isLost = true; }
@@ -1064,6 +1262,7 @@ float FullSystem::optimize(int mnumOptIts)
 			fh->shell->aff_g2l = fh->aff_g2l();
 		}
 	}
+	wlap(4);
 	const auto tq3 = std::chrono::steady_clock::now();
 	g.opt_split[0] += std::chrono::duration<double>(tq1 - tq0).count(); g.opt_split[1] += std::chrono::duration<double>(tq2 - tq1).count();
 	g.opt_split[2] += std::chrono::duration<double>(tq3 - tq2).count();

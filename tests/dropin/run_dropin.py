@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--realtime", type=float, default=0.0, metavar="FPS",
                     help="FullSystem(linearizeOperation = false): frames arrive at FPS on this thread (tracking), the reference's own mapping thread makes the keyframes — "
                          "tracking and mapping overlap like in a live system; nothing is recorded, the run is not reproducible bit for bit")
+    ap.add_argument("--resident", type=int, default=1, choices=[0, 1, 2],
+                    help="mode hip: how FullSystem::optimize hands the window over — 0 the pointer graph flattened every keyframe, 1 the resident window graph (the forwarded "
+                         "EnergyFunctional mutators keep it in step), 2 both, compared element for element")
     ap.add_argument("--mt", action="store_true", help="settings.cpp multiThreading = true (the reference's default: linearizeAll, applyRes, the accumulators on 6 workers)")
     ap.add_argument("--scopes", action="store_true", help="inclusive wall time per profiler label of the reference (util/TimeMeasurement scopes) for this run; switches the "
                                                            "event recording of the run off, so wall_s is the pipeline alone")
@@ -80,6 +83,8 @@ def main():
             np.savez(cache + ".tmp.npz", K4=np.asarray(K4), imgs=np.asarray(imgs, np.float32), poses=np.asarray(poses_true)); os.replace(cache + ".tmp.npz", cache)
     if D is not None and D.dropin_enable(1 if a.mode == "hip" else 0, 0, a.w, a.h, a.accumulators) != 0:
         raise SystemExit("dropin_enable failed")
+    if D is not None:
+        D.dropin_set_resident.argtypes = [C.c_int]; D.dropin_set_resident(a.resident)
     # the reference draws from the C library's rand() (PixelSelector's random pattern, CoarseInitializer's point selection): the same sequence in every mode, whatever the
     # static initialisers of the libraries loaded so far have consumed
     C.CDLL(None).srand(1)
@@ -157,6 +162,12 @@ def main():
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
         sp = (C.c_double * 3)(); D.dropin_get_optimize_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_optimize_split(sp)
         out["optimize_split_seconds"] = np.array(list(sp))      # flatten + upload, dmvio_hip_ba_optimize, write-back
+        us = (C.c_double * 6)(); D.dropin_get_upload_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_upload_split(us)
+        out["upload_split_seconds"] = np.array(list(us))        # frame tables, graph walk, set_window, set_graph(_from), frame states / thresholds / calibration, marginalisation prior
+        ws = (C.c_double * 5)(); D.dropin_get_writeback_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_writeback_split(ws)
+        out["writeback_split_seconds"] = np.array(list(ws))     # calibration + keyframe states + adjoints / precalc, downloads, per-point pass, removals, tail
+        rs = (C.c_long * 4)(); D.dropin_get_resident.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_resident(rs)
+        out["resident"] = np.array(list(rs))                    # forwarded EnergyFunctional mutations, resyncs, keyframes verified against the flattened graph, mismatches
         msg = C.create_string_buffer(512)
         out["failures"] = np.array([D.dropin_failures(msg, 512)])
         if out["failures"][0]:
@@ -181,6 +192,8 @@ def window_run(a, D, R, synth):
     """The members the adapter replaces, called one by one on a synthetic window through oracle/ref_py.py (no initialiser: nothing multi-threaded)."""
     if D is not None and D.dropin_enable(1 if a.mode == "hip" else 0, 0, 256, 192, a.accumulators) != 0:
         raise SystemExit("dropin_enable failed")
+    if D is not None:
+        D.dropin_set_resident.argtypes = [C.c_int]; D.dropin_set_resident(a.resident)
     case = synth.ba_case(256, 192, n_frames=4, n_points=150, hosts_share=(60, 50, 40, 0), seed=7)
     W = R.BAWindow(case)                                          # FrameHessian::makeImages per keyframe
     rng = np.random.RandomState(3)

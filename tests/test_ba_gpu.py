@@ -145,6 +145,89 @@ def test_optimize_parity(pkg, oracle, synth, gpu_required):
     assert e1 < e0
 
 
+def test_resident_graph_through_a_keyframe_cycle(pkg, synth, gpu_required):
+    """dmvio_hip_ba_set_graph_from: a window built from the resident graph (dmvio_hip_graph_*: the mutators of EnergyFunctional.cpp:435-518, 641-646, 766-782) optimises to
+    the same bits as the same window handed over as flat arrays — at first, and again after the graph went through what a keyframe does to it: residuals dropped, points
+    removed (their host's last point takes their index), the oldest keyframe marginalised (indices move down, its observations dropped), a new keyframe with residuals from
+    the old points, new points with new residuals; the inverse depths of the optimisation carried over with dmvio_hip_graph_set_idepths."""
+    F = 6
+    case = synth.ba_case(320, 256, n_frames=F, n_points=600, hosts_share=(150, 130, 120, 110, 90, 0), seed=31)
+    ctx = pkg.Context(320, 256, n_slots=F)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+    g = pkg.WindowGraph.from_case(case)
+
+    def both(cs, slots, frames):
+        """optimize(4) of window `cs` through flat arrays and through the graph: traces, poses and points must be identical bit for bit"""
+        out = []
+        for how in ("flat", "graph"):
+            ba = pkg.BundleAdjusterHip(ctx, accumulators=1)
+            if how == "flat":
+                ba.set_case(cs, slots)
+            else:
+                ba.set_window(slots, cs["poses0"], np.zeros((frames, 2)), np.ones(frames, np.float32), np.arange(frames, dtype=np.int32), cs["K4"])
+                ba.set_graph_from(g)
+            r = ba.optimize(4)
+            out.append((r["trace"].copy(), np.stack([ba.frame_pose(k)[0] for k in range(frames)]), ba.point_state()[0].copy()))
+            ba.close()
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+        return out[1]
+
+    _, _, idepth = both(case, list(range(F)), F)
+    g.set_idepths(idepth)
+    # ---- a keyframe: the mirror mutated call by call, a Python list model of the same statements beside it
+    rng = np.random.RandomState(5)
+    o = g.export()
+    pts = [[dict(u=o["u"][p], v=o["v"][p], idepth=o["idepth"][p], color=o["color"][p], weights=o["weights"][p], prior=bool(o["hasDepthPrior"][p]),
+                 res=list(o["res_target"][o["res_point"] == p])) for p in range(len(o["u"])) if o["host"][p] == f] for f in range(F)]
+    for f in range(F):                                          # FullSystem::optimize's tail: inactive residuals dropped
+        for i, p in enumerate(pts[f]):
+            if p["res"] and rng.rand() < 0.1:
+                k = rng.randint(len(p["res"])); g.drop_residual(f, i, k); p["res"][k] = p["res"][-1]; p["res"].pop()
+    for f in range(F):                                          # removeOutliers / flagPointsForRemoval: points without residuals, all points of the frame to be marginalised
+        i = 0
+        while i < len(pts[f]):
+            if f == 0 or not pts[f][i]["res"] or rng.rand() < 0.05:
+                g.remove_point(f, i); pts[f][i] = pts[f][-1]; pts[f].pop()
+            else:
+                i += 1
+    g.remove_frame(0); del pts[0]                               # ef->marginalizeFrame, then FullSystem::marginalizeFrame drops what still targets the frame
+    for f in range(F - 1):
+        for i, p in enumerate(pts[f]):
+            p["res"] = [t - 1 for t in p["res"]]               # target 0 -> -1 (dangling), the others move down
+            while -1 in p["res"]:
+                k = p["res"].index(-1); g.drop_residual(f, i, k); p["res"][k] = p["res"][-1]; p["res"].pop()
+    new = g.insert_frame(); pts.append([]); assert new == F - 1  # the new keyframe: a residual from every old point, then freshly activated points
+    for f in range(F - 1):
+        for i, p in enumerate(pts[f]):
+            assert g.insert_residual(f, i, new) == len(p["res"]); p["res"].append(new)
+    for _ in range(80):
+        h = rng.randint(0, F - 1)
+        rec = dict(u=np.float32(rng.uniform(20, 300)), v=np.float32(rng.uniform(20, 236)), idepth=np.float32(rng.uniform(0.15, 0.5)), color=(rng.rand(8) * 200 + 20).astype(np.float32),
+                   weights=(rng.rand(8) * 0.5 + 0.5).astype(np.float32), prior=False, res=[])
+        i = g.insert_point(h, rec["u"], rec["v"], rec["idepth"], rec["color"], rec["weights"]); pts[h].append(rec); assert i == len(pts[h]) - 1
+        for t in range(F):
+            if t != h and rng.rand() < 0.7:
+                g.insert_residual(h, i, t); rec["res"].append(t)
+    # the same window as flat arrays, from the list model
+    host, rp, rt = [], [], []
+    flat = dict(u=[], v=[], idepth=[], color=[], weights=[], prior=[])
+    for f in range(F):
+        for p in pts[f]:
+            for t in p["res"]:
+                rp.append(len(host)); rt.append(t)
+            host.append(f)
+            for key in flat:
+                flat[key].append(p[key])
+    cs = dict(case)
+    cs.update(host=np.array(host, np.int32), u=np.array(flat["u"], np.float32), v=np.array(flat["v"], np.float32), idepth0=np.array(flat["idepth"], np.float32),
+              color=np.stack(flat["color"]), weights=np.stack(flat["weights"]), hasDepthPrior=np.array(flat["prior"], np.uint8), res_point=np.array(rp, np.int32),
+              res_target=np.array(rt, np.int32), poses0=np.asarray(case["poses0"])[[1, 2, 3, 4, 5, 0]], aff=None, exposure=None, frameIDs=None)
+    assert g.counts() == (F, len(host), len(rp))
+    both(cs, [1, 2, 3, 4, 5, 0], F)                             # keyframe 0's slot serves as the "new" image: any image will do for bit equality of the two paths
+
+
 def test_small_window_and_ragged_graph(pkg, oracle, synth, gpu_required):
     """3-keyframe window (forces 15 iterations), hosts without points, points with a single residual."""
     case = synth.ba_case(320, 256, n_frames=3, n_points=150, hosts_share=(90, 60, 0), seed=99)

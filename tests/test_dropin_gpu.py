@@ -176,3 +176,37 @@ def test_every_call_of_a_live_reference_run_side_by_side(gpu_required, tmp_path,
     # (the shadow's own marginalize_points call sees a Hessian accumulated at ANOTHER linearisation point — the state after the last accepted step —: decisions near the threshold may differ there)
     assert reacc <= 0.01 * mg[1]
     assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+def test_resident_window_graph_follows_the_references_own(gpu_required, tmp_path):
+    """The window graph kept resident across keyframes (dmvio_hip_graph_*, forwarded from EnergyFunctional::insertFrame / insertPoint / insertResidual / dropResidual /
+    removePoint / marginalizeFrame by the adapter) against the pointer graph flattened at every keyframe, inside a live run of the reference's FullSystem (512x512, ~2000
+    points, keyframes created and marginalised): in mode 2 every keyframe's mirror is compared element for element with the flattened graph — never a mismatch, never a
+    resync — and the run is the SAME run, bit for bit, as with the graph flattened every time (mode 0) and as in plain resident mode (1): same arrays in, same kernels."""
+    seq = ["--w", "512", "--h", "512", "--frames", "100", "--step", "1.6", "--density", "2000", "--mode", "hip", "--init", "seq", "--accumulators", "1"]
+    flat = _run(tmp_path, "flat", "--resident", "0", *seq)
+    both = _run(tmp_path, "both", "--resident", "2", *seq)
+    res = _run(tmp_path, "res", "--resident", "1", *seq)
+    n_opt = len(flat["opt_rmse"])
+    assert n_opt >= 8 and flat["failures"][0] == 0 and both["failures"][0] == 0 and res["failures"][0] == 0
+    ops, resyncs, verified, mismatch = both["resident"]
+    assert resyncs == 0 and mismatch == 0 and verified == n_opt and ops > 20 * n_opt, both["resident"]
+    assert res["resident"][1] == 0 and res["resident"][0] == ops
+    for k in ("camToWorld", "opt_rmse", "opt_resInA", "opt_N", "opt_R", "aff"):
+        assert np.array_equal(flat[k], both[k]) and np.array_equal(flat[k], res[k]), k
+    sp0, sp1 = flat["optimize_split_seconds"] / n_opt * 1e3, res["optimize_split_seconds"] / n_opt * 1e3
+    print("adapter per keyframe (ms): hand-over %.3f -> %.3f, dmvio_hip_ba_optimize %.3f -> %.3f, write-back %.3f -> %.3f; %d forwarded mutations over %d keyframes"
+          % (sp0[0], sp1[0], sp0[1], sp1[1], sp0[2], sp1[2], ops, n_opt))
+    # the reference's default threading (multiThreading = true): the write-back runs on its worker pool; the rest of the reference then sums in thread order, so this run is
+    # compared loosely
+    mt = _run(tmp_path, "mt", "--resident", "1", "--mt", *seq)
+    assert mt["failures"][0] == 0 and mt["resident"][1] == 0 and not mt["lost"][-1]
+    rm, _ = _traj_diff(flat, mt)
+    assert rm < 1e-3, rm
+    spm = mt["optimize_split_seconds"] / len(mt["opt_rmse"]) * 1e3
+    print("with multiThreading = true: hand-over %.3f, dmvio_hip_ba_optimize %.3f, write-back %.3f ms per keyframe; trajectory rmse vs the single-threaded run %.2e m" % (spm[0], spm[1], spm[2], rm))
+    print("write-back split per keyframe (ms: states + adjoints + precalc, downloads, per-point pass, removals, tail): %s; multiThreading = true: %s"
+          % (np.round(res["writeback_split_seconds"] / n_opt * 1e3, 3), np.round(mt["writeback_split_seconds"] / len(mt["opt_rmse"]) * 1e3, 3)))
+    print("hand-over split per keyframe (ms: frame tables, graph walk, set_window, set_graph, frame states, prior): flattened %s, resident %s"
+          % (np.round(flat["upload_split_seconds"] / n_opt * 1e3, 3), np.round(res["upload_split_seconds"] / n_opt * 1e3, 3)))
