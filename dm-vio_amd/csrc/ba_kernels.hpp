@@ -1102,6 +1102,59 @@ __global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const 
   if (A.ticks) { __syncthreads(); if (threadIdx.x == 0) A.ticks[2 * blockIdx.x + 1] = wall_clock64(); }
 }
 
+// ------------------------------------------------------------------------------------------------ member lists of the Schur buckets, built on the device
+// AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:56-100) adds, for every point, one term per PAIR of its residuals (r1, r2) into accD[host, target(r1), target(r2)];
+// k_ba_accumulate walks each bucket's members [r1, r2, p] in the reference's traversal order (points ascending; inside a point r1, then r2).  A point has at most one residual
+// per target keyframe, so a bucket (h, t1, t2) receives at most ONE member per point, and the traversal order inside a bucket is simply "points ascending".  That makes the
+// lists cheap to build where they are used (the host built and uploaded 86k triples = 1 MB per keyframe before): ridx[p][t] = the residual of point p that targets t,
+// one thread per bucket scans the points of its host keyframe in order — first to count, then, behind a scan over the F^3 counts, to write.
+__global__ void __launch_bounds__(256) k_ba_scd_ridx(const int R, const int F, const int* __restrict__ point, const int* __restrict__ target, int* __restrict__ ridx) {
+  const int ri = blockIdx.x * 256 + threadIdx.x;
+  if (ri < R) ridx[point[ri] * F + target[ri]] = ri;
+}
+// mode 0: counts[k] = members of bucket k = h + F*t1 + F*F*t2;  mode 1: members written at begin[k]...   One WAVEFRONT per bucket (grid: F*F / 4 blocks of four waves x F
+// host keyframes): the lanes take 64 consecutive points of the host keyframe at a time, a ballot ranks the ones that observe both targets — points ascending, as the
+// reference's traversal leaves them.
+__global__ void __launch_bounds__(256) k_ba_scd_lists(const int F, const int* __restrict__ pt_first, const int* __restrict__ pt_last, const int* __restrict__ host,
+                                                        const int* __restrict__ ridx, const int mode, int* __restrict__ counts, const int* __restrict__ begin,
+                                                        int* __restrict__ members) {
+  const int h = blockIdx.y, F2 = F * F, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= F2) return;
+  const int t1 = b % F, t2 = b / F;
+  const int k = h + F * t1 + F2 * t2;
+  int n = 0;
+  const int base = mode ? begin[k] : 0;
+  if (t1 != h && t2 != h)
+    for (int p0 = pt_first[h]; p0 <= pt_last[h]; p0 += 64) {
+      const int p = p0 + lane;
+      int r1 = -1, r2 = -1;
+      if (p <= pt_last[h] && host[p] == h) { r1 = ridx[p * F + t1]; r2 = ridx[p * F + t2]; }
+      const bool in = r1 >= 0 && r2 >= 0;
+      const unsigned long long m = __ballot(in);
+      if (mode && in) {
+        int* o = members + 3 * (size_t)(base + n + __popcll(m & ((1ull << lane) - 1ull)));
+        o[0] = r1; o[1] = r2; o[2] = p;
+      }
+      n += __popcll(m);
+    }
+  if (!mode && lane == 0) counts[k] = n;
+}
+// begin[0 .. n] = exclusive prefix sums of counts[0 .. n)   (n = F^3 <= 1728: one workgroup, 1024 threads x 2 entries, Hillis-Steele in LDS)
+__global__ void __launch_bounds__(1024) k_ba_scd_scan(const int n, const int* __restrict__ counts, int* __restrict__ begin) {
+  __shared__ int s[2048];
+  for (int i = threadIdx.x; i < 2048; i += 1024) s[i] = i < n ? counts[i] : 0;
+  __syncthreads();
+  for (int d = 1; d < 2048; d <<= 1) {
+    int v[2];
+    for (int q = 0; q < 2; q++) { const int i = threadIdx.x + 1024 * q; v[q] = i >= d ? s[i - d] : 0; }
+    __syncthreads();
+    for (int q = 0; q < 2; q++) s[threadIdx.x + 1024 * q] += v[q];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i <= n; i += 1024) begin[i] = i == 0 ? 0 : s[i - 1];
+}
+
 // ------------------------------------------------------------------------------------------------ fp64 stitching
 // step 1: adjoint sandwiches per bucket (summed over the inner frame index where the destination block is fixed),
 // step 2 (k_ba_stitch_gather): every element of H_A, b_A, H_sc, b_sc sums <= 2F+1 slab entries in a fixed order.

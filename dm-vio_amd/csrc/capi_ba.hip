@@ -899,12 +899,22 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   { std::vector<int> cur(top_begin.begin(), top_begin.end() - 1); for (int ri = 0; ri < R; ri++) top_members[cur[host[res_point[ri]] + F * res_target[ri]]++] = ri; }
   size_t npairs = 0;
   for (int p = 0; p < N; p++) { const size_t k = b->h_res_begin[p + 1] - b->h_res_begin[p]; npairs += k * k; }
-  std::vector<int> scd_members(3 * npairs);
-  for (int p = 0; p < N; p++)
-    for (int r1 = b->h_res_begin[p]; r1 < b->h_res_begin[p + 1]; r1++)
-      for (int r2 = b->h_res_begin[p]; r2 < b->h_res_begin[p + 1]; r2++) scd_begin[(host[p] + F * res_target[r1]) + res_target[r2] * F2 + 1]++;
-  for (int k = 0; k < F2 * F; k++) scd_begin[k + 1] += scd_begin[k];
-  {
+  // The Schur buckets' member lists are built on the device (k_ba_scd_*: ba_kernels.hpp) when no point observes a keyframe twice — always, in the reference's graphs (one
+  // PointFrameResidual per point and target, FullSystem.cpp:1248-1262); a graph that does is served by the host loops below, as every graph was before.
+  std::vector<int> pt_first(F, N), pt_last(F, -1);
+  bool scd_on_device = true;
+  for (int p = 0; p < N && scd_on_device; p++) {
+    pt_first[host[p]] = std::min(pt_first[host[p]], p); pt_last[host[p]] = std::max(pt_last[host[p]], p);
+    unsigned int seen = 0;
+    for (int ri = b->h_res_begin[p]; ri < b->h_res_begin[p + 1]; ri++) { const unsigned int bit = 1u << res_target[ri]; if (seen & bit) scd_on_device = false; seen |= bit; }
+  }
+  std::vector<int> scd_members;
+  if (!scd_on_device) {
+    scd_members.resize(3 * npairs);
+    for (int p = 0; p < N; p++)
+      for (int r1 = b->h_res_begin[p]; r1 < b->h_res_begin[p + 1]; r1++)
+        for (int r2 = b->h_res_begin[p]; r2 < b->h_res_begin[p + 1]; r2++) scd_begin[(host[p] + F * res_target[r1]) + res_target[r2] * F2 + 1]++;
+    for (int k = 0; k < F2 * F; k++) scd_begin[k + 1] += scd_begin[k];
     std::vector<int> cur(scd_begin.begin(), scd_begin.end() - 1);
     for (int p = 0; p < N; p++)
       for (int r1 = b->h_res_begin[p]; r1 < b->h_res_begin[p + 1]; r1++)
@@ -950,8 +960,22 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
       dalloc(b, &b->d_accD, (size_t)F2 * F * 64 * b->nsD) || dalloc(b, &b->d_accE, (size_t)F2 * 40 * b->nsTop) || dalloc(b, &b->d_accC, 20 * b->nsC) || dalloc(b, &b->d_numTop, F2 * b->nsTop) || dalloc(b, &b->d_numD, F2 * F * b->nsD)) return -1;
   HIPCHK(b->bounce.h2d(b->d_top_begin, top_begin.data(), sizeof(int) * (F2 + 1), s));
   HIPCHK(b->bounce.h2d(b->d_top_members, top_members.data(), sizeof(int) * R, s));
-  HIPCHK(b->bounce.h2d(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), s));
-  HIPCHK(b->bounce.h2d(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, s));
+  if (!scd_on_device) {
+    HIPCHK(b->bounce.h2d(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), s));
+    HIPCHK(b->bounce.h2d(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, s));
+  } else {
+    // behind the uploads of host / point / target on the same stream: residual table, counts, scan, members
+    int *d_ridx, *d_cnt, *d_first, *d_last;
+    if (dalloc(b, &d_ridx, (size_t)N * F) || dalloc(b, &d_cnt, (size_t)F2 * F) || dalloc(b, &d_first, F) || dalloc(b, &d_last, F)) return -1;
+    HIPCHK(hipMemsetAsync(d_ridx, 0xff, sizeof(int) * (size_t)N * F, s));
+    HIPCHK(b->bounce.h2d(d_first, pt_first.data(), sizeof(int) * F, s));
+    HIPCHK(b->bounce.h2d(d_last, pt_last.data(), sizeof(int) * F, s));
+    hipLaunchKernelGGL(k_ba_scd_ridx, dim3((R + 255) / 256), dim3(256), 0, s, R, F, (const int*)d_point, (const int*)d_target, d_ridx);
+    hipLaunchKernelGGL(k_ba_scd_lists, dim3((F2 + 3) / 4, F), dim3(256), 0, s, F, (const int*)d_first, (const int*)d_last, (const int*)d_host, (const int*)d_ridx, 0, d_cnt, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_ba_scd_scan, dim3(1), dim3(1024), 0, s, F2 * F, (const int*)d_cnt, b->d_scd_begin);
+    hipLaunchKernelGGL(k_ba_scd_lists, dim3((F2 + 3) / 4, F), dim3(256), 0, s, F, (const int*)d_first, (const int*)d_last, (const int*)d_host, (const int*)d_ridx, 1, d_cnt, (const int*)b->d_scd_begin, b->d_scd_members);
+    HIPCHK(hipGetLastError());
+  }
   SG_PH(3);
   StitchBufs& SB = b->SB;
   if (dalloc(b, &SB.topHH, (size_t)F * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F * 32) ||
