@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true", help="exclude makeImages from the step (track only)")
+    ap.add_argument("--no-build-overlap", action="store_true", help="build the pyramids of batch k on the tracking stream, in front of its tracking (rounds 1-3), instead of "
+                                                                     "on a stream of their own while batch k-1 is tracked (two slot sets)")
     ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop_in leg (the reference's own FullSystem all-CPU vs with its hot-path members on libdmvio_hip.so)")
     ap.add_argument("--dropin-frames", type=int, default=100)
@@ -146,7 +148,9 @@ def main():
         xi = xi0 if k == 0 else xi0 * (1.0 + 0.35 * rngx.standard_normal(6))
         R, t = synth.se3_exp(xi)
         frames_meta.append(dict(R=R, t=t, pose7=synth.pose7(R, t), xi=xi))
-    ctx = pkg.Context(w, h, n_slots=B + 1 + 8, device=local_rank)   # slot 0: reference keyframe, 1..B: batch, B+1..B+8: BA window of the overlap leg
+    overlap_build = not args.no_build_overlap and not args.no_pyramid
+    # slot 0: reference keyframe, 1..B: batch (slot set 0), B+1..2B: slot set 1 of the double-buffered pipeline, 2B+1..2B+8: BA window of the overlap leg
+    ctx = pkg.Context(w, h, n_slots=2 * B + 1 + 8, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     trk = pkg.CoarseTrackerHip(ctx)
@@ -199,6 +203,41 @@ def main():
         trk.launch()
         return trk.fetch() if have_prev else None
 
+    # The pyramid build on a stream of its own (dmvio_hip_set_build_stream), double-buffered over two slot sets: while batch k is tracked (k_track_lm: bound by its L1 miss
+    # path and VALU issue) the pyramids of batch k+1 are built beside it (k_build_pyramids_reg: bound by HBM).  Work per step is unchanged — one build, one launch, one
+    # result download + unpack —, only the build of the NEXT batch no longer waits for the tracking of this one.  Events order the two streams: tracking of batch k behind
+    # its build, the build into a slot set behind the tracking that last read it.
+    slot_sets = [slots, np.arange(B + 1, 2 * B + 1, dtype=np.int32)]
+    if overlap_build:
+        bstream = torch.cuda.Stream(device=dev)   # default priority: a high-priority build stream was measured slower (4.45-4.50 vs 4.33-4.37 ms per step)
+        build_done = [torch.cuda.Event(), torch.cuda.Event()]
+        track_done = [torch.cuda.Event(), torch.cuda.Event()]
+        pipe = dict(k=0)
+
+        def overlap_prologue():
+            ctx.set_build_stream(bstream.cuda_stream)
+            ctx.frames_attach_device_batch(slot_sets[0], raw_ptr, frame_bytes)
+            build_done[0].record(bstream)
+            pipe["k"] = 0
+
+        def step_overlap(have_prev):
+            cur = pipe["k"] & 1; nxt = cur ^ 1
+            stream.wait_event(build_done[cur])                  # tracking of batch k behind the build of its slot set
+            if have_prev:
+                trk.fetch_begin()
+            trk.stage(slot_sets[cur], poses0, affs0)
+            trk.launch()
+            track_done[cur].record(stream)
+            bstream.wait_event(track_done[nxt])                 # the other slot set was last read by the tracking of batch k-1 (no-op before the first recording)
+            ctx.frames_attach_device_batch(slot_sets[nxt], raw_ptr, frame_bytes)   # batch k+1, on the build stream
+            build_done[nxt].record(bstream)
+            pipe["k"] += 1
+            return trk.fetch() if have_prev else None
+
+        def overlap_epilogue():
+            torch.cuda.synchronize(dev)
+            ctx.set_build_stream(0)
+
     # ---------------- warmup + correctness guard (poses must reach the ground truth)
     res = None
     for _ in range(max(args.warmup, 1)):
@@ -218,16 +257,36 @@ def main():
     # 2.5x slower), then the pipeline is filled (the results of that launch are unpacked by the first timed step)
     for _ in range(SETTLE_STEPS):
         step()
-    step_pipelined(False)
+    timed_step = step_pipelined
+    if overlap_build:
+        overlap_prologue()                               # the build of the first batch: the pipeline's fill, like the first launch below
+        timed_step = step_overlap
+    timed_step(False)
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res_pipe = step_pipelined(True)
+        res_pipe = timed_step(True)
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if not res_pipe["good"].all():
         raise SystemExit("bench: a pipelined step lost tracking")
     trk.fetch()                                         # drain the last launch (outside the timed region: K launches, K unpacks inside)
+    seq_ms = None
+    if overlap_build:
+        terr_pipe = np.linalg.norm(res_pipe["pose7"][:, :3] - truth[:, :3], axis=1)
+        if terr_pipe.max() >= 5e-3:
+            raise SystemExit("bench: the overlapped pipeline tracked a stale slot set (max err %.3g m)" % terr_pipe.max())
+        overlap_epilogue()
+        # the same K steps with the build on the tracking stream (what rounds 1-3 timed), after the timed region: reported beside the headline, not in it
+        ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
+        step_pipelined(False)
+        torch.cuda.synchronize(dev)
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            step_pipelined(True)
+        torch.cuda.synchronize(dev)
+        seq_ms = 1e3 * (time.perf_counter() - t0s) / args.steps
+        trk.fetch()
     rank_ms = [1e3 * elapsed / args.steps]
     if dist is not None:
         tall = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
@@ -335,12 +394,16 @@ def main():
                      ("torch.distributed.run" if world > 1 else "single process")),
         "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
                                "per step (%d distinct renders, each at its own pose), makeImages%s (level 0 = the resident image, attached in place; levels 1.. built) + trackNewestCoarse (useimu=0 LM) per frame; steady-state pipeline: the host unpacks the results of "
-                               "batch k-1 while batch k runs"
-                               % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else ""),
+                               "batch k-1 while batch k runs%s"
+                               % (w, h, ctx.levels, args.points, pc_n, B, args.distinct, " excluded" if args.no_pyramid else "",
+                                  ", and the pyramids of batch k+1 are built on a second stream meanwhile (two slot sets)" if overlap_build else ""),
                    "frames_per_step_per_gpu": B, "points": args.points, "parallelism": "replicas x%d (independent frames)" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "settle_steps": SETTLE_STEPS,
+        "pipeline": dict(build_overlaps_tracking=bool(overlap_build), ms_per_step_build_on_the_tracking_stream=None if seq_ms is None else round(seq_ms, 4),
+                         what="per step one pyramid build (B frames), one k_track_lm launch, one result download + unpack in every variant; overlapped: the build of "
+                              "batch k+1 runs on its own stream beside the tracking of batch k (dmvio_hip_set_build_stream, two slot sets, events between the streams)"),
         "lm_iterations_mean": float(np.mean(res["iterations"])),
         "max_pose_err_m": float(terr.max()),
     }
@@ -573,9 +636,10 @@ def measure_traffic(args, B, w, h):
         db = sqlite3.connect(dbs[0])
         rows = db.execute("select kernel_name, avg(value), max(value), count(*) from counters_collection where counter_name = 'FETCH_SIZE' group by kernel_name").fetchall()
         lm = [x for x in rows if "k_track_lm" in x[0]]
-        pyr = [x for x in rows if "k_build_pyramids" in x[0]]
+        pyr = [x for x in rows if "k_build_pyramids" in x[0] and "_raw" not in x[0]]
         if not lm or not pyr:
             return None
+        pyr = [max(pyr, key=lambda x: x[2])]     # the full-batch build among the pyramid kernels of the run (single uploads go through the LDS-tile kernel, the batch through the register build)
         # calibration: the full-batch pyramid build reads B raw images exactly once (its largest dispatch); FETCH_SIZE is reported in KiB
         factor = (B * w * h * 4) / (pyr[0][2] * 1024.0)
         traffic = int(lm[0][1] * 1024.0 * factor)
@@ -584,8 +648,8 @@ def measure_traffic(args, B, w, h):
         if ba_lin:     # the BA leg of the same child run: every k_ba_linearize dispatch reads the same window (taps, point and residual tables)
             ba = dict(traffic=int(ba_lin[0][1] * 1024.0 * factor), dispatches=int(ba_lin[0][3]), fetch_kib=float(ba_lin[0][1]), factor=float(factor))
         return dict(traffic=traffic, ba_linearize=ba, source="rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this workload: %d k_track_lm dispatches, FETCH_SIZE %.1f KiB each, x %.3f "
-                                            "(calibrated in the same run on k_build_pyramids, which reads %d B per launch and reports %.1f KiB)"
-                                            % (lm[0][3], lm[0][1], factor, B * w * h * 4, pyr[0][2]))
+                                            "(calibrated in the same run on %s, which reads %d B per launch and reports %.1f KiB)"
+                                            % (lm[0][3], lm[0][1], factor, pyr[0][0].split("(")[0].replace("void dmv::", ""), B * w * h * 4, pyr[0][2]))
     except Exception as ex:      # a diagnostic must not take the bench down
         sys.stderr.write("bench: traffic measurement skipped (%s: %s)\n" % (type(ex).__name__, ex))
         return None
@@ -653,7 +717,7 @@ def bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h):
     together vs one after the other — the reference's tracking / mapping threads on HIP streams."""
     import threading
     bcase = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED)
-    bslots = list(range(B + 1, B + 9))
+    bslots = list(range(2 * B + 1, 2 * B + 9))
     for k in range(8):
         ctx.frame_upload(bslots[k], bcase["imgs"][k])
     ba = pkg.BundleAdjusterHip(ctx)

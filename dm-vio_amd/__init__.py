@@ -305,6 +305,11 @@ class Context:
                                                       qs.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p)), "selftest_divide")
         return qs, qi
 
+    def set_build_stream(self, stream_ptr):
+        """dmvio_hip_set_build_stream: the batched pyramid builds on a stream of their own (0 / None: the context's stream); the caller orders the streams with events."""
+        fn = self.L.dmvio_hip_set_build_stream; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, C.c_void_p(stream_ptr or 0)), "set_build_stream")
+
     def frame_is_clean(self, slot):
         self.L.dmvio_hip_frame_is_clean.argtypes = [C.c_void_p, C.c_int]; self.L.dmvio_hip_frame_is_clean.restype = C.c_int
         return bool(_chk(self.L, self.L.dmvio_hip_frame_is_clean(self.p, int(slot)), "frame_is_clean"))

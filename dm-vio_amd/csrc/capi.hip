@@ -153,8 +153,7 @@ void dmvio_hip_destroy(dmvio_hip_ctx* c) {
   hipFree(c->d_upload);
   c->bounce.release();
   hipFree(c->d_f3);
-  hipFree(c->d_slots);
-  if (c->h_slots) hipHostFree(c->h_slots);
+  for (auto& L : c->slot_lists) { if (L.d) hipFree(L.d); if (L.h) hipHostFree(L.h); }
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -175,10 +174,24 @@ int dmvio_hip_set_stream(dmvio_hip_ctx* c, void* s) {
   return 0;
 }
 
+static hipStream_t buildStream(const dmvio_hip_ctx* c) { return c->build_stream ? c->build_stream : c->stream; }
+// The stream the BATCHED pyramid builds (dmvio_hip_frames_from_device_batch / _attach_device_batch / _from_raw_device_batch) are enqueued on; NULL (default): the context's
+// stream.  With a stream of its own the build of batch k+1 overlaps the tracking of batch k — the build is bound by HBM, k_track_lm by its L1 miss path and VALU issue.  The
+// CALLER orders the two streams (events): a build must not start before the consumers of the slots it rewrites have finished, a consumer not before the build of its slots.
+int dmvio_hip_set_build_stream(dmvio_hip_ctx* c, void* s) {
+  if (!c) return failmsg("null ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(buildStream(c)));
+  c->build_stream = (hipStream_t)s;
+  return 0;
+}
+
 int dmvio_hip_synchronize(dmvio_hip_ctx* c) {
   if (!c) return failmsg("null ctx");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->build_stream) HIPCHK(hipStreamSynchronize(c->build_stream));
   return 0;
 }
 
@@ -333,24 +346,30 @@ int dmvio_hip_frame_from_device(dmvio_hip_ctx* c, int slot, const float* dev) {
 
 // slot list of a batched build -> device (kept while the same list comes again); caller holds c->mu
 static int stageSlots(dmvio_hip_ctx* c, int B, const int* slots) {
-  if (B > c->slots_cap) {
-    if (c->d_slots) { HIPCHK(hipFree(c->d_slots)); HIPCHK(hipHostFree(c->h_slots)); }
-    c->slots_cap = std::max(B, 64); c->slots_valid = 0;
-    HIPCHK(hipMalloc((void**)&c->d_slots, sizeof(int) * c->slots_cap));
-    HIPCHK(hipHostMalloc((void**)&c->h_slots, sizeof(int) * c->slots_cap, hipHostMallocDefault));
+  for (int i = 0; i < B; i++) if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frame batch: slot out of range");
+  dmvio_hip_ctx::SlotList* hit = nullptr;
+  dmvio_hip_ctx::SlotList* lru = &c->slot_lists[0];
+  for (auto& L : c->slot_lists) {
+    if (L.n == B && L.h && !memcmp(L.h, slots, sizeof(int) * B)) { hit = &L; break; }
+    if (L.used < lru->used) lru = &L;
   }
-  bool same = (B == c->slots_valid);
-  for (int i = 0; i < B; i++) {
-    if (slots[i] < 0 || slots[i] >= c->n_slots) return failmsg("frame batch: slot out of range");
-    if (same && c->h_slots[i] != slots[i]) same = false;
+  if (!hit) {
+    hit = lru;
+    // the pinned copy may still be the source of an in-flight upload, the device copy the argument of a running build: drain before rewriting
+    HIPCHK(hipStreamSynchronize(buildStream(c)));
+    if (c->build_stream) HIPCHK(hipStreamSynchronize(c->stream));
+    if (B > hit->cap) {
+      if (hit->d) { HIPCHK(hipFree(hit->d)); HIPCHK(hipHostFree(hit->h)); hit->d = nullptr; hit->h = nullptr; }
+      hit->cap = std::max(B, 64);
+      HIPCHK(hipMalloc((void**)&hit->d, sizeof(int) * hit->cap));
+      HIPCHK(hipHostMalloc((void**)&hit->h, sizeof(int) * hit->cap, hipHostMallocDefault));
+    }
+    memcpy(hit->h, slots, sizeof(int) * B);
+    hit->n = B;
+    HIPCHK(hipMemcpyAsync(hit->d, hit->h, sizeof(int) * B, hipMemcpyHostToDevice, buildStream(c)));
   }
-  if (!same) {
-    // the pinned staging buffer may still be the source of an in-flight copy: drain before rewriting it
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < B; i++) c->h_slots[i] = slots[i];
-    HIPCHK(hipMemcpyAsync(c->d_slots, c->h_slots, sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
-    c->slots_valid = B;
-  }
+  hit->used = ++c->slot_clock;
+  c->d_slots = hit->d;
   return 0;
 }
 
@@ -362,9 +381,9 @@ static int framesFromDeviceBatch(dmvio_hip_ctx* c, int B, const int* slots, cons
   if (int r = stageSlots(c, B, slots)) return r;
   // attached in place: the register build (read-dominated: 5 % ahead); level 0 copied: the LDS-tile build (4 % ahead there) — both measured, tools/time_pyramids.py
   if (regBuild(c) && attach)
-    hipLaunchKernelGGL((k_build_pyramids_reg<true>), regGrid(c, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float), c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen);
+    hipLaunchKernelGGL((k_build_pyramids_reg<true>), regGrid(c, B), dim3(256), 0, buildStream(c), dev_base, stride_bytes / sizeof(float), c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen);
   else
-    hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, c->stream, dev_base, stride_bytes / sizeof(float),
+    hipLaunchKernelGGL(k_build_pyramids, dim3(c->pg.tiles_x * c->pg.tiles_y, B), dim3(256), 0, buildStream(c), dev_base, stride_bytes / sizeof(float),
                        c->pg, c->fs, (const int*)c->d_slots, 0, ++c->build_gen, attach ? 1 : 0);
   for (int i = 0; i < B; i++) { c->h_lvl0[slots[i]] = attach ? dev_base + (size_t)i * (stride_bytes / sizeof(float)) : c->fs.own_level(slots[i], 0); c->h_tiled[slots[i]] = 0; }
   HIPCHK(hipGetLastError());
@@ -388,7 +407,7 @@ int dmvio_hip_frames_from_raw_device_batch(dmvio_hip_ctx* c, dmvio_hip_undistort
   // the wave-autonomous build (a 4 x 8 pixel block per thread, levels in registers) where the pyramid allows it, the LDS-tile build otherwise
   const bool reg = regBuild(c);
   const dim3 grid = reg ? regGrid(c, B) : dim3(c->pg.tiles_x * c->pg.tiles_y, B);
-#define DMV_LAUNCH_RAW(K, T, TILED, stride) hipLaunchKernelGGL((K<T, TILED>), grid, dim3(256), 0, c->stream, (const T*)raw_dev_base, stride, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen)
+#define DMV_LAUNCH_RAW(K, T, TILED, stride) hipLaunchKernelGGL((K<T, TILED>), grid, dim3(256), 0, buildStream(c), (const T*)raw_dev_base, stride, U, c->pg, c->fs, (const int*)c->d_slots, ++c->build_gen)
   if (u->bytes_per_px == 1) {
     if (reg) { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, true, stride_bytes); else DMV_LAUNCH_RAW(k_build_pyramids_raw_reg, unsigned char, false, stride_bytes); }
     else { if (tiled) DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned char, true, stride_bytes); else DMV_LAUNCH_RAW(k_build_pyramids_raw, unsigned char, false, stride_bytes); }

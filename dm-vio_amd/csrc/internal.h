@@ -82,8 +82,12 @@ struct dmvio_hip_ctx {
   float* d_f3 = nullptr;      // download scratch (w*h*3)
   dmv::PyrGeom pg{};
   int wl[DMV_MAX_LEVELS] = {}, hl[DMV_MAX_LEVELS] = {};
-  int *d_slots = nullptr, *h_slots = nullptr;
-  int slots_cap = 0, slots_valid = 0;
+  // slot lists of the batched builds, staged on the device: the last few distinct lists stay (a double-buffered pipeline alternates between two)
+  struct SlotList { int *d = nullptr, *h = nullptr; int cap = 0, n = 0; unsigned long long used = 0; };
+  SlotList slot_lists[4];
+  unsigned long long slot_clock = 0;
+  int* d_slots = nullptr;               // the list the current batched build reads (one of slot_lists[].d)
+  hipStream_t build_stream = nullptr;   // dmvio_hip_set_build_stream: where the batched builds are enqueued (NULL: the context's stream)
   std::vector<const float*> h_lvl0;   // host mirror of FrameStore::lvl0 (kept by the build entry points)
   const float* levelPtr(int slot, int lvl) const { return lvl == 0 ? h_lvl0[slot] : fs.own_level(slot, lvl); }
   unsigned int build_gen = 0;   // generation counter of pyramid builds (FrameStore::build_gen / bad_gen stamps)

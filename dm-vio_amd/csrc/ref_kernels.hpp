@@ -47,9 +47,19 @@ template <int L>
 __device__ __forceinline__ float pooledSum(const float* __restrict__ p0, const int w0, const int x, const int y) {
   if constexpr (L == 0) {
     return p0[x + y * w0];
-  } else {
+  } else if constexpr (L <= 2) {
     return pooledSum<L - 1>(p0, w0, 2 * x, 2 * y) + pooledSum<L - 1>(p0, w0, 2 * x + 1, 2 * y) +
            pooledSum<L - 1>(p0, w0, 2 * x, 2 * y + 1) + pooledSum<L - 1>(p0, w0, 2 * x + 1, 2 * y + 1);
+  } else {
+    // from level 3 on the four children are visited by a ROLLED loop (same operand order): fully unrolled, level 5 issued its 1024 loads at once and took 256 VGPRs +
+    // 62 AGPRs for a kernel that runs once per keyframe
+    float t = 0.f;
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+      const float v = pooledSum<L - 1>(p0, w0, 2 * x + (q & 1), 2 * y + (q >> 1));
+      t = q == 0 ? v : t + v;
+    }
+    return t;
   }
 }
 

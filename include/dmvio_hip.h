@@ -43,6 +43,10 @@ void dmvio_hip_destroy(dmvio_hip_ctx* ctx);
 int dmvio_hip_pyr_levels(const dmvio_hip_ctx* ctx);
 /* Run all work of this ctx on a caller-provided hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int dmvio_hip_set_stream(dmvio_hip_ctx* ctx, void* hip_stream);
+/* A stream of their own for the BATCHED pyramid builds (dmvio_hip_frames_from_device_batch / _attach_device_batch / _from_raw_device_batch); NULL (default) = the context's
+ * stream.  Lets the build of batch k+1 overlap the tracking of batch k (different bounds: HBM vs L1 miss path / VALU).  The caller orders the two streams with events: a
+ * build must not start before the consumers of the slots it rewrites are done, a consumer not before the build of its slots.  dmvio_hip_synchronize waits for both. */
+int dmvio_hip_set_build_stream(dmvio_hip_ctx* ctx, void* hip_stream);
 int dmvio_hip_synchronize(dmvio_hip_ctx* ctx);
 
 /* ------------------------------------------------------------------ frames ------------------- */

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Copies the summaries of gpurun_out/prof_r04 (tools/profile_round.sh r04 + the driver's own bench command) into profiles/r04_*."""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "prof_r04"); P = os.path.join(ROOT, "profiles")
+d = json.loads(open(O + "/bench_n1.json").read().strip().splitlines()[-1])
+json.dump(d, open(P + "/r04_bench_n1.json", "w"), indent=1)
+dd = json.loads(open(O + "/bench_driver_cmd.json").read().strip().splitlines()[-1])
+json.dump(dd, open(P + "/r04_bench_n1_driver_command.json", "w"), indent=1)
+rf = d["roofline"]; ba = d["ba"]
+lines = open(O + "/kernel_stats.md").read().splitlines()
+body = [l for l in lines[2:] if ("dmv::" in l or "__amd_rocclr_copyBuffer" in l)]
+head = ("# r04 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-traffic` (defaults: 4096 frames per step, 200 steps, batch sweep, PCIe legs, BA / trace / overlap / live / "
+        "VIO legs), 1x MI355X\n\nProduced by `tools/profile_round.sh r04` + `tools/publish_r04.py`; durations in microseconds from the rocpd database (`tools/rocprof_summary.py`).  The dominant kernel of "
+        "the headline step is `k_track_lm<256, 4>` with 4096 workgroups (one per frame): avg below vs %.4f ms by HIP events on its stream in the un-profiled run (`profiles/r04_bench_n1.json`: "
+        "%.0f frames/s, algorithmic fraction %.3f, HBM-counter fraction %.3f).  BA kernels: `k_ba_linearize` avg below vs %.1f us by HIP events incl. the gap to the next launch "
+        "(`ba.roofline.chain_us`); `ba.value` = %.0f accepted GN iterations/s on fresh windows (optimize(6) = %.3f ms), %.0f/s on the converged (reject-dominated) loop.\n\n"
+        % (rf["kernel_ms"], d["value"], rf["frac"], rf.get("frac_hbm_counter", float("nan")), ba["roofline"]["kernel_us"], ba["value"], ba["optimize6_ms"], ba["value_converged_loop"]))
+open(P + "/r04_kernel_stats.md", "w").write(head + "\n".join(lines[:2] + body[:80]) + "\n")
+def filt(path):
+    return [l for l in open(path).read().splitlines() if l.startswith("| kernel") or l.startswith("|---") or "dmv::" in l]
+head = ("# r04 — HBM traffic counters (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, no other tracing), 1x MI355X\n\n"
+        "`bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 --ba-iters 20`.  Values are KiB as the counter reports them; on gfx950 FETCH_SIZE tallies 128-byte reads at half "
+        "their size (MI355X_MICROARCH.md): the in-run calibration on `k_build_pyramids` (reads exactly B x w x h x 4 bytes per launch) gives the factor 2.000 that `bench.py` applies "
+        "(`roofline.traffic_source`).  `k_track_lm<256,4>` with 4096 workgroups: %.2f GB per launch by the counter = %.2fx its %.2f GB of algorithmic bytes.\n\n"
+        % (rf["traffic"] / 1e9, rf["traffic"] / rf["algorithmic_bytes_per_launch"], rf["algorithmic_bytes_per_launch"] / 1e9))
+open(P + "/r04_pmc_hbm_traffic.md", "w").write(head + "## FETCH_SIZE\n" + "\n".join(filt(O + "/pmc_FETCH_SIZE.md")) + "\n\n## WRITE_SIZE\n" + "\n".join(filt(O + "/pmc_WRITE_SIZE.md")) + "\n")
+out = ["# r04 — BA: host-side split of the GN iteration (DMVIO_HIP_BA_TIMING=1, no synchronisation added) and kernel timeline (rocprofv3 --kernel-trace of tools/ba_loop.py, 1x MI355X)", ""]
+out += [l for l in open(O + "/ba_timing.log").read().splitlines() if l.startswith("[dmvio_hip_ba]")]
+out += ["", "## tools/ba_loop.py under rocprofv3 (one dmvio_hip_ba_gn_iteration call per iteration from Python; optimize(6) on fresh windows; the profiler adds ~15 % to these host-clock figures)"]
+out += [l for l in open(O + "/ba_loop.log").read().splitlines() if ("GN-iter" in l or "decision" in l or "optimize(" in l)]
+out += ["", "## kernel timeline (us): start, duration, gap to the previous kernel, workgroups — set-up, then accepted iterations of the first optimize"]
+out += open(O + "/ba_timeline.txt").read().splitlines()
+open(P + "/r04_ba_host_split_and_timeline.txt", "w").write("\n".join(out) + "\n")
+di = d.get("drop_in")
+if di and "error" not in di:
+    rows = ["# r04 — the reference's own FullSystem, all-CPU vs with its hot-path members on libdmvio_hip.so (`bench.py` -> `drop_in`, 1x MI355X box)", "",
+            di["what"] + ".", "",
+            "| run | wall clock of the %d addActiveFrame calls (s) | ms per frame after initialisation |" % di["frames"], "|---|---|---|",
+            "| all-CPU, the reference's default threading (multiThreading = true, its own thread-pooled initialiser) | %.3f | %.2f |" % (di["all_cpu_s"], di["ms_per_frame_after_initialisation"]["all_cpu"]),
+            "| all-CPU, single-threaded, sequential initialiser (bit-reproducible: the trajectory baseline) | %.3f | %.2f |" % (di["all_cpu_single_threaded_s"], di["ms_per_frame_after_initialisation"]["all_cpu_single_threaded"]),
+            "| HIP-backed (seven members + makeKeyFrame through tests/dropin/dmvio_hip_adapter.cpp) | %.3f | %.2f |" % (di["hip_backed_s"], di["ms_per_frame_after_initialisation"]["hip_backed"]),
+            "", "Trajectory HIP-backed vs the single-threaded baseline: rmse %.2e m, max %.2e m (bar 1e-3 m); the two all-CPU runs against each other: rmse %.2e m.  %d keyframe optimisations, adapter failures %d."
+            % (di["traj_rmse_m"], di["traj_max_m"], di["reference_own_spread_rmse_m"], di["keyframe_optimisations"], di["adapter_failures"]), "",
+            "## inclusive seconds under the reference's own profiler labels (util/TimeMeasurement scopes)", "", "| scope | all-CPU (default threading) | HIP-backed |", "|---|---|---|"]
+    for k in di["scopes_all_cpu"]:
+        rows.append("| %s | %.4f | %.4f |" % (k, di["scopes_all_cpu"][k], di["scopes_hip_backed"].get(k, 0.0)))
+    rows += ["", "## seconds inside the replaced members, HIP-backed run", "", "| member | seconds |", "|---|---|"]
+    for k, v in di["seconds_in_replaced_members"].items():
+        rows.append("| %s | %.4f |" % (k, v))
+    if "adapter_ms_per_keyframe" in di:
+        a = di["adapter_ms_per_keyframe"]; am = di.get("adapter_ms_per_keyframe_default_threading", {})
+        rows += ["", "## FullSystem::optimize member of the adapter, ms per keyframe (window graph resident: `dmvio_hip_graph_*`, %d forwarded EnergyFunctional mutations, %d resyncs)" % (di["window_graph"]["forwarded_mutations"], di["window_graph"]["resyncs"]), "",
+                 "| part | single-threaded run | multiThreading = true |", "|---|---|---|"]
+        for k in ("hand_over", "dmvio_hip_ba_optimize", "write_back"):
+            rows.append("| %s | %.3f | %.3f |" % (k, a[k], am.get(k, float("nan"))))
+        rows += ["", "HIP-backed with the reference's default threading for what it keeps doing itself: %.3f s (%.2fx the all-CPU default)." % (di["hip_backed_default_threading_s"], di["speedup_vs_reference_default_same_threading"])]
+    rows += ["", di["note"]]
+    open(P + "/r04_fullsystem_scopes.md", "w").write("\n".join(rows) + "\n")
+print(json.dumps({k: d[k] for k in ("value", "ms_per_step")}), json.dumps(rf)[:300])
+print("driver cmd:", dd["value"], dd["ms_per_step"], dd["roofline"]["frac"])
+for k in ("value", "optimize6_ms", "value_converged_loop", "value_per_call_api", "value_single_threaded_order", "gtsam_handoff"):
+    print("ba", k, ba.get(k))
+print("ba roofline", json.dumps(ba["roofline"])[:500]); print("ba cpu", json.dumps(ba["cpu_baseline"])[:300])
+print("live", d["live"]["value"], "vio", d["vio_handoff"]["handoff"]["ms_per_frame"], "pcie", d["pcie"]["value"], d["pcie"]["raw_u8"]["value"], "cpu", d["cpu_baseline"]["value"], "trace", d["trace"]["value"], d["trace"]["cpu_baseline"]["value"])
