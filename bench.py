@@ -1228,6 +1228,7 @@ def bench_dropin(args, w, h):
                 adapter_ms_per_keyframe_default_threading=dict(zip(["hand_over", "dmvio_hip_ba_optimize", "write_back"],
                                                                    [round(1e3 * float(x) / max(int(hip_mt["stat_calls"][4]), 1), 4) for x in hip_mt["optimize_split_seconds"]])),
                 window_graph=dict(zip(["forwarded_mutations", "resyncs"], [int(hip["resident"][0]), int(hip["resident"][1])])),
+                marginalizePointsF_on_device=dict(zip(["calls", "points"], [int(x) for x in hip["real_marginalization"]])),
                 ms_per_frame_after_initialisation=dict(all_cpu=round(1e3 * steady(cpu_mt), 3), all_cpu_single_threaded=round(1e3 * steady(cpu_st), 3), hip_backed=round(1e3 * steady(hip), 3)),
                 traj_rmse_m=float(np.sqrt((d ** 2).sum(1).mean())), traj_max_m=float(np.abs(d).max()),
                 reference_own_spread_rmse_m=float(np.sqrt((d2 ** 2).sum(1).mean())),

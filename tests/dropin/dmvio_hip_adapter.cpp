@@ -105,10 +105,15 @@ struct Backend
 	const EnergyFunctional* graph_ef = nullptr;   // the EnergyFunctional the mirror follows
 	bool graph_valid = false;
 	int resident = 1;
+	int real_marg = 1;                  // EnergyFunctional::marginalizePointsF: 1 = its accumulation on the device from the window optimize left there (resident mode, outside shadow mode), 0 = the reference's own
+	bool window_current = false;        // the BA handle holds the window of THIS keyframe's optimize, untouched since
+	long n_real_marg = 0, n_real_marg_pts = 0;
 	long graph_ops = 0, graph_resyncs = 0, graph_verified = 0, graph_mismatch = 0;
 	double wb_split[5] = {0, 0, 0, 0, 0};   // write-back of optimize: calibration + keyframe states + adjoints / precalc, the downloads, the per-point pass, the removals, the tail
 	double up_split[6] = {0, 0, 0, 0, 0, 0};   // uploadWindow: frame tables, graph walk (index / flatten / verify), set_window, set_graph(_from), frame states + thresholds + calibration, marginalisation prior
-	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize)
+	std::unordered_map<const PointHessian*, int> windowPoint;   // point -> index in the window the BA handle holds (set by the last optimize; shadow mode and resident mode 0)
+	std::vector<PointHessian*> windowPoints;   // resident mode: the points of that window by index; the index itself is kept in PointHessian::idx (a member the reference declares, HessianBlocks.h:
+	                                           // PointHessian, and never uses), written by optimize's write-back, which touches every point anyway
 	std::unordered_map<const PointHessian*, float> deviceHessian;   // shadow mode: idepth_hessian the DEVICE's optimize of this keyframe left behind
 	// CoarseInitializer::calcResAndGS: 0 = the reference's own (its point loop always runs on NUM_THREADS workers that take 50-point chunks as they come,
 	// CoarseInitializer.cpp:507 / util/IndexThreadReduce.h:83-87 — the sums, and with them everything downstream, vary in the last bits from run to run);
@@ -331,6 +336,8 @@ void dropin_set_resident(int mode) { g.resident = mode; }
 // forwarded EnergyFunctional mutations, keyframes at which the mirror had to be rebuilt from the pointer graph (0 in a run that went through the adapter from its first
 // frame), keyframes verified against the flattened pointer graph (mode 2), keyframes at which the two differed
 void dropin_get_writeback_split(double* out5) { for (int k = 0; k < 5; k++) out5[k] = g.wb_split[k]; }
+void dropin_set_real_marginalization(int on) { g.real_marg = on; }
+void dropin_get_real_marginalization(long* out2) { out2[0] = g.n_real_marg; out2[1] = g.n_real_marg_pts; }
 void dropin_get_upload_split(double* out6) { for (int k = 0; k < 6; k++) out6[k] = g.up_split[k]; }
 void dropin_get_resident(long* out4) { out4[0] = g.graph_ops; out4[1] = g.graph_resyncs; out4[2] = g.graph_verified; out4[3] = g.graph_mismatch; }
 int dropin_is_on() { return g.on ? 1 : 0; }
@@ -1009,6 +1016,54 @@ void EnergyFunctional::marginalizePointsF()
 {
 	typedef void (*Fn)(EnergyFunctional*);
 	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional18marginalizePointsFEv");
+	if (g.on && !g.shadow && g.fs && g.real_marg && g.window_current && graphFollows(this) && !setting_useGTSAMIntegration)
+	{
+		// ---- the real member: the window optimize left on the device IS the window the reference holds now (same states, FEJ points, residual states; points dropped since
+		// are simply no candidates).  The relinearisation of the flagged points (FullSystem.cpp:836-849), fixLinearizationF, addPoint<2> + the Schur side and the stitch run
+		// there; what stays here is the reference's bookkeeping around them (EnergyFunctional.cpp:686-700, 707, 715, 731-742).
+		assert(EFDeltaValid); assert(EFAdjointsValid); assert(EFIndicesValid);
+		g.window_current = false;
+		std::vector<unsigned char> cand;
+		cand.assign(g.windowPoints.size(), 0);   // the candidates are addressed in the order of the OPTIMIZE-TIME window (PointHessian::idx, checked against windowPoints)
+		allPointsToMarg.clear();
+		bool known = true;
+		for (EFFrame* f : frames)
+			for (EFPoint* p : f->points)
+				if (p->stateFlag == EFPointStatus::PS_MARGINALIZE)
+				{
+					const int i = p->data->idx;
+					if (i < 0 || i >= (int)g.windowPoints.size() || g.windowPoints[i] != p->data) { known = false; break; }
+					cand[i] = 1;
+					allPointsToMarg.push_back(p);
+				}
+		const int n = CPARS + 8 * nFrames;
+		std::vector<double> Hadd((size_t)n * n), badd(n);
+		std::vector<unsigned char> decision(cand.size(), 0);
+		int resInMdev = 0;
+		if (known && !allPointsToMarg.empty() && HIP_OK(dmvio_hip_ba_marginalize_points(g.ba, cand.data(), decision.data(), Hadd.data(), badd.data(), &resInMdev, 0)))
+		{
+			for (EFPoint* p : allPointsToMarg)
+			{
+				p->priorF *= setting_idepthFixPriorMargFac;
+				for (EFResidual* r : p->residualsAll)
+					if (r->isActive()) connectivityMap[(((uint64_t)r->host->frameID) << 32) + ((uint64_t)r->target->frameID)][1]++;
+			}
+			for (EFPoint* p : allPointsToMarg) removePoint(p);
+			resInM += resInMdev;
+			// (setting_solverMode = SOLVER_FIX_LAMBDA | SOLVER_ORTHOGONALIZE_X_LATER, settings.cpp:81: neither of the two orthogonalisations of :717-736 is selected)
+			for (int r = 0; r < n; r++)
+			{
+				for (int c = 0; c < n; c++) { HM(r, c) += Hadd[(size_t)r * n + c]; HMForGTSAM(r, c) += Hadd[(size_t)r * n + c]; }
+				bM[r] += badd[r]; bMForGTSAM[r] += badd[r];
+			}
+			EFIndicesValid = false;
+			makeIDX();
+			g.n_real_marg++; g.n_real_marg_pts += (long)allPointsToMarg.size();
+			return;
+		}
+		allPointsToMarg.clear();
+		orig(this); return;   // nothing flagged, or a point the window does not know: the reference's own
+	}
 	if (!g.on || !g.shadow || !g.fs) { orig(this); return; }
 	// the window as the reference holds it NOW (after optimize, removeOutliers, flagPointsForRemoval's relinearisation, dropPointsF): identical states on both sides; one
 	// linearisation + accumulation gives the device the per-point Hessians its marginalise-or-drop rule reads
@@ -1075,6 +1130,7 @@ float FullSystem::optimize(int mnumOptIts)
 	Timer tm(g.stats, 4);
 	g.fs = this;
 	g.imm_valid = false;   // a keyframe: immature points are about to be activated, dropped and created
+	g.window_current = false;
 	if (!g.on) return orig(this, mnumOptIts);
 	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;
 	if (!g.shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("FullSystemOptimize"));
@@ -1191,6 +1247,7 @@ float FullSystem::optimize(int mnumOptIts)
 			for (int pi = first; pi < end; pi++)
 			{
 				PointHessian* ph = points[pi];
+				ph->idx = pi;   // where marginalizePointsF finds the point in the window the device holds
 				ph->setIdepth(idepth[pi]); ph->setIdepthZero(idepth[pi]); ph->step = step[pi];
 				ph->idepth_hessian = hess[pi];
 				EFPoint* efp = ph->efPoint;
@@ -1263,6 +1320,8 @@ float FullSystem::optimize(int mnumOptIts)
 		}
 	}
 	wlap(4);
+	g.window_current = resident;   // marginalizePointsF of this keyframe finds the optimised window on the device
+	if (resident) g.windowPoints = points;
 	const auto tq3 = std::chrono::steady_clock::now();
 	g.opt_split[0] += std::chrono::duration<double>(tq1 - tq0).count(); g.opt_split[1] += std::chrono::duration<double>(tq2 - tq1).count();
 	g.opt_split[2] += std::chrono::duration<double>(tq3 - tq2).count();

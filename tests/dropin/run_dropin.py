@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--resident", type=int, default=1, choices=[0, 1, 2],
                     help="mode hip: how FullSystem::optimize hands the window over — 0 the pointer graph flattened every keyframe, 1 the resident window graph (the forwarded "
                          "EnergyFunctional mutators keep it in step), 2 both, compared element for element")
+    ap.add_argument("--real-marg", type=int, default=1, choices=[0, 1],
+                    help="mode hip, resident window: EnergyFunctional::marginalizePointsF accumulates on the device from the window optimize left there (1) or stays the reference's own (0)")
     ap.add_argument("--mt", action="store_true", help="settings.cpp multiThreading = true (the reference's default: linearizeAll, applyRes, the accumulators on 6 workers)")
     ap.add_argument("--scopes", action="store_true", help="inclusive wall time per profiler label of the reference (util/TimeMeasurement scopes) for this run; switches the "
                                                            "event recording of the run off, so wall_s is the pipeline alone")
@@ -85,6 +87,7 @@ def main():
         raise SystemExit("dropin_enable failed")
     if D is not None:
         D.dropin_set_resident.argtypes = [C.c_int]; D.dropin_set_resident(a.resident)
+        D.dropin_set_real_marginalization.argtypes = [C.c_int]; D.dropin_set_real_marginalization(a.real_marg)
     # the reference draws from the C library's rand() (PixelSelector's random pattern, CoarseInitializer's point selection): the same sequence in every mode, whatever the
     # static initialisers of the libraries loaded so far have consumed
     C.CDLL(None).srand(1)
@@ -166,6 +169,8 @@ def main():
         out["upload_split_seconds"] = np.array(list(us))        # frame tables, graph walk, set_window, set_graph(_from), frame states / thresholds / calibration, marginalisation prior
         ws = (C.c_double * 5)(); D.dropin_get_writeback_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_writeback_split(ws)
         out["writeback_split_seconds"] = np.array(list(ws))     # calibration + keyframe states + adjoints / precalc, downloads, per-point pass, removals, tail
+        rm = (C.c_long * 2)(); D.dropin_get_real_marginalization.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_real_marginalization(rm)
+        out["real_marginalization"] = np.array(list(rm))        # marginalizePointsF calls whose accumulation ran on the device, points marginalised there
         rs = (C.c_long * 4)(); D.dropin_get_resident.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_resident(rs)
         out["resident"] = np.array(list(rs))                    # forwarded EnergyFunctional mutations, resyncs, keyframes verified against the flattened graph, mismatches
         msg = C.create_string_buffer(512)
