@@ -551,7 +551,7 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
     b->cap_spart = 4096;
     ok = ok && hipHostMalloc((void**)&b->h_spart, sizeof(float) * b->cap_spart, hipHostMallocDefault) == hipSuccess;
     size_t off = 0;
-    ok = ok && b->bounce.reserve((size_t)8 << 20, b->stream, &off) == hipSuccess;
+    ok = ok && b->bounce.reserve((size_t)4 << 20, b->stream, &off) == hipSuccess;
     b->bounce.used = 0;
     if (!ok) { failmsg("ba_create: device / pinned allocation failed"); freeAll(b); hipStreamDestroy(b->stream); delete b; return nullptr; }
   }
