@@ -50,8 +50,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pyramid", action="store_true", help="exclude makeImages from the step (track only)")
-    ap.add_argument("--no-build-overlap", action="store_true", help="build the pyramids of batch k on the tracking stream, in front of its tracking (rounds 1-3), instead of "
-                                                                     "on a stream of their own while batch k-1 is tracked (two slot sets)")
+    ap.add_argument("--build-overlap", action="store_true", help="TIME the variant that builds the pyramids of batch k+1 on a stream of their own while batch k is tracked (two "
+                                                                  "slot sets) instead of the build on the tracking stream")
+    ap.add_argument("--build-overlap-leg", action="store_true", help="measure that variant AFTER the timed region (same K steps) and report it beside the headline "
+                                                                      "(pipeline.ms_per_step_build_on_its_own_stream); off by default: its launches would otherwise sit in the same "
+                                                                      "rows of a rocprofv3 kernel summary as the timed region's, stretched by the concurrency")
     ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop_in leg (the reference's own FullSystem all-CPU vs with its hot-path members on libdmvio_hip.so)")
     ap.add_argument("--dropin-frames", type=int, default=100)
@@ -148,7 +151,8 @@ def main():
         xi = xi0 if k == 0 else xi0 * (1.0 + 0.35 * rngx.standard_normal(6))
         R, t = synth.se3_exp(xi)
         frames_meta.append(dict(R=R, t=t, pose7=synth.pose7(R, t), xi=xi))
-    overlap_build = not args.no_build_overlap and not args.no_pyramid
+    overlap_build = args.build_overlap and not args.no_pyramid
+    overlap_leg = (args.build_overlap or args.build_overlap_leg) and not args.no_pyramid
     # slot 0: reference keyframe, 1..B: batch (slot set 0), B+1..2B: slot set 1 of the double-buffered pipeline, 2B+1..2B+8: BA window of the overlap leg
     ctx = pkg.Context(w, h, n_slots=2 * B + 1 + 8, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
@@ -208,7 +212,7 @@ def main():
     # result download + unpack —, only the build of the NEXT batch no longer waits for the tracking of this one.  Events order the two streams: tracking of batch k behind
     # its build, the build into a slot set behind the tracking that last read it.
     slot_sets = [slots, np.arange(B + 1, 2 * B + 1, dtype=np.int32)]
-    if overlap_build:
+    if overlap_leg:
         bstream = torch.cuda.Stream(device=dev)   # default priority: a high-priority build stream was measured slower (4.45-4.50 vs 4.33-4.37 ms per step)
         build_done = [torch.cuda.Event(), torch.cuda.Event()]
         track_done = [torch.cuda.Event(), torch.cuda.Event()]
@@ -271,13 +275,13 @@ def main():
     if not res_pipe["good"].all():
         raise SystemExit("bench: a pipelined step lost tracking")
     trk.fetch()                                         # drain the last launch (outside the timed region: K launches, K unpacks inside)
-    seq_ms = None
+    # the other pipeline variant, after the timed region (the same K steps, the same work per step): reported beside the headline, not in it
+    other_ms = None
     if overlap_build:
         terr_pipe = np.linalg.norm(res_pipe["pose7"][:, :3] - truth[:, :3], axis=1)
         if terr_pipe.max() >= 5e-3:
             raise SystemExit("bench: the overlapped pipeline tracked a stale slot set (max err %.3g m)" % terr_pipe.max())
         overlap_epilogue()
-        # the same K steps with the build on the tracking stream (what rounds 1-3 timed), after the timed region: reported beside the headline, not in it
         ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
         step_pipelined(False)
         torch.cuda.synchronize(dev)
@@ -285,8 +289,22 @@ def main():
         for _ in range(args.steps):
             step_pipelined(True)
         torch.cuda.synchronize(dev)
-        seq_ms = 1e3 * (time.perf_counter() - t0s) / args.steps
+        other_ms = 1e3 * (time.perf_counter() - t0s) / args.steps
         trk.fetch()
+    elif overlap_leg:
+        overlap_prologue()
+        step_overlap(False)
+        torch.cuda.synchronize(dev)
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            r_o = step_overlap(True)
+        torch.cuda.synchronize(dev)
+        other_ms = 1e3 * (time.perf_counter() - t0s) / args.steps
+        if not r_o["good"].all() or np.linalg.norm(r_o["pose7"][:, :3] - truth[:, :3], axis=1).max() >= 5e-3:
+            raise SystemExit("bench: the overlapped pipeline lost tracking or tracked a stale slot set")
+        trk.fetch()
+        overlap_epilogue()
+        ctx.frames_attach_device_batch(slots, raw_ptr, frame_bytes)
     rank_ms = [1e3 * elapsed / args.steps]
     if dist is not None:
         tall = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
@@ -336,6 +354,9 @@ def main():
         pyr_bytes = B * (4 * w * h + sum(4 * (w >> l) * (h >> l) for l in range(1, ctx.levels)))  # read the resident image + write the coarser levels (level 0 is the image itself)
         roofline["pyramid_kernel_ms"] = round(pm, 4)
         roofline["pyramid_GBps"] = round(pyr_bytes / (pm * 1e-3) / 1e9, 1)
+        # the whole step against the same peak: algorithmic bytes of tracking + the build's traffic over the step time of the timed region
+        roofline["step"] = dict(bytes=int(alg_bytes + pyr_bytes), ms=round(ms_per_step, 4), achieved=round((alg_bytes + pyr_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+                                frac=round((alg_bytes + pyr_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
 
     # ---------------- CPU baseline: the oracle (port of the reference's SSE path), 1 thread, bounded sample
     cpu = None
@@ -401,9 +422,14 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "settle_steps": SETTLE_STEPS,
-        "pipeline": dict(build_overlaps_tracking=bool(overlap_build), ms_per_step_build_on_the_tracking_stream=None if seq_ms is None else round(seq_ms, 4),
-                         what="per step one pyramid build (B frames), one k_track_lm launch, one result download + unpack in every variant; overlapped: the build of "
-                              "batch k+1 runs on its own stream beside the tracking of batch k (dmvio_hip_set_build_stream, two slot sets, events between the streams)"),
+        "pipeline": dict(build_overlaps_tracking=bool(overlap_build),
+                         ms_per_step_build_on_the_tracking_stream=round(ms_per_step, 4) if not overlap_build else (None if other_ms is None else round(other_ms, 4)),
+                         ms_per_step_build_on_its_own_stream=round(ms_per_step, 4) if overlap_build else (None if other_ms is None else round(other_ms, 4)),
+                         what="per step one pyramid build (B frames), one k_track_lm launch, one result download + unpack in every variant; `value` times the build on the "
+                              "tracking stream (every kernel alone on the device: the durations the roofline and the rocprofv3 statistics quote); on its own stream "
+                              "(dmvio_hip_set_build_stream, two slot sets, events between the streams; --build-overlap / --build-overlap-leg) the build of batch k+1 runs "
+                              "beside the tracking of batch k — measured between 1.5 % slower and 5.8 % faster over five boxes (profiles/r04_pyramid_build.md), because the "
+                              "register file is full of k_track_lm waves"),
         "lm_iterations_mean": float(np.mean(res["iterations"])),
         "max_pose_err_m": float(terr.max()),
     }

@@ -16,7 +16,8 @@ head = ("# r04 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu
         "%.0f frames/s, algorithmic fraction %.3f, HBM-counter fraction %.3f).  BA kernels: `k_ba_linearize` avg below vs %.1f us by HIP events incl. the gap to the next launch "
         "(`ba.roofline.chain_us`); `ba.value` = %.0f accepted GN iterations/s on fresh windows (optimize(6) = %.3f ms), %.0f/s on the converged (reject-dominated) loop.\n\n"
         % (rf["kernel_ms"], d["value"], rf["frac"], rf.get("frac_hbm_counter", float("nan")), ba["roofline"]["kernel_us"], ba["value"], ba["optimize6_ms"], ba["value_converged_loop"]))
-open(P + "/r04_kernel_stats.md", "w").write(head + "\n".join(lines[:2] + body[:80]) + "\n")
+tail = ""
+open(P + "/r04_kernel_stats.md", "w").write(head + "\n".join(lines[:2] + body[:80]) + "\n" + tail)
 def filt(path):
     return [l for l in open(path).read().splitlines() if l.startswith("| kernel") or l.startswith("|---") or "dmv::" in l]
 head = ("# r04 — HBM traffic counters (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, no other tracing), 1x MI355X\n\n"
