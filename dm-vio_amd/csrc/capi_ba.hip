@@ -262,8 +262,9 @@ static int uploadWindowTables(dmvio_hip_ba* b, bool new_state = false, bool swit
   return 0;
 }
 static int uploadAdjoints(dmvio_hip_ba* b) {
-  HIPCHK(hipMemcpyAsync(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), hipMemcpyHostToDevice, b->stream));
+  // staged in the handle's pinned area: the host tables may change (setAdjointsF of the next state) while the copy is still in flight
+  HIPCHK(b->bounce.h2d(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), b->stream));
+  HIPCHK(b->bounce.h2d(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), b->stream));
   return 0;
 }
 
@@ -870,9 +871,8 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   HIPCHK(hipStreamSynchronize(b->stream));
   b->th_pending = false;   // the stream is drained and h_res is cleared below (th_ticket restarts at 0 while b->ticket keeps counting): nothing of the old graph may be awaited
   freeDevice(b);
-  // the arena of the previous graph, cleared for this one (one memset per chunk on the handle's stream, one wait — the uploads below also use the NULL stream)
+  // the arena of the previous graph, cleared for this one on the handle's stream; the uploads and kernels below follow on the same stream: no wait
   for (size_t k = 0; k < b->arena.chunks.size(); k++) if (b->arena.used[k]) { HIPCHK(hipMemsetAsync(b->arena.chunks[k].first, 0, b->arena.used[k], b->stream)); b->arena.used[k] = 0; }   // what the previous graph used, not the whole chunk
-  HIPCHK(hipStreamSynchronize(b->stream));
   SG_PH(0);
   b->arena.cur = 0; b->arena.off = 0;
   struct ArenaScope { dmvio_hip_ba* b; ~ArenaScope() { b->arena.on = false; } } arenaScope{b};
@@ -1022,7 +1022,9 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   }
   SG_PH(4);
   if (int r = uploadAdjoints(b)) return r;
-  HIPCHK(hipStreamSynchronize(s));
+  // no wait: everything above is staged in pinned memory and enqueued on the handle's stream, and so is whatever uses it (the 0.1 ms the uploads take overlap the caller's
+  // next calls — frame states, prior, the first host-side steps of optimize)
+  HIPCHK(hipGetLastError());
   SG_PH(5);
 #undef SG_PH
   b->tm_graph_n++;

@@ -67,6 +67,31 @@ static int mappingDemo() {
   const float rmse2 = ef2.optimize(6, hooks, opt);
   if (rmse2 != rmse || ef2.lastEnergy != ef.lastEnergy) { std::fprintf(stderr, "hook path differs: rmse %.9g vs %.9g, energy %.9g vs %.9g\n", rmse2, rmse, ef2.lastEnergy, ef.lastEnergy); return 6; }
   std::printf("ok: the same window through the computeBAUpdate hook: identical result\n");
+  // the window graph kept resident (EnergyFunctional's own mutators, forwarded one by one): inserted with one residual too many per point and in another order,
+  // then brought to the same graph by dropResidual — the LAST residual takes the dropped one's index, as in EnergyFunctional::dropResidual —; same result
+  dmvio_hip::WindowGraph graph;
+  for (int f = 0; f < F; f++) graph.insertFrame();
+  for (int i = 0; i < N; i++) {
+    const dmvio_hip::ActivePoint& p = points[i];
+    const int idx = graph.insertPoint(p);
+    if (idx < 0) return 1;
+    // wanted: [t0, t1, ..., t(k-1)].  Inserted: a placeholder at index 0, then t1 ... t(k-1), then t0; dropping index 0 moves the last residual (t0) into its place
+    const size_t k = p.targets.size();
+    if (k == 0) continue;
+    graph.insertResidual(p.host, idx, p.targets[0]);
+    for (size_t r = 1; r < k; r++) graph.insertResidual(p.host, idx, p.targets[r]);
+    graph.insertResidual(p.host, idx, p.targets[0]);
+    if (!graph.dropResidual(p.host, idx, 0)) return 1;
+  }
+  if (graph.nPoints() != N) return 1;
+  dmvio_hip::WindowOptimizer ef3(frames);
+  if (!ef3.setWindow(frameHessians, fx, fy, cx, cy) || !ef3.setPoints(graph)) { std::fprintf(stderr, "window graph hand-over failed: %s\n", dmvio_hip::lastError().c_str()); return 1; }
+  const float rmse3 = ef3.optimize(6);
+  if (rmse3 != rmse || ef3.lastEnergy != ef.lastEnergy) { std::fprintf(stderr, "window graph path differs: rmse %.9g vs %.9g, energy %.9g vs %.9g\n", rmse3, rmse, ef3.lastEnergy, ef.lastEnergy); return 7; }
+  std::vector<float> id3;
+  ef3.idepths(id3);
+  if (!graph.setIdepths(id3)) return 1;
+  std::printf("ok: the same window from the resident graph (%d residuals through insertResidual / dropResidual): identical result\n", graph.nResiduals());
   return 0;
 }
 

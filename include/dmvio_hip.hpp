@@ -190,6 +190,33 @@ struct ActivePoint {
   std::vector<int> targets;   /* frame indices of its PointFrameResiduals */
 };
 
+/* The window's point / residual graph kept resident across keyframes: EnergyFunctional's own mutators over a host-side mirror (dmvio_hip_graph_*, include/dmvio_hip.h
+ * "window graph"; EnergyFunctional.cpp:435-518, 641-646, 766-782).  Elements are addressed as the reference addresses its objects: a keyframe by EFFrame::idx, a point by
+ * (host keyframe, EFPoint::idxInPoints), a residual by (point, EFResidual::idxInAll); insert* return the index the reference assigns in the same call, -1 on error. */
+class WindowGraph {
+ public:
+  WindowGraph() : g_(dmvio_hip_graph_create()) {}
+  ~WindowGraph() { if (g_) dmvio_hip_graph_destroy(g_); }
+  WindowGraph(const WindowGraph&) = delete;
+  WindowGraph& operator=(const WindowGraph&) = delete;
+  bool valid() const { return g_ != nullptr; }
+  int insertFrame() { return g_ ? dmvio_hip_graph_insert_frame(g_) : -1; }
+  bool marginalizeFrame(int idx) { return g_ && dmvio_hip_graph_remove_frame(g_, idx) == 0; }
+  int insertPoint(const ActivePoint& p) { return g_ ? dmvio_hip_graph_insert_point(g_, p.host, p.u, p.v, p.idepth, p.color, p.weights, p.hasDepthPrior ? 1 : 0) : -1; }
+  bool removePoint(int host, int idxInPoints) { return g_ && dmvio_hip_graph_remove_point(g_, host, idxInPoints) == 0; }
+  int insertResidual(int host, int idxInPoints, int target) { return g_ ? dmvio_hip_graph_insert_residual(g_, host, idxInPoints, target) : -1; }
+  bool dropResidual(int host, int idxInPoints, int idxInAll) { return g_ && dmvio_hip_graph_drop_residual(g_, host, idxInPoints, idxInAll) == 0; }
+  bool setIdepth(int host, int idxInPoints, float idepth) { return g_ && dmvio_hip_graph_set_idepth(g_, host, idxInPoints, idepth) == 0; }
+  bool setIdepths(const std::vector<float>& idepth) { return g_ && dmvio_hip_graph_set_idepths(g_, (int)idepth.size(), idepth.data()) == 0; }   /* makeIDX order */
+  int nFrames() const { int F = 0; return g_ && dmvio_hip_graph_counts(g_, &F, nullptr, nullptr) == 0 ? F : -1; }
+  int nPoints() const { int N = 0; return g_ && dmvio_hip_graph_counts(g_, nullptr, &N, nullptr) == 0 ? N : -1; }
+  int nResiduals() const { int R = 0; return g_ && dmvio_hip_graph_counts(g_, nullptr, nullptr, &R) == 0 ? R : -1; }
+  dmvio_hip_graph* handle() const { return g_; }
+
+ private:
+  dmvio_hip_graph* g_;
+};
+
 class WindowOptimizer {
  public:
   explicit WindowOptimizer(FrameStore& frames) : lastEnergy(NAN), lastIterations(0), ba_(frames.valid() ? dmvio_hip_ba_create(frames.handle()) : nullptr), F_(0), N_(0) {}
@@ -228,6 +255,12 @@ class WindowOptimizer {
     }
     if (dmvio_hip_ba_set_graph(ba_, (int)N, host.data(), u.data(), v.data(), id.data(), col.data(), wts.data(), prior.data(), (int)rp.size(), rp.data(), rt.data()) != 0) return false;
     N_ = (int)N;
+    return true;
+  }
+  /* the same from a resident WindowGraph (no flat arrays are formed by the caller); after optimize(): graph.setIdepths(<idepths()>) */
+  bool setPoints(const WindowGraph& graph) {
+    if (!ba_ || !graph.valid() || dmvio_hip_ba_set_graph_from(ba_, graph.handle()) != 0) return false;
+    N_ = graph.nPoints();
     return true;
   }
   /* returns sqrt(E / (patternNum * resInA)) like the reference; a negative value on a device / argument error (the adapter sets isLost) */
