@@ -147,6 +147,46 @@ def test_fp32_register_build_equals_the_lds_tile_build(pkg, gpu_required, size):
     pkg.set_raw_batch_kernel(ctx, 1)
 
 
+def test_batched_builds_on_a_stream_of_their_own(pkg, synth, gpu_required):
+    """dmvio_hip_set_build_stream: the batched pyramid builds enqueued on a second stream, ordered against the tracking stream by the caller's events (a build behind the
+    consumers of the slots it rewrites, a consumer behind the build of its slots) — two slot sets used alternately over several rounds with changing images, every round's
+    tracking results equal to those of the same images built on the context's stream, bit for bit; the slot lists stay cached on the device (no re-upload per round)."""
+    import torch
+    w, h = 256, 192
+    case = synth.tracking_case(w, h, n_ref=700, n_frames=4, xi_jitter=0.3)
+    B = 48
+    ctx = pkg.Context(w, h, n_slots=3 * B + 1)
+    stream = torch.cuda.Stream(); ctx.set_stream(stream.cuda_stream)
+    ctx.frame_upload(0, case["ref_img"])
+    trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    base = torch.from_numpy(np.stack([case["frames"][i % 4]["img"].reshape(-1) for i in range(B)]).astype(np.float32)).to("cuda:0")
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    sets = [list(range(1, B + 1)), list(range(B + 1, 2 * B + 1))]
+    ref_slots = list(range(2 * B + 1, 3 * B + 1))
+    bstream = torch.cuda.Stream()
+    built = [torch.cuda.Event(), torch.cuda.Event()]; tracked = [torch.cuda.Event(), torch.cuda.Event()]
+    for rnd in range(5):
+        imgs = torch.roll(base, shifts=rnd, dims=0).contiguous()              # another assignment of images to slots every round
+        torch.cuda.synchronize()
+        ctx.set_build_stream(0)
+        ctx.frames_attach_device_batch(ref_slots, imgs.data_ptr(), w * h * 4)     # the reference: built on the context's stream
+        want = trk.track_batch(ref_slots, [ident] * B, [(0.0, 0.0)] * B)
+        ctx.set_build_stream(bstream.cuda_stream)
+        cur = rnd & 1
+        bstream.wait_event(tracked[cur])                                       # the last consumer of this slot set (two rounds ago)
+        ctx.frames_attach_device_batch(sets[cur], imgs.data_ptr(), w * h * 4)
+        built[cur].record(bstream)
+        stream.wait_event(built[cur])
+        got = trk.track_batch(sets[cur], [ident] * B, [(0.0, 0.0)] * B)
+        tracked[cur].record(stream)
+        assert got["good"].all()
+        for k in ("pose7", "aff", "lastResiduals", "H", "b", "iterations"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (rnd, k)
+    ctx.set_build_stream(0)
+    ctx.synchronize()
+
+
 @pytest.mark.parametrize("B,launch", [(6, None), (200, (1, 512)), (600, (1, 256))])
 def test_tiled_level0_of_the_raw_batch_build_tracks_bit_for_bit(pkg, synth, gpu_required, B, launch):
     """dmvio_hip_frames_from_raw_device_batch can store level 0 in 8x4-pixel tiles (dmvio_hip_set_raw_batch_layout; it writes level 0 anyway): the coarse tracker's batch kernel gathers the same twelve values per
