@@ -856,8 +856,15 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   return 0;
 }
 
+static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
+                        const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target, bool wait);
+// synchronous on return, like every entry point that takes caller arrays; dmvio_hip_ba_set_graph_from is the stream-ordered form
 int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
                            const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target) {
+  return setGraphImpl(b, N, host, u, v, idepth, color8, weights8, hasDepthPrior, R, res_point, res_target, true);
+}
+static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u, const float* v, const float* idepth, const float* color8,
+                        const float* weights8, const unsigned char* hasDepthPrior, int R, const int* res_point, const int* res_target, bool wait) {
   if (!b || !host || !u || !v || !idepth || !color8 || !weights8 || !res_point || !res_target) return failmsg("ba_set_graph: null argument");
   BA_LOCK(b);
   b->sums_fresh = false; b->sys_ready = false;
@@ -1022,9 +1029,10 @@ int dmvio_hip_ba_set_graph(dmvio_hip_ba* b, int N, const int* host, const float*
   }
   SG_PH(4);
   if (int r = uploadAdjoints(b)) return r;
-  // no wait: everything above is staged in pinned memory and enqueued on the handle's stream, and so is whatever uses it (the 0.1 ms the uploads take overlap the caller's
-  // next calls — frame states, prior, the first host-side steps of optimize)
+  // everything above is staged in pinned memory and enqueued on the handle's stream, and so is whatever uses it: dmvio_hip_ba_set_graph_from does not wait (the 0.1 ms the
+  // uploads take overlap the caller's next calls — frame states, prior, the first host-side steps of optimize)
   HIPCHK(hipGetLastError());
+  if (wait) HIPCHK(hipStreamSynchronize(s));
   SG_PH(5);
 #undef SG_PH
   b->tm_graph_n++;
@@ -1057,7 +1065,7 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
       }
   }
   const auto& S = b->gscratch;
-  return dmvio_hip_ba_set_graph(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data());
+  return setGraphImpl(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data(), false);
 }
 
 #define BA_READY_LOCKED(b) do { if (!(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)

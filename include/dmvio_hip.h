@@ -314,7 +314,8 @@ int dmvio_hip_graph_point_residuals(dmvio_hip_graph* g, int host, int idxInPoint
 /* The graph as the flat arrays dmvio_hip_ba_set_graph takes, in makeIDX order (any output may be NULL; sizes from dmvio_hip_graph_counts; a dangling residual has target -1). */
 int dmvio_hip_graph_export(dmvio_hip_graph* g, int* host, float* u, float* v, float* idepth, float* color8, float* weights8, unsigned char* hasDepthPrior, int* res_point,
                            int* res_target);
-/* dmvio_hip_ba_set_graph from the resident graph (the window set by dmvio_hip_ba_set_window must have the graph's number of keyframes).  After an optimisation the caller
+/* dmvio_hip_ba_set_graph from the resident graph (the window set by dmvio_hip_ba_set_window must have the graph's number of keyframes).  Stream-ordered: unlike
+ * dmvio_hip_ba_set_graph it does not wait for its uploads (they are staged in the handle's pinned memory and enqueued in front of whatever uses them).  After an optimisation the caller
  * hands the new inverse depths back with dmvio_hip_graph_set_idepths(g, N, <idepth of dmvio_hip_ba_get_points>): same order. */
 int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* ba, dmvio_hip_graph* g);
 /* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  The library accumulates ACTIVE residuals only

@@ -12,3 +12,14 @@ for _ in range(25):
     t0 = time.perf_counter(); ba.set_case(case, list(range(8))); t1 = time.perf_counter(); ba.optimize(6); t2 = time.perf_counter()
     ts.append(t1 - t0); to.append(t2 - t1)
 print("set_window + set_graph: median %.3f ms (first %.3f ms); optimize(6): median %.3f ms" % (1e3 * np.median(ts[3:]), 1e3 * ts[0], 1e3 * np.median(to[3:])))
+
+# the same window from the resident graph (dmvio_hip_ba_set_graph_from: stream-ordered, does not wait for its uploads); optimize(6) behind it absorbs what is left of them
+g_ = P.WindowGraph.from_case(case)
+F = case["n_frames"]
+ts, to = [], []
+for _ in range(25):
+    t0 = time.perf_counter()
+    ba.set_window(list(range(F)), case["poses0"], np.zeros((F, 2)), np.ones(F, np.float32), np.arange(F, dtype=np.int32), case["K4"]); ba.set_graph_from(g_)
+    t1 = time.perf_counter(); ba.optimize(6); t2 = time.perf_counter()
+    ts.append(t1 - t0); to.append(t2 - t1)
+print("set_window + set_graph_from: median %.3f ms; optimize(6) behind it: median %.3f ms; together %.3f ms" % (1e3 * np.median(ts[3:]), 1e3 * np.median(to[3:]), 1e3 * np.median(np.array(ts[3:]) + np.array(to[3:]))))
