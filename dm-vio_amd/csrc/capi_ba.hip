@@ -1052,6 +1052,7 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
     if (g->nDangling) return failmsg("ba_set_graph_from: " + std::to_string(g->nDangling) + " residuals still target a removed keyframe (their dropResidual has not been forwarded)");
     N = g->nPoints; R = g->nRes;
     if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
+    g->flat_version = g->version;   // the flat order handed to the device: dmvio_hip_graph_set_idepths accepts values in this order until the structure changes
     auto& S = b->gscratch;
     S.host.resize(N); S.u.resize(N); S.v.resize(N); S.idepth.resize(N); S.color.resize(8 * (size_t)N); S.weights.resize(8 * (size_t)N); S.prior.resize(N);
     S.res_point.resize(R); S.res_target.resize(R);

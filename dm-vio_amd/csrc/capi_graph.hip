@@ -23,8 +23,6 @@
 
 using namespace dmv;
 
-int dmv_graph_fail(const std::string& m) { return failmsg(m); }
-
 extern "C" {
 
 dmvio_hip_graph* dmvio_hip_graph_create(void) { return new (std::nothrow) dmvio_hip_graph(); }
@@ -128,6 +126,8 @@ int dmvio_hip_graph_set_idepth(dmvio_hip_graph* g, int host, int idxInPoints, fl
 int dmvio_hip_graph_set_idepths(dmvio_hip_graph* g, int N, const float* idepth) {
   G_LOCK(g);
   if (!idepth || N != g->nPoints) return failmsg("graph_set_idepths: N differs from the graph's point count");
+  if (g->flat_version != g->version)
+    return failmsg("graph_set_idepths: the graph changed (or was never flattened) since dmvio_hip_ba_set_graph_from / dmvio_hip_graph_export — the flat order of these values is not the graph's any more");
   int i = 0;
   for (auto& fr : g->frames) for (DmvGraphPoint& P : fr) P.idepth = idepth[i++];
   return 0;
@@ -157,6 +157,7 @@ int dmvio_hip_graph_point_residuals(dmvio_hip_graph* g, int host, int idxInPoint
 int dmvio_hip_graph_export(dmvio_hip_graph* g, int* host, float* u, float* v, float* idepth, float* color8, float* weights8, unsigned char* hasDepthPrior, int* res_point,
                            int* res_target) {
   G_LOCK(g);
+  g->flat_version = g->version;
   int pi = 0, ri = 0;
   for (int f = 0; f < (int)g->frames.size(); f++)
     for (const DmvGraphPoint& P : g->frames[f]) {

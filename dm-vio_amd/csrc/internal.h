@@ -119,6 +119,8 @@ struct dmvio_hip_graph {
   std::vector<std::vector<DmvGraphPoint>> frames;   // EnergyFunctional::frames -> EFFrame::points
   int nPoints = 0, nRes = 0, nDangling = 0;
   unsigned long long version = 0;                    // counts structural changes (not value updates)
+  unsigned long long flat_version = ~0ull;           // `version` when the graph was last flattened (dmvio_hip_graph_export / dmvio_hip_ba_set_graph_from): values that come back in
+                                                     // flat order (dmvio_hip_graph_set_idepths) are only accepted while the two agree
 };
 
 // hypothesis-parallel trackNewCoarse: the element-wise fp64 sum over all ranks of a small HOST buffer, in place (set by dmvio_hip_tracker_set_comm /

@@ -307,7 +307,7 @@ int dmvio_hip_graph_remove_point(dmvio_hip_graph* g, int host, int idxInPoints);
 int dmvio_hip_graph_insert_residual(dmvio_hip_graph* g, int host, int idxInPoints, int target);  /* EnergyFunctional::insertResidual: appended; returns idxInAll */
 int dmvio_hip_graph_drop_residual(dmvio_hip_graph* g, int host, int idxInPoints, int idxInAll);  /* EnergyFunctional::dropResidual: the point's last residual takes its index */
 int dmvio_hip_graph_set_idepth(dmvio_hip_graph* g, int host, int idxInPoints, float idepth);     /* PointHessian::setIdepth of one point */
-int dmvio_hip_graph_set_idepths(dmvio_hip_graph* g, int N, const float* idepth);                /* ... of all points in makeIDX order: what dmvio_hip_ba_get_points returns after an optimisation */
+int dmvio_hip_graph_set_idepths(dmvio_hip_graph* g, int N, const float* idepth);                /* ... of all points in makeIDX order: what dmvio_hip_ba_get_points returns after an optimisation; refused once the graph's structure changed since it was flattened */
 int dmvio_hip_graph_counts(dmvio_hip_graph* g, int* F, int* N, int* R);                         /* EnergyFunctional::nFrames, nPoints, nResiduals */
 int dmvio_hip_graph_frame_points(dmvio_hip_graph* g, int host);                                 /* EFFrame::points.size() */
 int dmvio_hip_graph_point_residuals(dmvio_hip_graph* g, int host, int idxInPoints);             /* EFPoint::residualsAll.size() */

@@ -141,7 +141,11 @@ def test_errors_and_dangling_residuals(pkg):
     g.drop_residual(a, p, 0)                                                                   # FullSystem::marginalizeFrame's own drop of it: the last residual takes index 0
     assert list(g.export()["res_target"]) == [1] and g.point_residuals(a, p) == 1
     with pytest.raises(pkg.HipLibraryError):
-        g.set_idepths(np.zeros(5, np.float32))
+        g.set_idepths(np.zeros(5, np.float32))                                                 # wrong count
+    g.export(); g.set_idepths(np.full(1, 0.4, np.float32))                                     # flat values are accepted for the structure that was flattened ...
+    q = g.insert_point(a, 20, 20, 1, np.zeros(8), np.ones(8)); g.remove_point(a, q)
+    with pytest.raises(pkg.HipLibraryError):
+        g.set_idepths(np.full(1, 0.5, np.float32))                                             # ... and refused once it changed (same count, possibly another order)
     g.clear()
     assert g.counts() == (0, 0, 0)
 
