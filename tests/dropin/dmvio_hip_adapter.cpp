@@ -7,6 +7,9 @@
 //     FullSystem::optimize                  src/dso/FullSystem/FullSystemOptimize.cpp:417-647
 //     FullSystem::activatePointsMT_Reductor src/dso/FullSystem/FullSystem.cpp:589-601 (-> FullSystem::optimizeImmaturePoint, FullSystemOptPoint.cpp:51-205, for a range of candidates)
 //     CoarseInitializer::calcResAndGS       src/dso/FullSystem/CoarseInitializer.cpp:331-624   (optional: dropin_set_initializer)
+//     EnergyFunctional::insertFrame / insertPoint / insertResidual / dropResidual / removePoint / marginalizeFrame
+//                                           src/dso/OptimizationBackend/EnergyFunctional.cpp:435-518, 641-646, 766-782 (unchanged + one forwarded call each: the window graph stays resident)
+//     EnergyFunctional::marginalizePointsF  src/dso/OptimizationBackend/EnergyFunctional.cpp:678-742 (its accumulation on the device, from the window optimize left there)
 // — each forwarding to the C ABI of include/dmvio_hip.h (libdmvio_hip.so) and writing the results back into the reference's pointer graph, so that the rest of
 // FullSystem (initialiser, pixel selector, activation, marginalisation policy, keyframe management: all unmodified reference code) runs on unchanged.
 //
