@@ -153,8 +153,9 @@ def main():
         frames_meta.append(dict(R=R, t=t, pose7=synth.pose7(R, t), xi=xi))
     overlap_build = args.build_overlap and not args.no_pyramid
     overlap_leg = (args.build_overlap or args.build_overlap_leg) and not args.no_pyramid
-    # slot 0: reference keyframe, 1..B: batch (slot set 0), B+1..2B: slot set 1 of the double-buffered pipeline, 2B+1..2B+8: BA window of the overlap leg
-    ctx = pkg.Context(w, h, n_slots=2 * B + 1 + 8, device=local_rank)
+    # slot 0: reference keyframe, 1..B: batch (slot set 0), [B+1..2B: slot set 1 of the double-buffered pipeline variant,] then 8 slots for the BA window of the overlap leg
+    args.ba_slot0 = (2 * B if overlap_leg else B) + 1
+    ctx = pkg.Context(w, h, n_slots=args.ba_slot0 + 8, device=local_rank)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     trk = pkg.CoarseTrackerHip(ctx)
@@ -743,7 +744,7 @@ def bench_overlap(args, pkg, synth, ctx, trk, slots, poses0, affs0, B, w, h):
     together vs one after the other — the reference's tracking / mapping threads on HIP streams."""
     import threading
     bcase = synth.ba_case(w, h, n_frames=8, n_points=args.ba_points, seed=synth.SEED)
-    bslots = list(range(2 * B + 1, 2 * B + 9))
+    bslots = list(range(args.ba_slot0, args.ba_slot0 + 8))
     for k in range(8):
         ctx.frame_upload(bslots[k], bcase["imgs"][k])
     ba = pkg.BundleAdjusterHip(ctx)
