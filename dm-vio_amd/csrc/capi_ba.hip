@@ -950,6 +950,9 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
   if (hasDepthPrior) for (int p = 0; p < N; p++) prior[p] = hasDepthPrior[p] ? H.S.idepthFixPrior : 0.0f;   // EFPoint::takeData
   hipStream_t s = b->stream;
   SG_PH(2);
+  // the uploads of this call are staged and leave merged (DmvBounce::begin_group): the nine point / residual tables and the two copies of idepth are one copy, ...
+  struct GroupScope { DmvBounce& bn; ~GroupScope() { bn.grouping = false; bn.group.clear(); } } groupScope{b->bounce};   // an error return drops what was only staged
+  b->bounce.begin_group();
   HIPCHK(b->bounce.h2d(d_host, host, sizeof(int) * N, s));
   HIPCHK(b->bounce.h2d(d_res_begin, b->h_res_begin.data(), sizeof(int) * (N + 1), s));
   HIPCHK(b->bounce.h2d(d_point, res_point, sizeof(int) * R, s));
@@ -970,13 +973,15 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
   if (!scd_on_device) {
     HIPCHK(b->bounce.h2d(b->d_scd_begin, scd_begin.data(), sizeof(int) * (F2 * F + 1), s));
     HIPCHK(b->bounce.h2d(b->d_scd_members, scd_members.data(), sizeof(int) * 3 * npairs, s));
+    HIPCHK(b->bounce.end_group(s));
   } else {
     // behind the uploads of host / point / target on the same stream: residual table, counts, scan, members
     int *d_ridx, *d_cnt, *d_first, *d_last;
     if (dalloc(b, &d_ridx, (size_t)N * F) || dalloc(b, &d_cnt, (size_t)F2 * F) || dalloc(b, &d_first, F) || dalloc(b, &d_last, F)) return -1;
-    HIPCHK(hipMemsetAsync(d_ridx, 0xff, sizeof(int) * (size_t)N * F, s));
     HIPCHK(b->bounce.h2d(d_first, pt_first.data(), sizeof(int) * F, s));
     HIPCHK(b->bounce.h2d(d_last, pt_last.data(), sizeof(int) * F, s));
+    HIPCHK(b->bounce.end_group(s));   // the kernels below read what was staged so far
+    HIPCHK(hipMemsetAsync(d_ridx, 0xff, sizeof(int) * (size_t)N * F, s));
     hipLaunchKernelGGL(k_ba_scd_ridx, dim3((R + 255) / 256), dim3(256), 0, s, R, F, (const int*)d_point, (const int*)d_target, d_ridx);
     hipLaunchKernelGGL(k_ba_scd_lists, dim3((F2 + 3) / 4, F), dim3(256), 0, s, F, (const int*)d_first, (const int*)d_last, (const int*)d_host, (const int*)d_ridx, 0, d_cnt, (const int*)nullptr, (int*)nullptr);
     hipLaunchKernelGGL(k_ba_scd_scan, dim3(1), dim3(1024), 0, s, F2 * F, (const int*)d_cnt, b->d_scd_begin);
@@ -984,6 +989,7 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
     HIPCHK(hipGetLastError());
   }
   SG_PH(3);
+  b->bounce.begin_group();   // ... the slot table and the adjoint tables another
   StitchBufs& SB = b->SB;
   if (dalloc(b, &SB.topHH, (size_t)F * 64) || dalloc(b, &SB.topTT, (size_t)F2 * 64) || dalloc(b, &SB.topHT, (size_t)F2 * 64) || dalloc(b, &SB.topHC, (size_t)F * 32) ||
       dalloc(b, &SB.topTC, (size_t)F2 * 32) || dalloc(b, &SB.topBH, (size_t)F * 8) || dalloc(b, &SB.topBT, (size_t)F2 * 8) || dalloc(b, &SB.topCC, (size_t)F * 20) ||
@@ -1029,6 +1035,7 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
   }
   SG_PH(4);
   if (int r = uploadAdjoints(b)) return r;
+  HIPCHK(b->bounce.end_group(s));
   // everything above is staged in pinned memory and enqueued on the handle's stream, and so is whatever uses it: dmvio_hip_ba_set_graph_from does not wait (the 0.1 ms the
   // uploads take overlap the caller's next calls — frame states, prior, the first host-side steps of optimize)
   HIPCHK(hipGetLastError());

@@ -52,10 +52,37 @@ struct DmvBounce {
   }
   hipError_t h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
+    if (grouping && used + ((bytes + 255) & ~(size_t)255) > cap) { hipError_t e = flush_group(s); if (e != hipSuccess) return e; }   // reserve() is about to recycle the staging area
     size_t off; hipError_t e = reserve(bytes, s, &off); if (e != hipSuccess) return e;
     memcpy(h + off, h_src, bytes);
+    if (grouping) { group.push_back({(char*)d_dst, off, bytes}); return hipSuccess; }
     return hipMemcpyAsync(d_dst, h + off, bytes, hipMemcpyHostToDevice, s);
   }
+  // Uploads of one call whose destinations lie back to back on the device (arena allocations: 256-byte granules, like the staging area's) leave as ONE copy: between
+  // begin_group() and end_group() h2d() only stages; end_group() merges pieces that follow each other both in the staging area and on the device at the same padded
+  // distance (the padding it copies along is the unused tail of the previous allocation) and enqueues what is left.  Nothing that consumes the data may be enqueued
+  // before end_group().
+  struct Piece { char* dst; size_t off, bytes; };
+  std::vector<Piece> group;
+  bool grouping = false;
+  void begin_group() { grouping = true; group.clear(); }
+  hipError_t flush_group(hipStream_t s) {
+    size_t i = 0;
+    while (i < group.size()) {
+      size_t j = i;
+      while (j + 1 < group.size()) {
+        const size_t step = (group[j].bytes + 255) & ~(size_t)255;
+        if (group[j + 1].off != group[j].off + step || group[j + 1].dst != group[j].dst + step) break;
+        j++;
+      }
+      hipError_t e = hipMemcpyAsync(group[i].dst, h + group[i].off, group[j].off + group[j].bytes - group[i].off, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) { group.clear(); return e; }
+      i = j + 1;
+    }
+    group.clear();
+    return hipSuccess;
+  }
+  hipError_t end_group(hipStream_t s) { grouping = false; return flush_group(s); }
   hipError_t d2h(void* h_dst, const void* d_src, size_t bytes, hipStream_t s) {
     if (!bytes) return hipSuccess;
     size_t off; hipError_t e = reserve(bytes, s, &off); if (e != hipSuccess) return e;
@@ -70,7 +97,7 @@ struct DmvBounce {
     outs.clear(); used = 0;
     return e;
   }
-  void release() { if (h) hipHostFree(h); h = nullptr; cap = used = 0; outs.clear(); }
+  void release() { if (h) hipHostFree(h); h = nullptr; cap = used = 0; outs.clear(); group.clear(); grouping = false; }
 };
 
 struct dmvio_hip_ctx {
