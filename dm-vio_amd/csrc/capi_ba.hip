@@ -1267,6 +1267,14 @@ int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* b, const float* th) {
   b->th_dirty = true;
   return 0;
 }
+// IMUIntegration::newFrameEnergyTH (src/IMU/IMUIntegration.cpp:365-373, called from FullSystem::setNewFrameEnergyTH, FullSystemOptimize.cpp:136-140, when setting_useIMU):
+// IMUSettings::maxFrameEnergyThreshold caps the newest keyframe's threshold; <= 0 = no cap (the reference's default)
+int dmvio_hip_ba_set_frame_energy_th_cap(dmvio_hip_ba* b, float maxFrameEnergyThreshold) {
+  if (!b) return failmsg("ba_set_frame_energy_th_cap: null handle");
+  BA_LOCK(b);
+  b->th_cap = maxFrameEnergyThreshold;
+  return 0;
+}
 int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* b, const double value[4], const double value_zero[4]) {
   if (!b || !value || !value_zero) return failmsg("ba_set_calib_values: null argument");
   BA_LOCK(b);

@@ -263,6 +263,9 @@ int dmvio_hip_ba_set_frame_zero(dmvio_hip_ba* ba, int frame, const double state_
  * what an adapter that takes a window over from a running FullSystem uses (tests/dropin). */
 int dmvio_hip_ba_set_frame_states(dmvio_hip_ba* ba, const double* state_zero10, const double* state10);
 int dmvio_hip_ba_set_frame_energy_th(dmvio_hip_ba* ba, const float* th);
+/* IMUIntegration::newFrameEnergyTH (src/IMU/IMUIntegration.cpp:365-373; FullSystemOptimize.cpp:136-140, setting_useIMU only): IMUSettings::maxFrameEnergyThreshold caps the
+ * threshold setNewFrameEnergyTH selects for the newest keyframe.  <= 0 (the default, and the reference's): no cap. */
+int dmvio_hip_ba_set_frame_energy_th_cap(dmvio_hip_ba* ba, float maxFrameEnergyThreshold);
 int dmvio_hip_ba_set_calib_values(dmvio_hip_ba* ba, const double value[4], const double value_zero[4]);
 /* Point marginalisation: the relinearisation branch of FullSystem::flagPointsForRemoval (FullSystem.cpp:829-859: resetOOB, linearize,
  * applyRes, EFResidual::fixLinearizationF EnergyFunctionalStructs.cpp:76-106) for the points with candidates[i] != 0, the

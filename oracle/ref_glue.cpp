@@ -1192,8 +1192,80 @@ struct RefSystem
 	std::vector<RefEvent> events;
 	bool record = true;
 	bool realtime = false;   // FullSystem(linearizeOperation = false): tracking on the caller's thread, mapping on the reference's own mapping thread
+	struct VioStandIn* vio = nullptr;   // the reference's DEFAULT (VIO) configuration live: see VioStandIn below
 };
 static RefSystem* g_sys = nullptr;
+
+// ---- LIVE stand-in for the IMU / GTSAM side of the reference's default configuration (setting_useIMU = setting_useGTSAMIntegration = true, FullSystem.cpp:80), behind the
+// hooks of oracle/ref_shim/IMU/IMUIntegration.hpp.  GTSAM 4.2a6 and the IMU code are absent (out of scope); what a live run of FullSystem needs from them is
+// (i) the keyframe bookkeeping (in the stub itself, restated from src/IMU/IMUIntegration.cpp), (ii) a pose hint per frame (addIMUData), (iii) a coarse "factor graph" that turns
+// the tracker's (H, b) into the next pose estimate (computeCoarseUpdate / acceptCoarseUpdate / addVisualToCoarseGraph, CoarseTracker.cpp:612-637, 708, 765) and (iv) a BA "factor
+// graph" that solves the photometric system together with its own factors and reports their energy (computeBAUpdate, getBAEnergy, updateBAValues, acceptBAUpdate, canBreak,
+// updateDynamicWeight, postOptimization: EnergyFunctional.cpp:335-341, 958-969, FullSystemOptimize.cpp:491-503, 523, 553-572, 594, 641).  The stand-in's factors:
+//   coarse:  a motion prior  w_c/2 |log(T pred^-1)|^2  around the constant-velocity prediction (the role the preintegrated IMU factor plays), w_c = coarseWeight x the mean
+//            diagonal of the visual pose block, added to (H, b) and solved exactly like BAGTSAMIntegration / the visual branch do (damp by 1 + lambda, LDL^T, extrapolate, exp);
+//   BA:      the marginalisation prior of the frames marginalised so far — in GTSAM mode EnergyFunctional hands every HMForGTSAM / bMForGTSAM over to the graph
+//            (addMarginalizedPointsBA, EnergyFunctional.cpp:548) and keeps no use for HM itself; the graph's share is HM - HMForGTSAM, bM - bMForGTSAM, which the reference still
+//            maintains (:568-569 "redundant visual only marginalization") — plus an independent quadratic factor  w_b |s - s_0|^2  that ties every keyframe's pose state to
+//            its value at the start of this optimisation (what the IMU factors between consecutive keyframes do qualitatively); combined with the photometric system as
+//            BAGTSAMIntegration::computeBAUpdate does (BAGTSAMIntegration.cpp:160-186: add, damp the extra Hessian by 1 + lambda, precondition by (diag + 10)^-1/2, LDL^T).
+// The SAME closures serve the all-CPU run (the reference's members call the facade) and the HIP-backed run (the adapter's callbacks call the same facade members), so the two
+// runs differ only in who evaluated the photometric sums.  Everything is read from the objects the real classes read: EFFrame::data (FrameHessian states), CalibHessian,
+// FrameShell poses.  Test infrastructure.
+struct VioStandIn
+{
+	FullSystem* fs = nullptr;
+	double coarseWeight = 0.02, baWeight = 1e3;
+	SE3 pred, cur, pending;
+	std::map<int, VecX> s0;          // FrameShell::id -> state.head<8>() at the first updateBAValues of this optimisation
+	VecC c0; bool haveS0 = false;
+	VecX curS, nxtS, deltaCur, deltaNxt;   // stacked [calib | 8 per keyframe] values / value - zero, EFFrame::idx order
+	std::vector<int> ids;
+	bool canBreakFlag = false;
+	long n[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // addIMUData, computeCoarseUpdate, acceptCoarseUpdate, addVisualToCoarseGraph, updateBAValues, computeBAUpdate, getBAEnergy, acceptBAUpdate, updateDynamicWeight, canBreak, postOptimization, addMarginalizedPointsBA
+	double sumIncNorm = 0, sumXmax = 0, lastEnergy = 0;
+
+	void readValues(std::vector<EFFrame*>& frames)
+	{
+		const int nn = CPARS + 8 * (int)frames.size();
+		curS = VecX::Zero(nn); deltaCur = VecX::Zero(nn); ids.assign(frames.size(), -1);
+		for (int i = 0; i < CPARS; i++) { curS[i] = fs->Hcalib.value[i]; deltaCur[i] = fs->Hcalib.value_minus_value_zero[i]; }
+		for (EFFrame* h : frames)
+		{
+			const Vec10 st = h->data->get_state(), d = h->data->get_state_minus_stateZero();
+			for (int i = 0; i < 8; i++) { curS[CPARS + 8 * h->idx + i] = st[i]; deltaCur[CPARS + 8 * h->idx + i] = d[i]; }
+			ids[h->idx] = h->data->shell->id;
+		}
+		if (!haveS0)
+		{
+			s0.clear();
+			for (EFFrame* h : frames) s0[h->data->shell->id] = curS.segment(CPARS + 8 * h->idx, 8);
+			c0 = fs->Hcalib.value; haveS0 = true;
+		}
+	}
+	// graph share of the marginalisation prior + the tie to s_0: Hessian, and gradient at the values `vals` (delta = vals - zero)
+	void factors(const VecX& vals, const VecX& delta, MatXX& Hg, VecX& bg, double& energy) const
+	{
+		const EnergyFunctional* ef = fs->ef;
+		const int nn = (int)vals.size();
+		Hg = MatXX::Zero(nn, nn); bg = VecX::Zero(nn);
+		VecX p = VecX::Zero(nn);
+		if (ef->HM.rows() == nn && ef->HMForGTSAM.rows() == nn) { Hg = ef->HM - ef->HMForGTSAM; p = ef->bM - ef->bMForGTSAM; }
+		bg = p + Hg * delta;
+		energy = delta.dot(2 * p + Hg * delta);
+		for (size_t f = 0; f < ids.size(); f++)
+		{
+			auto it = s0.find(ids[f]);
+			if (it == s0.end()) continue;
+			for (int i = 0; i < 6; i++)
+			{
+				const int k = CPARS + 8 * (int)f + i;
+				const double d = vals[k] - it->second[i];
+				Hg(k, k) += baWeight; bg[k] += baWeight * d; energy += baWeight * d * d;
+			}
+		}
+	}
+};
 
 static void pushPose(std::vector<double>& d, const SE3& T) { double p[7]; se3To7(T, p); d.insert(d.end(), p, p + 7); }
 
@@ -1328,18 +1400,140 @@ static void scopeHook(const char* name, int phase)
 	RefSystem* S = g_sys;
 	if (!S || !S->record) return;
 	if (!strcmp(name, "makeKeyframeChangeTrackingRef") && phase > 0) snapshotSetRef(S);
-	else if (!strcmp(name, "FullSystem::trackNewCoarseNoIMU")) snapshotTrack(S, phase > 0);
+	else if (!strcmp(name, "FullSystem::trackNewCoarseNoIMU") || !strcmp(name, "FullSystem::trackNewCoarse")) snapshotTrack(S, phase > 0);   // the second label: with an IMU pose hint (FullSystem.cpp:302)
 	else if (!strcmp(name, "FullSystemOptimize") && S->fs->frameHessians.size() >= 2) snapshotOptimize(S, phase > 0);
 }
 
 // linearizeOperation of the systems created from now on (dmvio_dataset: true unless a playback speed is given; false = the two-thread real-time pipeline)
 static bool g_linearizeOperation = true;
 void ref_set_linearize_operation(int on) { g_linearizeOperation = on != 0; }
-// settings as dmvio_dataset's preset=0 leaves them (util/MainSettings.cpp:206-231) unless overridden; useimu=0
+// The systems created from now on run the reference's DEFAULT configuration (useimu=1: setting_useIMU, and with it setting_useGTSAMIntegration, FullSystem.cpp:80) against the
+// live stand-in above: initAfterKeyframes = keyframe optimisations after which the (absent) IMU initialiser counts as finished and the coarse tracker switches to its
+// computeCoarseUpdate branch; on = 0 back to useimu=0
+static int g_vioLive = 0, g_vioInitAfter = 3; static double g_vioCoarseWeight = 0.02, g_vioBAWeight = 1e3;
+void ref_set_live_vio(int on, int initAfterKeyframes, double coarseWeight, double baWeight)
+{
+	g_vioLive = on; g_vioInitAfter = initAfterKeyframes; g_vioCoarseWeight = coarseWeight; g_vioBAWeight = baWeight;
+}
+static dmvio::IMUData g_noImuData;
+static void installVioStandIn(RefSystem* S)
+{
+	VioStandIn* V = new VioStandIn();
+	S->vio = V;
+	FullSystem* fs = S->fs;
+	V->fs = fs; V->coarseWeight = g_vioCoarseWeight; V->baWeight = g_vioBAWeight;
+	dmvio::IMUIntegration& imu = fs->imuIntegration;
+	imu.initAfterKeyframes = g_vioInitAfter;
+	// (ii) the pose hint: constant motion over the last two tracked frames, relative to the CURRENT tracking reference — the first entry of the list the visual-only
+	// trackNewCoarse walks (FullSystem.cpp:346-364); it is also where the coarse graph's estimate of the new frame starts
+	imu.addIMUDataHook = [V, fs](int, double, bool, int) -> SE3
+	{
+		V->n[0]++;
+		SE3 hint;
+		const size_t nh = fs->allFrameHistory.size();   // the new frame's shell is in already (FullSystem.cpp:905)
+		if (nh >= 3)
+		{
+			FrameShell* slast = fs->allFrameHistory[nh - 2]; FrameShell* sprelast = fs->allFrameHistory[nh - 3];
+			FrameHessian* lastF = fs->coarseTracker->lastRef;
+			if (slast->poseValid && sprelast->poseValid && lastF->shell->poseValid)
+			{
+				boost::unique_lock<boost::mutex> crlock(fs->shellPoseMutex);
+				const SE3 fh_2_slast = sprelast->camToWorld.inverse() * slast->camToWorld;
+				const SE3 lastF_2_slast = slast->camToWorld.inverse() * lastF->shell->camToWorld;
+				hint = fh_2_slast.inverse() * lastF_2_slast;
+			}
+		}
+		V->pred = V->cur = V->pending = hint;
+		return hint;
+	};
+	imu.computeCoarseUpdateHook = [V](const Mat88& H, const Vec8& b, float extrapFac, float lambda, double& incA, double& incB, double& incNorm) -> SE3
+	{
+		V->n[1]++;
+		Mat88 Hl = H; Vec8 bl = b;
+		double tr = 0; for (int i = 0; i < 6; i++) tr += H(i, i);
+		const double w = V->coarseWeight * tr / 6;
+		const Vec6 d = (V->cur * V->pred.inverse()).log();
+		for (int i = 0; i < 6; i++) { Hl(i, i) += w; bl[i] += w * d[i]; }
+		for (int i = 0; i < 8; i++) Hl(i, i) *= (1 + lambda);
+		Vec8 inc = Hl.ldlt().solve(-bl);
+		inc *= extrapFac;
+		Vec8 incScaled = inc;
+		incScaled.segment<3>(0) *= SCALE_XI_ROT;
+		incScaled.segment<3>(3) *= SCALE_XI_TRANS;
+		incScaled.segment<1>(6) *= SCALE_A;
+		incScaled.segment<1>(7) *= SCALE_B;
+		if (!std::isfinite(incScaled.sum())) { incScaled.setZero(); inc.setZero(); }
+		incA = inc[6]; incB = inc[7]; incNorm = inc.norm();
+		V->sumIncNorm += incNorm;
+		V->pending = SE3::exp((Vec6)(incScaled.head<6>())) * V->cur;
+		return V->pending;
+	};
+	imu.acceptCoarseUpdateHook = [V]() { V->n[2]++; V->cur = V->pending; };
+	imu.addVisualToCoarseGraphHook = [V](const Mat88&, const Vec8&, bool) { V->n[3]++; };
+	dmvio::BAGTSAMIntegration* ba = fs->baIntegration;
+	ba->updateBAValuesHook = [V](std::vector<EFFrame*>& frames) { V->n[4]++; V->readValues(frames); };
+	ba->computeBAUpdateFramesHook = [V](const MatXX& H, const VecX& b, double lambda, std::vector<EFFrame*>& frames, const MatXX&) -> VecX
+	{
+		V->n[5]++;
+		V->readValues(frames);   // computeBAUpdate starts with updateBAValues(frames) (BAGTSAMIntegration.cpp:130)
+		const int nn = (int)b.size();
+		MatXX HFull; VecX bFull; double e;
+		V->factors(V->curS, V->deltaCur, HFull, bFull, e);
+		for (int i = 0; i < nn; i++) HFull(i, i) *= (1 + lambda);
+		HFull += H; bFull += b;
+		VecX SVecI = (HFull.diagonal() + VecX::Constant(HFull.cols(), 10)).cwiseSqrt().cwiseInverse();
+		MatXX H_scaled = SVecI.asDiagonal() * HFull * SVecI.asDiagonal();
+		VecX inc = SVecI.asDiagonal() * H_scaled.ldlt().solve(SVecI.asDiagonal() * bFull);
+		V->nxtS = V->curS - inc; V->deltaNxt = V->deltaCur - inc;
+		double xmax = 0;
+		for (int i = CPARS; i < nn; i++) xmax = std::max(xmax, std::fabs(inc[i]));
+		V->sumXmax += xmax;
+		V->canBreakFlag = xmax < 1e-7;
+		return inc;
+	};
+	ba->getBAEnergyHook = [V](bool useNew)
+	{
+		V->n[6]++;
+		MatXX Hg; VecX bg; double e = 0;
+		if (V->curS.size() == 0) return 0.0;
+		if (useNew && V->nxtS.size() == V->curS.size()) V->factors(V->nxtS, V->deltaNxt, Hg, bg, e); else V->factors(V->curS, V->deltaCur, Hg, bg, e);
+		V->lastEnergy = e;
+		return e;
+	};
+	ba->acceptBAUpdateHook = [V](double) { V->n[7]++; V->curS = V->nxtS; V->deltaCur = V->deltaNxt; };
+	ba->updateDynamicWeightHook = [V](double, double, bool) { V->n[8]++; return 1.0; };
+	ba->canBreakHook = [V]() { V->n[9]++; return V->canBreakFlag; };
+	ba->postOptimizationHook = [V](std::vector<EFFrame*>&) { V->n[10]++; V->haveS0 = false; };
+	ba->addMarginalizedPointsBAHook = [V](const MatXX&, const VecX&, std::vector<EFFrame*>&) { V->n[11]++; };
+}
+// the stand-in's counters (12: see VioStandIn::n) + [sum of coarse |inc|, sum of max |x| of the BA updates, last factor energy, coarseInitialized]: what a test reads to know
+// that the VIO branches really ran, and a fingerprint of what went through them
+int ref_system_vio_counters(void* p, double* out16)
+{
+	RefSystem* S = (RefSystem*)p;
+	if (!S->vio) return 0;
+	for (int i = 0; i < 12; i++) out16[i] = (double)S->vio->n[i];
+	out16[12] = S->vio->sumIncNorm; out16[13] = S->vio->sumXmax; out16[14] = S->vio->lastEnergy; out16[15] = S->fs->imuIntegration.isCoarseInitialized() ? 1 : 0;
+	return 16;
+}
+// the stand-in's state, saved / restored around a SHADOW call (tests/dropin: the device runs a call beside the reference's own from the same inputs, and both go through the
+// same stateful facade)
+void* ref_system_vio_save(void* p) { RefSystem* S = (RefSystem*)p; return S->vio ? new VioStandIn(*S->vio) : nullptr; }
+void ref_system_vio_restore(void* p, void* saved, int keepCounters)
+{
+	RefSystem* S = (RefSystem*)p; VioStandIn* W = (VioStandIn*)saved;
+	if (!S->vio || !W) return;
+	long nn[12]; double a = S->vio->sumIncNorm, b = S->vio->sumXmax;
+	memcpy(nn, S->vio->n, sizeof(nn));
+	*S->vio = *W;
+	if (keepCounters) { memcpy(S->vio->n, nn, sizeof(nn)); S->vio->sumIncNorm = a; S->vio->sumXmax = b; }
+	delete W;
+}
+// settings as dmvio_dataset's preset=0 leaves them (util/MainSettings.cpp:206-231) unless overridden; useimu=0 unless ref_set_live_vio(1, ...)
 void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensity, int maxFrames, int maxOptIterations, int minOptIterations)
 {
 	setCalib(w, h, K4);
-	setting_useIMU = false; setting_useGTSAMIntegration = false;
+	setting_useIMU = g_vioLive != 0; setting_useGTSAMIntegration = g_vioLive != 0;
 	setting_logStuff = false;
 	disableAllDisplay = true;   // nogui=1 (util/MainSettings.cpp:83), as BASELINE config 1 runs dmvio_dataset: FullSystem::debugPlot returns at once
 	multiThreading = false;
@@ -1360,6 +1554,7 @@ void* ref_system_create(int w, int h, const float K4[4], float desiredPointDensi
 	S->fs = new FullSystem(g_linearizeOperation, g_imuCalib, g_imuSettings);
 	cap.finish();
 	S->fs->coarseTrackingLog = 0;
+	if (g_vioLive) installVioStandIn(S);
 	g_sys = S;
 	ref_scope_hook = scopeHook;
 	return S;
@@ -1372,6 +1567,7 @@ void ref_system_destroy(void* p)
 	std::vector<FrameHessian*> frames = fs->frameHessians;
 	fs->frameHessians.clear();
 	StdoutCapture cap;
+	delete S->vio; S->vio = nullptr;
 	delete fs;
 	for (FrameHessian* fh : frames)
 	{
@@ -1438,11 +1634,11 @@ int ref_system_add_frame(void* p, const float* img, float exposure, double times
 	memcpy(im->image, img, sizeof(float) * S->w * S->h);
 	im->exposure_time = exposure;
 	std::string out;
-	if (S->realtime) S->fs->addActiveFrame(im, id, nullptr, nullptr);   // the mapping thread prints too: stdout is left alone
+	if (S->realtime) S->fs->addActiveFrame(im, id, &g_noImuData, nullptr);   // the mapping thread prints too: stdout is left alone
 	else
 	{
 		StdoutCapture cap;
-		S->fs->addActiveFrame(im, id, nullptr, nullptr);
+		S->fs->addActiveFrame(im, id, &g_noImuData, nullptr);
 		out = cap.finish();
 	}
 	delete im;

@@ -53,11 +53,15 @@ public:
 	void postOptimization(std::vector<dso::EFFrame*>& f) { if (postOptimizationHook) postOptimizationHook(f); }
 	void updateBAValues(std::vector<dso::EFFrame*>& f) { if (updateBAValuesHook) updateBAValuesHook(f); }
 	double getBAEnergy(bool useNew) { return getBAEnergyHook ? getBAEnergyHook(useNew) : 0.0; }
-	void addMarginalizedPointsBA(const dso::MatXX&, const dso::VecX&, std::vector<dso::EFFrame*>&) {}
+	// graph maintenance around the optimisation (FullSystem.cpp:1402-1406, EnergyFunctional.cpp:538-566): observable, no-ops without a hook
+	std::function<void(const dso::MatXX&, const dso::VecX&, std::vector<dso::EFFrame*>&)> addMarginalizedPointsBAHook;
+	std::function<void(dso::EFFrame*)> marginalizeBAFrameHook;
+	std::function<void(int, std::vector<dso::EFFrame*>&)> addKeyframeToBAHook;
+	void addMarginalizedPointsBA(const dso::MatXX& H, const dso::VecX& b, std::vector<dso::EFFrame*>& f) { if (addMarginalizedPointsBAHook) addMarginalizedPointsBAHook(H, b, f); }
 	void addPriorBA(dso::EFFrame*, const dso::MatXX&, const dso::VecX&) {}
 	template<typename A, typename B> void addPriorBA(dso::EFFrame*, const A&, const B&) {}
-	void marginalizeBAFrame(dso::EFFrame*) {}
-	void addKeyframeToBA(int, const Sophus::SE3d&, std::vector<dso::EFFrame*>&) {}
+	void marginalizeBAFrame(dso::EFFrame* f) { if (marginalizeBAFrameHook) marginalizeBAFrameHook(f); }
+	void addKeyframeToBA(int id, const Sophus::SE3d&, std::vector<dso::EFFrame*>& f) { if (addKeyframeToBAHook) addKeyframeToBAHook(id, f); }
 	void updateBAOrdering(std::vector<dso::EFFrame*>&) {}
 	void addFirstBAFrame(int) {}
 	dso::VecX computeBAUpdate(const dso::MatXX& H, const dso::VecX& b, double lambda, std::vector<dso::EFFrame*>& frames, const dso::MatXX& HNoLambda)
@@ -92,22 +96,56 @@ public:
 	void newFrameEnergyTH(float& th) { if (energyThCap > 0 && th > energyThCap) th = energyThCap; }
 	Sophus::SE3 TS_cam_imu;
 
-	// the rest of the facade FullSystem.cpp talks to: no IMU data ever arrives in the visual-only runs the tests make
+	// the rest of the facade FullSystem.cpp talks to.  The keyframe bookkeeping is the real class's (src/IMU/IMUIntegration.cpp:107-125 initCoarseGraph, :228-247
+	// prepareKeyframe, :282-308 postOptimization / finishKeyframeOptimization, :320-341): a LIVE run of FullSystem with setting_useIMU walks through it
+	// (FullSystem.cpp:986-1016, 1130-1200, 1442-1455).  What stands in for the IMU itself: `initAfterKeyframes` >= 0 declares the (absent) IMU initialiser finished after that
+	// many keyframe optimisations — from then on finishKeyframeOptimization hands "information BA -> coarse" over, the next initCoarseGraph sets coarseInitialized, and
+	// trackNewestCoarse takes its computeCoarseUpdate branch (CoarseTracker.cpp:612); addIMUData's pose hint and finishCoarseTracking are hooks.
+	int initAfterKeyframes = -1;          // < 0: never (the visual-only runs: no IMU data ever arrives)
+	int keyframesOptimized = 0;
+	bool baInitialized = false, initializedBeforePostOptimization = false, haveInformationBAToCoarse = false;
+	int preparedKeyframe = -1;
+	bool preparedKFCreated = false;
+	std::function<Sophus::SE3(int, double, bool, int)> addIMUDataHook;
+	std::function<void(const dso::FrameShell&, bool)> finishCoarseTrackingHook;
+	std::function<void(int)> initCoarseGraphHook;
 	const std::unique_ptr<BAGTSAMIntegration>& getBAGTSAMIntegration() const { return ba_; }
 	TransformDSOToIMU& getTransformDSOToIMU() { return transform_; }
 	double getCoarseScale() { return 1.0; }
 	void addIMUDataToBA(const IMUData&) {}
 	void setGTData(GTData*, int) {}
-	int getPreparedKeyframe() const { return -1; }
-	bool isPreparedKFCreated() const { return false; }
-	Sophus::SE3d initCoarseGraph() { return Sophus::SE3d(); }
-	Sophus::SE3 addIMUData(const IMUData&, int, double, bool, int, bool = false) { return Sophus::SE3(); }
-	void finishCoarseTracking(const dso::FrameShell&, bool) {}
-	void prepareKeyframe(int) {}
-	void keyframeCreated(int) {}
-	void skipPreparedKeyframe() {}
-	void postOptimization(int) {}
-	bool finishKeyframeOptimization(int) { return false; }
+	int getPreparedKeyframe() const { return preparedKeyframe; }
+	bool isPreparedKFCreated() const { return preparedKFCreated; }
+	Sophus::SE3d initCoarseGraph()
+	{
+		const int keyframeId = preparedKeyframe;
+		preparedKeyframe = -1;
+		if (!haveInformationBAToCoarse) return Sophus::SE3d();
+		haveInformationBAToCoarse = false;
+		coarseInitialized = true;
+		if (initCoarseGraphHook) initCoarseGraphHook(keyframeId);
+		return Sophus::SE3d();
+	}
+	Sophus::SE3 addIMUData(const IMUData&, int frameId, double timestamp, bool trackingRefChanged, int lastFrameId, bool = false)
+	{
+		return addIMUDataHook ? addIMUDataHook(frameId, timestamp, trackingRefChanged, lastFrameId) : Sophus::SE3();
+	}
+	void finishCoarseTracking(const dso::FrameShell& shell, bool willBecomeKeyframe) { if (finishCoarseTrackingHook) finishCoarseTrackingHook(shell, willBecomeKeyframe); }
+	void prepareKeyframe(int frameId) { preparedKeyframe = frameId; preparedKFCreated = false; }
+	void keyframeCreated(int) { preparedKFCreated = true; }
+	void skipPreparedKeyframe() { preparedKeyframe = -1; }
+	void postOptimization(int)
+	{
+		initializedBeforePostOptimization = baInitialized;
+		keyframesOptimized++;
+		if (initAfterKeyframes >= 0 && keyframesOptimized >= initAfterKeyframes) baInitialized = true;
+	}
+	bool finishKeyframeOptimization(int)
+	{
+		if (!initializedBeforePostOptimization) return false;
+		haveInformationBAToCoarse = true;
+		return true;
+	}
 	void finishKeyframeOperations(int) {}
 	void resetBAPreintegration() {}
 private:

@@ -110,7 +110,7 @@ struct Backend
 	int resident = 1;
 	int real_marg = 1;                  // EnergyFunctional::marginalizePointsF: 1 = its accumulation on the device from the window optimize left there (resident mode, outside shadow mode), 0 = the reference's own
 	bool window_current = false;        // the BA handle holds the window of THIS keyframe's optimize, untouched since
-	long n_real_marg = 0, n_real_marg_pts = 0;
+	long n_real_marg = 0, n_real_marg_pts = 0, n_real_marg_disagree = 0;
 	long graph_ops = 0, graph_resyncs = 0, graph_verified = 0, graph_mismatch = 0;
 	double wb_split[5] = {0, 0, 0, 0, 0};   // write-back of optimize: calibration + keyframe states + adjoints / precalc, the downloads, the per-point pass, the removals, the tail
 	double up_split[6] = {0, 0, 0, 0, 0, 0};   // uploadWindow: frame tables, graph walk (index / flatten / verify), set_window, set_graph(_from), frame states + thresholds + calibration, marginalisation prior
@@ -138,6 +138,14 @@ struct Backend
 	} sh;
 	dmvio_hip_initializer* ini = nullptr;
 	void* oracle_lib = nullptr;
+	// the reference's DEFAULT configuration (setting_useIMU / setting_useGTSAMIntegration): calls that went through dmvio_hip_tracker_track_vio with computeCoarseUpdate
+	// behind it, through it with the visual-only step (IMU not yet coarse-initialised), through dmvio_hip_ba_optimize_vio; hook calls made from the callbacks
+	long n_vio_track = 0, n_vio_track_visual = 0, n_vio_opt = 0, n_vio_hook_calls = 0;
+	// shadow mode and a stateful IMU / GTSAM facade: both sides of a shadowed call go through the same facade object, whose state is saved before the device's call and put
+	// back before the reference's own (the test's stand-in registers how: dropin_set_vio_state_hooks)
+	void* vio_sys = nullptr;
+	void* (*vio_save)(void*) = nullptr;
+	void (*vio_restore)(void*, void*, int) = nullptr;
 	Stats stats;
 	char error[512] = "";
 	long failures = 0;
@@ -254,6 +262,113 @@ dmvio_hip_tracker* trackerFor(const CoarseTracker* ct)
 	g.trackerOf[ct] = t;
 	return t;
 }
+
+// ---- the reference's DEFAULT branch, tracking side: the three IMUIntegration members CoarseTracker::trackNewestCoarse calls (CoarseTracker.cpp:620, 709, 766) as the callbacks
+// of dmvio_hip_tracker_track_vio.  `user` is the CoarseTracker, whose imuIntegration reference is the FullSystem's own object — exactly what the replaced loop talks to.
+int coarseUpdateThunk(void* user, const double H[64], const double b[8], float extrapFac, float lambda, const double* /*pose7_cur*/, const double* /*aff_cur*/, double pose7_new[7],
+                      double* incA, double* incB, double* incNorm)
+{
+	CoarseTracker* t = (CoarseTracker*)user;
+	Mat88 Hm; Vec8 bv;
+	for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) Hm(r, c) = H[8 * r + c]; bv[r] = b[r]; }
+	g.n_vio_hook_calls++;
+	const SE3 refToNew_new = t->imuIntegration.computeCoarseUpdate(Hm, bv, extrapFac, lambda, *incA, *incB, *incNorm);   // note: H, not Hl — the damping happens inside (:618-620)
+	toPose7(refToNew_new, pose7_new);
+	return 0;
+}
+void coarseAcceptThunk(void* user) { g.n_vio_hook_calls++; ((CoarseTracker*)user)->imuIntegration.acceptCoarseUpdate(); }
+void coarseVisualThunk(void* user, const double H[64], const double b[8], int trackingGood)
+{
+	Mat88 Hm; Vec8 bv;
+	for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) Hm(r, c) = H[8 * r + c]; bv[r] = b[r]; }
+	g.n_vio_hook_calls++;
+	((CoarseTracker*)user)->imuIntegration.addVisualToCoarseGraph(Hm, bv, trackingGood != 0);
+}
+// what trackNewestCoarse does when setting_useIMU is set: the LM loop of dmvio_hip_tracker_track_vio with computeCoarseUpdate in the place of the LDL^T step once the IMU is
+// coarse-initialised (:612), acceptCoarseUpdate after every accepted step and addVisualToCoarseGraph at the end whether it is or not (:708, :765: both only test setting_useIMU)
+bool trackVio(CoarseTracker* t, dmvio_hip_tracker* trk, int slot, float exposure, double pose7[7], double aff[2], int coarsestLvl, const double minRes[5], double lastRes[5], double flow[3],
+              double H[64], double b[8], int* good)
+{
+	dmvio_hip_coarse_callbacks cb;
+	memset(&cb, 0, sizeof(cb));
+	cb.user = t;
+	const bool initialised = t->imuIntegration.isCoarseInitialized();
+	cb.update = initialised ? coarseUpdateThunk : nullptr;   // NULL: the library's visual-only step = the reference's else-branch (:639-682)
+	cb.accept = coarseAcceptThunk;
+	cb.visual = coarseVisualThunk;
+	int n_evals = 0;
+	if (initialised) g.n_vio_track++; else g.n_vio_track_visual++;
+	return HIP_OK(dmvio_hip_tracker_track_vio(trk, slot, exposure, pose7, aff, coarsestLvl, minRes, &cb, lastRes, flow, H, b, good, &n_evals));
+}
+
+// ---- the reference's DEFAULT branch, mapping side: the seven BAGTSAMIntegration members EnergyFunctional::solveSystemF / calcMEnergyF and FullSystem::optimize call
+// (EnergyFunctional.cpp:335-341, 958-969; FullSystemOptimize.cpp:491-503, 523, 534-538, 569-572, 594, 641) as the callbacks of dmvio_hip_ba_optimize_vio.  The real class reads the
+// keyframes through std::vector<EFFrame*> (EFFrame::data->get_state(), PRE_worldToCam, shell->id; BAGTSAMIntegration.cpp:97-120) and the calibration through CalibHessian: the
+// frame views of a callback are written into those objects first, so the hook sees what it would see inside the reference's own loop at the same point.
+void writeFrameViews(FullSystem* fs, int F, const dmvio_hip_ba_frame_view* fr, const double calib_value[4])
+{
+	VecC v; for (int i = 0; i < 4; i++) v[i] = calib_value[i];
+	fs->Hcalib.setValue(v);
+	for (int f = 0; f < F; f++)
+	{
+		Vec10 st; for (int i = 0; i < 10; i++) st[i] = fr[f].state10[i];
+		fs->frameHessians[fr[f].index]->setState(st);
+	}
+}
+int baComputeThunk(void* user, int n, const double* HPassed, const double* b, double lambda, const double* HNoLambda, int F, const dmvio_hip_ba_frame_view* frames, const double calib_value[4],
+                   double* x_out)
+{
+	FullSystem* fs = (FullSystem*)user;
+	writeFrameViews(fs, F, frames, calib_value);
+	MatXX H(n, n), HN(n, n); VecX bv(n);
+	for (int r = 0; r < n; r++) { bv[r] = b[r]; for (int c = 0; c < n; c++) { H(r, c) = HPassed[(size_t)r * n + c]; HN(r, c) = HNoLambda[(size_t)r * n + c]; } }
+	g.n_vio_hook_calls++;
+	const VecX x = fs->baIntegration->computeBAUpdate(H, bv, lambda, fs->ef->frames, HN);
+	if (x.size() != n) return -1;
+	for (int i = 0; i < n; i++) x_out[i] = x[i];
+	return 0;
+}
+void baAcceptThunk(void* user, double energy) { g.n_vio_hook_calls++; ((FullSystem*)user)->baIntegration->acceptBAUpdate(energy); }
+double baEnergyThunk(void* user, int useNewValues) { g.n_vio_hook_calls++; return ((FullSystem*)user)->baIntegration->getBAEnergy(useNewValues != 0); }
+void baValuesThunk(void* user, int F, const dmvio_hip_ba_frame_view* frames, const double calib_value[4])
+{
+	FullSystem* fs = (FullSystem*)user;
+	writeFrameViews(fs, F, frames, calib_value);
+	g.n_vio_hook_calls++;
+	fs->baIntegration->updateBAValues(fs->ef->frames);
+}
+double baWeightThunk(void* user, double energy, double rmse, int good) { g.n_vio_hook_calls++; return ((FullSystem*)user)->baIntegration->updateDynamicWeight(energy, rmse, good != 0); }
+int baBreakThunk(void* user) { g.n_vio_hook_calls++; return ((FullSystem*)user)->baIntegration->canBreak() ? 1 : 0; }
+void baPostThunk(void* user, int F, const dmvio_hip_ba_frame_view* frames, const double calib_value[4])
+{
+	FullSystem* fs = (FullSystem*)user;
+	writeFrameViews(fs, F, frames, calib_value);
+	g.n_vio_hook_calls++;
+	fs->baIntegration->postOptimization(fs->ef->frames);
+}
+// FullSystem::optimize's loop on its default branch
+bool optimizeVio(FullSystem* fs, dmvio_hip_ba* ba, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations)
+{
+	dmvio_hip_ba_callbacks cb;
+	memset(&cb, 0, sizeof(cb));
+	cb.user = fs;
+	cb.computeBAUpdate = baComputeThunk; cb.acceptBAUpdate = baAcceptThunk; cb.getBAEnergy = baEnergyThunk; cb.updateBAValues = baValuesThunk;
+	cb.updateDynamicWeight = baWeightThunk; cb.canBreak = baBreakThunk; cb.postOptimization = baPostThunk;
+	EnergyFunctional* ef = fs->ef;
+	const int n = CPARS + 8 * ef->nFrames;
+	std::vector<double> HMg((size_t)n * n, 0.0), bMg(n, 0.0);
+	const bool havePrior = ef->HMForGTSAM.rows() == n && ef->bMForGTSAM.size() == n;
+	if (havePrior) for (int r = 0; r < n; r++) { bMg[r] = ef->bMForGTSAM[r]; for (int c = 0; c < n; c++) HMg[(size_t)r * n + c] = ef->HMForGTSAM(r, c); }
+	dmvio_hip_ba_vio_options opt;
+	memset(&opt, 0, sizeof(opt));
+	opt.coarseTrackingWasGood = fs->frameHessians.back()->shell->trackingWasGood ? 1 : 0;
+	opt.updateDynamicWeightDuringOptimization = fs->imuIntegration.getImuSettings().updateDynamicWeightDuringOptimization ? 1 : 0;
+	opt.minOptIterations = setting_minOptIterations;
+	opt.resInA_at_entry = ef->resInA;
+	opt.HMForGTSAM = havePrior ? HMg.data() : nullptr; opt.bMForGTSAM = havePrior ? bMg.data() : nullptr;
+	g.n_vio_opt++;
+	return HIP_OK(dmvio_hip_ba_optimize_vio(ba, mnumOptIts, &cb, &opt, rmse, finalEnergy, iterations, nullptr));
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
@@ -273,6 +388,7 @@ int dropin_enable(int on, int device, int w, int h, int accumulators)
 		g.ba = nullptr; g.imm = nullptr; g.ini = nullptr; g.ctx = nullptr; g.init_mode = 0;
 	}
 	g.slotOf.clear(); g.fs = nullptr; g.on = false; g.stats = Stats(); g.failures = 0; g.error[0] = 0;
+	g.n_vio_track = g.n_vio_track_visual = g.n_vio_opt = g.n_vio_hook_calls = 0;
 	if (g.graph) { dmvio_hip_graph_destroy(g.graph); g.graph = nullptr; }
 	g.graph_ef = nullptr; g.graph_valid = false; g.graph_ops = g.graph_resyncs = g.graph_verified = g.graph_mismatch = 0;
 	if (!on) return 0;
@@ -344,6 +460,11 @@ void dropin_get_real_marginalization(long* out2) { out2[0] = g.n_real_marg; out2
 void dropin_get_upload_split(double* out6) { for (int k = 0; k < 6; k++) out6[k] = g.up_split[k]; }
 void dropin_get_resident(long* out4) { out4[0] = g.graph_ops; out4[1] = g.graph_resyncs; out4[2] = g.graph_verified; out4[3] = g.graph_mismatch; }
 int dropin_is_on() { return g.on ? 1 : 0; }
+// the default (VIO) configuration: how the state of a stateful IMU / GTSAM facade is saved and restored around a shadowed call (sys = the argument of both functions)
+void dropin_set_vio_state_hooks(void* sys, void* (*save)(void*), void (*restore)(void*, void*, int)) { g.vio_sys = sys; g.vio_save = save; g.vio_restore = restore; }
+// trackNewestCoarse calls served by dmvio_hip_tracker_track_vio with computeCoarseUpdate as the step / with the visual-only step (IMU not coarse-initialised yet), optimize
+// calls served by dmvio_hip_ba_optimize_vio, IMUIntegration / BAGTSAMIntegration members called from the library's callbacks
+void dropin_get_vio(long* out4) { out4[0] = g.n_vio_track; out4[1] = g.n_vio_track_visual; out4[2] = g.n_vio_opt; out4[3] = g.n_vio_hook_calls; }
 // the FullSystem whose frames the slots belong to (lets the adapter see which frames are still alive before the first optimize / traceNewCoarse call comes by)
 void dropin_attach(void* fullSystem) { g.fs = (FullSystem*)fullSystem; }
 // seconds[6], calls[6] in the order makeImages, setCoarseTrackingRef, trackNewestCoarse, traceNewCoarse, optimize, activatePointsMT_Reductor — counted in both modes
@@ -518,8 +639,8 @@ void CoarseTracker::setCoarseTrackingRef(std::vector<FrameHessian*> frameHessian
 	firstCoarseRMSE = -1;
 }
 
-// ---- CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:539-770), visual-only branch (the runs of the comparison have no IMU; the default VIO branch is
-// dmvio_hip_tracker_track_vio with the three IMUIntegration members as callbacks — INTEGRATION.md section 3)
+// ---- CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:539-770): the visual-only branch through dmvio_hip_tracker_track, the default branch (setting_useIMU) through
+// dmvio_hip_tracker_track_vio with the three IMUIntegration members as callbacks (trackVio above)
 bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort, IOWrap::Output3DWrapper* wrap)
 {
 	typedef bool (*Fn)(CoarseTracker*, FrameHessian*, SE3&, AffLight&, int, Vec5, IOWrap::Output3DWrapper*);
@@ -532,7 +653,15 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
 		toPose7(lastToNew_out, pose7);
 		for (int i = 0; i < 5; i++) minRes[i] = minResForAbort[i];
 		int good = 0;
-		const bool ok = HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good));
+		bool ok;
+		if (setting_useIMU)
+		{
+			// both sides talk to the same stateful facade: the device's call first, on a state that is put back for the reference's own
+			void* saved = g.vio_save ? g.vio_save(g.vio_sys) : nullptr;
+			ok = trackVio(this, trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good);
+			if (g.vio_restore) g.vio_restore(g.vio_sys, saved, 0);
+		}
+		else ok = HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good));
 		const bool ret = orig(this, newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
 		if (ok)
 		{
@@ -558,8 +687,11 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
 	toPose7(lastToNew_out, pose7);
 	for (int i = 0; i < 5; i++) minRes[i] = minResForAbort[i];
 	int good = 0;
-	if (!HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good)))
-		return false;   // a device error reads as "tracking failed" 
+	// setting_useIMU (the reference's default): the LM step belongs to IMUIntegration::computeCoarseUpdate once the IMU is coarse-initialised (:612-637), acceptCoarseUpdate and
+	// addVisualToCoarseGraph are told about accepted steps and the final system either way (:708, :765)
+	const bool ok = setting_useIMU ? trackVio(this, trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good)
+	                               : HIP_OK(dmvio_hip_tracker_track(trackerFor(this), slotFor(newFrameHessian), newFrameHessian->ab_exposure, pose7, aff, coarsestLvl, minRes, lastRes, flow, H, b, &good));
+	if (!ok) return false;   // a device error reads as "tracking failed" 
 	for (int i = 0; i < 5; i++) lastResiduals[i] = lastRes[i];
 	// an aborted level leaves the outputs untouched and the flow indicators of the levels it finished (:729-733); otherwise they are the finest level's
 	bool finished = true;
@@ -1019,7 +1151,7 @@ void EnergyFunctional::marginalizePointsF()
 {
 	typedef void (*Fn)(EnergyFunctional*);
 	static Fn orig = original<Fn>("_ZN3dso16EnergyFunctional18marginalizePointsFEv");
-	if (g.on && !g.shadow && g.fs && g.real_marg && g.window_current && graphFollows(this) && !setting_useGTSAMIntegration)
+	if (g.on && !g.shadow && g.fs && g.real_marg && g.window_current && graphFollows(this))
 	{
 		// ---- the real member: the window optimize left on the device IS the window the reference holds now (same states, FEJ points, residual states; points dropped since
 		// are simply no candidates).  The relinearisation of the flagged points (FullSystem.cpp:836-849), fixLinearizationF, addPoint<2> + the Schur side and the stitch run
@@ -1043,7 +1175,11 @@ void EnergyFunctional::marginalizePointsF()
 		std::vector<double> Hadd((size_t)n * n), badd(n);
 		std::vector<unsigned char> decision(cand.size(), 0);
 		int resInMdev = 0;
-		if (known && !allPointsToMarg.empty() && HIP_OK(dmvio_hip_ba_marginalize_points(g.ba, cand.data(), decision.data(), Hadd.data(), badd.data(), &resInMdev, 0)))
+		bool done = known && !allPointsToMarg.empty() && HIP_OK(dmvio_hip_ba_marginalize_points(g.ba, cand.data(), decision.data(), Hadd.data(), badd.data(), &resInMdev, 0));
+		// the device classifies every candidate itself (marginalise = 1 / drop = 2, from the idepth_hessian ITS optimize left) and leaves a point it would drop out of Hadd / badd:
+		// if the two sides ever disagree about a point, the reference's own member runs instead — nothing has been mutated yet
+		if (done) for (size_t i = 0; i < cand.size(); i++) if (cand[i] && decision[i] != 1) { done = false; g.n_real_marg_disagree++; break; }
+		if (done)
 		{
 			for (EFPoint* p : allPointsToMarg)
 			{
@@ -1137,7 +1273,6 @@ float FullSystem::optimize(int mnumOptIts)
 	if (!g.on) return orig(this, mnumOptIts);
 	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;
 	if (!g.shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("FullSystemOptimize"));
-	if (setting_useGTSAMIntegration) { fprintf(stderr, "[dropin] GTSAM runs: use dmvio_hip_ba_optimize_vio with the BAGTSAMIntegration members as hooks\n"); abort(); }
 	const int F = (int)frameHessians.size();
 	if (F < 2) return 0;
 	// ---- statistics and active residuals (:429-448).  With the window graph resident nothing below needs the list (the write-back goes point by point), and resetOOB's
@@ -1164,7 +1299,23 @@ float FullSystem::optimize(int mnumOptIts)
 	std::vector<float> th(F);
 	// ---- the Gauss-Newton loop + final fix-linearisation (:450-609)
 	float rmse = 0; double finalEnergy = 0; int iterations = 0;
-	ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));
+	if (setting_useGTSAMIntegration)
+	{
+		// the reference's default solver branch: every solve, the marginalisation / factor energies and the loop's break / accept notifications go through BAGTSAMIntegration
+		// (optimizeVio above).  The hooks write the iteration's keyframe states into the FrameHessians (as the reference's own loop would have); in shadow mode they are put
+		// back, with the facade's state, for the reference's own optimize that follows
+		std::vector<Vec10> st0; VecC c0 = Hcalib.value;
+		void* saved = nullptr;
+		if (g.shadow) { for (FrameHessian* fh : frameHessians) st0.push_back(fh->get_state()); saved = g.vio_save ? g.vio_save(g.vio_sys) : nullptr; }
+		ok = ok && optimizeVio(this, ba, mnumOptIts, &rmse, &finalEnergy, &iterations);
+		if (g.shadow)
+		{
+			for (size_t f = 0; f < st0.size(); f++) frameHessians[f]->setState(st0[f]);
+			Hcalib.setValue(c0);
+			if (g.vio_restore) g.vio_restore(g.vio_sys, saved, 0);
+		}
+	}
+	else ok = ok && HIP_OK(dmvio_hip_ba_optimize(ba, mnumOptIts, &rmse, &finalEnergy, &iterations, nullptr));
 	const auto tq2 = std::chrono::steady_clock::now();
 	if (!ok && g.shadow) return orig(this, mnumOptIts);
 	if (!ok) { isLost = true; return 0; }   // a failure inside optimize reads as isLost (:613-617)

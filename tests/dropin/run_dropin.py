@@ -54,6 +54,12 @@ def main():
                          "EnergyFunctional mutators keep it in step), 2 both, compared element for element")
     ap.add_argument("--real-marg", type=int, default=1, choices=[0, 1],
                     help="mode hip, resident window: EnergyFunctional::marginalizePointsF accumulates on the device from the window optimize left there (1) or stays the reference's own (0)")
+    ap.add_argument("--vio", action="store_true",
+                    help="the reference's DEFAULT configuration: setting_useIMU / setting_useGTSAMIntegration on, a live stand-in for the (absent) IMU / GTSAM side behind the "
+                         "facade's hooks (oracle/ref_glue.cpp: VioStandIn) — trackNewestCoarse takes its computeCoarseUpdate branch once the stand-in declares the IMU "
+                         "initialised, optimize its computeBAUpdate / getBAEnergy / acceptBAUpdate / canBreak branch from the first keyframe on; mode hip: through "
+                         "dmvio_hip_tracker_track_vio / dmvio_hip_ba_optimize_vio with the facade's members as callbacks")
+    ap.add_argument("--vio-init-after", type=int, default=3, help="--vio: keyframe optimisations after which the stand-in declares the IMU initialised")
     ap.add_argument("--mt", action="store_true", help="settings.cpp multiThreading = true (the reference's default: linearizeAll, applyRes, the accumulators on 6 workers)")
     ap.add_argument("--scopes", action="store_true", help="inclusive wall time per profiler label of the reference (util/TimeMeasurement scopes) for this run; switches the "
                                                            "event recording of the run off, so wall_s is the pipeline alone")
@@ -103,7 +109,15 @@ def main():
             raise SystemExit("dropin_set_initializer failed")
     if a.realtime > 0:
         R.lib().ref_set_linearize_operation(0)
+    if a.vio:
+        R.lib().ref_set_live_vio.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        R.lib().ref_set_live_vio(1, a.vio_init_after, 0.02, 1e3)
     S = R.System(a.w, a.h, K4, point_density=a.density)
+    if a.vio and D is not None:
+        # shadow mode: both sides of a call go through the same stateful stand-in; the adapter saves / restores it around the device's call
+        L = R.lib()
+        D.dropin_set_vio_state_hooks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        D.dropin_set_vio_state_hooks(S.p, C.cast(L.ref_system_vio_save, C.c_void_p), C.cast(L.ref_system_vio_restore, C.c_void_p))
     if D is not None:
         R.lib().ref_system_fullsystem.restype = C.c_void_p; R.lib().ref_system_fullsystem.argtypes = [C.c_void_p]
         D.dropin_attach(R.lib().ref_system_fullsystem(S.p))
@@ -150,6 +164,17 @@ def main():
                window=np.array([s["window"] for s in status]), opt_rmse=np.array([e["rmse"] for e in opt]), opt_resInA=np.array([e["resInA"] for e in opt]),
                opt_F=np.array([e["F"] for e in opt_in]), opt_N=np.array([e["N"] for e in opt_in]), opt_R=np.array([e["R"] for e in opt_in]),
                n_tracks=np.array([sum(1 for e in ev if e["kind"] == "track_out")]))
+    if a.vio:
+        vc = (C.c_double * 16)()
+        R.lib().ref_system_vio_counters.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        R.lib().ref_system_vio_counters(S.p, vc)
+        # addIMUData, computeCoarseUpdate, acceptCoarseUpdate, addVisualToCoarseGraph, updateBAValues, computeBAUpdate, getBAEnergy, acceptBAUpdate, updateDynamicWeight, canBreak,
+        # postOptimization, addMarginalizedPointsBA; sum of coarse |inc|, sum of max |x| of the BA updates, last factor energy, coarseInitialized
+        out["vio_counters"] = np.array(list(vc))
+        print("vio stand-in:", [int(x) for x in vc[:12]], ["%.6g" % x for x in vc[12:]])
+        if D is not None:
+            dv = (C.c_long * 4)(); D.dropin_get_vio.argtypes = [C.POINTER(C.c_long)]; D.dropin_get_vio(dv)
+            out["vio_adapter"] = np.array(list(dv))      # track_vio calls with computeCoarseUpdate / with the visual step, optimize_vio calls, facade members called from callbacks
     if D is not None:
         sec = (C.c_double * 7)(); calls = (C.c_long * 7)()
         D.dropin_get_stats(sec, calls)

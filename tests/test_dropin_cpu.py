@@ -106,3 +106,23 @@ def test_real_time_mode_through_the_switched_off_adapter(dropin, tmp_path):
     v = (a["valid"] != 0) & (b["valid"] != 0)
     d = a["camToWorld"][v, :3] - b["camToWorld"][v, :3]
     assert v.sum() >= 40 and np.sqrt((d ** 2).sum(1).mean()) < 2e-2
+
+
+def test_the_references_default_vio_configuration_runs_live_against_the_stand_in(dropin, tmp_path):
+    """setting_useIMU / setting_useGTSAMIntegration ON — what dmvio_dataset runs by default — with the live stand-in for the absent IMU / GTSAM side behind the facade's hooks
+    (oracle/ref_glue.cpp: VioStandIn; keyframe bookkeeping restated from src/IMU/IMUIntegration.cpp in oracle/ref_shim/IMU/IMUIntegration.hpp): the reference's own
+    FullSystem initialises, walks prepareKeyframe / keyframeCreated / initCoarseGraph, switches trackNewestCoarse to its computeCoarseUpdate branch after three keyframe
+    optimisations and runs every optimize through computeBAUpdate / getBAEnergy / acceptBAUpdate / canBreak — deterministically (this is the all-CPU side of
+    tests/test_dropin_gpu.py's VIO comparisons), and differently from the visual-only run (the stand-in's factors really enter the solves)."""
+    a = _run("cpu", tmp_path / "a.npz", "--init", "seq", "--vio")
+    b = _run("cpu", tmp_path / "b.npz", "--init", "seq", "--vio")
+    v = _run("cpu", tmp_path / "v.npz", "--init", "seq")
+    assert a["initialized"][-1] and not a["lost"][-1] and len(a["opt_rmse"]) >= 6
+    c = a["vio_counters"]
+    # addIMUData per tracked frame; computeCoarseUpdate / acceptCoarseUpdate / addVisualToCoarseGraph; computeBAUpdate = Gauss-Newton iterations; one postOptimization per keyframe
+    assert c[0] >= 50 and c[1] > 100 and c[2] > 100 and c[3] >= 50 and c[5] >= len(a["opt_rmse"]) and c[7] >= len(a["opt_rmse"]) and c[10] == len(a["opt_rmse"]) and c[15] == 1, c
+    for k in ("camToWorld", "opt_rmse", "opt_N", "opt_R", "vio_counters"):
+        assert np.array_equal(a[k], b[k]), k
+    ok = (a["valid"] != 0) & (v["valid"] != 0)
+    d = a["camToWorld"][ok, :3] - v["camToWorld"][ok, :3]
+    assert 1e-6 < np.sqrt((d ** 2).sum(1).mean()) < 5e-3       # another estimator than the visual-only one, on the same trajectory

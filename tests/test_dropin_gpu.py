@@ -128,6 +128,62 @@ def test_real_time_pipeline_tracking_and_mapping_threads_on_the_library(gpu_requ
     assert rmse < 2e-2
 
 
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("shape", ["512x512", "640x480"])
+def test_reference_fullsystem_default_vio_configuration_on_the_hip_library(gpu_required, tmp_path, shape):
+    """The reference's DEFAULT configuration live (setting_useIMU = setting_useGTSAMIntegration = true — what dmvio_dataset runs unless told useimu=0): its own FullSystem,
+    all-CPU vs HIP-backed, with the SAME stand-in for the absent IMU / GTSAM side behind the facade on both sides (oracle/ref_glue.cpp: VioStandIn).  All-CPU the reference's
+    trackNewestCoarse / solveSystemF / calcMEnergyF / optimize call IMUIntegration::computeCoarseUpdate, acceptCoarseUpdate, addVisualToCoarseGraph and
+    BAGTSAMIntegration::computeBAUpdate, getBAEnergy, updateBAValues, updateDynamicWeight, canBreak, acceptBAUpdate, postOptimization themselves; HIP-backed the adapter's members
+    run dmvio_hip_tracker_track_vio / dmvio_hip_ba_optimize_vio and the library's callbacks call the very same members.  Same bars as the visual-only runs."""
+    w, h = shape.split("x")
+    seq = ["--w", w, "--h", h, "--frames", "100", "--step", "1.6", "--density", "2000", "--vio"]
+    cpu = _run(tmp_path, "cpu", "--mode", "cpu", "--init", "seq", *seq)
+    hip = _run(tmp_path, "hip", "--mode", "hip", "--init", "seq", "--accumulators", "1", *seq)
+    hipd = _run(tmp_path, "hipd", "--mode", "hip", "--init", "hip", *seq)
+    report = []
+    for name, r in (("hip_exact", hip), ("hip_default", hipd)):
+        assert r["failures"][0] == 0 and not r["lost"][-1] and r["initialized"][-1] and not cpu["lost"][-1], name
+        va = r["vio_adapter"]; vc = r["vio_counters"]; cc = cpu["vio_counters"]
+        # every trackNewestCoarse went through track_vio (visual step until the stand-in declares the IMU initialised, computeCoarseUpdate afterwards), every optimize through optimize_vio
+        assert va[0] >= 50 and va[1] >= 1 and va[0] + va[1] == r["stat_calls"][2] and va[2] == len(r["opt_rmse"]) >= 8 and va[3] > 500, (name, va)
+        assert vc[15] == 1 and vc[1] > 100 and vc[5] >= va[2] and vc[10] == va[2], (name, vc)
+        rmse, mx = _traj_diff(cpu, r)
+        n = min(len(cpu["opt_rmse"]), len(r["opt_rmse"]))
+        same = (cpu["opt_N"][:n] == r["opt_N"][:n]) & (cpu["opt_R"][:n] == r["opt_R"][:n])
+        dE = np.abs(_energies(cpu)[:n] - _energies(r)[:n]) / _energies(cpu)[:n]
+        report.append("%s %s (VIO): trajectory rmse %.2e max %.2e m; %d optimisations (%d all-CPU), %d windows of identical composition, their energy within %.1e, all within %.1e; hook calls "
+                      "all-CPU %s / HIP-backed %s; wall %.2f s vs %.2f s" % (shape, name, rmse, mx, len(r["opt_rmse"]), len(cpu["opt_rmse"]), int(same.sum()), dE[same].max(), dE.max(),
+                                                                            [int(x) for x in cc[:11]], [int(x) for x in vc[:11]], float(r["wall_s"][0]), float(cpu["wall_s"][0])))
+        assert rmse < 1e-3, report[-1]
+        assert same[0] and dE[0] < 1e-4 and dE[same].max() < 1e-4, report[-1]
+        assert dE.max() < 0.25 and abs(len(r["opt_rmse"]) - len(cpu["opt_rmse"])) <= 1, report[-1]
+    assert np.array_equal(hip["init_signature"], cpu["init_signature"])
+    print("\n".join(report))
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("shape,accumulators", [("512x512", 1), ("512x512", 0), ("640x480", 1)])
+def test_every_call_of_a_live_default_configuration_run_side_by_side(gpu_required, tmp_path, shape, accumulators):
+    """Shadow mode on the reference's DEFAULT configuration: its own members (VIO branches, the stand-in behind the facade) run the pipeline; every trackNewestCoarse is also run
+    through dmvio_hip_tracker_track_vio and every optimize through dmvio_hip_ba_optimize_vio from the same inputs AND the same facade state (saved before the device's call, put
+    back for the reference's own).  Same bars as the visual-only shadow test: no differing verdict, 1e-4 / 1e-3 m, the same number of Gauss-Newton iterations in every window."""
+    w, h = shape.split("x")
+    seq = ["--w", w, "--h", h, "--frames", "100", "--step", "1.6", "--density", "2000", "--vio"]
+    r = _run(tmp_path, "shadow", "--mode", "hip", "--init", "seq", "--shadow", "--accumulators", str(accumulators), *seq)
+    sh = dict(zip(SHADOW_FIELDS, r["shadow"]))
+    print(shape, "VIO shadow, accumulators", accumulators or "default (4)", {k: (int(v) if k.startswith("n_") else float("%.3g" % v)) for k, v in sh.items()}, "adapter", r["vio_adapter"])
+    assert r["failures"][0] == 0 and not r["lost"][-1] and r["initialized"][-1]
+    va = r["vio_adapter"]
+    assert sh["n_opt"] >= 8 and sh["n_track"] >= 80 and va[0] >= 50 and va[2] == sh["n_opt"]
+    assert sh["n_trace_diff"] == 0
+    assert sh["n_track_good_diff"] == 0 and sh["track_pose"] < 1e-4 and sh["track_res_rel"] < 1e-4, sh
+    exact = accumulators == 1
+    assert sh["n_opt_iter_diff"] == 0, sh
+    assert sh["n_resInA_diff"] <= (0 if exact else 1), sh
+    assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh
+
+
 SHADOW_FIELDS = ["n_opt", "n_track", "n_trace_pts", "n_trace_diff", "n_track_good_diff", "n_resInA_diff", "opt_rmse_rel", "opt_energy_rel", "opt_pose", "opt_aff", "opt_idepth_med",
                  "track_pose", "track_aff_a", "track_aff_b", "track_res_rel", "n_opt_iter_diff"]
 
