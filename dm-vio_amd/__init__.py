@@ -404,6 +404,15 @@ class CoarseTrackerHip:
         return dict(good=bool(r["good"][0]), pose7=r["pose7"][0], aff=r["aff"][0], lastResiduals=r["lastResiduals"][0],
                     flow=r["flow"][0], H=r["H"][0], b=r["b"][0], iterations=int(r["iterations"][0]))
 
+    def set_launch_shape(self, eval_blocks=0, lm_threads=0, lm_waves=0, lm_cluster=0):
+        """Measurement knobs (0 = the library's own choice): dmvio_hip_tracker_set_launch_shape."""
+        fn = self.L.dmvio_hip_tracker_set_launch_shape; fn.argtypes = [C.c_void_p] + [C.c_int] * 4; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, int(eval_blocks), int(lm_threads), int(lm_waves), int(lm_cluster)), "tracker_set_launch_shape")
+
+    def set_eval_server(self, on=True):
+        fn = self.L.dmvio_hip_tracker_set_eval_server; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if on else 0), "tracker_set_eval_server")
+
     def set_single_frame_mode(self, host_lm=True):
         """One alignment problem per call: host LM against the evaluation server (default) or the device-resident LM."""
         _chk(self.L, self.L.dmvio_hip_tracker_set_single_frame_mode(self.p, 1 if host_lm else 0), "tracker_set_single_frame_mode")

@@ -132,7 +132,6 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
     // tile shape of the pyramid build: as wide as the image (contiguous level-0 memory per workgroup), at least 2^(levels-1) rows for the 2x2 reductions
     int twl = 9;
     while (twl > 7 && ((1 << (twl - 1)) >= w || (PYR_TILE_PX >> twl) < (1 << (c->levels - 1)))) twl--;
-    if (const char* e = getenv("DMVIO_HIP_PYR_TILE_LOG2")) { const int v = atoi(e); if (v >= 7 && v <= 9 && (PYR_TILE_PX >> v) >= (1 << (c->levels - 1))) twl = v; }
     c->pg.tw_log2 = twl;
     const int TW = 1 << twl, TH = PYR_TILE_PX >> twl;
     c->pg.tiles_x = (w + TW - 1) / TW; c->pg.tiles_y = (h + TH - 1) / TH;
@@ -140,6 +139,18 @@ dmvio_hip_ctx* dmvio_hip_create(int device, int w, int h, int n_frame_slots) {
   HIPCHKP(hipMalloc((void**)&c->d_f3, sizeof(float) * 3 * w * h));
   HIPCHKP(hipStreamSynchronize(c->stream));
   return c;
+}
+
+// Tile shape of the LDS-tile pyramid build (k_build_pyramids / k_build_pyramids_raw): 2^tw_log2 pixels wide, 4096 / 2^tw_log2 high; 7 .. 9, and the tile must keep
+// 2^(levels-1) rows.  A measurement knob (profiles/r03_stream_ceilings.md); the default is as wide as the image allows.
+int dmvio_hip_set_pyramid_tile_log2(dmvio_hip_ctx* c, int tw_log2) {
+  if (!c) return failmsg("null context");
+  if (tw_log2 < 7 || tw_log2 > 9 || (PYR_TILE_PX >> tw_log2) < (1 << (c->levels - 1))) return failmsg("set_pyramid_tile_log2: 7 .. 9, with at least 2^(levels-1) rows per tile");
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->pg.tw_log2 = tw_log2;
+  const int TW = 1 << tw_log2, TH = PYR_TILE_PX >> tw_log2;
+  c->pg.tiles_x = (c->w + TW - 1) / TW; c->pg.tiles_y = (c->h + TH - 1) / TH;
+  return 0;
 }
 
 void dmvio_hip_destroy(dmvio_hip_ctx* c) {
@@ -537,17 +548,11 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   memset(t->h_mail, 0, sizeof(unsigned int) * EVAL_MAIL_DWORDS);
   HIPCHKP(hipHostMalloc((void**)&t->h_rec, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS, hipHostMallocCoherent | hipHostMallocMapped));
   memset(t->h_rec, 0, sizeof(float) * EVAL_RECORD_FLOATS * EVAL_SERVER_MAX_BLOCKS);
-  if (const char* e = getenv("DMVIO_HIP_EVAL_SERVER")) t->use_server = atoi(e);
-  if (const char* e = getenv("DMVIO_HIP_SINGLE_HOST_LM")) t->single_host_lm = atoi(e);
   HIPCHKP(hipMalloc((void**)&t->d_arrive, sizeof(unsigned int)));
   HIPCHKP(hipMemset(t->d_arrive, 0, sizeof(unsigned int)));
   HIPCHKP(hipMalloc((void**)&t->d_leave, sizeof(unsigned int)));
   HIPCHKP(hipMemset(t->d_leave, 0xFF, sizeof(unsigned int)));
   HIPCHKP(hipStreamSynchronize(nullptr));   // the clears above run on the NULL stream; the context's stream does not wait for it
-  if (const char* e = getenv("DMVIO_HIP_EVAL_BLOCKS")) t->eval_blocks_override = atoi(e);
-  if (const char* e = getenv("DMVIO_HIP_LM_THREADS")) t->lm_threads_override = atoi(e);
-  if (const char* e = getenv("DMVIO_HIP_LM_WAVES")) t->lm_waves_override = atoi(e);
-  if (const char* e = getenv("DMVIO_HIP_LM_CLUSTER")) t->lm_cluster_override = atoi(e);
   return t;
 }
 
@@ -1101,6 +1106,27 @@ int dmvio_hip_coarse_update_visual(const dmvio_hip_tracker_settings* st, const d
 int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* t, int host_lm) {
   if (!t) return failmsg("null tracker");
   t->single_host_lm = host_lm ? 1 : 0;
+  return 0;
+}
+// Measurement knobs (tools/sweep_tracking.py, profiles/): explicit calls instead of environment variables read behind the caller's back.  0 = the library's own choice.
+//   eval_blocks: workgroups per fused evaluation / evaluation server (changes how the fp32 partial sums are grouped)
+//   lm_threads / lm_waves: workgroup shape of k_track_lm (256 or 512 threads; 1, 2 or 4 tap sets in flight)
+//   lm_cluster: workgroups that share one alignment problem in cluster mode (2 .. 32; changes the grouping of the sums)
+int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* t, int eval_blocks, int lm_threads, int lm_waves, int lm_cluster) {
+  if (!t) return failmsg("null tracker");
+  if (eval_blocks < 0 || eval_blocks > t->max_eval_blocks) return failmsg("tracker_set_launch_shape: eval_blocks out of range");
+  if (lm_threads != 0 && lm_threads != 256 && lm_threads != 512) return failmsg("tracker_set_launch_shape: lm_threads is 0, 256 or 512");
+  if (lm_waves != 0 && lm_waves != 1 && lm_waves != 2 && lm_waves != 4) return failmsg("tracker_set_launch_shape: lm_waves is 0, 1, 2 or 4");
+  if (lm_cluster < 0 || lm_cluster > 32) return failmsg("tracker_set_launch_shape: lm_cluster out of range");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->eval_blocks_override = eval_blocks; t->lm_threads_override = lm_threads; t->lm_waves_override = lm_waves; t->lm_cluster_override = lm_cluster;
+  return 0;
+}
+// 1 (default): the evaluations of a host-driven LM go to the resident evaluation server (one launch per tracked frame); 0: one fused launch per evaluation
+int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* t, int on) {
+  if (!t) return failmsg("null tracker");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->use_server = on ? 1 : 0;
   return 0;
 }
 

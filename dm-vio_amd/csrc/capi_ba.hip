@@ -556,11 +556,9 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
     b->bounce.used = 0;
     if (!ok) { failmsg("ba_create: device / pinned allocation failed"); freeAll(b); hipStreamDestroy(b->stream); delete b; return nullptr; }
   }
-  // DMVIO_HIP_BA_SPLIT=k: k partial accumulators per bucket (the reference's multi-threaded mode, order-dependent in fp32)
+  // the only environment variable the library reads: a host-side timing printout of the GN loop (stderr), no effect on what is computed.  The accumulation order is
+  // chosen with dmvio_hip_ba_set_accumulators alone (tests/test_capi_cpu.py greps csrc/ for other getenv calls)
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
-  // the same mapping as dmvio_hip_ba_set_accumulators (k = 1: every accumulator single, the reference's single-threaded order bit for bit)
-  if (const char* e = getenv("DMVIO_HIP_BA_SPLIT")) { const int k = atoi(e); if (k >= 1 && k <= 8) { b->nsTop = k; b->nsD = std::min(k, 4); b->nsC = k == 1 ? 1 : 4 * k; } }
-  if (const char* e = getenv("DMVIO_HIP_BA_EXACT")) { if (atoi(e) != 0) { b->nsTop = b->nsD = b->nsC = 1; } }
   return b;
 }
 void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {

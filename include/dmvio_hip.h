@@ -47,6 +47,8 @@ int dmvio_hip_set_stream(dmvio_hip_ctx* ctx, void* hip_stream);
  * stream.  Lets the build of batch k+1 overlap the tracking of batch k (different bounds: HBM vs L1 miss path / VALU).  The caller orders the two streams with events: a
  * build must not start before the consumers of the slots it rewrites are done, a consumer not before the build of its slots.  dmvio_hip_synchronize waits for both. */
 int dmvio_hip_set_build_stream(dmvio_hip_ctx* ctx, void* hip_stream);
+/* Tile shape of the LDS-tile pyramid builds: 2^tw_log2 pixels wide x 4096 / 2^tw_log2 high (7 .. 9, at least 2^(levels-1) rows).  A measurement knob; default: as wide as the image allows. */
+int dmvio_hip_set_pyramid_tile_log2(dmvio_hip_ctx* ctx, int tw_log2);
 int dmvio_hip_synchronize(dmvio_hip_ctx* ctx);
 
 /* ------------------------------------------------------------------ frames ------------------- */
@@ -153,6 +155,12 @@ int dmvio_hip_tracker_track(dmvio_hip_tracker* trk, int new_slot, float new_expo
  * frame, every calcRes + calcGSSSE evaluation a request through host-coherent memory, the 8x8 solve / SE3 exp on the CPU (sub-microsecond there, 6.5 us per iteration on one
  * wavefront); 0 = the device-resident LM (cluster mode).  Same evaluation sums and iteration counts either way; batches of two and more always run device-resident. */
 int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm);
+/* Measurement knobs as explicit calls (the library reads no environment variable that changes what or how it computes).  0 = the library's own choice.
+ * eval_blocks: workgroups per fused evaluation / evaluation server; lm_threads (256 | 512) and lm_waves (1 | 2 | 4): workgroup shape of the device-resident LM; lm_cluster
+ * (2 .. 32): workgroups sharing one alignment problem.  eval_blocks and lm_cluster change how the fp32 partial sums are grouped (results move in the last bits). */
+int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* trk, int eval_blocks, int lm_threads, int lm_waves, int lm_cluster);
+/* 1 (default): a host-driven LM (dmvio_hip_tracker_track of one frame, dmvio_hip_tracker_track_vio) posts its evaluations to the resident evaluation server; 0: one launch each */
+int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* trk, int on);
 /* Idle limit of the evaluation server (the resident kernel behind a single-frame dmvio_hip_tracker_track / _track_vio call): it leaves after this long without a request
  * and is started again by the next one.  Default 5000 us; raise it when the computeCoarseUpdate hook (IMUIntegration's factor-graph solve) regularly takes longer, so
  * that an LM iteration does not pay a relaunch.  100 us .. 2 s. */

@@ -92,7 +92,6 @@ def test_accumulate_and_solve_parity(big, pkg, oracle, mode, monkeypatch):
     exact (dmvio_hip_ba_set_accumulators(1)): one accumulator per bucket replays the single-threaded reference order (incl. 1k/1M shift-up)
     -> systems agree to double rounding.  fast (the library's default, 4 partial accumulators per bucket, summed in double like the
     reference's six per-worker accumulators) -> agreement at fp32 summation level."""
-    monkeypatch.delenv("DMVIO_HIP_BA_SPLIT", raising=False); monkeypatch.delenv("DMVIO_HIP_BA_EXACT", raising=False)
     case = big["case"]
     ba = pkg.BundleAdjusterHip(big["ctx"], accumulators=1 if mode == "exact" else None)
     ba.set_case(case, list(range(case["n_frames"])))

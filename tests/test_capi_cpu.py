@@ -60,6 +60,21 @@ def test_product_does_not_import_oracle():
                 assert "oracle_py" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("see oracle/", ""), os.path.join(dp, f)
 
 
+def test_library_reads_no_environment_variable_that_changes_the_computation():
+    """Launch shapes, the evaluation path and the accumulation order are chosen through explicit entry points (dmvio_hip_tracker_set_launch_shape, _set_eval_server,
+    _set_single_frame_mode, dmvio_hip_set_pyramid_tile_log2, dmvio_hip_ba_set_accumulators): a stray variable in the environment of a production process must not change what the
+    library computes.  The one getenv left is DMVIO_HIP_BA_TIMING (a timing printout on stderr)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = []
+    for dp, _, files in os.walk(os.path.join(root, "dm-vio_amd", "csrc")):
+        for f in files:
+            for n, line in enumerate(open(os.path.join(dp, f), errors="ignore"), 1):
+                code = line.split("//")[0]
+                if "getenv" in code:
+                    found.append((f, n, re.findall(r'getenv\("([A-Z0-9_]+)"\)', code)))
+    assert [x[2] for x in found] == [["DMVIO_HIP_BA_TIMING"]], found
+
+
 def test_header_is_plain_c_and_cxx(pkg, tmp_path):
     """include/dmvio_hip.h is the drop-in boundary: it must compile as C99 and as C++11 on its own (no torch / HIP / Eigen types), and a
     C++ translation unit that takes the address of every declared entry point must link against the shared library."""

@@ -68,9 +68,8 @@ def cluster_sweep():
             row = []; chosen = 0; pc0 = 0
             for C in [0] + Cs:   # 0: the library's own choice
                 if B * C > 1024: row.append("-"); continue
-                if C: os.environ["DMVIO_HIP_LM_CLUSTER"] = str(C)
-                else: os.environ.pop("DMVIO_HIP_LM_CLUSTER", None)
-                trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])   # the override is read when the tracker is created
+                trk = pkg.CoarseTrackerHip(ctx); trk.makeK(case["K4"])
+                trk.set_launch_shape(lm_cluster=C)   # 0: the library's own choice
                 trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
                 pc0 = trk.pc_n(0)
                 trk.stage(list(range(1, B + 1)), [ident] * B, [(0, 0)] * B)
