@@ -1231,6 +1231,25 @@ def bench_dropin(args, w, h):
     cpu_st = run("cpu_st", "--mode", "cpu", "--init", "seq")             # deterministic single-threaded baseline (the trajectory the HIP-backed run is compared with)
     hip = run("hip", "--mode", "hip", "--init", "hip")
     hip_mt = run("hip_mt", "--mode", "hip", "--init", "hip", "--mt")     # what the reference keeps doing itself on its 6 workers, like cpu_mt: the like-for-like wall clock
+    # the reference's DEFAULT configuration (setting_useIMU / setting_useGTSAMIntegration) with the live stand-in for the absent IMU / GTSAM side behind the facade on both sides
+    vio = None
+    try:
+        vcpu = run("vio_cpu", "--mode", "cpu", "--init", "seq", "--vio")
+        vhip = run("vio_hip", "--mode", "hip", "--init", "hip", "--vio")
+        vv = (vcpu["valid"] != 0) & (vhip["valid"] != 0)
+        vd = vcpu["camToWorld"][vv, :3] - vhip["camToWorld"][vv, :3]
+        nk = max(int(vhip["stat_calls"][4]), 1)
+        vio = dict(what="the same run with setting_useIMU = setting_useGTSAMIntegration = true: trackNewestCoarse through dmvio_hip_tracker_track_vio (IMUIntegration::computeCoarseUpdate "
+                        "/ acceptCoarseUpdate / addVisualToCoarseGraph as callbacks), optimize through dmvio_hip_ba_optimize_vio (the seven BAGTSAMIntegration members as callbacks); "
+                        "behind the facade on BOTH sides the same stand-in (oracle/ref_glue.cpp: VioStandIn)",
+                   all_cpu_single_threaded_s=round(float(vcpu["wall_s"][0]), 3), hip_backed_s=round(float(vhip["wall_s"][0]), 3),
+                   traj_rmse_m=float(np.sqrt((vd ** 2).sum(1).mean())), traj_max_m=float(np.abs(vd).max()),
+                   adapter_calls=dict(zip(["track_vio_computeCoarseUpdate", "track_vio_visual_step", "optimize_vio", "facade_members_called"], [int(x) for x in vhip["vio_adapter"]])),
+                   facade_calls_all_cpu=[int(x) for x in vcpu["vio_counters"][:11]], facade_calls_hip_backed=[int(x) for x in vhip["vio_counters"][:11]],
+                   adapter_ms_per_keyframe=dict(zip(["hand_over", "dmvio_hip_ba_optimize_vio", "write_back"], [round(1e3 * float(x) / nk, 4) for x in vhip["optimize_split_seconds"]])),
+                   adapter_failures=int(vhip["failures"][0]), lost=bool(vhip["lost"][-1]))
+    except Exception as e:   # noqa: BLE001
+        vio = dict(error=str(e)[-300:])
     v = (cpu_st["valid"] != 0) & (hip["valid"] != 0)
     d = cpu_st["camToWorld"][v, :3] - hip["camToWorld"][v, :3]
     v2 = (cpu_st["valid"] != 0) & (cpu_mt["valid"] != 0)
@@ -1262,7 +1281,8 @@ def bench_dropin(args, w, h):
                 adapter_failures=int(hip["failures"][0]), lost=bool(hip["lost"][-1]),
                 seconds_in_replaced_members=dict(zip(["makeImages", "setCoarseTrackingRef", "trackNewestCoarse", "traceNewCoarse", "optimize", "activatePoints", "calcResAndGS"],
                                                      [round(float(x), 4) for x in hip["stat_seconds"]])),
-                scopes_all_cpu=scopes(cpu_mt, names), scopes_hip_backed=scopes(hip, names),
+                scopes_all_cpu=scopes(cpu_mt, names), scopes_hip_backed=scopes(hip, names), vio=vio,
+                track_new_coarse=dict(zip(["calls", "served_by_the_batched_try_loop", "past_try_0", "tries_walked"], [int(x) for x in hip["track_new_coarse"][:4]])),
                 note="all_cpu_s: multiThreading = true and the reference's own thread-pooled initialiser (settings.cpp defaults), %d host threads available; all_cpu_single_threaded_s: "
                      "multiThreading = false with the oracle's sequential CoarseInitializer::calcResAndGS (bit-reproducible: the trajectory baseline); reference_own_spread = "
                      "those two all-CPU runs against each other; scopes = inclusive seconds under the reference's own util/TimeMeasurement labels" % (os.cpu_count() or 0))

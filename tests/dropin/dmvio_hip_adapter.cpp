@@ -33,6 +33,7 @@
 #include <deque>
 #include <fstream>
 #include <functional>
+#include <iomanip>
 #include <iostream>
 #include <atomic>
 #include <map>
@@ -138,6 +139,12 @@ struct Backend
 	} sh;
 	dmvio_hip_initializer* ini = nullptr;
 	void* oracle_lib = nullptr;
+	// FullSystem::trackNewCoarse: 1 = the member below hands the whole try loop (FullSystem.cpp:364-489) to dmvio_hip_tracker_track_new_coarse — try 0 alone, the remaining
+	// motion hypotheses as ONE device batch, the sequential abort / winner rule replayed on their results; 0 = the reference's own loop, one trackNewestCoarse per try
+	int batch_tries = 1;
+	long n_tnc = 0, n_tnc_batched = 0, n_tnc_past_try0 = 0, n_tnc_tries = 0;
+	long tnc_inner_calls = 0;   // trackNewestCoarse calls made by the reference's own loop during the current trackNewCoarse (shadow: the number of tries it walked)
+	struct ShadowTnc { long n = 0, n_past_try0 = 0, n_tries_diff = 0, n_good_diff = 0; double pose = 0, aff_a = 0, res_rel = 0; long max_tries = 0; } tnc;
 	// the reference's DEFAULT configuration (setting_useIMU / setting_useGTSAMIntegration): calls that went through dmvio_hip_tracker_track_vio with computeCoarseUpdate
 	// behind it, through it with the visual-only step (IMU not yet coarse-initialised), through dmvio_hip_ba_optimize_vio; hook calls made from the callbacks
 	long n_vio_track = 0, n_vio_track_visual = 0, n_vio_opt = 0, n_vio_hook_calls = 0;
@@ -389,6 +396,7 @@ int dropin_enable(int on, int device, int w, int h, int accumulators)
 	}
 	g.slotOf.clear(); g.fs = nullptr; g.on = false; g.stats = Stats(); g.failures = 0; g.error[0] = 0;
 	g.n_vio_track = g.n_vio_track_visual = g.n_vio_opt = g.n_vio_hook_calls = 0;
+	g.n_tnc = g.n_tnc_batched = g.n_tnc_past_try0 = g.n_tnc_tries = 0; g.tnc = Backend::ShadowTnc();
 	if (g.graph) { dmvio_hip_graph_destroy(g.graph); g.graph = nullptr; }
 	g.graph_ef = nullptr; g.graph_valid = false; g.graph_ops = g.graph_resyncs = g.graph_verified = g.graph_mismatch = 0;
 	if (!on) return 0;
@@ -460,6 +468,17 @@ void dropin_get_real_marginalization(long* out2) { out2[0] = g.n_real_marg; out2
 void dropin_get_upload_split(double* out6) { for (int k = 0; k < 6; k++) out6[k] = g.up_split[k]; }
 void dropin_get_resident(long* out4) { out4[0] = g.graph_ops; out4[1] = g.graph_resyncs; out4[2] = g.graph_verified; out4[3] = g.graph_mismatch; }
 int dropin_is_on() { return g.on ? 1 : 0; }
+// FullSystem::trackNewCoarse: hand the try loop to dmvio_hip_tracker_track_new_coarse (1, default) or leave the reference's own loop in place (0)
+void dropin_set_batch_tries(int on) { g.batch_tries = on; }
+// trackNewCoarse calls seen, calls served by the batched try loop, calls among those whose walk went past try 0, tries walked in total;
+// shadow mode: calls compared, calls past try 0 (reference), calls whose number of tries differs, whose good-verdict differs, most tries walked in one call;
+// max deviation of the winning pose (translation, m), of aff a, of the achieved level-0 residual (relative)
+void dropin_get_track_new_coarse(double* out12)
+{
+	const double v[12] = {(double)g.n_tnc, (double)g.n_tnc_batched, (double)g.n_tnc_past_try0, (double)g.n_tnc_tries, (double)g.tnc.n, (double)g.tnc.n_past_try0,
+	                      (double)g.tnc.n_tries_diff, (double)g.tnc.n_good_diff, (double)g.tnc.max_tries, g.tnc.pose, g.tnc.aff_a, g.tnc.res_rel};
+	for (int i = 0; i < 12; i++) out12[i] = v[i];
+}
 // the default (VIO) configuration: how the state of a stateful IMU / GTSAM facade is saved and restored around a shadowed call (sys = the argument of both functions)
 void dropin_set_vio_state_hooks(void* sys, void* (*save)(void*), void (*restore)(void*, void*, int)) { g.vio_sys = sys; g.vio_save = save; g.vio_restore = restore; }
 // trackNewestCoarse calls served by dmvio_hip_tracker_track_vio with computeCoarseUpdate as the step / with the visual-only step (IMU not coarse-initialised yet), optimize
@@ -646,6 +665,7 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
 	typedef bool (*Fn)(CoarseTracker*, FrameHessian*, SE3&, AffLight&, int, Vec5, IOWrap::Output3DWrapper*);
 	static Fn orig = original<Fn>("_ZN3dso13CoarseTracker17trackNewestCoarseEPNS_12FrameHessianERN6Sophus8SE3GroupIdLi0EEERNS_8AffLightEiN5Eigen6MatrixIdLi5ELi1ELi0ELi5ELi1EEEPNS_6IOWrap15Output3DWrapperE");
 	Timer tm(g.stats, 2);
+	g.tnc_inner_calls++;
 	if (!g.on) return orig(this, newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort, wrap);
 	if (g.shadow)
 	{
@@ -701,6 +721,94 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
 	lastToNew_out = fromPose7(pose7);
 	aff_g2l_out = AffLight(aff[0], aff[1]);
 	return good != 0;
+}
+
+// ---- FullSystem::trackNewCoarse (FullSystem.cpp:300-539), visual-only branch without a pose hint: the motion hypotheses (:364-402) from dmvio_hip_make_track_hypotheses, the
+// try loop (:419-489) as dmvio_hip_tracker_track_new_coarse — try 0 alone (it usually wins), the remaining tries as ONE batch of alignment problems, then the reference's
+// sequential rule (abort against achievedRes, winner, re-track threshold) replayed on their results —, the bookkeeping around it (:304-345, 491-537) as in the reference.
+// With a hint (the IMU's, one try) or setting_useIMU (a try that is not good still counts, the facade is told about every accepted step: per-try state) the reference's own
+// loop stays and calls trackNewestCoarse above per try.
+std::pair<Vec4, bool> FullSystem::trackNewCoarse(FrameHessian* fh, Sophus::SE3* referenceToFrameHint)
+{
+	typedef std::pair<Vec4, bool> (*Fn)(FullSystem*, FrameHessian*, Sophus::SE3*);
+	static Fn orig = original<Fn>("_ZN3dso10FullSystem14trackNewCoarseEPNS_12FrameHessianEPN6Sophus8SE3GroupIdLi0EEE");
+	g.fs = this;
+	g.n_tnc++;
+	const bool batchable = g.on && g.batch_tries && !referenceToFrameHint && !setting_useIMU && allFrameHistory.size() > 2;
+	if (!batchable) return orig(this, fh, referenceToFrameHint);
+	FrameHessian* lastF = coarseTracker->lastRef;
+	FrameShell* slast = allFrameHistory[allFrameHistory.size() - 2];
+	FrameShell* sprelast = allFrameHistory[allFrameHistory.size() - 3];
+	double s7[7], p7[7], l7[7], aff_last[2];
+	bool posesValid;
+	{	// lock on global pose consistency (:354-360)
+		boost::unique_lock<boost::mutex> crlock(shellPoseMutex);
+		toPose7(slast->camToWorld, s7); toPose7(sprelast->camToWorld, p7); toPose7(lastF->shell->camToWorld, l7);
+		aff_last[0] = slast->aff_g2l.a; aff_last[1] = slast->aff_g2l.b;
+		posesValid = slast->poseValid && sprelast->poseValid && lastF->shell->poseValid;
+	}
+	std::vector<double> tries(7 * 64);
+	int n_tries = dmvio_hip_make_track_hypotheses(s7, p7, l7, tries.data(), 64);
+	if (n_tries < 1) { fail("dmvio_hip_make_track_hypotheses"); return orig(this, fh, referenceToFrameHint); }
+	if (!posesValid) { n_tries = 1; const double ident[7] = {0, 0, 0, 0, 0, 0, 1}; memcpy(tries.data(), ident, sizeof(ident)); }   // :397-401
+	double rmse[5], pose7[7], aff_out[2], flow[3];
+	for (int i = 0; i < 5; i++) rmse[i] = lastCoarseRMSE[i];
+	int winner = -1, used = 0, good = 0;
+	const bool shadow = g.shadow;
+	std::unique_ptr<dmvio::TimeMeasurement> timeMeasurement;
+	if (!shadow) timeMeasurement.reset(new dmvio::TimeMeasurement("FullSystem::trackNewCoarseNoIMU"));
+	if (!shadow) for (IOWrap::Output3DWrapper* ow : outputWrapper) ow->pushLiveFrame(fh);
+	dmvio_hip_tracker* trk = trackerFor(coarseTracker);
+	std::unique_ptr<Timer> tm;
+	if (!shadow) tm.reset(new Timer(g.stats, 2));   // counted where the per-try trackNewestCoarse calls it replaces were counted
+	const bool ok = HIP_OK(dmvio_hip_tracker_track_new_coarse(trk, slotFor(fh), fh->ab_exposure, n_tries, tries.data(), aff_last, rmse, setting_reTrackThreshold, pose7, aff_out, flow,
+	                                                         &winner, &used, &good));
+	if (shadow)
+	{
+		// the reference's own loop (every try through the shadowed trackNewestCoarse above), then the two walks side by side
+		g.tnc_inner_calls = 0;
+		const std::pair<Vec4, bool> ret = orig(this, fh, referenceToFrameHint);
+		if (ok)
+		{
+			g.tnc.n++;
+			if (g.tnc_inner_calls > 1) g.tnc.n_past_try0++;
+			g.tnc.max_tries = std::max(g.tnc.max_tries, g.tnc_inner_calls);
+			if (g.tnc_inner_calls != used) g.tnc.n_tries_diff++;
+			if ((good != 0) != ret.second) g.tnc.n_good_diff++;
+			double r7[7]; toPose7(fh->shell->camToTrackingRef.inverse(), r7);
+			for (int i = 0; i < 3; i++) g.tnc.pose = std::max(g.tnc.pose, std::fabs(r7[i] - pose7[i]));
+			g.tnc.aff_a = std::max(g.tnc.aff_a, std::fabs(fh->shell->aff_g2l.a - aff_out[0]));
+			if (std::isfinite(rmse[0]) && std::isfinite(lastCoarseRMSE[0])) g.tnc.res_rel = std::max(g.tnc.res_rel, std::fabs(rmse[0] - lastCoarseRMSE[0]) / lastCoarseRMSE[0]);
+		}
+		return ret;
+	}
+	tm.reset();
+	if (!ok) return orig(this, fh, referenceToFrameHint);
+	g.n_tnc_batched++; g.n_tnc_tries += used;
+	if (used > 1) g.n_tnc_past_try0++;
+	if (winner < 0)
+	{
+		// :491-505: no try was good — the predicted pose is taken (the library returned tries[0], the last affine parameters and zero flow)
+		printf("BIG ERROR! tracking failed entirely. Take predicted pose and hope we may somehow recover.\n");
+		const SE3 lastF_2_fh = fromPose7(pose7);
+		if (lastF_2_fh.translation().norm() > 100000 || lastF_2_fh.matrix().hasNaN()) { std::cerr << "TRACKING FAILED ENTIRELY, NO HOPE TO RECOVER" << std::endl; exit(1); }
+	}
+	for (int i = 0; i < 5; i++) lastCoarseRMSE[i] = rmse[i];   // = achievedRes (:507)
+	// the members of CoarseTracker the rest of FullSystem reads after the loop: what the LAST try it walked left there is not reproduced (nothing reads it), the winner's is
+	for (int i = 0; i < 5; i++) coarseTracker->lastResiduals[i] = rmse[i];
+	coarseTracker->lastFlowIndicators = Vec3(flow[0], flow[1], flow[2]);
+	// no lock required, as fh is not used anywhere yet (:509-514)
+	fh->shell->camToTrackingRef = fromPose7(pose7).inverse();
+	fh->shell->trackingRef = lastF->shell;
+	fh->shell->aff_g2l = AffLight(aff_out[0], aff_out[1]);
+	fh->shell->camToWorld = fh->shell->trackingRef->camToWorld * fh->shell->camToTrackingRef;
+	fh->shell->trackingWasGood = good != 0;
+	if (coarseTracker->firstCoarseRMSE < 0) coarseTracker->firstCoarseRMSE = rmse[0];
+	if (!setting_debugout_runquiet) printf("Coarse Tracker tracked ab = %f %f (exp %f). Res %f!\n", aff_out[0], aff_out[1], fh->ab_exposure, rmse[0]);
+	if (setting_logStuff)
+		(*coarseTrackingLog) << std::setprecision(16) << fh->shell->id << " " << fh->shell->timestamp << " " << fh->ab_exposure << " " << fh->shell->camToWorld.log().transpose() << " "
+		                     << aff_out[0] << " " << aff_out[1] << " " << rmse[0] << " " << used << "\n";
+	return std::make_pair(Vec4(rmse[0], flow[0], flow[1], flow[2]), good != 0);
 }
 
 // ---- FullSystem::traceNewCoarse (FullSystem.cpp:541-584): the per-host tables exactly as the reference forms them, ImmaturePoint::traceOn of every point on the device

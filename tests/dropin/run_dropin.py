@@ -54,6 +54,12 @@ def main():
                          "EnergyFunctional mutators keep it in step), 2 both, compared element for element")
     ap.add_argument("--real-marg", type=int, default=1, choices=[0, 1],
                     help="mode hip, resident window: EnergyFunctional::marginalizePointsF accumulates on the device from the window optimize left there (1) or stays the reference's own (0)")
+    ap.add_argument("--batch-tries", type=int, default=1, choices=[0, 1],
+                    help="mode hip: FullSystem::trackNewCoarse hands its try loop to dmvio_hip_tracker_track_new_coarse (1: try 0 alone, the other motion hypotheses as one device "
+                         "batch, the sequential rule replayed) or stays the reference's own loop with one trackNewestCoarse per try (0)")
+    ap.add_argument("--jump", default=None, metavar="K:N[,K:N...]",
+                    help="forced relocalisation: N frames are dropped from the sequence in front of frame K — the motion-model guess of that frame is off by N frame steps, so "
+                         "trackNewCoarse's walk goes past try 0")
     ap.add_argument("--vio", action="store_true",
                     help="the reference's DEFAULT configuration: setting_useIMU / setting_useGTSAMIntegration on, a live stand-in for the (absent) IMU / GTSAM side behind the "
                          "facade's hooks (oracle/ref_glue.cpp: VioStandIn) — trackNewestCoarse takes its computeCoarseUpdate branch once the stand-in declares the IMU "
@@ -89,11 +95,18 @@ def main():
         if cache:
             os.makedirs(a.cache, exist_ok=True)
             np.savez(cache + ".tmp.npz", K4=np.asarray(K4), imgs=np.asarray(imgs, np.float32), poses=np.asarray(poses_true)); os.replace(cache + ".tmp.npz", cache)
+    if a.jump:
+        drop = set()
+        for item in a.jump.split(","):
+            k, n = (int(x) for x in item.split(":"))
+            drop.update(range(k, k + n))
+        imgs = [im for i, im in enumerate(imgs) if i not in drop]; poses_true = [p for i, p in enumerate(poses_true) if i not in drop]
     if D is not None and D.dropin_enable(1 if a.mode == "hip" else 0, 0, a.w, a.h, a.accumulators) != 0:
         raise SystemExit("dropin_enable failed")
     if D is not None:
         D.dropin_set_resident.argtypes = [C.c_int]; D.dropin_set_resident(a.resident)
         D.dropin_set_real_marginalization.argtypes = [C.c_int]; D.dropin_set_real_marginalization(a.real_marg)
+        D.dropin_set_batch_tries.argtypes = [C.c_int]; D.dropin_set_batch_tries(a.batch_tries)
     # the reference draws from the C library's rand() (PixelSelector's random pattern, CoarseInitializer's point selection): the same sequence in every mode, whatever the
     # static initialisers of the libraries loaded so far have consumed
     C.CDLL(None).srand(1)
@@ -188,6 +201,10 @@ def main():
             mg2 = (C.c_double * 3)(); D.dropin_get_shadow_marginalization2.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_shadow_marginalization2(mg2)
             out["shadow_marginalization2"] = np.array(list(mg2))
         out["stat_seconds"] = np.array(list(sec)); out["stat_calls"] = np.array(list(calls))
+        tn = (C.c_double * 12)(); D.dropin_get_track_new_coarse.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_track_new_coarse(tn)
+        # trackNewCoarse calls, served by the batched try loop, of those past try 0, tries walked; shadow: compared, past try 0 (reference), tries differ, verdict differs, most tries
+        # in one call; max deviation of the winning pose (m), aff a, achieved level-0 residual (relative)
+        out["track_new_coarse"] = np.array(list(tn))
         sp = (C.c_double * 3)(); D.dropin_get_optimize_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_optimize_split(sp)
         out["optimize_split_seconds"] = np.array(list(sp))      # flatten + upload, dmvio_hip_ba_optimize, write-back
         us = (C.c_double * 6)(); D.dropin_get_upload_split.argtypes = [C.POINTER(C.c_double)]; D.dropin_get_upload_split(us)

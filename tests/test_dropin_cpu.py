@@ -22,6 +22,8 @@ MEMBERS = ["_ZN3dso10FullSystem25activatePointsMT_ReductorEPSt6vectorIPNS_12Poin
            "_ZN3dso13CoarseTracker17trackNewestCoarseEPNS_12FrameHessianERN6Sophus8SE3GroupIdLi0EEERNS_8AffLightEiN5Eigen6MatrixIdLi5ELi1ELi0ELi5ELi1EEEPNS_6IOWrap15Output3DWrapperE",
            "_ZN3dso10FullSystem14traceNewCoarseEPNS_12FrameHessianE",
            "_ZN3dso10FullSystem8optimizeEi",
+           # round 5: the try loop of trackNewCoarse as a member (one device batch for the motion hypotheses)
+           "_ZN3dso10FullSystem14trackNewCoarseEPNS_12FrameHessianEPN6Sophus8SE3GroupIdLi0EEE",
            # round 4: EnergyFunctional's graph mutators (forwarded to the resident window graph) and marginalizePointsF (a real member on top of it)
            "_ZN3dso16EnergyFunctional11insertFrameEPNS_12FrameHessianEPNS_12CalibHessianE", "_ZN3dso16EnergyFunctional11insertPointEPNS_12PointHessianE",
            "_ZN3dso16EnergyFunctional14insertResidualEPNS_18PointFrameResidualE", "_ZN3dso16EnergyFunctional12dropResidualEPNS_10EFResidualE",

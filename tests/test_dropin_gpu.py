@@ -184,6 +184,39 @@ def test_every_call_of_a_live_default_configuration_run_side_by_side(gpu_require
     assert sh["opt_pose"] < 1e-3 and sh["opt_energy_rel"] < 1e-4 and sh["opt_rmse_rel"] < 1e-4 and sh["opt_idepth_med"] < 1e-4, sh
 
 
+TNC_FIELDS = ["calls", "batched", "past_try0", "tries", "sh_n", "sh_past_try0", "sh_tries_diff", "sh_good_diff", "sh_max_tries", "sh_pose", "sh_aff_a", "sh_res_rel"]
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/libdropin_hip.so not built (needs /root/reference at build time)")
+def test_track_new_coarse_member_with_a_forced_relocalisation(gpu_required, tmp_path):
+    """FullSystem::trackNewCoarse as an adapter member (FullSystem.cpp:300-539): the motion hypotheses from dmvio_hip_make_track_hypotheses, the try loop as
+    dmvio_hip_tracker_track_new_coarse (try 0 alone, the other hypotheses as ONE device batch, the reference's sequential abort / winner / re-track rule replayed), inside the
+    reference's own FullSystem.  The sequence drops 30 frames in front of frame 40: the constant-motion guess of that frame is off by 30 frame steps, try 0 ends far above the
+    re-track threshold and the walk goes through the whole hypothesis list.
+      shadow mode: the reference's own loop (31 sequential trackNewestCoarse calls) and the batched walk side by side — same number of tries in every call, same verdict,
+                   winning pose within 1e-5 m, achieved residual within 1e-4;
+      whole runs:  batched try loop vs the reference's loop over the adapter's trackNewestCoarse vs all-CPU: the same trajectory within the north-star bar."""
+    seq = ["--w", "512", "--h", "512", "--frames", "110", "--step", "1.6", "--density", "2000", "--jump", "40:30", "--init", "seq", "--accumulators", "1"]
+    sh = _run(tmp_path, "shadow", "--mode", "hip", "--shadow", *seq)
+    t = dict(zip(TNC_FIELDS, sh["track_new_coarse"]))
+    print("shadow:", {k: (int(v) if not k.startswith("sh_") or k in ("sh_n", "sh_past_try0", "sh_tries_diff", "sh_good_diff", "sh_max_tries") else float("%.3g" % v)) for k, v in t.items()})
+    assert sh["failures"][0] == 0 and not sh["lost"][-1]
+    assert t["sh_n"] >= 60 and t["sh_past_try0"] >= 1 and t["sh_max_tries"] >= 10, t          # the forced relocalisation really walked the list
+    assert t["sh_tries_diff"] == 0 and t["sh_good_diff"] == 0, t
+    assert t["sh_pose"] < 1e-5 and t["sh_res_rel"] < 1e-4, t
+    cpu = _run(tmp_path, "cpu", "--mode", "cpu", *seq)
+    bat = _run(tmp_path, "bat", "--mode", "hip", "--batch-tries", "1", *seq)
+    seqt = _run(tmp_path, "seqt", "--mode", "hip", "--batch-tries", "0", *seq)
+    tb = dict(zip(TNC_FIELDS, bat["track_new_coarse"])); ts = dict(zip(TNC_FIELDS, seqt["track_new_coarse"]))
+    assert bat["failures"][0] == 0 and seqt["failures"][0] == 0 and not bat["lost"][-1] and not cpu["lost"][-1]
+    assert tb["batched"] >= 60 and tb["past_try0"] >= 1 and tb["tries"] >= tb["batched"] + 10 and ts["batched"] == 0, (tb, ts)
+    # the batched walk makes ONE trackNewestCoarse-equivalent call per try on the device but none through the member: the member's call counter only sees the initialiser-free rest
+    r1, m1 = _traj_diff(cpu, bat); r2, m2 = _traj_diff(cpu, seqt); r3, m3 = _traj_diff(bat, seqt)
+    print("forced relocalisation: %d calls, %d past try 0, %d tries walked; trajectory vs all-CPU: batched try loop rmse %.2e max %.2e m, sequential tries rmse %.2e max %.2e m; batched vs "
+          "sequential rmse %.2e m; seconds in trackNewestCoarse member (sequential) %.4f" % (tb["batched"], tb["past_try0"], tb["tries"], r1, m1, r2, m2, r3, float(seqt["stat_seconds"][2])))
+    assert r1 < 1e-3 and r2 < 1e-3, (r1, r2)
+
+
 SHADOW_FIELDS = ["n_opt", "n_track", "n_trace_pts", "n_trace_diff", "n_track_good_diff", "n_resInA_diff", "opt_rmse_rel", "opt_energy_rel", "opt_pose", "opt_aff", "opt_idepth_med",
                  "track_pose", "track_aff_a", "track_aff_b", "track_res_rel", "n_opt_iter_diff"]
 
