@@ -742,6 +742,47 @@ class ImmaturePointsHip:
         return dict(zip(("good", "oob", "outlier", "skipped", "badcondition", "uninitialized"), counts.tolist()))
 
 
+class BundleAdjusterBatch:
+    """dmvio_hip_ba_optimize_batch: FullSystem::optimize for W windows (BundleAdjusterHip objects of one context) per launch sequence, on the device-resident loop."""
+
+    def __init__(self, ctx, max_windows):
+        self.ctx = ctx; self.L = ctx.L
+        L = self.L
+        L.dmvio_hip_ba_batch_create.restype = C.c_void_p; L.dmvio_hip_ba_batch_create.argtypes = [C.c_void_p, C.c_int]
+        L.dmvio_hip_ba_batch_destroy.argtypes = [C.c_void_p]; L.dmvio_hip_ba_batch_destroy.restype = None
+        L.dmvio_hip_ba_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; L.dmvio_hip_ba_optimize_batch.restype = C.c_int
+        L.dmvio_hip_ba_batch_set_exact_backsub.argtypes = [C.c_void_p, C.c_int]; L.dmvio_hip_ba_batch_last_ms.argtypes = [C.c_void_p, C.c_void_p]
+        p = L.dmvio_hip_ba_batch_create(ctx.p, int(max_windows))
+        if not p:
+            raise HipLibraryError("ba_batch_create: " + _err(L))
+        self.p = C.c_void_p(p)
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.dmvio_hip_ba_batch_destroy(self.p); self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_exact_backsub(self, on=True):
+        _chk(self.L, self.L.dmvio_hip_ba_batch_set_exact_backsub(self.p, 1 if on else 0), "ba_batch_set_exact_backsub")
+
+    def optimize(self, windows, its=6):
+        W = len(windows)
+        hs = (C.c_void_p * W)(*[w.p for w in windows])
+        rm = np.zeros(W, np.float32); fe = np.zeros(W); it = np.zeros(W, np.int32); tr = np.zeros((W, 64, 4))
+        _chk(self.L, self.L.dmvio_hip_ba_optimize_batch(self.p, W, hs, its, rm.ctypes.data, fe.ctypes.data, it.ctypes.data, tr.ctypes.data), "ba_optimize_batch")
+        return [dict(rmse=float(rm[k]), finalEnergy=float(fe[k]), iterations=int(it[k]), trace=tr[k, :it[k] + 1].copy()) for k in range(W)]
+
+    def last_ms(self):
+        ms = np.zeros(2, np.float32)
+        _chk(self.L, self.L.dmvio_hip_ba_batch_last_ms(self.p, ms.ctypes.data), "ba_batch_last_ms")
+        return float(ms[0]), float(ms[1])
+
+
 class RcclCommunicator:
     """ncclComm_t created through the library's wrappers (dmvio_hip_comm_*): rank `rank` of `world` on the context's device.
     unique_id(): 128 bytes from one rank, to be handed to all ranks (e.g. torch.distributed broadcast) before construction."""
@@ -1172,3 +1213,14 @@ class BundleAdjusterHip:
         rm = C.c_float(0); fe = C.c_double(0); it = C.c_int(0); tr = np.zeros((64, 4))
         _chk(self.L, self.L.dmvio_hip_ba_optimize(self.p, its, C.byref(rm), C.byref(fe), C.byref(it), _d(tr)), "ba_optimize")
         return dict(rmse=rm.value, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])
+
+    def set_device_loop(self, on=True):
+        """dmvio_hip_ba_optimize through the device-resident Gauss-Newton loop (solve, frame step, accept test on the device; a batch of one window)."""
+        fn = self.L.dmvio_hip_ba_set_device_loop; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if on else 0), "ba_set_device_loop")
+
+    def last_x(self):
+        x = np.zeros(self.n)
+        fn = self.L.dmvio_hip_ba_get_last_x; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, x.ctypes.data), "ba_get_last_x")
+        return x

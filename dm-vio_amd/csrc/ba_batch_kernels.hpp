@@ -1,0 +1,445 @@
+// CDNA4 (gfx950) kernels of the DEVICE-RESIDENT Gauss-Newton loop of the sliding-window bundle adjustment (round 5): the whole body of FullSystem::optimize's loop
+// (src/dso/FullSystem/FullSystemOptimize.cpp:485-586) — solveSystemF (EnergyFunctional.cpp:841-996, the non-GTSAM branch), doStepFromBackup (FullSystemOptimize.cpp:224-317),
+// setPrecalcValues (FullSystem.cpp:1670-1680, HessianBlocks.cpp:193-223), calcLEnergy / calcMEnergy (EnergyFunctional.cpp:322-431), the accept test (:553-586) — on the
+// device, for W windows per launch:
+//   * k_ba_solve: ONE workgroup per window — what csrc/ba_host.hpp does on the host between two kernel chains (assemble HFinal_top / bFinal_top from the stitched system, the
+//     priors and the marginalisation prior; Jacobi scaling; the pivoted LDL^T of EnergyFunctional.cpp:971-973 with the arithmetic of BAHost::ldltSolveTransposed element for
+//     element; orthogonalisation; the frame / calibration step; SE3 exponentials; the F (F - 1) frame-pair tables; E_L and E_M of the stepped state) — writes the arguments of
+//     the window's next linearisation (calibration, pair tables, back-substitution inputs, the accept test's energies) into the window's record in device memory;
+//   * k_ba_*_b: the kernels of csrc/ba_kernels.hpp with the window taken from blockIdx.y and their arguments read from that record (same bodies, same arithmetic).
+// The loop then is a fixed sequence of launches enqueued up front (solve -> linearise + decide -> [rejected: restore + relinearise] -> [accepted: applyRes + per-point sums ->
+// accumulate -> stitch -> gather]), each kernel gated on the window's own decision in device memory: no host round trip, no PCIe poll per iteration, and W windows cost W
+// times the work but ONE launch sequence — windows of a batch never wait for each other inside a kernel (no cross-workgroup spinning: a grid that is only partly resident
+// cannot deadlock).
+#pragma once
+#include "ba_kernels.hpp"
+#include "lie_dev.h"
+
+namespace dmv {
+
+// ---- per-window record in device memory: the kernel arguments of the single-window path, plus what the solve kernel carries from iteration to iteration
+struct BAFrameDev {
+  Pose evalPT;
+  double state[10], state_zero[10], state_backup[10];
+  double prior[8];
+  float ab_exposure, pad;
+};
+struct BASolveDev {
+  int F, n, haveM, nBasis;
+  int stepped;                 // a step is pending: the previous solve stepped the window and a decision pass has run since
+  int iterations_done, n_accepted, exact_backsub;
+  double lambda;
+  double lastL, lastM, newL, newM;   // E_L / E_M of the state the window stands at / of the pending stepped state
+  double c_value[4], c_value_zero[4], c_value_backup[4], cPrior[4];
+  float cPriorF[4];
+  BAFrameDev fr[BA_MAXF_CAP];
+  const double* HM;            // n x n row-major (haveM) — the marginalisation prior
+  const double* bM;            // n
+  const double* basis;         // nBasis x n: orthonormal basis of the gauge nullspaces above the cut (BAHost::prepareOrthogonalize, host: a function of the evaluation points only)
+  const float* adHostF;        // F*F x 64, index h + F*t (BAHost::setAdjointsF)
+  const float* adTargetF;
+  double* trace;               // 64 x 4: [E_A, E_L, E_M, accepted] per iteration, row 0 = the initial state
+  double* x_last;              // n: the last solve's x (= MINUS the step), for tests
+};
+struct BAWinDev {
+  BAWindow W, Wb;              // Wb: calibration members of the backed-up state (the relinearisation after a rejected step)
+  BAPoints P;
+  BARes Rs;
+  const BAPrecalc* pre;
+  BADecide D;                  // per-window members; mode / update_th / publish / ticket are set per launch
+  BAPreDyn T, Tb;              // step-dependent pair tables of the state the next linearisation evaluates / of the backed-up state
+  ResubArgs X;
+  AccumArgs A;
+  StitchBufs SB;
+  const double *adHost, *adTarget;
+  double* sys;                 // device: [H_A | b_A | H_sc | b_sc | resInA]
+  BACtl* ctl;
+  int n_lin_blocks, n_pt8_blocks, n_acc_blocks, n_res_blocks, n_gather_blocks, n_stitch_blocks;
+  BASolveDev S;
+};
+
+// ------------------------------------------------------------------------------------------------ batched forms of the kernels of ba_kernels.hpp
+// window = blockIdx.y; a workgroup beyond its window's own grid leaves at once (grid.x is the largest count of the batch)
+enum { BA_LINB_INITIAL = 0, BA_LINB_STEPPED = 1, BA_LINB_RESTORE = 2, BA_LINB_FINAL = 3 };
+__global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize_b(const BAWinDev* __restrict__ wins, const FrameStore fs, const int kind) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_lin_blocks) return;
+  BADecide D = V.D;
+  D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1;
+  // INITIAL / FINAL: plain linearisation of the current state (energy + threshold); STEPPED: back-substitution + point step fused in front, accept test behind;
+  // RESTORE: only after a rejected step — the points go back to their backup, the backed-up state is relinearised
+  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin_blocks); }
+  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody(V.Wb, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
+  else { D.mode = 0; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
+}
+__global__ void __launch_bounds__(256) k_ba_apply_b(const BAWinDev* __restrict__ wins, const int mark_removed, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_res_blocks || baGateClosed(V.ctl, gate)) return;
+  baApplyBody(V.W.R, V.Rs, nullptr, mark_removed);
+}
+__global__ void __launch_bounds__(256) k_ba_point_sums_b(const BAWinDev* __restrict__ wins, const int backup, const int apply, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_pt8_blocks) return;
+  baPointSumsBody(V.W, V.P, V.Rs, backup, apply, V.ctl, gate, nullptr);
+}
+__global__ void __launch_bounds__(256) k_ba_accumulate_b(const BAWinDev* __restrict__ wins, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_acc_blocks) return;
+  baAccumulateBody(V.A, V.Rs, V.P, V.ctl, gate);
+}
+// every window of a batch has the same F (the host groups them): blockDim = 64 F
+__global__ void __launch_bounds__(64 * BA_MAXF_CAP) k_ba_stitch_b(const BAWinDev* __restrict__ wins, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  baStitchBody(V.A.F, V.A.nsTop, V.A.nsD, V.A.accTop, V.A.numTop, V.A.accD, V.A.numD, V.A.accE, V.adHost, V.adTarget, V.SB, V.ctl, gate);
+}
+template <int MF>
+__global__ void __launch_bounds__(256) k_ba_stitch_gather_b(const BAWinDev* __restrict__ wins, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_gather_blocks || baGateClosed(V.ctl, gate)) return;
+  const int F = V.A.F;
+  gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, blockIdx.x * blockDim.x + threadIdx.x, false);
+}
+
+// ------------------------------------------------------------------------------------------------ k_ba_solve
+// lower triangle packed by rows: element (r, c), c <= r
+__device__ __forceinline__ int triIdx(const int r, const int c) { return (r * (r + 1)) / 2 + c; }
+#define BA_SOLVE_THREADS 256
+#define BA_SOLVE_NMAX (4 + 8 * BA_MAXF_CAP)
+#define BA_SOLVE_QMAX ((BA_SOLVE_NMAX * (BA_SOLVE_NMAX + 1) / 2 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS)
+// LDS of k_ba_solve, in doubles: the packed matrix + the vectors below
+__host__ __device__ inline size_t baSolveLdsDoubles(const int n) { return (size_t)(n * (n + 1)) / 2 + 10 * (size_t)n + 64; }
+
+// AffLight::fromToVecExposure as BAHost::affFromToHost evaluates it (exp in double, the exposure ratio in float-to-double promotion order)
+__device__ __forceinline__ void baAffFromTo(float eF, float eT, const double aF, const double bF, const double aT, const double bT, double out[2]) {
+  if (eF == 0 || eT == 0) { eT = eF = 1; }
+  const double a = dexp(aT - aF) * eT / eF;
+  out[0] = a; out[1] = bT - a * bF;
+}
+
+// finish != 0: only settle the pending decision and publish the final state (behind the last iteration's chain)
+// last != 0: the host enqueues no accumulation behind this iteration's accepted step (the per-point sums then stay those of the last solve, as in the reference)
+__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restrict__ wins, const int iteration, const int finish) {
+  BAWinDev& V = wins[blockIdx.x];
+  BASolveDev& S = V.S;
+  extern __shared__ double s_mem[];
+  const int tid = threadIdx.x, n = S.n, F = S.F;
+  const int NP = (n * (n + 1)) / 2;
+  double* const M = s_mem;            // NP: scaled, permuted matrix -> L (strict lower) and D (diagonal)
+  double* const d = M + NP;           // n: stacked delta (calib | frames)
+  double* const bP = d + n;           // n: bM + HM delta
+  double* const HLd = bP + n;         // n
+  double* const sv = HLd + n;         // n
+  double* const rhs = sv + n;         // n: scaled right-hand side, permuted in place
+  double* const xs = rhs + n;         // n
+  double* const dg = xs + n;          // n: diagonal copy for the pivot search
+  double* const tv = dg + n;          // n: calcMEnergy rows / projections
+  double* const col = tv + n;         // n: the current column of L
+  int* const perm = reinterpret_cast<int*>(col + n);   // n ints (<= n doubles reserved)
+  __shared__ int s_flag[4];
+  __shared__ double s_scal[8];
+  __shared__ Pose s_w2c[BA_MAXF_CAP], s_c2w[BA_MAXF_CAP];
+  __shared__ double s_scaled[BA_MAXF_CAP][10];
+  __shared__ float s_K[9], s_Ki[9];
+
+  // ---- settle the pending decision (FullSystemOptimize.cpp:556-583 behind the accept test)
+  if (tid == 0) {
+    int acc = 1;
+    if (S.stepped) {
+      acc = __hip_atomic_load(&V.ctl->accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double E0 = __hip_atomic_load(&V.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (acc) { S.lastL = S.newL; S.lastM = S.newM; S.lambda = fmax(S.lambda * 0.25, 1e-5); S.n_accepted++; }
+      else S.lambda *= 1e2;
+      S.iterations_done++;
+      const int row = S.iterations_done;
+      if (row < 64) { S.trace[4 * row] = E0; S.trace[4 * row + 1] = S.lastL; S.trace[4 * row + 2] = S.lastM; S.trace[4 * row + 3] = acc ? 1.0 : 0.0; }
+      S.stepped = 0;
+    } else if (iteration == 0 && !finish) {
+      // row 0 of the trace: the initial state (its photometric energy is what the initial linearisation's decision pass left in the control block)
+      S.trace[0] = __hip_atomic_load(&V.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); S.trace[1] = S.lastL; S.trace[2] = S.lastM; S.trace[3] = 1.0;
+    }
+    s_flag[0] = acc;
+  }
+  __syncthreads();
+  const int prevAccepted = s_flag[0];
+  if (!prevAccepted) {
+    // loadSateBackup, frame / calibration part: the state and its pair tables go back to the backup's
+    for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) S.fr[i / 10].state[i % 10] = S.fr[i / 10].state_backup[i % 10];
+    if (tid < 4) S.c_value[tid] = S.c_value_backup[tid];
+    const int np = F * (F - 1) * 14;
+    float* Tcur = &V.T.v[0][0];
+    const float* Tbk = &V.Tb.v[0][0];
+    for (int i = tid; i < np; i += BA_SOLVE_THREADS) Tcur[i] = Tbk[i];
+    if (tid == 0) { V.W.fx = V.Wb.fx; V.W.fy = V.Wb.fy; V.W.cx = V.Wb.cx; V.W.cy = V.Wb.cy; V.W.fxi = V.Wb.fxi; V.W.fyi = V.Wb.fyi; V.W.cxi = V.Wb.cxi; V.W.cyi = V.Wb.cyi; }
+  }
+  __syncthreads();
+  if (finish) return;
+
+  // ---- backupState (frames, calibration) + the stacked delta (EnergyFunctional::setDeltaF as BAHost::setPrecalcValues keeps it)
+  for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) S.fr[i / 10].state_backup[i % 10] = S.fr[i / 10].state[i % 10];
+  if (tid < 4) { S.c_value_backup[tid] = S.c_value[tid]; d[tid] = (double)(float)(S.c_value[tid] - S.c_value_zero[tid]); HLd[tid] = S.cPrior[tid]; }
+  for (int i = tid; i < 8 * F; i += BA_SOLVE_THREADS) {
+    const BAFrameDev& f = S.fr[i >> 3];
+    d[4 + i] = f.state[i & 7] - f.state_zero[i & 7];
+    HLd[4 + i] = f.prior[i & 7];
+  }
+  if (tid == 0) {   // the backed-up state's tables for a relinearisation after a rejected step
+    V.Wb.fx = V.W.fx; V.Wb.fy = V.W.fy; V.Wb.cx = V.W.cx; V.Wb.cy = V.W.cy; V.Wb.fxi = V.W.fxi; V.Wb.fyi = V.W.fyi; V.Wb.cxi = V.W.cxi; V.Wb.cyi = V.W.cyi;
+  }
+  {
+    const int np = F * (F - 1) * 14;
+    const float* Tcur = &V.T.v[0][0];
+    float* Tbk = &V.Tb.v[0][0];
+    for (int i = tid; i < np; i += BA_SOLVE_THREADS) Tbk[i] = Tcur[i];
+  }
+  __syncthreads();
+  // bM_top = bM + HM * delta (EnergyFunctional.cpp:864), row sums in index order
+  const int haveM = S.haveM;
+  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {
+    double s = haveM ? S.bM[i] : 0.0;
+    if (haveM) for (int j = 0; j < n; j++) s += S.HM[(size_t)i * n + j] * d[j];
+    bP[i] = s;
+  }
+  // ---- HFinal_top - H_sc / (1 + lambda), lower triangle (BAHost::solveSystem: (HL + HM) + HA, the diagonal times (1 + lambda), minus H_sc * fac)
+  const double lambda = S.lambda;
+  const double fac = 1.0f / (1 + lambda);
+  const double* __restrict__ HA = V.sys;
+  const double* __restrict__ bA = V.sys + (size_t)n * n;
+  const double* __restrict__ Hsc = bA + n;
+  const double* __restrict__ bsc = Hsc + (size_t)n * n;
+  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {   // diagonal first: the Jacobi scaling needs it
+    const size_t o = (size_t)i * n + i;
+    double v = (HLd[i] + (haveM ? S.HM[o] : 0.0)) + HA[o];
+    v *= (1 + lambda);
+    v = v - Hsc[o] * fac;
+    sv[i] = 1.0 / sqrt(v + 10);
+    dg[i] = v;
+  }
+  __syncthreads();
+  for (int p = tid; p < NP; p += BA_SOLVE_THREADS) {
+    // unpack p -> (i, j), j <= i
+    int i = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while (triIdx(i + 1, 0) <= p) i++;
+    while (triIdx(i, 0) > p) i--;
+    const int j = p - triIdx(i, 0);
+    double v;
+    if (i == j) v = dg[i];
+    else {
+      const size_t o = (size_t)i * n + j;
+      v = ((0.0 + (haveM ? S.HM[o] : 0.0)) + HA[o]) - Hsc[o] * fac;
+    }
+    M[p] = sv[i] * v * sv[j];   // (sv_i * H_ij) * sv_j
+  }
+  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {
+    const double bL = i < 4 ? S.cPrior[i] * d[i] : S.fr[(i - 4) >> 3].prior[(i - 4) & 7] * S.fr[(i - 4) >> 3].state[(i - 4) & 7];   // prior * delta_prior (= state)
+    const double bF = ((bL + bP[i]) + bA[i]) - bsc[i];
+    rhs[i] = sv[i] * bF;
+  }
+  __syncthreads();
+  // ---- pivot order: Eigen's LDLT (and BAHost::ldltSolveTransposed) picks the largest |diagonal| of the NOT YET UPDATED trailing diagonal (left-looking: step k only
+  // touches column k), first one on ties, and swaps it to position k — the whole sequence follows from the diagonal alone.  Wavefront 0 replays the selection.
+  if (tid < 64) {
+    for (int i = tid; i < n; i += 64) { dg[i] = M[triIdx(i, i)]; perm[i] = i; }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < n; k++) {
+      double best = -1.0; int bi = 0x7fffffff;
+      for (int i = k + tid; i < n; i += 64) { const double v = fabs(dg[i]); if (v > best) { best = v; bi = i; } }   // ascending i per lane: strict > keeps the first
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (bi == 0x7fffffff) bi = k;   // all NaN: no swap (fabs(NaN) > x is false in the host loop too)
+      if (tid == 0 && bi != k) { const double t = dg[k]; dg[k] = dg[bi]; dg[bi] = t; const int q = perm[k]; perm[k] = perm[bi]; perm[bi] = q; }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  // ---- the permuted system: P A P^T in place of A (all swaps applied up front: the same operands meet in the same order as with swaps at every step)
+  // each thread owns the packed pairs tid, tid + 256, ...; it first reads its pairs from the unpermuted matrix, then (behind a barrier) stores them
+  int pr[BA_SOLVE_QMAX];            // (r << 8) | c of the owned pairs
+  double acc[BA_SOLVE_QMAX];        // sum_{j < k} L(r, j) D(j) L(c, j) of the owned pairs, j ascending (ldltSolveTransposed's acc[r], one per column)
+  {
+    double val[BA_SOLVE_QMAX];
+#pragma unroll
+    for (int q = 0; q < BA_SOLVE_QMAX; q++) {
+      const int p = tid + q * BA_SOLVE_THREADS;
+      pr[q] = -1; acc[q] = 0.0; val[q] = 0.0;
+      if (p < NP) {
+        int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+        while (triIdx(r + 1, 0) <= p) r++;
+        while (triIdx(r, 0) > p) r--;
+        const int c = p - triIdx(r, 0);
+        pr[q] = (r << 8) | c;
+        const int a = perm[r], b = perm[c];
+        val[q] = M[a >= b ? triIdx(a, b) : triIdx(b, a)];
+      }
+    }
+    double rv = 0.0;
+    if (tid < n) rv = rhs[perm[tid]];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < BA_SOLVE_QMAX; q++) { const int p = tid + q * BA_SOLVE_THREADS; if (p < NP) M[p] = val[q]; }
+    if (tid < n) rhs[tid] = rv;
+    if (tid == 0) s_flag[1] = 0;
+  }
+  __syncthreads();
+  // ---- LDL^T, column by column; the forward substitution rides along (d[i] -= L(i, j) d[j], j ascending)
+  for (int k = 0; k < n; k++) {
+    // column k: A(r, k) - acc (the owner of pair (r, k) holds acc)
+#pragma unroll
+    for (int q = 0; q < BA_SOLVE_QMAX; q++) {
+      if (pr[q] >= 0 && (pr[q] & 255) == k) {
+        const int r = pr[q] >> 8;
+        double v = M[triIdx(r, k)];
+        if (k > 0) v -= acc[q];
+        M[triIdx(r, k)] = v;
+        col[r] = v;
+      }
+    }
+    __syncthreads();
+    const double akk = col[k];
+    const bool ok = fabs(akk) > 0;
+    if (k == 0 && !ok) { if (tid == 0) s_flag[1] = 1; break; }
+    if (tid > k && tid < n) {
+      double l = col[tid];
+      if (ok) l /= akk;
+      col[tid] = l;
+      M[triIdx(tid, k)] = l;
+      rhs[tid] -= l * rhs[k];
+    }
+    __syncthreads();
+    // trailing update of the owned pairs (r, c), c > k: acc += L(r, k) * (D(k) L(c, k))
+#pragma unroll
+    for (int q = 0; q < BA_SOLVE_QMAX; q++) {
+      if (pr[q] >= 0) {
+        const int c = pr[q] & 255, r = pr[q] >> 8;
+        if (c > k) acc[q] += col[r] * (akk * col[c]);
+      }
+    }
+    // (the next step's column phase only reads registers and column k + 1 of M, which nobody writes here; col[] is rewritten behind its barrier)
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool zero = s_flag[1] != 0;
+  // ---- diagonal solve, back substitution
+  if (tid < n) {
+    const double dd = M[triIdx(tid, tid)];
+    double v = rhs[tid];
+    if (fabs(dd) > 2.2250738585072014e-308) v /= dd; else v = 0;
+    rhs[tid] = zero ? 0.0 : v;
+  }
+  __syncthreads();
+  if (!zero) {
+    if (S.exact_backsub) {
+      // the order of ldltSolveTransposed (row i subtracts L(j, i) x_j for j = i + 1 .. n - 1, ascending): one dependent chain of n^2 / 2 subtractions
+      if (tid == 0) for (int i = n - 1; i >= 0; i--) { double s = rhs[i]; for (int j = i + 1; j < n; j++) s -= M[triIdx(j, i)] * rhs[j]; rhs[i] = s; }
+    } else {
+      // column-oriented: as soon as x_i stands, every row above subtracts its term (row r then subtracts in the order i = n - 1 .. r + 1: the same terms, another association)
+      for (int i = n - 1; i > 0; i--) {
+        const double xi = rhs[i];
+        if (tid < i) rhs[tid] -= M[triIdx(i, tid)] * xi;
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  // undo the permutation and the scaling: x = S P^T x'
+  if (tid < n) xs[perm[tid]] = rhs[tid];
+  __syncthreads();
+  if (tid < n) xs[tid] = sv[tid] * xs[tid];
+  __syncthreads();
+  // ---- orthogonalisation against the gauge nullspaces from iteration 2 on (SOLVER_ORTHOGONALIZE_X_LATER, EnergyFunctional.cpp:977-981; BAHost::orthogonalize)
+  if (iteration >= 2 && S.nBasis > 0) {
+    if (tid < S.nBasis) { double dot = 0; const double* u = S.basis + (size_t)tid * n; for (int k = 0; k < n; k++) dot += u[k] * xs[k]; tv[tid] = dot; }
+    __syncthreads();
+    if (tid < n) { double proj = 0; for (int b = 0; b < S.nBasis; b++) proj += S.basis[(size_t)b * n + tid] * tv[b]; xs[tid] -= proj; }
+    __syncthreads();
+  }
+  if (tid < n) S.x_last[tid] = xs[tid];
+  // ---- resubstituteF_MT's inputs (BAHost::prepareResubstitute): xc, xAd[h F + t][c] = x_h . adHostF(:, c) + x_t . adTargetF(:, c) in fp32, sequential over r
+  if (tid < 4) V.X.xc[tid] = (float)xs[tid];
+  for (int o = tid; o < F * F * 8; o += BA_SOLVE_THREADS) {
+    const int c = o & 7, t = (o >> 3) % F, hh = (o >> 3) / F;
+    const size_t base = ((size_t)hh + (size_t)F * t) * 64;
+    float s1 = 0, s2 = 0;
+    for (int r = 0; r < 8; r++) { s1 += (float)xs[4 + 8 * hh + r] * S.adHostF[base + r * 8 + c]; s2 += (float)xs[4 + 8 * t + r] * S.adTargetF[base + r * 8 + c]; }
+    V.X.xAd[((size_t)F * hh + t) * 8 + c] = s1 + s2;
+  }
+  // ---- doStepFromBackup, frames and calibration (stepfac 1): value = backup + step, step = -x
+  if (tid < 4) {
+    const double stp = -xs[tid];
+    const double nv = S.c_value_backup[tid] + 1.0f * stp;
+    S.c_value[tid] = nv;
+    const double scaled = 50.0f * nv;
+    s_scal[tid] = scaled;
+    d[tid] = (double)(float)(nv - S.c_value_zero[tid]);   // cDeltaF of the stepped state
+  }
+  for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) {
+    const int f = i / 10, k = i % 10;
+    const double stp = k < 8 ? -xs[4 + 8 * f + k] : 0.0;
+    const double st = S.fr[f].state_backup[k] + (double)1.0f * stp;
+    S.fr[f].state[k] = st;
+    const float sc = (k < 6) ? 1.0f : ((k & 1) ? 1000.0f : 10.0f);   // SCALE_XI_*, SCALE_A (6, 8), SCALE_B (7, 9)
+    s_scaled[f][k] = sc * st;
+    if (k < 8) d[4 + 8 * f + k] = st - S.fr[f].state_zero[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // CalibHessian::setValue (BAHost::calibSetValue) and the K / K^-1 of setPrecalcValues, in float like the host
+    const float f0 = (float)s_scal[0], f1 = (float)s_scal[1], f2 = (float)s_scal[2], f3 = (float)s_scal[3];
+    V.W.fx = f0; V.W.fy = f1; V.W.cx = f2; V.W.cy = f3;
+    V.W.fxi = 1.0f / f0; V.W.fyi = 1.0f / f1; V.W.cxi = -f2 / f0; V.W.cyi = -f3 / f1;
+    const float K[9] = {f0, 0, f2, 0, f1, f3, 0, 0, 1};
+    const float a = K[0], e = K[4], c = K[2], ff = K[5];
+    const float det = a * (e * 1.0f - ff * 0.0f), invdet = 1.0f / det;
+    const float Ki[9] = {(e * 1.0f - ff * 0.0f) * invdet, (c * 0.0f - 0.0f * 1.0f) * invdet, (0.0f * ff - c * e) * invdet,
+                         (ff * 0.0f - 0.0f * 1.0f) * invdet, (a * 1.0f - c * 0.0f) * invdet, (c * 0.0f - a * ff) * invdet,
+                         (0.0f * 0.0f - e * 0.0f) * invdet, (0.0f * 0.0f - a * 0.0f) * invdet, (a * e - 0.0f * 0.0f) * invdet};
+    for (int i = 0; i < 9; i++) { s_K[i] = K[i]; s_Ki[i] = Ki[i]; }
+  }
+  if (tid >= 64 && tid < 64 + F) {   // FrameHessian::setState: PRE_worldToCam = exp(state_scaled) * worldToCam_evalPT (HessianBlocks.h:199-214)
+    const int f = tid - 64;
+    const Pose w = poseMul(poseExp(s_scaled[f]), S.fr[f].evalPT);
+    s_w2c[f] = w; s_c2w[f] = poseInv(w);
+  }
+  __syncthreads();
+  // ---- FrameFramePrecalc::set for the F (F - 1) ordered pairs (HessianBlocks.cpp:193-223; BAHost::setPrecalcValues): the step-dependent members
+  for (int o = tid; o < F * F; o += BA_SOLVE_THREADS) {
+    const int hh = o % F, t = o / F;
+    if (hh == t) continue;
+    const Pose l = poseMul(s_w2c[t], s_c2w[hh]);
+    double Rd[9];
+    quatToR(l.q, Rd);
+    float Rf[9], tf[3], KR[9], KRKi[9];
+    for (int i = 0; i < 9; i++) Rf[i] = (float)Rd[i];
+    for (int i = 0; i < 3; i++) tf[i] = (float)l.t[i];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR[r * 3 + c] = s_K[r * 3 + 0] * Rf[c] + s_K[r * 3 + 1] * Rf[3 + c] + s_K[r * 3 + 2] * Rf[6 + c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KRKi[r * 3 + c] = KR[r * 3 + 0] * s_Ki[c] + KR[r * 3 + 1] * s_Ki[3 + c] + KR[r * 3 + 2] * s_Ki[6 + c];
+    float* v = V.T.v[baPairIndex(hh, t, F)];
+    for (int i = 0; i < 9; i++) v[i] = KRKi[i];
+    for (int r = 0; r < 3; r++) v[9 + r] = s_K[r * 3 + 0] * tf[0] + s_K[r * 3 + 1] * tf[1] + s_K[r * 3 + 2] * tf[2];
+    double aff[2];
+    baAffFromTo(S.fr[hh].ab_exposure, S.fr[t].ab_exposure, s_scaled[hh][6], s_scaled[hh][7], s_scaled[t][6], s_scaled[t][7], aff);
+    v[12] = (float)aff[0]; v[13] = (float)aff[1];
+  }
+  // ---- E_M of the stepped state: delta . (2 bM + HM delta) (EnergyFunctional.cpp:332; BAHost::calcMEnergy), rows in index order
+  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {
+    double t = 0;
+    if (haveM) { t = 2 * S.bM[i]; for (int j = 0; j < n; j++) t += S.HM[(size_t)i * n + j] * d[j]; }
+    tv[i] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0;
+    if (haveM) for (int i = 0; i < n; i++) s += d[i] * tv[i];
+    // E_L, frame / calibration part (EnergyFunctional.cpp:349-369; BAHost::calcLEnergyFrames): delta_prior = state
+    double E = 0;
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) E += S.fr[f].state[i] * S.fr[f].prior[i] * S.fr[f].state[i];
+    float ec = 0;
+    for (int i = 0; i < 4; i++) { const float cd = (float)d[i]; ec += cd * S.cPriorF[i] * cd; }
+    S.newL = E + ec; S.newM = s;
+    V.D.lastL = S.lastL; V.D.lastM = S.lastM; V.D.newL = S.newL; V.D.newM = S.newM;
+    S.stepped = 1;
+  }
+}
+
+}  // namespace dmv

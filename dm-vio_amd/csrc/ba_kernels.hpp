@@ -333,11 +333,14 @@ __device__ __forceinline__ float seqSum8(const float v) {
 // gate: BA_GATE_REJECTED = this launch is the relinearisation that follows a rejected step (loadSateBackup + linearizeAll,
 // FullSystemOptimize.cpp:575-581): it returns at once when the step was accepted.  use_backup: the point part of loadSateBackup rides along
 // (idepth = idepth_zero = idepth_backup, written back by the group of the point's first residual).
-template <int MF>
-__global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
-                                                               const FrameStore fs, float* __restrict__ fullJ,
-                                                               const unsigned char* __restrict__ pt_mask, const BADecide D, const int gate, const int use_backup,
-                                                               const BAPreDynT<MF> T, const int use_dyn, const ResubArgsT<MF> X, const int do_resub) {
+// The body is shared by the single-window kernel (arguments by value: no upload between the host's step and the launch) and the batched kernel of the device-resident
+// loop (k_ba_linearize_b: arguments of window blockIdx.y read from device memory, where k_ba_solve wrote them).  Tv: the step-dependent precalc members per ordered pair,
+// xc / xAd: the back-substitution inputs; nblocks: workgroups of THIS window's linearisation (the arrive count of the decision pass).
+__device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const BAPrecalc* __restrict__ pre,
+                                                const FrameStore& fs, float* __restrict__ fullJ,
+                                                const unsigned char* __restrict__ pt_mask, const BADecide& D, const int gate, const int use_backup,
+                                                const float (*__restrict__ Tv)[14], const int use_dyn, const float* __restrict__ Xxc, const float* __restrict__ XxAd, const int do_resub,
+                                                const int nblocks) {
   if (baGateClosed(D.ctl, gate)) {
     if (D.publish && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&D.host->ticket, D.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
     const int hi = P.host[pi];
     BAPrecalc pc = pre[hi + W.F * ti];
     if (use_dyn) {
-      const float* __restrict__ dv = T.v[baPairIndex(hi, ti, W.F)];
+      const float* __restrict__ dv = Tv[baPairIndex(hi, ti, W.F)];
 #pragma unroll
       for (int k = 0; k < 9; k++) pc.KRKi[k] = dv[k];
       pc.Kt[0] = dv[9]; pc.Kt[1] = dv[10]; pc.Kt[2] = dv[11]; pc.aff0 = dv[12]; pc.aff1 = dv[13];
@@ -384,8 +387,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
       float bsum = P.bdSumF[pi];
       {
         float dotc = 0;
-        dotc += X.xc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += X.xc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
-        dotc += X.xc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += X.xc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
+        dotc += Xxc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += Xxc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
+        dotc += Xxc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += Xxc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
         bsum -= dotc;
       }
       const int grp = (threadIdx.x & 63) & ~7;
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
         const int rq = min(rb + idx, r1 - 1);
         const bool act = rb + idx < r1 && Rs.active[rq] != 0;
         const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
-        const float* __restrict__ xa = X.xAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
+        const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
         float d = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
@@ -557,13 +560,20 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, 
   __shared__ int s_last;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&D.ctl->cnt_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&D.ctl->cnt_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(nblocks - 1) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (threadIdx.x == 0) __hip_atomic_store(&D.ctl->cnt_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (D.mode == 3) baPackBlock(D, gridDim.x);
-  else baDecideBlock(D, gridDim.x, t_kernel0);
+  if (D.mode == 3) baPackBlock(D, nblocks);
+  else baDecideBlock(D, nblocks, t_kernel0);
+}
+template <int MF>
+__global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
+                                                               const FrameStore fs, float* __restrict__ fullJ,
+                                                               const unsigned char* __restrict__ pt_mask, const BADecide D, const int gate, const int use_backup,
+                                                               const BAPreDynT<MF> T, const int use_dyn, const ResubArgsT<MF> X, const int do_resub) {
+  baLinearizeBody(W, P, Rs, pre, fs, fullJ, pt_mask, D, gate, use_backup, T.v, use_dyn, X.xc, X.xAd, do_resub, (int)gridDim.x);
 }
 
 // the decisions of a linearisation whose points are sharded over ranks: one workgroup over the all-gathered records
@@ -579,7 +589,11 @@ __global__ void __launch_bounds__(1024) k_ba_publish_sys(const double* __restric
 
 // applyRes(true) for every active residual (Residuals.cpp:306-328): flips the applied-record selector.
 // mark_removed: the tail of FullSystem::linearizeAll(true) (FullSystemOptimize.cpp:176-212) — a residual that is not active after this applyRes is deleted from the graph
+__device__ __forceinline__ void baApplyBody(const int R, const BARes& Rs, const unsigned char* __restrict__ pt_mask, const int mark_removed);
 __global__ void __launch_bounds__(256) k_ba_apply(const int R, const BARes Rs, const unsigned char* __restrict__ pt_mask, const int mark_removed) {
+  baApplyBody(R, Rs, pt_mask, mark_removed);
+}
+__device__ __forceinline__ void baApplyBody(const int R, const BARes& Rs, const unsigned char* __restrict__ pt_mask, const int mark_removed) {
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= R) return;
   if (pt_mask && !pt_mask[Rs.point[ri]]) return;
@@ -622,8 +636,14 @@ __device__ __forceinline__ float seqAdd8(float s, const float v) {
 // belongs to exactly one lane of one group.  gate: see BACtl.
 // host_backup (may be NULL): host-coherent mirror of idepth_backup — doStepFromBackup's canbreak test sums |idepth_backup| over the points on the host, in
 // the reference's order (FullSystemOptimize.cpp:269-291), when the GTSAM branch can end the loop early
+__device__ __forceinline__ void baPointSumsBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const int backup, const int apply, const BACtl* __restrict__ ctl,
+                                                const int gate, float* __restrict__ host_backup);
 __global__ void __launch_bounds__(256) k_ba_point_sums(const BAWindow W, const BAPoints P, const BARes Rs, const int backup, const int apply, const BACtl* __restrict__ ctl,
                                                         const int gate, float* __restrict__ host_backup) {
+  baPointSumsBody(W, P, Rs, backup, apply, ctl, gate, host_backup);
+}
+__device__ __forceinline__ void baPointSumsBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const int backup, const int apply, const BACtl* __restrict__ ctl,
+                                                const int gate, float* __restrict__ host_backup) {
   if (baGateClosed(ctl, gate)) return;
   const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;
   if (pi >= W.N) return;   // group-uniform
@@ -1082,7 +1102,11 @@ struct AccumArgs {
   long long* ticks;   // optional [gridDim.x][2] start / end wall-clock stamps per block (DMVIO_HIP_BA_TIMING), else null
 };
 #define ACC_LDS_FLOATS (20 * SCC_STRIDE + 8)
+__device__ __forceinline__ void baAccumulateBody(const AccumArgs& A, const BARes& Rs, const BAPoints& P, const BACtl* __restrict__ ctl, const int gate);
 __global__ void __launch_bounds__(256) k_ba_accumulate(const AccumArgs A, const BARes Rs, const BAPoints P, const BACtl* __restrict__ ctl, const int gate) {
+  baAccumulateBody(A, Rs, P, ctl, gate);
+}
+__device__ __forceinline__ void baAccumulateBody(const AccumArgs& A, const BARes& Rs, const BAPoints& P, const BACtl* __restrict__ ctl, const int gate) {
   if (baGateClosed(ctl, gate)) return;
   __shared__ float s_buf[ACC_LDS_FLOATS];
   static_assert(ACC_LDS_FLOATS >= HT_TILE * HT_STRIDE + 8 && ACC_LDS_FLOATS >= 4 * 64 * SCD_STRIDE, "LDS carve-up");
@@ -1261,11 +1285,21 @@ __device__ __forceinline__ void stitchScWave(StitchWave& W, const int F, const i
   W.T1[e] = hh; W.T2[e] = th;
 }
 
+__device__ __forceinline__ void baStitchBody(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
+                                             const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE,
+                                             const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs& S,
+                                             const BACtl* __restrict__ ctl, const int gate);
 template <int MF>
 __global__ void __launch_bounds__(64 * MF) k_ba_stitch(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
                                                     const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE /* F*F x nsTop x 40 */,
                                                     const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs S,
                                                     const BACtl* __restrict__ ctl, const int gate) {
+  baStitchBody(F, nsTop, nsD, accTop, numTop, accD, numD, accE, adHost, adTarget, S, ctl, gate);
+}
+__device__ __forceinline__ void baStitchBody(const int F, const int nsTop, const int nsD, const float* __restrict__ accTop, const int* __restrict__ numTop,
+                                             const float* __restrict__ accD, const int* __restrict__ numD, const float* __restrict__ accE,
+                                             const double* __restrict__ adHost, const double* __restrict__ adTarget, const StitchBufs& S,
+                                             const BACtl* __restrict__ ctl, const int gate) {
   if (baGateClosed(ctl, gate)) return;
   extern __shared__ double s_dyn[];
   StitchWave* Ws = reinterpret_cast<StitchWave*>(s_dyn);

@@ -16,6 +16,7 @@
 #include "internal.h"
 #include "ba_kernels.hpp"
 #include "ba_host.hpp"
+#include "ba_batch_kernels.hpp"
 
 using namespace dmv;
 
@@ -157,6 +158,9 @@ struct dmvio_hip_ba {
   float* h_idepth_backup = nullptr;
   std::vector<dmvio_hip_ba_frame_view> vio_frames;
   hipEvent_t* prof = nullptr;        // dmvio_hip_ba_profile_chain: six events recorded between the launches of linearise -> per-point sums -> accumulate -> stitch -> gather
+  // dmvio_hip_ba_set_device_loop: dmvio_hip_ba_optimize runs the device-resident loop (a batch of one window) instead of the host-driven one
+  bool device_loop = false;
+  struct dmvio_hip_ba_batch* own_batch = nullptr;
 };
 #define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
 #define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
@@ -561,9 +565,11 @@ dmvio_hip_ba* dmvio_hip_ba_create(dmvio_hip_ctx* ctx) {
   if (const char* e = getenv("DMVIO_HIP_BA_TIMING")) b->timing = atoi(e) != 0;
   return b;
 }
+void dmvio_hip_ba_batch_destroy(struct dmvio_hip_ba_batch* B);
 void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
+  if (b->own_batch) { dmvio_hip_ba_batch_destroy(b->own_batch); b->own_batch = nullptr; }
   hipStreamSynchronize(b->stream);
   if (b->timing && b->tm_graph_n > 0)
     fprintf(stderr, "[dmvio_hip_ba] set_graph over %ld calls (us/call): drain + arena memset=%.1f host lists=%.1f allocation=%.1f uploads=%.1f pinned buffers + slot table=%.1f adjoints + wait=%.1f\n", b->tm_graph_n,
@@ -1663,8 +1669,17 @@ static int optimizeImpl(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_call
   if (vio && vio->postOptimization) { fillFrameViews(b); vio->postOptimization(vio->user, H.F, b->vio_frames.data(), H.c_value); }   // FullSystemOptimize.cpp:641
   return 0;
 }
+int dmvio_hip_ba_optimize_batch(struct dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
+struct dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_windows);
+void dmvio_hip_ba_batch_destroy(struct dmvio_hip_ba_batch* B);
 int dmvio_hip_ba_optimize(dmvio_hip_ba* b, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace /* 64x4 or NULL */) {
   BA_READY(b);
+  if (b->device_loop && !sharded(b)) {
+    if (!b->own_batch) b->own_batch = dmvio_hip_ba_batch_create(b->ctx, 1);
+    if (!b->own_batch) return -1;
+    dmvio_hip_ba* one = b;
+    return dmvio_hip_ba_optimize_batch(b->own_batch, 1, &one, mnumOptIts, rmse, finalEnergy, iterations, trace);
+  }
   return optimizeImpl(b, mnumOptIts, nullptr, nullptr, rmse, finalEnergy, iterations, trace);
 }
 // FullSystem::optimize with the reference's DEFAULT solver branch (settings.cpp:37 setting_useGTSAMIntegration = true): the same device-resident loop, the solve and
@@ -1695,4 +1710,320 @@ int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b_in, do
   return 0;
 }
 
+}  // extern "C"
+
+// ================================================================================================= device-resident Gauss-Newton loop, W windows per launch (round 5)
+// FullSystem::optimize (FullSystemOptimize.cpp:417-647) for W windows at once, the reference's non-GTSAM solver branch: per Gauss-Newton iteration the host enqueues ONE
+// fixed sequence of kernels for all windows (ba_batch_kernels.hpp) and never waits — the 68x68 solve, the frame step, the pair tables, the energies and the accept test run
+// on the device (k_ba_solve + the decision pass of the linearisation), every kernel of the chain takes its window from blockIdx.y and is gated on that window's own decision.
+// Two waits per call: behind the loop (the frame states come back, the host re-anchors the newest keyframe, FullSystemOptimize.cpp:596-603) and behind the final
+// fix-linearisation.  Windows of one call must hold the same number of keyframes (the adjoint stitch's workgroup shape); the caller groups them.
+struct dmvio_hip_ba_batch {
+  dmvio_hip_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  int cap = 0;
+  std::mutex mu;
+  BAWinDev* d_wins = nullptr;
+  BAWinDev* h_wins = nullptr;      // pinned
+  char* d_tab = nullptr;           // per window: [HM | bM | basis | adHostF | adTargetF] (uploaded) — stride tab_stride
+  char* h_tab = nullptr;           // pinned
+  char* d_out = nullptr;           // per window: [sys | trace (64 x 4) | x_last] (device-only / downloaded) — stride out_stride
+  double* h_trace = nullptr;       // pinned: cap x (256 + NMAX) doubles
+  size_t tab_stride = 0, out_stride = 0;
+  int exact_backsub = 0;
+  float last_ms[2] = {0, 0};       // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+static constexpr int BA_BATCH_NMAX = 4 + 8 * BA_MAXF_CAP;
+static size_t batchTabBytes() {
+  const size_t n = BA_BATCH_NMAX, F2 = (size_t)BA_MAXF_CAP * BA_MAXF_CAP;
+  return ((n * n + n + 7 * n) * sizeof(double) + 2 * F2 * 64 * sizeof(float) + 255) & ~(size_t)255;
+}
+static size_t batchOutBytes() {
+  const size_t n = BA_BATCH_NMAX;
+  return ((2 * (n * n + n) + 1 + 256 + n) * sizeof(double) + 255) & ~(size_t)255;
+}
+extern "C" {
+dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_windows) {
+  if (!ctx || max_windows < 1 || max_windows > 4096) { failmsg("ba_batch_create: bad argument"); return nullptr; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { failmsg("ba_batch_create: hipSetDevice failed"); return nullptr; }
+  dmvio_hip_ba_batch* B = new dmvio_hip_ba_batch();
+  B->ctx = ctx; B->cap = max_windows;
+  B->tab_stride = batchTabBytes(); B->out_stride = batchOutBytes();
+  bool ok = hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->d_wins, sizeof(BAWinDev) * max_windows) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&B->h_wins, sizeof(BAWinDev) * max_windows, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->d_tab, B->tab_stride * max_windows) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&B->h_tab, B->tab_stride * max_windows, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&B->d_out, B->out_stride * max_windows) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&B->h_trace, sizeof(double) * (256 + BA_BATCH_NMAX) * max_windows, hipHostMallocDefault) == hipSuccess;
+  for (int k = 0; k < 4 && ok; k++) ok = hipEventCreate(&B->ev[k]) == hipSuccess;
+  if (ok) ok = hipMemset(B->d_out, 0, B->out_stride * max_windows) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+  if (!ok) { failmsg("ba_batch_create: device / pinned allocation failed"); dmvio_hip_ba_batch_destroy(B); return nullptr; }
+  return B;
+}
+void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* B) {
+  if (!B) return;
+  hipSetDevice(B->ctx->device);
+  if (B->stream) { hipStreamSynchronize(B->stream); hipStreamDestroy(B->stream); }
+  if (B->d_wins) hipFree(B->d_wins);
+  if (B->h_wins) hipHostFree(B->h_wins);
+  if (B->d_tab) hipFree(B->d_tab);
+  if (B->h_tab) hipHostFree(B->h_tab);
+  if (B->d_out) hipFree(B->d_out);
+  if (B->h_trace) hipHostFree(B->h_trace);
+  for (int k = 0; k < 4; k++) if (B->ev[k]) hipEventDestroy(B->ev[k]);
+  delete B;
+}
+// 1: the back substitution of the 68x68 solve in the host's order (one dependent chain of n^2 / 2 subtractions: x bit-identical to BAHost::ldltSolveTransposed, ~10 us more per
+// iteration); 0 (default): column-oriented — the same terms in another association (measured |dx| <= 1e-12 relative, tests/test_ba_batch_gpu.py)
+int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* B, int on) {
+  if (!B) return failmsg("ba_batch: null handle");
+  std::lock_guard<std::mutex> lk(B->mu);
+  B->exact_backsub = on ? 1 : 0;
+  return 0;
+}
+int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* B, float ms2[2]) {
+  if (!B || !ms2) return failmsg("ba_batch: null argument");
+  std::lock_guard<std::mutex> lk(B->mu);
+  ms2[0] = B->last_ms[0]; ms2[1] = B->last_ms[1];
+  return 0;
+}
+}  // extern "C"
+
+static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba* const* hs, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace,
+                              double* x_last) {
+  const int F = hs[0]->H.F, n = hs[0]->H.n(), F2 = F * F, tot = 2 * (n * n + n);
+  if (F < 2) { for (int w = 0; w < Wn; w++) { if (rmse) rmse[w] = 0; if (iterations) iterations[w] = 0; if (finalEnergy) finalEnergy[w] = 0; } return 0; }
+  if (F < 3) mnumOptIts = 20;
+  if (F < 4) mnumOptIts = 15;
+  hipStream_t s = B->stream;
+  struct StreamSwap {   // the handles' own entry points (table uploads, the reset kernel) enqueue on the batch's stream for the duration of the call
+    std::vector<std::pair<dmvio_hip_ba*, hipStream_t>> saved;
+    ~StreamSwap() { for (auto& kv : saved) kv.first->stream = kv.second; }
+  } swap;
+  int gx_lin = 0, gx_pt8 = 0, gx_acc = 0, gx_res = 0;
+  const int n_gather = (tot + 256) / 256, n_stitch = F + F2;
+  for (int w = 0; w < Wn; w++) {
+    dmvio_hip_ba* b = hs[w];
+    if (b->stream != s) { HIPCHK(hipStreamSynchronize(b->stream)); swap.saved.emplace_back(b, b->stream); b->stream = s; }
+    BAHost& H = b->H;
+    b->vio = nullptr; b->vio_opt = nullptr; b->dynW = 1.0; H.gtsam = false;
+    b->pending_reject = false; b->pending_trace = -1; b->sums_fresh = false; b->sys_ready = false;
+    if (int r = resolveTh(b)) return r;
+    hipLaunchKernelGGL(k_ba_reset_oob, dim3((H.R + 255) / 256), dim3(256), 0, s, H.R, b->Rs);   // activate_all
+    if (int r = uploadWindowTables(b)) return r;
+    if (int r = uploadThresholds(b)) return r;
+    H.getNullspaces();
+    H.prepareOrthogonalize();
+    // ---- the window's record
+    BAWinDev& V = B->h_wins[w];
+    memset(&V, 0, sizeof(V));
+    fillWindow(b);
+    V.W = b->W; V.Wb = b->W;
+    V.P = b->P; V.Rs = b->Rs; V.pre = b->d_pre;
+    V.D = makeDecide(b, 0, true, false);
+    dynFromHost(H, V.T); V.Tb = V.T;
+    b->dyn_cur = V.T;
+    {
+      AccumArgs& A = V.A;
+      A.F = F; A.N = H.N; A.nsTop = b->nsTop; A.nsD = b->nsD; A.nsC = b->nsC;
+      A.top_begin = b->d_top_begin; A.top_members = b->d_top_members; A.scd_begin = b->d_scd_begin; A.scd_members = b->d_scd_members;
+      A.accTop = b->d_accTop; A.accD = b->d_accD; A.accE = b->d_accE; A.accC = b->d_accC; A.numTop = b->d_numTop; A.numD = b->d_numD;
+      A.ticks = nullptr;
+    }
+    V.SB = b->SB; V.adHost = b->d_adHost; V.adTarget = b->d_adTarget;
+    char* out = B->d_out + B->out_stride * (size_t)w;
+    V.sys = reinterpret_cast<double*>(out);
+    V.ctl = b->d_ctl;
+    V.n_lin_blocks = b->n_lin_blocks; V.n_pt8_blocks = b->n_pt8_blocks; V.n_acc_blocks = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
+    V.n_res_blocks = (H.R + 255) / 256; V.n_gather_blocks = n_gather; V.n_stitch_blocks = n_stitch;
+    gx_lin = std::max(gx_lin, V.n_lin_blocks); gx_pt8 = std::max(gx_pt8, V.n_pt8_blocks); gx_acc = std::max(gx_acc, V.n_acc_blocks); gx_res = std::max(gx_res, V.n_res_blocks);
+    BASolveDev& S = V.S;
+    S.F = F; S.n = n; S.stepped = 0; S.iterations_done = 0; S.n_accepted = 0; S.exact_backsub = B->exact_backsub;
+    S.lambda = 1e-5;
+    S.lastL = H.calcLEnergyFrames(); S.lastM = H.calcMEnergy(); S.newL = S.lastL; S.newM = S.lastM;
+    for (int i = 0; i < 4; i++) { S.c_value[i] = H.c_value[i]; S.c_value_zero[i] = H.c_value_zero[i]; S.c_value_backup[i] = H.c_value[i]; S.cPrior[i] = H.cPrior[i]; S.cPriorF[i] = H.cPriorF[i]; }
+    for (int f = 0; f < F; f++) {
+      BAFrameDev& q = S.fr[f]; const BAFrameHost& h = H.fr[f];
+      q.evalPT = h.evalPT; q.ab_exposure = h.ab_exposure;
+      for (int i = 0; i < 10; i++) { q.state[i] = h.state[i]; q.state_zero[i] = h.state_zero[i]; q.state_backup[i] = h.state[i]; }
+      for (int i = 0; i < 8; i++) q.prior[i] = h.prior[i];
+    }
+    // ---- the uploaded tables: [HM | bM | basis | adHostF | adTargetF]
+    char* tab = B->h_tab + B->tab_stride * (size_t)w;
+    char* dtab = B->d_tab + B->tab_stride * (size_t)w;
+    double* tHM = reinterpret_cast<double*>(tab);
+    const bool haveM = H.HM.size() == (size_t)n * n;
+    S.haveM = haveM ? 1 : 0;
+    if (haveM) { memcpy(tHM, H.HM.data(), sizeof(double) * n * n); memcpy(tHM + (size_t)n * n, H.bM.data(), sizeof(double) * n); }
+    double* tBasis = tHM + (size_t)n * n + n;
+    S.nBasis = (int)H.orthoBasis.size();
+    for (int k = 0; k < S.nBasis; k++) memcpy(tBasis + (size_t)k * n, H.orthoBasis[k].data(), sizeof(double) * n);
+    float* tAd = reinterpret_cast<float*>(tBasis + 7 * (size_t)n);
+    memcpy(tAd, H.adHostF.data(), sizeof(float) * F2 * 64); memcpy(tAd + (size_t)F2 * 64, H.adTargetF.data(), sizeof(float) * F2 * 64);
+    S.HM = reinterpret_cast<const double*>(dtab); S.bM = S.HM + (size_t)n * n; S.basis = S.bM + n;
+    S.adHostF = reinterpret_cast<const float*>(S.basis + 7 * (size_t)n); S.adTargetF = S.adHostF + (size_t)F2 * 64;
+    S.trace = V.sys + tot + 1; S.x_last = S.trace + 256;
+    // the initial state's row of the trace is written by the host below (its energy comes out of the initial linearisation)
+  }
+  HIPCHK(hipGetLastError());
+  const size_t used_tab = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float);
+  if (used_tab > B->tab_stride) return failmsg("ba_optimize_batch: table slab too small");
+  HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(B->d_tab, B->h_tab, B->tab_stride * (size_t)(Wn - 1) + used_tab, hipMemcpyHostToDevice, s));
+  const FrameStore fs = B->ctx->fs;
+  const BAWinDev* dw = B->d_wins;
+  const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n);
+  auto chain = [&](const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
+    hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, Wn), dim3(256), 0, s, dw, backup, apply, gate);
+    hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, Wn), dim3(256), 0, s, dw, gate);
+    hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, Wn), dim3(64 * F), sizeof(StitchWave) * F, s, dw, gate);
+    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, Wn), dim3(256), 0, s, dw, gate);
+    else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, Wn), dim3(256), 0, s, dw, gate);
+  };
+  HIPCHK(hipEventRecord(B->ev[0], s));
+  // ---- initial linearisation, applyRes and the first system (FullSystemOptimize.cpp:450-470)
+  hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_INITIAL);
+  hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 0, (int)BA_GATE_ALWAYS);
+  chain(1, 0, BA_GATE_ALWAYS);
+  // ---- the loop (:485-586): nothing in it waits for the host
+  for (int it = 0; it < mnumOptIts; it++) {
+    hipLaunchKernelGGL(k_ba_solve, dim3(Wn), dim3(BA_SOLVE_THREADS), solveLds, s, B->d_wins, it, 0);
+    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_STEPPED);
+    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_RESTORE);
+    if (it < mnumOptIts - 1) chain(1, 1, BA_GATE_ACCEPTED);
+    else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
+  }
+  hipLaunchKernelGGL(k_ba_solve, dim3(Wn), dim3(BA_SOLVE_THREADS), solveLds, s, B->d_wins, mnumOptIts, 1);   // settle the last decision
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(B->ev[1], s));
+  HIPCHK(hipMemcpyAsync(B->h_wins, B->d_wins, sizeof(BAWinDev) * Wn, hipMemcpyDeviceToHost, s));
+  for (int w = 0; w < Wn; w++)   // [trace (64 x 4) | x_last] behind the window's system
+    HIPCHK(hipMemcpyAsync(B->h_trace + (size_t)(256 + BA_BATCH_NMAX) * w, reinterpret_cast<const double*>(B->d_out + B->out_stride * (size_t)w) + tot + 1, sizeof(double) * (256 + n),
+                          hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  // ---- back on the host: the optimised states, then the newest keyframe's new evaluation point (:596-603) and the final fix-linearisation (:604-609)
+  for (int w = 0; w < Wn; w++) {
+    dmvio_hip_ba* b = hs[w];
+    BAHost& H = b->H;
+    const BAWinDev& V = B->h_wins[w];
+    const BASolveDev& S = V.S;
+    H.calibSetValue(S.c_value);
+    for (int i = 0; i < 4; i++) H.c_value_backup[i] = S.c_value_backup[i];
+    for (int f = 0; f < F; f++) {
+      BAHost::frameSetState(H.fr[f], S.fr[f].state);
+      for (int i = 0; i < 10; i++) H.fr[f].state_backup[i] = S.fr[f].state_backup[i];
+    }
+    const double* tr = B->h_trace + (size_t)(256 + BA_BATCH_NMAX) * w;
+    const int done = S.iterations_done;
+    b->iterations_done = done;
+    for (int k = 0; k <= done && k < 64; k++) for (int c = 0; c < 4; c++) b->trace[k][c] = tr[4 * k + c];   // row 0: the initial state (written by the first solve)
+    b->H.lastX.assign(tr + 256, tr + 256 + n);
+    if (x_last) memcpy(x_last + (size_t)BA_BATCH_NMAX * w, tr + 256, sizeof(double) * n);
+    H.resInA = (int)0;   // filled from the system below
+    BAFrameHost& last = H.fr[F - 1];
+    double newStateZero[10] = {0, 0, 0, 0, 0, 0, last.state[6], last.state[7], 0, 0};
+    last.evalPT = last.w2c;
+    BAHost::frameSetState(last, newStateZero);
+    BAHost::frameSetStateZero(last, newStateZero);
+    H.setAdjointsF();
+    if (int r = uploadAdjoints(b)) return r;
+    H.setPrecalcValues();
+    if (int r = uploadWindowTables(b)) return r;
+    fillWindow(b);
+    BAWinDev& V2 = B->h_wins[w];
+    V2.W = b->W; V2.pre = b->d_pre;
+    dynFromHost(H, V2.T); b->dyn_cur = V2.T;
+    b->th_dirty = false; b->th_pending = false;   // the thresholds live on the device; the newest one is read back behind the final linearisation
+  }
+  HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(B->ev[2], s));
+  hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_FINAL);
+  hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 1, (int)BA_GATE_ALWAYS);   // applyRes + linearizeAll(true)'s removal of inactive residuals
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(B->ev[3], s));
+  // resInA of the last accumulation (the count ef->resInA holds after the loop): the last element of every window's system
+  for (int w = 0; w < Wn; w++)
+    HIPCHK(hipMemcpyAsync(&B->h_trace[(size_t)(256 + BA_BATCH_NMAX) * w], reinterpret_cast<const double*>(B->d_out + B->out_stride * (size_t)w) + tot, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipEventElapsedTime(&B->last_ms[0], B->ev[0], B->ev[1]));
+  HIPCHK(hipEventElapsedTime(&B->last_ms[1], B->ev[2], B->ev[3]));
+  for (int w = 0; w < Wn; w++) {
+    dmvio_hip_ba* b = hs[w];
+    BAHost& H = b->H;
+    H.resInA = (int)B->h_trace[(size_t)(256 + BA_BATCH_NMAX) * w];
+    const double fe = b->h_res->E[0];
+    H.fr[F - 1].frameEnergyTH = b->h_res->th[0];
+    b->final_energy = fe;
+    if (rmse) rmse[w] = sqrtf((float)(fe / (8 * H.resInA)));
+    if (finalEnergy) finalEnergy[w] = fe;
+    if (iterations) iterations[w] = b->iterations_done;
+    if (trace) memcpy(trace + (size_t)256 * w, b->trace, sizeof(b->trace));
+    b->sums_fresh = false; b->sys_ready = false;
+    HIPCHK(b->bounce.finish(s));   // the staging area of this call's uploads is free again
+  }
+  return 0;
+}
+
+extern "C" {
+// windows[W]: handles of the batch's context, each with its window set (set_window + set_graph), all distinct.  rmse / finalEnergy / iterations: W entries each (may be
+// NULL); trace: W x 64 x 4 doubles or NULL ([E_A, E_L, E_M, accepted] per iteration, row 0 = the initial state).  Windows with different keyframe counts run as separate
+// groups, one after the other.  Every window's result is what a batch of that window alone gives, bit for bit (no arithmetic crosses windows).
+int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace) {
+  if (!B || !windows || W < 1) return failmsg("ba_optimize_batch: bad argument");
+  if (W > B->cap) return failmsg("ba_optimize_batch: more windows than the batch was created for");
+  std::lock_guard<std::mutex> lkB(B->mu);
+  HIPCHK(hipSetDevice(B->ctx->device));
+  // the handles' locks, in address order (two batches sharing handles cannot deadlock)
+  std::vector<dmvio_hip_ba*> order(windows, windows + W);
+  std::sort(order.begin(), order.end());
+  for (int i = 0; i < W; i++) {
+    if (!order[i]) return failmsg("ba_optimize_batch: null window");
+    if (i > 0 && order[i] == order[i - 1]) return failmsg("ba_optimize_batch: a window appears twice");
+    if (order[i]->ctx != B->ctx) return failmsg("ba_optimize_batch: a window belongs to another context");
+  }
+  std::vector<std::unique_lock<std::recursive_mutex>> locks;
+  for (dmvio_hip_ba* b : order) locks.emplace_back(b->mu);
+  for (int i = 0; i < W; i++) {
+    dmvio_hip_ba* b = windows[i];
+    if (!b->graph_ready) return failmsg("ba_optimize_batch: set_window + set_graph first");
+    if (sharded(b)) return failmsg("ba_optimize_batch: a window sharded over ranks cannot join a batch");
+  }
+  // groups of equal keyframe count, in the caller's order
+  std::vector<char> doneW(W, 0);
+  for (int i = 0; i < W; i++) {
+    if (doneW[i]) continue;
+    std::vector<int> idx;
+    for (int j = i; j < W; j++) if (!doneW[j] && windows[j]->H.F == windows[i]->H.F) { idx.push_back(j); doneW[j] = 1; }
+    const int Wn = (int)idx.size();
+    std::vector<dmvio_hip_ba*> hs(Wn);
+    std::vector<float> r(Wn); std::vector<double> fe(Wn), tr((size_t)256 * Wn); std::vector<int> its(Wn);
+    for (int k = 0; k < Wn; k++) hs[k] = windows[idx[k]];
+    if (int rc = optimizeBatchGroup(B, Wn, hs.data(), mnumOptIts, r.data(), fe.data(), its.data(), tr.data(), nullptr)) return rc;
+    for (int k = 0; k < Wn; k++) {
+      if (rmse) rmse[idx[k]] = r[k];
+      if (finalEnergy) finalEnergy[idx[k]] = fe[k];
+      if (iterations) iterations[idx[k]] = its[k];
+      if (trace) memcpy(trace + (size_t)256 * idx[k], tr.data() + (size_t)256 * k, sizeof(double) * 256);
+    }
+  }
+  return 0;
+}
+// dmvio_hip_ba_optimize of this handle through the device-resident loop (a batch of one window, created on first use): no PCIe poll per iteration.  The host-driven loop
+// (default) stays the reference for the hook branch (dmvio_hip_ba_optimize_vio), which needs the host in every iteration anyway.
+int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* b, int on) {
+  if (!b) return failmsg("ba: null handle");
+  BA_LOCK(b);
+  b->device_loop = on != 0;
+  return 0;
+}
+// the last solve's x (n = 4 + 8F doubles, MINUS the step: EnergyFunctional::lastX) of the last optimize / gn_iteration / solve of this window
+int dmvio_hip_ba_get_last_x(dmvio_hip_ba* b, double* x_out) {
+  if (!b || !x_out) return failmsg("ba_get_last_x: null argument");
+  BA_LOCK(b);
+  if ((int)b->H.lastX.size() != b->H.n()) return failmsg("ba_get_last_x: no solve yet");
+  memcpy(x_out, b->H.lastX.data(), sizeof(double) * b->H.n());
+  return 0;
+}
 }  // extern "C"

@@ -72,7 +72,9 @@ struct DmvBounce {
       size_t j = i;
       while (j + 1 < group.size()) {
         const size_t step = (group[j].bytes + 255) & ~(size_t)255;
-        if (group[j + 1].off != group[j].off + step || group[j + 1].dst != group[j].dst + step) break;
+        // merged only between arena granules (256-byte aligned destinations): the padding copied along is then the unused tail of the previous allocation,
+        // never live data of an array that holds both pieces
+        if (group[j + 1].off != group[j].off + step || group[j + 1].dst != group[j].dst + step || ((size_t)group[j].dst & 255) || ((size_t)group[j + 1].dst & 255)) break;
         j++;
       }
       hipError_t e = hipMemcpyAsync(group[i].dst, h + group[i].off, group[j].off + group[j].bytes - group[i].off, hipMemcpyHostToDevice, s);

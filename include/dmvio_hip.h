@@ -489,6 +489,24 @@ typedef struct dmvio_hip_ba_vio_options {
 } dmvio_hip_ba_vio_options;
 int dmvio_hip_ba_optimize_vio(dmvio_hip_ba* ba, int mnumOptIts, const dmvio_hip_ba_callbacks* cb, const dmvio_hip_ba_vio_options* opt, float* rmse, double* finalEnergy,
                               int* iterations, double* trace);
+/* ---- Device-resident Gauss-Newton loop, W windows per launch (round 5).  FullSystem::optimize (FullSystemOptimize.cpp:417-647, the non-GTSAM solver branch
+ * EnergyFunctional.cpp:971-973) for W independent windows at once: per iteration ONE sequence of kernels serves all windows (each kernel takes its window from blockIdx.y
+ * and is gated on that window's own accept / reject decision), the 68x68 solve, the frame step, FrameFramePrecalc, E_L / E_M and the accept test run on the device — no
+ * host round trip per iteration, two waits per call.  windows[W]: distinct handles of the batch's context, each with its window set; windows with different keyframe
+ * counts run as separate groups.  rmse / finalEnergy / iterations: W entries (may be NULL); trace: W x 64 x 4 or NULL.  A window's result does not depend on the
+ * other windows of the call (bit-identical to a batch of one).  Against dmvio_hip_ba_optimize's host-driven loop the device loop differs in the elementary functions of the
+ * frame step (device sin / cos / exp within 1 ulp of the C library's) and, unless dmvio_hip_ba_batch_set_exact_backsub(1), in the association of the back substitution. */
+typedef struct dmvio_hip_ba_batch dmvio_hip_ba_batch;
+dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_windows);
+void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* batch);
+int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* batch, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
+int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* batch, int on);
+/* HIP-event times of the last dmvio_hip_ba_optimize_batch call on the batch's stream: [0] initial chain + all iterations, [1] the final fix-linearisation (ms) */
+int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* batch, float ms2[2]);
+/* dmvio_hip_ba_optimize of this handle through the device-resident loop (a batch of one); 0 (default) = the host-driven loop */
+int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* ba, int on);
+/* EnergyFunctional::lastX of the window's last solve (n = 4 + 8F doubles; x = MINUS the step) */
+int dmvio_hip_ba_get_last_x(dmvio_hip_ba* ba, double* x_out);
 int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b, double* x_out);
 /* the same with the signature of dmvio_hip_ba_callbacks::computeBAUpdate (user, lambda, HNoLambda, frames, calib_value ignored): usable as the hook itself */
 int dmvio_hip_ba_hook_ldlt(void* user, int n, const double* HPassed, const double* b, double lambda, const double* HNoLambda, int F, const dmvio_hip_ba_frame_view* frames,

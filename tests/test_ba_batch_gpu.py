@@ -1,0 +1,132 @@
+"""The device-resident Gauss-Newton loop of the sliding-window BA and its batched form (round 5: csrc/ba_batch_kernels.hpp, dmvio_hip_ba_optimize_batch): FullSystem::optimize
+(FullSystemOptimize.cpp:417-647) with the 68x68 solve (EnergyFunctional.cpp:841-996), doStepFromBackup, FrameFramePrecalc, E_L / E_M and the accept test ON THE DEVICE, W windows
+per launch sequence.  Checked against (i) the oracle (= the reference's arithmetic, same bars as test_ba_gpu.py::test_optimize_parity), (ii) the library's host-driven loop
+(the same window, same kernels for the photometric part: the two loops differ in the elementary functions of the frame step and, by default, in the association of the back
+substitution), (iii) itself: a window's result must not depend on what else is in the batch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx_with(pkg, case, n_slots=None):
+    F = case["n_frames"]
+    ctx = pkg.Context(case["w"], case["h"], n_slots=n_slots or F)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+    return ctx
+
+
+def _poses(ba, F):
+    return np.stack([np.concatenate(ba.frame_pose(k)[:2]) for k in range(F)])
+
+
+@pytest.mark.parametrize("accumulators", [1, None])
+def test_device_loop_against_oracle_and_host_loop(pkg, oracle, synth, gpu_required, accumulators):
+    """One window (BASELINE config 3's shape: 8 keyframes, 2000 points, ~12.8k residuals) through dmvio_hip_ba_optimize with the device-resident loop: the oracle's accept
+    sequence, energies within 1e-4, poses within 1e-3 m (north_star); against the host-driven loop of the same library the energy trace within 1e-9 relative and the solve's x of
+    the last iteration within 1e-9 of its norm (exact back substitution: within 1e-11)."""
+    case = synth.ba_case(512, 512, n_frames=8, n_points=2000, seed=4321)
+    ctx = _ctx_with(pkg, case)
+    F = 8
+    W = oracle.BAWindow(case)
+    ro = W.optimize(6)
+    host = pkg.BundleAdjusterHip(ctx, accumulators=accumulators); host.set_case(case, list(range(F)))
+    rh = host.optimize(6)
+    dev = pkg.BundleAdjusterHip(ctx, accumulators=accumulators); dev.set_case(case, list(range(F))); dev.set_device_loop(True)
+    rd = dev.optimize(6)
+    assert rd["iterations"] == ro["iterations"] == 6
+    assert np.array_equal(rd["trace"][:, 3], ro["trace"][:, 3]), (rd["trace"], ro["trace"])
+    assert np.allclose(rd["trace"][:, 0], ro["trace"][:, 0], rtol=1e-4)
+    assert abs(rd["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"] and abs(rd["rmse"] - ro["rmse"]) <= 1e-4 * ro["rmse"]
+    for k in range(F):
+        pg, ag, _ = dev.frame_pose(k); po, ao, _ = W.frame_pose(k)
+        assert np.linalg.norm(pg[:3] - po[:3]) < 1e-3 and np.allclose(ag, ao, atol=1e-3)
+    # device loop vs host loop
+    assert np.array_equal(rd["trace"][:, 3], rh["trace"][:, 3])
+    dE = np.abs(rd["trace"][:, :3] - rh["trace"][:, :3]) / np.maximum(np.abs(rh["trace"][:, :3]), 1e-30)
+    xd, xh = dev.last_x(), host.last_x()
+    dx = np.abs(xd - xh).max() / np.abs(xh).max()
+    dp = np.abs(_poses(dev, F) - _poses(host, F)).max()
+    ig, _ = dev.point_state(); ih, _ = host.point_state()
+    print("device loop vs host loop (accumulators %s): trace within %.2e relative, last x within %.2e of its largest entry, poses / affine within %.2e, idepth within %.2e; "
+          "final energy %.9g vs %.9g (oracle %.9g)" % (accumulators, dE.max(), dx, dp, np.abs(ig - ih).max(), rd["finalEnergy"], rh["finalEnergy"], ro["finalEnergy"]))
+    assert dE.max() < 1e-7 and dx < 1e-6 and dp < 1e-8
+    assert abs(rd["finalEnergy"] - rh["finalEnergy"]) <= 1e-7 * rh["finalEnergy"]
+    # the exact back substitution (the host's order)
+    ex = pkg.BundleAdjusterHip(ctx, accumulators=accumulators); ex.set_case(case, list(range(F)))
+    B = pkg.BundleAdjusterBatch(ctx, 1); B.set_exact_backsub(True)
+    re_ = B.optimize([ex], 6)[0]
+    dxe = np.abs(ex.last_x() - xh).max() / np.abs(xh).max()
+    print("exact back substitution: last x within %.2e; default association within %.2e" % (dxe, dx))
+    assert np.array_equal(re_["trace"][:, 3], rh["trace"][:, 3]) and dxe < 1e-7
+    for o in (host, dev, ex, B):
+        o.close()
+    ctx.close()
+
+
+def test_first_solve_of_the_device_loop_equals_the_host_solve_bitwise(pkg, synth, gpu_required):
+    """One iteration from the same state: the device's x (k_ba_solve: assembly, Jacobi scaling, pivot order, LDL^T, forward substitution, exact back substitution) against the
+    host's (BAHost::solveSystem + ldltSolveTransposed) — the same system, no frame step in between, so every operation is specified: bit for bit.  The default back
+    substitution (column-oriented) is bounded against it."""
+    case = synth.ba_case(320, 256, n_frames=6, n_points=500, hosts_share=(120, 110, 100, 90, 80, 0), seed=11)
+    ctx = _ctx_with(pkg, case)
+    F = 6
+    host = pkg.BundleAdjusterHip(ctx, accumulators=1); host.set_case(case, list(range(F)))
+    host.optimize(1); xh = host.last_x()
+    ex = pkg.BundleAdjusterHip(ctx, accumulators=1); ex.set_case(case, list(range(F)))
+    B = pkg.BundleAdjusterBatch(ctx, 1); B.set_exact_backsub(True)
+    B.optimize([ex], 1); xe = ex.last_x()
+    fa = pkg.BundleAdjusterHip(ctx, accumulators=1); fa.set_case(case, list(range(F)))
+    B.set_exact_backsub(False)
+    B.optimize([fa], 1); xf = fa.last_x()
+    print("first solve: exact back substitution differs from the host's x in %d of %d entries (max %.2e); column-oriented: max %.2e relative to the largest entry"
+          % (int((xe != xh).sum()), len(xh), np.abs(xe - xh).max(), np.abs(xf - xh).max() / np.abs(xh).max()))
+    assert np.array_equal(xe, xh)
+    assert np.abs(xf - xh).max() <= 1e-12 * np.abs(xh).max()
+    for o in (host, ex, fa, B):
+        o.close()
+    ctx.close()
+
+
+def test_batched_windows_equal_single_window_calls_bitwise(pkg, synth, gpu_required):
+    """W = 5 windows in one dmvio_hip_ba_optimize_batch call — different sizes, one of them converged (its steps get rejected: the gated restore path), two keyframe counts
+    (grouped by the library) — against the same windows optimised one at a time: traces, poses, affine parameters, inverse depths bit for bit."""
+    cases = [synth.ba_case(320, 256, n_frames=6, n_points=500, hosts_share=(120, 110, 100, 90, 80, 0), seed=11),
+             synth.ba_case(320, 256, n_frames=6, n_points=300, hosts_share=(80, 70, 60, 50, 40, 0), seed=12),
+             synth.ba_case(320, 256, n_frames=4, n_points=150, hosts_share=(60, 50, 40, 0), seed=7),
+             synth.ba_case(320, 256, n_frames=6, n_points=400, hosts_share=(100, 90, 80, 70, 60, 0), seed=13),
+             synth.ba_case(320, 256, n_frames=4, n_points=200, hosts_share=(80, 70, 50, 0), seed=8)]
+    ctx = pkg.Context(320, 256, n_slots=32)
+    slots = []
+    nxt = 0
+    for cs in cases:
+        sl = list(range(nxt, nxt + cs["n_frames"])); nxt += cs["n_frames"]
+        for k, s in enumerate(sl):
+            ctx.frame_upload(s, cs["imgs"][k])
+        slots.append(sl)
+
+    def fresh(i, pre=False):
+        ba = pkg.BundleAdjusterHip(ctx); ba.set_case(cases[i], slots[i])
+        if pre:
+            ba.set_device_loop(True); ba.optimize(12)      # window 3 enters the comparison converged: most of its steps are rejected
+        return ba
+    B1 = pkg.BundleAdjusterBatch(ctx, 1); B5 = pkg.BundleAdjusterBatch(ctx, 8)
+    single = [fresh(i, pre=(i == 3)) for i in range(5)]
+    rs = [B1.optimize([b], 6)[0] for b in single]
+    batch = [fresh(i, pre=(i == 3)) for i in range(5)]
+    rb = B5.optimize(batch, 6)
+    n_rej = 0
+    for i in range(5):
+        F = cases[i]["n_frames"]
+        assert rs[i]["iterations"] == rb[i]["iterations"]
+        assert np.array_equal(rs[i]["trace"], rb[i]["trace"]), i
+        assert rs[i]["finalEnergy"] == rb[i]["finalEnergy"] and rs[i]["rmse"] == rb[i]["rmse"], i
+        assert np.array_equal(_poses(single[i], F), _poses(batch[i], F)), i
+        assert np.array_equal(single[i].point_state()[0], batch[i].point_state()[0]), i
+        n_rej += int((rb[i]["trace"][1:, 3] == 0).sum())
+    assert n_rej >= 1, "no rejected step in the batch: the gated restore path was not exercised"
+    print("batch of 5 windows (F = 6, 6, 4, 6, 4) == 5 single calls bit for bit; %d rejected steps among them; loop %.3f ms, final linearisation %.3f ms" % ((n_rej,) + B5.last_ms()))
+    for o in single + batch + [B1, B5]:
+        o.close()
+    ctx.close()
