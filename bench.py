@@ -980,6 +980,57 @@ def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, d
                      "accepted Gauss-Newton iterations of all threads / wall time.  `ba.value` is the K = 1 latency figure of the same call" % M)
 
 
+def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev):
+    """W windows per launch sequence on the device-resident Gauss-Newton loop (dmvio_hip_ba_optimize_batch): the 68x68 solve, the frame step and the accept test run on the
+    device, every kernel of the chain takes its window from blockIdx.y — the BA analogue of the tracker's batch.  All windows are set up before the timed region; timed: ONE
+    dmvio_hip_ba_optimize_batch(W windows, 6 iterations) call (host wall clock) and, inside it, the loop by HIP events on the batch's stream.  value = accepted iterations of all
+    windows / wall time.  W = 1 is the device loop's latency figure for a single window (`ba.value` is the host-driven loop's)."""
+    slots = list(range(F))
+    rows = []
+    pool = []
+    Wmax = 64
+    B = pkg.BundleAdjusterBatch(ctx, Wmax)
+    try:
+        for W in (1, 4, 16, 64):
+            while len(pool) < W:
+                pool.append(pkg.BundleAdjusterHip(ctx))
+            walls, loops, lins = [], [], []
+            n_acc = 0
+            for rep in range(6):
+                for h in pool[:W]:
+                    h.set_case(case, slots)
+                torch.cuda.synchronize(dev)
+                B.set_profile(rep >= 4)            # the last two repetitions carry the events around one stepped linearisation (not used for the wall figure)
+                t0 = time.perf_counter(); rs = B.optimize(pool[:W], 6); wall = time.perf_counter() - t0
+                ms = B.last_ms()
+                if rep >= 4:
+                    lins.append(ms[2])
+                elif rep >= 1:
+                    walls.append(wall); loops.append(ms[0] + ms[1])
+                n_acc = sum(int(r["trace"][1:, 3].sum()) for r in rs)
+            wall = float(np.median(walls)); loop_ms = float(np.median(loops)); lin_us = 1e3 * float(np.median(lins))
+            rows.append(dict(windows=W, accepted_iterations=n_acc, wall_ms=round(1e3 * wall, 4), device_ms=round(loop_ms, 4), value=round(n_acc / wall, 1),
+                             us_per_iteration_per_window=round(1e6 * wall / max(n_acc, 1) * W, 2), us_per_accepted_iteration=round(1e6 * wall / max(n_acc, 1), 3),
+                             k_ba_linearize_b_us=round(lin_us, 2), k_ba_linearize_b_GBs=round(W * bytes_lin / (lin_us * 1e-6) / 1e9, 1),
+                             k_ba_linearize_b_frac=round(W * bytes_lin / (lin_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)))
+    finally:
+        for h in pool:
+            h.close()
+        B.close()
+    best = max(rows, key=lambda r: r["value"])
+    ach = bytes_iter * best["value"] / 1e9
+    return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows,
+                single_window=dict(optimize6_ms=rows[0]["wall_ms"], us_per_accepted_iteration=rows[0]["us_per_accepted_iteration"],
+                                   what="dmvio_hip_ba_optimize_batch of ONE window = dmvio_hip_ba_optimize with dmvio_hip_ba_set_device_loop(1): the whole loop enqueued up front, two host waits per call"),
+                roofline=dict(bound="hbm", kernel="k_ba_linearize_b", achieved=best["k_ba_linearize_b_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=best["k_ba_linearize_b_frac"],
+                              kernel_us=best["k_ba_linearize_b_us"], algorithmic_bytes_per_launch=int(best["windows"] * bytes_lin),
+                              iteration=dict(achieved=round(ach, 2), frac=round(ach / HBM_PEAK_GBS, 5)),
+                              what="the stepped linearisation of all windows of the call (one launch, HIP events on the batch's stream): 464 B per residual x residuals of all windows / its "
+                                   "duration; `iteration`: all algorithmic bytes of an accepted iteration x accepted iterations per second"),
+                what="W fresh windows (own handles, set up before the timed region), ONE dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its "
+                     "wall time; device_ms = the same call by HIP events (loop + final fix-linearisation)")
+
+
 def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):
     """GN iterations / s of FullSystem::optimize's loop body (solveSystemF + doStepFromBackup + linearizeAll + energies + applyRes)
     on an 8-keyframe, ~2000-point, ~12k-residual window."""
@@ -1149,6 +1200,11 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         out["independent_windows_value"] = round(replicas, 1)
     if world == 1 and not getattr(args, "no_concurrent", False):
         out["concurrent_windows"] = bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
+    if world == 1:
+        try:
+            out["batched_windows"] = bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
+        except Exception as ex:   # reported in the line, never swallowed
+            out["batched_windows"] = dict(error="%s: %s" % (type(ex).__name__, ex))
     if world == 1:
         ba1 = pkg.BundleAdjusterHip(ctx, accumulators=1)
         ba1.set_case(case, list(range(F)))

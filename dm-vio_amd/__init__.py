@@ -778,9 +778,13 @@ class BundleAdjusterBatch:
         return [dict(rmse=float(rm[k]), finalEnergy=float(fe[k]), iterations=int(it[k]), trace=tr[k, :it[k] + 1].copy()) for k in range(W)]
 
     def last_ms(self):
-        ms = np.zeros(2, np.float32)
+        ms = np.zeros(3, np.float32)
         _chk(self.L, self.L.dmvio_hip_ba_batch_last_ms(self.p, ms.ctypes.data), "ba_batch_last_ms")
-        return float(ms[0]), float(ms[1])
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def set_profile(self, on=True):
+        fn = self.L.dmvio_hip_ba_batch_set_profile; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if on else 0), "ba_batch_set_profile")
 
 
 class RcclCommunicator:

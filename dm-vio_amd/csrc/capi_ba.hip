@@ -161,6 +161,7 @@ struct dmvio_hip_ba {
   // dmvio_hip_ba_set_device_loop: dmvio_hip_ba_optimize runs the device-resident loop (a batch of one window) instead of the host-driven one
   bool device_loop = false;
   struct dmvio_hip_ba_batch* own_batch = nullptr;
+  bool adj_dirty = false;   // the host's adjoint tables (H.adHost / adTarget) are newer than the device copy: uploaded by the next consumer (accumulateViews, a batch call)
 };
 #define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
 #define BA_PROF(b, k) do { if ((b)->prof) hipEventRecord((b)->prof[k], (b)->stream); } while (0)
@@ -266,6 +267,7 @@ static int uploadWindowTables(dmvio_hip_ba* b, bool new_state = false, bool swit
   return 0;
 }
 static int uploadAdjoints(dmvio_hip_ba* b) {
+  b->adj_dirty = false;
   // staged in the handle's pinned area: the host tables may change (setAdjointsF of the next state) while the copy is still in flight
   HIPCHK(b->bounce.h2d(b->d_adHost, b->H.adHost.data(), sizeof(double) * b->H.adHost.size(), b->stream));
   HIPCHK(b->bounce.h2d(b->d_adTarget, b->H.adTarget.data(), sizeof(double) * b->H.adTarget.size(), b->stream));
@@ -433,6 +435,7 @@ static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = t
 // the accumulation + stitching launches over an arbitrary (records, activity, per-point sums) view of the graph
 static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV, bool wait, int gate) {
   BAHost& H = b->H;
+  if (b->adj_dirty) { if (int r = uploadAdjoints(b)) return r; }
   const int F = H.F, F2 = F * F, n = H.n();
   hipStream_t s = b->stream;
   {
@@ -1718,7 +1721,72 @@ int dmvio_hip_ba_solve_ldlt(int n, const double* HPassed, const double* b_in, do
 // on the device (k_ba_solve + the decision pass of the linearisation), every kernel of the chain takes its window from blockIdx.y and is gated on that window's own decision.
 // Two waits per call: behind the loop (the frame states come back, the host re-anchors the newest keyframe, FullSystemOptimize.cpp:596-603) and behind the final
 // fix-linearisation.  Windows of one call must hold the same number of keyframes (the adjoint stitch's workgroup shape); the caller groups them.
+// the per-window host work of a batch call (tables, nullspace bases, staging copies before the launches; state write-back, adjoints and pair tables behind the loop:
+// 30-40 us per window each) is dealt out over a few persistent worker threads — at 64 windows it was 4.3 ms of a 12 ms call
+#include <thread>
+#include <condition_variable>
+struct BAWorkers {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::function<int(int)> fn;
+  int next = 0, count = 0, pending = 0, rc = 0, device = 0;
+  unsigned long long gen = 0;
+  bool quit = false;
+  std::string err;
+  void start(int n, int dev) {
+    device = dev;
+    for (int i = 0; i < n; i++) th.emplace_back([this] { run(); });
+  }
+  void run() {
+    hipSetDevice(device);
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return quit || (gen != seen && next < count); });
+      if (quit) return;
+      while (next < count) {
+        const int i = next++;
+        lk.unlock();
+        const int r = fn(i);
+        std::string e = r ? dmv_err() : std::string();
+        lk.lock();
+        if (r && !rc) { rc = r; err = e; }
+        if (--pending == 0) cv_done.notify_all();
+      }
+      seen = gen;
+    }
+  }
+  // fn(i) for i in [0, n): on the workers and on the calling thread; returns the first non-zero result (its message becomes this thread's last error)
+  int parallelFor(int n, std::function<int(int)> f) {
+    if (th.empty() || n < 8) { for (int i = 0; i < n; i++) if (int r = f(i)) return r; return 0; }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      fn = std::move(f); next = 0; count = n; pending = n; rc = 0; gen++;
+    }
+    cv.notify_all();
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      if (next >= count) { cv_done.wait(lk, [&] { return pending == 0; }); break; }
+      const int i = next++;
+      lk.unlock();
+      const int r = fn(i);
+      std::string e = r ? dmv_err() : std::string();
+      lk.lock();
+      if (r && !rc) { rc = r; err = e; }
+      if (--pending == 0) cv_done.notify_all();
+    }
+    if (rc) { dmv_err() = err; dmv_err_epoch()++; }
+    return rc;
+  }
+  ~BAWorkers() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
 struct dmvio_hip_ba_batch {
+  BAWorkers workers;
   dmvio_hip_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
   int cap = 0;
@@ -1731,13 +1799,16 @@ struct dmvio_hip_ba_batch {
   double* h_trace = nullptr;       // pinned: cap x (256 + NMAX) doubles
   size_t tab_stride = 0, out_stride = 0;
   int exact_backsub = 0;
-  float last_ms[2] = {0, 0};       // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_ms[3] = {0, 0, 0};    // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation, [profile] one stepped linearisation
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;   // the second half of a batch of >= 4 windows runs here, staggered behind the first (optimizeBatchGroup)
+  int single_stream = 0;           // dmvio_hip_ba_batch_set_streams(1): everything on one stream (measurement)
+  int profile = 0;                 // dmvio_hip_ba_batch_set_profile: events around the stepped linearisation of iteration 1 (k_ba_linearize_b of all windows)
 };
 static constexpr int BA_BATCH_NMAX = 4 + 8 * BA_MAXF_CAP;
 static size_t batchTabBytes() {
   const size_t n = BA_BATCH_NMAX, F2 = (size_t)BA_MAXF_CAP * BA_MAXF_CAP;
-  return ((n * n + n + 7 * n) * sizeof(double) + 2 * F2 * 64 * sizeof(float) + 255) & ~(size_t)255;
+  return ((n * n + n + 7 * n) * sizeof(double) + 2 * F2 * 64 * sizeof(float) + F2 * sizeof(BAPrecalc) + 255) & ~(size_t)255;
 }
 static size_t batchOutBytes() {
   const size_t n = BA_BATCH_NMAX;
@@ -1756,10 +1827,15 @@ dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_window
   ok = ok && hipMalloc((void**)&B->d_tab, B->tab_stride * max_windows) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&B->h_tab, B->tab_stride * max_windows, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&B->d_out, B->out_stride * max_windows) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&B->h_trace, sizeof(double) * (256 + BA_BATCH_NMAX) * max_windows, hipHostMallocDefault) == hipSuccess;
-  for (int k = 0; k < 4 && ok; k++) ok = hipEventCreate(&B->ev[k]) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&B->h_trace, sizeof(double) * (257 + BA_BATCH_NMAX) * max_windows, hipHostMallocDefault) == hipSuccess;
+  for (int k = 0; k < 8 && ok; k++) ok = hipEventCreate(&B->ev[k]) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&B->stream2, hipStreamNonBlocking) == hipSuccess;
   if (ok) ok = hipMemset(B->d_out, 0, B->out_stride * max_windows) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
   if (!ok) { failmsg("ba_batch_create: device / pinned allocation failed"); dmvio_hip_ba_batch_destroy(B); return nullptr; }
+  if (max_windows >= 8) {
+    const unsigned int hw = std::thread::hardware_concurrency();
+    B->workers.start((int)std::min<unsigned int>(7, hw > 2 ? hw - 2 : 0), ctx->device);
+  }
   return B;
 }
 void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* B) {
@@ -1772,7 +1848,8 @@ void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* B) {
   if (B->h_tab) hipHostFree(B->h_tab);
   if (B->d_out) hipFree(B->d_out);
   if (B->h_trace) hipHostFree(B->h_trace);
-  for (int k = 0; k < 4; k++) if (B->ev[k]) hipEventDestroy(B->ev[k]);
+  for (int k = 0; k < 8; k++) if (B->ev[k]) hipEventDestroy(B->ev[k]);
+  if (B->stream2) { hipStreamSynchronize(B->stream2); hipStreamDestroy(B->stream2); }
   delete B;
 }
 // 1: the back substitution of the 68x68 solve in the host's order (one dependent chain of n^2 / 2 subtractions: x bit-identical to BAHost::ldltSolveTransposed, ~10 us more per
@@ -1783,10 +1860,32 @@ int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* B, int on) {
   B->exact_backsub = on ? 1 : 0;
   return 0;
 }
-int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* B, float ms2[2]) {
-  if (!B || !ms2) return failmsg("ba_batch: null argument");
+int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* B, float ms3[3]) {
+  if (!B || !ms3) return failmsg("ba_batch: null argument");
   std::lock_guard<std::mutex> lk(B->mu);
-  ms2[0] = B->last_ms[0]; ms2[1] = B->last_ms[1];
+  ms3[0] = B->last_ms[0]; ms3[1] = B->last_ms[1]; ms3[2] = B->last_ms[2];
+  return 0;
+}
+// diagnostics: in-kernel timeline of window 0's last k_ba_solve of the last call, 100 MHz ticks since the kernel started: staged + settled, delta + bM_top, system
+// assembled, pivot order, permuted, factorised, back-substituted, x, resubstitution inputs + stepped states, exponentials, pair tables, energies
+int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* B, int ticks12[12]) {
+  if (!B || !ticks12) return failmsg("ba_batch: null argument");
+  std::lock_guard<std::mutex> lk(B->mu);
+  for (int i = 0; i < 12; i++) ticks12[i] = B->h_wins[0].S.ticks[i];
+  return 0;
+}
+// measurement: 1 = the whole batch on one stream (no staggered halves); 0 (default) = two halves on two streams from 4 windows on
+int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* B, int single) {
+  if (!B) return failmsg("ba_batch: null handle");
+  std::lock_guard<std::mutex> lk(B->mu);
+  B->single_stream = single ? 1 : 0;
+  return 0;
+}
+// measurement: HIP events around the stepped linearisation of the second iteration (k_ba_linearize_b over all windows of the call) -> dmvio_hip_ba_batch_last_ms()[2]
+int dmvio_hip_ba_batch_set_profile(dmvio_hip_ba_batch* B, int on) {
+  if (!B) return failmsg("ba_batch: null handle");
+  std::lock_guard<std::mutex> lk(B->mu);
+  B->profile = on ? 1 : 0;
   return 0;
 }
 }  // extern "C"
@@ -1807,13 +1906,17 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   for (int w = 0; w < Wn; w++) {
     dmvio_hip_ba* b = hs[w];
     if (b->stream != s) { HIPCHK(hipStreamSynchronize(b->stream)); swap.saved.emplace_back(b, b->stream); b->stream = s; }
+    const int nacc = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
+    gx_lin = std::max(gx_lin, b->n_lin_blocks); gx_pt8 = std::max(gx_pt8, b->n_pt8_blocks); gx_acc = std::max(gx_acc, nacc); gx_res = std::max(gx_res, (b->H.R + 255) / 256);
+  }
+  auto prepare = [&](const int w) -> int {
+    dmvio_hip_ba* b = hs[w];
     BAHost& H = b->H;
     b->vio = nullptr; b->vio_opt = nullptr; b->dynW = 1.0; H.gtsam = false;
     b->pending_reject = false; b->pending_trace = -1; b->sums_fresh = false; b->sys_ready = false;
     if (int r = resolveTh(b)) return r;
-    hipLaunchKernelGGL(k_ba_reset_oob, dim3((H.R + 255) / 256), dim3(256), 0, s, H.R, b->Rs);   // activate_all
-    if (int r = uploadWindowTables(b)) return r;
-    if (int r = uploadThresholds(b)) return r;
+    if (b->adj_dirty) { if (int r = uploadAdjoints(b)) return r; }
+    // (the precalc table, the thresholds and the activation of all residuals travel with the batch: one upload, one launch for all windows)
     H.getNullspaces();
     H.prepareOrthogonalize();
     // ---- the window's record
@@ -1821,8 +1924,11 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     memset(&V, 0, sizeof(V));
     fillWindow(b);
     V.W = b->W; V.Wb = b->W;
-    V.P = b->P; V.Rs = b->Rs; V.pre = b->d_pre;
+    V.P = b->P; V.Rs = b->Rs;
     V.D = makeDecide(b, 0, true, false);
+    for (int f = 0; f < BA_MAXF_CAP; f++) V.frameTH[f] = f < F ? H.fr[f].frameEnergyTH : 0.0f;
+    V.D.frameTH = B->d_wins[w].frameTH;   // (an address: the record's own copy on the device)
+    b->th_dirty = true;                    // the handle's own device copy is stale from here on; the host's values are brought up to date below
     dynFromHost(H, V.T); V.Tb = V.T;
     b->dyn_cur = V.T;
     {
@@ -1838,7 +1944,6 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     V.ctl = b->d_ctl;
     V.n_lin_blocks = b->n_lin_blocks; V.n_pt8_blocks = b->n_pt8_blocks; V.n_acc_blocks = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
     V.n_res_blocks = (H.R + 255) / 256; V.n_gather_blocks = n_gather; V.n_stitch_blocks = n_stitch;
-    gx_lin = std::max(gx_lin, V.n_lin_blocks); gx_pt8 = std::max(gx_pt8, V.n_pt8_blocks); gx_acc = std::max(gx_acc, V.n_acc_blocks); gx_res = std::max(gx_res, V.n_res_blocks);
     BASolveDev& S = V.S;
     S.F = F; S.n = n; S.stepped = 0; S.iterations_done = 0; S.n_accepted = 0; S.exact_backsub = B->exact_backsub;
     S.lambda = 1e-5;
@@ -1864,47 +1969,75 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     memcpy(tAd, H.adHostF.data(), sizeof(float) * F2 * 64); memcpy(tAd + (size_t)F2 * 64, H.adTargetF.data(), sizeof(float) * F2 * 64);
     S.HM = reinterpret_cast<const double*>(dtab); S.bM = S.HM + (size_t)n * n; S.basis = S.bM + n;
     S.adHostF = reinterpret_cast<const float*>(S.basis + 7 * (size_t)n); S.adTargetF = S.adHostF + (size_t)F2 * 64;
+    BAPrecalc* tPre = reinterpret_cast<BAPrecalc*>(tAd + 2 * (size_t)F2 * 64);
+    memcpy(tPre, H.pre.data(), sizeof(BAPrecalc) * F2);
+    V.pre = reinterpret_cast<const BAPrecalc*>(S.adTargetF + (size_t)F2 * 64);
+    b->pre_static_valid = false;           // the handle's own table was not refreshed
     S.trace = V.sys + tot + 1; S.x_last = S.trace + 256;
-    // the initial state's row of the trace is written by the host below (its energy comes out of the initial linearisation)
-  }
+    return 0;
+  };
+  if (int r = B->workers.parallelFor(Wn, prepare)) return r;
   HIPCHK(hipGetLastError());
-  const size_t used_tab = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float);
+  const size_t used_tab = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float) + (size_t)F2 * sizeof(BAPrecalc);
   if (used_tab > B->tab_stride) return failmsg("ba_optimize_batch: table slab too small");
   HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(B->d_tab, B->h_tab, B->tab_stride * (size_t)(Wn - 1) + used_tab, hipMemcpyHostToDevice, s));
   const FrameStore fs = B->ctx->fs;
-  const BAWinDev* dw = B->d_wins;
-  const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n);
-  auto chain = [&](const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
-    hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, Wn), dim3(256), 0, s, dw, backup, apply, gate);
-    hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, Wn), dim3(256), 0, s, dw, gate);
-    hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, Wn), dim3(64 * F), sizeof(StitchWave) * F, s, dw, gate);
-    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, Wn), dim3(256), 0, s, dw, gate);
-    else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, Wn), dim3(256), 0, s, dw, gate);
-  };
+  const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n, F);
+  // One half of the windows per stream from 4 windows on, the second half started behind the first half's first stepped linearisation: k_ba_solve is one workgroup per
+  // window (a latency chain on a handful of CUs), so while one half solves the other half's linearisation / accumulation fills the device.  The halves share nothing.
+  const int halves = (Wn >= 4 && B->stream2 && !B->single_stream) ? 2 : 1;
+  const int cut = halves == 2 ? (Wn + 1) / 2 : Wn;
   HIPCHK(hipEventRecord(B->ev[0], s));
-  // ---- initial linearisation, applyRes and the first system (FullSystemOptimize.cpp:450-470)
-  hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_INITIAL);
-  hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 0, (int)BA_GATE_ALWAYS);
-  chain(1, 0, BA_GATE_ALWAYS);
-  // ---- the loop (:485-586): nothing in it waits for the host
-  for (int it = 0; it < mnumOptIts; it++) {
-    hipLaunchKernelGGL(k_ba_solve, dim3(Wn), dim3(BA_SOLVE_THREADS), solveLds, s, B->d_wins, it, 0);
-    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_STEPPED);
-    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_RESTORE);
-    if (it < mnumOptIts - 1) chain(1, 1, BA_GATE_ACCEPTED);
-    else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
+  if (halves == 2) HIPCHK(hipStreamWaitEvent(B->stream2, B->ev[0], 0));   // the uploads above
+  for (int hf = 0; hf < halves; hf++) {
+    hipStream_t st = hf == 0 ? s : B->stream2;
+    const int w0 = hf == 0 ? 0 : cut, cnt = hf == 0 ? cut : Wn - cut;
+    BAWinDev* dwm = B->d_wins + w0;
+    const BAWinDev* dw = dwm;
+    auto solve = [&](const int it, const int finish) {
+      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF>), dim3(cnt), dim3(BA_SOLVE_THREADS), solveLds, st, dwm, it, finish);
+      else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP>), dim3(cnt), dim3(BA_SOLVE_THREADS), solveLds, st, dwm, it, finish);
+    };
+    auto chain = [&](const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
+      hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, cnt), dim3(256), 0, st, dw, backup, apply, gate);
+      hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, cnt), dim3(256), 0, st, dw, gate);
+      hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, cnt), dim3(64 * F), sizeof(StitchWave) * F, st, dw, gate);
+      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, cnt), dim3(256), 0, st, dw, gate);
+      else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, cnt), dim3(256), 0, st, dw, gate);
+    };
+    if (hf == 1) HIPCHK(hipStreamWaitEvent(st, B->ev[6], 0));   // the stagger
+    // ---- every residual still in the graph active again (FullSystemOptimize.cpp:431-448), initial linearisation, applyRes and the first system (:450-470)
+    hipLaunchKernelGGL(k_ba_reset_oob_b, dim3(gx_res, cnt), dim3(256), 0, st, dw);
+    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_INITIAL);
+    hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, cnt), dim3(256), 0, st, dw, 0, (int)BA_GATE_ALWAYS);
+    chain(1, 0, BA_GATE_ALWAYS);
+    // ---- the loop (:485-586): nothing in it waits for the host
+    for (int it = 0; it < mnumOptIts; it++) {
+      solve(it, 0);
+      const bool prof = B->profile && hf == 0 && it == std::min(1, mnumOptIts - 1);
+      if (prof) HIPCHK(hipEventRecord(B->ev[4], st));
+      hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_STEPPED);
+      if (prof) HIPCHK(hipEventRecord(B->ev[5], st));
+      if (hf == 0 && it == 0 && halves == 2) HIPCHK(hipEventRecord(B->ev[6], st));
+      hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_RESTORE);
+      if (it < mnumOptIts - 1) chain(1, 1, BA_GATE_ACCEPTED);
+      else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, cnt), dim3(256), 0, st, dw, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
+    }
+    solve(mnumOptIts, 1);   // settle the last decision
+    HIPCHK(hipGetLastError());
+    if (hf == 1) { HIPCHK(hipEventRecord(B->ev[7], st)); HIPCHK(hipStreamWaitEvent(s, B->ev[7], 0)); }
   }
-  hipLaunchKernelGGL(k_ba_solve, dim3(Wn), dim3(BA_SOLVE_THREADS), solveLds, s, B->d_wins, mnumOptIts, 1);   // settle the last decision
-  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(B->ev[1], s));
+  const BAWinDev* dw = B->d_wins;
   HIPCHK(hipMemcpyAsync(B->h_wins, B->d_wins, sizeof(BAWinDev) * Wn, hipMemcpyDeviceToHost, s));
-  for (int w = 0; w < Wn; w++)   // [trace (64 x 4) | x_last] behind the window's system
-    HIPCHK(hipMemcpyAsync(B->h_trace + (size_t)(256 + BA_BATCH_NMAX) * w, reinterpret_cast<const double*>(B->d_out + B->out_stride * (size_t)w) + tot + 1, sizeof(double) * (256 + n),
+  // [resInA | trace (64 x 4) | x_last] of every window: the tail of its system slab, one strided copy
+  HIPCHK(hipMemcpy2DAsync(B->h_trace, sizeof(double) * (257 + BA_BATCH_NMAX), reinterpret_cast<const double*>(B->d_out) + tot, B->out_stride, sizeof(double) * (257 + n), Wn,
                           hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   // ---- back on the host: the optimised states, then the newest keyframe's new evaluation point (:596-603) and the final fix-linearisation (:604-609)
-  for (int w = 0; w < Wn; w++) {
+  const size_t tab_pre_off = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float);
+  auto writeBack = [&](const int w) -> int {
     dmvio_hip_ba* b = hs[w];
     BAHost& H = b->H;
     const BAWinDev& V = B->h_wins[w];
@@ -1915,44 +2048,45 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       BAHost::frameSetState(H.fr[f], S.fr[f].state);
       for (int i = 0; i < 10; i++) H.fr[f].state_backup[i] = S.fr[f].state_backup[i];
     }
-    const double* tr = B->h_trace + (size_t)(256 + BA_BATCH_NMAX) * w;
+    const double* tr = B->h_trace + (size_t)(257 + BA_BATCH_NMAX) * w + 1;
+    H.resInA = (int)tr[-1];   // the count the last accumulation left behind (ef->resInA after the loop)
     const int done = S.iterations_done;
     b->iterations_done = done;
     for (int k = 0; k <= done && k < 64; k++) for (int c = 0; c < 4; c++) b->trace[k][c] = tr[4 * k + c];   // row 0: the initial state (written by the first solve)
     b->H.lastX.assign(tr + 256, tr + 256 + n);
     if (x_last) memcpy(x_last + (size_t)BA_BATCH_NMAX * w, tr + 256, sizeof(double) * n);
-    H.resInA = (int)0;   // filled from the system below
     BAFrameHost& last = H.fr[F - 1];
     double newStateZero[10] = {0, 0, 0, 0, 0, 0, last.state[6], last.state[7], 0, 0};
     last.evalPT = last.w2c;
     BAHost::frameSetState(last, newStateZero);
     BAHost::frameSetStateZero(last, newStateZero);
     H.setAdjointsF();
-    if (int r = uploadAdjoints(b)) return r;
+    b->adj_dirty = true;                   // uploaded by the next consumer (nothing in this call stitches again)
     H.setPrecalcValues();
-    if (int r = uploadWindowTables(b)) return r;
+    memcpy(reinterpret_cast<BAPrecalc*>(B->h_tab + B->tab_stride * (size_t)w + tab_pre_off), H.pre.data(), sizeof(BAPrecalc) * F2);
     fillWindow(b);
     BAWinDev& V2 = B->h_wins[w];
-    V2.W = b->W; V2.pre = b->d_pre;
+    V2.W = b->W;
     dynFromHost(H, V2.T); b->dyn_cur = V2.T;
-    b->th_dirty = false; b->th_pending = false;   // the thresholds live on the device; the newest one is read back behind the final linearisation
-  }
+    b->th_pending = false;                 // the thresholds live in the window's record; the newest one is read back behind the final linearisation
+    return 0;
+  };
+  if (int r = B->workers.parallelFor(Wn, writeBack)) return r;
   HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpy2DAsync(B->d_tab + tab_pre_off, B->tab_stride, B->h_tab + tab_pre_off, B->tab_stride, sizeof(BAPrecalc) * F2, Wn, hipMemcpyHostToDevice, s));   // the re-anchored pair tables
   HIPCHK(hipEventRecord(B->ev[2], s));
   hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_FINAL);
   hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 1, (int)BA_GATE_ALWAYS);   // applyRes + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(B->ev[3], s));
-  // resInA of the last accumulation (the count ef->resInA holds after the loop): the last element of every window's system
-  for (int w = 0; w < Wn; w++)
-    HIPCHK(hipMemcpyAsync(&B->h_trace[(size_t)(256 + BA_BATCH_NMAX) * w], reinterpret_cast<const double*>(B->d_out + B->out_stride * (size_t)w) + tot, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipEventElapsedTime(&B->last_ms[0], B->ev[0], B->ev[1]));
   HIPCHK(hipEventElapsedTime(&B->last_ms[1], B->ev[2], B->ev[3]));
+  B->last_ms[2] = 0;
+  if (B->profile) HIPCHK(hipEventElapsedTime(&B->last_ms[2], B->ev[4], B->ev[5]));
   for (int w = 0; w < Wn; w++) {
     dmvio_hip_ba* b = hs[w];
     BAHost& H = b->H;
-    H.resInA = (int)B->h_trace[(size_t)(256 + BA_BATCH_NMAX) * w];
     const double fe = b->h_res->E[0];
     H.fr[F - 1].frameEnergyTH = b->h_res->th[0];
     b->final_energy = fe;
@@ -1961,7 +2095,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     if (iterations) iterations[w] = b->iterations_done;
     if (trace) memcpy(trace + (size_t)256 * w, b->trace, sizeof(b->trace));
     b->sums_fresh = false; b->sys_ready = false;
-    HIPCHK(b->bounce.finish(s));   // the staging area of this call's uploads is free again
+    if (b->bounce.used || !b->bounce.outs.empty()) HIPCHK(b->bounce.finish(s));   // the staging area of this call's uploads is free again
   }
   return 0;
 }

@@ -501,8 +501,15 @@ dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_window
 void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* batch);
 int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* batch, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
 int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* batch, int on);
-/* HIP-event times of the last dmvio_hip_ba_optimize_batch call on the batch's stream: [0] initial chain + all iterations, [1] the final fix-linearisation (ms) */
-int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* batch, float ms2[2]);
+/* HIP-event times of the last dmvio_hip_ba_optimize_batch call on the batch's stream (ms): [0] initial chain + all iterations, [1] the final fix-linearisation,
+ * [2] with dmvio_hip_ba_batch_set_profile(1): the stepped linearisation of the second iteration (k_ba_linearize_b over all windows of the call) */
+int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* batch, float ms3[3]);
+int dmvio_hip_ba_batch_set_profile(dmvio_hip_ba_batch* batch, int on);
+/* measurement: 1 = the whole batch on one stream; 0 (default) = from 4 windows on two halves on two streams, the second started behind the first half's first stepped
+ * linearisation, so that one half's k_ba_solve (one workgroup per window) runs beside the other half's linearisation / accumulation.  Results do not depend on it. */
+int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* batch, int single);
+/* diagnostics: in-kernel timeline (100 MHz ticks since kernel start) of the first window's k_ba_solve of the LAST iteration of the last call, 12 phase boundaries */
+int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* batch, int ticks12[12]);
 /* dmvio_hip_ba_optimize of this handle through the device-resident loop (a batch of one); 0 (default) = the host-driven loop */
 int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* ba, int on);
 /* EnergyFunctional::lastX of the window's last solve (n = 4 + 8F doubles; x = MINUS the step) */

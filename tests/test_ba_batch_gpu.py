@@ -126,7 +126,7 @@ def test_batched_windows_equal_single_window_calls_bitwise(pkg, synth, gpu_requi
         assert np.array_equal(single[i].point_state()[0], batch[i].point_state()[0]), i
         n_rej += int((rb[i]["trace"][1:, 3] == 0).sum())
     assert n_rej >= 1, "no rejected step in the batch: the gated restore path was not exercised"
-    print("batch of 5 windows (F = 6, 6, 4, 6, 4) == 5 single calls bit for bit; %d rejected steps among them; loop %.3f ms, final linearisation %.3f ms" % ((n_rej,) + B5.last_ms()))
+    print("batch of 5 windows (F = 6, 6, 4, 6, 4) == 5 single calls bit for bit; %d rejected steps among them; loop %.3f ms, final linearisation %.3f ms" % ((n_rej,) + B5.last_ms()[:2]))
     for o in single + batch + [B1, B5]:
         o.close()
     ctx.close()
