@@ -269,10 +269,13 @@ def main():
     timed_step(False)
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         res_pipe = timed_step(True)
+        step_marks.append(time.perf_counter())          # the step returns once the PREVIOUS launch's results are unpacked: per-step wall time of the steady-state pipeline
     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    step_ms = 1e3 * np.diff(np.array([t0] + step_marks))
     if not res_pipe["good"].all():
         raise SystemExit("bench: a pipelined step lost tracking")
     trk.fetch()                                         # drain the last launch (outside the timed region: K launches, K unpacks inside)
@@ -412,6 +415,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+        "ms_per_step_p10_p50_p90": [round(float(x), 4) for x in np.percentile(step_ms, [10, 50, 90])],   # the K timed steps one by one (this rank): the spread behind the mean
+        "ms_per_step_min_max": [round(float(step_ms.min()), 4), round(float(step_ms.max()), 4)],
         "launcher": ("bench.py --gpus N (self-launched torch.distributed.run)" if os.environ.get("DMVIO_BENCH_SELF_LAUNCHED") else
                      ("torch.distributed.run" if world > 1 else "single process")),
         "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
@@ -1103,6 +1108,7 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
             torch.cuda.synchronize(dev)
             comm = pkg.RcclCommunicator(ctx, bytes(uid.cpu().numpy().tobytes()), rank, world)
             ba.set_comm(comm, rank, world)
+            ba.comm_timing(True)
             transport = "RCCL (ncclAllReduce fp64 sum + ncclAllGather on the BA stream)"
         else:
             ba.set_comm_torch(dist)    # single-GPU test hook (gloo, all ranks on one device): RCCL refuses two ranks per device
@@ -1114,6 +1120,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
     if not (lastE[0] < 0.8 * e0):
         raise SystemExit("bench: BA did not reduce the energy (%g -> %g)" % (e0, lastE[0]))
     torch.cuda.synchronize(dev)
+    if comm is not None:
+        ba.comm_timing(True)            # from here: the collectives of the timed iterations
     if dist is not None:
         dist.barrier()
     n_it = args.ba_iters
@@ -1174,6 +1182,12 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
             nr, rr = comm.info()
             out["rccl_ranks"] = int(nr)          # ncclCommCount of the communicator the sharded iteration ran on
             out["rccl_rank_of_reporter"] = int(rr)
+            ct = ba.comm_times()                 # HIP events around the two collectives of the sharded iteration on this rank's BA stream
+            out["allreduce_us"] = round(ct["allreduce_us"], 2); out["allgather_us"] = round(ct["allgather_us"], 2)
+            out["collectives_issued"] = dict(allreduce=ct["allreduces"], allgather=ct["allgathers"])
+            out["collectives_what"] = ("mean duration of the sharded iteration's ncclAllReduce (packed 68x68 systems, %d doubles) and ncclAllGather (decision records) on the BA "
+                                       "stream, the first 64 of each in the timed loop; a sharded accepted iteration pays one of each plus one more all-gather per rejected step"
+                                       % (2 * ((4 + 8 * F) ** 2 + (4 + 8 * F)) + 1))
     out["accepted_in_converged_loop"] = "%d of %d" % (n_acc, done)
     if optimize_ms is not None:
         out["value"] = round(6.0 / (optimize_ms * 1e-3), 1)
@@ -1198,6 +1212,7 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
                                     "not by HBM — the fraction says how far from the HBM roofline a latency-bound path sits")
     if replicas is not None:
         out["independent_windows_value"] = round(replicas, 1)
+        out["independent_windows_value_per_rank"] = round(replicas / world, 1)
     if world == 1 and not getattr(args, "no_concurrent", False):
         out["concurrent_windows"] = bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
     if world == 1:

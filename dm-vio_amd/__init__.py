@@ -1218,6 +1218,17 @@ class BundleAdjusterHip:
         _chk(self.L, self.L.dmvio_hip_ba_optimize(self.p, its, C.byref(rm), C.byref(fe), C.byref(it), _d(tr)), "ba_optimize")
         return dict(rmse=rm.value, finalEnergy=fe.value, iterations=it.value, trace=tr[:it.value + 1])
 
+    def comm_timing(self, on=True):
+        fn = self.L.dmvio_hip_ba_comm_timing; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if on else 0), "ba_comm_timing")
+
+    def comm_times(self):
+        """mean us of [all-reduce, all-gather] of the sharded iteration (HIP events on the BA stream) and how many of each were issued"""
+        us = (C.c_double * 2)(); nn = (C.c_long * 2)()
+        fn = self.L.dmvio_hip_ba_comm_times; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, us, nn), "ba_comm_times")
+        return dict(allreduce_us=float(us[0]), allgather_us=float(us[1]), allreduces=int(nn[0]), allgathers=int(nn[1]))
+
     def set_device_loop(self, on=True):
         """dmvio_hip_ba_optimize through the device-resident Gauss-Newton loop (solve, frame step, accept test on the device; a batch of one window)."""
         fn = self.L.dmvio_hip_ba_set_device_loop; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int

@@ -62,6 +62,8 @@ struct dmvio_hip_tracker {
   std::vector<unsigned char> h_rank;
   std::vector<int> last_repeat_lvl;            // per problem of the last fetch: the level that ran twice (or -1) ...
   std::vector<double> last_first_pass_res;     // ... and its residual after the first pass
+  int debug_mode = 0, log_cap = 0, log_B = 0;   // dmvio_hip_tracker_debug_record_replay
+  EvalP* d_log = nullptr; int* d_log_n = nullptr; float* d_log_sink = nullptr;
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
   int out_cur = 0, out_fetch = 0, staged_half = 0;    // half of the last launch / half a pending fetch_begin refers to / half staged for the next launch
   int batch_cap = 0, staged_B = 0, staged_coarsest = 0;
@@ -928,7 +930,25 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   // (129..512 problems) take 512 threads per problem (measured: B=256 0.47 -> 0.40 ms, B=512 0.62 -> 0.58 ms)
   const int T = t->lm_threads_override ? t->lm_threads_override : (C > 1 ? 256 : (B <= 128 ? 1024 : (B <= 512 ? 512 : 256)));
   const int W = t->lm_waves_override ? t->lm_waves_override : 4;
-  ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out;
+  ClusterArgs cl; cl.C = C; cl.part = nullptr; cl.cnt = nullptr; cl.discard = t->d_out; cl.log = nullptr; cl.log_n = nullptr;
+  if (t->debug_mode) {
+    // diagnostics: 1 = record the evaluations of this launch, 2 = run the recorded evaluations again without the control steps (dmvio_hip_tracker_debug_record_replay)
+    if (C != 1 || T != 256) return failmsg("tracker record / replay: full batches only (one 256-thread workgroup per problem)");
+    if (B > t->log_cap) {
+      if (t->d_log) { HIPCHK(hipFree(t->d_log)); HIPCHK(hipFree(t->d_log_n)); HIPCHK(hipFree(t->d_log_sink)); }
+      HIPCHK(hipMalloc((void**)&t->d_log, sizeof(EvalP) * (size_t)B * LM_LOG_EVALS)); HIPCHK(hipMalloc((void**)&t->d_log_n, sizeof(int) * B));
+      HIPCHK(hipMalloc((void**)&t->d_log_sink, sizeof(float) * (size_t)B * ACC_PAD));
+      t->log_cap = B; t->log_B = 0;
+    }
+    if (t->debug_mode == 1) { cl.log = t->d_log; cl.log_n = t->d_log_n; t->log_B = B; }
+    else {
+      if (t->log_B != B) return failmsg("tracker replay: record a launch of the same batch first");
+      hipLaunchKernelGGL((k_track_replay<256, 4>), dim3(B), dim3(256), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->staged_half * t->batch_cap, (const EvalP*)t->d_log,
+                         (const int*)t->d_log_n, t->d_log_sink);
+      HIPCHK(hipGetLastError());
+      return 0;   // nothing to fetch: the caller times the launch and synchronises the stream itself
+    }
+  }
   t->last_cluster = C; t->last_threads = T;
   t->out_cur = t->staged_half;   // the host may still be unpacking the previous launch's half (fetch_begin pipeline)
   if (C > 1) {
@@ -941,12 +961,14 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   // frames whose level 0 the batched raw-image build stored in 8x4 tiles: the (256, 4) and (512, 4) configurations have an instantiation that gathers from them directly
   // (decided per problem inside the kernel); any other configuration has those slots converted back first
   bool any_tiled = false;
+  // the context's lock from the scan of the layout flags to the launch: a batched raw-image build on another thread (dmvio_hip_set_build_stream invites one) must not flip a
+  // slot's layout between the choice of the instantiation and the launch that relies on it
+  std::lock_guard<std::mutex> lk_layout(c->mu);
   {
     const LMProblemIn* pin = t->h_in + (size_t)t->out_cur * t->batch_cap;
     for (int i = 0; i < B && !any_tiled; i++) any_tiled = c->h_tiled[pin[i].new_slot] != 0;
     const bool has_variant = (T == 256 && W < 6) || (T == 512 && W < 6 && C == 1);
     if (any_tiled && !has_variant) {
-      std::lock_guard<std::mutex> lk(c->mu);
       for (int i = 0; i < B; i++) if (int r = dmv_ensure_row_major_locked(c, pin[i].new_slot)) return r;
       any_tiled = false;
     }
@@ -1123,6 +1145,15 @@ int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* t, int eval_blocks, in
   return 0;
 }
 // 1 (default): the evaluations of a host-driven LM go to the resident evaluation server (one launch per tracked frame); 0: one fused launch per evaluation
+// Diagnostics for profiles/: mode 1 = the next dmvio_hip_tracker_track_batch_launch calls record the parameters of every evaluation they run (full batches: one 256-thread
+// workgroup per problem), mode 2 = they run the recorded evaluations again WITHOUT the LM control steps between them (k_track_replay: same points, same taps, same fused
+// sums; nothing to fetch — time the launch on the context's stream), 0 = normal operation.
+int dmvio_hip_tracker_debug_record_replay(dmvio_hip_tracker* t, int mode) {
+  if (!t || mode < 0 || mode > 2) return failmsg("tracker_debug_record_replay: bad argument");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->debug_mode = mode;
+  return 0;
+}
 int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* t, int on) {
   if (!t) return failmsg("null tracker");
   std::lock_guard<std::mutex> lk(t->ctx->mu);

@@ -161,6 +161,13 @@ struct dmvio_hip_ba {
   // dmvio_hip_ba_set_device_loop: dmvio_hip_ba_optimize runs the device-resident loop (a batch of one window) instead of the host-driven one
   bool device_loop = false;
   struct dmvio_hip_ba_batch* own_batch = nullptr;
+  // dmvio_hip_ba_comm_timing: HIP events around the collectives of the sharded iteration (RCCL transport), kind 0 = all-reduce of the packed system, 1 = all-gather of the
+  // decision records; up to COMM_EVS of each are kept and summed when asked for
+  enum { COMM_EVS = 64 };
+  bool comm_timing = false;
+  hipEvent_t comm_ev[2][COMM_EVS][2] = {};
+  int comm_n[2] = {0, 0};
+  long comm_total[2] = {0, 0};
   bool adj_dirty = false;   // the host's adjoint tables (H.adHost / adTarget) are newer than the device copy: uploaded by the next consumer (accumulateViews, a batch call)
 };
 #define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
@@ -334,8 +341,22 @@ static BADecide makeDecide(dmvio_hip_ba* b, int mode, bool update_th, bool publi
 // ---- exchange steps of the sharded iteration.  With an RCCL communicator they are enqueued on the handle's stream between the kernels that produce
 // and consume the buffers (no host hop); the callback transport stages them through host memory.
 static bool sharded(const dmvio_hip_ba* b) { return b->world > 0; }
+static hipEvent_t* commEvents(dmvio_hip_ba* b, const int kind) {
+  b->comm_total[kind]++;
+  if (!b->comm_timing || b->comm_n[kind] >= dmvio_hip_ba::COMM_EVS) return nullptr;
+  hipEvent_t* e = b->comm_ev[kind][b->comm_n[kind]];
+  if (!e[0] && (hipEventCreate(&e[0]) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess)) return nullptr;
+  b->comm_n[kind]++;
+  return e;
+}
 static int commAllReduceSum(dmvio_hip_ba* b, double* d_buf, size_t count) {
-  if (b->nccl) { NCCLCHK(rccl().allReduce(d_buf, d_buf, count, ncclDouble, ncclSum, b->nccl, b->stream)); return 0; }
+  if (b->nccl) {
+    hipEvent_t* e = commEvents(b, 0);
+    if (e) HIPCHK(hipEventRecord(e[0], b->stream));
+    NCCLCHK(rccl().allReduce(d_buf, d_buf, count, ncclDouble, ncclSum, b->nccl, b->stream));
+    if (e) HIPCHK(hipEventRecord(e[1], b->stream));
+    return 0;
+  }
   b->h_stage.resize(count);
   HIPCHK(hipMemcpyAsync(b->h_stage.data(), d_buf, sizeof(double) * count, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -344,7 +365,13 @@ static int commAllReduceSum(dmvio_hip_ba* b, double* d_buf, size_t count) {
   return 0;
 }
 static int commAllGather(dmvio_hip_ba* b, const float* d_in, float* d_out, size_t count_per_rank) {
-  if (b->nccl) { NCCLCHK(rccl().allGather(d_in, d_out, count_per_rank, ncclFloat, b->nccl, b->stream)); return 0; }
+  if (b->nccl) {
+    hipEvent_t* e = commEvents(b, 1);
+    if (e) HIPCHK(hipEventRecord(e[0], b->stream));
+    NCCLCHK(rccl().allGather(d_in, d_out, count_per_rank, ncclFloat, b->nccl, b->stream));
+    if (e) HIPCHK(hipEventRecord(e[1], b->stream));
+    return 0;
+  }
   const size_t bytes = sizeof(float) * count_per_rank;
   b->h_stage.resize((bytes * (b->world + 1) + 7) / 8);
   char* in = (char*)b->h_stage.data(); char* out = in + bytes;
@@ -573,6 +600,7 @@ void dmvio_hip_ba_destroy(dmvio_hip_ba* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
   if (b->own_batch) { dmvio_hip_ba_batch_destroy(b->own_batch); b->own_batch = nullptr; }
+  for (int k = 0; k < 2; k++) for (int i = 0; i < dmvio_hip_ba::COMM_EVS; i++) for (int j = 0; j < 2; j++) if (b->comm_ev[k][i][j]) hipEventDestroy(b->comm_ev[k][i][j]);
   hipStreamSynchronize(b->stream);
   if (b->timing && b->tm_graph_n > 0)
     fprintf(stderr, "[dmvio_hip_ba] set_graph over %ld calls (us/call): drain + arena memset=%.1f host lists=%.1f allocation=%.1f uploads=%.1f pinned buffers + slot table=%.1f adjoints + wait=%.1f\n", b->tm_graph_n,
@@ -645,6 +673,28 @@ static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callba
   return 0;
 }
 int dmvio_hip_ba_set_comm(dmvio_hip_ba* b, void* nccl_comm, int rank, int world) { return setComm(b, (ncclComm_t)nccl_comm, nullptr, rank, world); }
+// Measurement of the sharded iteration's two collectives (RCCL transport): on = 1 starts collecting HIP events around them on the BA stream (and clears the counters); the
+// query waits for the stream and returns mean microseconds of [all-reduce of the packed system, all-gather of the decision records] over the first 64 of each since then,
+// and how many of each were issued in total.  What a multi-GPU scaling line needs to explain itself (a window sharded over N GPUs pays both per iteration).
+int dmvio_hip_ba_comm_timing(dmvio_hip_ba* b, int on) {
+  if (!b) return failmsg("ba: null handle");
+  BA_LOCK(b);
+  b->comm_timing = on != 0; b->comm_n[0] = b->comm_n[1] = 0; b->comm_total[0] = b->comm_total[1] = 0;
+  return 0;
+}
+int dmvio_hip_ba_comm_times(dmvio_hip_ba* b, double mean_us2[2], long issued2[2]) {
+  if (!b || !mean_us2 || !issued2) return failmsg("ba_comm_times: null argument");
+  BA_LOCK(b);
+  HIPCHK(hipSetDevice(b->ctx->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int k = 0; k < 2; k++) {
+    double sum = 0;
+    for (int i = 0; i < b->comm_n[k]; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, b->comm_ev[k][i][0], b->comm_ev[k][i][1])); sum += 1e3 * ms; }
+    mean_us2[k] = b->comm_n[k] ? sum / b->comm_n[k] : 0.0;
+    issued2[k] = b->comm_total[k];
+  }
+  return 0;
+}
 int dmvio_hip_ba_partition_points(const int* host, int N, int world, double max_imbalance, int* owner_out) {
   if (N < 0 || world < 1 || (N > 0 && (!host || !owner_out))) return failmsg("dmvio_hip_ba_partition_points: bad argument");
   if (max_imbalance <= 0) max_imbalance = 1.25;

@@ -832,7 +832,9 @@ __device__ __forceinline__ bool lmWaveStep(LMState& S, const TrackerDev& trk, co
 // one device-scope arrive counter, every workgroup adds the C partials in rank order and runs the (deterministic) LM control
 // step redundantly — one inter-workgroup barrier per evaluation, no second one.  Partials are double-buffered by evaluation
 // parity; the launch guarantees B*C <= resident workgroups, so the spin cannot deadlock.
-struct ClusterArgs { int C; float* part; /* B x 2 x C x ACC_PAD */ unsigned int* cnt; /* B, zeroed before the launch */ LMProblemOut* discard; /* device scratch entry */ };
+#define LM_LOG_EVALS 96   // evaluations per problem the diagnostic log holds (a track runs ~15; maxIterations sum to 180, the log is cut there)
+struct ClusterArgs { int C; float* part; /* B x 2 x C x ACC_PAD */ unsigned int* cnt; /* B, zeroed before the launch */ LMProblemOut* discard; /* device scratch entry */
+                     EvalP* log; /* diagnostics (dmvio_hip_tracker_debug_record_replay): B x LM_LOG_EVALS evaluation parameters, or NULL */ int* log_n; /* B */ };
 
 __device__ __forceinline__ void clusterExchange(float* s_tot, const ClusterArgs& cl, const int prob, const int rank, const unsigned int phase) {
   float* __restrict__ mine = cl.part + (((size_t)prob * 2 + (phase & 1u)) * cl.C + rank) * ACC_PAD;
@@ -889,6 +891,7 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
   const bool tiled0 = TL && __builtin_amdgcn_readfirstlane((int)fs.tiled0[slot]) != 0;
   long long tStep = 0, tEval = 0;
+  unsigned int phase_log = 0;
   for (;;) {
     const long long t0 = wall_clock64();
     if (threadIdx.x < 64) {
@@ -898,6 +901,12 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     __syncthreads();
     const long long t1 = wall_clock64();
     tStep += t1 - t0;
+    if (cl.log && rank == 0 && threadIdx.x == 0) {   // diagnostics: the schedule of evaluations this problem runs (k_track_replay runs it again without the control steps)
+      const int k = (int)phase_log;
+      if (s_go && k < LM_LOG_EVALS) cl.log[(size_t)prob * LM_LOG_EVALS + k] = s_e;
+      if (!s_go) cl.log_n[prob] = k < LM_LOG_EVALS ? k : LM_LOG_EVALS;
+    }
+    phase_log++;
     if (!s_go) break;
     const int lvl = s_e.lvl;
     // the plane's address is wave-uniform (level 0 comes out of the pointer table): keep it in scalar registers
@@ -933,6 +942,37 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     if (threadIdx.x < 64) pout.H[threadIdx.x] = s_H[threadIdx.x];
     if (threadIdx.x < 8) pout.b[threadIdx.x] = s_b[threadIdx.x];
   }
+}
+
+// Diagnostics (profiles/r05_tracker_floor.md): the evaluations of a recorded k_track_lm launch — the same template points, the same taps, the same fused reductions, in the
+// same order per problem — WITHOUT the LM control steps between them (the parameters of evaluation k come out of the log instead of out of a solve).  The difference to the
+// recorded launch is what the control step costs on the critical path of a full batch; the sums of every evaluation are still formed (and the last one stored), so nothing of
+// the evaluation itself is optimised away.
+template <int T, int W>
+__global__ void __launch_bounds__(T, W) k_track_replay(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in, const EvalP* __restrict__ log,
+                                                     const int* __restrict__ log_n, float* __restrict__ sink) {
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
+  __shared__ float s_tot[ACC_PAD];
+  __shared__ EvalP s_e;
+  const int prob = blockIdx.x;
+  const int slot = in[prob].new_slot;
+  initStage<T>(s_stage);
+  const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
+  const int n = log_n[prob];
+  for (int k = 0; k < n; k++) {
+    if (threadIdx.x < sizeof(EvalP) / 4) reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x] = reinterpret_cast<const unsigned int*>(log + (size_t)prob * LM_LOG_EVALS + k)[threadIdx.x];
+    __syncthreads();
+    const int lvl = s_e.lvl;
+    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
+    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+    if (clean) blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot);
+    else blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot);
+    __syncthreads();
+  }
+  if (threadIdx.x < ACC_PAD) sink[(size_t)prob * ACC_PAD + threadIdx.x] = s_tot[threadIdx.x];
 }
 
 }  // namespace dmv

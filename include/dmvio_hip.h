@@ -161,6 +161,10 @@ int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm)
 int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* trk, int eval_blocks, int lm_threads, int lm_waves, int lm_cluster);
 /* 1 (default): a host-driven LM (dmvio_hip_tracker_track of one frame, dmvio_hip_tracker_track_vio) posts its evaluations to the resident evaluation server; 0: one launch each */
 int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* trk, int on);
+/* Diagnostics (profiles/r05_tracker_floor.md): mode 1 = the following dmvio_hip_tracker_track_batch_launch calls record the parameters of every evaluation they run (full
+ * batches: one 256-thread workgroup per problem); mode 2 = they run the recorded evaluations again without the LM control steps between them (same points, same taps, same
+ * fused reductions; no results to fetch — time the launch on the context's stream); 0 = normal operation. */
+int dmvio_hip_tracker_debug_record_replay(dmvio_hip_tracker* trk, int mode);
 /* Idle limit of the evaluation server (the resident kernel behind a single-frame dmvio_hip_tracker_track / _track_vio call): it leaves after this long without a request
  * and is started again by the next one.  Default 5000 us; raise it when the computeCoarseUpdate hook (IMUIntegration's factor-graph solve) regularly takes longer, so
  * that an LM iteration does not pay a relaunch.  100 us .. 2 s. */
@@ -395,6 +399,11 @@ int dmvio_hip_ba_last_decide_ticks(dmvio_hip_ba* ba, int ticks4[4]);
  *   nccl_comm: an ncclComm_t of RCCL whose rank `rank` lives on this handle's device (not owned; NULL with world 0 detaches).
  *   Every rank must issue the same sequence of BA calls. */
 int dmvio_hip_ba_set_comm(dmvio_hip_ba* ba, void* nccl_comm, int rank, int world);
+/* Measurement (RCCL transport): HIP events around the sharded iteration's collectives on the BA stream.  _comm_timing(1) starts collecting and clears the counters;
+ * _comm_times waits for the stream and returns the mean microseconds of [all-reduce of the packed system | all-gather of the decision records] over the first 64 of each,
+ * and how many of each were issued since. */
+int dmvio_hip_ba_comm_timing(dmvio_hip_ba* ba, int on);
+int dmvio_hip_ba_comm_times(dmvio_hip_ba* ba, double mean_us2[2], long issued2[2]);
 /* The partition policy of the sharded window (north_star: "one keyframe per GPU"): which rank owns which point.  Points follow their HOST keyframe
  * (FrameHessian::pointHessians, HessianBlocks.h:138; EFFrame::points, EnergyFunctionalStructs.h:160): whole keyframes are dealt to the ranks, largest first, each to the
  * currently lightest rank (ties: lower keyframe index / lower rank first); when the heaviest rank would then hold more than max_imbalance x N / world points (the newest

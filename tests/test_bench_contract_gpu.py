@@ -25,6 +25,8 @@ def test_bench_line_contract(gpu_required):
     assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["frames_per_step_per_gpu"] == 256
     assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]                 # whole-job frames/s == frames per step / step time
+    q = d["ms_per_step_p10_p50_p90"]
+    assert len(q) == 3 and q[0] <= q[1] <= q[2] and d["ms_per_step_min_max"][0] <= q[0] and q[2] <= d["ms_per_step_min_max"][1]      # the K timed steps one by one
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_track_lm"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
@@ -44,6 +46,12 @@ def test_bench_line_contract(gpu_required):
     assert rb["algorithmic_bytes_per_launch"] == 464 * ba["window"]["residuals"]
     assert abs(rb["achieved"] - rb["algorithmic_bytes_per_launch"] / (rb["kernel_us"] * 1e-6) / 1e9) < 2e-3 * rb["achieved"]
     assert set(rb["chain_us"]) == {"k_ba_linearize", "k_ba_point_sums", "k_ba_accumulate", "k_ba_stitch", "k_ba_stitch_gather"} and rb["iteration"]["kernels_us"] < rb["iteration"]["wall_us"] * 1.2
+    # W windows per launch sequence on the device-resident loop: the sweep, its own roofline object for the batched linearisation
+    bw = ba["batched_windows"]
+    assert "error" not in bw, bw
+    assert [r_["windows"] for r_ in bw["sweep"]] == [1, 4, 16, 64] and bw["value"] == max(r_["value"] for r_ in bw["sweep"]) and bw["value"] > ba["value"]
+    assert bw["roofline"]["kernel"] == "k_ba_linearize_b" and abs(bw["roofline"]["frac"] - bw["roofline"]["achieved"] / 8000.0) < 1e-3
+    assert bw["roofline"]["algorithmic_bytes_per_launch"] == bw["at_windows"] * 464 * ba["window"]["residuals"]
     cb = ba["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["unit"] == "GN-iters/s"
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref.so")):
@@ -55,6 +63,10 @@ def test_bench_line_contract(gpu_required):
         assert di["frames"] == 60 and di["keyframe_optimisations"] >= 3 and di["adapter_failures"] == 0 and not di["lost"]
         assert di["traj_rmse_m"] < 1e-3 and 0 < di["hip_backed_s"] < di["all_cpu_s"] <= di["all_cpu_single_threaded_s"] * 1.2
         assert di["ms_per_frame_after_initialisation"]["hip_backed"] < di["ms_per_frame_after_initialisation"]["all_cpu"]
+        # the reference's DEFAULT configuration (VIO) through the same adapter, and the batched try loop of trackNewCoarse
+        assert "error" not in di["vio"], di["vio"]
+        assert di["vio"]["adapter_failures"] == 0 and not di["vio"]["lost"] and di["vio"]["traj_rmse_m"] < 1.5e-3 and di["vio"]["adapter_calls"]["optimize_vio"] >= 3
+        assert di["track_new_coarse"]["served_by_the_batched_try_loop"] > 0
     assert d["pcie"]["good"] and d["pcie"]["raw_u8"]["good"] and d["pcie"]["raw_u8"]["value"] > d["pcie"]["value"]
     assert d["max_pose_err_m"] < 5e-3
 

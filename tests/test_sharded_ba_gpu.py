@@ -15,7 +15,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(pkg, case, ctx, setup=None, its=6):
+def _run(pkg, case, ctx, setup=None, its=6, before_close=None):
     ba = pkg.BundleAdjusterHip(ctx)
     ba.set_case(case, list(range(case["n_frames"])))
     if setup:
@@ -23,6 +23,8 @@ def _run(pkg, case, ctx, setup=None, its=6):
     out = ba.optimize(its)
     poses = np.stack([ba.frame_pose(k)[0] for k in range(case["n_frames"])])
     idepth = ba.point_state()[0]
+    if before_close:
+        before_close(ba)
     ba.close()
     return out, poses, idepth
 
@@ -36,10 +38,18 @@ def test_rccl_world1_runs_the_sharded_path_bit_identically(pkg, synth, gpu_requi
         ctx.frame_upload(k, case["imgs"][k])
     ref, rposes, rid = _run(pkg, case, ctx)
     comm = pkg.RcclCommunicator(ctx, pkg.RcclCommunicator.unique_id(ctx.L), 0, 1)
+    times = {}
+
+    def attach(ba):
+        ba.set_comm(comm, 0, 1); ba.comm_timing(True)
     try:
-        out, poses, idepth = _run(pkg, case, ctx, lambda ba: ba.set_comm(comm, 0, 1))
+        out, poses, idepth = _run(pkg, case, ctx, attach, before_close=lambda ba: times.update(ba.comm_times()))
     finally:
         comm.close()
+    # the collectives of the sharded iteration as HIP events on the BA stream (what the N > 1 bench line reports as ba.allreduce_us / ba.allgather_us): one all-reduce per
+    # accumulation, one all-gather per linearisation
+    print("RCCL world 1: all-reduce %.1f us x %d, all-gather %.1f us x %d" % (times["allreduce_us"], times["allreduces"], times["allgather_us"], times["allgathers"]))
+    assert times["allreduces"] >= out["iterations"] and times["allgathers"] >= out["iterations"] + 1 and 0 < times["allreduce_us"] < 5e4 and 0 < times["allgather_us"] < 5e4
     assert out["iterations"] == ref["iterations"] and out["rmse"] == ref["rmse"] and out["finalEnergy"] == ref["finalEnergy"]
     assert np.array_equal(out["trace"], ref["trace"])
     assert np.array_equal(poses, rposes) and np.array_equal(idepth, rid)
