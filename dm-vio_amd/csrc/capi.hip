@@ -62,6 +62,8 @@ struct dmvio_hip_tracker {
   std::vector<unsigned char> h_rank;
   std::vector<int> last_repeat_lvl;            // per problem of the last fetch: the level that ran twice (or -1) ...
   std::vector<double> last_first_pass_res;     // ... and its residual after the first pass
+  int batch_kernel = 0;          // dmvio_hip_tracker_set_batch_kernel: 1 = full batches on k_track_lm_pp (control steps beside the evaluations)
+  unsigned int* d_pp_next = nullptr;
   int debug_mode = 0, log_cap = 0, log_B = 0;   // dmvio_hip_tracker_debug_record_replay
   EvalP* d_log = nullptr; int* d_log_n = nullptr; float* d_log_sink = nullptr;
   LMProblemOut *d_out = nullptr, *h_out = nullptr;   // h_out: 2 x batch_cap entries of pinned host memory the kernel writes its results into (alternating per launch)
@@ -526,8 +528,14 @@ dmvio_hip_tracker* dmvio_hip_tracker_create(dmvio_hip_ctx* c) {
   }
   R.tile_off[c->levels] = tiles; R.total = off; t->n_tiles = tiles;
   R.seg_x0 = (R.w[0] + 7) / 8;
+  R.order = 0;
+  {
+    int so = 0;
+    for (int l = 0; l < c->levels; l++) { R.seg_x[l] = (R.w[l] + 7) / 8; R.seg_off[l] = so; so += R.seg_x[l] * R.h[l]; }
+    R.seg_off[c->levels] = so;
+  }
   t->flow_words = ((size_t)R.w[0] * R.h[0] + 63) / 64;
-  HIPCHKP(hipMalloc((void**)&t->d_seg, sizeof(int) * R.seg_x0 * R.h[0]));
+  HIPCHKP(hipMalloc((void**)&t->d_seg, sizeof(int) * R.seg_off[c->levels]));
   HIPCHKP(hipMalloc((void**)&t->d_flow_mask, sizeof(unsigned long long) * t->flow_words));
   HIPCHKP(hipMemset(t->d_flow_mask, 0, sizeof(unsigned long long) * t->flow_words));
   t->dev.flow_mask = t->d_flow_mask;
@@ -565,6 +573,8 @@ void dmvio_hip_tracker_destroy(dmvio_hip_tracker* t) {
   t->xchg = nullptr;   // the exchange owns a device buffer (RCCL transport): released now, while the context it was allocated under is still alive
   hipFree(t->d_idp); hipFree(t->d_wsp); hipFree(t->d_idp2); hipFree(t->d_wsp2); hipFree(t->d_dense);
   hipFree(t->d_tile_count); hipFree(t->d_tile_base); hipFree(t->d_pc_n); hipFree(t->d_seg); hipFree(t->d_flow_mask);
+  if (t->d_pp_next) hipFree(t->d_pp_next);
+  if (t->d_log) { hipFree(t->d_log); hipFree(t->d_log_n); hipFree(t->d_log_sink); }
   for (int l = 0; l < t->ctx->levels; l++) hipFree(t->d_pc[l]);
   hipFree(t->d_pc_ptrs); hipFree(t->d_pts); hipFree(t->d_partials); if (t->h_mail) hipHostFree(t->h_mail); if (t->h_rec) hipHostFree(t->h_rec);
   hipHostFree(t->h_tot); hipFree(t->d_arrive); hipFree(t->d_leave);
@@ -667,7 +677,7 @@ int dmvio_hip_tracker_set_ref(dmvio_hip_tracker* t, int ref_slot, float ref_expo
   hipLaunchKernelGGL(k_ref_dilate, dim3((unsigned)((R.total + 255) / 256)), dim3(256), 0, s, R, t->d_idp, t->d_wsp, t->d_idp2, t->d_wsp2);
   HIPCHK(hipMemsetAsync(t->d_flow_mask, 0, sizeof(unsigned long long) * t->flow_words, s));
   hipLaunchKernelGGL(k_ref_count, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_count, t->d_seg);
-  hipLaunchKernelGGL(k_ref_scan, dim3(R.levels + 1), dim3(1024), 0, s, R, t->d_tile_count, t->d_tile_base, t->d_pc_n, t->d_seg);
+  hipLaunchKernelGGL(k_ref_scan, dim3(2 * R.levels), dim3(1024), 0, s, R, t->d_tile_count, t->d_tile_base, t->d_pc_n, t->d_seg);
   hipLaunchKernelGGL(k_ref_write, dim3(t->n_tiles), dim3(256), 0, s, R, t->d_idp2, t->d_wsp2, c->fs, ref_slot, t->d_tile_base, t->d_seg, t->d_pc_ptrs,
                      t->d_dense, t->d_flow_mask);
   HIPCHK(hipGetLastError());
@@ -973,6 +983,20 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
       any_tiled = false;
     }
   }
+  if (t->batch_kernel == 1 && C == 1 && T == 256 && !any_tiled && !t->debug_mode && B >= 512) {
+    // full batches: five-wave workgroups holding two problems each, the LM control step of one beside the evaluation of the other; persistent grid, problems dealt out by a
+    // device-wide counter
+    if (!t->d_pp_next) HIPCHK(hipMalloc((void**)&t->d_pp_next, sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(t->d_pp_next, 0, sizeof(unsigned int), c->stream));
+    const int grid = std::min((B + 1) / 2, 1024);   // 256 CUs x 4 resident workgroups at 128 registers
+    hipLaunchKernelGGL(k_track_lm_pp, dim3(grid), dim3(256), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap,
+                       t->staged_coarsest, B, t->d_pp_next);
+    HIPCHK(hipGetLastError());
+    t->last_threads = 256;
+    if (!t->done_event[t->out_cur]) HIPCHK(hipEventCreateWithFlags(&t->done_event[t->out_cur], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(t->done_event[t->out_cur], c->stream));
+    return 0;
+  }
 #define DMV_LAUNCH_LM(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
 #define DMV_LAUNCH_LM_TILED(TT, WW) hipLaunchKernelGGL((k_track_lm<TT, WW, true>), dim3(B * C), dim3(TT), 0, c->stream, t->dev, c->fs, t->h_in + (size_t)t->out_cur * t->batch_cap, t->h_out + (size_t)t->out_cur * t->batch_cap, t->staged_coarsest, cl)
   if (any_tiled && T == 256) DMV_LAUNCH_LM_TILED(256, 4);
@@ -1152,6 +1176,24 @@ int dmvio_hip_tracker_debug_record_replay(dmvio_hip_tracker* t, int mode) {
   if (!t || mode < 0 || mode > 2) return failmsg("tracker_debug_record_replay: bad argument");
   std::lock_guard<std::mutex> lk(t->ctx->mu);
   t->debug_mode = mode;
+  return 0;
+}
+// Order in which setCoarseTrackingRef stores the template points of every level: 0 (default) = 8x8-pixel tiles, Z-ordered inside 16x16 blocks; 1 = the reference's
+// row-major order (CoarseTracker.cpp:249-293).  Takes effect with the next dmvio_hip_tracker_set_ref.  The sums of an evaluation are formed per 64-point group and then in
+// group order, so the two orders group the fp32 additions differently (results agree to rounding, like cluster sizes do); profiles/r05_tracker_floor.md has the measurement.
+int dmvio_hip_tracker_set_template_order(dmvio_hip_tracker* t, int row_major) {
+  if (!t) return failmsg("null tracker");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->R.order = row_major ? 1 : 0;
+  return 0;
+}
+// Kernel of FULL batches (>= 512 problems, one 256-thread evaluation group per problem): 0 = k_track_lm (four wavefronts per problem: they evaluate, then three wait
+// while the first solves), 1 = k_track_lm_pp (five wavefronts hold two problems: the control step of one runs beside the evaluation of the other; per problem the same
+// arithmetic in the same order — identical results).
+int dmvio_hip_tracker_set_batch_kernel(dmvio_hip_tracker* t, int mode) {
+  if (!t || mode < 0 || mode > 1) return failmsg("tracker_set_batch_kernel: 0 or 1");
+  std::lock_guard<std::mutex> lk(t->ctx->mu);
+  t->batch_kernel = mode;
   return 0;
 }
 int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* t, int on) {

@@ -21,6 +21,9 @@ struct RefLevels {
   int tile_off[DMV_MAX_LEVELS + 1];  // first 16x16 block of each level
   int blocks_x[DMV_MAX_LEVELS];      // 16x16 blocks per row of the level
   int seg_x0;                        // level 0: 8-pixel segments per row (row-major rank reconstruction)
+  int seg_x[DMV_MAX_LEVELS];         // 8-pixel segments per row of every level, and where the level's (row, segment) counts start in seg_count
+  int seg_off[DMV_MAX_LEVELS + 1];
+  int order;                         // 0: the template is stored in tile order; 1: in the reference's row-major order (dmvio_hip_tracker_set_template_order)
   size_t total;                    // total pixels over all levels
 };
 
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) k_ref_count(const RefLevels R, const floa
   const unsigned long long m = __ballot(flag);
   const int lane = threadIdx.x & 63;
   if (lane == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
-  if (lvl == 0 && inside && (lane & 7) == 0) seg_count[y * R.seg_x0 + (x >> 3)] = __popcll((m >> (lane & 56)) & 0xffull);
+  if (inside && (lane & 7) == 0) seg_count[R.seg_off[lvl] + y * R.seg_x[lvl] + (x >> 3)] = __popcll((m >> (lane & 56)) & 0xffull);
   __syncthreads();
   if (threadIdx.x == 0) blk_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
@@ -182,7 +185,7 @@ __device__ __forceinline__ int scan1024(const int c, int* s_wave, int& total) {
 }
 
 // pass 2: blockIdx.x < levels: exclusive scan of the block counts of that level -> blk_base, pc_n[lvl].
-//         blockIdx.x == levels: level-0 row-major rank tables: seg_count -> exclusive prefix in row-major order (in place).
+//         blockIdx.x >= levels: row-major rank tables of level blockIdx.x - levels: seg_count -> exclusive prefix in row-major order (in place).
 __global__ void __launch_bounds__(1024) k_ref_scan(const RefLevels R, const int* __restrict__ blk_count, int* __restrict__ blk_base,
                                                     int* __restrict__ pc_n, int* __restrict__ seg_count) {
   __shared__ int s_wave[16];
@@ -200,13 +203,15 @@ __global__ void __launch_bounds__(1024) k_ref_scan(const RefLevels R, const int*
     }
     if (threadIdx.x == 0) pc_n[lvl] = carry;
   } else {
-    const int n = R.h[0] * R.seg_x0;  // row-major (y, segment) order == raster order of the segments
+    const int lvl = blockIdx.x - R.levels;
+    const int n = R.h[lvl] * R.seg_x[lvl];  // row-major (y, segment) order == raster order of the segments
+    int* sc = seg_count + R.seg_off[lvl];
     for (int base = 0; base < n; base += 1024) {
       const int t = base + threadIdx.x;
-      const int c = (t < n) ? seg_count[t] : 0;
+      const int c = (t < n) ? sc[t] : 0;
       int total;
       const int ex = scan1024(c, s_wave, total);
-      if (t < n) seg_count[t] = carry + ex;
+      if (t < n) sc[t] = carry + ex;
       carry += total;
     }
   }
@@ -233,13 +238,11 @@ __global__ void __launch_bounds__(256) k_ref_write(const RefLevels R, const floa
   int woff = 0;
   for (int k = 0; k < wave; k++) woff += s_cnt[k];
   if (flag) {
-    const int pos = blk_base[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull));
+    const unsigned long long rowbits = (m >> (lane & 56)) & 0xffull;
+    const int raster = seg_prefix[R.seg_off[lvl] + y * R.seg_x[lvl] + (x >> 3)] + __popcll(rowbits & ((1ull << (lane & 7)) - 1ull));   // rank in the reference's row-major list
+    const int pos = R.order ? raster : blk_base[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull));
     pc[lvl][pos] = rec;
-    if (lvl == 0) {
-      const unsigned long long rowbits = (m >> (lane & 56)) & 0xffull;
-      const int raster = seg_prefix[y * R.seg_x0 + (x >> 3)] + __popcll(rowbits & ((1ull << (lane & 7)) - 1ull));
-      if ((raster & 31) == 0) atomicOr(&flow_mask[pos >> 6], 1ull << (pos & 63));
-    }
+    if (lvl == 0 && (raster & 31) == 0) atomicOr(&flow_mask[pos >> 6], 1ull << (pos & 63));
   }
   if (inside) idepth_dense[R.off[lvl] + x + y * R.w[lvl]] = idn;
 }

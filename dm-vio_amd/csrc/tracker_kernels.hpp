@@ -319,6 +319,116 @@ __device__ __forceinline__ void blockEval(const EvalP& e, const LevelGeom& g, co
   __syncthreads();
 }
 
+// blockEval with an UNEVEN split of the template over the wavefronts (k_track_lm_pp): the points are dealt out in chunks of 64; of every `period` consecutive chunks this wave
+// takes the chunks [lo, hi).  (blockEval itself is the case period = stride / 64, one chunk per wave.)  Per point the same arithmetic; the per-wave partial sums group the
+// points differently, the waves' partials are still combined in wave order — deterministic, reproducible run to run.
+template <int T, bool GUARD = true>
+__device__ __forceinline__ void blockEvalChunks(const EvalP& e, const LevelGeom& g, const float4* __restrict__ pc, const int n,
+                                                const unsigned long long* __restrict__ flow_mask, const int period, const int lo, const int hi,
+                                                const float* __restrict__ img, const float huberTH, float* s_stage, float* s_partH,
+                                                float (*s_partS)[8], float* s_tot) {
+  constexpr bool TILED = false;
+  const int first = threadIdx.x, stride = T;   // (the flow-indicator pass below keeps the even split over the threads)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* __restrict__ wJ = s_stage + wave * SJ_WAVE_FLOATS;
+  float* __restrict__ wW = wJ + SJ_ROWS * SJ_STRIDE;
+  // four independent accumulator chains: a 16x16x4 f32 MFMA has a 40-cycle dependent latency but a 32-cycle issue slot
+  f32x4 accH0 = {0.0f, 0.0f, 0.0f, 0.0f}, accH1 = accH0, accH2 = accH0, accH3 = accH0;
+  EvalStats st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool lvl0 = (e.lvl == 0);
+  const EvalU eu = makeEvalU(e, g, huberTH);
+  const int mi = lane & 15, mk = lane >> 4;
+  // wave-uniform trip count: lane 0 of the wave owns index first - lane.  The template record of the NEXT iteration is
+  // requested before this iteration's taps, so the two dependent memory round trips of a point (record -> projection ->
+  // taps) overlap across iterations.
+  const int m = hi - lo;                                   // chunks per period of this wave (wave-uniform; 0: the wave only takes part in the reduction)
+  // chunk c -> the wave's next chunk: inside its run of the period, else the first of the next period
+  auto nextBase = [&](const int base) -> int { const int c = base >> 6; return ((c % period) + 1 < hi ? c + 1 : c + period - (m - 1)) << 6; };
+  const int base0 = m > 0 ? lo << 6 : n;
+  // three-stage software pipeline per lane: template record two points ahead, warp + tap loads one point ahead, residual /
+  // Jacobian row / MFMA of the current point — the gathers of point i+1 are in flight during the arithmetic of point i
+  const int nm1 = max(n - 1, 0);
+  float4 P1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  PointProj q0;
+  Taps33 t0;
+  q0.u = q0.v = q0.new_idepth = q0.refColor = 0.f; q0.Ku = q0.Kv = 2.5f; q0.inb = false;
+  if (n > 0 && m > 0) {
+    const float4 P0 = pc[min(base0 + lane, nm1)];
+    P1 = pc[min(nextBase(base0) + lane, nm1)];
+    projectPoint<TILED>(P0, base0 + lane < n, eu, img, q0, t0);
+  }
+  // one pipeline step: finishes the point held in (qc, tc) while the taps of the next one are requested into (qn, tn).  The loop below is
+  // unrolled twice with the two register sets swapping roles, so the hand-over costs no register moves (19 per step otherwise).
+  auto step = [&](const PointProj& qc, const Taps33& tc, PointProj& qn, Taps33& tn, const int base) __attribute__((always_inline)) {
+    const int nb = nextBase(base);
+    projectPoint<TILED>(P1, nb + lane < n, eu, img, qn, tn);      // next point: its taps are requested now, consumed next step
+    P1 = pc[min(nextBase(nb) + lane, nm1)];                // unconditional (clamped) prefetch
+    float J[9], w;
+    finishPoint<GUARD>(qc, tc, eu, st, J, w);
+#pragma unroll
+    for (int k = 0; k < 9; k++) wJ[k * SJ_STRIDE + lane] = J[k];
+    wW[lane] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int m = 0; m < 16; m += 4) {
+      const float a0 = wJ[mi * SJ_STRIDE + 4 * m + mk], a1 = wJ[mi * SJ_STRIDE + 4 * m + 4 + mk];
+      const float a2 = wJ[mi * SJ_STRIDE + 4 * m + 8 + mk], a3 = wJ[mi * SJ_STRIDE + 4 * m + 12 + mk];
+      const float b0 = a0 * wW[4 * m + mk], b1 = a1 * wW[4 * m + 4 + mk], b2 = a2 * wW[4 * m + 8 + mk], b3 = a3 * wW[4 * m + 12 + mk];
+      accH0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accH0, 0, 0, 0);
+      accH1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accH1, 0, 0, 0);
+      accH2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, accH2, 0, 0, 0);
+      accH3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, accH3, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  PointProj q1;
+  Taps33 t1;
+  for (int base = base0; base < n;) {
+    step(q0, t0, q1, t1, base);
+    base = nextBase(base);
+    if (base >= n) break;   // wave-uniform
+    step(q1, t1, q0, t0, base);
+    base = nextBase(base);
+  }
+  if (lvl0) {
+    // flow-indicator samples: dense pass over the flagged entries (bit j of word k <=> template entry 64k + j)
+    const int nwords = (n + 63) >> 6;
+    for (int wI = first; wI < nwords; wI += stride) {
+      unsigned long long m = flow_mask[wI];
+      while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        flowSamplePoint(pc[64 * wI + bit], eu, g.Ki, st);
+      }
+    }
+  }
+  // per-wave partials -> LDS.  accH[r] = D[row = mk*4 + r][col = mi]
+#pragma unroll
+  for (int r = 0; r < 4; r++) s_partH[wave * 256 + (mk * 4 + r) * 16 + mi] = (accH0[r] + accH1[r]) + (accH2[r] + accH3[r]);
+  const float stot = waveReduceStats(st, lane);
+  if (lane < 8) s_partS[wave][lane] = stot;
+  __syncthreads();
+  if (threadIdx.x < ACC_PAD) {
+    // slot -> (r, c) of the upper triangle, or a statistic
+    float s = 0.0f;
+    const int k = threadIdx.x;
+    if (k < 45) {
+      int r = 0, off = 0;
+      while (k >= off + (9 - r)) { off += 9 - r; r++; }
+      const int c = r + (k - off);
+#pragma unroll
+      for (int wv = 0; wv < T / 64; wv++) s += s_partH[wv * 256 + r * 16 + c];
+    } else if (k < ACC_N) {
+#pragma unroll
+      for (int wv = 0; wv < T / 64; wv++) s += s_partS[wv][k - 45];
+    }
+    s_tot[k] = s;
+  }
+  __syncthreads();
+}
+
 // zero the rows 9..15 of every wave's staging area once (they are never written afterwards)
 template <int T>
 __device__ __forceinline__ void initStage(float* s_stage) {
@@ -895,7 +1005,11 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   for (;;) {
     const long long t0 = wall_clock64();
     if (threadIdx.x < 64) {
+      // the control step is ONE dependent chain of ~1100 instructions on this wavefront while its three siblings wait: raised issue priority lets it through ahead of the
+      // evaluation waves of the other workgroups that share the SIMD (they lose nothing they could not issue a few cycles later)
+      __builtin_amdgcn_s_setprio(3);
       const bool go = lmWaveStep(S, trk, pin, pout, s_tot, s_H, s_b, s_x, s_trk, s_e, threadIdx.x);
+      __builtin_amdgcn_s_setprio(0);
       if (threadIdx.x == 0) s_go = go ? 1 : 0;
     }
     __syncthreads();
@@ -941,6 +1055,113 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
   if (rank == 0) {
     if (threadIdx.x < 64) pout.H[threadIdx.x] = s_H[threadIdx.x];
     if (threadIdx.x < 8) pout.b[threadIdx.x] = s_b[threadIdx.x];
+  }
+}
+
+// ---- full batches, round 5: the LM control step off the evaluation waves' critical path.  k_track_lm's four waves evaluate, then three of them wait while wave 0 solves
+// the damped 8x8 system and steps the pose (13.7 us of every ~50 us round in a full batch; the evaluations alone run 17 % faster: k_track_replay, profiles/r05_tracker_floor.md).
+// Here a workgroup is FIVE wavefronts and holds TWO alignment problems: waves 0-3 evaluate problem X = round & 1 while wave 4 runs the control step of the other problem on the
+// sums its evaluation left in the previous round — the same blockEval over the same 256-thread grouping and the same lmWaveStep, so every problem's results are bit-identical
+// to k_track_lm<256>'s.  A slot that finishes its problem takes the next one from a device-wide counter (the grid is persistent: any number of problems).
+__global__ void __launch_bounds__(256, 4) k_track_lm_pp(const TrackerDev trk, const FrameStore fs, const LMProblemIn* __restrict__ in, LMProblemOut* __restrict__ out,
+                                                       const int coarsestLvl, const int B, unsigned int* __restrict__ next) {
+  constexpr int T = 256;
+  __shared__ float s_stage[(T / 64) * SJ_WAVE_FLOATS];
+  __shared__ float s_partH[(T / 64) * 256];
+  __shared__ float s_partS[T / 64][8];
+  __shared__ float s_tot[2][ACC_PAD];
+  __shared__ EvalP s_e[2];
+  __shared__ double s_H[2][64], s_b[2][8], s_x[2][8];
+  __shared__ int s_go[2], s_gon[2], s_trk[2][8], s_prob[2];   // s_gon: the flag the control wave leaves for the NEXT round (s_go is read by every wave at the top of a round)
+  __shared__ LMState S[2];
+  __shared__ LMProblemIn s_in[2];
+  __shared__ long long s_tstep[2], s_teval[2];
+  const bool ctrl = threadIdx.x < 64;   // wave 0: the control steps, and a smaller share of every evaluation
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < (T / 64) * SJ_WAVE_FLOATS; k += T) s_stage[k] = 0.0f;
+  // (control wave) slot <- the next problem of the batch, its first control step prepares its first evaluation; returns whether the slot has work
+  auto fetch = [&](const int slot) -> bool {
+    int prob = 0;
+    if (lane == 0) prob = (int)atomicAdd(next, 1u);
+    prob = __builtin_amdgcn_readfirstlane(prob);
+    if (prob >= B) { if (lane == 0) { s_gon[slot] = 0; s_prob[slot] = -1; } return false; }
+    if (lane < (int)(sizeof(LMProblemIn) / 4)) reinterpret_cast<unsigned int*>(&s_in[slot])[lane] = reinterpret_cast<const unsigned int*>(in + prob)[lane];
+    s_H[slot][lane] = 0; if (lane < 8) { s_b[slot][lane] = 0; s_x[slot][lane] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+      LMState& Q = S[slot];
+      Q.cur = poseFrom7(s_in[slot].pose7);
+      Q.affA = s_in[slot].aff[0]; Q.affB = s_in[slot].aff[1];
+      for (int i = 0; i < 5; i++) Q.lastRes[i] = __builtin_nan("");
+      for (int i = 0; i < 3; i++) Q.flow[i] = 1000;
+      Q.lvl = coarsestLvl; Q.st = LM_LEVEL_BEGIN; Q.totalIts = 0; Q.nEvals = 0; Q.nPointEvals = 0; Q.haveRepeated = 0;
+      Q.iteration = 0; Q.lambda = 0.01f; Q.cutoffRepeat = 1; Q.incNorm = 0;
+      out[prob].repeated_lvl = -1; out[prob].first_pass_res = __builtin_nan("");
+      s_prob[slot] = prob; s_tstep[slot] = 0; s_teval[slot] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+  };
+  // (control wave) one control step of the slot's problem; when the problem ends its results are stored and the slot refilled.  Leaves s_go[slot].
+  auto control = [&](const int slot) {
+    for (;;) {
+      const int prob = __builtin_amdgcn_readfirstlane(s_prob[slot]);
+      if (prob < 0) return;
+      const long long t0 = wall_clock64();
+      const bool go = lmWaveStep(S[slot], trk, s_in[slot], out[prob], s_tot[slot], s_H[slot], s_b[slot], s_x[slot], s_trk[slot], s_e[slot], lane);
+      if (lane == 0) { s_tstep[slot] += wall_clock64() - t0; s_gon[slot] = go ? 1 : 0; }
+      if (go) return;
+      // the problem is finished: its remaining outputs (k_track_lm's tail), then the next problem's first step
+      LMProblemOut& po = out[prob];
+      if (lane == 0) {
+        const LMState& Q = S[slot];
+        for (int i = 0; i < 5; i++) po.lastRes[i] = Q.lastRes[i];
+        for (int i = 0; i < 3; i++) po.flow[i] = Q.flow[i];
+        po.iterations = Q.totalIts; po.n_evals = Q.nEvals; po.n_point_evals = Q.nPointEvals;
+        po.ticks_step = s_tstep[slot]; po.ticks_eval = s_teval[slot];
+      }
+      po.H[lane] = s_H[slot][lane];
+      if (lane < 8) po.b[lane] = s_b[slot][lane];
+      if (!fetch(slot)) return;
+    }
+  };
+  if (ctrl) {
+    for (int slot = 0; slot < 2; slot++) if (fetch(slot)) control(slot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { s_go[0] = s_gon[0]; s_go[1] = s_gon[1]; }
+  }
+  __syncthreads();
+  for (int round = 0;; round++) {
+    const int X = round & 1, Y = X ^ 1;
+    const int goX = s_go[X], goY = s_go[Y];
+    if (!goX && !goY) break;                      // workgroup-uniform: both slots drained, every evaluation consumed
+    const bool stepped = round > 0 && goY;
+    if (ctrl && stepped) control(Y);                // goY was set before slot Y's evaluation of the previous round: that evaluation ran, its sums wait in s_tot[Y]
+    if (goX) {
+      const long long t1 = wall_clock64();
+      const int slot = s_in[X].new_slot;
+      const int lvl = s_e[X].lvl;
+      const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
+      const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
+      const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
+                                        (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+      // the split of this level's points: of every `period` chunks of 64 wave 0 takes k0 (it also runs a control step of ~C per round), waves 1-3 three each;
+      // balanced where k0 / period = 1/4 - 3 C / (16 E): large levels 2 of 11, middle ones 1 of 10, small ones none
+      const int npt = trk.pc_n[lvl];
+      const int k0 = (stepped || round == 0) ? (npt >= 7000 ? 2 : (npt >= 3500 ? 1 : 0)) : 3;   // no control step beside this evaluation: the even split
+      const int period = 9 + k0;
+      const int lo = wave == 0 ? 0 : k0 + 3 * (wave - 1), hi = wave == 0 ? k0 : k0 + 3 * wave;
+      if (clean) blockEvalChunks<T, false>(s_e[X], trk.g[lvl], trk.pc[lvl], npt, trk.flow_mask, period, lo, hi, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot[X]);
+      else blockEvalChunks<T, true>(s_e[X], trk.g[lvl], trk.pc[lvl], npt, trk.flow_mask, period, lo, hi, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot[X]);
+      if (threadIdx.x == 64) s_teval[X] += wall_clock64() - t1;
+    } else { __syncthreads(); __syncthreads(); }   // the two barriers of the evaluation
+    if (ctrl && stepped && lane == 0) s_go[Y] = s_gon[Y];   // every wave has read this round's flags by now (they sit behind the two barriers above)
+    __syncthreads();
   }
 }
 

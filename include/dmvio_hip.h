@@ -161,6 +161,13 @@ int dmvio_hip_tracker_set_single_frame_mode(dmvio_hip_tracker* trk, int host_lm)
 int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* trk, int eval_blocks, int lm_threads, int lm_waves, int lm_cluster);
 /* 1 (default): a host-driven LM (dmvio_hip_tracker_track of one frame, dmvio_hip_tracker_track_vio) posts its evaluations to the resident evaluation server; 0: one launch each */
 int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* trk, int on);
+/* Kernel of full batches (>= 512 alignment problems per launch): 0 = four wavefronts per problem (they evaluate, then three wait while the first runs the LM control step),
+ * 1 = five wavefronts hold two problems, the control step of one beside the evaluation of the other, problems dealt out to a persistent grid by a device-wide counter.
+ * Per problem the same arithmetic in the same order: identical results. */
+int dmvio_hip_tracker_set_batch_kernel(dmvio_hip_tracker* trk, int mode);
+/* Storage order of the template points (from the next dmvio_hip_tracker_set_ref on): 0 (default) = 8x8-pixel tiles, Z-ordered inside 16x16 blocks; 1 = the reference's
+ * row-major order (CoarseTracker.cpp:249-293).  Same points, same per-point arithmetic; the fp32 partial sums are grouped differently (results agree to rounding). */
+int dmvio_hip_tracker_set_template_order(dmvio_hip_tracker* trk, int row_major);
 /* Diagnostics (profiles/r05_tracker_floor.md): mode 1 = the following dmvio_hip_tracker_track_batch_launch calls record the parameters of every evaluation they run (full
  * batches: one 256-thread workgroup per problem); mode 2 = they run the recorded evaluations again without the LM control steps between them (same points, same taps, same
  * fused reductions; no results to fetch — time the launch on the context's stream); 0 = normal operation. */

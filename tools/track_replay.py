@@ -74,5 +74,38 @@ print("k_track_lm recording %.3f ms" % np.median(t_rec))
 print("k_track_replay       %.3f ms per launch: the same evaluations without the LM control steps = %.3f of the full kernel" % (b, b / a))
 print("=> everything the control step costs on the critical path of this batch: %.1f %% of the launch" % (100 * (1 - b / a)))
 print("algorithmic bytes %.3f GB per launch: %.2f TB/s full kernel, %.2f TB/s evaluations alone" % (64 * pe / 1e9, 64 * pe / (a * 1e-3) / 1e12, 64 * pe / (b * 1e-3) / 1e12))
+# ---- part 2: the template stored in the reference's row-major order instead of 8x8 tiles (tools/template_lines.py counts the cache lines per load for both)
+L.dmvio_hip_tracker_set_template_order.argtypes = [C.c_void_p, C.c_int]
+for order, name in ((1, "row-major"), (0, "8x8 tiles (default)")):
+    L.dmvio_hip_tracker_set_template_order(trk.p, order)
+    trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])
+    trk.stage(slots, poses0, affs0)
+    for _ in range(6):
+        trk.launch()
+    torch.cuda.synchronize()
+    tt = timed(8)
+    rr = trk.fetch()
+    ev2, pe2 = trk.last_work()
+    truth = np.stack([synth.pose7(m[0], m[1]) for m in metas])
+    err = np.linalg.norm(rr["pose7"][:, :3] - truth[:, :3], axis=1).max()
+    print("template order %-20s k_track_lm %.3f ms per launch (median of 8), %d point-evaluations, all good: %s, max pose error %.2e m -> %.2f TB/s algorithmic"
+          % (name, np.median(tt), pe2, bool(rr["good"].all()), err, 64 * pe2 / (np.median(tt) * 1e-3) / 1e12))
+# ---- part 3: the control step off the evaluation waves' critical path (k_track_lm_pp)
+L.dmvio_hip_tracker_set_batch_kernel.argtypes = [C.c_void_p, C.c_int]
+trk.stage(slots, poses0, affs0)
+trk.launch(); base = trk.fetch()
+L.dmvio_hip_tracker_set_batch_kernel(trk.p, 1)
+trk.stage(slots, poses0, affs0)
+for _ in range(6):
+    trk.launch()
+torch.cuda.synchronize()
+tp = timed(8)
+rp = trk.fetch()
+dpose = np.abs(rp["pose7"][:, :3] - base["pose7"][:, :3]).max(); dres = np.nanmax(np.abs(rp["lastResiduals"] - base["lastResiduals"]) / np.abs(base["lastResiduals"]))
+evp, pep = trk.last_work()
+print("k_track_lm_pp        %.3f ms per launch (two problems per workgroup, the solving wave evaluates less; median of 8) = %.3f of k_track_lm; all good: %s, same iteration counts: %s, "
+      "poses within %.2e m, level residuals within %.2e relative of k_track_lm's; %d point-evaluations -> %.2f TB/s algorithmic"
+      % (np.median(tp), np.median(tp) / a, bool(rp["good"].all()), bool(np.array_equal(rp["iterations"], base["iterations"])), dpose, dres, pep, 64 * pep / (np.median(tp) * 1e-3) / 1e12))
+L.dmvio_hip_tracker_set_batch_kernel(trk.p, 0)
 if tk:
     print("in-kernel ticks summed over problems (100 MHz): control steps %.3g, evaluations %.3g -> %.1f %% of a workgroup's time in the control step" % (tk[0], tk[1], 100.0 * tk[0] / (tk[0] + tk[1])))
