@@ -616,7 +616,13 @@ struct OWindow {
             if (relBS > p.maxRelBaseline) p.maxRelBaseline = relBS;
             p.numGoodResiduals++;
           }
-        } else r.dropped = true;
+        } else {
+          // EnergyFunctional::dropResidual (EnergyFunctional.cpp:500-520) and deleteOut (FullSystemOptimize.cpp:174-193): the last residual of the point
+          // takes the removed one's slot, which is the order every later per-point sum runs in
+          r.dropped = true;
+          std::vector<int>& pr = points[r.point].residuals;
+          for (size_t k = 0; k < pr.size(); k++) if (pr[k] == ri) { pr[k] = pr.back(); pr.pop_back(); break; }
+        }
       }
     }
     setNewFrameEnergyTH();
@@ -1155,10 +1161,52 @@ struct OWindow {
     float ec = 0;
     for (int i = 0; i < 4; i++) ec += cDeltaF[i] * cPriorF[i] * cDeltaF[i];
     E += ec;
-    // calcLEnergyPt: linearised residuals (none outside marginalisation) + per-point prior term, Accumulator11 float sum
-    float acc = 0;
-    for (auto& p : points) acc += p.deltaF * p.deltaF * p.priorF;
-    return E + acc;
+    // calcLEnergyPt (EnergyFunctional.cpp:349-409) through IndexThreadReduce::reduce with a step of 50 (EnergyFunctional.cpp:427-428; the reduce has no
+    // single-threaded shortcut, IndexThreadReduce.h:78-88): every run of 50 points gets its own Accumulator11 (MatrixAccumulators.h:91-172: four fp32 lanes, shifted up
+    // into a 1k and a 1M level when more than 1000 updates sit in the level below) that takes, point by point, the energy (2 res_toZeroF + J delta) . (J delta) of the
+    // point's linearised active residuals — two 4-lane updates per residual, no shift-up — and then the point's prior term deltaF^2 priorF as a single update WITH
+    // shift-up; the fp32 totals of the runs are added in double (in the reference in the order the workers finish; here in run order).
+    double A = 0;
+    for (size_t p0 = 0; p0 < points.size(); p0 += 50) {
+      float d1[4] = {0, 0, 0, 0}, d1k[4] = {0, 0, 0, 0}, d1m[4] = {0, 0, 0, 0};
+      float numIn1 = 0, numIn1k = 0, numIn1m = 0;
+      auto shiftUp = [&](bool force) {
+        if (numIn1 > 1000 || force) { for (int k = 0; k < 4; k++) { d1k[k] = d1[k] + d1k[k]; d1[k] = 0; } numIn1k += numIn1; numIn1 = 0; }
+        if (numIn1k > 1000 || force) { for (int k = 0; k < 4; k++) { d1m[k] = d1k[k] + d1m[k]; d1k[k] = 0; } numIn1m += numIn1k; numIn1k = 0; }
+      };
+      for (size_t pi = p0; pi < std::min(points.size(), p0 + 50); pi++) {
+        const OPoint& p = points[pi];
+        const float dd = p.deltaF;
+        for (int ri : p.residuals) {
+          const ORes& r = res[ri];
+          if (r.dropped || !r.isLinearized || !r.isActive) continue;
+          const RawJ& rJ = r.Jef;
+          const float* dp = &adHTdeltaF[(size_t)(r.host + nF * r.target) * 8];
+          float sx = 0, sy = 0, cx = 0, cy = 0;
+          for (int i = 0; i < 6; i++) { sx += rJ.Jpdxi[0][i] * dp[i]; sy += rJ.Jpdxi[1][i] * dp[i]; }
+          for (int i = 0; i < 4; i++) { cx += rJ.Jpdc[0][i] * cDeltaF[i]; cy += rJ.Jpdc[1][i] * cDeltaF[i]; }
+          const float Jp_delta_x_1 = sx + cx + rJ.Jpdd[0] * dd, Jp_delta_y_1 = sy + cy + rJ.Jpdd[1] * dd;
+          for (int i = 0; i + 3 < PATTERN; i += 4) {
+            for (int k = 0; k < 4; k++) {
+              float Jdelta = rJ.JIdx[0][i + k] * Jp_delta_x_1;
+              Jdelta = Jdelta + rJ.JIdx[1][i + k] * Jp_delta_y_1;
+              Jdelta = Jdelta + rJ.JabF[0][i + k] * dp[6];
+              Jdelta = Jdelta + rJ.JabF[1][i + k] * dp[7];
+              float r0 = r.res_toZeroF[i + k];
+              r0 = r0 + r0;
+              r0 = r0 + Jdelta;
+              d1[k] = d1[k] + Jdelta * r0;
+            }
+            numIn1++;   // updateSSENoShift
+          }
+        }
+        d1[0] += p.deltaF * p.deltaF * p.priorF; numIn1++;   // updateSingle
+        shiftUp(false);
+      }
+      shiftUp(true);
+      A += (double)(d1m[0] + d1m[1] + d1m[2] + d1m[3]);
+    }
+    return E + A;
   }
   double calcMEnergy() {
     if (S.forceAcceptStep) return 0;
@@ -1354,6 +1402,19 @@ void orc_ba_finalize(void* p) {
   W->setAdjointsF();
   W->setPrecalcValues();
   for (auto& f : W->frames) W->frameTakeData(f);
+}
+// EFResidual::fixLinearizationF for the active residuals with mask[ri] != 0, at the current state (setDeltaF first): from then on FullSystem::optimize leaves them out of
+// activeResiduals (FullSystemOptimize.cpp:436-446), accumulateLF_MT (addPoint<1>) and calcLEnergyPt carry them.  Returns the number of linearised residuals of the window.
+int orc_ba_fix_linearization(void* p, const unsigned char* mask) {
+  OWindow* W = (OWindow*)p;
+  W->setPrecalcValues();
+  int n = 0;
+  for (size_t ri = 0; ri < W->res.size(); ri++) {
+    ORes& r = W->res[ri];
+    if (mask[ri] && !r.dropped && r.isActive && !r.isLinearized) W->fixLinearizationF(r);
+    if (!r.dropped && r.isLinearized) n++;
+  }
+  return n;
 }
 int orc_ba_marginalize_points(void* p, const unsigned char* cand, unsigned char* decision, double* Hadd, double* badd) {
   OWindow* W = (OWindow*)p;

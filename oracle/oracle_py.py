@@ -487,6 +487,12 @@ class BAWindow:
         self.L.orc_ba_accumulate(self.p, *[_d(a) for a in m], C.byref(r))
         return dict(HA=m[0], bA=m[1], HL=m[2], bL=m[3], Hsc=m[4], bsc=m[5], resInA=r.value)
 
+    def fix_linearization(self, mask):
+        """EFResidual::fixLinearizationF for the active residuals with mask != 0 (they stay linearised: optimize leaves them out of activeResiduals); returns their count"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.orc_ba_fix_linearization.argtypes = [C.c_void_p, C.c_char_p]; self.L.orc_ba_fix_linearization.restype = C.c_int
+        return self.L.orc_ba_fix_linearization(self.p, m.tobytes())
+
     def set_marg_prior(self, HM, bM):
         self.L.orc_ba_set_marg_prior(self.p, _d(np.ascontiguousarray(HM, dtype=np.float64)), _d(np.ascontiguousarray(bM, dtype=np.float64)))
 

@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -981,6 +982,27 @@ void ref_ba_orthogonalize(void* p, double* x)
 	for (int i = 0; i < n; i++) x[i] = xv[i];
 }
 double ref_ba_calc_lenergy(void* p) { return ((RefWindow*)p)->fs->calcLEnergy(); }
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:76-106) for the active residuals with mask[ri] != 0 (flat residual order), at the current state: from then on
+// FullSystem::optimize leaves them out of activeResiduals (FullSystemOptimize.cpp:436-446) and EnergyFunctional carries them through accumulateLF_MT (addPoint<1>) and
+// calcLEnergyPt — the path the reference's flow never reaches (it linearises residuals only immediately before marginalising their point).  Returns the number linearised.
+int ref_ba_fix_linearization(void* p, const unsigned char* mask)
+{
+	RefWindow* W = (RefWindow*)p; FullSystem* fs = W->fs;
+	fs->setPrecalcValues();   // ef->setDeltaF: adHTdeltaF, cDeltaF, the points' deltaF at the current state
+	// (residuals that a fix-linearisation found inactive are deleted by the reference, FullSystemOptimize.cpp:176-212: only those still in the graph are looked at)
+	std::set<const PointFrameResidual*> live;
+	for (FrameHessian* fh : fs->frameHessians) for (PointHessian* ph : fh->pointHessians) for (PointFrameResidual* r : ph->residuals) live.insert(r);
+	int n = 0;
+	for (size_t ri = 0; ri < W->res.size(); ri++)
+	{
+		if (!live.count(W->res[ri])) continue;
+		EFResidual* r = W->res[ri]->efResidual;
+		if (!r) continue;
+		if (mask[ri] && r->isActive() && !r->isLinearized) r->fixLinearizationF(fs->ef);
+		if (r->isLinearized) n++;
+	}
+	return n;
+}
 double ref_ba_calc_menergy(void* p) { return ((RefWindow*)p)->fs->calcMEnergy(false); }
 void ref_ba_backup_state(void* p, int backupLastStep) { ((RefWindow*)p)->fs->backupState(backupLastStep != 0); }
 void ref_ba_load_state_backup(void* p) { ((RefWindow*)p)->fs->loadSateBackup(); }

@@ -651,6 +651,12 @@ class BAWindow:
     def lenergy(self):
         return self.L.ref_ba_calc_lenergy(self.p)
 
+    def fix_linearization(self, mask):
+        """EFResidual::fixLinearizationF of the active residuals with mask != 0; returns the number of linearised residuals of the window"""
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.ref_ba_fix_linearization.argtypes = [C.c_void_p, C.c_char_p]; self.L.ref_ba_fix_linearization.restype = C.c_int
+        return self.L.ref_ba_fix_linearization(self.p, m.tobytes())
+
     def menergy(self):
         return self.L.ref_ba_calc_menergy(self.p)
 

@@ -327,6 +327,41 @@ def test_full_system_optimize_bitwise(O, synth, kw):
     assert np.abs(io - ir).max() < 1e-6 * np.abs(io).max() and np.mean(io == ir) > 0.98
 
 
+def test_linearised_residuals_bitwise(O, synth):
+    """EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113), AccumulatedTopHessianSSE::addPoint<1> through accumulateLF_MT
+    (AccumulatedTopHessian.cpp:36-160, EnergyFunctional.cpp:268-299), calcLEnergyPt (EnergyFunctional.cpp:349-409: an Accumulator11 per run
+    of 50 points) and FullSystem::optimize with residuals outside activeResiduals (FullSystemOptimize.cpp:436-446).  The windows are brought
+    to the same bits first (one-iteration optimisations: no SVD orthogonalisation, and residuals dropped on the way change the order the
+    per-point sums run in, EnergyFunctional::dropResidual), then every third residual is linearised on both sides."""
+    case, WO, WR = _windows(O, synth, w=256, h=192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
+    for _ in range(3):
+        ro = WO.optimize(1); rr = WR.optimize(1)
+        assert ro["rmse"] == rr["rmse"]
+    mask = (np.arange(WO.R) % 3 == 0).astype(np.uint8)
+    n_lin = WO.fix_linearization(mask)
+    assert n_lin == WR.fix_linearization(mask) and 250 < n_lin < WO.R // 3 + 1
+    ao, ar = WO.accumulate(), WR.accumulate()
+    for k in ao:
+        assert same(np.asarray(ao[k]), np.asarray(ar[k])), k
+    F = case["n_frames"]
+    off = ar["HL"] - np.diag(np.diag(ar["HL"]))
+    assert np.abs(off).max() > 1e3 and np.abs(ar["bL"][4 + 8:]).max() > 1e2      # the L system is populated, not just the priors
+    po, pr = WO.point_acc(), WR.point_acc()
+    for k in po:
+        assert same(po[k], pr[k]), k
+    # the fp32 totals of the 50-point runs are added in double in the order the reference's workers finish
+    assert abs(WO.lenergy() - WR.lenergy()) <= 1e-12 * abs(WR.lenergy()) and abs(WR.lenergy()) > 1e3
+    ro = WO.optimize(2); rr = WR.optimize(2)                                        # iterations 0 and 1: no orthogonalisation
+    assert list(ro["trace"][1:, 3]) == list(rr["trace"][1:, 1]) and ro["rmse"] == rr["rmse"]
+    for k in range(F):
+        po_, pr_ = WO.frame_pose(k), WR.frame_pose(k)
+        assert same(po_[0], pr_[0]) and same(po_[1], pr_[1]) and same(po_[2], pr_[2])
+    io, so_ = WO.point_state(); ir, sr_ = WR.point_state()
+    assert same(io, ir)
+    assert abs(WO.lenergy() - WR.lenergy()) <= 1e-12 * abs(WR.lenergy())
+    assert WO.fix_linearization(np.zeros(WO.R, np.uint8)) == WR.fix_linearization(np.zeros(WO.R, np.uint8))   # linearised residuals left after the drops
+
+
 def _marg_pair(O, synth, case, perturb):
     Wr = R.BAWindow(case); Wo = O.BAWindow(case)
     rng = np.random.RandomState(3)
