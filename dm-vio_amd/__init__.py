@@ -939,6 +939,24 @@ class BundleAdjusterHip:
         fn = self.L.dmvio_hip_ba_set_residual_flags; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; fn.restype = C.c_int
         _chk(self.L, fn(self.p, len(fl), fl.ctypes.data), "ba_set_residual_flags")
 
+    def fix_linearization(self, res_mask):
+        """EFResidual::fixLinearizationF for the active residuals with res_mask != 0 on the resident graph (dmvio_hip_ba_fix_linearization): they leave activeResiduals and
+        enter every later system / energy through accumulateLF_MT (addPoint<1>) / calcLEnergyPt.  Needs BundleAdjusterHip(ctx, keep_jacobians=True).  Returns the
+        number of linearised residuals of the graph."""
+        m = np.ascontiguousarray(res_mask, dtype=np.uint8)
+        fn = self.L.dmvio_hip_ba_fix_linearization; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]; fn.restype = C.c_int
+        n = C.c_int(0)
+        _chk(self.L, fn(self.p, len(m), m.ctypes.data, C.byref(n)), "ba_fix_linearization")
+        return n.value
+
+    def lf_system(self):
+        """accumulateLF_MT's [HL, bL] (linearised residuals + priors) for the state of the last accumulation"""
+        n = self.n
+        HL = np.zeros((n, n)); bL = np.zeros(n)
+        fn = self.L.dmvio_hip_ba_get_lf_system; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, HL.ctypes.data, bL.ctypes.data), "ba_get_lf_system")
+        return HL, bL
+
     def set_stream(self, stream_ptr):
         _chk(self.L, self.L.dmvio_hip_ba_set_stream(self.p, C.c_void_p(stream_ptr)), "ba_set_stream")
 

@@ -57,6 +57,7 @@ struct BAHost {
   float cDeltaF[4], cPriorF[4];
   double cPrior[4];
   std::vector<double> HM, bM, lastX;
+  std::vector<double> HLraw, bLraw;   // see lfTop()
   // EnergyFunctional::HMForGTSAM / bMForGTSAM (EnergyFunctional.h:108-111): the marginalisation prior the GTSAM branch of solveSystemF / calcMEnergyF uses instead
   // of HM / bM (only the points marginalised since the last keyframe marginalisation; the rest lives in the GTSAM graph).  Used while `gtsam` is set.
   std::vector<double> HMG, bMG;
@@ -299,6 +300,15 @@ struct BAHost {
     for (int k = n - 1; k >= 0; k--) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
   }
 
+  // accumulateLF_MT's result (EnergyFunctional.cpp:223-233): the stitched system of the residuals kept linearised — HLraw / bLraw, filled by the accumulation when the graph
+  // carries any (dmvio_hip_ba_fix_linearization), otherwise empty = zero — plus the priors stitchDoubleInternal adds last (AccumulatedTopHessian.cpp:292-302).
+  // HLd: the prior diagonal, to be added to HLraw's; bL: the complete right-hand side.  Returns whether HLraw holds a system.
+  bool lfTop(double* HLd, double* bL) const {
+    const bool haveL = HLraw.size() == (size_t)n() * n();
+    for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = (haveL ? bLraw[i] : 0.0) + cPrior[i] * (double)cDeltaF[i]; }
+    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = (haveL ? bLraw[q] : 0.0) + fr[f].prior[i] * fr[f].delta_prior[i]; }
+    return haveL;
+  }
   // Everything of solveSystemF that depends on the window state only (nullspaces, orthogonalisation basis, prior right-hand side):
   // the GN loop runs it on the host while the accumulation kernels are in flight.
   void prepareSolve() {
@@ -329,15 +339,14 @@ struct BAHost {
     // HFinal_top = HL_top + HM + HA_top, bFinal_top = bL_top + bM_top + bA_top - b_sc (EnergyFunctional.cpp:906-907), summed in that order: HL_top / bL_top hold only the priors
     // (stitchDoubleInternal usePrior, AccumulatedTopHessian.cpp:292-302; no linearised residuals outside marginalisation), zero elsewhere
     double HLd[4 + 8 * BA_MAXF_CAP], bL[4 + 8 * BA_MAXF_CAP];
-    for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
-    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
+    const bool haveL = lfTop(HLd, bL);
     // only the lower triangle of HFinal_top - H_sc / (1 + lambda) is read below: one pass over it, per element the operations of the reference's whole-matrix statements
     // ((HL + HM) + HA, the diagonal times (1 + lambda), minus H_sc * fac) in their order
     const double fac = 1.0f / (1 + lambda);
     for (int i = 0; i < nn; i++)
       for (int j = 0; j <= i; j++) {
         const size_t o = (size_t)i * nn + j;
-        double v = ((i == j ? HLd[i] : 0.0) + (haveM ? HM[o] : 0.0)) + HA[o];
+        double v = (((haveL ? HLraw[o] : 0.0) + (i == j ? HLd[i] : 0.0)) + (haveM ? HM[o] : 0.0)) + HA[o];
         if (i == j) v *= (1 + lambda);
         HF[o] = v - Hsc[o] * fac;
       }
@@ -363,13 +372,12 @@ struct BAHost {
     const std::vector<double>& HMs = priorH();
     const bool haveM = HMs.size() == (size_t)nn * nn;
     double HLd[4 + 8 * BA_MAXF_CAP], bL[4 + 8 * BA_MAXF_CAP];
-    for (int i = 0; i < 4; i++) { HLd[i] = cPrior[i]; bL[i] = cPrior[i] * (double)cDeltaF[i]; }
-    for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) { const int q = 4 + 8 * f + i; HLd[q] = fr[f].prior[i]; bL[q] = fr[f].prior[i] * fr[f].delta_prior[i]; }
+    const bool haveL = lfTop(HLd, bL);
     const double fac = 1.0f / (1 + lambda);
     for (int i = 0; i < nn; i++)
       for (int j = 0; j < nn; j++) {
         const size_t o = (size_t)i * nn + j;
-        const double top = ((i == j ? HLd[i] : 0.0) + (haveM ? HMs[o] : 0.0)) + HA[o];
+        const double top = (((haveL ? HLraw[o] : 0.0) + (i == j ? HLd[i] : 0.0)) + (haveM ? HMs[o] : 0.0)) + HA[o];
         HNoLambda[o] = top - Hsc[o];
         HPassed[o] = (i == j ? top * (1 + lambda) : top) - Hsc[o] * fac;
       }

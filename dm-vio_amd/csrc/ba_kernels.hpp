@@ -86,6 +86,10 @@ struct BAPoints {   // SoA, N entries
   const int* res_begin;  // N+1: residuals of point p are [res_begin[p], res_begin[p+1])
   float *Hdd, *bd, *Hcd, *HdiF, *bdSumF;  // accumulated per point (Hcd: N x 4)
   float* idepth_hessian;                  // PointHessian::idepth_hessian (AccumulatedSCHessian.cpp:42,50)
+  // residuals kept linearised outside a marginalisation (dmvio_hip_ba_fix_linearization; all NULL otherwise): Hdd_accLF, bd_accLF, Hcd_accLF of addPoint<1>
+  // (AccumulatedTopHessian.cpp:84-98,131-143).  With them Hcd holds Hcd_accAF + Hcd_accLF — what every consumer reads — and HcdAF the A part alone.
+  const float *lHdd, *lbd, *lHcd;
+  float* HcdAF;
 };
 
 struct BARes {      // SoA, R entries
@@ -98,6 +102,8 @@ struct BARes {      // SoA, R entries
   const int* newestSlot;   // R: position of the residual among those that target the newest keyframe, or -1
   float* newestE;          // state_NewEnergyWithOutlier of exactly those residuals, contiguous (what setNewFrameEnergyTH looks at)
   float* rec[2];   // R x REC_FLOATS
+  const unsigned char* lin;   // EFResidual::isLinearized outside a marginalisation (NULL: none): such a residual is no member of activeResiduals (FullSystemOptimize.cpp:436-446) —
+                              // not relinearised, not applied, not counted in the energy or the newest keyframe's threshold; its record and activity stay what they were
 };
 
 __constant__ int c_patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:296, pattern 8
@@ -366,6 +372,7 @@ __device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoint
     }
     bool done = false;
     if (state == BA_OOB) { if (lead) Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
+    if (Rs.lin && !pt_mask && Rs.lin[ri]) { myE = 0.0; done = true; }   // kept linearised: outside activeResiduals (only the point's back-substitution below concerns it)
     const int pi = Rs.point[ri], ti = Rs.target[ri];
     const int hi = P.host[pi];
     BAPrecalc pc = pre[hi + W.F * ti];
@@ -597,6 +604,7 @@ __device__ __forceinline__ void baApplyBody(const int R, const BARes& Rs, const 
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= R) return;
   if (pt_mask && !pt_mask[Rs.point[ri]]) return;
+  if (Rs.lin && !pt_mask && Rs.lin[ri]) return;   // not in activeResiduals: applyRes_Reductor and the removal of linearizeAll(true) never see it
   if (Rs.state[ri] != BA_OOB) {  // can never go back from OOB
     const int ns = Rs.newState[ri];
     if (ns == BA_IN) { Rs.active[ri] = 1; Rs.which[ri] ^= 1; }
@@ -610,6 +618,7 @@ __device__ __forceinline__ void baApplyBody(const int R, const BARes& Rs, const 
 __global__ void __launch_bounds__(256) k_ba_reset_oob(const int R, const BARes Rs) {
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= R) return;
+  if (Rs.lin && Rs.lin[ri]) return;   // FullSystemOptimize.cpp:440-446: a linearised residual is not reset
   const bool gone = Rs.removed[ri] != 0;
   Rs.state[ri] = gone ? BA_OOB : BA_IN;
   Rs.newState[ri] = gone ? BA_OOB : BA_OUTLIER;
@@ -658,31 +667,38 @@ __device__ __forceinline__ void baPointSumsBody(const BAWindow& W, const BAPoint
     const int ri = min(rb + q, r1 - 1);
     const bool mine = rb + q < r1;
     int isAct = Rs.active[ri], wh = Rs.which[ri];
-    if (apply && mine && Rs.state[ri] != BA_OOB) {   // can never go back from OOB
+    const bool isLin = Rs.lin && Rs.lin[ri] != 0;   // addPoint<0> leaves it to addPoint<1> (AccumulatedTopHessian.cpp:52-53); the Schur side counts it (isActive())
+    if (apply && mine && !isLin && Rs.state[ri] != BA_OOB) {   // can never go back from OOB
       const int ns = Rs.newState[ri];
       if (ns == BA_IN) { isAct = 1; wh ^= 1; Rs.which[ri] = (unsigned char)wh; } else isAct = 0;
       Rs.active[ri] = (unsigned char)isAct;
       Rs.state[ri] = (unsigned char)ns;
       Rs.energy[ri] = Rs.newEnergy[ri];
     }
-    const bool act = mine && isAct != 0;
+    const bool good = mine && isAct != 0, act = good && !isLin;
     const float* __restrict__ rec = Rs.rec[wh] + (size_t)ri * REC_FLOATS;
     const float v0 = act ? rec[REC_BD] : 0.0f, v1 = act ? rec[REC_HDD] : 0.0f;
     const float h0 = act ? rec[REC_HCD + 0] : 0.0f, h1 = act ? rec[REC_HCD + 1] : 0.0f, h2 = act ? rec[REC_HCD + 2] : 0.0f, h3 = act ? rec[REC_HCD + 3] : 0.0f;
     bd = seqAdd8(bd, v0); Hdd = seqAdd8(Hdd, v1);
     Hcd0 = seqAdd8(Hcd0, h0); Hcd1 = seqAdd8(Hcd1, h1); Hcd2 = seqAdd8(Hcd2, h2); Hcd3 = seqAdd8(Hcd3, h3);
-    ngood += __popcll((__ballot(act) >> grp) & 0xFFull);
+    ngood += __popcll((__ballot(good) >> grp) & 0xFFull);
   }
   if (!lead) return;
   P.Hdd[pi] = Hdd; P.bd[pi] = bd;
+  float HddL = 0.0f, bdL = 0.0f;
+  if (P.lHdd) {   // Hdd_accLF, bd_accLF, Hcd_accLF of the residuals kept linearised (k_ba_lin_point_sums)
+    HddL = P.lHdd[pi]; bdL = P.lbd[pi];
+    P.HcdAF[4 * pi + 0] = Hcd0; P.HcdAF[4 * pi + 1] = Hcd1; P.HcdAF[4 * pi + 2] = Hcd2; P.HcdAF[4 * pi + 3] = Hcd3;
+    Hcd0 = Hcd0 + P.lHcd[4 * pi + 0]; Hcd1 = Hcd1 + P.lHcd[4 * pi + 1]; Hcd2 = Hcd2 + P.lHcd[4 * pi + 2]; Hcd3 = Hcd3 + P.lHcd[4 * pi + 3];
+  }
   P.Hcd[4 * pi + 0] = Hcd0; P.Hcd[4 * pi + 1] = Hcd1; P.Hcd[4 * pi + 2] = Hcd2; P.Hcd[4 * pi + 3] = Hcd3;
   if (ngood == 0) { P.HdiF[pi] = 0; P.bdSumF[pi] = 0; P.idepth_hessian[pi] = 0; return; }
-  float H = Hdd + 0.0f + prior;
+  float H = Hdd + HddL + prior;
   if (H < 1e-10) H = 1e-10;
   P.idepth_hessian[pi] = H;
   P.HdiF[pi] = 1.0 / H;
   const float deltaF = id - idz;
-  P.bdSumF[pi] = (bd + 0.0f) + prior * deltaF;  // shiftPriorToZero = true
+  P.bdSumF[pi] = (bd + bdL) + prior * deltaF;  // shiftPriorToZero = true
 }
 
 // ------------------------------------------------------------------------------------------------ point marginalisation
@@ -757,6 +773,96 @@ __global__ void __launch_bounds__(256) k_ba_marg_point_sums(const BAWindow W, co
   if (H < 1e-10) H = 1e-10;
   HdiF[pi] = 1.0 / H;
   bdSumF[pi] = 0.0f + bd;   // shiftPriorToZero = false
+}
+
+// ------------------------------------------------------------------------------------------------ residuals kept linearised (addPoint<1>)
+// The reference only ever linearises a residual on its way into the marginalisation prior (FullSystem.cpp:836-849), but EnergyFunctional carries the general case: a
+// residual with isLinearized set stays out of activeResiduals, and its frozen Jacobian + res_toZeroF enter every system through accumulateLF_MT (addPoint<1>,
+// AccumulatedTopHessian.cpp:84-98) and the energy through calcLEnergyPt (EnergyFunctional.cpp:349-409).  dmvio_hip_ba_fix_linearization builds that case on the resident
+// graph; it is off every fast path (three accumulation passes per system instead of one).
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the active, not yet linearised residuals with mask != 0: res_toZeroF from the applied Jacobian
+// (fullJ: the last linearisation, which the caller guarantees was applied) and the deltas of the current state; the applied record is frozen into linRec.
+__global__ void __launch_bounds__(256) k_ba_lin_fix(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ fullJ, const unsigned char* __restrict__ mask,
+                                                     const float* __restrict__ adHTdeltaF /* F*F x 8, h + F*t */, const float4 cDeltaF, unsigned char* __restrict__ lin,
+                                                     float* __restrict__ res_toZeroF /* R x 8 */, float* __restrict__ linRec) {
+  const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= W.R) return;
+  if (!mask[ri] || lin[ri] || !Rs.active[ri] || Rs.removed[ri]) return;
+  const int pi = Rs.point[ri];
+  const float* __restrict__ J = fullJ + (size_t)ri * 74;
+  const float* __restrict__ dp = adHTdeltaF + (size_t)(P.host[pi] + W.F * Rs.target[ri]) * 8;
+  const float dd = P.idepth[pi] - P.idepth_zero[pi];
+  const float cd[4] = {cDeltaF.x, cDeltaF.y, cDeltaF.z, cDeltaF.w};
+  float sx = 0, sy = 0, cx = 0, cy = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { sx += J[8 + i] * dp[i]; sy += J[14 + i] * dp[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { cx += J[20 + i] * cd[i]; cy += J[24 + i] * cd[i]; }
+  const float Jp_delta_x = sx + cx + J[28] * dd, Jp_delta_y = sy + cy + J[29] * dd;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float rtz = J[i];
+    rtz = rtz - J[30 + i] * Jp_delta_x; rtz = rtz - J[38 + i] * Jp_delta_y;
+    rtz = rtz - J[46 + i] * dp[6]; rtz = rtz - J[54 + i] * dp[7];
+    res_toZeroF[(size_t)ri * 8 + i] = rtz;
+  }
+  const float* __restrict__ src = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
+  float* __restrict__ dst = linRec + (size_t)ri * REC_FLOATS;
+  for (int k = 0; k < REC_FLOATS; k++) dst[k] = src[k];
+  lin[ri] = 1;
+}
+// The record addPoint<1> consumes, at the deltas of the current state: resApprox = res_toZeroF + [JI Jp | Jab] delta (AccumulatedTopHessian.cpp:84-98), its inner products
+// with the frozen Jacobian (:103-113) and the point's bd contribution (:132).  Also the two activity views of the three-pass accumulation: the A pass sees the active
+// residuals that are NOT linearised (addPoint<0>), the L pass those that are.
+__global__ void __launch_bounds__(256) k_ba_lin_records(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ fullJ, const unsigned char* __restrict__ lin,
+                                                         const float* __restrict__ res_toZeroF, const float* __restrict__ adHTdeltaF, const float4 cDeltaF,
+                                                         float* __restrict__ linRec, unsigned char* __restrict__ linActive, unsigned char* __restrict__ topActive) {
+  const int ri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ri >= W.R) return;
+  const bool act = Rs.active[ri] != 0, isLin = lin[ri] != 0;
+  linActive[ri] = (act && isLin) ? 1 : 0;
+  topActive[ri] = (act && !isLin) ? 1 : 0;
+  if (!(act && isLin)) return;
+  const int pi = Rs.point[ri];
+  const float* __restrict__ J = fullJ + (size_t)ri * 74;
+  const float* __restrict__ dp = adHTdeltaF + (size_t)(P.host[pi] + W.F * Rs.target[ri]) * 8;
+  const float dd = P.idepth[pi] - P.idepth_zero[pi];
+  const float cd[4] = {cDeltaF.x, cDeltaF.y, cDeltaF.z, cDeltaF.w};
+  float sx = 0, sy = 0, cx = 0, cy = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { sx += J[8 + i] * dp[i]; sy += J[14 + i] * dp[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { cx += J[20 + i] * cd[i]; cy += J[24 + i] * cd[i]; }
+  const float Jp_delta_x = sx + cx + J[28] * dd, Jp_delta_y = sy + cy + J[29] * dd;
+  float JIr0 = 0, JIr1 = 0, Jar0 = 0, Jar1 = 0, rr = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float ra = res_toZeroF[(size_t)ri * 8 + i];
+    ra = ra + J[30 + i] * Jp_delta_x; ra = ra + J[38 + i] * Jp_delta_y;
+    ra = ra + J[46 + i] * dp[6]; ra = ra + J[54 + i] * dp[7];
+    JIr0 += ra * J[30 + i]; JIr1 += ra * J[38 + i]; Jar0 += ra * J[46 + i]; Jar1 += ra * J[54 + i]; rr += ra * ra;
+  }
+  float* __restrict__ dst = linRec + (size_t)ri * REC_FLOATS;
+  dst[REC_JI_R + 0] = JIr0; dst[REC_JI_R + 1] = JIr1; dst[REC_JAB_R + 0] = Jar0; dst[REC_JAB_R + 1] = Jar1; dst[REC_RR] = rr;
+  dst[REC_BD] = JIr0 * J[28] + JIr1 * J[29];
+}
+// Hdd_accLF, bd_accLF, Hcd_accLF (AccumulatedTopHessian.cpp:131-143, mode 1): sequential over the point's linearised active residuals
+__global__ void __launch_bounds__(256) k_ba_lin_point_sums(const BAWindow W, const BAPoints P, const float* __restrict__ linRec, const unsigned char* __restrict__ linActive,
+                                                            float* __restrict__ lHdd, float* __restrict__ lbd, float* __restrict__ lHcd4) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= W.N) return;
+  float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
+  for (int ri = P.res_begin[pi]; ri < P.res_begin[pi + 1]; ri++) {
+    if (!linActive[ri]) continue;
+    const float* __restrict__ rec = linRec + (size_t)ri * REC_FLOATS;
+    bd += rec[REC_BD];
+    Hdd += rec[REC_HDD];
+#pragma unroll
+    for (int k = 0; k < 4; k++) Hcd[k] += rec[REC_HCD + k];
+  }
+  lHdd[pi] = Hdd; lbd[pi] = bd;
+#pragma unroll
+  for (int k = 0; k < 4; k++) lHcd4[4 * pi + k] = Hcd[k];
 }
 
 // hierarchical fp32 accumulator of the reference (Data / Data1k / Data1m + numIn1 counters), one value per thread

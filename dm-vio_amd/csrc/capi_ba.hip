@@ -168,6 +168,14 @@ struct dmvio_hip_ba {
   hipEvent_t comm_ev[2][COMM_EVS][2] = {};
   int comm_n[2] = {0, 0};
   long comm_total[2] = {0, 0};
+  // ---- residuals kept linearised outside a marginalisation (dmvio_hip_ba_fix_linearization; ba_kernels.hpp "residuals kept linearised"): flags, res_toZeroF, the record
+  // addPoint<1> consumes, the activity views of the three accumulation passes, the per-point LF sums; host copies of what calcLEnergyPt reads
+  int n_lin = 0;
+  unsigned char *d_lin = nullptr, *d_linMask = nullptr, *d_linActive = nullptr, *d_topActive = nullptr;
+  float *d_rtz = nullptr, *d_linRec = nullptr, *d_lHdd = nullptr, *d_lbd = nullptr, *d_lHcd = nullptr, *d_HcdAF = nullptr;
+  std::vector<unsigned char> h_lin, h_linAct;
+  std::vector<float> h_linJ, h_rtz;
+  bool fullJ_applied = false;   // d_fullJ holds the Jacobians of the APPLIED linearisation (the last linearisation was followed by its applyRes)
   bool adj_dirty = false;   // the host's adjoint tables (H.adHost / adTarget) are newer than the device copy: uploaded by the next consumer (accumulateViews, a batch call)
 };
 #define BA_LOCK(b) std::lock_guard<std::recursive_mutex> lk_(b->mu)
@@ -175,6 +183,7 @@ struct dmvio_hip_ba {
 // The kernels whose ARGUMENTS are sized by the window (ba_kernels.hpp: BAPreDynT / ResubArgsT, the stitch workgroup of 64 F threads): windows of up to BA_MAXF keyframes
 // take the compact instantiation (the host's wide structs cut down to their prefix), larger ones (up to BA_MAXF_CAP) the wide one.
 #define BA_LAUNCH_LINEARIZE(b, W_, fullJ_, mask_, D_, gate_, use_backup_, T_, use_dyn_, X_, do_resub_) do { \
+    (b)->fullJ_applied = false; \
     if ((b)->H.F <= BA_MAXF) hipLaunchKernelGGL((k_ba_linearize<BA_MAXF>), dim3((b)->n_lin_blocks), dim3(LIN_THREADS), 0, (b)->stream, W_, (b)->P, (b)->Rs, (const BAPrecalc*)(b)->d_pre, \
         (b)->ctx->fs, fullJ_, mask_, D_, (int)(gate_), (int)(use_backup_), baNarrow<BAPreDynT<BA_MAXF>>(T_), (int)(use_dyn_), baNarrow<ResubArgsT<BA_MAXF>>(X_), (int)(do_resub_)); \
     else hipLaunchKernelGGL((k_ba_linearize<BA_MAXF_CAP>), dim3((b)->n_lin_blocks), dim3(LIN_THREADS), 0, (b)->stream, W_, (b)->P, (b)->Rs, (const BAPrecalc*)(b)->d_pre, \
@@ -436,7 +445,7 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
   BA_PROF(b, 0);
   BA_LAUNCH_LINEARIZE(b, b->W, b->keep_fullJ ? b->d_fullJ : (float*)nullptr, (const unsigned char*)nullptr, shard ? packOnly(b, D) : D, BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
   BA_PROF(b, 1);
-  if (fix) hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr, 1);   // + linearizeAll(true)'s removal of inactive residuals
+  if (fix) { hipLaunchKernelGGL(k_ba_apply, dim3((H.R + 255) / 256), dim3(256), 0, b->stream, H.R, b->Rs, (const unsigned char*)nullptr, 1); b->fullJ_applied = b->keep_fullJ; }   // + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
   if (shard) { if (int r = decideGlobal(b, D)) return r; }
   if (defer) return 0;
@@ -447,13 +456,20 @@ static int linearizeAll(dmvio_hip_ba* b, bool fix, double* energy, int table_mod
 static int applyRes(dmvio_hip_ba* b) {
   hipLaunchKernelGGL(k_ba_apply, dim3((b->H.R + 255) / 256), dim3(256), 0, b->stream, b->H.R, b->Rs, (const unsigned char*)nullptr, 0);
   HIPCHK(hipGetLastError());
+  b->fullJ_applied = b->keep_fullJ;
   return 0;
 }
 // accumulateAF + accumulateSCF + adjoint stitching on the device; result in h_sys
 static int accumulateViews(dmvio_hip_ba* b, const BARes& Rs, const BAPoints& P, bool wait = true, int gate = BA_GATE_ALWAYS);
 static int accumulateWait(dmvio_hip_ba* b);
 // apply_first: applyRes_Reductor(true) fused into the per-point sums; gate: the whole chain only runs when the last accept test says so
+static int accumulateLin(dmvio_hip_ba* b, bool backup_points, bool apply_first);
 static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false, bool apply_first = false, int gate = BA_GATE_ALWAYS) {
+  if (b->n_lin > 0) {
+    if (!wait || gate != BA_GATE_ALWAYS) return failmsg("ba: a graph with residuals kept linearised is accumulated synchronously");
+    return accumulateLin(b, backup_points, apply_first);
+  }
+  if (apply_first) b->fullJ_applied = b->keep_fullJ;
   if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0, apply_first ? 1 : 0,
                                       (const BACtl*)b->d_ctl, gate, (backup_points && b->vio) ? b->h_idepth_backup : (float*)nullptr);
   BA_PROF(b, 2);
@@ -507,6 +523,79 @@ static int accumulateViews(dmvio_hip_ba* b, const BARes& RsV, const BAPoints& PV
   BA_PROF(b, 5);
   return wait ? accumulateWait(b) : 0;
 }
+// solveSystemF's three accumulations for a graph with residuals kept linearised (EnergyFunctional.cpp:846-852: accumulateAF_MT, accumulateLF_MT, accumulateSCF_MT).  One
+// accumulation kernel serves a (host,target) bucket's top block and its Schur terms from ONE activity flag; here the three reference passes see different sets — addPoint<0>
+// the active residuals that are not linearised, addPoint<1> those that are (with the res_toZeroF + J delta record), the Schur side every active one — so the kernel chain
+// runs three times over three views and each pass contributes its part: [HL | bL] -> BAHost::HLraw / bLraw, [HA | bA | resInA] and [Hsc | bsc] -> h_sys as always.
+static int accumulateLin(dmvio_hip_ba* b, bool backup_points, bool apply_first) {
+  BAHost& H = b->H;
+  hipStream_t s = b->stream;
+  const int R = H.R, N = H.N, n = H.n(), tot = 2 * (n * n + n);
+  if (apply_first) { if (int r = applyRes(b)) return r; }
+  std::vector<float> adHT;
+  H.adHTdeltaF(adHT);   // EnergyFunctional::setDeltaF at the current state
+  HIPCHK(b->bounce.h2d(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), s));
+  const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
+  hipLaunchKernelGGL(k_ba_lin_records, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, (const float*)b->d_fullJ, (const unsigned char*)b->d_lin, (const float*)b->d_rtz,
+                     (const float*)b->d_adHTdelta, cd, b->d_linRec, b->d_linActive, b->d_topActive);
+  hipLaunchKernelGGL(k_ba_lin_point_sums, dim3((N + 255) / 256), dim3(256), 0, s, b->W, b->P, (const float*)b->d_linRec, (const unsigned char*)b->d_linActive, b->d_lHdd, b->d_lbd, b->d_lHcd);
+  hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, s, b->W, b->P, b->Rs, backup_points ? 1 : 0, 0, (const BACtl*)b->d_ctl, (int)BA_GATE_ALWAYS,
+                     (backup_points && b->vio) ? b->h_idepth_backup : (float*)nullptr);
+  HIPCHK(hipGetLastError());
+  // L pass
+  BARes RsL = b->Rs; RsL.rec[0] = RsL.rec[1] = b->d_linRec; RsL.active = b->d_linActive; RsL.lin = nullptr;
+  if (int r = accumulateViews(b, RsL, b->P, true)) return r;
+  H.HLraw.assign(b->h_sys, b->h_sys + (size_t)n * n); H.bLraw.assign(b->h_sys + (size_t)n * n, b->h_sys + (size_t)n * n + n);
+  // A pass
+  BARes RsA = b->Rs; RsA.active = b->d_topActive;
+  if (int r = accumulateViews(b, RsA, b->P, true)) return r;
+  std::vector<double> top(b->h_sys, b->h_sys + (size_t)n * n + n);
+  const int resInA = H.resInA;
+  // Schur pass
+  if (int r = accumulateViews(b, b->Rs, b->P, true)) return r;
+  memcpy(b->h_sys, top.data(), sizeof(double) * top.size());
+  b->h_sys[tot] = (double)resInA; H.resInA = resInA;
+  return 0;
+}
+// calcLEnergyPt (EnergyFunctional.cpp:349-409) for the residuals kept linearised: (2 res_toZeroF + J delta) . (J delta), summed the way the reference does — an Accumulator11
+// (four fp32 lanes; its 1k / 1M levels never fill within a run) per run of 50 points (IndexThreadReduce::reduce with step 50, EnergyFunctional.cpp:427-428), two 4-lane
+// updates per residual in point / residual order, the runs' fp32 totals added in double.  The points' own prior term deltaF^2 priorF is zero: idepth_zero follows idepth.
+static double linEnergy(dmvio_hip_ba* b) {
+  const BAHost& H = b->H;
+  std::vector<float> adHT;
+  H.adHTdeltaF(adHT);
+  double A = 0;
+  for (int p0 = 0; p0 < H.N; p0 += 50) {
+    float d1[4] = {0, 0, 0, 0};
+    for (int pi = p0; pi < std::min(H.N, p0 + 50); pi++)
+      for (int ri = b->h_res_begin[pi]; ri < b->h_res_begin[pi + 1]; ri++) {
+        if (!b->h_lin[ri] || !b->h_linAct[ri]) continue;
+        const float* J = &b->h_linJ[(size_t)ri * 74];
+        const float* rtz = &b->h_rtz[(size_t)ri * 8];
+        const float* dp = &adHT[(size_t)(b->h_host[pi] + H.F * b->h_target[ri]) * 8];
+        const float dd = 0.0f;
+        float sx = 0, sy = 0, cx = 0, cy = 0;
+        for (int i = 0; i < 6; i++) { sx += J[8 + i] * dp[i]; sy += J[14 + i] * dp[i]; }
+        for (int i = 0; i < 4; i++) { cx += J[20 + i] * H.cDeltaF[i]; cy += J[24 + i] * H.cDeltaF[i]; }
+        const float Jp_delta_x = sx + cx + J[28] * dd, Jp_delta_y = sy + cy + J[29] * dd;
+        for (int i = 0; i < 8; i += 4)
+          for (int k = 0; k < 4; k++) {
+            float Jdelta = J[30 + i + k] * Jp_delta_x;
+            Jdelta = Jdelta + J[38 + i + k] * Jp_delta_y;
+            Jdelta = Jdelta + J[46 + i + k] * dp[6];
+            Jdelta = Jdelta + J[54 + i + k] * dp[7];
+            float r0 = rtz[i + k];
+            r0 = r0 + r0;
+            r0 = r0 + Jdelta;
+            d1[k] = d1[k] + Jdelta * r0;
+          }
+      }
+    A += (double)(d1[0] + d1[1] + d1[2] + d1[3]);
+  }
+  return A;
+}
+// EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:414-431)
+static double calcLEnergy(dmvio_hip_ba* b) { return b->n_lin > 0 ? b->H.calcLEnergyFrames() + linEnergy(b) : b->H.calcLEnergyFrames(); }
 // the gather kernel publishes per workgroup (BAHostRes::gticket): wait until every slot shows the chain's ticket
 static int waitGather(dmvio_hip_ba* b, const unsigned int ticket, const int nblk) {
   volatile unsigned int* slots = b->h_res->gticket;
@@ -658,6 +747,7 @@ static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callba
   BA_LOCK(b);
   if (world == 0 || (!comm && !cb)) { b->world = 0; b->rank = 0; b->nccl = nullptr; b->comm_cb = dmvio_hip_comm_callbacks{}; b->sys_ready = false; b->sums_fresh = false; return 0; }
   if (world < 1 || rank < 0 || rank >= world) return failmsg("ba_set_comm: 0 <= rank < world");
+  if (b->n_lin > 0) return failmsg("ba_set_comm: the graph carries residuals kept linearised (dmvio_hip_ba_fix_linearization): single-device windows only");
   if (cb && (!cb->allreduce_sum_f64 || !cb->allgather)) return failmsg("ba_set_comm_callbacks: both callbacks are required");
   if (comm) {
     RCCL_READY();
@@ -886,10 +976,17 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   if (int r = uploadWindowTables(b)) return r;
   if (int r = uploadThresholds(b)) return r;
   {
+    const bool fullJ_applied = b->fullJ_applied;
     const BADecide D = makeDecide(b, -1, false, false);   // masked relinearisation: no energy / threshold / accept pass
     BA_LAUNCH_LINEARIZE(b, b->W, b->d_fullJ, (const unsigned char*)b->d_cand, D, BA_GATE_ALWAYS, 0, b->dyn_cur, 0, b->x_none, 0);
+    b->fullJ_applied = fullJ_applied;   // the candidates' rows are rewritten and applied right below, the others untouched
   }
   hipLaunchKernelGGL(k_ba_apply, dim3((R + 255) / 256), dim3(256), 0, s, R, b->Rs, (const unsigned char*)b->d_cand, 0);
+  if (b->n_lin > 0) {   // FullSystem.cpp:840-843: a candidate point's residuals are relinearised with isLinearized = false
+    for (int ri = 0; ri < R; ri++) if (candidates[b->h_point[ri]] && b->h_lin[ri]) { b->h_lin[ri] = 0; b->n_lin--; }
+    HIPCHK(b->bounce.h2d(b->d_lin, b->h_lin.data(), R, s));
+    if (b->n_lin == 0) { b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear(); }
+  }
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
   hipLaunchKernelGGL(k_ba_fix_linearization, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, b->d_fullJ, b->d_decision, b->d_adHTdelta, cd, b->d_margRec,
@@ -935,6 +1032,9 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
   HIPCHK(hipStreamSynchronize(b->stream));
   b->th_pending = false;   // the stream is drained and h_res is cleared below (th_ticket restarts at 0 while b->ticket keeps counting): nothing of the old graph may be awaited
   freeDevice(b);
+  // residuals kept linearised belong to the graph they were linearised in
+  b->n_lin = 0; b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->d_lin = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear();
+  b->h_lin.clear(); b->h_linAct.clear(); b->h_linJ.clear(); b->h_rtz.clear(); b->fullJ_applied = false;
   // the arena of the previous graph, cleared for this one on the handle's stream; the uploads and kernels below follow on the same stream: no wait
   for (size_t k = 0; k < b->arena.chunks.size(); k++) if (b->arena.used[k]) { HIPCHK(hipMemsetAsync(b->arena.chunks[k].first, 0, b->arena.used[k], b->stream)); b->arena.used[k] = 0; }   // what the previous graph used, not the whole chunk
   SG_PH(0);
@@ -1145,9 +1245,70 @@ int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* b, int R, const unsigned char*
   for (int ri = 0; ri < R; ri++)
     if (isLinearized[ri]) {
       b->graph_ready = false;   // refused as a whole: nothing may run on a graph whose linearised energy term (accumulateLF_MT) would be missing
-      return failmsg("ba_set_residual_flags: residual " + std::to_string(ri) + " is linearised (EFResidual::isLinearized) outside a marginalisation: accumulateLF_MT / "
-                     "addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:84-98) is not built — the graph is refused");
+      return failmsg("ba_set_residual_flags: residual " + std::to_string(ri) + " arrives linearised (EFResidual::isLinearized): its frozen Jacobian and res_toZeroF, which "
+                     "accumulateLF_MT / addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:84-98) need, only exist for residuals linearised on the resident "
+                     "graph (dmvio_hip_ba_fix_linearization) — the graph is refused");
     }
+  return 0;
+}
+
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the active residuals with res_mask != 0, at the current state, on the resident graph: from then on
+// they stay out of activeResiduals (FullSystemOptimize.cpp:436-446) and enter every system through accumulateLF_MT / addPoint<1> and the energy through calcLEnergyPt, until
+// the next dmvio_hip_ba_set_graph (or until their point is marginalised).  Needs the Jacobians of the applied linearisation: dmvio_hip_ba_keep_jacobians(ba, 1) before the
+// dmvio_hip_ba_optimize / dmvio_hip_ba_linearize(fix) that precedes this call.  n_linearized: residuals of the graph that are linearised after the call.
+int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* res_mask, int* n_linearized) {
+  if (!b || !res_mask) return failmsg("ba_fix_linearization: null argument");
+  BA_LOCK(b);
+  BA_READY_LOCKED(b);
+  BAHost& H = b->H;
+  if (R != H.R) return failmsg("ba_fix_linearization: R differs from the graph's residual count");
+  if (sharded(b)) return failmsg("ba_fix_linearization: not available on a window whose points are sharded over ranks");
+  if (b->device_loop) return failmsg("ba_fix_linearization: the window runs the device-resident loop (dmvio_hip_ba_set_device_loop): host-driven loop only");
+  if (!b->keep_fullJ || !b->fullJ_applied)
+    return failmsg("ba_fix_linearization: the Jacobians of the applied linearisation are not resident — call dmvio_hip_ba_keep_jacobians(ba, 1) before the optimize / "
+                   "linearize(fix) + apply that precedes this call");
+  hipStream_t s = b->stream;
+  const int N = H.N;
+  if (!b->d_lin) {
+    if (dalloc(b, &b->d_lin, R) || dalloc(b, &b->d_linMask, R) || dalloc(b, &b->d_linActive, R) || dalloc(b, &b->d_topActive, R) || dalloc(b, &b->d_rtz, (size_t)R * 8) ||
+        dalloc(b, &b->d_linRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_lHdd, N) || dalloc(b, &b->d_lbd, N) || dalloc(b, &b->d_lHcd, (size_t)N * 4) ||
+        dalloc(b, &b->d_HcdAF, (size_t)N * 4)) return -1;
+    b->h_lin.assign(R, 0);
+  }
+  H.setPrecalcValues();
+  std::vector<float> adHT;
+  H.adHTdeltaF(adHT);
+  HIPCHK(b->bounce.h2d(b->d_linMask, res_mask, R, s));
+  HIPCHK(b->bounce.h2d(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), s));
+  const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
+  hipLaunchKernelGGL(k_ba_lin_fix, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, (const float*)b->d_fullJ, (const unsigned char*)b->d_linMask, (const float*)b->d_adHTdelta, cd,
+                     b->d_lin, b->d_rtz, b->d_linRec);
+  HIPCHK(hipGetLastError());
+  // what calcLEnergyPt reads, on the host (the energy terms are host arithmetic in this library)
+  b->h_linAct.resize(R); b->h_linJ.resize((size_t)R * 74); b->h_rtz.resize((size_t)R * 8);
+  HIPCHK(b->bounce.d2h(b->h_lin.data(), b->d_lin, R, s));
+  HIPCHK(b->bounce.d2h(b->h_linAct.data(), b->Rs.active, R, s));
+  HIPCHK(b->bounce.d2h(b->h_linJ.data(), b->d_fullJ, sizeof(float) * 74 * R, s));
+  HIPCHK(b->bounce.d2h(b->h_rtz.data(), b->d_rtz, sizeof(float) * 8 * R, s));
+  HIPCHK(b->bounce.finish(s));
+  b->n_lin = 0;
+  for (int ri = 0; ri < R; ri++) if (b->h_lin[ri]) b->n_lin++;
+  if (b->n_lin > 0) { b->Rs.lin = b->d_lin; b->P.lHdd = b->d_lHdd; b->P.lbd = b->d_lbd; b->P.lHcd = b->d_lHcd; b->P.HcdAF = b->d_HcdAF; }
+  if (n_linearized) *n_linearized = b->n_lin;
+  return 0;
+}
+// accumulateLF_MT's system as the reference returns it (stitched linearised residuals + priors, EnergyFunctional.cpp:223-233) for the state of the LAST accumulation
+// (dmvio_hip_ba_accumulate / _solve / _optimize); without residuals kept linearised it holds the priors only
+int dmvio_hip_ba_get_lf_system(dmvio_hip_ba* b, double* HL, double* bL) {
+  if (!b) return failmsg("ba: null handle");
+  BA_LOCK(b);
+  if (!b->graph_ready) return failmsg("ba: set_window + set_graph first");
+  const BAHost& H = b->H;
+  const int n = H.n();
+  double HLd[4 + 8 * BA_MAXF_CAP], bLv[4 + 8 * BA_MAXF_CAP];
+  const bool haveL = H.lfTop(HLd, bLv);
+  if (HL) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) HL[(size_t)i * n + j] = (haveL ? H.HLraw[(size_t)i * n + j] : 0.0) + (i == j ? HLd[i] : 0.0);
+  if (bL) memcpy(bL, bLv, sizeof(double) * n);
   return 0;
 }
 
@@ -1216,7 +1377,7 @@ int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hc
   const int N = b->H.N;
   if (Hdd) HIPCHK(b->bounce.d2h(Hdd, b->P.Hdd, sizeof(float) * N, s));
   if (bd) HIPCHK(b->bounce.d2h(bd, b->P.bd, sizeof(float) * N, s));
-  if (Hcd4) HIPCHK(b->bounce.d2h(Hcd4, b->P.Hcd, sizeof(float) * 4 * N, s));
+  if (Hcd4) HIPCHK(b->bounce.d2h(Hcd4, b->n_lin > 0 ? b->P.HcdAF : b->P.Hcd, sizeof(float) * 4 * N, s));   // Hcd_accAF
   if (HdiF) HIPCHK(b->bounce.d2h(HdiF, b->P.HdiF, sizeof(float) * N, s));
   if (bdSumF) HIPCHK(b->bounce.d2h(bdSumF, b->P.bdSumF, sizeof(float) * N, s));
   HIPCHK(b->bounce.finish(s));
@@ -1486,7 +1647,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   if (canbreak_out) *canbreak_out = canbreak;
   const int minOpt = (b->vio_opt && b->vio_opt->minOptIterations >= 0) ? b->vio_opt->minOptIterations : H.S.minOptIterations;
   if (canbreak && iteration >= minOpt) last = true;
-  const double newL = H.calcLEnergyFrames(), newM = calcMEnergy(b, true);
+  const double newL = calcLEnergy(b), newM = calcMEnergy(b, true);
   if (dynDuring) b->dynW = vioDynamicWeight(b, lastE[0], b->resInA_solve);   // before deciding whether to accept the step (FullSystemOptimize.cpp:534-538)
   // linearise the stepped state; the kernel's last workgroup sums the energy, sets the newest keyframe's threshold and decides
   fillWindow(b);
@@ -1530,7 +1691,7 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     H.setPrecalcValues();
     fillWindow(b);
     b->dyn_cur = dyn_backup;
-    const double oldL = H.calcLEnergyFrames(), oldM = calcMEnergy(b, false);
+    const double oldL = calcLEnergy(b), oldM = calcMEnergy(b, false);
     lastE[1] = oldL; lastE[2] = oldM;
     b->pending_reject = true; b->pending_ticket = D2.ticket; b->pending_trace = trace_slot;
     if (!defer) { if (int r = settleReject(b, lastE, true)) return r; }
@@ -1655,7 +1816,7 @@ int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
 int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
   if (!b) return failmsg("null ba");
   BA_LOCK(b);
-  if (EL) *EL = b->H.calcLEnergyFrames();
+  if (EL) *EL = calcLEnergy(b);
   if (EM) *EM = b->H.calcMEnergy();
   return 0;
 }
@@ -1688,7 +1849,7 @@ static int optimizeImpl(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_call
   if (int r = accumulate(b, true, true, false)) return r;   // backupState of the points rides in the per-point sums; the frames are backed up by the first iteration
   linearizePickUp(b, &lastE[0], false);
   b->sys_ready = true;
-  lastE[1] = H.calcLEnergyFrames(); lastE[2] = calcMEnergy(b, false);
+  lastE[1] = calcLEnergy(b); lastE[2] = calcMEnergy(b, false);
   double lambda = 1e-5;
   int done = 0;
   b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;
@@ -2173,6 +2334,7 @@ int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* cons
     dmvio_hip_ba* b = windows[i];
     if (!b->graph_ready) return failmsg("ba_optimize_batch: set_window + set_graph first");
     if (sharded(b)) return failmsg("ba_optimize_batch: a window sharded over ranks cannot join a batch");
+    if (b->n_lin > 0) return failmsg("ba_optimize_batch: a window with residuals kept linearised (dmvio_hip_ba_fix_linearization) runs through the host-driven loop only");
   }
   // groups of equal keyframe count, in the caller's order
   std::vector<char> doneW(W, 0);
@@ -2199,6 +2361,7 @@ int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* cons
 int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* b, int on) {
   if (!b) return failmsg("ba: null handle");
   BA_LOCK(b);
+  if (on && b->n_lin > 0) return failmsg("ba_set_device_loop: the graph carries residuals kept linearised (dmvio_hip_ba_fix_linearization): host-driven loop only");
   b->device_loop = on != 0;
   return 0;
 }

@@ -340,13 +340,27 @@ int dmvio_hip_graph_export(dmvio_hip_graph* g, int* host, float* u, float* v, fl
  * dmvio_hip_ba_set_graph it does not wait for its uploads (they are staged in the handle's pinned memory and enqueued in front of whatever uses them).  After an optimisation the caller
  * hands the new inverse depths back with dmvio_hip_graph_set_idepths(g, N, <idepth of dmvio_hip_ba_get_points>): same order. */
 int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* ba, dmvio_hip_graph* g);
-/* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  The library accumulates ACTIVE residuals only
- * (accumulateAF_MT / addPoint<0>) and, inside dmvio_hip_ba_marginalize_points, the residuals it fix-linearised itself (addPoint<2>); the reference's third accumulator —
- * accumulateLF_MT / addPoint<1> / calcLEnergyPt over residuals that are linearised but NOT being marginalised (EnergyFunctional.cpp:223-233, 349-431,
- * AccumulatedTopHessian.cpp:84-98) — is not built, because the reference never produces such a residual: it linearises only inside FullSystem::flagPointsForRemoval,
- * immediately before marginalizePointsF removes the point (FullSystem.cpp:836-849).  A graph that does contain one is REFUSED: the call returns an error, the graph is
- * dropped (every later call on it fails until the next dmvio_hip_ba_set_graph) — it is never silently optimised without that energy term.  All flags zero: no effect. */
+/* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  A residual that ARRIVES linearised cannot be served: its frozen
+ * Jacobian and res_toZeroF — what accumulateLF_MT / addPoint<1> / calcLEnergyPt read (EnergyFunctional.cpp:223-233, 349-431, AccumulatedTopHessian.cpp:84-98) — are not
+ * part of the graph hand-over (nor does the reference ever hold such a residual across a keyframe: it linearises only inside FullSystem::flagPointsForRemoval, immediately
+ * before marginalizePointsF removes the point, FullSystem.cpp:836-849).  A graph that contains one is REFUSED: the call returns an error, the graph is dropped (every later
+ * call on it fails until the next dmvio_hip_ba_set_graph) — it is never silently optimised without that energy term.  All flags zero: no effect.  Residuals linearised ON
+ * the resident graph are served: dmvio_hip_ba_fix_linearization. */
 int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* ba, int R, const unsigned char* isLinearized);
+/* EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the ACTIVE residuals with res_mask != 0 (R flags, graph order), at the window's current state:
+ * res_toZeroF = resF - [JI Jp | Jab] delta from the applied Jacobian, isLinearized = true.  From then on the residual is no member of activeResiduals
+ * (FullSystemOptimize.cpp:436-446: not relinearised, not applied, not removed, outside the photometric energy and the newest keyframe's threshold) and enters
+ *   - every system through accumulateLF_MT / AccumulatedTopHessianSSE::addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:52-58,84-98): H_L / b_L with
+ *     resApprox = res_toZeroF + J delta, Hdd_accLF / bd_accLF / Hcd_accLF into the points' Schur terms,
+ *   - the energy through calcLEnergyPt (EnergyFunctional.cpp:349-409),
+ * until the next dmvio_hip_ba_set_graph, or until dmvio_hip_ba_marginalize_points relinearises its point (FullSystem.cpp:840-843).  Requires the Jacobians of the APPLIED
+ * linearisation: dmvio_hip_ba_keep_jacobians(ba, 1) before the dmvio_hip_ba_optimize (or linearize(fix) / linearize + apply) that precedes this call.  Host-driven loop
+ * only: a window with linearised residuals is refused by dmvio_hip_ba_optimize_batch, dmvio_hip_ba_set_device_loop and dmvio_hip_ba_set_comm.  n_linearized (may be NULL):
+ * linearised residuals of the graph after the call. */
+int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* ba, int R, const unsigned char* res_mask, int* n_linearized);
+/* accumulateLF_MT's result as the reference returns it (EnergyFunctional.cpp:223-233: the stitched system of the linearised residuals plus the frame / calibration priors,
+ * AccumulatedTopHessian.cpp:292-302), n x n and n doubles, for the state of the last accumulation (dmvio_hip_ba_accumulate / _solve / _gn_iteration / _optimize) */
+int dmvio_hip_ba_get_lf_system(dmvio_hip_ba* ba, double* HL, double* bL);
 /* resetOOB of every residual (FullSystemOptimize.cpp:431-448) */
 int dmvio_hip_ba_activate_all(dmvio_hip_ba* ba);
 /* FullSystem::linearizeAll(fixLinearization) (FullSystemOptimize.cpp:150-218): PointFrameResidual::linearize over all residuals,

@@ -341,8 +341,9 @@ def test_window_size_is_a_runtime_setting(pkg, oracle, synth, gpu_required, F):
 
 
 def test_graph_with_a_linearised_residual_is_refused(pkg, synth, gpu_required):
-    """accumulateLF_MT / addPoint<1> (linearised residuals that are not being marginalised) is not built, because the reference's flow never produces one; a graph that
-    contains one is refused with an error instead of being optimised without that term, and stays refused until a new graph is set."""
+    """A residual that ARRIVES linearised with the graph cannot be served (its frozen Jacobian / res_toZeroF, which accumulateLF_MT / addPoint<1> read, are not part of
+    the hand-over — dmvio_hip_ba_fix_linearization linearises on the resident graph instead, see the next test): the graph is refused with an error instead of being
+    optimised without that term, and stays refused until a new graph is set."""
     case = synth.ba_case(256, 256, n_frames=4, n_points=120, seed=9, hosts_share=(50, 40, 30, 0))
     ctx = pkg.Context(256, 256, n_slots=4)
     for k in range(4):
@@ -359,6 +360,72 @@ def test_graph_with_a_linearised_residual_is_refused(pkg, synth, gpu_required):
         ba.optimize(2)
     ba.set_case(case, [0, 1, 2, 3])
     assert ba.optimize(2)["finalEnergy"] == r0["finalEnergy"]
+
+
+def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu_required):
+    """EFResidual::fixLinearizationF outside a marginalisation, accumulateLF_MT / addPoint<1> and calcLEnergyPt (EnergyFunctionalStructs.cpp:85-113,
+    AccumulatedTopHessian.cpp:52-58,84-98, EnergyFunctional.cpp:223-233,349-409); the oracle's branch is pinned bit for bit to libref.so (tests/test_ref_pin_cpu.py).
+    First with identical bits on both sides — non-zero frame deltas at the fix and other ones at the accumulation, set through the API: H_L / b_L, the A and Schur systems
+    as tight as the accumulation itself, the per-point sums bit for bit, E_L to double rounding.  Then through optimisations over the graph that carries them."""
+    case = synth.ba_case(256, 192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
+    ctx, ba, W = _window(pkg, oracle, case)
+    R = len(case["res_point"]); F = case["n_frames"]
+    rng = np.random.RandomState(11)
+
+    def perturb(scale):
+        for k in range(1, F):
+            st = np.zeros(10); st[:3] = 2e-3 * scale * rng.standard_normal(3); st[3:6] = 1e-3 * scale * rng.standard_normal(3)
+            st[6] = 1e-3 * scale * rng.standard_normal(); st[7] = 1e-4 * scale * rng.standard_normal()
+            ba.set_frame_state(k, st); W.set_frame_state(k, st)
+
+    perturb(1.0)
+    ba.activate_all(); W.activate_all()
+    ba.linearize_all(False); W.linearize_all(False)
+    ba.apply_res(); W.apply_res()
+    mask = (np.arange(R) % 3 == 0).astype(np.uint8)
+    n_lin = ba.fix_linearization(mask)                                                # res_toZeroF = resF - J delta at the first deltas
+    assert n_lin == W.fix_linearization(mask) and 100 < n_lin <= (R + 2) // 3
+    perturb(0.5)                                                                      # resApprox = res_toZeroF + J delta at the second ones
+    ag, ao = ba.accumulate(), W.accumulate()
+    HLg, bLg = ba.lf_system()
+    assert ag["resInA"] == ao["resInA"] and 0 < ag["resInA"] < R - n_lin + 1          # addPoint<0> left the linearised ones out
+    off = ao["HL"] - np.diag(np.diag(ao["HL"]))
+    assert np.abs(off).max() > 1e3 and np.abs(ao["bL"][12:]).max() > 1e2               # the L system is populated, not just the priors
+    for Hg, Ho in ((HLg, ao["HL"]), (ag["HA"], ao["HA"]), (ag["Hsc"], ao["Hsc"])):
+        assert np.linalg.norm(Hg - Ho) <= 1e-11 * np.linalg.norm(Ho)
+    for bg, bo in ((bLg, ao["bL"]), (ag["bA"], ao["bA"]), (ag["bsc"], ao["bsc"])):
+        assert np.linalg.norm(bg - bo) <= 1e-9 * np.linalg.norm(bo)
+    pg, po = ba.point_acc(), W.point_acc()
+    for k in ("Hdd", "bd", "Hcd", "HdiF", "bdSumF"):                                   # Hdd_accAF .. of addPoint<0>; HdiF / bdSumF carry the LF sums
+        assert np.array_equal(pg[k], po[k]), k
+    ELg, ELo = ba.energy_terms()[0], W.lenergy()
+    assert abs(ELo) > 1.0 and abs(ELg - ELo) <= 1e-12 * abs(ELo)
+    x_g = ba.solve(0, 1e-5); x_o = W.solve(0, 1e-5)
+    assert np.linalg.norm(x_g - x_o) <= 1e-6 * np.linalg.norm(x_o)
+    # a second optimize over the graph that carries them: same decisions, energies and states
+    rg = ba.optimize(4); ro = W.optimize(4)
+    assert np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3])
+    assert np.allclose(rg["trace"][:, 0], ro["trace"][:, 0], rtol=1e-4) and np.allclose(rg["trace"][:, 1], ro["trace"][:, 1], rtol=1e-4)
+    assert np.abs(ro["trace"][:, 1]).min() > 1.0                                      # E_L carries the linearised term in every row
+    assert abs(rg["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"] and abs(rg["rmse"] - ro["rmse"]) <= 1e-4 * ro["rmse"]
+    for k in range(5):
+        pg_, ag_, _ = ba.frame_pose(k); po_, ao_, _ = W.frame_pose(k)
+        assert np.linalg.norm(pg_[:3] - po_[:3]) < 1e-3 and np.allclose(ag_, ao_, atol=1e-3)
+    zero = np.zeros(R, np.uint8)
+    assert ba.fix_linearization(zero) == W.fix_linearization(zero) == n_lin            # the final linearizeAll(true) removes none of them
+    # the fast paths refuse such a window instead of dropping the term
+    with pytest.raises(pkg.HipLibraryError, match="kept linearised"):
+        ba.set_device_loop(True)
+    batch = pkg.BundleAdjusterBatch(ctx, 1)
+    with pytest.raises(pkg.HipLibraryError, match="kept linearised"):
+        batch.optimize([ba], 2)
+    # marginalising the points relinearises their residuals (FullSystem.cpp:840-843): the linearised flags of those points go
+    cand = np.zeros(ba.N, np.uint8); cand[: ba.N // 2] = 1
+    ba.marginalize_points(cand)
+    left = ba.fix_linearization(zero)
+    rp = np.asarray(case["res_point"])
+    assert left < n_lin and left <= int(np.sum(mask.astype(bool) & (rp >= ba.N // 2)))
+    ba.close()
 
 
 def test_new_graph_right_after_an_accepted_iteration_call(pkg, oracle, synth, gpu_required):
