@@ -925,7 +925,7 @@ def bench_trace(args, pkg, synth, ctx, torch, stream, case, cpu):
     return out
 
 
-def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev, M=8):
+def bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev, M=32):
     """What ONE GPU sustains with several windows in flight — the BA analogue of the tracker's 4096-frame batch.  A single window is a chain of dependent sub-10-us
     launches on a 256-CU device (latency-bound: `ba.value`); K host threads, each optimising its own fresh windows through its own dmvio_hip_ba handles (own HIP stream, own
     lock, own pinned result block), overlap those chains.  Every thread owns M windows, all set up BEFORE the timed region (set_graph is per-keyframe set-up, not iteration
