@@ -20,4 +20,6 @@ python tools/rocprof_timeline.py $(find $O/ba_kt -name '*.db' | head -1) k_ba_po
 rm -rf $O/ba_kt
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 python bench.py --steps 20 --warmup 3 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+bash tools/ba_batch_prof.sh 16 $O/ba_batch_kernels_w16.md > $O/ba_batch_probe_w16.log 2>&1 < /dev/null
+cd $GRAFT_REPO_ROOT
 tail -c 600 $O/bench_n1.json; cat $O/bench_wall.txt

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Copies the summaries of gpurun_out/prof_r05 (tools/profile_round.sh r05 + the driver's own bench command) into profiles/r05_*."""
+import json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "prof_r05"); P = os.path.join(ROOT, "profiles")
+d = json.loads(open(O + "/bench_n1.json").read().strip().splitlines()[-1])
+json.dump(d, open(P + "/r05_bench_n1.json", "w"), indent=1)
+dd = json.loads(open(O + "/bench_driver_cmd.json").read().strip().splitlines()[-1])
+json.dump(dd, open(P + "/r05_bench_n1_driver_command.json", "w"), indent=1)
+rf = d["roofline"]; ba = d["ba"]
+lines = open(O + "/kernel_stats.md").read().splitlines()
+body = [l for l in lines[2:] if ("dmv::" in l or "__amd_rocclr_copyBuffer" in l)]
+head = ("# r05 — `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --no-traffic` (defaults: 4096 frames per step, 200 steps, batch sweep, PCIe legs, BA / trace / overlap / live / "
+        "VIO legs), 1x MI355X\n\nProduced by `tools/profile_round.sh r05` + `tools/publish_r05.py`; durations in microseconds from the rocpd database (`tools/rocprof_summary.py`).  The dominant kernel of "
+        "the headline step is `k_track_lm<256, 4>` with 4096 workgroups (one per frame): avg below vs %.4f ms by HIP events on its stream in the un-profiled run (`profiles/r05_bench_n1.json`: "
+        "%.0f frames/s, algorithmic fraction %.3f, HBM-counter fraction %.3f).  BA kernels: `k_ba_linearize` avg below vs %.1f us by HIP events incl. the gap to the next launch "
+        "(`ba.roofline.chain_us`); `ba.value` = %.0f accepted GN iterations/s on fresh windows (optimize(6) = %.3f ms), %.0f/s on the converged (reject-dominated) loop.\n\n"
+        % (rf["kernel_ms"], d["value"], rf["frac"], rf.get("frac_hbm_counter", float("nan")), ba["roofline"]["kernel_us"], ba["value"], ba["optimize6_ms"], ba["value_converged_loop"]))
+tail = ""
+open(P + "/r05_kernel_stats.md", "w").write(head + "\n".join(lines[:2] + body[:80]) + "\n" + tail)
+def filt(path):
+    return [l for l in open(path).read().splitlines() if l.startswith("| kernel") or l.startswith("|---") or "dmv::" in l]
+head = ("# r05 — HBM traffic counters (`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, separate passes, no other tracing), 1x MI355X\n\n"
+        "`bench.py --no-cpu --no-traffic --no-sweep --no-pcie --steps 3 --warmup 1 --ba-iters 20`.  Values are KiB as the counter reports them; on gfx950 FETCH_SIZE tallies 128-byte reads at half "
+        "their size (MI355X_MICROARCH.md): the in-run calibration on `k_build_pyramids` (reads exactly B x w x h x 4 bytes per launch) gives the factor 2.000 that `bench.py` applies "
+        "(`roofline.traffic_source`).  `k_track_lm<256,4>` with 4096 workgroups: %.2f GB per launch by the counter = %.2fx its %.2f GB of algorithmic bytes.\n\n"
+        % (rf["traffic"] / 1e9, rf["traffic"] / rf["algorithmic_bytes_per_launch"], rf["algorithmic_bytes_per_launch"] / 1e9))
+open(P + "/r05_pmc_hbm_traffic.md", "w").write(head + "## FETCH_SIZE\n" + "\n".join(filt(O + "/pmc_FETCH_SIZE.md")) + "\n\n## WRITE_SIZE\n" + "\n".join(filt(O + "/pmc_WRITE_SIZE.md")) + "\n")
+import subprocess, sys
+summary = subprocess.run([sys.executable, ROOT + "/tools/ba_split_summary.py",
+                          "r05 — BA: host-side split of the GN iteration (DMVIO_HIP_BA_TIMING=1, no synchronisation added) and kernel timeline (rocprofv3 --kernel-trace of tools/ba_loop.py), 1x MI355X",
+                          O + "/ba_timing.log", O + "/ba_timeline.txt", O + "/ba_loop.log"], capture_output=True, text=True, check=True).stdout
+open(P + "/r05_ba_host_split_and_timeline.md", "w").write(summary)
+bw = ba.get("batched_windows")
+if bw and "error" not in bw:
+    rows = ["# r05 — `ba.batched_windows`: dmvio_hip_ba_optimize_batch, W windows per launch sequence on the device-resident loop (`bench.py`, 1x MI355X)", "", bw.get("what", ""), "",
+            "| W | accepted it/s (wall) | wall ms per optimize(6) of the batch | device ms | stepped linearisation us | k_ba_linearize_b: TB/s algorithmic | of 8 TB/s |", "|---|---|---|---|---|---|---|"]
+    for r in bw["sweep"]:
+        rows.append("| %d | %.0f | %.3f | %.3f | %.1f | %.3f | %.4f |" % (r["windows"], r["value"], r["wall_ms"], r["device_ms"], r["k_ba_linearize_b_us"], r["k_ba_linearize_b_GBs"] / 1e3, r["k_ba_linearize_b_frac"]))
+    rows += ["", "Single window, host-driven loop (the default of dmvio_hip_ba_optimize): %.3f ms per optimize(6) = %.0f accepted it/s." % (ba["optimize6_ms"], ba["value"])]
+    open(P + "/r05_ba_batched_windows.md", "w").write("\n".join(rows) + "\n")
+di = d.get("drop_in")
+if di and "error" not in di:
+    rows = ["# r05 — the reference's own FullSystem, all-CPU vs with its hot-path members on libdmvio_hip.so (`bench.py` -> `drop_in`, 1x MI355X box)", "",
+            di["what"] + ".", "",
+            "| run | wall clock of the %d addActiveFrame calls (s) | ms per frame after initialisation |" % di["frames"], "|---|---|---|",
+            "| all-CPU, the reference's default threading (multiThreading = true, its own thread-pooled initialiser) | %.3f | %.2f |" % (di["all_cpu_s"], di["ms_per_frame_after_initialisation"]["all_cpu"]),
+            "| all-CPU, single-threaded, sequential initialiser (bit-reproducible: the trajectory baseline) | %.3f | %.2f |" % (di["all_cpu_single_threaded_s"], di["ms_per_frame_after_initialisation"]["all_cpu_single_threaded"]),
+            "| HIP-backed (seven members + makeKeyFrame through tests/dropin/dmvio_hip_adapter.cpp) | %.3f | %.2f |" % (di["hip_backed_s"], di["ms_per_frame_after_initialisation"]["hip_backed"]),
+            "", "Trajectory HIP-backed vs the single-threaded baseline: rmse %.2e m, max %.2e m (bar 1e-3 m); the two all-CPU runs against each other: rmse %.2e m.  %d keyframe optimisations, adapter failures %d."
+            % (di["traj_rmse_m"], di["traj_max_m"], di["reference_own_spread_rmse_m"], di["keyframe_optimisations"], di["adapter_failures"]), "",
+            "## inclusive seconds under the reference's own profiler labels (util/TimeMeasurement scopes)", "", "| scope | all-CPU (default threading) | HIP-backed |", "|---|---|---|"]
+    for k in di["scopes_all_cpu"]:
+        rows.append("| %s | %.4f | %.4f |" % (k, di["scopes_all_cpu"][k], di["scopes_hip_backed"].get(k, 0.0)))
+    rows += ["", "## seconds inside the replaced members, HIP-backed run", "", "| member | seconds |", "|---|---|"]
+    for k, v in di["seconds_in_replaced_members"].items():
+        rows.append("| %s | %.4f |" % (k, v))
+    if "adapter_ms_per_keyframe" in di:
+        a = di["adapter_ms_per_keyframe"]; am = di.get("adapter_ms_per_keyframe_default_threading", {})
+        rows += ["", "## FullSystem::optimize member of the adapter, ms per keyframe (window graph resident: `dmvio_hip_graph_*`, %d forwarded EnergyFunctional mutations, %d resyncs)" % (di["window_graph"]["forwarded_mutations"], di["window_graph"]["resyncs"]), "",
+                 "| part | single-threaded run | multiThreading = true |", "|---|---|---|"]
+        for k in ("hand_over", "dmvio_hip_ba_optimize", "write_back"):
+            rows.append("| %s | %.3f | %.3f |" % (k, a[k], am.get(k, float("nan"))))
+        rows += ["", "HIP-backed with the reference's default threading for what it keeps doing itself: %.3f s (%.2fx the all-CPU default)." % (di["hip_backed_default_threading_s"], di["speedup_vs_reference_default_same_threading"])]
+    v = di.get("vio")
+    if v and "error" not in v:
+        rows += ["", "## the reference's DEFAULT configuration (setting_useIMU = setting_useGTSAMIntegration = true) live through the adapter", "", v["what"] + ".", "",
+                 "all-CPU (single-threaded) %.3f s, HIP-backed %.3f s; trajectory rmse %.2e m, max %.2e m; adapter failures %d, lost %s." % (v["all_cpu_single_threaded_s"], v["hip_backed_s"], v["traj_rmse_m"], v["traj_max_m"], v["adapter_failures"], v["lost"]),
+                 "adapter calls: " + ", ".join("%s %d" % kv for kv in v["adapter_calls"].items()) + ".",
+                 "facade member calls all-CPU %s / HIP-backed %s." % (v["facade_calls_all_cpu"], v["facade_calls_hip_backed"]),
+                 "optimize member per keyframe (ms): " + ", ".join("%s %.3f" % kv for kv in v["adapter_ms_per_keyframe"].items()) + "."]
+    t = di.get("track_new_coarse")
+    if t:
+        rows += ["", "FullSystem::trackNewCoarse adapter member: " + ", ".join("%s %d" % kv for kv in t.items()) + "."]
+    rows += ["", di["note"]]
+    open(P + "/r05_fullsystem_scopes.md", "w").write("\n".join(rows) + "\n")
+print(json.dumps({k: d[k] for k in ("value", "ms_per_step")}), json.dumps(rf)[:300])
+print("driver cmd:", dd["value"], dd["ms_per_step"], dd["roofline"]["frac"])
+for k in ("value", "optimize6_ms", "value_converged_loop", "value_per_call_api", "value_single_threaded_order", "gtsam_handoff"):
+    print("ba", k, ba.get(k))
+print("ba roofline", json.dumps(ba["roofline"])[:500]); print("ba cpu", json.dumps(ba["cpu_baseline"])[:300])
+print("live", d["live"]["value"], "vio", d["vio_handoff"]["handoff"]["ms_per_frame"], "pcie", d["pcie"]["value"], d["pcie"]["raw_u8"]["value"], "cpu", d["cpu_baseline"]["value"], "trace", d["trace"]["value"], d["trace"]["cpu_baseline"]["value"])
