@@ -1210,13 +1210,14 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
   if (!b || !g) return failmsg("ba_set_graph_from: null argument");
   BA_LOCK(b);
   int N = 0, R = 0;
+  unsigned long long flat_version = 0;
   {
     std::lock_guard<std::mutex> lg(g->mu);
     if ((int)g->frames.size() != b->H.F) return failmsg("ba_set_graph_from: the graph has " + std::to_string(g->frames.size()) + " keyframes, the window " + std::to_string(b->H.F));
     if (g->nDangling) return failmsg("ba_set_graph_from: " + std::to_string(g->nDangling) + " residuals still target a removed keyframe (their dropResidual has not been forwarded)");
     N = g->nPoints; R = g->nRes;
     if (N < 1 || R < 1) return failmsg("ba_set_graph: empty graph");
-    g->flat_version = g->version;   // the flat order handed to the device: dmvio_hip_graph_set_idepths accepts values in this order until the structure changes
+    flat_version = g->version;
     auto& S = b->gscratch;
     S.host.resize(N); S.u.resize(N); S.v.resize(N); S.idepth.resize(N); S.color.resize(8 * (size_t)N); S.weights.resize(8 * (size_t)N); S.prior.resize(N);
     S.res_point.resize(R); S.res_target.resize(R);
@@ -1230,7 +1231,12 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
       }
   }
   const auto& S = b->gscratch;
-  return setGraphImpl(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data(), false);
+  if (int r = setGraphImpl(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data(), false)) return r;
+  // only a window that WAS built makes its flat order the one dmvio_hip_graph_set_idepths accepts values in (until the structure changes).  The uploads are stream-ordered:
+  // an asynchronous copy error of this call is reported by the next BA call that synchronises
+  std::lock_guard<std::mutex> lg(g->mu);
+  g->flat_version = flat_version;
+  return 0;
 }
 
 #define BA_READY_LOCKED(b) do { if (!(b)->graph_ready) return failmsg("ba: set_window + set_graph first"); (b)->sums_fresh = false; (b)->sys_ready = false; HIPCHK(hipSetDevice((b)->ctx->device)); } while (0)
