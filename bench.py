@@ -1027,11 +1027,12 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
     return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows,
                 single_window=dict(optimize6_ms=rows[0]["wall_ms"], us_per_accepted_iteration=rows[0]["us_per_accepted_iteration"],
                                    what="dmvio_hip_ba_optimize_batch of ONE window = dmvio_hip_ba_optimize with dmvio_hip_ba_set_device_loop(1): the whole loop enqueued up front, two host waits per call"),
-                roofline=dict(bound="hbm", kernel="k_ba_linearize_b", achieved=best["k_ba_linearize_b_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=best["k_ba_linearize_b_frac"],
+                roofline=dict(bound="hbm", kernel="k_ba_linearize_b1" if best["windows"] >= 4 else "k_ba_linearize_b", achieved=best["k_ba_linearize_b_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=best["k_ba_linearize_b_frac"],
                               kernel_us=best["k_ba_linearize_b_us"], algorithmic_bytes_per_launch=int(best["windows"] * bytes_lin),
                               iteration=dict(achieved=round(ach, 2), frac=round(ach / HBM_PEAK_GBS, 5)),
-                              what="the stepped linearisation of all windows of the call (one launch, HIP events on the batch's stream): 464 B per residual x residuals of all windows / its "
-                                   "duration; `iteration`: all algorithmic bytes of an accepted iteration x accepted iterations per second"),
+                              what="the stepped linearisation of ALL windows of a call (one launch, HIP events on the batch's stream; the profiled repetitions run as one group on one "
+                                   "stream, alone on the device; from 4 windows on the one-lane-per-residual kernel k_ba_linearize_b1): 464 B per residual x residuals of all windows / "
+                                   "its duration; `iteration`: all algorithmic bytes of an accepted iteration x accepted iterations per second"),
                 what="W fresh windows (own handles, set up before the timed region), ONE dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its "
                      "wall time; device_ms = the same call by HIP events (loop + final fix-linearisation)")
 

@@ -786,6 +786,16 @@ class BundleAdjusterBatch:
         fn = self.L.dmvio_hip_ba_batch_set_profile; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
         _chk(self.L, fn(self.p, 1 if on else 0), "ba_batch_set_profile")
 
+    def set_streams(self, streams=0):
+        """0: automatic (up to three groups of windows on their own streams from 4 windows on); k >= 1: at most k groups"""
+        fn = self.L.dmvio_hip_ba_batch_set_streams; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, int(streams)), "ba_batch_set_streams")
+
+    def set_linearize_lanes(self, lanes=1):
+        """1: one lane per residual from 4 windows on (k_ba_linearize_b1, default); 8: the eight-lane kernel for every batch size"""
+        fn = self.L.dmvio_hip_ba_batch_set_linearize_lanes; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, int(lanes)), "ba_batch_set_linearize_lanes")
+
 
 class RcclCommunicator:
     """ncclComm_t created through the library's wrappers (dmvio_hip_comm_*): rank `rank` of `world` on the context's device.

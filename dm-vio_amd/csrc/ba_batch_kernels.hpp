@@ -56,6 +56,7 @@ struct BAWinDev {
   double* sys;                 // device: [H_A | b_A | H_sc | b_sc | resInA]
   BACtl* ctl;
   int n_lin_blocks, n_pt8_blocks, n_acc_blocks, n_res_blocks, n_gather_blocks, n_stitch_blocks;
+  int n_lin1_blocks;           // workgroups of the one-lane-per-residual linearisation (k_ba_linearize_b1): 256 residuals each
   float frameTH[BA_MAXF_CAP];  // FrameHessian::frameEnergyTH of the window's keyframes for the duration of a batch call (BADecide::frameTH points here)
   BASolveDev S;
 };
@@ -75,6 +76,16 @@ __global__ void __launch_bounds__(LIN_THREADS) __attribute__((amdgpu_waves_per_e
   if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin_blocks); }
   else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody(V.Wb, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
   else { D.mode = 0; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
+}
+// the one-lane-per-residual form (baLinearizeBody1): what a grid that fills the device wants — an eighth of the lanes, no redundant geometry; same values, same energy partials
+__global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize_b1(const BAWinDev* __restrict__ wins, const FrameStore fs, const int kind) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_lin1_blocks) return;
+  BADecide D = V.D;
+  D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1;
+  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin1_blocks, V.n_lin_blocks); }
+  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks); }
+  else { D.mode = 0; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks); }
 }
 __global__ void __launch_bounds__(256) k_ba_reset_oob_b(const BAWinDev* __restrict__ wins) {
   const BAWinDev& V = wins[blockIdx.y];

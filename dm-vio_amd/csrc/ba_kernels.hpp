@@ -575,6 +575,200 @@ __device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoint
   if (D.mode == 3) baPackBlock(D, nblocks);
   else baDecideBlock(D, nblocks, t_kernel0);
 }
+// The same linearisation with ONE lane per residual (the lane walks the eight pattern pixels itself): for launches that fill the device — the batched loop over many
+// windows — where the eight-lane form's redundant geometry (every lane of a residual computes the same projection and Jacobian rows) costs throughput instead of hiding
+// latency.  Every value is formed by the same operations in the same order: the pattern sums are 0 + v0 + v1 + ... in the lane, the point's back-substitution subtracts its
+// residuals' products in residual order, and the energy partials keep the eight-lane kernel's partition (runs of LIN_RES_PER_BLOCK residuals, summed in order, one partial
+// per run — nruns of them — so the decision pass adds the same numbers in the same tree).  nblocks: workgroups of this window's launch (256 residuals each).
+// No pt_mask / fullJ form: the callers that need those use the eight-lane kernel.
+__device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoints& P, const BARes& Rs, const BAPrecalc* __restrict__ pre, const FrameStore& fs,
+                                                 const BADecide& D, const int gate, const int use_backup, const float (*__restrict__ Tv)[14], const int use_dyn,
+                                                 const float* __restrict__ Xxc, const float* __restrict__ XxAd, const int do_resub, const int nblocks, const int nruns) {
+  if (baGateClosed(D.ctl, gate)) return;
+  const long long t_kernel0 = wall_clock64();
+  const int ri = blockIdx.x * LIN_THREADS + threadIdx.x;
+  double myE = 0.0;
+  if (ri < W.R) {
+    float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
+    const int state = Rs.state[ri];
+    const float oldEnergy = Rs.energy[ri];
+    Rs.newEnergyWO[ri] = -1.0f;
+    const int sl = Rs.newestSlot[ri];
+    if (sl >= 0) __hip_atomic_store(Rs.newestE + sl, -1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool done = false;
+    if (state == BA_OOB) { Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
+    if (Rs.lin && Rs.lin[ri]) { myE = 0.0; done = true; }
+    const int pi = Rs.point[ri], ti = Rs.target[ri];
+    const int hi = P.host[pi];
+    BAPrecalc pc = pre[hi + W.F * ti];
+    if (use_dyn) {
+      const float* __restrict__ dv = Tv[baPairIndex(hi, ti, W.F)];
+#pragma unroll
+      for (int k = 0; k < 9; k++) pc.KRKi[k] = dv[k];
+      pc.Kt[0] = dv[9]; pc.Kt[1] = dv[10]; pc.Kt[2] = dv[11]; pc.aff0 = dv[12]; pc.aff1 = dv[13];
+    }
+    const float pu = P.u[pi], pv = P.v[pi];
+    float id_new = 0.0f;
+    if (do_resub) {   // resubstituteFPt + the point part of doStepFromBackup (see baLinearizeBody)
+      const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
+      const float bk = P.idepth_backup[pi];
+      float bsum = P.bdSumF[pi];
+      {
+        float dotc = 0;
+        dotc += Xxc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += Xxc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
+        dotc += Xxc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += Xxc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
+        bsum -= dotc;
+      }
+      int ngood = 0;
+      for (int rq = r0; rq < r1; rq++) {
+        if (Rs.active[rq] == 0) continue;   // the eight-lane form subtracts +0.0f for it
+        const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
+        const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
+        float d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
+        bsum = bsum - d;
+        ngood++;
+      }
+      const float st = ngood == 0 ? 0.0f : -bsum * P.HdiF[pi];
+      id_new = bk + 1.0f * st;
+      if (r0 == ri) { P.step[pi] = st; P.idepth[pi] = id_new; P.idepth_zero[pi] = id_new; }
+    }
+    float d_xi_x[6], d_xi_y[6], d_C_x[4], d_C_y[4], d_d_x = 0, d_d_y = 0;
+    if (!done) {
+      const float idz = do_resub ? id_new : (use_backup ? P.idepth_backup[pi] : P.idepth_zero[pi]);
+      const float Kx = (pu + 0 - W.cx) * W.fxi, Ky = (pv + 0 - W.cy) * W.fyi;
+      const float p0 = pc.R0[0] * Kx + pc.R0[1] * Ky + pc.R0[2] * 1.0f + pc.t0[0] * idz;
+      const float p1 = pc.R0[3] * Kx + pc.R0[4] * Ky + pc.R0[5] * 1.0f + pc.t0[1] * idz;
+      const float p2 = pc.R0[6] * Kx + pc.R0[7] * Ky + pc.R0[8] * 1.0f + pc.t0[2] * idz;
+      const float drescale = 1.0f / p2;
+      const float new_idepth = idz * drescale;
+      bool ok = drescale > 0;
+      const float u = p0 * drescale, v = p1 * drescale;
+      const float Ku = u * W.fx + W.cx, Kv = v * W.fy + W.cy;
+      ok = ok && (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
+      if (!ok) { Rs.newState[ri] = BA_OOB; myE = oldEnergy; done = true; }
+      else {
+        Rs.center[3 * ri + 0] = Ku; Rs.center[3 * ri + 1] = Kv; Rs.center[3 * ri + 2] = new_idepth;
+        d_d_x = drescale * (pc.t0[0] - pc.t0[2] * u) * 1.0f * W.fx;
+        d_d_y = drescale * (pc.t0[1] - pc.t0[2] * v) * 1.0f * W.fy;
+        d_C_x[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
+        d_C_x[3] = W.fx * drescale * (pc.R0[7] * u - pc.R0[1]) * W.fyi;
+        d_C_x[0] = Kx * d_C_x[2];
+        d_C_x[1] = Ky * d_C_x[3];
+        d_C_y[2] = W.fy * drescale * (pc.R0[6] * v - pc.R0[3]) * W.fxi;
+        d_C_y[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
+        d_C_y[0] = Kx * d_C_y[2];
+        d_C_y[1] = Ky * d_C_y[3];
+        d_C_x[0] = (d_C_x[0] + u) * 50.0f; d_C_x[1] *= 50.0f; d_C_x[2] = (d_C_x[2] + 1) * 50.0f; d_C_x[3] *= 50.0f;   // SCALE_F, SCALE_C
+        d_C_y[0] *= 50.0f; d_C_y[1] = (d_C_y[1] + v) * 50.0f; d_C_y[2] *= 50.0f; d_C_y[3] = (d_C_y[3] + 1) * 50.0f;
+        d_xi_x[0] = new_idepth * W.fx; d_xi_x[1] = 0; d_xi_x[2] = -new_idepth * u * W.fx;
+        d_xi_x[3] = -u * v * W.fx; d_xi_x[4] = (1 + u * u) * W.fx; d_xi_x[5] = -v * W.fx;
+        d_xi_y[0] = 0; d_xi_y[1] = new_idepth * W.fy; d_xi_y[2] = -new_idepth * v * W.fy;
+        d_xi_y[3] = -(1 + v * v) * W.fy; d_xi_y[4] = u * v * W.fy; d_xi_y[5] = u * W.fy;
+      }
+    }
+    if (!done) {
+      const float* __restrict__ img = fs.level(W.slot[ti], 0);
+      const float ids = do_resub ? id_new : (use_backup ? P.idepth_backup[pi] : P.idepth[pi]);
+      float energyLeft = 0.0f, JI00 = 0.0f, JI11 = 0.0f, JI10 = 0.0f, Ja00 = 0.0f, Ja01 = 0.0f, Ja10 = 0.0f, Ja11 = 0.0f, Jb00 = 0.0f, Jb01 = 0.0f, Jb11 = 0.0f, wJI2 = 0.0f;
+      float JIr0 = 0.0f, JIr1 = 0.0f, Jar0 = 0.0f, Jar1 = 0.0f, rr = 0.0f;
+      bool allGood = true;
+#pragma unroll 2
+      for (int idx = 0; idx < 8; idx++) {
+        const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
+        const float q0 = pc.KRKi[0] * xu + pc.KRKi[1] * xv + pc.KRKi[2] * 1.0f + pc.Kt[0] * ids;
+        const float q1 = pc.KRKi[3] * xu + pc.KRKi[4] * xv + pc.KRKi[5] * 1.0f + pc.Kt[1] * ids;
+        const float q2 = pc.KRKi[6] * xu + pc.KRKi[7] * xv + pc.KRKi[8] * 1.0f + pc.Kt[2] * ids;
+        const float Ku = q0 / q2, Kv = q1 / q2;
+        const bool inb = (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
+        float3 hit = interp33(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, W.w);
+        allGood = allGood && inb && isfinite(hit.x);
+        const float color = P.color[pi * 8 + idx];
+        const float residual = hit.x - (pc.aff0 * color + pc.aff1);
+        const float drdA = (color - pc.b0);
+        float wgt = sqrtf(W.outlierTHSum / (W.outlierTHSum + (hit.y * hit.y + hit.z * hit.z)));
+        wgt = 0.5f * (wgt + P.weights[pi * 8 + idx]);
+        float hw = fabsf(residual) < W.huberTH ? 1.0f : W.huberTH / fabsf(residual);
+        const float eTerm = wgt * wgt * hw * residual * residual * (2 - hw);
+        if (hw < 1) hw = sqrtf(hw);
+        hw = hw * wgt;
+        hit.y *= hw; hit.z *= hw;
+        const float resF = residual * hw;
+        float jab0 = drdA * hw, jab1 = hw;
+        const float tJa00 = drdA * hw * hit.y, tJa01 = drdA * hw * hit.z, tJa10 = hw * hit.y, tJa11 = hw * hit.z;
+        const float tJb00 = drdA * drdA * hw * hw, tJb01 = drdA * hw * hw, tJb11 = hw * hw;
+        const float twJI2 = hw * hw * (hit.y * hit.y + hit.z * hit.z);
+        if (W.modeA < 0) jab0 = 0;
+        if (W.modeB < 0) jab1 = 0;
+        energyLeft = energyLeft + eTerm;
+        JI00 = JI00 + hit.y * hit.y; JI11 = JI11 + hit.z * hit.z; JI10 = JI10 + hit.y * hit.z;
+        Ja00 = Ja00 + tJa00; Ja01 = Ja01 + tJa01; Ja10 = Ja10 + tJa10; Ja11 = Ja11 + tJa11;
+        Jb00 = Jb00 + tJb00; Jb01 = Jb01 + tJb01; Jb11 = Jb11 + tJb11; wJI2 = wJI2 + twJI2;
+        JIr0 = JIr0 + resF * hit.y; JIr1 = JIr1 + resF * hit.z; Jar0 = Jar0 + resF * jab0; Jar1 = Jar1 + resF * jab1; rr = rr + resF * resF;
+      }
+      // the residual goes OOB if ANY of its pattern pixels fails (the reference breaks out of the loop at the first one)
+      if (!allGood) { Rs.newState[ri] = BA_OOB; myE = oldEnergy; }
+      else {
+        Rs.newEnergyWO[ri] = energyLeft;
+        if (sl >= 0) __hip_atomic_store(Rs.newestE + sl, energyLeft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float th = fmaxf(D.frameTH[hi], D.frameTH[ti]);
+        if (energyLeft > th || wJI2 < 2) { energyLeft = th; Rs.newState[ri] = BA_OUTLIER; }
+        else Rs.newState[ri] = BA_IN;
+        Rs.newEnergy[ri] = energyLeft;
+        myE = energyLeft;
+        // compact record: lane l writes record l's floats 208 bytes apart.  Staging the records through LDS so that a store instruction covers consecutive floats was
+        // measured SLOWER (318 vs 267 us for 64 windows: the staging traffic and its 28 KB of LDS cost more than the scattered stores, which L2 merges)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { rec[REC_JPDC0 + k] = d_C_x[k]; rec[REC_JPDC1 + k] = d_C_y[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { rec[REC_JPDXI0 + k] = d_xi_x[k]; rec[REC_JPDXI1 + k] = d_xi_y[k]; }
+        rec[REC_JIDX2 + 0] = JI00; rec[REC_JIDX2 + 1] = JI10; rec[REC_JIDX2 + 2] = JI11;
+        rec[REC_JABJIDX + 0] = Ja00; rec[REC_JABJIDX + 1] = Ja01; rec[REC_JABJIDX + 2] = Ja10; rec[REC_JABJIDX + 3] = Ja11;
+        rec[REC_JAB2 + 0] = Jb00; rec[REC_JAB2 + 1] = Jb01; rec[REC_JAB2 + 2] = Jb11;
+        rec[REC_JI_R + 0] = JIr0; rec[REC_JI_R + 1] = JIr1; rec[REC_JAB_R + 0] = Jar0; rec[REC_JAB_R + 1] = Jar1; rec[REC_RR] = rr;
+        rec[REC_JPDD + 0] = d_d_x; rec[REC_JPDD + 1] = d_d_y;
+        const float v0 = JI00 * d_d_x + JI10 * d_d_y, v1 = JI10 * d_d_x + JI11 * d_d_y;   // takeDataF (EnergyFunctionalStructs.cpp:39-49)
+#pragma unroll
+        for (int k = 0; k < 6; k++) rec[REC_JPJD + k] = d_xi_x[k] * v0 + d_xi_y[k] * v1;
+        rec[REC_JPJD + 6] = Ja00 * d_d_x + Ja01 * d_d_y;
+        rec[REC_JPJD + 7] = Ja10 * d_d_x + Ja11 * d_d_y;
+        rec[REC_BD] = JIr0 * d_d_x + JIr1 * d_d_y;
+        rec[REC_HDD] = v0 * d_d_x + v1 * d_d_y;
+#pragma unroll
+        for (int k = 0; k < 4; k++) rec[REC_HCD + k] = d_C_x[k] * v0 + d_C_y[k] * v1;
+      }
+    }
+  }
+  // energy partials: one per run of LIN_RES_PER_BLOCK residuals, summed in order (the eight-lane kernel's workgroup partials)
+  __shared__ double s_e1[LIN_THREADS];
+  s_e1[threadIdx.x] = myE;
+  __syncthreads();
+  if ((threadIdx.x & (LIN_RES_PER_BLOCK - 1)) == 0) {
+    const int run = blockIdx.x * (LIN_THREADS / LIN_RES_PER_BLOCK) + threadIdx.x / LIN_RES_PER_BLOCK;
+    if (run < nruns) {
+      double sum = 0;
+      for (int k = 0; k < LIN_RES_PER_BLOCK; k++) sum += s_e1[threadIdx.x + k];
+      __hip_atomic_store(D.epart + run, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // loadSateBackup, point part: the lane of a point's first residual restores it
+  if (use_backup && ri < W.R) {
+    const int pi = Rs.point[ri];
+    if (P.res_begin[pi] == ri) { const float bk = P.idepth_backup[pi]; P.idepth[pi] = bk; P.idepth_zero[pi] = bk; }
+  }
+  if (D.mode < 0) return;
+  __shared__ int s_last1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last1 = __hip_atomic_fetch_add(&D.ctl->cnt_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(nblocks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (threadIdx.x == 0) __hip_atomic_store(&D.ctl->cnt_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (D.mode == 3) baPackBlock(D, nruns);
+  else baDecideBlock(D, nruns, t_kernel0);
+}
 template <int MF>
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
                                                                const FrameStore fs, float* __restrict__ fullJ,

@@ -2018,8 +2018,13 @@ struct dmvio_hip_ba_batch {
   int exact_backsub = 0;
   float last_ms[3] = {0, 0, 0};    // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation, [profile] one stepped linearisation
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipStream_t stream2 = nullptr;   // the second half of a batch of >= 4 windows runs here, staggered behind the first (optimizeBatchGroup)
-  int single_stream = 0;           // dmvio_hip_ba_batch_set_streams(1): everything on one stream (measurement)
+  // a batch of >= 4 windows is cut into up to BA_BATCH_STREAMS groups, one stream each, their launches interleaved stage by stage (optimizeBatchGroup): while one group's
+  // k_ba_solve runs (one workgroup per window) the other groups' linearisations / accumulations fill the device
+  enum { BA_BATCH_STREAMS = 8 };
+  hipStream_t gstream[BA_BATCH_STREAMS] = {};   // [0] = stream
+  hipEvent_t gev[BA_BATCH_STREAMS][2] = {};                                        // per group: [0] its initial linearisation is enqueued (the next group's start), [1] its last kernel
+  int lin_lanes = 1;               // dmvio_hip_ba_batch_set_linearize_lanes: 1 = k_ba_linearize_b1 (one lane per residual) from 4 windows on, 8 = always the eight-lane kernel
+  int streams = 0;                 // dmvio_hip_ba_batch_set_streams: 0 = automatic, k >= 1 = at most k groups (1: the whole batch on one stream)
   int profile = 0;                 // dmvio_hip_ba_batch_set_profile: events around the stepped linearisation of iteration 1 (k_ba_linearize_b of all windows)
 };
 static constexpr int BA_BATCH_NMAX = 4 + 8 * BA_MAXF_CAP;
@@ -2046,7 +2051,9 @@ dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_window
   ok = ok && hipMalloc((void**)&B->d_out, B->out_stride * max_windows) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&B->h_trace, sizeof(double) * (257 + BA_BATCH_NMAX) * max_windows, hipHostMallocDefault) == hipSuccess;
   for (int k = 0; k < 8 && ok; k++) ok = hipEventCreate(&B->ev[k]) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&B->stream2, hipStreamNonBlocking) == hipSuccess;
+  B->gstream[0] = B->stream;
+  for (int g = 1; g < dmvio_hip_ba_batch::BA_BATCH_STREAMS && ok; g++) ok = hipStreamCreateWithFlags(&B->gstream[g], hipStreamNonBlocking) == hipSuccess;
+  for (int g = 0; g < dmvio_hip_ba_batch::BA_BATCH_STREAMS && ok; g++) for (int k = 0; k < 2 && ok; k++) ok = hipEventCreateWithFlags(&B->gev[g][k], hipEventDisableTiming) == hipSuccess;
   if (ok) ok = hipMemset(B->d_out, 0, B->out_stride * max_windows) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
   if (!ok) { failmsg("ba_batch_create: device / pinned allocation failed"); dmvio_hip_ba_batch_destroy(B); return nullptr; }
   if (max_windows >= 8) {
@@ -2066,7 +2073,8 @@ void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* B) {
   if (B->d_out) hipFree(B->d_out);
   if (B->h_trace) hipHostFree(B->h_trace);
   for (int k = 0; k < 8; k++) if (B->ev[k]) hipEventDestroy(B->ev[k]);
-  if (B->stream2) { hipStreamSynchronize(B->stream2); hipStreamDestroy(B->stream2); }
+  for (int g = 1; g < dmvio_hip_ba_batch::BA_BATCH_STREAMS; g++) if (B->gstream[g]) { hipStreamSynchronize(B->gstream[g]); hipStreamDestroy(B->gstream[g]); }
+  for (int g = 0; g < dmvio_hip_ba_batch::BA_BATCH_STREAMS; g++) for (int k = 0; k < 2; k++) if (B->gev[g][k]) hipEventDestroy(B->gev[g][k]);
   delete B;
 }
 // 1: the back substitution of the 68x68 solve in the host's order (one dependent chain of n^2 / 2 subtractions: x bit-identical to BAHost::ldltSolveTransposed, ~10 us more per
@@ -2091,11 +2099,20 @@ int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* B, int ticks12[12]) 
   for (int i = 0; i < 12; i++) ticks12[i] = B->h_wins[0].S.ticks[i];
   return 0;
 }
-// measurement: 1 = the whole batch on one stream (no staggered halves); 0 (default) = two halves on two streams from 4 windows on
-int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* B, int single) {
-  if (!B) return failmsg("ba_batch: null handle");
+// 0 (default): a batch of >= 4 windows is cut into up to four groups on four streams (at least two windows each), their launches interleaved; k >= 1: at most k groups
+// (1 = the whole batch on one stream).  The grouping changes no result: no arithmetic crosses windows.
+int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* B, int streams) {
+  if (!B || streams < 0) return failmsg("ba_batch_set_streams: bad argument");
   std::lock_guard<std::mutex> lk(B->mu);
-  B->single_stream = single ? 1 : 0;
+  B->streams = std::min<int>(streams, dmvio_hip_ba_batch::BA_BATCH_STREAMS);
+  return 0;
+}
+// which linearisation kernel a batch of >= 4 windows runs: 1 (default) = k_ba_linearize_b1, one lane per residual; 8 = k_ba_linearize_b, eight lanes per residual (what a
+// single window runs).  Same values either way.
+int dmvio_hip_ba_batch_set_linearize_lanes(dmvio_hip_ba_batch* B, int lanes) {
+  if (!B || (lanes != 1 && lanes != 8)) return failmsg("ba_batch_set_linearize_lanes: 1 or 8");
+  std::lock_guard<std::mutex> lk(B->mu);
+  B->lin_lanes = lanes;
   return 0;
 }
 // measurement: HIP events around the stepped linearisation of the second iteration (k_ba_linearize_b over all windows of the call) -> dmvio_hip_ba_batch_last_ms()[2]
@@ -2160,7 +2177,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     V.sys = reinterpret_cast<double*>(out);
     V.ctl = b->d_ctl;
     V.n_lin_blocks = b->n_lin_blocks; V.n_pt8_blocks = b->n_pt8_blocks; V.n_acc_blocks = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
-    V.n_res_blocks = (H.R + 255) / 256; V.n_gather_blocks = n_gather; V.n_stitch_blocks = n_stitch;
+    V.n_res_blocks = (H.R + 255) / 256; V.n_gather_blocks = n_gather; V.n_stitch_blocks = n_stitch; V.n_lin1_blocks = (H.R + LIN_THREADS - 1) / LIN_THREADS;
     BASolveDev& S = V.S;
     S.F = F; S.n = n; S.stepped = 0; S.iterations_done = 0; S.n_accepted = 0; S.exact_backsub = B->exact_backsub;
     S.lambda = 1e-5;
@@ -2201,50 +2218,68 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   HIPCHK(hipMemcpyAsync(B->d_tab, B->h_tab, B->tab_stride * (size_t)(Wn - 1) + used_tab, hipMemcpyHostToDevice, s));
   const FrameStore fs = B->ctx->fs;
   const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n, F);
-  // One half of the windows per stream from 4 windows on, the second half started behind the first half's first stepped linearisation: k_ba_solve is one workgroup per
-  // window (a latency chain on a handful of CUs), so while one half solves the other half's linearisation / accumulation fills the device.  The halves share nothing.
-  const int halves = (Wn >= 4 && B->stream2 && !B->single_stream) ? 2 : 1;
-  const int cut = halves == 2 ? (Wn + 1) / 2 : Wn;
+  // Up to four groups of windows, one stream each, from 4 windows on: k_ba_solve is one workgroup per window (a 100 us latency chain on a handful of CUs), so while one
+  // group solves, the other groups' linearisations / accumulations fill the device.  The groups share nothing.  Their launches are enqueued STAGE BY STAGE (initial chain of
+  // every group, iteration 0 of every group, ...): a stream whose commands the host has not submitted yet cannot overlap with anything (measured: with the groups enqueued one
+  // after the other the second one started three iterations late).  Group g starts behind group g-1's initial linearisation, which keeps the groups out of step.  A profiled
+  // call (dmvio_hip_ba_batch_set_profile) runs as ONE group: its timed linearisation then covers all windows of the call, alone on the device.
+  const int maxG = B->streams > 0 ? B->streams : 3;   // measured (tools/ba_batch_streams.py): three groups are best at W = 16 and 64; a fourth stream shares a hardware queue
+                                                        // with another one (GPU_MAX_HW_QUEUES = 4, one of them busy with the handles' own streams) and loses
+  const int G = (Wn >= 4 && !B->profile) ? std::max(1, std::min(maxG, Wn / 2)) : 1;
+  struct Grp { hipStream_t st; int w0, cnt; };
+  Grp grp[dmvio_hip_ba_batch::BA_BATCH_STREAMS];
+  for (int g = 0; g < G; g++) { grp[g].st = B->gstream[g]; grp[g].w0 = (int)(((long long)Wn * g) / G); grp[g].cnt = (int)(((long long)Wn * (g + 1)) / G) - grp[g].w0; }
   HIPCHK(hipEventRecord(B->ev[0], s));
-  if (halves == 2) HIPCHK(hipStreamWaitEvent(B->stream2, B->ev[0], 0));   // the uploads above
-  for (int hf = 0; hf < halves; hf++) {
-    hipStream_t st = hf == 0 ? s : B->stream2;
-    const int w0 = hf == 0 ? 0 : cut, cnt = hf == 0 ? cut : Wn - cut;
-    BAWinDev* dwm = B->d_wins + w0;
-    const BAWinDev* dw = dwm;
-    auto solve = [&](const int it, const int finish) {
-      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF>), dim3(cnt), dim3(BA_SOLVE_THREADS), solveLds, st, dwm, it, finish);
-      else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP>), dim3(cnt), dim3(BA_SOLVE_THREADS), solveLds, st, dwm, it, finish);
-    };
-    auto chain = [&](const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
-      hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, cnt), dim3(256), 0, st, dw, backup, apply, gate);
-      hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, cnt), dim3(256), 0, st, dw, gate);
-      hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, cnt), dim3(64 * F), sizeof(StitchWave) * F, st, dw, gate);
-      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, cnt), dim3(256), 0, st, dw, gate);
-      else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, cnt), dim3(256), 0, st, dw, gate);
-    };
-    if (hf == 1) HIPCHK(hipStreamWaitEvent(st, B->ev[6], 0));   // the stagger
-    // ---- every residual still in the graph active again (FullSystemOptimize.cpp:431-448), initial linearisation, applyRes and the first system (:450-470)
-    hipLaunchKernelGGL(k_ba_reset_oob_b, dim3(gx_res, cnt), dim3(256), 0, st, dw);
-    hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_INITIAL);
-    hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, cnt), dim3(256), 0, st, dw, 0, (int)BA_GATE_ALWAYS);
-    chain(1, 0, BA_GATE_ALWAYS);
-    // ---- the loop (:485-586): nothing in it waits for the host
-    for (int it = 0; it < mnumOptIts; it++) {
-      solve(it, 0);
-      const bool prof = B->profile && hf == 0 && it == std::min(1, mnumOptIts - 1);
-      if (prof) HIPCHK(hipEventRecord(B->ev[4], st));
-      hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_STEPPED);
-      if (prof) HIPCHK(hipEventRecord(B->ev[5], st));
-      if (hf == 0 && it == 0 && halves == 2) HIPCHK(hipEventRecord(B->ev[6], st));
-      hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dw, fs, (int)BA_LINB_RESTORE);
-      if (it < mnumOptIts - 1) chain(1, 1, BA_GATE_ACCEPTED);
-      else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, cnt), dim3(256), 0, st, dw, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
-    }
-    solve(mnumOptIts, 1);   // settle the last decision
-    HIPCHK(hipGetLastError());
-    if (hf == 1) { HIPCHK(hipEventRecord(B->ev[7], st)); HIPCHK(hipStreamWaitEvent(s, B->ev[7], 0)); }
+  for (int g = 1; g < G; g++) HIPCHK(hipStreamWaitEvent(grp[g].st, B->ev[0], 0));   // the uploads above
+  // the eight-lane kernel hides latency (few windows); the one-lane kernel does an eighth of the lane work (a grid that fills the device)
+  const bool lin1 = B->lin_lanes == 1 && Wn >= 4;
+  const int gx_lin1 = (gx_res * 256 + LIN_THREADS - 1) / LIN_THREADS;
+  auto linearize = [&](hipStream_t st, const BAWinDev* dwq, const int cnt, const int kind) {
+    if (lin1) hipLaunchKernelGGL(k_ba_linearize_b1, dim3(gx_lin1, cnt), dim3(LIN_THREADS), 0, st, dwq, fs, kind);
+    else hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dwq, fs, kind);
+  };
+  auto solve = [&](const Grp& q, const int it, const int finish) {
+    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it, finish);
+    else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it, finish);
+  };
+  auto chain = [&](const Grp& q, const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
+    const BAWinDev* dwq = B->d_wins + q.w0;
+    hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq, backup, apply, gate);
+    hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, q.cnt), dim3(256), 0, q.st, dwq, gate);
+    hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, q.cnt), dim3(64 * F), sizeof(StitchWave) * F, q.st, dwq, gate);
+    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate);
+    else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate);
+  };
+  // ---- every residual still in the graph active again (FullSystemOptimize.cpp:431-448), initial linearisation, applyRes and the first system (:450-470)
+  for (int g = 0; g < G; g++) {
+    const Grp& q = grp[g];
+    const BAWinDev* dwq = B->d_wins + q.w0;
+    if (g > 0) HIPCHK(hipStreamWaitEvent(q.st, B->gev[g - 1][0], 0));   // the stagger
+    hipLaunchKernelGGL(k_ba_reset_oob_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq);
+    linearize(q.st, dwq, q.cnt, BA_LINB_INITIAL);
+    if (g + 1 < G) HIPCHK(hipEventRecord(B->gev[g][0], q.st));
+    hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, 0, (int)BA_GATE_ALWAYS);
+    chain(q, 1, 0, BA_GATE_ALWAYS);
   }
+  // ---- the loop (:485-586): nothing in it waits for the host
+  for (int it = 0; it < mnumOptIts; it++)
+    for (int g = 0; g < G; g++) {
+      const Grp& q = grp[g];
+      const BAWinDev* dwq = B->d_wins + q.w0;
+      solve(q, it, 0);
+      const bool prof = B->profile && g == 0 && it == std::min(1, mnumOptIts - 1);
+      if (prof) HIPCHK(hipEventRecord(B->ev[4], q.st));
+      linearize(q.st, dwq, q.cnt, BA_LINB_STEPPED);
+      if (prof) HIPCHK(hipEventRecord(B->ev[5], q.st));
+      linearize(q.st, dwq, q.cnt, BA_LINB_RESTORE);
+      if (it < mnumOptIts - 1) chain(q, 1, 1, BA_GATE_ACCEPTED);
+      else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
+    }
+  for (int g = 0; g < G; g++) {
+    solve(grp[g], mnumOptIts, 1);   // settle the last decision
+    if (g > 0) { HIPCHK(hipEventRecord(B->gev[g][1], grp[g].st)); HIPCHK(hipStreamWaitEvent(s, B->gev[g][1], 0)); }
+  }
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(B->ev[1], s));
   const BAWinDev* dw = B->d_wins;
   HIPCHK(hipMemcpyAsync(B->h_wins, B->d_wins, sizeof(BAWinDev) * Wn, hipMemcpyDeviceToHost, s));
@@ -2292,7 +2327,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpy2DAsync(B->d_tab + tab_pre_off, B->tab_stride, B->h_tab + tab_pre_off, B->tab_stride, sizeof(BAPrecalc) * F2, Wn, hipMemcpyHostToDevice, s));   // the re-anchored pair tables
   HIPCHK(hipEventRecord(B->ev[2], s));
-  hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, Wn), dim3(LIN_THREADS), 0, s, dw, fs, (int)BA_LINB_FINAL);
+  linearize(s, dw, Wn, BA_LINB_FINAL);
   hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 1, (int)BA_GATE_ALWAYS);   // applyRes + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(B->ev[3], s));

@@ -532,12 +532,18 @@ void dmvio_hip_ba_batch_destroy(dmvio_hip_ba_batch* batch);
 int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* batch, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace);
 int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* batch, int on);
 /* HIP-event times of the last dmvio_hip_ba_optimize_batch call on the batch's stream (ms): [0] initial chain + all iterations, [1] the final fix-linearisation,
- * [2] with dmvio_hip_ba_batch_set_profile(1): the stepped linearisation of the second iteration (k_ba_linearize_b over all windows of the call) */
+ * [2] with dmvio_hip_ba_batch_set_profile(1): the stepped linearisation of the second iteration (k_ba_linearize_b over ALL windows of the call: a profiled call runs as one
+ * group on one stream) */
 int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* batch, float ms3[3]);
 int dmvio_hip_ba_batch_set_profile(dmvio_hip_ba_batch* batch, int on);
-/* measurement: 1 = the whole batch on one stream; 0 (default) = from 4 windows on two halves on two streams, the second started behind the first half's first stepped
- * linearisation, so that one half's k_ba_solve (one workgroup per window) runs beside the other half's linearisation / accumulation.  Results do not depend on it. */
-int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* batch, int single);
+/* 0 (default): from 4 windows on the batch is cut into up to four groups of at least two windows, one HIP stream each, their launches enqueued stage by stage, group g
+ * started behind group g-1's initial linearisation — so that one group's k_ba_solve (one workgroup per window) runs beside the other groups' linearisations / accumulations;
+ * k >= 1: at most k groups (1 = the whole batch on one stream).  A profiled call (dmvio_hip_ba_batch_set_profile) always runs as one group.  Results do not depend on it. */
+int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* batch, int streams);
+/* the linearisation kernel of a batch of >= 4 windows: 1 (default) = one lane per residual (k_ba_linearize_b1: the lane walks the eight pattern pixels; no redundant
+ * geometry — what a grid that fills the device wants), 8 = eight lanes per residual (k_ba_linearize_b: the single window's latency-hiding form).  Same values, same energy
+ * partials, same decisions either way. */
+int dmvio_hip_ba_batch_set_linearize_lanes(dmvio_hip_ba_batch* batch, int lanes);
 /* diagnostics: in-kernel timeline (100 MHz ticks since kernel start) of the first window's k_ba_solve of the LAST iteration of the last call, 12 phase boundaries */
 int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* batch, int ticks12[12]);
 /* dmvio_hip_ba_optimize of this handle through the device-resident loop (a batch of one); 0 (default) = the host-driven loop */

@@ -130,3 +130,48 @@ def test_batched_windows_equal_single_window_calls_bitwise(pkg, synth, gpu_requi
     for o in single + batch + [B1, B5]:
         o.close()
     ctx.close()
+
+
+def test_groups_streams_and_the_one_lane_linearisation_change_no_bit(pkg, synth, gpu_required):
+    """Eight windows of one keyframe count (so that they form ONE group of the call: from 4 windows on the library cuts it into up to three stream groups with interleaved
+    launches and linearises with k_ba_linearize_b1, one lane per residual) — three different graphs, one window entering converged (rejected steps: the gated restore
+    path of the one-lane kernel): every configuration of streams x linearisation kernel gives each window the bits of its single-window call (eight-lane kernel, one stream)."""
+    cases = [synth.ba_case(320, 256, n_frames=6, n_points=500, hosts_share=(120, 110, 100, 90, 80, 0), seed=11),
+             synth.ba_case(320, 256, n_frames=6, n_points=300, hosts_share=(80, 70, 60, 50, 40, 0), seed=12),
+             synth.ba_case(320, 256, n_frames=6, n_points=400, hosts_share=(100, 90, 80, 70, 60, 0), seed=13)]
+    which = [0, 1, 2, 0, 1, 2, 2, 1]
+    converged = 3
+    ctx = pkg.Context(320, 256, n_slots=18)
+    slots = []
+    for c, cs in enumerate(cases):
+        sl = list(range(6 * c, 6 * c + 6))
+        for k, s in enumerate(sl):
+            ctx.frame_upload(s, cs["imgs"][k])
+        slots.append(sl)
+
+    def fresh(w):
+        ba = pkg.BundleAdjusterHip(ctx); ba.set_case(cases[which[w]], slots[which[w]])
+        if w == converged:
+            ba.set_device_loop(True); ba.optimize(12)
+        return ba
+
+    def state(ba):
+        return _poses(ba, 6), ba.point_state()[0]
+    B1 = pkg.BundleAdjusterBatch(ctx, 1); B8 = pkg.BundleAdjusterBatch(ctx, 8)
+    ref = []
+    for w in range(8):
+        b = fresh(w); r = B1.optimize([b], 6)[0]; ref.append((r, state(b))); b.close()
+    assert sum(int((r["trace"][1:, 3] == 0).sum()) for r, _ in ref) >= 1, "no rejected step: the gated restore path was not exercised"
+    for lanes, streams in ((8, 1), (1, 1), (1, 0), (1, 2), (8, 3), (1, 4)):
+        B8.set_linearize_lanes(lanes); B8.set_streams(streams)
+        hs = [fresh(w) for w in range(8)]
+        rb = B8.optimize(hs, 6)
+        for w in range(8):
+            r0, (p0, d0) = ref[w]
+            assert np.array_equal(r0["trace"], rb[w]["trace"]), (lanes, streams, w)
+            assert r0["finalEnergy"] == rb[w]["finalEnergy"] and r0["rmse"] == rb[w]["rmse"], (lanes, streams, w)
+            p1, d1 = state(hs[w])
+            assert np.array_equal(p0, p1) and np.array_equal(d0, d1), (lanes, streams, w)
+        for h in hs:
+            h.close()
+    B1.close(); B8.close(); ctx.close()
