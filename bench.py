@@ -993,12 +993,16 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
     slots = list(range(F))
     rows = []
     pool = []
+    pool_default = []
     Wmax = 64
     B = pkg.BundleAdjusterBatch(ctx, Wmax)
+    default_order = None
     try:
         for W in (1, 4, 16, 64):
             while len(pool) < W:
-                pool.append(pkg.BundleAdjusterHip(ctx))
+                # the reference's single-threaded accumulation order (dmvio_hip_ba_set_accumulators(1)): bit-exact AND, in a grid that fills the device, the cheaper one — a
+                # quarter of the workgroups, each four times as long, less per-workgroup overhead (the latency argument for 4 partial accumulators only holds for one window)
+                pool.append(pkg.BundleAdjusterHip(ctx, accumulators=1))
             walls, loops, lins = [], [], []
             n_acc = 0
             for rep in range(6):
@@ -1018,13 +1022,24 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
                              us_per_iteration_per_window=round(1e6 * wall / max(n_acc, 1) * W, 2), us_per_accepted_iteration=round(1e6 * wall / max(n_acc, 1), 3),
                              k_ba_linearize_b_us=round(lin_us, 2), k_ba_linearize_b_GBs=round(W * bytes_lin / (lin_us * 1e-6) / 1e9, 1),
                              k_ba_linearize_b_frac=round(W * bytes_lin / (lin_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)))
+        # the library's default accumulation order (4 partial accumulators per bucket) at the largest batch, for comparison
+        W = Wmax
+        while len(pool_default) < W:
+            pool_default.append(pkg.BundleAdjusterHip(ctx))
+        walls = []
+        for rep in range(4):
+            for h in pool_default:
+                h.set_case(case, slots)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter(); rs = B.optimize(pool_default, 6); walls.append(time.perf_counter() - t0)
+        default_order = dict(windows=W, value=round(sum(int(r["trace"][1:, 3].sum()) for r in rs) / float(np.median(walls[1:])), 1))
     finally:
-        for h in pool:
+        for h in pool + pool_default:
             h.close()
         B.close()
     best = max(rows, key=lambda r: r["value"])
     ach = bytes_iter * best["value"] / 1e9
-    return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows,
+    return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows, accumulators_per_bucket=1, default_accumulation_order=default_order,
                 single_window=dict(optimize6_ms=rows[0]["wall_ms"], us_per_accepted_iteration=rows[0]["us_per_accepted_iteration"],
                                    what="dmvio_hip_ba_optimize_batch of ONE window = dmvio_hip_ba_optimize with dmvio_hip_ba_set_device_loop(1): the whole loop enqueued up front, two host waits per call"),
                 roofline=dict(bound="hbm", kernel="k_ba_linearize_b1" if best["windows"] >= 4 else "k_ba_linearize_b", achieved=best["k_ba_linearize_b_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=best["k_ba_linearize_b_frac"],
@@ -1033,8 +1048,9 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
                               what="the stepped linearisation of ALL windows of a call (one launch, HIP events on the batch's stream; the profiled repetitions run as one group on one "
                                    "stream, alone on the device; from 4 windows on the one-lane-per-residual kernel k_ba_linearize_b1): 464 B per residual x residuals of all windows / "
                                    "its duration; `iteration`: all algorithmic bytes of an accepted iteration x accepted iterations per second"),
-                what="W fresh windows (own handles, set up before the timed region), ONE dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its "
-                     "wall time; device_ms = the same call by HIP events (loop + final fix-linearisation)")
+                what="W fresh windows (own handles with dmvio_hip_ba_set_accumulators(1): the reference's single-threaded accumulation order; set up before the timed region), ONE "
+                     "dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its wall time; device_ms = the same call by HIP events (loop + final "
+                     "fix-linearisation); default_accumulation_order: the same at the largest batch with the library's default of 4 partial accumulators per bucket")
 
 
 def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):

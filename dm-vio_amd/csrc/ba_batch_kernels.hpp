@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
       // row 0 of the trace: the initial state (its photometric energy is what the initial linearisation's decision pass left in the control block)
       S.trace[0] = __hip_atomic_load(&V.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); S.trace[1] = S.lastL; S.trace[2] = S.lastM; S.trace[3] = 1.0;
     }
-    s_flag[0] = acc; s_flag[1] = 0; s_flag[2] = 0;
+    s_flag[0] = acc; s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0;
     s_scal[4] = S.lambda; s_scal[5] = S.lastL; s_scal[6] = S.lastM;
   }
   __syncthreads();
@@ -338,11 +338,18 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     }
     for (; j < n; j++) { const double o = fabs(dg[j]); rank += o > mine ? 1 : 0; same += o == mine ? 1 : 0; }
     if (!(mine == mine)) s_flag[2] = 1;   // NaN on the diagonal: the step-by-step replay below
+    if (same > 1) s_flag[3] = 1;          // a tie: the selection order inside the group depends on the swaps before it
     perm[tid] = (rank << 8) | same;       // group id, group size
   }
   __syncthreads();
-  const int needReplay = s_flag[2];
-  if (tid < 64) {
+  const int needReplay = s_flag[2], haveTies = s_flag[3];
+  if (!needReplay && !haveTies) {
+    // all |diagonal| values distinct: step k selects the k-th largest whatever the swaps did to the others — the order is the rank itself
+    int rk = -1;
+    if (tid < n) rk = perm[tid] >> 8;
+    __syncthreads();
+    if (tid < n) perm[rk] = tid;
+  } else if (tid < 64) {
     if (!needReplay) {
       int g0 = tid < n ? perm[tid] : 0x7fffff00, g1 = tid + 64 < n ? perm[tid + 64] : 0x7fffff00;   // (group << 8) | size of the element at position lane / lane + 64
       int p0 = tid, p1 = tid + 64;                                                                    // its original index

@@ -12,7 +12,8 @@ for k in range(F):
     ctx.frame_upload(k, case["imgs"][k])
 Ws = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '16,64'.split(','))]
 B = pkg.BundleAdjusterBatch(ctx, max(Ws))
-pool = [pkg.BundleAdjusterHip(ctx) for _ in range(max(Ws))]
+ACC = int(os.environ.get('BA_ACC', '0')) or None
+pool = [pkg.BundleAdjusterHip(ctx, accumulators=ACC) for _ in range(max(Ws))]
 fn = B.L.dmvio_hip_ba_batch_set_streams; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
 for single in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,2,3,4'.split(','))]:
     fn(B.p, single)

@@ -37,6 +37,9 @@ if bw and "error" not in bw:
             "| W | accepted it/s (wall) | wall ms per optimize(6) of the batch | device ms | stepped linearisation us | k_ba_linearize_b: TB/s algorithmic | of 8 TB/s |", "|---|---|---|---|---|---|---|"]
     for r in bw["sweep"]:
         rows.append("| %d | %.0f | %.3f | %.3f | %.1f | %.3f | %.4f |" % (r["windows"], r["value"], r["wall_ms"], r["device_ms"], r["k_ba_linearize_b_us"], r["k_ba_linearize_b_GBs"] / 1e3, r["k_ba_linearize_b_frac"]))
+    if bw.get("default_accumulation_order"):
+        rows += ["", "With the library's default of 4 partial accumulators per bucket (the handles of the sweep use dmvio_hip_ba_set_accumulators(1)): %.0f accepted it/s at W = %d." % (bw["default_accumulation_order"]["value"], bw["default_accumulation_order"]["windows"])]
+    rows += ["", "Roofline kernel `%s`: %.1f us for the stepped linearisation of all %d windows = %.1f GB/s algorithmic = %.4f of 8 TB/s." % (bw["roofline"]["kernel"], bw["roofline"]["kernel_us"], bw["at_windows"], bw["roofline"]["achieved"], bw["roofline"]["frac"])]
     rows += ["", "Single window, host-driven loop (the default of dmvio_hip_ba_optimize): %.3f ms per optimize(6) = %.0f accepted it/s." % (ba["optimize6_ms"], ba["value"])]
     open(P + "/r05_ba_batched_windows.md", "w").write("\n".join(rows) + "\n")
 di = d.get("drop_in")
