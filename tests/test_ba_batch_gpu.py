@@ -175,3 +175,55 @@ def test_groups_streams_and_the_one_lane_linearisation_change_no_bit(pkg, synth,
         for h in hs:
             h.close()
     B1.close(); B8.close(); ctx.close()
+
+
+def test_device_loop_with_a_marginalisation_prior_and_fej_deltas(pkg, synth, gpu_required):
+    """The terms a fresh window leaves at zero: a marginalisation prior (H_M / b_M: bM_top = b_M + H_M delta in every solve, E_M = delta . (2 b_M + H_M delta) in every accept
+    test, EnergyFunctional.cpp:322-345, 864-907) with keyframe states off their linearisation points (state != state_zero: non-zero delta from the first iteration on).  The
+    device-resident loop (k_ba_solve) against the host-driven loop of the same library — same kernels for the photometric part —: same accept sequence, E_M trace within 1e-9
+    relative, states within 1e-8; a batch of four such windows equals its single-window calls bit for bit."""
+    case = synth.ba_case(320, 256, n_frames=6, n_points=500, hosts_share=(120, 110, 100, 90, 80, 0), seed=11)
+    F = 6
+    n = 4 + 8 * F
+    ctx = _ctx_with(pkg, case)
+    rng = np.random.RandomState(7)
+    A = rng.standard_normal((n, n)) * 30.0
+    HM = A @ A.T; bM = rng.standard_normal(n) * 10.0
+    deltas = []
+    for k in range(F):
+        st = np.zeros(10)
+        if k > 0:
+            st[:3] = 1e-3 * rng.standard_normal(3); st[3:6] = 5e-4 * rng.standard_normal(3); st[6] = 1e-3 * rng.standard_normal(); st[7] = 1e-4 * rng.standard_normal()
+        deltas.append(st)
+
+    def window():
+        ba = pkg.BundleAdjusterHip(ctx, accumulators=1); ba.set_case(case, list(range(F)))
+        ba.set_marg_prior(HM, bM)
+        for k in range(F):
+            ba.set_frame_state(k, deltas[k])
+        return ba
+    host = window(); rh = host.optimize(6)
+    dev = window(); dev.set_device_loop(True); rd = dev.optimize(6)
+    assert rd["iterations"] == rh["iterations"] and np.array_equal(rd["trace"][:, 3], rh["trace"][:, 3])
+    assert np.abs(rh["trace"][:, 2]).min() > 0.1 and np.abs(rh["trace"][:, 2]).max() > 10.0, "E_M is not exercised"
+    dE = np.abs(rd["trace"][:, :3] - rh["trace"][:, :3]) / np.maximum(np.abs(rh["trace"][:, :3]), 1e-30)
+    dp = np.abs(_poses(dev, F) - _poses(host, F)).max()
+    dx = np.abs(dev.last_x() - host.last_x()).max() / np.abs(host.last_x()).max()
+    print("prior + FEJ deltas, device vs host loop: E_A / E_L / E_M within %.2e / %.2e / %.2e relative, last x within %.2e, states within %.2e; %d of %d steps accepted"
+          % (dE[:, 0].max(), dE[:, 1].max(), dE[:, 2].max(), dx, dp, int(rh["trace"][1:, 3].sum()), rh["iterations"]))
+    assert dE.max() < 1e-7 and dx < 1e-6 and dp < 1e-8
+    assert abs(rd["finalEnergy"] - rh["finalEnergy"]) <= 1e-7 * rh["finalEnergy"]
+    # four such windows (different priors) in one call == four single calls, bit for bit
+    B1 = pkg.BundleAdjusterBatch(ctx, 1); B4 = pkg.BundleAdjusterBatch(ctx, 4)
+
+    def scaled(f):
+        ba = window(); ba.set_marg_prior(f * HM, f * bM); return ba
+    fs = (1.0, 0.5, 2.0, 0.1)
+    single = [scaled(f) for f in fs]; rs = [B1.optimize([b], 6)[0] for b in single]
+    batch = [scaled(f) for f in fs]; rb = B4.optimize(batch, 6)
+    for i in range(4):
+        assert np.array_equal(rs[i]["trace"], rb[i]["trace"]) and rs[i]["finalEnergy"] == rb[i]["finalEnergy"], i
+        assert np.array_equal(_poses(single[i], F), _poses(batch[i], F)) and np.array_equal(single[i].point_state()[0], batch[i].point_state()[0]), i
+    for o in [host, dev, B1, B4] + single + batch:
+        o.close()
+    ctx.close()
