@@ -332,6 +332,14 @@ def test_window_size_is_a_runtime_setting(pkg, oracle, synth, gpu_required, F):
     ba4 = pkg.BundleAdjusterHip(ctx); ba4.set_case(case, list(range(F)))
     r4 = ba4.optimize(6)
     assert np.array_equal(r4["trace"][:, 3], ro["trace"][:, 3]) and abs(r4["finalEnergy"] - ro["finalEnergy"]) <= 1e-4 * ro["finalEnergy"]
+    # and the device-resident loop (k_ba_solve<8> up to 8 keyframes, <12> beyond: a 44 ... 100-dimensional solve on one workgroup) against the host-driven one
+    bad = pkg.BundleAdjusterHip(ctx, accumulators=1); bad.set_case(case, list(range(F))); bad.set_device_loop(True)
+    rd = bad.optimize(6)
+    assert np.array_equal(rd["trace"][:, 3], rg["trace"][:, 3]) and np.allclose(rd["trace"][:, :3], rg["trace"][:, :3], rtol=1e-7, atol=1e-9)
+    assert abs(rd["finalEnergy"] - rg["finalEnergy"]) <= 1e-7 * rg["finalEnergy"]
+    for k in range(F):
+        assert np.abs(np.concatenate(bad.frame_pose(k)[:2]) - np.concatenate(ba.frame_pose(k)[:2])).max() < 1e-8
+    bad.close()
     if F == 12:
         L = pkg.load_library()
         assert L.dmvio_hip_ba_max_frames() == 12
