@@ -687,37 +687,72 @@ __device__ __forceinline__ double readLaneD(const double v, const int src) {
   const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)b, src), hi = __builtin_amdgcn_readlane((unsigned int)(b >> 32), src);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// Wave-cooperative LDL^T with symmetric diagonal pivoting (largest |d| first — the pivot rule of the
-// decomposition CoarseTracker.cpp:639 calls).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).
-// Returns x(r) in every lane of row r.
+// Wave-cooperative LDL^T with symmetric diagonal pivoting, the decomposition CoarseTracker.cpp:639 calls (Eigen's ldlt_inplace<Lower>::unblocked as oracle/dense.h and the
+// host path's ldltSolveInPlace restate it).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).  Returns x(r) in every lane of row r.
+//
+// Round 5: that algorithm is LEFT-looking — step k updates column k only, so its pivot search over the trailing diagonal always sees ORIGINAL diagonal entries: the whole
+// pivot order follows from the diagonal of A (descending |a_ii|).  The order is therefore computed ONCE (two ballots), the system permuted once, and the factorisation runs
+// unpivoted: no per-step search (it was a third of the ~1100 dependent instructions of the right-looking form this replaces, which also pivoted on the UPDATED diagonal — not
+// the reference's rule), no per-step row / column swaps, no replay of the transpositions at the end.  The column updates are formed as the reference forms them
+// (temp_j = D_j L_kj; a_rk -= sum_j L_rj temp_j, the sum added up in j order first).  Ties on the diagonal (two fixed affine parameters: identity rows) are broken by index
+// — among uncoupled identity rows the order is immaterial; the back substitution stays column-oriented (each new x_k is consumed by all rows at once).
+// value of lane (l - k), k = 1..7, for a double: DPP row_shr on both halves (0.0 where the 16-lane DPP row ends)
+__device__ __forceinline__ double dppShrD(const double v, const int k) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  int lo = (int)(unsigned int)b, hi = (int)(unsigned int)(b >> 32), rl = 0, rh = 0;
+  switch (k) {
+    case 1: rl = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true); break;
+    case 2: rl = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true); break;
+    case 3: rl = __builtin_amdgcn_update_dpp(0, lo, 0x113, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x113, 0xF, 0xF, true); break;
+    case 4: rl = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true); break;
+    case 5: rl = __builtin_amdgcn_update_dpp(0, lo, 0x115, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x115, 0xF, 0xF, true); break;
+    case 6: rl = __builtin_amdgcn_update_dpp(0, lo, 0x116, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x116, 0xF, 0xF, true); break;
+    default: rl = __builtin_amdgcn_update_dpp(0, lo, 0x117, 0xF, 0xF, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x117, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned int)rh << 32) | (unsigned int)rl);
+}
 __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lane, int* s_trk) {
   // loops are deliberately NOT unrolled: this runs once per LM iteration on one wave, while its register footprint is
   // charged to every wave of the kernel (the evaluation loop wants the occupancy).
+  (void)s_trk;
   const int r = lane >> 3, c = lane & 7;
+  // ---- pivot order: position of element i = number of elements with a larger |a_ii| (ties: lower index first)
+  int pos_r;      // where original row r goes
+  {
+    const double ar = fabs(__shfl(m, r * 9, 64)), ac = fabs(__shfl(m, c * 9, 64));
+    const bool before = (ac > ar) || (ac == ar && c < r);   // element c is picked before element r
+    const unsigned long long mb = __ballot(before);
+    pos_r = __popc((unsigned int)(mb >> (8 * r)) & 0xFFu);
+    const int pos_c = __popc((unsigned int)(mb >> (8 * c)) & 0xFFu);
+    const unsigned long long mp = __ballot(pos_c == r);      // bit (r, c): element c stands at position r
+    const unsigned int br = (unsigned int)(mp >> (8 * r)) & 0xFFu, bc = (unsigned int)(mp >> (8 * c)) & 0xFFu;
+    const int el_r = br ? __builtin_ctz(br) : r, el_c = bc ? __builtin_ctz(bc) : c;   // (a NaN diagonal leaves positions unfilled: identity there, the result is NaN anyway)
+    m = __shfl(m, el_r * 8 + el_c, 64);
+    dv = __shfl(dv, el_r * 8 + c, 64);
+  }
+  // ---- unpivoted left-looking LDL^T of the permuted matrix (lower triangle); zero matrix: x = 0 (Eigen: the decomposition stops, solve() returns zeros)
+  const double a00 = readLaneD(m, 0);
+  if (!(fabs(a00) > 0)) return 0.0;
+  double Dc = a00;                                 // D_j of my column j = c, once it is final (j < k)
+  {
+    const double l = m / a00;
+    if (c == 0 && r > 0) m = l;
+  }
 #pragma unroll 1
-  for (int k = 0; k < 8; k++) {
-    int p = k;
-    double best = fabs(readLaneD(m, k * 9));
-#pragma unroll 1
-    for (int i = k + 1; i < 8; i++) {
-      const double v = fabs(readLaneD(m, i * 9));
-      if (v > best) { best = v; p = i; }
-    }
-    if (lane == 0) s_trk[k] = p;
-    if (p != k) {   // wave-uniform: the symmetric row / column swap is only needed when the pivot is not already in place
-      const int pr = (r == k) ? p : ((r == p) ? k : r);
-      const int pc = (c == k) ? p : ((c == p) ? k : c);
-      m = __shfl(m, pr * 8 + pc, 64);
-      dv = __shfl(dv, pr * 8 + c, 64);
-    }
-    const double dk = readLaneD(m, k * 9);
-    const bool ok = fabs(dk) > 0;
-    const double mrk = __shfl(m, r * 8 + k, 64);
-    const double mck = __shfl(m, c * 8 + k, 64);
-    const double Lrk = ok ? mrk / dk : mrk;
-    const double Lck = ok ? mck / dk : mck;
-    if (r > k && c > k) m = m - Lrk * (dk * Lck);
-    if (c == k && r > k) m = Lrk;
+  for (int k = 1; k < 8; k++) {
+    const double mk = __shfl(m, k * 8 + c, 64);    // L(k, j)
+    const double temp = Dc * mk;                   // temp_j = D_j L(k, j)
+    const double prod = c < k ? m * temp : 0.0;    // L(r, j) temp_j
+    // sum_j prod(r, j) in j order, formed IN lane (r, k): the terms sit k, k-1, ..., 1 lanes to its left, so the shifts 7 ... 1 deliver j = k-7 ... k-1 — ascending j; a shift
+    // that leaves the row lands on a lane with c >= k (its product is +0.0) or outside the 16-lane DPP row (0.0)
+    double s = 0.0;
+#pragma unroll
+    for (int q = 7; q >= 1; q--) s = s + dppShrD(prod, q);
+    if (c == k && r >= k) m = m - s;
+    const double akk = readLaneD(m, k * 9);
+    const bool ok = fabs(akk) > 0;
+    const double l = ok ? m / akk : m;
+    if (c == k) { if (r > k) m = l; Dc = akk; }
   }
   // row r and column r of L are gathered ONCE (16 independent cross-lane reads, pipelined); the substitutions then only need
   // wave-uniform reads of the running solution — no dependent shuffle per step
@@ -740,17 +775,8 @@ __device__ __noinline__ double waveLdltSolve8(double m, double dv, const int lan
     const double dkv = readLaneD(dv, k * 8);
     if (r < k) dv = dv - Lcol[k] * dkv;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-  for (int k = 7; k >= 0; k--) {
-    const int p = __builtin_amdgcn_readfirstlane(s_trk[k]);
-    if (p == k) continue;   // wave-uniform
-    const int pr = (r == k) ? p : ((r == p) ? k : r);
-    dv = __shfl(dv, pr * 8 + c, 64);
-  }
-  return dv;
+  // x = P^T (...): original row r sits at position pos_r
+  return __shfl(dv, pos_r * 8 + c, 64);
 }
 
 // One LM control step, executed by all 64 lanes of wave 0.  Consumes the finished evaluation in s_tot, decides,
