@@ -74,7 +74,14 @@ DMV_HD Quatd qmul(const Quatd& a, const Quatd& b) {
 }
 DMV_HD Quatd qnormalize(const Quatd& a) {
   const double n = sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
-  Quatd r = {a.w / n, a.x / n, a.y / n, a.z / n};
+#if !defined(__HIP_DEVICE_COMPILE__)
+  Quatd r = {a.w / n, a.x / n, a.y / n, a.z / n};   // Eigen's normalize(): one division per coefficient — the host side equals the reference bit for bit
+#else
+  // device (the serial tail of the LM control step, k_ba_solve's frame step): one reciprocal, four products — three IEEE fp64 divisions (~30 dependent instructions each)
+  // less per normalisation; differs from the host's quotient by at most an ulp of a coefficient, like the device's sin / cos / exp already do
+  const double inv = 1.0 / n;
+  Quatd r = {a.w * inv, a.x * inv, a.y * inv, a.z * inv};
+#endif
   return r;
 }
 DMV_HD void quatToR(const Quatd& q, double R[9]) {
