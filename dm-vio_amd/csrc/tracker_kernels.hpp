@@ -687,7 +687,7 @@ __device__ __forceinline__ double readLaneD(const double v, const int src) {
   const unsigned int lo = __builtin_amdgcn_readlane((unsigned int)b, src), hi = __builtin_amdgcn_readlane((unsigned int)(b >> 32), src);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// Wave-cooperative LDL^T with symmetric diagonal pivoting, the decomposition CoarseTracker.cpp:639 calls (Eigen's ldlt_inplace<Lower>::unblocked as oracle/dense.h and the
+// Wave-cooperative LDL^T with symmetric diagonal pivoting, the decomposition CoarseTracker.cpp:639 calls (Eigen's ldlt_inplace<Lower>::unblocked as the
 // host path's ldltSolveInPlace restate it).  lane = r*8+c holds m = A(r,c); dv = rhs(r) (replicated over c).  Returns x(r) in every lane of row r.
 //
 // Round 5: that algorithm is LEFT-looking — step k updates column k only, so its pivot search over the trailing diagonal always sees ORIGINAL diagonal entries: the whole
