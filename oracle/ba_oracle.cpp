@@ -993,12 +993,12 @@ struct OWindow {
     topStitch(accs, H, b, false);
     resInA = 0; for (const PaddedDouble& v : nres) resInA += (int)v.v;
   }
-  void accumulateLF(Mat& H, Mat& b) {
+  void accumulateLF(Mat& H, Mat& b, bool usePrior = true) {
     std::vector<std::vector<AccApprox>> accs(1, std::vector<AccApprox>((size_t)nF * nF));
     for (auto& x : accs[0]) x.initialize();
     int nres = 0;
     for (auto& p : points) topAddPoint(1, p, accs[0], nres);
-    topStitch(accs, H, b, true);
+    topStitch(accs, H, b, usePrior);
     resInL = nres;
   }
   void accumulateSCF(Mat& H, Mat& b) {
@@ -1482,6 +1482,15 @@ void orc_ba_accumulate(void* p, double* HA, double* bA, double* HL, double* bL, 
   memcpy(HA, a.data(), n * n * 8); memcpy(bA, b.data(), n * 8); memcpy(HL, c.data(), n * n * 8); memcpy(bL, d.data(), n * 8);
   memcpy(Hsc, e.data(), n * n * 8); memcpy(bsc, f.data(), n * 8);
   if (resInA) *resInA = W->resInA;
+}
+// the stitched system of the linearised residuals WITHOUT the priors stitchDoubleInternal adds last (AccumulatedTopHessian.cpp:292-302): what the library's host side keeps as
+// HLraw / bLraw and adds the priors to in the reference's order (tests/test_host_algebra_cpu.py)
+void orc_ba_accumulate_lf_raw(void* p, double* HL, double* bL) {
+  OWindow* W = (OWindow*)p;
+  Mat c, d;
+  W->accumulateLF(c, d, false);
+  const size_t n = CPARS + W->nF * 8;
+  memcpy(HL, c.data(), n * n * 8); memcpy(bL, d.data(), n * 8);
 }
 void orc_ba_get_point_acc(void* p, float* Hdd, float* bd, float* Hcd4, float* HdiF, float* bdSumF) {
   OWindow* W = (OWindow*)p;

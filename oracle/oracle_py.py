@@ -493,6 +493,13 @@ class BAWindow:
         self.L.orc_ba_fix_linearization.argtypes = [C.c_void_p, C.c_char_p]; self.L.orc_ba_fix_linearization.restype = C.c_int
         return self.L.orc_ba_fix_linearization(self.p, m.tobytes())
 
+    def accumulate_lf_raw(self):
+        """[H_L, b_L] of the linearised residuals without the priors (the state the last accumulate() / solve() saw)"""
+        HL = np.zeros((self.n, self.n)); bL = np.zeros(self.n)
+        self.L.orc_ba_accumulate_lf_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; self.L.orc_ba_accumulate_lf_raw.restype = None
+        self.L.orc_ba_accumulate_lf_raw(self.p, HL.ctypes.data, bL.ctypes.data)
+        return HL, bL
+
     def set_marg_prior(self, HM, bM):
         self.L.orc_ba_set_marg_prior(self.p, _d(np.ascontiguousarray(HM, dtype=np.float64)), _d(np.ascontiguousarray(bM, dtype=np.float64)))
 

@@ -68,6 +68,12 @@ void bah_set_marg_prior(void* p, const double* HM, const double* bM) {
   const int n = H->n();
   H->HM.assign(HM, HM + (size_t)n * n); H->bM.assign(bM, bM + n);
 }
+// the stitched system of the residuals kept linearised (accumulateLF_MT without the priors): what dmvio_hip_ba_fix_linearization's accumulation leaves in BAHost
+void bah_set_lf_raw(void* p, const double* HL, const double* bL) {
+  BAHost* H = (BAHost*)p;
+  const int n = H->n();
+  if (HL) { H->HLraw.assign(HL, HL + (size_t)n * n); H->bLraw.assign(bL, bL + n); } else { H->HLraw.clear(); H->bLraw.clear(); }
+}
 void bah_solve_system(void* p, int iteration, double lambda, const double* HA, const double* bA, const double* Hsc, const double* bsc, double* x) {
   BAHost* H = (BAHost*)p;
   std::vector<double> xv;

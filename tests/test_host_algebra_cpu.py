@@ -136,6 +136,20 @@ def test_ba_host_algebra_equals_the_oracle_bitwise(tmp_path, oracle, synth):
                 assert same(x, xo), (with_prior, it, np.abs(x - xo).max())
             else:
                 assert np.abs(x - xo).max() <= 1e-14 * np.abs(xo).max(), (with_prior, it)
+    # residuals kept linearised (EFResidual::fixLinearizationF outside a marginalisation): H_L / b_L of accumulateLF_MT enter HFinal_top = (H_L + priors) + H_M + H_A and
+    # bFinal_top likewise (EnergyFunctional.cpp:906-907) — the host side adds the stitched L system it is handed in that order
+    L.bah_set_lf_raw.argtypes = [C.c_void_p, cd, cd]
+    mask = (np.arange(W.R) % 3 == 0).astype(np.uint8)
+    assert W.fix_linearization(mask) > 100
+    ao = W.accumulate()
+    HLr, bLr = W.accumulate_lf_raw()
+    assert np.abs(HLr).max() > 1e3 and not same(ao["HL"], HLr)
+    L.bah_set_lf_raw(H, d(np.ascontiguousarray(HLr)), d(np.ascontiguousarray(bLr)))
+    sysm = [np.ascontiguousarray(ao[k]) for k in ("HA", "bA", "Hsc", "bsc")]
+    for it, lam in ((0, 1e-5), (1, 1e-4)):
+        xo = W.solve(it, lam); x = np.zeros(n)
+        L.bah_solve_system(H, it, lam, d(sysm[0]), d(sysm[1]), d(sysm[2]), d(sysm[3]), d(x))
+        assert same(x, xo), ("linearised", it, np.abs(x - xo).max())
     L.bah_destroy(H)
 
 
