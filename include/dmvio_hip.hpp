@@ -294,6 +294,16 @@ class WindowOptimizer {
     idepth.resize(N_);
     return ba_ && dmvio_hip_ba_get_points(ba_, idepth.data(), nullptr) == 0;
   }
+  /* EFResidual::fixLinearizationF for the active residuals with mask != 0 on the resident graph (outside a marginalisation): from then on they ride in every system through
+   * accumulateLF_MT / addPoint<1> and in E_L through calcLEnergyPt; needs keepJacobians(true) before the optimize that precedes it.  Returns the number of linearised
+   * residuals of the graph, -1 on error. */
+  int fixLinearization(const std::vector<unsigned char>& residualMask) {
+    int n = -1;
+    if (!ba_ || dmvio_hip_ba_fix_linearization(ba_, (int)residualMask.size(), residualMask.data(), &n) != 0) return -1;
+    return n;
+  }
+  bool keepJacobians(bool on) { return ba_ && dmvio_hip_ba_keep_jacobians(ba_, on ? 1 : 0) == 0; }
+  dmvio_hip_ba* handle() const { return ba_; }
   double lastEnergy;           /* E_A + E_L + E_M after the last optimize */
   int lastIterations;
   double energyTrace[64 * 4];  /* per iteration: E_A, E_L, E_M, accepted (row 0: before the first step) */
@@ -301,6 +311,36 @@ class WindowOptimizer {
  private:
   dmvio_hip_ba* ba_;
   int F_, N_;
+  friend class WindowBatch;
+};
+
+/* FullSystem::optimize for several windows per call (dmvio_hip_ba_optimize_batch): the whole Gauss-Newton loop — the 68x68 solve, the frame step and the accept test included —
+ * runs on the device for all of them, two host waits per call.  Each WindowOptimizer is set up as for its own optimize(); its results are read with its own getters afterwards. */
+class WindowBatch {
+ public:
+  WindowBatch(dmvio_hip_ctx* ctx, int maxWindows) : b_(dmvio_hip_ba_batch_create(ctx, maxWindows)) {}
+  ~WindowBatch() { if (b_) dmvio_hip_ba_batch_destroy(b_); }
+  WindowBatch(const WindowBatch&) = delete;
+  WindowBatch& operator=(const WindowBatch&) = delete;
+  bool valid() const { return b_ != nullptr; }
+  /* rmse[i] = sqrt(E / (patternNum * resInA)) of window i like the reference's return value; false on a device / argument error */
+  bool optimize(const std::vector<WindowOptimizer*>& windows, int mnumOptIts, std::vector<float>& rmse) {
+    if (!b_ || windows.empty()) return false;
+    std::vector<dmvio_hip_ba*> hs(windows.size());
+    for (size_t i = 0; i < windows.size(); i++) { if (!windows[i] || !windows[i]->ba_) return false; hs[i] = windows[i]->ba_; }
+    rmse.assign(windows.size(), -1.0f);
+    std::vector<double> energy(windows.size()), trace(windows.size() * 256);
+    std::vector<int> its(windows.size());
+    if (dmvio_hip_ba_optimize_batch(b_, (int)hs.size(), hs.data(), mnumOptIts, rmse.data(), energy.data(), its.data(), trace.data()) != 0) return false;
+    for (size_t i = 0; i < windows.size(); i++) {
+      windows[i]->lastEnergy = energy[i]; windows[i]->lastIterations = its[i];
+      for (int k = 0; k < 256; k++) windows[i]->energyTrace[k] = trace[i * 256 + k];
+    }
+    return true;
+  }
+
+ private:
+  dmvio_hip_ba_batch* b_;
 };
 
 }  // namespace dmvio_hip
