@@ -110,14 +110,18 @@ DMV_HD Pose poseExp(const double a[6]) {
   const double theta_sq = ox * ox + oy * oy + oz * oz;
   const double theta = sqrt(theta_sq);
   double imag, real;
+  double sh = 0.0, ch = 1.0;   // sin / cos of theta / 2 (theta >= 1e-10)
   if (theta < 1e-10) {
     const double p4 = theta_sq * theta_sq;
     imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * p4;
     real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * p4;
   } else {
-    double sh, ch;
     dsincos(0.5 * theta, &sh, &ch);
+#if !defined(__HIP_DEVICE_COMPILE__)
     imag = sh / theta;
+#else
+    imag = sh * (1.0 / theta);   // device: the reciprocal is shared with c1 / c2 below (the compiler keeps one)
+#endif
     real = ch;
   }
   Quatd q = {real, imag * ox, imag * oy, imag * oz};
@@ -127,11 +131,21 @@ DMV_HD Pose poseExp(const double a[6]) {
   if (theta < 1e-10) {
     quatToR(r.q, V);
   } else {
+#if !defined(__HIP_DEVICE_COMPILE__)
     double sth, cth;
     dsincos(theta, &sth, &cth);
     const double tsq = theta * theta;   // se3.hpp:417 squares the theta that so3's expAndTheta returned (sqrt of the sum of squares): not the sum itself in the last bit
     const double c1 = (1.0 - cth) / tsq;
     const double c2 = (theta - sth) / (tsq * theta);
+#else
+    // device (the serial tail of the LM control step): sin / cos of theta from the half-angle pair already at hand (sin = 2 s c, 1 - cos = 2 s^2) and ONE reciprocal for the
+    // three quotients — a second polynomial evaluation and two ~30-instruction IEEE divisions less on a single lane's dependent chain; within an ulp or two of the host's values,
+    // like the device's sin / cos / exp themselves
+    const double sth = 2.0 * sh * ch;
+    const double inv = 1.0 / theta, inv2 = inv * inv;
+    const double c1 = (2.0 * sh * sh) * inv2;
+    const double c2 = (theta - sth) * (inv2 * inv);
+#endif
     const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
     double O2[9];
     for (int i = 0; i < 3; i++)
