@@ -2018,7 +2018,7 @@ struct dmvio_hip_ba_batch {
   int exact_backsub = 0;
   float last_ms[3] = {0, 0, 0};    // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation, [profile] one stepped linearisation
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  // a batch of >= 4 windows is cut into up to BA_BATCH_STREAMS groups, one stream each, their launches interleaved stage by stage (optimizeBatchGroup): while one group's
+  // a batch of >= 4 windows is cut into groups (three by default, at most BA_BATCH_STREAMS), one stream each, their launches interleaved stage by stage (optimizeBatchGroup): while one group's
   // k_ba_solve runs (one workgroup per window) the other groups' linearisations / accumulations fill the device
   enum { BA_BATCH_STREAMS = 8 };
   hipStream_t gstream[BA_BATCH_STREAMS] = {};   // [0] = stream
@@ -2099,7 +2099,7 @@ int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* B, int ticks12[12]) 
   for (int i = 0; i < 12; i++) ticks12[i] = B->h_wins[0].S.ticks[i];
   return 0;
 }
-// 0 (default): a batch of >= 4 windows is cut into up to four groups on four streams (at least two windows each), their launches interleaved; k >= 1: at most k groups
+// 0 (default): a batch of >= 4 windows is cut into up to three groups on three streams (at least two windows each), their launches interleaved; k >= 1: at most k groups
 // (1 = the whole batch on one stream).  The grouping changes no result: no arithmetic crosses windows.
 int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* B, int streams) {
   if (!B || streams < 0) return failmsg("ba_batch_set_streams: bad argument");
@@ -2218,7 +2218,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   HIPCHK(hipMemcpyAsync(B->d_tab, B->h_tab, B->tab_stride * (size_t)(Wn - 1) + used_tab, hipMemcpyHostToDevice, s));
   const FrameStore fs = B->ctx->fs;
   const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n, F);
-  // Up to four groups of windows, one stream each, from 4 windows on: k_ba_solve is one workgroup per window (a 100 us latency chain on a handful of CUs), so while one
+  // Up to three groups of windows by default (at most BA_BATCH_STREAMS on request), one stream each, from 4 windows on: k_ba_solve is one workgroup per window (a 100 us latency chain on a handful of CUs), so while one
   // group solves, the other groups' linearisations / accumulations fill the device.  The groups share nothing.  Their launches are enqueued STAGE BY STAGE (initial chain of
   // every group, iteration 0 of every group, ...): a stream whose commands the host has not submitted yet cannot overlap with anything (measured: with the groups enqueued one
   // after the other the second one started three iterations late).  Group g starts behind group g-1's initial linearisation, which keeps the groups out of step.  A profiled

@@ -536,9 +536,9 @@ int dmvio_hip_ba_batch_set_exact_backsub(dmvio_hip_ba_batch* batch, int on);
  * group on one stream) */
 int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* batch, float ms3[3]);
 int dmvio_hip_ba_batch_set_profile(dmvio_hip_ba_batch* batch, int on);
-/* 0 (default): from 4 windows on the batch is cut into up to four groups of at least two windows, one HIP stream each, their launches enqueued stage by stage, group g
+/* 0 (default): from 4 windows on the batch is cut into up to three groups of at least two windows (measured best at 16 and 64 windows), one HIP stream each, their launches enqueued stage by stage, group g
  * started behind group g-1's initial linearisation — so that one group's k_ba_solve (one workgroup per window) runs beside the other groups' linearisations / accumulations;
- * k >= 1: at most k groups (1 = the whole batch on one stream).  A profiled call (dmvio_hip_ba_batch_set_profile) always runs as one group.  Results do not depend on it. */
+ * k >= 1: at most k groups, up to 8 (1 = the whole batch on one stream).  A profiled call (dmvio_hip_ba_batch_set_profile) always runs as one group.  Results do not depend on it. */
 int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* batch, int streams);
 /* the linearisation kernel of a batch of >= 4 windows: 1 (default) = one lane per residual (k_ba_linearize_b1: the lane walks the eight pattern pixels; no redundant
  * geometry — what a grid that fills the device wants), 8 = eight lanes per residual (k_ba_linearize_b: the single window's latency-hiding form).  Same values, same energy
