@@ -796,6 +796,38 @@ class BundleAdjusterBatch:
         fn = self.L.dmvio_hip_ba_batch_set_linearize_lanes; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
         _chk(self.L, fn(self.p, int(lanes)), "ba_batch_set_linearize_lanes")
 
+    def last_solve_ticks(self):
+        """in-kernel timeline of window 0's last k_ba_solve, microseconds since the kernel started (12 phase boundaries)"""
+        t = np.zeros(12, np.int32)
+        fn = self.L.dmvio_hip_ba_batch_last_solve_ticks; fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, t.ctypes.data), "ba_batch_last_solve_ticks")
+        return t / 100.0
+
+    def last_pivot_branch(self, w=0):
+        """how window w's last solve found Eigen's pivot order: 0 ranks (distinct |diagonal|), 1 ties replayed, 2 NaN"""
+        b = C.c_int(-1)
+        fn = self.L.dmvio_hip_ba_batch_last_pivot_branch; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, int(w), C.byref(b)), "ba_batch_last_pivot_branch")
+        return b.value
+
+
+def debug_solve(ctx, H, b, exact_backsub=True):
+    """dmvio_hip_ba_debug_solve: the device-resident loop's 68x68 solve (k_ba_solve's scaling, pivot order, LDL^T, substitutions) for a given system.
+    Returns (x, perm, branch, zero)."""
+    Hc = np.ascontiguousarray(H, dtype=np.float64); bc = np.ascontiguousarray(b, dtype=np.float64); n = len(bc)
+    x = np.zeros(n); perm = np.zeros(n, np.int32); br = C.c_int(-1); z = C.c_int(-1)
+    fn = ctx.L.dmvio_hip_ba_debug_solve
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+    _chk(ctx.L, fn(ctx.p, n, Hc.ctypes.data, bc.ctypes.data, 1 if exact_backsub else 0, x.ctypes.data, perm.ctypes.data, C.byref(br), C.byref(z)), "ba_debug_solve")
+    return x, perm, br.value, z.value
+
+
+def host_solve_ldlt(L, H, b):
+    """dmvio_hip_ba_solve_ldlt (host): BAHost::ldltSolveTransposed behind the reference's diagonal pre-scaling"""
+    Hc = np.ascontiguousarray(H, dtype=np.float64); bc = np.ascontiguousarray(b, dtype=np.float64); x = np.zeros(len(bc))
+    _chk(L, L.dmvio_hip_ba_solve_ldlt(len(bc), _d(Hc), _d(bc), _d(x)), "ba_solve_ldlt")
+    return x
+
 
 class RcclCommunicator:
     """ncclComm_t created through the library's wrappers (dmvio_hip_comm_*): rank `rank` of `world` on the context's device.

@@ -41,6 +41,7 @@ struct BASolveDev {
   double* trace;               // 64 x 4: [E_A, E_L, E_M, accepted] per iteration, row 0 = the initial state
   double* x_last;              // n: the last solve's x (= MINUS the step), for tests
   int ticks[16];               // diagnostics: 100 MHz wall-clock stamps of the last k_ba_solve, relative to its start (dmvio_hip_ba_batch_last_solve_ticks)
+  int pivot_branch, pad_;      // diagnostics: how the last solve found its pivot order (BA_PIVOT_*; dmvio_hip_ba_batch_last_pivot_branch)
 };
 struct BAWinDev {
   BAWindow W, Wb;              // Wb: calibration members of the backed-up state (the relinearisation after a rejected step)
@@ -126,16 +127,27 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather_b(const BAWinDev* __re
 }
 
 // ------------------------------------------------------------------------------------------------ k_ba_solve
-// lower triangle packed by rows: element (r, c), c <= r
+// Row-packed lower triangle (the scaled, not yet permuted matrix): element (r, c), c <= r
 __device__ __forceinline__ int triIdx(const int r, const int c) { return (r * (r + 1)) / 2 + c; }
-#define BA_SOLVE_THREADS 256
+// Column-packed lower triangle (the permuted matrix, then L and D in place): element (r, k), r >= k, at baColBase(k, n) + r — a column is contiguous, which is what the
+// factorisation publishes and reads per step
+__host__ __device__ inline int baColBase(const int k, const int n) { return k * (n - 1) - (k * (k - 1)) / 2; }
+#define BA_SOLVE_THREADS 512
 template <int MF> struct BASolveDims {
   static constexpr int NMAX = 4 + 8 * MF;
-  static constexpr int QMAX = (NMAX * (NMAX + 1) / 2 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS;
+  static constexpr int QMAX = (NMAX * (NMAX + 1) / 2 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS;   // packed pairs per thread
+  static constexpr int NCW = 2 * ((NMAX + 7) / 8); // columns per wavefront of the factorisation (the column PAIR c >> 1 belongs to wave (c >> 1) mod 4; wavefronts 4 .. 7 hold none)
+  static constexpr bool ALIAS_HM = MF > 8;         // n = 100: the prior's LDS copy shares the room of the packed matrix and its D L copy (staged twice: bM_top, E_M)
 };
-// dynamic LDS of k_ba_solve, in doubles: HM (n x n), the packed matrix, the nullspace basis (7 x n), 11 vectors, the frames' states
+// dynamic LDS of k_ba_solve, in doubles: HM (n x n; aliased: see ALIAS_HM), the packed matrix and its D L copy (+ 128 each: a wave reads a column with all its lanes), the
+// nullspace basis (7 x n), 12 vectors, the frames' states
 __host__ __device__ inline int baSolveHmStride(const int n) { return n | 1; }   // odd row stride (in doubles): thread i walking row i meets no LDS bank conflicts
-__host__ __device__ inline size_t baSolveLdsDoubles(const int n, const int F) { return (size_t)n * baSolveHmStride(n) + (size_t)(n * (n + 1)) / 2 + 7 * (size_t)n + 11 * (size_t)n + 40 * (size_t)F + 64; }
+__host__ __device__ inline size_t baSolveLdsDoubles(const int n, const int F, const bool aliasHM) {
+  const size_t NP = (size_t)(n * (n + 1)) / 2, hm = (size_t)n * baSolveHmStride(n), lt = 2 * (NP + 128);
+  return (aliasHM ? (hm > lt ? hm : lt) : hm + lt) + 7 * (size_t)n + 12 * (size_t)n + 40 * (size_t)F + 64;
+}
+// the debug kernel's share (no prior, no basis, no frame states)
+__host__ __device__ inline size_t baSolveCoreLdsDoubles(const int n) { return 2 * ((size_t)(n * (n + 1)) / 2 + 128) + 7 * (size_t)n + 64; }
 
 // AffLight::fromToVecExposure as BAHost::affFromToHost evaluates it (exp in double, the exposure ratio in float-to-double promotion order)
 __device__ __forceinline__ void baAffFromTo(float eF, float eT, const double aF, const double bF, const double aT, const double bT, double out[2]) {
@@ -157,12 +169,415 @@ __device__ __forceinline__ double baSeqDot(double s, const double* __restrict__ 
   for (; j < n; j++) s += a[j] * b[j];
   return s;
 }
+#define BA_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ double baReadLaneF64(const double v, const int l) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// the packed pairs a thread owns (tid, tid + 512, ...): (row << 8) | column of the row-packed triangle, -1 beyond it
+template <int QMAX>
+__device__ __forceinline__ void baOwnedPairs(const int n, int (&pr)[QMAX]) {
+  const int NP = (n * (n + 1)) / 2;
+#pragma unroll
+  for (int q = 0; q < QMAX; q++) {
+    const int p = (int)threadIdx.x + q * BA_SOLVE_THREADS;
+    pr[q] = -1;
+    if (p < NP) {
+      int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+      while (triIdx(r + 1, 0) <= p) r++;
+      while (triIdx(r, 0) > p) r--;
+      pr[q] = (r << 8) | (p - triIdx(r, 0));
+    }
+  }
+}
 
-// finish != 0: only settle the pending decision (behind the last iteration's chain); the host reads the final state from the window's record.
-// Everything a sequential (order-preserving) loop reads is staged in LDS first: a dependent chain over global memory costs a memory latency per term.
+// ---- the pivoted LDL^T solve of EnergyFunctional.cpp:971-973 (Eigen's ldlt().solve() as BAHost::ldltSolveTransposed restates it), one 512-thread workgroup, every
+// operation of the host's loop in the host's order per element:
+//   in : Lc[triIdx(i, j)] = the scaled matrix (row-packed lower triangle), dgS[i] = its diagonal, rhsS[i] = the scaled right-hand side
+//   out: xs[i] = the solution of the SCALED system in the ORIGINAL order (the caller multiplies by the scaling), perm[k] = the index Eigen's transpositions bring to position k,
+//        s_flag[1] = the matrix was zero (x = 0), s_flag[2] = how the pivot order was found (BA_PIVOT_*)
+// Pivot order: Eigen's unblocked LDL^T picks the largest |diagonal| of the NOT YET UPDATED trailing diagonal (left-looking: step k only touches column k), the first one
+// on ties, and swaps it to position k — the whole sequence follows from the original diagonal alone.  Without ties it is the descending order of |diagonal| (a rank count);
+// with ties the members of a tie group are taken in the order of their CURRENT positions when the group's first step comes (a member only moves when it is taken; the
+// displaced occupant of position k goes where the taken element stood) — wavefront 0 reconstructs those positions by chasing the displacement links of the earlier steps
+// (a few wave-wide rounds per tie group, see below) instead of replaying the n swaps one after the other; a NaN on the diagonal takes the literal loop on one lane.
+// Factorisation: wave w of row group G (rows 64 G + lane) owns the columns c = w (mod 4) of its rows and keeps their running sums sum_j L(r, j) D_j L(c, j) (j ascending:
+// the host's acc[r]) in registers, the next own column always in acc[0].  Step k: the owner of column k adds step k - 1's term to that column only, subtracts, takes the
+// pivot from lane k, divides, forward-substitutes and PUBLISHES the column (L and D L) in LDS — then ONE workgroup barrier — and every other wave adds the published
+// steps' terms to all its columns (the owner catches up in the next step: its trailing update is off the pivot chain).  Rows >= 64 (windows of more than 7 keyframes) form
+// row group 1, which runs one step behind (its column k needs the pivot row group 0 published in step k) and carries the pivot chain itself from column 64 on.
+#ifdef BA_SOLVE_PROBE
+__device__ long long g_ba_probe[64];
+#define BA_PROBE(base, i) do { if (k == BA_SOLVE_PROBE && lane == 0) g_ba_probe[(base) + (i)] = clock64(); } while (0)
+#else
+#define BA_PROBE(base, i) do { } while (0)
+#endif
+// One wavefront's share of the factorisation (see baLdltSolveCore): run<NL>(kg0, kg1) takes the groups of four slots (eight columns) kg0 .. kg1 - 1 with at most NL own
+// columns left.  TWO: the matrix has more than 64 rows — a second register set holds rows 64 + lane.
+template <int MF, bool TWO>
+struct BAFactor {
+  static constexpr int NCW = BASolveDims<MF>::NCW;
+  int n, lane, w, cbase, done, cbK, cbJ;                     // cbase: the column of acc[0]; done: steps <= done are in every own column's sum; cbK / cbJ: baColBase of the
+  double *__restrict__ Lc, *__restrict__ Tc, *__restrict__ rhs;   // slot's first column / of step done + 1, kept by additions
+  int* s_flag;
+  // element idx (a row index, uniform) of a column held one row per lane in (v, v2)
+  __device__ __forceinline__ double pick(const double v, const double v2, const int idx) const {
+    if (!TWO || idx < 64) return baReadLaneF64(v, idx & 63);
+    return baReadLaneF64(v2, idx & 63);
+  }
+  // column k of the permuted matrix minus its finished sum -> pivot, L(., k) (the division), D_k L(., k); published.  Returns through l / l2 / t / t2.
+  __device__ __forceinline__ void finish(const int k, const int cb, double a, double a2, double& l, double& l2, double& t, double& t2) {
+    const int nx = n - 64;                                   // rows of the second set (TWO)
+    const double akk = pick(a, a2, k);
+    const bool ok = fabs(akk) > 0;
+    if (k == 0 && !ok && lane == 0) s_flag[1] = 1;           // a zero matrix: x = 0 (everybody leaves behind the first group of slots)
+    l = a; l2 = a2;
+    if (ok) {
+      if (TWO && k >= nx) {
+        // rows 64 .. n - 1 ride in lanes 0 .. nx - 1 of the first set's division (rows below nx <= k are finished there)
+        const double q = (lane < nx ? a2 : a) / akk;
+        if (lane < nx) { if (64 + lane > k) l2 = q; } else if (lane > k) l = q;
+      } else {
+        const double q = a / akk;
+        if (lane > k) l = q;
+        if (TWO) { const double q2 = a2 / akk; if (64 + lane > k) l2 = q2; }
+      }
+    }
+    t = akk * l; t2 = TWO ? akk * l2 : 0.0;
+    if (lane >= k && lane < n) { Lc[cb + lane] = l; Tc[cb + lane] = t; }   // the diagonal slot of L keeps D_k
+    if (TWO && lane < nx && 64 + lane >= k) { Lc[cb + 64 + lane] = l2; Tc[cb + 64 + lane] = t2; }
+  }
+  template <int NL>
+  __device__ __forceinline__ void run(const int kg0, const int kg1, double (&acc)[NCW], double (&acc2)[NCW]) {
+    for (int kg = kg0; kg < kg1; kg++) {
+#pragma unroll 1
+      for (int sub = 0; sub < 4; sub++) {
+        const int k = 8 * kg + 2 * sub;                      // the slot's columns: k, k + 1
+        const bool own = sub == w && k < n;
+        if (own) {
+          // owner of the column pair (k, k + 1) = (cbase, cbase + 1), in acc[0], acc[1]: their sums lack only the previous slot's two steps (added here for these two
+          // columns alone: the other own columns catch up in the next slot), and column k + 1 also step k, which never leaves the wavefront
+          BA_PROBE(0, 0);
+          const int cb = cbK, cbn = cbK + n - 1 - k;         // baColBase(k), baColBase(k + 1)
+          const bool has2 = k + 1 < n;
+          double a = Lc[cb + lane], a2 = TWO ? Lc[cb + 64 + lane] : 0.0;
+          double b = Lc[cbn + lane], b2 = TWO ? Lc[cbn + 64 + lane] : 0.0;
+          double sa = acc[0], sa2 = acc2[0], sb = acc[1], sb2 = acc2[1];
+          if (k > 0) {
+            const int c1 = cbK - (n - k), c2 = c1 - (n - k + 1);   // baColBase(k - 1), baColBase(k - 2)
+            const double lp = Lc[c2 + lane], lp2 = TWO ? Lc[c2 + 64 + lane] : 0.0;
+            const double lq = Lc[c1 + lane], lq2 = TWO ? Lc[c1 + 64 + lane] : 0.0;
+            const double tpa = Tc[c2 + k], tpb = Tc[c2 + k + 1], tqa = Tc[c1 + k], tqb = Tc[c1 + k + 1];   // D_j L(k, j), D_j L(k + 1, j) for j = k - 2, k - 1
+            sa += lp * tpa; sa += lq * tqa;
+            sb += lp * tpb; sb += lq * tqb;
+            if (TWO) { sa2 += lp2 * tpa; sa2 += lq2 * tqa; sb2 += lp2 * tpb; sb2 += lq2 * tqb; }
+          }
+          a -= sa;
+          if (TWO) a2 -= sa2;
+          BA_PROBE(0, 1);
+          double l, l2, t, t2;
+          finish(k, cb, a, a2, l, l2, t, t2);
+          BA_PROBE(0, 2);
+          if (has2) {
+            const double tk = pick(t, t2, k + 1);            // D_k L(k + 1, k)
+            sb += l * tk;
+            if (TWO) sb2 += l2 * tk;
+            b -= sb;
+            if (TWO) b2 -= sb2;
+            double m, m2, u, u2;
+            finish(k + 1, cbn, b, b2, m, m2, u, u2);
+          }
+          BA_PROBE(0, 4);
+        }
+        // every published step not yet added (the previous slot's two; four right after an own slot; none IN the own slot), to all own columns: L(., j) one row per lane,
+        // D_j L(c, j) of the own columns as broadcast reads (the columns of acc[0], acc[1] once their own slot has passed, and columns beyond the matrix, collect values
+        // nobody reads)
+        const int jmax = (k < n && !own) ? k - 1 : done;
+        BA_PROBE(16 + 16 * (w == ((sub + 1) & 3) ? 1 : 0), 0);
+#pragma unroll 1
+        for (int j = done + 1; j <= jmax; j++) {
+          const double lr0 = Lc[cbJ + lane];
+          const double lr0b = TWO ? Lc[cbJ + 64 + lane] : 0.0;
+          const double* __restrict__ T0 = Tc + cbJ + cbase;
+          double t[NL];
+#pragma unroll
+          for (int i = 0; i < NL; i++) t[i] = T0[8 * (i >> 1) + (i & 1)];
+#pragma unroll
+          for (int i = 0; i < NL; i++) {
+            acc[i] += lr0 * t[i];
+            if (TWO) acc2[i] += lr0b * t[i];
+          }
+          cbJ += n - 1 - j;
+        }
+        if (jmax > done) done = jmax;
+        if (!own) BA_PROBE(16 + 16 * (w == ((sub + 1) & 3) ? 1 : 0), 1);
+        cbK += 2 * (n - 1 - k) - 1;
+        __syncthreads();
+        if (k < n) BA_PROBE(own ? 0 : 16 + 16 * (w == ((sub + 1) & 3) ? 1 : 0), 5);
+      }
+      if (kg == 0 && s_flag[1]) return;                      // (a zero matrix)
+#pragma unroll
+      for (int i = 0; i + 2 < NL; i++) { acc[i] = acc[i + 2]; if (TWO) acc2[i] = acc2[i + 2]; }
+      cbase += 8;
+    }
+  }
+  __device__ __forceinline__ void factor() {
+    const int ngroups = (n + 7) >> 3;
+    if (w >= 4) {
+      // wavefronts 4 .. 7 hold no columns: they keep the barrier count (and leave with the others on a zero matrix).  Wavefront 4 carries the forward substitution
+      // (d[i] -= L(i, j) d[j], j ascending: the right-hand side one row per lane, a slot's two columns as soon as the barrier behind it has published them)
+      double d1 = 0.0, d2 = 0.0;
+      if (w == 4) { d1 = rhs[min(lane, n - 1)]; if (TWO) d2 = rhs[min(64 + lane, n - 1)]; }
+      int cb = 0, j = 0;
+      for (int s = 0; s < 4 * ngroups; s++) {
+        __syncthreads();
+        if (s == 3 && s_flag[1]) return;
+        if (w == 4) {
+          for (int e = 0; e < 2 && j < n - 1; e++, j++) {
+            const double lj = Lc[cb + lane], lj2 = TWO ? Lc[cb + 64 + lane] : 0.0;
+            const double dj = pick(d1, d2, j);
+            if (lane > j) d1 -= lj * dj;
+            if (TWO && 64 + lane > j) d2 -= lj2 * dj;
+            cb += n - 1 - j;
+          }
+        }
+      }
+      if (w == 4) { if (lane < n) rhs[lane] = d1; if (TWO && 64 + lane < n) rhs[64 + lane] = d2; }
+      return;
+    }
+    double acc[NCW], acc2[NCW];
+#pragma unroll
+    for (int i = 0; i < NCW; i++) { acc[i] = 0.0; acc2[i] = 0.0; }
+    cbase = 2 * w; done = -1; cbK = 0; cbJ = 0;
+    // the own columns still to come shrink by two per group of four slots: four copies of the loop, each sized for what is left when it starts
+    constexpr int G = NCW / 2, Q1 = G / 4, Q2 = G / 2, Q3 = (3 * G) / 4;
+    run<NCW>(0, min(Q1, ngroups), acc, acc2);
+    if (s_flag[1]) return;
+    run<NCW - 2 * Q1>(Q1, min(Q2, ngroups), acc, acc2);
+    run<NCW - 2 * Q2>(Q2, min(Q3, ngroups), acc, acc2);
+    run<NCW - 2 * Q3>(Q3, ngroups, acc, acc2);
+  }
+};
+enum { BA_PIVOT_RANKS = 0, BA_PIVOT_TIES = 1, BA_PIVOT_NAN = 2 };
 template <int MF>
-__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restrict__ wins, const int iteration, const int finish) {
+__device__ __forceinline__ void baLdltSolveCore(const int n, double* __restrict__ Lc, double* __restrict__ Tc, double* __restrict__ dgS,
+                                                const double* __restrict__ rhsS, double* __restrict__ rhs, double* __restrict__ xs, int* __restrict__ perm, int* s_flag,
+                                                const int exact_backsub, const int (&pr)[BASolveDims<MF>::QMAX], int* ticks, const long long t_begin) {
   constexpr int QMAX = BASolveDims<MF>::QMAX;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform by construction; said so, everything derived from it lives in scalar registers and branches)
+  __shared__ int s_big[128];
+  // ---- pivot order (wavefront 0; position p of the sequence = lane p & 63, register p >> 6)
+  if (wave == 0) {
+    const bool v0 = lane < n, v1 = lane + 64 < n;
+    const double m0 = v0 ? fabs(dgS[lane]) : 0.0, m1 = v1 ? fabs(dgS[lane + 64]) : 0.0;
+    int rank0 = 0, same0 = 0, rank1 = 0, same1 = 0;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+      double o[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) o[q] = fabs(dgS[j + q]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) { rank0 += o[q] > m0 ? 1 : 0; same0 += o[q] == m0 ? 1 : 0; rank1 += o[q] > m1 ? 1 : 0; same1 += o[q] == m1 ? 1 : 0; }
+    }
+    for (; j < n; j++) { const double o = fabs(dgS[j]); rank0 += o > m0 ? 1 : 0; same0 += o == m0 ? 1 : 0; rank1 += o > m1 ? 1 : 0; same1 += o == m1 ? 1 : 0; }
+    const bool anyNan = __ballot((v0 && !(m0 == m0)) || (v1 && !(m1 == m1))) != 0ull;
+    const bool anyTie = __ballot((v0 && same0 > 1) || (v1 && same1 > 1)) != 0ull;
+    if (anyNan) {
+      // the literal selection loop (fabs(NaN) > x is false: a NaN is never selected, and nothing is selected over a NaN that stands at position k)
+      if (lane == 0) {
+        for (int i = 0; i < n; i++) perm[i] = i;
+        for (int k = 0; k < n; k++) {
+          int big = k; double bigv = fabs(dgS[k]);
+          for (int i = k + 1; i < n; i++) { const double v = fabs(dgS[i]); if (v > bigv) { bigv = v; big = i; } }
+          if (big != k) { const double t = dgS[k]; dgS[k] = dgS[big]; dgS[big] = t; const int q = perm[k]; perm[k] = perm[big]; perm[big] = q; }
+        }
+        s_flag[2] = BA_PIVOT_NAN;
+      }
+    } else if (!anyTie) {
+      // all |diagonal| values distinct: step k selects the k-th largest whatever the swaps did to the others — the order is the rank itself
+      if (v0) perm[rank0] = lane;
+      if (v1) perm[rank1] = lane + 64;
+      if (lane == 0) s_flag[2] = BA_PIVOT_RANKS;
+    } else {
+      // Ties.  Step t of the selection takes the element of rank t where that element is alone in its group (its rank = the number of larger elements = its step); a tie group
+      // of m elements fills the steps rank .. rank + m - 1 in the order of the members' CURRENT positions when the group starts.  An element only moves when the step that
+      // equals its position passes without taking it: it then goes to where that step's element stood (big[t], final once it is >= t).  So
+      //   big[t] = chase(sel[t], t),   position of e at step s = chase(e, s),   chase(p, s): while (p < s) p = big[p]
+      // and every big[u] a chase reads belongs to an earlier step: the steps before a tie group settle in a few wave-wide rounds (every unsettled step follows one link
+      // per round; the lowest unsettled one always can), the members chase, rank themselves by position, and fill their steps.  perm[] doubles as sel[]; bigA in LDS.
+      int* const bigA = s_big;
+      const bool two = n > 64;
+      if (v0) perm[lane] = -1;
+      if (v1) perm[lane + 64] = -1;
+      BA_WAVE_LDS_SYNC();
+      if (v0 && same0 == 1) perm[rank0] = lane;
+      if (v1 && same1 == 1) perm[rank1] = lane + 64;
+      BA_WAVE_LDS_SYNC();
+      int cur0 = v0 ? perm[lane] : 0, cur1 = v1 ? perm[lane + 64] : 0;          // step t = lane / lane + 64
+      bool known0 = v0 && cur0 >= 0, known1 = v1 && cur1 >= 0;
+      bool fin0 = known0 && cur0 >= lane, fin1 = known1 && cur1 >= lane + 64;
+      if (v0) bigA[lane] = fin0 ? cur0 : -1;
+      if (v1) bigA[lane + 64] = fin1 ? cur1 : -1;
+      unsigned long long ts0 = __ballot(v0 && !known0), ts1 = two ? __ballot(v1 && !known1) : 0ull;   // the steps of tie groups
+      while ((ts0 | ts1) != 0ull) {
+        const int s0 = ts0 ? __builtin_ctzll(ts0) : 64 + __builtin_ctzll(ts1);
+        const bool mem0 = v0 && rank0 == s0 && same0 > 1, mem1 = v1 && rank1 == s0 && same1 > 1;      // the group's members (elements lane / lane + 64)
+        const unsigned long long mm0 = __ballot(mem0), mm1 = two ? __ballot(mem1) : 0ull;
+        const int m = __popcll(mm0) + __popcll(mm1);
+        // (a) settle every step before s0
+        for (;;) {
+          const bool w0 = known0 && !fin0 && lane < s0, w1 = two && known1 && !fin1 && lane + 64 < s0;
+          if ((__ballot(w0) | __ballot(w1)) == 0ull) break;
+          BA_WAVE_LDS_SYNC();
+          if (w0) { const int bb = bigA[cur0]; if (bb >= 0) { cur0 = bb; if (cur0 >= lane) { fin0 = true; } } }
+          if (w1) { const int bb = bigA[cur1]; if (bb >= 0) { cur1 = bb; if (cur1 >= lane + 64) { fin1 = true; } } }
+          BA_WAVE_LDS_SYNC();
+          if (w0 && fin0) bigA[lane] = cur0;
+          if (w1 && fin1) bigA[lane + 64] = cur1;
+        }
+        BA_WAVE_LDS_SYNC();
+        // (b) where the members stand when step s0 begins
+        int p0 = lane, p1 = lane + 64;
+        for (;;) {
+          const bool c0 = mem0 && p0 < s0, c1 = mem1 && p1 < s0;
+          if ((__ballot(c0) | __ballot(c1)) == 0ull) break;
+          if (c0) p0 = bigA[p0];
+          if (c1) p1 = bigA[p1];
+        }
+        // (c) the members in the order of their positions
+        int o0 = 0, o1 = 0;
+        for (unsigned long long q = mm0; q; q &= q - 1ull) { const int pb = __builtin_amdgcn_readlane(p0, __builtin_ctzll(q)); o0 += pb < p0 ? 1 : 0; o1 += pb < p1 ? 1 : 0; }
+        for (unsigned long long q = mm1; q; q &= q - 1ull) { const int pb = __builtin_amdgcn_readlane(p1, __builtin_ctzll(q)); o0 += pb < p0 ? 1 : 0; o1 += pb < p1 ? 1 : 0; }
+        if (mem0) { perm[s0 + o0] = lane; bigA[s0 + o0] = p0; }
+        if (mem1) { perm[s0 + o1] = lane + 64; bigA[s0 + o1] = p1; }
+        BA_WAVE_LDS_SYNC();
+        // the group's steps are settled
+        if (v0 && lane >= s0 && lane < s0 + m) { known0 = true; fin0 = true; cur0 = bigA[lane]; }
+        if (v1 && lane + 64 >= s0 && lane + 64 < s0 + m) { known1 = true; fin1 = true; cur1 = bigA[lane + 64]; }
+        // (clear the steps s0 .. s0 + m - 1)
+        for (int t = s0; t < s0 + m; t++) { if (t < 64) ts0 &= ~(1ull << t); else ts1 &= ~(1ull << (t - 64)); }
+      }
+      BA_WAVE_LDS_SYNC();
+      if (lane == 0) s_flag[2] = BA_PIVOT_TIES;
+    }
+  }
+  __syncthreads();
+  if (ticks && tid == 0) ticks[3] = (int)(wall_clock64() - t_begin);   // pivot order
+  // ---- the permuted system P A P^T, column-packed in place of the row-packed A (through registers: all swaps applied up front — the same operands meet in the same
+  // order as with a swap at every step)
+  {
+    double val[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) {
+      val[q] = 0.0;
+      if (pr[q] >= 0) {
+        const int a = perm[pr[q] >> 8], b = perm[pr[q] & 255];
+        val[q] = Lc[a >= b ? triIdx(a, b) : triIdx(b, a)];
+      }
+    }
+    if (tid < n) rhs[tid] = rhsS[perm[tid]];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) if (pr[q] >= 0) Lc[baColBase(pr[q] & 255, n) + (pr[q] >> 8)] = val[q];
+  }
+  __syncthreads();
+  if (ticks && tid == 0) ticks[4] = (int)(wall_clock64() - t_begin);   // permuted
+  // ---- LDL^T with the forward substitution riding along (d[i] -= L(i, j) d[j], j ascending)
+  if (n > 64) { BAFactor<MF, true> fc; fc.n = n; fc.lane = lane; fc.w = wave; fc.Lc = Lc; fc.Tc = Tc; fc.rhs = rhs; fc.s_flag = s_flag; fc.factor(); }
+  else { BAFactor<MF, false> fc; fc.n = n; fc.lane = lane; fc.w = wave; fc.Lc = Lc; fc.Tc = Tc; fc.rhs = rhs; fc.s_flag = s_flag; fc.factor(); }
+  __syncthreads();   // (wavefront 4's right-hand side)
+  if (ticks && tid == 0) ticks[5] = (int)(wall_clock64() - t_begin);   // factorised + forward substitution
+  const bool zero = s_flag[1] != 0;
+  // ---- diagonal solve, back substitution (wavefront 0)
+  if (wave == 0) {
+    double x0 = 0.0, x1 = 0.0;
+    if (lane < n) { const double dd = Lc[baColBase(lane, n) + lane]; x0 = rhs[lane]; if (fabs(dd) > 2.2250738585072014e-308) x0 /= dd; else x0 = 0; if (zero) x0 = 0.0; }
+    if (lane + 64 < n) { const double dd = Lc[baColBase(lane + 64, n) + lane + 64]; x1 = rhs[lane + 64]; if (fabs(dd) > 2.2250738585072014e-308) x1 /= dd; else x1 = 0; if (zero) x1 = 0.0; }
+    if (!zero) {
+      if (exact_backsub) {
+        // the order of ldltSolveTransposed (row i subtracts L(j, i) x_j for j = i + 1 .. n - 1, ascending): one dependent chain of n^2 / 2 subtractions
+        if (lane < n) rhs[lane] = x0;
+        if (lane + 64 < n) rhs[lane + 64] = x1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) for (int i = n - 1; i >= 0; i--) { double sacc = rhs[i]; const double* Li = Lc + baColBase(i, n); for (int j = i + 1; j < n; j++) sacc -= Li[j] * rhs[j]; rhs[i] = sacc; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < n) x0 = rhs[lane];
+        if (lane + 64 < n) x1 = rhs[lane + 64];
+      } else {
+        // column-oriented (no barrier per step): as soon as x_i stands, every row above subtracts its term (row r subtracts in the order i = n - 1 .. r + 1: the same
+        // terms, another association)
+        const int b0 = baColBase(min(lane, n - 1), n), b1 = baColBase(min(lane + 64, n - 1), n);
+        double m0n = Lc[b0 + n - 1], m1n = Lc[b1 + n - 1];   // L(n - 1, lane): row i of L for the next step, one step ahead (lanes at or beyond row i read a slot they do not use)
+        for (int i = n - 1; i > 0; i--) {
+          const double m0 = m0n, m1 = m1n;
+          if (i > 1) { m0n = Lc[b0 + i - 1]; m1n = Lc[b1 + i - 1]; }
+          const double xi = baReadLaneF64(i >= 64 ? x1 : x0, i & 63);
+          if (lane < i) x0 -= m0 * xi;
+          if (lane + 64 < i) x1 -= m1 * xi;
+        }
+      }
+    }
+    // undo the permutation
+    if (lane < n) xs[perm[lane]] = x0;
+    if (lane + 64 < n) xs[perm[lane + 64]] = x1;
+  }
+  __syncthreads();
+  if (ticks && tid == 0) ticks[6] = (int)(wall_clock64() - t_begin);   // back substitution, x in the original order
+}
+
+// Diagnostics / tests (dmvio_hip_ba_debug_solve): the solve of a given system HPassed x = b exactly as k_ba_solve runs it — Jacobi scaling (H_ii + 10)^-1/2, pivot order,
+// LDL^T, forward / back substitution — against dmvio_hip_ba_solve_ldlt on the host.  out: x[n] | perm[n] (as doubles) | branch | zero
+template <int MF>
+__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve_debug(const int n, const double* __restrict__ H, const double* __restrict__ b, const int exact_backsub, double* __restrict__ out) {
+  constexpr int QMAX = BASolveDims<MF>::QMAX;
+  extern __shared__ double s_mem[];
+  const int tid = threadIdx.x;
+  const int NP = (n * (n + 1)) / 2;
+  double* const Lc = s_mem;
+  double* const Tc = Lc + NP + 128;
+  double* const sv = Tc + NP + 128;
+  double* const dgS = sv + n;
+  double* const rhsS = dgS + n;
+  double* const rhs = rhsS + n;
+  double* const xs = rhs + n;
+  int* const perm = reinterpret_cast<int*>(xs + n);
+  __shared__ int s_flag[4];
+  int pr[QMAX];
+  baOwnedPairs<QMAX>(n, pr);
+#ifdef BA_SOLVE_PROBE
+  for (int pass = 0; pass < 3; pass++) {   // (the same work three times in one launch: what a cold instruction cache costs the first pass)
+  const long long tp0 = wall_clock64();
+  __syncthreads();
+#endif
+  if (tid < 4) s_flag[tid] = 0;
+  if (tid < n) { const double v = H[(size_t)tid * n + tid]; const double sc = 1.0 / sqrt(v + 10); sv[tid] = sc; dgS[tid] = sc * v * sc; rhsS[tid] = sc * b[tid]; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QMAX; q++) if (pr[q] >= 0) { const int i = pr[q] >> 8, j = pr[q] & 255; Lc[tid + q * BA_SOLVE_THREADS] = sv[i] * H[(size_t)i * n + j] * sv[j]; }
+  __syncthreads();
+  baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, exact_backsub, pr, nullptr, 0);
+#ifdef BA_SOLVE_PROBE
+  if (tid == 0) g_ba_probe[48 + pass] = wall_clock64() - tp0;
+  }
+#endif
+  if (tid < n) { out[tid] = sv[tid] * xs[tid]; out[n + tid] = (double)perm[tid]; }
+  if (tid == 0) { out[2 * n] = (double)s_flag[2]; out[2 * n + 1] = (double)s_flag[1]; }
+}
+
+// FINISH: only settle the pending decision (behind the last iteration's chain); the host reads the final state from the window's record.
+// Everything a sequential (order-preserving) loop reads is staged in LDS first: a dependent chain over global memory costs a memory latency per term; the global loads the
+// assembly needs (the stitched system's triangle, two values per owned pair) are issued at the top and land while the state is settled.
+template <int MF, bool FINISH>
+__global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restrict__ wins, const int iteration) {
+  constexpr bool finish = FINISH;
+  constexpr int QMAX = BASolveDims<MF>::QMAX;
+  constexpr bool ALIAS = BASolveDims<MF>::ALIAS_HM;
   BAWinDev& V = wins[blockIdx.x];
   BASolveDev& S = V.S;
   extern __shared__ double s_mem[];
@@ -170,35 +585,81 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   const int NP = (n * (n + 1)) / 2;
   const int hs = baSolveHmStride(n);
   double* const HMs = s_mem;          // n rows of stride hs: the marginalisation prior
-  double* const M = HMs + (size_t)n * hs;   // NP: scaled, permuted matrix -> L (strict lower) and D (diagonal)
-  double* const basis = M + NP;       // 7 x n
+  double* const Lc = ALIAS ? s_mem : HMs + (size_t)n * hs;   // NP: the scaled matrix (row-packed), then the permuted one (column-packed) -> L (strict lower) and D (diagonal)
+  double* const Tc = Lc + NP + 128;   // NP: D_k L(., k), column-packed like L
+  double* const basis = ALIAS ? s_mem + max((size_t)n * hs, 2 * ((size_t)NP + 128)) : Tc + NP + 128;   // 7 x n
   double* const d = basis + 7 * n;    // n: stacked delta (calib | frames)
   double* const bP = d + n;           // n: bM + HM delta
   double* const HLd = bP + n;         // n
   double* const sv = HLd + n;         // n
-  double* const rhs = sv + n;         // n: scaled right-hand side, permuted in place
+  double* const rhsS = sv + n;        // n: scaled right-hand side
+  double* const rhs = rhsS + n;       // n: ... permuted
   double* const xs = rhs + n;         // n
-  double* const dg = xs + n;          // n: diagonal copy for the pivot search
-  double* const tv = dg + n;          // n: calcMEnergy rows / projections
-  double* const col = tv + n;         // n: the current column of L
-  double* const bMs = col + n;        // n
-  int* const perm = reinterpret_cast<int*>(bMs + n);   // n ints (<= n doubles reserved)
-  double* const fst = bMs + 2 * n;    // F x 10 state | F x 10 state_zero | F x 10 state_backup | F x 8 prior (+ pad): 40 F
+  double* const dgS = xs + n;         // n: scaled diagonal (the pivot search's input)
+  double* const tv = dgS + n;         // n: calcMEnergy rows / projections
+  double* const bMs = tv + n;         // n
+  double* const dgV = bMs + n;        // n: the unscaled diagonal
+  int* const perm = reinterpret_cast<int*>(dgV + n);   // n ints (<= n doubles reserved)
+  double* const fst = dgV + 2 * n;    // F x 10 state | F x 10 state_zero | F x 10 state_backup | F x 8 prior (+ pad): 40 F
   double* const fzero = fst + 10 * F;
   double* const fbak = fzero + 10 * F;
   double* const fprior = fbak + 10 * F;
   __shared__ int s_flag[4];
   __shared__ double s_scal[8];
   __shared__ double s_cal[16];        // c_value, c_value_zero, c_value_backup, cPrior
-  __shared__ Pose s_w2c[BA_MAXF_CAP], s_c2w[BA_MAXF_CAP];
+  __shared__ Pose s_w2c[BA_MAXF_CAP], s_c2w[BA_MAXF_CAP], s_evalPT[BA_MAXF_CAP];
+  __shared__ float s_abexp[BA_MAXF_CAP], s_cPriorF[4];
   __shared__ double s_scaled[BA_MAXF_CAP][10];
   __shared__ float s_K[9], s_Ki[9];
   const long long t_begin = wall_clock64();
+#ifdef BA_SOLVE_TICKS
 #define SOLVE_TICK(i) do { if (tid == 0) S.ticks[i] = (int)(wall_clock64() - t_begin); } while (0)
+#else
+#define SOLVE_TICK(i) do { } while (0)
+#endif
 
   // ---- stage the window's solve state (coalesced) while thread 0 settles the pending decision (FullSystemOptimize.cpp:556-583 behind the accept test)
   const int haveM = S.haveM;
+  // (gathering the system from the stitched blocks inside this kernel — no gather launch — was built and measured: one workgroup issuing the ~140k loads of
+  // gatherValue costs 45 us against the 12 us of the 37-workgroup gather kernel it would replace)
+  const double* __restrict__ HA = V.sys;
+  const double* __restrict__ bA = V.sys + (size_t)n * n;
+  const double* __restrict__ Hsc = bA + n;
+  const double* __restrict__ bsc = Hsc + (size_t)n * n;
+  int pr[QMAX];
+  double hA[QMAX], hS[QMAX];          // the owned pairs' entries of H_A and H_sc
+  double bAi = 0.0, bsci = 0.0;
+  // the pair tables and the calibration members of the state / of the backup: one of the two sets is copied over the other below (loads up front, stores behind the decision)
+  constexpr int TQ = (BA_MAXF_CAP * (BA_MAXF_CAP - 1) * 14 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS;
+  const int npT = F * (F - 1) * 14;
+  float tcur[TQ], tbk[TQ], wcur = 0.f, wbk = 0.f;
+  {
+    const float* Tcur = &V.T.v[0][0];
+    const float* Tbk = &V.Tb.v[0][0];
+#pragma unroll
+    for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; tcur[q] = 0.f; tbk[q] = 0.f; if (i < npT) { tcur[q] = Tcur[i]; tbk[q] = Tbk[i]; } }
+    if (tid < 8) { wcur = (&V.W.fx)[tid]; wbk = (&V.Wb.fx)[tid]; }
+  }
+  // pointers of the window's record the tail goes through (read once, up front: a pointer fetched where it is used costs a memory round trip in front of the access)
+  double* const x_last = S.x_last;
+  float* const Xxc = V.X.xc;
+  float* const XxAd = V.X.xAd;
+  const float* const adHostF = S.adHostF;
+  const float* const adTargetF = S.adTargetF;
+  // resubstitution input o = tid (hh, t, c): its adjoint columns, constant over the call
+  float ahP[8], atP[8];
+  if (!finish && tid < F * F * 8) {
+    const int c = tid & 7, t = (tid >> 3) % F, hh = (tid >> 3) / F;
+    const size_t base = ((size_t)hh + (size_t)F * t) * 64;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { ahP[r] = adHostF[base + r * 8 + c]; atP[r] = adTargetF[base + r * 8 + c]; }
+  }
   if (!finish) {
+    baOwnedPairs<QMAX>(n, pr);
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) { hA[q] = 0.0; hS[q] = 0.0; if (pr[q] >= 0) { const size_t o = (size_t)(pr[q] >> 8) * n + (pr[q] & 255); hA[q] = HA[o]; hS[q] = Hsc[o]; } }
+    if (tid < n) { bAi = bA[tid]; bsci = bsc[tid]; }
+    else if (tid >= 128 && tid < 128 + n) { const size_t o = (size_t)(tid - 128) * n + (tid - 128); bAi = HA[o]; bsci = Hsc[o]; }   // (the diagonal, for the threads that scale it)
     if (haveM) {
       for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];
       for (int i = tid; i < n; i += BA_SOLVE_THREADS) bMs[i] = S.bM[i];
@@ -207,6 +668,10 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   }
   for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { const BAFrameDev& f = S.fr[i / 10]; fst[i] = f.state[i % 10]; fzero[i] = f.state_zero[i % 10]; fbak[i] = f.state_backup[i % 10]; }
   for (int i = tid; i < 8 * F; i += BA_SOLVE_THREADS) fprior[i] = S.fr[i >> 3].prior[i & 7];
+  // (what the tail reads of the window's record: staged here so that no load stands between the tail's stores)
+  for (int i = tid; i < 7 * F; i += BA_SOLVE_THREADS) reinterpret_cast<double*>(&s_evalPT[i / 7])[i % 7] = reinterpret_cast<const double*>(&S.fr[i / 7].evalPT)[i % 7];
+  if (tid >= 64 && tid < 64 + F) s_abexp[tid - 64] = S.fr[tid - 64].ab_exposure;
+  if (tid >= 128 && tid < 132) s_cPriorF[tid - 128] = S.cPriorF[tid - 128];
   if (tid < 4) { s_cal[tid] = S.c_value[tid]; s_cal[4 + tid] = S.c_value_zero[tid]; s_cal[8 + tid] = S.c_value_backup[tid]; s_cal[12 + tid] = S.cPrior[tid]; }
   if (tid == 0) {
     int acc = 1;
@@ -227,255 +692,99 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     s_scal[4] = S.lambda; s_scal[5] = S.lastL; s_scal[6] = S.lastM;
   }
   __syncthreads();
+  // every load issued above has landed by now: say so once — the stores below carry loaded values, and behind the branches in between the compiler would otherwise drain the
+  // memory pipeline in front of each of them (a store round trip apiece: 5 us)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   SOLVE_TICK(0);   // staged + settled
   const int prevAccepted = s_flag[0];
-  if (!prevAccepted) {
-    // loadSateBackup, frame / calibration part: the state and its pair tables go back to the backup's
-    for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { fst[i] = fbak[i]; S.fr[i / 10].state[i % 10] = fbak[i]; }
-    if (tid < 4) { s_cal[tid] = s_cal[8 + tid]; S.c_value[tid] = s_cal[8 + tid]; }
-    const int np = F * (F - 1) * 14;
+  SOLVE_TICK(12);
+  {
+    // accepted (or nothing pending): backupState — the backup takes the state; rejected: loadSateBackup — the state and its pair tables go back to the backup's
+    // (after which the backup equals the state: one copy either way)
     float* Tcur = &V.T.v[0][0];
-    const float* Tbk = &V.Tb.v[0][0];
-    for (int i = tid; i < np; i += BA_SOLVE_THREADS) Tcur[i] = Tbk[i];
-    if (tid == 0) { V.W.fx = V.Wb.fx; V.W.fy = V.Wb.fy; V.W.cx = V.Wb.cx; V.W.cy = V.Wb.cy; V.W.fxi = V.Wb.fxi; V.W.fyi = V.Wb.fyi; V.W.cxi = V.Wb.cxi; V.W.cyi = V.Wb.cyi; }
+    float* Tbk = &V.Tb.v[0][0];
+    if (prevAccepted) {
+      if (!finish) {
+        for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) fbak[i] = fst[i];   // (the record's copy of the backup is written at the very end: off the solve's path)
+        SOLVE_TICK(13);
+        if (tid < 4) s_cal[8 + tid] = s_cal[tid];
+        SOLVE_TICK(14);
+#pragma unroll
+        for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; if (i < npT) Tbk[i] = tcur[q]; }
+        if (tid < 8) (&V.Wb.fx)[tid] = wcur;
+        SOLVE_TICK(15);
+      }
+    } else {
+      for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { fst[i] = fbak[i]; S.fr[i / 10].state[i % 10] = fbak[i]; }
+      if (tid < 4) { s_cal[tid] = s_cal[8 + tid]; S.c_value[tid] = s_cal[8 + tid]; }
+#pragma unroll
+      for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; if (i < npT) Tcur[i] = tbk[q]; }
+      if (tid < 8) (&V.W.fx)[tid] = wbk;
+    }
   }
-  __syncthreads();
   if (finish) return;
-
-  // ---- backupState (frames, calibration) + the stacked delta (EnergyFunctional::setDeltaF as BAHost::setPrecalcValues keeps it)
-  for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { fbak[i] = fst[i]; S.fr[i / 10].state_backup[i % 10] = fst[i]; }
-  if (tid < 4) { s_cal[8 + tid] = s_cal[tid]; S.c_value_backup[tid] = s_cal[tid]; d[tid] = (double)(float)(s_cal[tid] - s_cal[4 + tid]); HLd[tid] = s_cal[12 + tid]; }
+  __syncthreads();
+  // ---- the stacked delta (EnergyFunctional::setDeltaF as BAHost::setPrecalcValues keeps it), the prior diagonal
+  if (tid < 4) { d[tid] = (double)(float)(s_cal[tid] - s_cal[4 + tid]); HLd[tid] = s_cal[12 + tid]; }
   for (int i = tid; i < 8 * F; i += BA_SOLVE_THREADS) {
     const int f = i >> 3, k = i & 7;
     d[4 + i] = fst[10 * f + k] - fzero[10 * f + k];
     HLd[4 + i] = fprior[i];
   }
-  if (tid == 0) {   // the backed-up state's tables for a relinearisation after a rejected step
-    V.Wb.fx = V.W.fx; V.Wb.fy = V.W.fy; V.Wb.cx = V.W.cx; V.Wb.cy = V.W.cy; V.Wb.fxi = V.W.fxi; V.Wb.fyi = V.W.fyi; V.Wb.cxi = V.W.cxi; V.Wb.cyi = V.W.cyi;
-  }
-  {
-    const int np = F * (F - 1) * 14;
-    const float* Tcur = &V.T.v[0][0];
-    float* Tbk = &V.Tb.v[0][0];
-    for (int i = tid; i < np; i += BA_SOLVE_THREADS) Tbk[i] = Tcur[i];
-  }
   __syncthreads();
-  // bM_top = bM + HM * delta (EnergyFunctional.cpp:864), row sums in index order
-  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {
-    double s = haveM ? bMs[i] : 0.0;
-    if (haveM) s = baSeqDot(s, HMs + (size_t)i * hs, d, n);
-    bP[i] = s;
-  }
-  SOLVE_TICK(1);   // backup, delta, bM_top
-  // ---- HFinal_top - H_sc / (1 + lambda), lower triangle (BAHost::solveSystem: (HL + HM) + HA, the diagonal times (1 + lambda), minus H_sc * fac)
+  // bM_top = bM + HM * delta (EnergyFunctional.cpp:864), row sums in index order — beside it the diagonal of HFinal_top - H_sc / (1 + lambda) (BAHost::solveSystem:
+  // (HL + HM) + HA, times (1 + lambda), minus H_sc * fac) and its Jacobi scaling
   const double lambda = s_scal[4];
   const double fac = 1.0f / (1 + lambda);
-  const double* __restrict__ HA = V.sys;
-  const double* __restrict__ bA = V.sys + (size_t)n * n;
-  const double* __restrict__ Hsc = bA + n;
-  const double* __restrict__ bsc = Hsc + (size_t)n * n;
-  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {   // diagonal first: the Jacobi scaling needs it
-    const size_t o = (size_t)i * n + i;
-    double v = (HLd[i] + (haveM ? HMs[(size_t)i * hs + i] : 0.0)) + HA[o];
+  if (tid < n) {
+    double s = haveM ? bMs[tid] : 0.0;
+    if (haveM) s = baSeqDot(s, HMs + (size_t)tid * hs, d, n);
+    bP[tid] = s;
+  } else if (tid >= 128 && tid < 128 + n) {
+    const int i = tid - 128;
+    double v = (HLd[i] + (haveM ? HMs[(size_t)i * hs + i] : 0.0)) + bAi;
     v *= (1 + lambda);
-    v = v - Hsc[o] * fac;
-    sv[i] = 1.0 / sqrt(v + 10);
-    dg[i] = v;
-  }
-  // the packed pairs this thread owns (tid, tid + 256, ...): (row << 8) | column
-  int pr[QMAX];
-  double acc[QMAX];                   // sum_{j < k} L(r, j) D(j) L(c, j) of the owned pairs, j ascending (ldltSolveTransposed's acc[r], one per column)
-  double val[QMAX];
-#pragma unroll
-  for (int q = 0; q < QMAX; q++) {
-    const int p = tid + q * BA_SOLVE_THREADS;
-    pr[q] = -1; acc[q] = 0.0; val[q] = 0.0;
-    if (p < NP) {
-      int r = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-      while (triIdx(r + 1, 0) <= p) r++;
-      while (triIdx(r, 0) > p) r--;
-      pr[q] = (r << 8) | (p - triIdx(r, 0));
-    }
+    v = v - bsci * fac;
+    const double sc = 1.0 / sqrt(v + 10);
+    sv[i] = sc;
+    dgV[i] = v;
+    dgS[i] = sc * v * sc;
   }
   __syncthreads();
+  SOLVE_TICK(1);   // backup, delta, bM_top, diagonal
+  // ---- the scaled system, row-packed (ALIAS: the prior's entries leave the shared room before the first element is written)
+  {
+    double hm[QMAX];
 #pragma unroll
-  for (int q = 0; q < QMAX; q++) {
-    if (pr[q] >= 0) {
-      const int i = pr[q] >> 8, j = pr[q] & 255;
-      double v;
-      if (i == j) v = dg[i];
-      else {
-        const size_t o = (size_t)i * n + j;
-        v = ((0.0 + (haveM ? HMs[(size_t)i * hs + j] : 0.0)) + HA[o]) - Hsc[o] * fac;
+    for (int q = 0; q < QMAX; q++) hm[q] = (pr[q] >= 0 && haveM) ? HMs[(size_t)(pr[q] >> 8) * hs + (pr[q] & 255)] : 0.0;
+    if (ALIAS) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) {
+      if (pr[q] >= 0) {
+        const int i = pr[q] >> 8, j = pr[q] & 255;
+        double v;
+        if (i == j) v = dgV[i];
+        else v = ((0.0 + hm[q]) + hA[q]) - hS[q] * fac;
+        Lc[tid + q * BA_SOLVE_THREADS] = sv[i] * v * sv[j];   // (sv_i * H_ij) * sv_j
       }
-      M[tid + q * BA_SOLVE_THREADS] = sv[i] * v * sv[j];   // (sv_i * H_ij) * sv_j
     }
   }
-  for (int i = tid; i < n; i += BA_SOLVE_THREADS) {
+  if (tid < n) {
+    const int i = tid;
     const double bL = i < 4 ? s_cal[12 + i] * d[i] : fprior[i - 4] * fst[10 * ((i - 4) >> 3) + ((i - 4) & 7)];   // prior * delta_prior (= state)
-    const double bF = ((bL + bP[i]) + bA[i]) - bsc[i];
-    rhs[i] = sv[i] * bF;
+    const double bF = ((bL + bP[i]) + bAi) - bsci;
+    rhsS[i] = sv[i] * bF;
   }
   __syncthreads();
   SOLVE_TICK(2);   // system assembled and scaled
-  // ---- pivot order: Eigen's LDLT (and BAHost::ldltSolveTransposed) picks the largest |diagonal| of the NOT YET UPDATED trailing diagonal (left-looking: step k only
-  // touches column k), first one on ties, and swaps it to position k — the whole sequence follows from the diagonal alone.  Without ties it is the descending order of
-  // |diagonal| (a rank count); with ties (or NaN) the selection-with-swaps is replayed step by step by wavefront 0.
-  // Group id of an element = the number of elements with a larger |diagonal| (equal for tied ones, ascending with descending value); the selection then walks the groups in
-  // order and inside a group always takes the member at the lowest CURRENT position >= k — two ballots per step on wavefront 0 (positions lane, lane + 64; n <= 128).
-  if (tid < n) dg[tid] = M[triIdx(tid, tid)];
-  __syncthreads();
-  if (tid < n) {
-    const double mine = fabs(dg[tid]);
-    int rank = 0, same = 0;
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
-      double o[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) o[q] = fabs(dg[j + q]);
-#pragma unroll
-      for (int q = 0; q < 8; q++) { rank += o[q] > mine ? 1 : 0; same += o[q] == mine ? 1 : 0; }
-    }
-    for (; j < n; j++) { const double o = fabs(dg[j]); rank += o > mine ? 1 : 0; same += o == mine ? 1 : 0; }
-    if (!(mine == mine)) s_flag[2] = 1;   // NaN on the diagonal: the step-by-step replay below
-    if (same > 1) s_flag[3] = 1;          // a tie: the selection order inside the group depends on the swaps before it
-    perm[tid] = (rank << 8) | same;       // group id, group size
-  }
-  __syncthreads();
-  const int needReplay = s_flag[2], haveTies = s_flag[3];
-  if (!needReplay && !haveTies) {
-    // all |diagonal| values distinct: step k selects the k-th largest whatever the swaps did to the others — the order is the rank itself
-    int rk = -1;
-    if (tid < n) rk = perm[tid] >> 8;
-    __syncthreads();
-    if (tid < n) perm[rk] = tid;
-  } else if (tid < 64) {
-    if (!needReplay) {
-      int g0 = tid < n ? perm[tid] : 0x7fffff00, g1 = tid + 64 < n ? perm[tid + 64] : 0x7fffff00;   // (group << 8) | size of the element at position lane / lane + 64
-      int p0 = tid, p1 = tid + 64;                                                                    // its original index
-      __builtin_amdgcn_wave_barrier();
-      int gcur = 0, left = 0, lastsize = 0;
-      for (int k = 0; k < n; k++) {
-        if (left == 0) gcur += lastsize;
-        const unsigned long long m0 = __ballot((g0 >> 8) == gcur && tid >= k), m1 = __ballot((g1 >> 8) == gcur && tid + 64 >= k);
-        const int big = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : k);
-        const int gb = big < 64 ? __builtin_amdgcn_readlane(g0, big) : __builtin_amdgcn_readlane(g1, big - 64);
-        const int pb = big < 64 ? __builtin_amdgcn_readlane(p0, big) : __builtin_amdgcn_readlane(p1, big - 64);
-        const int gk = k < 64 ? __builtin_amdgcn_readlane(g0, k) : __builtin_amdgcn_readlane(g1, k - 64);
-        const int pk = k < 64 ? __builtin_amdgcn_readlane(p0, k) : __builtin_amdgcn_readlane(p1, k - 64);
-        if (left == 0) { left = gb & 255; lastsize = left; }
-        left--;
-        if (big != k) {
-          if (tid == (big & 63)) { if (big < 64) { g0 = gk; p0 = pk; } else { g1 = gk; p1 = pk; } }
-          if (tid == (k & 63)) { if (k < 64) { g0 = gb; p0 = pb; } else { g1 = gb; p1 = pb; } }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (tid < n) perm[tid] = p0;
-      if (tid + 64 < n) perm[tid + 64] = p1;
-    } else {
-      for (int i = tid; i < n; i += 64) perm[i] = i;
-      __builtin_amdgcn_wave_barrier();
-      for (int k = 0; k < n; k++) {
-        double best = -1.0; int bi = 0x7fffffff;
-        for (int i = k + tid; i < n; i += 64) { const double v = fabs(dg[i]); if (v > best) { best = v; bi = i; } }   // ascending i per lane: strict > keeps the first
-        for (int off = 32; off > 0; off >>= 1) {
-          const double ov = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
-          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        if (bi == 0x7fffffff) bi = k;   // all NaN: no swap (fabs(NaN) > x is false in the host loop too)
-        if (tid == 0 && bi != k) { const double t = dg[k]; dg[k] = dg[bi]; dg[bi] = t; const int q = perm[k]; perm[k] = perm[bi]; perm[bi] = q; }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-  __syncthreads();
-  SOLVE_TICK(3);   // pivot order
-  // ---- the permuted system: P A P^T in place of A (all swaps applied up front: the same operands meet in the same order as with swaps at every step); every thread
-  // keeps its pairs' values in registers
-  int rq[QMAX], cq[QMAX];
-#pragma unroll
-  for (int q = 0; q < QMAX; q++) {
-    rq[q] = 0; cq[q] = -1;
-    if (pr[q] >= 0) {
-      rq[q] = pr[q] >> 8; cq[q] = pr[q] & 255;
-      const int a = perm[rq[q]], b = perm[cq[q]];
-      val[q] = M[a >= b ? triIdx(a, b) : triIdx(b, a)];
-    }
-  }
-  {
-    double rv = 0.0;
-    if (tid < n) rv = rhs[perm[tid]];
-    __syncthreads();
-    if (tid < n) rhs[tid] = rv;
-  }
-  __syncthreads();
-  SOLVE_TICK(4);   // permuted
-  // ---- LDL^T, column by column; the forward substitution rides along (d[i] -= L(i, j) d[j], j ascending).  Per step: [owners publish column k = A - acc] barrier
-  // [rows divide, forward-substitute, publish L(., k)] barrier [every pair (r, c > k) adds L(r, k) (D_k L(c, k)) to its sum].
-  for (int k = 0; k < n; k++) {
-#pragma unroll
-    for (int q = 0; q < QMAX; q++) if (cq[q] == k) col[rq[q]] = k > 0 ? val[q] - acc[q] : val[q];
-    __syncthreads();
-    const double akk = col[k];
-    const bool ok = fabs(akk) > 0;
-    if (k == 0 && !ok) { if (tid == 0) s_flag[1] = 1; break; }
-    if (tid >= k && tid < n) {
-      double l = col[tid];
-      if (tid > k) {
-        if (ok) l /= akk;
-        rhs[tid] -= l * rhs[k];
-      }
-      M[triIdx(tid, k)] = l;
-      tv[tid] = tid > k ? l : 0.0;    // L(., k) for the trailing update (col[] is rewritten by the next step's column phase)
-    }
-    __syncthreads();
-    // trailing update, branch-free: the loads of all owned pairs go out together; a pair outside the trailing block adds +0.0 (its sum is never -0.0: it starts at +0.0)
-    double lr[QMAX], lc[QMAX];
-#pragma unroll
-    for (int q = 0; q < QMAX; q++) { lr[q] = tv[rq[q]]; lc[q] = tv[cq[q] > 0 ? cq[q] : 0]; }
-#pragma unroll
-    for (int q = 0; q < QMAX; q++) { const double pq = lr[q] * (akk * lc[q]); acc[q] += cq[q] > k ? pq : 0.0; }
-    // (no barrier here: the next column phase writes col[], which the update above does not read; tv[] is rewritten only behind the next step's first barrier)
-  }
-  __syncthreads();
-  SOLVE_TICK(5);   // factorised + forward substitution
-  const bool zero = s_flag[1] != 0;
-  // ---- diagonal solve, back substitution
-  if (tid < n) {
-    const double dd = M[triIdx(tid, tid)];
-    double v = rhs[tid];
-    if (fabs(dd) > 2.2250738585072014e-308) v /= dd; else v = 0;
-    rhs[tid] = zero ? 0.0 : v;
-  }
-  __syncthreads();
-  if (!zero) {
-    if (S.exact_backsub) {
-      // the order of ldltSolveTransposed (row i subtracts L(j, i) x_j for j = i + 1 .. n - 1, ascending): one dependent chain of n^2 / 2 subtractions
-      if (tid == 0) for (int i = n - 1; i >= 0; i--) { double s = rhs[i]; for (int j = i + 1; j < n; j++) s -= M[triIdx(j, i)] * rhs[j]; rhs[i] = s; }
-    } else if (tid < 64) {
-      // column-oriented, one wavefront (no workgroup barrier per step): as soon as x_i stands, every row above subtracts its term (row r subtracts in the order
-      // i = n - 1 .. r + 1: the same terms, another association)
-      double x0 = tid < n ? rhs[tid] : 0.0, x1 = tid + 64 < n ? rhs[tid + 64] : 0.0;
-      double m0n = M[triIdx(n - 1, min(tid, n - 2))], m1n = M[triIdx(n - 1, min(tid + 64, n - 2))];   // row i of L for the next step, fetched one step ahead
-      for (int i = n - 1; i > 0; i--) {
-        const double m0 = m0n, m1 = m1n;
-        if (i > 1) { m0n = M[triIdx(i - 1, min(tid, i - 2))]; m1n = M[triIdx(i - 1, min(tid + 64, i - 2))]; }
-        const double src = i >= 64 ? x1 : x0;
-        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) & 0xffffffffll), i & 63), hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(src) >> 32), i & 63);
-        const double xi = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-        if (tid < i) x0 -= m0 * xi;
-        if (tid + 64 < i) x1 -= m1 * xi;
-      }
-      if (tid < n) rhs[tid] = x0;
-      if (tid + 64 < n) rhs[tid + 64] = x1;
-    }
-  }
-  __syncthreads();
-  SOLVE_TICK(6);   // back substitution
-  // undo the permutation and the scaling: x = S P^T x'
-  if (tid < n) xs[perm[tid]] = rhs[tid];
-  __syncthreads();
+#ifdef BA_SOLVE_TICKS
+  baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, S.exact_backsub, pr, S.ticks, t_begin);
+#else
+  baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, S.exact_backsub, pr, nullptr, t_begin);
+#endif
+  if (ALIAS && haveM) for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];   // (back into the shared room, for E_M below)
+  if (tid == 0) S.pivot_branch = s_flag[2];
+  // undo the scaling: x = S P^T x'
   if (tid < n) xs[tid] = sv[tid] * xs[tid];
   __syncthreads();
   // ---- orthogonalisation against the gauge nullspaces from iteration 2 on (SOLVER_ORTHOGONALIZE_X_LATER, EnergyFunctional.cpp:977-981; BAHost::orthogonalize)
@@ -486,20 +795,25 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     if (tid < n) { double proj = 0; for (int b = 0; b < nB; b++) proj += basis[(size_t)b * n + tid] * tv[b]; xs[tid] -= proj; }
     __syncthreads();
   }
-  if (tid < n) S.x_last[tid] = xs[tid];
+  if (tid < n) x_last[tid] = xs[tid];
   SOLVE_TICK(7);   // x
   // ---- resubstituteF_MT's inputs (BAHost::prepareResubstitute): xc, xAd[h F + t][c] = x_h . adHostF(:, c) + x_t . adTargetF(:, c) in fp32, sequential over r
-  if (tid < 4) V.X.xc[tid] = (float)xs[tid];
+  if (tid < 4) Xxc[tid] = (float)xs[tid];
   for (int o = tid; o < F * F * 8; o += BA_SOLVE_THREADS) {
     const int c = o & 7, t = (o >> 3) % F, hh = (o >> 3) / F;
-    const size_t base = ((size_t)hh + (size_t)F * t) * 64;
     float ah[8], at[8];
+    if (o == tid) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) { ah[r] = S.adHostF[base + r * 8 + c]; at[r] = S.adTargetF[base + r * 8 + c]; }   // sixteen loads in flight, then the ordered sums
+      for (int r = 0; r < 8; r++) { ah[r] = ahP[r]; at[r] = atP[r]; }   // (fetched at the top)
+    } else {
+      const size_t base = ((size_t)hh + (size_t)F * t) * 64;
+#pragma unroll
+      for (int r = 0; r < 8; r++) { ah[r] = adHostF[base + r * 8 + c]; at[r] = adTargetF[base + r * 8 + c]; }   // sixteen loads in flight, then the ordered sums
+    }
     float s1 = 0, s2 = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) { s1 += (float)xs[4 + 8 * hh + r] * ah[r]; s2 += (float)xs[4 + 8 * t + r] * at[r]; }
-    V.X.xAd[((size_t)F * hh + t) * 8 + c] = s1 + s2;
+    XxAd[((size_t)F * hh + t) * 8 + c] = s1 + s2;
   }
   // ---- doStepFromBackup, frames and calibration (stepfac 1): value = backup + step, step = -x
   if (tid < 4) {
@@ -537,11 +851,11 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   }
   if (tid >= 64 && tid < 64 + F) {   // FrameHessian::setState: PRE_worldToCam = exp(state_scaled) * worldToCam_evalPT (HessianBlocks.h:199-214)
     const int f = tid - 64;
-    const Pose w = poseMul(poseExp(s_scaled[f]), S.fr[f].evalPT);
+    const Pose w = poseMul(poseExp(s_scaled[f]), s_evalPT[f]);
     s_w2c[f] = w; s_c2w[f] = poseInv(w);
   }
   // E_M of the stepped state, rows in index order (independent of the poses: runs beside the exponentials)
-  if (tid >= 128 && tid < 128 + n && tid < BA_SOLVE_THREADS) {
+  if (tid >= 128 && tid < 128 + n) {
     const int i = tid - 128;
     double t = 0;
     if (haveM) t = baSeqDot(2 * bMs[i], HMs + (size_t)i * hs, d, n);
@@ -565,7 +879,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     for (int i = 0; i < 9; i++) v[i] = KRKi[i];
     for (int r = 0; r < 3; r++) v[9 + r] = s_K[r * 3 + 0] * tf[0] + s_K[r * 3 + 1] * tf[1] + s_K[r * 3 + 2] * tf[2];
     double aff[2];
-    baAffFromTo(S.fr[hh].ab_exposure, S.fr[t].ab_exposure, s_scaled[hh][6], s_scaled[hh][7], s_scaled[t][6], s_scaled[t][7], aff);
+    baAffFromTo(s_abexp[hh], s_abexp[t], s_scaled[hh][6], s_scaled[hh][7], s_scaled[t][6], s_scaled[t][7], aff);
     v[12] = (float)aff[0]; v[13] = (float)aff[1];
   }
   if (tid == BA_SOLVE_THREADS - 1) {
@@ -576,14 +890,19 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     double E = 0;
     for (int f = 0; f < F; f++) for (int i = 0; i < 8; i++) E += fst[10 * f + i] * fprior[8 * f + i] * fst[10 * f + i];
     float ec = 0;
-    for (int i = 0; i < 4; i++) { const float cd = (float)d[i]; ec += cd * S.cPriorF[i] * cd; }
+    for (int i = 0; i < 4; i++) { const float cd = (float)d[i]; ec += cd * s_cPriorF[i] * cd; }
     const double newL = E + ec;
     S.newL = newL; S.newM = s;
     V.D.lastL = s_scal[5]; V.D.lastM = s_scal[6]; V.D.newL = newL; V.D.newM = s;
     S.stepped = 1;
+#ifdef BA_SOLVE_TICKS
     S.ticks[11] = (int)(wall_clock64() - t_begin);   // energies
+#endif
   }
   SOLVE_TICK(10);  // pair tables (thread 0's share)
+  // backupState's copy in the window's record (what a rejected step restores from, and what the host reads back)
+  for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) S.fr[i / 10].state_backup[i % 10] = fbak[i];
+  if (tid < 4) S.c_value_backup[tid] = s_cal[8 + tid];
 #undef SOLVE_TICK
 }
 

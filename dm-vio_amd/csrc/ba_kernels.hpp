@@ -1680,22 +1680,10 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&host->gticket[blockIdx.x], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// element t of one stitched system — t < n^2: H[t / n][t % n], then b[t - n^2] — sc: the Schur-complement system (H_sc, b_sc) instead of the top system (H_A, b_A)
 template <int MF>
-__device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
-                                              const int nNum, double* __restrict__ out, const int tid, const bool sys) {
-  // sys: `out` is host-coherent memory the host polls — write through (system-scope stores) instead of a system-scope fence per thread
-  auto put = [&](const int i, const double v) { if (sys) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else out[i] = v; };
+__device__ __forceinline__ double gatherValue(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int t, const bool sc) {
   const int n = 4 + 8 * F, F2 = F * F;
-  const int per = n * n + n;
-  if (tid == 2 * per) {   // resInA: number of active residuals that entered the top accumulation, appended to the system
-    int cnt = 0;
-    for (int k = 0; k < nNum; k++) cnt += numTop[k];
-    put(2 * per, (double)cnt);
-    return;
-  }
-  if (tid >= 2 * per) return;
-  const bool sc = tid >= per;
-  const int t = sc ? tid - per : tid;
   // sum_{q < F} base[q * stride] in index order; the (up to 8) loads are issued together, only the adds are sequential
   auto sumF = [&](const double* __restrict__ base, const int stride) {
     double v[MF];
@@ -1732,7 +1720,6 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
         val += sumF(S.scHT + (bi + bj * F2) * 64 + r * 8 + c, F * 64);
       }
     }
-    put((sc ? per : 0) + t, val);
   } else {
     const int row = t - n * n;
     if (row < 4) {
@@ -1743,8 +1730,26 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
       if (!sc) { val = S.topBH[f * 8 + r]; val += sumF(S.topBT + (F * f) * 8 + r, 8); }
       else { val = sumF(S.scBH + f * 8 + r, F * 8); val += sumF(S.scBT + (F * f) * 8 + r, 8); }
     }
-    put((sc ? per : 0) + n * n + row, val);
   }
+  return val;
+}
+template <int MF>
+__device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
+                                              const int nNum, double* __restrict__ out, const int tid, const bool sys) {
+  // sys: `out` is host-coherent memory the host polls — write through (system-scope stores) instead of a system-scope fence per thread
+  auto put = [&](const int i, const double v) { if (sys) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else out[i] = v; };
+  const int n = 4 + 8 * F;
+  const int per = n * n + n;
+  if (tid == 2 * per) {   // resInA: number of active residuals that entered the top accumulation, appended to the system
+    int cnt = 0;
+    for (int k = 0; k < nNum; k++) cnt += numTop[k];
+    put(2 * per, (double)cnt);
+    return;
+  }
+  if (tid >= 2 * per) return;
+  const bool sc = tid >= per;
+  const int t = sc ? tid - per : tid;
+  put(tid, gatherValue<MF>(F, nsC, accC, S, t, sc));
 }
 
 // ------------------------------------------------------------------------------------------------ back-substitution / stepping

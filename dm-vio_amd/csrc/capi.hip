@@ -929,7 +929,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   // Up to 128 problems -> cluster mode: C workgroups of 256 threads per problem (latency; measured on MI355X: B=1 240 us with C=8 vs
   // 367 us for one 1024-thread workgroup); more -> one workgroup per problem (512 threads up to 512 problems, then 256 threads,
   // four resident per CU: throughput).
-  // Overridable for experiments: DMVIO_HIP_LM_THREADS / DMVIO_HIP_LM_WAVES / DMVIO_HIP_LM_CLUSTER.
+  // Overridable for experiments: dmvio_hip_tracker_set_launch_shape (lm_threads / lm_waves / lm_cluster).
   int C = 1;
   if (t->lm_cluster_override > 0) C = t->lm_cluster_override;
   else if (!t->lm_threads_override) C = clusterSize(B, t->dev.pc_n[0]);
@@ -1007,7 +1007,7 @@ int dmvio_hip_tracker_track_batch_launch(dmvio_hip_tracker* t) {
   else if (T == 256 && W >= 6) DMV_LAUNCH_LM(256, 6);
   else if (T == 256) DMV_LAUNCH_LM(256, 4);
   else if (T == 128 && C == 1) DMV_LAUNCH_LM(128, 4);
-  else return failmsg("track_batch_launch: DMVIO_HIP_LM_THREADS must be 128/256/512/1024 (cluster mode: 256)");
+  else return failmsg("track_batch_launch: lm_threads (dmvio_hip_tracker_set_launch_shape) must be 128/256/512/1024 (cluster mode: 256)");
 #undef DMV_LAUNCH_LM
 #undef DMV_LAUNCH_LM_TILED
   HIPCHK(hipGetLastError());
@@ -1188,7 +1188,7 @@ int dmvio_hip_tracker_set_template_order(dmvio_hip_tracker* t, int row_major) {
   return 0;
 }
 // Kernel of FULL batches (>= 512 problems, one 256-thread evaluation group per problem): 0 = k_track_lm (four wavefronts per problem: they evaluate, then three wait
-// while the first solves), 1 = k_track_lm_pp (five wavefronts hold two problems: the control step of one runs beside the evaluation of the other; per problem the same
+// while the first solves), 1 = k_track_lm_pp (a four-wavefront workgroup holds two problems: wavefront 0 runs the control step of one, then joins the evaluation of the other; per problem the same
 // arithmetic in the same order — identical results).
 int dmvio_hip_tracker_set_batch_kernel(dmvio_hip_tracker* t, int mode) {
   if (!t || mode < 0 || mode > 1) return failmsg("tracker_set_batch_kernel: 0 or 1");

@@ -469,7 +469,8 @@ static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = t
     if (!wait || gate != BA_GATE_ALWAYS) return failmsg("ba: a graph with residuals kept linearised is accumulated synchronously");
     return accumulateLin(b, backup_points, apply_first);
   }
-  if (apply_first) b->fullJ_applied = b->keep_fullJ;
+  // (the flag describes the DEVICE's state: a gated chain may not run its applyRes, and a chain without one leaves the buffer as the last linearisation wrote it)
+  if (apply_first) b->fullJ_applied = gate == BA_GATE_ALWAYS ? b->keep_fullJ : false;
   if (!sums_fresh) hipLaunchKernelGGL(k_ba_point_sums, dim3(b->n_pt8_blocks), dim3(256), 0, b->stream, b->W, b->P, b->Rs, backup_points ? 1 : 0, apply_first ? 1 : 0,
                                       (const BACtl*)b->d_ctl, gate, (backup_points && b->vio) ? b->h_idepth_backup : (float*)nullptr);
   BA_PROF(b, 2);
@@ -2091,12 +2092,51 @@ int dmvio_hip_ba_batch_last_ms(dmvio_hip_ba_batch* B, float ms3[3]) {
   ms3[0] = B->last_ms[0]; ms3[1] = B->last_ms[1]; ms3[2] = B->last_ms[2];
   return 0;
 }
-// diagnostics: in-kernel timeline of window 0's last k_ba_solve of the last call, 100 MHz ticks since the kernel started: staged + settled, delta + bM_top, system
+// diagnostics: in-kernel timeline of window 0's last k_ba_solve of the last call, 100 MHz ticks since the kernel started: staged + settled, delta + bM_top + diagonal, system
 // assembled, pivot order, permuted, factorised, back-substituted, x, resubstitution inputs + stepped states, exponentials, pair tables, energies
 int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* B, int ticks12[12]) {
   if (!B || !ticks12) return failmsg("ba_batch: null argument");
   std::lock_guard<std::mutex> lk(B->mu);
   for (int i = 0; i < 12; i++) ticks12[i] = B->h_wins[0].S.ticks[i];
+  if (getenv("DMVIO_HIP_BA_TIMING")) fprintf(stderr, "k_ba_solve extra ticks: %d %d %d %d\n", B->h_wins[0].S.ticks[12], B->h_wins[0].S.ticks[13], B->h_wins[0].S.ticks[14], B->h_wins[0].S.ticks[15]);
+  return 0;
+}
+// diagnostics: how window w's last k_ba_solve of the last call found its pivot order — 0 = ranks of the scaled diagonal (all |values| distinct), 1 = ties replayed
+// (selection with swaps on one wavefront), 2 = a NaN on the diagonal (the literal loop)
+int dmvio_hip_ba_batch_last_pivot_branch(dmvio_hip_ba_batch* B, int w, int* branch) {
+  if (!B || !branch || w < 0 || w >= B->cap) return failmsg("ba_batch_last_pivot_branch: bad argument");
+  std::lock_guard<std::mutex> lk(B->mu);
+  *branch = B->h_wins[w].S.pivot_branch;
+  return 0;
+}
+// Tests / diagnostics: the solve of EnergyFunctional.cpp:971-973 for a GIVEN system on the device, exactly as k_ba_solve runs it (Jacobi scaling (H_ii + 10)^-1/2, Eigen's
+// pivot order, LDL^T, forward / back substitution on one 512-thread workgroup) — the device counterpart of dmvio_hip_ba_solve_ldlt.  HPassed: n x n row-major (the lower
+// triangle is read), n = 4 + 8 F <= 100.  x_out[n]; perm_out[n] (may be NULL): the index the transpositions bring to position k; branch_out (may be NULL): 0 ranks /
+// 1 ties / 2 NaN; zero_out (may be NULL): the matrix's first pivot was zero (x = 0).  exact_backsub as dmvio_hip_ba_batch_set_exact_backsub.
+int dmvio_hip_ba_debug_solve(dmvio_hip_ctx* ctx, int n, const double* HPassed, const double* b_in, int exact_backsub, double* x_out, int* perm_out, int* branch_out, int* zero_out) {
+  if (!ctx || !HPassed || !b_in || !x_out || n < 2 || n > 4 + 8 * BA_MAXF_CAP) return failmsg("ba_debug_solve: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  double* d = nullptr;
+  const size_t nin = (size_t)n * n + n, nout = 2 * (size_t)n + 2;
+  HIPCHK(hipMalloc((void**)&d, sizeof(double) * (nin + nout)));
+  std::vector<double> h(nin + nout, 0.0);
+  memcpy(h.data(), HPassed, sizeof(double) * n * n); memcpy(h.data() + (size_t)n * n, b_in, sizeof(double) * n);
+  hipError_t e = hipMemcpy(d, h.data(), sizeof(double) * nin, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const bool small = n <= 4 + 8 * BA_MAXF;
+    const size_t lds = sizeof(double) * baSolveCoreLdsDoubles(n);
+    if (small) hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, d, d + (size_t)n * n, exact_backsub, d + nin);
+    else hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF_CAP>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, d, d + (size_t)n * n, exact_backsub, d + nin);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h.data() + nin, d + nin, sizeof(double) * nout, hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return failmsg((std::string("ba_debug_solve: ") + hipGetErrorString(e)).c_str());
+  const double* o = h.data() + nin;
+  memcpy(x_out, o, sizeof(double) * n);
+  if (perm_out) for (int i = 0; i < n; i++) perm_out[i] = (int)o[n + i];
+  if (branch_out) *branch_out = (int)o[2 * n];
+  if (zero_out) *zero_out = (int)o[2 * n + 1];
   return 0;
 }
 // 0 (default): a batch of >= 4 windows is cut into up to three groups on three streams (at least two windows each), their launches interleaved; k >= 1: at most k groups
@@ -2130,6 +2170,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   if (F < 2) { for (int w = 0; w < Wn; w++) { if (rmse) rmse[w] = 0; if (iterations) iterations[w] = 0; if (finalEnergy) finalEnergy[w] = 0; } return 0; }
   if (F < 3) mnumOptIts = 20;
   if (F < 4) mnumOptIts = 15;
+  if (mnumOptIts < 1) return failmsg("ba_optimize_batch: mnumOptIts < 1 (the device-resident loop writes the trace's first row in its first solve)");
   hipStream_t s = B->stream;
   struct StreamSwap {   // the handles' own entry points (table uploads, the reset kernel) enqueue on the batch's stream for the duration of the call
     std::vector<std::pair<dmvio_hip_ba*, hipStream_t>> saved;
@@ -2148,6 +2189,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     BAHost& H = b->H;
     b->vio = nullptr; b->vio_opt = nullptr; b->dynW = 1.0; H.gtsam = false;
     b->pending_reject = false; b->pending_trace = -1; b->sums_fresh = false; b->sys_ready = false;
+    b->fullJ_applied = false;   // the batched linearisations relinearise and apply every residual without writing d_fullJ: what the buffer holds is no longer the applied state's
     if (int r = resolveTh(b)) return r;
     if (b->adj_dirty) { if (int r = uploadAdjoints(b)) return r; }
     // (the precalc table, the thresholds and the activation of all residuals travel with the batch: one upload, one launch for all windows)
@@ -2217,7 +2259,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(B->d_tab, B->h_tab, B->tab_stride * (size_t)(Wn - 1) + used_tab, hipMemcpyHostToDevice, s));
   const FrameStore fs = B->ctx->fs;
-  const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n, F);
+  const size_t solveLds = sizeof(double) * baSolveLdsDoubles(n, F, F <= BA_MAXF ? BASolveDims<BA_MAXF>::ALIAS_HM : BASolveDims<BA_MAXF_CAP>::ALIAS_HM);
   // Up to three groups of windows by default (at most BA_BATCH_STREAMS on request), one stream each, from 4 windows on: k_ba_solve is one workgroup per window (a 100 us latency chain on a handful of CUs), so while one
   // group solves, the other groups' linearisations / accumulations fill the device.  The groups share nothing.  Their launches are enqueued STAGE BY STAGE (initial chain of
   // every group, iteration 0 of every group, ...): a stream whose commands the host has not submitted yet cannot overlap with anything (measured: with the groups enqueued one
@@ -2239,8 +2281,13 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     else hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dwq, fs, kind);
   };
   auto solve = [&](const Grp& q, const int it, const int finish) {
-    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it, finish);
-    else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it, finish);
+    if (finish) {
+      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF, true>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
+      else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP, true>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
+    } else {
+      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_solve<BA_MAXF, false>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
+      else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP, false>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
+    }
   };
   auto chain = [&](const Grp& q, const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
     const BAWinDev* dwq = B->d_wins + q.w0;

@@ -162,7 +162,8 @@ int dmvio_hip_tracker_set_launch_shape(dmvio_hip_tracker* trk, int eval_blocks, 
 /* 1 (default): a host-driven LM (dmvio_hip_tracker_track of one frame, dmvio_hip_tracker_track_vio) posts its evaluations to the resident evaluation server; 0: one launch each */
 int dmvio_hip_tracker_set_eval_server(dmvio_hip_tracker* trk, int on);
 /* Kernel of full batches (>= 512 alignment problems per launch): 0 = four wavefronts per problem (they evaluate, then three wait while the first runs the LM control step),
- * 1 = five wavefronts hold two problems, the control step of one beside the evaluation of the other, problems dealt out to a persistent grid by a device-wide counter.
+ * 1 = a four-wavefront workgroup holds two problems: wavefront 0 runs the control step of one problem and then joins the other three in the evaluation of the other;
+ * problems dealt out to a persistent grid by a device-wide counter.
  * Per problem the same arithmetic in the same order: identical results. */
 int dmvio_hip_tracker_set_batch_kernel(dmvio_hip_tracker* trk, int mode);
 /* Storage order of the template points (from the next dmvio_hip_tracker_set_ref on): 0 (default) = 8x8-pixel tiles, Z-ordered inside 16x16 blocks; 1 = the reference's
@@ -546,6 +547,13 @@ int dmvio_hip_ba_batch_set_streams(dmvio_hip_ba_batch* batch, int streams);
 int dmvio_hip_ba_batch_set_linearize_lanes(dmvio_hip_ba_batch* batch, int lanes);
 /* diagnostics: in-kernel timeline (100 MHz ticks since kernel start) of the first window's k_ba_solve of the LAST iteration of the last call, 12 phase boundaries */
 int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* batch, int ticks12[12]);
+/* diagnostics: how window w's last k_ba_solve of the last call found Eigen's pivot order (EnergyFunctional.cpp:971-973, ldlt()): 0 = ranks of the scaled diagonal (all
+ * |values| distinct), 1 = ties replayed (selection with swaps), 2 = NaN on the diagonal (the literal loop) */
+int dmvio_hip_ba_batch_last_pivot_branch(dmvio_hip_ba_batch* batch, int w, int* branch);
+/* Tests / diagnostics: the solve of EnergyFunctional.cpp:971-973 (diagonal pre-scaling, pivoted LDL^T) for a GIVEN n x n system on the device, exactly as the device-resident
+ * loop's k_ba_solve runs it — the device counterpart of dmvio_hip_ba_solve_ldlt.  HPassed row-major (lower triangle read), 2 <= n <= 100.  perm_out[n]: the index the
+ * transpositions bring to position k; branch_out: as dmvio_hip_ba_batch_last_pivot_branch; zero_out: the first pivot was zero (x = 0).  The three may be NULL. */
+int dmvio_hip_ba_debug_solve(dmvio_hip_ctx* ctx, int n, const double* HPassed, const double* b_in, int exact_backsub, double* x_out, int* perm_out, int* branch_out, int* zero_out);
 /* dmvio_hip_ba_optimize of this handle through the device-resident loop (a batch of one); 0 (default) = the host-driven loop */
 int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* ba, int on);
 /* EnergyFunctional::lastX of the window's last solve (n = 4 + 8F doubles; x = MINUS the step) */
