@@ -64,7 +64,7 @@ struct BAWinDev {
 
 // ------------------------------------------------------------------------------------------------ batched forms of the kernels of ba_kernels.hpp
 // window = blockIdx.y; a workgroup beyond its window's own grid leaves at once (grid.x is the largest count of the batch)
-enum { BA_LINB_INITIAL = 0, BA_LINB_STEPPED = 1, BA_LINB_RESTORE = 2, BA_LINB_FINAL = 3 };
+enum { BA_LINB_INITIAL = 0, BA_LINB_STEPPED = 1, BA_LINB_RESTORE = 2, BA_LINB_FINAL = 3, BA_LINB_STEPPED_DONE = 4 };   // _DONE: the step was taken by k_ba_resubstitute_b
 // (three workgroups per CU instead of two: the batched grid is throughput-bound by resident waves; 170 -> <= 168 registers.  Four — 128 registers, 172 B of scratch per
 // lane — was measured slower: 364 vs 250 us for 32 windows; k_ba_accumulate_b: six waves per SIMD, 88 -> 80 registers, 153 -> 88 us for 16 windows; seven spill)
 __global__ void __launch_bounds__(LIN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ba_linearize_b(const BAWinDev* __restrict__ wins, const FrameStore fs, const int kind) {
@@ -84,9 +84,36 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize_b1(const BAWinDev*
   if ((int)blockIdx.x >= V.n_lin1_blocks) return;
   BADecide D = V.D;
   D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1;
-  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin1_blocks, V.n_lin_blocks); }
-  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks); }
-  else { D.mode = 0; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks); }
+  extern __shared__ float s_patch[];   // LIN_THREADS x BA_PATCH_STRIDE floats: every lane's 8x8 window of its target image (then the decision pass's key staging)
+  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if (kind == BA_LINB_STEPPED_DONE) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else { D.mode = 0; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+}
+// What follows a stepped linearisation's decision, in ONE launch (a gated-off launch still costs ~4.5 us of dispatch): a window whose step was REJECTED restores its points
+// and relinearises the backed-up state (BA_LINB_RESTORE above); a window whose step was ACCEPTED runs applyRes + the per-point sums of the new state (k_ba_point_sums_b;
+// what = 0) or, behind the last iteration, applyRes alone (k_ba_apply_b; what = 1).  The decision does not change while this kernel runs (the restore's decision pass
+// writes the energy only).  LIN1: the one-lane-per-residual form of the relinearisation.
+template <bool LIN1>
+__global__ void __launch_bounds__(LIN_THREADS) k_ba_post_decide_b(const BAWinDev* __restrict__ wins, const FrameStore fs, const int what) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if (!baGateClosed(V.ctl, BA_GATE_ACCEPTED)) {
+    if (what == 0) { if ((int)blockIdx.x < V.n_pt8_blocks) baPointSumsBody(V.W, V.P, V.Rs, 1, 1, V.ctl, BA_GATE_ALWAYS, nullptr); }
+    else if ((int)blockIdx.x < V.n_res_blocks) baApplyBody(V.W.R, V.Rs, nullptr, 0);
+    return;
+  }
+  BADecide D = V.D;
+  D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1; D.mode = 2;
+  extern __shared__ float s_patch[];
+  if (LIN1) { if ((int)blockIdx.x < V.n_lin1_blocks) baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if ((int)blockIdx.x < V.n_lin_blocks) baLinearizeBody(V.Wb, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks);
+}
+// resubstituteF_MT + the points' share of doStepFromBackup for every window of a launch (k_ba_resubstitute: eight lanes per point, the loads of a point's residuals side by
+// side) — in front of the one-lane linearisation, whose own form of it walks a point's residuals one dependent load pair after the other
+__global__ void __launch_bounds__(256) k_ba_resubstitute_b(const BAWinDev* __restrict__ wins) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if ((int)blockIdx.x >= V.n_pt8_blocks) return;
+  baResubstituteBody(V.W, V.P, V.Rs, V.X.xc, V.X.xAd, 1);
 }
 __global__ void __launch_bounds__(256) k_ba_reset_oob_b(const BAWinDev* __restrict__ wins) {
   const BAWinDev& V = wins[blockIdx.y];
@@ -612,11 +639,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   __shared__ double s_scaled[BA_MAXF_CAP][10];
   __shared__ float s_K[9], s_Ki[9];
   const long long t_begin = wall_clock64();
-#ifdef BA_SOLVE_TICKS
-#define SOLVE_TICK(i) do { if (tid == 0) S.ticks[i] = (int)(wall_clock64() - t_begin); } while (0)
-#else
-#define SOLVE_TICK(i) do { } while (0)
-#endif
+#define SOLVE_TICK(i) do { if (tid == 0) S.ticks[i] = (int)(wall_clock64() - t_begin); } while (0)   // (measured: no effect on the kernel's duration)
 
   // ---- stage the window's solve state (coalesced) while thread 0 settles the pending decision (FullSystemOptimize.cpp:556-583 behind the accept test)
   const int haveM = S.haveM;
@@ -697,7 +720,6 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   SOLVE_TICK(0);   // staged + settled
   const int prevAccepted = s_flag[0];
-  SOLVE_TICK(12);
   {
     // accepted (or nothing pending): backupState — the backup takes the state; rejected: loadSateBackup — the state and its pair tables go back to the backup's
     // (after which the backup equals the state: one copy either way)
@@ -706,14 +728,11 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     if (prevAccepted) {
       if (!finish) {
         for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) fbak[i] = fst[i];   // (the record's copy of the backup is written at the very end: off the solve's path)
-        SOLVE_TICK(13);
-        if (tid < 4) s_cal[8 + tid] = s_cal[tid];
-        SOLVE_TICK(14);
-#pragma unroll
+              if (tid < 4) s_cal[8 + tid] = s_cal[tid];
+      #pragma unroll
         for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; if (i < npT) Tbk[i] = tcur[q]; }
         if (tid < 8) (&V.Wb.fx)[tid] = wcur;
-        SOLVE_TICK(15);
-      }
+            }
     } else {
       for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { fst[i] = fbak[i]; S.fr[i / 10].state[i % 10] = fbak[i]; }
       if (tid < 4) { s_cal[tid] = s_cal[8 + tid]; S.c_value[tid] = s_cal[8 + tid]; }
@@ -777,11 +796,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   }
   __syncthreads();
   SOLVE_TICK(2);   // system assembled and scaled
-#ifdef BA_SOLVE_TICKS
   baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, S.exact_backsub, pr, S.ticks, t_begin);
-#else
-  baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, S.exact_backsub, pr, nullptr, t_begin);
-#endif
   if (ALIAS && haveM) for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];   // (back into the shared room, for E_M below)
   if (tid == 0) S.pivot_branch = s_flag[2];
   // undo the scaling: x = S P^T x'
@@ -895,9 +910,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     S.newL = newL; S.newM = s;
     V.D.lastL = s_scal[5]; V.D.lastM = s_scal[6]; V.D.newL = newL; V.D.newM = s;
     S.stepped = 1;
-#ifdef BA_SOLVE_TICKS
     S.ticks[11] = (int)(wall_clock64() - t_begin);   // energies
-#endif
   }
   SOLVE_TICK(10);  // pair tables (thread 0's share)
   // backupState's copy in the window's record (what a rejected step restores from, and what the host reads back)

@@ -186,12 +186,19 @@ __device__ __forceinline__ void baPackBlock(const BADecide& D, const int nblocks
 }
 #define BA_DECIDE_KEYS 4096
 // executed by all 256 threads of the last workgroup of a linearisation
-__device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nblocks, const long long t_start) {
-  __shared__ unsigned int s_keys[BA_DECIDE_KEYS];
-  __shared__ unsigned int s_scan[256];
-  __shared__ double s_red[256];
-  __shared__ unsigned int s_cnt, s_prefix, s_k;
-  __shared__ double s_E;
+// EXT_KEYS: the radix select's key staging (16 KB) lives in LDS the calling kernel no longer needs (k_ba_linearize_b1: its pattern patches) instead of an array of its own
+template <bool EXT_KEYS = false>
+__device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nblocks, const long long t_start, unsigned int* ext_keys = nullptr) {
+  __shared__ unsigned int s_keys_own[EXT_KEYS ? 1 : BA_DECIDE_KEYS];
+  __shared__ unsigned int s_scan_own[EXT_KEYS ? 1 : 256];
+  __shared__ double s_red_own[EXT_KEYS ? 1 : 256];
+  __shared__ unsigned int s_misc_own[EXT_KEYS ? 1 : 8];
+  unsigned int* const s_keys = EXT_KEYS ? ext_keys : s_keys_own;                       // BA_DECIDE_KEYS
+  unsigned int* const s_scan = EXT_KEYS ? ext_keys + BA_DECIDE_KEYS : s_scan_own;      // 256
+  double* const s_red = EXT_KEYS ? reinterpret_cast<double*>(ext_keys + BA_DECIDE_KEYS + 256) : s_red_own;   // 256 doubles
+  unsigned int* const s_misc = EXT_KEYS ? ext_keys + BA_DECIDE_KEYS + 256 + 512 : s_misc_own;               // 8
+  unsigned int &s_cnt = s_misc[0], &s_prefix = s_misc[1], &s_k = s_misc[2];
+  double& s_E = *reinterpret_cast<double*>(s_misc + 4);
   const int tid = threadIdx.x;
   const long long tk0 = wall_clock64();
   long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
@@ -313,6 +320,7 @@ __device__ __forceinline__ void baDecideBlock(const BADecide& D, const int nbloc
 // the pattern are formed in pattern order — ((((0 + v0) + v1) + v2) ...) — by seven DPP row-shift adds per quantity, so every
 // value is bit-identical to the reference's sequential loop while the eight gathers of a residual are in flight together.
 #define LIN_THREADS 256
+#define BA_PATCH_STRIDE 49   // floats per lane of the one-lane linearisation's 6x8 pattern patch (odd: lanes reading the same patch element meet no bank conflict)
 #define LIN_RES_PER_BLOCK (LIN_THREADS / 8)
 __device__ __forceinline__ float dppShl(const float v, const int k) {   // value of lane (l + k) of the same 16-lane row, k = 1..7
   int r = 0;
@@ -583,7 +591,8 @@ __device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoint
 // No pt_mask / fullJ form: the callers that need those use the eight-lane kernel.
 __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoints& P, const BARes& Rs, const BAPrecalc* __restrict__ pre, const FrameStore& fs,
                                                  const BADecide& D, const int gate, const int use_backup, const float (*__restrict__ Tv)[14], const int use_dyn,
-                                                 const float* __restrict__ Xxc, const float* __restrict__ XxAd, const int do_resub, const int nblocks, const int nruns) {
+                                                 const float* __restrict__ Xxc, const float* __restrict__ XxAd, const int do_resub, const int nblocks, const int nruns,
+                                                 float* __restrict__ patch) {
   if (baGateClosed(D.ctl, gate)) return;
   const long long t_kernel0 = wall_clock64();
   const int ri = blockIdx.x * LIN_THREADS + threadIdx.x;
@@ -610,29 +619,37 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
     const float pu = P.u[pi], pv = P.v[pi];
     float id_new = 0.0f;
     if (do_resub) {   // resubstituteFPt + the point part of doStepFromBackup (see baLinearizeBody)
-      const int r0 = P.res_begin[pi], r1 = P.res_begin[pi + 1];
-      const float bk = P.idepth_backup[pi];
-      float bsum = P.bdSumF[pi];
-      {
-        float dotc = 0;
-        dotc += Xxc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += Xxc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
-        dotc += Xxc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += Xxc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
-        bsum -= dotc;
-      }
-      int ngood = 0;
-      for (int rq = r0; rq < r1; rq++) {
-        if (Rs.active[rq] == 0) continue;   // the eight-lane form subtracts +0.0f for it
-        const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
-        const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
-        float d = 0;
+      // the residuals of a point are consecutive lanes: the first of them IN THIS WAVEFRONT forms the point's step (the sums below, once per point and wavefront instead
+      // of once per residual: a sixth of the scattered loads), the others take it from that lane
+      const int r0 = P.res_begin[pi];
+      const int lane = threadIdx.x & 63;
+      const int lead = max(0, lane - (ri - r0));           // the lane of the point's first residual, or lane 0 where the point began in the previous wavefront
+      if (lane == lead) {
+        const int r1 = P.res_begin[pi + 1];
+        const float bk = P.idepth_backup[pi];
+        float bsum = P.bdSumF[pi];
+        {
+          float dotc = 0;
+          dotc += Xxc[0] * (P.Hcd[4 * pi + 0] + 0.0f); dotc += Xxc[1] * (P.Hcd[4 * pi + 1] + 0.0f);
+          dotc += Xxc[2] * (P.Hcd[4 * pi + 2] + 0.0f); dotc += Xxc[3] * (P.Hcd[4 * pi + 3] + 0.0f);
+          bsum -= dotc;
+        }
+        int ngood = 0;
+        for (int rq = r0; rq < r1; rq++) {
+          if (Rs.active[rq] == 0) continue;   // the eight-lane form subtracts +0.0f for it
+          const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
+          const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
+          float d = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
-        bsum = bsum - d;
-        ngood++;
+          for (int k = 0; k < 8; k++) d += xa[k] * jp[k];
+          bsum = bsum - d;
+          ngood++;
+        }
+        const float st = ngood == 0 ? 0.0f : -bsum * P.HdiF[pi];
+        id_new = bk + 1.0f * st;
+        if (r0 == ri) { P.step[pi] = st; P.idepth[pi] = id_new; P.idepth_zero[pi] = id_new; }
       }
-      const float st = ngood == 0 ? 0.0f : -bsum * P.HdiF[pi];
-      id_new = bk + 1.0f * st;
-      if (r0 == ri) { P.step[pi] = st; P.idepth[pi] = id_new; P.idepth_zero[pi] = id_new; }
+      id_new = __shfl(id_new, lead, 64);
     }
     float d_xi_x[6], d_xi_y[6], d_C_x[4], d_C_y[4], d_d_x = 0, d_d_y = 0;
     if (!done) {
@@ -674,15 +691,59 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
       float energyLeft = 0.0f, JI00 = 0.0f, JI11 = 0.0f, JI10 = 0.0f, Ja00 = 0.0f, Ja01 = 0.0f, Ja10 = 0.0f, Ja11 = 0.0f, Jb00 = 0.0f, Jb01 = 0.0f, Jb11 = 0.0f, wJI2 = 0.0f;
       float JIr0 = 0.0f, JIr1 = 0.0f, Jar0 = 0.0f, Jar1 = 0.0f, rr = 0.0f;
       bool allGood = true;
+      // The pattern pixels' 4x4 tap neighbourhoods overlap — eight pixels inside 5x5 read the same image rows again and again, and with a different target image under
+      // every lane none of those rows survives in the vector L1 (measured: 32 L2 requests per residual, one per tap row).  The pattern is sorted by rows (y = -2, -1, -1,
+      // 0 | 0, 0, 1, 2): each half's neighbourhoods fit a window of 6 rows x 8 columns for any warp near unit scale.  Per half the lane fetches that window ONCE — six rows
+      // of 32 bytes — into its private patch in LDS and interpolates from there: the same twelve values per tap, the same arithmetic (interp33Finish), 12 line requests
+      // per residual instead of 32.  A half whose neighbourhoods do not fit (or an image too small) taps the image directly, as before.
+      float* const mine = patch + (size_t)threadIdx.x * BA_PATCH_STRIDE;
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {
+        float Kus[4], Kvs[4];
+        bool inbs[4];
+        bool allIn = true;
+        int ixmin = 0x7fffffff, ixmax = -1, iymin = 0x7fffffff, iymax = -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int idx = 4 * half + k;
+          const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
+          const float q0 = pc.KRKi[0] * xu + pc.KRKi[1] * xv + pc.KRKi[2] * 1.0f + pc.Kt[0] * ids;
+          const float q1 = pc.KRKi[3] * xu + pc.KRKi[4] * xv + pc.KRKi[5] * 1.0f + pc.Kt[1] * ids;
+          const float q2 = pc.KRKi[6] * xu + pc.KRKi[7] * xv + pc.KRKi[8] * 1.0f + pc.Kt[2] * ids;
+          const float Ku = q0 / q2, Kv = q1 / q2;
+          const bool inb = (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
+          Kus[k] = inb ? Ku : 2.5f; Kvs[k] = inb ? Kv : 2.5f; inbs[k] = inb;
+          allIn = allIn && inb;
+          const int ix = (int)Kus[k], iy = (int)Kvs[k];
+          ixmin = min(ixmin, ix); ixmax = max(ixmax, ix); iymin = min(iymin, iy); iymax = max(iymax, iy);
+        }
+        const bool usePatch = allIn && ixmax - ixmin <= 4 && iymax - iymin <= 2 && W.w >= 8 && W.h >= 6;
+        const int xs = min(ixmin - 1, W.w - 8), ys = min(iymin - 1, W.h - 6);   // window origin (kept inside the plane; the taps' columns / rows shift by the difference)
+        if (usePatch) {
+          const float* __restrict__ src = img + (size_t)ys * W.w + xs;
+          float4 lo[6], hi4[6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) { __builtin_memcpy(&lo[r], src + (size_t)r * W.w, 16); __builtin_memcpy(&hi4[r], src + (size_t)r * W.w + 4, 16); }
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            mine[8 * r + 0] = lo[r].x; mine[8 * r + 1] = lo[r].y; mine[8 * r + 2] = lo[r].z; mine[8 * r + 3] = lo[r].w;
+            mine[8 * r + 4] = hi4[r].x; mine[8 * r + 5] = hi4[r].y; mine[8 * r + 6] = hi4[r].z; mine[8 * r + 7] = hi4[r].w;
+          }
+        }
 #pragma unroll 2
-      for (int idx = 0; idx < 8; idx++) {
-        const float xu = pu + c_patternP[idx][0], xv = pv + c_patternP[idx][1];
-        const float q0 = pc.KRKi[0] * xu + pc.KRKi[1] * xv + pc.KRKi[2] * 1.0f + pc.Kt[0] * ids;
-        const float q1 = pc.KRKi[3] * xu + pc.KRKi[4] * xv + pc.KRKi[5] * 1.0f + pc.Kt[1] * ids;
-        const float q2 = pc.KRKi[6] * xu + pc.KRKi[7] * xv + pc.KRKi[8] * 1.0f + pc.Kt[2] * ids;
-        const float Ku = q0 / q2, Kv = q1 / q2;
-        const bool inb = (Ku > 1.1f && Kv > 1.1f && Ku < W.wM3 && Kv < W.hM3);
-        float3 hit = interp33(img, inb ? Ku : 2.5f, inb ? Kv : 2.5f, W.w);
+      for (int k = 0; k < 4; k++) {
+        const int idx = 4 * half + k;
+        const float Ku = Kus[k], Kv = Kvs[k];
+        const bool inb = inbs[k];
+        Taps33 tp;
+        if (usePatch) {
+          const float* __restrict__ q = mine + ((int)Kv - 1 - ys) * 8 + ((int)Ku - 1 - xs);
+          tp.A.x = q[1]; tp.A.y = q[2];
+          tp.B.x = q[8]; tp.B.y = q[9]; tp.B.z = q[10]; tp.B.w = q[11];
+          tp.C.x = q[16]; tp.C.y = q[17]; tp.C.z = q[18]; tp.C.w = q[19];
+          tp.D.x = q[25]; tp.D.y = q[26];
+        } else interp33Load(img, Ku, Kv, W.w, tp);
+        float3 hit = interp33Finish<true>(tp, Ku, Kv);
         allGood = allGood && inb && isfinite(hit.x);
         const float color = P.color[pi * 8 + idx];
         const float residual = hit.x - (pc.aff0 * color + pc.aff1);
@@ -706,6 +767,7 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
         Ja00 = Ja00 + tJa00; Ja01 = Ja01 + tJa01; Ja10 = Ja10 + tJa10; Ja11 = Ja11 + tJa11;
         Jb00 = Jb00 + tJb00; Jb01 = Jb01 + tJb01; Jb11 = Jb11 + tJb11; wJI2 = wJI2 + twJI2;
         JIr0 = JIr0 + resF * hit.y; JIr1 = JIr1 + resF * hit.z; Jar0 = Jar0 + resF * jab0; Jar1 = Jar1 + resF * jab1; rr = rr + resF * resF;
+      }
       }
       // the residual goes OOB if ANY of its pattern pixels fails (the reference breaks out of the loop at the first one)
       if (!allGood) { Rs.newState[ri] = BA_OOB; myE = oldEnergy; }
@@ -741,7 +803,8 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
     }
   }
   // energy partials: one per run of LIN_RES_PER_BLOCK residuals, summed in order (the eight-lane kernel's workgroup partials)
-  __shared__ double s_e1[LIN_THREADS];
+  double* const s_e1 = reinterpret_cast<double*>(patch);   // LIN_THREADS doubles in the room of the patches (every lane is done with its own: the barrier)
+  __syncthreads();
   s_e1[threadIdx.x] = myE;
   __syncthreads();
   if ((threadIdx.x & (LIN_RES_PER_BLOCK - 1)) == 0) {
@@ -767,7 +830,7 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (threadIdx.x == 0) __hip_atomic_store(&D.ctl->cnt_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (D.mode == 3) baPackBlock(D, nruns);
-  else baDecideBlock(D, nruns, t_kernel0);
+  else baDecideBlock<true>(D, nruns, t_kernel0, reinterpret_cast<unsigned int*>(patch));   // (every lane is done with its patch: behind the barrier above)
 }
 template <int MF>
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize(const BAWindow W, const BAPoints P, const BARes Rs, const BAPrecalc* __restrict__ pre,
@@ -1758,10 +1821,12 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
 // xc and xAd travel as kernel arguments (2 KB): no separate upload, no staging buffer
 // Eight lanes per point like k_ba_point_sums: lane q forms xAd[h,t_q] . JpJdF of the point's q-th residual (sequential over the 8 entries), the
 // leading lane subtracts the products in residual order (an inactive residual subtracts +0.0f: no change).
+__device__ __forceinline__ void baResubstituteBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const float* __restrict__ xc, const float* __restrict__ xAd, const int apply_step);
 template <int MF>
 __global__ void __launch_bounds__(256) k_ba_resubstitute(const BAWindow W, const BAPoints P, const BARes Rs, const ResubArgsT<MF> X, const int apply_step) {
-  const float* __restrict__ xc = X.xc;
-  const float* __restrict__ xAd = X.xAd;
+  baResubstituteBody(W, P, Rs, X.xc, X.xAd, apply_step);
+}
+__device__ __forceinline__ void baResubstituteBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const float* __restrict__ xc, const float* __restrict__ xAd, const int apply_step) {
   const int pi = blockIdx.x * PT_GROUPS_PER_BLOCK + (threadIdx.x >> 3), q = threadIdx.x & 7;
   if (pi >= W.N) return;   // group-uniform
   const bool lead = q == 0;

@@ -2098,7 +2098,6 @@ int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* B, int ticks12[12]) 
   if (!B || !ticks12) return failmsg("ba_batch: null argument");
   std::lock_guard<std::mutex> lk(B->mu);
   for (int i = 0; i < 12; i++) ticks12[i] = B->h_wins[0].S.ticks[i];
-  if (getenv("DMVIO_HIP_BA_TIMING")) fprintf(stderr, "k_ba_solve extra ticks: %d %d %d %d\n", B->h_wins[0].S.ticks[12], B->h_wins[0].S.ticks[13], B->h_wins[0].S.ticks[14], B->h_wins[0].S.ticks[15]);
   return 0;
 }
 // diagnostics: how window w's last k_ba_solve of the last call found its pivot order — 0 = ranks of the scaled diagonal (all |values| distinct), 1 = ties replayed
@@ -2276,8 +2275,9 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   // the eight-lane kernel hides latency (few windows); the one-lane kernel does an eighth of the lane work (a grid that fills the device)
   const bool lin1 = B->lin_lanes == 1 && Wn >= 4;
   const int gx_lin1 = (gx_res * 256 + LIN_THREADS - 1) / LIN_THREADS;
+  const size_t patchLds = sizeof(float) * LIN_THREADS * BA_PATCH_STRIDE;   // the one-lane linearisation's per-lane 8x8 image windows
   auto linearize = [&](hipStream_t st, const BAWinDev* dwq, const int cnt, const int kind) {
-    if (lin1) hipLaunchKernelGGL(k_ba_linearize_b1, dim3(gx_lin1, cnt), dim3(LIN_THREADS), 0, st, dwq, fs, kind);
+    if (lin1) hipLaunchKernelGGL(k_ba_linearize_b1, dim3(gx_lin1, cnt), dim3(LIN_THREADS), patchLds, st, dwq, fs, kind);
     else hipLaunchKernelGGL(k_ba_linearize_b, dim3(gx_lin, cnt), dim3(LIN_THREADS), 0, st, dwq, fs, kind);
   };
   auto solve = [&](const Grp& q, const int it, const int finish) {
@@ -2289,9 +2289,9 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP, false>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
     }
   };
-  auto chain = [&](const Grp& q, const int backup, const int apply, const int gate) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
+  auto chain = [&](const Grp& q, const int backup, const int apply, const int gate, const bool sums_done) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
     const BAWinDev* dwq = B->d_wins + q.w0;
-    hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq, backup, apply, gate);
+    if (!sums_done) hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq, backup, apply, gate);
     hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, q.cnt), dim3(256), 0, q.st, dwq, gate);
     hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, q.cnt), dim3(64 * F), sizeof(StitchWave) * F, q.st, dwq, gate);
     if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate);
@@ -2306,7 +2306,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     linearize(q.st, dwq, q.cnt, BA_LINB_INITIAL);
     if (g + 1 < G) HIPCHK(hipEventRecord(B->gev[g][0], q.st));
     hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, 0, (int)BA_GATE_ALWAYS);
-    chain(q, 1, 0, BA_GATE_ALWAYS);
+    chain(q, 1, 0, BA_GATE_ALWAYS, false);
   }
   // ---- the loop (:485-586): nothing in it waits for the host
   for (int it = 0; it < mnumOptIts; it++)
@@ -2316,11 +2316,15 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       solve(q, it, 0);
       const bool prof = B->profile && g == 0 && it == std::min(1, mnumOptIts - 1);
       if (prof) HIPCHK(hipEventRecord(B->ev[4], q.st));
-      linearize(q.st, dwq, q.cnt, BA_LINB_STEPPED);
+      if (lin1) { hipLaunchKernelGGL(k_ba_resubstitute_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq); linearize(q.st, dwq, q.cnt, BA_LINB_STEPPED_DONE); }
+      else linearize(q.st, dwq, q.cnt, BA_LINB_STEPPED);
       if (prof) HIPCHK(hipEventRecord(B->ev[5], q.st));
-      linearize(q.st, dwq, q.cnt, BA_LINB_RESTORE);
-      if (it < mnumOptIts - 1) chain(q, 1, 1, BA_GATE_ACCEPTED);
-      else hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, 0, (int)BA_GATE_ACCEPTED);   // the last iteration's accepted step is applied; nobody solves its system
+      // rejected: restore + relinearise | accepted: applyRes + per-point sums (the last iteration's accepted step is only applied: nobody solves its system) — one launch
+      const int what = it < mnumOptIts - 1 ? 0 : 1;
+      const int gx_post = std::max(lin1 ? gx_lin1 : gx_lin, what == 0 ? gx_pt8 : gx_res);
+      if (lin1) hipLaunchKernelGGL((k_ba_post_decide_b<true>), dim3(gx_post, q.cnt), dim3(LIN_THREADS), patchLds, q.st, dwq, fs, what);
+      else hipLaunchKernelGGL((k_ba_post_decide_b<false>), dim3(gx_post, q.cnt), dim3(LIN_THREADS), 0, q.st, dwq, fs, what);
+      if (what == 0) chain(q, 1, 1, BA_GATE_ACCEPTED, true);
     }
   for (int g = 0; g < G; g++) {
     solve(grp[g], mnumOptIts, 1);   // settle the last decision
