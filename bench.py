@@ -416,7 +416,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
         "ms_per_step_p10_p50_p90": [round(float(x), 4) for x in np.percentile(step_ms, [10, 50, 90])],   # the K timed steps one by one (this rank): the spread behind the mean
-        "ms_per_step_min_max": [round(float(step_ms.min()), 4), round(float(step_ms.max()), 4)],
+        # (the first timed step only waits for the batch the warm-up left in flight: it is not a step's duration and stays out of min / max)
+        "ms_per_step_min_max": [round(float(step_ms[1:].min()), 4), round(float(step_ms[1:].max()), 4)] if len(step_ms) > 1 else [round(float(step_ms.min()), 4), round(float(step_ms.max()), 4)],
         "launcher": ("bench.py --gpus N (self-launched torch.distributed.run)" if os.environ.get("DMVIO_BENCH_SELF_LAUNCHED") else
                      ("torch.distributed.run" if world > 1 else "single process")),
         "config": {"workload": "synthetic %dx%d plane-world, %d-level pyramid, %d reference points (pc_n=%s), batch of %d new frames per GPU "
@@ -637,6 +638,26 @@ def main():
             # ranks that really exchanged over RCCL: ncclCommCount of the library's own communicator (the sharded window ran on it); the launcher's process group otherwise
             out["rccl_ranks"] = int((ba_out or {}).get("rccl_ranks", world if backend == "nccl" else 0))
             out["process_group"] = backend
+        if isinstance(ba_out, dict) and "value" in ba_out:
+            # the mapping half of BASELINE.json's metric inside the objects a reader of the first level keeps (roofline / cpu_baseline / config) and as a top-level scalar
+            rb = ba_out.get("roofline") if isinstance(ba_out.get("roofline"), dict) else {}
+            bw = ba_out.get("batched_windows") if isinstance(ba_out.get("batched_windows"), dict) else {}
+            w64 = next((r for r in bw.get("sweep", []) if r.get("windows") == 64), {})
+            w16 = next((r for r in bw.get("sweep", []) if r.get("windows") == 16), {})
+            out["ba_value"] = ba_out["value"]; out["ba_unit"] = "GN-iters/s"
+            out["ba_value_batched_w16"] = w16.get("value"); out["ba_value_batched_w64"] = w64.get("value")
+            out["roofline"]["ba"] = dict(kernel=rb.get("kernel"), frac=rb.get("frac"), kernel_us=rb.get("kernel_us"), achieved=rb.get("achieved"), unit="GB/s",
+                                         iteration_us=(rb.get("iteration") or {}).get("wall_us"), kernels_us=(rb.get("iteration") or {}).get("kernels_us"),
+                                         kernel_batched="k_ba_linearize_b1", frac_batched_w64=w64.get("k_ba_linearize_b_frac"), kernel_us_batched_w64=w64.get("k_ba_linearize_b_us"),
+                                         frac_batched_w16=w16.get("k_ba_linearize_b_frac"),
+                                         what="ba.roofline (one window: k_ba_linearize, 464 B per residual) and ba.batched_windows (W windows per launch: k_ba_linearize_b1)")
+            cb = ba_out.get("cpu_baseline") if isinstance(ba_out.get("cpu_baseline"), dict) else None
+            if cb and isinstance(out.get("cpu_baseline"), dict):
+                out["cpu_baseline"]["ba"] = dict(value=cb.get("value"), unit=cb.get("unit"), cores=cb.get("cores"), kind=cb.get("kind"))
+            wd = ba_out.get("window") or {}
+            out["config"]["ba_workload"] = ("sliding-window photometric bundle adjustment, %sx%s synthetic plane-world, %s keyframes, %s points, %s residuals; ba_value = accepted "
+                                            "Gauss-Newton iterations / s of FullSystem::optimize(6) on fresh windows (one window per call); ba_value_batched_wN = the same with N "
+                                            "windows per dmvio_hip_ba_optimize_batch call" % (w, h, wd.get("frames"), wd.get("points"), wd.get("residuals")))
         out.update(ba=ba_out, trace=trace_out, drop_in=dropin_out, overlap=overlap_out, live=live_out, vio_handoff=vio_out, pcie=pcie_out, batch_sweep=sweep_out)
         emit(json.dumps(out))
     if world > 1:
@@ -1003,43 +1024,42 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
                 # the reference's single-threaded accumulation order (dmvio_hip_ba_set_accumulators(1)): bit-exact AND, in a grid that fills the device, the cheaper one — a
                 # quarter of the workgroups, each four times as long, less per-workgroup overhead (the latency argument for 4 partial accumulators only holds for one window)
                 pool.append(pkg.BundleAdjusterHip(ctx, accumulators=1))
-            walls, loops, lins = [], [], []
-            n_acc = 0
-            for rep in range(6):
-                for h in pool[:W]:
-                    h.set_case(case, slots)
-                torch.cuda.synchronize(dev)
-                B.set_profile(rep >= 4)            # the last two repetitions carry the events around one stepped linearisation (not used for the wall figure)
-                t0 = time.perf_counter(); rs = B.optimize(pool[:W], 6); wall = time.perf_counter() - t0
-                ms = B.last_ms()
-                if rep >= 4:
-                    lins.append(ms[2])
-                elif rep >= 1:
-                    walls.append(wall); loops.append(ms[0] + ms[1])
-                n_acc = sum(int(r["trace"][1:, 3].sum()) for r in rs)
-            wall = float(np.median(walls)); loop_ms = float(np.median(loops)); lin_us = 1e3 * float(np.median(lins))
-            rows.append(dict(windows=W, accepted_iterations=n_acc, wall_ms=round(1e3 * wall, 4), device_ms=round(loop_ms, 4), value=round(n_acc / wall, 1),
-                             us_per_iteration_per_window=round(1e6 * wall / max(n_acc, 1) * W, 2), us_per_accepted_iteration=round(1e6 * wall / max(n_acc, 1), 3),
-                             k_ba_linearize_b_us=round(lin_us, 2), k_ba_linearize_b_GBs=round(W * bytes_lin / (lin_us * 1e-6) / 1e9, 1),
-                             k_ba_linearize_b_frac=round(W * bytes_lin / (lin_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)))
-        # the library's default accumulation order (4 partial accumulators per bucket) at the largest batch, for comparison
-        W = Wmax
-        while len(pool_default) < W:
-            pool_default.append(pkg.BundleAdjusterHip(ctx))
-        walls = []
-        for rep in range(4):
-            for h in pool_default:
-                h.set_case(case, slots)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter(); rs = B.optimize(pool_default, 6); walls.append(time.perf_counter() - t0)
-        default_order = dict(windows=W, value=round(sum(int(r["trace"][1:, 3].sum()) for r in rs) / float(np.median(walls[1:])), 1))
+                pool_default.append(pkg.BundleAdjusterHip(ctx))            # the library's default: 4 partial accumulators per bucket
+            row = dict(windows=W)
+            for order, hs in (("default", pool_default[:W]), ("single_threaded", pool[:W])):
+                walls, loops, lins = [], [], []
+                n_acc = 0
+                for rep in range(6 if order == "default" else 4):
+                    for h in hs:
+                        h.set_case(case, slots)
+                    torch.cuda.synchronize(dev)
+                    B.set_profile(order == "default" and rep >= 4)   # the last two repetitions carry the events around one stepped linearisation (not used for the wall figure)
+                    t0 = time.perf_counter(); rs = B.optimize(hs, 6); wall = time.perf_counter() - t0
+                    ms = B.last_ms()
+                    if order == "default" and rep >= 4:
+                        lins.append(ms[2])
+                    elif rep >= 1:
+                        walls.append(wall); loops.append(ms[0] + ms[1])
+                    n_acc = sum(int(r["trace"][1:, 3].sum()) for r in rs)
+                wall = float(np.median(walls)); loop_ms = float(np.median(loops))
+                if order == "default":
+                    lin_us = 1e3 * float(np.median(lins))
+                    row.update(accepted_iterations=n_acc, wall_ms=round(1e3 * wall, 4), device_ms=round(loop_ms, 4), value=round(n_acc / wall, 1),
+                               us_per_iteration_per_window=round(1e6 * wall / max(n_acc, 1) * W, 2), us_per_accepted_iteration=round(1e6 * wall / max(n_acc, 1), 3),
+                               k_ba_linearize_b_us=round(lin_us, 2), k_ba_linearize_b_GBs=round(W * bytes_lin / (lin_us * 1e-6) / 1e9, 1),
+                               k_ba_linearize_b_frac=round(W * bytes_lin / (lin_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+                else:
+                    row.update(value_single_threaded_order=round(n_acc / wall, 1), wall_ms_single_threaded_order=round(1e3 * wall, 4))
+            rows.append(row)
+        default_order = dict(windows=rows[-1]["windows"], value=rows[-1]["value"])
     finally:
         for h in pool + pool_default:
             h.close()
         B.close()
     best = max(rows, key=lambda r: r["value"])
     ach = bytes_iter * best["value"] / 1e9
-    return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows, accumulators_per_bucket=1, default_accumulation_order=default_order,
+    return dict(unit="GN-iters/s", value=best["value"], at_windows=best["windows"], sweep=rows, accumulators_per_bucket=4, default_accumulation_order=default_order,
+                value_single_threaded_order=max(r["value_single_threaded_order"] for r in rows),
                 single_window=dict(optimize6_ms=rows[0]["wall_ms"], us_per_accepted_iteration=rows[0]["us_per_accepted_iteration"],
                                    what="dmvio_hip_ba_optimize_batch of ONE window = dmvio_hip_ba_optimize with dmvio_hip_ba_set_device_loop(1): the whole loop enqueued up front, two host waits per call"),
                 roofline=dict(bound="hbm", kernel="k_ba_linearize_b1" if best["windows"] >= 4 else "k_ba_linearize_b", achieved=best["k_ba_linearize_b_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=best["k_ba_linearize_b_frac"],
@@ -1048,9 +1068,10 @@ def bench_ba_batched(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
                               what="the stepped linearisation of ALL windows of a call (one launch, HIP events on the batch's stream; the profiled repetitions run as one group on one "
                                    "stream, alone on the device; from 4 windows on the one-lane-per-residual kernel k_ba_linearize_b1): 464 B per residual x residuals of all windows / "
                                    "its duration; `iteration`: all algorithmic bytes of an accepted iteration x accepted iterations per second"),
-                what="W fresh windows (own handles with dmvio_hip_ba_set_accumulators(1): the reference's single-threaded accumulation order; set up before the timed region), ONE "
-                     "dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its wall time; device_ms = the same call by HIP events (loop + final "
-                     "fix-linearisation); default_accumulation_order: the same at the largest batch with the library's default of 4 partial accumulators per bucket")
+                what="W fresh windows (own handles in the library's DEFAULT accumulation order, 4 partial accumulators per bucket; set up before the timed region), ONE "
+                     "dmvio_hip_ba_optimize_batch(6) call: accepted Gauss-Newton iterations of all windows / its wall time (`value`, every row of `sweep`); device_ms = the same "
+                     "call by HIP events (loop + final fix-linearisation); value_single_threaded_order (every row): the same with handles in the reference's single-threaded "
+                     "accumulation order (dmvio_hip_ba_set_accumulators(1): the bit-exact replay)")
 
 
 def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, torch, cpu):
@@ -1098,6 +1119,7 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         chain_us = ba.profile_chain(30)
         ba.set_case(case, list(range(F)))
     replicas = None
+    batched_replicas = None
     comm = None
     if world > 1:
         # reference point for the sharded figure: every rank optimising its OWN whole window (independent windows, no exchange)
@@ -1116,6 +1138,33 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         replicas = world * args.ba_iters / float(tr.item())
         ba_full.close()
+        # ... and the batched device-resident loop on W = 16 windows of its own per rank (dmvio_hip_ba_optimize_batch): the fast path's weak-scaling figure
+        try:
+            Wb = 16
+            Bb = pkg.BundleAdjusterBatch(ctx, Wb)
+            poolb = [pkg.BundleAdjusterHip(ctx) for _ in range(Wb)]
+            walls_b = []
+            n_acc_b = 0
+            for rep in range(4):
+                for hb in poolb:
+                    hb.set_case(case_full, list(range(F)))
+                torch.cuda.synchronize(dev); dist.barrier()
+                t0 = time.perf_counter(); rsb = Bb.optimize(poolb, 6); torch.cuda.synchronize(dev)
+                tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                if rep >= 1:
+                    walls_b.append(float(tb.item()))
+                nb = torch.tensor([float(sum(int(r["trace"][1:, 3].sum()) for r in rsb))], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+                n_acc_b = float(nb.item())
+            batched_replicas = dict(windows_per_rank=Wb, value=round(n_acc_b / float(np.median(walls_b)), 1), value_per_rank=round(n_acc_b / float(np.median(walls_b)) / world, 1),
+                                    what="every rank: ONE dmvio_hip_ba_optimize_batch(16 fresh windows of its own, 6 iterations) call, all ranks started together; accepted iterations of "
+                                         "all ranks / the slowest rank's wall time (weak scaling of the batched device-resident loop; default accumulation order)")
+            for hb in poolb:
+                hb.close()
+            Bb.close()
+        except Exception as ex:
+            batched_replicas = dict(error="%s: %s" % (type(ex).__name__, ex))
         if coll_dev.type != "cpu":
             # the library's own RCCL communicator: the unique id travels over the process group that launched us
             uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
@@ -1230,6 +1279,8 @@ def bench_ba(args, pkg, synth, ctx_device, rank, world, dist, dev, coll_dev, tor
     if replicas is not None:
         out["independent_windows_value"] = round(replicas, 1)
         out["independent_windows_value_per_rank"] = round(replicas / world, 1)
+    if batched_replicas is not None:
+        out["independent_batched_windows"] = batched_replicas
     if world == 1 and not getattr(args, "no_concurrent", False):
         out["concurrent_windows"] = bench_ba_concurrent(args, pkg, ctx, case, F, bytes_iter, bytes_lin, torch, dev)
     if world == 1:

@@ -5,6 +5,7 @@
 R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$R; rm -rf $O; mkdir -p $O
+python tools/publish_round.py --hash > $O/csrc_hash.txt   # what is being profiled (tools/publish_round.py refuses summaries of other sources)
 t0=$(date +%s)
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 t1=$(date +%s); echo "default bench.py wall seconds: $((t1 - t0))" > $O/bench_wall.txt
@@ -21,5 +22,6 @@ rm -rf $O/ba_kt
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 python bench.py --steps 20 --warmup 3 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 bash tools/ba_batch_prof.sh 16 $O/ba_batch_kernels_w16.md > $O/ba_batch_probe_w16.log 2>&1 < /dev/null
+bash tools/ba_batch_prof.sh 64 $O/ba_batch_kernels_w64.md > $O/ba_batch_probe_w64.log 2>&1 < /dev/null
 cd $GRAFT_REPO_ROOT
 tail -c 600 $O/bench_n1.json; cat $O/bench_wall.txt
