@@ -415,7 +415,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "ms_per_step_ranks": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
-        "ms_per_step_p10_p50_p90": [round(float(x), 4) for x in np.percentile(step_ms, [10, 50, 90])],   # the K timed steps one by one (this rank): the spread behind the mean
+        # the K timed steps one by one (this rank): the spread behind the mean — without the first one, which only waits for the batch the warm-up left in flight
+        "ms_per_step_p10_p50_p90": [round(float(x), 4) for x in np.percentile(step_ms[1:] if len(step_ms) > 1 else step_ms, [10, 50, 90])],
         # (the first timed step only waits for the batch the warm-up left in flight: it is not a step's duration and stays out of min / max)
         "ms_per_step_min_max": [round(float(step_ms[1:].min()), 4), round(float(step_ms[1:].max()), 4)] if len(step_ms) > 1 else [round(float(step_ms.min()), 4), round(float(step_ms.max()), 4)],
         "launcher": ("bench.py --gpus N (self-launched torch.distributed.run)" if os.environ.get("DMVIO_BENCH_SELF_LAUNCHED") else

@@ -694,8 +694,12 @@ __device__ __forceinline__ double readLaneD(const double v, const int src) {
 // pivot order follows from the diagonal of A (descending |a_ii|).  The order is therefore computed ONCE (two ballots), the system permuted once, and the factorisation runs
 // unpivoted: no per-step search (it was a third of the ~1100 dependent instructions of the right-looking form this replaces, which also pivoted on the UPDATED diagonal — not
 // the reference's rule), no per-step row / column swaps, no replay of the transpositions at the end.  The column updates are formed as the reference forms them
-// (temp_j = D_j L_kj; a_rk -= sum_j L_rj temp_j, the sum added up in j order first).  Ties on the diagonal (two fixed affine parameters: identity rows) are broken by index
-// — among uncoupled identity rows the order is immaterial; the back substitution stays column-oriented (each new x_k is consumed by all rows at once).
+// (temp_j = D_j L_kj; a_rk -= sum_j L_rj temp_j, the sum added up in j order first).  Ties on the diagonal are broken by index (a STABLE order) — NOT Eigen's rule under
+// ties: its selection-with-swaps takes the tied entry that stands first AFTER the earlier swaps (diag [5a, 5b, 9] -> 9, 5b, 5a; the stable order gives 9, 5a, 5b; k_ba_solve
+// replays Eigen's order exactly, csrc/ba_batch_kernels.hpp).  Here the only ties that occur are the identity rows of fixed affine parameters, which are uncoupled from
+// everything else: their order changes no operand of any other row, the solution is the same bit for bit; a tie between two live diagonal entries of an 8x8 photometric
+// Hessian is a measure-zero event and this solve is not bit-pinned (third-party arithmetic).  The back substitution stays column-oriented (each new
+// x_k is consumed by all rows at once).
 // value of lane (l - k), k = 1..7, for a double: DPP row_shr on both halves (0.0 where the 16-lane DPP row ends)
 __device__ __forceinline__ double dppShrD(const double v, const int k) {
   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
