@@ -59,6 +59,17 @@ struct BAWinDev {
   int n_lin_blocks, n_pt8_blocks, n_acc_blocks, n_res_blocks, n_gather_blocks, n_stitch_blocks;
   int n_lin1_blocks;           // workgroups of the one-lane-per-residual linearisation (k_ba_linearize_b1): 256 residuals each
   float frameTH[BA_MAXF_CAP];  // FrameHessian::frameEnergyTH of the window's keyframes for the duration of a batch call (BADecide::frameTH points here)
+  // residuals kept linearised outside a marginalisation (dmvio_hip_ba_fix_linearization; n_lin == 0: none, the pointers are NULL): what accumulateLF_MT / addPoint<1> and
+  // calcLEnergyPt read (csrc/ba_kernels.hpp "residuals kept linearised"), the three-pass accumulation's views, and EnergyFunctional::setDeltaF's adHTdeltaF / cDeltaF of
+  // the state the window stands at ([0]) and of its backup ([1]) — k_ba_solve keeps them like the pair tables
+  int n_lin, n_lin_runs;
+  unsigned int lin_cnt, pad_lin;
+  const float* fullJ; const unsigned char* lin; const float* rtz;
+  float* linRec; unsigned char* linActive; unsigned char* topActive;
+  float* linE;                 // R x 8: every residual's terms of the linearised energy, in the reference's lane order
+  double* sysL;                // [H_L | b_L] of the last accumulation's L pass
+  float adHTdelta[2][BA_MAXF_CAP * BA_MAXF_CAP * 8];
+  float cDeltaF[2][4];
   BASolveDev S;
 };
 
@@ -135,22 +146,121 @@ __global__ void __launch_bounds__(256) k_ba_point_sums_b(const BAWinDev* __restr
   if ((int)blockIdx.x >= V.n_pt8_blocks) return;
   baPointSumsBody(V.W, V.P, V.Rs, backup, apply, V.ctl, gate, nullptr);
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_ba_accumulate_b(const BAWinDev* __restrict__ wins, const int gate) {
+// pass: 0 = the one accumulation of a graph without residuals kept linearised; 1 / 2 / 3 = the L / A / Schur pass of the three-pass accumulation (accumulateLin in
+// capi_ba.hip: addPoint<1> over the linearised residuals' records, addPoint<0> over the others, the Schur side over every active one).  A window WITHOUT such residuals in a
+// launch of pass 1 or 3 has nothing to do; in pass 2 it runs its one ordinary accumulation.
+enum { BA_PASS_ALL = 0, BA_PASS_L = 1, BA_PASS_A = 2, BA_PASS_S = 3 };
+__device__ __forceinline__ bool baPassIdle(const BAWinDev& V, const int pass) { return V.n_lin == 0 && (pass == BA_PASS_L || pass == BA_PASS_S); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_ba_accumulate_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
-  if ((int)blockIdx.x >= V.n_acc_blocks) return;
-  baAccumulateBody(V.A, V.Rs, V.P, V.ctl, gate);
+  if ((int)blockIdx.x >= V.n_acc_blocks || baPassIdle(V, pass)) return;
+  if (V.n_lin == 0 || pass == BA_PASS_S || pass == BA_PASS_ALL) { baAccumulateBody(V.A, V.Rs, V.P, V.ctl, gate); return; }
+  BARes Rv = V.Rs;
+  if (pass == BA_PASS_L) { Rv.rec[0] = Rv.rec[1] = V.linRec; Rv.active = V.linActive; Rv.lin = nullptr; }
+  else Rv.active = V.topActive;
+  baAccumulateBody(V.A, Rv, V.P, V.ctl, gate);
 }
 // every window of a batch has the same F (the host groups them): blockDim = 64 F
-__global__ void __launch_bounds__(64 * BA_MAXF_CAP) k_ba_stitch_b(const BAWinDev* __restrict__ wins, const int gate) {
+__global__ void __launch_bounds__(64 * BA_MAXF_CAP) k_ba_stitch_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
+  if (baPassIdle(V, pass)) return;
   baStitchBody(V.A.F, V.A.nsTop, V.A.nsD, V.A.accTop, V.A.numTop, V.A.accD, V.A.numD, V.A.accE, V.adHost, V.adTarget, V.SB, V.ctl, gate);
 }
 template <int MF>
-__global__ void __launch_bounds__(256) k_ba_stitch_gather_b(const BAWinDev* __restrict__ wins, const int gate) {
+__global__ void __launch_bounds__(256) k_ba_stitch_gather_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
-  if ((int)blockIdx.x >= V.n_gather_blocks || baGateClosed(V.ctl, gate)) return;
+  if ((int)blockIdx.x >= V.n_gather_blocks || baGateClosed(V.ctl, gate) || baPassIdle(V, pass)) return;
   const int F = V.A.F;
-  gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, blockIdx.x * blockDim.x + threadIdx.x, false);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (V.n_lin == 0 || pass == BA_PASS_ALL) gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, t, false, 3, true);
+  else if (pass == BA_PASS_L) gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sysL, t, false, 1, false);
+  else gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, t, false, pass == BA_PASS_A ? 1 : 2, true);
+}
+// the records addPoint<1> consumes and the linearised residuals' per-point sums, at the deltas of the state the window stands at (k_ba_lin_records / k_ba_lin_point_sums)
+__global__ void __launch_bounds__(256) k_ba_lin_records_b(const BAWinDev* __restrict__ wins, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if (V.n_lin == 0 || (int)blockIdx.x >= V.n_res_blocks || baGateClosed(V.ctl, gate)) return;
+  baLinRecordsBody(V.W, V.P, V.Rs, V.fullJ, V.lin, V.rtz, V.adHTdelta[0], make_float4(V.cDeltaF[0][0], V.cDeltaF[0][1], V.cDeltaF[0][2], V.cDeltaF[0][3]), V.linRec, V.linActive, V.topActive);
+}
+__global__ void __launch_bounds__(256) k_ba_lin_point_sums_b(const BAWinDev* __restrict__ wins, const int gate) {
+  const BAWinDev& V = wins[blockIdx.y];
+  if (V.n_lin == 0 || (int)blockIdx.x * 256 >= V.W.N || baGateClosed(V.ctl, gate)) return;
+  baLinPointSumsBody(V.W, V.P, V.linRec, V.linActive, const_cast<float*>(V.P.lHdd), const_cast<float*>(V.P.lbd), const_cast<float*>(V.P.lHcd));
+}
+// calcLEnergyPt's term of the residuals kept linearised (EnergyFunctional.cpp:349-409), at the deltas of the STEPPED state k_ba_solve just left in the record: every residual's
+// eight products (2 res_toZeroF + J delta) . (J delta) in parallel, then — last workgroup of the window — the reference's summation: an Accumulator11 (four fp32 lanes) per run of
+// 50 points, two 4-lane updates per residual in point / residual order, the runs' totals added in double (capi_ba.hip: linEnergy).  The sum goes on top of the frame / calibration
+// prior energy the solve stored (BADecide::newL, BASolveDev::newL): the stepped linearisation's accept test, next in the stream, reads it there.
+__global__ void __launch_bounds__(256) k_ba_lin_energy_b(BAWinDev* __restrict__ wins) {
+  BAWinDev& V = wins[blockIdx.y];
+  if (V.n_lin == 0 || (int)blockIdx.x >= V.n_res_blocks) return;
+  const int ri = blockIdx.x * 256 + threadIdx.x;
+  const float* __restrict__ adHT = V.adHTdelta[0];
+  if (ri < V.W.R) {
+    float* __restrict__ e = V.linE + (size_t)ri * 8;
+    if (V.lin[ri] && V.Rs.active[ri]) {
+      const int pi = V.Rs.point[ri];
+      const float* __restrict__ J = V.fullJ + (size_t)ri * 74;
+      const float* __restrict__ rtz = V.rtz + (size_t)ri * 8;
+      const float* __restrict__ dp = adHT + (size_t)(V.P.host[pi] + V.W.F * V.Rs.target[ri]) * 8;
+      const float dd = 0.0f;
+      float sx = 0, sy = 0, cx = 0, cy = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { sx += J[8 + i] * dp[i]; sy += J[14 + i] * dp[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { cx += J[20 + i] * V.cDeltaF[0][i]; cy += J[24 + i] * V.cDeltaF[0][i]; }
+      const float Jp_delta_x = sx + cx + J[28] * dd, Jp_delta_y = sy + cy + J[29] * dd;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        float Jdelta = J[30 + q] * Jp_delta_x;
+        Jdelta = Jdelta + J[38 + q] * Jp_delta_y;
+        Jdelta = Jdelta + J[46 + q] * dp[6];
+        Jdelta = Jdelta + J[54 + q] * dp[7];
+        float r0 = rtz[q];
+        r0 = r0 + r0;
+        r0 = r0 + Jdelta;
+        e[q] = Jdelta * r0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) e[q] = 0.0f;   // (skipped below: the flag is tested again — a +0.0f would not change a sum that is never -0.0f either)
+    }
+  }
+  __shared__ int s_last;
+  __shared__ double s_run[256];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&V.lin_cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(V.n_res_blocks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) __hip_atomic_store(&V.lin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // runs of 50 points: thread = run (the four lanes of its Accumulator11 in registers); more than 256 runs: strided, the partial totals added in run order below
+  const int nruns = (V.W.N + 49) / 50;
+  double A = 0.0;
+  for (int base = 0; base < nruns; base += 256) {
+    const int run = base + threadIdx.x;
+    double tot = 0.0;
+    if (run < nruns) {
+      float d1[4] = {0, 0, 0, 0};
+      const int p1 = min(V.W.N, 50 * run + 50);
+      const int r0 = V.P.res_begin[50 * run], r1 = V.P.res_begin[p1];
+      for (int rj = r0; rj < r1; rj++) {
+        if (!V.lin[rj] || !V.Rs.active[rj]) continue;
+        const float* __restrict__ e = V.linE + (size_t)rj * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d1[k] = d1[k] + __hip_atomic_load(e + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 4; k++) d1[k] = d1[k] + __hip_atomic_load(e + 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      tot = (double)(d1[0] + d1[1] + d1[2] + d1[3]);
+    }
+    s_run[threadIdx.x] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int k = 0; k < min(256, nruns - base); k++) A += s_run[k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { V.S.newL += A; V.D.newL += A; }
 }
 
 // ------------------------------------------------------------------------------------------------ k_ba_solve
@@ -650,8 +760,10 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   const double* __restrict__ Hsc = bA + n;
   const double* __restrict__ bsc = Hsc + (size_t)n * n;
   int pr[QMAX];
-  double hA[QMAX], hS[QMAX];          // the owned pairs' entries of H_A and H_sc
-  double bAi = 0.0, bsci = 0.0;
+  double hA[QMAX], hS[QMAX], hL[QMAX];   // the owned pairs' entries of H_A, H_sc and (residuals kept linearised: accumulateLF_MT's system) H_L
+  double bAi = 0.0, bsci = 0.0, bLi = 0.0;
+  const bool haveL = V.n_lin > 0;
+  const double* __restrict__ HLr = V.sysL;
   // the pair tables and the calibration members of the state / of the backup: one of the two sets is copied over the other below (loads up front, stores behind the decision)
   constexpr int TQ = (BA_MAXF_CAP * (BA_MAXF_CAP - 1) * 14 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS;
   const int npT = F * (F - 1) * 14;
@@ -680,9 +792,9 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   if (!finish) {
     baOwnedPairs<QMAX>(n, pr);
 #pragma unroll
-    for (int q = 0; q < QMAX; q++) { hA[q] = 0.0; hS[q] = 0.0; if (pr[q] >= 0) { const size_t o = (size_t)(pr[q] >> 8) * n + (pr[q] & 255); hA[q] = HA[o]; hS[q] = Hsc[o]; } }
-    if (tid < n) { bAi = bA[tid]; bsci = bsc[tid]; }
-    else if (tid >= 128 && tid < 128 + n) { const size_t o = (size_t)(tid - 128) * n + (tid - 128); bAi = HA[o]; bsci = Hsc[o]; }   // (the diagonal, for the threads that scale it)
+    for (int q = 0; q < QMAX; q++) { hA[q] = 0.0; hS[q] = 0.0; hL[q] = 0.0; if (pr[q] >= 0) { const size_t o = (size_t)(pr[q] >> 8) * n + (pr[q] & 255); hA[q] = HA[o]; hS[q] = Hsc[o]; if (haveL) hL[q] = HLr[o]; } }
+    if (tid < n) { bAi = bA[tid]; bsci = bsc[tid]; if (haveL) bLi = HLr[(size_t)n * n + tid]; }
+    else if (tid >= 128 && tid < 128 + n) { const size_t o = (size_t)(tid - 128) * n + (tid - 128); bAi = HA[o]; bsci = Hsc[o]; if (haveL) bLi = HLr[o]; }   // (the diagonal, for the threads that scale it)
     if (haveM) {
       for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];
       for (int i = tid; i < n; i += BA_SOLVE_THREADS) bMs[i] = S.bM[i];
@@ -732,6 +844,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
       #pragma unroll
         for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; if (i < npT) Tbk[i] = tcur[q]; }
         if (tid < 8) (&V.Wb.fx)[tid] = wcur;
+        if (haveL) { for (int i = tid; i < F * F * 8; i += BA_SOLVE_THREADS) V.adHTdelta[1][i] = V.adHTdelta[0][i]; if (tid < 4) V.cDeltaF[1][tid] = V.cDeltaF[0][tid]; }
             }
     } else {
       for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { fst[i] = fbak[i]; S.fr[i / 10].state[i % 10] = fbak[i]; }
@@ -739,6 +852,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
 #pragma unroll
       for (int q = 0; q < TQ; q++) { const int i = tid + q * BA_SOLVE_THREADS; if (i < npT) Tcur[i] = tbk[q]; }
       if (tid < 8) (&V.W.fx)[tid] = wbk;
+      if (haveL) { for (int i = tid; i < F * F * 8; i += BA_SOLVE_THREADS) V.adHTdelta[0][i] = V.adHTdelta[1][i]; if (tid < 4) V.cDeltaF[0][tid] = V.cDeltaF[1][tid]; }
     }
   }
   if (finish) return;
@@ -761,7 +875,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     bP[tid] = s;
   } else if (tid >= 128 && tid < 128 + n) {
     const int i = tid - 128;
-    double v = (HLd[i] + (haveM ? HMs[(size_t)i * hs + i] : 0.0)) + bAi;
+    double v = ((bLi + HLd[i]) + (haveM ? HMs[(size_t)i * hs + i] : 0.0)) + bAi;   // ((HL + prior) + HM) + HA (BAHost::solveSystem); bLi holds H_L's diagonal entry here
     v *= (1 + lambda);
     v = v - bsci * fac;
     const double sc = 1.0 / sqrt(v + 10);
@@ -783,7 +897,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
         const int i = pr[q] >> 8, j = pr[q] & 255;
         double v;
         if (i == j) v = dgV[i];
-        else v = ((0.0 + hm[q]) + hA[q]) - hS[q] * fac;
+        else v = (((hL[q] + 0.0) + hm[q]) + hA[q]) - hS[q] * fac;
         Lc[tid + q * BA_SOLVE_THREADS] = sv[i] * v * sv[j];   // (sv_i * H_ij) * sv_j
       }
     }
@@ -791,7 +905,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   if (tid < n) {
     const int i = tid;
     const double bL = i < 4 ? s_cal[12 + i] * d[i] : fprior[i - 4] * fst[10 * ((i - 4) >> 3) + ((i - 4) & 7)];   // prior * delta_prior (= state)
-    const double bF = ((bL + bP[i]) + bAi) - bsci;
+    const double bF = (((bLi + bL) + bP[i]) + bAi) - bsci;   // bL_top = accumulateLF's b + prior * delta (BAHost::lfTop)
     rhsS[i] = sv[i] * bF;
   }
   __syncthreads();
@@ -851,6 +965,27 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   }
   __syncthreads();
   SOLVE_TICK(8);   // resubstitution inputs, stepped states
+  if (haveL) {
+    // EnergyFunctional::setDeltaF at the stepped state (BAHost::adHTdeltaF): adHTdeltaF[h + F t][c] = delta_h . adHostF(:, c) + delta_t . adTargetF(:, c) in fp32, sequential over r — what
+    // the linearised residuals' energy (k_ba_lin_energy_b, next in the stream) and, once the step is accepted, their records (k_ba_lin_records_b) are evaluated at
+    for (int o = tid; o < F * F * 8; o += BA_SOLVE_THREADS) {
+      const int c = o & 7, t = (o >> 3) % F, hh = (o >> 3) / F;
+      float ah[8], at[8];
+      if (o == tid) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) { ah[r] = ahP[r]; at[r] = atP[r]; }
+      } else {
+        const size_t base = ((size_t)hh + (size_t)F * t) * 64;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { ah[r] = adHostF[base + r * 8 + c]; at[r] = adTargetF[base + r * 8 + c]; }
+      }
+      float s1 = 0, s2 = 0;
+#pragma unroll
+      for (int r = 0; r < 8; r++) { s1 += (float)d[4 + 8 * hh + r] * ah[r]; s2 += (float)d[4 + 8 * t + r] * at[r]; }
+      V.adHTdelta[0][((size_t)hh + (size_t)F * t) * 8 + c] = s1 + s2;
+    }
+    if (tid < 4) V.cDeltaF[0][tid] = (float)d[tid];
+  }
   if (tid == 0) {
     // CalibHessian::setValue (BAHost::calibSetValue) and the K / K^-1 of setPrecalcValues, in float like the host
     const float f0 = (float)s_scal[0], f1 = (float)s_scal[1], f2 = (float)s_scal[2], f3 = (float)s_scal[3];

@@ -1071,9 +1071,17 @@ __global__ void __launch_bounds__(256) k_ba_lin_fix(const BAWindow W, const BAPo
 // The record addPoint<1> consumes, at the deltas of the current state: resApprox = res_toZeroF + [JI Jp | Jab] delta (AccumulatedTopHessian.cpp:84-98), its inner products
 // with the frozen Jacobian (:103-113) and the point's bd contribution (:132).  Also the two activity views of the three-pass accumulation: the A pass sees the active
 // residuals that are NOT linearised (addPoint<0>), the L pass those that are.
+__device__ __forceinline__ void baLinRecordsBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const float* __restrict__ fullJ, const unsigned char* __restrict__ lin,
+                                                 const float* __restrict__ res_toZeroF, const float* __restrict__ adHTdeltaF, const float4 cDeltaF,
+                                                 float* __restrict__ linRec, unsigned char* __restrict__ linActive, unsigned char* __restrict__ topActive);
 __global__ void __launch_bounds__(256) k_ba_lin_records(const BAWindow W, const BAPoints P, const BARes Rs, const float* __restrict__ fullJ, const unsigned char* __restrict__ lin,
                                                          const float* __restrict__ res_toZeroF, const float* __restrict__ adHTdeltaF, const float4 cDeltaF,
                                                          float* __restrict__ linRec, unsigned char* __restrict__ linActive, unsigned char* __restrict__ topActive) {
+  baLinRecordsBody(W, P, Rs, fullJ, lin, res_toZeroF, adHTdeltaF, cDeltaF, linRec, linActive, topActive);
+}
+__device__ __forceinline__ void baLinRecordsBody(const BAWindow& W, const BAPoints& P, const BARes& Rs, const float* __restrict__ fullJ, const unsigned char* __restrict__ lin,
+                                                 const float* __restrict__ res_toZeroF, const float* __restrict__ adHTdeltaF, const float4 cDeltaF,
+                                                 float* __restrict__ linRec, unsigned char* __restrict__ linActive, unsigned char* __restrict__ topActive) {
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= W.R) return;
   const bool act = Rs.active[ri] != 0, isLin = lin[ri] != 0;
@@ -1104,8 +1112,14 @@ __global__ void __launch_bounds__(256) k_ba_lin_records(const BAWindow W, const 
   dst[REC_BD] = JIr0 * J[28] + JIr1 * J[29];
 }
 // Hdd_accLF, bd_accLF, Hcd_accLF (AccumulatedTopHessian.cpp:131-143, mode 1): sequential over the point's linearised active residuals
+__device__ __forceinline__ void baLinPointSumsBody(const BAWindow& W, const BAPoints& P, const float* __restrict__ linRec, const unsigned char* __restrict__ linActive,
+                                                   float* __restrict__ lHdd, float* __restrict__ lbd, float* __restrict__ lHcd4);
 __global__ void __launch_bounds__(256) k_ba_lin_point_sums(const BAWindow W, const BAPoints P, const float* __restrict__ linRec, const unsigned char* __restrict__ linActive,
                                                             float* __restrict__ lHdd, float* __restrict__ lbd, float* __restrict__ lHcd4) {
+  baLinPointSumsBody(W, P, linRec, linActive, lHdd, lbd, lHcd4);
+}
+__device__ __forceinline__ void baLinPointSumsBody(const BAWindow& W, const BAPoints& P, const float* __restrict__ linRec, const unsigned char* __restrict__ linActive,
+                                                   float* __restrict__ lHdd, float* __restrict__ lbd, float* __restrict__ lHcd4) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= W.N) return;
   float Hdd = 0, bd = 0, Hcd[4] = {0, 0, 0, 0};
@@ -1725,7 +1739,7 @@ __device__ __forceinline__ void baStitchBody(const int F, const int nsTop, const
 // gated-off launch (rejected step: the system of the restored state is the one the host already holds) publishes at once.
 template <int MF>
 __device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
-                                              const int nNum, double* __restrict__ out, const int tid, const bool sys);
+                                              const int nNum, double* __restrict__ out, const int tid, const bool sys, const int parts, const bool with_count);
 template <int MF>
 __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs S,
                                                            const int* __restrict__ numTop, const int nNum, double* __restrict__ out, BACtl* __restrict__ ctl, const int gate,
@@ -1734,7 +1748,7 @@ __global__ void __launch_bounds__(256) k_ba_stitch_gather(const int F, const int
     if (host && threadIdx.x == 0) __hip_atomic_store(&host->gticket[blockIdx.x], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  gatherElement<MF>(F, nsC, accC, S, numTop, nNum, out, blockIdx.x * blockDim.x + threadIdx.x, host != nullptr);
+  gatherElement<MF>(F, nsC, accC, S, numTop, nNum, out, blockIdx.x * blockDim.x + threadIdx.x, host != nullptr, 3, true);
   if (!host) return;
   // every workgroup publishes its own slice: write-through stores, a workgroup-scope release (its stores are acknowledged), then the chain's ticket into the
   // workgroup's slot of host-coherent memory; the host waits for all slots.  (A last-workgroup pattern needed a system-scope fence per thread and an agent-scope
@@ -1796,14 +1810,17 @@ __device__ __forceinline__ double gatherValue(const int F, const int nsC, const 
   }
   return val;
 }
+// parts: 1 = the top system (+ resInA), 2 = the Schur system, 3 = both (one accumulation serves both); the three-pass accumulation of a graph with residuals kept
+// linearised takes the top system of its L pass (into a buffer of its own) and of its A pass, the Schur system of its third pass
 template <int MF>
 __device__ __forceinline__ void gatherElement(const int F, const int nsC, const float* __restrict__ accC, const StitchBufs& S, const int* __restrict__ numTop,
-                                              const int nNum, double* __restrict__ out, const int tid, const bool sys) {
+                                              const int nNum, double* __restrict__ out, const int tid, const bool sys, const int parts, const bool with_count) {
   // sys: `out` is host-coherent memory the host polls — write through (system-scope stores) instead of a system-scope fence per thread
   auto put = [&](const int i, const double v) { if (sys) __hip_atomic_store(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else out[i] = v; };
   const int n = 4 + 8 * F;
   const int per = n * n + n;
   if (tid == 2 * per) {   // resInA: number of active residuals that entered the top accumulation, appended to the system
+    if (!(parts & 1) || !with_count) return;
     int cnt = 0;
     for (int k = 0; k < nNum; k++) cnt += numTop[k];
     put(2 * per, (double)cnt);
@@ -1811,6 +1828,7 @@ __device__ __forceinline__ void gatherElement(const int F, const int nsC, const 
   }
   if (tid >= 2 * per) return;
   const bool sc = tid >= per;
+  if (!(parts & (sc ? 2 : 1))) return;
   const int t = sc ? tid - per : tid;
   put(tid, gatherValue<MF>(F, nsC, accC, S, t, sc));
 }

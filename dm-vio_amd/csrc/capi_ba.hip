@@ -172,7 +172,7 @@ struct dmvio_hip_ba {
   // addPoint<1> consumes, the activity views of the three accumulation passes, the per-point LF sums; host copies of what calcLEnergyPt reads
   int n_lin = 0;
   unsigned char *d_lin = nullptr, *d_linMask = nullptr, *d_linActive = nullptr, *d_topActive = nullptr;
-  float *d_rtz = nullptr, *d_linRec = nullptr, *d_lHdd = nullptr, *d_lbd = nullptr, *d_lHcd = nullptr, *d_HcdAF = nullptr;
+  float *d_rtz = nullptr, *d_linRec = nullptr, *d_lHdd = nullptr, *d_lbd = nullptr, *d_lHcd = nullptr, *d_HcdAF = nullptr, *d_linE = nullptr;
   std::vector<unsigned char> h_lin, h_linAct;
   std::vector<float> h_linJ, h_rtz;
   bool fullJ_applied = false;   // d_fullJ holds the Jacobians of the APPLIED linearisation (the last linearisation was followed by its applyRes)
@@ -1270,7 +1270,6 @@ int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* 
   BAHost& H = b->H;
   if (R != H.R) return failmsg("ba_fix_linearization: R differs from the graph's residual count");
   if (sharded(b)) return failmsg("ba_fix_linearization: not available on a window whose points are sharded over ranks");
-  if (b->device_loop) return failmsg("ba_fix_linearization: the window runs the device-resident loop (dmvio_hip_ba_set_device_loop): host-driven loop only");
   if (!b->keep_fullJ || !b->fullJ_applied)
     return failmsg("ba_fix_linearization: the Jacobians of the applied linearisation are not resident — call dmvio_hip_ba_keep_jacobians(ba, 1) before the optimize / "
                    "linearize(fix) + apply that precedes this call");
@@ -1279,7 +1278,7 @@ int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* 
   if (!b->d_lin) {
     if (dalloc(b, &b->d_lin, R) || dalloc(b, &b->d_linMask, R) || dalloc(b, &b->d_linActive, R) || dalloc(b, &b->d_topActive, R) || dalloc(b, &b->d_rtz, (size_t)R * 8) ||
         dalloc(b, &b->d_linRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_lHdd, N) || dalloc(b, &b->d_lbd, N) || dalloc(b, &b->d_lHcd, (size_t)N * 4) ||
-        dalloc(b, &b->d_HcdAF, (size_t)N * 4)) return -1;
+        dalloc(b, &b->d_HcdAF, (size_t)N * 4) || dalloc(b, &b->d_linE, (size_t)R * 8)) return -1;
     b->h_lin.assign(R, 0);
   }
   H.setPrecalcValues();
@@ -2033,9 +2032,9 @@ static size_t batchTabBytes() {
   const size_t n = BA_BATCH_NMAX, F2 = (size_t)BA_MAXF_CAP * BA_MAXF_CAP;
   return ((n * n + n + 7 * n) * sizeof(double) + 2 * F2 * 64 * sizeof(float) + F2 * sizeof(BAPrecalc) + 255) & ~(size_t)255;
 }
-static size_t batchOutBytes() {
+static size_t batchOutBytes() {   // [sys | trace | x_last | H_L, b_L of the residuals kept linearised]
   const size_t n = BA_BATCH_NMAX;
-  return ((2 * (n * n + n) + 1 + 256 + n) * sizeof(double) + 255) & ~(size_t)255;
+  return ((2 * (n * n + n) + 1 + 256 + n + (n * n + n)) * sizeof(double) + 255) & ~(size_t)255;
 }
 extern "C" {
 dmvio_hip_ba_batch* dmvio_hip_ba_batch_create(dmvio_hip_ctx* ctx, int max_windows) {
@@ -2175,13 +2174,13 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     std::vector<std::pair<dmvio_hip_ba*, hipStream_t>> saved;
     ~StreamSwap() { for (auto& kv : saved) kv.first->stream = kv.second; }
   } swap;
-  int gx_lin = 0, gx_pt8 = 0, gx_acc = 0, gx_res = 0;
+  int gx_lin = 0, gx_pt8 = 0, gx_acc = 0, gx_res = 0, gx_pts = 0;
   const int n_gather = (tot + 256) / 256, n_stitch = F + F2;
   for (int w = 0; w < Wn; w++) {
     dmvio_hip_ba* b = hs[w];
     if (b->stream != s) { HIPCHK(hipStreamSynchronize(b->stream)); swap.saved.emplace_back(b, b->stream); b->stream = s; }
     const int nacc = b->nsC + F2 * b->nsTop + (F2 * F * b->nsD + 3) / 4;
-    gx_lin = std::max(gx_lin, b->n_lin_blocks); gx_pt8 = std::max(gx_pt8, b->n_pt8_blocks); gx_acc = std::max(gx_acc, nacc); gx_res = std::max(gx_res, (b->H.R + 255) / 256);
+    gx_lin = std::max(gx_lin, b->n_lin_blocks); gx_pt8 = std::max(gx_pt8, b->n_pt8_blocks); gx_acc = std::max(gx_acc, nacc); gx_res = std::max(gx_res, (b->H.R + 255) / 256); gx_pts = std::max(gx_pts, b->H.N);
   }
   auto prepare = [&](const int w) -> int {
     dmvio_hip_ba* b = hs[w];
@@ -2222,7 +2221,15 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     BASolveDev& S = V.S;
     S.F = F; S.n = n; S.stepped = 0; S.iterations_done = 0; S.n_accepted = 0; S.exact_backsub = B->exact_backsub;
     S.lambda = 1e-5;
-    S.lastL = H.calcLEnergyFrames(); S.lastM = H.calcMEnergy(); S.newL = S.lastL; S.newM = S.lastM;
+    S.lastL = calcLEnergy(b); S.lastM = H.calcMEnergy(); S.newL = S.lastL; S.newM = S.lastM;
+    // residuals kept linearised (dmvio_hip_ba_fix_linearization): what the three-pass accumulation and the linearised energy read, at the deltas of the state the window enters with
+    V.n_lin = b->n_lin; V.n_lin_runs = (H.N + 49) / 50; V.lin_cnt = 0;
+    if (b->n_lin > 0) {
+      V.fullJ = b->d_fullJ; V.lin = b->d_lin; V.rtz = b->d_rtz; V.linRec = b->d_linRec; V.linActive = b->d_linActive; V.topActive = b->d_topActive; V.linE = b->d_linE;
+      std::vector<float> adHT;
+      H.adHTdeltaF(adHT);
+      for (int k = 0; k < 2; k++) { memcpy(V.adHTdelta[k], adHT.data(), sizeof(float) * adHT.size()); for (int i = 0; i < 4; i++) V.cDeltaF[k][i] = H.cDeltaF[i]; }
+    }
     for (int i = 0; i < 4; i++) { S.c_value[i] = H.c_value[i]; S.c_value_zero[i] = H.c_value_zero[i]; S.c_value_backup[i] = H.c_value[i]; S.cPrior[i] = H.cPrior[i]; S.cPriorF[i] = H.cPriorF[i]; }
     for (int f = 0; f < F; f++) {
       BAFrameDev& q = S.fr[f]; const BAFrameHost& h = H.fr[f];
@@ -2249,6 +2256,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     V.pre = reinterpret_cast<const BAPrecalc*>(S.adTargetF + (size_t)F2 * 64);
     b->pre_static_valid = false;           // the handle's own table was not refreshed
     S.trace = V.sys + tot + 1; S.x_last = S.trace + 256;
+    V.sysL = S.x_last + BA_BATCH_NMAX;
     return 0;
   };
   if (int r = B->workers.parallelFor(Wn, prepare)) return r;
@@ -2289,13 +2297,24 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       else hipLaunchKernelGGL((k_ba_solve<BA_MAXF_CAP, false>), dim3(q.cnt), dim3(BA_SOLVE_THREADS), solveLds, q.st, B->d_wins + q.w0, it);
     }
   };
-  auto chain = [&](const Grp& q, const int backup, const int apply, const int gate, const bool sums_done) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
+  // a group that holds a window with residuals kept linearised runs EnergyFunctional's three accumulations (L / A / Schur pass: accumulateLin above) for those windows; its
+  // other windows take their one ordinary accumulation in the A pass
+  bool grpLin[dmvio_hip_ba_batch::BA_BATCH_STREAMS];
+  for (int g = 0; g < G; g++) { grpLin[g] = false; for (int w = grp[g].w0; w < grp[g].w0 + grp[g].cnt; w++) grpLin[g] = grpLin[g] || hs[w]->n_lin > 0; }
+  auto linRecords = [&](const Grp& q, const int gate, const bool sums) {   // the addPoint<1> records (and the A / L activity views); sums: + the linearised residuals' per-point sums
+    const BAWinDev* dwq = B->d_wins + q.w0;
+    hipLaunchKernelGGL(k_ba_lin_records_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, gate);
+    if (sums) hipLaunchKernelGGL(k_ba_lin_point_sums_b, dim3((gx_pts + 255) / 256, q.cnt), dim3(256), 0, q.st, dwq, gate);
+  };
+  auto chain = [&](const Grp& q, const int g, const int backup, const int apply, const int gate, const bool sums_done) {   // applyRes + per-point sums -> accumulate -> stitch -> gather: the system of the (new) state
     const BAWinDev* dwq = B->d_wins + q.w0;
     if (!sums_done) hipLaunchKernelGGL(k_ba_point_sums_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq, backup, apply, gate);
-    hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, q.cnt), dim3(256), 0, q.st, dwq, gate);
-    hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, q.cnt), dim3(64 * F), sizeof(StitchWave) * F, q.st, dwq, gate);
-    if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate);
-    else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate);
+    for (int pass = grpLin[g] ? (int)BA_PASS_L : (int)BA_PASS_ALL; pass <= (grpLin[g] ? (int)BA_PASS_S : (int)BA_PASS_ALL); pass++) {
+      hipLaunchKernelGGL(k_ba_accumulate_b, dim3(gx_acc, q.cnt), dim3(256), 0, q.st, dwq, gate, pass);
+      hipLaunchKernelGGL(k_ba_stitch_b, dim3(n_stitch, q.cnt), dim3(64 * F), sizeof(StitchWave) * F, q.st, dwq, gate, pass);
+      if (F <= BA_MAXF) hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate, pass);
+      else hipLaunchKernelGGL((k_ba_stitch_gather_b<BA_MAXF_CAP>), dim3(n_gather, q.cnt), dim3(256), 0, q.st, dwq, gate, pass);
+    }
   };
   // ---- every residual still in the graph active again (FullSystemOptimize.cpp:431-448), initial linearisation, applyRes and the first system (:450-470)
   for (int g = 0; g < G; g++) {
@@ -2306,7 +2325,8 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     linearize(q.st, dwq, q.cnt, BA_LINB_INITIAL);
     if (g + 1 < G) HIPCHK(hipEventRecord(B->gev[g][0], q.st));
     hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, dwq, 0, (int)BA_GATE_ALWAYS);
-    chain(q, 1, 0, BA_GATE_ALWAYS, false);
+    if (grpLin[g]) linRecords(q, BA_GATE_ALWAYS, true);
+    chain(q, g, 1, 0, BA_GATE_ALWAYS, false);
   }
   // ---- the loop (:485-586): nothing in it waits for the host
   for (int it = 0; it < mnumOptIts; it++)
@@ -2314,6 +2334,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       const Grp& q = grp[g];
       const BAWinDev* dwq = B->d_wins + q.w0;
       solve(q, it, 0);
+      if (grpLin[g]) hipLaunchKernelGGL(k_ba_lin_energy_b, dim3(gx_res, q.cnt), dim3(256), 0, q.st, B->d_wins + q.w0);   // E_L's linearised term of the stepped state, for the accept test
       const bool prof = B->profile && g == 0 && it == std::min(1, mnumOptIts - 1);
       if (prof) HIPCHK(hipEventRecord(B->ev[4], q.st));
       if (lin1) { hipLaunchKernelGGL(k_ba_resubstitute_b, dim3(gx_pt8, q.cnt), dim3(256), 0, q.st, dwq); linearize(q.st, dwq, q.cnt, BA_LINB_STEPPED_DONE); }
@@ -2321,10 +2342,12 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
       if (prof) HIPCHK(hipEventRecord(B->ev[5], q.st));
       // rejected: restore + relinearise | accepted: applyRes + per-point sums (the last iteration's accepted step is only applied: nobody solves its system) — one launch
       const int what = it < mnumOptIts - 1 ? 0 : 1;
+      if (grpLin[g] && what == 0) linRecords(q, BA_GATE_ACCEPTED, true);   // (the per-point sums below add the linearised residuals' Hdd / bd / Hcd)
       const int gx_post = std::max(lin1 ? gx_lin1 : gx_lin, what == 0 ? gx_pt8 : gx_res);
       if (lin1) hipLaunchKernelGGL((k_ba_post_decide_b<true>), dim3(gx_post, q.cnt), dim3(LIN_THREADS), patchLds, q.st, dwq, fs, what);
       else hipLaunchKernelGGL((k_ba_post_decide_b<false>), dim3(gx_post, q.cnt), dim3(LIN_THREADS), 0, q.st, dwq, fs, what);
-      if (what == 0) chain(q, 1, 1, BA_GATE_ACCEPTED, true);
+      if (grpLin[g] && what == 0) linRecords(q, BA_GATE_ACCEPTED, false);  // (again behind applyRes: the A pass's activity view follows the applied states)
+      if (what == 0) chain(q, g, 1, 1, BA_GATE_ACCEPTED, true);
     }
   for (int g = 0; g < G; g++) {
     solve(grp[g], mnumOptIts, 1);   // settle the last decision
@@ -2390,6 +2413,11 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   for (int w = 0; w < Wn; w++) {
     dmvio_hip_ba* b = hs[w];
     BAHost& H = b->H;
+    if (b->n_lin > 0) {   // accumulateLF_MT's system of the last accumulation, for dmvio_hip_ba_get_lf_system and the host-side solve entry points
+      std::vector<double> lf((size_t)n * n + n);
+      HIPCHK(hipMemcpy(lf.data(), B->h_wins[w].sysL, sizeof(double) * lf.size(), hipMemcpyDeviceToHost));
+      H.HLraw.assign(lf.begin(), lf.begin() + (size_t)n * n); H.bLraw.assign(lf.begin() + (size_t)n * n, lf.end());
+    }
     const double fe = b->h_res->E[0];
     H.fr[F - 1].frameEnergyTH = b->h_res->th[0];
     b->final_energy = fe;
@@ -2426,7 +2454,6 @@ int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* cons
     dmvio_hip_ba* b = windows[i];
     if (!b->graph_ready) return failmsg("ba_optimize_batch: set_window + set_graph first");
     if (sharded(b)) return failmsg("ba_optimize_batch: a window sharded over ranks cannot join a batch");
-    if (b->n_lin > 0) return failmsg("ba_optimize_batch: a window with residuals kept linearised (dmvio_hip_ba_fix_linearization) runs through the host-driven loop only");
   }
   // groups of equal keyframe count, in the caller's order
   std::vector<char> doneW(W, 0);
@@ -2453,7 +2480,6 @@ int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* cons
 int dmvio_hip_ba_set_device_loop(dmvio_hip_ba* b, int on) {
   if (!b) return failmsg("ba: null handle");
   BA_LOCK(b);
-  if (on && b->n_lin > 0) return failmsg("ba_set_device_loop: the graph carries residuals kept linearised (dmvio_hip_ba_fix_linearization): host-driven loop only");
   b->device_loop = on != 0;
   return 0;
 }

@@ -370,30 +370,46 @@ def test_graph_with_a_linearised_residual_is_refused(pkg, synth, gpu_required):
     assert ba.optimize(2)["finalEnergy"] == r0["finalEnergy"]
 
 
-def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu_required):
+@pytest.mark.parametrize("loop", ["host", "device", "batch4"])
+def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu_required, loop):
     """EFResidual::fixLinearizationF outside a marginalisation, accumulateLF_MT / addPoint<1> and calcLEnergyPt (EnergyFunctionalStructs.cpp:85-113,
     AccumulatedTopHessian.cpp:52-58,84-98, EnergyFunctional.cpp:223-233,349-409); the oracle's branch is pinned bit for bit to libref.so (tests/test_ref_pin_cpu.py).
     First with identical bits on both sides — non-zero frame deltas at the fix and other ones at the accumulation, set through the API: H_L / b_L, the A and Schur systems
-    as tight as the accumulation itself, the per-point sums bit for bit, E_L to double rounding.  Then through optimisations over the graph that carries them."""
+    as tight as the accumulation itself, the per-point sums bit for bit, E_L to double rounding.  Then through optimisations over the graph that carries them — on the
+    host-driven loop, on the device-resident loop (dmvio_hip_ba_set_device_loop: k_ba_solve adds H_L / b_L, k_ba_lin_energy_b the linearised energy, three accumulation
+    passes per system on the device) and as one of four windows of a dmvio_hip_ba_optimize_batch call (two more windows carrying linearised residuals, one without)."""
     case = synth.ba_case(256, 192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
-    ctx, ba, W = _window(pkg, oracle, case)
     R = len(case["res_point"]); F = case["n_frames"]
-    rng = np.random.RandomState(11)
-
-    def perturb(scale):
-        for k in range(1, F):
-            st = np.zeros(10); st[:3] = 2e-3 * scale * rng.standard_normal(3); st[3:6] = 1e-3 * scale * rng.standard_normal(3)
-            st[6] = 1e-3 * scale * rng.standard_normal(); st[7] = 1e-4 * scale * rng.standard_normal()
-            ba.set_frame_state(k, st); W.set_frame_state(k, st)
-
-    perturb(1.0)
-    ba.activate_all(); W.activate_all()
-    ba.linearize_all(False); W.linearize_all(False)
-    ba.apply_res(); W.apply_res()
     mask = (np.arange(R) % 3 == 0).astype(np.uint8)
-    n_lin = ba.fix_linearization(mask)                                                # res_toZeroF = resF - J delta at the first deltas
-    assert n_lin == W.fix_linearization(mask) and 100 < n_lin <= (R + 2) // 3
-    perturb(0.5)                                                                      # resApprox = res_toZeroF + J delta at the second ones
+
+    def lin_window(ctx=None, with_oracle=True, check=False):
+        """a window with a third of its residuals kept linearised at one set of frame deltas, standing at another one"""
+        if ctx is None:
+            ctx, ba, W = _window(pkg, oracle, case)
+        else:
+            ba = pkg.BundleAdjusterHip(ctx, accumulators=1, keep_jacobians=True); ba.set_case(case, list(range(F)))
+            W = oracle.BAWindow(case) if with_oracle else None
+        rng = np.random.RandomState(11)
+
+        def perturb(scale):
+            for k in range(1, F):
+                st = np.zeros(10); st[:3] = 2e-3 * scale * rng.standard_normal(3); st[3:6] = 1e-3 * scale * rng.standard_normal(3)
+                st[6] = 1e-3 * scale * rng.standard_normal(); st[7] = 1e-4 * scale * rng.standard_normal()
+                ba.set_frame_state(k, st)
+                if W is not None:
+                    W.set_frame_state(k, st)
+        perturb(1.0)
+        ba.activate_all(); ba.linearize_all(False); ba.apply_res()
+        if W is not None:
+            W.activate_all(); W.linearize_all(False); W.apply_res()
+        n_lin = ba.fix_linearization(mask)                                              # res_toZeroF = resF - J delta at the first deltas
+        if W is not None:
+            assert n_lin == W.fix_linearization(mask)
+        assert 100 < n_lin <= (R + 2) // 3
+        perturb(0.5)                                                                    # resApprox = res_toZeroF + J delta at the second ones
+        return ctx, ba, W, n_lin
+
+    ctx, ba, W, n_lin = lin_window()
     ag, ao = ba.accumulate(), W.accumulate()
     HLg, bLg = ba.lf_system()
     assert ag["resInA"] == ao["resInA"] and 0 < ag["resInA"] < R - n_lin + 1          # addPoint<0> left the linearised ones out
@@ -411,7 +427,31 @@ def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu
     x_g = ba.solve(0, 1e-5); x_o = W.solve(0, 1e-5)
     assert np.linalg.norm(x_g - x_o) <= 1e-6 * np.linalg.norm(x_o)
     # a second optimize over the graph that carries them: same decisions, energies and states
-    rg = ba.optimize(4); ro = W.optimize(4)
+    others = []
+    if loop == "host":
+        rg = ba.optimize(4)
+    elif loop == "device":
+        ba.set_device_loop(True)
+        rg = ba.optimize(4)
+    else:
+        # the same window twice more (their solve / accumulate calls above replayed, so that they stand where `ba` stands) and a window without linearised residuals
+        for _ in range(2):
+            _, b2, _, n2 = lin_window(ctx, with_oracle=False)
+            assert n2 == n_lin
+            b2.accumulate(); b2.solve(0, 1e-5)
+            others.append(b2)
+        plain = pkg.BundleAdjusterHip(ctx, accumulators=1); plain.set_case(case, list(range(F)))
+        single = pkg.BundleAdjusterHip(ctx, accumulators=1); single.set_case(case, list(range(F)))
+        B1 = pkg.BundleAdjusterBatch(ctx, 1); r_single = B1.optimize([single], 4)[0]
+        B4 = pkg.BundleAdjusterBatch(ctx, 4)
+        rs = B4.optimize([ba, others[0], plain, others[1]], 4)
+        rg = rs[0]
+        for r2 in (rs[1], rs[3]):                                                      # the three windows that carry the same linearised residuals: the same bits
+            assert np.array_equal(r2["trace"], rg["trace"]) and r2["finalEnergy"] == rg["finalEnergy"]
+        assert np.array_equal(rs[2]["trace"], r_single["trace"]) and rs[2]["finalEnergy"] == r_single["finalEnergy"]   # ... and their neighbour is not touched by them
+        assert np.abs(r_single["trace"][:, 1]).max() < np.abs(rg["trace"][:, 1]).min()    # (its E_L has no linearised term)
+        others += [plain, single, B1, B4]
+    ro = W.optimize(4)
     assert np.array_equal(rg["trace"][:, 3], ro["trace"][:, 3])
     assert np.allclose(rg["trace"][:, 0], ro["trace"][:, 0], rtol=1e-4) and np.allclose(rg["trace"][:, 1], ro["trace"][:, 1], rtol=1e-4)
     assert np.abs(ro["trace"][:, 1]).min() > 1.0                                      # E_L carries the linearised term in every row
@@ -419,20 +459,20 @@ def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu
     for k in range(5):
         pg_, ag_, _ = ba.frame_pose(k); po_, ao_, _ = W.frame_pose(k)
         assert np.linalg.norm(pg_[:3] - po_[:3]) < 1e-3 and np.allclose(ag_, ao_, atol=1e-3)
+    HL2, bL2 = ba.lf_system()                                                          # accumulateLF_MT's system of the loop's last accumulation came back with the states
+    assert np.abs(HL2 - np.diag(np.diag(HL2))).max() > 1e3
     zero = np.zeros(R, np.uint8)
-    assert ba.fix_linearization(zero) == W.fix_linearization(zero) == n_lin            # the final linearizeAll(true) removes none of them
-    # the fast paths refuse such a window instead of dropping the term
-    with pytest.raises(pkg.HipLibraryError, match="kept linearised"):
-        ba.set_device_loop(True)
-    batch = pkg.BundleAdjusterBatch(ctx, 1)
-    with pytest.raises(pkg.HipLibraryError, match="kept linearised"):
-        batch.optimize([ba], 2)
-    # marginalising the points relinearises their residuals (FullSystem.cpp:840-843): the linearised flags of those points go
-    cand = np.zeros(ba.N, np.uint8); cand[: ba.N // 2] = 1
-    ba.marginalize_points(cand)
-    left = ba.fix_linearization(zero)
-    rp = np.asarray(case["res_point"])
-    assert left < n_lin and left <= int(np.sum(mask.astype(bool) & (rp >= ba.N // 2)))
+    if loop == "host":
+        assert ba.fix_linearization(zero) == W.fix_linearization(zero) == n_lin        # the final linearizeAll(true) removes none of them
+        # marginalising the points relinearises their residuals (FullSystem.cpp:840-843): the linearised flags of those points go
+        cand = np.zeros(ba.N, np.uint8); cand[: ba.N // 2] = 1
+        ba.marginalize_points(cand)
+        left = ba.fix_linearization(zero)
+        rp = np.asarray(case["res_point"])
+        assert left < n_lin and left <= int(np.sum(mask.astype(bool) & (rp >= ba.N // 2)))
+    # a window sharded over ranks still refuses such a graph instead of dropping the term (the L system would have to join the all-reduce)
+    for o in others:
+        o.close()
     ba.close()
 
 
