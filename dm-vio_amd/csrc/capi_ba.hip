@@ -171,6 +171,8 @@ struct dmvio_hip_ba {
   // ---- residuals kept linearised outside a marginalisation (dmvio_hip_ba_fix_linearization; ba_kernels.hpp "residuals kept linearised"): flags, res_toZeroF, the record
   // addPoint<1> consumes, the activity views of the three accumulation passes, the per-point LF sums; host copies of what calcLEnergyPt reads
   int n_lin = 0;
+  long long n_lin_global = 0;   // sharded window: the ranks' n_lin summed (dmvio_hip_ba_fix_linearization is collective there) — every rank takes the three-pass accumulation or none
+  double* d_red1 = nullptr;     // one double for small all-reduces (the linearised energy of a sharded window)
   unsigned char *d_lin = nullptr, *d_linMask = nullptr, *d_linActive = nullptr, *d_topActive = nullptr;
   float *d_rtz = nullptr, *d_linRec = nullptr, *d_lHdd = nullptr, *d_lbd = nullptr, *d_lHcd = nullptr, *d_HcdAF = nullptr, *d_linE = nullptr;
   std::vector<unsigned char> h_lin, h_linAct;
@@ -350,6 +352,7 @@ static BADecide makeDecide(dmvio_hip_ba* b, int mode, bool update_th, bool publi
 // ---- exchange steps of the sharded iteration.  With an RCCL communicator they are enqueued on the handle's stream between the kernels that produce
 // and consume the buffers (no host hop); the callback transport stages them through host memory.
 static bool sharded(const dmvio_hip_ba* b) { return b->world > 0; }
+static bool linAny(const dmvio_hip_ba* b) { return sharded(b) ? b->n_lin_global > 0 : b->n_lin > 0; }   // any rank holds a residual kept linearised
 static hipEvent_t* commEvents(dmvio_hip_ba* b, const int kind) {
   b->comm_total[kind]++;
   if (!b->comm_timing || b->comm_n[kind] >= dmvio_hip_ba::COMM_EVS) return nullptr;
@@ -465,7 +468,7 @@ static int accumulateWait(dmvio_hip_ba* b);
 // apply_first: applyRes_Reductor(true) fused into the per-point sums; gate: the whole chain only runs when the last accept test says so
 static int accumulateLin(dmvio_hip_ba* b, bool backup_points, bool apply_first);
 static int accumulate(dmvio_hip_ba* b, bool backup_points = false, bool wait = true, bool sums_fresh = false, bool apply_first = false, int gate = BA_GATE_ALWAYS) {
-  if (b->n_lin > 0) {
+  if (linAny(b)) {
     if (!wait || gate != BA_GATE_ALWAYS) return failmsg("ba: a graph with residuals kept linearised is accumulated synchronously");
     return accumulateLin(b, backup_points, apply_first);
   }
@@ -597,6 +600,19 @@ static double linEnergy(dmvio_hip_ba* b) {
 }
 // EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:414-431)
 static double calcLEnergy(dmvio_hip_ba* b) { return b->n_lin > 0 ? b->H.calcLEnergyFrames() + linEnergy(b) : b->H.calcLEnergyFrames(); }
+// ... of a window whose points are sharded over ranks: the frame / calibration part is the same on every rank, the linearised residuals' term is this rank's points' share —
+// summed over the ranks by one more (one-double) all-reduce, which every rank enters (n_lin_global decides, not the rank's own count)
+static int calcLEnergyR(dmvio_hip_ba* b, double* out) {
+  if (!sharded(b) || b->n_lin_global == 0) { *out = calcLEnergy(b); return 0; }
+  double l = b->n_lin > 0 ? linEnergy(b) : 0.0;
+  if (!b->d_red1) { if (dalloc(b, &b->d_red1, 1)) return -1; }
+  HIPCHK(b->bounce.h2d(b->d_red1, &l, sizeof(double), b->stream));
+  if (int r = commAllReduceSum(b, b->d_red1, 1)) return r;
+  HIPCHK(b->bounce.d2h(&l, b->d_red1, sizeof(double), b->stream));
+  HIPCHK(b->bounce.finish(b->stream));
+  *out = b->H.calcLEnergyFrames() + l;
+  return 0;
+}
 // the gather kernel publishes per workgroup (BAHostRes::gticket): wait until every slot shows the chain's ticket
 static int waitGather(dmvio_hip_ba* b, const unsigned int ticket, const int nblk) {
   volatile unsigned int* slots = b->h_res->gticket;
@@ -748,7 +764,7 @@ static int setComm(dmvio_hip_ba* b, ncclComm_t comm, const dmvio_hip_comm_callba
   BA_LOCK(b);
   if (world == 0 || (!comm && !cb)) { b->world = 0; b->rank = 0; b->nccl = nullptr; b->comm_cb = dmvio_hip_comm_callbacks{}; b->sys_ready = false; b->sums_fresh = false; return 0; }
   if (world < 1 || rank < 0 || rank >= world) return failmsg("ba_set_comm: 0 <= rank < world");
-  if (b->n_lin > 0) return failmsg("ba_set_comm: the graph carries residuals kept linearised (dmvio_hip_ba_fix_linearization): single-device windows only");
+  if (b->n_lin > 0) return failmsg("ba_set_comm: the graph already carries residuals kept linearised — set the communicator first, dmvio_hip_ba_fix_linearization is collective on a sharded window");
   if (cb && (!cb->allreduce_sum_f64 || !cb->allgather)) return failmsg("ba_set_comm_callbacks: both callbacks are required");
   if (comm) {
     RCCL_READY();
@@ -986,7 +1002,8 @@ int dmvio_hip_ba_marginalize_points(dmvio_hip_ba* b, const unsigned char* candid
   if (b->n_lin > 0) {   // FullSystem.cpp:840-843: a candidate point's residuals are relinearised with isLinearized = false
     for (int ri = 0; ri < R; ri++) if (candidates[b->h_point[ri]] && b->h_lin[ri]) { b->h_lin[ri] = 0; b->n_lin--; }
     HIPCHK(b->bounce.h2d(b->d_lin, b->h_lin.data(), R, s));
-    if (b->n_lin == 0) { b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear(); }
+    if (!sharded(b)) b->n_lin_global = b->n_lin;
+    if (b->n_lin == 0 && !sharded(b)) { b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear(); }
   }
   hipLaunchKernelGGL(k_ba_marg_decide, dim3((N + 255) / 256), dim3(256), 0, s, N, b->d_cand, b->P.idepth_hessian, setting_minIdepthH_marg, b->d_decision);
   const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
@@ -1034,7 +1051,7 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
   b->th_pending = false;   // the stream is drained and h_res is cleared below (th_ticket restarts at 0 while b->ticket keeps counting): nothing of the old graph may be awaited
   freeDevice(b);
   // residuals kept linearised belong to the graph they were linearised in
-  b->n_lin = 0; b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->d_lin = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear();
+  b->n_lin = 0; b->n_lin_global = 0; b->Rs.lin = nullptr; b->P.lHdd = b->P.lbd = b->P.lHcd = nullptr; b->P.HcdAF = nullptr; b->d_lin = nullptr; b->d_red1 = nullptr; b->H.HLraw.clear(); b->H.bLraw.clear();
   b->h_lin.clear(); b->h_linAct.clear(); b->h_linJ.clear(); b->h_rtz.clear(); b->fullJ_applied = false;
   // the arena of the previous graph, cleared for this one on the handle's stream; the uploads and kernels below follow on the same stream: no wait
   for (size_t k = 0; k < b->arena.chunks.size(); k++) if (b->arena.used[k]) { HIPCHK(hipMemsetAsync(b->arena.chunks[k].first, 0, b->arena.used[k], b->stream)); b->arena.used[k] = 0; }   // what the previous graph used, not the whole chunk
@@ -1269,7 +1286,6 @@ int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* 
   BA_READY_LOCKED(b);
   BAHost& H = b->H;
   if (R != H.R) return failmsg("ba_fix_linearization: R differs from the graph's residual count");
-  if (sharded(b)) return failmsg("ba_fix_linearization: not available on a window whose points are sharded over ranks");
   if (!b->keep_fullJ || !b->fullJ_applied)
     return failmsg("ba_fix_linearization: the Jacobians of the applied linearisation are not resident — call dmvio_hip_ba_keep_jacobians(ba, 1) before the optimize / "
                    "linearize(fix) + apply that precedes this call");
@@ -1299,7 +1315,17 @@ int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* 
   HIPCHK(b->bounce.finish(s));
   b->n_lin = 0;
   for (int ri = 0; ri < R; ri++) if (b->h_lin[ri]) b->n_lin++;
-  if (b->n_lin > 0) { b->Rs.lin = b->d_lin; b->P.lHdd = b->d_lHdd; b->P.lbd = b->d_lbd; b->P.lHcd = b->d_lHcd; b->P.HcdAF = b->d_HcdAF; }
+  b->n_lin_global = b->n_lin;
+  if (sharded(b)) {   // collective: every rank of the window calls this (with the flags of its own residuals); the ranks' counts are summed
+    double cnt = (double)b->n_lin;
+    if (!b->d_red1) { if (dalloc(b, &b->d_red1, 1)) return -1; }
+    HIPCHK(b->bounce.h2d(b->d_red1, &cnt, sizeof(double), s));
+    if (int r = commAllReduceSum(b, b->d_red1, 1)) return r;
+    HIPCHK(b->bounce.d2h(&cnt, b->d_red1, sizeof(double), s));
+    HIPCHK(b->bounce.finish(s));
+    b->n_lin_global = (long long)(cnt + 0.5);
+  }
+  if (linAny(b)) { b->Rs.lin = b->d_lin; b->P.lHdd = b->d_lHdd; b->P.lbd = b->d_lbd; b->P.lHcd = b->d_lHcd; b->P.HcdAF = b->d_HcdAF; }
   if (n_linearized) *n_linearized = b->n_lin;
   return 0;
 }
@@ -1383,7 +1409,7 @@ int dmvio_hip_ba_get_point_acc(dmvio_hip_ba* b, float* Hdd, float* bd, float* Hc
   const int N = b->H.N;
   if (Hdd) HIPCHK(b->bounce.d2h(Hdd, b->P.Hdd, sizeof(float) * N, s));
   if (bd) HIPCHK(b->bounce.d2h(bd, b->P.bd, sizeof(float) * N, s));
-  if (Hcd4) HIPCHK(b->bounce.d2h(Hcd4, b->n_lin > 0 ? b->P.HcdAF : b->P.Hcd, sizeof(float) * 4 * N, s));   // Hcd_accAF
+  if (Hcd4) HIPCHK(b->bounce.d2h(Hcd4, linAny(b) ? b->P.HcdAF : b->P.Hcd, sizeof(float) * 4 * N, s));   // Hcd_accAF
   if (HdiF) HIPCHK(b->bounce.d2h(HdiF, b->P.HdiF, sizeof(float) * N, s));
   if (bdSumF) HIPCHK(b->bounce.d2h(bdSumF, b->P.bdSumF, sizeof(float) * N, s));
   HIPCHK(b->bounce.finish(s));
@@ -1653,7 +1679,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
   if (canbreak_out) *canbreak_out = canbreak;
   const int minOpt = (b->vio_opt && b->vio_opt->minOptIterations >= 0) ? b->vio_opt->minOptIterations : H.S.minOptIterations;
   if (canbreak && iteration >= minOpt) last = true;
-  const double newL = calcLEnergy(b), newM = calcMEnergy(b, true);
+  double newL = 0;
+  if (int r = calcLEnergyR(b, &newL)) return r;
+  const double newM = calcMEnergy(b, true);
   if (dynDuring) b->dynW = vioDynamicWeight(b, lastE[0], b->resInA_solve);   // before deciding whether to accept the step (FullSystemOptimize.cpp:534-538)
   // linearise the stepped state; the kernel's last workgroup sums the energy, sets the newest keyframe's threshold and decides
   fillWindow(b);
@@ -1697,7 +1725,9 @@ static int gnIteration(dmvio_hip_ba* b, int iteration, double& lambda, double la
     H.setPrecalcValues();
     fillWindow(b);
     b->dyn_cur = dyn_backup;
-    const double oldL = calcLEnergy(b), oldM = calcMEnergy(b, false);
+    double oldL = 0;
+    if (int r = calcLEnergyR(b, &oldL)) return r;
+    const double oldM = calcMEnergy(b, false);
     lastE[1] = oldL; lastE[2] = oldM;
     b->pending_reject = true; b->pending_ticket = D2.ticket; b->pending_trace = trace_slot;
     if (!defer) { if (int r = settleReject(b, lastE, true)) return r; }
@@ -1822,7 +1852,7 @@ int dmvio_hip_ba_set_new_frame_energy_th(dmvio_hip_ba* b, float th) {
 int dmvio_hip_ba_energy_terms(dmvio_hip_ba* b, double* EL, double* EM) {
   if (!b) return failmsg("null ba");
   BA_LOCK(b);
-  if (EL) *EL = calcLEnergy(b);
+  if (EL) { if (int r = calcLEnergyR(b, EL)) return r; }
   if (EM) *EM = b->H.calcMEnergy();
   return 0;
 }
@@ -1855,7 +1885,8 @@ static int optimizeImpl(dmvio_hip_ba* b, int mnumOptIts, const dmvio_hip_ba_call
   if (int r = accumulate(b, true, true, false)) return r;   // backupState of the points rides in the per-point sums; the frames are backed up by the first iteration
   linearizePickUp(b, &lastE[0], false);
   b->sys_ready = true;
-  lastE[1] = calcLEnergy(b); lastE[2] = calcMEnergy(b, false);
+  if (int r = calcLEnergyR(b, &lastE[1])) return r;
+  lastE[2] = calcMEnergy(b, false);
   double lambda = 1e-5;
   int done = 0;
   b->trace[0][0] = lastE[0]; b->trace[0][1] = lastE[1]; b->trace[0][2] = lastE[2]; b->trace[0][3] = 1;

@@ -358,8 +358,10 @@ int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* ba, int R, const unsigned char
  * linearisation: dmvio_hip_ba_keep_jacobians(ba, 1) before the HOST-DRIVEN dmvio_hip_ba_optimize (or linearize(fix) / linearize + apply) that precedes this call (the
  * device-resident loop does not write them).  A graph that carries such residuals is optimised by the host-driven loop, by the device-resident loop
  * (dmvio_hip_ba_set_device_loop: k_ba_solve adds H_L / b_L, the linearised energy and the three accumulation passes run on the device) and inside
- * dmvio_hip_ba_optimize_batch beside windows without them; only a window sharded over ranks (dmvio_hip_ba_set_comm) refuses it.  n_linearized (may be NULL): linearised
- * residuals of the graph after the call. */
+ * dmvio_hip_ba_optimize_batch beside windows without them.  On a window sharded over ranks (dmvio_hip_ba_set_comm before this call) the call is COLLECTIVE: every rank
+ * passes the flags of its own residuals, the ranks' counts are summed, and from then on every rank runs the three accumulation passes — each with its all-reduce — and one more
+ * one-double all-reduce per calcLEnergyF of calcLEnergyPt's term (tests/test_sharded_ba_gpu.py, world 2).  n_linearized (may be NULL): linearised residuals of the graph
+ * (of this rank's part of it) after the call. */
 int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* ba, int R, const unsigned char* res_mask, int* n_linearized);
 /* accumulateLF_MT's result as the reference returns it (EnergyFunctional.cpp:223-233: the stitched system of the linearised residuals plus the frame / calibration priors,
  * AccumulatedTopHessian.cpp:292-302), n x n and n doubles, for the state of the last accumulation (dmvio_hip_ba_accumulate / _solve / _gn_iteration / _optimize) */

@@ -14,16 +14,28 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
-def run_window(P, case, slots_case, comm_setup=None, its=6):
+def run_window(P, case, slots_case, comm_setup=None, its=6, lin_mask=None):
     F = case["n_frames"]
     ctx = P.Context(case["w"], case["h"], n_slots=F)
     for k in range(F):
         ctx.frame_upload(k, slots_case["imgs"][k])
-    ba = P.BundleAdjusterHip(ctx)
+    ba = P.BundleAdjusterHip(ctx, keep_jacobians=lin_mask is not None)
     ba.set_case(case, list(range(F)))
     if comm_setup:
         comm_setup(ba)
-    out = ba.optimize(its)
+    if lin_mask is not None:
+        # EFResidual::fixLinearizationF after two iterations, on the states they left (a collective: every rank passes the flags of its own residuals) — the remaining
+        # iterations run over a graph whose L system, linearised energy and A / Schur views are each the sum of the ranks' parts
+        first = ba.optimize(2)
+        n_lin = ba.fix_linearization(lin_mask)
+        assert 0 < n_lin <= int(lin_mask.sum())
+        out = ba.optimize(its)
+        out["trace"] = np.concatenate([first["trace"], out["trace"]])
+        out["iterations"] += first["iterations"]
+        out["EL"] = ba.energy_terms()[0]
+        out["n_lin"] = n_lin
+    else:
+        out = ba.optimize(its)
     poses = np.stack([ba.frame_pose(k)[0] for k in range(F)])
     aff = np.stack([ba.frame_pose(k)[1] for k in range(F)])
     idepth = ba.point_state()[0]
@@ -41,12 +53,19 @@ def main():
     modes = [("by-keyframe", 10.0), ("equal-ranges", 1.0)]
     if os.environ.get("SHARD_MODES"):
         modes = [dict(modes)[m] and (m, dict(modes)[m]) for m in os.environ["SHARD_MODES"].split(",")]
+    lin = bool(os.environ.get("SHARD_LIN"))
+    full_mask = (np.arange(len(case["res_point"])) % 3 == 0).astype(np.uint8) if lin else None
     for mode, imbalance in modes:
         parts = sh.partition_points_by_host(case["host"], world, max_imbalance=imbalance)
         mine = sh.shard_case(case, parts[rank])
-        out, poses, aff, idepth = run_window(P, mine, case, lambda ba: ba.set_comm_torch(dist))
+        my_mask = None
+        if lin:
+            member = np.zeros(len(case["u"]), dtype=bool); member[np.asarray(parts[rank])] = True
+            my_mask = np.ascontiguousarray(full_mask[member[case["res_point"]]])      # shard_case keeps a point's residuals in their order
+            assert len(my_mask) == len(mine["res_point"])
+        out, poses, aff, idepth = run_window(P, mine, case, lambda ba: ba.set_comm_torch(dist), its=4 if lin else 6, lin_mask=my_mask)
         # every rank took the same decisions and holds the same frame states, bit for bit
-        blob = torch.from_numpy(np.concatenate([out["trace"].ravel(), poses.ravel(), aff.ravel(), [out["rmse"], out["finalEnergy"]]]).copy())
+        blob = torch.from_numpy(np.concatenate([out["trace"].ravel(), poses.ravel(), aff.ravel(), [out["rmse"], out["finalEnergy"], out.get("EL", 0.0)]]).copy())
         allb = [torch.zeros_like(blob) for _ in range(world)]
         dist.all_gather(allb, blob)
         for o in allb[1:]:
@@ -54,7 +73,9 @@ def main():
         if os.environ.get("SHARD_DEBUG") and rank == 0:
             print("sharded trace", mode, "\n", out["trace"], flush=True)
         if rank == 0 and not os.environ.get("SHARD_NOFULL"):
-            full, fposes, faff, fid = run_window(P, case, case)
+            full, fposes, faff, fid = run_window(P, case, case, its=4 if lin else 6, lin_mask=full_mask)
+            if lin:
+                assert abs(out["EL"] - full["EL"]) <= 1e-4 * max(1.0, abs(full["EL"])), (out["EL"], full["EL"])
             if os.environ.get("SHARD_DEBUG"):
                 print("sharded trace\n", out["trace"], "\nfull trace\n", full["trace"], flush=True)
             assert out["iterations"] == full["iterations"]

@@ -74,11 +74,16 @@ def test_set_comm_validates_rank_and_world(pkg, synth, gpu_required):
         ba.close(); comm.close()
 
 
-def test_sharded_optimize_world2_on_a_shared_device(gpu_required):
+@pytest.mark.parametrize("lin", [False, True], ids=["plain", "residuals-kept-linearised"])
+def test_sharded_optimize_world2_on_a_shared_device(gpu_required, lin):
     """Two processes on one GPU, each with its share of the points: identical decisions and frame states on both ranks, the unsharded result within
-    the rounding of a different summation order (tests/dist_worker_gpu.py)."""
+    the rounding of a different summation order (tests/dist_worker_gpu.py).  Second case: after two iterations a third of the residuals is kept linearised
+    (dmvio_hip_ba_fix_linearization on every rank, for its own residuals) and four more iterations run over that graph — accumulateLF_MT's system, the A and
+    Schur views and calcLEnergyPt's term are each all-reduced."""
     port = _free_port()
     env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    if lin:
+        env["SHARD_LIN"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

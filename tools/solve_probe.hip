@@ -32,6 +32,44 @@ int main(int argc, char** argv) {
       if (rep == 2) printf("n = %d, exact_backsub = %d: %.2f us per launch (20 back to back), %s\n", n, exact, 1e3 * ms / 20, hipGetErrorString(hipGetLastError()));
     }
   }
+  {
+    // the same launches with a DIFFERENT kernel of similar code size between them (the other instantiation on its own system): what a cold instruction cache costs a launch — in
+    // the real loop the linearisation / accumulation kernels run on the CU between two solves
+    const int n2 = small ? 100 : 68;
+    std::vector<double> H2((size_t)n2 * n2, 0.0), b2(n2, 1.0);
+    for (int i = 0; i < n2; i++) H2[(size_t)i * n2 + i] = 10.0 + i;
+    double *dH2, *db2, *dout2;
+    hipMalloc((void**)&dH2, sizeof(double) * n2 * n2); hipMalloc((void**)&db2, sizeof(double) * n2); hipMalloc((void**)&dout2, sizeof(double) * (2 * n2 + 2));
+    hipMemcpy(dH2, H2.data(), sizeof(double) * n2 * n2, hipMemcpyHostToDevice); hipMemcpy(db2, b2.data(), sizeof(double) * n2, hipMemcpyHostToDevice);
+    const size_t lds2 = sizeof(double) * baSolveCoreLdsDoubles(n2);
+    hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+    float t_mine = 0, t_other = 0;
+    for (int rep = 0; rep < 3; rep++) {
+      t_mine = 0; t_other = 0;
+      for (int i = 0; i < 20; i++) {
+        hipEventRecord(a0);
+        if (small) hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, dH, db, 0, dout);
+        else hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF_CAP>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, dH, db, 0, dout);
+        hipEventRecord(a1); hipEventSynchronize(a1);
+        float ms; hipEventElapsedTime(&ms, a0, a1); t_mine += ms;
+        hipEventRecord(a0);
+        if (small) hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF_CAP>), dim3(1), dim3(BA_SOLVE_THREADS), lds2, nullptr, n2, dH2, db2, 0, dout2);
+        else hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF>), dim3(1), dim3(BA_SOLVE_THREADS), lds2, nullptr, n2, dH2, db2, 0, dout2);
+        hipEventRecord(a1); hipEventSynchronize(a1);
+        hipEventElapsedTime(&ms, a0, a1); t_other += ms;
+      }
+    }
+    // and the same launch pattern (one launch per event pair) without the other kernel
+    float t_alone = 0;
+    for (int i = 0; i < 20; i++) {
+      hipEventRecord(a0);
+      if (small) hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, dH, db, 0, dout);
+      else hipLaunchKernelGGL((k_ba_solve_debug<BA_MAXF_CAP>), dim3(1), dim3(BA_SOLVE_THREADS), lds, nullptr, n, dH, db, 0, dout);
+      hipEventRecord(a1); hipEventSynchronize(a1);
+      float ms; hipEventElapsedTime(&ms, a0, a1); t_alone += ms;
+    }
+    printf("one launch per event pair: %.2f us alone, %.2f us with the other instantiation launched between two launches (that one: %.2f us)\n", 1e3 * t_alone / 20, 1e3 * t_mine / 20, 1e3 * t_other / 20);
+  }
 #ifdef BA_SOLVE_PROBE
   long long pr[64];
   hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_ba_probe), sizeof(pr));
