@@ -872,7 +872,8 @@ class WindowGraph:
         for name, args in (("destroy", [vp]), ("clear", [vp]), ("insert_frame", [vp]), ("remove_frame", [vp, ci]), ("insert_point", [vp, ci, cf, cf, cf, fp, fp, ci]),
                            ("remove_point", [vp, ci, ci]), ("insert_residual", [vp, ci, ci, ci]), ("drop_residual", [vp, ci, ci, ci]), ("set_idepth", [vp, ci, ci, cf]),
                            ("set_idepths", [vp, ci, fp]), ("counts", [vp, ip, ip, ip]), ("frame_points", [vp, ci]), ("point_residuals", [vp, ci, ci]),
-                           ("export", [vp, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_ubyte), ip, ip])):
+                           ("export", [vp, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_ubyte), ip, ip]), ("set_residual_linearized", [vp, ci, ci, ci, fp, fp]),
+                           ("linearized_count", [vp]), ("export_linearized", [vp, C.POINTER(C.c_ubyte), fp, fp])):
             fn = getattr(self.L, "dmvio_hip_graph_" + name); fn.argtypes = args; fn.restype = None if name == "destroy" else ci
         self.p = C.c_void_p(self.L.dmvio_hip_graph_create())
         if not self.p:
@@ -901,6 +902,22 @@ class WindowGraph:
     def set_idepths(self, idepth):
         a = np.ascontiguousarray(idepth, dtype=np.float32)
         self._c("set_idepths", len(a), _f(a))
+
+    def set_residual_linearized(self, host, idx, k, J74=None, res_toZeroF=None):
+        """EFResidual::isLinearized = true with its frozen Jacobian (74) and res_toZeroF (8); J74 None: not linearised any more"""
+        if J74 is None:
+            self._c("set_residual_linearized", int(host), int(idx), int(k), None, None); return
+        J = np.ascontiguousarray(J74, dtype=np.float32).ravel(); r = np.ascontiguousarray(res_toZeroF, dtype=np.float32).ravel()
+        assert J.size == 74 and r.size == 8
+        self._c("set_residual_linearized", int(host), int(idx), int(k), _f(J), _f(r))
+
+    def linearized_count(self): return self._c("linearized_count")
+
+    def export_linearized(self):
+        _, _, R = self.counts()
+        fl = np.zeros(R, np.uint8); J = np.zeros((R, 74), np.float32); r = np.zeros((R, 8), np.float32)
+        self._c("export_linearized", fl.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(J), _f(r))
+        return fl, J, r
 
     def counts(self):
         F, N, R = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -980,6 +997,23 @@ class BundleAdjusterHip:
         fl = np.ascontiguousarray(is_linearized, dtype=np.uint8)
         fn = self.L.dmvio_hip_ba_set_residual_flags; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; fn.restype = C.c_int
         _chk(self.L, fn(self.p, len(fl), fl.ctypes.data), "ba_set_residual_flags")
+
+    def set_linearized_residuals(self, is_linearized, J74, res_toZeroF):
+        """Residuals that arrive linearised (dmvio_hip_ba_set_linearized_residuals); returns the number of linearised residuals of the graph"""
+        fl = np.ascontiguousarray(is_linearized, dtype=np.uint8); J = np.ascontiguousarray(J74, dtype=np.float32); r = np.ascontiguousarray(res_toZeroF, dtype=np.float32)
+        assert J.size == 74 * len(fl) and r.size == 8 * len(fl)
+        fn = self.L.dmvio_hip_ba_set_linearized_residuals; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]; fn.restype = C.c_int
+        n = C.c_int(0)
+        _chk(self.L, fn(self.p, len(fl), fl.ctypes.data, J.ctypes.data, r.ctypes.data, C.byref(n)), "ba_set_linearized_residuals")
+        return n.value
+
+    def linearized_residuals(self):
+        """(flags, J74, res_toZeroF) of the graph's residuals as they stand (dmvio_hip_ba_get_linearized_residuals)"""
+        R = self.R
+        fl = np.zeros(R, np.uint8); J = np.zeros((R, 74), np.float32); r = np.zeros((R, 8), np.float32)
+        fn = self.L.dmvio_hip_ba_get_linearized_residuals; fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, R, fl.ctypes.data, J.ctypes.data, r.ctypes.data), "ba_get_linearized_residuals")
+        return fl, J, r
 
     def fix_linearization(self, res_mask):
         """EFResidual::fixLinearizationF for the active residuals with res_mask != 0 on the resident graph (dmvio_hip_ba_fix_linearization): they leave activeResiduals and

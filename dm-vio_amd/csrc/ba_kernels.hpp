@@ -1068,6 +1068,59 @@ __global__ void __launch_bounds__(256) k_ba_lin_fix(const BAWindow W, const BAPo
   for (int k = 0; k < REC_FLOATS; k++) dst[k] = src[k];
   lin[ri] = 1;
 }
+// A residual that ARRIVES linearised (dmvio_hip_ba_set_linearized_residuals: EFResidual::isLinearized with its RawResidualJacobian and res_toZeroF, EnergyFunctionalStructs.h:
+// 63-87): what k_ba_lin_fix leaves behind for one linearised on the resident graph — the frozen Jacobian row, res_toZeroF, the Jacobian part of the applied record (formed
+// from J by the linearisation's own expressions, takeDataF EnergyFunctionalStructs.cpp:39-49 included) — plus the state an active residual of the reference has
+// (ResState::IN, in the energy functional).  idx: the n flagged residuals; packed: n x 82 floats [J (74) | res_toZeroF (8)].
+__global__ void __launch_bounds__(256) k_ba_lin_import(const int n, const int* __restrict__ idx, const float* __restrict__ packed, const BARes Rs, float* __restrict__ fullJ,
+                                                        float* __restrict__ res_toZeroF, float* __restrict__ linRec, unsigned char* __restrict__ lin) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int ri = idx[k];
+  const float* __restrict__ J = packed + (size_t)k * 82;
+  float* __restrict__ fj = fullJ + (size_t)ri * 74;
+  for (int i = 0; i < 74; i++) fj[i] = J[i];
+  for (int i = 0; i < 8; i++) res_toZeroF[(size_t)ri * 8 + i] = J[74 + i];
+  float rec[REC_FLOATS];
+  const float d_d_x = J[28], d_d_y = J[29];
+  const float JI00 = J[62], JI10 = J[63], JI11 = J[65];
+  const float Ja00 = J[66], Ja01 = J[67], Ja10 = J[68], Ja11 = J[69];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { rec[REC_JPDC0 + i] = J[20 + i]; rec[REC_JPDC1 + i] = J[24 + i]; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { rec[REC_JPDXI0 + i] = J[8 + i]; rec[REC_JPDXI1 + i] = J[14 + i]; }
+  rec[REC_JIDX2 + 0] = JI00; rec[REC_JIDX2 + 1] = JI10; rec[REC_JIDX2 + 2] = JI11;
+  rec[REC_JABJIDX + 0] = Ja00; rec[REC_JABJIDX + 1] = Ja01; rec[REC_JABJIDX + 2] = Ja10; rec[REC_JABJIDX + 3] = Ja11;
+  rec[REC_JAB2 + 0] = J[70]; rec[REC_JAB2 + 1] = J[71]; rec[REC_JAB2 + 2] = J[73];
+  // the inner products with resF in pattern order, as the linearisation sums them (the applied record of the linearisation this residual was frozen at; the L pass works on
+  // linRec, where k_ba_lin_records replaces them by those with resApprox)
+  float JIr0 = 0.f, JIr1 = 0.f, Jar0 = 0.f, Jar1 = 0.f, rr = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const float resF = J[i];
+    JIr0 = JIr0 + resF * J[30 + i]; JIr1 = JIr1 + resF * J[38 + i]; Jar0 = Jar0 + resF * J[46 + i]; Jar1 = Jar1 + resF * J[54 + i]; rr = rr + resF * resF;
+  }
+  rec[REC_JI_R + 0] = JIr0; rec[REC_JI_R + 1] = JIr1; rec[REC_JAB_R + 0] = Jar0; rec[REC_JAB_R + 1] = Jar1; rec[REC_RR] = rr;
+  rec[REC_JPDD + 0] = d_d_x; rec[REC_JPDD + 1] = d_d_y;
+  const float v0 = JI00 * d_d_x + JI10 * d_d_y, v1 = JI10 * d_d_x + JI11 * d_d_y;
+#pragma unroll
+  for (int i = 0; i < 6; i++) rec[REC_JPJD + i] = J[8 + i] * v0 + J[14 + i] * v1;
+  rec[REC_JPJD + 6] = Ja00 * d_d_x + Ja01 * d_d_y;
+  rec[REC_JPJD + 7] = Ja10 * d_d_x + Ja11 * d_d_y;
+  rec[REC_BD] = JIr0 * d_d_x + JIr1 * d_d_y;
+  rec[REC_HDD] = v0 * d_d_x + v1 * d_d_y;
+#pragma unroll
+  for (int i = 0; i < 4; i++) rec[REC_HCD + i] = J[20 + i] * v0 + J[24 + i] * v1;
+  rec[REC_PAD] = 0.f;
+  // the applied record (both buffers: whichever the selector points at) — the Schur pass and the points' back-substitution read JpJdF from it — and the frozen copy
+  float* __restrict__ d0 = Rs.rec[0] + (size_t)ri * REC_FLOATS;
+  float* __restrict__ d1 = Rs.rec[1] + (size_t)ri * REC_FLOATS;
+  float* __restrict__ d2 = linRec + (size_t)ri * REC_FLOATS;
+#pragma unroll
+  for (int i = 0; i < REC_FLOATS; i++) { d0[i] = rec[i]; d1[i] = rec[i]; d2[i] = rec[i]; }
+  lin[ri] = 1;
+  Rs.active[ri] = 1; Rs.removed[ri] = 0; Rs.state[ri] = BA_IN; Rs.newState[ri] = BA_IN; Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f;
+}
 // The record addPoint<1> consumes, at the deltas of the current state: resApprox = res_toZeroF + [JI Jp | Jab] delta (AccumulatedTopHessian.cpp:84-98), its inner products
 // with the frozen Jacobian (:103-113) and the point's bd contribution (:132).  Also the two activity views of the three-pass accumulation: the A pass sees the active
 // residuals that are NOT linearised (addPoint<0>), the L pass those that are.

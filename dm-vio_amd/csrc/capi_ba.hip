@@ -139,7 +139,7 @@ struct dmvio_hip_ba {
   long long* d_accTicks = nullptr;   // per-block stamps of k_ba_accumulate (timing mode only)
   int accTicksBlocks = 0;
   // flat arrays of dmvio_hip_ba_set_graph_from (kept between keyframes: no allocation in the steady state)
-  struct GraphScratch { std::vector<int> host, res_point, res_target; std::vector<float> u, v, idepth, color, weights; std::vector<unsigned char> prior; } gscratch;
+  struct GraphScratch { std::vector<int> host, res_point, res_target; std::vector<float> u, v, idepth, color, weights, linJ, linRtz; std::vector<unsigned char> prior, lin; } gscratch;
   // ---- points sharded over ranks (dmvio_hip_ba_set_comm): every rank holds all keyframes and ITS points; the stitched system is summed by
   // an all-reduce in HBM on this handle's stream, the accept / threshold decisions are taken over the all-gathered per-rank records
   int rank = 0, world = 0;           // world == 0: no communicator
@@ -1224,6 +1224,7 @@ static int setGraphImpl(dmvio_hip_ba* b, int N, const int* host, const float* u,
 
 // dmvio_hip_ba_set_graph from a resident graph (capi_graph.hip): the mirror flattened in makeIDX order — compact records, a few tens of microseconds — instead of arrays
 // the caller rebuilt from its pointer graph.  The window (dmvio_hip_ba_set_window) must have as many keyframes as the graph.  The scratch arrays stay with the handle.
+static int linImport(dmvio_hip_ba* b, const unsigned char* flags, const float* J74, const float* rtz, int* n_linearized);
 int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
   if (!b || !g) return failmsg("ba_set_graph_from: null argument");
   BA_LOCK(b);
@@ -1239,17 +1240,26 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
     auto& S = b->gscratch;
     S.host.resize(N); S.u.resize(N); S.v.resize(N); S.idepth.resize(N); S.color.resize(8 * (size_t)N); S.weights.resize(8 * (size_t)N); S.prior.resize(N);
     S.res_point.resize(R); S.res_target.resize(R);
+    const bool anyLin = g->nLin > 0;   // residuals that arrive linearised: their flags / Jacobians / res_toZeroF in flat order (only then)
+    if (anyLin) { S.lin.assign(R, 0); S.linJ.resize((size_t)R * 74); S.linRtz.resize((size_t)R * 8); } else S.lin.clear();
     int pi = 0, ri = 0;
     for (int f = 0; f < (int)g->frames.size(); f++)
       for (const DmvGraphPoint& P : g->frames[f]) {
         S.host[pi] = f; S.u[pi] = P.u; S.v[pi] = P.v; S.idepth[pi] = P.idepth; S.prior[pi] = P.prior;
         memcpy(&S.color[8 * (size_t)pi], P.color, sizeof(P.color)); memcpy(&S.weights[8 * (size_t)pi], P.weights, sizeof(P.weights));
-        for (int k = 0; k < P.nres; k++, ri++) { S.res_point[ri] = pi; S.res_target[ri] = P.target[k]; }
+        for (int k = 0; k < P.nres; k++, ri++) {
+          S.res_point[ri] = pi; S.res_target[ri] = P.target[k];
+          if (anyLin && P.lin[k] >= 0) {
+            S.lin[ri] = 1;
+            memcpy(&S.linJ[(size_t)ri * 74], g->linPool[P.lin[k]].J, sizeof(float) * 74); memcpy(&S.linRtz[(size_t)ri * 8], g->linPool[P.lin[k]].res_toZeroF, sizeof(float) * 8);
+          }
+        }
         pi++;
       }
   }
   const auto& S = b->gscratch;
   if (int r = setGraphImpl(b, N, S.host.data(), S.u.data(), S.v.data(), S.idepth.data(), S.color.data(), S.weights.data(), S.prior.data(), R, S.res_point.data(), S.res_target.data(), false)) return r;
+  if (!S.lin.empty()) { if (int r = linImport(b, S.lin.data(), S.linJ.data(), S.linRtz.data(), nullptr)) { b->graph_ready = false; return r; } }
   // only a window that WAS built makes its flat order the one dmvio_hip_graph_set_idepths accepts values in (until the structure changes).  The uploads are stream-ordered:
   // an asynchronous copy error of this call is reported by the next BA call that synchronises
   std::lock_guard<std::mutex> lg(g->mu);
@@ -1261,52 +1271,21 @@ int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* b, dmvio_hip_graph* g) {
 // first statement of an entry point: null check, the handle's lock for the whole call (declares a guard in the function's scope), then the state checks
 #define BA_READY(b) if (!(b)) return failmsg("ba: null handle"); BA_LOCK(b); BA_READY_LOCKED(b)
 
-int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* b, int R, const unsigned char* isLinearized) {
-  if (!b || !isLinearized) return failmsg("ba_set_residual_flags: null argument");
-  BA_LOCK(b);
-  if (!b->graph_ready) return failmsg("ba: set_window + set_graph first");
-  if (R != b->H.R) return failmsg("ba_set_residual_flags: R differs from the graph's residual count");
-  for (int ri = 0; ri < R; ri++)
-    if (isLinearized[ri]) {
-      b->graph_ready = false;   // refused as a whole: nothing may run on a graph whose linearised energy term (accumulateLF_MT) would be missing
-      return failmsg("ba_set_residual_flags: residual " + std::to_string(ri) + " arrives linearised (EFResidual::isLinearized): its frozen Jacobian and res_toZeroF, which "
-                     "accumulateLF_MT / addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:84-98) need, only exist for residuals linearised on the resident "
-                     "graph (dmvio_hip_ba_fix_linearization) — the graph is refused");
-    }
+// buffers of the residuals kept linearised (first use on a graph)
+static int linAlloc(dmvio_hip_ba* b) {
+  const int R = b->H.R, N = b->H.N;
+  if (b->d_lin) return 0;
+  if (dalloc(b, &b->d_lin, R) || dalloc(b, &b->d_linMask, R) || dalloc(b, &b->d_linActive, R) || dalloc(b, &b->d_topActive, R) || dalloc(b, &b->d_rtz, (size_t)R * 8) ||
+      dalloc(b, &b->d_linRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_lHdd, N) || dalloc(b, &b->d_lbd, N) || dalloc(b, &b->d_lHcd, (size_t)N * 4) ||
+      dalloc(b, &b->d_HcdAF, (size_t)N * 4) || dalloc(b, &b->d_linE, (size_t)R * 8)) return -1;
+  b->h_lin.assign(R, 0);
+  HIPCHK(hipMemsetAsync(b->d_lin, 0, R, b->stream));   // (the arena hands out zeroed memory after set_graph; a second graph's first use must not depend on it)
   return 0;
 }
-
-// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the active residuals with res_mask != 0, at the current state, on the resident graph: from then on
-// they stay out of activeResiduals (FullSystemOptimize.cpp:436-446) and enter every system through accumulateLF_MT / addPoint<1> and the energy through calcLEnergyPt, until
-// the next dmvio_hip_ba_set_graph (or until their point is marginalised).  Needs the Jacobians of the applied linearisation: dmvio_hip_ba_keep_jacobians(ba, 1) before the
-// dmvio_hip_ba_optimize / dmvio_hip_ba_linearize(fix) that precedes this call.  n_linearized: residuals of the graph that are linearised after the call.
-int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* res_mask, int* n_linearized) {
-  if (!b || !res_mask) return failmsg("ba_fix_linearization: null argument");
-  BA_LOCK(b);
-  BA_READY_LOCKED(b);
-  BAHost& H = b->H;
-  if (R != H.R) return failmsg("ba_fix_linearization: R differs from the graph's residual count");
-  if (!b->keep_fullJ || !b->fullJ_applied)
-    return failmsg("ba_fix_linearization: the Jacobians of the applied linearisation are not resident — call dmvio_hip_ba_keep_jacobians(ba, 1) before the optimize / "
-                   "linearize(fix) + apply that precedes this call");
+// after the device flags changed: the host copies calcLEnergyPt reads (the energy terms are host arithmetic in this library), the counts, the kernels' views
+static int linFinish(dmvio_hip_ba* b, int* n_linearized) {
+  const int R = b->H.R;
   hipStream_t s = b->stream;
-  const int N = H.N;
-  if (!b->d_lin) {
-    if (dalloc(b, &b->d_lin, R) || dalloc(b, &b->d_linMask, R) || dalloc(b, &b->d_linActive, R) || dalloc(b, &b->d_topActive, R) || dalloc(b, &b->d_rtz, (size_t)R * 8) ||
-        dalloc(b, &b->d_linRec, (size_t)R * REC_FLOATS) || dalloc(b, &b->d_lHdd, N) || dalloc(b, &b->d_lbd, N) || dalloc(b, &b->d_lHcd, (size_t)N * 4) ||
-        dalloc(b, &b->d_HcdAF, (size_t)N * 4) || dalloc(b, &b->d_linE, (size_t)R * 8)) return -1;
-    b->h_lin.assign(R, 0);
-  }
-  H.setPrecalcValues();
-  std::vector<float> adHT;
-  H.adHTdeltaF(adHT);
-  HIPCHK(b->bounce.h2d(b->d_linMask, res_mask, R, s));
-  HIPCHK(b->bounce.h2d(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), s));
-  const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
-  hipLaunchKernelGGL(k_ba_lin_fix, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, (const float*)b->d_fullJ, (const unsigned char*)b->d_linMask, (const float*)b->d_adHTdelta, cd,
-                     b->d_lin, b->d_rtz, b->d_linRec);
-  HIPCHK(hipGetLastError());
-  // what calcLEnergyPt reads, on the host (the energy terms are host arithmetic in this library)
   b->h_linAct.resize(R); b->h_linJ.resize((size_t)R * 74); b->h_rtz.resize((size_t)R * 8);
   HIPCHK(b->bounce.d2h(b->h_lin.data(), b->d_lin, R, s));
   HIPCHK(b->bounce.d2h(b->h_linAct.data(), b->Rs.active, R, s));
@@ -1327,6 +1306,99 @@ int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* 
   }
   if (linAny(b)) { b->Rs.lin = b->d_lin; b->P.lHdd = b->d_lHdd; b->P.lbd = b->d_lbd; b->P.lHcd = b->d_lHcd; b->P.HcdAF = b->d_HcdAF; }
   if (n_linearized) *n_linearized = b->n_lin;
+  return 0;
+}
+// residuals that arrive linearised: flags (R), J74 (R x 74) and res_toZeroF (R x 8) indexed by residual; only the flagged rows travel
+static int linImport(dmvio_hip_ba* b, const unsigned char* flags, const float* J74, const float* rtz, int* n_linearized) {
+  const int R = b->H.R;
+  hipStream_t s = b->stream;
+  std::vector<int> idx;
+  for (int ri = 0; ri < R; ri++) if (flags[ri]) idx.push_back(ri);
+  if (idx.empty() && !sharded(b)) { if (n_linearized) *n_linearized = b->n_lin; return 0; }
+  if (int r = linAlloc(b)) return r;
+  const int n = (int)idx.size();
+  if (n > 0) {
+    std::vector<float> packed((size_t)n * 82);
+    for (int k = 0; k < n; k++) {
+      memcpy(&packed[(size_t)k * 82], J74 + (size_t)idx[k] * 74, sizeof(float) * 74);
+      memcpy(&packed[(size_t)k * 82 + 74], rtz + (size_t)idx[k] * 8, sizeof(float) * 8);
+    }
+    int* d_idx = nullptr; float* d_packed = nullptr;
+    if (dalloc(b, &d_idx, n) || dalloc(b, &d_packed, (size_t)n * 82)) return -1;
+    HIPCHK(b->bounce.h2d(d_idx, idx.data(), sizeof(int) * n, s));
+    HIPCHK(b->bounce.h2d(d_packed, packed.data(), sizeof(float) * packed.size(), s));
+    hipLaunchKernelGGL(k_ba_lin_import, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int*)d_idx, (const float*)d_packed, b->Rs, b->d_fullJ, b->d_rtz, b->d_linRec, b->d_lin);
+    HIPCHK(hipGetLastError());
+  }
+  b->sums_fresh = false; b->sys_ready = false;
+  return linFinish(b, n_linearized);
+}
+
+int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* b, int R, const unsigned char* isLinearized) {
+  if (!b || !isLinearized) return failmsg("ba_set_residual_flags: null argument");
+  BA_LOCK(b);
+  if (!b->graph_ready) return failmsg("ba: set_window + set_graph first");
+  if (R != b->H.R) return failmsg("ba_set_residual_flags: R differs from the graph's residual count");
+  for (int ri = 0; ri < R; ri++)
+    if (isLinearized[ri]) {
+      b->graph_ready = false;   // refused as a whole: nothing may run on a graph whose linearised energy term (accumulateLF_MT) would be missing
+      return failmsg("ba_set_residual_flags: residual " + std::to_string(ri) + " arrives linearised (EFResidual::isLinearized): its frozen Jacobian and res_toZeroF, which "
+                     "accumulateLF_MT / addPoint<1> (EnergyFunctional.cpp:223-233, AccumulatedTopHessian.cpp:84-98) need, do not come with a bare flag — hand them over with "
+                     "dmvio_hip_ba_set_linearized_residuals (or dmvio_hip_graph_set_residual_linearized + dmvio_hip_ba_set_graph_from); the graph is refused");
+    }
+  return 0;
+}
+
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the active residuals with res_mask != 0, at the current state, on the resident graph: from then on
+// they stay out of activeResiduals (FullSystemOptimize.cpp:436-446) and enter every system through accumulateLF_MT / addPoint<1> and the energy through calcLEnergyPt, until
+// the next dmvio_hip_ba_set_graph (or until their point is marginalised).  Needs the Jacobians of the applied linearisation: dmvio_hip_ba_keep_jacobians(ba, 1) before the
+// dmvio_hip_ba_optimize / dmvio_hip_ba_linearize(fix) that precedes this call.  n_linearized: residuals of the graph that are linearised after the call.
+int dmvio_hip_ba_fix_linearization(dmvio_hip_ba* b, int R, const unsigned char* res_mask, int* n_linearized) {
+  if (!b || !res_mask) return failmsg("ba_fix_linearization: null argument");
+  BA_LOCK(b);
+  BA_READY_LOCKED(b);
+  BAHost& H = b->H;
+  if (R != H.R) return failmsg("ba_fix_linearization: R differs from the graph's residual count");
+  if (!b->keep_fullJ || !b->fullJ_applied)
+    return failmsg("ba_fix_linearization: the Jacobians of the applied linearisation are not resident — call dmvio_hip_ba_keep_jacobians(ba, 1) before the optimize / "
+                   "linearize(fix) + apply that precedes this call");
+  hipStream_t s = b->stream;
+  if (int r = linAlloc(b)) return r;
+  H.setPrecalcValues();
+  std::vector<float> adHT;
+  H.adHTdeltaF(adHT);
+  HIPCHK(b->bounce.h2d(b->d_linMask, res_mask, R, s));
+  HIPCHK(b->bounce.h2d(b->d_adHTdelta, adHT.data(), sizeof(float) * adHT.size(), s));
+  const float4 cd = make_float4(H.cDeltaF[0], H.cDeltaF[1], H.cDeltaF[2], H.cDeltaF[3]);
+  hipLaunchKernelGGL(k_ba_lin_fix, dim3((R + 255) / 256), dim3(256), 0, s, b->W, b->P, b->Rs, (const float*)b->d_fullJ, (const unsigned char*)b->d_linMask, (const float*)b->d_adHTdelta, cd,
+                     b->d_lin, b->d_rtz, b->d_linRec);
+  HIPCHK(hipGetLastError());
+  return linFinish(b, n_linearized);
+}
+// EFResidual::isLinearized / J / res_toZeroF of residuals that were linearised ELSEWHERE (a graph handed over with dmvio_hip_ba_set_graph whose residuals carry the flag:
+// EnergyFunctionalStructs.h:63-87), for the flagged residuals: rows of J74 (R x 74, the RawResidualJacobian in dmvio_hip_ba_get_full_jacobians' layout) and res_toZeroF
+// (R x 8); the rows of the others are not read.  They become what dmvio_hip_ba_fix_linearization leaves behind.
+int dmvio_hip_ba_set_linearized_residuals(dmvio_hip_ba* b, int R, const unsigned char* isLinearized, const float* J74, const float* res_toZeroF, int* n_linearized) {
+  if (!b || !isLinearized || !J74 || !res_toZeroF) return failmsg("ba_set_linearized_residuals: null argument");
+  BA_LOCK(b);
+  BA_READY_LOCKED(b);
+  if (R != b->H.R) return failmsg("ba_set_linearized_residuals: R differs from the graph's residual count");
+  return linImport(b, isLinearized, J74, res_toZeroF, n_linearized);
+}
+// ... and back: EFResidual::isLinearized / J / res_toZeroF of the graph's residuals as they stand (linearised here or handed over) — what an adapter writes back into the
+// reference's objects, or hands to the next window's dmvio_hip_graph_set_residual_linearized.  Rows of residuals that are not linearised are zeroed.  Any output may be NULL.
+int dmvio_hip_ba_get_linearized_residuals(dmvio_hip_ba* b, int R, unsigned char* isLinearized, float* J74, float* res_toZeroF) {
+  if (!b) return failmsg("ba: null handle");
+  BA_LOCK(b);
+  if (!b->graph_ready) return failmsg("ba: set_window + set_graph first");
+  if (R != b->H.R) return failmsg("ba_get_linearized_residuals: R differs from the graph's residual count");
+  const bool have = b->d_lin != nullptr && (int)b->h_lin.size() == R && b->h_linJ.size() == (size_t)R * 74;
+  for (int ri = 0; ri < R; ri++) {
+    const bool l = have && b->h_lin[ri];
+    if (isLinearized) isLinearized[ri] = l ? 1 : 0;
+    if (J74) { if (l) memcpy(J74 + (size_t)ri * 74, &b->h_linJ[(size_t)ri * 74], sizeof(float) * 74); else memset(J74 + (size_t)ri * 74, 0, sizeof(float) * 74); }
+    if (res_toZeroF) { if (l) memcpy(res_toZeroF + (size_t)ri * 8, &b->h_rtz[(size_t)ri * 8], sizeof(float) * 8); else memset(res_toZeroF + (size_t)ri * 8, 0, sizeof(float) * 8); }
+  }
   return 0;
 }
 // accumulateLF_MT's system as the reference returns it (stitched linearised residuals + priors, EnergyFunctional.cpp:223-233) for the state of the LAST accumulation

@@ -15,6 +15,7 @@
 // in makeIDX order and builds the device arrays from it.
 //
 // Host only: no device, no stream; one mutex per graph.
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -36,7 +37,7 @@ void dmvio_hip_graph_destroy(dmvio_hip_graph* g) { delete g; }
 
 int dmvio_hip_graph_clear(dmvio_hip_graph* g) {
   G_LOCK(g);
-  g->frames.clear(); g->nPoints = g->nRes = g->nDangling = 0; g->version++;
+  g->frames.clear(); g->linPool.clear(); g->linFree.clear(); g->nLin = 0; g->nPoints = g->nRes = g->nDangling = 0; g->version++;
   return 0;
 }
 
@@ -84,7 +85,10 @@ int dmvio_hip_graph_insert_point(dmvio_hip_graph* g, int host, float u, float v,
 int dmvio_hip_graph_remove_point(dmvio_hip_graph* g, int host, int idxInPoints) {
   G_LOCK(g);
   G_POINT(g, host, idxInPoints, "graph_remove_point");
-  for (int k = 0; k < P.nres; k++) if (P.target[k] < 0) g->nDangling--;
+  for (int k = 0; k < P.nres; k++) {
+    if (P.target[k] < 0) g->nDangling--;
+    if (P.lin[k] >= 0) { g->linFree.push_back(P.lin[k]); g->nLin--; }
+  }
   g->nRes -= P.nres;
   P = g->frames[host].back();
   g->frames[host].pop_back();
@@ -98,7 +102,7 @@ int dmvio_hip_graph_insert_residual(dmvio_hip_graph* g, int host, int idxInPoint
   G_POINT(g, host, idxInPoints, "graph_insert_residual");
   if (target < 0 || target >= (int)g->frames.size() || target == host) return failmsg("graph_insert_residual: bad target frame");
   if (P.nres >= DMV_GRAPH_MAX_FRAMES) return failmsg("graph_insert_residual: the point already has " + std::to_string((int)P.nres) + " residuals");
-  P.target[P.nres] = (short)target;
+  P.target[P.nres] = (short)target; P.lin[P.nres] = -1;
   g->nRes++; g->version++;
   return P.nres++;
 }
@@ -109,9 +113,50 @@ int dmvio_hip_graph_drop_residual(dmvio_hip_graph* g, int host, int idxInPoints,
   G_POINT(g, host, idxInPoints, "graph_drop_residual");
   if (idxInAll < 0 || idxInAll >= P.nres) return failmsg("graph_drop_residual: residual index out of range");
   if (P.target[idxInAll] < 0) g->nDangling--;
-  P.target[idxInAll] = P.target[P.nres - 1];
+  if (P.lin[idxInAll] >= 0) { g->linFree.push_back(P.lin[idxInAll]); g->nLin--; }
+  P.target[idxInAll] = P.target[P.nres - 1]; P.lin[idxInAll] = P.lin[P.nres - 1];
   P.nres--;
   g->nRes--; g->version++;
+  return 0;
+}
+
+// EFResidual::fixLinearizationF's result on the caller's side (EnergyFunctionalStructs.cpp:85-113): isLinearized = true with the frozen Jacobian (EFResidual::J, 74 floats in
+// dmvio_hip_ba_get_full_jacobians' layout) and res_toZeroF (8).  J74 == NULL: isLinearized = false again (FullSystem.cpp:840-843).  A value, not structure: the version stays.
+int dmvio_hip_graph_set_residual_linearized(dmvio_hip_graph* g, int host, int idxInPoints, int idxInAll, const float* J74, const float* res_toZeroF) {
+  G_LOCK(g);
+  G_POINT(g, host, idxInPoints, "graph_set_residual_linearized");
+  if (idxInAll < 0 || idxInAll >= P.nres) return failmsg("graph_set_residual_linearized: residual index out of range");
+  if (!J74) {
+    if (P.lin[idxInAll] >= 0) { g->linFree.push_back(P.lin[idxInAll]); g->nLin--; P.lin[idxInAll] = -1; }
+    return 0;
+  }
+  if (!res_toZeroF) return failmsg("graph_set_residual_linearized: null res_toZeroF");
+  int slot = P.lin[idxInAll];
+  if (slot < 0) {
+    if (!g->linFree.empty()) { slot = g->linFree.back(); g->linFree.pop_back(); }
+    else { slot = (int)g->linPool.size(); g->linPool.emplace_back(); }
+    P.lin[idxInAll] = slot; g->nLin++;
+  }
+  memcpy(g->linPool[slot].J, J74, sizeof(float) * 74);
+  memcpy(g->linPool[slot].res_toZeroF, res_toZeroF, sizeof(float) * 8);
+  return 0;
+}
+int dmvio_hip_graph_linearized_count(dmvio_hip_graph* g) {
+  G_LOCK(g);
+  return g->nLin;
+}
+// ... in flat (makeIDX) order beside dmvio_hip_graph_export's arrays: R flags, R x 74 and R x 8 floats (rows of the residuals that are not linearised are zeroed); any may be NULL
+int dmvio_hip_graph_export_linearized(dmvio_hip_graph* g, unsigned char* isLinearized, float* J74, float* res_toZeroF) {
+  G_LOCK(g);
+  int ri = 0;
+  for (auto& fr : g->frames)
+    for (const DmvGraphPoint& P : fr)
+      for (int k = 0; k < P.nres; k++, ri++) {
+        const int slot = P.lin[k];
+        if (isLinearized) isLinearized[ri] = slot >= 0 ? 1 : 0;
+        if (J74) { if (slot >= 0) memcpy(J74 + (size_t)ri * 74, g->linPool[slot].J, sizeof(float) * 74); else memset(J74 + (size_t)ri * 74, 0, sizeof(float) * 74); }
+        if (res_toZeroF) { if (slot >= 0) memcpy(res_toZeroF + (size_t)ri * 8, g->linPool[slot].res_toZeroF, sizeof(float) * 8); else memset(res_toZeroF + (size_t)ri * 8, 0, sizeof(float) * 8); }
+      }
   return 0;
 }
 

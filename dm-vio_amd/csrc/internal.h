@@ -140,12 +140,17 @@ struct DmvGraphPoint {
   float u, v, idepth;
   float color[8], weights[8];
   short target[DMV_GRAPH_MAX_FRAMES];   // EFPoint::residualsAll order: frame index of each residual's target; -1 = its frame was removed, the residual not yet dropped
+  int lin[DMV_GRAPH_MAX_FRAMES];        // EFResidual::isLinearized: index of the residual's frozen linearisation in dmvio_hip_graph::linPool, -1 = not linearised
   int nres;
   unsigned char prior;
 };
+struct DmvGraphLin { float J[74]; float res_toZeroF[8]; };   // EFResidual::J (RawResidualJacobian, dmvio_hip_ba_get_full_jacobians' layout) and ::res_toZeroF
 struct dmvio_hip_graph {
   std::mutex mu;
   std::vector<std::vector<DmvGraphPoint>> frames;   // EnergyFunctional::frames -> EFFrame::points
+  std::vector<DmvGraphLin> linPool;                  // linearisations of the residuals that carry one; linFree: slots given back by dropped residuals / removed points
+  std::vector<int> linFree;
+  int nLin = 0;
   int nPoints = 0, nRes = 0, nDangling = 0;
   unsigned long long version = 0;                    // counts structural changes (not value updates)
   unsigned long long flat_version = ~0ull;           // `version` when the graph was last flattened (dmvio_hip_graph_export / dmvio_hip_ba_set_graph_from): values that come back in

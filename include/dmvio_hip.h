@@ -329,6 +329,11 @@ int dmvio_hip_graph_insert_point(dmvio_hip_graph* g, int host, float u, float v,
 int dmvio_hip_graph_remove_point(dmvio_hip_graph* g, int host, int idxInPoints);                /* EnergyFunctional::removePoint: its residuals go with it, the host's last point takes its index */
 int dmvio_hip_graph_insert_residual(dmvio_hip_graph* g, int host, int idxInPoints, int target);  /* EnergyFunctional::insertResidual: appended; returns idxInAll */
 int dmvio_hip_graph_drop_residual(dmvio_hip_graph* g, int host, int idxInPoints, int idxInAll);  /* EnergyFunctional::dropResidual: the point's last residual takes its index */
+/* EFResidual::fixLinearizationF's result (EnergyFunctionalStructs.cpp:85-113) of one residual: isLinearized = true with its frozen Jacobian (74 floats, layout above) and
+ * res_toZeroF (8); J74 == NULL: isLinearized = false again (FullSystem.cpp:840-843).  The record moves with the residual (dropResidual) and goes with its point (removePoint). */
+int dmvio_hip_graph_set_residual_linearized(dmvio_hip_graph* g, int host, int idxInPoints, int idxInAll, const float* J74, const float* res_toZeroF);
+int dmvio_hip_graph_linearized_count(dmvio_hip_graph* g);
+int dmvio_hip_graph_export_linearized(dmvio_hip_graph* g, unsigned char* isLinearized, float* J74, float* res_toZeroF);   /* flat order of dmvio_hip_graph_export; any may be NULL */
 int dmvio_hip_graph_set_idepth(dmvio_hip_graph* g, int host, int idxInPoints, float idepth);     /* PointHessian::setIdepth of one point */
 int dmvio_hip_graph_set_idepths(dmvio_hip_graph* g, int N, const float* idepth);                /* ... of all points in makeIDX order: what dmvio_hip_ba_get_points returns after an optimisation; refused once the graph's structure changed since it was flattened */
 int dmvio_hip_graph_counts(dmvio_hip_graph* g, int* F, int* N, int* R);                         /* EnergyFunctional::nFrames, nPoints, nResiduals */
@@ -341,12 +346,21 @@ int dmvio_hip_graph_export(dmvio_hip_graph* g, int* host, float* u, float* v, fl
  * dmvio_hip_ba_set_graph it does not wait for its uploads (they are staged in the handle's pinned memory and enqueued in front of whatever uses them).  After an optimisation the caller
  * hands the new inverse depths back with dmvio_hip_graph_set_idepths(g, N, <idepth of dmvio_hip_ba_get_points>): same order. */
 int dmvio_hip_ba_set_graph_from(dmvio_hip_ba* ba, dmvio_hip_graph* g);
-/* EFResidual::isLinearized of the residuals just handed to dmvio_hip_ba_set_graph (R flags, same order).  A residual that ARRIVES linearised cannot be served: its frozen
- * Jacobian and res_toZeroF — what accumulateLF_MT / addPoint<1> / calcLEnergyPt read (EnergyFunctional.cpp:223-233, 349-431, AccumulatedTopHessian.cpp:84-98) — are not
- * part of the graph hand-over (nor does the reference ever hold such a residual across a keyframe: it linearises only inside FullSystem::flagPointsForRemoval, immediately
- * before marginalizePointsF removes the point, FullSystem.cpp:836-849).  A graph that contains one is REFUSED: the call returns an error, the graph is dropped (every later
- * call on it fails until the next dmvio_hip_ba_set_graph) — it is never silently optimised without that energy term.  All flags zero: no effect.  Residuals linearised ON
- * the resident graph are served: dmvio_hip_ba_fix_linearization. */
+/* Residuals that ARRIVE linearised (EFResidual::isLinearized with EFResidual::J and ::res_toZeroF, EnergyFunctionalStructs.h:63-87 — linearised by the reference itself, or by
+ * an earlier window of this library) right after dmvio_hip_ba_set_graph: R flags in the graph's residual order, J74 = R x 74 floats (RawResidualJacobian in
+ * dmvio_hip_ba_get_full_jacobians' layout: resF 8 | Jpdxi 2x6 | Jpdc 2x4 | Jpdd 2 | JIdx 2x8 | JabF 2x8 | JIdx2 4 | JabJIdx 4 | Jab2 4), res_toZeroF = R x 8; only the rows
+ * of flagged residuals are read.  They become what dmvio_hip_ba_fix_linearization leaves behind: active, ResState::IN, out of activeResiduals, served by accumulateLF_MT /
+ * addPoint<1> and calcLEnergyPt on the host loop, the device loop, in a batch and on a sharded window (collective there, like _fix_linearization).  The record the
+ * accumulation reads (JpJdF of EFResidual::takeDataF, EnergyFunctionalStructs.cpp:39-49, Hdd / Hcd contributions) is formed from J by the linearisation kernel's own
+ * expressions: a graph that carries them over gives the bits of the graph they were linearised on (tests/test_ba_gpu.py).  With a resident graph:
+ * dmvio_hip_graph_set_residual_linearized per residual, then dmvio_hip_ba_set_graph_from hands them over in the same call.  n_linearized may be NULL. */
+int dmvio_hip_ba_set_linearized_residuals(dmvio_hip_ba* ba, int R, const unsigned char* isLinearized, const float* J74, const float* res_toZeroF, int* n_linearized);
+/* ... and back: flags / J / res_toZeroF of the graph's residuals as they stand (rows of the others zeroed; any output may be NULL) */
+int dmvio_hip_ba_get_linearized_residuals(dmvio_hip_ba* ba, int R, unsigned char* isLinearized, float* J74, float* res_toZeroF);
+/* A bare EFResidual::isLinearized flag (R flags, same order) WITHOUT the frozen Jacobian and res_toZeroF cannot be served — what accumulateLF_MT / addPoint<1> / calcLEnergyPt
+ * read (EnergyFunctional.cpp:223-233, 349-431, AccumulatedTopHessian.cpp:84-98) would be missing.  A graph flagged this way is REFUSED: the call returns an error, the graph is
+ * dropped (every later call on it fails until the next dmvio_hip_ba_set_graph) — it is never silently optimised without that energy term.  All flags zero: no effect.  Hand
+ * linearised residuals over with dmvio_hip_ba_set_linearized_residuals. */
 int dmvio_hip_ba_set_residual_flags(dmvio_hip_ba* ba, int R, const unsigned char* isLinearized);
 /* EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:85-113) for the ACTIVE residuals with res_mask != 0 (R flags, graph order), at the window's current state:
  * res_toZeroF = resF - [JI Jp | Jab] delta from the applied Jacobian, isLinearized = true.  From then on the residual is no member of activeResiduals

@@ -348,26 +348,127 @@ def test_window_size_is_a_runtime_setting(pkg, oracle, synth, gpu_required, F):
             ba4.set_case(big, [0] * 13)
 
 
-def test_graph_with_a_linearised_residual_is_refused(pkg, synth, gpu_required):
-    """A residual that ARRIVES linearised with the graph cannot be served (its frozen Jacobian / res_toZeroF, which accumulateLF_MT / addPoint<1> read, are not part of
-    the hand-over — dmvio_hip_ba_fix_linearization linearises on the resident graph instead, see the next test): the graph is refused with an error instead of being
-    optimised without that term, and stays refused until a new graph is set."""
-    case = synth.ba_case(256, 256, n_frames=4, n_points=120, seed=9, hosts_share=(50, 40, 30, 0))
-    ctx = pkg.Context(256, 256, n_slots=4)
-    for k in range(4):
+def test_graph_arrives_with_linearised_residuals(pkg, synth, gpu_required):
+    """A graph whose residuals ARRIVE linearised (EFResidual::isLinearized with EFResidual::J and ::res_toZeroF, EnergyFunctionalStructs.h:63-87) is served like one whose
+    residuals were linearised on the resident graph (next test; that path is the one pinned to the oracle and libref.so):
+      - flat hand-over (dmvio_hip_ba_set_linearized_residuals) onto a window standing in the same state: every accumulated system, the per-point sums and E_L bit for bit
+        — the record formed from J is the record the linearisation wrote;
+      - through the resident graph (dmvio_hip_graph_set_residual_linearized + dmvio_hip_ba_set_graph_from) onto a FRESH window: the optimisation that follows takes the
+        same decisions and ends in the same state, bit for bit, on the host loop and on the device loop;
+      - the records follow dropResidual / removePoint in the mirror;
+      - a bare flag without the Jacobians is still refused (never optimised without the term)."""
+    case = synth.ba_case(256, 192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
+    R = len(case["res_point"]); F = case["n_frames"]
+    mask = (np.arange(R) % 3 == 0).astype(np.uint8)
+    ctx = pkg.Context(case["w"], case["h"], n_slots=F)
+    for k in range(F):
         ctx.frame_upload(k, case["imgs"][k])
-    ba = pkg.BundleAdjusterHip(ctx); ba.set_case(case, [0, 1, 2, 3])
-    R = len(case["res_point"])
-    ba.set_residual_flags(np.zeros(R, dtype=np.uint8))             # nothing linearised: accepted
-    r0 = ba.optimize(2)
-    flags = np.zeros(R, dtype=np.uint8); flags[R // 2] = 1
-    ba.set_case(case, [0, 1, 2, 3])
+
+    def perturb(ba, rng, scale):
+        for k in range(1, F):
+            st = np.zeros(10); st[:3] = 2e-3 * scale * rng.standard_normal(3); st[3:6] = 1e-3 * scale * rng.standard_normal(3)
+            st[6] = 1e-3 * scale * rng.standard_normal(); st[7] = 1e-4 * scale * rng.standard_normal()
+            ba.set_frame_state(k, st)
+
+    def standing(keep):
+        ba = pkg.BundleAdjusterHip(ctx, accumulators=1, keep_jacobians=keep); ba.set_case(case, list(range(F)))
+        rng = np.random.RandomState(11)
+        perturb(ba, rng, 1.0)
+        ba.activate_all(); ba.linearize_all(False); ba.apply_res()
+        return ba, rng
+
+    # A: linearised on the resident graph
+    A, rngA = standing(True)
+    n_lin = A.fix_linearization(mask)
+    assert 100 < n_lin <= (R + 2) // 3
+    fl, J, rtz = A.linearized_residuals()
+    assert int(fl.sum()) == n_lin and np.abs(J[fl == 1]).max() > 0 and not J[fl == 0].any() and not rtz[fl == 0].any()
+    perturb(A, rngA, 0.5)
+    # B: the same window, the residuals handed over
+    B, rngB = standing(False)
+    assert B.set_linearized_residuals(fl, J, rtz) == n_lin
+    fl2, J2, rtz2 = B.linearized_residuals()
+    assert np.array_equal(fl, fl2) and np.array_equal(J, J2) and np.array_equal(rtz, rtz2)
+    perturb(B, rngB, 0.5)
+    aA, aB = A.accumulate(), B.accumulate()
+    assert aA["resInA"] == aB["resInA"]
+    for k in ("HA", "bA", "Hsc", "bsc"):
+        assert np.array_equal(aA[k], aB[k]), k
+    for x, y in zip(A.lf_system(), B.lf_system()):
+        assert np.array_equal(x, y) and np.abs(x).max() > 1e2
+    pA, pB = A.point_acc(), B.point_acc()
+    for k in ("Hdd", "bd", "Hcd", "HdiF", "bdSumF"):
+        assert np.array_equal(pA[k], pB[k]), k
+    assert A.energy_terms()[0] == B.energy_terms()[0] and abs(A.energy_terms()[0]) > 1.0
+    th = A.frame_energy_th()          # FrameHessian::frameEnergyTH as the earlier linearisation left it: frame state, handed over like the poses
+    rA = A.optimize(4)
+    rB = B.optimize(4)
+    assert np.array_equal(rA["trace"], rB["trace"]) and rA["finalEnergy"] == rB["finalEnergy"]
+    def frames_of(ba):
+        return np.concatenate([np.concatenate([np.ravel(x) for x in ba.frame_pose(k)]) for k in range(F)])
+    states = [frames_of(A)]
+    assert np.array_equal(states[0], frames_of(B))
+    # C: a FRESH window built from the mirror that carries them — nothing linearised or applied before the hand-over
+    g = pkg.WindowGraph.from_case(case, ctx.L)
+    flat = g.export()
+    assert np.array_equal(flat["res_point"], case["res_point"]) and np.array_equal(flat["res_target"], case["res_target"])
+    first = np.concatenate([[0], np.cumsum(np.bincount(case["res_point"], minlength=len(case["u"])))])
+    idx_in_host = np.zeros(len(case["u"]), dtype=np.int64)
+    for h in range(F):
+        m = np.where(case["host"] == h)[0]; idx_in_host[m] = np.arange(len(m))
+    for ri in np.where(fl == 1)[0]:
+        p = case["res_point"][ri]
+        g.set_residual_linearized(case["host"][p], idx_in_host[p], ri - first[p], J[ri], rtz[ri])
+    assert g.linearized_count() == n_lin
+    gf, gJ, gr = g.export_linearized()
+    assert np.array_equal(gf, fl) and np.array_equal(gJ, J) and np.array_equal(gr, rtz)
+    for device_loop in (False, True):
+        Cw = pkg.BundleAdjusterHip(ctx, accumulators=1)
+        aff = np.zeros((F, 2)) if case.get("aff") is None else case["aff"]
+        Cw.set_window(list(range(F)), np.asarray(case["poses0"], dtype=np.float64).reshape(F, 7), aff, np.ones(F, dtype=np.float32), np.arange(F, dtype=np.int32), case["K4"])
+        Cw.set_graph_from(g)
+        rng = np.random.RandomState(11)
+        perturb(Cw, rng, 1.0); perturb(Cw, rng, 0.5)
+        Cw.set_frame_energy_th(th)
+        assert Cw.linearized_residuals()[0].sum() == n_lin
+        Cw.set_device_loop(device_loop)
+        rC = Cw.optimize(4)
+        ref, r_ref = A, rA
+        if device_loop:      # the resident-graph counterpart on the same loop
+            ref, rng2 = standing(True)
+            assert ref.fix_linearization(mask) == n_lin
+            perturb(ref, rng2, 0.5)
+            ref.set_device_loop(True)
+            r_ref = ref.optimize(4)
+            assert np.array_equal(r_ref["trace"][:, 3], rA["trace"][:, 3]) and np.allclose(r_ref["trace"][:, :2], rA["trace"][:, :2], rtol=1e-6)
+        assert np.array_equal(r_ref["trace"], rC["trace"]), (device_loop, r_ref["trace"] - rC["trace"])
+        assert np.array_equal(frames_of(ref), frames_of(Cw))
+        assert np.array_equal(ref.point_state()[0], Cw.point_state()[0])
+        Cw.close()
+        if device_loop:
+            ref.close()
+    # the mirror keeps a record with its residual: dropResidual moves the point's last residual (and its record) into the hole, removePoint gives the records back
+    p = int(case["res_point"][np.where(fl == 1)[0][0]])
+    nres = g.point_residuals(case["host"][p], idx_in_host[p])
+    lin_of_p = [int(fl[first[p] + k]) for k in range(nres)]
+    g.drop_residual(case["host"][p], idx_in_host[p], 0)
+    assert g.linearized_count() == n_lin - lin_of_p[0]
+    gf2 = g.export_linearized()[0]
+    moved = lin_of_p[1:]
+    if len(moved):
+        moved = [moved[-1]] + moved[:-1]
+    assert list(gf2[first[p]:first[p] + nres - 1]) == moved
+    g.remove_point(case["host"][p], idx_in_host[p])
+    assert g.linearized_count() == n_lin - sum(lin_of_p)
+    # a bare flag is refused, and the graph with it
+    D = pkg.BundleAdjusterHip(ctx); D.set_case(case, list(range(F)))
+    D.set_residual_flags(np.zeros(R, dtype=np.uint8))
     with pytest.raises(pkg.HipLibraryError, match="accumulateLF_MT"):
-        ba.set_residual_flags(flags)
+        D.set_residual_flags(fl)
     with pytest.raises(pkg.HipLibraryError, match="set_graph first"):
-        ba.optimize(2)
-    ba.set_case(case, [0, 1, 2, 3])
-    assert ba.optimize(2)["finalEnergy"] == r0["finalEnergy"]
+        D.optimize(2)
+    for w in (A, B, D):
+        w.close()
 
 
 @pytest.mark.parametrize("loop", ["host", "device", "batch4"])
@@ -470,7 +571,7 @@ def test_residuals_kept_linearised_across_optimize_calls(pkg, oracle, synth, gpu
         left = ba.fix_linearization(zero)
         rp = np.asarray(case["res_point"])
         assert left < n_lin and left <= int(np.sum(mask.astype(bool) & (rp >= ba.N // 2)))
-    # a window sharded over ranks still refuses such a graph instead of dropping the term (the L system would have to join the all-reduce)
+    # (a window sharded over ranks: tests/test_sharded_ba_gpu.py)
     for o in others:
         o.close()
     ba.close()

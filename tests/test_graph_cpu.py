@@ -122,6 +122,79 @@ def test_random_mutations_equal_the_references_containers(pkg, seed):
         assert np.array_equal(g.export()["idepth"], np.arange(len(host), dtype=np.float32))
 
 
+@pytest.mark.parametrize("seed", [4, 5])
+def test_linearised_records_travel_with_their_residuals(pkg, seed):
+    """EFResidual::isLinearized / J / res_toZeroF (EnergyFunctionalStructs.h:63-87) are members of the residual object: they move with it when dropResidual fills a hole
+    with the point's last residual, go when the residual or its point goes, and come out in makeIDX order (dmvio_hip_graph_set_residual_linearized / _export_linearized)."""
+    rng = np.random.RandomState(seed)
+    g = pkg.WindowGraph(); ef = EF()
+    lin = {}                                   # id of the restatement's point dict -> list parallel to its "res": None or (J74, res_toZeroF)
+    for _ in range(4):
+        assert g.insert_frame() == ef.insertFrame()
+    n_lin = 0
+
+    def check():
+        fl, J, r = g.export_linearized()
+        want = [x for fr in ef.frames for p in fr for x in lin[id(p)]]
+        assert len(want) == len(fl) and g.linearized_count() == sum(x is not None for x in want) == n_lin
+        for ri, x in enumerate(want):
+            if x is None:
+                assert fl[ri] == 0 and not J[ri].any() and not r[ri].any()
+            else:
+                assert fl[ri] == 1 and np.array_equal(J[ri], x[0]) and np.array_equal(r[ri], x[1])
+
+    for step in range(1500):
+        F = len(ef.frames)
+        op = rng.randint(0, 100)
+        h = rng.randint(F)
+        if op < 25:
+            r = _rec(rng)
+            i = ef.insertPoint(h, r); assert g.insert_point(h, r[0], r[1], r[2], r[3], r[4], r[5]) == i
+            lin[id(ef.frames[h][i])] = []
+        elif op < 55 and ef.frames[h]:
+            i = rng.randint(len(ef.frames[h])); p = ef.frames[h][i]
+            cand = [t for t in range(F) if t != h and t not in p["res"]]
+            if cand:
+                t = cand[rng.randint(len(cand))]
+                assert g.insert_residual(h, i, t) == ef.insertResidual(h, i, t)
+                lin[id(p)].append(None)
+        elif op < 75 and ef.frames[h]:                                                        # fixLinearizationF / isLinearized = false on a random residual
+            i = rng.randint(len(ef.frames[h])); p = ef.frames[h][i]
+            if p["res"]:
+                k = rng.randint(len(p["res"]))
+                if rng.rand() < 0.75:
+                    x = (rng.standard_normal(74).astype(np.float32), rng.standard_normal(8).astype(np.float32))
+                    n_lin += lin[id(p)][k] is None
+                    lin[id(p)][k] = x
+                    g.set_residual_linearized(h, i, k, x[0], x[1])
+                else:
+                    n_lin -= lin[id(p)][k] is not None
+                    lin[id(p)][k] = None
+                    g.set_residual_linearized(h, i, k, None)
+        elif op < 90 and ef.frames[h]:                                                        # dropResidual
+            i = rng.randint(len(ef.frames[h])); p = ef.frames[h][i]
+            if p["res"]:
+                k = rng.randint(len(p["res"]))
+                L = lin[id(p)]
+                n_lin -= L[k] is not None
+                L[k] = L[-1]; L.pop()
+                g.drop_residual(h, i, k); ef.dropResidual(h, i, k)
+        elif ef.frames[h]:                                                                    # removePoint
+            i = rng.randint(len(ef.frames[h])); p = ef.frames[h][i]
+            n_lin -= sum(x is not None for x in lin[id(p)])
+            del lin[id(p)]
+            g.remove_point(h, i); ef.removePoint(h, i)
+        if step % 53 == 0:
+            check(); _same(g, ef)
+    check()
+    r = _rec(rng)
+    i = g.insert_point(0, r[0], r[1], r[2], r[3], r[4], r[5])
+    with pytest.raises(pkg.HipLibraryError, match="residual index out of range"):
+        g.set_residual_linearized(0, i, 0, np.zeros(74, np.float32), np.zeros(8, np.float32))
+    g.clear()
+    assert g.linearized_count() == 0
+
+
 def test_errors_and_dangling_residuals(pkg):
     g = pkg.WindowGraph()
     with pytest.raises(pkg.HipLibraryError):
