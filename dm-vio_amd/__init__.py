@@ -803,6 +803,13 @@ class BundleAdjusterBatch:
         _chk(self.L, fn(self.p, t.ctypes.data), "ba_batch_last_solve_ticks")
         return t / 100.0
 
+    def last_host_us(self):
+        """host clock at the phase boundaries of the last call (dmvio_hip_ba_batch_last_host_us)"""
+        o = (C.c_double * 8)()
+        fn = self.L.dmvio_hip_ba_batch_last_host_us; fn.argtypes = [C.c_void_p, C.POINTER(C.c_double)]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, o), "ba_batch_last_host_us")
+        return [float(x) for x in o]
+
     def last_pivot_branch(self, w=0):
         """how window w's last solve found Eigen's pivot order: 0 ranks (distinct |diagonal|), 1 ties replayed, 2 NaN"""
         b = C.c_int(-1)

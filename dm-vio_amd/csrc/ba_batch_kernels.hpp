@@ -73,6 +73,58 @@ struct BAWinDev {
   BASolveDev S;
 };
 
+// ---- the record's pointers as GLOBAL pointers.  A pointer that arrives as a kernel argument is known to point into global memory; one that a kernel loads from a
+// structure in memory is a generic ("flat") pointer to the compiler: every access through it becomes a flat_load / flat_store, which counts on BOTH wait counters — an
+// `s_waitcnt lgkmcnt(0)` in front of an LDS read then also waits for every outstanding global load, and the software pipelines of the accumulation / linearisation bodies
+// (global loads issued tiles ahead of the LDS traffic that consumes them) collapse to load -> wait -> use.  gl() reads the pointer through an lvalue whose type carries the
+// global address space; the address-space inference pass then turns every access derived from it into global_load / global_store.  The bl*() functions below build the
+// local argument structures of a body from a window's record this way (they live in registers: no member is read with a dynamic index, see baRec()).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wincompatible-pointer-types-discards-qualifiers"
+template <class T> __device__ __forceinline__ T* gl(T* const& member) {
+  return (T*)(*reinterpret_cast<__attribute__((address_space(1))) T* const*>(&member));
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ BAPoints blPoints(const BAPoints& g) {
+  BAPoints v;
+  v.host = gl(g.host); v.u = gl(g.u); v.v = gl(g.v);
+  v.idepth = gl(g.idepth); v.idepth_zero = gl(g.idepth_zero); v.idepth_backup = gl(g.idepth_backup); v.step = gl(g.step);
+  v.color = gl(g.color); v.weights = gl(g.weights); v.priorF = gl(g.priorF); v.res_begin = gl(g.res_begin);
+  v.Hdd = gl(g.Hdd); v.bd = gl(g.bd); v.Hcd = gl(g.Hcd); v.HdiF = gl(g.HdiF); v.bdSumF = gl(g.bdSumF); v.idepth_hessian = gl(g.idepth_hessian);
+  v.lHdd = gl(g.lHdd); v.lbd = gl(g.lbd); v.lHcd = gl(g.lHcd); v.HcdAF = gl(g.HcdAF);
+  return v;
+}
+__device__ __forceinline__ BARes blRes(const BARes& g) {
+  BARes v;
+  v.point = gl(g.point); v.target = gl(g.target);
+  v.state = gl(g.state); v.newState = gl(g.newState); v.active = gl(g.active); v.which = gl(g.which); v.removed = gl(g.removed);
+  v.energy = gl(g.energy); v.newEnergy = gl(g.newEnergy); v.newEnergyWO = gl(g.newEnergyWO); v.center = gl(g.center);
+  v.newestSlot = gl(g.newestSlot); v.newestE = gl(g.newestE);
+  v.rec[0] = gl(g.rec[0]); v.rec[1] = gl(g.rec[1]);
+  v.lin = gl(g.lin);
+  return v;
+}
+__device__ __forceinline__ AccumArgs blAccum(const AccumArgs& g) {
+  AccumArgs v;
+  v.F = g.F; v.N = g.N; v.nsTop = g.nsTop; v.nsD = g.nsD; v.nsC = g.nsC;
+  v.top_begin = gl(g.top_begin); v.top_members = gl(g.top_members); v.scd_begin = gl(g.scd_begin); v.scd_members = gl(g.scd_members);
+  v.accTop = gl(g.accTop); v.accD = gl(g.accD); v.accE = gl(g.accE); v.accC = gl(g.accC); v.numTop = gl(g.numTop); v.numD = gl(g.numD);
+  v.ticks = nullptr;
+  return v;
+}
+__device__ __forceinline__ StitchBufs blStitch(const StitchBufs& g) {
+  StitchBufs v;
+  v.topHH = gl(g.topHH); v.topTT = gl(g.topTT); v.topHT = gl(g.topHT); v.topHC = gl(g.topHC); v.topTC = gl(g.topTC); v.topBH = gl(g.topBH); v.topBT = gl(g.topBT); v.topCC = gl(g.topCC);
+  v.scHH = gl(g.scHH); v.scTH = gl(g.scTH); v.scTT = gl(g.scTT); v.scHT = gl(g.scHT); v.scHC = gl(g.scHC); v.scTC = gl(g.scTC); v.scBH = gl(g.scBH); v.scBT = gl(g.scBT);
+  return v;
+}
+__device__ __forceinline__ BADecide blDecide(const BADecide& g) {
+  BADecide v = g;
+  v.newestE = gl(g.newestE); v.frameTH = gl(g.frameTH); v.epart = gl(g.epart); v.ctl = gl(g.ctl); v.host = gl(g.host);
+  v.xchg_local = gl(g.xchg_local); v.xchg_all = gl(g.xchg_all);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------ batched forms of the kernels of ba_kernels.hpp
 // window = blockIdx.y; a workgroup beyond its window's own grid leaves at once (grid.x is the largest count of the batch)
 enum { BA_LINB_INITIAL = 0, BA_LINB_STEPPED = 1, BA_LINB_RESTORE = 2, BA_LINB_FINAL = 3, BA_LINB_STEPPED_DONE = 4 };   // _DONE: the step was taken by k_ba_resubstitute_b
@@ -81,25 +133,27 @@ enum { BA_LINB_INITIAL = 0, BA_LINB_STEPPED = 1, BA_LINB_RESTORE = 2, BA_LINB_FI
 __global__ void __launch_bounds__(LIN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ba_linearize_b(const BAWinDev* __restrict__ wins, const FrameStore fs, const int kind) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_lin_blocks) return;
-  BADecide D = V.D;
+  BADecide D = blDecide(V.D);
   D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1;
+  const BAPoints P = blPoints(V.P); const BARes Rs = blRes(V.Rs); const BAPrecalc* const pre = gl(V.pre);
   // INITIAL / FINAL: plain linearisation of the current state (energy + threshold); STEPPED: back-substitution + point step fused in front, accept test behind;
   // RESTORE: only after a rejected step — the points go back to their backup, the backed-up state is relinearised
-  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin_blocks); }
-  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody(V.Wb, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
-  else { D.mode = 0; baLinearizeBody(V.W, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
+  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody(V.W, P, Rs, pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin_blocks); }
+  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody(V.Wb, P, Rs, pre, fs, nullptr, nullptr, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
+  else { D.mode = 0; baLinearizeBody(V.W, P, Rs, pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin_blocks); }
 }
 // the one-lane-per-residual form (baLinearizeBody1): what a grid that fills the device wants — an eighth of the lanes, no redundant geometry; same values, same energy partials
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize_b1(const BAWinDev* __restrict__ wins, const FrameStore fs, const int kind) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_lin1_blocks) return;
-  BADecide D = V.D;
+  BADecide D = blDecide(V.D);
   D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1;
+  const BAPoints P = blPoints(V.P); const BARes Rs = blRes(V.Rs); const BAPrecalc* const pre = gl(V.pre);
   extern __shared__ float s_patch[];   // LIN_THREADS x BA_PATCH_STRIDE floats: every lane's 8x8 window of its target image (then the decision pass's key staging)
-  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
-  else if (kind == BA_LINB_STEPPED_DONE) { D.mode = 1; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
-  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
-  else { D.mode = 0; baLinearizeBody1(V.W, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  if (kind == BA_LINB_STEPPED) { D.mode = 1; baLinearizeBody1(V.W, P, Rs, pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 1, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if (kind == BA_LINB_STEPPED_DONE) { D.mode = 1; baLinearizeBody1(V.W, P, Rs, pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if (kind == BA_LINB_RESTORE) { D.mode = 2; baLinearizeBody1(V.Wb, P, Rs, pre, fs, D, BA_GATE_REJECTED, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else { D.mode = 0; baLinearizeBody1(V.W, P, Rs, pre, fs, D, BA_GATE_ALWAYS, 0, V.T.v, kind == BA_LINB_INITIAL ? 1 : 0, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
 }
 // What follows a stepped linearisation's decision, in ONE launch (a gated-off launch still costs ~4.5 us of dispatch): a window whose step was REJECTED restores its points
 // and relinearises the backed-up state (BA_LINB_RESTORE above); a window whose step was ACCEPTED runs applyRes + the per-point sums of the new state (k_ba_point_sums_b;
@@ -108,43 +162,47 @@ __global__ void __launch_bounds__(LIN_THREADS) k_ba_linearize_b1(const BAWinDev*
 template <bool LIN1>
 __global__ void __launch_bounds__(LIN_THREADS) k_ba_post_decide_b(const BAWinDev* __restrict__ wins, const FrameStore fs, const int what) {
   const BAWinDev& V = wins[blockIdx.y];
-  if (!baGateClosed(V.ctl, BA_GATE_ACCEPTED)) {
-    if (what == 0) { if ((int)blockIdx.x < V.n_pt8_blocks) baPointSumsBody(V.W, V.P, V.Rs, 1, 1, V.ctl, BA_GATE_ALWAYS, nullptr); }
-    else if ((int)blockIdx.x < V.n_res_blocks) baApplyBody(V.W.R, V.Rs, nullptr, 0);
+  const BACtl* const ctl = gl(V.ctl);
+  const BAPoints P = blPoints(V.P); const BARes Rs = blRes(V.Rs);
+  if (!baGateClosed(ctl, BA_GATE_ACCEPTED)) {
+    if (what == 0) { if ((int)blockIdx.x < V.n_pt8_blocks) baPointSumsBody(V.W, P, Rs, 1, 1, ctl, BA_GATE_ALWAYS, nullptr); }
+    else if ((int)blockIdx.x < V.n_res_blocks) baApplyBody(V.W.R, Rs, nullptr, 0);
     return;
   }
-  BADecide D = V.D;
+  BADecide D = blDecide(V.D);
   D.publish = 0; D.update_th = 1; D.lastE0_from_ctl = 1; D.mode = 2;
+  const BAPrecalc* const pre = gl(V.pre);
   extern __shared__ float s_patch[];
-  if (LIN1) { if ((int)blockIdx.x < V.n_lin1_blocks) baLinearizeBody1(V.Wb, V.P, V.Rs, V.pre, fs, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
-  else if ((int)blockIdx.x < V.n_lin_blocks) baLinearizeBody(V.Wb, V.P, V.Rs, V.pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks);
+  if (LIN1) { if ((int)blockIdx.x < V.n_lin1_blocks) baLinearizeBody1(V.Wb, P, Rs, pre, fs, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin1_blocks, V.n_lin_blocks, s_patch); }
+  else if ((int)blockIdx.x < V.n_lin_blocks) baLinearizeBody(V.Wb, P, Rs, pre, fs, nullptr, nullptr, D, BA_GATE_ALWAYS, 1, V.Tb.v, 1, V.X.xc, V.X.xAd, 0, V.n_lin_blocks);
 }
 // resubstituteF_MT + the points' share of doStepFromBackup for every window of a launch (k_ba_resubstitute: eight lanes per point, the loads of a point's residuals side by
 // side) — in front of the one-lane linearisation, whose own form of it walks a point's residuals one dependent load pair after the other
 __global__ void __launch_bounds__(256) k_ba_resubstitute_b(const BAWinDev* __restrict__ wins) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_pt8_blocks) return;
-  baResubstituteBody(V.W, V.P, V.Rs, V.X.xc, V.X.xAd, 1);
+  baResubstituteBody(V.W, blPoints(V.P), blRes(V.Rs), V.X.xc, V.X.xAd, 1);
 }
 __global__ void __launch_bounds__(256) k_ba_reset_oob_b(const BAWinDev* __restrict__ wins) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_res_blocks) return;
   const int ri = blockIdx.x * blockDim.x + threadIdx.x;
   if (ri >= V.W.R) return;
-  const bool gone = V.Rs.removed[ri] != 0;   // PointFrameResidual::resetOOB of every residual still in the graph (k_ba_reset_oob)
-  V.Rs.state[ri] = gone ? BA_OOB : BA_IN;
-  V.Rs.newState[ri] = gone ? BA_OOB : BA_OUTLIER;
-  V.Rs.energy[ri] = 0.f; V.Rs.newEnergy[ri] = 0.f;
+  const BARes Rs = blRes(V.Rs);
+  const bool gone = Rs.removed[ri] != 0;   // PointFrameResidual::resetOOB of every residual still in the graph (k_ba_reset_oob)
+  Rs.state[ri] = gone ? BA_OOB : BA_IN;
+  Rs.newState[ri] = gone ? BA_OOB : BA_OUTLIER;
+  Rs.energy[ri] = 0.f; Rs.newEnergy[ri] = 0.f;
 }
 __global__ void __launch_bounds__(256) k_ba_apply_b(const BAWinDev* __restrict__ wins, const int mark_removed, const int gate) {
   const BAWinDev& V = wins[blockIdx.y];
-  if ((int)blockIdx.x >= V.n_res_blocks || baGateClosed(V.ctl, gate)) return;
-  baApplyBody(V.W.R, V.Rs, nullptr, mark_removed);
+  if ((int)blockIdx.x >= V.n_res_blocks || baGateClosed(gl(V.ctl), gate)) return;
+  baApplyBody(V.W.R, blRes(V.Rs), nullptr, mark_removed);
 }
 __global__ void __launch_bounds__(256) k_ba_point_sums_b(const BAWinDev* __restrict__ wins, const int backup, const int apply, const int gate) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_pt8_blocks) return;
-  baPointSumsBody(V.W, V.P, V.Rs, backup, apply, V.ctl, gate, nullptr);
+  baPointSumsBody(V.W, blPoints(V.P), blRes(V.Rs), backup, apply, gl(V.ctl), gate, nullptr);
 }
 // pass: 0 = the one accumulation of a graph without residuals kept linearised; 1 / 2 / 3 = the L / A / Schur pass of the three-pass accumulation (accumulateLin in
 // capi_ba.hip: addPoint<1> over the linearised residuals' records, addPoint<0> over the others, the Schur side over every active one).  A window WITHOUT such residuals in a
@@ -154,38 +212,43 @@ __device__ __forceinline__ bool baPassIdle(const BAWinDev& V, const int pass) { 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_ba_accumulate_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
   if ((int)blockIdx.x >= V.n_acc_blocks || baPassIdle(V, pass)) return;
-  if (V.n_lin == 0 || pass == BA_PASS_S || pass == BA_PASS_ALL) { baAccumulateBody(V.A, V.Rs, V.P, V.ctl, gate); return; }
-  BARes Rv = V.Rs;
-  if (pass == BA_PASS_L) { Rv.rec[0] = Rv.rec[1] = V.linRec; Rv.active = V.linActive; Rv.lin = nullptr; }
-  else Rv.active = V.topActive;
-  baAccumulateBody(V.A, Rv, V.P, V.ctl, gate);
+  const AccumArgs A = blAccum(V.A); const BAPoints P = blPoints(V.P); const BACtl* const ctl = gl(V.ctl);
+  BARes Rv = blRes(V.Rs);
+  if (V.n_lin == 0 || pass == BA_PASS_S || pass == BA_PASS_ALL) { baAccumulateBody(A, Rv, P, ctl, gate); return; }
+  if (pass == BA_PASS_L) { Rv.rec[0] = Rv.rec[1] = gl(V.linRec); Rv.active = gl(V.linActive); Rv.lin = nullptr; }
+  else Rv.active = gl(V.topActive);
+  baAccumulateBody(A, Rv, P, ctl, gate);
 }
 // every window of a batch has the same F (the host groups them): blockDim = 64 F
 __global__ void __launch_bounds__(64 * BA_MAXF_CAP) k_ba_stitch_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
   if (baPassIdle(V, pass)) return;
-  baStitchBody(V.A.F, V.A.nsTop, V.A.nsD, V.A.accTop, V.A.numTop, V.A.accD, V.A.numD, V.A.accE, V.adHost, V.adTarget, V.SB, V.ctl, gate);
+  const AccumArgs A = blAccum(V.A);
+  baStitchBody(A.F, A.nsTop, A.nsD, A.accTop, A.numTop, A.accD, A.numD, A.accE, gl(V.adHost), gl(V.adTarget), blStitch(V.SB), gl(V.ctl), gate);
 }
 template <int MF>
 __global__ void __launch_bounds__(256) k_ba_stitch_gather_b(const BAWinDev* __restrict__ wins, const int gate, const int pass) {
   const BAWinDev& V = wins[blockIdx.y];
-  if ((int)blockIdx.x >= V.n_gather_blocks || baGateClosed(V.ctl, gate) || baPassIdle(V, pass)) return;
+  if ((int)blockIdx.x >= V.n_gather_blocks || baGateClosed(gl(V.ctl), gate) || baPassIdle(V, pass)) return;
   const int F = V.A.F;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (V.n_lin == 0 || pass == BA_PASS_ALL) gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, t, false, 3, true);
-  else if (pass == BA_PASS_L) gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sysL, t, false, 1, false);
-  else gatherElement<MF>(F, V.A.nsC, V.A.accC, V.SB, V.A.numTop, F * F * V.A.nsTop, V.sys, t, false, pass == BA_PASS_A ? 1 : 2, true);
+  const AccumArgs A = blAccum(V.A); const StitchBufs SB = blStitch(V.SB);
+  if (V.n_lin == 0 || pass == BA_PASS_ALL) gatherElement<MF>(F, A.nsC, A.accC, SB, A.numTop, F * F * A.nsTop, gl(V.sys), t, false, 3, true);
+  else if (pass == BA_PASS_L) gatherElement<MF>(F, A.nsC, A.accC, SB, A.numTop, F * F * A.nsTop, gl(V.sysL), t, false, 1, false);
+  else gatherElement<MF>(F, A.nsC, A.accC, SB, A.numTop, F * F * A.nsTop, gl(V.sys), t, false, pass == BA_PASS_A ? 1 : 2, true);
 }
 // the records addPoint<1> consumes and the linearised residuals' per-point sums, at the deltas of the state the window stands at (k_ba_lin_records / k_ba_lin_point_sums)
 __global__ void __launch_bounds__(256) k_ba_lin_records_b(const BAWinDev* __restrict__ wins, const int gate) {
   const BAWinDev& V = wins[blockIdx.y];
-  if (V.n_lin == 0 || (int)blockIdx.x >= V.n_res_blocks || baGateClosed(V.ctl, gate)) return;
-  baLinRecordsBody(V.W, V.P, V.Rs, V.fullJ, V.lin, V.rtz, V.adHTdelta[0], make_float4(V.cDeltaF[0][0], V.cDeltaF[0][1], V.cDeltaF[0][2], V.cDeltaF[0][3]), V.linRec, V.linActive, V.topActive);
+  if (V.n_lin == 0 || (int)blockIdx.x >= V.n_res_blocks || baGateClosed(gl(V.ctl), gate)) return;
+  baLinRecordsBody(V.W, blPoints(V.P), blRes(V.Rs), gl(V.fullJ), gl(V.lin), gl(V.rtz), V.adHTdelta[0], make_float4(V.cDeltaF[0][0], V.cDeltaF[0][1], V.cDeltaF[0][2], V.cDeltaF[0][3]),
+                   gl(V.linRec), gl(V.linActive), gl(V.topActive));
 }
 __global__ void __launch_bounds__(256) k_ba_lin_point_sums_b(const BAWinDev* __restrict__ wins, const int gate) {
   const BAWinDev& V = wins[blockIdx.y];
-  if (V.n_lin == 0 || (int)blockIdx.x * 256 >= V.W.N || baGateClosed(V.ctl, gate)) return;
-  baLinPointSumsBody(V.W, V.P, V.linRec, V.linActive, const_cast<float*>(V.P.lHdd), const_cast<float*>(V.P.lbd), const_cast<float*>(V.P.lHcd));
+  if (V.n_lin == 0 || (int)blockIdx.x * 256 >= V.W.N || baGateClosed(gl(V.ctl), gate)) return;
+  const BAPoints P = blPoints(V.P);
+  baLinPointSumsBody(V.W, P, gl(V.linRec), gl(V.linActive), const_cast<float*>(P.lHdd), const_cast<float*>(P.lbd), const_cast<float*>(P.lHcd));
 }
 // calcLEnergyPt's term of the residuals kept linearised (EnergyFunctional.cpp:349-409), at the deltas of the STEPPED state k_ba_solve just left in the record: every residual's
 // eight products (2 res_toZeroF + J delta) . (J delta) in parallel, then — last workgroup of the window — the reference's summation: an Accumulator11 (four fp32 lanes) per run of
@@ -196,13 +259,15 @@ __global__ void __launch_bounds__(256) k_ba_lin_energy_b(BAWinDev* __restrict__ 
   if (V.n_lin == 0 || (int)blockIdx.x >= V.n_res_blocks) return;
   const int ri = blockIdx.x * 256 + threadIdx.x;
   const float* __restrict__ adHT = V.adHTdelta[0];
+  float* const linE = gl(V.linE); const unsigned char* const lin = gl(V.lin); const unsigned char* const active = gl(V.Rs.active);
+  const int* const res_begin = gl(V.P.res_begin);
   if (ri < V.W.R) {
-    float* __restrict__ e = V.linE + (size_t)ri * 8;
-    if (V.lin[ri] && V.Rs.active[ri]) {
-      const int pi = V.Rs.point[ri];
-      const float* __restrict__ J = V.fullJ + (size_t)ri * 74;
-      const float* __restrict__ rtz = V.rtz + (size_t)ri * 8;
-      const float* __restrict__ dp = adHT + (size_t)(V.P.host[pi] + V.W.F * V.Rs.target[ri]) * 8;
+    float* __restrict__ e = linE + (size_t)ri * 8;
+    if (lin[ri] && active[ri]) {
+      const int pi = gl(V.Rs.point)[ri];
+      const float* __restrict__ J = gl(V.fullJ) + (size_t)ri * 74;
+      const float* __restrict__ rtz = gl(V.rtz) + (size_t)ri * 8;
+      const float* __restrict__ dp = adHT + (size_t)(gl(V.P.host)[pi] + V.W.F * gl(V.Rs.target)[ri]) * 8;
       const float dd = 0.0f;
       float sx = 0, sy = 0, cx = 0, cy = 0;
 #pragma unroll
@@ -244,10 +309,10 @@ __global__ void __launch_bounds__(256) k_ba_lin_energy_b(BAWinDev* __restrict__ 
     if (run < nruns) {
       float d1[4] = {0, 0, 0, 0};
       const int p1 = min(V.W.N, 50 * run + 50);
-      const int r0 = V.P.res_begin[50 * run], r1 = V.P.res_begin[p1];
+      const int r0 = res_begin[50 * run], r1 = res_begin[p1];
       for (int rj = r0; rj < r1; rj++) {
-        if (!V.lin[rj] || !V.Rs.active[rj]) continue;
-        const float* __restrict__ e = V.linE + (size_t)rj * 8;
+        if (!lin[rj] || !active[rj]) continue;
+        const float* __restrict__ e = linE + (size_t)rj * 8;
 #pragma unroll
         for (int k = 0; k < 4; k++) d1[k] = d1[k] + __hip_atomic_load(e + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -755,15 +820,16 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   const int haveM = S.haveM;
   // (gathering the system from the stitched blocks inside this kernel — no gather launch — was built and measured: one workgroup issuing the ~140k loads of
   // gatherValue costs 45 us against the 12 us of the 37-workgroup gather kernel it would replace)
-  const double* __restrict__ HA = V.sys;
-  const double* __restrict__ bA = V.sys + (size_t)n * n;
+  const double* const gHM = gl(S.HM); const double* const gbM = gl(S.bM); const double* const gBasis = gl(S.basis); double* const gTrace = gl(S.trace); BACtl* const gCtl = gl(V.ctl);
+  const double* __restrict__ HA = gl(V.sys);
+  const double* __restrict__ bA = gl(V.sys) + (size_t)n * n;
   const double* __restrict__ Hsc = bA + n;
   const double* __restrict__ bsc = Hsc + (size_t)n * n;
   int pr[QMAX];
   double hA[QMAX], hS[QMAX], hL[QMAX];   // the owned pairs' entries of H_A, H_sc and (residuals kept linearised: accumulateLF_MT's system) H_L
   double bAi = 0.0, bsci = 0.0, bLi = 0.0;
   const bool haveL = V.n_lin > 0;
-  const double* __restrict__ HLr = V.sysL;
+  const double* __restrict__ HLr = gl(V.sysL);
   // the pair tables and the calibration members of the state / of the backup: one of the two sets is copied over the other below (loads up front, stores behind the decision)
   constexpr int TQ = (BA_MAXF_CAP * (BA_MAXF_CAP - 1) * 14 + BA_SOLVE_THREADS - 1) / BA_SOLVE_THREADS;
   const int npT = F * (F - 1) * 14;
@@ -776,11 +842,11 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     if (tid < 8) { wcur = (&V.W.fx)[tid]; wbk = (&V.Wb.fx)[tid]; }
   }
   // pointers of the window's record the tail goes through (read once, up front: a pointer fetched where it is used costs a memory round trip in front of the access)
-  double* const x_last = S.x_last;
+  double* const x_last = gl(S.x_last);
   float* const Xxc = V.X.xc;
   float* const XxAd = V.X.xAd;
-  const float* const adHostF = S.adHostF;
-  const float* const adTargetF = S.adTargetF;
+  const float* const adHostF = gl(S.adHostF);
+  const float* const adTargetF = gl(S.adTargetF);
   // resubstitution input o = tid (hh, t, c): its adjoint columns, constant over the call
   float ahP[8], atP[8];
   if (!finish && tid < F * F * 8) {
@@ -796,10 +862,10 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
     if (tid < n) { bAi = bA[tid]; bsci = bsc[tid]; if (haveL) bLi = HLr[(size_t)n * n + tid]; }
     else if (tid >= 128 && tid < 128 + n) { const size_t o = (size_t)(tid - 128) * n + (tid - 128); bAi = HA[o]; bsci = Hsc[o]; if (haveL) bLi = HLr[o]; }   // (the diagonal, for the threads that scale it)
     if (haveM) {
-      for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];
-      for (int i = tid; i < n; i += BA_SOLVE_THREADS) bMs[i] = S.bM[i];
+      for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = gHM[i];
+      for (int i = tid; i < n; i += BA_SOLVE_THREADS) bMs[i] = gbM[i];
     }
-    if (iteration >= 2) for (int i = tid; i < S.nBasis * n; i += BA_SOLVE_THREADS) basis[i] = S.basis[i];
+    if (iteration >= 2) for (int i = tid; i < S.nBasis * n; i += BA_SOLVE_THREADS) basis[i] = gBasis[i];
   }
   for (int i = tid; i < 10 * F; i += BA_SOLVE_THREADS) { const BAFrameDev& f = S.fr[i / 10]; fst[i] = f.state[i % 10]; fzero[i] = f.state_zero[i % 10]; fbak[i] = f.state_backup[i % 10]; }
   for (int i = tid; i < 8 * F; i += BA_SOLVE_THREADS) fprior[i] = S.fr[i >> 3].prior[i & 7];
@@ -811,17 +877,17 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   if (tid == 0) {
     int acc = 1;
     if (S.stepped) {
-      acc = __hip_atomic_load(&V.ctl->accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double E0 = __hip_atomic_load(&V.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc = __hip_atomic_load(&gCtl->accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double E0 = __hip_atomic_load(&gCtl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (acc) { S.lastL = S.newL; S.lastM = S.newM; S.lambda = fmax(S.lambda * 0.25, 1e-5); S.n_accepted++; }
       else S.lambda *= 1e2;
       S.iterations_done++;
       const int row = S.iterations_done;
-      if (row < 64) { S.trace[4 * row] = E0; S.trace[4 * row + 1] = S.lastL; S.trace[4 * row + 2] = S.lastM; S.trace[4 * row + 3] = acc ? 1.0 : 0.0; }
+      if (row < 64) { gTrace[4 * row] = E0; gTrace[4 * row + 1] = S.lastL; gTrace[4 * row + 2] = S.lastM; gTrace[4 * row + 3] = acc ? 1.0 : 0.0; }
       S.stepped = 0;
     } else if (iteration == 0 && !finish) {
       // row 0 of the trace: the initial state (its photometric energy is what the initial linearisation's decision pass left in the control block)
-      S.trace[0] = __hip_atomic_load(&V.ctl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); S.trace[1] = S.lastL; S.trace[2] = S.lastM; S.trace[3] = 1.0;
+      gTrace[0] = __hip_atomic_load(&gCtl->lastE0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); gTrace[1] = S.lastL; gTrace[2] = S.lastM; gTrace[3] = 1.0;
     }
     s_flag[0] = acc; s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0;
     s_scal[4] = S.lambda; s_scal[5] = S.lastL; s_scal[6] = S.lastM;
@@ -911,7 +977,7 @@ __global__ void __launch_bounds__(BA_SOLVE_THREADS) k_ba_solve(BAWinDev* __restr
   __syncthreads();
   SOLVE_TICK(2);   // system assembled and scaled
   baLdltSolveCore<MF>(n, Lc, Tc, dgS, rhsS, rhs, xs, perm, s_flag, S.exact_backsub, pr, S.ticks, t_begin);
-  if (ALIAS && haveM) for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = S.HM[i];   // (back into the shared room, for E_M below)
+  if (ALIAS && haveM) for (int i = tid; i < n * n; i += BA_SOLVE_THREADS) HMs[(i / n) * hs + (i % n)] = gHM[i];   // (back into the shared room, for E_M below)
   if (tid == 0) S.pivot_branch = s_flag[2];
   // undo the scaling: x = S P^T x'
   if (tid < n) xs[tid] = sv[tid] * xs[tid];

@@ -106,6 +106,10 @@ struct BARes {      // SoA, R entries
                               // not relinearised, not applied, not counted in the energy or the newest keyframe's threshold; its record and activity stay what they were
 };
 
+// the record buffer `w` of a residual: a select between the two pointers, never an indexed read of the array — a dynamically indexed member would force the whole
+// structure into scratch memory wherever it is a local copy (the batched kernels, ba_batch_kernels.hpp)
+__device__ __forceinline__ float* baRec(const BARes& Rs, const int w) { return w ? Rs.rec[1] : Rs.rec[0]; }
+
 __constant__ int c_patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:296, pattern 8
 
 // ------------------------------------------------------------------------------------------------ device-side decisions
@@ -368,7 +372,7 @@ __device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoint
   double myE = 0.0;
   // all eight lanes of a residual take the same branches below (group-uniform conditions); stores come from the leading lane
   if (ri < W.R && (!pt_mask || pt_mask[Rs.point[ri]])) {
-    float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
+    float* __restrict__ rec = baRec(Rs, Rs.which[ri] ^ 1) + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
     int state = Rs.state[ri];
     const float oldEnergy = pt_mask ? 0.f : Rs.energy[ri];
     const bool gone = Rs.removed[ri] != 0;   // deleted by an earlier fix-linearisation: the reference has no such residual any more (state stays OOB below)
@@ -411,7 +415,7 @@ __device__ __forceinline__ void baLinearizeBody(const BAWindow& W, const BAPoint
       for (int rb = r0; rb < r1; rb += 8) {
         const int rq = min(rb + idx, r1 - 1);
         const bool act = rb + idx < r1 && Rs.active[rq] != 0;
-        const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
+        const float* __restrict__ jp = baRec(Rs, Rs.which[rq]) + (size_t)rq * REC_FLOATS + REC_JPJD;
         const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
         float d = 0;
 #pragma unroll
@@ -598,7 +602,7 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
   const int ri = blockIdx.x * LIN_THREADS + threadIdx.x;
   double myE = 0.0;
   if (ri < W.R) {
-    float* __restrict__ rec = Rs.rec[Rs.which[ri] ^ 1] + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
+    float* __restrict__ rec = baRec(Rs, Rs.which[ri] ^ 1) + (size_t)ri * REC_FLOATS;  // write the NON-applied buffer
     const int state = Rs.state[ri];
     const float oldEnergy = Rs.energy[ri];
     Rs.newEnergyWO[ri] = -1.0f;
@@ -637,7 +641,7 @@ __device__ __forceinline__ void baLinearizeBody1(const BAWindow& W, const BAPoin
         int ngood = 0;
         for (int rq = r0; rq < r1; rq++) {
           if (Rs.active[rq] == 0) continue;   // the eight-lane form subtracts +0.0f for it
-          const float* __restrict__ jp = Rs.rec[Rs.which[rq]] + (size_t)rq * REC_FLOATS + REC_JPJD;
+          const float* __restrict__ jp = baRec(Rs, Rs.which[rq]) + (size_t)rq * REC_FLOATS + REC_JPJD;
           const float* __restrict__ xa = XxAd + (size_t)(hi * W.F + Rs.target[rq]) * 8;
           float d = 0;
 #pragma unroll
@@ -933,7 +937,7 @@ __device__ __forceinline__ void baPointSumsBody(const BAWindow& W, const BAPoint
       Rs.energy[ri] = Rs.newEnergy[ri];
     }
     const bool good = mine && isAct != 0, act = good && !isLin;
-    const float* __restrict__ rec = Rs.rec[wh] + (size_t)ri * REC_FLOATS;
+    const float* __restrict__ rec = baRec(Rs, wh) + (size_t)ri * REC_FLOATS;
     const float v0 = act ? rec[REC_BD] : 0.0f, v1 = act ? rec[REC_HDD] : 0.0f;
     const float h0 = act ? rec[REC_HCD + 0] : 0.0f, h1 = act ? rec[REC_HCD + 1] : 0.0f, h2 = act ? rec[REC_HCD + 2] : 0.0f, h3 = act ? rec[REC_HCD + 3] : 0.0f;
     bd = seqAdd8(bd, v0); Hdd = seqAdd8(Hdd, v1);
@@ -992,7 +996,7 @@ __global__ void __launch_bounds__(256) k_ba_fix_linearization(const BAWindow W, 
     if (res_toZeroF) res_toZeroF[(size_t)ri * 8 + i] = rtz;
     JIr0 += rtz * J[30 + i]; JIr1 += rtz * J[38 + i]; Jar0 += rtz * J[46 + i]; Jar1 += rtz * J[54 + i]; rr += rtz * rtz;
   }
-  const float* __restrict__ src = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
+  const float* __restrict__ src = baRec(Rs, Rs.which[ri]) + (size_t)ri * REC_FLOATS;
   float* __restrict__ dst = margRec + (size_t)ri * REC_FLOATS;
   for (int k = 0; k < REC_FLOATS; k++) dst[k] = src[k];
   dst[REC_JI_R + 0] = JIr0; dst[REC_JI_R + 1] = JIr1; dst[REC_JAB_R + 0] = Jar0; dst[REC_JAB_R + 1] = Jar1; dst[REC_RR] = rr;
@@ -1063,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_ba_lin_fix(const BAWindow W, const BAPo
     rtz = rtz - J[46 + i] * dp[6]; rtz = rtz - J[54 + i] * dp[7];
     res_toZeroF[(size_t)ri * 8 + i] = rtz;
   }
-  const float* __restrict__ src = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS;
+  const float* __restrict__ src = baRec(Rs, Rs.which[ri]) + (size_t)ri * REC_FLOATS;
   float* __restrict__ dst = linRec + (size_t)ri * REC_FLOATS;
   for (int k = 0; k < REC_FLOATS; k++) dst[k] = src[k];
   lin[ri] = 1;
@@ -1336,7 +1340,7 @@ __device__ __forceinline__ HTMeta htLoadMeta(const BARes& Rs, const int ri) {
   return m;
 }
 __device__ __forceinline__ void htLoadRec(const BARes& Rs, const BAPoints& P, const int ri, const HTMeta m, const int part, HTFetch& f) {
-  const float* __restrict__ rec = Rs.rec[m.which] + (size_t)ri * REC_FLOATS;
+  const float* __restrict__ rec = baRec(Rs, m.which) + (size_t)ri * REC_FLOATS;
 #pragma unroll
   for (int k = 0; k < 12; k++) f.r[k] = rec[part + 4 * k];   // part + 44 <= 47 < REC_FLOATS: in bounds, columns >= 45 are not staged
   f.hc = P.Hcd[4 * m.pi + part] + 0.0f;
@@ -1433,8 +1437,8 @@ __device__ __forceinline__ void accumScDWave(float* __restrict__ s_buf, const in
   SCDMeta me1 = scdLoadMeta(Rs, P, a1[0], a1[1], a1[2]), me2 = scdLoadMeta(Rs, P, a2[0], a2[1], a2[2]);
   float q1[8], q2[8];
   auto ldRec = [&](const int* a, const SCDMeta& m) {
-    const float* __restrict__ p1 = Rs.rec[m.w1] + (size_t)a[0] * REC_FLOATS + REC_JPJD;
-    const float* __restrict__ p2 = Rs.rec[m.w2] + (size_t)a[1] * REC_FLOATS + REC_JPJD;
+    const float* __restrict__ p1 = baRec(Rs, m.w1) + (size_t)a[0] * REC_FLOATS + REC_JPJD;
+    const float* __restrict__ p2 = baRec(Rs, m.w2) + (size_t)a[1] * REC_FLOATS + REC_JPJD;
 #pragma unroll
     for (int k = 0; k < 8; k++) { q1[k] = p1[k]; q2[k] = p2[k]; }
   };
@@ -1916,7 +1920,7 @@ __device__ __forceinline__ void baResubstituteBody(const BAWindow& W, const BAPo
   for (int rb = r0; rb < r1; rb += 8) {
     const int ri = min(rb + q, r1 - 1);
     const bool act = rb + q < r1 && Rs.active[ri] != 0;
-    const float* __restrict__ jp = Rs.rec[Rs.which[ri]] + (size_t)ri * REC_FLOATS + REC_JPJD;
+    const float* __restrict__ jp = baRec(Rs, Rs.which[ri]) + (size_t)ri * REC_FLOATS + REC_JPJD;
     const float* __restrict__ xa = xAd + (size_t)(hi * W.F + Rs.target[ri]) * 8;
     float d = 0;
 #pragma unroll

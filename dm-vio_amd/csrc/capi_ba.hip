@@ -2119,6 +2119,7 @@ struct dmvio_hip_ba_batch {
   double* h_trace = nullptr;       // pinned: cap x (256 + NMAX) doubles
   size_t tab_stride = 0, out_stride = 0;
   int exact_backsub = 0;
+  double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host clock of the last call's phases (dmvio_hip_ba_batch_last_host_us)
   float last_ms[3] = {0, 0, 0};    // HIP-event times of the last call: the loop (init chain + iterations), the final fix-linearisation, [profile] one stepped linearisation
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // a batch of >= 4 windows is cut into groups (three by default, at most BA_BATCH_STREAMS), one stream each, their launches interleaved stage by stage (optimizeBatchGroup): while one group's
@@ -2273,6 +2274,8 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   if (F < 4) mnumOptIts = 15;
   if (mnumOptIts < 1) return failmsg("ba_optimize_batch: mnumOptIts < 1 (the device-resident loop writes the trace's first row in its first solve)");
   hipStream_t s = B->stream;
+  const auto t_call = std::chrono::steady_clock::now();
+  auto stamp = [&](const int k) { B->host_us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(); };
   struct StreamSwap {   // the handles' own entry points (table uploads, the reset kernel) enqueue on the batch's stream for the duration of the call
     std::vector<std::pair<dmvio_hip_ba*, hipStream_t>> saved;
     ~StreamSwap() { for (auto& kv : saved) kv.first->stream = kv.second; }
@@ -2362,7 +2365,9 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     V.sysL = S.x_last + BA_BATCH_NMAX;
     return 0;
   };
+  stamp(0);
   if (int r = B->workers.parallelFor(Wn, prepare)) return r;
+  stamp(1);
   HIPCHK(hipGetLastError());
   const size_t used_tab = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float) + (size_t)F2 * sizeof(BAPrecalc);
   if (used_tab > B->tab_stride) return failmsg("ba_optimize_batch: table slab too small");
@@ -2463,7 +2468,9 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   // [resInA | trace (64 x 4) | x_last] of every window: the tail of its system slab, one strided copy
   HIPCHK(hipMemcpy2DAsync(B->h_trace, sizeof(double) * (257 + BA_BATCH_NMAX), reinterpret_cast<const double*>(B->d_out) + tot, B->out_stride, sizeof(double) * (257 + n), Wn,
                           hipMemcpyDeviceToHost, s));
+  stamp(2);
   HIPCHK(hipStreamSynchronize(s));
+  stamp(3);
   // ---- back on the host: the optimised states, then the newest keyframe's new evaluation point (:596-603) and the final fix-linearisation (:604-609)
   const size_t tab_pre_off = ((size_t)n * n + n + 7 * (size_t)n) * sizeof(double) + 2 * (size_t)F2 * 64 * sizeof(float);
   auto writeBack = [&](const int w) -> int {
@@ -2501,6 +2508,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     return 0;
   };
   if (int r = B->workers.parallelFor(Wn, writeBack)) return r;
+  stamp(4);
   HIPCHK(hipMemcpyAsync(B->d_wins, B->h_wins, sizeof(BAWinDev) * Wn, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpy2DAsync(B->d_tab + tab_pre_off, B->tab_stride, B->h_tab + tab_pre_off, B->tab_stride, sizeof(BAPrecalc) * F2, Wn, hipMemcpyHostToDevice, s));   // the re-anchored pair tables
   HIPCHK(hipEventRecord(B->ev[2], s));
@@ -2508,7 +2516,9 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
   hipLaunchKernelGGL(k_ba_apply_b, dim3(gx_res, Wn), dim3(256), 0, s, dw, 1, (int)BA_GATE_ALWAYS);   // applyRes + linearizeAll(true)'s removal of inactive residuals
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(B->ev[3], s));
+  stamp(5);
   HIPCHK(hipStreamSynchronize(s));
+  stamp(6);
   HIPCHK(hipEventElapsedTime(&B->last_ms[0], B->ev[0], B->ev[1]));
   HIPCHK(hipEventElapsedTime(&B->last_ms[1], B->ev[2], B->ev[3]));
   B->last_ms[2] = 0;
@@ -2531,6 +2541,7 @@ static int optimizeBatchGroup(dmvio_hip_ba_batch* B, const int Wn, dmvio_hip_ba*
     b->sums_fresh = false; b->sys_ready = false;
     if (b->bounce.used || !b->bounce.outs.empty()) HIPCHK(b->bounce.finish(s));   // the staging area of this call's uploads is free again
   }
+  stamp(7);
   return 0;
 }
 
@@ -2538,6 +2549,14 @@ extern "C" {
 // windows[W]: handles of the batch's context, each with its window set (set_window + set_graph), all distinct.  rmse / finalEnergy / iterations: W entries each (may be
 // NULL); trace: W x 64 x 4 doubles or NULL ([E_A, E_L, E_M, accepted] per iteration, row 0 = the initial state).  Windows with different keyframe counts run as separate
 // groups, one after the other.  Every window's result is what a batch of that window alone gives, bit for bit (no arithmetic crosses windows).
+// Diagnostics: host clock (us since the call began) at the phase boundaries of the last dmvio_hip_ba_optimize_batch group: [0] stream hand-over done, [1] per-window tables
+// prepared, [2] whole loop enqueued, [3] loop finished (first wait), [4] states written back, [5] final linearisation enqueued, [6] finished (second wait), [7] results out
+int dmvio_hip_ba_batch_last_host_us(dmvio_hip_ba_batch* B, double us8[8]) {
+  if (!B || !us8) return failmsg("ba_batch_last_host_us: null argument");
+  std::lock_guard<std::mutex> lkB(B->mu);
+  for (int k = 0; k < 8; k++) us8[k] = B->host_us[k];
+  return 0;
+}
 int dmvio_hip_ba_optimize_batch(dmvio_hip_ba_batch* B, int W, dmvio_hip_ba* const* windows, int mnumOptIts, float* rmse, double* finalEnergy, int* iterations, double* trace) {
   if (!B || !windows || W < 1) return failmsg("ba_optimize_batch: bad argument");
   if (W > B->cap) return failmsg("ba_optimize_batch: more windows than the batch was created for");

@@ -36,10 +36,25 @@ struct FrameStore {
   // the 4x4 footprint of a bilinear tap then touches 2.4 lines on average instead of 4.3.  Only k_track_lm's tiled instantiation reads such a plane; every other
   // consumer has the slot converted back first (dmv_ensure_row_major, host side).  Every build stamps the flag of its slot.
   unsigned char* tiled0;
-  __device__ const float* level(int slot, int lvl) const { return lvl == 0 ? lvl0[slot] : base + (size_t)slot * slot_stride + level_off[lvl]; }
+  // (the table entry is read through an lvalue whose pointee carries the GLOBAL address space: a pointer loaded from memory is otherwise a generic one to the compiler and
+  // every image tap behind it a flat_load, which counts on both wait counters and ties the taps to the LDS traffic of the kernels that gather through it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wincompatible-pointer-types-discards-qualifiers"
+  __device__ const float* level(int slot, int lvl) const {
+    const float* l0 = (const float*)(*reinterpret_cast<const __attribute__((address_space(1))) float* const*>(&lvl0[slot]));
+    return lvl == 0 ? l0 : base + (size_t)slot * slot_stride + level_off[lvl];
+  }
+#pragma clang diagnostic pop
   __host__ __device__ float* own_level(int slot, int lvl) const { return base + (size_t)slot * slot_stride + level_off[lvl]; }
 };
 
+// a level's base address made wave-uniform (scalar registers) and typed as a GLOBAL pointer: an integer cast straight to `const float*` is a generic pointer, and every tap
+// through it a flat_load
+__device__ __forceinline__ const float* dmvUniformGlobal(const float* p) {
+  const unsigned long long ia = (unsigned long long)p;
+  const unsigned long long ua = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)ia);
+  return (const float*)(const __attribute__((address_space(1))) float*)ua;
+}
 // element (x, y) of a level-0 plane stored in 8x4 tiles (tpr = w / 8 tiles per tile row): float offset from the plane's base
 __host__ __device__ __forceinline__ unsigned int tiled84Offset(const int x, const int y, const int tpr) {
   return ((((unsigned int)(y >> 2) * (unsigned int)tpr) + (unsigned int)(x >> 3)) << 5) + (unsigned int)(((y & 3) << 3) + (x & 7));

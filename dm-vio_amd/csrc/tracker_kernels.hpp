@@ -487,9 +487,7 @@ __global__ void __launch_bounds__(T) k_eval_fused(const TrackerDev trk, const Fr
   initStage<T>(s_stage);
   const int lvl = e.lvl;
   const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
-  const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
-  const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
-                                    (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+  const float* img = dmvUniformGlobal(fs.level(slot, lvl));
   if (clean)
     blockEval<T, false>(e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH,
                         s_stage, s_partH, s_partS, s_tot);
@@ -570,9 +568,7 @@ __global__ void __launch_bounds__(T) k_eval_server(const TrackerDev trk, const F
     const long long q_seen = wall_clock64();
 #endif
     const int lvl = s_e.lvl;
-    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
-    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
-                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+    const float* img = dmvUniformGlobal(fs.level(slot, lvl));
     if (clean)
       blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, blockIdx.x * T + threadIdx.x, gridDim.x * T, img, trk.huberTH, s_stage, s_partH, s_partS,
                           s_tot);
@@ -1054,9 +1050,7 @@ __global__ void __launch_bounds__(T, W) k_track_lm(const TrackerDev trk, const F
     if (!s_go) break;
     const int lvl = s_e.lvl;
     // the plane's address is wave-uniform (level 0 comes out of the pointer table): keep it in scalar registers
-    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
-    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
-                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+    const float* img = dmvUniformGlobal(fs.level(slot, lvl));
     if (TL && tiled0 && lvl == 0) {   // workgroup-uniform
       if (clean)
         blockEval<T, false, TL>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, rank * T + threadIdx.x, cl.C * T, img, trk.huberTH, s_stage, s_partH, s_partS,
@@ -1177,9 +1171,7 @@ __global__ void __launch_bounds__(256, 4) k_track_lm_pp(const TrackerDev trk, co
       const int slot = s_in[X].new_slot;
       const int lvl = s_e[X].lvl;
       const bool clean = __builtin_amdgcn_readfirstlane((int)(fs.bad_gen[slot] != fs.build_gen[slot])) != 0;
-      const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
-      const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
-                                        (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+      const float* img = dmvUniformGlobal(fs.level(slot, lvl));
       // the split of this level's points: of every `period` chunks of 64 wave 0 takes k0 (it also runs a control step of ~C per round), waves 1-3 three each;
       // balanced where k0 / period = 1/4 - 3 C / (16 E): large levels 2 of 11, middle ones 1 of 10, small ones none
       const int npt = trk.pc_n[lvl];
@@ -1216,9 +1208,7 @@ __global__ void __launch_bounds__(T, W) k_track_replay(const TrackerDev trk, con
     if (threadIdx.x < sizeof(EvalP) / 4) reinterpret_cast<unsigned int*>(&s_e)[threadIdx.x] = reinterpret_cast<const unsigned int*>(log + (size_t)prob * LM_LOG_EVALS + k)[threadIdx.x];
     __syncthreads();
     const int lvl = s_e.lvl;
-    const unsigned long long ia = (unsigned long long)fs.level(slot, lvl);
-    const float* img = (const float*)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(ia >> 32)) << 32) |
-                                      (unsigned int)__builtin_amdgcn_readfirstlane((int)ia));
+    const float* img = dmvUniformGlobal(fs.level(slot, lvl));
     if (clean) blockEval<T, false>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot);
     else blockEval<T, true>(s_e, trk.g[lvl], trk.pc[lvl], trk.pc_n[lvl], trk.flow_mask, threadIdx.x, T, img, trk.huberTH, s_stage, s_partH, s_partS, s_tot);
     __syncthreads();

@@ -568,6 +568,9 @@ int dmvio_hip_ba_batch_last_solve_ticks(dmvio_hip_ba_batch* batch, int ticks12[1
 /* diagnostics: how window w's last k_ba_solve of the last call found Eigen's pivot order (EnergyFunctional.cpp:971-973, ldlt()): 0 = ranks of the scaled diagonal (all
  * |values| distinct), 1 = ties replayed (selection with swaps), 2 = NaN on the diagonal (the literal loop) */
 int dmvio_hip_ba_batch_last_pivot_branch(dmvio_hip_ba_batch* batch, int w, int* branch);
+/* Diagnostics: host clock (us since the call began) at the phase boundaries of the last call's (last group's) loop: [0] streams handed over, [1] per-window tables prepared,
+ * [2] whole loop enqueued, [3] loop finished (first wait), [4] states written back, [5] final linearisation enqueued, [6] finished (second wait), [7] results out */
+int dmvio_hip_ba_batch_last_host_us(struct dmvio_hip_ba_batch* batch, double us8[8]);
 /* Tests / diagnostics: the solve of EnergyFunctional.cpp:971-973 (diagonal pre-scaling, pivoted LDL^T) for a GIVEN n x n system on the device, exactly as the device-resident
  * loop's k_ba_solve runs it — the device counterpart of dmvio_hip_ba_solve_ldlt.  HPassed row-major (lower triangle read), 2 <= n <= 100.  perm_out[n]: the index the
  * transpositions bring to position k; branch_out: as dmvio_hip_ba_batch_last_pivot_branch; zero_out: the first pivot was zero (x = 0).  The three may be NULL. */

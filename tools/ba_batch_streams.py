@@ -27,7 +27,7 @@ for single in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else
             dev.append(B.last_ms())
         acc = sum(int(r["trace"][1:, 3].sum()) for r in rs)
         w = np.median(walls[1:]); d = np.median([x[0] + x[1] for x in dev[1:]])
-        print("streams=%d W=%3d: wall %.3f ms, device %.3f ms -> %.1f it/s" % (single, W, 1e3 * w, d, acc / w), flush=True)
+        print("streams=%d W=%3d: wall %.3f ms, device %.3f ms -> %.1f it/s   host phases (us) %s" % (single, W, 1e3 * w, d, acc / w, [round(x) for x in B.last_host_us()]), flush=True)
 fl = B.L.dmvio_hip_ba_batch_set_linearize_lanes; fl.argtypes = [C.c_void_p, C.c_int]; fl.restype = C.c_int
 Rn = len(case["res_point"])
 for lanes in (8, 1):
