@@ -1340,9 +1340,12 @@ __device__ __forceinline__ HTMeta htLoadMeta(const BARes& Rs, const int ri) {
   return m;
 }
 __device__ __forceinline__ void htLoadRec(const BARes& Rs, const BAPoints& P, const int ri, const HTMeta m, const int part, HTFetch& f) {
-  const float* __restrict__ rec = baRec(Rs, m.which) + (size_t)ri * REC_FLOATS;
+  // three 16-byte loads per lane (floats [16 k + 4 part, + 4), k = 0..2: columns 0..47 of the record; the 208-byte records are 16-byte aligned) — the four lanes of a member
+  // read 64 contiguous bytes per instruction.  Twelve 4-byte loads per lane (column part + 4 k) cost four times the instructions and vector-L1 tag look-ups for the same
+  // lines, and the look-ups are what bounds this kernel (profiles/r06_counters_ba.md)
+  const float4* __restrict__ rec4 = reinterpret_cast<const float4*>(baRec(Rs, m.which) + (size_t)ri * REC_FLOATS) + part;
 #pragma unroll
-  for (int k = 0; k < 12; k++) f.r[k] = rec[part + 4 * k];   // part + 44 <= 47 < REC_FLOATS: in bounds, columns >= 45 are not staged
+  for (int k = 0; k < 3; k++) { const float4 q = rec4[4 * k]; f.r[4 * k] = q.x; f.r[4 * k + 1] = q.y; f.r[4 * k + 2] = q.z; f.r[4 * k + 3] = q.w; }   // columns >= 45 are loaded, not staged
   f.hc = P.Hcd[4 * m.pi + part] + 0.0f;
   f.hdi = P.HdiF[m.pi];
   f.bds = P.bdSumF[m.pi];
@@ -1378,7 +1381,7 @@ __device__ __forceinline__ void accumHTBlock(float* __restrict__ s_buf, const in
     {
       const bool act = base + j < m1 && me1.act;
 #pragma unroll
-      for (int k = 0; k < 12; k++) { const int idx = part + 4 * k; if (idx < 45) s_rec[j][idx] = act ? pf.r[k] : 0.0f; }
+      for (int k = 0; k < 12; k++) { const int idx = 16 * (k >> 2) + 4 * part + (k & 3); if (idx < 45) s_rec[j][idx] = act ? pf.r[k] : 0.0f; }
       s_rec[j][45 + part] = act ? pf.hc : 0.0f;
       if (part == 0) { s_rec[j][49] = act ? pf.hdi : 0.0f; s_rec[j][50] = act ? pf.hdi * pf.bds : 0.0f; s_rec[j][51] = act ? 1.0f : 0.0f; }
     }
@@ -1409,6 +1412,7 @@ __device__ __forceinline__ void accumHTBlock(float* __restrict__ s_buf, const in
 // ------------------------------------------------------------------------------------------------ Schur accumulation
 // accD[h,t1,t2] (8x8) += (HdiF * JpJd(r1)) JpJd(r2)^T : one WAVEFRONT per bucket (four buckets per workgroup), lane (i,j) owns
 // element (i,j); member = (r1, r2, point).  Same three-deep staging pipeline, wave-level synchronisation only.
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte access at a 4-byte boundary
 #define SCD_STRIDE 19   // [0,8) HdiF-side JpJd(r1), [8,16) JpJd(r2), 16 HdiF, 17 active flag
 struct SCDMeta { int act, w1, w2; float hdi; };
 __device__ __forceinline__ SCDMeta scdLoadMeta(const BARes& Rs, const BAPoints& P, const int r1, const int r2, const int pi) {
@@ -1439,8 +1443,11 @@ __device__ __forceinline__ void accumScDWave(float* __restrict__ s_buf, const in
   auto ldRec = [&](const int* a, const SCDMeta& m) {
     const float* __restrict__ p1 = baRec(Rs, m.w1) + (size_t)a[0] * REC_FLOATS + REC_JPJD;
     const float* __restrict__ p2 = baRec(Rs, m.w2) + (size_t)a[1] * REC_FLOATS + REC_JPJD;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { q1[k] = p1[k]; q2[k] = p2[k]; }
+    // (JpJdF sits at float 37 of the record: 4-byte aligned only; global memory takes 16-byte accesses at any 4-byte boundary)
+    const float4u a0 = *reinterpret_cast<const float4u*>(p1), a1_ = *reinterpret_cast<const float4u*>(p1 + 4);
+    const float4u b0 = *reinterpret_cast<const float4u*>(p2), b1_ = *reinterpret_cast<const float4u*>(p2 + 4);
+    q1[0] = a0.x; q1[1] = a0.y; q1[2] = a0.z; q1[3] = a0.w; q1[4] = a1_.x; q1[5] = a1_.y; q1[6] = a1_.z; q1[7] = a1_.w;
+    q2[0] = b0.x; q2[1] = b0.y; q2[2] = b0.z; q2[3] = b0.w; q2[4] = b1_.x; q2[5] = b1_.y; q2[6] = b1_.z; q2[7] = b1_.w;
   };
   ldRec(a1, me1);
   for (int base = m0; base < m1; base += 64) {
