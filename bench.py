@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--build-overlap-leg", action="store_true", help="measure that variant AFTER the timed region (same K steps) and report it beside the headline "
                                                                       "(pipeline.ms_per_step_build_on_its_own_stream); off by default: its launches would otherwise sit in the same "
                                                                       "rows of a rocprofv3 kernel summary as the timed region's, stretched by the concurrency")
+    ap.add_argument("--template-order", type=int, default=-1, help="measurement: storage order of the tracker's template (0 tiles, 1 row-major; -1 = the library's default)")
+    ap.add_argument("--batch-kernel", type=int, default=-1, help="measurement: dmvio_hip_tracker_set_batch_kernel (-1 = the library's default)")
     ap.add_argument("--no-ba", action="store_true", help="skip the bundle-adjustment leg (BA GN-iterations/s)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop_in leg (the reference's own FullSystem all-CPU vs with its hot-path members on libdmvio_hip.so)")
     ap.add_argument("--dropin-frames", type=int, default=100)
@@ -159,6 +161,10 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     trk = pkg.CoarseTrackerHip(ctx)
+    if args.template_order >= 0:
+        trk.set_template_order(args.template_order)
+    if args.batch_kernel >= 0:
+        trk.set_batch_kernel(args.batch_kernel)
     trk.makeK(case["K4"])
     ctx.frame_upload(0, case["ref_img"])
     trk.setCoarseTrackingRef(0, case["u"], case["v"], case["idepth"], case["hdiF"])

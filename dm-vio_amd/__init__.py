@@ -409,6 +409,16 @@ class CoarseTrackerHip:
         fn = self.L.dmvio_hip_tracker_set_launch_shape; fn.argtypes = [C.c_void_p] + [C.c_int] * 4; fn.restype = C.c_int
         _chk(self.L, fn(self.p, int(eval_blocks), int(lm_threads), int(lm_waves), int(lm_cluster)), "tracker_set_launch_shape")
 
+    def set_batch_kernel(self, mode):
+        """0 = four wavefronts per problem (default), 1 = two problems per workgroup (dmvio_hip_tracker_set_batch_kernel)"""
+        fn = self.L.dmvio_hip_tracker_set_batch_kernel; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, int(mode)), "tracker_set_batch_kernel")
+
+    def set_template_order(self, row_major):
+        """storage order of the template from the next setCoarseTrackingRef on (dmvio_hip_tracker_set_template_order)"""
+        fn = self.L.dmvio_hip_tracker_set_template_order; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+        _chk(self.L, fn(self.p, 1 if row_major else 0), "tracker_set_template_order")
+
     def set_eval_server(self, on=True):
         fn = self.L.dmvio_hip_tracker_set_eval_server; fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
         _chk(self.L, fn(self.p, 1 if on else 0), "tracker_set_eval_server")
