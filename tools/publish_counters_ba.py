@@ -75,7 +75,7 @@ out += ["What the counters said and what was done about it.  The kernel was NOT 
         "lane against 64 different images', which only a residual order sorted by (target, image tile) would change — that order is the graph's (residuals of a point contiguous: the per-point",
         "sums and the Schur member lists are built on it).", ""]
 out += ["## `k_ba_accumulate_b` (50 176 workgroups per 64-window launch: per window 16 calibration + 256 (host, target) + 512 Schur workgroups, one wavefront per bucket part)", ""]
-out += section("k_ba_accumulate_b", CB, "at HEAD (the kernel did not change this round)", 4)
+out += section("k_ba_accumulate_b", CB, "at HEAD (round 6: global instead of flat loads, 16-byte staging loads of the records)", 4)
 c = CB["k_ba_accumulate_b"]
 out += ["The same picture, more so: the vector L1 is busy %.0f %% of the time with %.0f M tag look-ups (%.1f per vector-memory instruction: the members of a bucket are gathered one per lane — 2 x 32 bytes"
         % (100 * c["TCP_GATE_EN2_sum"] / c["TCP_GATE_EN1_sum"], c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 1e6, c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"]),
