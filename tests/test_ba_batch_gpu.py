@@ -227,3 +227,28 @@ def test_device_loop_with_a_marginalisation_prior_and_fej_deltas(pkg, synth, gpu
     for o in [host, dev, B1, B4] + single + batch:
         o.close()
     ctx.close()
+
+
+def test_jacobians_of_an_earlier_host_loop_are_not_taken_for_the_batched_loops(pkg, synth, gpu_required):
+    """The batched / device-resident loop relinearises and applies every residual WITHOUT writing the 74-float Jacobians (dmvio_hip_ba_keep_jacobians): after it the buffer still
+    holds what an earlier host-driven optimize left there, for another state.  dmvio_hip_ba_fix_linearization (EFResidual::fixLinearizationF needs the Jacobian of the APPLIED
+    linearisation) must refuse then instead of freezing stale rows — and serve again once a host-driven linearisation + apply has refreshed them."""
+    case = synth.ba_case(256, 192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
+    F = case["n_frames"]; R = len(case["res_point"])
+    ctx = _ctx_with(pkg, case)
+    mask = (np.arange(R) % 3 == 0).astype(np.uint8)
+    ba = pkg.BundleAdjusterHip(ctx, accumulators=1, keep_jacobians=True)
+    ba.set_case(case, list(range(F)))
+    ba.optimize(2)                                            # host-driven: the Jacobians of its last applied linearisation are resident
+    B = pkg.BundleAdjusterBatch(ctx, 1)
+    B.optimize([ba], 2)                                       # the batched loop moves the window on; the buffer is not rewritten
+    with pytest.raises(pkg.HipLibraryError, match="not resident"):
+        ba.fix_linearization(mask)
+    ba.set_device_loop(True)
+    ba.optimize(1)                                            # the same loop behind dmvio_hip_ba_optimize
+    with pytest.raises(pkg.HipLibraryError, match="not resident"):
+        ba.fix_linearization(mask)
+    ba.set_device_loop(False)
+    ba.activate_all(); ba.linearize_all(False); ba.apply_res()   # host-driven linearisation + applyRes: resident again
+    assert ba.fix_linearization(mask) > 0
+    ba.close(); B.close()
