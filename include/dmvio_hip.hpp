@@ -208,6 +208,12 @@ class WindowGraph {
   bool dropResidual(int host, int idxInPoints, int idxInAll) { return g_ && dmvio_hip_graph_drop_residual(g_, host, idxInPoints, idxInAll) == 0; }
   bool setIdepth(int host, int idxInPoints, float idepth) { return g_ && dmvio_hip_graph_set_idepth(g_, host, idxInPoints, idepth) == 0; }
   bool setIdepths(const std::vector<float>& idepth) { return g_ && dmvio_hip_graph_set_idepths(g_, (int)idepth.size(), idepth.data()) == 0; }   /* makeIDX order */
+  /* EFResidual::fixLinearizationF's result of one residual (isLinearized = true with its 74-float RawResidualJacobian and res_toZeroF), or isLinearized = false again
+   * (J74 == nullptr): the record follows the residual through dropResidual / removePoint and WindowOptimizer::setGraphFrom hands it over */
+  bool setResidualLinearized(int host, int idxInPoints, int idxInAll, const float* J74, const float* resToZeroF8) {
+    return g_ && dmvio_hip_graph_set_residual_linearized(g_, host, idxInPoints, idxInAll, J74, resToZeroF8) == 0;
+  }
+  int nLinearized() const { return g_ ? dmvio_hip_graph_linearized_count(g_) : -1; }
   int nFrames() const { int F = 0; return g_ && dmvio_hip_graph_counts(g_, &F, nullptr, nullptr) == 0 ? F : -1; }
   int nPoints() const { int N = 0; return g_ && dmvio_hip_graph_counts(g_, nullptr, &N, nullptr) == 0 ? N : -1; }
   int nResiduals() const { int R = 0; return g_ && dmvio_hip_graph_counts(g_, nullptr, nullptr, &R) == 0 ? R : -1; }
@@ -301,6 +307,19 @@ class WindowOptimizer {
     int n = -1;
     if (!ba_ || dmvio_hip_ba_fix_linearization(ba_, (int)residualMask.size(), residualMask.data(), &n) != 0) return -1;
     return n;
+  }
+  /* residuals that ARRIVE linearised with a flat graph (right after setGraph): flags, 74-float Jacobians and res_toZeroF per residual, graph order; and what the window holds,
+   * to be handed to the next one.  Returns the number of linearised residuals, -1 on error. */
+  int setLinearizedResiduals(const std::vector<unsigned char>& isLinearized, const std::vector<float>& J74, const std::vector<float>& resToZeroF8) {
+    int n = -1;
+    const size_t R = isLinearized.size();
+    if (!ba_ || J74.size() != 74 * R || resToZeroF8.size() != 8 * R) return -1;
+    if (dmvio_hip_ba_set_linearized_residuals(ba_, (int)R, isLinearized.data(), J74.data(), resToZeroF8.data(), &n) != 0) return -1;
+    return n;
+  }
+  bool linearizedResiduals(int R, std::vector<unsigned char>& isLinearized, std::vector<float>& J74, std::vector<float>& resToZeroF8) const {
+    isLinearized.resize(R); J74.resize(74 * (size_t)R); resToZeroF8.resize(8 * (size_t)R);
+    return ba_ && dmvio_hip_ba_get_linearized_residuals(ba_, R, isLinearized.data(), J74.data(), resToZeroF8.data()) == 0;
   }
   bool keepJacobians(bool on) { return ba_ && dmvio_hip_ba_keep_jacobians(ba_, on ? 1 : 0) == 0; }
   dmvio_hip_ba* handle() const { return ba_; }
