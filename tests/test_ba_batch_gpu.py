@@ -126,6 +126,15 @@ def test_batched_windows_equal_single_window_calls_bitwise(pkg, synth, gpu_requi
         assert np.array_equal(single[i].point_state()[0], batch[i].point_state()[0]), i
         n_rej += int((rb[i]["trace"][1:, 3] == 0).sum())
     assert n_rej >= 1, "no rejected step in the batch: the gated restore path was not exercised"
+    # diagnostics of the call: how every window's last solve found Eigen's pivot order (0 = ranks of a distinct diagonal, 1 = the parallel tie replay — the usual case in a real
+    # window: the prior-dominated diagonal entries tie — never 2, the NaN rule; the three branches themselves are pinned by tests/test_ba_solve_gpu.py), the in-kernel stamps of
+    # a solve and the host clock at the call's phase boundaries
+    branches = [B5.last_pivot_branch(i) for i in range(3)]           # (the last group of the call: the three windows of six keyframes)
+    assert all(b in (0, 1) for b in branches), branches
+    ticks = B5.last_solve_ticks()
+    assert len(ticks) >= 12 and ticks[0] > 0 and 0 < ticks[5] <= ticks[10] < 1000, ticks       # microseconds since the kernel began: a solve takes < 1 ms
+    hu = B5.last_host_us()
+    assert len(hu) == 8 and all(hu[k] <= hu[k + 1] for k in range(7)) and 0 < hu[7] < 1e6, hu
     print("batch of 5 windows (F = 6, 6, 4, 6, 4) == 5 single calls bit for bit; %d rejected steps among them; loop %.3f ms, final linearisation %.3f ms" % ((n_rej,) + B5.last_ms()[:2]))
     for o in single + batch + [B1, B5]:
         o.close()
