@@ -812,3 +812,43 @@ def test_host_solver_equals_the_oracle_bitwise(pkg, oracle, synth, gpu_required)
             # the library keeps unit singular vectors, the oracle scales by the singular values; same projector, rounding apart
             assert np.abs(xg - xo).max() <= 1e-14 * np.abs(xo).max(), (it, lam, worst)
     ba.close()
+
+
+def test_linearised_residuals_in_a_window_of_ten_keyframes_on_every_loop(pkg, synth, gpu_required):
+    """Residuals kept linearised in a window of MORE than eight keyframes (the wide instantiations: k_ba_solve<12>, the 8-member Schur tiles of the stitch, 100 ticket slots):
+    the device-resident loop and a batch of two such windows against the host-driven loop on the same graph — the accept sequence, E_A / E_L / E_M of every iteration and the
+    final states (the loops differ in the elementary functions of the frame step: rounding level)."""
+    F = 10
+    share = tuple([120, 110, 100, 90, 80, 70, 60, 50, 40, 0])
+    case = synth.ba_case(320, 256, n_frames=F, n_points=720, seed=77, hosts_share=share, step_t=0.05, step_r=np.deg2rad(1.0))
+    R = len(case["res_point"])
+    mask = (np.arange(R) % 4 == 1).astype(np.uint8)
+    ctx = pkg.Context(case["w"], case["h"], n_slots=F)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+
+    def window():
+        ba = pkg.BundleAdjusterHip(ctx, accumulators=1, keep_jacobians=True); ba.set_case(case, list(range(F)))
+        ba.optimize(2)
+        n = ba.fix_linearization(mask)
+        assert 0.15 * R < n <= (R + 3) // 4
+        return ba, n
+    host, n_lin = window()
+    r_h = host.optimize(4)
+    assert np.abs(r_h["trace"][:5, 1]).min() > 0            # E_L carries the linearised term
+    dev, _ = window(); dev.set_device_loop(True)
+    r_d = dev.optimize(4)
+    b0, _ = window(); b1, _ = window()
+    B = pkg.BundleAdjusterBatch(ctx, 2)
+    r_b = B.optimize([b0, b1], 4)
+    assert np.array_equal(r_b[0]["trace"], r_d["trace"]) and np.array_equal(r_b[1]["trace"], r_d["trace"])      # the batch is the device loop, bit for bit
+    for r in (r_d,):
+        assert r["iterations"] == r_h["iterations"] and np.array_equal(r["trace"][:, 3], r_h["trace"][:, 3])
+        assert np.allclose(r["trace"][:5, :3], r_h["trace"][:5, :3], rtol=1e-6, atol=1e-9)
+    for k in range(F):
+        assert np.linalg.norm(dev.frame_pose(k)[0][:3] - host.frame_pose(k)[0][:3]) < 1e-6
+        assert np.array_equal(b0.frame_pose(k)[0], dev.frame_pose(k)[0])
+    assert np.abs(dev.point_state()[0] - host.point_state()[0]).max() < 1e-5
+    for o in (host, dev, b0, b1, B):
+        o.close()
+    ctx.close()
