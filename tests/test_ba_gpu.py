@@ -852,3 +852,38 @@ def test_linearised_residuals_in_a_window_of_ten_keyframes_on_every_loop(pkg, sy
     for o in (host, dev, b0, b1, B):
         o.close()
     ctx.close()
+
+
+def test_marginalising_points_whose_residuals_arrived_linearised(pkg, synth, gpu_required):
+    """FullSystem::flagPointsForRemoval relinearises the residuals of the points it marginalises with isLinearized = false (FullSystem.cpp:840-843) — also when they were kept
+    linearised before.  A window that RECEIVED its linearised residuals (dmvio_hip_ba_set_linearized_residuals) must go through dmvio_hip_ba_marginalize_points exactly like the
+    window they were linearised on: the decisions, the prior increment and the flags that are left, bit for bit."""
+    case = synth.ba_case(256, 192, n_frames=5, n_points=300, hosts_share=(90, 80, 70, 60, 0), seed=5)
+    R = len(case["res_point"]); F = case["n_frames"]; N = len(case["u"])
+    mask = (np.arange(R) % 3 == 0).astype(np.uint8)
+    ctx = pkg.Context(case["w"], case["h"], n_slots=F)
+    for k in range(F):
+        ctx.frame_upload(k, case["imgs"][k])
+
+    def standing(keep):
+        ba = pkg.BundleAdjusterHip(ctx, accumulators=1, keep_jacobians=keep); ba.set_case(case, list(range(F)))
+        ba.optimize(3)
+        return ba
+    A = standing(True)
+    n_lin = A.fix_linearization(mask)
+    fl, J, rtz = A.linearized_residuals()
+    B = standing(True)
+    assert B.set_linearized_residuals(fl, J, rtz) == n_lin
+    cand = np.zeros(N, np.uint8); cand[::3] = 1
+    dA, HA, bA, rA = A.marginalize_points(cand)
+    dB, HB, bB, rB = B.marginalize_points(cand)
+    assert np.array_equal(dA, dB) and rA == rB and rA > 0
+    assert np.array_equal(HA, HB) and np.array_equal(bA, bB) and np.abs(HA).max() > 0
+    zero = np.zeros(R, np.uint8)
+    left = A.fix_linearization(zero)
+    assert left == B.fix_linearization(zero) and 0 < left < n_lin          # the marginalised points' residuals lost the flag, the others kept it
+    fa, fb = A.linearized_residuals()[0], B.linearized_residuals()[0]
+    assert np.array_equal(fa, fb) and not fa[cand[case["res_point"]] == 1].any()
+    for o in (A, B):
+        o.close()
+    ctx.close()
