@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
-def run_window(P, case, slots_case, comm_setup=None, its=6, lin_mask=None):
+def run_window(P, case, slots_case, comm_setup=None, its=6, lin_mask=None, lin_rows=None):
     F = case["n_frames"]
     ctx = P.Context(case["w"], case["h"], n_slots=F)
     for k in range(F):
@@ -27,13 +27,20 @@ def run_window(P, case, slots_case, comm_setup=None, its=6, lin_mask=None):
         # EFResidual::fixLinearizationF after two iterations, on the states they left (a collective: every rank passes the flags of its own residuals) — the remaining
         # iterations run over a graph whose L system, linearised energy and A / Schur views are each the sum of the ranks' parts
         first = ba.optimize(2)
-        n_lin = ba.fix_linearization(lin_mask)
+        if lin_rows is None:
+            n_lin = ba.fix_linearization(lin_mask)
+        else:
+            # the same residuals handed over with their frozen Jacobians / res_toZeroF (dmvio_hip_ba_set_linearized_residuals: collective on a sharded window as well)
+            n_lin = ba.set_linearized_residuals(lin_rows[0], lin_rows[1], lin_rows[2])
+            assert n_lin == int(lin_rows[0].sum())
         assert 0 < n_lin <= int(lin_mask.sum())
+        out_rows = ba.linearized_residuals()
         out = ba.optimize(its)
         out["trace"] = np.concatenate([first["trace"], out["trace"]])
         out["iterations"] += first["iterations"]
         out["EL"] = ba.energy_terms()[0]
         out["n_lin"] = n_lin
+        out["rows"] = out_rows
     else:
         out = ba.optimize(its)
     poses = np.stack([ba.frame_pose(k)[0] for k in range(F)])
@@ -63,7 +70,14 @@ def main():
             member = np.zeros(len(case["u"]), dtype=bool); member[np.asarray(parts[rank])] = True
             my_mask = np.ascontiguousarray(full_mask[member[case["res_point"]]])      # shard_case keeps a point's residuals in their order
             assert len(my_mask) == len(mine["res_point"])
-        out, poses, aff, idepth = run_window(P, mine, case, lambda ba: ba.set_comm_torch(dist), its=4 if lin else 6, lin_mask=my_mask)
+        my_rows = None
+        if os.environ.get("SHARD_LIN") == "import":
+            # the rows come from an unsharded window at (to rounding) the same state; every rank takes those of its own residuals
+            pre, _, _, _ = run_window(P, case, case, its=1, lin_mask=full_mask)
+            keep = member[case["res_point"]]
+            my_rows = tuple(np.ascontiguousarray(x[keep]) for x in pre["rows"])
+            full_rows = pre["rows"]
+        out, poses, aff, idepth = run_window(P, mine, case, lambda ba: ba.set_comm_torch(dist), its=4 if lin else 6, lin_mask=my_mask, lin_rows=my_rows)
         # every rank took the same decisions and holds the same frame states, bit for bit
         blob = torch.from_numpy(np.concatenate([out["trace"].ravel(), poses.ravel(), aff.ravel(), [out["rmse"], out["finalEnergy"], out.get("EL", 0.0)]]).copy())
         allb = [torch.zeros_like(blob) for _ in range(world)]
@@ -73,7 +87,7 @@ def main():
         if os.environ.get("SHARD_DEBUG") and rank == 0:
             print("sharded trace", mode, "\n", out["trace"], flush=True)
         if rank == 0 and not os.environ.get("SHARD_NOFULL"):
-            full, fposes, faff, fid = run_window(P, case, case, its=4 if lin else 6, lin_mask=full_mask)
+            full, fposes, faff, fid = run_window(P, case, case, its=4 if lin else 6, lin_mask=full_mask, lin_rows=full_rows if os.environ.get("SHARD_LIN") == "import" else None)
             if lin:
                 assert abs(out["EL"] - full["EL"]) <= 1e-4 * max(1.0, abs(full["EL"])), (out["EL"], full["EL"])
             if os.environ.get("SHARD_DEBUG"):

@@ -74,7 +74,7 @@ def test_set_comm_validates_rank_and_world(pkg, synth, gpu_required):
         ba.close(); comm.close()
 
 
-@pytest.mark.parametrize("lin", [False, True], ids=["plain", "residuals-kept-linearised"])
+@pytest.mark.parametrize("lin", [False, True, "import"], ids=["plain", "residuals-kept-linearised", "residuals-arrive-linearised"])
 def test_sharded_optimize_world2_on_a_shared_device(gpu_required, lin):
     """Two processes on one GPU, each with its share of the points: identical decisions and frame states on both ranks, the unsharded result within
     the rounding of a different summation order (tests/dist_worker_gpu.py).  Second case: after two iterations a third of the residuals is kept linearised
@@ -83,7 +83,7 @@ def test_sharded_optimize_world2_on_a_shared_device(gpu_required, lin):
     port = _free_port()
     env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
     if lin:
-        env["SHARD_LIN"] = "1"
+        env["SHARD_LIN"] = "import" if lin == "import" else "1"   # import: the rows of an unsharded window handed to the ranks (dmvio_hip_ba_set_linearized_residuals, collective)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
